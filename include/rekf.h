@@ -1,0 +1,156 @@
+/*
+ * rekf.h -- C ABI of the MI355X-native reflector EKF-SLAM core (librekf.so).
+ *
+ * This is the drop-in boundary underneath the reference's C++ interface
+ * ekf::ReflectorEKFSLAMInterface (reference include/reflector_ekf_slam/
+ * ekf_slam_interface.h:50-67).  The reference has no FFI of its own; each entry
+ * point below names the reference method it replaces.  A header-only C++ adapter
+ * with the reference's class and method names lives in
+ * include/reflector_ekf_slam_amd/ekf_slam_adapter.hpp; INTEGRATION.md shows the
+ * five-line change in the reference's ros_node.cc.
+ *
+ * Conventions
+ *  - opaque handle, one HIP stream per handle, NOT thread-safe: the caller
+ *    serialises calls (the reference's caller is the single-threaded
+ *    ros::spin(), reference src/ros_node.cc:68).
+ *  - plain pointers and sizes only; all buffers are caller-owned HOST memory and
+ *    are borrowed for the duration of the call.
+ *  - every function returns 0 (REKF_OK) or a negative REKF_ERR_* code; nothing
+ *    calls exit() or throws across this boundary (the reference LOG(ERROR)+exit(-1)s,
+ *    reflector_ekf_slam.cc:373-378; the C++ adapter may restore that).
+ *  - rekf_handle_odometry / rekf_handle_observation only ENQUEUE device work and
+ *    return; nothing in them waits for the GPU.  Getters synchronise the stream.
+ *  - the covariance lives in HBM for the life of the handle, column-major like
+ *    Eigen::MatrixXd (ekf_slam_interface.h:47) with a fixed leading dimension.
+ */
+#ifndef REKF_H_
+#define REKF_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define REKF_ABI_VERSION 1
+
+/* Most observations one scan may carry (K).  m = 2*K (+3 with a pose
+ * observation) innovation rows must fit the single-workgroup LDS solve. */
+#define REKF_MAX_OBS 64
+
+enum {
+    REKF_OK = 0,
+    REKF_ERR_INVALID = -1,        /* bad argument / null handle */
+    REKF_ERR_HIP = -2,            /* a HIP runtime call failed; see rekf_last_hip_error */
+    REKF_ERR_TOO_MANY_OBS = -3,   /* K > REKF_MAX_OBS */
+    REKF_ERR_CAPACITY = -4,       /* state grew past max_landmarks; extra reflectors were dropped */
+    REKF_ERR_SINGULAR = -5,       /* innovation covariance had a non-positive pivot */
+    REKF_ERR_BUFFER = -6,         /* caller buffer too small */
+    REKF_ERR_UNSUPPORTED = -7     /* e.g. use_imu != 0 (the reference's IMU path is empty) */
+};
+
+enum { REKF_ODOM_DIFF = 0, REKF_ODOM_OMNI = 1 };   /* sensor::OdometryModel, sensor_data.h:56-60 */
+
+/* ekf::EKFOptions (ekf_slam_interface.h:28-41).  The three *_cov fields are
+ * variances: the reference's caller squares the launch-file sigmas
+ * (src/ros_node.cc:207-238).  map_path is handled by the host side
+ * (rekf_set_map); use_imu must be 0 (forced false at src/ros_node.cc:186). */
+typedef struct rekf_options {
+    int odom_model;
+    int use_imu;
+    double init_time;
+    double init_pose[3];
+    double linear_velocity_cov;
+    double angular_velocity_cov;
+    double observation_cov;
+} rekf_options;
+
+typedef struct rekf rekf_t;
+
+/* ReflectorEKFSLAM::ReflectorEKFSLAM(options)  (reflector_ekf_slam.cc:6-37).
+ * Allocates mu / P / scratch for up to max_landmarks reflectors on HIP device
+ * `device`.  P is n_max x n_max FP64 with n_max = 3 + 2*max_landmarks. */
+int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t **out);
+void rekf_destroy(rekf_t *h);
+
+/* map_ as LoadMapFromTxtFile leaves it (reflector_ekf_slam.cc:80-94): M points
+ * (float32 xy) with M row-major 2x2 covariances.  M = 0 clears the map. */
+int rekf_set_map(rekf_t *h, const float *xy, const double *cov, int M);
+
+/* HandleOdometryMessage (reflector_ekf_slam.cc:208-223): drops t < state time,
+ * stores (vx, vy, wz), predicts by t - state time.  Asynchronous. */
+int rekf_handle_odometry(rekf_t *h, double t, double vx, double vy, double wz);
+
+/* HandleObservationMessage (reflector_ekf_slam.cc:229-368): predict to t,
+ * ReflectorMatch, EKF update, landmark augmentation.  xy = K robot-frame points
+ * (sensor::Observation::cloud_).  gps_pose3 = nullable (x, y, yaw): the pose
+ * observation of the USE_GPS build (reflector_ekf_slam_gps.cc:305-340).
+ * Asynchronous: xy is copied before the call returns. */
+int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K,
+                            const double *gps_pose3);
+
+/* PredictState (reflector_ekf_slam.cc:97-152), pose block only: non-mutating.
+ * Synchronises. */
+int rekf_predict_state(rekf_t *h, double t, double mu3[3], double sigma3x3[9]);
+
+/* GetLatestTime (reflector_ekf_slam.h:33-36).  No device access. */
+int rekf_get_time(rekf_t *h, double *t);
+
+/* Pose-only fast path for the GetState() call the reference's caller makes
+ * after every callback (src/ros_node.cc:515,592,638): 96 bytes D2H.
+ * sigma3x3 is column-major.  Synchronises. */
+int rekf_get_pose(rekf_t *h, double *t, double mu3[3], double sigma3x3[9]);
+
+/* Current state dimension n = 3 + 2*landmarks.  Synchronises. */
+int rekf_get_n(rekf_t *h, int *n);
+
+/* GetState (reflector_ekf_slam.h:37-40): full copy.  mu (n doubles) and sigma
+ * (n*n doubles, column-major, leading dimension n) may each be NULL.
+ * mu_cap / sigma_cap are the buffer capacities in doubles.  Synchronises. */
+int rekf_get_state(rekf_t *h, double *t, int *n, double *mu, long mu_cap,
+                   double *sigma, long sigma_cap);
+
+/* Restore a full state (checkpoint resume / tests).  sigma column-major, ld = n.
+ * vt3 = nullable last odometry velocity. */
+int rekf_set_state(rekf_t *h, double t, int n, const double *mu, const double *sigma,
+                   const double *vt3);
+
+/* The ReflectorMatchResult of the last observation (ekf_slam_interface.h:18-26):
+ * pairs are (observation index, landmark/map index).  Buffers hold up to
+ * REKF_MAX_OBS entries (pairs: 2*REKF_MAX_OBS ints).  Any pointer may be NULL.
+ * Synchronises. */
+int rekf_get_last_match(rekf_t *h, int *n_state, int *state_pairs, int *n_map,
+                        int *map_pairs, int *n_new, int *new_ids);
+
+/* Wait for all enqueued work; returns a sticky device-side error
+ * (REKF_ERR_CAPACITY / REKF_ERR_SINGULAR) once, then clears it. */
+int rekf_sync(rekf_t *h);
+
+/* ---- measurement hooks (bench.py, rocprof cross-checks) -------------------- */
+enum {
+    REKF_K_PREDICT = 0,   /* odometry-path covariance/mean propagate */
+    REKF_K_FRONT = 1,     /* predict + ReflectorMatch + H rows       */
+    REKF_K_GATHER = 2,    /* W = P H^T                               */
+    REKF_K_SOLVE = 3,     /* S = H W + Q, S^-1                       */
+    REKF_K_GAIN = 4,      /* K = W S^-1, mu += K dz                  */
+    REKF_K_DOWNDATE = 5,  /* P -= K W^T  (the roofline kernel)       */
+    REKF_K_AUGMENT = 6,   /* new landmarks                           */
+    REKF_K_COUNT = 7
+};
+/* When on, every kernel launch is bracketed by hipEvents on the handle's stream. */
+int rekf_profile_enable(rekf_t *h, int on);
+/* Sum (microseconds) and count of the recorded launches of kernel k since the
+ * last rekf_profile_reset.  Synchronises. */
+int rekf_profile_read(rekf_t *h, int k, double *total_us, long *count);
+int rekf_profile_reset(rekf_t *h);
+/* The hipStream_t of the handle (as void*), for callers that record their own events. */
+void *rekf_stream(rekf_t *h);
+/* Leading dimension (doubles) of the device covariance and its device pointer. */
+int rekf_device_layout(rekf_t *h, int *ld, int *n_max, void **P_dev, void **mu_dev);
+
+const char *rekf_strerror(int code);
+const char *rekf_last_hip_error(rekf_t *h);
+int rekf_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REKF_H_ */

@@ -1,0 +1,161 @@
+"""oracle/binding.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+ctypes binding of oracle/liboracle.so (the C restatement in ekf_oracle.c,
+detect2d_oracle.c, detect3d_oracle.c).  Importable only from tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+def build(force: bool = False) -> str:
+    """Compile liboracle.so with gcc via oracle/Makefile (idempotent)."""
+    if force:
+        subprocess.check_call(["make", "-C", _HERE, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        build()
+    L = C.CDLL(_LIB_PATH)
+    L.oekf_create.restype = C.c_void_p
+    L.oekf_create.argtypes = [C.c_int, C.c_double, _f64p, C.c_double, C.c_double, C.c_double]
+    L.oekf_destroy.argtypes = [C.c_void_p]
+    L.oekf_set_mode.argtypes = [C.c_void_p, C.c_int]
+    L.oekf_set_map.argtypes = [C.c_void_p, _f32p, _f64p, C.c_int]
+    L.oekf_handle_odometry.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]
+    L.oekf_handle_observation.restype = C.c_int
+    L.oekf_handle_observation.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_void_p]
+    L.oekf_predict_state.argtypes = [C.c_void_p, C.c_double, _f64p, C.c_void_p]
+    L.oekf_get_n.restype = C.c_int
+    L.oekf_get_n.argtypes = [C.c_void_p]
+    L.oekf_get_time.restype = C.c_double
+    L.oekf_get_time.argtypes = [C.c_void_p]
+    L.oekf_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.oekf_set_state.argtypes = [C.c_void_p, C.c_double, C.c_int, _f64p, _f64p, _f64p]
+    L.oekf_get_vt.argtypes = [C.c_void_p, _f64p]
+    L.oekf_get_last_match.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    _lib = L
+    return L
+
+
+class OracleEKF:
+    """Python face of the C oracle; method names follow the reference class
+    (reflector_ekf_slam.h:13-64) in snake_case."""
+
+    def __init__(self, odom_model, init_time, init_pose, lin_cov, ang_cov, obs_cov, literal=False):
+        self._L = lib()
+        pose = np.ascontiguousarray(init_pose, dtype=np.float64)
+        self._h = self._L.oekf_create(int(odom_model), float(init_time), pose,
+                                      float(lin_cov), float(ang_cov), float(obs_cov))
+        self._max_obs = 0
+        if literal:
+            self.set_mode(True)
+
+    def close(self):
+        if self._h:
+            self._L.oekf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_mode(self, literal: bool):
+        self._L.oekf_set_mode(self._h, 1 if literal else 0)
+
+    def set_map(self, xy, cov):
+        xy = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
+        cov = np.ascontiguousarray(cov, dtype=np.float64).reshape(-1, 4)
+        self._L.oekf_set_map(self._h, xy, cov, xy.shape[0])
+
+    def handle_odometry(self, t, vx, vy, wz):
+        self._L.oekf_handle_odometry(self._h, float(t), float(vx), float(vy), float(wz))
+
+    def handle_observation(self, t, obs, gps_pose=None):
+        obs = np.ascontiguousarray(obs, dtype=np.float32).reshape(-1, 2)
+        self._max_obs = max(self._max_obs, obs.shape[0])
+        gp = None
+        if gps_pose is not None:
+            gps = np.ascontiguousarray(gps_pose, dtype=np.float64)
+            gp = gps.ctypes.data_as(C.c_void_p)
+        rc = self._L.oekf_handle_observation(self._h, float(t), obs.ctypes.data_as(C.c_void_p),
+                                             obs.shape[0], gp)
+        if rc != 0:
+            raise RuntimeError(f"oracle handle_observation failed rc={rc}")
+
+    def predict_state(self, t, full=False):
+        n = self.n
+        mu = np.zeros(n)
+        if full:
+            sig = np.zeros((n, n), order="F")
+            self._L.oekf_predict_state(self._h, float(t), mu, sig.ctypes.data_as(C.c_void_p))
+            return mu, sig
+        self._L.oekf_predict_state(self._h, float(t), mu, None)
+        return mu, None
+
+    @property
+    def n(self):
+        return self._L.oekf_get_n(self._h)
+
+    @property
+    def time(self):
+        return self._L.oekf_get_time(self._h)
+
+    def mu(self):
+        m = np.zeros(self.n)
+        self._L.oekf_get_state(self._h, m.ctypes.data_as(C.c_void_p), None)
+        return m
+
+    def state(self):
+        n = self.n
+        m = np.zeros(n)
+        s = np.zeros((n, n), order="F")
+        self._L.oekf_get_state(self._h, m.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p))
+        return m, s
+
+    def set_state(self, t, mu, sigma, vt=(0.0, 0.0, 0.0)):
+        mu = np.ascontiguousarray(mu, dtype=np.float64)
+        n = mu.shape[0]
+        sig = np.asfortranarray(sigma, dtype=np.float64)
+        assert sig.shape == (n, n)
+        flat = np.ascontiguousarray(sig.T).reshape(-1)  # column-major bytes
+        self._L.oekf_set_state(self._h, float(t), n, mu, flat, np.ascontiguousarray(vt, dtype=np.float64))
+
+    def vt(self):
+        v = np.zeros(3)
+        self._L.oekf_get_vt(self._h, v)
+        return v
+
+    def last_match(self):
+        cap = max(self._max_obs, 1)
+        sp = np.zeros((cap, 2), np.int32)
+        mp = np.zeros((cap, 2), np.int32)
+        nw = np.zeros((cap,), np.int32)
+        ns, nm, nn = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._L.oekf_get_last_match(self._h, C.byref(ns), sp.ctypes.data_as(C.c_void_p),
+                                    C.byref(nm), mp.ctypes.data_as(C.c_void_p),
+                                    C.byref(nn), nw.ctypes.data_as(C.c_void_p))
+        return sp[: ns.value].copy(), mp[: nm.value].copy(), nw[: nn.value].copy()

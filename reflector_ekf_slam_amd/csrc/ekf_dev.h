@@ -1,0 +1,82 @@
+// ekf_dev.h -- device-side data layout shared by the EKF kernels and the C-ABI host.
+//
+// HBM layout of one filter handle (all FP64 unless noted), sized once at
+// rekf_create for n_max = 3 + 2*max_landmarks and never reallocated:
+//
+//   mu   [ld]            state mean  [x, y, theta, l0x, l0y, l1x, ...]
+//   P    [ld x ld]       covariance, COLUMN-major (Eigen::MatrixXd order,
+//                        reference ekf_slam_interface.h:47), leading dimension
+//                        ld = roundup(n_max, 64) so every 64x64 tile is in bounds
+//                        and every column starts on a 512-byte boundary
+//   W    [ld x MR_PAD]   W = P H^T  (column r = P * H(r,:)^T), column-major
+//   HPt  [ld x MR_PAD]   HPt = (H P)^T gathered from the ROWS of P, column-major
+//   Kn   [ld x MR_PAD]   Kn = -K = -W S^-1, column-major
+//   Sinv [MR_PAD x MR_PAD], y[MR_PAD] = S^-1 (z - zhat)
+//   ctl                  RekfCtl below: n, error flags, the scan record
+//
+// Rows/columns >= n of W, HPt and Kn are kept exactly zero so that the tile kernels
+// never need bounds checks on P.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define REKF_MAX_OBS_DEV 64
+#define REKF_MAX_ROWS 128                           // 2 per match (+3 pose rows: then K <= 62)
+#define REKF_MR_PAD 128                             // leading dimension of Sinv
+
+enum { REKF_FLAG_CAPACITY = 1, REKF_FLAG_SINGULAR = 2 };
+
+struct RekfCtl {
+    int n;                    // committed state dimension (3 + 2 L)
+    int err;                  // sticky REKF_FLAG_* bits
+    // ---- record of the last observation (ReflectorMatchResult + H rows) ----
+    int K;                    // observations in the scan
+    int n_state, n_map, n_new;
+    int m;                    // innovation rows = 2*(n_state+n_map) (+3 with a pose observation)
+    int m_pad;                // m rounded up to 16; W/Kn columns [m, m_pad) are zero
+    int state_pairs[2 * REKF_MAX_OBS_DEV];
+    int map_pairs[2 * REKF_MAX_OBS_DEV];
+    int new_ids[REKF_MAX_OBS_DEV];
+    int hcol[REKF_MAX_ROWS];      // landmark column 3+2g of row r, or -1 (map / pose rows)
+    double ha[REKF_MAX_ROWS][3];  // H(r, 0..2)
+    double hb[REKF_MAX_ROWS][2];  // H(r, hcol..hcol+1)
+    double dz[REKF_MAX_ROWS];     // z - zhat
+    double qd[REKF_MAX_ROWS];     // diag(Q)
+};
+
+// By-value kernel argument of the front kernel: one scan's worth of host input.
+struct RekfFrontArgs {
+    double dt;                // t - state time (host tracks time)
+    double vt[3];             // vt_ used for this predict
+    double lin_cov, ang_cov, obs_cov;
+    double gps[3];
+    int model;                // 0 DIFF, 1 OMNI
+    int is_obs;               // 0: odometry path (predict only, scan record untouched)
+    int K;
+    int has_gps;
+    float obs[2 * REKF_MAX_OBS_DEV];
+};
+
+struct RekfDev {
+    RekfCtl *ctl;
+    double *mu;
+    double *P;
+    double *W;
+    double *HPt;
+    double *Kn;
+    double *Sinv;
+    double *y;
+    float *map_xy;      // M_map x 2
+    double *map_cov;    // M_map x 4 row-major
+    int M_map;
+    int ld;
+    int n_max;
+};
+
+// launch wrappers (ekf_kernels.hip)
+void rekf_launch_front(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);
+void rekf_launch_gather(const RekfDev &d, int n_ub, hipStream_t s);
+void rekf_launch_solve(const RekfDev &d, hipStream_t s);
+void rekf_launch_gain(const RekfDev &d, int n_ub, hipStream_t s);
+void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s);
+void rekf_launch_augment(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);
+void rekf_launch_predict_pose(const RekfDev &d, const RekfFrontArgs &a, double *out12, hipStream_t s);

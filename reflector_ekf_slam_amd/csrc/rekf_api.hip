@@ -1,0 +1,454 @@
+// rekf_api.hip -- host side of the C ABI declared in include/rekf.h.
+//
+// Owns the HIP device buffers and the stream of one filter handle and turns
+// each reference method (reflector_ekf_slam.cc) into an asynchronous kernel
+// chain.  Time bookkeeping (State::time, the "drop old odometry" test at
+// reflector_ekf_slam.cc:211-212) is pure host data and stays on the host; every
+// size that depends on device results (n, m, the match lists) stays on the
+// device so no call here waits for the GPU except the getters.
+#include "../../include/rekf.h"
+#include "ekf_dev.h"
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+static_assert(REKF_MAX_OBS == REKF_MAX_OBS_DEV, "host/device observation capacity mismatch");
+
+namespace {
+
+struct ProfSlot {
+    hipEvent_t a, b;
+    int kernel;
+};
+
+}  // namespace
+
+struct rekf {
+    rekf_options opt;
+    int device;
+    int max_landmarks;
+    hipStream_t stream;
+    RekfDev dev;
+    double time;
+    double vt[3];
+    int n_ub;                  // host upper bound of the device-resident n
+    double *pose_staging;      // pinned, 12 doubles
+    double *dev_out12;         // device scratch for k_predict_pose
+    RekfCtl *ctl_staging;      // pinned copy of the control block
+    std::string hip_error;
+    // profiling
+    bool prof_on;
+    std::vector<ProfSlot> prof_slots;
+    size_t prof_used;
+    double prof_total_us[REKF_K_COUNT];
+    long prof_count[REKF_K_COUNT];
+};
+
+namespace {
+
+#define HIP_TRY(h, expr)                                                         \
+    do {                                                                         \
+        hipError_t e_ = (expr);                                                  \
+        if (e_ != hipSuccess) {                                                  \
+            if (h) (h)->hip_error = std::string(#expr) + ": " + hipGetErrorString(e_); \
+            return REKF_ERR_HIP;                                                 \
+        }                                                                        \
+    } while (0)
+
+int round_up(int x, int q) { return (x + q - 1) / q * q; }
+
+int prof_flush(rekf_t *h)
+{
+    if (h->prof_used == 0) return REKF_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < h->prof_used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->prof_slots[i].a, h->prof_slots[i].b));
+        h->prof_total_us[h->prof_slots[i].kernel] += 1e3 * (double)ms;
+        h->prof_count[h->prof_slots[i].kernel] += 1;
+    }
+    h->prof_used = 0;
+    return REKF_OK;
+}
+
+struct ProfScope {
+    rekf_t *h;
+    ProfSlot *slot;
+    ProfScope(rekf_t *h_, int kernel) : h(h_), slot(nullptr)
+    {
+        if (!h->prof_on) return;
+        if (h->prof_used == h->prof_slots.size()) {
+            if (h->prof_slots.size() >= 65536) {
+                prof_flush(h);
+            } else {
+                ProfSlot s;
+                if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return;
+                s.kernel = kernel;
+                h->prof_slots.push_back(s);
+            }
+        }
+        slot = &h->prof_slots[h->prof_used++];
+        slot->kernel = kernel;
+        (void)hipEventRecord(slot->a, h->stream);
+    }
+    ~ProfScope()
+    {
+        if (slot) (void)hipEventRecord(slot->b, h->stream);
+    }
+};
+
+void fill_front_args(const rekf_t *h, RekfFrontArgs &a, double dt)
+{
+    std::memset(&a, 0, sizeof(a));
+    a.dt = dt;
+    a.vt[0] = h->vt[0]; a.vt[1] = h->vt[1]; a.vt[2] = h->vt[2];
+    a.lin_cov = h->opt.linear_velocity_cov;
+    a.ang_cov = h->opt.angular_velocity_cov;
+    a.obs_cov = h->opt.observation_cov;
+    a.model = (h->opt.odom_model == REKF_ODOM_DIFF) ? 0 : 1;   // cc:13-32: anything else -> OMNI
+}
+
+int device_flags_to_code(int flags)
+{
+    if (flags & REKF_FLAG_SINGULAR) return REKF_ERR_SINGULAR;
+    if (flags & REKF_FLAG_CAPACITY) return REKF_ERR_CAPACITY;
+    return REKF_OK;
+}
+
+// Synchronise and refresh the host copy of the control block.
+int pull_ctl(rekf_t *h)
+{
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(h->ctl_staging, h->dev.ctl, sizeof(RekfCtl), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->n_ub = h->ctl_staging->n;
+    return REKF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rekf_abi_version(void) { return REKF_ABI_VERSION; }
+
+const char *rekf_strerror(int code)
+{
+    switch (code) {
+    case REKF_OK: return "ok";
+    case REKF_ERR_INVALID: return "invalid argument";
+    case REKF_ERR_HIP: return "HIP runtime error";
+    case REKF_ERR_TOO_MANY_OBS: return "too many observations in one scan";
+    case REKF_ERR_CAPACITY: return "landmark capacity exceeded; new reflectors dropped";
+    case REKF_ERR_SINGULAR: return "innovation covariance not positive definite";
+    case REKF_ERR_BUFFER: return "caller buffer too small";
+    case REKF_ERR_UNSUPPORTED: return "unsupported option";
+    default: return "unknown error";
+    }
+}
+
+const char *rekf_last_hip_error(rekf_t *h) { return h ? h->hip_error.c_str() : ""; }
+
+int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t **out)
+{
+    if (!opt || !out || max_landmarks < 1) return REKF_ERR_INVALID;
+    if (opt->use_imu) return REKF_ERR_UNSUPPORTED;   // reference IMU path is empty (cc:222-227)
+    *out = nullptr;
+    rekf_t *h = new (std::nothrow) rekf();
+    if (!h) return REKF_ERR_INVALID;
+    h->opt = *opt;
+    h->device = device;
+    h->max_landmarks = max_landmarks;
+    h->time = opt->init_time;                         // cc:8
+    h->vt[0] = h->vt[1] = h->vt[2] = 0.0;             // cc:6
+    h->n_ub = 3;
+    h->prof_on = false;
+    h->prof_used = 0;
+    for (int k = 0; k < REKF_K_COUNT; ++k) { h->prof_total_us[k] = 0; h->prof_count[k] = 0; }
+    h->stream = nullptr;
+    h->pose_staging = nullptr;
+    h->ctl_staging = nullptr;
+    h->dev_out12 = nullptr;
+    std::memset(&h->dev, 0, sizeof(h->dev));
+
+    const int n_max = 3 + 2 * max_landmarks;
+    const int ld = round_up(n_max, 64);
+    int rc = [&]() -> int {
+        HIP_TRY(h, hipSetDevice(device));
+        HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        HIP_TRY(h, hipMalloc(&h->dev.ctl, sizeof(RekfCtl)));
+        HIP_TRY(h, hipMalloc(&h->dev.mu, sizeof(double) * ld));
+        HIP_TRY(h, hipMalloc(&h->dev.P, sizeof(double) * (size_t)ld * ld));
+        HIP_TRY(h, hipMalloc(&h->dev.W, sizeof(double) * (size_t)ld * REKF_MR_PAD));
+        HIP_TRY(h, hipMalloc(&h->dev.HPt, sizeof(double) * (size_t)ld * REKF_MR_PAD));
+        HIP_TRY(h, hipMalloc(&h->dev.Kn, sizeof(double) * (size_t)ld * REKF_MR_PAD));
+        HIP_TRY(h, hipMalloc(&h->dev.Sinv, sizeof(double) * REKF_MR_PAD * REKF_MR_PAD));
+        HIP_TRY(h, hipMalloc(&h->dev.y, sizeof(double) * REKF_MR_PAD));
+        HIP_TRY(h, hipMalloc(&h->dev_out12, sizeof(double) * 12));
+        HIP_TRY(h, hipHostMalloc(&h->pose_staging, sizeof(double) * 16));
+        HIP_TRY(h, hipHostMalloc(&h->ctl_staging, sizeof(RekfCtl)));
+        h->dev.ld = ld;
+        h->dev.n_max = n_max;
+        h->dev.M_map = 0;
+        HIP_TRY(h, hipMemsetAsync(h->dev.ctl, 0, sizeof(RekfCtl), h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->dev.mu, 0, sizeof(double) * ld, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->dev.P, 0, sizeof(double) * (size_t)ld * ld, h->stream));   // cc:10-11
+        HIP_TRY(h, hipMemsetAsync(h->dev.W, 0, sizeof(double) * (size_t)ld * REKF_MR_PAD, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->dev.HPt, 0, sizeof(double) * (size_t)ld * REKF_MR_PAD, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->dev.Kn, 0, sizeof(double) * (size_t)ld * REKF_MR_PAD, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->dev.Sinv, 0, sizeof(double) * REKF_MR_PAD * REKF_MR_PAD, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->dev.y, 0, sizeof(double) * REKF_MR_PAD, h->stream));
+        std::memset(h->ctl_staging, 0, sizeof(RekfCtl));
+        h->ctl_staging->n = 3;
+        HIP_TRY(h, hipMemcpyAsync(h->dev.ctl, h->ctl_staging, sizeof(int) * 2, hipMemcpyHostToDevice, h->stream));
+        h->pose_staging[0] = opt->init_pose[0];       // cc:9
+        h->pose_staging[1] = opt->init_pose[1];
+        h->pose_staging[2] = opt->init_pose[2];
+        HIP_TRY(h, hipMemcpyAsync(h->dev.mu, h->pose_staging, sizeof(double) * 3, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        return REKF_OK;
+    }();
+    if (rc != REKF_OK) {
+        std::fprintf(stderr, "rekf_create: %s\n", h->hip_error.c_str());
+        rekf_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return REKF_OK;
+}
+
+void rekf_destroy(rekf_t *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto &s : h->prof_slots) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+    (void)hipFree(h->dev.ctl); (void)hipFree(h->dev.mu); (void)hipFree(h->dev.P);
+    (void)hipFree(h->dev.W); (void)hipFree(h->dev.HPt); (void)hipFree(h->dev.Kn); (void)hipFree(h->dev.Sinv); (void)hipFree(h->dev.y);
+    (void)hipFree(h->dev.map_xy); (void)hipFree(h->dev.map_cov); (void)hipFree(h->dev_out12);
+    if (h->pose_staging) (void)hipHostFree(h->pose_staging);
+    if (h->ctl_staging) (void)hipHostFree(h->ctl_staging);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int rekf_set_map(rekf_t *h, const float *xy, const double *cov, int M)
+{
+    if (!h || M < 0 || (M > 0 && (!xy || !cov))) return REKF_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    (void)hipFree(h->dev.map_xy); (void)hipFree(h->dev.map_cov);
+    h->dev.map_xy = nullptr; h->dev.map_cov = nullptr; h->dev.M_map = 0;
+    if (M == 0) return REKF_OK;
+    HIP_TRY(h, hipMalloc(&h->dev.map_xy, sizeof(float) * 2 * (size_t)M));
+    HIP_TRY(h, hipMalloc(&h->dev.map_cov, sizeof(double) * 4 * (size_t)M));
+    HIP_TRY(h, hipMemcpy(h->dev.map_xy, xy, sizeof(float) * 2 * (size_t)M, hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->dev.map_cov, cov, sizeof(double) * 4 * (size_t)M, hipMemcpyHostToDevice));
+    h->dev.M_map = M;
+    return REKF_OK;
+}
+
+int rekf_handle_odometry(rekf_t *h, double t, double vx, double vy, double wz)
+{
+    if (!h) return REKF_ERR_INVALID;
+    if (t < h->time) return REKF_OK;                  // drop old data, cc:211-212
+    h->vt[0] = vx; h->vt[1] = vy; h->vt[2] = wz;      // cc:216
+    RekfFrontArgs a;
+    fill_front_args(h, a, t - h->time);               // cc:217
+    a.is_obs = 0;
+    HIP_TRY(h, hipSetDevice(h->device));
+    {
+        ProfScope ps(h, REKF_K_PREDICT);
+        rekf_launch_front(h->dev, a, h->stream);      // cc:218 Predict(dt)
+    }
+    h->time = t;                                      // cc:219
+    return REKF_OK;
+}
+
+int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const double *gps_pose3)
+{
+    if (!h || K < 0 || (K > 0 && !xy)) return REKF_ERR_INVALID;
+    if (K > REKF_MAX_OBS || 2 * K + (gps_pose3 ? 3 : 0) > REKF_MAX_ROWS) return REKF_ERR_TOO_MANY_OBS;
+    RekfFrontArgs a;
+    fill_front_args(h, a, t - h->time);               // cc:232 (dt may be negative, Q8)
+    a.is_obs = 1;
+    a.K = K;
+    if (K > 0) std::memcpy(a.obs, xy, sizeof(float) * 2 * (size_t)K);
+    if (gps_pose3) {
+        a.has_gps = 1;
+        a.gps[0] = gps_pose3[0]; a.gps[1] = gps_pose3[1]; a.gps[2] = gps_pose3[2];
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    { ProfScope ps(h, REKF_K_FRONT); rekf_launch_front(h->dev, a, h->stream); }
+    h->time = t;                                      // cc:234
+    if (K == 0) return REKF_OK;                       // cc:235-236
+    const int n_ub = h->n_ub;
+    { ProfScope ps(h, REKF_K_GATHER); rekf_launch_gather(h->dev, n_ub, h->stream); }
+    { ProfScope ps(h, REKF_K_SOLVE); rekf_launch_solve(h->dev, h->stream); }
+    { ProfScope ps(h, REKF_K_GAIN); rekf_launch_gain(h->dev, n_ub, h->stream); }
+    { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_downdate(h->dev, n_ub, h->stream); }
+    { ProfScope ps(h, REKF_K_AUGMENT); rekf_launch_augment(h->dev, a, h->stream); }
+    // the scan may have appended up to K reflectors; the exact n stays on the device
+    int grown = n_ub + 2 * K;
+    h->n_ub = grown > h->dev.n_max ? h->dev.n_max : grown;
+    HIP_TRY(h, hipGetLastError());
+    return REKF_OK;
+}
+
+int rekf_predict_state(rekf_t *h, double t, double mu3[3], double sigma3x3[9])
+{
+    if (!h || !mu3) return REKF_ERR_INVALID;
+    RekfFrontArgs a;
+    fill_front_args(h, a, t - h->time);               // cc:100
+    HIP_TRY(h, hipSetDevice(h->device));
+    rekf_launch_predict_pose(h->dev, a, h->dev_out12, h->stream);
+    HIP_TRY(h, hipMemcpyAsync(h->pose_staging, h->dev_out12, sizeof(double) * 12, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    std::memcpy(mu3, h->pose_staging, sizeof(double) * 3);
+    if (sigma3x3) std::memcpy(sigma3x3, h->pose_staging + 3, sizeof(double) * 9);
+    return REKF_OK;
+}
+
+int rekf_get_time(rekf_t *h, double *t)
+{
+    if (!h || !t) return REKF_ERR_INVALID;
+    *t = h->time;
+    return REKF_OK;
+}
+
+int rekf_get_pose(rekf_t *h, double *t, double mu3[3], double sigma3x3[9])
+{
+    if (!h) return REKF_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(h->pose_staging, h->dev.mu, sizeof(double) * 3, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpy2DAsync(h->pose_staging + 3, sizeof(double) * 3, h->dev.P, sizeof(double) * h->dev.ld,
+                                sizeof(double) * 3, 3, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (t) *t = h->time;
+    if (mu3) std::memcpy(mu3, h->pose_staging, sizeof(double) * 3);
+    if (sigma3x3) std::memcpy(sigma3x3, h->pose_staging + 3, sizeof(double) * 9);
+    return REKF_OK;
+}
+
+int rekf_get_n(rekf_t *h, int *n)
+{
+    if (!h || !n) return REKF_ERR_INVALID;
+    int rc = pull_ctl(h);
+    if (rc != REKF_OK) return rc;
+    *n = h->ctl_staging->n;
+    return REKF_OK;
+}
+
+int rekf_get_state(rekf_t *h, double *t, int *n_out, double *mu, long mu_cap, double *sigma, long sigma_cap)
+{
+    if (!h) return REKF_ERR_INVALID;
+    int rc = pull_ctl(h);
+    if (rc != REKF_OK) return rc;
+    const int n = h->ctl_staging->n;
+    if (t) *t = h->time;
+    if (n_out) *n_out = n;
+    if (mu) {
+        if (mu_cap < n) return REKF_ERR_BUFFER;
+        HIP_TRY(h, hipMemcpyAsync(mu, h->dev.mu, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    }
+    if (sigma) {
+        if (sigma_cap < (long)n * n) return REKF_ERR_BUFFER;
+        HIP_TRY(h, hipMemcpy2DAsync(sigma, sizeof(double) * n, h->dev.P, sizeof(double) * h->dev.ld,
+                                    sizeof(double) * n, n, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return REKF_OK;
+}
+
+int rekf_set_state(rekf_t *h, double t, int n, const double *mu, const double *sigma, const double *vt3)
+{
+    if (!h || !mu || !sigma || n < 3 || n > h->dev.n_max || ((n - 3) & 1)) return REKF_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const int ld = h->dev.ld;
+    HIP_TRY(h, hipMemsetAsync(h->dev.P, 0, sizeof(double) * (size_t)ld * ld, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->dev.mu, 0, sizeof(double) * ld, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->dev.mu, mu, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpy2DAsync(h->dev.P, sizeof(double) * ld, sigma, sizeof(double) * n, sizeof(double) * n, n,
+                                hipMemcpyHostToDevice, h->stream));
+    std::memset(h->ctl_staging, 0, sizeof(RekfCtl));
+    h->ctl_staging->n = n;
+    HIP_TRY(h, hipMemcpyAsync(h->dev.ctl, h->ctl_staging, sizeof(RekfCtl), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->time = t;
+    h->n_ub = n;
+    if (vt3) { h->vt[0] = vt3[0]; h->vt[1] = vt3[1]; h->vt[2] = vt3[2]; }
+    return REKF_OK;
+}
+
+int rekf_get_last_match(rekf_t *h, int *n_state, int *state_pairs, int *n_map, int *map_pairs, int *n_new,
+                        int *new_ids)
+{
+    if (!h) return REKF_ERR_INVALID;
+    int rc = pull_ctl(h);
+    if (rc != REKF_OK) return rc;
+    const RekfCtl *c = h->ctl_staging;
+    if (n_state) *n_state = c->n_state;
+    if (n_map) *n_map = c->n_map;
+    if (n_new) *n_new = c->n_new;
+    if (state_pairs) std::memcpy(state_pairs, c->state_pairs, sizeof(int) * 2 * (size_t)c->n_state);
+    if (map_pairs) std::memcpy(map_pairs, c->map_pairs, sizeof(int) * 2 * (size_t)c->n_map);
+    if (new_ids) std::memcpy(new_ids, c->new_ids, sizeof(int) * (size_t)c->n_new);
+    return REKF_OK;
+}
+
+int rekf_sync(rekf_t *h)
+{
+    if (!h) return REKF_ERR_INVALID;
+    int rc = pull_ctl(h);
+    if (rc != REKF_OK) return rc;
+    const int flags = h->ctl_staging->err;
+    if (flags) {
+        int zero = 0;
+        HIP_TRY(h, hipMemcpy(&h->dev.ctl->err, &zero, sizeof(int), hipMemcpyHostToDevice));
+    }
+    return device_flags_to_code(flags);
+}
+
+int rekf_profile_enable(rekf_t *h, int on)
+{
+    if (!h) return REKF_ERR_INVALID;
+    if (!on) { int rc = prof_flush(h); if (rc != REKF_OK) return rc; }
+    h->prof_on = on != 0;
+    return REKF_OK;
+}
+
+int rekf_profile_read(rekf_t *h, int k, double *total_us, long *count)
+{
+    if (!h || k < 0 || k >= REKF_K_COUNT) return REKF_ERR_INVALID;
+    int rc = prof_flush(h);
+    if (rc != REKF_OK) return rc;
+    if (total_us) *total_us = h->prof_total_us[k];
+    if (count) *count = h->prof_count[k];
+    return REKF_OK;
+}
+
+int rekf_profile_reset(rekf_t *h)
+{
+    if (!h) return REKF_ERR_INVALID;
+    int rc = prof_flush(h);
+    if (rc != REKF_OK) return rc;
+    for (int k = 0; k < REKF_K_COUNT; ++k) { h->prof_total_us[k] = 0; h->prof_count[k] = 0; }
+    return REKF_OK;
+}
+
+void *rekf_stream(rekf_t *h) { return h ? (void *)h->stream : nullptr; }
+
+int rekf_device_layout(rekf_t *h, int *ld, int *n_max, void **P_dev, void **mu_dev)
+{
+    if (!h) return REKF_ERR_INVALID;
+    if (ld) *ld = h->dev.ld;
+    if (n_max) *n_max = h->dev.n_max;
+    if (P_dev) *P_dev = h->dev.P;
+    if (mu_dev) *mu_dev = h->dev.mu;
+    return REKF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,293 @@
+"""Host-side mirror of the reference's EKF interface over the C ABI (include/rekf.h).
+
+``ReflectorEKFSLAM`` keeps the method names of ekf::ReflectorEKFSLAMInterface
+(/root/reference/include/reflector_ekf_slam/ekf_slam_interface.h:50-67), including
+the ``GetCoviarance`` spelling, so that tests read like calls into the reference.
+All arithmetic happens in the HIP kernels behind librekf.so; this file only
+marshals arguments.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+
+DIFF, OMNI = 0, 1   # sensor::OdometryModel (sensor_data.h:56-60)
+
+KERNELS = {"predict": 0, "front": 1, "gather": 2, "solve": 3, "gain": 4, "downdate": 5, "augment": 6}
+
+
+class RekfError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        msg = _lib.rekf().rekf_strerror(code).decode()
+        super().__init__(f"{where}: {msg} ({code}) {detail}")
+
+
+@dataclass
+class EKFOptions:
+    """ekf::EKFOptions (ekf_slam_interface.h:28-41).  *_cov are variances
+    (the reference's caller squares the launch sigmas, src/ros_node.cc:207-238)."""
+    use_imu: bool = False
+    init_time: float = 0.0
+    init_pose: tuple = (0.0, 0.0, 0.0)
+    map_path: str = ""
+    odom_model: int = DIFF
+    linear_velocity_cov: float = 0.05 * 0.05
+    angular_velocity_cov: float = 0.08 * 0.08
+    observation_cov: float = 0.05 * 0.05
+
+
+@dataclass
+class State:
+    """ekf::State (ekf_slam_interface.h:43-48)."""
+    time: float
+    mu: np.ndarray
+    sigma: np.ndarray
+
+
+@dataclass
+class OdometryData:
+    """sensor::OdometryData (sensor_data.h:39-46); only time, linear_velocity.x/y and
+    angular_velocity.z reach the EKF (reflector_ekf_slam.cc:216)."""
+    time: float
+    linear_velocity: tuple = (0.0, 0.0, 0.0)
+    angular_velocity: tuple = (0.0, 0.0, 0.0)
+    position: tuple = (0.0, 0.0, 0.0)
+    orientation: tuple = (1.0, 0.0, 0.0, 0.0)   # w, x, y, z
+
+
+@dataclass
+class Observation:
+    """sensor::Observation (sensor_data.h:20-28)."""
+    time_: float
+    cloud_: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), np.float32))
+    gps_pose_: tuple | None = None   # (x, y, yaw) -- USE_GPS build only
+
+
+@dataclass
+class ReflectorMatchResult:
+    """ekf::ReflectorMatchResult (ekf_slam_interface.h:18-26)."""
+    map_obs_match_ids: np.ndarray
+    state_obs_match_ids: np.ndarray
+    new_ids: np.ndarray
+
+
+@dataclass
+class Map:
+    """sensor::Map (sensor_data.h:30-37)."""
+    reflector_map_: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), np.float32))
+    reflector_map_coviarance_: np.ndarray = field(default_factory=lambda: np.zeros((0, 2, 2)))
+
+
+def load_map_txt(path: str) -> Map:
+    """The two-line txt map (reflector_ekf_slam.cc:43-95) read as its author meant it:
+    line 0 = x,y,...  line 1 = c00,c01,c10,c11,...  (the reference indexes line 0 for the
+    covariances, :90 -- undefined behaviour we do not reproduce)."""
+    import os
+    if not path or not os.path.exists(path):
+        return Map()
+    rows = []
+    with open(path) as f:
+        for line in f:
+            line = line.rstrip("\n")
+            if line:
+                rows.append([float(p) for p in line.split(",") if p != ""])
+    if len(rows) != 2 or len(rows[1]) != 2 * len(rows[0]):
+        return Map()
+    xy = np.asarray(rows[0], dtype=np.float64).reshape(-1, 2).astype(np.float32)
+    cov = np.asarray(rows[1], dtype=np.float64).reshape(-1, 2, 2)
+    return Map(xy, cov)
+
+
+def save_map_txt(path: str, state: State, loaded: Map | None = None) -> None:
+    """SaveReflectorResult (src/ros_node.cc:75-140) without the leading-comma bug (Q10):
+    pre-loaded map points first, then the state's landmarks with their 2x2 blocks."""
+    pts, covs = [], []
+    if loaded is not None:
+        for p, c in zip(loaded.reflector_map_, loaded.reflector_map_coviarance_):
+            pts.append((float(p[0]), float(p[1])))
+            covs.append(np.asarray(c, dtype=np.float64).reshape(4))
+    L = (state.mu.shape[0] - 3) // 2
+    for j in range(L):
+        pts.append((state.mu[3 + 2 * j], state.mu[4 + 2 * j]))
+        covs.append(state.sigma[3 + 2 * j: 5 + 2 * j, 3 + 2 * j: 5 + 2 * j].reshape(4))
+    with open(path, "w") as f:
+        f.write(",".join(f"{v:.17g}" for p in pts for v in p) + "\n")
+        f.write(",".join(f"{v:.17g}" for c in covs for v in c) + "\n")
+
+
+class ReflectorEKFSLAM:
+    """ekf::ReflectorEKFSLAM (reflector_ekf_slam.h:13-64) on one MI355X."""
+
+    def __init__(self, options: EKFOptions, max_landmarks: int = 1024, device: int = 0):
+        self._L = _lib.rekf()
+        self.options = options
+        o = _lib.RekfOptions()
+        o.odom_model = int(options.odom_model)
+        o.use_imu = 1 if options.use_imu else 0
+        o.init_time = float(options.init_time)
+        for k in range(3):
+            o.init_pose[k] = float(options.init_pose[k])
+        o.linear_velocity_cov = float(options.linear_velocity_cov)
+        o.angular_velocity_cov = float(options.angular_velocity_cov)
+        o.observation_cov = float(options.observation_cov)
+        h = C.c_void_p()
+        rc = self._L.rekf_create(C.byref(o), int(max_landmarks), int(device), C.byref(h))
+        if rc != 0:
+            raise RekfError(rc, "rekf_create")
+        self._h = h
+        self.max_landmarks = int(max_landmarks)
+        self._map = load_map_txt(options.map_path)          # cc:36
+        if self._map.reflector_map_.shape[0] > 0:
+            self.SetGlobalMap(self._map)
+
+    # -- lifetime -----------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rekf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, where):
+        if rc != 0:
+            raise RekfError(rc, where, self._L.rekf_last_hip_error(self._h).decode())
+
+    # -- reference interface --------------------------------------------------
+    def HandleOdometryMessage(self, odometry: OdometryData):
+        self._chk(self._L.rekf_handle_odometry(self._h, float(odometry.time), float(odometry.linear_velocity[0]),
+                                               float(odometry.linear_velocity[1]),
+                                               float(odometry.angular_velocity[2])), "HandleOdometryMessage")
+
+    def HandleImuMessage(self, imu):
+        return None   # empty in the reference too (reflector_ekf_slam.cc:224-227)
+
+    def HandleObservationMessage(self, observation: Observation):
+        self.handle_observation(observation.time_, observation.cloud_, observation.gps_pose_)
+
+    def PredictState(self, time: float) -> State:
+        """Pose block of PredictState (cc:97-152); landmarks are unchanged by a predict."""
+        mu3 = (C.c_double * 3)()
+        s9 = (C.c_double * 9)()
+        self._chk(self._L.rekf_predict_state(self._h, float(time), mu3, s9), "PredictState")
+        return State(float(time), np.array(mu3[:]), np.array(s9[:]).reshape(3, 3).T.copy())
+
+    def GetStateVector(self) -> np.ndarray:
+        return self.GetState().mu
+
+    def GetCoviarance(self) -> np.ndarray:
+        return self.GetState().sigma
+
+    def GetLatestTime(self) -> float:
+        t = C.c_double()
+        self._chk(self._L.rekf_get_time(self._h, C.byref(t)), "GetLatestTime")
+        return t.value
+
+    def GetState(self) -> State:
+        n = self.n
+        mu = np.zeros(n)
+        sig = np.zeros((n, n), order="F")
+        t = C.c_double()
+        nn = C.c_int()
+        self._chk(self._L.rekf_get_state(self._h, C.byref(t), C.byref(nn), mu.ctypes.data_as(C.c_void_p), n,
+                                         sig.ctypes.data_as(C.c_void_p), n * n), "GetState")
+        return State(t.value, mu, sig)
+
+    def GetGlobalMap(self) -> Map:
+        return self._map
+
+    # -- snake_case fast paths (no Eigen-shaped copies) ------------------------
+    def handle_odometry(self, t, vx, vy, wz):
+        self._chk(self._L.rekf_handle_odometry(self._h, float(t), float(vx), float(vy), float(wz)),
+                  "handle_odometry")
+
+    def handle_observation(self, t, cloud, gps_pose=None):
+        cloud = np.ascontiguousarray(cloud, dtype=np.float32).reshape(-1, 2)
+        gp = None
+        if gps_pose is not None:
+            g = np.ascontiguousarray(gps_pose, dtype=np.float64)
+            gp = g.ctypes.data_as(C.c_void_p)
+        self._chk(self._L.rekf_handle_observation(self._h, float(t), cloud.ctypes.data_as(C.c_void_p),
+                                                  cloud.shape[0], gp), "HandleObservationMessage")
+
+    def SetGlobalMap(self, m: Map):
+        xy = np.ascontiguousarray(m.reflector_map_, dtype=np.float32).reshape(-1, 2)
+        cov = np.ascontiguousarray(m.reflector_map_coviarance_, dtype=np.float64).reshape(-1, 4)
+        self._chk(self._L.rekf_set_map(self._h, xy.ctypes.data_as(C.c_void_p), cov.ctypes.data_as(C.c_void_p),
+                                       xy.shape[0]), "SetGlobalMap")
+        self._map = Map(xy.copy(), cov.reshape(-1, 2, 2).copy())
+
+    @property
+    def n(self) -> int:
+        n = C.c_int()
+        self._chk(self._L.rekf_get_n(self._h, C.byref(n)), "get_n")
+        return n.value
+
+    def pose(self):
+        t = C.c_double()
+        mu3 = (C.c_double * 3)()
+        s9 = (C.c_double * 9)()
+        self._chk(self._L.rekf_get_pose(self._h, C.byref(t), mu3, s9), "get_pose")
+        return t.value, np.array(mu3[:]), np.array(s9[:]).reshape(3, 3).T.copy()
+
+    def mu(self) -> np.ndarray:
+        n = self.n
+        mu = np.zeros(n)
+        self._chk(self._L.rekf_get_state(self._h, None, None, mu.ctypes.data_as(C.c_void_p), n, None, 0), "get_mu")
+        return mu
+
+    def set_state(self, t, mu, sigma, vt=None):
+        mu = np.ascontiguousarray(mu, dtype=np.float64)
+        n = mu.shape[0]
+        flat = np.ascontiguousarray(np.asarray(sigma, dtype=np.float64).T).reshape(-1)   # column-major bytes
+        v = None
+        if vt is not None:
+            vv = np.ascontiguousarray(vt, dtype=np.float64)
+            v = vv.ctypes.data_as(C.c_void_p)
+        self._chk(self._L.rekf_set_state(self._h, float(t), n, mu.ctypes.data_as(C.c_void_p),
+                                         flat.ctypes.data_as(C.c_void_p), v), "set_state")
+
+    def last_match(self) -> ReflectorMatchResult:
+        sp = np.zeros((_lib.MAX_OBS, 2), np.int32)
+        mp = np.zeros((_lib.MAX_OBS, 2), np.int32)
+        nw = np.zeros((_lib.MAX_OBS,), np.int32)
+        ns, nm, nn = C.c_int(), C.c_int(), C.c_int()
+        self._chk(self._L.rekf_get_last_match(self._h, C.byref(ns), sp.ctypes.data_as(C.c_void_p), C.byref(nm),
+                                              mp.ctypes.data_as(C.c_void_p), C.byref(nn),
+                                              nw.ctypes.data_as(C.c_void_p)), "get_last_match")
+        return ReflectorMatchResult(mp[: nm.value].copy(), sp[: ns.value].copy(), nw[: nn.value].copy())
+
+    def sync(self):
+        self._chk(self._L.rekf_sync(self._h), "sync")
+
+    def sync_code(self) -> int:
+        return self._L.rekf_sync(self._h)
+
+    # -- measurement hooks -----------------------------------------------------
+    def profile(self, on: bool):
+        self._chk(self._L.rekf_profile_enable(self._h, 1 if on else 0), "profile_enable")
+
+    def profile_reset(self):
+        self._chk(self._L.rekf_profile_reset(self._h), "profile_reset")
+
+    def profile_read(self) -> dict:
+        out = {}
+        for name, k in KERNELS.items():
+            us, cnt = C.c_double(), C.c_long()
+            self._chk(self._L.rekf_profile_read(self._h, k, C.byref(us), C.byref(cnt)), "profile_read")
+            out[name] = (us.value, cnt.value)
+        return out
+
+    def device_layout(self):
+        ld, nmax = C.c_int(), C.c_int()
+        p, m = C.c_void_p(), C.c_void_p()
+        self._chk(self._L.rekf_device_layout(self._h, C.byref(ld), C.byref(nmax), C.byref(p), C.byref(m)), "layout")
+        return ld.value, nmax.value, p.value, m.value
