@@ -100,10 +100,12 @@ def _route(cfg: SessionConfig, landmarks: np.ndarray) -> np.ndarray:
         xs = (lo[0] + 2.0, hi[0] - 2.0) if r % 2 == 0 else (hi[0] - 2.0, lo[0] + 2.0)
         pts.append((xs[0], y))
         pts.append((xs[1], y))
-    # return leg closes the loop
+    # return leg closes the loop, then the robot parks in the middle of the field
+    # (so that steady-state scans see a full set of obs_per_scan reflectors)
     pts.append((pts[-1][0], ys[0]))
     if pts[-1] != pts[0]:
         pts.append(pts[0])
+    pts.append((float((lo[0] + hi[0]) / 2), float((lo[1] + hi[1]) / 2)))
     return np.array(pts, dtype=np.float64)
 
 
@@ -119,7 +121,8 @@ def make_session(cfg: SessionConfig, max_scans: int | None = None) -> Session:
     dt = 1.0 / cfg.odom_hz
     odom_per_scan = int(round(cfg.odom_hz / cfg.scan_hz))
     route_len = float(np.sum(np.linalg.norm(np.diff(route, axis=0), axis=1)))
-    n_scans_route = int(cfg.laps * route_len / cfg.speed * cfg.scan_hz)
+    # 1.1x: the controller slows down in turns; once parked the robot stands still
+    n_scans_route = int(1.1 * cfg.laps * route_len / cfg.speed * cfg.scan_hz)
     n_scans = n_scans_route + cfg.extra_scans
     if max_scans is not None:
         n_scans = min(n_scans, max_scans)
@@ -133,12 +136,13 @@ def make_session(cfg: SessionConfig, max_scans: int | None = None) -> Session:
     for s in range(n_scans):
         for _ in range(odom_per_scan):
             # pure-pursuit style controller on the waypoint route
-            tgt = route[wp % len(route)]
+            tgt = route[min(wp, len(route) - 1)]
             d = tgt - pose[:2]
-            if np.hypot(*d) < 1.0:
+            if np.hypot(*d) < 1.0 and wp < len(route) - 1:
                 wp += 1
-                tgt = route[wp % len(route)]
+                tgt = route[wp]
                 d = tgt - pose[:2]
+            parked = wp == len(route) - 1 and np.hypot(*d) < 0.5
             err = math.atan2(d[1], d[0]) - pose[2]
             err = math.atan2(math.sin(err), math.cos(err))
             w = max(-w_max, min(w_max, k_heading * err))
@@ -146,6 +150,8 @@ def make_session(cfg: SessionConfig, max_scans: int | None = None) -> Session:
             vy = 0.0
             if cfg.odom_model == OMNI:
                 vy = 0.3 * math.sin(0.2 * t)
+            if parked:
+                v, vy, w = 0.0, 0.0, 0.0
             # true motion: the same integrator the filter linearises
             if cfg.odom_model == DIFF:
                 half = pose[2] + w * dt / 2
