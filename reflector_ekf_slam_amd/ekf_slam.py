@@ -225,6 +225,9 @@ class ReflectorEKFSLAM:
                                        xy.shape[0]), "SetGlobalMap")
         self._map = Map(xy.copy(), cov.reshape(-1, 2, 2).copy())
 
+    def set_map(self, xy, cov):
+        self.SetGlobalMap(Map(np.asarray(xy, np.float32).reshape(-1, 2), np.asarray(cov, np.float64).reshape(-1, 2, 2)))
+
     @property
     def n(self) -> int:
         n = C.c_int()
