@@ -146,6 +146,9 @@ void *rekf_stream(rekf_t *h);
 /* Leading dimension (doubles) of the device covariance and its device pointer. */
 int rekf_device_layout(rekf_t *h, int *ld, int *n_max, void **P_dev, void **mu_dev);
 
+/* Debug builds (-DREKF_DEBUG_TIMING) let kernels drop cycle counters here; zeros otherwise. */
+int rekf_debug_counters(rekf_t *h, long long out8[8]);
+
 const char *rekf_strerror(int code);
 const char *rekf_last_hip_error(rekf_t *h);
 int rekf_abi_version(void);

@@ -41,6 +41,7 @@ struct RekfCtl {
     double hb[REKF_MAX_ROWS][2];  // H(r, hcol..hcol+1)
     double dz[REKF_MAX_ROWS];     // z - zhat
     double qd[REKF_MAX_ROWS];     // diag(Q)
+    long long dbg[8];             // scratch for in-kernel timing experiments (REKF_DEBUG_TIMING builds)
 };
 
 // By-value kernel argument of the front kernel: one scan's worth of host input.

@@ -50,7 +50,8 @@ __device__ static void motion_terms(const RekfFrontArgs &A, double theta, Motion
     if (A.model == 0) {                                   // DIFF  cc:156-183
         const double delta_theta = w * dt;
         const double half = theta + delta_theta / 2;
-        const double ch = cos(half), sh = sin(half);
+        double sh, ch;
+        sincos(half, &sh, &ch);
         mo.d[0] = vx * dt * ch;
         mo.d[1] = vx * dt * sh;
         mo.d[2] = delta_theta;
@@ -63,7 +64,8 @@ __device__ static void motion_terms(const RekfFrontArgs &A, double theta, Motion
         Qu[0] = A.lin_cov; Qu[1] = A.ang_cov; Qu[2] = 0;
     } else {                                              // OMNI  cc:184-205
         const double delta_theta = w * dt;
-        const double ct = cos(theta), st = sin(theta);
+        double st, ct;
+        sincos(theta, &st, &ct);
         mo.d[0] = vx * dt * ct - vy * dt * st;
         mo.d[1] = vx * dt * st + vy * dt * ct;
         mo.d[2] = delta_theta;
@@ -104,13 +106,14 @@ __device__ static void corner_predict(double *P, int ld, const Motion &mo)
             P[i + (size_t)j * ld] += mo.V[i * 3 + j];
 }
 
-__device__ static void obs_to_global(double x, double y, double th, float px, float py,
+__device__ static void obs_to_global(double x, double y, double c, double s, float px, float py,
                                      float &gx, float &gy)
 {
 #pragma clang fp contract(off)
     // cc:389-393 / cc:327-331: evaluated in double, rounded to float32 on assignment
-    gx = (float)((double)px * cos(th) - (double)py * sin(th) + x);
-    gy = (float)((double)px * sin(th) + (double)py * cos(th) + y);
+    // (c, s = cos, sin of the heading)
+    gx = (float)((double)px * c - (double)py * s + x);
+    gy = (float)((double)px * s + (double)py * c + y);
 }
 
 __device__ static double yaw_innovation(double delta_theta)
@@ -124,6 +127,20 @@ __device__ static double yaw_innovation(double delta_theta)
     const double angle = 2. * atan2(fabs(z), w);
     const double scale = angle < 1e-7 ? 2. : angle / sin(angle / 2.);
     return scale * z;
+}
+
+// bare v_min_f64 / v_max_f64 (fmin/fmax would add a canonicalising v_max x,x per operand)
+__device__ static inline double vmin_f64(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ static inline double vmax_f64(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 // wave-wide arg-min of (d, j) with the "first minimum in index order" rule
@@ -141,56 +158,101 @@ __device__ static void wave_argmin(double &d, int &j)
 // ----------------------------------------------------------------------------
 // k_front: one workgroup of 16 waves.
 // ----------------------------------------------------------------------------
+#define LM_LDS_MAX 4096       // landmarks kept as float32 pairs in LDS (32 KiB); beyond that: global loop
+#define COV_PF 3              // covariance-predict operands prefetched per thread (covers n <= 3072)
 __global__ __launch_bounds__(1024) void k_front(RekfDev d, RekfFrontArgs A)
 {
     __shared__ Motion mo;
-    __shared__ double pose[3];
-    __shared__ int s_n;
+    __shared__ double pose[5];                 // x, y, theta, cos(theta), sin(theta) after Predict
     __shared__ int s_kind[REKF_MAX_OBS_DEV];   // 0 map match, 1 state match, 2 new
     __shared__ int s_idx[REKF_MAX_OBS_DEV];
     __shared__ int s_pair_obs[REKF_MAX_OBS_DEV], s_pair_id[REKF_MAX_OBS_DEV], s_pair_state[REKF_MAX_OBS_DEV];
     __shared__ int s_counts[4];
+    __shared__ float s_lm[2 * LM_LDS_MAX];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR)
     RekfCtl *ctl = d.ctl;
-    double *P = d.P;
+    double *__restrict__ P = d.P;
     double *mu = d.mu;
     const size_t ld = (size_t)d.ld;
+    const int n = ctl->n;
+    const int L = (n - 3) / 2;
+    const bool lm_in_lds = L <= LM_LDS_MAX;
+#ifdef REKF_DEBUG_TIMING
+    long long tq[6]; tq[0] = clock64();
+#define TMARK(i) tq[i] = clock64()
+#else
+#define TMARK(i)
+#endif
 
+    // ---- everything that only depends on the OLD state is put in flight first:
+    // (1) landmark means -> LDS as float32 (the matcher casts them to float, cc:431; Predict
+    //     does not touch them), (2) the covariance-predict operands, (3) the pose block.
+    if (A.is_obs && A.K > 0 && lm_in_lds)
+        for (int j = tid; j < L; j += 1024) {
+            s_lm[2 * j] = (float)mu[3 + 2 * j];
+            s_lm[2 * j + 1] = (float)mu[4 + 2 * j];
+        }
+    double c0[COV_PF], c1[COV_PF], c2[COV_PF], r0[COV_PF], r1[COV_PF], r2[COV_PF];
+#pragma unroll
+    for (int t = 0; t < COV_PF; ++t) {
+        const int idx = tid + 1024 * t;
+        if (idx >= 3 && idx < n) {
+            c0[t] = P[idx + 0 * ld]; c1[t] = P[idx + 1 * ld]; c2[t] = P[idx + 2 * ld];   // column part (coalesced)
+            r0[t] = P[0 + idx * ld]; r1[t] = P[1 + idx * ld]; r2[t] = P[2 + idx * ld];   // row part (strided)
+        }
+    }
+    double C9[9], mu0 = 0, mu1 = 0, mu2 = 0;
     if (tid == 0) {
-        s_n = ctl->n;
-        motion_terms(A, mu[2], mo);
+        for (int q = 0; q < 9; ++q) C9[q] = P[(q % 3) + (size_t)(q / 3) * ld];   // pose block, column-major 3x3
+        mu0 = mu[0]; mu1 = mu[1]; mu2 = mu[2];
+        motion_terms(A, mu2, mo);
     }
     __syncthreads();
-    const int n = s_n;
+    TMARK(1);
 
     // ---- Predict, covariance: P <- G P G^T + Gu Qu Gu^T.  G = I + a e0 e2^T + b e1 e2^T
     // touches rows 0,1 and columns 0,1 only (the reference multiplies dense n x n, cc:178/202).
     {
 #pragma clang fp contract(off)
         const double a = mo.a, b = mo.b;
-        for (int idx = tid; idx < n; idx += 1024) {
-            if (idx >= 3) {
-                const double p2 = P[idx + 2 * ld];                 // column part (coalesced)
-                P[idx + 0 * ld] = P[idx + 0 * ld] + a * p2;
-                P[idx + 1 * ld] = P[idx + 1 * ld] + b * p2;
-                const double q2 = P[2 + idx * ld];                 // row part (strided)
-                P[0 + idx * ld] = P[0 + idx * ld] + a * q2;
-                P[1 + idx * ld] = P[1 + idx * ld] + b * q2;
+#pragma unroll
+        for (int t = 0; t < COV_PF; ++t) {
+            const int idx = tid + 1024 * t;
+            if (idx >= 3 && idx < n) {
+                P[idx + 0 * ld] = c0[t] + a * c2[t];
+                P[idx + 1 * ld] = c1[t] + b * c2[t];
+                P[0 + idx * ld] = r0[t] + a * r2[t];
+                P[1 + idx * ld] = r1[t] + b * r2[t];
             }
         }
+        for (int idx = tid + 1024 * COV_PF; idx < n; idx += 1024) {
+            const double p2 = P[idx + 2 * ld];
+            P[idx + 0 * ld] = P[idx + 0 * ld] + a * p2;
+            P[idx + 1 * ld] = P[idx + 1 * ld] + b * p2;
+            const double q2 = P[2 + idx * ld];
+            P[0 + idx * ld] = P[0 + idx * ld] + a * q2;
+            P[1 + idx * ld] = P[1 + idx * ld] + b * q2;
+        }
         if (tid == 0) {
-            corner_predict(P, d.ld, mo);
+            corner_predict(C9, 3, mo);
+            for (int q = 0; q < 9; ++q) P[(q % 3) + (size_t)(q / 3) * ld] = C9[q];
             // mean (cc:180-181 / :204-205)
-            const double x = mu[0] + mo.d[0], y = mu[1] + mo.d[1];
-            double th = mu[2] + mo.d[2];
-            th = atan2(sin(th), cos(th));
+            const double x = mu0 + mo.d[0], y = mu1 + mo.d[1];
+            double th = mu2 + mo.d[2], sn, cs;
+            sincos(th, &sn, &cs);
+            th = atan2(sn, cs);
             mu[0] = x; mu[1] = y; mu[2] = th;
             pose[0] = x; pose[1] = y; pose[2] = th;
+            // the reference re-evaluates cos/sin(mu(2)) at every use (cc:252-253, :390-391);
+            // same argument, same value: evaluate once
+            sincos(th, &sn, &cs);
+            pose[3] = cs; pose[4] = sn;
         }
     }
     __syncthreads();
+    TMARK(2);
     if (!A.is_obs) return;                    // odometry path: HandleOdometryMessage cc:208-223
 
     const int K = A.K;
@@ -201,47 +263,106 @@ __global__ __launch_bounds__(1024) void k_front(RekfDev d, RekfFrontArgs A)
         return;
     }
 
-    // ---- ReflectorMatch (cc:370-455): one wave per observation, lanes over candidates
-    const int L = (n - 3) / 2;
+    // ---- ReflectorMatch (cc:370-455): wave w owns observations w, w+16, w+32, w+48 and sweeps
+    // the candidates once for all of them (lanes over candidates, landmarks read once).
     const int M_ = d.M_map;
-    for (int i = wave; i < K; i += 16) {
-        float gx, gy;
-        obs_to_global(pose[0], pose[1], pose[2], A.obs[2 * i], A.obs[2 * i + 1], gx, gy);
-        int kind = 2, best_j = -1;
-        if (M_ > 0) {                                              // cc:401-425
-#pragma clang fp contract(off)
-            double best = 0; int bj = -1;
-            for (int j = lane; j < M_; j += WAVE) {
-                const double *S = d.map_cov + 4 * (size_t)j;
-                const float ex = d.map_xy[2 * j] - gx;             // float32 subtract (cc:408)
-                const float ey = d.map_xy[2 * j + 1] - gy;
-                const double dx = (double)ex, dy = (double)ey;
-                const double t0 = dx * S[0] + dy * S[2];
-                const double t1 = dx * S[1] + dy * S[3];
-                const double dist = sqrt(t0 * dx + t1 * dy);       // delta Sigma delta^T (cc:411)
-                if (bj < 0 || dist < best) { best = dist; bj = j; }
-            }
-            wave_argmin(best, bj);
-            if (bj >= 0 && best < 0.05) { kind = 0; best_j = bj; } // cc:420
+    {
+        constexpr int OQ = REKF_MAX_OBS_DEV / 16;
+        float gx[OQ], gy[OQ];
+        int kind[OQ], best_j[OQ];
+#pragma unroll
+        for (int q = 0; q < OQ; ++q) {
+            const int i = wave + 16 * q;
+            kind[q] = 2; best_j[q] = -1;
+            gx[q] = 0.f; gy[q] = 0.f;
+            if (i < K) obs_to_global(pose[0], pose[1], pose[3], pose[4], A.obs[2 * i], A.obs[2 * i + 1], gx[q], gy[q]);
         }
-        if (kind == 2 && L > 0) {                                  // cc:426-451
+        if (M_ > 0) {                                              // cc:401-425 (pre-loaded map first)
+#pragma unroll
+            for (int q = 0; q < OQ; ++q) {
 #pragma clang fp contract(off)
-            double best = 0; int bj = -1;
+                const int i = wave + 16 * q;
+                if (i >= K) continue;
+                double best = 0; int bj = -1;
+                for (int j = lane; j < M_; j += WAVE) {
+                    const double *S = d.map_cov + 4 * (size_t)j;
+                    const float ex = d.map_xy[2 * j] - gx[q];      // float32 subtract (cc:408)
+                    const float ey = d.map_xy[2 * j + 1] - gy[q];
+                    const double dx = (double)ex, dy = (double)ey;
+                    const double t0 = dx * S[0] + dy * S[2];
+                    const double t1 = dx * S[1] + dy * S[3];
+                    const double dist = sqrt(t0 * dx + t1 * dy);   // delta Sigma delta^T (cc:411)
+                    if (bj < 0 || dist < best) { best = dist; bj = j; }
+                }
+                wave_argmin(best, bj);
+                if (bj >= 0 && best < 0.05) { kind[q] = 0; best_j[q] = bj; }   // cc:420
+            }
+        }
+        if (L > 0) {                                               // cc:426-451
+#pragma clang fp contract(off)
+            // dist = sqrt(dx*dx + dy*dy) (cc:437), first minimum in index order.  sqrt is monotone
+            // and correctly rounded, so the arg-min runs on the squared distances; every lane also
+            // keeps its runner-up so that a second candidate inside a 2e-15 relative band above the
+            // minimum (where sqrt could merge two values) is detected; only then (never, for real
+            // maps) is the literal sqrt-per-candidate scan executed.
+            auto lm_of = [&](int j, float &lx, float &ly) {
+                if (lm_in_lds) { lx = s_lm[2 * j]; ly = s_lm[2 * j + 1]; }
+                else { lx = (float)mu[3 + 2 * j]; ly = (float)mu[4 + 2 * j]; }   // cc:431
+            };
+            double b1[OQ], b2[OQ];                                 // lane-local minimum and runner-up
+            int bj[OQ];
+#pragma unroll
+            for (int q = 0; q < OQ; ++q) { b1[q] = 1e300; b2[q] = 1e300; bj[q] = -1; }
+            const int nq = (K - wave + 15) / 16;                   // observations this wave owns (uniform)
             for (int j = lane; j < L; j += WAVE) {
-                const float lx = (float)mu[3 + 2 * j];             // cc:431
-                const float ly = (float)mu[4 + 2 * j];
-                const float ex = gx - lx;                          // cc:433
-                const float ey = gy - ly;
-                const double dx = (double)ex, dy = (double)ey;
-                const double dist = sqrt(dx * dx + dy * dy);       // cc:437
-                if (bj < 0 || dist < best) { best = dist; bj = j; }
+                float lx, ly;
+                lm_of(j, lx, ly);
+#pragma unroll
+                for (int q = 0; q < OQ; ++q) {
+                    if (q < nq) {
+                        const float ex = gx[q] - lx;               // cc:433
+                        const float ey = gy[q] - ly;
+                        const double dx = (double)ex, dy = (double)ey;
+                        const double d2 = dx * dx + dy * dy;
+                        b2[q] = vmin_f64(b2[q], vmax_f64(d2, b1[q]));
+                        bj[q] = (d2 < b1[q]) ? j : bj[q];          // strict: first index wins inside a lane
+                        b1[q] = vmin_f64(b1[q], d2);
+                    }
+                }
             }
-            wave_argmin(best, bj);
-            if (bj >= 0 && best < 0.6) { kind = 1; best_j = bj; }  // cc:446
+#pragma unroll
+            for (int q = 0; q < OQ; ++q) {
+                const int i = wave + 16 * q;
+                if (i >= K || kind[q] != 2) continue;              // wave-uniform
+                double g1 = b1[q]; int gj = bj[q];
+                wave_argmin(g1, gj);
+                const double band = g1 * 1.000000000000002;
+                int near = ((bj[q] >= 0 && b1[q] <= band) ? 1 : 0) + ((b2[q] <= band) ? 1 : 0);
+                for (int off = 32; off >= 1; off >>= 1) near += __shfl_xor(near, off, WAVE);
+                double best = sqrt(g1);
+                if (near > 1) {                                    // literal scan (wave-uniform, rare)
+                    best = 0; gj = -1;
+                    for (int j = lane; j < L; j += WAVE) {
+                        float lx, ly;
+                        lm_of(j, lx, ly);
+                        const float ex = gx[q] - lx, ey = gy[q] - ly;
+                        const double dx = (double)ex, dy = (double)ey;
+                        const double dist = sqrt(dx * dx + dy * dy);   // cc:437
+                        if (gj < 0 || dist < best) { best = dist; gj = j; }
+                    }
+                    wave_argmin(best, gj);
+                }
+                if (gj >= 0 && best < 0.6) { kind[q] = 1; best_j[q] = gj; }   // cc:446
+            }
         }
-        if (lane == 0) { s_kind[i] = kind; s_idx[i] = best_j; }
+#pragma unroll
+        for (int q = 0; q < OQ; ++q) {
+            const int i = wave + 16 * q;
+            if (i < K && lane == 0) { s_kind[i] = kind[q]; s_idx[i] = best_j[q]; }
+        }
     }
     __syncthreads();
+    TMARK(3);
 
     // ---- ordered compaction into the three lists (obs order preserved)
     if (wave == 0) {
@@ -279,13 +400,14 @@ __global__ __launch_bounds__(1024) void k_front(RekfDev d, RekfFrontArgs A)
     }
     __syncthreads();
 
+    TMARK(4);
     // ---- H rows, z - zhat, Q (cc:248-304): row pair p per thread
     const int M = s_counts[0], MM = s_counts[0] + s_counts[1];
     if (tid < MM) {
 #pragma clang fp contract(off)
         const int p = tid;
         const int local_id = s_pair_obs[p], global_id = s_pair_id[p], is_state = s_pair_state[p];
-        const double c = cos(pose[2]), s = sin(pose[2]);           // cc:252-253
+        const double c = pose[3], s = pose[4];                      // cc:252-253
         const double z0 = (double)A.obs[2 * local_id], z1 = (double)A.obs[2 * local_id + 1];
         double lx, ly;
         if (is_state) { lx = mu[3 + 2 * global_id]; ly = mu[4 + 2 * global_id]; }
@@ -315,6 +437,10 @@ __global__ __launch_bounds__(1024) void k_front(RekfDev d, RekfFrontArgs A)
         ctl->qd[r0] = 0.05 * 0.05; ctl->qd[r0 + 1] = 0.05 * 0.05; ctl->qd[r0 + 2] = 0.017 * 0.017;
     }
     (void)M;
+#ifdef REKF_DEBUG_TIMING
+    __syncthreads();
+    if (tid == 0) { tq[5] = clock64(); for (int i = 1; i < 6; ++i) ctl->dbg[1 + i] = tq[i] - tq[0]; }
+#endif
 }
 
 // ----------------------------------------------------------------------------
@@ -332,41 +458,47 @@ __global__ __launch_bounds__(256) void k_gather(RekfDev d)
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= d.ld) return;
     const bool valid = c < n;
-    const double *P = d.P;
-    double p0 = 0, p1 = 0, p2 = 0, q0 = 0, q1 = 0, q2 = 0;
-    const double *Pc = P + (size_t)c * ld;                       // column c
-    if (valid) {
-        p0 = P[c]; p1 = P[c + ld]; p2 = P[c + 2 * ld];
-        q0 = Pc[0]; q1 = Pc[1]; q2 = Pc[2];
-    }
+    const double *__restrict__ P = d.P;
+    double *__restrict__ W = d.W;
+    double *__restrict__ HPt = d.HPt;
+    const double *__restrict__ Pc = P + (size_t)(valid ? c : 0) * ld;   // column c (rows of P for H P)
+    const int cc = valid ? c : 0;
+    const double p0 = P[cc], p1 = P[cc + ld], p2 = P[cc + 2 * ld];
+    const double q0 = Pc[0], q1 = Pc[1], q2 = Pc[2];
     for (int pr = blockIdx.y; pr < m_pad / 2; pr += gridDim.y) {
+        const int r0 = 2 * pr;
+        // both rows of a pair share the landmark columns (cc:275)
+        const int col = (r0 < m) ? ctl->hcol[r0] : -1;
+        const int cl = (col >= 0) ? col : 0;
+        const double pl0 = P[cc + (size_t)cl * ld], pl1 = P[cc + (size_t)(cl + 1) * ld];
+        const double ql0 = Pc[cl], ql1 = Pc[cl + 1];
+#pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
-            const int r = 2 * pr + rr;
+            const int r = r0 + rr;
             double v = 0, u = 0;
             if (valid && r < m) {
-                const int col = ctl->hcol[r];
                 const double h0 = ctl->ha[r][0], h1 = ctl->ha[r][1], h2 = ctl->ha[r][2];
                 v = p0 * h0; v += p1 * h1; v += p2 * h2;
                 u = h0 * q0; u += h1 * q1; u += h2 * q2;
-                if (col >= 0) {
+                if (ctl->hcol[r] >= 0) {
                     const double g0 = ctl->hb[r][0], g1 = ctl->hb[r][1];
-                    v += P[c + (size_t)col * ld] * g0;
-                    v += P[c + (size_t)(col + 1) * ld] * g1;
-                    u += g0 * Pc[col];
-                    u += g1 * Pc[col + 1];
+                    v += pl0 * g0; v += pl1 * g1;
+                    u += g0 * ql0; u += g1 * ql1;
                 }
             }
-            d.W[c + (size_t)r * ld] = v;
-            d.HPt[c + (size_t)r * ld] = u;
+            W[c + (size_t)r * ld] = v;
+            HPt[c + (size_t)r * ld] = u;
         }
     }
 }
 
 // ----------------------------------------------------------------------------
 // k_solve: S = H W + Q (m x m), S^-1 by Gauss-Jordan, y = S^-1 dz.
-// 1024 threads as a 32x32 grid; thread (ti,tj) keeps S(ti+32a, tj+32b) in
-// registers; per elimination step only row k and column k travel through LDS
-// (ping-pong buffers, one barrier per step).
+// One workgroup of 4 waves (one per SIMD) as a 16x16 thread grid; thread (ti,tj)
+// keeps S(ti+16a, tj+16b) in registers, so one elimination step costs NB*NB
+// FMAs per lane; only row k and column k travel through LDS (ping-pong buffers,
+// ONE barrier per step).  The 64 (128) steps are inherently sequential: this
+// kernel is latency-, not throughput-bound.
 // ----------------------------------------------------------------------------
 template <int NB>
 __device__ static void solve_body(const RekfDev &d, int m, double (*rowbuf)[REKF_MR_PAD],
@@ -374,103 +506,135 @@ __device__ static void solve_body(const RekfDev &d, int m, double (*rowbuf)[REKF
 {
     RekfCtl *ctl = d.ctl;
     const int tid = threadIdx.x;
-    const int ti = tid >> 5, tj = tid & 31;
+    const int ti = tid >> 4, tj = tid & 15;
     const size_t ld = (size_t)d.ld;
+    const double *__restrict__ W = d.W;
     double S[NB][NB];
+    {
+        double h0[NB], h1[NB], h2[NB], g0[NB], g1[NB], qd[NB];
+        int hc[NB];
 #pragma unroll
-    for (int a = 0; a < NB; ++a) {
-        const int i = ti + 32 * a;
+        for (int a = 0; a < NB; ++a) {
+            const int i = ti + 16 * a;
+            const bool in = i < m;
+            h0[a] = in ? ctl->ha[i][0] : 0.0; h1[a] = in ? ctl->ha[i][1] : 0.0; h2[a] = in ? ctl->ha[i][2] : 0.0;
+            hc[a] = in ? ctl->hcol[i] : -1;
+            g0[a] = (hc[a] >= 0) ? ctl->hb[i][0] : 0.0; g1[a] = (hc[a] >= 0) ? ctl->hb[i][1] : 0.0;
+            qd[a] = in ? ctl->qd[i] : 0.0;
+            if (hc[a] < 0) hc[a] = 0;              // harmless in-bounds address, coefficient is 0
+        }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const int j = tj + 32 * b;
-            double v = (i == j) ? 1.0 : 0.0;
-            if (i < m && j < m) {
-                const double *w = d.W + (size_t)j * ld;          // column j of W
-                const int col = ctl->hcol[i];
-                v = ctl->ha[i][0] * w[0];
-                v += ctl->ha[i][1] * w[1];
-                v += ctl->ha[i][2] * w[2];
-                if (col >= 0) {
-                    v += ctl->hb[i][0] * w[col];
-                    v += ctl->hb[i][1] * w[col + 1];
-                }
-                if (i == j) v += ctl->qd[i];
+            const int j = tj + 16 * b;
+            const double *__restrict__ w = W + (size_t)((j < m) ? j : 0) * ld;     // column j of W
+            const double w0 = w[0], w1 = w[1], w2 = w[2];
+#pragma unroll
+            for (int a = 0; a < NB; ++a) {
+                const int i = ti + 16 * a;
+                double v = h0[a] * w0;
+                v += h1[a] * w1;
+                v += h2[a] * w2;
+                v += g0[a] * w[hc[a]];
+                v += g1[a] * w[hc[a] + 1];
+                if (i == j) v += qd[a];
+                if (i >= m || j >= m) v = (i == j) ? 1.0 : 0.0;
+                S[a][b] = v;
             }
-            S[a][b] = v;
         }
     }
     bool bad = false;
+#ifdef REKF_DEBUG_TIMING
+    const long long t0c = clock64(), t0w = wall_clock64();
+#endif
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
-        for (int kk = 0; kk < 32; ++kk) {
-            const int k = 32 * kb + kk;
+        for (int kk = 0; kk < 16; ++kk) {
+            const int k = 16 * kb + kk;
             if (k >= m) break;
             const int buf = k & 1;
-            if (ti == kk) {
+            const bool own_row = ti == kk, own_col = tj == kk;   // row/col k live in block kb of these threads
+            if (own_row) {
 #pragma unroll
-                for (int b = 0; b < NB; ++b) rowbuf[buf][tj + 32 * b] = S[kb][b];
+                for (int b = 0; b < NB; ++b) rowbuf[buf][tj + 16 * b] = S[kb][b];
             }
-            if (tj == kk) {
+            if (own_col) {
 #pragma unroll
-                for (int a = 0; a < NB; ++a) colbuf[buf][ti + 32 * a] = S[a][kb];
+                for (int a = 0; a < NB; ++a) colbuf[buf][ti + 16 * a] = S[a][kb];
             }
             __syncthreads();
             const double piv = rowbuf[buf][k];
             if (!(piv > 0.0)) bad = true;
-            const double p = 1.0 / piv;
+            // p = 1/piv: hardware reciprocal + two Newton steps (<= 2 ulp; S is SPD and well scaled,
+            // the IEEE division's scaling/fix-up paths are never needed here)
+            double p = __builtin_amdgcn_rcp(piv);
+            p = fma(p, fma(-piv, p, 1.0), p);
+            p = fma(p, fma(-piv, p, 1.0), p);
+            // in-place Gauss-Jordan step: R = p * row k with R_k = p; for i != k:
+            //   S(i,j) <- S(i,j)[col k zeroed] - S(i,k) * R_j ;   row k <- R
+            double R[NB], f[NB];
 #pragma unroll
-            for (int a = 0; a < NB; ++a) {
-                const int i = ti + 32 * a;
-                const double f = colbuf[buf][i] * p;
+            for (int b = 0; b < NB; ++b) R[b] = rowbuf[buf][tj + 16 * b] * p;
+            if (own_col) R[kb] = p;
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const int j = tj + 32 * b;
-                    const double rj = rowbuf[buf][j];
-                    double v;
-                    if (i == k) v = (j == k) ? p : rj * p;
-                    else if (j == k) v = -f;
-                    else v = S[a][b] - f * rj;
-                    S[a][b] = v;
-                }
+            for (int a = 0; a < NB; ++a) f[a] = colbuf[buf][ti + 16 * a];
+            if (own_col) {
+#pragma unroll
+                for (int a = 0; a < NB; ++a) S[a][kb] = 0.0;
+            }
+#pragma unroll
+            for (int a = 0; a < NB; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) S[a][b] = fma(-f[a], R[b], S[a][b]);
+            if (own_row) {
+#pragma unroll
+                for (int b = 0; b < NB; ++b) S[kb][b] = R[b];
             }
         }
     }
+#ifdef REKF_DEBUG_TIMING
+    if (tid == 0) { ctl->dbg[0] = clock64() - t0c; ctl->dbg[1] = wall_clock64() - t0w; }
+#endif
     if (bad && tid == 0) atomicOr(&ctl->err, REKF_FLAG_SINGULAR);
     // S^-1 out (pad rows/cols are the identity) and y = S^-1 dz
+    double dzj[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) dzj[b] = (tj + 16 * b < m) ? ctl->dz[tj + 16 * b] : 0.0;
 #pragma unroll
     for (int a = 0; a < NB; ++a) {
-        const int i = ti + 32 * a;
+        const int i = ti + 16 * a;
         double acc = 0;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const int j = tj + 32 * b;
+            const int j = tj + 16 * b;
             d.Sinv[i + (size_t)j * REKF_MR_PAD] = S[a][b];
-            if (j < m) acc += S[a][b] * ctl->dz[j];
+            acc += S[a][b] * dzj[b];
         }
-        for (int off = 16; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 32);
+        for (int off = 8; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 16);
         if (tj == 0) d.y[i] = (i < m) ? acc : 0.0;
     }
 }
 
-__global__ __launch_bounds__(1024) void k_solve(RekfDev d)
+__global__ __launch_bounds__(256) void k_solve(RekfDev d)
 {
     __shared__ double rowbuf[2][REKF_MR_PAD];
     __shared__ double colbuf[2][REKF_MR_PAD];
     const int m = d.ctl->m;
     if (m == 0) return;
-    if (m <= 32) solve_body<1>(d, m, rowbuf, colbuf);
-    else if (m <= 64) solve_body<2>(d, m, rowbuf, colbuf);
-    else if (m <= 96) solve_body<3>(d, m, rowbuf, colbuf);
-    else solve_body<4>(d, m, rowbuf, colbuf);
+    if (m <= 32) solve_body<2>(d, m, rowbuf, colbuf);
+    else if (m <= 64) solve_body<4>(d, m, rowbuf, colbuf);
+    else solve_body<8>(d, m, rowbuf, colbuf);
 }
 
 // ----------------------------------------------------------------------------
 // k_gain: Kn(i, j) = -sum_k W(i,k) Sinv(k,j) with v_mfma_f64_16x16x4_f64,
 // computed transposed (MFMA rows <-> j, MFMA cols <-> i) so that the 16 lanes
-// of a row group store 128 contiguous bytes of a Kn column.  mu += W y.
-// One workgroup = 16 state rows; wave w takes column tiles w, w+4, ...
+// of a row group store 128 contiguous bytes of a Kn column.
+// One workgroup = 16 state rows, one wave per 16-column tile of Kn; one more
+// wave computes the mean increment with the same instruction by using y as an
+// extra "column" of S^-1:  dmu(i) = sum_k W(i,k) y(k)  (cc:306), theta wrap (cc:307).
+// All operands of a 16-k-step chunk are loaded before the MFMA chain starts.
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gain(RekfDev d)
+__global__ __launch_bounds__(512) void k_gain(RekfDev d)
 {
     const RekfCtl *ctl = d.ctl;
     const int m = ctl->m;
@@ -481,29 +645,41 @@ __global__ __launch_bounds__(256) void k_gain(RekfDev d)
     const size_t ld = (size_t)d.ld;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int idx = lane & 15, kq = lane >> 4;
-    for (int jt = wave; jt < m_pad / 16; jt += 4) {
+    const int ntile = m_pad / 16;
+    const double *__restrict__ Wp = d.W + (size_t)(i0 + idx);
+    for (int jt = wave; jt <= ntile; jt += 8) {
+        const bool is_mu = jt == ntile;
         const int j0 = 16 * jt;
         v4d acc = {0, 0, 0, 0};
-        for (int kk = 0; kk < m_pad / 4; ++kk) {
-            const int k = 4 * kk + kq;
-            const double a = d.Sinv[k + (size_t)(j0 + idx) * REKF_MR_PAD];   // A[j][k] = Sinv(k, j)
-            const double b = d.W[(i0 + idx) + (size_t)k * ld];               // B[k][i] = W(i, k)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-        }
+        for (int kc = 0; kc < m_pad / 4; kc += 16) {
+            double a[16], b[16];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = j0 + kq + 4 * r;                                   // D row
-            d.Kn[(i0 + idx) + (size_t)j * ld] = -acc[r];                     // D col = idx
+            for (int q = 0; q < 16; ++q) {
+                const int kk = kc + q;
+                const int k = 4 * kk + kq;
+                const bool live = kk < m_pad / 4;
+                // A[j][k] = Sinv(k, j)   (mu tile: row 0 = y(k), other rows 0)
+                if (is_mu) a[q] = (live && idx == 0) ? d.y[k] : 0.0;
+                else a[q] = live ? d.Sinv[k + (size_t)(j0 + idx) * REKF_MR_PAD] : 0.0;
+                b[q] = live ? Wp[(size_t)k * ld] : 0.0;                     // B[k][i] = W(i, k)
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
         }
-    }
-    if (wave == 0 && lane < 16) {
-        const int i = i0 + lane;
-        if (i < n) {
-            double acc = 0;
-            for (int k = 0; k < m; ++k) acc += d.W[i + (size_t)k * ld] * d.y[k];   // cc:306
-            double v = d.mu[i] + acc;
-            if (i == 2) v = atan2(sin(v), cos(v));                                   // cc:307
-            d.mu[i] = v;
+        if (!is_mu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = j0 + kq + 4 * r;                               // D row
+                d.Kn[(i0 + idx) + (size_t)j * ld] = -acc[r];                 // D col = idx
+            }
+        } else if (kq == 0) {                                                // D row 0 = dmu
+            const int i = i0 + idx;
+            if (i < n) {
+                double v = d.mu[i] + acc[0];
+                if (i == 2) v = atan2(sin(v), cos(v));
+                d.mu[i] = v;
+            }
         }
     }
 }
@@ -512,7 +688,9 @@ __global__ __launch_bounds__(256) void k_gain(RekfDev d)
 // k_downdate: P(i,j) += sum_k Kn(i,k) HPt(j,k)   (P <- P - K (H P), cc:308)
 //
 // 64x64 tile of P per 256-thread workgroup; the Kn row panel and HPt row panel of
-// the tile are staged once in LDS ([k][64] doubles each, 32 KiB + 32 KiB) and
+// the tile are staged through LDS in k-chunks of DKC=32 ([k][64] doubles each,
+// 16 KiB + 16 KiB, so five workgroups fit a CU and the whole C3 grid is resident
+// in one round: loads, MFMA and stores of different tiles overlap) and
 // every wave owns a 32x32 sub-tile = 2x2 v_mfma_f64_16x16x4_f64 accumulators
 // initialised with P itself, so P is read once and written once.
 // The MFMA is evaluated transposed (MFMA M <-> j, N <-> i) and MFMA tile t of a
@@ -522,10 +700,11 @@ __global__ __launch_bounds__(256) void k_gain(RekfDev d)
 // tiles, conflict-free on the linear [k][64] LDS image.
 // ----------------------------------------------------------------------------
 #define DT 64
-__global__ __launch_bounds__(256, 2) void k_downdate(RekfDev d)
+#define DKC 32
+__global__ __launch_bounds__(256, 4) void k_downdate(RekfDev d)
 {
-    __shared__ __attribute__((aligned(16))) double sK[DT * 64];
-    __shared__ __attribute__((aligned(16))) double sW[DT * 64];
+    __shared__ __attribute__((aligned(16))) double sK[DKC * 64];
+    __shared__ __attribute__((aligned(16))) double sW[DKC * 64];
     const RekfCtl *ctl = d.ctl;
     const int m_pad = ctl->m_pad;
     if (ctl->m == 0) return;
@@ -552,8 +731,8 @@ __global__ __launch_bounds__(256, 2) void k_downdate(RekfDev d)
             acc[mt][1][r] = v.y;
         }
 
-    for (int k0 = 0; k0 < m_pad; k0 += 64) {
-        const int kmax = (m_pad - k0 < 64) ? (m_pad - k0) : 64;
+    for (int k0 = 0; k0 < m_pad; k0 += DKC) {
+        const int kmax = (m_pad - k0 < DKC) ? (m_pad - k0) : DKC;
         if (k0 > 0) __syncthreads();
         for (int e = tid; e < kmax * 32; e += 256) {
             const int k = e >> 5, pr = e & 31;
@@ -589,7 +768,7 @@ __global__ __launch_bounds__(256, 2) void k_downdate(RekfDev d)
 // ----------------------------------------------------------------------------
 // k_augment (cc:311-364): one workgroup; runs only while the map is growing.
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_augment(RekfDev d, RekfFrontArgs A)
+__global__ __launch_bounds__(256) void k_augment(RekfDev d, RekfFrontArgs A)
 {
     __shared__ double Gp[REKF_MAX_OBS_DEV][6];
     __shared__ double Sxi[9];
@@ -608,7 +787,7 @@ __global__ __launch_bounds__(1024) void k_augment(RekfDev d, RekfFrontArgs A)
         if (tid < N2) {
             const int local_id = ctl->new_ids[tid];                 // cc:338
             float gx, gy;
-            obs_to_global(x, y, th, A.obs[2 * local_id], A.obs[2 * local_id + 1], gx, gy);
+            obs_to_global(x, y, c, s, A.obs[2 * local_id], A.obs[2 * local_id + 1], gx, gy);
             d.mu[n + 2 * tid] = (double)gx;                         // cc:341-342 (float32-rounded)
             d.mu[n + 2 * tid + 1] = (double)gy;
             const double rx = (double)A.obs[2 * local_id], ry = (double)A.obs[2 * local_id + 1];
@@ -625,7 +804,7 @@ __global__ __launch_bounds__(1024) void k_augment(RekfDev d, RekfFrontArgs A)
     }
     __syncthreads();
     // sigma_mx = G_fx * sigma (cc:355-357): rows n+2a+rr, all old columns, and the mirror
-    for (int e = tid; e < n * N2; e += 1024) {
+    for (int e = tid; e < n * N2; e += 256) {
 #pragma clang fp contract(off)
         const int a = e / n, col = e - a * n;
         const double q0 = P[0 + (size_t)col * ld], q1 = P[1 + (size_t)col * ld], q2 = P[2 + (size_t)col * ld];
@@ -639,7 +818,7 @@ __global__ __launch_bounds__(1024) void k_augment(RekfDev d, RekfFrontArgs A)
         }
     }
     // sigma_mm (cc:354,358): every (a,b) block, a != b included, gets + R Qt R^T
-    for (int e = tid; e < N2 * N2; e += 1024) {
+    for (int e = tid; e < N2 * N2; e += 256) {
 #pragma clang fp contract(off)
         const int a = e / N2, b = e - a * N2;
         for (int rr = 0; rr < 2; ++rr)
@@ -686,15 +865,15 @@ void rekf_launch_front(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s)
 }
 void rekf_launch_gather(const RekfDev &d, int n_ub, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_gather, dim3((n_ub + 255) / 256, 8), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(k_gather, dim3((n_ub + 255) / 256, 32), dim3(256), 0, s, d);
 }
 void rekf_launch_solve(const RekfDev &d, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_solve, dim3(1), dim3(1024), 0, s, d);
+    hipLaunchKernelGGL(k_solve, dim3(1), dim3(256), 0, s, d);
 }
 void rekf_launch_gain(const RekfDev &d, int n_ub, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_gain, dim3((n_ub + 15) / 16), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(k_gain, dim3((n_ub + 15) / 16), dim3(512), 0, s, d);
 }
 void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s)
 {
@@ -703,7 +882,7 @@ void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s)
 }
 void rekf_launch_augment(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_augment, dim3(1), dim3(1024), 0, s, d, a);
+    hipLaunchKernelGGL(k_augment, dim3(1), dim3(256), 0, s, d, a);
 }
 void rekf_launch_predict_pose(const RekfDev &d, const RekfFrontArgs &a, double *out12, hipStream_t s)
 {

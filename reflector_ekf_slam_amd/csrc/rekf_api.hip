@@ -441,6 +441,16 @@ int rekf_profile_reset(rekf_t *h)
 
 void *rekf_stream(rekf_t *h) { return h ? (void *)h->stream : nullptr; }
 
+/* debug builds only: the 8 scratch counters kernels may fill (see REKF_DEBUG_TIMING) */
+int rekf_debug_counters(rekf_t *h, long long out8[8])
+{
+    if (!h || !out8) return REKF_ERR_INVALID;
+    int rc = pull_ctl(h);
+    if (rc != REKF_OK) return rc;
+    for (int i = 0; i < 8; ++i) out8[i] = h->ctl_staging->dbg[i];
+    return REKF_OK;
+}
+
 int rekf_device_layout(rekf_t *h, int *ld, int *n_max, void **P_dev, void **mu_dev)
 {
     if (!h) return REKF_ERR_INVALID;
