@@ -146,8 +146,15 @@ void *rekf_stream(rekf_t *h);
 /* Leading dimension (doubles) of the device covariance and its device pointer. */
 int rekf_device_layout(rekf_t *h, int *ld, int *n_max, void **P_dev, void **mu_dev);
 
+/* Measurement hook: time `reps` back-to-back launches of one kernel of the chain (REKF_K_GATHER,
+ * _SOLVE, _GAIN, _DOWNDATE) on the scratch left by the last observation; the filter state is not
+ * meaningful afterwards (snapshot/restore it with rekf_get_state / rekf_set_state).
+ * `ablate` = 0, or bits that switch parts of k_downdate off for bottleneck analysis
+ * (1 no write-back, 2 no P reads, 4 no MFMA, 8 no panel reads). */
+int rekf_debug_time_kernel(rekf_t *h, int kernel, int reps, int ablate, double *avg_us);
+
 /* Debug builds (-DREKF_DEBUG_TIMING) let kernels drop cycle counters here; zeros otherwise. */
-int rekf_debug_counters(rekf_t *h, long long out8[8]);
+int rekf_debug_counters(rekf_t *h, long long out32[32]);
 
 const char *rekf_strerror(int code);
 const char *rekf_last_hip_error(rekf_t *h);

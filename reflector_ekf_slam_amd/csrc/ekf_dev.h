@@ -41,7 +41,7 @@ struct RekfCtl {
     double hb[REKF_MAX_ROWS][2];  // H(r, hcol..hcol+1)
     double dz[REKF_MAX_ROWS];     // z - zhat
     double qd[REKF_MAX_ROWS];     // diag(Q)
-    long long dbg[8];             // scratch for in-kernel timing experiments (REKF_DEBUG_TIMING builds)
+    long long dbg[32];            // scratch for in-kernel timing experiments (REKF_DEBUG_TIMING builds)
 };
 
 // By-value kernel argument of the front kernel: one scan's worth of host input.
@@ -71,6 +71,7 @@ struct RekfDev {
     int M_map;
     int ld;
     int n_max;
+    int dbg;            // ablation bits for rekf_debug_time_kernel; 0 in normal operation
 };
 
 // launch wrappers (ekf_kernels.hip)

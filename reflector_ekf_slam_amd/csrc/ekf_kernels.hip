@@ -687,82 +687,234 @@ __global__ __launch_bounds__(512) void k_gain(RekfDev d)
 // ----------------------------------------------------------------------------
 // k_downdate: P(i,j) += sum_k Kn(i,k) HPt(j,k)   (P <- P - K (H P), cc:308)
 //
-// 64x64 tile of P per 256-thread workgroup; the Kn row panel and HPt row panel of
-// the tile are staged through LDS in k-chunks of DKC=32 ([k][64] doubles each,
-// 16 KiB + 16 KiB, so five workgroups fit a CU and the whole C3 grid is resident
-// in one round: loads, MFMA and stores of different tiles overlap) and
-// every wave owns a 32x32 sub-tile = 2x2 v_mfma_f64_16x16x4_f64 accumulators
-// initialised with P itself, so P is read once and written once.
+// Persistent, software-pipelined rank-m downdate.  One 256-thread workgroup
+// (4 waves, one per SIMD) per CU walks a contiguous range of 64x64 tiles of P.
+// Per tile the Kn row panel and the HPt row panel are staged in LDS ([k][64]
+// doubles each, 32 KiB + 32 KiB, double-buffered = 128 KiB) and every wave owns
+// a 32x32 sub-tile = 2x2 v_mfma_f64_16x16x4_f64 accumulators initialised with P
+// itself, so P is read once and written once.  While the 64 MFMAs of tile t run
+// (4096 cycles per SIMD) the panels and the P block of tile t+1 are already in
+// flight into registers, and the stores of tile t drain under tile t+1: the
+// only synchronisation is ONE LDS-only barrier per tile.
+//
 // The MFMA is evaluated transposed (MFMA M <-> j, N <-> i) and MFMA tile t of a
 // pair covers the interleaved rows i = base + 2*idx + t, so that each lane
 // holds two adjacent rows of one column: 16-byte global accesses, 256 contiguous
 // bytes per 16 lanes, and ONE ds_read_b128 per operand per k-step feeds both
 // tiles, conflict-free on the linear [k][64] LDS image.
+// m_pad > 64 (more than 32 observations) runs as several 64-wide k-chunks
+// through the same pipeline.
 // ----------------------------------------------------------------------------
 #define DT 64
-#define DKC 32
-__global__ __launch_bounds__(256, 4) void k_downdate(RekfDev d)
+#define DKC 64
+#define DD_STG (DKC * 32 / 256)      // 16-byte panel pieces per thread per panel
+#ifndef DD_NBUF
+#define DD_NBUF 1                    // LDS panel buffers per workgroup (1: 64 KiB, two workgroups per CU)
+#endif
+#define DD_WG_PER_CU (DD_NBUF == 1 ? 2 : 1)
+
+__device__ static inline void dd_lds_barrier()
 {
-    __shared__ __attribute__((aligned(16))) double sK[DKC * 64];
-    __shared__ __attribute__((aligned(16))) double sW[DKC * 64];
-    const RekfCtl *ctl = d.ctl;
-    const int m_pad = ctl->m_pad;
-    if (ctl->m == 0) return;
-    const int n = ctl->n;
+    // LDS-only workgroup barrier: do NOT wait for outstanding global stores (vmcnt)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// FAST = the whole innovation fits one full 64-wide k-chunk (m_pad == 64, i.e. 25..32 matched
+// observations: BASELINE.json's N=1024 x 32 configuration).  Its loop is peeled so that every
+// prefetch/consume pair is unconditional and hipcc's waitcnt pass can count them exactly.
+template <bool FAST>
+__device__ static void downdate_body(const RekfDev &d, double *dd_smem, int n, int m_pad)
+{
     const int T = (n + DT - 1) / DT;
-    const int I = blockIdx.x, J = blockIdx.y;
-    if (I >= T || J >= T) return;
+    const int nchunk = FAST ? 1 : (m_pad + DKC - 1) / DKC;
+    const int ntiles = T * T;
+    const int t_begin = (int)(((long long)blockIdx.x * ntiles) / gridDim.x);
+    const int t_end = (int)(((long long)(blockIdx.x + 1) * ntiles) / gridDim.x);
+    if (t_begin >= t_end) return;
+    const int nitems = (t_end - t_begin) * nchunk;
     const size_t ld = (size_t)d.ld;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int idx = lane & 15, kq = lane >> 4;
     const int wi = wave & 1, wj = wave >> 1;
-    const int ib = DT * I + 32 * wi, jb = DT * J + 32 * wj;
+    const double *__restrict__ Kn = d.Kn;
+    const double *__restrict__ HPt = d.HPt;
+    double *__restrict__ P = d.P;
 
-    // accumulators <- P sub-tile
+    v2d stgK[DD_STG], stgW[DD_STG], pnext[8];
     v4d acc[2][2];
-    double *Pw = d.P + (size_t)(ib + 2 * idx);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = jb + 2 * (kq + 4 * r) + mt;
-            const v2d v = *(const v2d *)(Pw + (size_t)j * ld);
-            acc[mt][0][r] = v.x;
-            acc[mt][1][r] = v.y;
-        }
 
-    for (int k0 = 0; k0 < m_pad; k0 += DKC) {
-        const int kmax = (m_pad - k0 < DKC) ? (m_pad - k0) : DKC;
-        if (k0 > 0) __syncthreads();
-        for (int e = tid; e < kmax * 32; e += 256) {
-            const int k = e >> 5, pr = e & 31;
-            const v2d kv = *(const v2d *)(d.Kn + (size_t)(DT * I + 2 * pr) + (size_t)(k0 + k) * ld);
-            const v2d wv = *(const v2d *)(d.HPt + (size_t)(DT * J + 2 * pr) + (size_t)(k0 + k) * ld);
-            *(v2d *)(sK + k * 64 + 2 * pr) = kv;
-            *(v2d *)(sW + k * 64 + 2 * pr) = wv;
+    auto tile_IJ = [&](int tile, int &I, int &J) { J = tile / T; I = tile - J * T; };
+    auto load_panels = [&](int item) {
+        if (d.dbg & 8) return;                 // ablation hook: skip the panel reads
+        int I, J;
+        tile_IJ(t_begin + item / nchunk, I, J);
+        const int k0 = FAST ? 0 : (item % nchunk) * DKC;
+        const int kmax = FAST ? DKC : ((m_pad - k0 < DKC) ? (m_pad - k0) : DKC);
+        const double *kp = Kn + (size_t)(DT * I + 2 * (tid & 31)) + (size_t)(k0 + (tid >> 5)) * ld;
+        const double *wp = HPt + (size_t)(DT * J + 2 * (tid & 31)) + (size_t)(k0 + (tid >> 5)) * ld;
+#pragma unroll
+        for (int q = 0; q < DD_STG; ++q) {
+            if (FAST || 8 * q + (tid >> 5) < kmax) {
+                stgK[q] = *(const v2d *)(kp + (size_t)(8 * q) * ld);
+                stgW[q] = *(const v2d *)(wp + (size_t)(8 * q) * ld);
+            }
         }
-        __syncthreads();
-        for (int kk = 0; kk < kmax / 4; ++kk) {
-            const int k = 4 * kk + kq;
-            const v2d a2 = *(const v2d *)(sW + k * 64 + 32 * wj + 2 * idx);   // A[j][k] = HP(k,j)
-            const v2d b2 = *(const v2d *)(sK + k * 64 + 32 * wi + 2 * idx);   // B[k][i] = Kn(i,k)
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.y, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.y, acc[1][1], 0, 0, 0);
+    };
+    auto write_panels = [&](int item, int buf) {
+        const int k0 = FAST ? 0 : (item % nchunk) * DKC;
+        const int kmax = FAST ? DKC : ((m_pad - k0 < DKC) ? (m_pad - k0) : DKC);
+        double *sK = dd_smem + (size_t)(buf * DD_NBUF / 2) * 2 * DKC * 64 + (tid >> 5) * 64 + 2 * (tid & 31);
+        double *sW = sK + DKC * 64;
+#pragma unroll
+        for (int q = 0; q < DD_STG; ++q) {
+            if (FAST || 8 * q + (tid >> 5) < kmax) {
+                *(v2d *)(sK + 8 * q * 64) = stgK[q];
+                *(v2d *)(sW + 8 * q * 64) = stgW[q];
+            }
+        }
+    };
+    auto p_ptr = [&](int tile) -> double * {
+        int I, J;
+        tile_IJ(tile, I, J);
+        return P + (size_t)(DT * I + 32 * wi + 2 * idx) + (size_t)(DT * J + 32 * wj + 2 * kq) * ld;
+    };
+    auto load_p = [&](int tile) {
+        if (d.dbg & 2) {                       // ablation hook: skip the P reads
+            for (int q = 0; q < 8; ++q) { pnext[q].x = 1e-3 * tile; pnext[q].y = 2e-3; }
+            return;
+        }
+        const double *Pw = p_ptr(tile);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                pnext[mt * 4 + r] = *(const v2d *)(Pw + (size_t)(8 * r + mt) * ld);
+    };
+    auto acc_from_pnext = [&]() {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[mt][0][r] = pnext[mt * 4 + r].x;
+                acc[mt][1][r] = pnext[mt * 4 + r].y;
+            }
+    };
+    auto mfma_chunk = [&](int item) {
+        const int k0 = FAST ? 0 : (item % nchunk) * DKC;
+        const int kmax = FAST ? DKC : ((m_pad - k0 < DKC) ? (m_pad - k0) : DKC);
+        const double *sK = dd_smem + (size_t)((item & 1) * DD_NBUF / 2) * 2 * DKC * 64, *sW = sK + DKC * 64;
+        const double *aW = sW + 32 * wj + 2 * idx + kq * 64;        // A[j][k] = HP(k,j)
+        const double *bK = sK + 32 * wi + 2 * idx + kq * 64;        // B[k][i] = Kn(i,k)
+        if (d.dbg & 4) return;                 // ablation hook: skip the MFMA loop
+        if (FAST) {
+            // fully unrolled, operands of k-step kk+1 are read from LDS before the MFMAs of step kk issue
+            v2d a2 = *(const v2d *)(aW), b2 = *(const v2d *)(bK);
+#pragma unroll
+            for (int kk = 0; kk < DKC / 4; ++kk) {
+                v2d a2n = a2, b2n = b2;
+                if (kk + 1 < DKC / 4) {
+                    a2n = *(const v2d *)(aW + (kk + 1) * 256);
+                    b2n = *(const v2d *)(bK + (kk + 1) * 256);
+                }
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.x, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.y, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.x, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.y, acc[1][1], 0, 0, 0);
+                a2 = a2n; b2 = b2n;
+            }
+        } else {
+            for (int kk = 0; kk < kmax / 4; ++kk) {
+                const v2d a2 = *(const v2d *)(aW + kk * 256);
+                const v2d b2 = *(const v2d *)(bK + kk * 256);
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.x, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.y, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.x, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.y, acc[1][1], 0, 0, 0);
+            }
+        }
+    };
+    auto store_tile = [&](int tile) {
+        if (d.dbg & 1) return;                 // ablation hook (rekf_debug_time_kernel): skip the write-back
+        double *Pw = p_ptr(tile);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v2d v;
+                v.x = acc[mt][0][r];
+                v.y = acc[mt][1][r];
+                *(v2d *)(Pw + (size_t)(8 * r + mt) * ld) = v;
+            }
+    };
+
+    // prologue: item 0
+    load_panels(0);
+    load_p(t_begin);
+    write_panels(0, 0);
+    acc_from_pnext();
+    dd_lds_barrier();
+
+    if (FAST) {
+#ifdef REKF_DEBUG_TIMING
+        long long tq[24]; int nq = 0;
+        const bool rec = blockIdx.x == 0 && tid == 0;
+#define DMARK() do { if (rec && nq < 24) tq[nq++] = clock64(); } while (0)
+#else
+#define DMARK()
+#endif
+        DMARK();
+        for (int item = 0; item < nitems - 1; ++item) {
+            const int tile = t_begin + item;
+            load_panels(item + 1);            // (A) next tile's operands go in flight
+            load_p(tile + 1);
+            DMARK();
+            mfma_chunk(item);                 // (B) 64 MFMAs per wave on the current LDS buffer
+            DMARK();
+            store_tile(tile);                 // (C) drains under the next tile
+            DMARK();
+            if (DD_NBUF == 1) dd_lds_barrier();       // single LDS buffer: everyone is done reading it
+            write_panels(item + 1, (item + 1) & 1);   // (D) staged panels -> LDS
+            DMARK();
+            acc_from_pnext();
+            dd_lds_barrier();
+            DMARK();
+        }
+#ifdef REKF_DEBUG_TIMING
+        if (rec) for (int i = 1; i < nq; ++i) const_cast<RekfCtl *>(d.ctl)->dbg[8 + i - 1] = tq[i] - tq[0];
+#endif
+        mfma_chunk(nitems - 1);
+        store_tile(t_begin + nitems - 1);
+    } else {
+        for (int item = 0; item < nitems; ++item) {
+            const int tile = t_begin + item / nchunk;
+            const int chunk = item % nchunk;
+            const bool has_next = item + 1 < nitems;
+            const bool next_new_tile = has_next && (chunk == nchunk - 1);
+            if (has_next) load_panels(item + 1);
+            if (next_new_tile) load_p(tile + 1);
+            mfma_chunk(item);
+            if (chunk == nchunk - 1) store_tile(tile);
+            if (has_next) {
+                if (DD_NBUF == 1) dd_lds_barrier();
+                write_panels(item + 1, (item + 1) & 1);
+                if (next_new_tile) acc_from_pnext();
+                dd_lds_barrier();
+            }
         }
     }
+}
 
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = jb + 2 * (kq + 4 * r) + mt;
-            v2d v;
-            v.x = acc[mt][0][r];
-            v.y = acc[mt][1][r];
-            *(v2d *)(Pw + (size_t)j * ld) = v;
-        }
+__global__ __launch_bounds__(256, 2) void k_downdate(RekfDev d)
+{
+    extern __shared__ __attribute__((aligned(16))) double dd_smem[];   // [2 buffers][Kn | HPt][DKC*64]
+    const RekfCtl *ctl = d.ctl;
+    const int m_pad = ctl->m_pad;
+    if (ctl->m == 0) return;
+    const int n = ctl->n;
+    if (m_pad == DKC) downdate_body<true>(d, dd_smem, n, m_pad);
+    else downdate_body<false>(d, dd_smem, n, m_pad);
 }
 
 // ----------------------------------------------------------------------------
@@ -877,8 +1029,23 @@ void rekf_launch_gain(const RekfDev &d, int n_ub, hipStream_t s)
 }
 void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s)
 {
+    // persistent: one workgroup per CU (128 KiB of LDS each), never more workgroups than tiles
+    static int n_cu = 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+        (void)hipFuncSetAttribute((const void *)k_downdate, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  DD_NBUF * 2 * DKC * 64 * (int)sizeof(double));
+        attr_set = true;
+    }
     const int T = (n_ub + DT - 1) / DT;
-    hipLaunchKernelGGL(k_downdate, dim3(T, T), dim3(256), 0, s, d);
+    const int slots = n_cu * DD_WG_PER_CU;
+    const int grid = (T * T < slots) ? T * T : slots;
+    hipLaunchKernelGGL(k_downdate, dim3(grid), dim3(256), DD_NBUF * 2 * DKC * 64 * sizeof(double), s, d);
 }
 void rekf_launch_augment(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s)
 {

@@ -441,13 +441,48 @@ int rekf_profile_reset(rekf_t *h)
 
 void *rekf_stream(rekf_t *h) { return h ? (void *)h->stream : nullptr; }
 
+/* measurement hook: launch ONE kernel of the chain `reps` times back to back on the handle's
+ * stream (operating on whatever the last observation left in the scratch buffers) and return the
+ * average device time per launch in microseconds (hipEvents).  The state is NOT meaningful
+ * afterwards (P -= K HP applied repeatedly): callers snapshot/restore with get/set_state. */
+int rekf_debug_time_kernel(rekf_t *h, int kernel, int reps, int ablate, double *avg_us)
+{
+    if (!h || !avg_us || reps < 1) return REKF_ERR_INVALID;
+    RekfDev dev = h->dev;
+    dev.dbg = ablate;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipEvent_t a, b;
+    HIP_TRY(h, hipEventCreate(&a));
+    HIP_TRY(h, hipEventCreate(&b));
+    const int n_ub = h->n_ub;
+    auto launch = [&]() {
+        switch (kernel) {
+        case REKF_K_GATHER: rekf_launch_gather(dev, n_ub, h->stream); break;
+        case REKF_K_SOLVE: rekf_launch_solve(dev, h->stream); break;
+        case REKF_K_GAIN: rekf_launch_gain(dev, n_ub, h->stream); break;
+        case REKF_K_DOWNDATE: rekf_launch_downdate(dev, n_ub, h->stream); break;
+        default: break;
+        }
+    };
+    for (int i = 0; i < 3; ++i) launch();
+    HIP_TRY(h, hipEventRecord(a, h->stream));
+    for (int i = 0; i < reps; ++i) launch();
+    HIP_TRY(h, hipEventRecord(b, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIP_TRY(h, hipEventElapsedTime(&ms, a, b));
+    *avg_us = 1e3 * (double)ms / reps;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return REKF_OK;
+}
+
 /* debug builds only: the 8 scratch counters kernels may fill (see REKF_DEBUG_TIMING) */
-int rekf_debug_counters(rekf_t *h, long long out8[8])
+int rekf_debug_counters(rekf_t *h, long long out8[32])
 {
     if (!h || !out8) return REKF_ERR_INVALID;
     int rc = pull_ctl(h);
     if (rc != REKF_OK) return rc;
-    for (int i = 0; i < 8; ++i) out8[i] = h->ctl_staging->dbg[i];
+    for (int i = 0; i < 32; ++i) out8[i] = h->ctl_staging->dbg[i];
     return REKF_OK;
 }
 
