@@ -55,6 +55,19 @@ def lib():
     L.oekf_set_state.argtypes = [C.c_void_p, C.c_double, C.c_int, _f64p, _f64p, _f64p]
     L.oekf_get_vt.argtypes = [C.c_void_p, _f64p]
     L.oekf_get_last_match.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    # ---- 2D detector oracle (detect2d_oracle.c)
+    L.od2_create.restype = C.c_void_p
+    L.od2_create.argtypes = [C.c_double, C.c_double, C.c_double, C.c_float, C.c_float, _f64p]
+    L.od2_destroy.argtypes = [C.c_void_p]
+    L.od2_handle_odometry.argtypes = [C.c_void_p] + [C.c_double] * 8
+    L.od2_handle_scan.restype = C.c_int
+    L.od2_handle_scan.argtypes = [C.c_void_p, C.c_double, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                  C.c_float, _f32p, _f32p, C.c_int, _f32p, C.c_int, C.POINTER(C.c_double)]
+    L.od2_get_returns.restype = C.c_int
+    L.od2_get_returns.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    if hasattr(L, "od3_handle_cloud"):
+        L.od3_handle_cloud.restype = C.c_int
+        L.od3_handle_cloud.argtypes = [C.c_double, _f64p, _f32p, C.c_int, _f32p, C.c_int]
     _lib = L
     return L
 
@@ -159,3 +172,47 @@ class OracleEKF:
                                     C.byref(nm), mp.ctypes.data_as(C.c_void_p),
                                     C.byref(nn), nw.ctypes.data_as(C.c_void_p))
         return sp[: ns.value].copy(), mp[: nm.value].copy(), nw[: nn.value].copy()
+
+
+class OracleDetect2D:
+    """Python face of oracle/detect2d_oracle.c (LaserReflectorDetect + PoseExtrapolator)."""
+
+    def __init__(self, intensity_min=160.0, reflector_min_length=0.18, reflector_length_error=0.06,
+                 range_min=0.3, range_max=10.0, sensor_to_base_link=(0.0, 0.0, 0.0)):
+        self._L = lib()
+        s2b = np.ascontiguousarray(sensor_to_base_link, dtype=np.float64)
+        self._h = self._L.od2_create(intensity_min, reflector_min_length, reflector_length_error,
+                                     range_min, range_max, s2b)
+
+    def close(self):
+        if self._h:
+            self._L.od2_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def handle_odometry(self, t, px, py, qz, qw, vx, vy, wz):
+        self._L.od2_handle_odometry(self._h, t, px, py, qz, qw, vx, vy, wz)
+
+    def handle_scan(self, scan, max_centers=256):
+        """scan: object with the LaserScan fields.  Returns (obs_time, centers[K,2]); raises on a bad scan."""
+        r = np.ascontiguousarray(scan.ranges, dtype=np.float32)
+        it = np.ascontiguousarray(scan.intensities, dtype=np.float32)
+        out = np.zeros((max_centers, 2), np.float32)
+        t = C.c_double()
+        k = self._L.od2_handle_scan(self._h, float(scan.stamp), scan.angle_min, scan.angle_max, scan.angle_increment,
+                                    scan.scan_time, scan.range_min, scan.range_max, r, it, r.shape[0],
+                                    out.reshape(-1), max_centers, C.byref(t))
+        if k < 0:
+            raise ValueError(f"oracle detect2d rc={k}")
+        return t.value, out[:k].copy()
+
+    def returns(self):
+        n = self._L.od2_get_returns(self._h, None, 0)
+        out = np.zeros((max(n, 1), 2), np.float32)
+        self._L.od2_get_returns(self._h, out.ctypes.data_as(C.c_void_p), n)
+        return out[:n].copy()

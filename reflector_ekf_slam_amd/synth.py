@@ -223,3 +223,47 @@ def steady_state_scans(session: Session, n: int, seed_offset: int = 1000) -> lis
         meas = np.stack([rx, ry], -1) + rng.normal(0, cfg.obs_noise, size=(rx.size, 2))
         out.append((t0 + (k + 1) / cfg.scan_hz, meas.astype(np.float32)))
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# raw sensor synthesis for the detector paths ("2D-detect variant")
+# ---------------------------------------------------------------------------------------------
+def make_laser_scan(landmarks: np.ndarray, pose, stamp: float, rng: np.random.Generator, n_beams: int = 3600,
+                    sensor_xy=(0.13686, 0.0), reflector_width: float = 0.18, scan_time: float = 0.1,
+                    room_half: float = 60.0, range_noise: float = 0.005, max_range: float = 30.0):
+    """One 360-degree LaserScan taken at ``pose`` (x, y, theta of base_link): reflectors are flat
+    plates of ``reflector_width`` facing the sensor (intensity 200), everything else is a distant
+    wall (intensity 50).  Returns a dict with the sensor_msgs::LaserScan fields (float32 arrays).
+    Sensor mounted at ``sensor_xy`` in base_link (launch/slam.launch:27), yaw 0."""
+    x, y, th = pose
+    c, s = math.cos(th), math.sin(th)
+    sx = x + c * sensor_xy[0] - s * sensor_xy[1]
+    sy = y + s * sensor_xy[0] + c * sensor_xy[1]
+    inc = np.float32(2.0 * math.pi / n_beams)
+    angle_min = np.float32(-math.pi)
+    ang = angle_min + inc * np.arange(n_beams, dtype=np.float64)      # close enough for synthesis
+    ranges = np.full(n_beams, np.float32(max_range * 0.8), dtype=np.float64)
+    ranges += rng.normal(0, 0.05, size=n_beams)
+    inten = np.full(n_beams, 50.0) + rng.normal(0, 5.0, size=n_beams)
+    rel = landmarks - np.array([sx, sy])
+    dist = np.hypot(rel[:, 0], rel[:, 1])
+    bearing = np.arctan2(rel[:, 1], rel[:, 0]) - th
+    bearing = np.arctan2(np.sin(bearing), np.cos(bearing))
+    order = np.argsort(-dist)                        # nearer reflectors overwrite farther ones
+    for j in order:
+        if dist[j] > max_range * 0.7 or dist[j] < 0.2:
+            continue
+        half = math.atan2(reflector_width / 2.0, dist[j])
+        lo = int(math.ceil((bearing[j] - half - float(angle_min)) / float(inc)))
+        hi = int(math.floor((bearing[j] + half - float(angle_min)) / float(inc)))
+        for b in range(lo, hi + 1):
+            bb = b % n_beams
+            delta = ang[bb] - bearing[j]
+            delta = math.atan2(math.sin(delta), math.cos(delta))
+            r = dist[j] / max(math.cos(delta), 1e-3)
+            if r < ranges[bb]:
+                ranges[bb] = r + rng.normal(0, range_noise)
+                inten[bb] = 200.0 + rng.normal(0, 5.0)
+    return dict(stamp=float(stamp), angle_min=float(angle_min), angle_max=float(angle_min + inc * (n_beams - 1)),
+                angle_increment=float(inc), scan_time=float(scan_time), range_min=0.05, range_max=float(max_range),
+                ranges=ranges.astype(np.float32), intensities=inten.astype(np.float32))

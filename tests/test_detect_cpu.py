@@ -1,0 +1,106 @@
+"""CPU suite: pins the 2D detector oracle (oracle/detect2d_oracle.c) with hand-checkable scans.
+The reference (laser_reflector_detect.cc) has no tests of its own -- parity unpinned -- so each
+case below encodes one documented behaviour of its state machine."""
+import math
+
+import numpy as np
+import pytest
+
+from tests.detect_cases import S2B, beams_for_width, odom_stream, plate_scan, world_scan
+
+
+def _oracle(**kw):
+    from oracle.binding import OracleDetect2D
+    return OracleDetect2D(sensor_to_base_link=kw.pop("s2b", (0.0, 0.0, 0.0)), **kw)
+
+
+def test_single_plate_centre_and_width_gate(oracle_lib):
+    n = 720
+    rng_ = 5.0
+    nb = beams_for_width(0.18, rng_, n)                       # ~0.18 m wide: accepted
+    sc = plate_scan(n, [(100, nb, rng_, 200.0), (300, 3 * nb, rng_, 200.0)])   # second one ~0.57 m: rejected
+    t, c = _oracle().handle_scan(sc)
+    assert t == sc.stamp and c.shape == (1, 2)
+    inc = 2 * math.pi / n
+    mid = -math.pi + inc * (100 + (nb - 1) / 2.0)
+    # centroid of points on an arc of radius 5 around the mid bearing
+    assert abs(math.atan2(c[0, 1], c[0, 0]) - mid) < 1e-4
+    assert abs(np.hypot(*c[0]) - rng_) < 2e-3
+
+
+def test_gap_is_bridged_only_under_the_three_conditions(oracle_lib):
+    n, rng_ = 720, 5.0
+    nb = beams_for_width(0.18, rng_, n)                       # 5 beams
+    base = plate_scan(n, [(100, nb, rng_, 200.0)])
+    one = _oracle().handle_scan(base)[1]
+    # a dim beam in the middle (gap of 1): still ONE reflector, the dim beam's point is included (:111-138)
+    sc = plate_scan(n, [(100, nb, rng_, 200.0)])
+    sc.intensities[102] = 50.0
+    c = _oracle().handle_scan(sc)[1]
+    assert c.shape == (1, 2) and np.abs(c - one).max() < 1e-6
+    # the dim beam is at a very different range: no bridge -> run splits into 2+2 beams, both too short
+    sc.ranges[102] = 9.0
+    sc.ranges[103] = 5.4                                     # |r_i - r_last| = 0.4 >= 0.3
+    assert _oracle().handle_scan(sc)[1].shape[0] == 0
+    # an inf gap beam is skipped, not averaged in (:120-121)
+    sc2 = plate_scan(n, [(100, nb, rng_, 200.0)])
+    sc2.intensities[102] = 50.0
+    sc2.ranges[102] = np.inf
+    c2 = _oracle().handle_scan(sc2)[1]
+    assert c2.shape == (1, 2) and np.isfinite(c2).all()
+
+
+def test_wraparound_union_of_first_and_last_run(oracle_lib):
+    n, rng_ = 720, 5.0
+    nb = beams_for_width(0.18, rng_, n)                       # 5 beams
+    # 2 beams at the end + 3 at the start of the scan: one plate across the +-pi seam (:188-195)
+    sc = plate_scan(n, [(n - 2, 2, rng_, 200.0), (0, 3, rng_, 200.0), (200, nb, rng_, 200.0)])
+    c = _oracle().handle_scan(sc)[1]
+    assert c.shape == (2, 2)
+    # cluster 0 is the seam plate: its centre sits at bearing ~ -pi/+pi
+    assert abs(abs(math.atan2(c[0, 1], c[0, 0])) - math.pi) < 0.02
+    assert abs(np.hypot(*c[0]) - rng_) < 5e-3
+
+
+def test_circle_scan_first_run_from_beam0_is_accepted_unconditionally(oracle_lib):
+    n, rng_ = 720, 5.0
+    sc = plate_scan(n, [(0, 2, rng_, 200.0), (200, beams_for_width(0.18, rng_, n), rng_, 200.0)])
+    c = _oracle().handle_scan(sc)[1]
+    # the 2-beam run starting at beam 0 (0.04 m wide) passes only through the circle-scan clause (:151)
+    assert c.shape == (2, 2)
+
+
+def test_no_bright_beam_is_an_empty_observation_and_bad_scans_are_errors(oracle_lib):
+    sc = plate_scan(360, [])
+    t, c = _oracle().handle_scan(sc)
+    assert c.shape == (0, 2)                                  # Q13: defined, the reference has UB here
+    sc.range_max = sc.range_min
+    with pytest.raises(ValueError):
+        _oracle().handle_scan(sc)                             # reference: LOG(ERROR) + exit(-1), :27-32
+
+
+def test_deskew_moves_points_and_keeps_the_last_point_fixed(oracle_lib):
+    sc, _ = world_scan()
+    still = _oracle(s2b=S2B)
+    t0, c0 = still.handle_scan(sc)
+    r0 = still.returns()
+    mov = _oracle(s2b=S2B)
+    for o in odom_stream(sc.stamp - 0.3, sc.stamp + 0.05):
+        mov.handle_odometry(*o)
+    t1, c1 = mov.handle_scan(sc)
+    r1 = mov.returns()
+    assert c0.shape == c1.shape and c0.shape[0] >= 16
+    assert np.abs(r1[-1] - r0[-1]).max() < 1e-5               # the scan-end frame: last point unchanged
+    assert 0.01 < np.abs(r1[0] - r0[0]).max() < 2.0           # first point (a 24 m wall hit) moved by ~v*dt + r*w*dt
+    assert np.abs(c1 - c0).max() > 1e-3
+
+
+def test_world_scan_detects_the_true_reflectors(oracle_lib):
+    sc, lms = world_scan()
+    c = _oracle(s2b=S2B).handle_scan(sc)[1]
+    pose = (16.0, 17.7, 0.6)
+    rel = lms - np.array(pose[:2])
+    cc, ss = math.cos(pose[2]), math.sin(pose[2])
+    gt = np.stack([cc * rel[:, 0] + ss * rel[:, 1], -ss * rel[:, 0] + cc * rel[:, 1]], -1)
+    d = np.linalg.norm(gt[None] - c[:, None], axis=-1).min(1)
+    assert c.shape[0] >= 20 and d.max() < 0.02

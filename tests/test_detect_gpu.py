@@ -1,0 +1,146 @@
+"""GPU suite for the 2D/3D reflector detectors: the HIP path through the C ABI (librdet.so)
+against the CPU oracle on the same scans.  Run membership / reflector count must be IDENTICAL;
+centres and de-skewed returns agree to float32 round-off (device cosf/sinf of per-point angles
+differ from glibc's in the last bit): tolerance 1e-5 m, the north-star bar."""
+import math
+
+import numpy as np
+import pytest
+
+from tests.detect_cases import S2B, beams_for_width, odom_stream, plate_scan, world_scan
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _pair(s2b=(0.0, 0.0, 0.0), **kw):
+    from oracle.binding import OracleDetect2D
+    from reflector_ekf_slam_amd.detect import LaserReflectorDetect, ReflectorDetectOptions
+    g = LaserReflectorDetect(ReflectorDetectOptions(**kw), max_beams=8192, sensor_to_base_link=s2b)
+    o = OracleDetect2D(sensor_to_base_link=s2b, **kw)
+    return g, o
+
+
+def _scan_msg(sc):
+    from reflector_ekf_slam_amd.detect import LaserScan
+    return LaserScan(sc.stamp, sc.angle_min, sc.angle_max, sc.angle_increment, sc.scan_time, sc.range_min,
+                     sc.range_max, sc.ranges, sc.intensities)
+
+
+def _feed_odom(g, o, stream):
+    from reflector_ekf_slam_amd import OdometryData
+    for (t, px, py, qz, qw, vx, vy, wz) in stream:
+        g.HandleOdometryData(OdometryData(t, (vx, vy, 0.0), (0.0, 0.0, wz), (px, py, 0.0), (qw, 0.0, 0.0, qz)))
+        o.handle_odometry(t, px, py, qz, qw, vx, vy, wz)
+
+
+def _compare(g, o, sc, check_returns=True):
+    obs = g.HandleLaserScan(_scan_msg(sc))
+    t, c = o.handle_scan(sc)
+    assert obs.time_ == t
+    assert obs.cloud_.shape == c.shape, (obs.cloud_.shape, c.shape)
+    if c.size:
+        assert np.abs(obs.cloud_ - c).max() < TOL
+    if check_returns:
+        rg, ro = g.GetRangeData().returns, o.returns()
+        assert rg.shape == ro.shape
+        if ro.size:
+            assert np.abs(rg - ro).max() < 2e-5 * max(1.0, float(np.abs(ro).max()))
+    return obs
+
+
+def test_world_scans_static_and_moving(oracle_lib):
+    for seed, pose in ((1, (16.0, 17.7, 0.6)), (2, (8.0, 30.0, -2.0)), (3, (25.0, 9.0, 3.0))):
+        sc, _ = world_scan(seed=seed, pose=pose)
+        g, o = _pair(S2B)
+        obs = _compare(g, o, sc)
+        assert obs.cloud_.shape[0] >= 15
+        g2, o2 = _pair(S2B)
+        _feed_odom(g2, o2, odom_stream(sc.stamp - 0.3, sc.stamp + 0.05))
+        _compare(g2, o2, sc)
+        # a second scan through the same handles (angle table cached, odometry trimmed)
+        sc.stamp += 0.1
+        _feed_odom(g2, o2, odom_stream(sc.stamp - 0.02, sc.stamp + 0.05, v=0.8, w=-0.2))
+        _compare(g2, o2, sc)
+
+
+def test_state_machine_cases_match(oracle_lib):
+    n, rng_ = 720, 5.0
+    nb = beams_for_width(0.18, rng_, n)
+    cases = []
+    cases.append(plate_scan(n, [(100, nb, rng_, 200.0), (300, 3 * nb, rng_, 200.0)]))         # width gate
+    sc = plate_scan(n, [(100, nb, rng_, 200.0)]); sc.intensities[102] = 50.0; cases.append(sc)   # bridged gap
+    sc = plate_scan(n, [(100, nb, rng_, 200.0)]); sc.intensities[102] = 50.0; sc.ranges[102] = 9.0
+    sc.ranges[103] = 5.4; cases.append(sc)                                                       # gap not bridged
+    sc = plate_scan(n, [(100, nb, rng_, 200.0)]); sc.intensities[102] = 50.0; sc.ranges[102] = np.inf
+    cases.append(sc)                                                                             # inf gap beam
+    cases.append(plate_scan(n, [(n - 2, 2, rng_, 200.0), (0, 3, rng_, 200.0), (200, nb, rng_, 200.0)]))   # seam union
+    cases.append(plate_scan(n, [(0, 2, rng_, 200.0), (200, nb, rng_, 200.0)]))                   # circle clause
+    cases.append(plate_scan(n, [(n - nb, nb, rng_, 200.0)]))                                     # open last run only
+    cases.append(plate_scan(n, [(50, nb, rng_, 200.0), (n - nb, nb, rng_, 200.0)]))              # closed + open tail
+    cases.append(plate_scan(360, []))                                                            # nothing bright
+    sc = plate_scan(n, [(100, nb, rng_, 200.0)]); sc.ranges[:50] = 100.0; cases.append(sc)       # beams outside msg range
+    for i, sc in enumerate(cases):
+        g, o = _pair()
+        _compare(g, o, sc)
+
+
+def test_ragged_sizes_and_many_reflectors(oracle_lib):
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 63, 1025, 3601, 8192):
+        rng_ = 4.0
+        nb = max(beams_for_width(0.18, rng_, n), 1)
+        plates = [(int(s), nb, rng_, 200.0) for s in range(5, max(n - nb - 5, 6), max(4 * nb, 8))][:200]
+        sc = plate_scan(n, plates if n > 64 else [])
+        sc.ranges += rng.normal(0, 0.002, size=n).astype(np.float32)
+        g, o = _pair()
+        _compare(g, o, sc)
+
+
+def test_bad_scan_and_capacity_are_error_codes(oracle_lib):
+    from reflector_ekf_slam_amd.detect import LaserReflectorDetect, RdetError, ReflectorDetectOptions
+    g = LaserReflectorDetect(ReflectorDetectOptions(), max_beams=256)
+    sc = plate_scan(360, [])
+    with pytest.raises(RdetError) as e:
+        g.HandleLaserScan(_scan_msg(sc))
+    assert e.value.code == -4                                   # more beams than the handle holds
+    sc = plate_scan(128, [])
+    sc.range_max = sc.range_min
+    with pytest.raises(RdetError) as e:
+        g.HandleLaserScan(_scan_msg(sc))
+    assert e.value.code == -3                                   # malformed (reference: exit(-1))
+
+
+def test_detector_feeds_the_filter_end_to_end(oracle_lib):
+    """LaserScan -> HIP detector -> HIP EKF vs LaserScan -> oracle detector -> oracle EKF."""
+    from oracle.binding import OracleEKF
+    from reflector_ekf_slam_amd import EKFOptions, ReflectorEKFSLAM, synth
+    cfg = synth.SessionConfig("e2e", 40, 12, synth.DIFF, seed=31, speed=1.0, row_spacing=6.0)
+    sess = synth.make_session(cfg, max_scans=60)
+    rng = np.random.Generator(np.random.PCG64(77))
+    g, o = _pair(S2B)
+    opt = EKFOptions(init_time=0.0, init_pose=tuple(sess.init_pose), odom_model=cfg.odom_model,
+                     linear_velocity_cov=cfg.sigma_v ** 2, angular_velocity_cov=cfg.sigma_w ** 2,
+                     observation_cov=cfg.sigma_obs ** 2)
+    fg = ReflectorEKFSLAM(opt, max_landmarks=64)
+    fo = OracleEKF(cfg.odom_model, 0.0, sess.init_pose, opt.linear_velocity_cov, opt.angular_velocity_cov,
+                   opt.observation_cov)
+    first = True
+    for e in range(sess.n_events):
+        t = sess.ev_time[e]
+        if sess.ev_type[e] == synth.EV_ODOM:
+            fg.handle_odometry(t, *sess.odom[e]); fo.handle_odometry(t, *sess.odom[e])
+            x, y, th = sess.true_pose[e]
+            _feed_odom(g, o, [(t, x, y, math.sin(th / 2), math.cos(th / 2), sess.odom[e][0], 0.0, sess.odom[e][2])])
+            continue
+        sc = __import__("types").SimpleNamespace(**synth.make_laser_scan(sess.landmarks, sess.true_pose[e], t, rng,
+                                                                         n_beams=2880))
+        og = g.HandleLaserScan(_scan_msg(sc))
+        to, co = o.handle_scan(sc)
+        assert og.cloud_.shape == co.shape and np.abs(og.cloud_ - co).max() < TOL
+        if first:
+            first = False
+            continue
+        fg.handle_observation(og.time_, og.cloud_[:64]); fo.handle_observation(to, co[:64])
+    assert fg.n == fo.n and fg.n > 3 + 2 * 10
+    assert np.abs(fg.mu() - fo.mu()).max() < 1e-4          # detector float32 round-off propagates (1e-6 m inputs)
