@@ -65,9 +65,9 @@ def lib():
                                   C.c_float, _f32p, _f32p, C.c_int, _f32p, C.c_int, C.POINTER(C.c_double)]
     L.od2_get_returns.restype = C.c_int
     L.od2_get_returns.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-    if hasattr(L, "od3_handle_cloud"):
-        L.od3_handle_cloud.restype = C.c_int
-        L.od3_handle_cloud.argtypes = [C.c_double, _f64p, _f32p, C.c_int, _f32p, C.c_int]
+    L.od3_handle_cloud_ex.restype = C.c_int
+    L.od3_handle_cloud_ex.argtypes = [C.c_double, _f64p, _f32p, C.c_int, _f32p, C.c_int,
+                                      C.POINTER(C.c_int), C.POINTER(C.c_int)]
     _lib = L
     return L
 
@@ -216,3 +216,16 @@ class OracleDetect2D:
         out = np.zeros((max(n, 1), 2), np.float32)
         self._L.od2_get_returns(self._h, out.ctypes.data_as(C.c_void_p), n)
         return out[:n].copy()
+
+
+def oracle_detect3d(xyzi, intensity_min=160.0, sensor_to_base_link=(0.0, 0.0, 0.0), max_centers=256):
+    """oracle/detect3d_oracle.c: returns (centers[K,2], n_after_intensity, n_after_sor)."""
+    L = lib()
+    pts = np.ascontiguousarray(xyzi, dtype=np.float32).reshape(-1, 4)
+    out = np.zeros((max_centers, 2), np.float32)
+    m1, m2 = C.c_int(), C.c_int()
+    k = L.od3_handle_cloud_ex(float(intensity_min), np.ascontiguousarray(sensor_to_base_link, dtype=np.float64),
+                              pts.reshape(-1), pts.shape[0], out.reshape(-1), max_centers, C.byref(m1), C.byref(m2))
+    if k < 0:
+        raise ValueError(f"oracle detect3d rc={k}")
+    return out[:k].copy(), m1.value, m2.value

@@ -267,3 +267,53 @@ def make_laser_scan(landmarks: np.ndarray, pose, stamp: float, rng: np.random.Ge
     return dict(stamp=float(stamp), angle_min=float(angle_min), angle_max=float(angle_min + inc * (n_beams - 1)),
                 angle_increment=float(inc), scan_time=float(scan_time), range_min=0.05, range_max=float(max_range),
                 ranges=ranges.astype(np.float32), intensities=inten.astype(np.float32))
+
+
+def make_point_cloud(landmarks: np.ndarray, pose, rng: np.random.Generator, rings: int = 16, n_az: int = 1800,
+                     sensor_height: float = 0.7, post_radius: float = 0.09, post_z=(0.2, 1.2),
+                     max_range: float = 25.0, n_outliers: int = 40):
+    """One XYZI sweep of a `rings` x `n_az` spinning lidar at base_link `pose` (sensor at the base_link
+    origin): reflector posts (vertical strips, intensity 200+-20) and a dim
+    background (ground / far wall, intensity 20+-10), plus `n_outliers` isolated bright points that
+    the statistical outlier removal must reject.  Returns float32 (N, 4) in the sensor frame."""
+    x, y, th = pose
+    rel = landmarks - np.array([x, y])
+    c, s = math.cos(th), math.sin(th)
+    lx = c * rel[:, 0] + s * rel[:, 1]
+    ly = -s * rel[:, 0] + c * rel[:, 1]
+    dist = np.hypot(lx, ly)
+    bearing = np.arctan2(ly, lx)
+    az = -math.pi + 2.0 * math.pi * np.arange(n_az) / n_az
+    elev = np.deg2rad(np.linspace(-15.0, 15.0, rings))
+    near = np.argsort(dist)
+    near = near[(dist[near] < max_range) & (dist[near] > 0.5)]
+    hit_range = np.full(n_az, np.inf)
+    for j in near[::-1]:                                   # nearer posts overwrite farther ones
+        half = math.asin(min(post_radius / dist[j], 1.0))
+        lo = int(math.ceil((bearing[j] - half + math.pi) / (2 * math.pi) * n_az))
+        hi = int(math.floor((bearing[j] + half + math.pi) / (2 * math.pi) * n_az))
+        for b in range(lo, hi + 1):
+            hit_range[b % n_az] = dist[j]
+    pts = []
+    for e in elev:
+        rho = np.where(np.isfinite(hit_range), hit_range, np.nan)
+        zhit = sensor_height + rho * math.tan(e)
+        post = np.isfinite(hit_range) & (zhit >= post_z[0]) & (zhit <= post_z[1])
+        if e < -1e-3:
+            ground = sensor_height / math.tan(-e)
+        else:
+            ground = 40.0
+        rr = np.where(post, hit_range, min(ground, 40.0))
+        rr = rr + rng.normal(0, 0.01, size=n_az)
+        inten = np.where(post, 200.0 + rng.normal(0, 20.0, size=n_az), 20.0 + rng.normal(0, 10.0, size=n_az))
+        px = rr * np.cos(az) * 1.0
+        py = rr * np.sin(az) * 1.0
+        pz = np.where(post, rr * math.tan(e), np.where(e < -1e-3, -sensor_height, rr * math.tan(e)))
+        pts.append(np.stack([px, py, pz, inten], -1))
+    cloud = np.concatenate(pts)
+    if n_outliers > 0:
+        o = np.stack([rng.uniform(-15, 15, n_outliers), rng.uniform(-15, 15, n_outliers),
+                      rng.uniform(-0.5, 2.0, n_outliers), np.full(n_outliers, 220.0)], -1)
+        idx = rng.choice(cloud.shape[0], n_outliers, replace=False)
+        cloud[idx] = o
+    return cloud.astype(np.float32)

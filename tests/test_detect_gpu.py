@@ -144,3 +144,50 @@ def test_detector_feeds_the_filter_end_to_end(oracle_lib):
         fg.handle_observation(og.time_, og.cloud_[:64]); fo.handle_observation(to, co[:64])
     assert fg.n == fo.n and fg.n > 3 + 2 * 10
     assert np.abs(fg.mu() - fo.mu()).max() < 1e-4          # detector float32 round-off propagates (1e-6 m inputs)
+
+
+# ---------------------------------------------------------------------------- 3D detector
+def _blob(center, n, spread, rng, intensity=200.0):
+    p = rng.normal(0, spread, size=(n, 3)) + np.asarray(center)
+    return np.concatenate([p, np.full((n, 1), intensity)], -1)
+
+
+def _compare3d(cloud, s2b=(0.0, 0.0, 0.0)):
+    from oracle.binding import oracle_detect3d
+    from reflector_ekf_slam_amd.detect import PointCloudOptions, PointCloudReflectorDetect
+    g = PointCloudReflectorDetect(PointCloudOptions(), max_points=65536, sensor_to_base_link=s2b)
+    obs = g.HandlePointCloud(3.25, cloud)
+    c, m1, m2 = oracle_detect3d(cloud, sensor_to_base_link=s2b)
+    assert obs.time_ == 3.25
+    assert obs.cloud_.shape == c.shape, (obs.cloud_.shape, c.shape)
+    if c.size:
+        assert np.abs(obs.cloud_ - c).max() < TOL          # identical clusters, identical order
+    return obs
+
+
+def test_detect3d_micro_cases_match(oracle_lib):
+    rng = np.random.default_rng(0)
+    dim = _blob((0, 0, 0), 500, 5.0, rng, intensity=20.0)
+    a = _blob((3.0, 1.0, 0.5), 40, 0.03, rng)
+    b = _blob((-2.0, 4.0, 0.7), 25, 0.03, rng)
+    far = _blob((8.0, -6.0, 0.3), 3, 0.01, rng)
+    big = _blob((1.0, 1.0, 0.5), 300, 0.055, rng)       # ~220 points survive SOR: above MaxClusterSize
+    assert _compare3d(np.concatenate([dim, a, b, far]).astype(np.float32)).cloud_.shape == (2, 2)
+    _compare3d(np.concatenate([dim, b]).astype(np.float32))                      # < 31 bright points
+    _compare3d(np.concatenate([big, a]).astype(np.float32))                      # oversize cluster dropped
+    _compare3d(np.concatenate([a, b]).astype(np.float32), s2b=(1.0, -2.0, math.pi / 2))
+    _compare3d(np.zeros((0, 4), np.float32))
+    _compare3d(dim.astype(np.float32))                                           # nothing bright at all
+    # a long chain (diameter ~ 100 hops of 0.15 m): label propagation must still converge
+    chain = np.stack([0.15 * np.arange(120), np.zeros(120), np.zeros(120), np.full(120, 200.0)], -1)
+    _compare3d(chain.astype(np.float32))
+
+
+def test_detect3d_world_clouds_match(oracle_lib):
+    from reflector_ekf_slam_amd import synth
+    for seed, pose in ((3, (34.4, 34.0, 1.15)), (4, (10.0, 50.0, -0.4))):
+        rng = np.random.Generator(np.random.PCG64(seed))
+        lms = synth.make_world(synth.C4, rng)
+        cloud = synth.make_point_cloud(lms, pose, rng)
+        obs = _compare3d(cloud)
+        assert obs.cloud_.shape[0] >= 40
