@@ -2,7 +2,7 @@
 //
 // Replaces reflector_detect::PointCloudReflectorDetect::HandlePointCloud (reference
 // src/reflector_detect/point_cloud/point_cloud_reflector_detect.cc:9-106), whose arithmetic
-// is PCL 1.7's (un-vendored; semantics restated in oracle/detect3d_oracle.c and DESIGN.md):
+// is PCL 1.7's (un-vendored; the PCL semantics this file implements are spelled out in DESIGN.md section 4):
 //
 //   k3_filter     intensity > threshold, order-preserving compaction            (:31-39)
 //   k3_knn        StatisticalOutlierRemoval part 1: per point the MeanK+1 = 31 smallest float32
