@@ -133,9 +133,12 @@ enum {
     REKF_K_GAIN = 4,      /* K = W S^-1, mu += K dz                  */
     REKF_K_DOWNDATE = 5,  /* P -= K W^T  (the roofline kernel)       */
     REKF_K_AUGMENT = 6,   /* new landmarks                           */
-    REKF_K_COUNT = 7
+    REKF_K_EMPTY = 7,     /* an event pair around nothing: the bracket's own cost, in situ */
+    REKF_K_COUNT = 8
 };
-/* When on, every kernel launch is bracketed by hipEvents on the handle's stream. */
+/* When on, kernel launches are bracketed by hipEvents on the handle's stream: `on` is a bit mask
+ * over the REKF_K_* ids (1 << id); -1 = all.  Brackets perturb the stream (each costs a few
+ * microseconds of command-processor time), so measure one kernel at a time for absolute numbers. */
 int rekf_profile_enable(rekf_t *h, int on);
 /* Sum (microseconds) and count of the recorded launches of kernel k since the
  * last rekf_profile_reset.  Synchronises. */

@@ -41,6 +41,11 @@ struct RekfCtl {
     double hb[REKF_MAX_ROWS][2];  // H(r, hcol..hcol+1)
     double dz[REKF_MAX_ROWS];     // z - zhat
     double qd[REKF_MAX_ROWS];     // diag(Q)
+    // ---- hand-off between the multi-workgroup front kernel and k_record / k_gain ----
+    double pose_pred[5];          // x, y, theta, cos(theta), sin(theta) after Predict (mu[0..2] is committed by k_gain)
+    int pose_pending;
+    int obs_kind[REKF_MAX_OBS_DEV];   // per observation: 0 map match, 1 state match, 2 new
+    int obs_idx[REKF_MAX_OBS_DEV];
     long long dbg[32];            // scratch for in-kernel timing experiments (REKF_DEBUG_TIMING builds)
 };
 
@@ -76,6 +81,7 @@ struct RekfDev {
 
 // launch wrappers (ekf_kernels.hip)
 void rekf_launch_front(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);
+void rekf_launch_front_mb(const RekfDev &d, const RekfFrontArgs &a, int n_ub, hipStream_t s);
 void rekf_launch_gather(const RekfDev &d, int n_ub, hipStream_t s);
 void rekf_launch_solve(const RekfDev &d, hipStream_t s);
 void rekf_launch_gain(const RekfDev &d, int n_ub, hipStream_t s);

@@ -444,6 +444,255 @@ __global__ __launch_bounds__(1024) void k_front(RekfDev d, RekfFrontArgs A)
 }
 
 // ----------------------------------------------------------------------------
+// k_front_mb + k_record: the observation path's front end spread over FRONT_MB workgroups.
+//
+// The single-workgroup k_front is bounded by one CU's VALU and by serial reductions (15 us at
+// L = 1024, K = 32).  Here every workgroup recomputes the (cheap) predicted pose from the OLD
+// mean -- nobody writes mu[0..2] in this kernel: the predicted pose goes to ctl->pose_pred and is
+// committed by k_gain together with the update -- then takes a 1/FRONT_MB slice of the
+// covariance predict and whole observations of ReflectorMatch (all 16 waves sweep disjoint
+// landmark slices, block-wide literal arg-min).  k_record (one wave) then does the ordered
+// compaction and the H rows exactly like the tail of k_front.
+// ----------------------------------------------------------------------------
+#define FRONT_MB 32
+
+struct BlockArgminScratch { double d[16]; int j[16]; double rd; int rj; int cnt[16]; int rcnt; };
+
+// block-wide arg-min with the literal rule (smaller value, then smaller index); all threads get it
+__device__ static void block_argmin(double &v, int &j, BlockArgminScratch &s)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    wave_argmin(v, j);
+    if (lane == 0) { s.d[wave] = v; s.j[wave] = j; }
+    __syncthreads();
+    if (wave == 0) {
+        double x = (lane < 16) ? s.d[lane] : 0.0;
+        int y = (lane < 16) ? s.j[lane] : -1;
+        wave_argmin(x, y);
+        if (lane == 0) { s.rd = x; s.rj = y; }
+    }
+    __syncthreads();
+    v = s.rd; j = s.rj;
+    __syncthreads();
+}
+__device__ static int block_sum(int c, BlockArgminScratch &s)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, WAVE);
+    if (lane == 0) s.cnt[wave] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += s.cnt[w]; s.rcnt = t; }
+    __syncthreads();
+    const int r = s.rcnt;
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
+{
+    __shared__ Motion mo;
+    __shared__ double pose[5];
+    __shared__ BlockArgminScratch sc;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x, nb = gridDim.x;
+    RekfCtl *ctl = d.ctl;
+    double *__restrict__ P = d.P;
+    const double *mu = d.mu;
+    const size_t ld = (size_t)d.ld;
+    const int n = ctl->n;
+    const int L = (n - 3) / 2;
+    const int K = A.K;
+
+    // operands that depend only on the old state go in flight first
+    const int idx0 = b * 1024 + tid;
+    double c0 = 0, c1 = 0, c2 = 0, r0 = 0, r1 = 0, r2 = 0;
+    if (idx0 >= 3 && idx0 < n) {
+        c0 = P[idx0 + 0 * ld]; c1 = P[idx0 + 1 * ld]; c2 = P[idx0 + 2 * ld];
+        r0 = P[0 + idx0 * ld]; r1 = P[1 + idx0 * ld]; r2 = P[2 + idx0 * ld];
+    }
+    float lmx = 0.f, lmy = 0.f;                       // this lane's first landmark (covers L <= 1024)
+    if (tid < L) { lmx = (float)mu[3 + 2 * tid]; lmy = (float)mu[4 + 2 * tid]; }
+    double C9[9];
+    if (tid == 0) {
+        if (b == 0) for (int q = 0; q < 9; ++q) C9[q] = P[(q % 3) + (size_t)(q / 3) * ld];
+        const double mu0 = mu[0], mu1 = mu[1], mu2 = mu[2];
+        motion_terms(A, mu2, mo);
+        const double x = mu0 + mo.d[0], y = mu1 + mo.d[1];
+        double th = mu2 + mo.d[2], sn, cs;
+        sincos(th, &sn, &cs);
+        th = atan2(sn, cs);                           // cc:181 / :205
+        sincos(th, &sn, &cs);
+        pose[0] = x; pose[1] = y; pose[2] = th; pose[3] = cs; pose[4] = sn;
+    }
+    __syncthreads();
+
+    // ---- Predict, covariance slice (cc:178 / :202), corner by workgroup 0
+    {
+#pragma clang fp contract(off)
+        const double a = mo.a, bb = mo.b;
+        if (idx0 >= 3 && idx0 < n) {
+            P[idx0 + 0 * ld] = c0 + a * c2;
+            P[idx0 + 1 * ld] = c1 + bb * c2;
+            P[0 + idx0 * ld] = r0 + a * r2;
+            P[1 + idx0 * ld] = r1 + bb * r2;
+        }
+        for (int idx = idx0 + nb * 1024; idx < n; idx += nb * 1024) {
+            const double p2 = P[idx + 2 * ld];
+            P[idx + 0 * ld] = P[idx + 0 * ld] + a * p2;
+            P[idx + 1 * ld] = P[idx + 1 * ld] + bb * p2;
+            const double q2 = P[2 + idx * ld];
+            P[0 + idx * ld] = P[0 + idx * ld] + a * q2;
+            P[1 + idx * ld] = P[1 + idx * ld] + bb * q2;
+        }
+        if (b == 0 && tid == 0) {
+            corner_predict(C9, 3, mo);
+            for (int q = 0; q < 9; ++q) P[(q % 3) + (size_t)(q / 3) * ld] = C9[q];
+            for (int q = 0; q < 5; ++q) ctl->pose_pred[q] = pose[q];
+            ctl->pose_pending = 1;
+        }
+    }
+
+    // ---- ReflectorMatch (cc:370-455): whole observations per workgroup
+    const int M_ = d.M_map;
+    for (int i = b; i < K; i += nb) {
+        float gx, gy;
+        obs_to_global(pose[0], pose[1], pose[3], pose[4], A.obs[2 * i], A.obs[2 * i + 1], gx, gy);
+        int kind = 2, best_j = -1;
+        if (M_ > 0) {                                              // cc:401-425
+#pragma clang fp contract(off)
+            double best = 0; int bj = -1;
+            for (int j = tid; j < M_; j += 1024) {
+                const double *S = d.map_cov + 4 * (size_t)j;
+                const float ex = d.map_xy[2 * j] - gx;
+                const float ey = d.map_xy[2 * j + 1] - gy;
+                const double dx = (double)ex, dy = (double)ey;
+                const double t0 = dx * S[0] + dy * S[2];
+                const double t1 = dx * S[1] + dy * S[3];
+                const double dist = sqrt(t0 * dx + t1 * dy);
+                if (bj < 0 || dist < best) { best = dist; bj = j; }
+            }
+            block_argmin(best, bj, sc);
+            if (bj >= 0 && best < 0.05) { kind = 0; best_j = bj; }
+        }
+        if (kind == 2 && L > 0) {                                  // cc:426-451
+#pragma clang fp contract(off)
+            auto lm_of = [&](int j, float &lx, float &ly) {
+                if (j == tid) { lx = lmx; ly = lmy; }
+                else { lx = (float)mu[3 + 2 * j]; ly = (float)mu[4 + 2 * j]; }     // cc:431
+            };
+            double b1 = 1e300, b2 = 1e300; int bj = -1;            // see k_front for the band argument
+            for (int j = tid; j < L; j += 1024) {
+                float lx, ly;
+                lm_of(j, lx, ly);
+                const float ex = gx - lx, ey = gy - ly;             // cc:433
+                const double dx = (double)ex, dy = (double)ey;
+                const double d2 = dx * dx + dy * dy;
+                b2 = vmin_f64(b2, vmax_f64(d2, b1));
+                bj = (d2 < b1) ? j : bj;
+                b1 = vmin_f64(b1, d2);
+            }
+            double g1 = b1; int gj = bj;
+            block_argmin(g1, gj, sc);
+            const double band = g1 * 1.000000000000002;
+            const int near = block_sum(((bj >= 0 && b1 <= band) ? 1 : 0) + ((b2 <= band) ? 1 : 0), sc);
+            double best = sqrt(g1);
+            if (near > 1) {                                        // literal scan (uniform, rare)
+                best = 0; gj = -1;
+                for (int j = tid; j < L; j += 1024) {
+                    float lx, ly;
+                    lm_of(j, lx, ly);
+                    const float ex = gx - lx, ey = gy - ly;
+                    const double dx = (double)ex, dy = (double)ey;
+                    const double dist = sqrt(dx * dx + dy * dy);   // cc:437
+                    if (gj < 0 || dist < best) { best = dist; gj = j; }
+                }
+                block_argmin(best, gj, sc);
+            }
+            if (gj >= 0 && best < 0.6) { kind = 1; best_j = gj; }  // cc:446
+        }
+        if (tid == 0) { ctl->obs_kind[i] = kind; ctl->obs_idx[i] = best_j; }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_record(RekfDev d, RekfFrontArgs A)
+{
+    __shared__ int s_pair_obs[REKF_MAX_OBS_DEV], s_pair_id[REKF_MAX_OBS_DEV], s_pair_state[REKF_MAX_OBS_DEV];
+    RekfCtl *ctl = d.ctl;
+    const int lane = threadIdx.x;
+    const int K = A.K;
+    const int n = ctl->n;
+    const double *mu = d.mu;
+    const double pose[5] = {ctl->pose_pred[0], ctl->pose_pred[1], ctl->pose_pred[2], ctl->pose_pred[3], ctl->pose_pred[4]};
+    // ---- ordered compaction into the three lists (obs order preserved)
+    const int kind = (lane < K) ? ctl->obs_kind[lane] : -1;
+    const int oidx = (lane < K) ? ctl->obs_idx[lane] : -1;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const unsigned long long ms = __ballot(kind == 1);
+    const unsigned long long mm = __ballot(kind == 0);
+    const unsigned long long mn = __ballot(kind == 2);
+    const int M = __popcll(ms), Mm = __popcll(mm);
+    int N2 = __popcll(mn);
+    const int room = (d.n_max - n) / 2;
+    if (N2 > room) {                                               // capacity guard (ours)
+        if (lane == 0) atomicOr(&ctl->err, REKF_FLAG_CAPACITY);
+        N2 = room;
+    }
+    if (kind == 1) {
+        const int p = __popcll(ms & lt);
+        ctl->state_pairs[2 * p] = lane; ctl->state_pairs[2 * p + 1] = oidx;
+        s_pair_obs[p] = lane; s_pair_id[p] = oidx; s_pair_state[p] = 1;
+    } else if (kind == 0) {
+        const int p = __popcll(mm & lt);
+        ctl->map_pairs[2 * p] = lane; ctl->map_pairs[2 * p + 1] = oidx;
+        s_pair_obs[M + p] = lane; s_pair_id[M + p] = oidx; s_pair_state[M + p] = 0;
+    } else if (kind == 2) {
+        const int p = __popcll(mn & lt);
+        if (p < N2) ctl->new_ids[p] = lane;
+    }
+    const int MM = M + Mm;
+    const int m = (MM > 0) ? 2 * MM + (A.has_gps ? 3 : 0) : 0;
+    if (lane == 0) {
+        ctl->K = K; ctl->n_state = M; ctl->n_map = Mm; ctl->n_new = N2;
+        ctl->m = m; ctl->m_pad = (m + 15) & ~15;
+    }
+    __syncthreads();
+    // ---- H rows, z - zhat, Q (cc:248-304): row pair p per lane
+    if (lane < MM) {
+#pragma clang fp contract(off)
+        const int p = lane;
+        const int local_id = s_pair_obs[p], global_id = s_pair_id[p], is_state = s_pair_state[p];
+        const double c = pose[3], s = pose[4];                      // cc:252-253
+        const double z0 = (double)A.obs[2 * local_id], z1 = (double)A.obs[2 * local_id + 1];
+        double lx, ly;
+        if (is_state) { lx = mu[3 + 2 * global_id]; ly = mu[4 + 2 * global_id]; }
+        else { lx = (double)d.map_xy[2 * global_id]; ly = (double)d.map_xy[2 * global_id + 1]; }
+        const double dx = lx - pose[0], dy = ly - pose[1];         // cc:267-268
+        const double zh0 = dx * c + dy * s, zh1 = -dx * s + dy * c; // cc:269-270
+        const int r0 = 2 * p, r1 = 2 * p + 1;
+        ctl->ha[r0][0] = -c; ctl->ha[r0][1] = -s; ctl->ha[r0][2] = -dx * s + dy * c;   // A_i cc:272-273
+        ctl->ha[r1][0] = s;  ctl->ha[r1][1] = -c; ctl->ha[r1][2] = -dx * c - dy * s;
+        ctl->hb[r0][0] = c;  ctl->hb[r0][1] = s;                   // B cc:255 (state rows only, cc:275)
+        ctl->hb[r1][0] = -s; ctl->hb[r1][1] = c;
+        const int col = is_state ? 3 + 2 * global_id : -1;
+        ctl->hcol[r0] = col; ctl->hcol[r1] = col;
+        ctl->dz[r0] = z0 - zh0; ctl->dz[r1] = z1 - zh1;
+        ctl->qd[r0] = A.obs_cov; ctl->qd[r1] = A.obs_cov;          // cc:276 / :302
+    }
+    if (lane == 0 && A.has_gps && MM > 0) {                        // gps.cc:305-332
+#pragma clang fp contract(off)
+        const int r0 = 2 * MM;
+        for (int k = 0; k < 3; ++k) {
+            ctl->ha[r0 + k][0] = (k == 0); ctl->ha[r0 + k][1] = (k == 1); ctl->ha[r0 + k][2] = (k == 2);
+            ctl->hb[r0 + k][0] = 0; ctl->hb[r0 + k][1] = 0; ctl->hcol[r0 + k] = -1;
+        }
+        ctl->dz[r0] = A.gps[0] - pose[0];
+        ctl->dz[r0 + 1] = A.gps[1] - pose[1];
+        ctl->dz[r0 + 2] = yaw_innovation(A.gps[2] - pose[2]);
+        ctl->qd[r0] = 0.05 * 0.05; ctl->qd[r0 + 1] = 0.05 * 0.05; ctl->qd[r0 + 2] = 0.017 * 0.017;
+    }
+}
+
+// ----------------------------------------------------------------------------
 // k_gather: W(c, r) = sum_k P(c,k) H(r,k)  (columns of P: coalesced) and
 // HPt(c, r) = (H P)(r, c) = sum_k H(r,k) P(k,c)  (rows of P: each thread walks
 // its own column c); thread per state index c, blockIdx.y strides over row pairs.
@@ -501,8 +750,8 @@ __global__ __launch_bounds__(256) void k_gather(RekfDev d)
 // kernel is latency-, not throughput-bound.
 // ----------------------------------------------------------------------------
 template <int NB>
-__device__ static void solve_body(const RekfDev &d, int m, double (*rowbuf)[REKF_MR_PAD],
-                                  double (*colbuf)[REKF_MR_PAD])
+__device__ static void solve_body(const RekfDev &d, int m, double (*rowbuf)[2 * REKF_MR_PAD],
+                                  double (*colbuf)[2 * REKF_MR_PAD])
 {
     RekfCtl *ctl = d.ctl;
     const int tid = threadIdx.x;
@@ -546,48 +795,63 @@ __device__ static void solve_body(const RekfDev &d, int m, double (*rowbuf)[REKF
 #ifdef REKF_DEBUG_TIMING
     const long long t0c = clock64(), t0w = wall_clock64();
 #endif
+    // Block Gauss-Jordan with 2x2 pivots (rows come in pairs anyway): m/2 sequential steps instead
+    // of m -- the step is a latency chain (LDS hand-off, barrier, reciprocal), not a throughput one.
+    // Step with pivot block K = {k, k+1}, D = S(K,K):  with the pivot columns replaced by unit
+    // vectors,  R = D^-1 S(K,:),  S(i,:) -= S(i,K) R  for i not in K,  S(K,:) = R.
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
-        for (int kk = 0; kk < 16; ++kk) {
+        for (int kk = 0; kk < 16; kk += 2) {
             const int k = 16 * kb + kk;
             if (k >= m) break;
-            const int buf = k & 1;
-            const bool own_row = ti == kk, own_col = tj == kk;   // row/col k live in block kb of these threads
-            if (own_row) {
+            const int buf = (k >> 1) & 1;
+            const bool own_r0 = ti == kk, own_r1 = ti == kk + 1, own_c0 = tj == kk, own_c1 = tj == kk + 1;
+            if (own_r0 || own_r1) {
 #pragma unroll
-                for (int b = 0; b < NB; ++b) rowbuf[buf][tj + 16 * b] = S[kb][b];
+                for (int b = 0; b < NB; ++b) rowbuf[buf][(own_r1 ? REKF_MR_PAD : 0) + tj + 16 * b] = S[kb][b];
             }
-            if (own_col) {
+            if (own_c0 || own_c1) {
 #pragma unroll
-                for (int a = 0; a < NB; ++a) colbuf[buf][ti + 16 * a] = S[a][kb];
+                for (int a = 0; a < NB; ++a) colbuf[buf][(own_c1 ? REKF_MR_PAD : 0) + ti + 16 * a] = S[a][kb];
             }
             __syncthreads();
-            const double piv = rowbuf[buf][k];
-            if (!(piv > 0.0)) bad = true;
-            // p = 1/piv: hardware reciprocal + two Newton steps (<= 2 ulp; S is SPD and well scaled,
-            // the IEEE division's scaling/fix-up paths are never needed here)
-            double p = __builtin_amdgcn_rcp(piv);
-            p = fma(p, fma(-piv, p, 1.0), p);
-            p = fma(p, fma(-piv, p, 1.0), p);
-            // in-place Gauss-Jordan step: R = p * row k with R_k = p; for i != k:
-            //   S(i,j) <- S(i,j)[col k zeroed] - S(i,k) * R_j ;   row k <- R
-            double R[NB], f[NB];
+            const double *r0p = rowbuf[buf], *r1p = rowbuf[buf] + REKF_MR_PAD;
+            const double *c0p = colbuf[buf], *c1p = colbuf[buf] + REKF_MR_PAD;
+            const double d00 = r0p[k], d01 = r0p[k + 1], d10 = r1p[k], d11 = r1p[k + 1];
+            const double det = d00 * d11 - d01 * d10;
+            if (!(det > 0.0) || !(d00 > 0.0)) bad = true;
+            double q = __builtin_amdgcn_rcp(det);          // 1/det: hardware reciprocal + two Newton steps
+            q = fma(q, fma(-det, q, 1.0), q);
+            q = fma(q, fma(-det, q, 1.0), q);
+            const double i00 = d11 * q, i01 = -d01 * q, i10 = -d10 * q, i11 = d00 * q;
+            double R0[NB], R1[NB], f0[NB], f1[NB];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) R[b] = rowbuf[buf][tj + 16 * b] * p;
-            if (own_col) R[kb] = p;
+            for (int b = 0; b < NB; ++b) {
+                double x0 = r0p[tj + 16 * b], x1 = r1p[tj + 16 * b];
+                if (b == kb) {                              // pivot columns act as unit vectors
+                    if (own_c0) { x0 = 1.0; x1 = 0.0; }
+                    if (own_c1) { x0 = 0.0; x1 = 1.0; }
+                }
+                R0[b] = i00 * x0 + i01 * x1;
+                R1[b] = i10 * x0 + i11 * x1;
+            }
 #pragma unroll
-            for (int a = 0; a < NB; ++a) f[a] = colbuf[buf][ti + 16 * a];
-            if (own_col) {
+            for (int a = 0; a < NB; ++a) { f0[a] = c0p[ti + 16 * a]; f1[a] = c1p[ti + 16 * a]; }
+            if (own_c0 || own_c1) {
 #pragma unroll
                 for (int a = 0; a < NB; ++a) S[a][kb] = 0.0;
             }
 #pragma unroll
             for (int a = 0; a < NB; ++a)
 #pragma unroll
-                for (int b = 0; b < NB; ++b) S[a][b] = fma(-f[a], R[b], S[a][b]);
-            if (own_row) {
+                for (int b = 0; b < NB; ++b) S[a][b] = fma(-f1[a], R1[b], fma(-f0[a], R0[b], S[a][b]));
+            if (own_r0) {
 #pragma unroll
-                for (int b = 0; b < NB; ++b) S[kb][b] = R[b];
+                for (int b = 0; b < NB; ++b) S[kb][b] = R0[b];
+            }
+            if (own_r1) {
+#pragma unroll
+                for (int b = 0; b < NB; ++b) S[kb][b] = R1[b];
             }
         }
     }
@@ -616,8 +880,8 @@ __device__ static void solve_body(const RekfDev &d, int m, double (*rowbuf)[REKF
 
 __global__ __launch_bounds__(256) void k_solve(RekfDev d)
 {
-    __shared__ double rowbuf[2][REKF_MR_PAD];
-    __shared__ double colbuf[2][REKF_MR_PAD];
+    __shared__ double rowbuf[2][2 * REKF_MR_PAD];    // ping-pong x {row k, row k+1}
+    __shared__ double colbuf[2][2 * REKF_MR_PAD];
     const int m = d.ctl->m;
     if (m == 0) return;
     if (m <= 32) solve_body<2>(d, m, rowbuf, colbuf);
@@ -636,9 +900,14 @@ __global__ __launch_bounds__(256) void k_solve(RekfDev d)
 // ----------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void k_gain(RekfDev d)
 {
-    const RekfCtl *ctl = d.ctl;
+    RekfCtl *ctl = d.ctl;
     const int m = ctl->m;
-    if (m == 0) return;
+    const bool pending = ctl->pose_pending != 0;        // multi-workgroup front: mu[0..2] still holds the old pose
+    if (m == 0) {
+        if (pending && blockIdx.x == 0 && threadIdx.x < 3) d.mu[threadIdx.x] = ctl->pose_pred[threadIdx.x];
+        if (pending && blockIdx.x == 0 && threadIdx.x == 0) ctl->pose_pending = 0;
+        return;
+    }
     const int n = ctl->n, m_pad = ctl->m_pad;
     const int i0 = blockIdx.x * 16;
     if (i0 >= n) return;
@@ -676,9 +945,11 @@ __global__ __launch_bounds__(512) void k_gain(RekfDev d)
         } else if (kq == 0) {                                                // D row 0 = dmu
             const int i = i0 + idx;
             if (i < n) {
-                double v = d.mu[i] + acc[0];
+                const double base = (pending && i < 3) ? ctl->pose_pred[i] : d.mu[i];
+                double v = base + acc[0];
                 if (i == 2) v = atan2(sin(v), cos(v));
                 d.mu[i] = v;
+                if (i == 0) ctl->pose_pending = 0;
             }
         }
     }
@@ -729,9 +1000,21 @@ __device__ static void downdate_body(const RekfDev &d, double *dd_smem, int n, i
 {
     const int T = (n + DT - 1) / DT;
     const int nchunk = FAST ? 1 : (m_pad + DKC - 1) / DKC;
-    const int ntiles = T * T;
-    const int t_begin = (int)(((long long)blockIdx.x * ntiles) / gridDim.x);
-    const int t_end = (int)(((long long)(blockIdx.x + 1) * ntiles) / gridDim.x);
+    // Tile assignment.  Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only):
+    // the tile grid is cut into 2 x 4 regions, one per XCD, so that an XCD's private L2 only ever
+    // needs 1/2 of the Kn panels and 1/4 of the HPt panels (0.8 MB instead of 2.2 MB from HBM per XCD).
+    // Inside a region the XCD's workgroups take contiguous tile ranges.  Any grid that is not a
+    // multiple of 8 falls back to one linear split (same result, placement-independent either way).
+    int i_lo = 0, i_n = T, j_lo = 0, j_n = T, w = blockIdx.x, nw = gridDim.x;
+    if (gridDim.x >= 8 && (gridDim.x & 7) == 0) {
+        const int x = blockIdx.x & 7, ri = x >> 2, rj = x & 3;
+        i_lo = ri * T / 2; i_n = (ri + 1) * T / 2 - i_lo;
+        j_lo = rj * T / 4; j_n = (rj + 1) * T / 4 - j_lo;
+        w = blockIdx.x >> 3; nw = gridDim.x >> 3;
+    }
+    const int ntiles = i_n * j_n;
+    const int t_begin = (int)(((long long)w * ntiles) / nw);
+    const int t_end = (int)(((long long)(w + 1) * ntiles) / nw);
     if (t_begin >= t_end) return;
     const int nitems = (t_end - t_begin) * nchunk;
     const size_t ld = (size_t)d.ld;
@@ -745,7 +1028,7 @@ __device__ static void downdate_body(const RekfDev &d, double *dd_smem, int n, i
     v2d stgK[DD_STG], stgW[DD_STG], pnext[8];
     v4d acc[2][2];
 
-    auto tile_IJ = [&](int tile, int &I, int &J) { J = tile / T; I = tile - J * T; };
+    auto tile_IJ = [&](int tile, int &I, int &J) { const int jj = tile / i_n; I = i_lo + (tile - jj * i_n); J = j_lo + jj; };
     auto load_panels = [&](int item) {
         if (d.dbg & 8) return;                 // ablation hook: skip the panel reads
         int I, J;
@@ -867,10 +1150,50 @@ __device__ static void downdate_body(const RekfDev &d, double *dd_smem, int n, i
         DMARK();
         for (int item = 0; item < nitems - 1; ++item) {
             const int tile = t_begin + item;
-            load_panels(item + 1);            // (A) next tile's operands go in flight
-            load_p(tile + 1);
-            DMARK();
-            mfma_chunk(item);                 // (B) 64 MFMAs per wave on the current LDS buffer
+            // The next tile's 24 loads per lane are issued BETWEEN the MFMAs of this tile (two per
+            // k-step, sched_barrier keeps them there): issuing them in one burst stalls the wave in
+            // VMEM issue for as long as the transfer takes (the per-CU queue is full whenever the chip
+            // is HBM-bound) and the matrix pipe idles; spread out, the MFMAs run in the gaps.
+            int In, Jn;
+            tile_IJ(tile + 1, In, Jn);
+            const double *kp = Kn + (size_t)(DT * In + 2 * (tid & 31)) + (size_t)(tid >> 5) * ld;
+            const double *wp = HPt + (size_t)(DT * Jn + 2 * (tid & 31)) + (size_t)(tid >> 5) * ld;
+            const double *Pn = p_ptr(tile + 1);
+            const bool no_p = (d.dbg & 2) != 0, no_panels = (d.dbg & 8) != 0, no_mfma = (d.dbg & 4) != 0;
+            const double *sK = dd_smem + (size_t)((item & 1) * DD_NBUF / 2) * 2 * DKC * 64, *sW = sK + DKC * 64;
+            const double *aW = sW + 32 * wj + 2 * idx + kq * 64;
+            const double *bK = sK + 32 * wi + 2 * idx + kq * 64;
+            v2d a2 = *(const v2d *)(aW), b2 = *(const v2d *)(bK);
+#pragma unroll
+            for (int kk = 0; kk < DKC / 4; ++kk) {
+                v2d a2n = a2, b2n = b2;
+                if (kk + 1 < DKC / 4) {
+                    a2n = *(const v2d *)(aW + (kk + 1) * 256);
+                    b2n = *(const v2d *)(bK + (kk + 1) * 256);
+                }
+                if (!no_mfma) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.x, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.y, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.x, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.y, acc[1][1], 0, 0, 0);
+                }
+                if (kk < DD_STG) {                       // k-steps 0..7: one Kn and one HPt panel piece each
+                    if (!no_panels) {
+                        stgK[kk] = *(const v2d *)(kp + (size_t)(8 * kk) * ld);
+                        stgW[kk] = *(const v2d *)(wp + (size_t)(8 * kk) * ld);
+                    }
+                } else if (kk < DD_STG + 4) {            // k-steps 8..11: two P pieces each
+                    const int q = 2 * (kk - DD_STG);
+                    if (!no_p) {
+                        pnext[q] = *(const v2d *)(Pn + (size_t)(8 * (q & 3) + (q >> 2)) * ld);
+                        pnext[q + 1] = *(const v2d *)(Pn + (size_t)(8 * ((q + 1) & 3) + ((q + 1) >> 2)) * ld);
+                    } else {
+                        pnext[q].x = 1e-3; pnext[q].y = 2e-3; pnext[q + 1] = pnext[q];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                a2 = a2n; b2 = b2n;
+            }
             DMARK();
             store_tile(tile);                 // (C) drains under the next tile
             DMARK();
@@ -1015,6 +1338,12 @@ void rekf_launch_front(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s)
 {
     hipLaunchKernelGGL(k_front, dim3(1), dim3(1024), 0, s, d, a);
 }
+void rekf_launch_front_mb(const RekfDev &d, const RekfFrontArgs &a, int n_ub, hipStream_t s)
+{
+    (void)n_ub;
+    hipLaunchKernelGGL(k_front_mb, dim3(FRONT_MB), dim3(1024), 0, s, d, a);
+    hipLaunchKernelGGL(k_record, dim3(1), dim3(64), 0, s, d, a);
+}
 void rekf_launch_gather(const RekfDev &d, int n_ub, hipStream_t s)
 {
     hipLaunchKernelGGL(k_gather, dim3((n_ub + 255) / 256, 32), dim3(256), 0, s, d);
@@ -1044,7 +1373,8 @@ void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s)
     }
     const int T = (n_ub + DT - 1) / DT;
     const int slots = n_cu * DD_WG_PER_CU;
-    const int grid = (T * T < slots) ? T * T : slots;
+    int grid = (T * T < slots) ? T * T : slots;
+    if (grid >= 64) grid &= ~7;                     // multiple of 8: enables the per-XCD tile regions
     hipLaunchKernelGGL(k_downdate, dim3(grid), dim3(256), DD_NBUF * 2 * DKC * 64 * sizeof(double), s, d);
 }
 void rekf_launch_augment(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s)

@@ -41,6 +41,7 @@ struct rekf {
     std::string hip_error;
     // profiling
     bool prof_on;
+    int prof_mask;
     std::vector<ProfSlot> prof_slots;
     size_t prof_used;
     double prof_total_us[REKF_K_COUNT];
@@ -79,7 +80,7 @@ struct ProfScope {
     ProfSlot *slot;
     ProfScope(rekf_t *h_, int kernel) : h(h_), slot(nullptr)
     {
-        if (!h->prof_on) return;
+        if (!h->prof_on || !((h->prof_mask >> kernel) & 1)) return;
         if (h->prof_used == h->prof_slots.size()) {
             if (h->prof_slots.size() >= 65536) {
                 prof_flush(h);
@@ -165,6 +166,7 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
     h->vt[0] = h->vt[1] = h->vt[2] = 0.0;             // cc:6
     h->n_ub = 3;
     h->prof_on = false;
+    h->prof_mask = -1;
     h->prof_used = 0;
     for (int k = 0; k < REKF_K_COUNT; ++k) { h->prof_total_us[k] = 0; h->prof_count[k] = 0; }
     h->stream = nullptr;
@@ -281,15 +283,21 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         a.gps[0] = gps_pose3[0]; a.gps[1] = gps_pose3[1]; a.gps[2] = gps_pose3[2];
     }
     HIP_TRY(h, hipSetDevice(h->device));
-    { ProfScope ps(h, REKF_K_FRONT); rekf_launch_front(h->dev, a, h->stream); }
+    if (K == 0) {                                     // cc:235-236: predict only, single-workgroup kernel
+        ProfScope ps(h, REKF_K_FRONT);
+        rekf_launch_front(h->dev, a, h->stream);
+        h->time = t;
+        return REKF_OK;
+    }
+    { ProfScope ps(h, REKF_K_FRONT); rekf_launch_front_mb(h->dev, a, h->n_ub, h->stream); }
     h->time = t;                                      // cc:234
-    if (K == 0) return REKF_OK;                       // cc:235-236
     const int n_ub = h->n_ub;
     { ProfScope ps(h, REKF_K_GATHER); rekf_launch_gather(h->dev, n_ub, h->stream); }
     { ProfScope ps(h, REKF_K_SOLVE); rekf_launch_solve(h->dev, h->stream); }
     { ProfScope ps(h, REKF_K_GAIN); rekf_launch_gain(h->dev, n_ub, h->stream); }
     { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_downdate(h->dev, n_ub, h->stream); }
     { ProfScope ps(h, REKF_K_AUGMENT); rekf_launch_augment(h->dev, a, h->stream); }
+    { ProfScope ps(h, REKF_K_EMPTY); }
     // the scan may have appended up to K reflectors; the exact n stays on the device
     int grown = n_ub + 2 * K;
     h->n_ub = grown > h->dev.n_max ? h->dev.n_max : grown;
@@ -417,6 +425,7 @@ int rekf_profile_enable(rekf_t *h, int on)
     if (!h) return REKF_ERR_INVALID;
     if (!on) { int rc = prof_flush(h); if (rc != REKF_OK) return rc; }
     h->prof_on = on != 0;
+    h->prof_mask = on;
     return REKF_OK;
 }
 

@@ -17,7 +17,7 @@ from . import _lib
 
 DIFF, OMNI = 0, 1   # sensor::OdometryModel (sensor_data.h:56-60)
 
-KERNELS = {"predict": 0, "front": 1, "gather": 2, "solve": 3, "gain": 4, "downdate": 5, "augment": 6}
+KERNELS = {"predict": 0, "front": 1, "gather": 2, "solve": 3, "gain": 4, "downdate": 5, "augment": 6, "empty": 7}
 
 
 class RekfError(RuntimeError):
@@ -275,8 +275,12 @@ class ReflectorEKFSLAM:
         return self._L.rekf_sync(self._h)
 
     # -- measurement hooks -----------------------------------------------------
-    def profile(self, on: bool):
-        self._chk(self._L.rekf_profile_enable(self._h, 1 if on else 0), "profile_enable")
+    def profile(self, on, only=None):
+        """Bracket kernel launches with hipEvents.  ``only`` = iterable of kernel names to restrict to."""
+        mask = 0
+        if on:
+            mask = -1 if only is None else sum(1 << KERNELS[k] for k in only)
+        self._chk(self._L.rekf_profile_enable(self._h, mask), "profile_enable")
 
     def profile_reset(self):
         self._chk(self._L.rekf_profile_reset(self._h), "profile_reset")

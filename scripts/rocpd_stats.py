@@ -19,3 +19,8 @@ for name, rs in by.items():
 for t, name, c, a, med, mn, mx, r in sorted(out, reverse=True):
     print(f"{name[:60]:60s} {c:7d} {t:12.1f} {a:9.2f} {med:9.2f} {mn:9.2f} {mx:9.2f}  {r[3]}x{r[4]} {r[5]} {r[6]} {r[7]} {r[8]} {r[9]} {r[10]}")
 print(f"total kernel time {tot:.1f} us over {len(rows)} dispatches" + (f" (last {last} per kernel)" if last else ""))
+
+if "--json" in sys.argv:
+    import json
+    path = sys.argv[sys.argv.index("--json") + 1]
+    json.dump({name.split("(")[0]: round(a, 3) for t, name, c, a, med, mn, mx, r in out}, open(path, "w"), indent=1)
