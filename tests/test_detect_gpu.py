@@ -191,3 +191,43 @@ def test_detect3d_world_clouds_match(oracle_lib):
         cloud = synth.make_point_cloud(lms, pose, rng)
         obs = _compare3d(cloud)
         assert obs.cloud_.shape[0] >= 40
+
+
+def test_c4_short_cloud_to_filter_omni(oracle_lib):
+    """BASELINE.json configs[3] (shortened): synthetic 3D clouds -> 3D detector -> EKF with the OMNI
+    odometry model, HIP path vs oracle path, lock-step."""
+    from oracle.binding import OracleEKF, oracle_detect3d
+    from reflector_ekf_slam_amd import EKFOptions, ReflectorEKFSLAM, synth
+    from reflector_ekf_slam_amd.detect import PointCloudOptions, PointCloudReflectorDetect
+    import dataclasses
+    cfg = dataclasses.replace(synth.C4, name="C4_short")
+    sess = synth.make_session(cfg, max_scans=70)
+    rng = np.random.Generator(np.random.PCG64(99))
+    det = PointCloudReflectorDetect(PointCloudOptions(), max_points=32768)
+    opt = EKFOptions(init_time=0.0, init_pose=tuple(sess.init_pose), odom_model=cfg.odom_model,
+                     linear_velocity_cov=cfg.sigma_v ** 2, angular_velocity_cov=cfg.sigma_w ** 2,
+                     observation_cov=cfg.sigma_obs ** 2)
+    fg = ReflectorEKFSLAM(opt, max_landmarks=cfg.n_landmarks)
+    fo = OracleEKF(cfg.odom_model, 0.0, sess.init_pose, opt.linear_velocity_cov, opt.angular_velocity_cov,
+                   opt.observation_cov)
+    first = True
+    n_obs = 0
+    for e in range(sess.n_events):
+        t = sess.ev_time[e]
+        if sess.ev_type[e] == synth.EV_ODOM:
+            fg.handle_odometry(t, *sess.odom[e]); fo.handle_odometry(t, *sess.odom[e])
+            continue
+        cloud = synth.make_point_cloud(sess.landmarks, sess.true_pose[e], rng, n_outliers=20)
+        og = det.HandlePointCloud(t, cloud)
+        co, _, _ = oracle_detect3d(cloud)
+        assert og.cloud_.shape == co.shape and np.abs(og.cloud_ - co).max() < TOL
+        if first:
+            first = False
+            continue
+        k = min(co.shape[0], 64)
+        fg.handle_observation(t, og.cloud_[:k]); fo.handle_observation(t, co[:k])
+        n_obs += 1
+        sg, so = fg.last_match(), fo.last_match()
+        assert np.array_equal(sg.state_obs_match_ids, so[0]) and np.array_equal(sg.new_ids, so[2])
+    assert n_obs >= 60 and fg.n == fo.n and fg.n > 3 + 2 * 40
+    assert np.abs(fg.mu() - fo.mu()).max() < 1e-4

@@ -270,3 +270,42 @@ def test_c_abi_direct_calls_reject_bad_arguments():
     assert L.rekf_get_state(h, None, None, buf, 2, None, 0) == -6     # buffer too small
     assert L.rekf_handle_observation(h, 0.0, None, 3, None) == -1
     L.rekf_destroy(h)
+
+
+@pytest.mark.parametrize("obs_per_scan,range_max", [(48, 14.0), (64, 16.0), (20, 10.0)], ids=["m96", "m128", "m40"])
+def test_large_innovation_blocks(oracle_lib, obs_per_scan, range_max):
+    """More than 32 observations per scan: m up to 128 exercises the 8x8-register solve, the multi-chunk
+    (non-FAST) downdate pipeline and partially filled k-chunks (m_pad = 48, 96, 128)."""
+    cfg = synth.SessionConfig("wide", 160, obs_per_scan, synth.DIFF, seed=41, speed=1.5, row_spacing=12.0,
+                              range_max=range_max)
+    sess = synth.make_session(cfg, max_scans=140)
+    g, o = _pair(cfg, sess)
+    worst = [0.0]
+    seen = [0]
+
+    def chk(e, k):
+        a, b = norm_match(g.last_match()), norm_match(o.last_match())
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)), f"association differs at scan {k}"
+        seen[0] = max(seen[0], 2 * a[0].shape[0])
+        if k % 5 == 0:
+            worst[0] = max(worst[0], float(np.abs(g.mu() - o.mu()).max()))
+
+    drive_pair(sess, g, o, chk)
+    assert seen[0] >= min(2 * obs_per_scan - 8, 100) or obs_per_scan <= 20
+    assert worst[0] < TIGHT
+    st = g.GetState()
+    mo, Po = o.state()
+    assert np.abs(st.sigma - Po).max() < 1e-11 and g.sync_code() == 0
+
+
+def test_odometry_only_stretches_and_interleaving(oracle_lib):
+    """Long runs of HandleOdometryMessage between scans (the single-workgroup predict kernel) interleaved
+    with observations (the multi-workgroup front): the pose hand-off between the two paths."""
+    cfg = synth.SessionConfig("odo", 30, 8, synth.OMNI, seed=51, speed=1.0, row_spacing=6.0, scan_hz=2.0)
+    sess = synth.make_session(cfg, max_scans=40)
+    g, o = _pair(cfg, sess)
+    drive_pair(sess, g, o)
+    assert np.abs(g.mu() - o.mu()).max() < TIGHT
+    t, mu3, s3 = g.pose()
+    mo, Po = o.state()
+    assert np.abs(mu3 - mo[:3]).max() < TIGHT and np.abs(s3 - Po[:3, :3]).max() < 1e-12
