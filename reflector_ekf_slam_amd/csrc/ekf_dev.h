@@ -82,7 +82,7 @@ struct RekfDev {
 // launch wrappers (ekf_kernels.hip)
 void rekf_launch_front(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);
 void rekf_launch_front_mb(const RekfDev &d, const RekfFrontArgs &a, int n_ub, hipStream_t s);
-void rekf_launch_gather(const RekfDev &d, int n_ub, hipStream_t s);
+void rekf_launch_gather(const RekfDev &d, const RekfFrontArgs &a, int n_ub, hipStream_t s);
 void rekf_launch_solve(const RekfDev &d, hipStream_t s);
 void rekf_launch_gain(const RekfDev &d, int n_ub, hipStream_t s);
 void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s);

@@ -444,15 +444,15 @@ __global__ __launch_bounds__(1024) void k_front(RekfDev d, RekfFrontArgs A)
 }
 
 // ----------------------------------------------------------------------------
-// k_front_mb + k_record: the observation path's front end spread over FRONT_MB workgroups.
+// k_front_mb: the observation path's front end spread over FRONT_MB workgroups.
 //
 // The single-workgroup k_front is bounded by one CU's VALU and by serial reductions (15 us at
 // L = 1024, K = 32).  Here every workgroup recomputes the (cheap) predicted pose from the OLD
 // mean -- nobody writes mu[0..2] in this kernel: the predicted pose goes to ctl->pose_pred and is
 // committed by k_gain together with the update -- then takes a 1/FRONT_MB slice of the
 // covariance predict and whole observations of ReflectorMatch (all 16 waves sweep disjoint
-// landmark slices, block-wide literal arg-min).  k_record (one wave) then does the ordered
-// compaction and the H rows exactly like the tail of k_front.
+// landmark slices, block-wide literal arg-min).  The ordered compaction and the H rows (the tail of
+// k_front) are resolved by k_gather from the per-observation results left in ctl->obs_kind/obs_idx.
 // ----------------------------------------------------------------------------
 #define FRONT_MB 32
 
@@ -614,110 +614,148 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
     }
 }
 
-__global__ __launch_bounds__(64) void k_record(RekfDev d, RekfFrontArgs A)
-{
-    __shared__ int s_pair_obs[REKF_MAX_OBS_DEV], s_pair_id[REKF_MAX_OBS_DEV], s_pair_state[REKF_MAX_OBS_DEV];
-    RekfCtl *ctl = d.ctl;
-    const int lane = threadIdx.x;
-    const int K = A.K;
-    const int n = ctl->n;
-    const double *mu = d.mu;
-    const double pose[5] = {ctl->pose_pred[0], ctl->pose_pred[1], ctl->pose_pred[2], ctl->pose_pred[3], ctl->pose_pred[4]};
-    // ---- ordered compaction into the three lists (obs order preserved)
-    const int kind = (lane < K) ? ctl->obs_kind[lane] : -1;
-    const int oidx = (lane < K) ? ctl->obs_idx[lane] : -1;
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const unsigned long long ms = __ballot(kind == 1);
-    const unsigned long long mm = __ballot(kind == 0);
-    const unsigned long long mn = __ballot(kind == 2);
-    const int M = __popcll(ms), Mm = __popcll(mm);
-    int N2 = __popcll(mn);
-    const int room = (d.n_max - n) / 2;
-    if (N2 > room) {                                               // capacity guard (ours)
-        if (lane == 0) atomicOr(&ctl->err, REKF_FLAG_CAPACITY);
-        N2 = room;
-    }
-    if (kind == 1) {
-        const int p = __popcll(ms & lt);
-        ctl->state_pairs[2 * p] = lane; ctl->state_pairs[2 * p + 1] = oidx;
-        s_pair_obs[p] = lane; s_pair_id[p] = oidx; s_pair_state[p] = 1;
-    } else if (kind == 0) {
-        const int p = __popcll(mm & lt);
-        ctl->map_pairs[2 * p] = lane; ctl->map_pairs[2 * p + 1] = oidx;
-        s_pair_obs[M + p] = lane; s_pair_id[M + p] = oidx; s_pair_state[M + p] = 0;
-    } else if (kind == 2) {
-        const int p = __popcll(mn & lt);
-        if (p < N2) ctl->new_ids[p] = lane;
-    }
-    const int MM = M + Mm;
-    const int m = (MM > 0) ? 2 * MM + (A.has_gps ? 3 : 0) : 0;
-    if (lane == 0) {
-        ctl->K = K; ctl->n_state = M; ctl->n_map = Mm; ctl->n_new = N2;
-        ctl->m = m; ctl->m_pad = (m + 15) & ~15;
-    }
-    __syncthreads();
-    // ---- H rows, z - zhat, Q (cc:248-304): row pair p per lane
-    if (lane < MM) {
-#pragma clang fp contract(off)
-        const int p = lane;
-        const int local_id = s_pair_obs[p], global_id = s_pair_id[p], is_state = s_pair_state[p];
-        const double c = pose[3], s = pose[4];                      // cc:252-253
-        const double z0 = (double)A.obs[2 * local_id], z1 = (double)A.obs[2 * local_id + 1];
-        double lx, ly;
-        if (is_state) { lx = mu[3 + 2 * global_id]; ly = mu[4 + 2 * global_id]; }
-        else { lx = (double)d.map_xy[2 * global_id]; ly = (double)d.map_xy[2 * global_id + 1]; }
-        const double dx = lx - pose[0], dy = ly - pose[1];         // cc:267-268
-        const double zh0 = dx * c + dy * s, zh1 = -dx * s + dy * c; // cc:269-270
-        const int r0 = 2 * p, r1 = 2 * p + 1;
-        ctl->ha[r0][0] = -c; ctl->ha[r0][1] = -s; ctl->ha[r0][2] = -dx * s + dy * c;   // A_i cc:272-273
-        ctl->ha[r1][0] = s;  ctl->ha[r1][1] = -c; ctl->ha[r1][2] = -dx * c - dy * s;
-        ctl->hb[r0][0] = c;  ctl->hb[r0][1] = s;                   // B cc:255 (state rows only, cc:275)
-        ctl->hb[r1][0] = -s; ctl->hb[r1][1] = c;
-        const int col = is_state ? 3 + 2 * global_id : -1;
-        ctl->hcol[r0] = col; ctl->hcol[r1] = col;
-        ctl->dz[r0] = z0 - zh0; ctl->dz[r1] = z1 - zh1;
-        ctl->qd[r0] = A.obs_cov; ctl->qd[r1] = A.obs_cov;          // cc:276 / :302
-    }
-    if (lane == 0 && A.has_gps && MM > 0) {                        // gps.cc:305-332
-#pragma clang fp contract(off)
-        const int r0 = 2 * MM;
-        for (int k = 0; k < 3; ++k) {
-            ctl->ha[r0 + k][0] = (k == 0); ctl->ha[r0 + k][1] = (k == 1); ctl->ha[r0 + k][2] = (k == 2);
-            ctl->hb[r0 + k][0] = 0; ctl->hb[r0 + k][1] = 0; ctl->hcol[r0 + k] = -1;
-        }
-        ctl->dz[r0] = A.gps[0] - pose[0];
-        ctl->dz[r0 + 1] = A.gps[1] - pose[1];
-        ctl->dz[r0 + 2] = yaw_innovation(A.gps[2] - pose[2]);
-        ctl->qd[r0] = 0.05 * 0.05; ctl->qd[r0 + 1] = 0.05 * 0.05; ctl->qd[r0 + 2] = 0.017 * 0.017;
-    }
-}
-
 // ----------------------------------------------------------------------------
 // k_gather: W(c, r) = sum_k P(c,k) H(r,k)  (columns of P: coalesced) and
 // HPt(c, r) = (H P)(r, c) = sum_k H(r,k) P(k,c)  (rows of P: each thread walks
 // its own column c); thread per state index c, blockIdx.y strides over row pairs.
 // ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gather(RekfDev d)
+// H row pair p of the scan (cc:248-304, gps.cc:305-332): coefficients of rows 2p, 2p+1.
+struct HPair {
+    double a0[3], a1[3], b0[2], b1[2], dz0, dz1, q0, q1;
+    int col;
+};
+__device__ static HPair make_hpair(const RekfDev &d, const RekfFrontArgs &A, const double *pose,
+                                   int local_id, int global_id, int is_state)
 {
-    const RekfCtl *ctl = d.ctl;
-    const int m = ctl->m;
-    if (m == 0) return;
-    const int n = ctl->n, m_pad = ctl->m_pad;
+#pragma clang fp contract(off)
+    HPair h;
+    const double c = pose[3], s = pose[4];                      // cc:252-253
+    const double z0 = (double)A.obs[2 * local_id], z1 = (double)A.obs[2 * local_id + 1];
+    double lx, ly;
+    if (is_state) { lx = d.mu[3 + 2 * global_id]; ly = d.mu[4 + 2 * global_id]; }
+    else { lx = (double)d.map_xy[2 * global_id]; ly = (double)d.map_xy[2 * global_id + 1]; }
+    const double dx = lx - pose[0], dy = ly - pose[1];         // cc:267-268
+    const double zh0 = dx * c + dy * s, zh1 = -dx * s + dy * c; // cc:269-270
+    h.a0[0] = -c; h.a0[1] = -s; h.a0[2] = -dx * s + dy * c;    // A_i cc:272-273
+    h.a1[0] = s;  h.a1[1] = -c; h.a1[2] = -dx * c - dy * s;
+    h.b0[0] = c;  h.b0[1] = s;                                 // B cc:255 (state rows only, cc:275)
+    h.b1[0] = -s; h.b1[1] = c;
+    h.col = is_state ? 3 + 2 * global_id : -1;
+    h.dz0 = z0 - zh0; h.dz1 = z1 - zh1;
+    h.q0 = A.obs_cov; h.q1 = A.obs_cov;                         // cc:276 / :302
+    return h;
+}
+
+// k_gather also resolves the scan record: every workgroup redoes the (tiny) ordered compaction of
+// the per-observation match results left by k_front_mb and derives the H rows it needs on the fly;
+// workgroup (0,0) additionally writes the full record (match lists, all H rows, z - zhat, m) for
+// k_solve / k_gain / the getters.  This replaces a separate one-wave kernel (4 us of launch floor).
+__global__ __launch_bounds__(256) void k_gather(RekfDev d, RekfFrontArgs A)
+{
+    __shared__ int s_pair_obs[REKF_MAX_OBS_DEV], s_pair_id[REKF_MAX_OBS_DEV], s_pair_state[REKF_MAX_OBS_DEV];
+    __shared__ int s_cnt[4];
+    RekfCtl *ctl = d.ctl;
+    const int tid = threadIdx.x;
+    const int n = ctl->n;
+    const int K = A.K;
     const size_t ld = (size_t)d.ld;
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= d.ld) return;
-    const bool valid = c < n;
+    const int c = blockIdx.x * 256 + tid;
+    const bool valid = c < n && c < d.ld;
     const double *__restrict__ P = d.P;
     double *__restrict__ W = d.W;
     double *__restrict__ HPt = d.HPt;
-    const double *__restrict__ Pc = P + (size_t)(valid ? c : 0) * ld;   // column c (rows of P for H P)
     const int cc = valid ? c : 0;
+    const double *__restrict__ Pc = P + (size_t)cc * ld;               // column c (rows of P for H P)
+    // operands that do not depend on the record go in flight first
     const double p0 = P[cc], p1 = P[cc + ld], p2 = P[cc + 2 * ld];
     const double q0 = Pc[0], q1 = Pc[1], q2 = Pc[2];
+    const double pose[5] = {ctl->pose_pred[0], ctl->pose_pred[1], ctl->pose_pred[2], ctl->pose_pred[3], ctl->pose_pred[4]};
+
+    // ---- ordered compaction (obs order preserved), wave 0
+    if (tid < 64) {
+        const int lane = tid;
+        const int kind = (lane < K) ? ctl->obs_kind[lane] : -1;
+        const int oidx = (lane < K) ? ctl->obs_idx[lane] : -1;
+        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        const unsigned long long ms = __ballot(kind == 1);
+        const unsigned long long mm = __ballot(kind == 0);
+        const unsigned long long mn = __ballot(kind == 2);
+        const int M = __popcll(ms), Mm = __popcll(mm);
+        int N2 = __popcll(mn);
+        const int room = (d.n_max - n) / 2;
+        const bool first = blockIdx.x == 0 && blockIdx.y == 0;
+        if (N2 > room) {                                               // capacity guard (ours)
+            if (first && lane == 0) atomicOr(&ctl->err, REKF_FLAG_CAPACITY);
+            N2 = room;
+        }
+        if (kind == 1) {
+            const int p = __popcll(ms & lt);
+            s_pair_obs[p] = lane; s_pair_id[p] = oidx; s_pair_state[p] = 1;
+            if (first) { ctl->state_pairs[2 * p] = lane; ctl->state_pairs[2 * p + 1] = oidx; }
+        } else if (kind == 0) {
+            const int p = __popcll(mm & lt);
+            s_pair_obs[M + p] = lane; s_pair_id[M + p] = oidx; s_pair_state[M + p] = 0;
+            if (first) { ctl->map_pairs[2 * p] = lane; ctl->map_pairs[2 * p + 1] = oidx; }
+        } else if (kind == 2) {
+            const int p = __popcll(mn & lt);
+            if (first && p < N2) ctl->new_ids[p] = lane;
+        }
+        if (lane == 0) {
+            const int MM = M + Mm;
+            const int m = (MM > 0) ? 2 * MM + (A.has_gps ? 3 : 0) : 0;
+            s_cnt[0] = MM; s_cnt[1] = m; s_cnt[2] = (m + 15) & ~15;
+            if (first) {
+                ctl->K = K; ctl->n_state = M; ctl->n_map = Mm; ctl->n_new = N2;
+                ctl->m = m; ctl->m_pad = (m + 15) & ~15;
+            }
+        }
+    }
+    __syncthreads();
+    const int MM = s_cnt[0], m = s_cnt[1], m_pad = s_cnt[2];
+    if (m == 0) return;
+
+    // ---- workgroup (0,0): the full record for the kernels downstream
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        if (tid < MM) {
+            const HPair h = make_hpair(d, A, pose, s_pair_obs[tid], s_pair_id[tid], s_pair_state[tid]);
+            const int r0 = 2 * tid, r1 = r0 + 1;
+            for (int k = 0; k < 3; ++k) { ctl->ha[r0][k] = h.a0[k]; ctl->ha[r1][k] = h.a1[k]; }
+            ctl->hb[r0][0] = h.b0[0]; ctl->hb[r0][1] = h.b0[1]; ctl->hb[r1][0] = h.b1[0]; ctl->hb[r1][1] = h.b1[1];
+            ctl->hcol[r0] = h.col; ctl->hcol[r1] = h.col;
+            ctl->dz[r0] = h.dz0; ctl->dz[r1] = h.dz1;
+            ctl->qd[r0] = h.q0; ctl->qd[r1] = h.q1;
+        }
+        if (tid == 0 && A.has_gps && MM > 0) {                         // gps.cc:305-332
+#pragma clang fp contract(off)
+            const int r0 = 2 * MM;
+            for (int k = 0; k < 3; ++k) {
+                ctl->ha[r0 + k][0] = (k == 0); ctl->ha[r0 + k][1] = (k == 1); ctl->ha[r0 + k][2] = (k == 2);
+                ctl->hb[r0 + k][0] = 0; ctl->hb[r0 + k][1] = 0; ctl->hcol[r0 + k] = -1;
+            }
+            ctl->dz[r0] = A.gps[0] - pose[0];
+            ctl->dz[r0 + 1] = A.gps[1] - pose[1];
+            ctl->dz[r0 + 2] = yaw_innovation(A.gps[2] - pose[2]);
+            ctl->qd[r0] = 0.05 * 0.05; ctl->qd[r0 + 1] = 0.05 * 0.05; ctl->qd[r0 + 2] = 0.017 * 0.017;
+        }
+    }
+    if (c >= d.ld) return;
+
+    // ---- W(c, r) = sum_k P(c,k) H(r,k)  and  HPt(c, r) = sum_k H(r,k) P(k,c) for this workgroup's row pairs
     for (int pr = blockIdx.y; pr < m_pad / 2; pr += gridDim.y) {
         const int r0 = 2 * pr;
-        // both rows of a pair share the landmark columns (cc:275)
-        const int col = (r0 < m) ? ctl->hcol[r0] : -1;
+        double ha[2][3] = {{0, 0, 0}, {0, 0, 0}}, hb[2][2] = {{0, 0}, {0, 0}};
+        int col = -1;
+        if (pr < MM) {
+            const HPair h = make_hpair(d, A, pose, s_pair_obs[pr], s_pair_id[pr], s_pair_state[pr]);
+            for (int k = 0; k < 3; ++k) { ha[0][k] = h.a0[k]; ha[1][k] = h.a1[k]; }
+            hb[0][0] = h.b0[0]; hb[0][1] = h.b0[1]; hb[1][0] = h.b1[0]; hb[1][1] = h.b1[1];
+            col = h.col;
+        } else if (A.has_gps) {                                        // pose rows: unit vectors e_k
+            for (int rr = 0; rr < 2; ++rr) {
+                const int k = r0 + rr - 2 * MM;
+                if (k >= 0 && k < 3) ha[rr][k] = 1.0;
+            }
+        }
         const int cl = (col >= 0) ? col : 0;
         const double pl0 = P[cc + (size_t)cl * ld], pl1 = P[cc + (size_t)(cl + 1) * ld];
         const double ql0 = Pc[cl], ql1 = Pc[cl + 1];
@@ -726,11 +764,11 @@ __global__ __launch_bounds__(256) void k_gather(RekfDev d)
             const int r = r0 + rr;
             double v = 0, u = 0;
             if (valid && r < m) {
-                const double h0 = ctl->ha[r][0], h1 = ctl->ha[r][1], h2 = ctl->ha[r][2];
+                const double h0 = ha[rr][0], h1 = ha[rr][1], h2 = ha[rr][2];
                 v = p0 * h0; v += p1 * h1; v += p2 * h2;
                 u = h0 * q0; u += h1 * q1; u += h2 * q2;
-                if (ctl->hcol[r] >= 0) {
-                    const double g0 = ctl->hb[r][0], g1 = ctl->hb[r][1];
+                if (col >= 0) {
+                    const double g0 = hb[rr][0], g1 = hb[rr][1];
                     v += pl0 * g0; v += pl1 * g1;
                     u += g0 * ql0; u += g1 * ql1;
                 }
@@ -1342,11 +1380,10 @@ void rekf_launch_front_mb(const RekfDev &d, const RekfFrontArgs &a, int n_ub, hi
 {
     (void)n_ub;
     hipLaunchKernelGGL(k_front_mb, dim3(FRONT_MB), dim3(1024), 0, s, d, a);
-    hipLaunchKernelGGL(k_record, dim3(1), dim3(64), 0, s, d, a);
 }
-void rekf_launch_gather(const RekfDev &d, int n_ub, hipStream_t s)
+void rekf_launch_gather(const RekfDev &d, const RekfFrontArgs &a, int n_ub, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_gather, dim3((n_ub + 255) / 256, 32), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(k_gather, dim3((n_ub + 255) / 256, 32), dim3(256), 0, s, d, a);
 }
 void rekf_launch_solve(const RekfDev &d, hipStream_t s)
 {

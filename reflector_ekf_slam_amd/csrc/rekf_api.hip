@@ -35,6 +35,7 @@ struct rekf {
     double time;
     double vt[3];
     int n_ub;                  // host upper bound of the device-resident n
+    bool full;                 // a readback showed n == n_max: no landmark can ever be added again
     double *pose_staging;      // pinned, 12 doubles
     double *dev_out12;         // device scratch for k_predict_pose
     RekfCtl *ctl_staging;      // pinned copy of the control block
@@ -126,6 +127,7 @@ int pull_ctl(rekf_t *h)
     HIP_TRY(h, hipMemcpyAsync(h->ctl_staging, h->dev.ctl, sizeof(RekfCtl), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->n_ub = h->ctl_staging->n;
+    h->full = h->ctl_staging->n >= h->dev.n_max;
     return REKF_OK;
 }
 
@@ -165,6 +167,7 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
     h->time = opt->init_time;                         // cc:8
     h->vt[0] = h->vt[1] = h->vt[2] = 0.0;             // cc:6
     h->n_ub = 3;
+    h->full = false;
     h->prof_on = false;
     h->prof_mask = -1;
     h->prof_used = 0;
@@ -292,11 +295,13 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     { ProfScope ps(h, REKF_K_FRONT); rekf_launch_front_mb(h->dev, a, h->n_ub, h->stream); }
     h->time = t;                                      // cc:234
     const int n_ub = h->n_ub;
-    { ProfScope ps(h, REKF_K_GATHER); rekf_launch_gather(h->dev, n_ub, h->stream); }
+    { ProfScope ps(h, REKF_K_GATHER); rekf_launch_gather(h->dev, a, n_ub, h->stream); }
     { ProfScope ps(h, REKF_K_SOLVE); rekf_launch_solve(h->dev, h->stream); }
     { ProfScope ps(h, REKF_K_GAIN); rekf_launch_gain(h->dev, n_ub, h->stream); }
     { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_downdate(h->dev, n_ub, h->stream); }
-    { ProfScope ps(h, REKF_K_AUGMENT); rekf_launch_augment(h->dev, a, h->stream); }
+    // the state only grows: once a readback has shown it full, k_augment can never have work again
+    // (k_record drops the extra reflectors and raises REKF_FLAG_CAPACITY)
+    if (!h->full) { ProfScope ps(h, REKF_K_AUGMENT); rekf_launch_augment(h->dev, a, h->stream); }
     { ProfScope ps(h, REKF_K_EMPTY); }
     // the scan may have appended up to K reflectors; the exact n stays on the device
     int grown = n_ub + 2 * K;
@@ -387,6 +392,7 @@ int rekf_set_state(rekf_t *h, double t, int n, const double *mu, const double *s
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->time = t;
     h->n_ub = n;
+    h->full = n >= h->dev.n_max;
     if (vt3) { h->vt[0] = vt3[0]; h->vt[1] = vt3[1]; h->vt[2] = vt3[2]; }
     return REKF_OK;
 }
@@ -466,7 +472,7 @@ int rekf_debug_time_kernel(rekf_t *h, int kernel, int reps, int ablate, double *
     const int n_ub = h->n_ub;
     auto launch = [&]() {
         switch (kernel) {
-        case REKF_K_GATHER: rekf_launch_gather(dev, n_ub, h->stream); break;
+        case REKF_K_GATHER: break;   /* needs the scan's arguments: not re-launchable standalone */
         case REKF_K_SOLVE: rekf_launch_solve(dev, h->stream); break;
         case REKF_K_GAIN: rekf_launch_gain(dev, n_ub, h->stream); break;
         case REKF_K_DOWNDATE: rekf_launch_downdate(dev, n_ub, h->stream); break;
