@@ -293,6 +293,15 @@ class ReflectorEKFSLAM:
             out[name] = (us.value, cnt.value)
         return out
 
+    def time_kernel(self, name: str, reps: int = 200, ablate: int = 0) -> float:
+        """Average device time (us) of `reps` back-to-back launches of one kernel of the chain between ONE
+        pair of hipEvents on the handle's stream (rekf_debug_time_kernel).  Leaves the state meaningless."""
+        us = C.c_double()
+        self._L.rekf_debug_time_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        self._chk(self._L.rekf_debug_time_kernel(self._h, KERNELS[name], int(reps), int(ablate), C.byref(us)),
+                  "rekf_debug_time_kernel")
+        return us.value
+
     def device_layout(self):
         ld, nmax = C.c_int(), C.c_int()
         p, m = C.c_void_p(), C.c_void_p()
