@@ -475,17 +475,39 @@ __device__ static void block_argmin(double &v, int &j, BlockArgminScratch &s)
     v = s.rd; j = s.rj;
     __syncthreads();
 }
-__device__ static int block_sum(int c, BlockArgminScratch &s)
+// arg-min that also carries the runner-up value: (v, j) = smallest value / its first index, v2 = the
+// second smallest value over all candidates (the lanes' own runner-ups included)
+__device__ static inline void argmin2_combine(double &a1, int &ja, double &a2, double b1, int jb, double b2)
+{
+    const bool take = (jb >= 0) && (ja < 0 || b1 < a1 || (b1 == a1 && jb < ja));
+    const double lose = take ? a1 : b1;                 // the larger of the two minima
+    const double n2 = vmin_f64(vmin_f64(a2, b2), (ja >= 0 && jb >= 0) ? lose : 1e300);
+    if (take) { a1 = b1; ja = jb; }
+    a2 = n2;
+}
+__device__ static void block_argmin2(double &v, int &j, double &v2, BlockArgminScratch &s, double *s2)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, WAVE);
-    if (lane == 0) s.cnt[wave] = c;
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double ov = __shfl_xor(v, off, WAVE), ov2 = __shfl_xor(v2, off, WAVE);
+        const int oj = __shfl_xor(j, off, WAVE);
+        argmin2_combine(v, j, v2, ov, oj, ov2);
+    }
+    if (lane == 0) { s.d[wave] = v; s.j[wave] = j; s2[wave] = v2; }
     __syncthreads();
-    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += s.cnt[w]; s.rcnt = t; }
+    if (wave == 0) {
+        double x = (lane < 16) ? s.d[lane] : 0.0, x2 = (lane < 16) ? s2[lane] : 1e300;
+        int y = (lane < 16) ? s.j[lane] : -1;
+        for (int off = 8; off >= 1; off >>= 1) {
+            const double ov = __shfl_xor(x, off, WAVE), ov2 = __shfl_xor(x2, off, WAVE);
+            const int oj = __shfl_xor(y, off, WAVE);
+            argmin2_combine(x, y, x2, ov, oj, ov2);
+        }
+        if (lane == 0) { s.rd = x; s.rj = y; s2[16] = x2; }
+    }
     __syncthreads();
-    const int r = s.rcnt;
+    v = s.rd; j = s.rj; v2 = s2[16];
     __syncthreads();
-    return r;
 }
 
 __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
@@ -493,6 +515,7 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
     __shared__ Motion mo;
     __shared__ double pose[5];
     __shared__ BlockArgminScratch sc;
+    __shared__ double sc2[17];
     const int tid = threadIdx.x;
     const int b = blockIdx.x, nb = gridDim.x;
     RekfCtl *ctl = d.ctl;
@@ -591,12 +614,10 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
                 bj = (d2 < b1) ? j : bj;
                 b1 = vmin_f64(b1, d2);
             }
-            double g1 = b1; int gj = bj;
-            block_argmin(g1, gj, sc);
-            const double band = g1 * 1.000000000000002;
-            const int near = block_sum(((bj >= 0 && b1 <= band) ? 1 : 0) + ((b2 <= band) ? 1 : 0), sc);
+            double g1 = b1, g2 = b2; int gj = bj;
+            block_argmin2(g1, gj, g2, sc, sc2);                    // minimum, its first index, runner-up
             double best = sqrt(g1);
-            if (near > 1) {                                        // literal scan (uniform, rare)
+            if (g2 <= g1 * 1.000000000000002) {                    // literal scan (uniform, rare)
                 best = 0; gj = -1;
                 for (int j = tid; j < L; j += 1024) {
                     float lx, ly;
