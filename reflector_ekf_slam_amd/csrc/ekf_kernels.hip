@@ -1054,9 +1054,10 @@ __device__ static inline void dd_lds_barrier()
 // FAST = the whole innovation fits one full 64-wide k-chunk (m_pad == 64, i.e. 25..32 matched
 // observations: BASELINE.json's N=1024 x 32 configuration).  Its loop is peeled so that every
 // prefetch/consume pair is unconditional and hipcc's waitcnt pass can count them exactly.
-template <bool FAST>
+template <bool FAST, bool ABL>
 __device__ static void downdate_body(const RekfDev &d, double *dd_smem, int n, int m_pad)
 {
+    const int dbg = ABL ? d.dbg : 0;       // ablation hooks compile away in the production instance
     const int T = (n + DT - 1) / DT;
     const int nchunk = FAST ? 1 : (m_pad + DKC - 1) / DKC;
     // Tile assignment.  Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only):
@@ -1089,7 +1090,7 @@ __device__ static void downdate_body(const RekfDev &d, double *dd_smem, int n, i
 
     auto tile_IJ = [&](int tile, int &I, int &J) { const int jj = tile / i_n; I = i_lo + (tile - jj * i_n); J = j_lo + jj; };
     auto load_panels = [&](int item) {
-        if (d.dbg & 8) return;                 // ablation hook: skip the panel reads
+        if (dbg & 8) return;                 // ablation hook: skip the panel reads
         int I, J;
         tile_IJ(t_begin + item / nchunk, I, J);
         const int k0 = FAST ? 0 : (item % nchunk) * DKC;
@@ -1123,7 +1124,7 @@ __device__ static void downdate_body(const RekfDev &d, double *dd_smem, int n, i
         return P + (size_t)(DT * I + 32 * wi + 2 * idx) + (size_t)(DT * J + 32 * wj + 2 * kq) * ld;
     };
     auto load_p = [&](int tile) {
-        if (d.dbg & 2) {                       // ablation hook: skip the P reads
+        if (dbg & 2) {                       // ablation hook: skip the P reads
             for (int q = 0; q < 8; ++q) { pnext[q].x = 1e-3 * tile; pnext[q].y = 2e-3; }
             return;
         }
@@ -1149,7 +1150,7 @@ __device__ static void downdate_body(const RekfDev &d, double *dd_smem, int n, i
         const double *sK = dd_smem + (size_t)((item & 1) * DD_NBUF / 2) * 2 * DKC * 64, *sW = sK + DKC * 64;
         const double *aW = sW + 32 * wj + 2 * idx + kq * 64;        // A[j][k] = HP(k,j)
         const double *bK = sK + 32 * wi + 2 * idx + kq * 64;        // B[k][i] = Kn(i,k)
-        if (d.dbg & 4) return;                 // ablation hook: skip the MFMA loop
+        if (dbg & 4) return;                 // ablation hook: skip the MFMA loop
         if (FAST) {
             // fully unrolled, operands of k-step kk+1 are read from LDS before the MFMAs of step kk issue
             v2d a2 = *(const v2d *)(aW), b2 = *(const v2d *)(bK);
@@ -1178,7 +1179,7 @@ __device__ static void downdate_body(const RekfDev &d, double *dd_smem, int n, i
         }
     };
     auto store_tile = [&](int tile) {
-        if (d.dbg & 1) return;                 // ablation hook (rekf_debug_time_kernel): skip the write-back
+        if (dbg & 1) return;                 // ablation hook (rekf_debug_time_kernel): skip the write-back
         double *Pw = p_ptr(tile);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -1218,7 +1219,7 @@ __device__ static void downdate_body(const RekfDev &d, double *dd_smem, int n, i
             const double *kp = Kn + (size_t)(DT * In + 2 * (tid & 31)) + (size_t)(tid >> 5) * ld;
             const double *wp = HPt + (size_t)(DT * Jn + 2 * (tid & 31)) + (size_t)(tid >> 5) * ld;
             const double *Pn = p_ptr(tile + 1);
-            const bool no_p = (d.dbg & 2) != 0, no_panels = (d.dbg & 8) != 0, no_mfma = (d.dbg & 4) != 0;
+            const bool no_p = (dbg & 2) != 0, no_panels = (dbg & 8) != 0, no_mfma = (dbg & 4) != 0;
             const double *sK = dd_smem + (size_t)((item & 1) * DD_NBUF / 2) * 2 * DKC * 64, *sW = sK + DKC * 64;
             const double *aW = sW + 32 * wj + 2 * idx + kq * 64;
             const double *bK = sK + 32 * wi + 2 * idx + kq * 64;
@@ -1295,8 +1296,11 @@ __global__ __launch_bounds__(256, 2) void k_downdate(RekfDev d)
     const int m_pad = ctl->m_pad;
     if (ctl->m == 0) return;
     const int n = ctl->n;
-    if (m_pad == DKC) downdate_body<true>(d, dd_smem, n, m_pad);
-    else downdate_body<false>(d, dd_smem, n, m_pad);
+    if (d.dbg) {                                   // ablation runs (rekf_debug_time_kernel)
+        if (m_pad == DKC) downdate_body<true, true>(d, dd_smem, n, m_pad);
+        else downdate_body<false, true>(d, dd_smem, n, m_pad);
+    } else if (m_pad == DKC) downdate_body<true, false>(d, dd_smem, n, m_pad);
+    else downdate_body<false, false>(d, dd_smem, n, m_pad);
 }
 
 // ----------------------------------------------------------------------------
