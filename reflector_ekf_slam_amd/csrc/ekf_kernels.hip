@@ -1039,7 +1039,7 @@ __global__ __launch_bounds__(512) void k_gain(RekfDev d)
 #define DKC 64
 #define DD_STG (DKC * 32 / 256)      // 16-byte panel pieces per thread per panel
 #ifndef DD_NBUF
-#define DD_NBUF 1                    // LDS panel buffers per workgroup (1: 64 KiB, two workgroups per CU)
+#define DD_NBUF 2                    // LDS panel buffers per workgroup (2: 128 KiB, one workgroup per CU, one barrier per tile; 1: 64 KiB, two per CU)
 #endif
 #define DD_WG_PER_CU (DD_NBUF == 1 ? 2 : 1)
 
