@@ -309,3 +309,54 @@ def test_odometry_only_stretches_and_interleaving(oracle_lib):
     t, mu3, s3 = g.pose()
     mo, Po = o.state()
     assert np.abs(mu3 - mo[:3]).max() < TIGHT and np.abs(s3 - Po[:3, :3]).max() < 1e-12
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103, 104, 105, 106])
+def test_randomised_sessions_with_map_and_pose_observations(oracle_lib, seed):
+    """Randomised small sessions: random model, noise levels, obs counts (ragged, incl. empty scans),
+    optional pre-loaded map and pose observations, occasional time jumps backwards (Q8)."""
+    rng = np.random.default_rng(seed)
+    model = int(rng.integers(0, 2))
+    L = int(rng.integers(10, 60))
+    K = int(rng.integers(3, 20))
+    cfg = synth.SessionConfig(f"rnd{seed}", L, K, model, seed=seed, speed=float(rng.uniform(0.5, 2.0)), row_spacing=6.0,
+                              sigma_v=float(rng.uniform(0.02, 0.1)), sigma_w=float(rng.uniform(0.02, 0.1)),
+                              sigma_obs=float(rng.uniform(0.03, 0.08)))
+    sess = synth.make_session(cfg, max_scans=120)
+    g, o = _pair(cfg, sess)
+    use_map = bool(rng.integers(0, 2))
+    use_gps = bool(rng.integers(0, 2))
+    if use_map:
+        ids = rng.choice(L, size=max(2, L // 4), replace=False)
+        mxy = (sess.landmarks[ids] + rng.normal(0, 0.01, size=(ids.size, 2))).astype(np.float32)
+        mcov = np.tile(np.array([0.01, 0.0, 0.0, 0.01]), (ids.size, 1))
+        g.set_map(mxy, mcov); o.set_map(mxy, mcov)
+    first = True
+    worst = 0.0
+    for e in range(sess.n_events):
+        t = float(sess.ev_time[e])
+        if sess.ev_type[e] == synth.EV_ODOM:
+            g.handle_odometry(t, *sess.odom[e]); o.handle_odometry(t, *sess.odom[e])
+            continue
+        if first:
+            first = False
+            continue
+        ob = sess.obs_of(e)
+        r = rng.random()
+        if r < 0.05:
+            ob = ob[:0]                                   # empty cloud: predict only
+        elif r < 0.3:
+            ob = ob[: int(rng.integers(1, ob.shape[0] + 1))]   # ragged
+        if rng.random() < 0.03:
+            t -= 0.05                                     # stamped slightly in the past: negative dt
+        gps = (sess.true_pose[e] + rng.normal(0, [0.03, 0.03, 0.01])) if (use_gps and rng.random() < 0.5) else None
+        g.handle_observation(t, ob, gps); o.handle_observation(t, ob, gps)
+        a, b = norm_match(g.last_match()), norm_match(o.last_match())
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)), f"association differs at event {e}"
+        mg, mo = g.mu(), o.mu()
+        assert mg.shape == mo.shape
+        worst = max(worst, float(np.abs(mg - mo).max()))
+    assert worst < TIGHT
+    st = g.GetState()
+    mo, Po = o.state()
+    assert np.abs(st.sigma - Po).max() < 1e-10 and g.sync_code() == 0
