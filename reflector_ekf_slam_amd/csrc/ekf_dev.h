@@ -11,7 +11,8 @@
 //   W    [ld x MR_PAD]   W = P H^T  (column r = P * H(r,:)^T), column-major
 //   HPt  [ld x MR_PAD]   HPt = (H P)^T gathered from the ROWS of P, column-major
 //   Kn   [ld x MR_PAD]   Kn = -K = -W S^-1, column-major
-//   Sinv [MR_PAD x MR_PAD], y[MR_PAD] = S^-1 (z - zhat)
+//   Sinv [MR_PAD x MR_PAD] (row-major), y[MR_PAD] = S^-1 (z - zhat)
+//   Wc   rows {0,1,2} and the matched landmarks' rows of W, compact (k_gather -> k_solve; layout at RekfDev::Wc)
 //   ctl                  RekfCtl below: n, error flags, the scan record
 //
 // Rows/columns >= n of W, HPt and Kn are kept exactly zero so that the tile kernels
@@ -22,6 +23,8 @@
 #define REKF_MAX_OBS_DEV 64
 #define REKF_MAX_ROWS 128                           // 2 per match (+3 pose rows: then K <= 62)
 #define REKF_MR_PAD 128                             // leading dimension of Sinv
+#define REKF_WC_PAIRS (3 * REKF_MR_PAD)              // offset of the pair section of Wc
+#define REKF_WC_DOUBLES (3 * REKF_MR_PAD + REKF_MAX_OBS_DEV * REKF_MR_PAD * 2)
 
 enum { REKF_FLAG_CAPACITY = 1, REKF_FLAG_SINGULAR = 2 };
 
@@ -36,11 +39,9 @@ struct RekfCtl {
     int state_pairs[2 * REKF_MAX_OBS_DEV];
     int map_pairs[2 * REKF_MAX_OBS_DEV];
     int new_ids[REKF_MAX_OBS_DEV];
-    int hcol[REKF_MAX_ROWS];      // landmark column 3+2g of row r, or -1 (map / pose rows)
-    double ha[REKF_MAX_ROWS][3];  // H(r, 0..2)
-    double hb[REKF_MAX_ROWS][2];  // H(r, hcol..hcol+1)
-    double dz[REKF_MAX_ROWS];     // z - zhat
-    double qd[REKF_MAX_ROWS];     // diag(Q)
+    // H row r packed in 64 bytes: { H(r,0), H(r,1), H(r,2), H(r,col), H(r,col+1), Q(r,r), (z - zhat)(r), 0 }
+    // where col = 3 + 2*landmark for the rows of state matches (rows < 2*n_state); map and pose rows have no landmark block
+    double hrow[REKF_MAX_ROWS][8];
     // ---- hand-off between the multi-workgroup front kernel and k_record / k_gain ----
     double pose_pred[5];          // x, y, theta, cos(theta), sin(theta) after Predict (mu[0..2] is committed by k_gain)
     int pose_pending;
@@ -69,7 +70,9 @@ struct RekfDev {
     double *W;
     double *HPt;
     double *Kn;
-    double *Sinv;
+    double *Sinv;       // S^-1, ROW-major, ld REKF_MR_PAD
+    double *Wc;         // compact rows of W for k_solve: rows 0..2 as [3][MR_PAD], then per state pair p the two
+                        // landmark rows interleaved, [p][MR_PAD][2]  (REKF_WC_DOUBLES doubles)
     double *y;
     float *map_xy;      // M_map x 2
     double *map_cov;    // M_map x 4 row-major
@@ -83,7 +86,7 @@ struct RekfDev {
 void rekf_launch_front(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);
 void rekf_launch_front_mb(const RekfDev &d, const RekfFrontArgs &a, int n_ub, hipStream_t s);
 void rekf_launch_gather(const RekfDev &d, const RekfFrontArgs &a, int n_ub, hipStream_t s);
-void rekf_launch_solve(const RekfDev &d, hipStream_t s);
+void rekf_launch_solve(const RekfDev &d, int m_ub, hipStream_t s);
 void rekf_launch_gain(const RekfDev &d, int n_ub, hipStream_t s);
 void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s);
 void rekf_launch_augment(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);

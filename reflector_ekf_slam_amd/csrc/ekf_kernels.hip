@@ -156,44 +156,22 @@ __device__ static void wave_argmin(double &d, int &j)
 }
 
 // ----------------------------------------------------------------------------
-// k_front: one workgroup of 16 waves.
+// k_front: Predict alone (odometry messages, cc:208-223, and empty scans, cc:235-236), one
+// workgroup of 16 waves.  Scans with observations use k_front_mb.
 // ----------------------------------------------------------------------------
-#define LM_LDS_MAX 4096       // landmarks kept as float32 pairs in LDS (32 KiB); beyond that: global loop
 #define COV_PF 3              // covariance-predict operands prefetched per thread (covers n <= 3072)
 __global__ __launch_bounds__(1024) void k_front(RekfDev d, RekfFrontArgs A)
 {
     __shared__ Motion mo;
     __shared__ double pose[5];                 // x, y, theta, cos(theta), sin(theta) after Predict
-    __shared__ int s_kind[REKF_MAX_OBS_DEV];   // 0 map match, 1 state match, 2 new
-    __shared__ int s_idx[REKF_MAX_OBS_DEV];
-    __shared__ int s_pair_obs[REKF_MAX_OBS_DEV], s_pair_id[REKF_MAX_OBS_DEV], s_pair_state[REKF_MAX_OBS_DEV];
-    __shared__ int s_counts[4];
-    __shared__ float s_lm[2 * LM_LDS_MAX];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR)
     RekfCtl *ctl = d.ctl;
     double *__restrict__ P = d.P;
     double *mu = d.mu;
     const size_t ld = (size_t)d.ld;
     const int n = ctl->n;
-    const int L = (n - 3) / 2;
-    const bool lm_in_lds = L <= LM_LDS_MAX;
-#ifdef REKF_DEBUG_TIMING
-    long long tq[6]; tq[0] = clock64();
-#define TMARK(i) tq[i] = clock64()
-#else
-#define TMARK(i)
-#endif
-
-    // ---- everything that only depends on the OLD state is put in flight first:
-    // (1) landmark means -> LDS as float32 (the matcher casts them to float, cc:431; Predict
-    //     does not touch them), (2) the covariance-predict operands, (3) the pose block.
-    if (A.is_obs && A.K > 0 && lm_in_lds)
-        for (int j = tid; j < L; j += 1024) {
-            s_lm[2 * j] = (float)mu[3 + 2 * j];
-            s_lm[2 * j + 1] = (float)mu[4 + 2 * j];
-        }
+    // ---- the covariance-predict operands and the pose block go in flight first
     double c0[COV_PF], c1[COV_PF], c2[COV_PF], r0[COV_PF], r1[COV_PF], r2[COV_PF];
 #pragma unroll
     for (int t = 0; t < COV_PF; ++t) {
@@ -210,7 +188,6 @@ __global__ __launch_bounds__(1024) void k_front(RekfDev d, RekfFrontArgs A)
         motion_terms(A, mu2, mo);
     }
     __syncthreads();
-    TMARK(1);
 
     // ---- Predict, covariance: P <- G P G^T + Gu Qu Gu^T.  G = I + a e0 e2^T + b e1 e2^T
     // touches rows 0,1 and columns 0,1 only (the reference multiplies dense n x n, cc:178/202).
@@ -252,7 +229,6 @@ __global__ __launch_bounds__(1024) void k_front(RekfDev d, RekfFrontArgs A)
         }
     }
     __syncthreads();
-    TMARK(2);
     if (!A.is_obs) return;                    // odometry path: HandleOdometryMessage cc:208-223
 
     const int K = A.K;
@@ -263,184 +239,7 @@ __global__ __launch_bounds__(1024) void k_front(RekfDev d, RekfFrontArgs A)
         return;
     }
 
-    // ---- ReflectorMatch (cc:370-455): wave w owns observations w, w+16, w+32, w+48 and sweeps
-    // the candidates once for all of them (lanes over candidates, landmarks read once).
-    const int M_ = d.M_map;
-    {
-        constexpr int OQ = REKF_MAX_OBS_DEV / 16;
-        float gx[OQ], gy[OQ];
-        int kind[OQ], best_j[OQ];
-#pragma unroll
-        for (int q = 0; q < OQ; ++q) {
-            const int i = wave + 16 * q;
-            kind[q] = 2; best_j[q] = -1;
-            gx[q] = 0.f; gy[q] = 0.f;
-            if (i < K) obs_to_global(pose[0], pose[1], pose[3], pose[4], A.obs[2 * i], A.obs[2 * i + 1], gx[q], gy[q]);
-        }
-        if (M_ > 0) {                                              // cc:401-425 (pre-loaded map first)
-#pragma unroll
-            for (int q = 0; q < OQ; ++q) {
-#pragma clang fp contract(off)
-                const int i = wave + 16 * q;
-                if (i >= K) continue;
-                double best = 0; int bj = -1;
-                for (int j = lane; j < M_; j += WAVE) {
-                    const double *S = d.map_cov + 4 * (size_t)j;
-                    const float ex = d.map_xy[2 * j] - gx[q];      // float32 subtract (cc:408)
-                    const float ey = d.map_xy[2 * j + 1] - gy[q];
-                    const double dx = (double)ex, dy = (double)ey;
-                    const double t0 = dx * S[0] + dy * S[2];
-                    const double t1 = dx * S[1] + dy * S[3];
-                    const double dist = sqrt(t0 * dx + t1 * dy);   // delta Sigma delta^T (cc:411)
-                    if (bj < 0 || dist < best) { best = dist; bj = j; }
-                }
-                wave_argmin(best, bj);
-                if (bj >= 0 && best < 0.05) { kind[q] = 0; best_j[q] = bj; }   // cc:420
-            }
-        }
-        if (L > 0) {                                               // cc:426-451
-#pragma clang fp contract(off)
-            // dist = sqrt(dx*dx + dy*dy) (cc:437), first minimum in index order.  sqrt is monotone
-            // and correctly rounded, so the arg-min runs on the squared distances; every lane also
-            // keeps its runner-up so that a second candidate inside a 2e-15 relative band above the
-            // minimum (where sqrt could merge two values) is detected; only then (never, for real
-            // maps) is the literal sqrt-per-candidate scan executed.
-            auto lm_of = [&](int j, float &lx, float &ly) {
-                if (lm_in_lds) { lx = s_lm[2 * j]; ly = s_lm[2 * j + 1]; }
-                else { lx = (float)mu[3 + 2 * j]; ly = (float)mu[4 + 2 * j]; }   // cc:431
-            };
-            double b1[OQ], b2[OQ];                                 // lane-local minimum and runner-up
-            int bj[OQ];
-#pragma unroll
-            for (int q = 0; q < OQ; ++q) { b1[q] = 1e300; b2[q] = 1e300; bj[q] = -1; }
-            const int nq = (K - wave + 15) / 16;                   // observations this wave owns (uniform)
-            for (int j = lane; j < L; j += WAVE) {
-                float lx, ly;
-                lm_of(j, lx, ly);
-#pragma unroll
-                for (int q = 0; q < OQ; ++q) {
-                    if (q < nq) {
-                        const float ex = gx[q] - lx;               // cc:433
-                        const float ey = gy[q] - ly;
-                        const double dx = (double)ex, dy = (double)ey;
-                        const double d2 = dx * dx + dy * dy;
-                        b2[q] = vmin_f64(b2[q], vmax_f64(d2, b1[q]));
-                        bj[q] = (d2 < b1[q]) ? j : bj[q];          // strict: first index wins inside a lane
-                        b1[q] = vmin_f64(b1[q], d2);
-                    }
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < OQ; ++q) {
-                const int i = wave + 16 * q;
-                if (i >= K || kind[q] != 2) continue;              // wave-uniform
-                double g1 = b1[q]; int gj = bj[q];
-                wave_argmin(g1, gj);
-                const double band = g1 * 1.000000000000002;
-                int near = ((bj[q] >= 0 && b1[q] <= band) ? 1 : 0) + ((b2[q] <= band) ? 1 : 0);
-                for (int off = 32; off >= 1; off >>= 1) near += __shfl_xor(near, off, WAVE);
-                double best = sqrt(g1);
-                if (near > 1) {                                    // literal scan (wave-uniform, rare)
-                    best = 0; gj = -1;
-                    for (int j = lane; j < L; j += WAVE) {
-                        float lx, ly;
-                        lm_of(j, lx, ly);
-                        const float ex = gx[q] - lx, ey = gy[q] - ly;
-                        const double dx = (double)ex, dy = (double)ey;
-                        const double dist = sqrt(dx * dx + dy * dy);   // cc:437
-                        if (gj < 0 || dist < best) { best = dist; gj = j; }
-                    }
-                    wave_argmin(best, gj);
-                }
-                if (gj >= 0 && best < 0.6) { kind[q] = 1; best_j[q] = gj; }   // cc:446
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < OQ; ++q) {
-            const int i = wave + 16 * q;
-            if (i < K && lane == 0) { s_kind[i] = kind[q]; s_idx[i] = best_j[q]; }
-        }
-    }
-    __syncthreads();
-    TMARK(3);
-
-    // ---- ordered compaction into the three lists (obs order preserved)
-    if (wave == 0) {
-        const int kind = (lane < K) ? s_kind[lane] : -1;
-        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        const unsigned long long ms = __ballot(kind == 1);
-        const unsigned long long mm = __ballot(kind == 0);
-        const unsigned long long mn = __ballot(kind == 2);
-        const int M = __popcll(ms), Mm = __popcll(mm);
-        int N2 = __popcll(mn);
-        const int room = (d.n_max - n) / 2;
-        if (N2 > room) {                                           // capacity guard (ours)
-            if (lane == 0) atomicOr(&ctl->err, REKF_FLAG_CAPACITY);
-            N2 = room;
-        }
-        if (kind == 1) {
-            const int p = __popcll(ms & lt);
-            ctl->state_pairs[2 * p] = lane; ctl->state_pairs[2 * p + 1] = s_idx[lane];
-            s_pair_obs[p] = lane; s_pair_id[p] = s_idx[lane]; s_pair_state[p] = 1;
-        } else if (kind == 0) {
-            const int p = __popcll(mm & lt);
-            ctl->map_pairs[2 * p] = lane; ctl->map_pairs[2 * p + 1] = s_idx[lane];
-            s_pair_obs[M + p] = lane; s_pair_id[M + p] = s_idx[lane]; s_pair_state[M + p] = 0;
-        } else if (kind == 2) {
-            const int p = __popcll(mn & lt);
-            if (p < N2) ctl->new_ids[p] = lane;
-        }
-        if (lane == 0) {
-            const int MM = M + Mm;
-            const int m = (MM > 0) ? 2 * MM + (A.has_gps ? 3 : 0) : 0;
-            ctl->K = K; ctl->n_state = M; ctl->n_map = Mm; ctl->n_new = N2;
-            ctl->m = m; ctl->m_pad = (m + 15) & ~15;
-            s_counts[0] = M; s_counts[1] = Mm; s_counts[2] = m;
-        }
-    }
-    __syncthreads();
-
-    TMARK(4);
-    // ---- H rows, z - zhat, Q (cc:248-304): row pair p per thread
-    const int M = s_counts[0], MM = s_counts[0] + s_counts[1];
-    if (tid < MM) {
-#pragma clang fp contract(off)
-        const int p = tid;
-        const int local_id = s_pair_obs[p], global_id = s_pair_id[p], is_state = s_pair_state[p];
-        const double c = pose[3], s = pose[4];                      // cc:252-253
-        const double z0 = (double)A.obs[2 * local_id], z1 = (double)A.obs[2 * local_id + 1];
-        double lx, ly;
-        if (is_state) { lx = mu[3 + 2 * global_id]; ly = mu[4 + 2 * global_id]; }
-        else { lx = (double)d.map_xy[2 * global_id]; ly = (double)d.map_xy[2 * global_id + 1]; }
-        const double dx = lx - pose[0], dy = ly - pose[1];         // cc:267-268
-        const double zh0 = dx * c + dy * s, zh1 = -dx * s + dy * c; // cc:269-270
-        const int r0 = 2 * p, r1 = 2 * p + 1;
-        ctl->ha[r0][0] = -c; ctl->ha[r0][1] = -s; ctl->ha[r0][2] = -dx * s + dy * c;   // A_i cc:272-273
-        ctl->ha[r1][0] = s;  ctl->ha[r1][1] = -c; ctl->ha[r1][2] = -dx * c - dy * s;
-        ctl->hb[r0][0] = c;  ctl->hb[r0][1] = s;                   // B cc:255 (state rows only, cc:275)
-        ctl->hb[r1][0] = -s; ctl->hb[r1][1] = c;
-        const int col = is_state ? 3 + 2 * global_id : -1;
-        ctl->hcol[r0] = col; ctl->hcol[r1] = col;
-        ctl->dz[r0] = z0 - zh0; ctl->dz[r1] = z1 - zh1;
-        ctl->qd[r0] = A.obs_cov; ctl->qd[r1] = A.obs_cov;          // cc:276 / :302
-    }
-    if (tid == 0 && A.has_gps && MM > 0) {                         // gps.cc:305-332
-#pragma clang fp contract(off)
-        const int r0 = 2 * MM;
-        for (int k = 0; k < 3; ++k) {
-            ctl->ha[r0 + k][0] = (k == 0); ctl->ha[r0 + k][1] = (k == 1); ctl->ha[r0 + k][2] = (k == 2);
-            ctl->hb[r0 + k][0] = 0; ctl->hb[r0 + k][1] = 0; ctl->hcol[r0 + k] = -1;
-        }
-        ctl->dz[r0] = A.gps[0] - pose[0];
-        ctl->dz[r0 + 1] = A.gps[1] - pose[1];
-        ctl->dz[r0 + 2] = yaw_innovation(A.gps[2] - pose[2]);
-        ctl->qd[r0] = 0.05 * 0.05; ctl->qd[r0 + 1] = 0.05 * 0.05; ctl->qd[r0 + 2] = 0.017 * 0.017;
-    }
-    (void)M;
-#ifdef REKF_DEBUG_TIMING
-    __syncthreads();
-    if (tid == 0) { tq[5] = clock64(); for (int i = 1; i < 6; ++i) ctl->dbg[1 + i] = tq[i] - tq[0]; }
-#endif
+    // scans with K > 0 never come here: the host routes them to k_front_mb + k_gather
 }
 
 // ----------------------------------------------------------------------------
@@ -739,27 +538,35 @@ __global__ __launch_bounds__(256) void k_gather(RekfDev d, RekfFrontArgs A)
     if (blockIdx.x == 0 && blockIdx.y == 0) {
         if (tid < MM) {
             const HPair h = make_hpair(d, A, pose, s_pair_obs[tid], s_pair_id[tid], s_pair_state[tid]);
-            const int r0 = 2 * tid, r1 = r0 + 1;
-            for (int k = 0; k < 3; ++k) { ctl->ha[r0][k] = h.a0[k]; ctl->ha[r1][k] = h.a1[k]; }
-            ctl->hb[r0][0] = h.b0[0]; ctl->hb[r0][1] = h.b0[1]; ctl->hb[r1][0] = h.b1[0]; ctl->hb[r1][1] = h.b1[1];
-            ctl->hcol[r0] = h.col; ctl->hcol[r1] = h.col;
-            ctl->dz[r0] = h.dz0; ctl->dz[r1] = h.dz1;
-            ctl->qd[r0] = h.q0; ctl->qd[r1] = h.q1;
+            double *h0 = ctl->hrow[2 * tid], *h1 = ctl->hrow[2 * tid + 1];
+            h0[0] = h.a0[0]; h0[1] = h.a0[1]; h0[2] = h.a0[2]; h0[3] = h.b0[0]; h0[4] = h.b0[1]; h0[5] = h.q0; h0[6] = h.dz0; h0[7] = 0;
+            h1[0] = h.a1[0]; h1[1] = h.a1[1]; h1[2] = h.a1[2]; h1[3] = h.b1[0]; h1[4] = h.b1[1]; h1[5] = h.q1; h1[6] = h.dz1; h1[7] = 0;
         }
-        if (tid == 0 && A.has_gps && MM > 0) {                         // gps.cc:305-332
+        if (tid < 3 && A.has_gps && MM > 0) {                          // gps.cc:305-332, pose row k = tid
 #pragma clang fp contract(off)
-            const int r0 = 2 * MM;
-            for (int k = 0; k < 3; ++k) {
-                ctl->ha[r0 + k][0] = (k == 0); ctl->ha[r0 + k][1] = (k == 1); ctl->ha[r0 + k][2] = (k == 2);
-                ctl->hb[r0 + k][0] = 0; ctl->hb[r0 + k][1] = 0; ctl->hcol[r0 + k] = -1;
-            }
-            ctl->dz[r0] = A.gps[0] - pose[0];
-            ctl->dz[r0 + 1] = A.gps[1] - pose[1];
-            ctl->dz[r0 + 2] = yaw_innovation(A.gps[2] - pose[2]);
-            ctl->qd[r0] = 0.05 * 0.05; ctl->qd[r0 + 1] = 0.05 * 0.05; ctl->qd[r0 + 2] = 0.017 * 0.017;
+            double *hr = ctl->hrow[2 * MM + tid];
+            hr[0] = (tid == 0); hr[1] = (tid == 1); hr[2] = (tid == 2); hr[3] = 0; hr[4] = 0;
+            hr[5] = (tid == 2) ? 0.017 * 0.017 : 0.05 * 0.05;
+            const double e0 = A.gps[0] - pose[0], e1 = A.gps[1] - pose[1], e2 = yaw_innovation(A.gps[2] - pose[2]);
+            hr[6] = (tid == 0) ? e0 : ((tid == 1) ? e1 : e2);             // no dynamic indexing of A / pose
+            hr[7] = 0;
         }
     }
     if (c >= d.ld) return;
+    // rows of W that S = H W needs ({0,1,2} and the matched landmarks' rows) also go to the compact,
+    // row-major copy Wc (slot 3+2p+{0,1} for state pair p) that k_solve reads coalesced
+    int slot = (valid && c < 3) ? c : -1;
+    bool dup = false;                       // two observations matched to this landmark (the reference allows it)
+    if (valid && c >= 3) {
+        for (int p = 0; p < MM && s_pair_state[p]; ++p) {                 // state pairs come first
+            const int dc = c - (3 + 2 * s_pair_id[p]);
+            if (dc == 0 || dc == 1) {
+                if (slot < 0) slot = 3 + 2 * p + dc;
+                else dup = true;
+            }
+        }
+    }
+    double *__restrict__ Wc = d.Wc;
 
     // ---- W(c, r) = sum_k P(c,k) H(r,k)  and  HPt(c, r) = sum_k H(r,k) P(k,c) for this workgroup's row pairs
     for (int pr = blockIdx.y; pr < m_pad / 2; pr += gridDim.y) {
@@ -772,9 +579,12 @@ __global__ __launch_bounds__(256) void k_gather(RekfDev d, RekfFrontArgs A)
             hb[0][0] = h.b0[0]; hb[0][1] = h.b0[1]; hb[1][0] = h.b1[0]; hb[1][1] = h.b1[1];
             col = h.col;
         } else if (A.has_gps) {                                        // pose rows: unit vectors e_k
+#pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
-                const int k = r0 + rr - 2 * MM;
-                if (k >= 0 && k < 3) ha[rr][k] = 1.0;
+                const int k = r0 + rr - 2 * MM;                            // no dynamic register indexing
+                ha[rr][0] = (k == 0) ? 1.0 : 0.0;
+                ha[rr][1] = (k == 1) ? 1.0 : 0.0;
+                ha[rr][2] = (k == 2) ? 1.0 : 0.0;
             }
         }
         const int cl = (col >= 0) ? col : 0;
@@ -796,156 +606,278 @@ __global__ __launch_bounds__(256) void k_gather(RekfDev d, RekfFrontArgs A)
             }
             W[c + (size_t)r * ld] = v;
             HPt[c + (size_t)r * ld] = u;
+            if (slot >= 0) {
+                if (slot < 3) Wc[slot * REKF_MR_PAD + r] = v;
+                else Wc[REKF_WC_PAIRS + ((size_t)((slot - 3) >> 1) * REKF_MR_PAD + r) * 2 + ((slot - 3) & 1)] = v;
+                if (dup) {
+                    for (int p = (slot - 3) / 2 + 1; p < MM && s_pair_state[p]; ++p) {
+                        const int dc = c - (3 + 2 * s_pair_id[p]);
+                        if (dc == 0 || dc == 1) Wc[REKF_WC_PAIRS + ((size_t)p * REKF_MR_PAD + r) * 2 + dc] = v;
+                    }
+                }
+            }
         }
     }
 }
 
 // ----------------------------------------------------------------------------
-// k_solve: S = H W + Q (m x m), S^-1 by Gauss-Jordan, y = S^-1 dz.
-// One workgroup of 4 waves (one per SIMD) as a 16x16 thread grid; thread (ti,tj)
-// keeps S(ti+16a, tj+16b) in registers, so one elimination step costs NB*NB
-// FMAs per lane; only row k and column k travel through LDS (ping-pong buffers,
-// ONE barrier per step).  The 64 (128) steps are inherently sequential: this
-// kernel is latency-, not throughput-bound.
+// k_solve: S = H W + Q (m x m), S^-1 by block Gauss-Jordan, y = S^-1 dz.
+//
+// The inverse is a chain of m sequential pivots, so the kernel is latency-bound;
+// the design minimises what sits on that chain:
+//   * S lives in registers as 16x16 blocks in the v_mfma_f64_16x16x4_f64 C/D
+//     layout (lane (g,c) = (lane>>4, lane&15), register r <-> element (g+4r, c));
+//     wave w owns block COLUMN w (one wave per SIMD for m <= 64).
+//   * Block step K: wave K publishes its column blocks S(i,K) to LDS, inverts
+//     the diagonal block entirely in-wave (2x2 pivots, 8 steps, operands
+//     broadcast with v_readlane / ds_bpermute: no LDS round trip, no barrier)
+//     and publishes D^-1: ONE LDS barrier per block step.  Every other wave j
+//     then forms its block of the pivot row, R = D^-1 S(K,j), and applies
+//     S(i,j) -= S(i,K) R with MFMA; wave K+1 does block (K+1,K+1) first and goes
+//     straight into the next leaf, so the chain per step is leaf + 2 block
+//     products -- the other 4*NBR-2 products run in the shadow of the leaf.
+//     A block in C layout is directly an MFMA B operand; the A operand is the
+//     C layout of the transposed block, read with transposed addressing from
+//     the row-major 16x17 patch the owner published.
+//   * S is built from Wc, the compact copy of the rows {0,1,2, matched
+//     landmark rows} of W that k_gather emits (coalesced, one round trip).
+// S^-1 is stored ROW-major (ld REKF_MR_PAD): coalesced here and in k_gain.
 // ----------------------------------------------------------------------------
-template <int NB>
-__device__ static void solve_body(const RekfDev &d, int m, double (*rowbuf)[2 * REKF_MR_PAD],
-                                  double (*colbuf)[2 * REKF_MR_PAD])
+__device__ static inline double bperm_f64(double v, int byte_addr)
 {
-    RekfCtl *ctl = d.ctl;
-    const int tid = threadIdx.x;
-    const int ti = tid >> 4, tj = tid & 15;
-    const size_t ld = (size_t)d.ld;
-    const double *__restrict__ W = d.W;
-    double S[NB][NB];
-    {
-        double h0[NB], h1[NB], h2[NB], g0[NB], g1[NB], qd[NB];
-        int hc[NB];
+    const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ static inline void lds_barrier()
+{
+    // LDS-only workgroup barrier: does not wait for outstanding global memory traffic (vmcnt)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// In-wave Gauss-Jordan inverse of one 16x16 block in C layout, 2x2 pivots (the rows come in (x,y)
+// pairs).  Step with pivot block K = {k,k+1}, D = A(K,K): with the pivot columns replaced by unit
+// vectors, R = D^-1 A(K,:), A(i,:) -= A(i,K) R for i not in K, A(K,:) = R.  Pivot rows and columns
+// are exchanged through a 64-double LDS scratch private to the wave (LDS operations of one wave
+// execute in order: no barrier, 5 writes + 7 16-byte reads per step).  Returns true when a pivot
+// block is not positive definite (S must be: it is H P H^T + Q).
+#define REKF_LEAF_SCRATCH 64
+__device__ static inline bool leaf_inverse16(v4d &a, int g, int c, double *lp)
+{
+    bool bad = false;
+    double *rowbuf = lp;            // [col c][row k / k+1]
+    double *colbuf = lp + 32;       // [g][r][col k / k+1]
 #pragma unroll
-        for (int a = 0; a < NB; ++a) {
-            const int i = ti + 16 * a;
-            const bool in = i < m;
-            h0[a] = in ? ctl->ha[i][0] : 0.0; h1[a] = in ? ctl->ha[i][1] : 0.0; h2[a] = in ? ctl->ha[i][2] : 0.0;
-            hc[a] = in ? ctl->hcol[i] : -1;
-            g0[a] = (hc[a] >= 0) ? ctl->hb[i][0] : 0.0; g1[a] = (hc[a] >= 0) ? ctl->hb[i][1] : 0.0;
-            qd[a] = in ? ctl->qd[i] : 0.0;
-            if (hc[a] < 0) hc[a] = 0;              // harmless in-bounds address, coefficient is 0
+    for (int kk = 0; kk < 8; ++kk) {
+        const int k = 2 * kk, rk = k >> 2, gk = k & 3;      // rows k, k+1 live in lane groups gk, gk+1, register rk
+        if (g == gk || g == gk + 1) rowbuf[2 * c + (g - gk)] = a[rk];
+        if (c == k || c == k + 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) colbuf[(4 * g + r) * 2 + (c - k)] = a[r];
         }
+        __builtin_amdgcn_wave_barrier();
+        const v2d dA = *(const v2d *)(rowbuf + 2 * k), dB = *(const v2d *)(rowbuf + 2 * k + 2);
+        const v2d xx = *(const v2d *)(rowbuf + 2 * c);
+        v2d ff[4];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int j = tj + 16 * b;
-            const double *__restrict__ w = W + (size_t)((j < m) ? j : 0) * ld;     // column j of W
-            const double w0 = w[0], w1 = w[1], w2 = w[2];
+        for (int r = 0; r < 4; ++r) ff[r] = *(const v2d *)(colbuf + (4 * g + r) * 2);
+        __builtin_amdgcn_wave_barrier();
+        const double d00 = dA.x, d10 = dA.y, d01 = dB.x, d11 = dB.y;
+        const double det = d00 * d11 - d01 * d10;
+        if (!(det > 0.0) || !(d00 > 0.0)) bad = true;
+        double q = __builtin_amdgcn_rcp(det);               // 1/det: hardware reciprocal + two Newton steps
+        q = fma(q, fma(-det, q, 1.0), q);
+        q = fma(q, fma(-det, q, 1.0), q);
+        const double i00 = d11 * q, i01 = -d01 * q, i10 = -d10 * q, i11 = d00 * q;
+        const bool pc0 = c == k, pc1 = c == k + 1;          // pivot columns act as unit vectors
+        double x0 = xx.x, x1 = xx.y;
+        if (pc0) { x0 = 1.0; x1 = 0.0; }
+        if (pc1) { x0 = 0.0; x1 = 1.0; }
+        const double R0 = i00 * x0 + i01 * x1, R1 = i10 * x0 + i11 * x1;
 #pragma unroll
-            for (int a = 0; a < NB; ++a) {
-                const int i = ti + 16 * a;
-                double v = h0[a] * w0;
-                v += h1[a] * w1;
-                v += h2[a] * w2;
-                v += g0[a] * w[hc[a]];
-                v += g1[a] * w[hc[a] + 1];
-                if (i == j) v += qd[a];
-                if (i >= m || j >= m) v = (i == j) ? 1.0 : 0.0;
-                S[a][b] = v;
+        for (int r = 0; r < 4; ++r) {
+            const double base = (pc0 || pc1) ? 0.0 : a[r];
+            double v = fma(-ff[r].y, R1, fma(-ff[r].x, R0, base));
+            if (r == rk) v = (g == gk) ? R0 : ((g == gk + 1) ? R1 : v);
+            a[r] = v;
+        }
+    }
+    return bad;
+}
+
+// 16x17 row-major LDS patch <-> C layout; read_patch_T gives the C layout of the TRANSPOSED block,
+// i.e. the block as an MFMA A operand (register q = k-slice q).
+#define REKF_PATCH (16 * 17)
+__device__ static inline void write_patch(double *patch, const v4d &a, int g, int c)
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r) patch[(g + 4 * r) * 17 + c] = a[r];
+}
+__device__ static inline v4d read_patch_T(const double *patch, int g, int c)
+{
+    v4d t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = patch[c * 17 + g + 4 * q];
+    return t;
+}
+
+// acc + A B for 16x16 blocks: At = C layout of A^T (register q = k-slice q), B in C layout.
+__device__ static inline v4d block_mma(const v4d &At, const v4d &B, v4d acc)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(At[q], B[q], acc, 0, 0, 0);
+    return acc;
+}
+
+#ifdef REKF_DEBUG_TIMING
+__device__ static inline long long pinned_clock()
+{
+    __builtin_amdgcn_sched_barrier(0);
+    const long long t = clock64();
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#endif
+// same product as two independent accumulation chains (a dependent MFMA costs ~100 cycles, an
+// independent one 64): for the two products that sit on the pivot chain
+__device__ static inline v4d block_mma2(const v4d &At, const v4d &B, v4d acc)
+{
+    v4d acc1 = {0, 0, 0, 0};
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(At[0], B[0], acc, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(At[2], B[2], acc1, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(At[1], B[1], acc, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(At[3], B[3], acc1, 0, 0, 0);
+    return acc + acc1;
+}
+
+template <int NBR>
+__global__ __launch_bounds__(64 * NBR) void k_solve(RekfDev d)
+{
+    __shared__ double s_col[2][NBR + 1][REKF_PATCH];   // pivot column blocks S(i,K), slot NBR = D^-1; ping-pong over block steps
+    __shared__ double s_leaf[NBR][REKF_LEAF_SCRATCH];  // leaf exchange scratch, private per wave
+    __shared__ __attribute__((aligned(16))) double s_coef[8 * REKF_MAX_ROWS];   // ctl->hrow staged: 64-byte packed H rows
+    RekfCtl *ctl = d.ctl;
+    const int m = ctl->m;
+    if (m == 0) return;
+    const int nbr = ctl->m_pad >> 4;                 // live blocks per side (<= NBR: the host sized the launch from 2K+3)
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane >> 4, c = lane & 15;
+    if (w >= nbr) return;                            // ended waves do not take part in s_barrier
+#ifdef REKF_DEBUG_TIMING
+    const long long tsc = pinned_clock();
+#endif
+    v4d S[NBR];                                      // S[bi] = block (bi, w)
+    const int j = 16 * w + c;                        // this lane's column of S
+    {
+        // every global load below depends only on kernel arguments: ONE memory round trip
+        const int rows_state = 2 * ctl->n_state;     // rows [0, rows_state) carry landmark columns
+        const double *__restrict__ Wc = d.Wc;
+        const v2d stage = ((const v2d *)&ctl->hrow[0][0])[threadIdx.x];     // 16*nbr rows x 64 B over 64*nbr threads
+        const double w0 = Wc[j], w1 = Wc[REKF_MR_PAD + j], w2 = Wc[2 * REKF_MR_PAD + j];
+        v2d wl[NBR][4];
+#pragma unroll
+        for (int bi = 0; bi < NBR; ++bi) {
+            if (bi < nbr) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int pair = (16 * bi + g + 4 * r) >> 1;
+                    wl[bi][r] = *(const v2d *)(Wc + REKF_WC_PAIRS + ((size_t)pair * REKF_MR_PAD + j) * 2);
+                }
+            }
+        }
+        ((v2d *)s_coef)[threadIdx.x] = stage;
+        __syncthreads();
+#pragma unroll
+        for (int bi = 0; bi < NBR; ++bi) {
+            if (bi < nbr) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * bi + g + 4 * r;
+                    const v2d ha01 = *(const v2d *)(s_coef + 8 * i), ha2b0 = *(const v2d *)(s_coef + 8 * i + 2);
+                    const v2d b1q = *(const v2d *)(s_coef + 8 * i + 4);
+                    double v = ha01.x * w0;
+                    v += ha01.y * w1;
+                    v += ha2b0.x * w2;
+                    if (i < rows_state) { v += ha2b0.y * wl[bi][r].x; v += b1q.x * wl[bi][r].y; }
+                    if (i == j) v += b1q.y;
+                    if (i >= m || j >= m) v = (i == j) ? 1.0 : 0.0;
+                    S[bi][r] = v;
+                }
             }
         }
     }
     bool bad = false;
+    double *lp = s_leaf[w];
 #ifdef REKF_DEBUG_TIMING
-    const long long t0c = clock64(), t0w = wall_clock64();
+    const long long t0c = pinned_clock(), t0w = wall_clock64();
 #endif
-    // Block Gauss-Jordan with 2x2 pivots (rows come in pairs anyway): m/2 sequential steps instead
-    // of m -- the step is a latency chain (LDS hand-off, barrier, reciprocal), not a throughput one.
-    // Step with pivot block K = {k, k+1}, D = S(K,K):  with the pivot columns replaced by unit
-    // vectors,  R = D^-1 S(K,:),  S(i,:) -= S(i,K) R  for i not in K,  S(K,:) = R.
+    const v4d zero4 = {0, 0, 0, 0};
+    // wave 0 opens the chain: publish column 0, invert S(0,0)
+    if (w == 0) {
 #pragma unroll
-    for (int kb = 0; kb < NB; ++kb) {
-        for (int kk = 0; kk < 16; kk += 2) {
-            const int k = 16 * kb + kk;
-            if (k >= m) break;
-            const int buf = (k >> 1) & 1;
-            const bool own_r0 = ti == kk, own_r1 = ti == kk + 1, own_c0 = tj == kk, own_c1 = tj == kk + 1;
-            if (own_r0 || own_r1) {
+        for (int bi = 1; bi < NBR; ++bi)
+            if (bi < nbr) write_patch(s_col[0][bi], S[bi], g, c);
+        bad |= leaf_inverse16(S[0], g, c, lp);
+        write_patch(s_col[0][NBR], S[0], g, c);
+    }
 #pragma unroll
-                for (int b = 0; b < NB; ++b) rowbuf[buf][(own_r1 ? REKF_MR_PAD : 0) + tj + 16 * b] = S[kb][b];
-            }
-            if (own_c0 || own_c1) {
+    for (int K = 0; K < NBR; ++K) {
+        if (K >= nbr) break;
+        double (*col)[REKF_PATCH] = s_col[K & 1];
+        lds_barrier();                                // column K and D^-1 of step K are published
+        if (w == K) {
+            // S(i,K) <- -S(i,K) D^-1 ; S(K,K) = D^-1 is already in place
 #pragma unroll
-                for (int a = 0; a < NB; ++a) colbuf[buf][(own_c1 ? REKF_MR_PAD : 0) + ti + 16 * a] = S[a][kb];
-            }
-            __syncthreads();
-            const double *r0p = rowbuf[buf], *r1p = rowbuf[buf] + REKF_MR_PAD;
-            const double *c0p = colbuf[buf], *c1p = colbuf[buf] + REKF_MR_PAD;
-            const double d00 = r0p[k], d01 = r0p[k + 1], d10 = r1p[k], d11 = r1p[k + 1];
-            const double det = d00 * d11 - d01 * d10;
-            if (!(det > 0.0) || !(d00 > 0.0)) bad = true;
-            double q = __builtin_amdgcn_rcp(det);          // 1/det: hardware reciprocal + two Newton steps
-            q = fma(q, fma(-det, q, 1.0), q);
-            q = fma(q, fma(-det, q, 1.0), q);
-            const double i00 = d11 * q, i01 = -d01 * q, i10 = -d10 * q, i11 = d00 * q;
-            double R0[NB], R1[NB], f0[NB], f1[NB];
+            for (int bi = 0; bi < NBR; ++bi)
+                if (bi != K && bi < nbr) S[bi] = block_mma(-read_patch_T(col[bi], g, c), S[K], zero4);
+        } else {
+            // pivot-row block R = D^-1 S(K,w), then S(i,w) -= S(i,K) R, block (K+1, .) first
+            const v4d R = block_mma2(read_patch_T(col[NBR], g, c), S[K], zero4);
+            S[K] = R;
+            if (K + 1 < NBR && K + 1 < nbr)
+                S[K + 1] = block_mma2(-read_patch_T(col[K + 1], g, c), R, S[K + 1]);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                double x0 = r0p[tj + 16 * b], x1 = r1p[tj + 16 * b];
-                if (b == kb) {                              // pivot columns act as unit vectors
-                    if (own_c0) { x0 = 1.0; x1 = 0.0; }
-                    if (own_c1) { x0 = 0.0; x1 = 1.0; }
-                }
-                R0[b] = i00 * x0 + i01 * x1;
-                R1[b] = i10 * x0 + i11 * x1;
-            }
+            for (int bi = 0; bi < NBR; ++bi)
+                if (bi != K && bi != K + 1 && bi < nbr) S[bi] = block_mma(-read_patch_T(col[bi], g, c), R, S[bi]);
+            if (K + 1 < NBR && w == K + 1) {
+                // next pivot wave: publish column K+1 (other buffer), invert the diagonal block
+                double (*ncol)[REKF_PATCH] = s_col[(K + 1) & 1];
 #pragma unroll
-            for (int a = 0; a < NB; ++a) { f0[a] = c0p[ti + 16 * a]; f1[a] = c1p[ti + 16 * a]; }
-            if (own_c0 || own_c1) {
-#pragma unroll
-                for (int a = 0; a < NB; ++a) S[a][kb] = 0.0;
-            }
-#pragma unroll
-            for (int a = 0; a < NB; ++a)
-#pragma unroll
-                for (int b = 0; b < NB; ++b) S[a][b] = fma(-f1[a], R1[b], fma(-f0[a], R0[b], S[a][b]));
-            if (own_r0) {
-#pragma unroll
-                for (int b = 0; b < NB; ++b) S[kb][b] = R0[b];
-            }
-            if (own_r1) {
-#pragma unroll
-                for (int b = 0; b < NB; ++b) S[kb][b] = R1[b];
+                for (int bi = 0; bi < NBR; ++bi)
+                    if (bi != K + 1 && bi < nbr) write_patch(ncol[bi], S[bi], g, c);
+                bad |= leaf_inverse16(S[K + 1], g, c, lp);
+                write_patch(ncol[NBR], S[K + 1], g, c);
             }
         }
     }
 #ifdef REKF_DEBUG_TIMING
-    if (tid == 0) { ctl->dbg[0] = clock64() - t0c; ctl->dbg[1] = wall_clock64() - t0w; }
+    const long long t1c = pinned_clock();
+    if (threadIdx.x == 0) { ctl->dbg[0] = t1c - t0c; ctl->dbg[1] = wall_clock64() - t0w; ctl->dbg[2] = t0c - tsc; }
 #endif
-    if (bad && tid == 0) atomicOr(&ctl->err, REKF_FLAG_SINGULAR);
-    // S^-1 out (pad rows/cols are the identity) and y = S^-1 dz
-    double dzj[NB];
+    if (bad && lane == 0) atomicOr(&ctl->err, REKF_FLAG_SINGULAR);
+    // S^-1 out, row-major (pad rows/cols are the identity).  y: this wave holds COLUMNS of S^-1, so it
+    // forms y(j) = sum_i Sinv(i,j) dz(i) = (S^-T dz)(j) -- equal to S^-1 dz up to the rounding-level
+    // asymmetry of the computed inverse -- with 4 FMAs per block and two cross-group adds, no LDS.
+    double acc = 0.0;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) dzj[b] = (tj + 16 * b < m) ? ctl->dz[tj + 16 * b] : 0.0;
+    for (int bi = 0; bi < NBR; ++bi) {
+        if (bi < nbr) {
 #pragma unroll
-    for (int a = 0; a < NB; ++a) {
-        const int i = ti + 16 * a;
-        double acc = 0;
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int j = tj + 16 * b;
-            d.Sinv[i + (size_t)j * REKF_MR_PAD] = S[a][b];
-            acc += S[a][b] * dzj[b];
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * bi + g + 4 * r;
+                d.Sinv[(size_t)i * REKF_MR_PAD + j] = S[bi][r];
+                acc += S[bi][r] * ((i < m) ? s_coef[8 * i + 6] : 0.0);
+            }
         }
-        for (int off = 8; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 16);
-        if (tj == 0) d.y[i] = (i < m) ? acc : 0.0;
     }
-}
-
-__global__ __launch_bounds__(256) void k_solve(RekfDev d)
-{
-    __shared__ double rowbuf[2][2 * REKF_MR_PAD];    // ping-pong x {row k, row k+1}
-    __shared__ double colbuf[2][2 * REKF_MR_PAD];
-    const int m = d.ctl->m;
-    if (m == 0) return;
-    if (m <= 32) solve_body<2>(d, m, rowbuf, colbuf);
-    else if (m <= 64) solve_body<4>(d, m, rowbuf, colbuf);
-    else solve_body<8>(d, m, rowbuf, colbuf);
+    acc += bperm_f64(acc, ((lane ^ 16) << 2));
+    acc += bperm_f64(acc, ((lane ^ 32) << 2));
+    if (g == 0) d.y[j] = (j < m) ? acc : 0.0;
+#ifdef REKF_DEBUG_TIMING
+    if (threadIdx.x == 0) ctl->dbg[3] = pinned_clock() - t1c;
+#endif
 }
 
 // ----------------------------------------------------------------------------
@@ -988,7 +920,7 @@ __global__ __launch_bounds__(512) void k_gain(RekfDev d)
                 const bool live = kk < m_pad / 4;
                 // A[j][k] = Sinv(k, j)   (mu tile: row 0 = y(k), other rows 0)
                 if (is_mu) a[q] = (live && idx == 0) ? d.y[k] : 0.0;
-                else a[q] = live ? d.Sinv[k + (size_t)(j0 + idx) * REKF_MR_PAD] : 0.0;
+                else a[q] = live ? d.Sinv[(size_t)k * REKF_MR_PAD + j0 + idx] : 0.0;   // row-major S^-1
                 b[q] = live ? Wp[(size_t)k * ld] : 0.0;                     // B[k][i] = W(i, k)
             }
 #pragma unroll
@@ -1043,13 +975,7 @@ __global__ __launch_bounds__(512) void k_gain(RekfDev d)
 #endif
 #define DD_WG_PER_CU (DD_NBUF == 1 ? 2 : 1)
 
-__device__ static inline void dd_lds_barrier()
-{
-    // LDS-only workgroup barrier: do NOT wait for outstanding global stores (vmcnt)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
+__device__ static inline void dd_lds_barrier() { lds_barrier(); }
 
 // FAST = the whole innovation fits one full 64-wide k-chunk (m_pad == 64, i.e. 25..32 matched
 // observations: BASELINE.json's N=1024 x 32 configuration).  Its loop is peeled so that every
@@ -1410,9 +1336,12 @@ void rekf_launch_gather(const RekfDev &d, const RekfFrontArgs &a, int n_ub, hipS
 {
     hipLaunchKernelGGL(k_gather, dim3((n_ub + 255) / 256, 32), dim3(256), 0, s, d, a);
 }
-void rekf_launch_solve(const RekfDev &d, hipStream_t s)
+void rekf_launch_solve(const RekfDev &d, int m_ub, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_solve, dim3(1), dim3(256), 0, s, d);
+    // one wave per 16-row block of S; m <= m_ub = 2K (+3) is all the host knows
+    if (m_ub <= 32) hipLaunchKernelGGL(k_solve<2>, dim3(1), dim3(128), 0, s, d);
+    else if (m_ub <= 64) hipLaunchKernelGGL(k_solve<4>, dim3(1), dim3(256), 0, s, d);
+    else hipLaunchKernelGGL(k_solve<8>, dim3(1), dim3(512), 0, s, d);
 }
 void rekf_launch_gain(const RekfDev &d, int n_ub, hipStream_t s)
 {

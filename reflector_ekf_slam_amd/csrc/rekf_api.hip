@@ -35,6 +35,7 @@ struct rekf {
     double time;
     double vt[3];
     int n_ub;                  // host upper bound of the device-resident n
+    int last_m_ub = 64;        // innovation-row bound of the last scan (sizes the k_solve launch)
     bool full;                 // a readback showed n == n_max: no landmark can ever be added again
     double *pose_staging;      // pinned, 12 doubles
     double *dev_out12;         // device scratch for k_predict_pose
@@ -190,6 +191,7 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
         HIP_TRY(h, hipMalloc(&h->dev.HPt, sizeof(double) * (size_t)ld * REKF_MR_PAD));
         HIP_TRY(h, hipMalloc(&h->dev.Kn, sizeof(double) * (size_t)ld * REKF_MR_PAD));
         HIP_TRY(h, hipMalloc(&h->dev.Sinv, sizeof(double) * REKF_MR_PAD * REKF_MR_PAD));
+        HIP_TRY(h, hipMalloc(&h->dev.Wc, sizeof(double) * REKF_WC_DOUBLES));
         HIP_TRY(h, hipMalloc(&h->dev.y, sizeof(double) * REKF_MR_PAD));
         HIP_TRY(h, hipMalloc(&h->dev_out12, sizeof(double) * 12));
         HIP_TRY(h, hipHostMalloc(&h->pose_staging, sizeof(double) * 16));
@@ -204,6 +206,7 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
         HIP_TRY(h, hipMemsetAsync(h->dev.HPt, 0, sizeof(double) * (size_t)ld * REKF_MR_PAD, h->stream));
         HIP_TRY(h, hipMemsetAsync(h->dev.Kn, 0, sizeof(double) * (size_t)ld * REKF_MR_PAD, h->stream));
         HIP_TRY(h, hipMemsetAsync(h->dev.Sinv, 0, sizeof(double) * REKF_MR_PAD * REKF_MR_PAD, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->dev.Wc, 0, sizeof(double) * REKF_WC_DOUBLES, h->stream));
         HIP_TRY(h, hipMemsetAsync(h->dev.y, 0, sizeof(double) * REKF_MR_PAD, h->stream));
         std::memset(h->ctl_staging, 0, sizeof(RekfCtl));
         h->ctl_staging->n = 3;
@@ -231,7 +234,7 @@ void rekf_destroy(rekf_t *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &s : h->prof_slots) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     (void)hipFree(h->dev.ctl); (void)hipFree(h->dev.mu); (void)hipFree(h->dev.P);
-    (void)hipFree(h->dev.W); (void)hipFree(h->dev.HPt); (void)hipFree(h->dev.Kn); (void)hipFree(h->dev.Sinv); (void)hipFree(h->dev.y);
+    (void)hipFree(h->dev.W); (void)hipFree(h->dev.HPt); (void)hipFree(h->dev.Kn); (void)hipFree(h->dev.Sinv); (void)hipFree(h->dev.Wc); (void)hipFree(h->dev.y);
     (void)hipFree(h->dev.map_xy); (void)hipFree(h->dev.map_cov); (void)hipFree(h->dev_out12);
     if (h->pose_staging) (void)hipHostFree(h->pose_staging);
     if (h->ctl_staging) (void)hipHostFree(h->ctl_staging);
@@ -296,7 +299,8 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     h->time = t;                                      // cc:234
     const int n_ub = h->n_ub;
     { ProfScope ps(h, REKF_K_GATHER); rekf_launch_gather(h->dev, a, n_ub, h->stream); }
-    { ProfScope ps(h, REKF_K_SOLVE); rekf_launch_solve(h->dev, h->stream); }
+    { ProfScope ps(h, REKF_K_SOLVE); rekf_launch_solve(h->dev, 2 * K + (gps_pose3 ? 3 : 0), h->stream); }
+    h->last_m_ub = 2 * K + (gps_pose3 ? 3 : 0);
     { ProfScope ps(h, REKF_K_GAIN); rekf_launch_gain(h->dev, n_ub, h->stream); }
     { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_downdate(h->dev, n_ub, h->stream); }
     // the state only grows: once a readback has shown it full, k_augment can never have work again
@@ -473,7 +477,7 @@ int rekf_debug_time_kernel(rekf_t *h, int kernel, int reps, int ablate, double *
     auto launch = [&]() {
         switch (kernel) {
         case REKF_K_GATHER: break;   /* needs the scan's arguments: not re-launchable standalone */
-        case REKF_K_SOLVE: rekf_launch_solve(dev, h->stream); break;
+        case REKF_K_SOLVE: rekf_launch_solve(dev, h->last_m_ub, h->stream); break;
         case REKF_K_GAIN: rekf_launch_gain(dev, n_ub, h->stream); break;
         case REKF_K_DOWNDATE: rekf_launch_downdate(dev, n_ub, h->stream); break;
         default: break;

@@ -10,4 +10,4 @@ L = _lib.rekf(); L.rekf_debug_counters.argtypes=[C.c_void_p, C.POINTER(C.c_longl
 for t, ob in synth.steady_state_scans(sess, 20):
     g.handle_observation(t, ob)
 out = (C.c_longlong*32)(); L.rekf_debug_counters(g._h, out)
-print("dbg", list(out)[:8], "\ndowndate marks", list(out)[8:], "shader clocks per wallclock tick(100MHz):", out[0]/max(out[1],1), "-> GHz", out[0]/max(out[1],1)*0.1)
+print("dbg", list(out)[:8], "tail", list(out)[24:32], "\ndowndate marks", list(out)[8:], "shader clocks per wallclock tick(100MHz):", out[0]/max(out[1],1), "-> GHz", out[0]/max(out[1],1)*0.1)
