@@ -474,8 +474,10 @@ __global__ __launch_bounds__(256) void k_gather(RekfDev d, RekfFrontArgs A)
 {
     __shared__ int s_pair_obs[REKF_MAX_OBS_DEV], s_pair_id[REKF_MAX_OBS_DEV], s_pair_state[REKF_MAX_OBS_DEV];
     __shared__ int s_cnt[4];
+    __shared__ int s_slot[256], s_dup[256];
     RekfCtl *ctl = d.ctl;
     const int tid = threadIdx.x;
+    s_slot[tid] = 0x7fffffff; s_dup[tid] = 0;
     const int n = ctl->n;
     const int K = A.K;
     const size_t ld = (size_t)d.ld;
@@ -552,20 +554,25 @@ __global__ __launch_bounds__(256) void k_gather(RekfDev d, RekfFrontArgs A)
             hr[7] = 0;
         }
     }
-    if (c >= d.ld) return;
     // rows of W that S = H W needs ({0,1,2} and the matched landmarks' rows) also go to the compact,
     // row-major copy Wc (slot 3+2p+{0,1} for state pair p) that k_solve reads coalesced
-    int slot = (valid && c < 3) ? c : -1;
-    bool dup = false;                       // two observations matched to this landmark (the reference allows it)
-    if (valid && c >= 3) {
-        for (int p = 0; p < MM && s_pair_state[p]; ++p) {                 // state pairs come first
-            const int dc = c - (3 + 2 * s_pair_id[p]);
-            if (dc == 0 || dc == 1) {
-                if (slot < 0) slot = 3 + 2 * p + dc;
-                else dup = true;
+    // (s_slot[row - chunk base] = smallest slot of a state pair on that row, filled by the pair threads;
+    // a collision = two observations matched to one landmark, which the reference allows: s_dup)
+    if (tid < MM && s_pair_state[tid]) {
+        const int cc0 = 3 + 2 * s_pair_id[tid] - (int)blockIdx.x * 256;
+#pragma unroll
+        for (int dc = 0; dc < 2; ++dc) {
+            if (cc0 + dc >= 0 && cc0 + dc < 256) {
+                const int old = atomicMin(&s_slot[cc0 + dc], 3 + 2 * tid + dc);
+                if (old != 0x7fffffff) s_dup[cc0 + dc] = 1;
             }
         }
     }
+    __syncthreads();
+    if (c >= d.ld) return;
+    int slot = (valid && c < 3) ? c : -1;
+    if (valid && c >= 3 && s_slot[tid] != 0x7fffffff) slot = s_slot[tid];
+    const bool dup = s_dup[tid] != 0;
     double *__restrict__ Wc = d.Wc;
 
     // ---- W(c, r) = sum_k P(c,k) H(r,k)  and  HPt(c, r) = sum_k H(r,k) P(k,c) for this workgroup's row pairs
@@ -662,9 +669,12 @@ __device__ static inline void lds_barrier()
 // vectors, R = D^-1 A(K,:), A(i,:) -= A(i,K) R for i not in K, A(K,:) = R.  Pivot rows and columns
 // are exchanged through a 64-double LDS scratch private to the wave (LDS operations of one wave
 // execute in order: no barrier, 5 writes + 7 16-byte reads per step).  Returns true when a pivot
-// block is not positive definite (S must be: it is H P H^T + Q).
+// block is not positive definite (S must be: it is H P H^T + Q).  side(kk) is called once per step with
+// independent work of the caller (MFMAs, LDS publishes) that is issued under the step's latency.
 #define REKF_LEAF_SCRATCH 64
-__device__ static inline bool leaf_inverse16(v4d &a, int g, int c, double *lp)
+struct NoSideWork { __device__ void operator()(int) const {} };
+template <class Side>
+__device__ static inline bool leaf_inverse16(v4d &a, int g, int c, double *lp, Side &&side)
 {
     bool bad = false;
     double *rowbuf = lp;            // [col c][row k / k+1]
@@ -684,6 +694,7 @@ __device__ static inline bool leaf_inverse16(v4d &a, int g, int c, double *lp)
 #pragma unroll
         for (int r = 0; r < 4; ++r) ff[r] = *(const v2d *)(colbuf + (4 * g + r) * 2);
         __builtin_amdgcn_wave_barrier();
+        side(kk);                                           // independent work that fills this step's latency
         const double d00 = dA.x, d10 = dA.y, d01 = dB.x, d11 = dB.y;
         const double det = d00 * d11 - d01 * d10;
         if (!(det > 0.0) || !(d00 > 0.0)) bad = true;
@@ -819,7 +830,7 @@ __global__ __launch_bounds__(64 * NBR) void k_solve(RekfDev d)
 #pragma unroll
         for (int bi = 1; bi < NBR; ++bi)
             if (bi < nbr) write_patch(s_col[0][bi], S[bi], g, c);
-        bad |= leaf_inverse16(S[0], g, c, lp);
+        bad |= leaf_inverse16(S[0], g, c, lp, NoSideWork());
         write_patch(s_col[0][NBR], S[0], g, c);
     }
 #pragma unroll
@@ -838,17 +849,49 @@ __global__ __launch_bounds__(64 * NBR) void k_solve(RekfDev d)
             S[K] = R;
             if (K + 1 < NBR && K + 1 < nbr)
                 S[K + 1] = block_mma2(-read_patch_T(col[K + 1], g, c), R, S[K + 1]);
-#pragma unroll
-            for (int bi = 0; bi < NBR; ++bi)
-                if (bi != K && bi != K + 1 && bi < nbr) S[bi] = block_mma(-read_patch_T(col[bi], g, c), R, S[bi]);
             if (K + 1 < NBR && w == K + 1) {
-                // next pivot wave: publish column K+1 (other buffer), invert the diagonal block
+                // Next pivot wave: invert the diagonal block now.  Its other NBR-2 products and the
+                // publication of column K+1 (other buffer) are issued from inside the leaf, under
+                // the latency of its pivot steps, so they leave the pivot chain.
+                constexpr int NP = (NBR > 2) ? NBR - 2 : 0;            // pending products, blocks bi not in {K, K+1}
+                constexpr int PH = (NBR <= 4) ? 4 : 6;                 // leaf steps that carry MFMAs; the rest carry publishes
+                constexpr int PER = (4 * NP + PH - 1) / PH, PP = (NBR - 1 + 7 - PH) / (8 - PH);
                 double (*ncol)[REKF_PATCH] = s_col[(K + 1) & 1];
+                v4d At[NP > 0 ? NP : 1];
+#pragma unroll
+                for (int idx = 0; idx < NP; ++idx) {
+                    const int bi = (idx >= K) ? idx + 2 : idx;
+                    At[idx] = (bi < nbr) ? -read_patch_T(col[bi], g, c) : zero4;
+                }
+                auto side = [&](int kk) {
+                    if (kk < PH) {
+#pragma unroll
+                        for (int t = 0; t < PER; ++t) {
+                            const int q = kk * PER + t;                // consecutive MFMAs belong to different products
+                            if (q < 4 * NP) {
+                                const int idx = q % (NP > 0 ? NP : 1), slice = q / (NP > 0 ? NP : 1);
+                                const int bi = (idx >= K) ? idx + 2 : idx;
+                                if (bi < nbr)
+                                    S[bi] = __builtin_amdgcn_mfma_f64_16x16x4f64(At[idx][slice], R[slice], S[bi], 0, 0, 0);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < PP; ++t) {
+                            const int pidx = (kk - PH) * PP + t;
+                            if (pidx < NBR - 1) {
+                                const int bi = (pidx >= K + 1) ? pidx + 1 : pidx;
+                                if (bi < nbr) write_patch(ncol[bi], S[bi], g, c);
+                            }
+                        }
+                    }
+                };
+                bad |= leaf_inverse16(S[K + 1], g, c, lp, side);
+                write_patch(ncol[NBR], S[K + 1], g, c);
+            } else {
 #pragma unroll
                 for (int bi = 0; bi < NBR; ++bi)
-                    if (bi != K + 1 && bi < nbr) write_patch(ncol[bi], S[bi], g, c);
-                bad |= leaf_inverse16(S[K + 1], g, c, lp);
-                write_patch(ncol[NBR], S[K + 1], g, c);
+                    if (bi != K && bi != K + 1 && bi < nbr) S[bi] = block_mma(-read_patch_T(col[bi], g, c), R, S[bi]);
             }
         }
     }
