@@ -205,6 +205,32 @@ def test_threshold_edges_and_duplicate_matches():
     assert g.last_match().state_obs_match_ids[:, 1].tolist() == [0, 0]      # Q6: both match landmark 0
 
 
+def test_duplicate_matches_state_parity_incl_chunk_boundary_landmark(oracle_lib):
+    """Q6 with numbers: several observations matched to ONE landmark give duplicated H row pairs.  Landmark
+    126 owns state rows 255/256, which straddle two 256-row workgroup chunks of k_gather (compact-row table)."""
+    g = _simple(cap=160)
+    o = make_oracle(0, 0.0, np.zeros(3), 0.0025, 0.0064, 0.0025)
+    gx, gy = np.meshgrid(np.arange(15) * 1.5 - 10.0, np.arange(10) * 1.5 - 7.0, indexing="ij")
+    pts = np.stack([gx.ravel() + 0.3, gy.ravel() + 0.2], 1).astype(np.float32)          # 150 reflectors, 1.5 m apart
+    for f in (g, o):
+        for a in range(0, 150, 50):
+            f.handle_observation(0.0, pts[a:a + 50])
+    assert g.n == o.n == 303
+    dup = np.stack([pts[126] + [0.05, 0.0], pts[126] + [-0.04, 0.03], pts[126] + [0.0, -0.05],
+                    pts[7] + [0.03, 0.0], pts[7] + [0.0, 0.04], pts[127], pts[60] + [0.01, 0.01]]).astype(np.float32)
+    for f in (g, o):
+        f.handle_odometry(0.1, 0.2, 0.0, 0.05)
+        f.handle_observation(0.2, dup)
+    sg, so = norm_match(g.last_match()), norm_match(o.last_match())
+    assert sg[0][:, 1].tolist() == [126, 126, 126, 7, 7, 127, 60]
+    assert all(np.array_equal(a, b) for a, b in zip(sg, so))
+    mg, Pg = g.GetState().mu, g.GetState().sigma
+    mo, Po = o.state()
+    assert np.abs(mg - mo).max() < 1e-12
+    assert np.abs(Pg - Po).max() < 1e-12 * max(1.0, np.abs(Po).max())
+    assert g.sync_code() == 0
+
+
 def test_too_many_observations_is_an_error_code_not_a_crash():
     from reflector_ekf_slam_amd import RekfError
     g = _simple()
