@@ -74,6 +74,16 @@ public:
         sigma = Eigen::Map<Eigen::Matrix3d>(c9);
     }
 
+    // Node::ReflectorToRosMarkers (ros_node.cc:736-790) without the n x n GetState(): the 2x2 eigen-solves run on
+    // the device; marker i gets position (x, y), orientation (0, 0, sin(angle/2), cos(angle/2)) and
+    // scale (s*x_len, s*y_len, 0.1*s*(x_len+y_len)).
+    std::vector<rekfpp::EkfSlam::MarkerEllipse> GetMarkerEllipses()
+    {
+        std::vector<rekfpp::EkfSlam::MarkerEllipse> e;
+        guard([&] { e = impl_.MarkerEllipses(); });
+        return e;
+    }
+
 private:
     static rekf_options to_c(const EKFOptions &o)
     {

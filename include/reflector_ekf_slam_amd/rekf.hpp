@@ -55,6 +55,18 @@ public:
         sigma.resize((size_t)n * n);
         chk(rekf_get_state(h_, &t, &n, mu.data(), (long)mu.size(), sigma.data(), (long)sigma.size()), "GetState");
     }
+    // Node::ReflectorToRosMarkers' numbers (src/ros_node.cc:750-765), one per landmark, computed on the device
+    struct MarkerEllipse { double x, y, angle, x_len, y_len; };
+    std::vector<MarkerEllipse> MarkerEllipses()
+    {
+        const int cap = (Dim() - 3) / 2;
+        std::vector<MarkerEllipse> e((size_t)(cap > 0 ? cap : 0));
+        int k = 0;
+        static_assert(sizeof(MarkerEllipse) == 5 * sizeof(double), "packed");
+        chk(rekf_get_marker_ellipses(h_, cap > 0 ? &e[0].x : nullptr, cap, &k), "rekf_get_marker_ellipses");
+        e.resize((size_t)k);
+        return e;
+    }
     MatchResult LastMatch()
     {
         int ns = 0, nm = 0, nn = 0;

@@ -108,6 +108,14 @@ int rekf_get_n(rekf_t *h, int *n);
 int rekf_get_state(rekf_t *h, double *t, int *n, double *mu, long mu_cap,
                    double *sigma, long sigma_cap);
 
+/* Landmark covariance ellipses for the caller's visualisation (Node::ReflectorToRosMarkers,
+ * src/ros_node.cc:736-765): per landmark i the 2x2 block sigma(3+2i.., 3+2i..) is eigen-decomposed ON THE
+ * DEVICE and only 5 doubles come back -- {mx, my, angle, x_len, y_len} with angle = atan2 of the first
+ * pseudo-eigenvector (:763) and x_len/y_len = 2 sqrt(5.991 * eigenvalue) (:764-765) -- instead of the
+ * n x n GetState() copy the reference makes for this (33 MB at 1024 landmarks vs 40 KB).
+ * out5 holds cap landmarks (5*cap doubles); *count = landmarks written.  Synchronises. */
+int rekf_get_marker_ellipses(rekf_t *h, double *out5, int cap, int *count);
+
 /* Restore a full state (checkpoint resume / tests).  sigma column-major, ld = n.
  * vt3 = nullable last odometry velocity. */
 int rekf_set_state(rekf_t *h, double t, int n, const double *mu, const double *sigma,

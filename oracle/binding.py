@@ -55,6 +55,8 @@ def lib():
     L.oekf_set_state.argtypes = [C.c_void_p, C.c_double, C.c_int, _f64p, _f64p, _f64p]
     L.oekf_get_vt.argtypes = [C.c_void_p, _f64p]
     L.oekf_get_last_match.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    L.oekf_marker_ellipses.restype = C.c_int
+    L.oekf_marker_ellipses.argtypes = [C.c_void_p, _f64p]
     # ---- 2D detector oracle (detect2d_oracle.c)
     L.od2_create.restype = C.c_void_p
     L.od2_create.argtypes = [C.c_double, C.c_double, C.c_double, C.c_float, C.c_float, _f64p]
@@ -161,6 +163,12 @@ class OracleEKF:
         v = np.zeros(3)
         self._L.oekf_get_vt(self._h, v)
         return v
+
+    def marker_ellipses(self):
+        """src/ros_node.cc:736-765 restated: (L,5) = mx, my, angle, x_len, y_len."""
+        out = np.zeros((max((self.n - 3) // 2, 1), 5))
+        k = self._L.oekf_marker_ellipses(self._h, out.reshape(-1))
+        return out[:k].copy()
 
     def last_match(self):
         cap = max(self._max_obs, 1)

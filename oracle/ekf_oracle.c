@@ -530,6 +530,46 @@ void oekf_get_state(const oekf_t *e, double *mu, double *sigma)
     if (mu) memcpy(mu, e->mu, sizeof(double) * (size_t)e->n);
     if (sigma) memcpy(sigma, e->P, sizeof(double) * (size_t)e->n * e->n);
 }
+/* ---- marker ellipses: the caller's per-landmark covariance ellipse, src/ros_node.cc:736-765 -------
+ * For landmark i (state rows id = 3+2i, id+1): sigma_m = the 2x2 block (NOT symmetrised), its
+ * eigen-decomposition by Eigen::EigenSolver (:759-761), angle = atan2(V(1,0), V(0,0)) of the FIRST
+ * pseudo-eigenvector (:763), x_len = 2 sqrt(5.991 D(0,0)), y_len = 2 sqrt(5.991 D(1,1)) (:764-765).
+ * Eigen is not in this image, so the ORDER and SIGN conventions below restate the published
+ * algorithm of Eigen 3.3 RealSchur for a 2x2 real matrix (no Hessenberg step; findSmallSubdiagEntry; then
+ * splitOffTwoRows = EISPACK hqr2's two-real-roots branch with a Givens rotation): PARITY UNPINNED.
+ *   T = [[a, b],[c, d]];  if |c| <= eps (|a|+|d|): already triangular -> D = (a, d), V(:,0) = (1, 0).
+ *   else p = (a-d)/2, q = p^2 + c b, z = sqrt|q| (q >= 0 for a covariance block), pz = p >= 0 ? p+z : p-z,
+ *        D0 = d + pz, D1 = pz != 0 ? d - c b / pz : D0, V(:,0) = (pz, c)/|(pz, c)|.
+ * out: 5 doubles per landmark {mx, my, angle, x_len, y_len}.  Returns the landmark count. */
+int oekf_marker_ellipses(const oekf_t *e, double *out5)
+{
+    const int L = (e->n - 3) / 2;
+    const size_t ld = (size_t)e->n;
+    for (int i = 0; i < L; ++i) {
+        const int id = 3 + 2 * i;
+        const double a = e->P[id + id * ld], b = e->P[id + (id + 1) * ld];
+        const double c = e->P[(id + 1) + id * ld], d = e->P[(id + 1) + (id + 1) * ld];
+        double d0, d1, vx, vy;
+        if (fabs(c) <= 2.220446049250313e-16 * (fabs(a) + fabs(d))) {
+            d0 = a; d1 = d; vx = 1.0; vy = 0.0;
+        } else {
+            const double p = 0.5 * (a - d);
+            const double q = p * p + c * b;
+            const double z = sqrt(fabs(q));
+            const double pz = (p >= 0.0) ? p + z : p - z;
+            d0 = d + pz;
+            d1 = (pz != 0.0) ? d - c * b / pz : d0;
+            vx = pz; vy = c;
+        }
+        out5[5 * i + 0] = e->mu[id];
+        out5[5 * i + 1] = e->mu[id + 1];
+        out5[5 * i + 2] = atan2(vy, vx);
+        out5[5 * i + 3] = 2.0 * sqrt(d0 * 5.991);
+        out5[5 * i + 4] = 2.0 * sqrt(d1 * 5.991);
+    }
+    return L;
+}
+
 /* test hook: overwrite the whole filter state (used to start the CPU leg from
  * a state the device path produced). sigma column-major, ld = n. */
 void oekf_set_state(oekf_t *e, double time, int n, const double *mu,

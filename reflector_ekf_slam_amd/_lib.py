@@ -57,6 +57,7 @@ def rekf():
     L.rekf_get_time.argtypes = [vp, dp]
     L.rekf_get_pose.argtypes = [vp, dp, dp, dp]
     L.rekf_get_n.argtypes = [vp, ip]
+    L.rekf_get_marker_ellipses.argtypes = [vp, vp, C.c_int, ip]
     L.rekf_get_state.argtypes = [vp, dp, ip, vp, C.c_long, vp, C.c_long]
     L.rekf_set_state.argtypes = [vp, C.c_double, C.c_int, vp, vp, vp]
     L.rekf_get_last_match.argtypes = [vp, ip, vp, ip, vp, ip, vp]

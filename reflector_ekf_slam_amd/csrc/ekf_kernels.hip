@@ -1415,6 +1415,50 @@ void rekf_launch_augment(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s
 {
     hipLaunchKernelGGL(k_augment, dim3(1), dim3(256), 0, s, d, a);
 }
+// ----------------------------------------------------------------------------
+// k_ellipses: the caller's marker ellipses (src/ros_node.cc:750-765), one thread per landmark.
+// Eigen-decomposition of the (unsymmetrised) 2x2 block T = [[a,b],[c,d]] in the order/sign convention
+// of Eigen 3.3's RealSchur for a 2x2 real matrix (what Eigen::EigenSolver runs, :759-761): if the
+// sub-diagonal is negligible, |c| <= eps(|a|+|d|), T is left alone: D = (a,d), V(:,0) = e0; else the
+// two-real-roots step of hqr2: p = (a-d)/2, z = sqrt|p^2 + c b|, pz = p +- z (sign of p), D0 = d + pz,
+// D1 = d - c b / pz, V(:,0) = (pz, c)/|.|.  So the eigenvalue that stays with T(0,0) comes first.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ellipses(RekfDev d, double *out5, int cap)
+{
+#pragma clang fp contract(off)
+    const int n = d.ctl->n;
+    const int L = (n - 3) / 2;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= L || i >= cap) return;
+    const size_t ld = (size_t)d.ld;
+    const int id = 3 + 2 * i;
+    const double a = d.P[id + id * ld], b = d.P[id + (id + 1) * ld];
+    const double c = d.P[(id + 1) + id * ld], dd = d.P[(id + 1) + (id + 1) * ld];
+    double d0, d1, vx, vy;
+    if (fabs(c) <= 2.220446049250313e-16 * (fabs(a) + fabs(dd))) {
+        d0 = a; d1 = dd; vx = 1.0; vy = 0.0;
+    } else {
+        const double p = 0.5 * (a - dd);
+        const double q = p * p + c * b;
+        const double z = sqrt(fabs(q));
+        const double pz = (p >= 0.0) ? p + z : p - z;
+        d0 = dd + pz;
+        d1 = (pz != 0.0) ? dd - c * b / pz : d0;
+        vx = pz; vy = c;
+    }
+    double *o = out5 + 5 * (size_t)i;
+    o[0] = d.mu[id];
+    o[1] = d.mu[id + 1];
+    o[2] = atan2(vy, vx);
+    o[3] = 2.0 * sqrt(d0 * 5.991);
+    o[4] = 2.0 * sqrt(d1 * 5.991);
+}
+
+void rekf_launch_ellipses(const RekfDev &d, double *out5, int cap, hipStream_t s)
+{
+    if (cap <= 0) return;
+    hipLaunchKernelGGL(k_ellipses, dim3((cap + 255) / 256), dim3(256), 0, s, d, out5, cap);
+}
 void rekf_launch_predict_pose(const RekfDev &d, const RekfFrontArgs &a, double *out12, hipStream_t s)
 {
     hipLaunchKernelGGL(k_predict_pose, dim3(1), dim3(64), 0, s, d, a, out12);

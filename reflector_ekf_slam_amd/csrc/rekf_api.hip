@@ -39,6 +39,7 @@ struct rekf {
     bool full;                 // a readback showed n == n_max: no landmark can ever be added again
     double *pose_staging;      // pinned, 12 doubles
     double *dev_out12;         // device scratch for k_predict_pose
+    double *dev_ell;           // device scratch for k_ellipses (5 doubles per landmark of capacity)
     RekfCtl *ctl_staging;      // pinned copy of the control block
     std::string hip_error;
     // profiling
@@ -177,6 +178,7 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
     h->pose_staging = nullptr;
     h->ctl_staging = nullptr;
     h->dev_out12 = nullptr;
+    h->dev_ell = nullptr;
     std::memset(&h->dev, 0, sizeof(h->dev));
 
     const int n_max = 3 + 2 * max_landmarks;
@@ -194,6 +196,7 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
         HIP_TRY(h, hipMalloc(&h->dev.Wc, sizeof(double) * REKF_WC_DOUBLES));
         HIP_TRY(h, hipMalloc(&h->dev.y, sizeof(double) * REKF_MR_PAD));
         HIP_TRY(h, hipMalloc(&h->dev_out12, sizeof(double) * 12));
+        HIP_TRY(h, hipMalloc(&h->dev_ell, sizeof(double) * 5 * (size_t)(max_landmarks > 0 ? max_landmarks : 1)));
         HIP_TRY(h, hipHostMalloc(&h->pose_staging, sizeof(double) * 16));
         HIP_TRY(h, hipHostMalloc(&h->ctl_staging, sizeof(RekfCtl)));
         h->dev.ld = ld;
@@ -235,7 +238,7 @@ void rekf_destroy(rekf_t *h)
     for (auto &s : h->prof_slots) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     (void)hipFree(h->dev.ctl); (void)hipFree(h->dev.mu); (void)hipFree(h->dev.P);
     (void)hipFree(h->dev.W); (void)hipFree(h->dev.HPt); (void)hipFree(h->dev.Kn); (void)hipFree(h->dev.Sinv); (void)hipFree(h->dev.Wc); (void)hipFree(h->dev.y);
-    (void)hipFree(h->dev.map_xy); (void)hipFree(h->dev.map_cov); (void)hipFree(h->dev_out12);
+    (void)hipFree(h->dev.map_xy); (void)hipFree(h->dev.map_cov); (void)hipFree(h->dev_out12); (void)hipFree(h->dev_ell);
     if (h->pose_staging) (void)hipHostFree(h->pose_staging);
     if (h->ctl_staging) (void)hipHostFree(h->ctl_staging);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -347,6 +350,21 @@ int rekf_get_pose(rekf_t *h, double *t, double mu3[3], double sigma3x3[9])
     if (mu3) std::memcpy(mu3, h->pose_staging, sizeof(double) * 3);
     if (sigma3x3) std::memcpy(sigma3x3, h->pose_staging + 3, sizeof(double) * 9);
     return REKF_OK;
+}
+
+int rekf_get_marker_ellipses(rekf_t *h, double *out5, int cap, int *count)
+{
+    if (!h || !count || cap < 0 || (cap > 0 && !out5)) return REKF_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int lim = cap < h->max_landmarks ? cap : h->max_landmarks;
+    rekf_launch_ellipses(h->dev, h->dev_ell, lim, h->stream);
+    int rc = pull_ctl(h);                              // synchronises the stream; n is exact afterwards
+    if (rc != REKF_OK) return rc;
+    const int L = (h->ctl_staging->n - 3) / 2;
+    const int k = L < lim ? L : lim;
+    if (k > 0) HIP_TRY(h, hipMemcpy(out5, h->dev_ell, sizeof(double) * 5 * (size_t)k, hipMemcpyDeviceToHost));
+    *count = k;
+    return (L > cap) ? REKF_ERR_BUFFER : REKF_OK;
 }
 
 int rekf_get_n(rekf_t *h, int *n)

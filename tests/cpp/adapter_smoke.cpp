@@ -26,6 +26,8 @@ int main(int argc, char **)
     const auto m = f.LastMatch();
     if (mu.size() != 7 || m.state_obs_match_ids.size() != 2 || !m.new_ids.empty()) { std::printf("FAIL\n"); return 1; }
     if (!(std::fabs(sig[0] - sig[0]) == 0.0)) return 1;
+    const auto ell = f.MarkerEllipses();
+    if (ell.size() != 2 || !(ell[0].x_len > 0.0) || std::fabs(ell[0].x - mu[3]) > 0.0) { std::printf("FAIL ellipses\n"); return 1; }
     std::printf("ADAPTER_OK n=%zu t=%.2f x=%.6f\n", mu.size(), t, mu[0]);
     return 0;
 }

@@ -87,3 +87,13 @@ def drive_pair(sess, a, b, on_scan=None, max_events=None):
             if on_scan is not None:
                 on_scan(e, scans)
     return scans
+
+
+def ellipse_matrices(ell):
+    """(L,5) marker ellipses {mx,my,angle,x_len,y_len} -> (L,2,2) the matrices R diag(l0,l1) R^T they draw
+    (l = (len/2)^2 / 5.991): two descriptions of the same ellipse (pairs swapped, vector sign) agree here."""
+    ell = np.asarray(ell, np.float64).reshape(-1, 5)
+    c, s = np.cos(ell[:, 2]), np.sin(ell[:, 2])
+    l0, l1 = (ell[:, 3] / 2) ** 2 / 5.991, (ell[:, 4] / 2) ** 2 / 5.991
+    R = np.stack([np.stack([c, -s], -1), np.stack([s, c], -1)], -2)
+    return np.einsum("nij,nj,nkj->nik", R, np.stack([l0, l1], -1), R)

@@ -231,6 +231,30 @@ def test_duplicate_matches_state_parity_incl_chunk_boundary_landmark(oracle_lib)
     assert g.sync_code() == 0
 
 
+def test_marker_ellipses_on_device_match_oracle(oracle_lib):
+    """rekf_get_marker_ellipses (src/ros_node.cc:750-765 on the device, 5 doubles per landmark) vs the oracle's
+    restatement on the oracle's own state; compared as ellipses (R diag R^T) and component-wise."""
+    from tests.helpers import ellipse_matrices
+    cfg = synth.SessionConfig("ell", 40, 12, synth.OMNI, seed=33, speed=1.0, row_spacing=6.0)
+    sess = synth.make_session(cfg, max_scans=120)
+    g, o = _pair(cfg, sess)
+    drive_pair(sess, g, o)
+    eg, eo = g.marker_ellipses(), o.marker_ellipses()
+    L = (o.n - 3) // 2
+    assert eg.shape == eo.shape == (L, 5) and L > 8
+    assert np.abs(eg[:, :2] - eo[:, :2]).max() < 1e-12                       # landmark means
+    Mg, Mo = ellipse_matrices(eg), ellipse_matrices(eo)
+    assert np.abs(Mg - Mo).max() <= 1e-9 * np.abs(Mo).max()
+    assert np.allclose(eg[:, 3:], eo[:, 3:], rtol=1e-9, atol=0) and np.abs(np.sin(eg[:, 2] - eo[:, 2])).max() < 1e-6
+    assert g.marker_ellipses(max_landmarks=L).shape == (L, 5)
+    from reflector_ekf_slam_amd import RekfError
+    with pytest.raises(RekfError) as e:                                        # caller buffer too small: code, not a crash
+        g.marker_ellipses(max_landmarks=3)
+    assert e.value.code == -6
+    f = _simple()
+    assert f.marker_ellipses().shape == (0, 5)                                 # "No reflector detected" (ros_node.cc:741-745)
+
+
 def test_too_many_observations_is_an_error_code_not_a_crash():
     from reflector_ekf_slam_amd import RekfError
     g = _simple()
