@@ -15,6 +15,8 @@
 //   Wc   rows {0,1,2} and the matched landmarks' rows of W, compact (k_gather -> k_solve; layout at RekfDev::Wc)
 //   ctl                  RekfCtl below: n, error flags, the scan record
 //
+//   KnB, HPtB [4 x MR_PAD]  copies of rows nb..nb+3 of Kn / HPt, nb = 64*floor(n/64), when n mod 64 <= 4
+//                        (written by k_gain / k_gather for k_downdate's border strips)
 // Rows/columns >= n of W, HPt and Kn are kept exactly zero so that the tile kernels
 // never need bounds checks on P.
 #pragma once
@@ -23,6 +25,7 @@
 #define REKF_MAX_OBS_DEV 64
 #define REKF_MAX_ROWS 128                           // 2 per match (+3 pose rows: then K <= 62)
 #define REKF_MR_PAD 128                             // leading dimension of Sinv
+#define REKF_STRIP_MAX 4                            // border rows (n mod 64) that k_downdate handles as strips
 #define REKF_WC_PAIRS (3 * REKF_MR_PAD)              // offset of the pair section of Wc
 #define REKF_WC_DOUBLES (3 * REKF_MR_PAD + REKF_MAX_OBS_DEV * REKF_MR_PAD * 2)
 
@@ -74,6 +77,7 @@ struct RekfDev {
     double *Wc;         // compact rows of W for k_solve: rows 0..2 as [3][MR_PAD], then per state pair p the two
                         // landmark rows interleaved, [p][MR_PAD][2]  (REKF_WC_DOUBLES doubles)
     double *y;
+    double *KnB, *HPtB; // rows nb..nb+3 of Kn / HPt, [REKF_STRIP_MAX][MR_PAD] row-major (k_downdate border strips)
     float *map_xy;      // M_map x 2
     double *map_cov;    // M_map x 4 row-major
     int M_map;
@@ -81,6 +85,14 @@ struct RekfDev {
     int n_max;
     int dbg;            // ablation bits for rekf_debug_time_kernel; 0 in normal operation
 };
+
+// first row of the thin border that k_downdate treats as strips, or -1 (n a multiple of 64, border wider than
+// REKF_STRIP_MAX rows, or less than one full tile)
+__host__ __device__ static inline int rekf_strip_base(int n)
+{
+    const int rem = n % 64;
+    return (rem > 0 && rem <= REKF_STRIP_MAX && n >= 64) ? n - rem : -1;
+}
 
 // launch wrappers (ekf_kernels.hip)
 void rekf_launch_front(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);

@@ -574,6 +574,7 @@ __global__ __launch_bounds__(256) void k_gather(RekfDev d, RekfFrontArgs A)
     if (valid && c >= 3 && s_slot[tid] != 0x7fffffff) slot = s_slot[tid];
     const bool dup = s_dup[tid] != 0;
     double *__restrict__ Wc = d.Wc;
+    const int strip_nb = rekf_strip_base(n);          // k_downdate's border strips want rows nb.. of HPt contiguous
 
     // ---- W(c, r) = sum_k P(c,k) H(r,k)  and  HPt(c, r) = sum_k H(r,k) P(k,c) for this workgroup's row pairs
     for (int pr = blockIdx.y; pr < m_pad / 2; pr += gridDim.y) {
@@ -613,6 +614,7 @@ __global__ __launch_bounds__(256) void k_gather(RekfDev d, RekfFrontArgs A)
             }
             W[c + (size_t)r * ld] = v;
             HPt[c + (size_t)r * ld] = u;
+            if (strip_nb >= 0 && c >= strip_nb && c < strip_nb + REKF_STRIP_MAX) d.HPtB[(c - strip_nb) * REKF_MR_PAD + r] = u;
             if (slot >= 0) {
                 if (slot < 3) Wc[slot * REKF_MR_PAD + r] = v;
                 else Wc[REKF_WC_PAIRS + ((size_t)((slot - 3) >> 1) * REKF_MR_PAD + r) * 2 + ((slot - 3) & 1)] = v;
@@ -949,6 +951,7 @@ __global__ __launch_bounds__(512) void k_gain(RekfDev d)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int idx = lane & 15, kq = lane >> 4;
     const int ntile = m_pad / 16;
+    const int strip_nb = rekf_strip_base(n);          // k_downdate's border strips want rows nb.. of Kn contiguous
     const double *__restrict__ Wp = d.W + (size_t)(i0 + idx);
     for (int jt = wave; jt <= ntile; jt += 8) {
         const bool is_mu = jt == ntile;
@@ -975,6 +978,8 @@ __global__ __launch_bounds__(512) void k_gain(RekfDev d)
             for (int r = 0; r < 4; ++r) {
                 const int j = j0 + kq + 4 * r;                               // D row
                 d.Kn[(i0 + idx) + (size_t)j * ld] = -acc[r];                 // D col = idx
+                if (strip_nb >= 0 && i0 + idx >= strip_nb && i0 + idx < strip_nb + REKF_STRIP_MAX)
+                    d.KnB[(i0 + idx - strip_nb) * REKF_MR_PAD + j] = -acc[r];
             }
         } else if (kq == 0) {                                                // D row 0 = dmu
             const int i = i0 + idx;
@@ -1020,6 +1025,13 @@ __global__ __launch_bounds__(512) void k_gain(RekfDev d)
 
 __device__ static inline void dd_lds_barrier() { lds_barrier(); }
 
+// Border strips.  When n is a few rows past a multiple of the tile size (n = 3 + 2L with L a multiple of
+// 32: three rows), a last tile row/column would be 95 % padding yet cost a full tile of traffic and MFMA
+// time -- and with 33^2 = 1089 tiles on 256 workgroups, a FIFTH tile for a quarter of them.  Instead the
+// tile grid covers [0, nb)^2, nb = 64*floor(n/64), and the strips P(nb.., :) and P(:, nb..) ride on the
+// diagonal tiles: the workgroup that has the panels Kn(I,:) and HPt(I,:) of tile (I,I) in LDS also updates
+// P(64I.., nb..) and P(nb.., 64I..) with plain FMAs against the border rows of Kn / HPt (s_border).
+#define DD_STRIP_MAX REKF_STRIP_MAX
 // FAST = the whole innovation fits one full 64-wide k-chunk (m_pad == 64, i.e. 25..32 matched
 // observations: BASELINE.json's N=1024 x 32 configuration).  Its loop is peeled so that every
 // prefetch/consume pair is unconditional and hipcc's waitcnt pass can count them exactly.
@@ -1027,7 +1039,13 @@ template <bool FAST, bool ABL>
 __device__ static void downdate_body(const RekfDev &d, double *dd_smem, int n, int m_pad)
 {
     const int dbg = ABL ? d.dbg : 0;       // ablation hooks compile away in the production instance
-    const int T = (n + DT - 1) / DT;
+#ifdef REKF_DEBUG_TIMING
+    const long long t_entry = clock64();
+#endif
+    __shared__ __attribute__((aligned(16))) double s_border[2][DD_STRIP_MAX][REKF_MR_PAD];            // [Kn | HPt] border rows nb.., all k
+    const int rem = n % DT;
+    const bool strips = rem > 0 && rem <= DD_STRIP_MAX && n >= DT;       // thin border: strips instead of padded tiles
+    const int T = strips ? n / DT : (n + DT - 1) / DT;
     const int nchunk = FAST ? 1 : (m_pad + DKC - 1) / DKC;
     // Tile assignment.  Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only):
     // the tile grid is cut into 2 x 4 regions, one per XCD, so that an XCD's private L2 only ever
@@ -1057,7 +1075,22 @@ __device__ static void downdate_body(const RekfDev &d, double *dd_smem, int n, i
     v2d stgK[DD_STG], stgW[DD_STG], pnext[8];
     v4d acc[2][2];
 
-    auto tile_IJ = [&](int tile, int &I, int &J) { const int jj = tile / i_n; I = i_lo + (tile - jj * i_n); J = j_lo + jj; };
+    // A workgroup's diagonal tile (at most one: they are i_n + 1 apart) is taken LAST, so that its border-strip
+    // work stays out of the pipelined loop: positions t_diag and t_end - 1 of the range are swapped.
+    int t_diag = t_end - 1;
+    if (strips) {                                          // tile t = jj*i_n + ii is diagonal iff ii = jj + (j_lo - i_lo)
+        const int jj0 = t_begin / i_n, dl = j_lo - i_lo;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {                       // a range this short (< i_n) meets at most two tile columns
+            const int jj = jj0 + q, ii = jj + dl, t = jj * i_n + ii;
+            if (ii >= 0 && ii < i_n && jj < j_n && t >= t_begin && t < t_end) t_diag = t;
+        }
+    }
+    auto tile_IJ = [&](int tile, int &I, int &J) {
+        const int tt = (tile == t_end - 1) ? t_diag : ((tile == t_diag) ? t_end - 1 : tile);
+        const int jj = tt / i_n;
+        I = i_lo + (tt - jj * i_n); J = j_lo + jj;
+    };
     auto load_panels = [&](int item) {
         if (dbg & 8) return;                 // ablation hook: skip the panel reads
         int I, J;
@@ -1161,9 +1194,160 @@ __device__ static void downdate_body(const RekfDev &d, double *dd_smem, int n, i
             }
     };
 
+    // Tile (I,I) of an item: its LDS panels are Kn(64I.., k0..) and HPt(64I.., k0..); see "Border strips" above.
+    // 192 threads, two outputs each: threads [0,96) the column strip P(64I+x.., nb+b), [96,192) the row strip
+    // P(nb+b, 64I+x..), x = 2*(u%32), b = u/32.  The P operands are fetched before the tile's MFMA loop
+    // (strip_prefetch) and consumed after it (strip_finish); rem <= 3 pairs per pass, DD_STRIP_MAX rows in two.
+    v2d strip_p[(2 * DD_STRIP_MAX * 32 + 255) / 256];
+    bool strip_on = false;
+    int strip_I = 0;
+    auto strip_addr = [&](int pass, int I, double *&p0, double *&p1, int &which, int &b, int &x) {
+        const int t = tid + 256 * pass;               // fixed DD_STRIP_MAX*32 slots per strip: no runtime division
+        which = t / (DD_STRIP_MAX * 32); const int u = t % (DD_STRIP_MAX * 32);
+        b = u >> 5; x = 2 * (u & 31);
+        const int nb = DT * T;
+        if (which == 0) { p0 = P + (size_t)(DT * I + x) + (size_t)(nb + b) * ld; p1 = p0 + 1; }
+        else { p0 = P + (size_t)(nb + b) + (size_t)(DT * I + x) * ld; p1 = p0 + ld; }
+    };
+    auto strip_prefetch = [&](int item) {
+        strip_on = false;
+        if (!strips || (ABL && (dbg & 128))) return;
+        int I, J;
+        tile_IJ(t_begin + item / nchunk, I, J);
+        if (I != J) return;
+        strip_on = true; strip_I = I;
+#pragma unroll
+        for (int pass = 0; pass < (2 * DD_STRIP_MAX * 32 + 255) / 256; ++pass) {
+            {
+                double *p0, *p1; int which, b, x;
+                strip_addr(pass, I, p0, p1, which, b, x);
+                if (which < 2 && b < rem) { strip_p[pass].x = *p0; strip_p[pass].y = *p1; }
+            }
+        }
+    };
+    auto strip_finish = [&](int item) {
+        if (!strip_on) return;
+        const int I = strip_I;
+        const int k0 = FAST ? 0 : (item % nchunk) * DKC;
+        const int kmax = FAST ? DKC : ((m_pad - k0 < DKC) ? (m_pad - k0) : DKC);
+        const double *sK = dd_smem + (size_t)((item & 1) * DD_NBUF / 2) * 2 * DKC * 64, *sW = sK + DKC * 64;
+#pragma unroll
+        for (int pass = 0; pass < (2 * DD_STRIP_MAX * 32 + 255) / 256; ++pass) {
+            {
+                double *p0, *p1; int which, b, x;
+                strip_addr(pass, I, p0, p1, which, b, x);
+                if (which >= 2 || b >= rem) continue;
+                // which = 0: += sum_k Kn(64I+x, k) HPt(nb+b, k);  1: += sum_k Kn(nb+b, k) HPt(64I+x, k)
+                const double *panel = (which ? sW : sK) + x;
+                const double *brow = s_border[which ? 0 : 1][b] + k0;
+                v2d acc = strip_p[pass];
+#pragma unroll 8
+                for (int k = 0; k < kmax; k += 2) {
+                    const v2d bb = *(const v2d *)(brow + k);
+                    const v2d v0 = *(const v2d *)(panel + k * 64), v1 = *(const v2d *)(panel + (k + 1) * 64);
+                    acc.x = fma(v0.x, bb.x, acc.x); acc.y = fma(v0.y, bb.x, acc.y);
+                    acc.x = fma(v1.x, bb.y, acc.x); acc.y = fma(v1.y, bb.y, acc.y);
+                }
+                *p0 = acc.x; *p1 = acc.y;
+            }
+        }
+        if (I == 0 && tid < rem * rem) {          // the corner block P(nb.., nb..)
+            const int nb = DT * T;
+            const int a = tid / rem, b = tid - a * rem;
+            double *pp = P + (size_t)(nb + a) + (size_t)(nb + b) * ld;
+            double v = *pp;
+#pragma unroll 16
+            for (int k = 0; k < kmax; ++k) v = fma(s_border[0][a][k0 + k], s_border[1][b][k0 + k], v);
+            *pp = v;
+        }
+    };
+
     // prologue: item 0
     load_panels(0);
     load_p(t_begin);
+    // FAST epilogue of a workgroup with a diagonal tile: the strip FMAs ride inside the tile's MFMA loop (the
+    // matrix pipe is the bound there, VALU and LDS have room).  The k range is split over the four waves -- each
+    // lane: two x, all DD_STRIP_MAX border rows, so the panel reads are shared -- partial sums meet in the LDS
+    // buffer that has no next tile to hold, and the threads of the prefetch mapping finish their (which, b, x).
+    auto mfma_chunk_strips = [&](int item) {
+        const double *sK = dd_smem + (size_t)((item & 1) * DD_NBUF / 2) * 2 * DKC * 64, *sW = sK + DKC * 64;
+        const double *aW = sW + 32 * wj + 2 * idx + kq * 64;        // A[j][k] = HP(k,j)
+        const double *bK = sK + 32 * wi + 2 * idx + kq * 64;        // B[k][i] = Kn(i,k)
+        const int which = lane >> 5, x = 2 * (lane & 31), kb = (DKC / 4) * wave;
+        const double *panel = (which ? sW : sK) + x + kb * 64;
+        const double *brow = &s_border[which ? 0 : 1][0][kb];
+        v2d sacc[DD_STRIP_MAX];
+#pragma unroll
+        for (int b = 0; b < DD_STRIP_MAX; ++b) { sacc[b].x = 0.0; sacc[b].y = 0.0; }
+        v2d a2 = *(const v2d *)(aW), b2 = *(const v2d *)(bK);
+#pragma unroll
+        for (int kk = 0; kk < DKC / 4; ++kk) {
+            v2d a2n = a2, b2n = b2;
+            if (kk + 1 < DKC / 4) {
+                a2n = *(const v2d *)(aW + (kk + 1) * 256);
+                b2n = *(const v2d *)(bK + (kk + 1) * 256);
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.y, acc[1][1], 0, 0, 0);
+            if ((kk & 1) == 0) {                            // k pair (kk, kk+1) of this wave's quarter of the k range
+                const v2d v0 = *(const v2d *)(panel + kk * 64), v1 = *(const v2d *)(panel + (kk + 1) * 64);
+#pragma unroll
+                for (int b = 0; b < DD_STRIP_MAX; ++b) {
+                    const v2d bb = *(const v2d *)(brow + b * REKF_MR_PAD + kk);
+                    sacc[b].x = fma(v0.x, bb.x, sacc[b].x); sacc[b].y = fma(v0.y, bb.x, sacc[b].y);
+                    sacc[b].x = fma(v1.x, bb.y, sacc[b].x); sacc[b].y = fma(v1.y, bb.y, sacc[b].y);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            a2 = a2n; b2 = b2n;
+        }
+        v2d *red = (v2d *)(dd_smem + (size_t)(((item + 1) & 1) * DD_NBUF / 2) * 2 * DKC * 64);
+#pragma unroll
+        for (int b = 0; b < DD_STRIP_MAX; ++b) red[(wave * DD_STRIP_MAX + b) * 64 + lane] = sacc[b];
+    };
+    auto strip_reduce_store = [&](int item) {
+        const int I = strip_I;
+        const v2d *red = (const v2d *)(dd_smem + (size_t)(((item + 1) & 1) * DD_NBUF / 2) * 2 * DKC * 64);
+        dd_lds_barrier();
+        {
+            double *p0, *p1; int which, b, x;
+            strip_addr(0, I, p0, p1, which, b, x);
+            if (which < 2 && b < rem) {
+                v2d t = strip_p[0];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { const v2d r = red[(w * DD_STRIP_MAX + b) * 64 + which * 32 + (x >> 1)]; t.x += r.x; t.y += r.y; }
+                *p0 = t.x; *p1 = t.y;
+            }
+        }
+        if (I == 0 && tid < 64) {                 // the corner block P(nb.., nb..): 16 (a,b) slots x 4 quarters of k
+            const int a = (tid >> 2) & 3, b = tid & 3, k4 = tid >> 4;
+            const double *ra = &s_border[0][a][(DKC / 4) * k4], *rb = &s_border[1][b][(DKC / 4) * k4];
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < DKC / 4; k += 2) {
+                const v2d u = *(const v2d *)(ra + k), w = *(const v2d *)(rb + k);
+                v = fma(u.x, w.x, v); v = fma(u.y, w.y, v);
+            }
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (k4 == 0 && a < rem && b < rem) {
+                double *pp = P + (size_t)(DT * T + a) + (size_t)(DT * T + b) * ld;
+                *pp += v;
+            }
+        }
+    };
+    static_assert(2 * DD_STRIP_MAX * 32 <= 256, "one pass of the prefetch mapping");
+
+    bool has_diag = false;
+    if (strips) { int I, J; tile_IJ(t_end - 1, I, J); has_diag = I == J; }
+    if (has_diag) {                         // border rows of Kn / HPt -> LDS (visible after the barrier below)
+        // rows nb..nb+3 of Kn and HPt, as k_gain / k_gather left them contiguous in KnB / HPtB (2 x 4 KB)
+        const v2d b0 = ((const v2d *)d.KnB)[tid], b1 = ((const v2d *)d.HPtB)[tid];
+        ((v2d *)&s_border[0][0][0])[tid] = b0;
+        ((v2d *)&s_border[1][0][0])[tid] = b1;
+    }
     write_panels(0, 0);
     acc_from_pnext();
     dd_lds_barrier();
@@ -1235,9 +1419,33 @@ __device__ static void downdate_body(const RekfDev &d, double *dd_smem, int n, i
         }
 #ifdef REKF_DEBUG_TIMING
         if (rec) for (int i = 1; i < nq; ++i) const_cast<RekfCtl *>(d.ctl)->dbg[8 + i - 1] = tq[i] - tq[0];
+        if (rec) const_cast<RekfCtl *>(d.ctl)->dbg[7] = tq[0] - t_entry;      // prologue
 #endif
-        mfma_chunk(nitems - 1);
+#ifdef REKF_DEBUG_TIMING
+        const long long te0 = clock64();
+#endif
+        strip_prefetch(nitems - 1);
+        if (strip_on) mfma_chunk_strips(nitems - 1);
+        else mfma_chunk(nitems - 1);
+#ifdef REKF_DEBUG_TIMING
+        __builtin_amdgcn_sched_barrier(0);
+        const long long te1 = clock64();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         store_tile(t_begin + nitems - 1);
+#ifdef REKF_DEBUG_TIMING
+        __builtin_amdgcn_sched_barrier(0);
+        const long long te2 = clock64();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        if (strip_on) strip_reduce_store(nitems - 1);
+#ifdef REKF_DEBUG_TIMING
+        if (rec) {
+            RekfCtl *c = const_cast<RekfCtl *>(d.ctl);
+            c->dbg[6] = clock64() - t_entry;          // whole body, stores issued
+            c->dbg[24] = te1 - te0; c->dbg[25] = te2 - te1; c->dbg[26] = clock64() - te2;
+        }
+#endif
     } else {
         for (int item = 0; item < nitems; ++item) {
             const int tile = t_begin + item / nchunk;
@@ -1246,7 +1454,9 @@ __device__ static void downdate_body(const RekfDev &d, double *dd_smem, int n, i
             const bool next_new_tile = has_next && (chunk == nchunk - 1);
             if (has_next) load_panels(item + 1);
             if (next_new_tile) load_p(tile + 1);
+            strip_prefetch(item);
             mfma_chunk(item);
+            strip_finish(item);
             if (chunk == nchunk - 1) store_tile(tile);
             if (has_next) {
                 if (DD_NBUF == 1) dd_lds_barrier();

@@ -194,6 +194,8 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
         HIP_TRY(h, hipMalloc(&h->dev.Kn, sizeof(double) * (size_t)ld * REKF_MR_PAD));
         HIP_TRY(h, hipMalloc(&h->dev.Sinv, sizeof(double) * REKF_MR_PAD * REKF_MR_PAD));
         HIP_TRY(h, hipMalloc(&h->dev.Wc, sizeof(double) * REKF_WC_DOUBLES));
+        HIP_TRY(h, hipMalloc(&h->dev.KnB, sizeof(double) * REKF_STRIP_MAX * REKF_MR_PAD));
+        HIP_TRY(h, hipMalloc(&h->dev.HPtB, sizeof(double) * REKF_STRIP_MAX * REKF_MR_PAD));
         HIP_TRY(h, hipMalloc(&h->dev.y, sizeof(double) * REKF_MR_PAD));
         HIP_TRY(h, hipMalloc(&h->dev_out12, sizeof(double) * 12));
         HIP_TRY(h, hipMalloc(&h->dev_ell, sizeof(double) * 5 * (size_t)(max_landmarks > 0 ? max_landmarks : 1)));
@@ -210,6 +212,8 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
         HIP_TRY(h, hipMemsetAsync(h->dev.Kn, 0, sizeof(double) * (size_t)ld * REKF_MR_PAD, h->stream));
         HIP_TRY(h, hipMemsetAsync(h->dev.Sinv, 0, sizeof(double) * REKF_MR_PAD * REKF_MR_PAD, h->stream));
         HIP_TRY(h, hipMemsetAsync(h->dev.Wc, 0, sizeof(double) * REKF_WC_DOUBLES, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->dev.KnB, 0, sizeof(double) * REKF_STRIP_MAX * REKF_MR_PAD, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->dev.HPtB, 0, sizeof(double) * REKF_STRIP_MAX * REKF_MR_PAD, h->stream));
         HIP_TRY(h, hipMemsetAsync(h->dev.y, 0, sizeof(double) * REKF_MR_PAD, h->stream));
         std::memset(h->ctl_staging, 0, sizeof(RekfCtl));
         h->ctl_staging->n = 3;
@@ -237,7 +241,7 @@ void rekf_destroy(rekf_t *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &s : h->prof_slots) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     (void)hipFree(h->dev.ctl); (void)hipFree(h->dev.mu); (void)hipFree(h->dev.P);
-    (void)hipFree(h->dev.W); (void)hipFree(h->dev.HPt); (void)hipFree(h->dev.Kn); (void)hipFree(h->dev.Sinv); (void)hipFree(h->dev.Wc); (void)hipFree(h->dev.y);
+    (void)hipFree(h->dev.W); (void)hipFree(h->dev.HPt); (void)hipFree(h->dev.Kn); (void)hipFree(h->dev.Sinv); (void)hipFree(h->dev.Wc); (void)hipFree(h->dev.KnB); (void)hipFree(h->dev.HPtB); (void)hipFree(h->dev.y);
     (void)hipFree(h->dev.map_xy); (void)hipFree(h->dev.map_cov); (void)hipFree(h->dev_out12); (void)hipFree(h->dev_ell);
     if (h->pose_staging) (void)hipHostFree(h->pose_staging);
     if (h->ctl_staging) (void)hipHostFree(h->ctl_staging);

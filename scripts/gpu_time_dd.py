@@ -14,6 +14,6 @@ L = _lib.rekf(); L.rekf_debug_time_kernel.argtypes=[C.c_void_p, C.c_int, C.c_int
 for name, k in (("solve",3),("gain",4),("downdate",5)):
     us = C.c_double(); rc = L.rekf_debug_time_kernel(g._h, k, 300, 0, C.byref(us))
     print(name, "rc", rc, "avg_us %.2f" % us.value)
-for ab in (32, 32+64, 32+128):
+for ab in (0, 512, 0, 8192, 0, 512, 0):
     us = C.c_double(); rc = L.rekf_debug_time_kernel(g._h, 5, 300, ab, C.byref(us))
     print("downdate ablate", ab, "avg_us %.2f" % us.value)

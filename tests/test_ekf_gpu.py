@@ -231,6 +231,31 @@ def test_duplicate_matches_state_parity_incl_chunk_boundary_landmark(oracle_lib)
     assert g.sync_code() == 0
 
 
+@pytest.mark.parametrize("L,obs", [(63, 10), (64, 12), (65, 12), (95, 40), (96, 20)],
+                         ids=["n129_rem1", "n131_rem3", "n133_rem5_padded", "n193_rem1_m80", "n195_rem3"])
+def test_downdate_border_strips_full_covariance(oracle_lib, L, obs):
+    """k_downdate treats a border of <= 4 rows past a multiple of 64 (n = 3 + 2L odd: 1 or 3) as strips riding on the
+    diagonal tiles instead of padded tiles; 5 rows fall back to padded tiles.  Whole P against the oracle, in the
+    single-chunk (m_pad = 64 never here), generic (m_pad < 64) and multi-chunk (m_pad = 80) forms."""
+    cfg = synth.SessionConfig(f"strip{L}", L, obs, synth.DIFF, seed=700 + L, speed=2.0, row_spacing=8.0,
+                              range_max=16.0 if obs > 20 else 10.0, extra_scans=40)
+    sess = synth.make_session(cfg)                    # whole route: the map is complete for the second half
+    g, o = _pair(cfg, sess)
+
+    def chk(e, k):
+        a, b = norm_match(g.last_match()), norm_match(o.last_match())
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)), f"association differs at scan {k}"
+
+    drive_pair(sess, g, o, chk)
+    st = g.GetState()
+    mo, Po = o.state()
+    assert st.mu.shape == mo.shape == (3 + 2 * L,)
+    assert np.abs(st.mu - mo).max() < 1e-9
+    assert np.abs(st.sigma - Po).max() < 1e-11 * max(1.0, np.abs(Po).max())
+    assert np.abs(st.sigma - st.sigma.T).max() < 1e-12
+    assert g.sync_code() == 0
+
+
 def test_marker_ellipses_on_device_match_oracle(oracle_lib):
     """rekf_get_marker_ellipses (src/ros_node.cc:750-765 on the device, 5 doubles per landmark) vs the oracle's
     restatement on the oracle's own state; compared as ellipses (R diag R^T) and component-wise."""
