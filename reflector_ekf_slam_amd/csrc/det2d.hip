@@ -62,6 +62,7 @@ struct Det2dOut {
 struct Det2dBufs {
     const float *ranges, *intens, *ang, *cosv, *sinv;
     float2 *pt;            // per beam: point in base_link (valid beams)
+    float2 *contrib;       // per beam of an accepted cluster: its de-skewed point in the scan-end frame (flags bit 8)
     float *pt_t;           // per beam: float32 point time
     int *lastvalid;        // last valid beam <= i  (point_cloud.back() at beam i), -1 if none
     int *cloud_idx;        // index of beam i in point_cloud (valid beams)
@@ -349,31 +350,54 @@ __global__ __launch_bounds__(1024) void k_det2d(Det2dArgs A, Det2dBufs B)
         B.returns[B.cloud_idx[i]] = r2f_apply(rel, p.x, p.y);
     }
 
-    // ---- cluster centres (:277-306): one lane per cluster, float32 running sum in beam order
+    // ---- cluster centres (:277-306).  The expensive part of a member beam -- its own extrapolated pose
+    // (FP64 trigonometry) -- is computed for all member beams in parallel; the float32 running sum in beam
+    // order that the reference takes (:300-305) is then a chain of plain additions, one wave per cluster.
     const int K = s_tot[0], off = s_tot[1];
-    if (tid < K) {
+    const float tb_c = cosf(to_base.a), tb_s = sinf(to_base.a);
+    for (int j = tid; j < N; j += 1024) {
 #pragma clang fp contract(off)
-        const int k = tid + off;
+        bool member = false;
+        for (int k = off; k < off + K && !member; ++k)
+            member = (s_cl[4 * k] <= j && j <= s_cl[4 * k + 1]) || (s_cl[4 * k + 2] >= 0 && s_cl[4 * k + 2] <= j && j <= s_cl[4 * k + 3]);
+        if (!member) continue;
+        float2 p; float t;
+        if (B.flags[j] & 2) { const int lvj = B.lastvalid[j]; p = B.pt[lvj]; t = B.pt_t[lvj]; }
+        else if (isinf(B.ranges[j])) continue;                             // :120-121
+        else t = gap_time_and_point(A, B, j, p);
+        const R2f pose = r2_cast(extrapolator_pose(A, (double)t));          // :287,:293
+        const float2 po = r2f_apply(pose, p.x, p.y);
+        B.contrib[j] = r2f_apply_cs(tb_c, tb_s, to_base.x, to_base.y, po.x, po.y);
+        B.flags[j] |= 8;
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int c = wave; c < K; c += 16) {
+#pragma clang fp contract(off)
+        const int k = c + off;
         float cx = 0.f, cy = 0.f;
         int count = 0;
-        const float tb_c = cosf(to_base.a), tb_s = sinf(to_base.a);
         for (int seg = 0; seg < 2; ++seg) {
             const int fi = s_cl[4 * k + 2 * seg], li = s_cl[4 * k + 2 * seg + 1];
             if (fi < 0) continue;
-            for (int j = fi; j <= li; ++j) {
-                float2 p; float t;
-                if (B.flags[j] & 2) { const int lvj = B.lastvalid[j]; p = B.pt[lvj]; t = B.pt_t[lvj]; }
-                else if (isinf(B.ranges[j])) continue;                         // :120-121
-                else t = gap_time_and_point(A, B, j, p);
-                const R2f pose = r2_cast(extrapolator_pose(A, (double)t));      // :287,:293
-                const float2 po = r2f_apply(pose, p.x, p.y);
-                const float2 pb2 = r2f_apply_cs(tb_c, tb_s, to_base.x, to_base.y, po.x, po.y);
-                cx += pb2.x; cy += pb2.y;
-                ++count;
+            for (int j0 = fi; j0 <= li; j0 += 64) {
+                const int j = j0 + lane;
+                const bool mem = j <= li && (B.flags[j] & 8);
+                const float2 v = mem ? B.contrib[j] : make_float2(0.f, 0.f);
+                unsigned long long mask = __ballot(mem);
+                count += __popcll(mask);
+                while (mask) {
+                    const int b = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    cx += __shfl(v.x, b, 64);
+                    cy += __shfl(v.y, b, 64);
+                }
             }
         }
-        B.out->centers[2 * tid] = cx / (float)count;                             // :305
-        B.out->centers[2 * tid + 1] = cy / (float)count;
+        if (lane == 0) {
+            B.out->centers[2 * c] = cx / (float)count;                           // :305
+            B.out->centers[2 * c + 1] = cy / (float)count;
+        }
     }
 }
 
@@ -388,7 +412,7 @@ struct rdet2d {
     std::vector<Odom> odom;            // PoseExtrapolator::odometry_data_
     // device buffers
     float *d_ranges, *d_intens, *d_ang, *d_cos, *d_sin, *d_pt_t;
-    float2 *d_pt, *d_returns;
+    float2 *d_pt, *d_returns, *d_contrib;
     int *d_lastvalid, *d_cloud_idx, *d_prevb, *d_runid, *d_run_first, *d_run_last, *d_run_acc;
     unsigned char *d_flags;
     Det2dOut *d_out, *h_out;           // h_out pinned
@@ -445,7 +469,7 @@ int rdet2d_create(const rdet2d_options *opt, const double s2b[3], int max_beams,
         DET_TRY(h, hipMalloc(&h->d_ranges, 4 * nb)); DET_TRY(h, hipMalloc(&h->d_intens, 4 * nb));
         DET_TRY(h, hipMalloc(&h->d_ang, 4 * nb)); DET_TRY(h, hipMalloc(&h->d_cos, 4 * nb));
         DET_TRY(h, hipMalloc(&h->d_sin, 4 * nb)); DET_TRY(h, hipMalloc(&h->d_pt_t, 4 * nb));
-        DET_TRY(h, hipMalloc(&h->d_pt, 8 * nb)); DET_TRY(h, hipMalloc(&h->d_returns, 8 * nb));
+        DET_TRY(h, hipMalloc(&h->d_pt, 8 * nb)); DET_TRY(h, hipMalloc(&h->d_returns, 8 * nb)); DET_TRY(h, hipMalloc(&h->d_contrib, 8 * nb));
         DET_TRY(h, hipMalloc(&h->d_lastvalid, 4 * nb)); DET_TRY(h, hipMalloc(&h->d_cloud_idx, 4 * nb));
         DET_TRY(h, hipMalloc(&h->d_prevb, 4 * nb)); DET_TRY(h, hipMalloc(&h->d_runid, 4 * nb));
         DET_TRY(h, hipMalloc(&h->d_run_first, 4 * nb)); DET_TRY(h, hipMalloc(&h->d_run_last, 4 * nb));
@@ -465,7 +489,7 @@ void rdet2d_destroy(rdet2d_t *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *ptrs[] = {h->d_ranges, h->d_intens, h->d_ang, h->d_cos, h->d_sin, h->d_pt_t, h->d_pt, h->d_returns,
+    void *ptrs[] = {h->d_ranges, h->d_intens, h->d_ang, h->d_cos, h->d_sin, h->d_pt_t, h->d_pt, h->d_returns, h->d_contrib,
                     h->d_lastvalid, h->d_cloud_idx, h->d_prevb, h->d_runid, h->d_run_first, h->d_run_last,
                     h->d_run_acc, h->d_flags, h->d_out};
     for (void *p : ptrs) (void)hipFree(p);
@@ -556,7 +580,7 @@ int rdet2d_handle_scan(rdet2d_t *h, double stamp, float angle_min, float angle_m
     B.pt = h->d_pt; B.pt_t = h->d_pt_t; B.lastvalid = h->d_lastvalid; B.cloud_idx = h->d_cloud_idx;
     B.prevb = h->d_prevb; B.runid = h->d_runid; B.flags = h->d_flags;
     B.run_first = h->d_run_first; B.run_last = h->d_run_last; B.run_acc = h->d_run_acc;
-    B.returns = h->d_returns; B.out = h->d_out;
+    B.returns = h->d_returns; B.contrib = h->d_contrib; B.out = h->d_out;
     hipLaunchKernelGGL(k_det2d, dim3(1), dim3(1024), 0, h->stream, A, B);
     DET_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, sizeof(Det2dOut), hipMemcpyDeviceToHost, h->stream));
     DET_TRY(h, hipStreamSynchronize(h->stream));
