@@ -123,37 +123,46 @@ __device__ static inline void knn_insert(float (&L)[KNN], float x)
 }
 __global__ __launch_bounds__(256) void k3_knn(Det3dBufs B)
 {
-    __shared__ float tile[4][3][256];             // per-wave candidate tile, SoA
     __shared__ float part[3][KNN][64];            // partial lists of waves 1..3
     const int M = B.ctl->M;
     const int q0 = blockIdx.x * 64;
     if (q0 >= M) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = q0 + lane;
     const bool live = i < M;
-    const float *X = B.p1, *Y = B.p1 + B.cap, *Z = B.p1 + 2 * B.cap;
+    const float *__restrict__ X = B.p1, *__restrict__ Y = B.p1 + B.cap, *__restrict__ Z = B.p1 + 2 * B.cap;
     const float px = live ? X[i] : 0.f, py = live ? Y[i] : 0.f, pz = live ? Z[i] : 0.f;
     float L[KNN];
 #pragma unroll
     for (int q = 0; q < KNN; ++q) L[q] = INFINITY;
     const int ntiles = (M + 255) / 256, qt = q0 / 256;
-    // tiles by distance from the queries' tile: qt, qt+1, qt-1, qt+2, ...; wave w takes every 4th of them
-    for (int k = wave; k < 2 * ntiles; k += 4) {
+    // tiles by distance from the queries' tile: qt, qt+1, qt-1, qt+2, ...; wave w takes every 4th of them.
+    // A candidate is the same for all 64 lanes: its coordinates come through the SCALAR cache (uniform
+    // addresses -> s_load), eight at a time, and enter the VALU as SGPR operands: no LDS, no vector loads.
+    int valid = 0;                                            // valid tiles so far: the v-th one goes to wave v % 4
+    for (int k = 0; k < 2 * ntiles; ++k) {
         const int t = (k & 1) ? qt + (k + 1) / 2 : qt - k / 2;
         if (t < 0 || t >= ntiles) continue;
+        if ((valid++ & 3) != wave) continue;
         const int j0 = 256 * t, jn = min(256, M - j0);
+        float nx[8], ny[8], nz[8];                            // the next group of eight is loaded while this one is used
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + lane + 64 * u;
-            if (j < M) { tile[wave][0][lane + 64 * u] = X[j]; tile[wave][1][lane + 64 * u] = Y[j]; tile[wave][2][lane + 64 * u] = Z[j]; }
+        for (int u = 0; u < 8; ++u) { const int j = min(j0 + u, M - 1); nx[u] = X[j]; ny[u] = Y[j]; nz[u] = Z[j]; }
+        for (int c0 = 0; c0 < jn; c0 += 8) {
+            float cx[8], cy[8], cz[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { cx[u] = nx[u]; cy[u] = ny[u]; cz[u] = nz[u]; }
+            if (c0 + 8 < jn) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int j = min(j0 + c0 + 8 + u, M - 1); nx[u] = X[j]; ny[u] = Y[j]; nz[u] = Z[j]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float d2 = d2f(px, py, pz, cx[u], cy[u], cz[u]);
+                const bool need = (c0 + u < jn) && d2 < L[KNN - 1];
+                if (__any(need)) knn_insert(L, need ? d2 : INFINITY);
+            }
         }
-        __builtin_amdgcn_wave_barrier();           // one wave writes and reads its own tile: LDS is in order
-        for (int c = 0; c < jn; ++c) {
-            const float d2 = d2f(px, py, pz, tile[wave][0][c], tile[wave][1][c], tile[wave][2][c]);
-            const bool need = d2 < L[KNN - 1];
-            if (__any(need)) knn_insert(L, need ? d2 : INFINITY);
-        }
-        __builtin_amdgcn_wave_barrier();
     }
     if (wave > 0) {
 #pragma unroll
@@ -244,29 +253,29 @@ __device__ static int uf_find(int *parent, int x)
 }
 __global__ __launch_bounds__(256) void k3_cc(Det3dBufs B)
 {
-    __shared__ float tile[4][3][256];
     const int M2 = B.ctl->M2;
     const int q0 = blockIdx.x * 64;
     if (q0 >= M2) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = q0 + lane;
     const bool live = i < M2;
-    const float *X = B.p2, *Y = B.p2 + B.cap, *Z = B.p2 + 2 * B.cap;
+    const float *__restrict__ X = B.p2, *__restrict__ Y = B.p2 + B.cap, *__restrict__ Z = B.p2 + 2 * B.cap;
     const float px = live ? X[i] : 0.f, py = live ? Y[i] : 0.f, pz = live ? Z[i] : 0.f;
     int *parent = B.label;
     int ri = i;                                               // a (possibly stale) ancestor of i
-    const int tmax = min((M2 + 255) / 256, (q0 + 63) / 256 + 1);   // only j < i: every edge is handled by its larger end
-    for (int t = wave; t < tmax; t += 4) {
-        const int j0 = 256 * t, jn = min(256, M2 - j0);
+    const int jend = min(M2, q0 + 63);                        // only j < i: every edge is handled by its larger end
+    // candidates through the scalar cache as in k3_knn; wave w takes the 8-candidate groups w, w+4, ...
+    for (int c0 = 8 * wave; c0 < jend; c0 += 32) {
+        float cx[8], cy[8], cz[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + lane + 64 * u;
-            if (j < M2) { tile[wave][0][lane + 64 * u] = X[j]; tile[wave][1][lane + 64 * u] = Y[j]; tile[wave][2][lane + 64 * u] = Z[j]; }
+        for (int u = 0; u < 8; ++u) {
+            const int j = min(c0 + u, M2 - 1);
+            cx[u] = X[j]; cy[u] = Y[j]; cz[u] = Z[j];
         }
-        __builtin_amdgcn_wave_barrier();
-        for (int c = 0; c < jn; ++c) {
-            const int j = j0 + c;
-            if (live && j < i && d2f(px, py, pz, tile[wave][0][c], tile[wave][1][c], tile[wave][2][c]) < TOL2) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = c0 + u;
+            if (live && j < i && d2f(px, py, pz, cx[u], cy[u], cz[u]) < TOL2) {
                 int a = uf_find(parent, ri), b = uf_find(parent, j);
                 while (a != b) {
                     const int hi = max(a, b), lo = min(a, b);
@@ -277,7 +286,6 @@ __global__ __launch_bounds__(256) void k3_cc(Det3dBufs B)
                 ri = a;
             }
         }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
