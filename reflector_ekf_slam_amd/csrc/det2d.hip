@@ -142,37 +142,44 @@ __device__ static R2d extrapolator_pose(const Det2dArgs &A, double time)
 }
 
 // ---- block-wide exclusive scans over 1024 per-thread values -----------------------------------
+// in-wave scan by shuffles (no barrier), the 16 wave totals through LDS: two barriers per scan instead of
+// the twenty of a Hillis-Steele scan over 1024 LDS slots
 __device__ static int block_excl_sum(int v, int *lds, int *total)
 {
-    const int tid = threadIdx.x;
-    lds[tid] = v;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int t = (tid >= off) ? lds[tid - off] : 0;
-        __syncthreads();
-        lds[tid] += t;
-        __syncthreads();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
     }
-    const int incl = lds[tid];
-    if (total) *total = lds[1023];
+    if (lane == 63) lds[wave] = incl;
     __syncthreads();
-    return incl - v;
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const int c = lds[w]; if (w < wave) base += c; tot += c; }
+    if (total) *total = tot;
+    __syncthreads();
+    return base + incl - v;
 }
 __device__ static int block_excl_max(int v, int *lds, int *total)
 {
-    const int tid = threadIdx.x;
-    lds[tid] = v;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int t = (tid >= off) ? lds[tid - off] : -1;
-        __syncthreads();
-        lds[tid] = max(lds[tid], t);
-        __syncthreads();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl = max(incl, t);
     }
-    const int excl = (tid > 0) ? lds[tid - 1] : -1;
-    if (total) *total = lds[1023];
+    if (lane == 63) lds[wave] = incl;
     __syncthreads();
-    return excl;
+    int base = -1, tot = -1;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const int c = lds[w]; if (w < wave) base = max(base, c); tot = max(tot, c); }
+    if (total) *total = tot;
+    __syncthreads();
+    const int prev = __shfl_up(incl, 1, 64);                    // inclusive value of the previous lane
+    return (lane == 0) ? base : max(base, prev);
 }
 
 __device__ static float gap_time_and_point(const Det2dArgs &A, const Det2dBufs &B, int j, float2 &p)
@@ -198,32 +205,51 @@ __global__ __launch_bounds__(1024) void k_det2d(Det2dArgs A, Det2dBufs B)
     const int CH = (N + 1023) / 1024;
     const int b0 = tid * CH, b1 = min(N, b0 + CH);
 
-    // ---- pass 1: points, validity, brightness (:63-83)
+    // ---- pass 1: points, validity, brightness (:63-83).  A thread owns CH <= 8 consecutive beams through
+    // passes 1-3; their inputs and flags stay in registers (all loads of the pass in flight at once).
+    constexpr int MAXCH = 8;
+    float rg[MAXCH], cv[MAXCH], sv[MAXCH], it[MAXCH];
+    unsigned char fl[MAXCH];
+    int prevb_r[MAXCH];
+#pragma unroll
+    for (int q = 0; q < MAXCH; ++q) {
+        const int i = b0 + q;
+        const bool in = q < CH && i < b1;
+        rg[q] = in ? B.ranges[i] : 0.f; cv[q] = in ? B.cosv[i] : 0.f; sv[q] = in ? B.sinv[i] : 0.f; it[q] = in ? B.intens[i] : 0.f;
+    }
     int cnt_valid = 0, last_valid = -1;
-    for (int i = b0; i < b1; ++i) {
+#pragma unroll
+    for (int q = 0; q < MAXCH; ++q) {
 #pragma clang fp contract(off)
-        const float range = B.ranges[i];
+        const int i = b0 + q;
+        fl[q] = 0;
+        if (q >= CH || i >= b1) continue;
+        const float range = rg[q];
         unsigned char f = 0;
         if (range >= A.msg_range_min && range <= A.msg_range_max) {
             f |= 1;
-            const float nx = range * B.cosv[i], ny = range * B.sinv[i];
+            const float nx = range * cv[q], ny = range * sv[q];
             B.pt[i] = r2f_apply_cs(A.s2b_c, A.s2b_s, A.s2b_x, A.s2b_y, nx, ny);
             B.pt_t[i] = (float)(A.first_point_time + i * A.point_delta_t);
             ++cnt_valid; last_valid = i;
         }
-        if (A.opt_range_min <= range && range <= A.opt_range_max && (double)B.intens[i] > A.intensity_min) f |= 4;
-        B.flags[i] = f;
+        if (A.opt_range_min <= range && range <= A.opt_range_max && (double)it[q] > A.intensity_min) f |= 4;
+        fl[q] = f;
     }
     int n_cloud;
     const int cloud_base = block_excl_sum(cnt_valid, lds, &n_cloud);
     int lv = block_excl_max(last_valid, lds, nullptr);
     // ---- pass 2: point_cloud index / back(), guarded bright flag, previous bright beam
     int c = cloud_base, last_bright = -1;
-    for (int i = b0; i < b1; ++i) {
-        unsigned char f = B.flags[i];
+#pragma unroll
+    for (int q = 0; q < MAXCH; ++q) {
+        const int i = b0 + q;
+        if (q >= CH || i >= b1) continue;
+        unsigned char f = fl[q];
         if (f & 1) { B.cloud_idx[i] = c++; lv = i; }
         B.lastvalid[i] = lv;
         if ((f & 4) && lv >= 0) { f |= 2; last_bright = i; }
+        fl[q] = f;
         B.flags[i] = f;
     }
     __syncthreads();
@@ -231,27 +257,34 @@ __global__ __launch_bounds__(1024) void k_det2d(Det2dArgs A, Det2dBufs B)
     int pb = block_excl_max(last_bright, lds, &last_bright_all);
     // ---- pass 3: run starts (:85-169) and run index
     int n_start = 0;
-    for (int i = b0; i < b1; ++i) {
-        if (!(B.flags[i] & 2)) continue;
+    unsigned start_mask = 0;
+#pragma unroll
+    for (int q = 0; q < MAXCH; ++q) {
+        const int i = b0 + q;
+        prevb_r[q] = -1;
+        if (q >= CH || i >= b1 || !(fl[q] & 2)) continue;
         B.prevb[i] = pb;
+        prevb_r[q] = pb;
         bool start = pb < 0;
         if (!start && i - pb != 1) {
             const int nx = (i + 1 < N) ? i + 1 : i;
-            const bool gap = (i - pb < 4) && (fabs((double)(B.ranges[i] - B.ranges[pb])) < 0.3) &&
+            const bool gap = (i - pb < 4) && (fabs((double)(rg[q] - B.ranges[pb])) < 0.3) &&
                              ((double)B.intens[nx] > A.intensity_min);                 // :111
             start = !gap;
         }
-        B.runid[i] = start ? 1 : 0;       // provisional: start flag
+        if (start) start_mask |= 1u << q;
         n_start += start ? 1 : 0;
         pb = i;
     }
     int n_runs;
     int rid = block_excl_sum(n_start, lds, &n_runs);
-    for (int i = b0; i < b1; ++i) {
-        if (!(B.flags[i] & 2)) continue;
-        if (B.runid[i]) {                  // start of run `rid`
+#pragma unroll
+    for (int q = 0; q < MAXCH; ++q) {
+        const int i = b0 + q;
+        if (q >= CH || i >= b1 || !(fl[q] & 2)) continue;
+        if (start_mask & (1u << q)) {      // start of run `rid`
             B.run_first[rid] = i;
-            if (B.prevb[i] >= 0) B.run_last[rid - 1] = B.prevb[i];
+            if (prevb_r[q] >= 0) B.run_last[rid - 1] = prevb_r[q];
             ++rid;
         }
         B.runid[i] = rid - 1;
@@ -355,12 +388,19 @@ __global__ __launch_bounds__(1024) void k_det2d(Det2dArgs A, Det2dBufs B)
     // order that the reference takes (:300-305) is then a chain of plain additions, one wave per cluster.
     const int K = s_tot[0], off = s_tot[1];
     const float tb_c = cosf(to_base.a), tb_s = sinf(to_base.a);
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int c = wave; c < K; c += 16) {                      // mark the member beams (bit 16), one wave per cluster
+        const int k = c + off;
+        for (int seg = 0; seg < 2; ++seg) {
+            const int fi = s_cl[4 * k + 2 * seg], li = s_cl[4 * k + 2 * seg + 1];
+            if (fi < 0) continue;
+            for (int j = fi + lane; j <= li; j += 64) B.flags[j] |= 16;
+        }
+    }
+    __syncthreads();
     for (int j = tid; j < N; j += 1024) {
 #pragma clang fp contract(off)
-        bool member = false;
-        for (int k = off; k < off + K && !member; ++k)
-            member = (s_cl[4 * k] <= j && j <= s_cl[4 * k + 1]) || (s_cl[4 * k + 2] >= 0 && s_cl[4 * k + 2] <= j && j <= s_cl[4 * k + 3]);
-        if (!member) continue;
+        if (!(B.flags[j] & 16)) continue;
         float2 p; float t;
         if (B.flags[j] & 2) { const int lvj = B.lastvalid[j]; p = B.pt[lvj]; t = B.pt_t[lvj]; }
         else if (isinf(B.ranges[j])) continue;                             // :120-121
@@ -371,7 +411,6 @@ __global__ __launch_bounds__(1024) void k_det2d(Det2dArgs A, Det2dBufs B)
         B.flags[j] |= 8;
     }
     __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
     for (int c = wave; c < K; c += 16) {
 #pragma clang fp contract(off)
         const int k = c + off;
@@ -527,7 +566,7 @@ int rdet2d_handle_scan(rdet2d_t *h, double stamp, float angle_min, float angle_m
     if (angle_increment < 0.f && angle_max <= angle_min) return RDET_ERR_BAD_SCAN;   // :33-38
     h->last_n_returns = 0;
     if (N == 0) return RDET_OK;
-    if (N > h->max_beams) return RDET_ERR_CAPACITY;
+    if (N > h->max_beams || N > 8192) return RDET_ERR_CAPACITY;      // k_det2d: one workgroup, <= 8 beams per thread
     DET_TRY(h, hipSetDevice(h->device));
 
     Det2dArgs A;
