@@ -1,0 +1,85 @@
+/* rgrid.h -- C ABI of the MI355X-native grid-mapper front-end: the step right after
+ * the hot path, which consumes the detector's de-skewed returns (rdet2d_get_range_data) and the EKF pose.
+ *
+ * It replaces, in the reference (ShihanWang/reflector_ekf_slam):
+ *   sensor::VoxelFilter::Filter                 src/sensor/voxel_filter.cc:81-95   (called from map_builder.cc:30-31)
+ *   sensor::AdaptiveVoxelFilter::Filter         src/sensor/voxel_filter.cc:116-120 (map_builder.cc:73)
+ *   scan_matching::RealTimeCorrelativeScanMatcher2D::Match
+ *                                               src/scan_matching/real_time_correlative_scan_matcher_2d.cc:84-118
+ *                                               (map_builder.cc:43) with its helpers SearchParameters,
+ *                                               GenerateRotatedScans, DiscretizeScans
+ *                                               (correlative_scan_matcher_2d.cc:10-123)
+ * Not covered: CeresScanMatcher2D, the range-data inserter, submap handling, IO.
+ *
+ * Conventions as in rekf.h / rdet.h: opaque handles, plain pointers and sizes, 0 / negative error codes,
+ * caller owns every buffer, a handle is not thread-safe, calls synchronise before returning.
+ */
+#ifndef RGRID_H_
+#define RGRID_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGRID_ABI_VERSION 1
+
+enum {
+    RGRID_OK = 0,
+    RGRID_ERR_INVALID = -1,       /* bad argument */
+    RGRID_ERR_HIP = -2,           /* a HIP runtime call failed */
+    RGRID_ERR_CAPACITY = -4,      /* more points / cells / candidates than the handle was created for */
+    RGRID_ERR_BUFFER = -5,        /* caller buffer too small */
+    RGRID_ERR_EMPTY = -6          /* empty point cloud (the reference CHECK-fails, real_time_...cc:33) */
+};
+
+typedef struct rgrid rgrid_t;
+
+/* scan_matching::RealTimeCorrelativeScanMatcherOptions (real_time_correlative_scan_matcher_2d.h:34-40);
+ * defaults in the reference's caller: 0.2 m, 15 deg (in radians here), 1e-1, 1e-1 (src/ros_node.cc:329-344). */
+typedef struct rgrid_match_options {
+    double linear_search_window;
+    double angular_search_window;
+    double translation_delta_cost_weight;
+    double rotation_delta_cost_weight;
+} rgrid_match_options;
+
+/* One handle = one HIP stream + device buffers for up to max_points points, max_cells grid cells and
+ * max_candidates search candidates (num_scans * (2 * num_linear + 1)^2). */
+int rgrid_create(int max_points, int max_cells, int max_candidates, int device, rgrid_t **out);
+void rgrid_destroy(rgrid_t *h);
+
+/* sensor::VoxelFilter(resolution).Filter(points): the first point that falls into every voxel, input
+ * order kept (voxel_filter.cc:81-95).  out_xy holds out_cap points; *m = points written. */
+int rgrid_voxel_filter(rgrid_t *h, const float *xy, int n, float resolution, float *out_xy, int out_cap, int *m);
+
+/* sensor::AdaptiveVoxelFilter(options).Filter(points) (voxel_filter.cc:15-76,116-120): range gate, then the
+ * coarsest voxel size <= max_length (bisection to 10 %) that still leaves min_num_points points.
+ * Reference defaults: 0.9, 500, 100 (src/ros_node.cc:312-322). */
+int rgrid_adaptive_voxel_filter(rgrid_t *h, const float *xy, int n, double max_length, double min_num_points,
+                                double max_range, float *out_xy, int out_cap, int *m);
+
+/* The probability grid the matcher scores against (mapping::ProbabilityGrid / Grid2D): correspondence-cost cell
+ * values as the reference stores them (uint16, 0 = unknown, grid_2d.h:83-91), flat index num_x_cells * y + x
+ * (grid_2d.h:102-106), MapLimits (resolution, max.x, max.y) (map_limits.h:24-45).  The cells are copied to the
+ * device and stay resident until the next call. */
+int rgrid_set_grid(rgrid_t *h, const uint16_t *cells, int num_x_cells, int num_y_cells, double resolution,
+                   double max_x, double max_y);
+
+/* RealTimeCorrelativeScanMatcher2D::Match (real_time_correlative_scan_matcher_2d.cc:84-118):
+ * initial_pose = (x, y, rotation angle); points in the tracking frame; pose_estimate = (x, y, angle) of the best
+ * candidate (first maximum in the reference's candidate order); returns its score in *score.
+ * best3 (nullable) = (scan_index, x_index_offset, y_index_offset); info3 (nullable) = (num_scans,
+ * num_linear_perturbations, num_candidates). */
+int rgrid_match(rgrid_t *h, const rgrid_match_options *opt, const double initial_pose[3], const float *points_xy,
+                int n, double pose_estimate[3], double *score, int best3[3], int info3[3]);
+
+const char *rgrid_strerror(int code);
+const char *rgrid_last_hip_error(rgrid_t *h);
+int rgrid_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGRID_H_ */

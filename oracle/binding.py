@@ -7,6 +7,7 @@ __graft_entry__.smoke() and bench.py's cpu_baseline leg.
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 import subprocess
 
@@ -70,6 +71,16 @@ def lib():
     L.od3_handle_cloud_ex.restype = C.c_int
     L.od3_handle_cloud_ex.argtypes = [C.c_double, _f64p, _f32p, C.c_int, _f32p, C.c_int,
                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    # ---- grid-mapper front-end oracle (grid_oracle.c)
+    L.ogrid_voxel_filter.restype = C.c_int
+    L.ogrid_voxel_filter.argtypes = [_f32p, C.c_int, C.c_float, _f32p]
+    L.ogrid_adaptive_voxel_filter.restype = C.c_int
+    L.ogrid_adaptive_voxel_filter.argtypes = [_f32p, C.c_int, C.c_double, C.c_double, C.c_double, _f32p]
+    L.ogrid_value_to_probability.restype = C.c_float
+    L.ogrid_value_to_probability.argtypes = [C.c_uint16]
+    L.ogrid_match.restype = C.c_double
+    L.ogrid_match.argtypes = [C.c_void_p, _f64p, _f32p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double,
+                              C.c_double, _f64p, _i32p, _i32p]
     _lib = L
     return L
 
@@ -237,3 +248,46 @@ def oracle_detect3d(xyzi, intensity_min=160.0, sensor_to_base_link=(0.0, 0.0, 0.
     if k < 0:
         raise ValueError(f"oracle detect3d rc={k}")
     return out[:k].copy(), m1.value, m2.value
+
+
+def oracle_voxel_filter(xy, resolution):
+    """sensor::VoxelFilter::Filter (voxel_filter.cc:81-95): first point of every voxel, input order."""
+    L = lib()
+    pts = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
+    out = np.zeros((max(pts.shape[0], 1), 2), np.float32)
+    m = L.ogrid_voxel_filter(pts.reshape(-1), pts.shape[0], float(resolution), out.reshape(-1))
+    return out[:m].copy()
+
+
+def oracle_adaptive_voxel_filter(xy, max_length=0.9, min_num_points=500, max_range=100.0):
+    """sensor::AdaptiveVoxelFilter::Filter (voxel_filter.cc:116-120); defaults = src/ros_node.cc:312-322."""
+    L = lib()
+    pts = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
+    out = np.zeros((max(pts.shape[0], 1), 2), np.float32)
+    m = L.ogrid_adaptive_voxel_filter(pts.reshape(-1), pts.shape[0], float(max_length), float(min_num_points),
+                                      float(max_range), out.reshape(-1))
+    return out[:m].copy()
+
+
+class _MatchOpt(C.Structure):
+    _fields_ = [("linear_search_window", C.c_double), ("angular_search_window", C.c_double),
+                ("translation_delta_cost_weight", C.c_double), ("rotation_delta_cost_weight", C.c_double)]
+
+
+def oracle_match(initial_pose, points_xy, cells, resolution, max_xy, linear_search_window=0.2,
+                 angular_search_window=math.radians(15.0), translation_delta_cost_weight=1e-1,
+                 rotation_delta_cost_weight=1e-1):
+    """RealTimeCorrelativeScanMatcher2D::Match (real_time_correlative_scan_matcher_2d.cc:84-118); option defaults =
+    src/ros_node.cc:329-344.  cells: uint16 (num_y_cells, num_x_cells) correspondence-cost values.
+    Returns (score, pose_estimate[3], best (scan_index, x_off, y_off), info (num_scans, num_linear, num_candidates))."""
+    L = lib()
+    pts = np.ascontiguousarray(points_xy, dtype=np.float32).reshape(-1, 2)
+    g = np.ascontiguousarray(cells, dtype=np.uint16)
+    opt = _MatchOpt(linear_search_window, angular_search_window, translation_delta_cost_weight, rotation_delta_cost_weight)
+    pose = np.zeros(3)
+    best = np.zeros(3, np.int32)
+    info = np.zeros(3, np.int32)
+    score = L.ogrid_match(C.byref(opt), np.ascontiguousarray(initial_pose, dtype=np.float64), pts.reshape(-1), pts.shape[0],
+                          g.ctypes.data_as(C.c_void_p), g.shape[1], g.shape[0], float(resolution), float(max_xy[0]),
+                          float(max_xy[1]), pose, best, info)
+    return score, pose, tuple(int(v) for v in best), tuple(int(v) for v in info)

@@ -1,0 +1,511 @@
+// rgrid.hip -- MI355X-native grid-mapper front-end behind include/rgrid.h.
+//
+// Replaces, in the reference: sensor::VoxelFilter / AdaptiveVoxelFilter (src/sensor/voxel_filter.cc:12-120) and
+// scan_matching::RealTimeCorrelativeScanMatcher2D::Match with SearchParameters / GenerateRotatedScans /
+// DiscretizeScans (src/scan_matching/real_time_correlative_scan_matcher_2d.cc:20-136,
+// correlative_scan_matcher_2d.cc:10-123), scored against a mapping::ProbabilityGrid given by its uint16 cells.
+//
+// Split of work.  Host (O(points) + O(scans), same libm as a CPU build, so every transcendental the
+// discretisation depends on is bit-identical to a CPU run): the initial rotation of the cloud, the search
+// parameters, one (cos, sin) pair per rotated scan.  Device (O(scans * points) + O(candidates * points)):
+//   kg_discretize  rotate, translate and discretise every point of every scan into cell indices   (:86-123)
+//   kg_score       one workgroup per rotated scan, one lane per translation candidate: float32 sum of the cell
+//                  probabilities in point order (:20-36), the exp(-(.)^2) penalty (:127-133), workgroup arg-max with
+//                  the first-maximum rule of std::max_element (:104-105)
+//   kg_best        arg-max over the workgroups
+// and for the voxel filters: kg_keys (voxel of every point), kg_first (a point survives iff no EARLIER point
+// shares its voxel: all-pairs, the candidates arrive through the scalar cache), kg_compact (order-preserving
+// ballot-scan compaction; also the range gate of the adaptive filter).  The bisection over voxel sizes of the
+// adaptive filter (:47-73) stays on the host: a dozen dependent decisions on one integer each.
+#include "../../include/rgrid.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct BestRec { float score; int id; };
+
+// ---- voxel filter -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kg_keys(const float *__restrict__ xy, int n, float res, int2 *__restrict__ key,
+                                               unsigned char *__restrict__ keep)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    // GetCellIndex (voxel_filter.cc:105-110): RoundToInt(point / resolution), float division, lround
+    key[i] = make_int2((int)lroundf(xy[2 * i] / res), (int)lroundf(xy[2 * i + 1] / res));
+    keep[i] = 1;                                                       // kg_first clears it when an earlier point shares the voxel
+}
+
+// Workgroup (bi, bj), bj <= bi: the 256 points i of block bi against the 256 candidates j of block bj (j < i).
+// A point that finds an earlier point in its voxel clears its flag (several workgroups may: same value).
+__global__ __launch_bounds__(256) void kg_first(const int2 *__restrict__ key, int n, unsigned char *__restrict__ keep)
+{
+    const int bi = blockIdx.x, bj = blockIdx.y;
+    if (bj > bi) return;
+    const int i = bi * 256 + threadIdx.x;
+    const bool live = i < n;
+    const int2 k = live ? key[i] : make_int2(0, 0);
+    bool dup = false;
+    const int jbase = bj * 256, jend = min(n, jbase + 256);
+    for (int j0 = jbase; j0 < jend; j0 += 8) {
+        int2 c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] = key[min(j0 + u, n - 1)];   // uniform addresses: scalar loads
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dup |= (j0 + u < i) && c[u].x == k.x && c[u].y == k.y;
+    }
+    if (live && dup) keep[i] = 0;                                     // unordered_set::insert(...).second == false (:89-93)
+}
+
+__global__ __launch_bounds__(256) void kg_range_gate(const float *__restrict__ xy, int n, float max_range,
+                                                     unsigned char *__restrict__ keep)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = xy[2 * i], y = xy[2 * i + 1];
+    keep[i] = (sqrtf(x * x + y * y) <= max_range) ? 1 : 0;           // FilterByMaxRange (:15-27): point.norm() <= max_range
+}
+
+// order-preserving compaction of the kept points, one workgroup, ballot scan per 1024-point tile
+__global__ __launch_bounds__(1024) void kg_compact(const float *__restrict__ xy, const unsigned char *__restrict__ keep, int n,
+                                                   float *__restrict__ out, int *__restrict__ count)
+{
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < n; t0 += 1024) {
+        const int i = t0 + tid;
+        const bool k = i < n && keep[i];
+        const unsigned long long bal = __ballot(k);
+        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const int c = wsum[w]; if (w < wave) off += c; tot += c; }
+        if (k) { const int pos = off + __popcll(bal & lt); out[2 * pos] = xy[2 * i]; out[2 * pos + 1] = xy[2 * i + 1]; }
+        __syncthreads();
+        if (tid == 0) base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) *count = base;
+}
+
+// ---- correlative scan matcher ---------------------------------------------------------------------
+struct MatchArgs {
+    int n, num_scans, num_linear, nx, ny;
+    float tx, ty;                      // Eigen::Translation2f(initial translation)
+    double resolution, max_x, max_y;
+    double num_angular_d, step;        // orientation = (scan - num_angular) * step
+    double wt, wr;
+};
+
+__global__ __launch_bounds__(256) void kg_discretize(MatchArgs A, const float *__restrict__ rot0, const float *__restrict__ cs,
+                                                     int2 *__restrict__ idx)
+{
+#pragma clang fp contract(off)
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= A.num_scans * A.n) return;
+    const int scan = e / A.n, p = e - scan * A.n;
+    const float c = cs[2 * scan], s = cs[2 * scan + 1];
+    const float x = rot0[2 * p], y = rot0[2 * p + 1];
+    const float rx = c * x - s * y, ry = s * x + c * y;                         // Rotation2Df * point (:95-98)
+    const float px = rx + A.tx, py = ry + A.ty;                                 // Affine2f(initial_translation) * point (:117-118)
+    // MapLimits::GetCellIndex (map_limits.h:47-55): (x index from y, y index from x), double arithmetic, lround
+    idx[e] = make_int2((int)lround((A.max_y - (double)py) / A.resolution - 0.5),
+                       (int)lround((A.max_x - (double)px) / A.resolution - 0.5));
+}
+
+__device__ static inline float value_to_probability(unsigned v16)
+{
+#pragma clang fp contract(off)
+    // probability_values.cc:11-20 (the table entry, recomputed: same two float operations), probability_values.h:53-57
+    const float kMinProbability = 0.1f, kMaxProbability = 1.f - kMinProbability;
+    const float lower = 1.f - kMaxProbability, upper = 1.f - kMinProbability;
+    const unsigned v = v16 & 32767u;
+    float cost = upper;
+    if (v != 0) {
+        const float kScale = (upper - lower) / (32768 - 2.f);
+        cost = (float)v * kScale + (lower - kScale);
+    }
+    return 1.f - cost;
+}
+
+// One workgroup per rotated scan, one lane per translation candidate of that scan.  The discretised point is the
+// same for the whole workgroup: its indices come through the scalar cache; the float32 sum has to run in point
+// order (:27-33), so the parallelism inside a candidate is in the LOADS: the cell values of sixteen points are in
+// flight before their sixteen additions.
+#define KG_PF 16
+__global__ __launch_bounds__(128) void kg_score(MatchArgs A, const int2 *__restrict__ idx, const unsigned short *__restrict__ cells,
+                                                BestRec *__restrict__ block_best)
+{
+#pragma clang fp contract(off)
+    __shared__ float s_sc[2];
+    __shared__ int s_id[2];
+    const int scan = blockIdx.x;
+    const int W = 2 * A.num_linear + 1, WW = W * W;
+    const int2 *__restrict__ di = idx + (size_t)scan * A.n;
+    const double orientation = ((double)scan - A.num_angular_d) * A.step;
+    float best = -1.f; int bid = 0x7fffffff;
+    for (int r0 = 0; r0 < WW; r0 += 128) {                                         // 81 candidates per scan with the default window: one pass
+        const int r = r0 + threadIdx.x;
+        const bool live = r < WW;
+        const int xo = (live ? r / W : 0) - A.num_linear, yo = (live ? r - (r / W) * W : 0) - A.num_linear;   // order: x offset, y offset (:64-74)
+        float sum = 0.f;
+        for (int p0 = 0; p0 < A.n; p0 += KG_PF) {                                  // ComputeCandidateScore (:20-36), point order
+            unsigned short v[KG_PF];
+            bool in[KG_PF];
+#pragma unroll
+            for (int u = 0; u < KG_PF; ++u) {
+                const int2 c = di[min(p0 + u, A.n - 1)];                           // uniform address: scalar load
+                const int cx = c.x + xo, cy = c.y + yo;
+                in[u] = cx >= 0 && cy >= 0 && cx < A.nx && cy < A.ny;
+                v[u] = in[u] ? cells[(size_t)A.nx * cy + cx] : (unsigned short)0;
+            }
+#pragma unroll
+            for (int u = 0; u < KG_PF; ++u)
+                if (p0 + u < A.n) sum += in[u] ? value_to_probability(v[u]) : 0.1f;   // outside the grid: kMinProbability
+        }
+        sum /= (float)A.n;
+        const double x = -yo * A.resolution, y = -xo * A.resolution;              // Candidate2D (correlative_scan_matcher_2d.h:62-66)
+        const double a = hypot(x, y) * A.wt + fabs(orientation) * A.wr;
+        const float score = (float)((double)sum * exp(-(a * a)));                  // :127-133
+        const int id = scan * WW + r;
+        if (live && (score > best || (score == best && id < bid))) { best = score; bid = id; }
+    }
+    // workgroup arg-max, first maximum (smaller id wins a tie)
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float os = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bid, off, 64);
+        if (os > best || (os == best && oi < bid)) { best = os; bid = oi; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_sc[wave] = best; s_id[wave] = bid; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_sc[1] > best || (s_sc[1] == best && s_id[1] < bid)) { best = s_sc[1]; bid = s_id[1]; }
+        block_best[blockIdx.x].score = best;
+        block_best[blockIdx.x].id = bid;
+    }
+}
+
+__global__ __launch_bounds__(256) void kg_best(const BestRec *__restrict__ block_best, int nblocks, BestRec *__restrict__ out)
+{
+    __shared__ float s_sc[256];
+    __shared__ int s_id[256];
+    float best = -1.f; int bid = 0x7fffffff;
+    for (int b = threadIdx.x; b < nblocks; b += 256) {
+        const BestRec r = block_best[b];
+        if (r.score > best || (r.score == best && r.id < bid)) { best = r.score; bid = r.id; }
+    }
+    s_sc[threadIdx.x] = best; s_id[threadIdx.x] = bid;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const float os = s_sc[threadIdx.x + off]; const int oi = s_id[threadIdx.x + off];
+            if (os > s_sc[threadIdx.x] || (os == s_sc[threadIdx.x] && oi < s_id[threadIdx.x])) { s_sc[threadIdx.x] = os; s_id[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out->score = s_sc[0]; out->id = s_id[0]; }
+}
+
+// Project2D(Rigid3f::Rotation(AngleAxisf(angle, UnitZ))) as a (cos, sin) pair, restating Eigen 3.3 in float32:
+// Quaternionf(AngleAxisf) = (cos(a/2), 0, 0, sin(a/2)); GetYaw (transform.h:27-33) = atan2 of q * UnitX with
+// Eigen's  v + w*uv + vec x uv,  uv = 2 (vec x v); Rotation2Df(yaw) rotates with (cos yaw, sin yaw).  Host libm.
+void rotation_cs(float angle, float *c, float *s)
+{
+#pragma clang fp contract(off)
+    const float ha = 0.5f * angle;
+    const float w = std::cos(ha), z = std::sin(ha);
+    const float uvy = z + z;
+    const float dx = (1.f + w * 0.f) + (0.f * 0.f - z * uvy);
+    const float dy = (0.f + w * uvy) + (z * 0.f - 0.f * 0.f);
+    const float yaw = std::atan2(dy, dx);
+    *c = std::cos(yaw); *s = std::sin(yaw);
+}
+
+}  // namespace
+
+struct rgrid {
+    int max_points, max_cells, max_candidates, device;
+    hipStream_t stream;
+    float *d_in, *d_a, *d_b, *d_cs;       // points in / two result buffers / per-scan (cos, sin)
+    int2 *d_key, *d_idx;
+    unsigned char *d_keep;
+    unsigned short *d_cells;
+    BestRec *d_bb, *d_best;
+    int *d_count;
+    // pinned staging
+    float *h_pts;
+    int *h_count;
+    BestRec *h_best;
+    // grid
+    int nx, ny;
+    double resolution, max_x, max_y;
+    bool have_grid;
+    std::string hip_error;
+};
+
+#define G_TRY(h, expr)                                                              \
+    do {                                                                            \
+        hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess) {                                                     \
+            if (h) (h)->hip_error = std::string(#expr) + ": " + hipGetErrorString(e_); \
+            return RGRID_ERR_HIP;                                                   \
+        }                                                                           \
+    } while (0)
+
+namespace {
+
+// VoxelFilter(res).Filter on the device buffer `src` (n points) into `dst`; *m = survivors (synchronises)
+int voxel_pass(rgrid_t *h, const float *src, int n, float res, float *dst, int *m)
+{
+    if (n == 0) { *m = 0; return RGRID_OK; }
+    const int blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(kg_keys, dim3(blocks), dim3(256), 0, h->stream, src, n, res, h->d_key, h->d_keep);
+    hipLaunchKernelGGL(kg_first, dim3(blocks, blocks), dim3(256), 0, h->stream, h->d_key, n, h->d_keep);
+    hipLaunchKernelGGL(kg_compact, dim3(1), dim3(1024), 0, h->stream, src, h->d_keep, n, dst, h->d_count);
+    G_TRY(h, hipMemcpyAsync(h->h_count, h->d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    G_TRY(h, hipStreamSynchronize(h->stream));
+    *m = *h->h_count;
+    return RGRID_OK;
+}
+
+int upload_points(rgrid_t *h, const float *xy, int n)
+{
+    std::memcpy(h->h_pts, xy, sizeof(float) * 2 * (size_t)n);
+    G_TRY(h, hipMemcpyAsync(h->d_in, h->h_pts, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, h->stream));
+    return RGRID_OK;
+}
+
+int download_points(rgrid_t *h, const float *d_src, int m, float *out_xy, int out_cap)
+{
+    if (m > out_cap) return RGRID_ERR_BUFFER;
+    if (m > 0) {
+        G_TRY(h, hipMemcpyAsync(h->h_pts, d_src, sizeof(float) * 2 * (size_t)m, hipMemcpyDeviceToHost, h->stream));
+        G_TRY(h, hipStreamSynchronize(h->stream));
+        std::memcpy(out_xy, h->h_pts, sizeof(float) * 2 * (size_t)m);
+    }
+    return RGRID_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rgrid_abi_version(void) { return RGRID_ABI_VERSION; }
+
+const char *rgrid_strerror(int code)
+{
+    switch (code) {
+    case RGRID_OK: return "ok";
+    case RGRID_ERR_INVALID: return "invalid argument";
+    case RGRID_ERR_HIP: return "HIP runtime error";
+    case RGRID_ERR_CAPACITY: return "capacity of the handle exceeded";
+    case RGRID_ERR_BUFFER: return "caller buffer too small";
+    case RGRID_ERR_EMPTY: return "empty point cloud";
+    default: return "unknown error";
+    }
+}
+
+const char *rgrid_last_hip_error(rgrid_t *h) { return h ? h->hip_error.c_str() : ""; }
+
+int rgrid_create(int max_points, int max_cells, int max_candidates, int device, rgrid_t **out)
+{
+    if (!out || max_points < 1 || max_cells < 1 || max_candidates < 1) return RGRID_ERR_INVALID;
+    *out = nullptr;
+    rgrid_t *h = new (std::nothrow) rgrid();
+    if (!h) return RGRID_ERR_INVALID;
+    h->max_points = max_points; h->max_cells = max_cells; h->max_candidates = max_candidates; h->device = device;
+    h->have_grid = false;
+    const size_t np = (size_t)max_points;
+    // discretised scans: every candidate's scan must fit: num_scans <= max_candidates, num_scans * n <= np * scans_cap
+    int rc = [&]() -> int {
+        G_TRY(h, hipSetDevice(device));
+        G_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        G_TRY(h, hipMalloc(&h->d_in, 8 * np)); G_TRY(h, hipMalloc(&h->d_a, 8 * np)); G_TRY(h, hipMalloc(&h->d_b, 8 * np));
+        G_TRY(h, hipMalloc(&h->d_key, 8 * np)); G_TRY(h, hipMalloc(&h->d_keep, np));
+        G_TRY(h, hipMalloc(&h->d_cs, 8 * (size_t)max_candidates));
+        G_TRY(h, hipMalloc(&h->d_idx, 8 * np * 1024));                       // up to 1024 rotated scans of max_points points
+        G_TRY(h, hipMalloc(&h->d_cells, 2 * (size_t)max_cells));
+        G_TRY(h, hipMalloc(&h->d_bb, sizeof(BestRec) * 1024));                   // one record per rotated scan
+        G_TRY(h, hipMalloc(&h->d_best, sizeof(BestRec)));
+        G_TRY(h, hipMalloc(&h->d_count, sizeof(int)));
+        G_TRY(h, hipHostMalloc(&h->h_pts, 8 * np)); G_TRY(h, hipHostMalloc(&h->h_count, sizeof(int)));
+        G_TRY(h, hipHostMalloc(&h->h_best, sizeof(BestRec)));
+        return RGRID_OK;
+    }();
+    if (rc != RGRID_OK) { std::fprintf(stderr, "rgrid_create: %s\n", h->hip_error.c_str()); rgrid_destroy(h); return rc; }
+    *out = h;
+    return RGRID_OK;
+}
+
+void rgrid_destroy(rgrid_t *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void *ptrs[] = {h->d_in, h->d_a, h->d_b, h->d_cs, h->d_key, h->d_idx, h->d_keep, h->d_cells, h->d_bb, h->d_best, h->d_count};
+    for (void *p : ptrs) (void)hipFree(p);
+    if (h->h_pts) (void)hipHostFree(h->h_pts);
+    if (h->h_count) (void)hipHostFree(h->h_count);
+    if (h->h_best) (void)hipHostFree(h->h_best);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int rgrid_voxel_filter(rgrid_t *h, const float *xy, int n, float resolution, float *out_xy, int out_cap, int *m)
+{
+    if (!h || !m || n < 0 || (n > 0 && !xy) || !(resolution > 0.f) || out_cap < 0 || (out_cap > 0 && !out_xy)) return RGRID_ERR_INVALID;
+    *m = 0;
+    if (n == 0) return RGRID_OK;
+    if (n > h->max_points) return RGRID_ERR_CAPACITY;
+    G_TRY(h, hipSetDevice(h->device));
+    int rc = upload_points(h, xy, n);
+    if (rc != RGRID_OK) return rc;
+    int cnt = 0;
+    rc = voxel_pass(h, h->d_in, n, resolution, h->d_a, &cnt);
+    if (rc != RGRID_OK) return rc;
+    rc = download_points(h, h->d_a, cnt, out_xy, out_cap);
+    if (rc != RGRID_OK) return rc;
+    *m = cnt;
+    return RGRID_OK;
+}
+
+int rgrid_adaptive_voxel_filter(rgrid_t *h, const float *xy, int n, double max_length, double min_num_points,
+                                double max_range, float *out_xy, int out_cap, int *m)
+{
+    if (!h || !m || n < 0 || (n > 0 && !xy) || !(max_length > 0.) || out_cap < 0 || (out_cap > 0 && !out_xy)) return RGRID_ERR_INVALID;
+    *m = 0;
+    if (n == 0) return RGRID_OK;
+    if (n > h->max_points) return RGRID_ERR_CAPACITY;
+    G_TRY(h, hipSetDevice(h->device));
+    int rc = upload_points(h, xy, n);
+    if (rc != RGRID_OK) return rc;
+    // FilterByMaxRange (voxel_filter.cc:15-27) -> d_key is free here, the gated cloud goes to d_in's twin: reuse d_b as "in"
+    hipLaunchKernelGGL(kg_range_gate, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_in, n, (float)max_range, h->d_keep);
+    hipLaunchKernelGGL(kg_compact, dim3(1), dim3(1024), 0, h->stream, h->d_in, h->d_keep, n, h->d_b, h->d_count);
+    G_TRY(h, hipMemcpyAsync(h->h_count, h->d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    G_TRY(h, hipStreamSynchronize(h->stream));
+    const int ni = *h->h_count;
+    const float *src = h->d_b;                 // the gated cloud
+    float *res_buf = h->d_a, *cand_buf = h->d_in;   // d_in is free again after the gate
+    int cnt = ni;
+    const float *final_buf = src;
+    if (!((double)ni <= min_num_points)) {                                         // :33-37
+        rc = voxel_pass(h, src, ni, (float)max_length, res_buf, &cnt);             // :38
+        if (rc != RGRID_OK) return rc;
+        final_buf = res_buf;
+        if (!((double)cnt >= min_num_points)) {                                    // :39-43
+            bool done = false;
+            for (float high = (float)max_length; !done && high > 1e-2f * (float)max_length; high /= 2.f) {   // :47-48
+                float low = high / 2.f;
+                rc = voxel_pass(h, src, ni, low, res_buf, &cnt);
+                if (rc != RGRID_OK) return rc;
+                final_buf = res_buf;
+                if ((double)cnt >= min_num_points) {
+                    while ((high - low) / low > 1e-1f) {                            // :57
+                        const float mid = (low + high) / 2.f;
+                        int mc = 0;
+                        rc = voxel_pass(h, src, ni, mid, cand_buf, &mc);
+                        if (rc != RGRID_OK) return rc;
+                        if ((double)mc >= min_num_points) {
+                            low = mid; cnt = mc;
+                            float *t = res_buf; res_buf = cand_buf; cand_buf = t;  // result = candidate
+                            final_buf = res_buf;
+                        } else high = mid;
+                    }
+                    done = true;
+                }
+            }
+        }
+    }
+    rc = download_points(h, final_buf, cnt, out_xy, out_cap);
+    if (rc != RGRID_OK) return rc;
+    *m = cnt;
+    return RGRID_OK;
+}
+
+int rgrid_set_grid(rgrid_t *h, const uint16_t *cells, int num_x_cells, int num_y_cells, double resolution,
+                   double max_x, double max_y)
+{
+    if (!h || !cells || num_x_cells < 1 || num_y_cells < 1 || !(resolution > 0.)) return RGRID_ERR_INVALID;
+    if ((long long)num_x_cells * num_y_cells > h->max_cells) return RGRID_ERR_CAPACITY;
+    G_TRY(h, hipSetDevice(h->device));
+    G_TRY(h, hipMemcpyAsync(h->d_cells, cells, sizeof(uint16_t) * (size_t)num_x_cells * num_y_cells, hipMemcpyHostToDevice, h->stream));
+    G_TRY(h, hipStreamSynchronize(h->stream));
+    h->nx = num_x_cells; h->ny = num_y_cells; h->resolution = resolution; h->max_x = max_x; h->max_y = max_y;
+    h->have_grid = true;
+    return RGRID_OK;
+}
+
+int rgrid_match(rgrid_t *h, const rgrid_match_options *opt, const double initial_pose[3], const float *points_xy,
+                int n, double pose_estimate[3], double *score, int best3[3], int info3[3])
+{
+#pragma clang fp contract(off)
+    if (!h || !opt || !initial_pose || !pose_estimate || !score || n < 0 || (n > 0 && !points_xy)) return RGRID_ERR_INVALID;
+    if (!h->have_grid) return RGRID_ERR_INVALID;
+    if (n == 0) return RGRID_ERR_EMPTY;
+    if (n > h->max_points) return RGRID_ERR_CAPACITY;
+    G_TRY(h, hipSetDevice(h->device));
+    // initial rotation of the cloud (real_time_correlative_scan_matcher_2d.cc:91-97), host float32
+    float c0, s0;
+    rotation_cs((float)initial_pose[2], &c0, &s0);
+    float max_scan_range = 3.f * (float)h->resolution;                                   // correlative_scan_matcher_2d.cc:18-24
+    for (int i = 0; i < n; ++i) {
+        const float x = points_xy[2 * i], y = points_xy[2 * i + 1];
+        const float rx = c0 * x - s0 * y, ry = s0 * x + c0 * y;
+        h->h_pts[2 * i] = rx; h->h_pts[2 * i + 1] = ry;
+        const float range = std::sqrt(rx * rx + ry * ry);
+        if (range > max_scan_range) max_scan_range = range;
+    }
+    const double res = h->resolution;
+    const double kSafetyMargin = 1. - 1e-3;
+    const double step = kSafetyMargin * std::acos(1. - (res * res) / (2. * (double)(max_scan_range * max_scan_range)));   // :25-28
+    const int num_angular = (int)std::ceil(opt->angular_search_window / step);            // :29-31
+    const int num_scans = 2 * num_angular + 1;
+    const int num_linear = (int)std::ceil(opt->linear_search_window / res);               // :33-34
+    const long long W = 2LL * num_linear + 1, ncand = (long long)num_scans * W * W;
+    if (num_scans > 1024 || ncand > h->max_candidates) return RGRID_ERR_CAPACITY;
+    std::vector<float> cs(2 * (size_t)num_scans);
+    double delta_theta = -num_angular * step;                                             // :90-94 (accumulated in double)
+    for (int s = 0; s < num_scans; ++s, delta_theta += step) rotation_cs((float)delta_theta, &cs[2 * s], &cs[2 * s + 1]);
+    G_TRY(h, hipMemcpyAsync(h->d_in, h->h_pts, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, h->stream));
+    G_TRY(h, hipMemcpyAsync(h->d_cs, cs.data(), sizeof(float) * cs.size(), hipMemcpyHostToDevice, h->stream));
+    MatchArgs A;
+    A.n = n; A.num_scans = num_scans; A.num_linear = num_linear; A.nx = h->nx; A.ny = h->ny;
+    A.tx = (float)initial_pose[0]; A.ty = (float)initial_pose[1];
+    A.resolution = res; A.max_x = h->max_x; A.max_y = h->max_y;
+    A.num_angular_d = (double)num_angular; A.step = step;
+    A.wt = opt->translation_delta_cost_weight; A.wr = opt->rotation_delta_cost_weight;
+    const int nb_d = (num_scans * n + 255) / 256, nb_s = num_scans;
+    hipLaunchKernelGGL(kg_discretize, dim3(nb_d), dim3(256), 0, h->stream, A, h->d_in, h->d_cs, h->d_idx);
+    hipLaunchKernelGGL(kg_score, dim3(nb_s), dim3(128), 0, h->stream, A, h->d_idx, h->d_cells, h->d_bb);
+    hipLaunchKernelGGL(kg_best, dim3(1), dim3(256), 0, h->stream, h->d_bb, nb_s, h->d_best);
+    G_TRY(h, hipMemcpyAsync(h->h_best, h->d_best, sizeof(BestRec), hipMemcpyDeviceToHost, h->stream));
+    G_TRY(h, hipStreamSynchronize(h->stream));                                            // cs stays alive until here
+    const int id = h->h_best->id;
+    const int scan = id / (int)(W * W), r = id - scan * (int)(W * W);
+    const int xo = r / (int)W - num_linear, yo = r - (r / (int)W) * (int)W - num_linear;
+    const double x = -yo * res, y = -xo * res, orientation = (scan - num_angular) * step;
+    pose_estimate[0] = initial_pose[0] + x;                                               // :106-110
+    pose_estimate[1] = initial_pose[1] + y;
+    pose_estimate[2] = initial_pose[2] + orientation;
+    *score = (double)h->h_best->score;
+    if (best3) { best3[0] = scan; best3[1] = xo; best3[2] = yo; }
+    if (info3) { info3[0] = num_scans; info3[1] = num_linear; info3[2] = (int)ncand; }
+    return RGRID_OK;
+}
+
+}  // extern "C"

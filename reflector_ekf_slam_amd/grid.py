@@ -1,0 +1,152 @@
+"""ctypes mirror of the grid-mapper front-end (include/rgrid.h): sensor::VoxelFilter, sensor::AdaptiveVoxelFilter
+(src/sensor/voxel_filter.cc) and scan_matching::RealTimeCorrelativeScanMatcher2D (src/scan_matching/
+real_time_correlative_scan_matcher_2d.cc) of the reference, on the device.  No CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+
+
+class RgridError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        super().__init__(f"{where}: rgrid error {code}" + (f" ({detail})" if detail else ""))
+
+
+class _MatchOptions(C.Structure):
+    _fields_ = [("linear_search_window", C.c_double), ("angular_search_window", C.c_double),
+                ("translation_delta_cost_weight", C.c_double), ("rotation_delta_cost_weight", C.c_double)]
+
+
+_rgrid = None
+
+
+def _lib_rgrid():
+    global _rgrid
+    if _rgrid is not None:
+        return _rgrid
+    path = _lib.lib_path("librgrid.so")
+    if not os.path.exists(path):
+        raise _lib.LibraryMissing(f"{path} not found: the HIP extension is not built "
+                                  "(run `python __graft_entry__.py`); there is no CPU fallback")
+    L = C.CDLL(path)
+    vp, ip, dp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)
+    L.rgrid_abi_version.restype = C.c_int
+    L.rgrid_strerror.restype = C.c_char_p
+    L.rgrid_strerror.argtypes = [C.c_int]
+    L.rgrid_last_hip_error.restype = C.c_char_p
+    L.rgrid_last_hip_error.argtypes = [vp]
+    L.rgrid_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.rgrid_destroy.argtypes = [vp]
+    L.rgrid_destroy.restype = None
+    L.rgrid_voxel_filter.argtypes = [vp, vp, C.c_int, C.c_float, vp, C.c_int, ip]
+    L.rgrid_adaptive_voxel_filter.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, C.c_double, vp, C.c_int, ip]
+    L.rgrid_set_grid.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
+    L.rgrid_match.argtypes = [vp, C.POINTER(_MatchOptions), dp, vp, C.c_int, dp, dp, ip, ip]
+    _rgrid = L
+    return L
+
+
+@dataclass
+class RealTimeCorrelativeScanMatcherOptions:
+    """scan_matching::RealTimeCorrelativeScanMatcherOptions (real_time_correlative_scan_matcher_2d.h:34-40);
+    defaults = the reference's caller, src/ros_node.cc:329-344 (the angular window converted to radians there)."""
+    linear_search_window: float = 0.2
+    angular_search_window: float = math.radians(15.0)
+    translation_delta_cost_weight: float = 1e-1
+    rotation_delta_cost_weight: float = 1e-1
+
+
+@dataclass
+class AdaptiveVoxelFilterOptions:
+    """sensor::AdaptiveVoxelFilterOptions (voxel_filter.h); defaults = src/ros_node.cc:312-322."""
+    max_length: float = 0.9
+    min_num_points: float = 500
+    max_range: float = 100.0
+
+
+@dataclass
+class MatchResult:
+    score: float
+    pose_estimate: np.ndarray        # x, y, angle
+    best: tuple                      # (scan_index, x_index_offset, y_index_offset)
+    info: tuple                      # (num_scans, num_linear_perturbations, num_candidates)
+
+
+class GridFrontEnd:
+    """One handle of include/rgrid.h: voxel filters + the real-time correlative scan matcher."""
+
+    def __init__(self, max_points: int = 8192, max_cells: int = 4096 * 4096, max_candidates: int = 1 << 20, device: int = 0):
+        self._L = _lib_rgrid()
+        h = C.c_void_p()
+        rc = self._L.rgrid_create(int(max_points), int(max_cells), int(max_candidates), int(device), C.byref(h))
+        if rc != 0:
+            raise RgridError(rc, "rgrid_create")
+        self._h = h
+        self.max_points = int(max_points)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rgrid_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, where):
+        if rc != 0:
+            raise RgridError(rc, where, self._L.rgrid_last_hip_error(self._h).decode() if rc == -2 else
+                             self._L.rgrid_strerror(rc).decode())
+
+    # sensor::VoxelFilter(size).Filter(point_cloud)  (voxel_filter.cc:81-95)
+    def VoxelFilter(self, points_xy, size: float) -> np.ndarray:
+        pts = np.ascontiguousarray(points_xy, dtype=np.float32).reshape(-1, 2)
+        out = np.zeros((max(pts.shape[0], 1), 2), np.float32)
+        m = C.c_int()
+        self._chk(self._L.rgrid_voxel_filter(self._h, pts.ctypes.data_as(C.c_void_p), pts.shape[0], float(size),
+                                             out.ctypes.data_as(C.c_void_p), out.shape[0], C.byref(m)), "VoxelFilter")
+        return out[: m.value].copy()
+
+    # sensor::AdaptiveVoxelFilter(options).Filter(point_cloud)  (voxel_filter.cc:116-120)
+    def AdaptiveVoxelFilter(self, points_xy, options: AdaptiveVoxelFilterOptions | None = None) -> np.ndarray:
+        o = options or AdaptiveVoxelFilterOptions()
+        pts = np.ascontiguousarray(points_xy, dtype=np.float32).reshape(-1, 2)
+        out = np.zeros((max(pts.shape[0], 1), 2), np.float32)
+        m = C.c_int()
+        self._chk(self._L.rgrid_adaptive_voxel_filter(self._h, pts.ctypes.data_as(C.c_void_p), pts.shape[0],
+                                                      float(o.max_length), float(o.min_num_points), float(o.max_range),
+                                                      out.ctypes.data_as(C.c_void_p), out.shape[0], C.byref(m)),
+                  "AdaptiveVoxelFilter")
+        return out[: m.value].copy()
+
+    def SetGrid(self, cells, resolution: float, max_xy):
+        """cells: uint16 (num_y_cells, num_x_cells) correspondence-cost values (grid_2d.h:83-106); MapLimits
+        resolution and max corner (map_limits.h:24-45)."""
+        g = np.ascontiguousarray(cells, dtype=np.uint16)
+        assert g.ndim == 2
+        self._chk(self._L.rgrid_set_grid(self._h, g.ctypes.data_as(C.c_void_p), g.shape[1], g.shape[0], float(resolution),
+                                         float(max_xy[0]), float(max_xy[1])), "SetGrid")
+
+    # RealTimeCorrelativeScanMatcher2D::Match  (real_time_correlative_scan_matcher_2d.cc:84-118)
+    def Match(self, initial_pose_estimate, point_cloud, options: RealTimeCorrelativeScanMatcherOptions | None = None) -> MatchResult:
+        o = options or RealTimeCorrelativeScanMatcherOptions()
+        co = _MatchOptions(o.linear_search_window, o.angular_search_window, o.translation_delta_cost_weight,
+                           o.rotation_delta_cost_weight)
+        pts = np.ascontiguousarray(point_cloud, dtype=np.float32).reshape(-1, 2)
+        ip = (C.c_double * 3)(*[float(v) for v in initial_pose_estimate])
+        pe = (C.c_double * 3)()
+        sc = C.c_double()
+        best = (C.c_int * 3)()
+        info = (C.c_int * 3)()
+        self._chk(self._L.rgrid_match(self._h, C.byref(co), ip, pts.ctypes.data_as(C.c_void_p), pts.shape[0], pe,
+                                      C.byref(sc), best, info), "Match")
+        return MatchResult(sc.value, np.array(pe[:]), tuple(best[:]), tuple(info[:]))

@@ -1,0 +1,99 @@
+"""CPU tests of the grid front-end ORACLE (oracle/grid_oracle.c) against independent numpy restatements and
+hand-checkable cases.  The reference ships no tests for this code either: parity unpinned (see the oracle header)."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import pytest
+
+from tests.grid_cases import room_grid, scan_of
+
+
+def _np_voxel_filter(pts, res):
+    seen, out = set(), []
+    for p in np.asarray(pts, np.float32):
+        # RoundToInt = lround: half away from zero (port.h:25); float32 division
+        q = np.float32(p) / np.float32(res)
+        k = tuple(int(math.floor(abs(float(v)) + 0.5) * (1 if v >= 0 else -1)) for v in q)
+        if k not in seen:
+            seen.add(k); out.append(p)
+    return np.array(out, np.float32).reshape(-1, 2)
+
+
+def test_voxel_filter_keeps_first_point_per_voxel_in_order(oracle_lib):
+    from oracle.binding import oracle_voxel_filter
+    rng = np.random.default_rng(0)
+    pts = rng.uniform(-6, 6, (3000, 2)).astype(np.float32)
+    for res in (0.025, 0.3, 0.9):
+        got = oracle_voxel_filter(pts, res)
+        assert np.array_equal(got, _np_voxel_filter(pts, res))
+    # hand case: half-way values round away from zero; the second point of a voxel is dropped
+    hand = np.array([[0.5, 0.5], [0.49, 0.2], [1.4, -0.5], [0.6, 1.4], [-0.5, 0.0], [-1.49, 0.4]], np.float32)
+    assert np.array_equal(oracle_voxel_filter(hand, 1.0), hand[[0, 1, 2, 4]])
+    assert oracle_voxel_filter(np.zeros((0, 2), np.float32), 0.1).shape == (0, 2)
+
+
+def test_adaptive_voxel_filter_paths(oracle_lib):
+    from oracle.binding import oracle_adaptive_voxel_filter, oracle_voxel_filter
+    rng = np.random.default_rng(1)
+    pts = rng.uniform(-8, 8, (4000, 2)).astype(np.float32)
+    # (a) already sparse: returned unchanged apart from the range gate
+    few = pts[:300]
+    assert np.array_equal(oracle_adaptive_voxel_filter(few, 0.9, 500, 100.0), few)
+    gated = oracle_adaptive_voxel_filter(few, 0.9, 500, 5.0)
+    assert np.array_equal(gated, few[np.sqrt(few[:, 0] ** 2 + few[:, 1] ** 2) <= np.float32(5.0)])
+    # (b) max_length already leaves enough points
+    assert np.array_equal(oracle_adaptive_voxel_filter(pts, 0.3, 500, 100.0), oracle_voxel_filter(pts, 0.3))
+    # (c) bisection: the result has >= min points, a voxel size 10 % larger would not (within the bisection tolerance)
+    out = oracle_adaptive_voxel_filter(pts, 2.0, 500, 100.0)
+    assert 500 <= out.shape[0] < 700
+    assert oracle_voxel_filter(pts, 2.0).shape[0] < 500
+    # (d) impossible target: gives up after shrinking the edge by 1e-2 and returns the last attempt
+    dense = np.tile(np.array([[1.0, 1.0]], np.float32), (600, 1)) + rng.normal(0, 1e-4, (600, 2)).astype(np.float32)
+    out = oracle_adaptive_voxel_filter(dense, 0.9, 550, 100.0)
+    assert 1 <= out.shape[0] < 550
+
+
+def test_value_to_probability_table(oracle_lib):
+    L = oracle_lib
+    f32 = np.float32
+    lower, upper = f32(1) - (f32(1) - f32(0.1)), f32(1) - f32(0.1)
+    kscale = (upper - lower) / f32(32766)
+    for v in (0, 1, 2, 1000, 16384, 32767, 32768, 32769, 40000, 65535):
+        vv = v & 32767
+        cost = upper if vv == 0 else f32(vv) * kscale + (lower - kscale)
+        assert L.ogrid_value_to_probability(v) == float(f32(1) - cost)
+    assert abs(L.ogrid_value_to_probability(1) - 0.9) < 1e-6 and abs(L.ogrid_value_to_probability(32767) - 0.1) < 1e-6
+
+
+def test_matcher_recovers_a_known_offset_and_obeys_the_search_structure(oracle_lib):
+    from oracle.binding import oracle_match
+    cells, max_xy, occ = room_grid()
+    true = np.array([0.8, -0.6, 0.35])
+    pts = scan_of(occ, true)
+    init = true + np.array([0.10, -0.15, math.radians(4.0)])
+    score, pose, best, info = oracle_match(init, pts, cells, 0.05, max_xy)
+    num_scans, num_linear, ncand = info
+    assert num_linear == 4 and ncand == num_scans * 81 and num_scans % 2 == 1           # ceil(0.2 / 0.05); 2 n + 1 scans
+    # angular step: (1 - 1e-3) acos(1 - r^2 / (2 dmax^2)) with dmax the largest range of the rotated cloud
+    dmax = float(np.sqrt((pts.astype(np.float64) ** 2).sum(1)).max())
+    step = (1 - 1e-3) * math.acos(1 - 0.05 ** 2 / (2 * dmax ** 2))
+    assert abs((num_scans - 1) / 2 - math.ceil(math.radians(15.0) / step)) <= 1
+    assert np.abs(pose[:2] - true[:2]).max() <= 0.05 + 1e-9 and abs(pose[2] - true[2]) < 2.5 * step
+    assert 0.5 < score < 0.9
+    # pose_estimate is the initial pose plus the candidate's offsets: x = -y_off * r, y = -x_off * r (Candidate2D)
+    scan, xo, yo = best
+    assert np.allclose(pose, init + np.array([-yo * 0.05, -xo * 0.05, (scan - (num_scans - 1) // 2) * step]), atol=1e-6)
+    # a perfect initial guess is its own best candidate: zero offsets win through the exp(-(.)^2) penalty
+    _, _, best0, info0 = oracle_match(true, scan_of(occ, true, noise=0.0), cells, 0.05, max_xy)
+    assert best0[1] == 0 and best0[2] == 0 and abs(best0[0] - (info0[0] - 1) // 2) <= 1
+
+
+def test_matcher_outside_the_grid_scores_min_probability(oracle_lib):
+    from oracle.binding import oracle_match
+    cells = np.full((40, 40), 2000, np.uint16)
+    pts = np.array([[50.0, 50.0], [51.0, 49.0], [52.0, 50.5]], np.float32)                # far outside: kMinProbability everywhere
+    score, pose, best, info = oracle_match(np.zeros(3), pts, cells, 0.05, (1.0, 1.0), linear_search_window=0.1)
+    assert best[1] == 0 and best[2] == 0                                                   # all sums equal: the smallest penalty wins
+    assert abs(score - 0.1) < 1e-6

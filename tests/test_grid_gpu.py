@@ -1,0 +1,88 @@
+"""GPU parity of the grid front-end (include/rgrid.h, csrc/rgrid.hip) against the CPU oracle, through the C ABI."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import pytest
+
+from tests.grid_cases import room_grid, scan_of
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gf():
+    from reflector_ekf_slam_amd.grid import GridFrontEnd
+    g = GridFrontEnd(max_points=16384, max_cells=1024 * 1024, max_candidates=1 << 18)
+    yield g
+    g.close()
+
+
+def test_voxel_filter_matches_oracle_bit_for_bit(gf, oracle_lib):
+    from oracle.binding import oracle_voxel_filter
+    rng = np.random.default_rng(11)
+    for n, span in ((1, 1.0), (257, 2.0), (3600, 8.0), (12000, 20.0)):
+        pts = rng.uniform(-span, span, (n, 2)).astype(np.float32)
+        pts[::7] = pts[::7].round(1)                                   # exact voxel-boundary values
+        for res in (0.025, 0.11, 0.9):
+            assert np.array_equal(gf.VoxelFilter(pts, res), oracle_voxel_filter(pts, res))
+    assert gf.VoxelFilter(np.zeros((0, 2), np.float32), 0.1).shape == (0, 2)
+
+
+def test_adaptive_voxel_filter_matches_oracle(gf, oracle_lib):
+    from oracle.binding import oracle_adaptive_voxel_filter
+    from reflector_ekf_slam_amd.grid import AdaptiveVoxelFilterOptions
+    rng = np.random.default_rng(12)
+    pts = rng.uniform(-9, 9, (5000, 2)).astype(np.float32)
+    dense = np.tile(np.array([[1.0, 1.0]], np.float32), (600, 1)) + rng.normal(0, 1e-4, (600, 2)).astype(np.float32)
+    for cloud, opt in ((pts[:300], AdaptiveVoxelFilterOptions()), (pts[:300], AdaptiveVoxelFilterOptions(max_range=5.0)),
+                       (pts, AdaptiveVoxelFilterOptions(max_length=0.3)), (pts, AdaptiveVoxelFilterOptions(max_length=2.0)),
+                       (pts, AdaptiveVoxelFilterOptions(max_length=2.0, min_num_points=1500, max_range=8.0)),
+                       (dense, AdaptiveVoxelFilterOptions(min_num_points=550))):
+        got = gf.AdaptiveVoxelFilter(cloud, opt)
+        exp = oracle_adaptive_voxel_filter(cloud, opt.max_length, opt.min_num_points, opt.max_range)
+        assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("true,dinit,npts", [((0.8, -0.6, 0.35), (0.10, -0.15, 4.0), 700), ((-2.0, 1.2, -1.9), (-0.12, 0.08, -7.0), 500),
+                                             ((0.0, 0.0, 3.0), (0.0, 0.0, 0.0), 300), ((3.1, 2.2, 0.9), (0.19, 0.19, 14.0), 900)])
+def test_match_identical_candidate_and_score(gf, oracle_lib, true, dinit, npts):
+    """Same best candidate (scan, x offset, y offset) as the oracle, same float32 score (the exp() of the penalty is
+    evaluated in FP64 on the device and on the host: tolerance one float32 ulp), same pose estimate."""
+    from oracle.binding import oracle_match
+    cells, max_xy, occ = room_grid()
+    gf.SetGrid(cells, 0.05, max_xy)
+    true = np.array(true)
+    pts = scan_of(occ, true, n_points=npts, seed=int(10 * abs(true[0]) + npts))
+    init = true + np.array([dinit[0], dinit[1], math.radians(dinit[2])])
+    r = gf.Match(init, pts)
+    score, pose, best, info = oracle_match(init, pts, cells, 0.05, max_xy)
+    assert r.info == info and r.best == best
+    assert abs(r.score - score) <= 1.2e-7 * score
+    assert np.abs(r.pose_estimate - pose).max() < 1e-12
+    assert np.abs(pose[:2] - true[:2]).max() <= 0.1
+
+
+def test_match_options_windows_and_errors(gf, oracle_lib):
+    from oracle.binding import oracle_match
+    from reflector_ekf_slam_amd.grid import RealTimeCorrelativeScanMatcherOptions, RgridError
+    cells, max_xy, occ = room_grid(resolution=0.1, half=10.0)
+    gf.SetGrid(cells, 0.1, max_xy)
+    true = np.array([1.0, 1.0, 0.2])
+    pts = scan_of(occ, true, n_points=400)
+    o = RealTimeCorrelativeScanMatcherOptions(linear_search_window=0.35, angular_search_window=math.radians(6.0),
+                                              translation_delta_cost_weight=2.0, rotation_delta_cost_weight=5.0)
+    r = gf.Match(true + [0.2, -0.1, 0.03], pts, o)
+    score, pose, best, info = oracle_match(true + [0.2, -0.1, 0.03], pts, cells, 0.1, max_xy, 0.35, math.radians(6.0), 2.0, 5.0)
+    assert r.info == info and r.best == best and abs(r.score - score) <= 1.2e-7 * score
+    assert info[1] == 4                                                            # ceil(0.35 / 0.1)
+    with pytest.raises(RgridError) as e:
+        gf.Match(np.zeros(3), np.zeros((0, 2), np.float32))
+    assert e.value.code == -6                                                      # empty cloud: code, not a CHECK failure
+    # points far outside the grid: every lookup is kMinProbability
+    r = gf.Match(np.zeros(3), np.array([[30.0, 30.0], [31.0, 29.0]], np.float32))
+    assert r.best[1:] == (0, 0) and abs(r.score - 0.1) < 1e-6
+    with pytest.raises(RgridError) as e:                                           # more rotated scans than the handle holds
+        gf.Match(np.zeros(3), np.array([[5000.0, 5000.0]], np.float32))
+    assert e.value.code == -4

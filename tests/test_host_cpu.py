@@ -16,10 +16,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols(header):
     text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b((?:rekf|rdet2d|rdet3d|rdet)_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b((?:rekf|rdet2d|rdet3d|rdet|rgrid)_[a-z0-9_]+)\s*\(", text)))
 
 
-@pytest.mark.parametrize("header,lib", [("rekf.h", "librekf.so"), ("rdet.h", "librdet.so")])
+@pytest.mark.parametrize("header,lib", [("rekf.h", "librekf.so"), ("rdet.h", "librdet.so"), ("rgrid.h", "librgrid.so")])
 def test_abi_library_exports_every_declared_symbol(header, lib):
     if not os.path.exists(os.path.join(ROOT, "include", header)):
         pytest.skip(f"{header} not part of this build yet")
@@ -52,7 +52,7 @@ def test_product_never_imports_the_oracle():
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
-                for pat in (r"^\s*(from|import)\s+oracle", r"liboracle", r"\boekf_", r"oracle/"):
+                for pat in (r"^\s*(from|import)\s+oracle", r"liboracle", r"\boekf_", r"\bogrid_", r"oracle/"):
                     assert not re.search(pat, txt, flags=re.M), f"{f} reaches into the oracle ({pat})"
 
 
