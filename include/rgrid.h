@@ -9,7 +9,10 @@
  *                                               (map_builder.cc:43) with its helpers SearchParameters,
  *                                               GenerateRotatedScans, DiscretizeScans
  *                                               (correlative_scan_matcher_2d.cc:10-123)
- * Not covered: CeresScanMatcher2D, the range-data inserter, submap handling, IO.
+ *   mapping::ProbabilityGridRangeDataInserter2D::Insert
+ *                                               src/mapping/probability_grid_range_data_inserter_2d.cc:40-114
+ *                                               (map_builder.cc: range_data_inserter_->Insert), without grid growth
+ * Not covered: CeresScanMatcher2D, grid growth (Grid2D::GrowLimits), submap handling, IO.
  *
  * Conventions as in rekf.h / rdet.h: opaque handles, plain pointers and sizes, 0 / negative error codes,
  * caller owns every buffer, a handle is not thread-safe, calls synchronise before returning.
@@ -66,6 +69,19 @@ int rgrid_adaptive_voxel_filter(rgrid_t *h, const float *xy, int n, double max_l
  * device and stay resident until the next call. */
 int rgrid_set_grid(rgrid_t *h, const uint16_t *cells, int num_x_cells, int num_y_cells, double resolution,
                    double max_x, double max_y);
+
+/* ProbabilityGridRangeDataInserter2D::Insert (src/mapping/probability_grid_range_data_inserter_2d.cc:40-114) on the
+ * resident grid: the cell of every return gets the hit table, every cell on the rays origin -> return and
+ * origin -> miss the miss table (RayToPixelMask, ray_to_pixel_mask.cc:17-168, sub-pixel scale 1000), a cell is
+ * updated at most once per insertion and hits win (probability_grid.cc:38-53), then FinishUpdate (grid_2d.cc:20-29).
+ * hit / miss probabilities: the reference's options are float (0.55 / 0.49, src/ros_node.cc:390-396).
+ * GrowAsNeeded is the caller's: a point outside the grid returns RGRID_ERR_CAPACITY and leaves the grid untouched.
+ * The grid must be in the finished state (no cell with the update marker 0x8000 set). */
+int rgrid_insert(rgrid_t *h, const float origin_xy[2], const float *returns_xy, int n_returns, const float *misses_xy,
+                 int n_misses, float hit_probability, float miss_probability, int insert_free_space);
+
+/* Copy of the resident grid cells (num_x_cells * num_y_cells values, same layout as rgrid_set_grid). */
+int rgrid_get_grid(rgrid_t *h, uint16_t *cells, long cap);
 
 /* RealTimeCorrelativeScanMatcher2D::Match (real_time_correlative_scan_matcher_2d.cc:84-118):
  * initial_pose = (x, y, rotation angle); points in the tracking frame; pose_estimate = (x, y, angle) of the best

@@ -81,6 +81,10 @@ def lib():
     L.ogrid_match.restype = C.c_double
     L.ogrid_match.argtypes = [C.c_void_p, _f64p, _f32p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double,
                               C.c_double, _f64p, _i32p, _i32p]
+    L.ogrid_lookup_table.argtypes = [C.c_float, C.c_void_p]
+    L.ogrid_insert.restype = C.c_int
+    L.ogrid_insert.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, _f32p, _f32p, C.c_int,
+                               _f32p, C.c_int, C.c_float, C.c_float, C.c_int]
     _lib = L
     return L
 
@@ -291,3 +295,26 @@ def oracle_match(initial_pose, points_xy, cells, resolution, max_xy, linear_sear
                           g.ctypes.data_as(C.c_void_p), g.shape[1], g.shape[0], float(resolution), float(max_xy[0]),
                           float(max_xy[1]), pose, best, info)
     return score, pose, tuple(int(v) for v in best), tuple(int(v) for v in info)
+
+
+def oracle_lookup_table(probability):
+    """ComputeLookupTableToApplyCorrespondenceCostOdds(Odds(probability)) (probability_values.cc:76-96): uint16[32768]."""
+    t = np.zeros(32768, np.uint16)
+    lib().ogrid_lookup_table(float(probability), t.ctypes.data_as(C.c_void_p))
+    return t
+
+
+def oracle_insert(cells, resolution, max_xy, origin, returns_xy, misses_xy=None, hit_probability=0.55,
+                  miss_probability=0.49, insert_free_space=True):
+    """ProbabilityGridRangeDataInserter2D::Insert on a copy of `cells` (no growth: everything must be inside);
+    option defaults = src/ros_node.cc:386-396.  Returns the updated uint16 grid."""
+    g = np.array(cells, dtype=np.uint16, order="C", copy=True)
+    ret = np.ascontiguousarray(returns_xy, dtype=np.float32).reshape(-1, 2)
+    mis = np.zeros((0, 2), np.float32) if misses_xy is None else np.ascontiguousarray(misses_xy, dtype=np.float32).reshape(-1, 2)
+    rc = lib().ogrid_insert(g.ctypes.data_as(C.c_void_p), g.shape[1], g.shape[0], float(resolution), float(max_xy[0]),
+                            float(max_xy[1]), np.ascontiguousarray(origin, dtype=np.float32), ret.reshape(-1) if ret.size else np.zeros(1, np.float32),
+                            ret.shape[0], mis.reshape(-1) if mis.size else np.zeros(1, np.float32), mis.shape[0],
+                            float(hit_probability), float(miss_probability), 1 if insert_free_space else 0)
+    if rc != 0:
+        raise ValueError("oracle insert: a point lies outside the grid (the caller must grow it first)")
+    return g

@@ -192,3 +192,119 @@ double ogrid_match(const ogrid_match_options *opt, const double initial_pose[3],
     free(rot0); free(rot); free(dix);
     return best_score_d;
 }
+
+/* ===== range-data inserter: ProbabilityGridRangeDataInserter2D::Insert ==================================
+ *   tables                ComputeLookupTableToApplyCorrespondenceCostOdds   src/mapping/probability_values.cc:76-96
+ *   CastRays              src/mapping/probability_grid_range_data_inserter_2d.cc:40-92
+ *   RayToPixelMask        src/mapping/ray_to_pixel_mask.cc:17-168 (restated below with one column-walk for both slopes)
+ *   ApplyLookupTable      src/mapping/probability_grid.cc:38-53   (a cell is updated at most once per insertion)
+ *   FinishUpdate          src/mapping/grid_2d.cc:20-29
+ * GrowAsNeeded / GrowLimits (:19-38, grid_2d.cc:47-98) is NOT restated: the caller hands in a grid that already
+ * contains the origin and every end point; anything outside is an error (return -1) and leaves the grid untouched. */
+#define OG_MARKER 32768u
+#define OG_SUBPIXEL 1000
+
+static float og_value_to_cost(int v)          /* kValueToCorrespondenceCost, v in [0, 32767] (probability_values.cc:11-20,46-51) */
+{
+    const float kMinProbability = 0.1f, kMaxProbability = 1.f - kMinProbability;
+    const float lower = 1.f - kMaxProbability, upper = 1.f - kMinProbability;
+    if (v == 0) return upper;
+    const float kScale = (upper - lower) / (32768 - 2.f);
+    return v * kScale + (lower - kScale);
+}
+static uint16_t og_cost_to_value(float c)     /* CorrespondenceCostToValue -> BoundedFloatToValue (probability_values.h:15-29,68-72) */
+{
+    const float kMinProbability = 0.1f, kMaxProbability = 1.f - kMinProbability;
+    const float lower = 1.f - kMaxProbability, upper = 1.f - kMinProbability;
+    float cl = c;
+    if (cl > upper) cl = upper;
+    if (cl < lower) cl = lower;
+    return (uint16_t)((int)lroundf((cl - lower) * (32766.f / (upper - lower))) + 1);
+}
+/* table[cell] for cell in [0, 32768): value after applying `odds`, with the update marker set */
+void ogrid_lookup_table(float probability, uint16_t *table)
+{
+    const float odds = probability / (1.f - probability);                       /* Odds() */
+    {
+        const float p = odds / (odds + 1.f);                                    /* ProbabilityFromOdds */
+        table[0] = (uint16_t)(og_cost_to_value(1.f - p) + OG_MARKER);
+    }
+    for (int cell = 1; cell != 32768; ++cell) {
+        const float pc = 1.f - og_value_to_cost(cell);                          /* CorrespondenceCostToProbability */
+        const float o = odds * (pc / (1.f - pc));
+        const float p = o / (o + 1.f);
+        table[cell] = (uint16_t)(og_cost_to_value(1.f - p) + OG_MARKER);
+    }
+}
+
+typedef struct { uint16_t *cells; int nx, ny; const uint16_t *table; } og_apply_ctx;
+static void og_apply(og_apply_ctx *g, int cx, int cy)                           /* ApplyLookupTable */
+{
+    uint16_t *cell = &g->cells[(size_t)g->nx * cy + cx];
+    if (*cell >= OG_MARKER) return;
+    *cell = g->table[*cell];
+}
+
+/* every pixel that contains part of the segment between the two superscaled points (ray_to_pixel_mask.cc:17-168);
+ * the reference de-duplicates consecutive pixels, applying a table twice is a no-op, so no de-duplication here */
+static void og_ray(og_apply_ctx *g, int bx, int by, int ex, int ey)
+{
+    const int S = OG_SUBPIXEL;
+    if (bx > ex) { int t = bx; bx = ex; ex = t; t = by; by = ey; ey = t; }     /* ordered by x (:24-27) */
+    if (bx / S == ex / S) {                                                     /* one pixel column (:35-47) */
+        const int x = bx / S, y0 = (by < ey ? by : ey) / S, y1 = (by < ey ? ey : by) / S;
+        for (int y = y0; y <= y1; ++y) og_apply(g, x, y);
+        return;
+    }
+    const long long dx = ex - bx, dy = ey - by, den = 2LL * S * dx;
+    int cx = bx / S, cy = by / S;
+    og_apply(g, cx, cy);
+    long long sub_y = (2LL * (by % S) + 1) * dx;                                /* (:64) */
+    const int first_pixel = 2 * S - 2 * (bx % S) - 1, last_pixel = 2 * (ex % S) + 1, end_x = ex / S;
+    sub_y += dy * first_pixel;
+    const int up = dy > 0;
+    for (;;) {
+        og_apply(g, cx, cy);
+        if (up) { while (sub_y > den) { sub_y -= den; ++cy; og_apply(g, cx, cy); } }
+        else { while (sub_y < 0) { sub_y += den; --cy; og_apply(g, cx, cy); } }
+        ++cx;
+        if (up) { if (sub_y == den) { sub_y -= den; ++cy; } }
+        else { if (sub_y == 0) { sub_y += den; --cy; } }
+        if (cx == end_x) break;
+        sub_y += dy * 2 * S;
+    }
+    sub_y += dy * last_pixel;
+    og_apply(g, cx, cy);
+    if (up) { while (sub_y > den) { sub_y -= den; ++cy; og_apply(g, cx, cy); } }
+    else { while (sub_y < 0) { sub_y += den; --cy; og_apply(g, cx, cy); } }
+}
+
+int ogrid_insert(uint16_t *cells, int nx, int ny, double resolution, double max_x, double max_y, const float origin[2],
+                 const float *returns_xy, int n_ret, const float *misses_xy, int n_miss, float hit_probability,
+                 float miss_probability, int insert_free_space)
+{
+    uint16_t *hit = (uint16_t *)malloc(2 * 32768), *miss = (uint16_t *)malloc(2 * 32768);
+    int *ends = (int *)malloc(sizeof(int) * 2 * (size_t)(n_ret + n_miss + 1));
+    ogrid_lookup_table(hit_probability, hit);
+    ogrid_lookup_table(miss_probability, miss);
+    const double rs = resolution / OG_SUBPIXEL;                                  /* superscaled limits (:48-53) */
+    const long long sx = (long long)nx * OG_SUBPIXEL, sy = (long long)ny * OG_SUBPIXEL;
+    int rc = 0;
+#define OG_IDX(px, py, ox, oy) do { ox = (int)lround((max_y - (double)(py)) / rs - 0.5); oy = (int)lround((max_x - (double)(px)) / rs - 0.5); \
+                                    if (ox < 0 || oy < 0 || ox >= sx || oy >= sy) rc = -1; } while (0)
+    int bx, by;
+    OG_IDX(origin[0], origin[1], bx, by);
+    for (int i = 0; i < n_ret; ++i) OG_IDX(returns_xy[2 * i], returns_xy[2 * i + 1], ends[2 * i], ends[2 * i + 1]);
+    for (int i = 0; i < n_miss; ++i) OG_IDX(misses_xy[2 * i], misses_xy[2 * i + 1], ends[2 * (n_ret + i)], ends[2 * (n_ret + i) + 1]);
+    if (rc == 0) {
+        og_apply_ctx g = {cells, nx, ny, hit};
+        for (int i = 0; i < n_ret; ++i) og_apply(&g, ends[2 * i] / OG_SUBPIXEL, ends[2 * i + 1] / OG_SUBPIXEL);   /* hits first (:57-62) */
+        if (insert_free_space) {
+            g.table = miss;
+            for (int i = 0; i < n_ret + n_miss; ++i) og_ray(&g, bx, by, ends[2 * i], ends[2 * i + 1]);          /* (:69-91) */
+        }
+        for (size_t k = 0; k < (size_t)nx * ny; ++k) if (cells[k] >= OG_MARKER) cells[k] -= OG_MARKER;         /* FinishUpdate */
+    }
+    free(hit); free(miss); free(ends);
+    return rc;
+}

@@ -220,6 +220,129 @@ __global__ __launch_bounds__(256) void kg_best(const BestRec *__restrict__ block
     if (threadIdx.x == 0) { out->score = s_sc[0]; out->id = s_id[0]; }
 }
 
+// ---- range-data inserter --------------------------------------------------------------------------
+// ApplyLookupTable (probability_grid.cc:38-53): a cell without the update marker takes table[cell] (which carries the
+// marker).  Concurrent lanes may race on one cell, but within a phase (hits, then misses: separate launches) every
+// writer stores the SAME value table[original], and a reader sees either the original or the marked value: the plain
+// 16-bit load/store pair gives the reference's result without atomics.
+struct InsertArgs {
+    int nx, ny, n_ret, n_miss;
+    double max_x, max_y, rs;           // rs = resolution / 1000 (superscaled limits, :48-53)
+    float ox, oy;
+};
+constexpr int SUBPX = 1000;
+constexpr unsigned MARKER = 32768u;
+
+__device__ static inline void apply_table(unsigned short *cells, int nx, int cx, int cy, const unsigned short *__restrict__ table)
+{
+    unsigned short *c = cells + (size_t)nx * cy + cx;
+    const unsigned short v = *c;
+    if (v < MARKER) *c = table[v];
+}
+__device__ static inline bool super_index(const InsertArgs &A, float px, float py, int &ix, int &iy)
+{
+    // superscaled MapLimits::GetCellIndex (map_limits.h:47-55): x index from y, y index from x
+    ix = (int)lround((A.max_y - (double)py) / A.rs - 0.5);
+    iy = (int)lround((A.max_x - (double)px) / A.rs - 0.5);
+    return ix >= 0 && iy >= 0 && (long long)ix < (long long)A.nx * SUBPX && (long long)iy < (long long)A.ny * SUBPX;
+}
+
+// end points of all rays (returns first, then misses); *bad = 1 if anything lies outside the grid
+__global__ __launch_bounds__(256) void kg_ends(InsertArgs A, const float *__restrict__ ret, const float *__restrict__ mis,
+                                               int2 *__restrict__ ends, int *__restrict__ bad)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int n = A.n_ret + A.n_miss;
+    if (i > n) return;
+    int ix, iy;
+    bool ok;
+    if (i == n) ok = super_index(A, A.ox, A.oy, ix, iy);                        // the origin (:54-55)
+    else {
+        const float *p = (i < A.n_ret) ? ret + 2 * i : mis + 2 * (i - A.n_ret);
+        ok = super_index(A, p[0], p[1], ix, iy);
+    }
+    ends[i] = make_int2(ix, iy);
+    if (!ok) *bad = 1;
+}
+__global__ __launch_bounds__(256) void kg_hits(InsertArgs A, const int2 *__restrict__ ends, const int *__restrict__ bad,
+                                               unsigned short *cells, const unsigned short *__restrict__ hit_table)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (*bad || i >= A.n_ret) return;
+    apply_table(cells, A.nx, ends[i].x / SUBPX, ends[i].y / SUBPX, hit_table);   // (:59-62)
+}
+// one lane per ray: every pixel that contains part of the segment (ray_to_pixel_mask.cc:17-168; the reference
+// de-duplicates consecutive pixels -- applying the table twice is a no-op, so no de-duplication here)
+__global__ __launch_bounds__(64) void kg_rays(InsertArgs A, const int2 *__restrict__ ends, const int *__restrict__ bad,
+                                              unsigned short *cells, const unsigned short *__restrict__ miss_table)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int n = A.n_ret + A.n_miss;
+    if (*bad || i >= n) return;
+    const int S = SUBPX;
+    int bx = ends[n].x, by = ends[n].y, ex = ends[i].x, ey = ends[i].y;
+    if (bx > ex) { int t = bx; bx = ex; ex = t; t = by; by = ey; ey = t; }      // ordered by x (:24-27)
+    if (bx / S == ex / S) {                                                      // one pixel column (:35-47)
+        const int x = bx / S, y0 = min(by, ey) / S, y1 = max(by, ey) / S;
+        for (int y = y0; y <= y1; ++y) apply_table(cells, A.nx, x, y, miss_table);
+        return;
+    }
+    const long long dx = ex - bx, dy = ey - by, den = 2LL * S * dx;
+    int cx = bx / S, cy = by / S;
+    apply_table(cells, A.nx, cx, cy, miss_table);
+    long long sub_y = (2LL * (by % S) + 1) * dx;                                 // (:64)
+    const int first_pixel = 2 * S - 2 * (bx % S) - 1, last_pixel = 2 * (ex % S) + 1, end_x = ex / S;
+    sub_y += dy * first_pixel;
+    const bool up = dy > 0;
+    for (;;) {
+        apply_table(cells, A.nx, cx, cy, miss_table);
+        if (up) { while (sub_y > den) { sub_y -= den; ++cy; apply_table(cells, A.nx, cx, cy, miss_table); } }
+        else { while (sub_y < 0) { sub_y += den; --cy; apply_table(cells, A.nx, cx, cy, miss_table); } }
+        ++cx;
+        if (up) { if (sub_y == den) { sub_y -= den; ++cy; } }
+        else { if (sub_y == 0) { sub_y += den; --cy; } }
+        if (cx == end_x) break;
+        sub_y += dy * 2 * S;
+    }
+    sub_y += dy * last_pixel;
+    apply_table(cells, A.nx, cx, cy, miss_table);
+    if (up) { while (sub_y > den) { sub_y -= den; ++cy; apply_table(cells, A.nx, cx, cy, miss_table); } }
+    else { while (sub_y < 0) { sub_y += den; --cy; apply_table(cells, A.nx, cx, cy, miss_table); } }
+}
+__global__ __launch_bounds__(256) void kg_finish(unsigned short *cells, long long ncells, const int *__restrict__ bad)
+{
+    if (*bad) return;
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k < ncells && cells[k] >= MARKER) cells[k] -= MARKER;                    // Grid2D::FinishUpdate (grid_2d.cc:20-29)
+}
+
+// ComputeLookupTableToApplyCorrespondenceCostOdds(Odds(probability)) (probability_values.cc:76-96), host float32
+void lookup_table(float probability, unsigned short *table)
+{
+#pragma clang fp contract(off)
+    const float kMinProbability = 0.1f, kMaxProbability = 1.f - kMinProbability;
+    const float lower = 1.f - kMaxProbability, upper = 1.f - kMinProbability;
+    auto cost_to_value = [&](float c) -> unsigned short {                        // BoundedFloatToValue (probability_values.h:15-29)
+        float cl = c;
+        if (cl > upper) cl = upper;
+        if (cl < lower) cl = lower;
+        return (unsigned short)((int)std::lround((cl - lower) * (32766.f / (upper - lower))) + 1);
+    };
+    const float odds = probability / (1.f - probability);
+    {
+        const float p = odds / (odds + 1.f);
+        table[0] = (unsigned short)(cost_to_value(1.f - p) + MARKER);
+    }
+    const float kScale = (upper - lower) / (32768 - 2.f);
+    for (int cell = 1; cell != 32768; ++cell) {
+        const float cost = cell * kScale + (lower - kScale);                     // kValueToCorrespondenceCost[cell]
+        const float pc = 1.f - cost;
+        const float o = odds * (pc / (1.f - pc));
+        const float p = o / (o + 1.f);
+        table[cell] = (unsigned short)(cost_to_value(1.f - p) + MARKER);
+    }
+}
+
 // Project2D(Rigid3f::Rotation(AngleAxisf(angle, UnitZ))) as a (cos, sin) pair, restating Eigen 3.3 in float32:
 // Quaternionf(AngleAxisf) = (cos(a/2), 0, 0, sin(a/2)); GetYaw (transform.h:27-33) = atan2 of q * UnitX with
 // Eigen's  v + w*uv + vec x uv,  uv = 2 (vec x v); Rotation2Df(yaw) rotates with (cos yaw, sin yaw).  Host libm.
@@ -243,7 +366,11 @@ struct rgrid {
     float *d_in, *d_a, *d_b, *d_cs;       // points in / two result buffers / per-scan (cos, sin)
     int2 *d_key, *d_idx;
     unsigned char *d_keep;
-    unsigned short *d_cells;
+    unsigned short *d_cells, *d_hit, *d_miss;   // grid; hit / miss lookup tables (uint16[32768])
+    float *d_mis;                               // misses of an insertion
+    int2 *d_ends;
+    int *d_bad;
+    float tab_hit_p, tab_miss_p;                // probabilities the resident tables were built for
     BestRec *d_bb, *d_best;
     int *d_count;
     // pinned staging
@@ -329,6 +456,7 @@ int rgrid_create(int max_points, int max_cells, int max_candidates, int device, 
     if (!h) return RGRID_ERR_INVALID;
     h->max_points = max_points; h->max_cells = max_cells; h->max_candidates = max_candidates; h->device = device;
     h->have_grid = false;
+    h->tab_hit_p = h->tab_miss_p = -1.f;
     const size_t np = (size_t)max_points;
     // discretised scans: every candidate's scan must fit: num_scans <= max_candidates, num_scans * n <= np * scans_cap
     int rc = [&]() -> int {
@@ -339,6 +467,8 @@ int rgrid_create(int max_points, int max_cells, int max_candidates, int device, 
         G_TRY(h, hipMalloc(&h->d_cs, 8 * (size_t)max_candidates));
         G_TRY(h, hipMalloc(&h->d_idx, 8 * np * 1024));                       // up to 1024 rotated scans of max_points points
         G_TRY(h, hipMalloc(&h->d_cells, 2 * (size_t)max_cells));
+        G_TRY(h, hipMalloc(&h->d_hit, 2 * 32768)); G_TRY(h, hipMalloc(&h->d_miss, 2 * 32768));
+        G_TRY(h, hipMalloc(&h->d_mis, 8 * np)); G_TRY(h, hipMalloc(&h->d_ends, 8 * (2 * np + 1))); G_TRY(h, hipMalloc(&h->d_bad, sizeof(int)));
         G_TRY(h, hipMalloc(&h->d_bb, sizeof(BestRec) * 1024));                   // one record per rotated scan
         G_TRY(h, hipMalloc(&h->d_best, sizeof(BestRec)));
         G_TRY(h, hipMalloc(&h->d_count, sizeof(int)));
@@ -356,7 +486,8 @@ void rgrid_destroy(rgrid_t *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *ptrs[] = {h->d_in, h->d_a, h->d_b, h->d_cs, h->d_key, h->d_idx, h->d_keep, h->d_cells, h->d_bb, h->d_best, h->d_count};
+    void *ptrs[] = {h->d_in, h->d_a, h->d_b, h->d_cs, h->d_key, h->d_idx, h->d_keep, h->d_cells, h->d_bb, h->d_best, h->d_count,
+                    h->d_hit, h->d_miss, h->d_mis, h->d_ends, h->d_bad};
     for (void *p : ptrs) (void)hipFree(p);
     if (h->h_pts) (void)hipHostFree(h->h_pts);
     if (h->h_count) (void)hipHostFree(h->h_count);
@@ -447,6 +578,61 @@ int rgrid_set_grid(rgrid_t *h, const uint16_t *cells, int num_x_cells, int num_y
     G_TRY(h, hipStreamSynchronize(h->stream));
     h->nx = num_x_cells; h->ny = num_y_cells; h->resolution = resolution; h->max_x = max_x; h->max_y = max_y;
     h->have_grid = true;
+    return RGRID_OK;
+}
+
+int rgrid_insert(rgrid_t *h, const float origin_xy[2], const float *returns_xy, int n_returns, const float *misses_xy,
+                 int n_misses, float hit_probability, float miss_probability, int insert_free_space)
+{
+    if (!h || !origin_xy || n_returns < 0 || n_misses < 0 || (n_returns > 0 && !returns_xy) || (n_misses > 0 && !misses_xy))
+        return RGRID_ERR_INVALID;
+    if (!h->have_grid || !(hit_probability > 0.f && hit_probability < 1.f) || !(miss_probability > 0.f && miss_probability < 1.f))
+        return RGRID_ERR_INVALID;
+    if (n_returns > h->max_points || n_misses > h->max_points) return RGRID_ERR_CAPACITY;
+    G_TRY(h, hipSetDevice(h->device));
+    if (hit_probability != h->tab_hit_p || miss_probability != h->tab_miss_p) {      // the tables only depend on the two options
+        std::vector<unsigned short> t(32768);
+        lookup_table(hit_probability, t.data());
+        G_TRY(h, hipMemcpy(h->d_hit, t.data(), 2 * 32768, hipMemcpyHostToDevice));
+        lookup_table(miss_probability, t.data());
+        G_TRY(h, hipMemcpy(h->d_miss, t.data(), 2 * 32768, hipMemcpyHostToDevice));
+        h->tab_hit_p = hit_probability; h->tab_miss_p = miss_probability;
+    }
+    if (n_returns > 0) {
+        std::memcpy(h->h_pts, returns_xy, sizeof(float) * 2 * (size_t)n_returns);
+        G_TRY(h, hipMemcpyAsync(h->d_in, h->h_pts, sizeof(float) * 2 * (size_t)n_returns, hipMemcpyHostToDevice, h->stream));
+        G_TRY(h, hipStreamSynchronize(h->stream));                                   // h_pts is reused for the misses below
+    }
+    if (n_misses > 0) {
+        std::memcpy(h->h_pts, misses_xy, sizeof(float) * 2 * (size_t)n_misses);
+        G_TRY(h, hipMemcpyAsync(h->d_mis, h->h_pts, sizeof(float) * 2 * (size_t)n_misses, hipMemcpyHostToDevice, h->stream));
+    }
+    G_TRY(h, hipMemsetAsync(h->d_bad, 0, sizeof(int), h->stream));
+    InsertArgs A;
+    A.nx = h->nx; A.ny = h->ny; A.n_ret = n_returns; A.n_miss = n_misses;
+    A.max_x = h->max_x; A.max_y = h->max_y; A.rs = h->resolution / SUBPX;
+    A.ox = origin_xy[0]; A.oy = origin_xy[1];
+    const int n = n_returns + n_misses;
+    hipLaunchKernelGGL(kg_ends, dim3((n + 1 + 255) / 256), dim3(256), 0, h->stream, A, h->d_in, h->d_mis, h->d_ends, h->d_bad);
+    if (n_returns > 0)
+        hipLaunchKernelGGL(kg_hits, dim3((n_returns + 255) / 256), dim3(256), 0, h->stream, A, h->d_ends, h->d_bad, h->d_cells, h->d_hit);
+    if (insert_free_space && n > 0)
+        hipLaunchKernelGGL(kg_rays, dim3((n + 63) / 64), dim3(64), 0, h->stream, A, h->d_ends, h->d_bad, h->d_cells, h->d_miss);
+    const long long ncells = (long long)h->nx * h->ny;
+    hipLaunchKernelGGL(kg_finish, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, h->stream, h->d_cells, ncells, h->d_bad);
+    G_TRY(h, hipMemcpyAsync(h->h_count, h->d_bad, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    G_TRY(h, hipStreamSynchronize(h->stream));
+    return *h->h_count ? RGRID_ERR_CAPACITY : RGRID_OK;
+}
+
+int rgrid_get_grid(rgrid_t *h, uint16_t *cells, long cap)
+{
+    if (!h || !cells || !h->have_grid) return RGRID_ERR_INVALID;
+    const long long ncells = (long long)h->nx * h->ny;
+    if (cap < ncells) return RGRID_ERR_BUFFER;
+    G_TRY(h, hipSetDevice(h->device));
+    G_TRY(h, hipMemcpyAsync(cells, h->d_cells, sizeof(uint16_t) * (size_t)ncells, hipMemcpyDeviceToHost, h->stream));
+    G_TRY(h, hipStreamSynchronize(h->stream));
     return RGRID_OK;
 }
 

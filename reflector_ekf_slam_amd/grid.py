@@ -49,6 +49,8 @@ def _lib_rgrid():
     L.rgrid_adaptive_voxel_filter.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, C.c_double, vp, C.c_int, ip]
     L.rgrid_set_grid.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
     L.rgrid_match.argtypes = [vp, C.POINTER(_MatchOptions), dp, vp, C.c_int, dp, dp, ip, ip]
+    L.rgrid_insert.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, C.c_float, C.c_float, C.c_int]
+    L.rgrid_get_grid.argtypes = [vp, vp, C.c_long]
     _rgrid = L
     return L
 
@@ -69,6 +71,15 @@ class AdaptiveVoxelFilterOptions:
     max_length: float = 0.9
     min_num_points: float = 500
     max_range: float = 100.0
+
+
+@dataclass
+class RangeDataInserterOptions:
+    """mapping::ProbabilityGridRangeDataInserterOptions2D (probability_grid_range_data_inserter_2d.h:16-21);
+    defaults = src/ros_node.cc:386-396."""
+    insert_free_space: bool = True
+    hit_probability: float = 0.55
+    miss_probability: float = 0.49
 
 
 @dataclass
@@ -133,8 +144,25 @@ class GridFrontEnd:
         resolution and max corner (map_limits.h:24-45)."""
         g = np.ascontiguousarray(cells, dtype=np.uint16)
         assert g.ndim == 2
+        self._grid_shape = g.shape
         self._chk(self._L.rgrid_set_grid(self._h, g.ctypes.data_as(C.c_void_p), g.shape[1], g.shape[0], float(resolution),
                                          float(max_xy[0]), float(max_xy[1])), "SetGrid")
+
+    # ProbabilityGridRangeDataInserter2D::Insert  (probability_grid_range_data_inserter_2d.cc:103-114), no grid growth
+    def Insert(self, origin_xy, returns_xy, misses_xy=None, options: "RangeDataInserterOptions | None" = None):
+        o = options or RangeDataInserterOptions()
+        org = (C.c_float * 2)(float(origin_xy[0]), float(origin_xy[1]))
+        ret = np.ascontiguousarray(returns_xy, dtype=np.float32).reshape(-1, 2)
+        mis = np.zeros((0, 2), np.float32) if misses_xy is None else np.ascontiguousarray(misses_xy, dtype=np.float32).reshape(-1, 2)
+        self._chk(self._L.rgrid_insert(self._h, org, ret.ctypes.data_as(C.c_void_p) if ret.size else None, ret.shape[0],
+                                       mis.ctypes.data_as(C.c_void_p) if mis.size else None, mis.shape[0],
+                                       float(o.hit_probability), float(o.miss_probability), 1 if o.insert_free_space else 0),
+                  "Insert")
+
+    def GetGrid(self) -> np.ndarray:
+        out = np.zeros(self._grid_shape, np.uint16)
+        self._chk(self._L.rgrid_get_grid(self._h, out.ctypes.data_as(C.c_void_p), out.size), "GetGrid")
+        return out
 
     # RealTimeCorrelativeScanMatcher2D::Match  (real_time_correlative_scan_matcher_2d.cc:84-118)
     def Match(self, initial_pose_estimate, point_cloud, options: RealTimeCorrelativeScanMatcherOptions | None = None) -> MatchResult:

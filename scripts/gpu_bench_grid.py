@@ -4,7 +4,7 @@ import json, math, sys, time
 sys.path.insert(0, ".")
 import numpy as np
 from reflector_ekf_slam_amd.grid import GridFrontEnd, AdaptiveVoxelFilterOptions
-from oracle.binding import oracle_voxel_filter, oracle_adaptive_voxel_filter, oracle_match
+from oracle.binding import oracle_voxel_filter, oracle_adaptive_voxel_filter, oracle_match, oracle_insert
 from tests.grid_cases import room_grid, scan_of
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
@@ -43,3 +43,19 @@ for name, pts in (("match_adaptive_cloud", av), ("match_full_cloud", vf)):
                       "same_candidate": bool(r.best == best), "score": r.score, "score_rel_diff": abs(r.score - sc) / sc,
                       "gpu_call_us": round(timeit(lambda: g.Match(init, pts), reps), 1),
                       "cpu_oracle_us": round(timeit(lambda: oracle_match(init, pts, cells, 0.05, max_xy), 3), 1)}))
+
+# range-data insertion into an initially unknown grid (3600 returns + 100 misses), then cell-for-cell comparison
+pose = (0.5, 0.3, 0.2)
+c, s_ = math.cos(pose[2]), math.sin(pose[2])
+world = np.stack([pose[0] + c * returns[:, 0] - s_ * returns[:, 1], pose[1] + s_ * returns[:, 0] + c * returns[:, 1]], 1).astype(np.float32)
+ang = rng.uniform(-math.pi, math.pi, 100)
+misses = np.stack([pose[0] + 5.0 * np.cos(ang), pose[1] + 3.5 * np.sin(ang)], 1).astype(np.float32)
+origin = np.array(pose[:2], np.float32)
+empty = np.zeros_like(cells)
+g.SetGrid(empty, 0.05, max_xy)
+g.Insert(origin, world, misses)
+same = bool(np.array_equal(g.GetGrid(), oracle_insert(empty, 0.05, max_xy, origin, world, misses)))
+print(json.dumps({"case": "insert_range_data", "returns": int(world.shape[0]), "misses": 100, "cells": int(empty.size),
+                  "identical_to_oracle": same,
+                  "gpu_call_us": round(timeit(lambda: g.Insert(origin, world, misses), reps), 1),
+                  "cpu_oracle_us": round(timeit(lambda: oracle_insert(empty, 0.05, max_xy, origin, world, misses), 5), 1)}))

@@ -97,3 +97,50 @@ def test_matcher_outside_the_grid_scores_min_probability(oracle_lib):
     score, pose, best, info = oracle_match(np.zeros(3), pts, cells, 0.05, (1.0, 1.0), linear_search_window=0.1)
     assert best[1] == 0 and best[2] == 0                                                   # all sums equal: the smallest penalty wins
     assert abs(score - 0.1) < 1e-6
+
+
+def test_lookup_tables_and_hit_miss_semantics(oracle_lib):
+    from oracle.binding import oracle_insert, oracle_lookup_table
+    hit, miss = oracle_lookup_table(0.55), oracle_lookup_table(0.49)
+    assert hit.min() >= 32768 and miss.min() >= 32768                            # every entry carries the update marker
+    f32 = np.float32
+    # unknown cell: value of the probability itself (probability_values.cc:80-82): cost = 1 - p
+    lower, upper = f32(1) - (f32(1) - f32(0.1)), f32(1) - f32(0.1)
+    v0 = int(np.rint((f32(1) - f32(0.55) - lower) * (f32(32766) / (upper - lower)))) + 1
+    assert abs(int(hit[0]) - 32768 - v0) <= 1
+    # a hit lowers the correspondence cost of a known cell, a miss raises it; both are monotone in the old value
+    known = np.arange(1, 32768)
+    assert ((hit[known] - 32768).astype(int) <= known).all() and ((miss[known] - 32768).astype(int) >= known).all()
+    assert (np.diff((hit[known] - 32768).astype(int)) >= 0).all()
+    # one return seen from the origin: its cell gets the hit table, the cells on the ray the miss table, hits win
+    n = 80
+    cells = np.zeros((n, n), np.uint16)
+    res, max_xy = 0.1, (4.0, 4.0)
+    origin = np.array([0.03, -0.02], np.float32)
+    ret = np.array([[2.51, 1.27], [2.65, 1.15]], np.float32)                    # second return: same ray region, other cell
+    out = oracle_insert(cells, res, max_xy, origin, ret)
+    def cell_of(p):
+        return int(np.floor((max_xy[0] - p[0]) / res)), int(np.floor((max_xy[1] - p[1]) / res))   # (row = y index from x, col = x index from y)
+    for p in ret:
+        r, c = cell_of(p)
+        assert out[r, c] == hit[0] - 32768
+    r0, c0 = cell_of(origin)
+    assert out[r0, c0] == miss[0] - 32768
+    touched = np.argwhere(out != 0)
+    assert 30 < touched.shape[0] < 90                                            # ~ |dx| + |dy| cells per ray, two nearly equal rays
+    assert (out[out != 0] < 32768).all()                                         # FinishUpdate removed every marker
+    # supercover property: every point of the segment lies in an updated cell
+    for p in ret:
+        for t in np.linspace(0, 1, 2001):
+            q = origin.astype(np.float64) * (1 - t) + p.astype(np.float64) * t
+            r, c = cell_of(q)
+            assert out[r, c] != 0
+    # a second identical insertion moves known cells: hit cell gets more certain, ray cells freer
+    out2 = oracle_insert(out, res, max_xy, origin, ret)
+    r, c = cell_of(ret[0])
+    assert out2[r, c] < out[r, c] and out2[r0, c0] > out[r0, c0]
+    # hits only
+    out3 = oracle_insert(cells, res, max_xy, origin, ret, insert_free_space=False)
+    assert np.count_nonzero(out3) == 2
+    with pytest.raises(ValueError):
+        oracle_insert(cells, res, max_xy, origin, np.array([[9.0, 0.0]], np.float32))
