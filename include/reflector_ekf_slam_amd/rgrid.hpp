@@ -1,0 +1,89 @@
+// rgrid.hpp -- header-only C++ RAII wrapper over include/rgrid.h (grid-mapper front-end): the calls
+// mapping::MapBuilder makes to sensor::VoxelFilter / AdaptiveVoxelFilter, RealTimeCorrelativeScanMatcher2D::Match and
+// ProbabilityGridRangeDataInserter2D::Insert (src/mapping/map_builder.cc:30-31,43,73), with plain std types.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../rgrid.h"
+
+namespace rekfpp {
+
+struct GridError : std::runtime_error {
+    int code;
+    GridError(int c, const std::string &where) : std::runtime_error(where + ": " + rgrid_strerror(c)), code(c) {}
+};
+
+class GridFrontEnd {
+public:
+    using Cloud = std::vector<float>;                 // x0, y0, x1, y1, ... (sensor::PointCloud = std::vector<Eigen::Vector2f>)
+
+    explicit GridFrontEnd(int max_points = 8192, int max_cells = 4096 * 4096, int max_candidates = 1 << 20, int device = 0)
+    {
+        const int rc = rgrid_create(max_points, max_cells, max_candidates, device, &h_);
+        if (rc != RGRID_OK) throw GridError(rc, "rgrid_create");
+    }
+    ~GridFrontEnd() { rgrid_destroy(h_); }
+    GridFrontEnd(const GridFrontEnd &) = delete;
+    GridFrontEnd &operator=(const GridFrontEnd &) = delete;
+
+    // sensor::VoxelFilter(size).Filter(cloud)  (voxel_filter.cc:81-95)
+    Cloud VoxelFilter(const Cloud &cloud, float size)
+    {
+        Cloud out(cloud.size());
+        int m = 0;
+        chk(rgrid_voxel_filter(h_, cloud.data(), (int)(cloud.size() / 2), size, out.data(), (int)(out.size() / 2), &m), "VoxelFilter");
+        out.resize(2 * (size_t)m);
+        return out;
+    }
+    // sensor::AdaptiveVoxelFilter(options).Filter(cloud)  (voxel_filter.cc:116-120)
+    Cloud AdaptiveVoxelFilter(const Cloud &cloud, double max_length, double min_num_points, double max_range)
+    {
+        Cloud out(cloud.size());
+        int m = 0;
+        chk(rgrid_adaptive_voxel_filter(h_, cloud.data(), (int)(cloud.size() / 2), max_length, min_num_points, max_range,
+                                        out.data(), (int)(out.size() / 2), &m), "AdaptiveVoxelFilter");
+        out.resize(2 * (size_t)m);
+        return out;
+    }
+    // the ProbabilityGrid: grid.correspondence_cost_cells(), grid.limits()  (grid_2d.h:83-106, map_limits.h:24-45)
+    void SetGrid(const std::vector<uint16_t> &cells, int num_x_cells, int num_y_cells, double resolution, double max_x, double max_y)
+    {
+        if ((size_t)num_x_cells * num_y_cells != cells.size()) throw GridError(RGRID_ERR_INVALID, "SetGrid");
+        chk(rgrid_set_grid(h_, cells.data(), num_x_cells, num_y_cells, resolution, max_x, max_y), "SetGrid");
+        ncells_ = cells.size();
+    }
+    std::vector<uint16_t> GetGrid()
+    {
+        std::vector<uint16_t> out(ncells_);
+        chk(rgrid_get_grid(h_, out.data(), (long)out.size()), "GetGrid");
+        return out;
+    }
+    // ProbabilityGridRangeDataInserter2D::Insert  (probability_grid_range_data_inserter_2d.cc:103-114), no grid growth
+    void Insert(const std::array<float, 2> &origin, const Cloud &returns, const Cloud &misses, float hit_probability = 0.55f,
+                float miss_probability = 0.49f, bool insert_free_space = true)
+    {
+        chk(rgrid_insert(h_, origin.data(), returns.data(), (int)(returns.size() / 2), misses.data(), (int)(misses.size() / 2),
+                         hit_probability, miss_probability, insert_free_space ? 1 : 0), "Insert");
+    }
+    // RealTimeCorrelativeScanMatcher2D::Match  (real_time_correlative_scan_matcher_2d.cc:84-118): returns the score
+    double Match(const rgrid_match_options &opt, const std::array<double, 3> &initial_pose, const Cloud &cloud,
+                 std::array<double, 3> &pose_estimate)
+    {
+        double score = 0;
+        chk(rgrid_match(h_, &opt, initial_pose.data(), cloud.data(), (int)(cloud.size() / 2), pose_estimate.data(), &score,
+                        nullptr, nullptr), "Match");
+        return score;
+    }
+    rgrid_t *handle() { return h_; }
+
+private:
+    static void chk(int rc, const char *where) { if (rc != RGRID_OK) throw GridError(rc, where); }
+    rgrid_t *h_ = nullptr;
+    size_t ncells_ = 0;
+};
+
+}  // namespace rekfpp

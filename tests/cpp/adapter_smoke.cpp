@@ -8,6 +8,7 @@
 #include "reflector_ekf_slam_amd/detect_adapter.hpp"
 #include "reflector_ekf_slam_amd/ekf_slam_adapter.hpp"
 #include "reflector_ekf_slam_amd/rekf.hpp"
+#include "reflector_ekf_slam_amd/rgrid.hpp"
 
 int main(int argc, char **)
 {
@@ -28,6 +29,25 @@ int main(int argc, char **)
     if (!(std::fabs(sig[0] - sig[0]) == 0.0)) return 1;
     const auto ell = f.MarkerEllipses();
     if (ell.size() != 2 || !(ell[0].x_len > 0.0) || std::fabs(ell[0].x - mu[3]) > 0.0) { std::printf("FAIL ellipses\n"); return 1; }
+    // grid front-end: insert a short wall into an unknown grid, then find it again with the matcher
+    {
+        rekfpp::GridFrontEnd gf(4096, 200 * 200, 1 << 16);
+        gf.SetGrid(std::vector<uint16_t>(200 * 200, 0), 200, 200, 0.05, 5.0, 5.0);
+        rekfpp::GridFrontEnd::Cloud wall;
+        for (int i = 0; i < 120; ++i) { wall.push_back(2.0f); wall.push_back(-1.5f + 0.025f * i); }
+        for (int rep = 0; rep < 3; ++rep) gf.Insert({0.f, 0.f}, wall, {});
+        const auto g = gf.GetGrid();
+        size_t known = 0;
+        for (uint16_t v : g) known += v != 0;
+        const auto thin = gf.VoxelFilter(wall, 0.05f);
+        rgrid_match_options mo{0.2, 0.1, 1e-1, 1e-1};
+        std::array<double, 3> pe{};
+        const double score = gf.Match(mo, {0.1, 0.05, 0.0}, thin, pe);
+        if (known < 1000 || thin.size() >= wall.size() || !(score > 0.3) || std::fabs(pe[0]) > 0.051) {
+            std::printf("FAIL grid known=%zu thin=%zu score=%f pe=%f\n", known, thin.size() / 2, score, pe[0]);
+            return 1;
+        }
+    }
     std::printf("ADAPTER_OK n=%zu t=%.2f x=%.6f\n", mu.size(), t, mu[0]);
     return 0;
 }

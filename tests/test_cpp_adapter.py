@@ -16,7 +16,7 @@ def _build(tmp_path):
     exe = str(tmp_path / "adapter_smoke")
     lib = os.path.join(ROOT, "reflector_ekf_slam_amd")
     cmd = ["g++", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "adapter_smoke.cpp"),
-           "-L", lib, "-lrekf", "-lrdet", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-o", exe]
+           "-L", lib, "-lrekf", "-lrdet", "-lrgrid", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-o", exe]
     out = subprocess.run(cmd, capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-3000:]
     return exe
