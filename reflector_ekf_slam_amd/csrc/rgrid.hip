@@ -271,43 +271,69 @@ __global__ __launch_bounds__(256) void kg_hits(InsertArgs A, const int2 *__restr
     if (*bad || i >= A.n_ret) return;
     apply_table(cells, A.nx, ends[i].x / SUBPX, ends[i].y / SUBPX, hit_table);   // (:59-62)
 }
-// one lane per ray: every pixel that contains part of the segment (ray_to_pixel_mask.cc:17-168; the reference
-// de-duplicates consecutive pixels -- applying the table twice is a no-op, so no de-duplication here)
-__global__ __launch_bounds__(64) void kg_rays(InsertArgs A, const int2 *__restrict__ ends, const int *__restrict__ bad,
-                                              unsigned short *cells, const unsigned short *__restrict__ miss_table)
+// One WAVE per ray.  RayToPixelMask (ray_to_pixel_mask.cc:17-168) walks the ray pixel column by pixel column and
+// carries a sub-pixel ordinate `sub_y` (in units of 1 / (2 * 1000 * dx)); that recurrence has a closed form --
+// with A(X) = A0 + dy * (first_pixel + 2000 * (X - X0)) the absolute ordinate at the right border of column X
+// (dy * last_pixel instead of the full 2000 for the last column), column X covers the rows
+//   dy > 0:  floor(A(X-1) / den) .. ceil(A(X) / den) - 1        (`while (sub_y > den)` / `if (sub_y == den)`)
+//   dy <= 0: ceil(A(X-1) / den) - 1 .. floor(A(X) / den)        (`while (sub_y < 0)`  / `if (sub_y == 0)`)
+// (first column: from the begin pixel's row) -- so the columns are independent.  Lanes take 64 columns at a time,
+// a wave prefix sum of the rows per column flattens them into one pixel list, and the lanes share that list evenly:
+// every lane has work whatever the slope.  The reference de-duplicates consecutive pixels; applying the table twice
+// is a no-op, so no de-duplication here.
+__global__ __launch_bounds__(256) void kg_rays(InsertArgs A, const int2 *__restrict__ ends, const int *__restrict__ bad,
+                                               unsigned short *cells, const unsigned short *__restrict__ miss_table)
 {
-    const int i = blockIdx.x * 64 + threadIdx.x;
+    __shared__ int s_pref[4][65], s_lo[4][64], s_step[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wave;
     const int n = A.n_ret + A.n_miss;
     if (*bad || i >= n) return;
-    const int S = SUBPX;
-    int bx = ends[n].x, by = ends[n].y, ex = ends[i].x, ey = ends[i].y;
-    if (bx > ex) { int t = bx; bx = ex; ex = t; t = by; by = ey; ey = t; }      // ordered by x (:24-27)
-    if (bx / S == ex / S) {                                                      // one pixel column (:35-47)
-        const int x = bx / S, y0 = min(by, ey) / S, y1 = max(by, ey) / S;
-        for (int y = y0; y <= y1; ++y) apply_table(cells, A.nx, x, y, miss_table);
+    const long long S = SUBPX;
+    long long bx = ends[n].x, by = ends[n].y, ex = ends[i].x, ey = ends[i].y;
+    if (bx > ex) { long long t = bx; bx = ex; ex = t; t = by; by = ey; ey = t; }   // ordered by x (:24-27)
+    const int X0 = (int)(bx / S), X1 = (int)(ex / S);
+    if (X0 == X1) {                                                               // one pixel column (:35-47)
+        const int y0 = (int)((by < ey ? by : ey) / S), y1 = (int)((by < ey ? ey : by) / S);
+        for (int y = y0 + lane; y <= y1; y += 64) apply_table(cells, A.nx, X0, y, miss_table);
         return;
     }
-    const long long dx = ex - bx, dy = ey - by, den = 2LL * S * dx;
-    int cx = bx / S, cy = by / S;
-    apply_table(cells, A.nx, cx, cy, miss_table);
-    long long sub_y = (2LL * (by % S) + 1) * dx;                                 // (:64)
-    const int first_pixel = 2 * S - 2 * (bx % S) - 1, last_pixel = 2 * (ex % S) + 1, end_x = ex / S;
-    sub_y += dy * first_pixel;
+    const long long dx = ex - bx, dy = ey - by, den = 2 * S * dx;
+    const long long A0 = (2 * (by % S) + 1) * dx + (by / S) * den;                // absolute ordinate of the begin point (:64)
+    const long long first_pixel = 2 * S - 2 * (bx % S) - 1, last_pixel = 2 * (ex % S) + 1;
     const bool up = dy > 0;
-    for (;;) {
-        apply_table(cells, A.nx, cx, cy, miss_table);
-        if (up) { while (sub_y > den) { sub_y -= den; ++cy; apply_table(cells, A.nx, cx, cy, miss_table); } }
-        else { while (sub_y < 0) { sub_y += den; --cy; apply_table(cells, A.nx, cx, cy, miss_table); } }
-        ++cx;
-        if (up) { if (sub_y == den) { sub_y -= den; ++cy; } }
-        else { if (sub_y == 0) { sub_y += den; --cy; } }
-        if (cx == end_x) break;
-        sub_y += dy * 2 * S;
+    auto a_out = [&](int X) -> long long {                                        // ordinate at the right border of column X
+        return A0 + dy * (first_pixel + 2 * S * (long long)(X - X0) + ((X == X1) ? last_pixel - 2 * S : 0));
+    };
+    auto fdiv = [&](long long a) -> long long { return a / den; };                // a >= 0 inside the grid
+    auto cdiv = [&](long long a) -> long long { return (a + den - 1) / den; };
+    for (int Xc = X0; Xc <= X1; Xc += 64) {
+        const int X = Xc + lane;
+        int lo = 0, cnt = 0, step = 1;
+        if (X <= X1) {
+            const long long ao = a_out(X);
+            int r_in, r_out;
+            if (up) { r_in = (X == X0) ? (int)(by / S) : (int)fdiv(a_out(X - 1)); r_out = (int)cdiv(ao) - 1; cnt = r_out - r_in + 1; }
+            else { r_in = (X == X0) ? (int)(by / S) : (int)cdiv(a_out(X - 1)) - 1; r_out = (int)fdiv(ao); cnt = r_in - r_out + 1; step = -1; }
+            if (cnt < 1) cnt = 1;                                                 // the column's entry pixel is always visited
+            lo = r_in;
+        }
+        // exclusive prefix sum of cnt over the wave
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+        s_pref[wave][lane + 1] = incl; s_lo[wave][lane] = lo; s_step[wave][lane] = step;
+        if (lane == 0) s_pref[wave][0] = 0;
+        __builtin_amdgcn_wave_barrier();
+        const int total = s_pref[wave][64];
+        for (int p = lane; p < total; p += 64) {
+            int a = 0, b = 63;                                                    // column c with pref[c] <= p < pref[c+1]
+            while (a < b) { const int mid = (a + b + 1) >> 1; if (s_pref[wave][mid] <= p) a = mid; else b = mid - 1; }
+            const int row = s_lo[wave][a] + s_step[wave][a] * (p - s_pref[wave][a]);
+            apply_table(cells, A.nx, Xc + a, row, miss_table);
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-    sub_y += dy * last_pixel;
-    apply_table(cells, A.nx, cx, cy, miss_table);
-    if (up) { while (sub_y > den) { sub_y -= den; ++cy; apply_table(cells, A.nx, cx, cy, miss_table); } }
-    else { while (sub_y < 0) { sub_y += den; --cy; apply_table(cells, A.nx, cx, cy, miss_table); } }
 }
 __global__ __launch_bounds__(256) void kg_finish(unsigned short *cells, long long ncells, const int *__restrict__ bad)
 {
@@ -617,7 +643,7 @@ int rgrid_insert(rgrid_t *h, const float origin_xy[2], const float *returns_xy, 
     if (n_returns > 0)
         hipLaunchKernelGGL(kg_hits, dim3((n_returns + 255) / 256), dim3(256), 0, h->stream, A, h->d_ends, h->d_bad, h->d_cells, h->d_hit);
     if (insert_free_space && n > 0)
-        hipLaunchKernelGGL(kg_rays, dim3((n + 63) / 64), dim3(64), 0, h->stream, A, h->d_ends, h->d_bad, h->d_cells, h->d_miss);
+        hipLaunchKernelGGL(kg_rays, dim3((n + 3) / 4), dim3(256), 0, h->stream, A, h->d_ends, h->d_bad, h->d_cells, h->d_miss);
     const long long ncells = (long long)h->nx * h->ny;
     hipLaunchKernelGGL(kg_finish, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, h->stream, h->d_cells, ncells, h->d_bad);
     G_TRY(h, hipMemcpyAsync(h->h_count, h->d_bad, sizeof(int), hipMemcpyDeviceToHost, h->stream));

@@ -127,3 +127,32 @@ def test_insert_matches_oracle_cell_for_cell_and_feeds_the_matcher(gf, oracle_li
     score, pose, best, info = oracle_match(true + [0.1, 0.05, 0.05], pts, ref, res, max_xy)
     assert r.best == best and abs(r.score - score) <= 1.2e-7 * score
     assert np.abs(r.pose_estimate[:2] - true[:2]).max() <= 0.1
+
+
+def test_insert_exact_corner_crossings(gf, oracle_lib):
+    """Rays between cell CENTRES pass exactly through pixel corners (sub_y == denominator in RayToPixelMask): the
+    closed-form column ranges of kg_rays must make the reference's choice there.  Every (dx, dy) cell offset in a
+    25 x 25 neighbourhood, from three origins, against the oracle's sequential walk."""
+    from oracle.binding import oracle_insert
+    res, n = 0.1, 120
+    max_xy = (6.0, 6.0)
+    cells = np.zeros((n, n), np.uint16)
+    k = np.arange(-12, 13)
+    for origin_cell in ((60, 60), (30, 75), (90, 20)):
+        # centre of cell (row r, col c): x = max_x - (r + 0.5) res, y = max_y - (c + 0.5) res  (map_limits.h:57-62)
+        ox, oy = max_xy[0] - (origin_cell[0] + 0.5) * res, max_xy[1] - (origin_cell[1] + 0.5) * res
+        gx, gy = np.meshgrid(k, k, indexing="ij")
+        ret = np.stack([ox + gx.ravel() * res, oy + gy.ravel() * res], 1).astype(np.float32)
+        origin = np.array([ox, oy], np.float32)
+        for free in (True,):
+            gf.SetGrid(cells, res, max_xy)
+            gf.Insert(origin, ret[:300], ret[300:])
+            ref = oracle_insert(cells, res, max_xy, origin, ret[:300], ret[300:])
+            got = gf.GetGrid()
+            assert np.array_equal(got, ref), f"origin {origin_cell}: {np.count_nonzero(got != ref)} cells differ"
+    # half-cell offsets: rays that start / end exactly on pixel borders
+    ox, oy = max_xy[0] - 60 * res, max_xy[1] - 60 * res
+    ret = np.stack([ox + (gx.ravel() + 0.5) * res, oy + gy.ravel() * res], 1).astype(np.float32)
+    gf.SetGrid(cells, res, max_xy)
+    gf.Insert(np.array([ox, oy], np.float32), ret)
+    assert np.array_equal(gf.GetGrid(), oracle_insert(cells, res, max_xy, np.array([ox, oy], np.float32), ret))
