@@ -167,10 +167,11 @@ __global__ __launch_bounds__(128) void kg_score(MatchArgs A, const int2 *__restr
             bool in[KG_PF];
 #pragma unroll
             for (int u = 0; u < KG_PF; ++u) {
-                const int2 c = di[min(p0 + u, A.n - 1)];                           // uniform address: scalar load
+                const int2 c = di[p0 + u];                                         // uniform, contiguous: wide scalar loads (d_idx is padded by KG_PF)
                 const int cx = c.x + xo, cy = c.y + yo;
                 in[u] = cx >= 0 && cy >= 0 && cx < A.nx && cy < A.ny;
-                v[u] = in[u] ? cells[(size_t)A.nx * cy + cx] : (unsigned short)0;
+                v[u] = cells[in[u] ? A.nx * cy + cx : 0];                          // unconditional load (clamped address): a predicated
+                                                                                   // one is compiled to a branch + wait per point
             }
 #pragma unroll
             for (int u = 0; u < KG_PF; ++u)
@@ -491,7 +492,8 @@ int rgrid_create(int max_points, int max_cells, int max_candidates, int device, 
         G_TRY(h, hipMalloc(&h->d_in, 8 * np)); G_TRY(h, hipMalloc(&h->d_a, 8 * np)); G_TRY(h, hipMalloc(&h->d_b, 8 * np));
         G_TRY(h, hipMalloc(&h->d_key, 8 * np)); G_TRY(h, hipMalloc(&h->d_keep, np));
         G_TRY(h, hipMalloc(&h->d_cs, 8 * (size_t)max_candidates));
-        G_TRY(h, hipMalloc(&h->d_idx, 8 * np * 1024));                       // up to 1024 rotated scans of max_points points
+        G_TRY(h, hipMalloc(&h->d_idx, 8 * (np * 1024 + 64)));                // up to 1024 rotated scans of max_points points (+ read-ahead pad)
+        G_TRY(h, hipMemset(h->d_idx, 0, 8 * (np * 1024 + 64)));
         G_TRY(h, hipMalloc(&h->d_cells, 2 * (size_t)max_cells));
         G_TRY(h, hipMalloc(&h->d_hit, 2 * 32768)); G_TRY(h, hipMalloc(&h->d_miss, 2 * 32768));
         G_TRY(h, hipMalloc(&h->d_mis, 8 * np)); G_TRY(h, hipMalloc(&h->d_ends, 8 * (2 * np + 1))); G_TRY(h, hipMalloc(&h->d_bad, sizeof(int)));
