@@ -45,7 +45,7 @@ struct RekfCtl {
     // H row r packed in 64 bytes: { H(r,0), H(r,1), H(r,2), H(r,col), H(r,col+1), Q(r,r), (z - zhat)(r), 0 }
     // where col = 3 + 2*landmark for the rows of state matches (rows < 2*n_state); map and pose rows have no landmark block
     double hrow[REKF_MAX_ROWS][8];
-    // ---- hand-off between the multi-workgroup front kernel and k_record / k_gain ----
+    // ---- hand-off between the multi-workgroup front kernel and k_gather / k_gain ----
     double pose_pred[5];          // x, y, theta, cos(theta), sin(theta) after Predict (mu[0..2] is committed by k_gain)
     int pose_pending;
     int obs_kind[REKF_MAX_OBS_DEV];   // per observation: 0 map match, 1 state match, 2 new

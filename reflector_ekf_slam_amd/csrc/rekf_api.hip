@@ -311,7 +311,7 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     { ProfScope ps(h, REKF_K_GAIN); rekf_launch_gain(h->dev, n_ub, h->stream); }
     { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_downdate(h->dev, n_ub, h->stream); }
     // the state only grows: once a readback has shown it full, k_augment can never have work again
-    // (k_record drops the extra reflectors and raises REKF_FLAG_CAPACITY)
+    // (k_gather drops the extra reflectors and raises REKF_FLAG_CAPACITY)
     if (!h->full) { ProfScope ps(h, REKF_K_AUGMENT); rekf_launch_augment(h->dev, a, h->stream); }
     { ProfScope ps(h, REKF_K_EMPTY); }
     // the scan may have appended up to K reflectors; the exact n stays on the device
