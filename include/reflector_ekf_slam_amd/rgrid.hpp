@@ -62,10 +62,28 @@ public:
         chk(rgrid_get_grid(h_, out.data(), (long)out.size()), "GetGrid");
         return out;
     }
-    // ProbabilityGridRangeDataInserter2D::Insert  (probability_grid_range_data_inserter_2d.cc:103-114), no grid growth
+    // MapLimits of the resident grid
+    struct Limits { int num_x_cells, num_y_cells; double resolution, max_x, max_y; };
+    Limits GetLimits()
+    {
+        Limits l{};
+        chk(rgrid_get_limits(h_, &l.num_x_cells, &l.num_y_cells, &l.resolution, &l.max_x, &l.max_y), "GetLimits");
+        return l;
+    }
+    // GrowAsNeeded  (probability_grid_range_data_inserter_2d.cc:20-38 -> Grid2D::GrowLimits, grid_2d.cc:59-99)
+    void GrowAsNeeded(const std::array<float, 2> &origin, const Cloud &returns, const Cloud &misses)
+    {
+        chk(rgrid_grow_as_needed(h_, origin.data(), returns.data(), (int)(returns.size() / 2), misses.data(), (int)(misses.size() / 2)),
+            "GrowAsNeeded");
+        const Limits l = GetLimits();
+        ncells_ = (size_t)l.num_x_cells * l.num_y_cells;
+    }
+    // ProbabilityGridRangeDataInserter2D::Insert  (probability_grid_range_data_inserter_2d.cc:103-114); grows the grid
+    // first, as the reference's CastRays does (:45)
     void Insert(const std::array<float, 2> &origin, const Cloud &returns, const Cloud &misses, float hit_probability = 0.55f,
                 float miss_probability = 0.49f, bool insert_free_space = true)
     {
+        GrowAsNeeded(origin, returns, misses);
         chk(rgrid_insert(h_, origin.data(), returns.data(), (int)(returns.size() / 2), misses.data(), (int)(misses.size() / 2),
                          hit_probability, miss_probability, insert_free_space ? 1 : 0), "Insert");
     }

@@ -11,8 +11,10 @@
  *                                               (correlative_scan_matcher_2d.cc:10-123)
  *   mapping::ProbabilityGridRangeDataInserter2D::Insert
  *                                               src/mapping/probability_grid_range_data_inserter_2d.cc:40-114
- *                                               (map_builder.cc: range_data_inserter_->Insert), without grid growth
- * Not covered: CeresScanMatcher2D, grid growth (Grid2D::GrowLimits), submap handling, IO.
+ *                                               (map_builder.cc: range_data_inserter_->Insert); its GrowAsNeeded /
+ *                                               Grid2D::GrowLimits step (:20-38, src/mapping/grid_2d.cc:59-99) is
+ *                                               rgrid_grow_as_needed
+ * Not covered: CeresScanMatcher2D, submap handling, IO.
  *
  * Conventions as in rekf.h / rdet.h: opaque handles, plain pointers and sizes, 0 / negative error codes,
  * caller owns every buffer, a handle is not thread-safe, calls synchronise before returning.
@@ -26,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RGRID_ABI_VERSION 1
+#define RGRID_ABI_VERSION 2
 
 enum {
     RGRID_OK = 0,
@@ -75,10 +77,22 @@ int rgrid_set_grid(rgrid_t *h, const uint16_t *cells, int num_x_cells, int num_y
  * origin -> miss the miss table (RayToPixelMask, ray_to_pixel_mask.cc:17-168, sub-pixel scale 1000), a cell is
  * updated at most once per insertion and hits win (probability_grid.cc:38-53), then FinishUpdate (grid_2d.cc:20-29).
  * hit / miss probabilities: the reference's options are float (0.55 / 0.49, src/ros_node.cc:390-396).
- * GrowAsNeeded is the caller's: a point outside the grid returns RGRID_ERR_CAPACITY and leaves the grid untouched.
+ * GrowAsNeeded is a call of its own (rgrid_grow_as_needed, to be made first as CastRays does, :45): here a point
+ * outside the grid returns RGRID_ERR_CAPACITY and leaves the grid untouched.
  * The grid must be in the finished state (no cell with the update marker 0x8000 set). */
 int rgrid_insert(rgrid_t *h, const float origin_xy[2], const float *returns_xy, int n_returns, const float *misses_xy,
                  int n_misses, float hit_probability, float miss_probability, int insert_free_space);
+
+/* GrowAsNeeded (probability_grid_range_data_inserter_2d.cc:20-38): the float bounding box of origin, returns and
+ * misses, padded by 1e-6, and Grid2D::GrowLimits (src/mapping/grid_2d.cc:59-99) for its two corners -- the grid
+ * doubles in both directions (old cells in the middle, new cells unknown, max += resolution * (ny / 2, nx / 2))
+ * until it contains the corner.  RGRID_ERR_CAPACITY (grid untouched) if that needs more than max_cells cells;
+ * non-finite coordinates are RGRID_ERR_INVALID (the reference would loop forever). */
+int rgrid_grow_as_needed(rgrid_t *h, const float origin_xy[2], const float *returns_xy, int n_returns,
+                         const float *misses_xy, int n_misses);
+
+/* MapLimits of the resident grid (any pointer may be NULL). */
+int rgrid_get_limits(rgrid_t *h, int *num_x_cells, int *num_y_cells, double *resolution, double *max_x, double *max_y);
 
 /* Copy of the resident grid cells (num_x_cells * num_y_cells values, same layout as rgrid_set_grid). */
 int rgrid_get_grid(rgrid_t *h, uint16_t *cells, long cap);

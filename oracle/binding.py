@@ -318,3 +318,27 @@ def oracle_insert(cells, resolution, max_xy, origin, returns_xy, misses_xy=None,
     if rc != 0:
         raise ValueError("oracle insert: a point lies outside the grid (the caller must grow it first)")
     return g
+
+
+def oracle_grow(cells, resolution, max_xy, origin, returns_xy, misses_xy=None):
+    """GrowAsNeeded + Grid2D::GrowLimits (probability_grid_range_data_inserter_2d.cc:20-38, grid_2d.cc:59-99):
+    returns (grown uint16 grid, new max_xy, offset of the old cell (0, 0))."""
+    g = np.ascontiguousarray(cells, dtype=np.uint16)
+    ret = np.ascontiguousarray(returns_xy, dtype=np.float32).reshape(-1, 2)
+    mis = np.zeros((0, 2), np.float32) if misses_xy is None else np.ascontiguousarray(misses_xy, dtype=np.float32).reshape(-1, 2)
+    dims = (C.c_int * 2)(g.shape[1], g.shape[0])
+    mx = (C.c_double * 2)(float(max_xy[0]), float(max_xy[1]))
+    off = (C.c_int * 2)()
+    L = lib()
+    L.ogrid_grow_limits.restype = None
+    L.ogrid_grow_limits.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    org = np.ascontiguousarray(origin, dtype=np.float32)
+    r0 = ret.reshape(-1) if ret.size else np.zeros(1, np.float32)
+    m0 = mis.reshape(-1) if mis.size else np.zeros(1, np.float32)
+    L.ogrid_grow_limits(dims, float(resolution), mx, org.ctypes.data_as(C.c_void_p), r0.ctypes.data_as(C.c_void_p), ret.shape[0],
+                        m0.ctypes.data_as(C.c_void_p), mis.shape[0], off)
+    new = np.zeros((dims[1], dims[0]), np.uint16)
+    L.ogrid_grow_copy.restype = None
+    L.ogrid_grow_copy.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.ogrid_grow_copy(g.ctypes.data_as(C.c_void_p), g.shape[1], g.shape[0], new.ctypes.data_as(C.c_void_p), dims[0], dims[1], off)
+    return new, (mx[0], mx[1]), (off[0], off[1])

@@ -308,3 +308,41 @@ int ogrid_insert(uint16_t *cells, int nx, int ny, double resolution, double max_
     free(hit); free(miss); free(ends);
     return rc;
 }
+
+/* ------------------------------------------------------------------------------------------------------------
+ * GrowAsNeeded + Grid2D::GrowLimits (probability_grid_range_data_inserter_2d.cc:20-38, grid_2d.cc:59-99).
+ * Limits only: `dims` = (num_x_cells, num_y_cells) and `max_xy` are updated in place, `offset` receives where
+ * the old cell (0, 0) lands in the grown grid.  The cell copy is ogrid_grow_copy. */
+static void og_grow_point(int dims[2], double resolution, double max_xy[2], float px, float py, int offset[2])
+{
+    for (;;) {
+        const long ix = lround((max_xy[1] - (double)py) / resolution - 0.5);       /* MapLimits::GetCellIndex (map_limits.h:48-57) */
+        const long iy = lround((max_xy[0] - (double)px) / resolution - 0.5);
+        if (ix >= 0 && iy >= 0 && ix < dims[0] && iy < dims[1]) return;            /* Contains (map_limits.h:67-73) */
+        const int x_offset = dims[0] / 2, y_offset = dims[1] / 2;                  /* grid_2d.cc:66-67 */
+        max_xy[0] = max_xy[0] + resolution * (double)y_offset;                     /* (:70-71): max + res * (y_offset, x_offset) */
+        max_xy[1] = max_xy[1] + resolution * (double)x_offset;
+        dims[0] *= 2; dims[1] *= 2;
+        offset[0] += x_offset; offset[1] += y_offset;
+    }
+}
+void ogrid_grow_limits(int dims[2], double resolution, double max_xy[2], const float origin[2], const float *returns_xy,
+                       int n_ret, const float *misses_xy, int n_miss, int offset[2])
+{
+    float lo[2] = {origin[0], origin[1]}, hi[2] = {origin[0], origin[1]};          /* AlignedBox2f(origin), extend (:23-33) */
+    for (int i = 0; i < n_ret; ++i)
+        for (int k = 0; k < 2; ++k) { const float v = returns_xy[2 * i + k]; if (v < lo[k]) lo[k] = v; if (v > hi[k]) hi[k] = v; }
+    for (int i = 0; i < n_miss; ++i)
+        for (int k = 0; k < 2; ++k) { const float v = misses_xy[2 * i + k]; if (v < lo[k]) lo[k] = v; if (v > hi[k]) hi[k] = v; }
+    const float pad = 1e-6f;
+    offset[0] = offset[1] = 0;
+    og_grow_point(dims, resolution, max_xy, lo[0] - pad, lo[1] - pad, offset);     /* (:34-37) */
+    og_grow_point(dims, resolution, max_xy, hi[0] + pad, hi[1] + pad, offset);
+}
+/* new_cells (nnx * nny) = unknown everywhere, the old grid at `offset` (grid_2d.cc:81-91) */
+void ogrid_grow_copy(const uint16_t *cells, int nx, int ny, uint16_t *new_cells, int nnx, int nny, const int offset[2])
+{
+    memset(new_cells, 0, sizeof(uint16_t) * (size_t)nnx * nny);
+    for (int i = 0; i < ny; ++i)
+        for (int j = 0; j < nx; ++j) new_cells[(size_t)(offset[0] + j) + (size_t)(offset[1] + i) * nnx] = cells[j + (size_t)i * nx];
+}

@@ -343,6 +343,18 @@ __global__ __launch_bounds__(256) void kg_finish(unsigned short *cells, long lon
     if (k < ncells && cells[k] >= MARKER) cells[k] -= MARKER;                    // Grid2D::FinishUpdate (grid_2d.cc:20-29)
 }
 
+// Grid2D::GrowLimits' cell copy (grid_2d.cc:81-91): every cell of the grown grid in one pass -- the old value
+// inside the window at (off_x, off_y), unknown (0) outside
+__global__ __launch_bounds__(256) void kg_grow(const unsigned short *__restrict__ old_cells, int nx, int ny, unsigned short *__restrict__ new_cells,
+                                               int nnx, int nny, int off_x, int off_y)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= nnx) return;
+    const int ox = x - off_x, oy = y - off_y;
+    const bool in = ox >= 0 && oy >= 0 && ox < nx && oy < ny;
+    new_cells[(size_t)y * nnx + x] = in ? old_cells[(size_t)oy * nx + ox] : (unsigned short)0;
+}
+
 // ComputeLookupTableToApplyCorrespondenceCostOdds(Odds(probability)) (probability_values.cc:76-96), host float32
 void lookup_table(float probability, unsigned short *table)
 {
@@ -394,6 +406,7 @@ struct rgrid {
     int2 *d_key, *d_idx;
     unsigned char *d_keep;
     unsigned short *d_cells, *d_hit, *d_miss;   // grid; hit / miss lookup tables (uint16[32768])
+    unsigned short *d_cells2;                   // second grid buffer: target of a growth (then swapped with d_cells)
     float *d_mis;                               // misses of an insertion
     int2 *d_ends;
     int *d_bad;
@@ -494,7 +507,7 @@ int rgrid_create(int max_points, int max_cells, int max_candidates, int device, 
         G_TRY(h, hipMalloc(&h->d_cs, 8 * (size_t)max_candidates));
         G_TRY(h, hipMalloc(&h->d_idx, 8 * (np * 1024 + 64)));                // up to 1024 rotated scans of max_points points (+ read-ahead pad)
         G_TRY(h, hipMemset(h->d_idx, 0, 8 * (np * 1024 + 64)));
-        G_TRY(h, hipMalloc(&h->d_cells, 2 * (size_t)max_cells));
+        G_TRY(h, hipMalloc(&h->d_cells, 2 * (size_t)max_cells)); G_TRY(h, hipMalloc(&h->d_cells2, 2 * (size_t)max_cells));
         G_TRY(h, hipMalloc(&h->d_hit, 2 * 32768)); G_TRY(h, hipMalloc(&h->d_miss, 2 * 32768));
         G_TRY(h, hipMalloc(&h->d_mis, 8 * np)); G_TRY(h, hipMalloc(&h->d_ends, 8 * (2 * np + 1))); G_TRY(h, hipMalloc(&h->d_bad, sizeof(int)));
         G_TRY(h, hipMalloc(&h->d_bb, sizeof(BestRec) * 1024));                   // one record per rotated scan
@@ -515,7 +528,7 @@ void rgrid_destroy(rgrid_t *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->d_in, h->d_a, h->d_b, h->d_cs, h->d_key, h->d_idx, h->d_keep, h->d_cells, h->d_bb, h->d_best, h->d_count,
-                    h->d_hit, h->d_miss, h->d_mis, h->d_ends, h->d_bad};
+                    h->d_hit, h->d_miss, h->d_mis, h->d_ends, h->d_bad, h->d_cells2};
     for (void *p : ptrs) (void)hipFree(p);
     if (h->h_pts) (void)hipHostFree(h->h_pts);
     if (h->h_count) (void)hipHostFree(h->h_count);
@@ -651,6 +664,68 @@ int rgrid_insert(rgrid_t *h, const float origin_xy[2], const float *returns_xy, 
     G_TRY(h, hipMemcpyAsync(h->h_count, h->d_bad, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     G_TRY(h, hipStreamSynchronize(h->stream));
     return *h->h_count ? RGRID_ERR_CAPACITY : RGRID_OK;
+}
+
+namespace {
+// Grid2D::GrowLimits(point) on the limits only (grid_2d.cc:64-75,93); false if the grown grid exceeds `max_cells`
+bool grow_limits_for(float px, float py, double res, long long max_cells, int &nx, int &ny, double &max_x, double &max_y, int &off_x, int &off_y)
+{
+#pragma clang fp contract(off)
+    for (;;) {
+        const long ix = std::lround((max_y - (double)py) / res - 0.5), iy = std::lround((max_x - (double)px) / res - 0.5);
+        if (ix >= 0 && iy >= 0 && ix < nx && iy < ny) return true;
+        if (4ll * nx * ny > max_cells) return false;
+        const int xo = nx / 2, yo = ny / 2;
+        max_x = max_x + res * (double)yo;
+        max_y = max_y + res * (double)xo;
+        nx *= 2; ny *= 2; off_x += xo; off_y += yo;
+    }
+}
+}  // namespace
+
+int rgrid_grow_as_needed(rgrid_t *h, const float origin_xy[2], const float *returns_xy, int n_returns, const float *misses_xy,
+                         int n_misses)
+{
+    if (!h || !origin_xy || n_returns < 0 || n_misses < 0 || (n_returns > 0 && !returns_xy) || (n_misses > 0 && !misses_xy))
+        return RGRID_ERR_INVALID;
+    if (!h->have_grid) return RGRID_ERR_INVALID;
+    // Eigen::AlignedBox2f(origin).extend(every return and miss)  (probability_grid_range_data_inserter_2d.cc:23-33)
+    float lo[2] = {origin_xy[0], origin_xy[1]}, hi[2] = {origin_xy[0], origin_xy[1]};
+    auto extend = [&](const float *p, int n) {
+        for (int i = 0; i < 2 * n; ++i) {
+            const float v = p[i];
+            if (!std::isfinite(v)) return false;
+            if (v < lo[i & 1]) lo[i & 1] = v;
+            if (v > hi[i & 1]) hi[i & 1] = v;
+        }
+        return true;
+    };
+    if (!std::isfinite(lo[0]) || !std::isfinite(lo[1]) || !extend(returns_xy, n_returns) || !extend(misses_xy, n_misses)) return RGRID_ERR_INVALID;
+    const float pad = 1e-6f;                                                        // kPadding (:25)
+    int nx = h->nx, ny = h->ny, off_x = 0, off_y = 0;
+    double max_x = h->max_x, max_y = h->max_y;
+    if (!grow_limits_for(lo[0] - pad, lo[1] - pad, h->resolution, h->max_cells, nx, ny, max_x, max_y, off_x, off_y) ||
+        !grow_limits_for(hi[0] + pad, hi[1] + pad, h->resolution, h->max_cells, nx, ny, max_x, max_y, off_x, off_y))
+        return RGRID_ERR_CAPACITY;
+    if (nx == h->nx && ny == h->ny) return RGRID_OK;
+    G_TRY(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(kg_grow, dim3((nx + 255) / 256, ny), dim3(256), 0, h->stream, h->d_cells, h->nx, h->ny, h->d_cells2, nx, ny, off_x, off_y);
+    G_TRY(h, hipGetLastError());
+    G_TRY(h, hipStreamSynchronize(h->stream));
+    std::swap(h->d_cells, h->d_cells2);
+    h->nx = nx; h->ny = ny; h->max_x = max_x; h->max_y = max_y;
+    return RGRID_OK;
+}
+
+int rgrid_get_limits(rgrid_t *h, int *num_x_cells, int *num_y_cells, double *resolution, double *max_x, double *max_y)
+{
+    if (!h || !h->have_grid) return RGRID_ERR_INVALID;
+    if (num_x_cells) *num_x_cells = h->nx;
+    if (num_y_cells) *num_y_cells = h->ny;
+    if (resolution) *resolution = h->resolution;
+    if (max_x) *max_x = h->max_x;
+    if (max_y) *max_y = h->max_y;
+    return RGRID_OK;
 }
 
 int rgrid_get_grid(rgrid_t *h, uint16_t *cells, long cap)

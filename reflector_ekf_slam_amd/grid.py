@@ -51,6 +51,8 @@ def _lib_rgrid():
     L.rgrid_match.argtypes = [vp, C.POINTER(_MatchOptions), dp, vp, C.c_int, dp, dp, ip, ip]
     L.rgrid_insert.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int, C.c_float, C.c_float, C.c_int]
     L.rgrid_get_grid.argtypes = [vp, vp, C.c_long]
+    L.rgrid_grow_as_needed.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int]
+    L.rgrid_get_limits.argtypes = [vp, ip, ip, dp, dp, dp]
     _rgrid = L
     return L
 
@@ -148,9 +150,29 @@ class GridFrontEnd:
         self._chk(self._L.rgrid_set_grid(self._h, g.ctypes.data_as(C.c_void_p), g.shape[1], g.shape[0], float(resolution),
                                          float(max_xy[0]), float(max_xy[1])), "SetGrid")
 
-    # ProbabilityGridRangeDataInserter2D::Insert  (probability_grid_range_data_inserter_2d.cc:103-114), no grid growth
-    def Insert(self, origin_xy, returns_xy, misses_xy=None, options: "RangeDataInserterOptions | None" = None):
+    # GrowAsNeeded  (probability_grid_range_data_inserter_2d.cc:20-38 -> Grid2D::GrowLimits, grid_2d.cc:59-99)
+    def GrowAsNeeded(self, origin_xy, returns_xy, misses_xy=None):
+        org = (C.c_float * 2)(float(origin_xy[0]), float(origin_xy[1]))
+        ret = np.ascontiguousarray(returns_xy, dtype=np.float32).reshape(-1, 2)
+        mis = np.zeros((0, 2), np.float32) if misses_xy is None else np.ascontiguousarray(misses_xy, dtype=np.float32).reshape(-1, 2)
+        self._chk(self._L.rgrid_grow_as_needed(self._h, org, ret.ctypes.data_as(C.c_void_p) if ret.size else None, ret.shape[0],
+                                               mis.ctypes.data_as(C.c_void_p) if mis.size else None, mis.shape[0]), "GrowAsNeeded")
+        nx, ny, _, _, _ = self.GetLimits()
+        self._grid_shape = (ny, nx)
+
+    def GetLimits(self):
+        """MapLimits of the resident grid: (num_x_cells, num_y_cells, resolution, max_x, max_y)."""
+        nx, ny = C.c_int(), C.c_int()
+        res, mx, my = C.c_double(), C.c_double(), C.c_double()
+        self._chk(self._L.rgrid_get_limits(self._h, C.byref(nx), C.byref(ny), C.byref(res), C.byref(mx), C.byref(my)), "GetLimits")
+        return nx.value, ny.value, res.value, mx.value, my.value
+
+    # ProbabilityGridRangeDataInserter2D::Insert  (probability_grid_range_data_inserter_2d.cc:103-114); grow=True runs
+    # GrowAsNeeded first, as the reference's CastRays does (:45)
+    def Insert(self, origin_xy, returns_xy, misses_xy=None, options: "RangeDataInserterOptions | None" = None, grow: bool = True):
         o = options or RangeDataInserterOptions()
+        if grow:
+            self.GrowAsNeeded(origin_xy, returns_xy, misses_xy)
         org = (C.c_float * 2)(float(origin_xy[0]), float(origin_xy[1]))
         ret = np.ascontiguousarray(returns_xy, dtype=np.float32).reshape(-1, 2)
         mis = np.zeros((0, 2), np.float32) if misses_xy is None else np.ascontiguousarray(misses_xy, dtype=np.float32).reshape(-1, 2)

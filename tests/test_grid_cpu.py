@@ -144,3 +144,30 @@ def test_lookup_tables_and_hit_miss_semantics(oracle_lib):
     assert np.count_nonzero(out3) == 2
     with pytest.raises(ValueError):
         oracle_insert(cells, res, max_xy, origin, np.array([[9.0, 0.0]], np.float32))
+
+
+def test_grow_limits_doubles_around_the_old_grid(oracle_lib):
+    """Grid2D::GrowLimits (grid_2d.cc:59-99): the grid doubles until the padded bounding box is inside; the old cells
+    sit at the returned offset, everything else is unknown, and cell centres keep their world coordinates."""
+    from oracle.binding import oracle_grow
+    res = 0.1
+    rng = np.random.default_rng(2)
+    cells = rng.integers(1, 32767, (21, 30)).astype(np.uint16)                 # (num_y_cells, num_x_cells)
+    max_xy = (1.5, 2.0)
+    origin = np.array([0.2, 0.3], np.float32)
+    inside = np.array([[0.5, 0.5], [-0.3, 0.1]], np.float32)
+    g, mx, off = oracle_grow(cells, res, max_xy, origin, inside)
+    assert g.shape == cells.shape and mx == max_xy and off == (0, 0) and np.array_equal(g, cells)
+    far = np.array([[4.0, 0.0]], np.float32)                                   # beyond max_x: two doublings
+    g, mx, off = oracle_grow(cells, res, max_xy, origin, inside, far)
+    assert g.shape == (84, 120)
+    assert off == (15 + 30, 10 + 21)                                           # nx/2 + (2 nx)/2 , ny/2 + (2 ny)/2
+    assert mx[0] == pytest.approx(1.5 + res * (10 + 21)) and mx[1] == pytest.approx(2.0 + res * (15 + 30))
+    assert np.array_equal(g[off[1]:off[1] + 21, off[0]:off[0] + 30], cells)
+    assert np.count_nonzero(g) == np.count_nonzero(cells)
+    # the centre of old cell (row r, col c) is unchanged: x = max_x - (r + 0.5) res, y = max_y - (c + 0.5) res
+    assert mx[0] - (off[1] + 0.5) * res == pytest.approx(max_xy[0] - 0.5 * res)
+    assert mx[1] - (off[0] + 0.5) * res == pytest.approx(max_xy[1] - 0.5 * res)
+    # the far point is now inside
+    ix = round((mx[1] - 0.0) / res - 0.5); iy = round((mx[0] - 4.0) / res - 0.5)
+    assert 0 <= ix < g.shape[1] and 0 <= iy < g.shape[0]

@@ -118,6 +118,9 @@ def test_insert_matches_oracle_cell_for_cell_and_feeds_the_matcher(gf, oracle_li
     # a point outside the grid: error code, grid untouched
     from reflector_ekf_slam_amd.grid import RgridError
     with pytest.raises(RgridError) as e:
+        gf.Insert(np.zeros(2, np.float32), np.array([[100.0, 0.0]], np.float32), grow=False)
+    assert e.value.code == -4 and np.array_equal(gf.GetGrid(), ref)
+    with pytest.raises(RgridError) as e:                                      # growing that far exceeds max_cells
         gf.Insert(np.zeros(2, np.float32), np.array([[100.0, 0.0]], np.float32))
     assert e.value.code == -4 and np.array_equal(gf.GetGrid(), ref)
     # the matcher runs on the grid the inserter built
@@ -156,3 +159,39 @@ def test_insert_exact_corner_crossings(gf, oracle_lib):
     gf.SetGrid(cells, res, max_xy)
     gf.Insert(np.array([ox, oy], np.float32), ret)
     assert np.array_equal(gf.GetGrid(), oracle_insert(cells, res, max_xy, np.array([ox, oy], np.float32), ret))
+
+
+def test_grow_as_needed_matches_oracle_and_insert_continues_on_the_grown_grid(gf, oracle_lib):
+    """GrowAsNeeded / Grid2D::GrowLimits: a small map, scans that leave it on each side in turn (one, then two
+    doublings), odd cell counts; limits, offsets and every cell equal to the oracle's, then Insert on the grown grid."""
+    from oracle.binding import oracle_grow, oracle_insert
+    res = 0.05
+    for (ny, nx) in ((40, 40), (33, 57)):
+        max_xy = (1.0, 1.4)
+        rng = np.random.default_rng(nx)
+        ref = rng.integers(1, 32767, (ny, nx)).astype(np.uint16)
+        ref[rng.random((ny, nx)) < 0.3] = 0
+        gf.SetGrid(ref, res, max_xy)
+        origin = np.array([0.3, 0.5], np.float32)
+        for k, far in enumerate(((0.9, 0.8), (2.2, 0.4), (-1.9, 0.2), (0.1, -6.5), (0.2, 7.9))):
+            ang = rng.uniform(-math.pi, math.pi, 200)
+            rad = rng.uniform(0.05, 0.4, 200)
+            ret = np.stack([origin[0] + rad * np.cos(ang), origin[1] + rad * np.sin(ang)], 1).astype(np.float32)
+            ret[0] = far
+            mis = np.array([[far[0] * 0.5, far[1] * 0.5]], np.float32)
+            grown, new_max, off = oracle_grow(ref, res, max_xy, origin, ret, mis)
+            gf.GrowAsNeeded(origin, ret, mis)
+            lim = gf.GetLimits()
+            assert (lim[0], lim[1]) == (grown.shape[1], grown.shape[0]) and lim[3] == new_max[0] and lim[4] == new_max[1], (k, lim, grown.shape, new_max)
+            assert np.array_equal(gf.GetGrid(), grown)
+            if k == 0:
+                assert grown.shape == ref.shape                                # everything inside: no growth
+            gf.Insert(origin, ret, mis)                                        # grows again: a no-op now
+            ref = oracle_insert(grown, res, new_max, origin, ret, mis)
+            max_xy = new_max
+            assert np.array_equal(gf.GetGrid(), ref), f"case {k}: {np.count_nonzero(gf.GetGrid() != ref)} cells differ"
+        assert ref.shape[0] >= 8 * ny
+    from reflector_ekf_slam_amd.grid import RgridError
+    with pytest.raises(RgridError) as e:
+        gf.GrowAsNeeded(origin, np.array([[np.nan, 0.0]], np.float32))
+    assert e.value.code == -1
