@@ -96,6 +96,15 @@ public:
                         nullptr, nullptr), "Match");
         return score;
     }
+    // CeresScanMatcher2D::Match  (ceres_scan_matcher_2d.cc:26-62): returns the summary, pose in `pose_estimate`
+    rgrid_refine_summary RefineMatch(const rgrid_refine_options &opt, const std::array<double, 2> &target_translation,
+                                     const std::array<double, 3> &initial_pose, const Cloud &cloud, std::array<double, 3> &pose_estimate)
+    {
+        rgrid_refine_summary s{};
+        chk(rgrid_refine_match(h_, &opt, target_translation.data(), initial_pose.data(), cloud.data(), (int)(cloud.size() / 2),
+                               pose_estimate.data(), &s), "RefineMatch");
+        return s;
+    }
     rgrid_t *handle() { return h_; }
 
 private:

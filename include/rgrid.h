@@ -14,7 +14,11 @@
  *                                               (map_builder.cc: range_data_inserter_->Insert); its GrowAsNeeded /
  *                                               Grid2D::GrowLimits step (:20-38, src/mapping/grid_2d.cc:59-99) is
  *                                               rgrid_grow_as_needed
- * Not covered: CeresScanMatcher2D, submap handling, IO.
+ *   scan_matching::CeresScanMatcher2D::Match    src/scan_matching/ceres_scan_matcher_2d.cc:26-62 (map_builder.cc:49-53) with
+ *                                               occupied_space_cost_function_2d.cc:25-52 and the translation / rotation
+ *                                               delta functors -- the Ceres solve restated (Ceres is not a pinned
+ *                                               dependency of the reference: parity with a Ceres build is unpinned)
+ * Not covered: submap handling, IO.
  *
  * Conventions as in rekf.h / rdet.h: opaque handles, plain pointers and sizes, 0 / negative error codes,
  * caller owns every buffer, a handle is not thread-safe, calls synchronise before returning.
@@ -104,6 +108,35 @@ int rgrid_get_grid(rgrid_t *h, uint16_t *cells, long cap);
  * num_linear_perturbations, num_candidates). */
 int rgrid_match(rgrid_t *h, const rgrid_match_options *opt, const double initial_pose[3], const float *points_xy,
                 int n, double pose_estimate[3], double *score, int best3[3], int info3[3]);
+
+/* scan_matching::CeresScanMatcherOptions2D (ceres_scan_matcher_2d.h:16-22) + the two ceres::Solver::Options fields the
+ * reference sets (src/ros_node.cc:350-377): defaults 1.0, 0.1, 0.4, 100 iterations, non-monotonic steps on. */
+typedef struct rgrid_refine_options {
+    double occupied_space_weight;
+    double translation_weight;
+    double rotation_weight;
+    int max_num_iterations;
+    int use_nonmonotonic_steps;
+} rgrid_refine_options;
+
+/* What the reference reads of ceres::Solver::Summary, reduced: termination 0 = CONVERGENCE, 1 = NO_CONVERGENCE
+ * (iteration limit), 2 = FAILURE (five invalid steps in a row). */
+typedef struct rgrid_refine_summary {
+    double initial_cost;
+    double final_cost;
+    int iterations;
+    int termination;
+} rgrid_refine_summary;
+
+/* CeresScanMatcher2D::Match (ceres_scan_matcher_2d.cc:26-62) against the resident grid: minimises over (x, y, angle)
+ *   sum_i (occupied_space_weight / sqrt(n) * bicubic correspondence cost at point i)^2
+ *   + (translation_weight * (xy - target_translation))^2 + (rotation_weight * (angle - initial angle))^2
+ * with Ceres' Levenberg-Marquardt trust-region loop at its default tolerances.  initial_pose_estimate = the
+ * correlative matcher's answer, target_translation = the prediction's translation (map_builder.cc:49-53).
+ * summary may be NULL. */
+int rgrid_refine_match(rgrid_t *h, const rgrid_refine_options *opt, const double target_translation[2],
+                       const double initial_pose[3], const float *points_xy, int n, double pose_estimate[3],
+                       rgrid_refine_summary *summary);
 
 const char *rgrid_strerror(int code);
 const char *rgrid_last_hip_error(rgrid_t *h);

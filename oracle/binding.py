@@ -342,3 +342,27 @@ def oracle_grow(cells, resolution, max_xy, origin, returns_xy, misses_xy=None):
     L.ogrid_grow_copy.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.ogrid_grow_copy(g.ctypes.data_as(C.c_void_p), g.shape[1], g.shape[0], new.ctypes.data_as(C.c_void_p), dims[0], dims[1], off)
     return new, (mx[0], mx[1]), (off[0], off[1])
+
+
+def oracle_refine_match(target_translation, initial_pose, points_xy, cells, resolution, max_xy, occupied_space_weight=1.0,
+                        translation_weight=0.1, rotation_weight=0.4, max_num_iterations=100, use_nonmonotonic_steps=True):
+    """CeresScanMatcher2D::Match (ceres_scan_matcher_2d.cc:26-62; option defaults = src/ros_node.cc:350-377).
+    Returns (pose_estimate[3], summary dict)."""
+    g = np.ascontiguousarray(cells, dtype=np.uint16)
+    pts = np.ascontiguousarray(points_xy, dtype=np.float32).reshape(-1, 2)
+    L = lib()
+    L.ogrid_refine_match.restype = C.c_int
+    L.ogrid_refine_match.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double,
+                                     C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    opt = np.array([occupied_space_weight, translation_weight, rotation_weight, max_num_iterations, 1.0 if use_nonmonotonic_steps else 0.0])
+    tt = np.array(target_translation, dtype=np.float64)
+    ip = np.array(initial_pose, dtype=np.float64)
+    pose = np.zeros(3)
+    summ = np.zeros(4)
+    rc = L.ogrid_refine_match(opt.ctypes.data_as(C.c_void_p), tt.ctypes.data_as(C.c_void_p), ip.ctypes.data_as(C.c_void_p),
+                              pts.ctypes.data_as(C.c_void_p), pts.shape[0], g.ctypes.data_as(C.c_void_p), g.shape[1], g.shape[0],
+                              float(resolution), float(max_xy[0]), float(max_xy[1]), pose.ctypes.data_as(C.c_void_p),
+                              summ.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise ValueError("oracle refine: empty point cloud")
+    return pose, {"initial_cost": summ[0], "final_cost": summ[1], "iterations": int(summ[2]), "termination": int(summ[3])}

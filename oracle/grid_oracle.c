@@ -106,18 +106,18 @@ static void rotate_cloud(const float *in, int n, float c, float s, float *out)
 
 /* ---- probability of a cell value (probability_values.cc:11-20, probability_values.h:53-57,
  * probability_grid.cc:56-62): out of the grid -> kMinProbability; value 0 (unknown) -> 1 - kMaxCorrespondenceCost */
-float ogrid_value_to_probability(uint16_t value)
+static float og_value_to_cost(uint16_t value)                  /* ValueToCorrespondenceCost (probability_values.h:53-57) */
 {
     const float kMinProbability = 0.1f, kMaxProbability = 1.f - kMinProbability;
     const float lower = 1.f - kMaxProbability /* kMinCorrespondenceCost */, upper = 1.f - kMinProbability /* kMax... */;
     const uint16_t v = (uint16_t)(value & 32767u);             /* the table repeats for values with the update marker */
-    float cost;
-    if (v == 0) cost = upper;                                   /* unknown_result = kMaxCorrespondenceCost */
-    else {
-        const float kScale = (upper - lower) / (32768 - 2.f);
-        cost = v * kScale + (lower - kScale);
-    }
-    return 1.f - cost;                                          /* CorrespondenceCostToProbability */
+    if (v == 0) return upper;                                   /* unknown_result = kMaxCorrespondenceCost */
+    const float kScale = (upper - lower) / (32768 - 2.f);
+    return v * kScale + (lower - kScale);
+}
+float ogrid_value_to_probability(uint16_t value)
+{
+    return 1.f - og_value_to_cost(value);                       /* CorrespondenceCostToProbability */
 }
 
 typedef struct {
@@ -199,19 +199,12 @@ double ogrid_match(const ogrid_match_options *opt, const double initial_pose[3],
  *   RayToPixelMask        src/mapping/ray_to_pixel_mask.cc:17-168 (restated below with one column-walk for both slopes)
  *   ApplyLookupTable      src/mapping/probability_grid.cc:38-53   (a cell is updated at most once per insertion)
  *   FinishUpdate          src/mapping/grid_2d.cc:20-29
- * GrowAsNeeded / GrowLimits (:19-38, grid_2d.cc:47-98) is NOT restated: the caller hands in a grid that already
- * contains the origin and every end point; anything outside is an error (return -1) and leaves the grid untouched. */
+ * GrowAsNeeded / GrowLimits (:19-38, grid_2d.cc:47-98) is a step of its own (ogrid_grow_limits / ogrid_grow_copy below):
+ * here anything outside the grid is an error (return -1) and leaves the grid untouched. */
 #define OG_MARKER 32768u
 #define OG_SUBPIXEL 1000
 
-static float og_value_to_cost(int v)          /* kValueToCorrespondenceCost, v in [0, 32767] (probability_values.cc:11-20,46-51) */
-{
-    const float kMinProbability = 0.1f, kMaxProbability = 1.f - kMinProbability;
-    const float lower = 1.f - kMaxProbability, upper = 1.f - kMinProbability;
-    if (v == 0) return upper;
-    const float kScale = (upper - lower) / (32768 - 2.f);
-    return v * kScale + (lower - kScale);
-}
+/* kValueToCorrespondenceCost (probability_values.cc:11-20,46-51): og_value_to_cost above */
 static uint16_t og_cost_to_value(float c)     /* CorrespondenceCostToValue -> BoundedFloatToValue (probability_values.h:15-29,68-72) */
 {
     const float kMinProbability = 0.1f, kMaxProbability = 1.f - kMinProbability;
@@ -345,4 +338,176 @@ void ogrid_grow_copy(const uint16_t *cells, int nx, int ny, uint16_t *new_cells,
     memset(new_cells, 0, sizeof(uint16_t) * (size_t)nnx * nny);
     for (int i = 0; i < ny; ++i)
         for (int j = 0; j < nx; ++j) new_cells[(size_t)(offset[0] + j) + (size_t)(offset[1] + i) * nnx] = cells[j + (size_t)i * nx];
+}
+
+/* ------------------------------------------------------------------------------------------------------------
+ * CeresScanMatcher2D::Match (src/scan_matching/ceres_scan_matcher_2d.cc:26-62): three residual blocks on the pose
+ * (x, y, angle) --
+ *   occupied space (occupied_space_cost_function_2d.cc:25-52): per point, weight / sqrt(n) * the bicubic
+ *     interpolation of the correspondence cost at the point's (row, column) = ((max.x - wx) / res - 0.5,
+ *     (max.y - wy) / res - 0.5), both shifted by kPadding = INT_MAX / 4; outside the grid the cost is
+ *     kMaxCorrespondenceCost (:69-81)
+ *   translation delta (translation_delta_cost_functor_2d.h:24-29), rotation delta (rotation_delta_cost_functor_2d.h:24-28)
+ * minimised by ceres::Solve with the options of src/ros_node.cc:364-377 (DENSE_QR, use_nonmonotonic_steps,
+ * max_num_iterations 100; everything else Ceres' defaults).
+ *
+ * Ceres Solver is a third-party dependency that is absent here and un-pinned by the reference
+ * (CMakeLists.txt:34 `find_package(Ceres REQUIRED ...)`): PARITY UNPINNED.  What follows restates its published
+ * algorithm -- ceres::BiCubicInterpolator / CubicHermiteSpline (cubic_interpolation.h: Catmull-Rom, first along the
+ * columns of the four rows, then along the rows), automatic differentiation replaced by the analytic chain rule, and
+ * the Levenberg-Marquardt trust-region loop of trust_region_minimizer.cc / levenberg_marquardt_strategy.cc /
+ * trust_region_step_evaluator.cc (1.13 and later): Jacobi scaling 1 / (1 + ||column||) fixed at iteration 0, LM
+ * diagonal clamp(diag(J'J), 1e-6, 1e32) / radius, model cost change -(J d)'(r + J d / 2), parameter tolerance 1e-8,
+ * function tolerance 1e-6, gradient tolerance 1e-10, min relative decrease 1e-3, radius 1e4 .. 1e16 (min 1e-32),
+ * radius update r / max(1/3, 1 - (2 rho - 1)^3) on success and r / 2, / 4, ... on failure, Conn-Gould-Toint
+ * non-monotonic acceptance over 5 steps, the answer = the accepted iterate of least cost.  The 3-parameter damped
+ * least-squares step is solved through its normal equations (Cholesky) instead of a QR of the stacked Jacobian:
+ * the same minimiser up to rounding. */
+#define OG_PAD 536870911.0                                     /* kPadding = INT_MAX / 4 (:57) */
+typedef struct {
+    const uint16_t *cells; int nx, ny; double res, max_x, max_y;
+    const float *pts; int n;
+    double w_occ, w_t, w_r, tx, ty, angle0;
+} og_refine_ctx;
+
+static double og_cost_at(const og_refine_ctx *c, long row, long col)             /* GridArrayAdapter::GetValue (:69-81) */
+{
+    const long y = row - (long)OG_PAD, x = col - (long)OG_PAD;
+    if (x < 0 || y < 0 || x >= c->nx || y >= c->ny) return (double)0.9f;        /* kMaxCorrespondenceCost */
+    return (double)og_value_to_cost(c->cells[(size_t)c->nx * y + x]);
+}
+static void og_hermite(double p0, double p1, double p2, double p3, double x, double *f, double *dfdx)
+{
+    const double a = 0.5 * (-p0 + 3.0 * p1 - 3.0 * p2 + p3);
+    const double b = 0.5 * (2.0 * p0 - 5.0 * p1 + 4.0 * p2 - p3);
+    const double cc = 0.5 * (-p0 + p2);
+    const double d = p1;
+    if (f) *f = d + x * (cc + x * (b + x * a));
+    if (dfdx) *dfdx = cc + x * (2.0 * b + 3.0 * a * x);
+}
+/* cost = 1/2 |r|^2, g = J'r, H = J'J (upper triangle xx, xy, xt, yy, yt, tt) at pose p */
+static void og_refine_eval(const og_refine_ctx *c, const double p[3], double *cost, double g[3], double H[6])
+{
+    const double cs = cos(p[2]), sn = sin(p[2]);
+    const double scale = c->w_occ / sqrt((double)c->n);
+    double ss = 0.;
+    for (int k = 0; k < 3; ++k) g[k] = 0.;
+    for (int k = 0; k < 6; ++k) H[k] = 0.;
+    for (int i = 0; i < c->n; ++i) {
+        const double px = (double)c->pts[2 * i], py = (double)c->pts[2 * i + 1];
+        const double wx = cs * px - sn * py + p[0], wy = sn * px + cs * py + p[1];
+        const double dwx = -sn * px - cs * py, dwy = cs * px - sn * py;          /* d world / d angle */
+        const double r = (c->max_x - wx) / c->res - 0.5 + OG_PAD, q = (c->max_y - wy) / c->res - 0.5 + OG_PAD;
+        const double rf = floor(r), qf = floor(q);
+        const long row = (long)rf, col = (long)qf;
+        double f[4], dq[4];
+        for (int a = 0; a < 4; ++a)
+            og_hermite(og_cost_at(c, row - 1 + a, col - 1), og_cost_at(c, row - 1 + a, col), og_cost_at(c, row - 1 + a, col + 1),
+                       og_cost_at(c, row - 1 + a, col + 2), q - qf, &f[a], &dq[a]);
+        double v, dvdr, dvdq;
+        og_hermite(f[0], f[1], f[2], f[3], r - rf, &v, &dvdr);
+        og_hermite(dq[0], dq[1], dq[2], dq[3], r - rf, &dvdq, NULL);
+        const double res_i = scale * v;
+        const double ninv = -1.0 / c->res;                                       /* Jet / scalar multiplies by 1 / scalar (ceres/jet.h) */
+        const double J[3] = {scale * (dvdr * ninv), scale * (dvdq * ninv), scale * (dvdr * (dwx * ninv) + dvdq * (dwy * ninv))};
+        ss += res_i * res_i;
+        for (int k = 0; k < 3; ++k) g[k] += J[k] * res_i;
+        H[0] += J[0] * J[0]; H[1] += J[0] * J[1]; H[2] += J[0] * J[2]; H[3] += J[1] * J[1]; H[4] += J[1] * J[2]; H[5] += J[2] * J[2];
+    }
+    const double r0 = c->w_t * (p[0] - c->tx), r1 = c->w_t * (p[1] - c->ty), r2 = c->w_r * (p[2] - c->angle0);
+    ss += r0 * r0 + r1 * r1 + r2 * r2;
+    g[0] += c->w_t * r0; g[1] += c->w_t * r1; g[2] += c->w_r * r2;
+    H[0] += c->w_t * c->w_t; H[3] += c->w_t * c->w_t; H[5] += c->w_r * c->w_r;
+    *cost = 0.5 * ss;
+}
+/* (A) y = b for the symmetric positive definite 3x3 A (upper triangle); 0 on failure */
+static int og_chol3(const double A[6], const double b[3], double y[3])
+{
+    const double l00 = sqrt(A[0]);
+    if (!(l00 > 0.)) return 0;
+    const double l10 = A[1] / l00, l20 = A[2] / l00;
+    const double d1 = A[3] - l10 * l10;
+    if (!(d1 > 0.)) return 0;
+    const double l11 = sqrt(d1), l21 = (A[4] - l20 * l10) / l11;
+    const double d2 = A[5] - l20 * l20 - l21 * l21;
+    if (!(d2 > 0.)) return 0;
+    const double l22 = sqrt(d2);
+    const double z0 = b[0] / l00, z1 = (b[1] - l10 * z0) / l11, z2 = (b[2] - l20 * z0 - l21 * z1) / l22;
+    y[2] = z2 / l22; y[1] = (z1 - l21 * y[2]) / l11; y[0] = (z0 - l10 * y[1] - l20 * y[2]) / l00;
+    return isfinite(y[0]) && isfinite(y[1]) && isfinite(y[2]);
+}
+/* options = {occupied_space_weight, translation_weight, rotation_weight, max_num_iterations, use_nonmonotonic_steps};
+ * summary = {initial_cost, final_cost, iterations, termination (0 convergence, 1 no convergence, 2 failure)} */
+int ogrid_refine_match(const double options[5], const double target_translation[2], const double initial_pose[3],
+                       const float *points_xy, int n, const uint16_t *cells, int nx, int ny, double resolution, double max_x,
+                       double max_y, double pose_estimate[3], double summary[4])
+{
+    if (n <= 0) return -1;
+    og_refine_ctx c = {cells, nx, ny, resolution, max_x, max_y, points_xy, n, options[0], options[1], options[2],
+                       target_translation[0], target_translation[1], initial_pose[2]};
+    const int max_iter = (int)options[3], max_nonmono = options[4] != 0. ? 5 : 0;
+    double x[3] = {initial_pose[0], initial_pose[1], initial_pose[2]}, x_cost, g[3], H[6];
+    og_refine_eval(&c, x, &x_cost, g, H);                                       /* IterationZero */
+    double s[3] = {1. / (1. + sqrt(H[0])), 1. / (1. + sqrt(H[3])), 1. / (1. + sqrt(H[5]))};
+    double x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    double gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
+    double radius = 1e4, decrease = 2.;
+    double ev_min = x_cost, ev_cur = x_cost, ev_ref = x_cost, ev_cand = x_cost, acc_ref = 0., acc_cand = 0.;
+    int nonmono = 0, invalid = 0, iter = 0, successful = 1, termination = 1;
+    double best[3] = {x[0], x[1], x[2]}, min_cost = INFINITY;
+    summary[0] = x_cost;
+    for (;;) {
+        if (successful && x_cost < min_cost) { min_cost = x_cost; best[0] = x[0]; best[1] = x[1]; best[2] = x[2]; }
+        if (iter >= max_iter) { termination = 1; break; }
+        if (successful && gmax <= 1e-10) { termination = 0; break; }
+        if (radius < 1e-32) { termination = 0; break; }
+        ++iter;
+        /* LevenbergMarquardtStrategy::ComputeStep on the column-scaled Jacobian */
+        const double Hs[6] = {s[0] * H[0] * s[0], s[0] * H[1] * s[1], s[0] * H[2] * s[2], s[1] * H[3] * s[1], s[1] * H[4] * s[2], s[2] * H[5] * s[2]};
+        const double gs[3] = {s[0] * g[0], s[1] * g[1], s[2] * g[2]};
+        double A[6] = {Hs[0], Hs[1], Hs[2], Hs[3], Hs[4], Hs[5]}, y[3], step[3];
+        A[0] += fmin(fmax(Hs[0], 1e-6), 1e32) / radius; A[3] += fmin(fmax(Hs[3], 1e-6), 1e32) / radius; A[5] += fmin(fmax(Hs[5], 1e-6), 1e32) / radius;
+        double mcc = -1.;
+        if (og_chol3(A, gs, y)) {
+            for (int k = 0; k < 3; ++k) step[k] = -y[k];
+            const double Hd[3] = {Hs[0] * step[0] + Hs[1] * step[1] + Hs[2] * step[2], Hs[1] * step[0] + Hs[3] * step[1] + Hs[4] * step[2],
+                                  Hs[2] * step[0] + Hs[4] * step[1] + Hs[5] * step[2]};
+            mcc = -(step[0] * gs[0] + step[1] * gs[1] + step[2] * gs[2]) - 0.5 * (step[0] * Hd[0] + step[1] * Hd[1] + step[2] * Hd[2]);
+        }
+        if (!(mcc > 0.)) {                                                       /* HandleInvalidStep */
+            successful = 0;
+            if (++invalid >= 5) { termination = 2; break; }
+            radius /= decrease; decrease *= 2.;
+            continue;
+        }
+        invalid = 0;
+        const double xc[3] = {x[0] + step[0] * s[0], x[1] + step[1] * s[1], x[2] + step[2] * s[2]};
+        double c_cost, cg[3], cH[6];
+        og_refine_eval(&c, xc, &c_cost, cg, cH);
+        const double d0 = x[0] - xc[0], d1 = x[1] - xc[1], d2 = x[2] - xc[2];
+        if (sqrt(d0 * d0 + d1 * d1 + d2 * d2) <= 1e-8 * (x_norm + 1e-8)) { termination = 0; break; }      /* ParameterToleranceReached */
+        if (fabs(x_cost - c_cost) <= 1e-6 * x_cost) { termination = 0; break; }                            /* FunctionToleranceReached */
+        const double rho = fmax((ev_cur - c_cost) / mcc, (ev_ref - c_cost) / (acc_ref + mcc));             /* StepQuality */
+        if (rho > 1e-3) {                                                        /* HandleSuccessfulStep */
+            for (int k = 0; k < 3; ++k) { x[k] = xc[k]; g[k] = cg[k]; }
+            for (int k = 0; k < 6; ++k) H[k] = cH[k];
+            x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+            x_cost = c_cost;
+            gmax = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
+            successful = 1;
+            const double t = 2. * rho - 1.;
+            radius = fmin(1e16, radius / fmax(1. / 3., 1. - t * t * t));
+            decrease = 2.;
+            ev_cur = c_cost; acc_cand += mcc; acc_ref += mcc;                    /* TrustRegionStepEvaluator::StepAccepted */
+            if (ev_cur < ev_min) { ev_min = ev_cur; nonmono = 0; ev_cand = ev_cur; acc_cand = 0.; }
+            else { ++nonmono; if (ev_cur > ev_cand) { ev_cand = ev_cur; acc_cand = 0.; } }
+            if (nonmono == max_nonmono) { ev_ref = ev_cand; acc_ref = acc_cand; }
+        } else {                                                                 /* HandleUnsuccessfulStep */
+            successful = 0;
+            radius /= decrease; decrease *= 2.;
+        }
+    }
+    pose_estimate[0] = best[0]; pose_estimate[1] = best[1]; pose_estimate[2] = best[2];
+    summary[1] = min_cost; summary[2] = (double)iter; summary[3] = (double)termination;
+    return 0;
 }

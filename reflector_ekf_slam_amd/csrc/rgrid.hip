@@ -355,6 +355,245 @@ __global__ __launch_bounds__(256) void kg_grow(const unsigned short *__restrict_
     new_cells[(size_t)y * nnx + x] = in ? old_cells[(size_t)oy * nx + ox] : (unsigned short)0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// CeresScanMatcher2D::Match (src/scan_matching/ceres_scan_matcher_2d.cc:26-62) -- the whole Levenberg-Marquardt solve in
+// ONE workgroup: a 3-parameter problem whose only wide part is the sum over the points (a few hundred after the
+// adaptive voxel filter).  Every iteration the threads evaluate their points at the candidate pose (bicubic
+// interpolation of the correspondence cost, 16 cell reads, analytic chain rule instead of Ceres' jets) and reduce
+// 1/2|r|^2, J'r and J'J (10 doubles) through shuffles + LDS; thread 0 then runs the scalar trust-region logic on a
+// state that lives in LDS (so the kernel fits 1024 threads: one point per thread up to 1024 points) and publishes
+// the next candidate -- no host round trip, no second launch.
+// Ceres is not in the image and not pinned by the reference: the algorithm is restated from its published sources
+// (DESIGN.md 4b lists them); parity with a Ceres build is unpinned.
+struct RefineArgs {
+    int nx, ny, n, max_iter, max_nonmono;
+    double res, max_x, max_y, w_occ, w_t, w_r, tx, ty, x0, y0, a0;
+};
+struct RefineOut { double pose[3]; double initial_cost, final_cost; int iterations, termination; };
+struct RefineState {
+    double x[3], xc[3], g[3], H[6], s[3], best[3];
+    double x_cost, x_norm, gmax, radius, decrease, mcc, min_cost, initial_cost;
+    double ev_min, ev_cur, ev_ref, ev_cand, acc_ref, acc_cand;              // TrustRegionStepEvaluator
+    int nonmono, invalid, iter, termination, successful, done;
+};
+constexpr double REFINE_PAD = 536870911.0;                                      // kPadding = INT_MAX / 4 (occupied_space_cost_function_2d.cc:57)
+
+__device__ static inline float value_to_cost(unsigned v16)
+{
+#pragma clang fp contract(off)
+    const float kMinProbability = 0.1f, kMaxProbability = 1.f - kMinProbability;
+    const float lower = 1.f - kMaxProbability, upper = 1.f - kMinProbability;
+    const unsigned v = v16 & 32767u;
+    const float kScale = (upper - lower) / (32768 - 2.f);
+    const float c = (float)v * kScale + (lower - kScale);
+    return v == 0 ? upper : c;
+}
+__device__ static inline void hermite(double p0, double p1, double p2, double p3, double x, double &f, double &dfdx)
+{
+#pragma clang fp contract(off)
+    const double a = 0.5 * (-p0 + 3.0 * p1 - 3.0 * p2 + p3);                    // ceres::CubicHermiteSpline
+    const double b = 0.5 * (2.0 * p0 - 5.0 * p1 + 4.0 * p2 - p3);
+    const double c = 0.5 * (-p0 + p2);
+    f = p1 + x * (c + x * (b + x * a));
+    dfdx = c + x * (2.0 * b + 3.0 * a * x);
+}
+// Partial sums of this wave into part[wave][]: [0] = |r|^2, [1..3] = J'r, [4..9] = J'J (xx xy xt yy yt tt)
+__device__ static void refine_eval(const RefineArgs &A, const unsigned short *__restrict__ cells, const float *__restrict__ pts,
+                                   const double p0, const double p1, const double p2, double (*part)[10])
+{
+#pragma clang fp contract(off)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double sn, cs;
+    sincos(p2, &sn, &cs);
+    const double scale = A.w_occ / sqrt((double)A.n);
+    const double ninv = -1.0 / A.res;                                            // d(row) / d(world x): Jet / scalar = * (1 / scalar)
+    double acc[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[k] = 0.;
+    for (int i = tid; i < A.n; i += blockDim.x) {
+        const float2 pt = reinterpret_cast<const float2 *>(pts)[i];
+        const double px = (double)pt.x, py = (double)pt.y;
+        const double wx = cs * px - sn * py + p0, wy = sn * px + cs * py + p1;
+        const double dwx = -sn * px - cs * py, dwy = cs * px - sn * py;          // d world / d angle
+        const double r = (A.max_x - wx) / A.res - 0.5 + REFINE_PAD, q = (A.max_y - wy) / A.res - 0.5 + REFINE_PAD;
+        const double rf = floor(r), qf = floor(q);
+        // cell (x = col, y = row) of the interpolation's base corner, as int32 (clamped far outside the grid first)
+        const int row = (int)fmin(fmax(rf - REFINE_PAD, -8.), (double)A.ny + 8.), col = (int)fmin(fmax(qf - REFINE_PAD, -8.), (double)A.nx + 8.);
+        double f[4], dq[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            double v[4];
+            const int y = row - 1 + a;
+            const int yc = min(max(y, 0), A.ny - 1);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int x = col - 1 + b;
+                const bool in = x >= 0 && y >= 0 && x < A.nx && y < A.ny;        // GridArrayAdapter::GetValue (:69-81)
+                const float cv = value_to_cost(cells[A.nx * yc + min(max(x, 0), A.nx - 1)]);   // unconditional clamped load, select after
+                v[b] = (double)(in ? cv : 0.9f);
+            }
+            hermite(v[0], v[1], v[2], v[3], q - qf, f[a], dq[a]);
+        }
+        double val, dvdr, dvdq, unused;
+        hermite(f[0], f[1], f[2], f[3], r - rf, val, dvdr);
+        hermite(dq[0], dq[1], dq[2], dq[3], r - rf, dvdq, unused);
+        const double ri = scale * val;
+        const double J0 = scale * (dvdr * ninv), J1 = scale * (dvdq * ninv);
+        const double J2 = scale * (dvdr * (dwx * ninv) + dvdq * (dwy * ninv));
+        acc[0] += ri * ri;
+        acc[1] += J0 * ri; acc[2] += J1 * ri; acc[3] += J2 * ri;
+        acc[4] += J0 * J0; acc[5] += J0 * J1; acc[6] += J0 * J2; acc[7] += J1 * J1; acc[8] += J1 * J2; acc[9] += J2 * J2;
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        double v = acc[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        acc[k] = v;
+    }
+    if (lane == 0)
+        for (int k = 0; k < 10; ++k) part[wave][k] = acc[k];
+}
+__device__ static inline bool chol3(const double A[6], const double b[3], double y[3])
+{
+#pragma clang fp contract(off)
+    const double l00 = sqrt(A[0]);
+    if (!(l00 > 0.)) return false;
+    const double l10 = A[1] / l00, l20 = A[2] / l00;
+    const double d1 = A[3] - l10 * l10;
+    if (!(d1 > 0.)) return false;
+    const double l11 = sqrt(d1), l21 = (A[4] - l20 * l10) / l11;
+    const double d2 = A[5] - l20 * l20 - l21 * l21;
+    if (!(d2 > 0.)) return false;
+    const double l22 = sqrt(d2);
+    const double z0 = b[0] / l00, z1 = (b[1] - l10 * z0) / l11, z2 = (b[2] - l20 * z0 - l21 * z1) / l22;
+    y[2] = z2 / l22; y[1] = (z1 - l21 * y[2]) / l11; y[0] = (z0 - l10 * y[1] - l20 * y[2]) / l00;
+    return isfinite(y[0]) && isfinite(y[1]) && isfinite(y[2]);
+}
+// Thread 0: totals of an evaluation at pose p (the wave partials + the translation / rotation delta blocks,
+// translation_delta_cost_functor_2d.h:24-29, rotation_delta_cost_functor_2d.h:24-28)
+__device__ static void refine_totals(const RefineArgs &A, const double (*part)[10], int nw, const double p[3], double S[10])
+{
+#pragma clang fp contract(off)
+    for (int k = 0; k < 10; ++k) {
+        double v = 0.;
+        for (int w = 0; w < nw; ++w) v += part[w][k];
+        S[k] = v;
+    }
+    const double r0 = A.w_t * (p[0] - A.tx), r1 = A.w_t * (p[1] - A.ty), r2 = A.w_r * (p[2] - A.a0);
+    S[0] += r0 * r0 + r1 * r1 + r2 * r2;
+    S[1] += A.w_t * r0; S[2] += A.w_t * r1; S[3] += A.w_r * r2;
+    S[4] += A.w_t * A.w_t; S[7] += A.w_t * A.w_t; S[9] += A.w_r * A.w_r;
+}
+// Thread 0: TrustRegionMinimizer's loop head up to the next candidate -- FinalizeIterationAndCheckIfMinimizerCanContinue,
+// LevenbergMarquardtStrategy::ComputeStep on the column-scaled Jacobian (through the normal equations), the model cost
+// change; invalid steps shrink the radius and retry without a new evaluation.  Sets st.xc / st.mcc or st.done.
+__device__ static void refine_next_candidate(const RefineArgs &A, RefineState &st)
+{
+#pragma clang fp contract(off)
+    for (;;) {
+        if (st.successful && st.x_cost < st.min_cost) { st.min_cost = st.x_cost; st.best[0] = st.x[0]; st.best[1] = st.x[1]; st.best[2] = st.x[2]; }
+        if (st.iter >= A.max_iter) { st.termination = 1; st.done = 1; return; }
+        if (st.successful && st.gmax <= 1e-10) { st.termination = 0; st.done = 1; return; }
+        if (st.radius < 1e-32) { st.termination = 0; st.done = 1; return; }
+        ++st.iter;
+        const double s0 = st.s[0], s1 = st.s[1], s2 = st.s[2];
+        const double Hs[6] = {s0 * st.H[0] * s0, s0 * st.H[1] * s1, s0 * st.H[2] * s2, s1 * st.H[3] * s1, s1 * st.H[4] * s2, s2 * st.H[5] * s2};
+        const double gs[3] = {s0 * st.g[0], s1 * st.g[1], s2 * st.g[2]};
+        double M[6] = {Hs[0], Hs[1], Hs[2], Hs[3], Hs[4], Hs[5]}, y[3], step[3] = {0., 0., 0.};
+        M[0] += fmin(fmax(Hs[0], 1e-6), 1e32) / st.radius; M[3] += fmin(fmax(Hs[3], 1e-6), 1e32) / st.radius; M[5] += fmin(fmax(Hs[5], 1e-6), 1e32) / st.radius;
+        double mcc = -1.;
+        if (chol3(M, gs, y)) {
+            step[0] = -y[0]; step[1] = -y[1]; step[2] = -y[2];
+            const double Hd[3] = {Hs[0] * step[0] + Hs[1] * step[1] + Hs[2] * step[2], Hs[1] * step[0] + Hs[3] * step[1] + Hs[4] * step[2],
+                                  Hs[2] * step[0] + Hs[4] * step[1] + Hs[5] * step[2]};
+            mcc = -(step[0] * gs[0] + step[1] * gs[1] + step[2] * gs[2]) - 0.5 * (step[0] * Hd[0] + step[1] * Hd[1] + step[2] * Hd[2]);
+        }
+        if (!(mcc > 0.)) {                                                       // HandleInvalidStep
+            st.successful = 0;
+            if (++st.invalid >= 5) { st.termination = 2; st.done = 1; return; }
+            st.radius /= st.decrease; st.decrease *= 2.;
+            continue;
+        }
+        st.invalid = 0;
+        st.mcc = mcc;
+        st.xc[0] = st.x[0] + step[0] * s0; st.xc[1] = st.x[1] + step[1] * s1; st.xc[2] = st.x[2] + step[2] * s2;
+        return;
+    }
+}
+// Thread 0: the candidate's evaluation is in -- tolerances, step quality, accept / reject (HandleSuccessfulStep /
+// HandleUnsuccessfulStep, LevenbergMarquardtStrategy::StepAccepted / StepRejected, TrustRegionStepEvaluator)
+__device__ static void refine_judge(const RefineArgs &A, RefineState &st, const double S[10])
+{
+#pragma clang fp contract(off)
+    const double c_cost = 0.5 * S[0];
+    const double d0 = st.x[0] - st.xc[0], d1 = st.x[1] - st.xc[1], d2 = st.x[2] - st.xc[2];
+    if (sqrt(d0 * d0 + d1 * d1 + d2 * d2) <= 1e-8 * (st.x_norm + 1e-8)) { st.termination = 0; st.done = 1; return; }   // ParameterToleranceReached
+    if (fabs(st.x_cost - c_cost) <= 1e-6 * st.x_cost) { st.termination = 0; st.done = 1; return; }                      // FunctionToleranceReached
+    const double rho = fmax((st.ev_cur - c_cost) / st.mcc, (st.ev_ref - c_cost) / (st.acc_ref + st.mcc));               // StepQuality
+    if (rho > 1e-3) {
+        st.x[0] = st.xc[0]; st.x[1] = st.xc[1]; st.x[2] = st.xc[2];
+        st.g[0] = S[1]; st.g[1] = S[2]; st.g[2] = S[3];
+        for (int k = 0; k < 6; ++k) st.H[k] = S[4 + k];
+        st.x_norm = sqrt(st.x[0] * st.x[0] + st.x[1] * st.x[1] + st.x[2] * st.x[2]);
+        st.x_cost = c_cost;
+        st.gmax = fmax(fabs(S[1]), fmax(fabs(S[2]), fabs(S[3])));
+        st.successful = 1;
+        const double t = 2. * rho - 1.;
+        st.radius = fmin(1e16, st.radius / fmax(1. / 3., 1. - t * t * t));
+        st.decrease = 2.;
+        st.ev_cur = c_cost; st.acc_cand += st.mcc; st.acc_ref += st.mcc;
+        if (st.ev_cur < st.ev_min) { st.ev_min = st.ev_cur; st.nonmono = 0; st.ev_cand = st.ev_cur; st.acc_cand = 0.; }
+        else { ++st.nonmono; if (st.ev_cur > st.ev_cand) { st.ev_cand = st.ev_cur; st.acc_cand = 0.; } }
+        if (st.nonmono == A.max_nonmono) { st.ev_ref = st.ev_cand; st.acc_ref = st.acc_cand; }
+    } else {
+        st.successful = 0;
+        st.radius /= st.decrease; st.decrease *= 2.;
+    }
+}
+__global__ __launch_bounds__(1024) void kg_refine(RefineArgs A, const unsigned short *__restrict__ cells, const float *__restrict__ pts,
+                                                  RefineOut *__restrict__ out)
+{
+#pragma clang fp contract(off)
+    __shared__ double part[16][10];
+    __shared__ RefineState st;
+    const int nw = blockDim.x >> 6;
+    refine_eval(A, cells, pts, A.x0, A.y0, A.a0, part);                          // IterationZero
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double S[10];
+        const double x[3] = {A.x0, A.y0, A.a0};
+        refine_totals(A, part, nw, x, S);
+        for (int k = 0; k < 3; ++k) { st.x[k] = st.xc[k] = st.best[k] = x[k]; st.g[k] = S[1 + k]; }
+        for (int k = 0; k < 6; ++k) st.H[k] = S[4 + k];
+        st.s[0] = 1. / (1. + sqrt(S[4])); st.s[1] = 1. / (1. + sqrt(S[7])); st.s[2] = 1. / (1. + sqrt(S[9]));   // Jacobi scaling, fixed
+        st.x_cost = st.initial_cost = 0.5 * S[0];
+        st.x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+        st.gmax = fmax(fabs(S[1]), fmax(fabs(S[2]), fabs(S[3])));
+        st.radius = 1e4; st.decrease = 2.; st.mcc = 0.; st.min_cost = INFINITY;
+        st.ev_min = st.ev_cur = st.ev_ref = st.ev_cand = st.x_cost; st.acc_ref = st.acc_cand = 0.;
+        st.nonmono = st.invalid = st.iter = 0; st.termination = 1; st.successful = 1; st.done = 0;
+        refine_next_candidate(A, st);
+    }
+    __syncthreads();
+    while (!st.done) {
+        const double c0 = st.xc[0], c1 = st.xc[1], c2 = st.xc[2];
+        refine_eval(A, cells, pts, c0, c1, c2, part);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double S[10];
+            const double xc[3] = {c0, c1, c2};
+            refine_totals(A, part, nw, xc, S);
+            refine_judge(A, st, S);
+            if (!st.done) refine_next_candidate(A, st);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out->pose[0] = st.best[0]; out->pose[1] = st.best[1]; out->pose[2] = st.best[2];
+        out->initial_cost = st.initial_cost; out->final_cost = st.min_cost; out->iterations = st.iter; out->termination = st.termination;
+    }
+}
+
 // ComputeLookupTableToApplyCorrespondenceCostOdds(Odds(probability)) (probability_values.cc:76-96), host float32
 void lookup_table(float probability, unsigned short *table)
 {
@@ -417,6 +656,7 @@ struct rgrid {
     float *h_pts;
     int *h_count;
     BestRec *h_best;
+    RefineOut *d_refine, *h_refine;
     // grid
     int nx, ny;
     double resolution, max_x, max_y;
@@ -473,6 +713,37 @@ extern "C" {
 
 int rgrid_abi_version(void) { return RGRID_ABI_VERSION; }
 
+int rgrid_refine_match(rgrid_t *h, const rgrid_refine_options *opt, const double target_translation[2], const double initial_pose[3],
+                       const float *points_xy, int n, double pose_estimate[3], rgrid_refine_summary *summary)
+{
+    if (!h || !opt || !target_translation || !initial_pose || !pose_estimate || n < 0 || (n > 0 && !points_xy)) return RGRID_ERR_INVALID;
+    if (!h->have_grid || !(opt->occupied_space_weight > 0.) || !(opt->translation_weight > 0.) || !(opt->rotation_weight > 0.) ||
+        opt->max_num_iterations < 0)
+        return RGRID_ERR_INVALID;                                                // the reference CHECK_GTs the weights (ceres_scan_matcher_2d.cc:37,47,52)
+    if (n == 0) return RGRID_ERR_EMPTY;
+    if (n > h->max_points) return RGRID_ERR_CAPACITY;
+    G_TRY(h, hipSetDevice(h->device));
+    std::memcpy(h->h_pts, points_xy, sizeof(float) * 2 * (size_t)n);
+    G_TRY(h, hipMemcpyAsync(h->d_in, h->h_pts, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, h->stream));
+    RefineArgs A;
+    A.nx = h->nx; A.ny = h->ny; A.n = n; A.max_iter = opt->max_num_iterations; A.max_nonmono = opt->use_nonmonotonic_steps ? 5 : 0;
+    A.res = h->resolution; A.max_x = h->max_x; A.max_y = h->max_y;
+    A.w_occ = opt->occupied_space_weight; A.w_t = opt->translation_weight; A.w_r = opt->rotation_weight;
+    A.tx = target_translation[0]; A.ty = target_translation[1];
+    A.x0 = initial_pose[0]; A.y0 = initial_pose[1]; A.a0 = initial_pose[2];
+    const int threads = std::min(1024, ((n + 63) / 64) * 64);                      // no idle waves in the barriers and the partial sums
+    hipLaunchKernelGGL(kg_refine, dim3(1), dim3(threads), 0, h->stream, A, h->d_cells, h->d_in, h->d_refine);
+    G_TRY(h, hipGetLastError());
+    G_TRY(h, hipMemcpyAsync(h->h_refine, h->d_refine, sizeof(RefineOut), hipMemcpyDeviceToHost, h->stream));
+    G_TRY(h, hipStreamSynchronize(h->stream));
+    pose_estimate[0] = h->h_refine->pose[0]; pose_estimate[1] = h->h_refine->pose[1]; pose_estimate[2] = h->h_refine->pose[2];
+    if (summary) {
+        summary->initial_cost = h->h_refine->initial_cost; summary->final_cost = h->h_refine->final_cost;
+        summary->iterations = h->h_refine->iterations; summary->termination = h->h_refine->termination;
+    }
+    return RGRID_OK;
+}
+
 const char *rgrid_strerror(int code)
 {
     switch (code) {
@@ -515,6 +786,7 @@ int rgrid_create(int max_points, int max_cells, int max_candidates, int device, 
         G_TRY(h, hipMalloc(&h->d_count, sizeof(int)));
         G_TRY(h, hipHostMalloc(&h->h_pts, 8 * np)); G_TRY(h, hipHostMalloc(&h->h_count, sizeof(int)));
         G_TRY(h, hipHostMalloc(&h->h_best, sizeof(BestRec)));
+        G_TRY(h, hipMalloc(&h->d_refine, sizeof(RefineOut))); G_TRY(h, hipHostMalloc(&h->h_refine, sizeof(RefineOut)));
         return RGRID_OK;
     }();
     if (rc != RGRID_OK) { std::fprintf(stderr, "rgrid_create: %s\n", h->hip_error.c_str()); rgrid_destroy(h); return rc; }
@@ -528,11 +800,12 @@ void rgrid_destroy(rgrid_t *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->d_in, h->d_a, h->d_b, h->d_cs, h->d_key, h->d_idx, h->d_keep, h->d_cells, h->d_bb, h->d_best, h->d_count,
-                    h->d_hit, h->d_miss, h->d_mis, h->d_ends, h->d_bad, h->d_cells2};
+                    h->d_hit, h->d_miss, h->d_mis, h->d_ends, h->d_bad, h->d_cells2, h->d_refine};
     for (void *p : ptrs) (void)hipFree(p);
     if (h->h_pts) (void)hipHostFree(h->h_pts);
     if (h->h_count) (void)hipHostFree(h->h_count);
     if (h->h_best) (void)hipHostFree(h->h_best);
+    if (h->h_refine) (void)hipHostFree(h->h_refine);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }

@@ -53,8 +53,38 @@ def _lib_rgrid():
     L.rgrid_get_grid.argtypes = [vp, vp, C.c_long]
     L.rgrid_grow_as_needed.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int]
     L.rgrid_get_limits.argtypes = [vp, ip, ip, dp, dp, dp]
+    L.rgrid_refine_match.argtypes = [vp, C.POINTER(_RefineOptions), dp, dp, vp, C.c_int, dp, C.POINTER(_RefineSummary)]
     _rgrid = L
     return L
+
+
+class _RefineOptions(C.Structure):
+    _fields_ = [("occupied_space_weight", C.c_double), ("translation_weight", C.c_double), ("rotation_weight", C.c_double),
+                ("max_num_iterations", C.c_int), ("use_nonmonotonic_steps", C.c_int)]
+
+
+class _RefineSummary(C.Structure):
+    _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("iterations", C.c_int), ("termination", C.c_int)]
+
+
+@dataclass
+class CeresScanMatcherOptions2D:
+    """scan_matching::CeresScanMatcherOptions2D (ceres_scan_matcher_2d.h:16-22) with the two ceres::Solver::Options
+    fields the reference sets; defaults = src/ros_node.cc:350-377."""
+    occupied_space_weight: float = 1.0
+    translation_weight: float = 0.1
+    rotation_weight: float = 0.4
+    max_num_iterations: int = 100
+    use_nonmonotonic_steps: bool = True
+
+
+@dataclass
+class RefineResult:
+    pose_estimate: np.ndarray
+    initial_cost: float
+    final_cost: float
+    iterations: int
+    termination: int            # 0 CONVERGENCE, 1 NO_CONVERGENCE, 2 FAILURE
 
 
 @dataclass
@@ -180,6 +210,21 @@ class GridFrontEnd:
                                        mis.ctypes.data_as(C.c_void_p) if mis.size else None, mis.shape[0],
                                        float(o.hit_probability), float(o.miss_probability), 1 if o.insert_free_space else 0),
                   "Insert")
+
+    # CeresScanMatcher2D::Match  (ceres_scan_matcher_2d.cc:26-62)
+    def RefineMatch(self, target_translation, initial_pose_estimate, point_cloud,
+                    options: "CeresScanMatcherOptions2D | None" = None) -> "RefineResult":
+        o = options or CeresScanMatcherOptions2D()
+        co = _RefineOptions(o.occupied_space_weight, o.translation_weight, o.rotation_weight, int(o.max_num_iterations),
+                            1 if o.use_nonmonotonic_steps else 0)
+        pts = np.ascontiguousarray(point_cloud, dtype=np.float32).reshape(-1, 2)
+        tt = (C.c_double * 2)(float(target_translation[0]), float(target_translation[1]))
+        ip = (C.c_double * 3)(*[float(v) for v in initial_pose_estimate])
+        pe = (C.c_double * 3)()
+        sm = _RefineSummary()
+        self._chk(self._L.rgrid_refine_match(self._h, C.byref(co), tt, ip, pts.ctypes.data_as(C.c_void_p), pts.shape[0], pe,
+                                             C.byref(sm)), "RefineMatch")
+        return RefineResult(np.array(pe[:]), sm.initial_cost, sm.final_cost, sm.iterations, sm.termination)
 
     def GetGrid(self) -> np.ndarray:
         out = np.zeros(self._grid_shape, np.uint16)

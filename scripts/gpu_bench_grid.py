@@ -4,7 +4,7 @@ import json, math, sys, time
 sys.path.insert(0, ".")
 import numpy as np
 from reflector_ekf_slam_amd.grid import GridFrontEnd, AdaptiveVoxelFilterOptions
-from oracle.binding import oracle_voxel_filter, oracle_adaptive_voxel_filter, oracle_match, oracle_insert
+from oracle.binding import oracle_voxel_filter, oracle_adaptive_voxel_filter, oracle_match, oracle_insert, oracle_refine_match
 from tests.grid_cases import room_grid, scan_of
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
@@ -43,6 +43,14 @@ for name, pts in (("match_adaptive_cloud", av), ("match_full_cloud", vf)):
                       "same_candidate": bool(r.best == best), "score": r.score, "score_rel_diff": abs(r.score - sc) / sc,
                       "gpu_call_us": round(timeit(lambda: g.Match(init, pts), reps), 1),
                       "cpu_oracle_us": round(timeit(lambda: oracle_match(init, pts, cells, 0.05, max_xy), 3), 1)}))
+    if name == "match_adaptive_cloud":                      # the refinement MapBuilder::ScanMatch runs next (map_builder.cc:49-53)
+        rr = g.RefineMatch(init[:2], r.pose_estimate, pts)
+        po, so = oracle_refine_match(init[:2], r.pose_estimate, pts, cells, 0.05, max_xy)
+        print(json.dumps({"case": "refine_match_adaptive_cloud", "points": int(pts.shape[0]), "iterations": rr.iterations,
+                          "oracle_iterations": so["iterations"], "pose_abs_diff_vs_oracle": float(np.abs(rr.pose_estimate - po).max()),
+                          "pose_error_m_rad": [float(v) for v in np.abs(rr.pose_estimate - true)],
+                          "gpu_call_us": round(timeit(lambda: g.RefineMatch(init[:2], r.pose_estimate, pts), reps), 1),
+                          "cpu_oracle_us": round(timeit(lambda: oracle_refine_match(init[:2], r.pose_estimate, pts, cells, 0.05, max_xy), 10), 1)}))
 
 # range-data insertion into an initially unknown grid (3600 returns + 100 misses), then cell-for-cell comparison
 pose = (0.5, 0.3, 0.2)

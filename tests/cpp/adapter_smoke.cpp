@@ -47,6 +47,14 @@ int main(int argc, char **)
             std::printf("FAIL grid known=%zu thin=%zu score=%f pe=%f\n", known, thin.size() / 2, score, pe[0]);
             return 1;
         }
+        rgrid_refine_options ro{1.0, 0.1, 0.4, 100, 1};
+        std::array<double, 3> refined{};
+        const rgrid_refine_summary rs = gf.RefineMatch(ro, {0.1, 0.05}, pe, thin, refined);
+        const auto lim = gf.GetLimits();
+        if (rs.termination != 0 || !(rs.final_cost <= rs.initial_cost) || std::fabs(refined[0]) > 0.06 || lim.num_x_cells != 200) {
+            std::printf("FAIL refine term=%d cost %f -> %f x=%f nx=%d\n", rs.termination, rs.initial_cost, rs.final_cost, refined[0], lim.num_x_cells);
+            return 1;
+        }
     }
     std::printf("ADAPTER_OK n=%zu t=%.2f x=%.6f\n", mu.size(), t, mu[0]);
     return 0;

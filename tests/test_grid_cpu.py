@@ -171,3 +171,79 @@ def test_grow_limits_doubles_around_the_old_grid(oracle_lib):
     # the far point is now inside
     ix = round((mx[1] - 0.0) / res - 0.5); iy = round((mx[0] - 4.0) / res - 0.5)
     assert 0 <= ix < g.shape[1] and 0 <= iy < g.shape[0]
+
+
+def _np_refine_residuals(p, pts, cells, res, max_xy, target, angle0, w=(1.0, 0.1, 0.4)):
+    """Independent numpy statement of the three residual blocks (vectorised Catmull-Rom bicubic)."""
+    ny, nx = cells.shape
+    v = (cells & 32767).astype(np.float32)
+    one, kmin = np.float32(1), np.float32(0.1)                                  # float32 constants as the reference forms them
+    upper, lower = one - kmin, one - (one - kmin)
+    kscale = (upper - lower) / np.float32(32766)
+    cost = np.where(v == 0, upper, v * kscale + (lower - kscale)).astype(np.float64)
+    c, s = math.cos(p[2]), math.sin(p[2])
+    wx = c * pts[:, 0] - s * pts[:, 1] + p[0]
+    wy = s * pts[:, 0] + c * pts[:, 1] + p[1]
+    pad = float(2147483647 // 4)                                               # kPadding: costs ~1e-7 cell of resolution
+    r = (max_xy[0] - wx) / res - 0.5 + pad
+    q = (max_xy[1] - wy) / res - 0.5 + pad
+    fr, fq = r - np.floor(r), q - np.floor(q)
+    r0, q0 = (np.floor(r) - pad).astype(int), (np.floor(q) - pad).astype(int)
+
+    def at(row, col):
+        ok = (row >= 0) & (col >= 0) & (row < ny) & (col < nx)
+        return np.where(ok, cost[np.clip(row, 0, ny - 1), np.clip(col, 0, nx - 1)], float(upper))
+
+    def spline(p0, p1, p2, p3, x):
+        a = 0.5 * (-p0 + 3 * p1 - 3 * p2 + p3)
+        b = 0.5 * (2 * p0 - 5 * p1 + 4 * p2 - p3)
+        cc = 0.5 * (-p0 + p2)
+        return p1 + x * (cc + x * (b + x * a))
+
+    rows = [spline(at(r0 - 1 + a, q0 - 1), at(r0 - 1 + a, q0), at(r0 - 1 + a, q0 + 1), at(r0 - 1 + a, q0 + 2), fq) for a in range(4)]
+    f = spline(rows[0], rows[1], rows[2], rows[3], fr)
+    return np.concatenate([w[0] / math.sqrt(len(pts)) * f, [w[1] * (p[0] - target[0]), w[1] * (p[1] - target[1]), w[2] * (p[2] - angle0)]])
+
+
+def test_refine_match_restatement_against_scipy_least_squares(oracle_lib):
+    """CeresScanMatcher2D::Match restated (Ceres is absent: parity unpinned).  Cross-checks: the oracle's cost at the
+    start equals an independent numpy statement of the residuals; its answer is a local minimum of that cost and agrees
+    with scipy's trust-region least-squares solver started from the same point; it pulls a perturbed pose back."""
+    from scipy.optimize import least_squares
+    from oracle.binding import oracle_insert, oracle_refine_match
+    _, max_xy, occ = room_grid()
+    res = 0.05
+    cells = np.zeros((480, 480), np.uint16)
+    for k, pose in enumerate(((0.0, 0.0, 0.0), (1.0, -0.5, 0.7), (-1.5, 0.8, -1.2))):
+        loc = scan_of(occ, pose, n_points=1200, seed=60 + k)
+        c, s = math.cos(pose[2]), math.sin(pose[2])
+        world = np.stack([pose[0] + c * loc[:, 0] - s * loc[:, 1], pose[1] + s * loc[:, 0] + c * loc[:, 1]], 1).astype(np.float32)
+        cells = oracle_insert(cells, res, max_xy, np.array(pose[:2], np.float32), world)
+    true = np.array([0.3, -0.2, 0.25])
+    pts = scan_of(occ, true, n_points=500, seed=91).astype(np.float32)
+    from oracle.binding import oracle_match
+    prediction = true + [-0.06, 0.05, -0.03]                                   # more than a cell away: the correlative matcher first,
+    _, coarse, _, _ = oracle_match(prediction, pts, cells, res, max_xy)        # as MapBuilder::ScanMatch does (map_builder.cc:43-55)
+    for start, target in ((true + [0.04, -0.03, 0.02], None), (np.array(coarse), prediction[:2]), (true, None)):
+        target = start[:2] if target is None else target
+        pose, summ = oracle_refine_match(target, start, pts, cells, res, max_xy)
+        r0 = _np_refine_residuals(start, pts.astype(np.float64), cells, res, max_xy, target, start[2])
+        assert summ["initial_cost"] == pytest.approx(0.5 * float(r0 @ r0), rel=1e-12)
+        assert summ["termination"] == 0 and 1 <= summ["iterations"] < 100
+        assert summ["final_cost"] <= summ["initial_cost"]
+        rf = _np_refine_residuals(pose, pts.astype(np.float64), cells, res, max_xy, target, start[2])
+        assert summ["final_cost"] == pytest.approx(0.5 * float(rf @ rf), rel=1e-12)
+        sol = least_squares(_np_refine_residuals, start, args=(pts.astype(np.float64), cells, res, max_xy, target, start[2]),
+                            method="lm", xtol=1e-10, ftol=1e-10, gtol=1e-10, diff_step=1e-4)   # finite differences must step over
+        scipy_cost = 0.5 * float(sol.fun @ sol.fun)                                   # the kPadding quantisation of the coordinates
+        assert abs(scipy_cost - summ["final_cost"]) <= 2e-3 * scipy_cost             # function_tolerance 1e-6 stops a little short
+        assert np.abs(pose - sol.x).max() < 5e-3
+        assert np.abs(pose[:2] - true[:2]).max() < 0.03 and abs(pose[2] - true[2]) < 0.01
+    # monotonic steps, a hard iteration cap, heavier priors
+    p1, s1 = oracle_refine_match(target, true + [0.05, 0.05, 0.03], pts, cells, res, max_xy, use_nonmonotonic_steps=False)
+    assert s1["termination"] == 0 and np.abs(p1[:2] - true[:2]).max() < 0.03
+    p2, s2 = oracle_refine_match(target, true + [0.05, 0.05, 0.03], pts, cells, res, max_xy, max_num_iterations=1)
+    assert s2["termination"] == 1 and s2["iterations"] == 1
+    p3, s3 = oracle_refine_match(true[:2] + [0.05, 0.05], true + [0.05, 0.05, 0.03], pts, cells, res, max_xy,
+                                 translation_weight=1e3, rotation_weight=1e3)
+    assert np.abs(p3 - (true + [0.05, 0.05, 0.03])).max() < 1e-3                       # the priors pin the pose

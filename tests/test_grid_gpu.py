@@ -195,3 +195,47 @@ def test_grow_as_needed_matches_oracle_and_insert_continues_on_the_grown_grid(gf
     with pytest.raises(RgridError) as e:
         gf.GrowAsNeeded(origin, np.array([[np.nan, 0.0]], np.float32))
     assert e.value.code == -1
+
+
+def test_refine_match_follows_the_oracle_iterate_for_iterate(gf, oracle_lib):
+    """CeresScanMatcher2D::Match restated: the one-workgroup LM solve against the oracle's -- same number of iterations,
+    same termination, pose equal to 1e-8 (measured: <= 3e-11; the reductions run in another order; the trust-region decisions do not flip).
+    The map is built by the inserter, the start pose comes from the correlative matcher, as in MapBuilder::ScanMatch."""
+    from oracle.binding import oracle_insert, oracle_refine_match
+    from reflector_ekf_slam_amd.grid import CeresScanMatcherOptions2D
+    _, max_xy, occ = room_grid()
+    res = 0.05
+    cells = np.zeros((480, 480), np.uint16)
+    for k, pose in enumerate(((0.0, 0.0, 0.0), (1.0, -0.5, 0.7), (-1.5, 0.8, -1.2))):
+        loc = scan_of(occ, pose, n_points=1200, seed=60 + k)
+        c, s = math.cos(pose[2]), math.sin(pose[2])
+        world = np.stack([pose[0] + c * loc[:, 0] - s * loc[:, 1], pose[1] + s * loc[:, 0] + c * loc[:, 1]], 1).astype(np.float32)
+        cells = oracle_insert(cells, res, max_xy, np.array(pose[:2], np.float32), world)
+    gf.SetGrid(cells, res, max_xy)
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        true = np.array([rng.uniform(-1.5, 1.5), rng.uniform(-1.0, 1.0), rng.uniform(-3.0, 3.0)])
+        pts = scan_of(occ, true, n_points=(3, 64, 500, 700, 2400, 5000)[trial], seed=100 + trial).astype(np.float32)
+        prediction = true + rng.uniform(-1, 1, 3) * [0.08, 0.08, 0.04]
+        coarse = gf.Match(prediction, pts).pose_estimate
+        for opt in (CeresScanMatcherOptions2D(), CeresScanMatcherOptions2D(2.0, 10.0, 40.0, 100, False), CeresScanMatcherOptions2D(max_num_iterations=3)):
+            r = gf.RefineMatch(prediction[:2], coarse, pts, opt)
+            pose, summ = oracle_refine_match(prediction[:2], coarse, pts, cells, res, max_xy, opt.occupied_space_weight, opt.translation_weight,
+                                             opt.rotation_weight, opt.max_num_iterations, opt.use_nonmonotonic_steps)
+            assert (r.iterations, r.termination) == (summ["iterations"], summ["termination"]), (trial, opt, r, summ)
+            tol = 1e-8 if len(pts) >= 64 else 1e-5       # 3 points: a nearly flat valley, 70+ iterations, rounding is amplified
+            assert np.abs(r.pose_estimate - pose).max() < tol, (trial, r.pose_estimate - pose)
+            assert r.initial_cost == pytest.approx(summ["initial_cost"], rel=1e-12) and r.final_cost == pytest.approx(summ["final_cost"], rel=tol)
+            assert r.final_cost <= r.initial_cost
+        if len(pts) >= 500:
+            r = gf.RefineMatch(prediction[:2], coarse, pts)
+            assert np.abs(r.pose_estimate[:2] - true[:2]).max() < 0.03 and abs(r.pose_estimate[2] - true[2]) < 0.01
+    # a cloud entirely outside the grid: every cell reads kMaxCorrespondenceCost, the gradient of the occupied-space term is 0
+    far = np.array([[500.0, 500.0], [501.0, 500.0]], np.float32)
+    r = gf.RefineMatch([0.0, 0.0], [0.0, 0.0, 0.0], far)
+    pose, summ = oracle_refine_match([0.0, 0.0], [0.0, 0.0, 0.0], far, cells, res, max_xy)
+    assert (r.iterations, r.termination) == (summ["iterations"], summ["termination"]) and np.abs(r.pose_estimate - pose).max() < 1e-12
+    from reflector_ekf_slam_amd.grid import RgridError
+    with pytest.raises(RgridError) as e:
+        gf.RefineMatch([0, 0], [0, 0, 0], np.zeros((0, 2), np.float32))
+    assert e.value.code == -6
