@@ -105,6 +105,20 @@ public:
                                pose_estimate.data(), &s), "RefineMatch");
         return s;
     }
+    // ProbabilityGrid::DrawToSubmapTexture  (probability_grid.cc:86-131): (value, alpha) bytes of the known-cells window
+    struct Texture { std::vector<uint8_t> cells; int offset_x, offset_y, width, height; double slice_max_x, slice_max_y; };
+    Texture DrawTexture()
+    {
+        Texture t;
+        t.cells.resize(2 * ncells_);
+        int box[4];
+        double sm[2];
+        chk(rgrid_draw_texture(h_, t.cells.data(), (long)t.cells.size(), box, sm), "DrawTexture");
+        t.offset_x = box[0]; t.offset_y = box[1]; t.width = box[2]; t.height = box[3];
+        t.slice_max_x = sm[0]; t.slice_max_y = sm[1];
+        t.cells.resize(2 * (size_t)t.width * t.height);
+        return t;
+    }
     rgrid_t *handle() { return h_; }
 
 private:

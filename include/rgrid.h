@@ -18,7 +18,11 @@
  *                                               occupied_space_cost_function_2d.cc:25-52 and the translation / rotation
  *                                               delta functors -- the Ceres solve restated (Ceres is not a pinned
  *                                               dependency of the reference: parity with a Ceres build is unpinned)
- * Not covered: submap handling, IO.
+ *   mapping::ProbabilityGrid::DrawToSubmapTexture
+ *                                               src/mapping/probability_grid.cc:86-131 (Submap2D::GetMapTextureData,
+ *                                               MapBuilder::ToSubmapTexture, map_builder.cc:128-134) without the gzip
+ *                                               container
+ * Not covered: Submap2D::Finish / ComputeCroppedGrid (never called by the reference's node), IO.
  *
  * Conventions as in rekf.h / rdet.h: opaque handles, plain pointers and sizes, 0 / negative error codes,
  * caller owns every buffer, a handle is not thread-safe, calls synchronise before returning.
@@ -108,6 +112,13 @@ int rgrid_get_grid(rgrid_t *h, uint16_t *cells, long cap);
  * num_linear_perturbations, num_candidates). */
 int rgrid_match(rgrid_t *h, const rgrid_match_options *opt, const double initial_pose[3], const float *points_xy,
                 int n, double pose_estimate[3], double *score, int best3[3], int info3[3]);
+
+/* ProbabilityGrid::DrawToSubmapTexture (probability_grid.cc:86-131): the resident grid cropped to the bounding box of its
+ * known cells, two bytes per cell (value, alpha), x fastest -- the string the reference gzips into SubmapTexture::cells.
+ * box = (offset_x, offset_y, width, height) in cells; slice_max = limits.max - resolution * (offset_y, offset_x), the
+ * translation of SubmapTexture::slice_pose before local_pose^-1 is applied (:122-126).  cells needs
+ * 2 * width * height bytes (at most 2 * num_x_cells * num_y_cells); RGRID_ERR_BUFFER reports the box it would need. */
+int rgrid_draw_texture(rgrid_t *h, uint8_t *cells, long cap, int box[4], double slice_max[2]);
 
 /* scan_matching::CeresScanMatcherOptions2D (ceres_scan_matcher_2d.h:16-22) + the two ceres::Solver::Options fields the
  * reference sets (src/ros_node.cc:350-377): defaults 1.0, 0.1, 0.4, 100 iterations, non-monotonic steps on. */

@@ -366,3 +366,19 @@ def oracle_refine_match(target_translation, initial_pose, points_xy, cells, reso
     if rc != 0:
         raise ValueError("oracle refine: empty point cloud")
     return pose, {"initial_cost": summ[0], "final_cost": summ[1], "iterations": int(summ[2]), "termination": int(summ[3])}
+
+
+def oracle_draw_texture(cells, resolution, max_xy):
+    """ProbabilityGrid::DrawToSubmapTexture (probability_grid.cc:86-131) without gzip:
+    returns (uint8 array (height, width, 2), box (offset_x, offset_y, width, height), slice_max (x, y))."""
+    g = np.ascontiguousarray(cells, dtype=np.uint16)
+    out = np.zeros(2 * g.size + 2, np.uint8)
+    box = (C.c_int * 4)()
+    sm = (C.c_double * 2)()
+    L = lib()
+    L.ogrid_draw_texture.restype = C.c_long
+    L.ogrid_draw_texture.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
+    nb = L.ogrid_draw_texture(g.ctypes.data_as(C.c_void_p), g.shape[1], g.shape[0], float(resolution), float(max_xy[0]), float(max_xy[1]),
+                              out.ctypes.data_as(C.c_void_p), out.size, box, sm)
+    assert nb == 2 * box[2] * box[3]
+    return out[:nb].reshape(box[3], box[2], 2).copy(), tuple(box[:]), (sm[0], sm[1])

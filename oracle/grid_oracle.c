@@ -511,3 +511,41 @@ int ogrid_refine_match(const double options[5], const double target_translation[
     summary[1] = min_cost; summary[2] = (double)iter; summary[3] = (double)termination;
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------------------
+ * ProbabilityGrid::DrawToSubmapTexture (src/mapping/probability_grid.cc:86-131) without the gzip container:
+ * the grid cropped to the bounding box of its known cells (Grid2D::ComputeCroppedLimits, grid_2d.cc:36-48 -- the
+ * box ApplyLookupTable keeps is the box of the cells that are not 0), two bytes per cell in x-fastest order
+ * (xy_index.h:45-60): (value, alpha) from 128 - ProbabilityToLogOddsInteger(probability) (submaps.h:22-41).
+ * box = (offset_x, offset_y, width, height); slice_max = limits.max - resolution * (offset_y, offset_x) (:122-123).
+ * Returns the number of bytes written (2 * width * height), or -1 if `cap` is too small. */
+static void og_texture_bytes(uint16_t v, uint8_t out[2])
+{
+    if (v == 0) { out[0] = 0; out[1] = 0; return; }                             /* unknown (:97-102) */
+    const float kMinP = 0.1f, kMaxP = 1.f - kMinP;
+    const float kMaxLogOdds = logf(kMaxP / (1.f - kMaxP)), kMinLogOdds = logf(kMinP / (1.f - kMinP));
+    const float p = 1.f - og_value_to_cost(v);                                  /* GetProbability (:57-63) */
+    const float logit = logf(p / (1.f - p));
+    const int li = (int)lroundf((logit - kMinLogOdds) * 254.f / (kMaxLogOdds - kMinLogOdds)) + 1;
+    const int delta = 128 - li;
+    const uint8_t alpha = (uint8_t)(delta > 0 ? 0 : -delta), value = (uint8_t)(delta > 0 ? delta : 0);
+    out[0] = value;
+    out[1] = (value || alpha) ? alpha : 1;
+}
+long ogrid_draw_texture(const uint16_t *cells, int nx, int ny, double resolution, double max_x, double max_y, uint8_t *out,
+                        long cap, int box[4], double slice_max[2])
+{
+    int x0 = nx, y0 = ny, x1 = -1, y1 = -1;
+    for (int y = 0; y < ny; ++y)
+        for (int x = 0; x < nx; ++x)
+            if (cells[(size_t)nx * y + x] != 0) { if (x < x0) x0 = x; if (x > x1) x1 = x; if (y < y0) y0 = y; if (y > y1) y1 = y; }
+    if (x1 < 0) { x0 = y0 = 0; x1 = y1 = 0; }                                   /* empty box: offset 0, CellLimits(1, 1) (grid_2d.cc:39-44) */
+    const int w = x1 - x0 + 1, hgt = y1 - y0 + 1;
+    box[0] = x0; box[1] = y0; box[2] = w; box[3] = hgt;
+    slice_max[0] = max_x - resolution * y0;
+    slice_max[1] = max_y - resolution * x0;
+    if (2l * w * hgt > cap) return -1;
+    for (int y = 0; y < hgt; ++y)
+        for (int x = 0; x < w; ++x) og_texture_bytes(cells[(size_t)nx * (y0 + y) + (x0 + x)], out + 2 * ((size_t)w * y + x));
+    return 2l * w * hgt;
+}

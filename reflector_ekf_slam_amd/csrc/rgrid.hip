@@ -21,6 +21,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -594,6 +595,50 @@ __global__ __launch_bounds__(1024) void kg_refine(RefineArgs A, const unsigned s
     }
 }
 
+// ProbabilityGrid::DrawToSubmapTexture (probability_grid.cc:86-131): bounding box of the known cells
+// (Grid2D::ComputeCroppedLimits -- the box ApplyLookupTable keeps is the box of the cells that are not 0) ...
+__global__ __launch_bounds__(256) void kg_known_box(const unsigned short *__restrict__ cells, int nx, int ny, int *__restrict__ box)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const bool known = x < nx && cells[(size_t)nx * y + x] != 0;
+    const unsigned long long m = __ballot(known);
+    if (m == 0) return;
+    if ((threadIdx.x & 63) == 0) {                                               // one lane per wave: its lanes' x range, the row
+        const int base = blockIdx.x * 256 + (threadIdx.x & ~63);
+        atomicMin(&box[0], base + __ffsll((long long)m) - 1);
+        atomicMax(&box[2], base + 63 - __clzll((long long)m));
+        atomicMin(&box[1], y);
+        atomicMax(&box[3], y);
+    }
+}
+// ... and two bytes (value, alpha) per cell of that window, x fastest, through a 32768-entry table of byte pairs
+__global__ __launch_bounds__(256) void kg_texture(const unsigned short *__restrict__ cells, int nx, int x0, int y0, int w,
+                                                  const unsigned short *__restrict__ table, unsigned short *__restrict__ out)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x < w) out[(size_t)w * y + x] = table[cells[(size_t)nx * (y0 + y) + (x0 + x)] & 32767u];
+}
+
+// (value, alpha) of every cell value: 128 - ProbabilityToLogOddsInteger(GetProbability) (probability_grid.cc:97-114,
+// submaps.h:22-41), host float32 with the same libm a CPU build uses; entry = value | alpha << 8
+void texture_table(unsigned short *table)
+{
+#pragma clang fp contract(off)
+    const float kMinP = 0.1f, kMaxP = 1.f - kMinP;
+    const float kMaxLogOdds = std::log(kMaxP / (1.f - kMaxP)), kMinLogOdds = std::log(kMinP / (1.f - kMinP));
+    const float lower = 1.f - kMaxP, upper = 1.f - kMinP, kScale = (upper - lower) / (32768 - 2.f);
+    table[0] = 0;                                                                // unknown: (0, 0)
+    for (int v = 1; v < 32768; ++v) {
+        const float cost = (float)v * kScale + (lower - kScale);
+        const float p = 1.f - cost;
+        const float logit = std::log(p / (1.f - p));
+        const int li = (int)std::lround((logit - kMinLogOdds) * 254.f / (kMaxLogOdds - kMinLogOdds)) + 1;
+        const int delta = 128 - li;
+        const unsigned alpha = (unsigned)(delta > 0 ? 0 : -delta) & 255u, value = (unsigned)(delta > 0 ? delta : 0) & 255u;
+        table[v] = (unsigned short)(value | ((value || alpha) ? alpha : 1u) << 8);
+    }
+}
+
 // ComputeLookupTableToApplyCorrespondenceCostOdds(Odds(probability)) (probability_values.cc:76-96), host float32
 void lookup_table(float probability, unsigned short *table)
 {
@@ -645,7 +690,9 @@ struct rgrid {
     int2 *d_key, *d_idx;
     unsigned char *d_keep;
     unsigned short *d_cells, *d_hit, *d_miss;   // grid; hit / miss lookup tables (uint16[32768])
-    unsigned short *d_cells2;                   // second grid buffer: target of a growth (then swapped with d_cells)
+    unsigned short *d_cells2;                   // second grid buffer: target of a growth (then swapped with d_cells), texture staging
+    unsigned short *d_tex;                      // (value, alpha) table of the texture export, built on first use
+    int *d_box, *h_box;
     float *d_mis;                               // misses of an insertion
     int2 *d_ends;
     int *d_bad;
@@ -712,6 +759,35 @@ int download_points(rgrid_t *h, const float *d_src, int m, float *out_xy, int ou
 extern "C" {
 
 int rgrid_abi_version(void) { return RGRID_ABI_VERSION; }
+
+int rgrid_draw_texture(rgrid_t *h, uint8_t *cells, long cap, int box[4], double slice_max[2])
+{
+    if (!h || !cells || !box || !slice_max || !h->have_grid) return RGRID_ERR_INVALID;
+    G_TRY(h, hipSetDevice(h->device));
+    if (!h->d_tex) {
+        std::vector<unsigned short> t(32768);
+        texture_table(t.data());
+        G_TRY(h, hipMalloc(&h->d_tex, 2 * 32768));
+        G_TRY(h, hipMemcpy(h->d_tex, t.data(), 2 * 32768, hipMemcpyHostToDevice));
+    }
+    h->h_box[0] = h->h_box[1] = INT_MAX; h->h_box[2] = h->h_box[3] = -1;
+    G_TRY(h, hipMemcpyAsync(h->d_box, h->h_box, 4 * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(kg_known_box, dim3((h->nx + 255) / 256, h->ny), dim3(256), 0, h->stream, h->d_cells, h->nx, h->ny, h->d_box);
+    G_TRY(h, hipMemcpyAsync(h->h_box, h->d_box, 4 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    G_TRY(h, hipStreamSynchronize(h->stream));
+    int x0 = h->h_box[0], y0 = h->h_box[1], x1 = h->h_box[2], y1 = h->h_box[3];
+    if (x1 < 0) { x0 = y0 = 0; x1 = y1 = 0; }                                     // nothing known: offset 0, CellLimits(1, 1) (grid_2d.cc:39-44)
+    const int w = x1 - x0 + 1, hh = y1 - y0 + 1;
+    box[0] = x0; box[1] = y0; box[2] = w; box[3] = hh;
+    slice_max[0] = h->max_x - h->resolution * y0;                                // (:122-123)
+    slice_max[1] = h->max_y - h->resolution * x0;
+    if (2l * w * hh > cap) return RGRID_ERR_BUFFER;
+    hipLaunchKernelGGL(kg_texture, dim3((w + 255) / 256, hh), dim3(256), 0, h->stream, h->d_cells, h->nx, x0, y0, w, h->d_tex, h->d_cells2);
+    G_TRY(h, hipGetLastError());
+    G_TRY(h, hipMemcpyAsync(cells, h->d_cells2, 2 * (size_t)w * hh, hipMemcpyDeviceToHost, h->stream));
+    G_TRY(h, hipStreamSynchronize(h->stream));
+    return RGRID_OK;
+}
 
 int rgrid_refine_match(rgrid_t *h, const rgrid_refine_options *opt, const double target_translation[2], const double initial_pose[3],
                        const float *points_xy, int n, double pose_estimate[3], rgrid_refine_summary *summary)
@@ -786,6 +862,7 @@ int rgrid_create(int max_points, int max_cells, int max_candidates, int device, 
         G_TRY(h, hipMalloc(&h->d_count, sizeof(int)));
         G_TRY(h, hipHostMalloc(&h->h_pts, 8 * np)); G_TRY(h, hipHostMalloc(&h->h_count, sizeof(int)));
         G_TRY(h, hipHostMalloc(&h->h_best, sizeof(BestRec)));
+        G_TRY(h, hipMalloc(&h->d_box, 4 * sizeof(int))); G_TRY(h, hipHostMalloc(&h->h_box, 4 * sizeof(int)));
         G_TRY(h, hipMalloc(&h->d_refine, sizeof(RefineOut))); G_TRY(h, hipHostMalloc(&h->h_refine, sizeof(RefineOut)));
         return RGRID_OK;
     }();
@@ -800,12 +877,13 @@ void rgrid_destroy(rgrid_t *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->d_in, h->d_a, h->d_b, h->d_cs, h->d_key, h->d_idx, h->d_keep, h->d_cells, h->d_bb, h->d_best, h->d_count,
-                    h->d_hit, h->d_miss, h->d_mis, h->d_ends, h->d_bad, h->d_cells2, h->d_refine};
+                    h->d_hit, h->d_miss, h->d_mis, h->d_ends, h->d_bad, h->d_cells2, h->d_refine, h->d_tex, h->d_box};
     for (void *p : ptrs) (void)hipFree(p);
     if (h->h_pts) (void)hipHostFree(h->h_pts);
     if (h->h_count) (void)hipHostFree(h->h_count);
     if (h->h_best) (void)hipHostFree(h->h_best);
     if (h->h_refine) (void)hipHostFree(h->h_refine);
+    if (h->h_box) (void)hipHostFree(h->h_box);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }

@@ -53,6 +53,7 @@ def _lib_rgrid():
     L.rgrid_get_grid.argtypes = [vp, vp, C.c_long]
     L.rgrid_grow_as_needed.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int]
     L.rgrid_get_limits.argtypes = [vp, ip, ip, dp, dp, dp]
+    L.rgrid_draw_texture.argtypes = [vp, vp, C.c_long, ip, dp]
     L.rgrid_refine_match.argtypes = [vp, C.POINTER(_RefineOptions), dp, dp, vp, C.c_int, dp, C.POINTER(_RefineSummary)]
     _rgrid = L
     return L
@@ -225,6 +226,17 @@ class GridFrontEnd:
         self._chk(self._L.rgrid_refine_match(self._h, C.byref(co), tt, ip, pts.ctypes.data_as(C.c_void_p), pts.shape[0], pe,
                                              C.byref(sm)), "RefineMatch")
         return RefineResult(np.array(pe[:]), sm.initial_cost, sm.final_cost, sm.iterations, sm.termination)
+
+    # ProbabilityGrid::DrawToSubmapTexture  (probability_grid.cc:86-131), without the gzip container
+    def DrawTexture(self):
+        """Returns (uint8 (height, width, 2) = (value, alpha) per cell of the known-cells window,
+        box (offset_x, offset_y, width, height), slice_max (x, y))."""
+        ny, nx = self._grid_shape
+        out = np.zeros(2 * nx * ny, np.uint8)
+        box = (C.c_int * 4)()
+        sm = (C.c_double * 2)()
+        self._chk(self._L.rgrid_draw_texture(self._h, out.ctypes.data_as(C.c_void_p), out.size, box, sm), "DrawTexture")
+        return out[: 2 * box[2] * box[3]].reshape(box[3], box[2], 2).copy(), tuple(box[:]), (sm[0], sm[1])
 
     def GetGrid(self) -> np.ndarray:
         out = np.zeros(self._grid_shape, np.uint16)

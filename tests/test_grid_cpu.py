@@ -247,3 +247,19 @@ def test_refine_match_restatement_against_scipy_least_squares(oracle_lib):
     p3, s3 = oracle_refine_match(true[:2] + [0.05, 0.05], true + [0.05, 0.05, 0.03], pts, cells, res, max_xy,
                                  translation_weight=1e3, rotation_weight=1e3)
     assert np.abs(p3 - (true + [0.05, 0.05, 0.03])).max() < 1e-3                       # the priors pin the pose
+
+
+def test_draw_texture_semantics(oracle_lib):
+    """DrawToSubmapTexture (probability_grid.cc:86-131): unknown -> (0, 0); probability 0.5 -> log-odds integer 128 ->
+    delta 0 -> (0, 1); occupied cells carry alpha, free cells carry value; the window is the known cells' box."""
+    from oracle.binding import oracle_draw_texture
+    g = np.zeros((20, 30), np.uint16)
+    # cost value v <-> probability 1 - (0.1 + (v - 1) * 0.8 / 32766): v = 1 -> p = 0.9, v = 32767 -> p = 0.1, v = 16384 -> p ~ 0.5
+    g[5, 7] = 1; g[9, 12] = 32767; g[6, 8] = 16384
+    tex, box, sm = oracle_draw_texture(g, 0.1, (2.0, 3.0))
+    assert box == (7, 5, 6, 5) and tex.shape == (5, 6, 2)
+    assert sm == (2.0 - 0.1 * 5, 3.0 - 0.1 * 7)
+    assert tex[0, 0].tolist() == [0, 127]                                       # p = 0.9: log-odds integer 255, delta -127 -> alpha
+    assert tex[4, 5].tolist() == [127, 0]                                       # p = 0.1: integer 1, delta 127 -> value
+    assert tex[1, 1].tolist() == [0, 1]                                         # p ~ 0.5: delta 0 -> (0, 1)
+    assert tex[2, 2].tolist() == [0, 0]                                         # unknown inside the window

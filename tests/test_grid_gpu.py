@@ -239,3 +239,37 @@ def test_refine_match_follows_the_oracle_iterate_for_iterate(gf, oracle_lib):
     with pytest.raises(RgridError) as e:
         gf.RefineMatch([0, 0], [0, 0, 0], np.zeros((0, 2), np.float32))
     assert e.value.code == -6
+
+
+def test_draw_texture_matches_oracle(gf, oracle_lib):
+    """ProbabilityGrid::DrawToSubmapTexture: known-cells window, (value, alpha) bytes, slice corner -- byte for byte."""
+    from oracle.binding import oracle_draw_texture, oracle_insert
+    res = 0.05
+    max_xy = (3.0, 4.0)
+    empty = np.zeros((130, 170), np.uint16)
+    gf.SetGrid(empty, res, max_xy)
+    tex, box, sm = gf.DrawTexture()
+    otex, obox, osm = oracle_draw_texture(empty, res, max_xy)
+    assert box == obox == (0, 0, 1, 1) and sm == osm and np.array_equal(tex, otex) and tex.tolist() == [[[0, 0]]]
+    rng = np.random.default_rng(8)
+    cells = empty.copy()
+    origin = np.array([0.5, 1.0], np.float32)
+    for k in range(3):
+        ang = rng.uniform(-math.pi, math.pi, 300)
+        rad = rng.uniform(0.3, 1.6, 300)
+        ret = np.stack([origin[0] + rad * np.cos(ang), origin[1] + rad * np.sin(ang)], 1).astype(np.float32)
+        cells = oracle_insert(cells, res, max_xy, origin, ret)
+    every = np.arange(170 * 130, dtype=np.uint32).reshape(130, 170)                # every cell value once: the whole table
+    for g in (cells, (every % 32768).astype(np.uint16), np.where(every % 7 == 0, 1 + every % 32767, 0).astype(np.uint16)):
+        gf.SetGrid(g, res, max_xy)
+        tex, box, sm = gf.DrawTexture()
+        otex, obox, osm = oracle_draw_texture(g, res, max_xy)
+        assert box == obox and sm == osm and np.array_equal(tex, otex)
+    big = np.zeros((256, 256), np.uint16)
+    big[:, :128] = np.arange(256 * 128).reshape(256, 128) % 32768
+    gf.SetGrid(big, res, max_xy)
+    tex, box, sm = gf.DrawTexture()
+    otex, obox, osm = oracle_draw_texture(big, res, max_xy)
+    assert box == obox and np.array_equal(tex, otex)
+    # premultiplied alpha: a cell has a value or an alpha, never both
+    assert not np.any((tex[..., 0] > 0) & (tex[..., 1] > 0))
