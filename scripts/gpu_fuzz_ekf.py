@@ -1,0 +1,77 @@
+"""Randomised soak of the EKF path against the CPU oracle (wider than tests/test_ekf_gpu.py's randomised test):
+random model, landmark count (state sizes across several 64-column tile boundaries), observations per scan up to 32,
+ragged / empty scans, pre-loaded map, pose observations, negative dt.  One JSON line per seed + a summary.
+GPU box: python scripts/gpu_fuzz_ekf.py [n_seeds] [first_seed]"""
+import json, sys, time
+sys.path.insert(0, ".")
+import numpy as np
+from reflector_ekf_slam_amd import synth
+from tests.helpers import make_gpu, make_oracle, norm_match
+
+n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+bad = 0
+t_start = time.time()
+for seed in range(first, first + n_seeds):
+    rng = np.random.default_rng(seed)
+    model = int(rng.integers(0, 2))
+    L = int(rng.choice([int(rng.integers(4, 40)), int(rng.integers(40, 140)), int(rng.integers(140, 330))]))
+    K = int(rng.integers(1, 33))
+    cfg = synth.SessionConfig(f"fz{seed}", L, K, model, seed=seed, speed=float(rng.uniform(0.5, 2.5)),
+                              row_spacing=float(rng.choice([6.0, 9.0, 12.0])), sigma_v=float(rng.uniform(0.02, 0.1)),
+                              sigma_w=float(rng.uniform(0.02, 0.1)), sigma_obs=float(rng.uniform(0.03, 0.08)),
+                              range_max=float(rng.choice([8.0, 10.0, 14.0])), extra_scans=int(rng.integers(0, 30)))
+    sess = synth.make_session(cfg, max_scans=int(rng.integers(60, 220)) if L < 140 else int(rng.integers(300, 900)))
+    lin, ang, obs = cfg.sigma_v ** 2, cfg.sigma_w ** 2, cfg.sigma_obs ** 2
+    cap = L if rng.random() < 0.7 else max(4, L // 2)                     # sometimes a capacity the session overflows
+    g = make_gpu(model, sess.init_time, sess.init_pose, lin, ang, obs, cap)
+    o = make_oracle(model, sess.init_time, sess.init_pose, lin, ang, obs)
+    use_map, use_gps = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    if use_map:
+        ids = rng.choice(L, size=max(2, L // 4), replace=False)
+        mxy = (sess.landmarks[ids] + rng.normal(0, 0.01, size=(ids.size, 2))).astype(np.float32)
+        mcov = np.tile(np.array([0.01, 0.0, 0.0, 0.01]), (ids.size, 1))
+        g.set_map(mxy, mcov); o.set_map(mxy, mcov)
+    worst, assoc_bad, scans, overflow, first_scan = 0.0, 0, 0, False, True
+    for e in range(sess.n_events):
+        t = float(sess.ev_time[e])
+        if sess.ev_type[e] == synth.EV_ODOM:
+            g.handle_odometry(t, *sess.odom[e]); o.handle_odometry(t, *sess.odom[e])
+            continue
+        if first_scan:
+            first_scan = False
+            continue
+        ob = sess.obs_of(e)
+        r = rng.random()
+        if r < 0.05:
+            ob = ob[:0]
+        elif r < 0.3:
+            ob = ob[: int(rng.integers(1, ob.shape[0] + 1))]
+        if rng.random() < 0.03:
+            t -= 0.05
+        gps = (sess.true_pose[e] + rng.normal(0, [0.03, 0.03, 0.01])) if (use_gps and rng.random() < 0.5) else None
+        g.handle_observation(t, ob, gps)
+        if g.sync_code() != 0:                                             # capacity overflow: reported, state stays valid
+            overflow = True
+            break
+        o.handle_observation(t, ob, gps)
+        scans += 1
+        a, b = norm_match(g.last_match()), norm_match(o.last_match())
+        if not all(np.array_equal(x, y) for x, y in zip(a, b)):
+            assoc_bad += 1
+            break
+        mg, mo = g.mu(), o.mu()
+        if mg.shape != mo.shape:
+            assoc_bad += 1
+            break
+        worst = max(worst, float(np.abs(mg - mo).max()))
+    cov = 0.0
+    if not overflow and not assoc_bad:
+        st = g.GetState()
+        _, Po = o.state()
+        cov = float(np.abs(st.sigma - Po).max())
+    ok = assoc_bad == 0 and worst < 1e-9 and cov < 1e-10 and (overflow == (cap < L) or not overflow)
+    bad += 0 if ok else 1
+    print(json.dumps({"seed": seed, "model": model, "L": L, "K": K, "cap": cap, "map": use_map, "gps": use_gps, "scans": scans,
+                      "n_final": int(g.mu().shape[0]), "overflow": overflow, "assoc_bad": assoc_bad, "worst_mu": worst, "worst_cov": cov, "ok": ok}))
+print(json.dumps({"summary": True, "seeds": n_seeds, "failed": bad, "seconds": round(time.time() - t_start, 1)}))
