@@ -65,6 +65,50 @@ __global__ __launch_bounds__(256) void kg_first(const int2 *__restrict__ key, in
     if (live && dup) keep[i] = 0;                                     // unordered_set::insert(...).second == false (:89-93)
 }
 
+// Batched variants for the adaptive filter's search: blockIdx.z / blockIdx.y picks one of up to VOX_BATCH voxel sizes,
+// slice r of `key` / `keep` holds its keys / first-occurrence flags; kg_count_b sums a slice.
+constexpr int VOX_BATCH = 32;
+struct VoxBatch { int r; float res[VOX_BATCH]; };
+__global__ __launch_bounds__(256) void kg_keys_b(const float *__restrict__ xy, int n, VoxBatch B, int2 *__restrict__ key,
+                                                 unsigned char *__restrict__ keep)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (i >= n) return;
+    const float res = B.res[r];
+    key[(size_t)r * n + i] = make_int2((int)lroundf(xy[2 * i] / res), (int)lroundf(xy[2 * i + 1] / res));
+    keep[(size_t)r * n + i] = 1;
+}
+__global__ __launch_bounds__(256) void kg_first_b(const int2 *__restrict__ key_all, int n, unsigned char *__restrict__ keep_all)
+{
+    const int bi = blockIdx.x, bj = blockIdx.y;
+    if (bj > bi) return;
+    const int2 *__restrict__ key = key_all + (size_t)blockIdx.z * n;
+    const int i = bi * 256 + threadIdx.x;
+    const bool live = i < n;
+    const int2 k = live ? key[i] : make_int2(0, 0);
+    bool dup = false;
+    const int jbase = bj * 256, jend = min(n, jbase + 256);
+    for (int j0 = jbase; j0 < jend; j0 += 8) {
+        int2 c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] = key[min(j0 + u, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dup |= (j0 + u < i) && c[u].x == k.x && c[u].y == k.y;
+    }
+    if (live && dup) keep_all[(size_t)blockIdx.z * n + i] = 0;
+}
+__global__ __launch_bounds__(256) void kg_count_b(const unsigned char *__restrict__ keep_all, int n, int *__restrict__ counts)
+{
+    __shared__ int ws[4];
+    const unsigned char *keep = keep_all + (size_t)blockIdx.x * n;
+    int c = 0;
+    for (int i = threadIdx.x; i < n; i += 256) c += keep[i];
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
 __global__ __launch_bounds__(256) void kg_range_gate(const float *__restrict__ xy, int n, float max_range,
                                                      unsigned char *__restrict__ keep)
 {
@@ -688,6 +732,9 @@ struct rgrid {
     hipStream_t stream;
     float *d_in, *d_a, *d_b, *d_cs;       // points in / two result buffers / per-scan (cos, sin)
     int2 *d_key, *d_idx;
+    int2 *d_key_b;                              // VOX_BATCH key slices (adaptive filter search)
+    unsigned char *d_keep_b;                    // VOX_BATCH + 1 flag slices (the last one parks the current result)
+    int *d_counts, *h_counts;
     unsigned char *d_keep;
     unsigned short *d_cells, *d_hit, *d_miss;   // grid; hit / miss lookup tables (uint16[32768])
     unsigned short *d_cells2;                   // second grid buffer: target of a growth (then swapped with d_cells), texture staging
@@ -733,6 +780,23 @@ int voxel_pass(rgrid_t *h, const float *src, int n, float res, float *dst, int *
     G_TRY(h, hipMemcpyAsync(h->h_count, h->d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     G_TRY(h, hipStreamSynchronize(h->stream));
     *m = *h->h_count;
+    return RGRID_OK;
+}
+
+// Survivor counts of VoxelFilter(res[r]) for r < R <= VOX_BATCH on the device cloud `src`, one round trip; the
+// first-occurrence flags stay in slice r of d_keep_b for voxel_emit
+int voxel_counts(rgrid_t *h, const float *src, int n, const float *res, int R, int *counts)
+{
+    VoxBatch B;
+    B.r = R;
+    for (int r = 0; r < R; ++r) B.res[r] = res[r];
+    const int blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(kg_keys_b, dim3(blocks, R), dim3(256), 0, h->stream, src, n, B, h->d_key_b, h->d_keep_b);
+    hipLaunchKernelGGL(kg_first_b, dim3(blocks, blocks, R), dim3(256), 0, h->stream, h->d_key_b, n, h->d_keep_b);
+    hipLaunchKernelGGL(kg_count_b, dim3(R), dim3(256), 0, h->stream, h->d_keep_b, n, h->d_counts);
+    G_TRY(h, hipMemcpyAsync(h->h_counts, h->d_counts, sizeof(int) * R, hipMemcpyDeviceToHost, h->stream));
+    G_TRY(h, hipStreamSynchronize(h->stream));
+    for (int r = 0; r < R; ++r) counts[r] = h->h_counts[r];
     return RGRID_OK;
 }
 
@@ -851,6 +915,8 @@ int rgrid_create(int max_points, int max_cells, int max_candidates, int device, 
         G_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         G_TRY(h, hipMalloc(&h->d_in, 8 * np)); G_TRY(h, hipMalloc(&h->d_a, 8 * np)); G_TRY(h, hipMalloc(&h->d_b, 8 * np));
         G_TRY(h, hipMalloc(&h->d_key, 8 * np)); G_TRY(h, hipMalloc(&h->d_keep, np));
+        G_TRY(h, hipMalloc(&h->d_key_b, 8 * np * VOX_BATCH)); G_TRY(h, hipMalloc(&h->d_keep_b, np * (VOX_BATCH + 1)));
+        G_TRY(h, hipMalloc(&h->d_counts, sizeof(int) * VOX_BATCH)); G_TRY(h, hipHostMalloc(&h->h_counts, sizeof(int) * VOX_BATCH));
         G_TRY(h, hipMalloc(&h->d_cs, 8 * (size_t)max_candidates));
         G_TRY(h, hipMalloc(&h->d_idx, 8 * (np * 1024 + 64)));                // up to 1024 rotated scans of max_points points (+ read-ahead pad)
         G_TRY(h, hipMemset(h->d_idx, 0, 8 * (np * 1024 + 64)));
@@ -877,13 +943,14 @@ void rgrid_destroy(rgrid_t *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->d_in, h->d_a, h->d_b, h->d_cs, h->d_key, h->d_idx, h->d_keep, h->d_cells, h->d_bb, h->d_best, h->d_count,
-                    h->d_hit, h->d_miss, h->d_mis, h->d_ends, h->d_bad, h->d_cells2, h->d_refine, h->d_tex, h->d_box};
+                    h->d_hit, h->d_miss, h->d_mis, h->d_ends, h->d_bad, h->d_cells2, h->d_refine, h->d_tex, h->d_box, h->d_key_b, h->d_keep_b, h->d_counts};
     for (void *p : ptrs) (void)hipFree(p);
     if (h->h_pts) (void)hipHostFree(h->h_pts);
     if (h->h_count) (void)hipHostFree(h->h_count);
     if (h->h_best) (void)hipHostFree(h->h_best);
     if (h->h_refine) (void)hipHostFree(h->h_refine);
     if (h->h_box) (void)hipHostFree(h->h_box);
+    if (h->h_counts) (void)hipHostFree(h->h_counts);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -923,36 +990,78 @@ int rgrid_adaptive_voxel_filter(rgrid_t *h, const float *xy, int n, double max_l
     G_TRY(h, hipStreamSynchronize(h->stream));
     const int ni = *h->h_count;
     const float *src = h->d_b;                 // the gated cloud
-    float *res_buf = h->d_a, *cand_buf = h->d_in;   // d_in is free again after the gate
     int cnt = ni;
     const float *final_buf = src;
+    // AdaptivelyVoxelFiltered (voxel_filter.cc:29-76).  Its decisions only need the survivor COUNT of a voxel size, and
+    // the sizes it can ask for are known in advance: the halving ladder (:47-48) and, between the bracketing pair, the
+    // bisection tree (:57-70).  So the ladder is one batched launch and the tree is evaluated a few levels at a time
+    // (every node of those levels at once), the host walks the answers: 3-4 round trips instead of a dozen, and the
+    // point set is compacted once, for the size the search ends on.
     if (!((double)ni <= min_num_points)) {                                         // :33-37
-        rc = voxel_pass(h, src, ni, (float)max_length, res_buf, &cnt);             // :38
+        const float maxl = (float)max_length;
+        float ladder[VOX_BATCH];
+        int counts[VOX_BATCH];
+        int R = 0;
+        ladder[R++] = maxl;                                                        // :38
+        for (float high = maxl; high > 1e-2f * maxl && R < VOX_BATCH; high /= 2.f) ladder[R++] = high / 2.f;   // :47-50
+        rc = voxel_counts(h, src, ni, ladder, R, counts);
         if (rc != RGRID_OK) return rc;
-        final_buf = res_buf;
-        if (!((double)cnt >= min_num_points)) {                                    // :39-43
-            bool done = false;
-            for (float high = (float)max_length; !done && high > 1e-2f * (float)max_length; high /= 2.f) {   // :47-48
-                float low = high / 2.f;
-                rc = voxel_pass(h, src, ni, low, res_buf, &cnt);
-                if (rc != RGRID_OK) return rc;
-                final_buf = res_buf;
-                if ((double)cnt >= min_num_points) {
-                    while ((high - low) / low > 1e-1f) {                            // :57
-                        const float mid = (low + high) / 2.f;
-                        int mc = 0;
-                        rc = voxel_pass(h, src, ni, mid, cand_buf, &mc);
-                        if (rc != RGRID_OK) return rc;
-                        if ((double)mc >= min_num_points) {
-                            low = mid; cnt = mc;
-                            float *t = res_buf; res_buf = cand_buf; cand_buf = t;  // result = candidate
-                            final_buf = res_buf;
-                        } else high = mid;
+        int slot = R - 1;                                                          // nothing dense enough: the last size tried (:75)
+        if ((double)counts[0] >= min_num_points) slot = 0;                         // :39-43
+        else {
+            int k = 1;
+            while (k < R && !((double)counts[k] >= min_num_points)) ++k;
+            if (k < R) {
+                slot = k;
+                float low = ladder[k], high = (k == 1) ? maxl : ladder[k - 1];     // high of that iteration = the previous low
+                unsigned char *park = h->d_keep_b + (size_t)VOX_BATCH * ni;        // `result` while later batches reuse the slices
+                bool parked = false;
+                const int depth = ni <= 4096 ? 5 : (ni <= 8192 ? 3 : 2);
+                while ((high - low) / low > 1e-1f) {                               // :57
+                    // the next `depth` levels of the bisection tree under (low, high), breadth first
+                    struct Node { float low, high, mid; int yes, no; };
+                    Node nodes[VOX_BATCH];
+                    int nn = 0, level_begin = 0;
+                    nodes[nn++] = Node{low, high, (low + high) / 2.f, -1, -1};
+                    for (int lv = 1; lv < depth; ++lv) {
+                        const int level_end = nn;
+                        for (int q = level_begin; q < level_end; ++q) {
+                            const Node nd = nodes[q];
+                            if ((nd.high - nd.mid) / nd.mid > 1e-1f && nn < VOX_BATCH) {          // count(mid) >= min: low = mid
+                                nodes[q].yes = nn; nodes[nn++] = Node{nd.mid, nd.high, (nd.mid + nd.high) / 2.f, -1, -1};
+                            }
+                            if ((nd.mid - nd.low) / nd.low > 1e-1f && nn < VOX_BATCH) {            // else: high = mid
+                                nodes[q].no = nn; nodes[nn++] = Node{nd.low, nd.mid, (nd.low + nd.mid) / 2.f, -1, -1};
+                            }
+                        }
+                        level_begin = level_end;
                     }
-                    done = true;
+                    float mids[VOX_BATCH];
+                    for (int q = 0; q < nn; ++q) mids[q] = nodes[q].mid;
+                    if (!parked) {                                                 // `result` lives in a slice the batch overwrites
+                        G_TRY(h, hipMemcpyAsync(park, h->d_keep_b + (size_t)slot * ni, (size_t)ni, hipMemcpyDeviceToDevice, h->stream));
+                        parked = true;
+                    }
+                    rc = voxel_counts(h, src, ni, mids, nn, counts);
+                    if (rc != RGRID_OK) return rc;
+                    int q = 0, chosen = -1;
+                    while (q >= 0) {
+                        const bool dense = (double)counts[q] >= min_num_points;
+                        if (dense) { low = nodes[q].mid; chosen = q; } else high = nodes[q].mid;
+                        q = dense ? nodes[q].yes : nodes[q].no;                    // -1: the loop condition failed there, or the depth ran out
+                    }
+                    if (chosen >= 0) {                                             // result = candidate (:63-66)
+                        slot = chosen; parked = false;
+                    }
                 }
+                if (parked) slot = VOX_BATCH;
             }
         }
+        hipLaunchKernelGGL(kg_compact, dim3(1), dim3(1024), 0, h->stream, src, h->d_keep_b + (size_t)slot * ni, ni, h->d_a, h->d_count);
+        G_TRY(h, hipMemcpyAsync(h->h_count, h->d_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        G_TRY(h, hipStreamSynchronize(h->stream));
+        cnt = *h->h_count;
+        final_buf = h->d_a;
     }
     rc = download_points(h, final_buf, cnt, out_xy, out_cap);
     if (rc != RGRID_OK) return rc;

@@ -45,6 +45,36 @@ def test_adaptive_voxel_filter_matches_oracle(gf, oracle_lib):
         assert np.array_equal(got, exp)
 
 
+def test_adaptive_voxel_filter_search_paths(gf, oracle_lib):
+    """The speculative search (the halving ladder in one batch, the bisection tree several levels at a time -- 5, 3 or 2
+    depending on the cloud size) must end on the voxel size the reference's sequential loop ends on: random clouds of
+    every size class, thresholds that stop the search at every stage (first size, some rung of the ladder, nothing dense
+    enough, deep bisection), wall-like and blob-like point sets."""
+    from oracle.binding import oracle_adaptive_voxel_filter
+    from reflector_ekf_slam_amd.grid import AdaptiveVoxelFilterOptions
+    rng = np.random.default_rng(33)
+    seen = set()
+    for trial, n in enumerate((600, 800, 1500, 2600, 4000, 4097, 6000, 8192, 8193, 12000, 16000, 900, 3000, 5000)):
+        if trial % 3 == 0:                                                      # walls of a room
+            t = rng.uniform(0, 4, n)
+            side = np.floor(t).astype(int)
+            u = (t - side) * 16 - 8
+            pts = np.stack([np.where(side % 2 == 0, u, np.where(side == 1, 8.0, -8.0)), np.where(side % 2 == 1, u, np.where(side == 0, -8.0, 8.0))], 1)
+            pts += rng.normal(0, 0.01, pts.shape)
+        elif trial % 3 == 1:
+            pts = rng.uniform(-12, 12, (n, 2))
+        else:
+            pts = rng.normal(0, 2.5, (n, 2))
+        pts = pts.astype(np.float32)
+        for frac, max_length in ((0.9, 0.9), (0.5, 0.9), (0.2, 2.0), (0.05, 0.5), (0.999, 0.3), (0.7, 5.0)):
+            opt = AdaptiveVoxelFilterOptions(max_length=max_length, min_num_points=max(2.0, round(frac * n)), max_range=50.0)
+            got = gf.AdaptiveVoxelFilter(pts, opt)
+            exp = oracle_adaptive_voxel_filter(pts, opt.max_length, opt.min_num_points, opt.max_range)
+            assert np.array_equal(got, exp), (n, frac, max_length, got.shape, exp.shape)
+            seen.add((got.shape[0] >= opt.min_num_points, got.shape[0] == n))
+    assert len(seen) >= 3                                                        # dense enough / never dense enough / untouched
+
+
 @pytest.mark.parametrize("true,dinit,npts", [((0.8, -0.6, 0.35), (0.10, -0.15, 4.0), 700), ((-2.0, 1.2, -1.9), (-0.12, 0.08, -7.0), 500),
                                              ((0.0, 0.0, 3.0), (0.0, 0.0, 0.0), 300), ((3.1, 2.2, 0.9), (0.19, 0.19, 14.0), 900)])
 def test_match_identical_candidate_and_score(gf, oracle_lib, true, dinit, npts):
