@@ -414,7 +414,18 @@ struct RefineArgs {
     int nx, ny, n, max_iter, max_nonmono;
     double res, max_x, max_y, w_occ, w_t, w_r, tx, ty, x0, y0, a0;
 };
-struct RefineOut { double pose[3]; double initial_cost, final_cost; int iterations, termination; };
+struct RefineOut {
+    double pose[3]; double initial_cost, final_cost; int iterations, termination;
+#ifdef RGRID_DEBUG_TIMING
+    long long dbg[16];                                 // cycles per phase, summed over the iterations (thread 0)
+#endif
+};
+#ifdef RGRID_DEBUG_TIMING
+__device__ static inline long long pinned_clock() { __builtin_amdgcn_sched_barrier(0); const long long t = clock64(); __builtin_amdgcn_sched_barrier(0); return t; }
+#define RT_MARK(k) do { if (threadIdx.x == 0) { const long long t_ = pinned_clock(); dbg[k] += t_ - tprev; tprev = t_; } } while (0)
+#else
+#define RT_MARK(k) do { } while (0)
+#endif
 struct RefineState {
     double x[3], xc[3], g[3], H[6], s[3], best[3];
     double x_cost, x_norm, gmax, radius, decrease, mcc, min_cost, initial_cost;
@@ -443,13 +454,23 @@ __device__ static inline void hermite(double p0, double p1, double p2, double p3
     dfdx = c + x * (2.0 * b + 3.0 * a * x);
 }
 // Partial sums of this wave into part[wave][]: [0] = |r|^2, [1..3] = J'r, [4..9] = J'J (xx xy xt yy yt tt)
+#ifdef RGRID_DEBUG_TIMING
+__shared__ long long edbg[8];
+#define ET_MARK(k) do { if (threadIdx.x == 0) { const long long t_ = pinned_clock(); edbg[k] += t_ - et; et = t_; } } while (0)
+#else
+#define ET_MARK(k) do { } while (0)
+#endif
 __device__ static void refine_eval(const RefineArgs &A, const unsigned short *__restrict__ cells, const float *__restrict__ pts,
                                    const double p0, const double p1, const double p2, double (*part)[10])
 {
 #pragma clang fp contract(off)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef RGRID_DEBUG_TIMING
+    long long et = pinned_clock();
+#endif
     double sn, cs;
     sincos(p2, &sn, &cs);
+    ET_MARK(0);
     const double scale = A.w_occ / sqrt((double)A.n);
     const double ninv = -1.0 / A.res;                                            // d(row) / d(world x): Jet / scalar = * (1 / scalar)
     double acc[10];
@@ -479,6 +500,7 @@ __device__ static void refine_eval(const RefineArgs &A, const unsigned short *__
             }
             hermite(v[0], v[1], v[2], v[3], q - qf, f[a], dq[a]);
         }
+        ET_MARK(1);
         double val, dvdr, dvdq, unused;
         hermite(f[0], f[1], f[2], f[3], r - rf, val, dvdr);
         hermite(dq[0], dq[1], dq[2], dq[3], r - rf, dvdq, unused);
@@ -488,15 +510,22 @@ __device__ static void refine_eval(const RefineArgs &A, const unsigned short *__
         acc[0] += ri * ri;
         acc[1] += J0 * ri; acc[2] += J1 * ri; acc[3] += J2 * ri;
         acc[4] += J0 * J0; acc[5] += J0 * J1; acc[6] += J0 * J2; acc[7] += J1 * J1; acc[8] += J1 * J2; acc[9] += J2 * J2;
+        ET_MARK(2);
     }
+    ET_MARK(3);
+    // butterfly over the wave, the ten sums side by side: all twenty permutes of a step are in flight together (one sum
+    // at a time, every step waits for its own two)
 #pragma unroll
-    for (int k = 0; k < 10; ++k) {
-        double v = acc[k];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        acc[k] = v;
+    for (int off = 32; off > 0; off >>= 1) {
+        double t[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) t[k] = __shfl_xor(acc[k], off, 64);
+#pragma unroll
+        for (int k = 0; k < 10; ++k) acc[k] += t[k];
     }
     if (lane == 0)
         for (int k = 0; k < 10; ++k) part[wave][k] = acc[k];
+    ET_MARK(4);
 }
 __device__ static inline bool chol3(const double A[6], const double b[3], double y[3])
 {
@@ -514,15 +543,18 @@ __device__ static inline bool chol3(const double A[6], const double b[3], double
     y[2] = z2 / l22; y[1] = (z1 - l21 * y[2]) / l11; y[0] = (z0 - l10 * y[1] - l20 * y[2]) / l00;
     return isfinite(y[0]) && isfinite(y[1]) && isfinite(y[2]);
 }
-// Thread 0: totals of an evaluation at pose p (the wave partials + the translation / rotation delta blocks,
+// First wave: totals of an evaluation at pose p (the wave partials + the translation / rotation delta blocks,
 // translation_delta_cost_functor_2d.h:24-29, rotation_delta_cost_functor_2d.h:24-28)
 __device__ static void refine_totals(const RefineArgs &A, const double (*part)[10], int nw, const double p[3], double S[10])
 {
 #pragma clang fp contract(off)
-    for (int k = 0; k < 10; ++k) {
+    // called by the whole first wave: lane k < 10 adds sum k over the waves (in wave order), lane 0 collects them
+    {
+        const int lane = threadIdx.x & 63, k = lane < 10 ? lane : 0;
         double v = 0.;
         for (int w = 0; w < nw; ++w) v += part[w][k];
-        S[k] = v;
+#pragma unroll
+        for (int q = 0; q < 10; ++q) S[q] = __shfl(v, q, 64);
     }
     const double r0 = A.w_t * (p[0] - A.tx), r1 = A.w_t * (p[1] - A.ty), r2 = A.w_r * (p[2] - A.a0);
     S[0] += r0 * r0 + r1 * r1 + r2 * r2;
@@ -604,10 +636,13 @@ __global__ __launch_bounds__(1024) void kg_refine(RefineArgs A, const unsigned s
     const int nw = blockDim.x >> 6;
     refine_eval(A, cells, pts, A.x0, A.y0, A.a0, part);                          // IterationZero
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double S[10];
+    double S[10];
+    if (threadIdx.x < 64) {
         const double x[3] = {A.x0, A.y0, A.a0};
         refine_totals(A, part, nw, x, S);
+    }
+    if (threadIdx.x == 0) {
+        const double x[3] = {A.x0, A.y0, A.a0};
         for (int k = 0; k < 3; ++k) { st.x[k] = st.xc[k] = st.best[k] = x[k]; st.g[k] = S[1 + k]; }
         for (int k = 0; k < 6; ++k) st.H[k] = S[4 + k];
         st.s[0] = 1. / (1. + sqrt(S[4])); st.s[1] = 1. / (1. + sqrt(S[7])); st.s[2] = 1. / (1. + sqrt(S[9]));   // Jacobi scaling, fixed
@@ -620,22 +655,38 @@ __global__ __launch_bounds__(1024) void kg_refine(RefineArgs A, const unsigned s
         refine_next_candidate(A, st);
     }
     __syncthreads();
+#ifdef RGRID_DEBUG_TIMING
+    if (threadIdx.x < 8) edbg[threadIdx.x] = 0;
+    __syncthreads();
+    long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = pinned_clock();
+#endif
     while (!st.done) {
         const double c0 = st.xc[0], c1 = st.xc[1], c2 = st.xc[2];
+        RT_MARK(0);                                                              // loop head: LDS read of the candidate
         refine_eval(A, cells, pts, c0, c1, c2, part);
+        RT_MARK(1);                                                              // evaluation + wave reduction
         __syncthreads();
-        if (threadIdx.x == 0) {
-            double S[10];
+        RT_MARK(2);                                                              // barrier
+        if (threadIdx.x < 64) {
             const double xc[3] = {c0, c1, c2};
             refine_totals(A, part, nw, xc, S);
+        }
+        if (threadIdx.x == 0) {
+            RT_MARK(3);
             refine_judge(A, st, S);
+            RT_MARK(4);
             if (!st.done) refine_next_candidate(A, st);
+            RT_MARK(5);
         }
         __syncthreads();
+        RT_MARK(6);
     }
     if (threadIdx.x == 0) {
         out->pose[0] = st.best[0]; out->pose[1] = st.best[1]; out->pose[2] = st.best[2];
         out->initial_cost = st.initial_cost; out->final_cost = st.min_cost; out->iterations = st.iter; out->termination = st.termination;
+#ifdef RGRID_DEBUG_TIMING
+        for (int k = 0; k < 8; ++k) { out->dbg[k] = dbg[k]; out->dbg[8 + k] = edbg[k]; }
+#endif
     }
 }
 
@@ -883,6 +934,14 @@ int rgrid_refine_match(rgrid_t *h, const rgrid_refine_options *opt, const double
     }
     return RGRID_OK;
 }
+
+#ifdef RGRID_DEBUG_TIMING
+int rgrid_debug_refine_cycles(rgrid_t *h, long long out[16])
+{
+    for (int k = 0; k < 16; ++k) out[k] = h->h_refine->dbg[k];
+    return RGRID_OK;
+}
+#endif
 
 const char *rgrid_strerror(int code)
 {
