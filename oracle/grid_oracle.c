@@ -12,6 +12,10 @@
  *   mapping::MapLimits::GetCellIndex / Contains                          include/mapping/map_limits.h:47-72
  *   mapping::ProbabilityGrid::GetProbability, value tables               src/mapping/probability_grid.cc:56-62,
  *                                  src/mapping/probability_values.cc:11-20, include/mapping/probability_values.h:53-57
+ *   mapping::ProbabilityGridRangeDataInserter2D::Insert, RayToPixelMask, GrowAsNeeded / Grid2D::GrowLimits
+ *                 src/mapping/probability_grid_range_data_inserter_2d.cc:20-114, ray_to_pixel_mask.cc:17-168, grid_2d.cc:59-99
+ *   scan_matching::CeresScanMatcher2D::Match (Ceres restated)           src/scan_matching/ceres_scan_matcher_2d.cc:26-62
+ *   mapping::ProbabilityGrid::DrawToSubmapTexture                        src/mapping/probability_grid.cc:86-131
  *
  * The float32 point algebra of the reference goes through Eigen (Quaternionf from AngleAxisf, quaternion *
  * UnitX, Rotation2Df * Vector2f, Translation2f) and transform::GetYaw (transform.h:27-33); Eigen is not in
