@@ -164,6 +164,11 @@ int rekf_device_layout(rekf_t *h, int *ld, int *n_max, void **P_dev, void **mu_d
  * (1 no write-back, 2 no P reads, 4 no MFMA, 8 no panel reads). */
 int rekf_debug_time_kernel(rekf_t *h, int kernel, int reps, int ablate, double *avg_us);
 
+/* Measurement hook: does k_downdate overlap with the single-workgroup chain of a following update?  out_us[0] =
+ * k_downdate alone, [1] = (k_solve, k_gain) alone, [2] = both on two streams, microseconds per repetition.
+ * The filter state is not meaningful afterwards. */
+int rekf_debug_overlap(rekf_t *h, int reps, double out_us[3]);
+
 /* Debug builds (-DREKF_DEBUG_TIMING) let kernels drop cycle counters here; zeros otherwise. */
 int rekf_debug_counters(rekf_t *h, long long out32[32]);
 

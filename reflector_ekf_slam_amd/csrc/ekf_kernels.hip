@@ -1035,14 +1035,14 @@ __device__ static inline void dd_lds_barrier() { lds_barrier(); }
 // FAST = the whole innovation fits one full 64-wide k-chunk (m_pad == 64, i.e. 25..32 matched
 // observations: BASELINE.json's N=1024 x 32 configuration).  Its loop is peeled so that every
 // prefetch/consume pair is unconditional and hipcc's waitcnt pass can count them exactly.
+typedef double DdBorder[DD_STRIP_MAX][REKF_MR_PAD];
 template <bool FAST, bool ABL>
-__device__ static void downdate_body(const RekfDev &d, double *dd_smem, int n, int m_pad)
+__device__ static void downdate_body(const RekfDev &d, double *dd_smem, DdBorder *s_border, int n, int m_pad)
 {
     const int dbg = ABL ? d.dbg : 0;       // ablation hooks compile away in the production instance
 #ifdef REKF_DEBUG_TIMING
     const long long t_entry = clock64();
 #endif
-    __shared__ __attribute__((aligned(16))) double s_border[2][DD_STRIP_MAX][REKF_MR_PAD];            // [Kn | HPt] border rows nb.., all k
     const int rem = n % DT;
     const bool strips = rem > 0 && rem <= DD_STRIP_MAX && n >= DT;       // thin border: strips instead of padded tiles
     const int T = strips ? n / DT : (n + DT - 1) / DT;
@@ -1471,15 +1471,19 @@ __device__ static void downdate_body(const RekfDev &d, double *dd_smem, int n, i
 __global__ __launch_bounds__(256, 2) void k_downdate(RekfDev d)
 {
     extern __shared__ __attribute__((aligned(16))) double dd_smem[];   // [2 buffers][Kn | HPt][DKC*64]
+    // [Kn | HPt] border rows nb.., all k -- declared once here: a copy per template instance would be summed into the
+    // kernel's static LDS (4 x 8 KiB = the whole CU with the 128 KiB of panels) and no other workgroup could ever share
+    // the CU with this one
+    __shared__ __attribute__((aligned(16))) double s_border[2][DD_STRIP_MAX][REKF_MR_PAD];
     const RekfCtl *ctl = d.ctl;
     const int m_pad = ctl->m_pad;
     if (ctl->m == 0) return;
     const int n = ctl->n;
     if (d.dbg) {                                   // ablation runs (rekf_debug_time_kernel)
-        if (m_pad == DKC) downdate_body<true, true>(d, dd_smem, n, m_pad);
-        else downdate_body<false, true>(d, dd_smem, n, m_pad);
-    } else if (m_pad == DKC) downdate_body<true, false>(d, dd_smem, n, m_pad);
-    else downdate_body<false, false>(d, dd_smem, n, m_pad);
+        if (m_pad == DKC) downdate_body<true, true>(d, dd_smem, s_border, n, m_pad);
+        else downdate_body<false, true>(d, dd_smem, s_border, n, m_pad);
+    } else if (m_pad == DKC) downdate_body<true, false>(d, dd_smem, s_border, n, m_pad);
+    else downdate_body<false, false>(d, dd_smem, s_border, n, m_pad);
 }
 
 // ----------------------------------------------------------------------------

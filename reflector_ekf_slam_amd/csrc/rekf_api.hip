@@ -9,6 +9,7 @@
 #include "../../include/rekf.h"
 #include "ekf_dev.h"
 
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -514,6 +515,43 @@ int rekf_debug_time_kernel(rekf_t *h, int kernel, int reps, int ablate, double *
     HIP_TRY(h, hipEventElapsedTime(&ms, a, b));
     *avg_us = 1e3 * (double)ms / reps;
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return REKF_OK;
+}
+
+/* Measurement hook: can k_downdate run under the latency chain of a following update?  Times `reps` launches of
+ * k_downdate alone (stream A), `reps` x (k_solve, k_gain) alone (stream B), and both streams together; out_us[0..2] =
+ * microseconds per repetition.  Like rekf_debug_time_kernel it leaves the state meaningless. */
+int rekf_debug_overlap(rekf_t *h, int reps, double out_us[3])
+{
+    if (!h || !out_us || reps < 1) return REKF_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t sb;
+    HIP_TRY(h, hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+    hipEvent_t a0, a1, b0, b1;
+    HIP_TRY(h, hipEventCreate(&a0)); HIP_TRY(h, hipEventCreate(&a1)); HIP_TRY(h, hipEventCreate(&b0)); HIP_TRY(h, hipEventCreate(&b1));
+    const int n_ub = h->n_ub;
+    auto run_a = [&]() { for (int i = 0; i < reps; ++i) rekf_launch_downdate(h->dev, n_ub, h->stream); };
+    auto run_b = [&]() { for (int i = 0; i < reps; ++i) { rekf_launch_solve(h->dev, h->last_m_ub, sb); rekf_launch_gain(h->dev, n_ub, sb); } };
+    float ms = 0.f;
+    for (int w = 0; w < 2; ++w) {                    // first pass warms up
+        HIP_TRY(h, hipEventRecord(a0, h->stream)); run_a(); HIP_TRY(h, hipEventRecord(a1, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipEventElapsedTime(&ms, a0, a1)); out_us[0] = 1e3 * ms / reps;
+        HIP_TRY(h, hipEventRecord(b0, sb)); run_b(); HIP_TRY(h, hipEventRecord(b1, sb));
+        HIP_TRY(h, hipStreamSynchronize(sb));
+        HIP_TRY(h, hipEventElapsedTime(&ms, b0, b1)); out_us[1] = 1e3 * ms / reps;
+    }
+    HIP_TRY(h, hipDeviceSynchronize());
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < reps; ++i) {                 // interleaved enqueue: both queues stay fed
+        rekf_launch_downdate(h->dev, n_ub, h->stream);
+        rekf_launch_solve(h->dev, h->last_m_ub, sb); rekf_launch_gain(h->dev, n_ub, sb);
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipStreamSynchronize(sb));
+    out_us[2] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+    (void)hipEventDestroy(a0); (void)hipEventDestroy(a1); (void)hipEventDestroy(b0); (void)hipEventDestroy(b1);
+    (void)hipStreamDestroy(sb);
     return REKF_OK;
 }
 
