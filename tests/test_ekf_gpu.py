@@ -435,3 +435,43 @@ def test_randomised_sessions_with_map_and_pose_observations(oracle_lib, seed):
     st = g.GetState()
     mo, Po = o.state()
     assert np.abs(st.sigma - Po).max() < 1e-10 and g.sync_code() == 0
+
+
+def test_interleaved_sessions_on_one_gpu_do_not_interact(oracle_lib):
+    """Fleet serving: several handles (one HIP stream each) fed event by event in round-robin, different sessions and
+    models; each must follow its own oracle exactly as if it ran alone."""
+    cfgs = [synth.SessionConfig("ms0", 40, 12, synth.DIFF, seed=901, speed=1.0, row_spacing=6.0),
+            synth.SessionConfig("ms1", 70, 20, synth.OMNI, seed=902, speed=1.5, row_spacing=6.0),
+            synth.SessionConfig("ms2", 33, 8, synth.DIFF, seed=903, speed=0.8, row_spacing=6.0)]
+    runs = []
+    for cfg in cfgs:
+        sess = synth.make_session(cfg, max_scans=90)
+        g, o = _pair(cfg, sess)
+        runs.append({"sess": sess, "g": g, "o": o, "e": 0, "first": True, "worst": 0.0})
+    alive = True
+    while alive:
+        alive = False
+        for r in runs:                                   # one event of every session per round
+            sess, g, o = r["sess"], r["g"], r["o"]
+            if r["e"] >= sess.n_events:
+                continue
+            alive = True
+            e = r["e"]; r["e"] += 1
+            t = float(sess.ev_time[e])
+            if sess.ev_type[e] == synth.EV_ODOM:
+                g.handle_odometry(t, *sess.odom[e]); o.handle_odometry(t, *sess.odom[e])
+                continue
+            if r["first"]:
+                r["first"] = False
+                continue
+            ob = sess.obs_of(e)
+            g.handle_observation(t, ob); o.handle_observation(t, ob)     # no sync between the sessions: the streams overlap
+            if e % 7 == 0:
+                a, b = norm_match(g.last_match()), norm_match(o.last_match())
+                assert all(np.array_equal(x, y) for x, y in zip(a, b))
+                r["worst"] = max(r["worst"], float(np.abs(g.mu() - o.mu()).max()))
+    for r in runs:
+        mg, mo = r["g"].mu(), r["o"].mu()
+        assert mg.shape == mo.shape and np.abs(mg - mo).max() < TIGHT and r["worst"] < TIGHT
+        st = r["g"].GetState()
+        assert np.abs(st.sigma - r["o"].state()[1]).max() < 1e-10 and r["g"].sync_code() == 0
