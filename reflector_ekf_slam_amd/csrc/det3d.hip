@@ -4,16 +4,16 @@
 // src/reflector_detect/point_cloud/point_cloud_reflector_detect.cc:9-106), whose arithmetic
 // is PCL 1.7's (un-vendored; the PCL semantics this file implements are spelled out in DESIGN.md section 4):
 //
-//   k3_filter     intensity > threshold, order-preserving compaction (ballot scan per 1024-point
-//                 tile, coalesced 16-byte reads)                                   (:31-39)
+//   k3_filter_*   intensity > threshold, order-preserving compaction (a workgroup per 1024-point tile: counts, then
+//                 ballot scan + write; coalesced 16-byte reads)                        (:31-39)
 //   k3_knn        StatisticalOutlierRemoval part 1: per point the MeanK+1 = 31 smallest float32
 //                 squared distances (the query first), brute force over LDS-staged candidate
 //                 tiles; lane = point, the sorted list lives in registers (min/max insertion
 //                 chain), four waves share the candidates of 64 points                  (:43-47)
 //   k3_sor        part 2: mean / (n-1)-variance in FP64, threshold, second compaction
-//   k3_cc         EuclideanClusterExtraction as connected components of the radius-0.2 m graph:
-//                 one all-pairs pass with a lock-free union-find (roots are only ever hooked under
-//                 smaller roots, so a component's label is its smallest index)        (:65-74)
+//   k3_cc_*       EuclideanClusterExtraction as connected components of the radius-0.2 m graph: smallest-neighbour
+//                 pointers, a snapshot of the chain tops, then a lock-free union-find for the few adjacent pairs whose
+//                 tops differ (roots are only ever hooked under smaller roots: the label is the smallest index) (:65-74)
 //   k3_finish     component sizes, size gate [4,160], order (size desc, first index asc),
 //                 float32 centroids in index order (one wave per component), Rigid2f to base_link (:77-97)
 //
@@ -83,25 +83,42 @@ __device__ static int tile_compact_pos(bool flag, int *wsum, int *base)
     return off + __popcll(bal & lt);
 }
 
-// ---- intensity filter + compaction (one workgroup keeps the point order; coalesced 16-byte reads) --
-__global__ __launch_bounds__(1024) void k3_filter(Det3dBufs B, int N, double intensity_min)
+// ---- intensity filter + order-preserving compaction, one workgroup per 1024-point tile: the tiles' survivor counts
+// first (k3_filter_count), then every tile adds up the counts in front of it and writes (k3_filter_write).  One
+// workgroup walking all tiles with two barriers each took 45 us for 29 k points; coalesced 16-byte reads.
+__global__ __launch_bounds__(1024) void k3_filter_count(Det3dBufs B, int N, double intensity_min)
+{
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x * 1024 + tid;
+    const bool keep = i < N && (double)((const float4 *)B.xyzi)[i].w > intensity_min;      // :33
+    const unsigned long long bal = __ballot(keep);
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    if (tid == 0) {
+        int c = 0;
+        for (int w = 0; w < 16; ++w) c += wsum[w];
+        B.cnt[blockIdx.x] = c;                                                   // B.cnt is rebuilt by k3_sor for its own use
+    }
+}
+__global__ __launch_bounds__(1024) void k3_filter_write(Det3dBufs B, int N, double intensity_min)
 {
     __shared__ int wsum[16];
     __shared__ int base;
     const int tid = threadIdx.x;
-    if (tid == 0) base = 0;
-    __syncthreads();
-    const float4 *src = (const float4 *)B.xyzi;
-    float4 p = (tid < N) ? src[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int t0 = 0; t0 < N; t0 += 1024) {
-        const int i = t0 + tid;
-        const float4 cur = p;
-        if (i + 1024 < N) p = src[i + 1024];                                      // next tile in flight
-        const bool keep = i < N && (double)cur.w > intensity_min;                // :33
-        const int pos = tile_compact_pos(keep, wsum, &base);
-        if (keep) { B.p1[pos] = cur.x; B.p1[B.cap + pos] = cur.y; B.p1[2 * B.cap + pos] = cur.z; }
+    if (tid < 64) {                                                              // survivors in the tiles before this one
+        int c = 0;
+        for (int w = tid; w < (int)blockIdx.x; w += 64) c += B.cnt[w];
+        for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+        if (tid == 0) base = c;
     }
-    if (tid == 0) { B.ctl->M = base; B.ctl->M2 = 0; B.ctl->K = 0; B.ctl->err = 0; }
+    __syncthreads();
+    const int i = blockIdx.x * 1024 + tid;
+    const float4 cur = (i < N) ? ((const float4 *)B.xyzi)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool keep = i < N && (double)cur.w > intensity_min;
+    const int pos = tile_compact_pos(keep, wsum, &base);
+    if (keep) { B.p1[pos] = cur.x; B.p1[B.cap + pos] = cur.y; B.p1[2 * B.cap + pos] = cur.z; }
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) { B.ctl->M = base; B.ctl->M2 = 0; B.ctl->K = 0; B.ctl->err = 0; }   // base now includes this tile
 }
 
 // ---- SOR part 1: mean distance to the MeanK nearest neighbours ---------------------------------
@@ -121,9 +138,10 @@ __device__ static inline void knn_insert(float (&L)[KNN], float x)
         L[q] = lo;
     }
 }
-__global__ __launch_bounds__(256) void k3_knn(Det3dBufs B)
+constexpr int KNN_WAVES = 4;        // waves sharing the candidates of 64 queries
+__global__ __launch_bounds__(64 * KNN_WAVES) void k3_knn(Det3dBufs B)
 {
-    __shared__ float part[3][KNN][64];            // partial lists of waves 1..3
+    __shared__ float part[KNN_WAVES / 2][KNN][64];   // hand-over buffers of the merge tree
     const int M = B.ctl->M;
     const int q0 = blockIdx.x * 64;
     if (q0 >= M) return;
@@ -143,18 +161,18 @@ __global__ __launch_bounds__(256) void k3_knn(Det3dBufs B)
     for (int k = 0; k < 2 * ntiles; ++k) {
         const int t = (k & 1) ? qt + (k + 1) / 2 : qt - k / 2;
         if (t < 0 || t >= ntiles) continue;
-        if ((valid++ & 3) != wave) continue;
+        if ((valid++ % KNN_WAVES) != wave) continue;
         const int j0 = 256 * t, jn = min(256, M - j0);
         float nx[8], ny[8], nz[8];                            // the next group of eight is loaded while this one is used
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int j = min(j0 + u, M - 1); nx[u] = X[j]; ny[u] = Y[j]; nz[u] = Z[j]; }
+        for (int u = 0; u < 8; ++u) { const int j = j0 + u; nx[u] = X[j]; ny[u] = Y[j]; nz[u] = Z[j]; }   // contiguous: ONE s_load_dwordx8 per array (a clamp per element would split it); reads past M stay inside the padded buffers
         for (int c0 = 0; c0 < jn; c0 += 8) {
             float cx[8], cy[8], cz[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) { cx[u] = nx[u]; cy[u] = ny[u]; cz[u] = nz[u]; }
             if (c0 + 8 < jn) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int j = min(j0 + c0 + 8 + u, M - 1); nx[u] = X[j]; ny[u] = Y[j]; nz[u] = Z[j]; }
+                for (int u = 0; u < 8; ++u) { const int j = j0 + c0 + 8 + u; nx[u] = X[j]; ny[u] = Y[j]; nz[u] = Z[j]; }
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -164,20 +182,24 @@ __global__ __launch_bounds__(256) void k3_knn(Det3dBufs B)
             }
         }
     }
-    if (wave > 0) {
+    // merge tree: in every round the upper half of the remaining waves hands its list to the lower half
+    for (int half = KNN_WAVES / 2; half >= 1; half >>= 1) {
+        if (wave >= half && wave < 2 * half) {
 #pragma unroll
-        for (int q = 0; q < KNN; ++q) part[wave - 1][q][lane] = L[q];
-    }
-    __syncthreads();
-    if (wave == 0) {
-#pragma unroll
-        for (int w = 0; w < 3; ++w)
-            for (int q = 0; q < KNN; ++q) {                   // each partial list is ascending: stop once it cannot improve
-                const float v = part[w][q][lane];
+            for (int q = 0; q < KNN; ++q) part[wave - half][q][lane] = L[q];
+        }
+        __syncthreads();
+        if (wave < half) {
+            for (int q = 0; q < KNN; ++q) {                   // the partner's list is ascending: stop once it cannot improve
+                const float v = part[wave][q][lane];
                 const bool need = v < L[KNN - 1];
                 if (!__any(need)) break;
                 knn_insert(L, need ? v : INFINITY);
             }
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
         if (live) {
             float dst = 0.f;                                      // search "failed": fewer than MeanK+1 points
             if (M >= KNN) {
@@ -238,54 +260,130 @@ __global__ __launch_bounds__(1024) void k3_sor(Det3dBufs B)
 // ---- connected components of the radius graph: lock-free union-find ------------------------------
 // parent = B.label.  Only roots are ever hooked (CAS root -> a SMALLER root), so the final root of a
 // component is its smallest index whatever the interleaving: deterministic labels from one all-pairs pass
-// (the previous version needed up to 64 propagation launches).  All accesses to parent[] are device-scope
-// atomics: the XCDs' L2 caches are not coherent with each other for plain loads/stores.
-__device__ static inline int uf_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// (the previous version needed up to 64 propagation launches).  The XCDs' L2 caches are not coherent with each other
+// for plain loads, and a device-scope atomic load is a ~1.5 us round trip, so the finds read parent[] through the
+// caches: every value parent[x] has ever held is an ancestor of x for good (hooks attach roots under smaller indices,
+// halving only shortcuts upwards), hence a stale read can only return an ancestor that is no longer the root -- never a
+// wrong one.  What must be exact is the hook itself: the CAS on the larger root goes to memory and fails when that
+// node has stopped being a root, and only then the finds are repeated with device-scope loads (FRESH).
+template <bool FRESH>
+__device__ static inline int uf_load(const int *p)
+{
+    if (FRESH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *(const volatile int *)p;
+}
+template <bool FRESH>
 __device__ static int uf_find(int *parent, int x)
 {
-    int p = uf_load(&parent[x]);
+    int p = uf_load<FRESH>(&parent[x]);
     while (p != x) {
-        const int gp = uf_load(&parent[p]);
+        const int gp = uf_load<FRESH>(&parent[p]);
         if (gp != p) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // path halving
         x = p; p = gp;
     }
     return x;
 }
-__global__ __launch_bounds__(256) void k3_cc(Det3dBufs B)
+// Three passes.  Doing every union inside the all-pairs sweep serialises: a candidate that is adjacent to ANY lane of the
+// wave makes the whole wave walk through a dependent chain of memory operations (finds, CAS), ~100 such candidates per
+// wave = 150 us.  Instead:
+//   k3_cc_min   sweep 1, registers only: parent[i] = smallest index among i and its neighbours.  That alone puts nearly
+//               every point of a compact cluster in one tree (the chains run towards the cluster's first point);
+//   k3_cc_jump  root[i] = top of i's chain (a snapshot; plain loads);
+//   k3_cc_link  sweep 2: the candidate's snapshot root arrives through the scalar cache with its coordinates, and only
+//               an adjacent pair whose snapshot roots differ goes into the union code -- a few per cluster.
+constexpr int CC_WAVES = 16;        // waves per 64 queries in the two sweeps: the sweep is a chain of scalar-cache misses per wave
+__global__ __launch_bounds__(64 * CC_WAVES) void k3_cc_min(Det3dBufs B)
 {
+    __shared__ int s_min[CC_WAVES][64];
     const int M2 = B.ctl->M2;
-    const int q0 = blockIdx.x * 64;
-    if (q0 >= M2) return;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int q0 = blockIdx.x * 64; q0 < M2; q0 += gridDim.x * 64) {      // the grid is capped: tiles of 64 queries, strided
     const int i = q0 + lane;
     const bool live = i < M2;
     const float *__restrict__ X = B.p2, *__restrict__ Y = B.p2 + B.cap, *__restrict__ Z = B.p2 + 2 * B.cap;
     const float px = live ? X[i] : 0.f, py = live ? Y[i] : 0.f, pz = live ? Z[i] : 0.f;
-    int *parent = B.label;
-    int ri = i;                                               // a (possibly stale) ancestor of i
-    const int jend = min(M2, q0 + 63);                        // only j < i: every edge is handled by its larger end
-    // candidates through the scalar cache as in k3_knn; wave w takes the 8-candidate groups w, w+4, ...
-    for (int c0 = 8 * wave; c0 < jend; c0 += 32) {
+    int mi = i;
+    const int jend = min(M2, q0 + 63);                        // only j < i
+    float nx[8], ny[8], nz[8];                                // the next group of eight is loaded while this one is used
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int j = 8 * wave + u; nx[u] = X[j]; ny[u] = Y[j]; nz[u] = Z[j]; }   // contiguous -> s_load_dwordx8; past M2: padding, masked by j < i
+    for (int c0 = 8 * wave; c0 < jend; c0 += 8 * CC_WAVES) {  // candidates through the scalar cache, ascending within a wave
         float cx[8], cy[8], cz[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int j = min(c0 + u, M2 - 1);
-            cx[u] = X[j]; cy[u] = Y[j]; cz[u] = Z[j];
-        }
+        for (int u = 0; u < 8; ++u) { cx[u] = nx[u]; cy[u] = ny[u]; cz[u] = nz[u]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int j = c0 + 8 * CC_WAVES + u; nx[u] = X[j]; ny[u] = Y[j]; nz[u] = Z[j]; }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int j = c0 + u;
-            if (live && j < i && d2f(px, py, pz, cx[u], cy[u], cz[u]) < TOL2) {
-                int a = uf_find(parent, ri), b = uf_find(parent, j);
+            const bool adj = j < i && d2f(px, py, pz, cx[u], cy[u], cz[u]) < TOL2;
+            mi = adj ? min(mi, j) : mi;
+        }
+        if (__ballot(live && mi == i) == 0ull) break;          // every lane has its (for this wave) smallest neighbour
+    }
+    s_min[wave][lane] = mi;
+    __syncthreads();
+    if (wave == 0 && live) {
+        int m = s_min[0][lane];
+#pragma unroll
+        for (int w = 1; w < CC_WAVES; ++w) m = min(m, s_min[w][lane]);
+        B.label[i] = m;
+    }
+    __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k3_cc_jump(Det3dBufs B)
+{
+    const int M2 = B.ctl->M2;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M2) return;
+    const int *parent = B.label;
+    int r = parent[i];
+    for (int p = parent[r]; p != r; p = parent[r]) r = p;     // parent[] is constant during this kernel
+    reinterpret_cast<int *>(B.dist)[i] = r;                   // the SOR distances are dead: snapshot roots live there
+}
+__global__ __launch_bounds__(64 * CC_WAVES) void k3_cc_link(Det3dBufs B)
+{
+    const int M2 = B.ctl->M2;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int q0 = blockIdx.x * 64; q0 < M2; q0 += gridDim.x * 64) {
+    const int i = q0 + lane;
+    const bool live = i < M2;
+    const float *__restrict__ X = B.p2, *__restrict__ Y = B.p2 + B.cap, *__restrict__ Z = B.p2 + 2 * B.cap;
+    const int *__restrict__ root = reinterpret_cast<const int *>(B.dist);
+    const float px = live ? X[i] : 0.f, py = live ? Y[i] : 0.f, pz = live ? Z[i] : 0.f;
+    int *parent = B.label;
+    const int rs = live ? root[i] : -1;                       // snapshot root of i
+    int ri = rs;                                              // a (possibly stale) ancestor of i
+    int rm = rs;                                              // snapshot root of the tree merged last
+    const int jend = min(M2, q0 + 63);                        // only j < i: every edge is handled by its larger end
+    float nx[8], ny[8], nz[8];
+    int nr[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int j = 8 * wave + u; nx[u] = X[j]; ny[u] = Y[j]; nz[u] = Z[j]; nr[u] = root[j]; }
+    for (int c0 = 8 * wave; c0 < jend; c0 += 8 * CC_WAVES) {
+        float cx[8], cy[8], cz[8];
+        int cr[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { cx[u] = nx[u]; cy[u] = ny[u]; cz[u] = nz[u]; cr[u] = nr[u]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int j = c0 + 8 * CC_WAVES + u; nx[u] = X[j]; ny[u] = Y[j]; nz[u] = Z[j]; nr[u] = root[j]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = c0 + u;
+            if (live && j < i && cr[u] != rs && cr[u] != rm && d2f(px, py, pz, cx[u], cy[u], cz[u]) < TOL2) {
+                int a = uf_find<false>(parent, ri), b = uf_find<false>(parent, cr[u]);
                 while (a != b) {
                     const int hi = max(a, b), lo = min(a, b);
                     const int old = atomicCAS(&parent[hi], hi, lo);
                     if (old == hi) { a = lo; break; }
-                    a = uf_find(parent, a); b = uf_find(parent, b);
+                    a = uf_find<true>(parent, a); b = uf_find<true>(parent, b);
                 }
                 ri = a;
+                rm = cr[u];
             }
         }
+    }
     }
 }
 
@@ -399,9 +497,10 @@ int rdet3d_create(const rdet3d_options *opt, const double s2b[3], int max_points
         DET3_TRY(h, hipSetDevice(device));
         DET3_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         DET3_TRY(h, hipMalloc(&h->d_xyzi, 16 * np));
-        DET3_TRY(h, hipMalloc(&h->d_p1, 12 * np));
-        DET3_TRY(h, hipMalloc(&h->d_p2, 12 * np));
-        DET3_TRY(h, hipMalloc(&h->d_dist, 4 * np));
+        // + 1024 floats: the sweeps read candidates eight at a time through the scalar cache, unclamped, up to a few groups past the end
+        DET3_TRY(h, hipMalloc(&h->d_p1, 12 * np + 4096)); DET3_TRY(h, hipMemset(h->d_p1, 0, 12 * np + 4096));
+        DET3_TRY(h, hipMalloc(&h->d_p2, 12 * np + 4096)); DET3_TRY(h, hipMemset(h->d_p2, 0, 12 * np + 4096));
+        DET3_TRY(h, hipMalloc(&h->d_dist, 4 * np + 4096)); DET3_TRY(h, hipMemset(h->d_dist, 0, 4 * np + 4096));
         DET3_TRY(h, hipMalloc(&h->d_label, 4 * np));
         DET3_TRY(h, hipMalloc(&h->d_cnt, 4 * np));
         DET3_TRY(h, hipMalloc(&h->d_last, 4 * np));
@@ -444,10 +543,15 @@ int rdet3d_handle_cloud(rdet3d_t *h, double stamp, const float *xyzi, int N, flo
     B.xyzi = h->d_xyzi; B.p1 = h->d_p1; B.p2 = h->d_p2; B.dist = h->d_dist; B.label = h->d_label; B.cnt = h->d_cnt; B.last = h->d_last;
     B.ctl = h->d_ctl; B.cap = h->max_points;
     const int blocks = (N + 63) / 64;                                 // 64 query points per workgroup; M <= N stays on the device
-    hipLaunchKernelGGL(k3_filter, dim3(1), dim3(1024), 0, h->stream, B, N, h->opt.intensity_min);
-    hipLaunchKernelGGL(k3_knn, dim3(blocks), dim3(256), 0, h->stream, B);
+    const int ftiles = N > 0 ? (N + 1023) / 1024 : 1;
+    hipLaunchKernelGGL(k3_filter_count, dim3(ftiles), dim3(1024), 0, h->stream, B, N, h->opt.intensity_min);
+    hipLaunchKernelGGL(k3_filter_write, dim3(ftiles), dim3(1024), 0, h->stream, B, N, h->opt.intensity_min);
+    hipLaunchKernelGGL(k3_knn, dim3(blocks), dim3(64 * KNN_WAVES), 0, h->stream, B);
     hipLaunchKernelGGL(k3_sor, dim3(1), dim3(1024), 0, h->stream, B);
-    hipLaunchKernelGGL(k3_cc, dim3(blocks), dim3(256), 0, h->stream, B);
+    const int cc_blocks = blocks < 256 ? blocks : 256;                 // grid-stride over the query tiles: M2 is only known on the device
+    hipLaunchKernelGGL(k3_cc_min, dim3(cc_blocks), dim3(64 * CC_WAVES), 0, h->stream, B);
+    hipLaunchKernelGGL(k3_cc_jump, dim3((h->max_points + 255) / 256), dim3(256), 0, h->stream, B);
+    hipLaunchKernelGGL(k3_cc_link, dim3(cc_blocks), dim3(64 * CC_WAVES), 0, h->stream, B);
     const float sa = (float)h->s2b[2];
     hipLaunchKernelGGL(k3_finish, dim3(1), dim3(1024), 0, h->stream, B, (float)h->s2b[0], (float)h->s2b[1], cosf(sa),
                        sinf(sa), max_centers < RDET_MAX_CENTERS ? max_centers : RDET_MAX_CENTERS);
