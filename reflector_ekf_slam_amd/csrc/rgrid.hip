@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void kg_first(const int2 *__restrict__ key, in
     for (int j0 = jbase; j0 < jend; j0 += 8) {
         int2 c[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) c[u] = key[min(j0 + u, n - 1)];   // uniform addresses: scalar loads
+        for (int u = 0; u < 8; ++u) c[u] = key[j0 + u];   // uniform, CONTIGUOUS addresses: one s_load_dwordx16 (a clamp per element would
+                                                           // split it into eight loads); entries past n are padding, masked by j0 + u < i
 #pragma unroll
         for (int u = 0; u < 8; ++u) dup |= (j0 + u < i) && c[u].x == k.x && c[u].y == k.y;
     }
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void kg_first_b(const int2 *__restrict__ key_a
     for (int j0 = jbase; j0 < jend; j0 += 8) {
         int2 c[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) c[u] = key[min(j0 + u, n - 1)];
+        for (int u = 0; u < 8; ++u) c[u] = key[j0 + u];
 #pragma unroll
         for (int u = 0; u < 8; ++u) dup |= (j0 + u < i) && c[u].x == k.x && c[u].y == k.y;
     }
@@ -973,8 +974,8 @@ int rgrid_create(int max_points, int max_cells, int max_candidates, int device, 
         G_TRY(h, hipSetDevice(device));
         G_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         G_TRY(h, hipMalloc(&h->d_in, 8 * np)); G_TRY(h, hipMalloc(&h->d_a, 8 * np)); G_TRY(h, hipMalloc(&h->d_b, 8 * np));
-        G_TRY(h, hipMalloc(&h->d_key, 8 * np)); G_TRY(h, hipMalloc(&h->d_keep, np));
-        G_TRY(h, hipMalloc(&h->d_key_b, 8 * np * VOX_BATCH)); G_TRY(h, hipMalloc(&h->d_keep_b, np * (VOX_BATCH + 1)));
+        G_TRY(h, hipMalloc(&h->d_key, 8 * np + 64)); G_TRY(h, hipMemset(h->d_key, 0, 8 * np + 64)); G_TRY(h, hipMalloc(&h->d_keep, np));   // + one read-ahead group
+        G_TRY(h, hipMalloc(&h->d_key_b, 8 * np * VOX_BATCH + 64)); G_TRY(h, hipMemset(h->d_key_b, 0, 8 * np * VOX_BATCH + 64)); G_TRY(h, hipMalloc(&h->d_keep_b, np * (VOX_BATCH + 1)));
         G_TRY(h, hipMalloc(&h->d_counts, sizeof(int) * VOX_BATCH)); G_TRY(h, hipHostMalloc(&h->h_counts, sizeof(int) * VOX_BATCH));
         G_TRY(h, hipMalloc(&h->d_cs, 8 * (size_t)max_candidates));
         G_TRY(h, hipMalloc(&h->d_idx, 8 * (np * 1024 + 64)));                // up to 1024 rotated scans of max_points points (+ read-ahead pad)
