@@ -435,16 +435,25 @@ __global__ __launch_bounds__(1024) void k3_finish(Det3dBufs B, float sx, float s
 #pragma clang fp contract(off)
         const int root = s_root[cidx], last = B.last[root];
         float cx = 0.f, cy = 0.f;
-        for (int b0 = root; b0 <= last; b0 += 64) {
-            const int i = b0 + lane;
-            const bool mem = i <= last && B.label[i] == root;
-            const float x = mem ? X[i] : 0.f, y = mem ? Y[i] : 0.f;
-            unsigned long long mask = __ballot(mem);
-            while (mask) {
-                const int b = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                cx += __shfl(x, b, 64);
-                cy += __shfl(y, b, 64);
+        // a component's members sit in one stripe per scan ring, far apart in index: most 64-point chunks hold none, so
+        // four chunks' labels are fetched per round trip and only the chunks with members pay for the coordinates
+        for (int b0 = root; b0 <= last; b0 += 256) {
+            int lab[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = b0 + 64 * u + lane; lab[u] = (i <= last) ? B.label[i] : -1; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = b0 + 64 * u + lane;
+                const bool mem = lab[u] == root;
+                unsigned long long mask = __ballot(mem);
+                if (mask == 0ull) continue;
+                const float x = mem ? X[i] : 0.f, y = mem ? Y[i] : 0.f;
+                while (mask) {
+                    const int b = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    cx += __shfl(x, b, 64);
+                    cy += __shfl(y, b, 64);
+                }
             }
         }
         if (lane == 0) {
