@@ -14,8 +14,8 @@
 //   k3_cc_*       EuclideanClusterExtraction as connected components of the radius-0.2 m graph: smallest-neighbour
 //                 pointers, a snapshot of the chain tops, then a lock-free union-find for the few adjacent pairs whose
 //                 tops differ (roots are only ever hooked under smaller roots: the label is the smallest index) (:65-74)
-//   k3_finish     component sizes, size gate [4,160], order (size desc, first index asc),
-//                 float32 centroids in index order (one wave per component), Rigid2f to base_link (:77-97)
+//   k3_finish     component sizes, size gate [4,160], order (size desc, first index asc)
+//   k3_centroids  float32 centroids in index order (one wave per component, spread over the CUs), Rigid2f to base_link (:77-97)
 //
 // No kd-tree: after the intensity gate a cloud holds 10^2..10^4 points, for which the
 // all-pairs distance sweep is a coalesced, LDS-tiled, embarrassingly parallel kernel, while a
@@ -41,6 +41,7 @@ constexpr int MIN_SZ = 4, MAX_SZ = 160;      // :70-71
 struct Det3dCtl {
     int M, M2, K, err;
     float centers[2 * RDET_MAX_CENTERS];
+    int croot[RDET_MAX_CENTERS], csize[RDET_MAX_CENTERS], crank[RDET_MAX_CENTERS];   // accepted components: k3_finish -> k3_centroids
 };
 
 struct Det3dBufs {
@@ -388,13 +389,13 @@ __global__ __launch_bounds__(64 * CC_WAVES) void k3_cc_link(Det3dBufs B)
 }
 
 // ---- sizes, gate, order, centroids ------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k3_finish(Det3dBufs B, float sx, float sy, float cs, float sn, int max_centers)
+__global__ __launch_bounds__(1024) void k3_finish(Det3dBufs B, int max_centers)
 {
     __shared__ int s_root[RDET_MAX_CENTERS], s_size[RDET_MAX_CENTERS], s_rank[RDET_MAX_CENTERS];
     __shared__ int wsum[16];
     __shared__ int base;
     __shared__ int s_err;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int M2 = B.ctl->M2;
     if (tid == 0) { base = 0; s_err = 0; }
     __syncthreads();
@@ -429,41 +430,50 @@ __global__ __launch_bounds__(1024) void k3_finish(Det3dBufs B, float sx, float s
         s_rank[tid] = rank;
     }
     __syncthreads();
-    // centroids: one wave per component; members are found 64 at a time, the float32 sums run in index order (:94)
-    const float *X = B.p2, *Y = B.p2 + B.cap;
-    for (int cidx = wave; cidx < n; cidx += 16) {
+    if (tid < n) { B.ctl->croot[tid] = s_root[tid]; B.ctl->csize[tid] = s_size[tid]; B.ctl->crank[tid] = s_rank[tid]; }
+    if (tid == 0) B.ctl->K = n;
+}
+
+// Centroids: one WAVE per accepted component, four per workgroup, spread over the CUs (inside the single workgroup of
+// k3_finish sixteen waves took turns on up to 256 components).  Members are found 64 at a time; the float32 sums run in
+// index order (:94).
+__global__ __launch_bounds__(256) void k3_centroids(Det3dBufs B, float sx, float sy, float cs, float sn)
+{
 #pragma clang fp contract(off)
-        const int root = s_root[cidx], last = B.last[root];
-        float cx = 0.f, cy = 0.f;
-        // a component's members sit in one stripe per scan ring, far apart in index: most 64-point chunks hold none, so
-        // four chunks' labels are fetched per round trip and only the chunks with members pay for the coordinates
-        for (int b0 = root; b0 <= last; b0 += 256) {
-            int lab[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cidx = blockIdx.x * 4 + wave;
+    if (cidx >= B.ctl->K) return;
+    const float *X = B.p2, *Y = B.p2 + B.cap;
+    const int root = B.ctl->croot[cidx], last = B.last[root];
+    float cx = 0.f, cy = 0.f;
+    // a component's members sit in one stripe per scan ring, far apart in index: most 64-point chunks hold none, so
+    // four chunks' labels are fetched per round trip and only the chunks with members pay for the coordinates
+    for (int b0 = root; b0 <= last; b0 += 256) {
+        int lab[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int i = b0 + 64 * u + lane; lab[u] = (i <= last) ? B.label[i] : -1; }
+        for (int u = 0; u < 4; ++u) { const int i = b0 + 64 * u + lane; lab[u] = (i <= last) ? B.label[i] : -1; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = b0 + 64 * u + lane;
-                const bool mem = lab[u] == root;
-                unsigned long long mask = __ballot(mem);
-                if (mask == 0ull) continue;
-                const float x = mem ? X[i] : 0.f, y = mem ? Y[i] : 0.f;
-                while (mask) {
-                    const int b = __ffsll((long long)mask) - 1;
-                    mask &= mask - 1;
-                    cx += __shfl(x, b, 64);
-                    cy += __shfl(y, b, 64);
-                }
+        for (int u = 0; u < 4; ++u) {
+            const int i = b0 + 64 * u + lane;
+            const bool mem = lab[u] == root;
+            unsigned long long mask = __ballot(mem);
+            if (mask == 0ull) continue;
+            const float x = mem ? X[i] : 0.f, y = mem ? Y[i] : 0.f;
+            while (mask) {
+                const int b = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                cx += __shfl(x, b, 64);
+                cy += __shfl(y, b, 64);
             }
         }
-        if (lane == 0) {
-            cx /= (float)s_size[cidx]; cy /= (float)s_size[cidx];
-            const int r = s_rank[cidx];
-            B.ctl->centers[2 * r] = (cs * cx + (-sn) * cy) + sx;                // :96 Project2D(s2b).cast<float>() * p
-            B.ctl->centers[2 * r + 1] = (sn * cx + cs * cy) + sy;
-        }
     }
-    if (tid == 0) B.ctl->K = n;
+    if (lane == 0) {
+        const float sz = (float)B.ctl->csize[cidx];
+        cx /= sz; cy /= sz;
+        const int r = B.ctl->crank[cidx];
+        B.ctl->centers[2 * r] = (cs * cx + (-sn) * cy) + sx;                    // :96 Project2D(s2b).cast<float>() * p
+        B.ctl->centers[2 * r + 1] = (sn * cx + cs * cy) + sy;
+    }
 }
 
 }  // namespace
@@ -562,8 +572,8 @@ int rdet3d_handle_cloud(rdet3d_t *h, double stamp, const float *xyzi, int N, flo
     hipLaunchKernelGGL(k3_cc_jump, dim3((h->max_points + 255) / 256), dim3(256), 0, h->stream, B);
     hipLaunchKernelGGL(k3_cc_link, dim3(cc_blocks), dim3(64 * CC_WAVES), 0, h->stream, B);
     const float sa = (float)h->s2b[2];
-    hipLaunchKernelGGL(k3_finish, dim3(1), dim3(1024), 0, h->stream, B, (float)h->s2b[0], (float)h->s2b[1], cosf(sa),
-                       sinf(sa), max_centers < RDET_MAX_CENTERS ? max_centers : RDET_MAX_CENTERS);
+    hipLaunchKernelGGL(k3_finish, dim3(1), dim3(1024), 0, h->stream, B, max_centers < RDET_MAX_CENTERS ? max_centers : RDET_MAX_CENTERS);
+    hipLaunchKernelGGL(k3_centroids, dim3(RDET_MAX_CENTERS / 4), dim3(256), 0, h->stream, B, (float)h->s2b[0], (float)h->s2b[1], cosf(sa), sinf(sa));
     DET3_TRY(h, hipMemcpyAsync(h->h_ctl, h->d_ctl, sizeof(Det3dCtl), hipMemcpyDeviceToHost, h->stream));
     DET3_TRY(h, hipStreamSynchronize(h->stream));
     if (h->h_ctl->err) return h->h_ctl->err;
