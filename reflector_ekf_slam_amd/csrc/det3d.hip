@@ -139,10 +139,13 @@ __device__ static inline void knn_insert(float (&L)[KNN], float x)
         L[q] = lo;
     }
 }
-constexpr int KNN_WAVES = 4;        // waves sharing the candidates of 64 queries
+constexpr int KNN_WAVES = 8;        // waves sharing the candidates of 64 queries
+constexpr int KNN_TILE = 128;       // candidates per tile (the unit dealt to the waves)
+
 __global__ __launch_bounds__(64 * KNN_WAVES) void k3_knn(Det3dBufs B)
 {
     __shared__ float part[KNN_WAVES / 2][KNN][64];   // hand-over buffers of the merge tree
+    __shared__ float thr[KNN_WAVES][64];             // every wave's current 31st-smallest distance per query (see below)
     const int M = B.ctl->M;
     const int q0 = blockIdx.x * 64;
     if (q0 >= M) return;
@@ -154,7 +157,13 @@ __global__ __launch_bounds__(64 * KNN_WAVES) void k3_knn(Det3dBufs B)
     float L[KNN];
 #pragma unroll
     for (int q = 0; q < KNN; ++q) L[q] = INFINITY;
-    const int ntiles = (M + 255) / 256, qt = q0 / 256;
+    // The waves see disjoint candidates, so each one's list alone tightens four times slower than the true one would --
+    // and the insertion chain runs for every candidate that ANY lane still admits.  But a wave's 31st-smallest value is an
+    // upper bound of the final one whatever subset it has seen, so the waves publish theirs and admit only below the
+    // smallest: no barrier needed, a stale (larger) bound is still a bound; the merged multiset stays exact.
+    thr[wave][lane] = INFINITY;
+    float tau = INFINITY;
+    const int ntiles = (M + KNN_TILE - 1) / KNN_TILE, qt = q0 / KNN_TILE;
     // tiles by distance from the queries' tile: qt, qt+1, qt-1, qt+2, ...; wave w takes every 4th of them.
     // A candidate is the same for all 64 lanes: its coordinates come through the SCALAR cache (uniform
     // addresses -> s_load), eight at a time, and enter the VALU as SGPR operands: no LDS, no vector loads.
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(64 * KNN_WAVES) void k3_knn(Det3dBufs B)
         const int t = (k & 1) ? qt + (k + 1) / 2 : qt - k / 2;
         if (t < 0 || t >= ntiles) continue;
         if ((valid++ % KNN_WAVES) != wave) continue;
-        const int j0 = 256 * t, jn = min(256, M - j0);
+        const int j0 = KNN_TILE * t, jn = min(KNN_TILE, M - j0);
         float nx[8], ny[8], nz[8];                            // the next group of eight is loaded while this one is used
 #pragma unroll
         for (int u = 0; u < 8; ++u) { const int j = j0 + u; nx[u] = X[j]; ny[u] = Y[j]; nz[u] = Z[j]; }   // contiguous: ONE s_load_dwordx8 per array (a clamp per element would split it); reads past M stay inside the padded buffers
@@ -178,8 +187,15 @@ __global__ __launch_bounds__(64 * KNN_WAVES) void k3_knn(Det3dBufs B)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const float d2 = d2f(px, py, pz, cx[u], cy[u], cz[u]);
-                const bool need = (c0 + u < jn) && d2 < L[KNN - 1];
+                const bool need = (c0 + u < jn) && d2 < L[KNN - 1] && d2 < tau;
                 if (__any(need)) knn_insert(L, need ? d2 : INFINITY);
+            }
+            if ((c0 & 31) == 24) {                              // every 32 candidates: publish / refresh the shared bound
+                thr[wave][lane] = L[KNN - 1];
+                float t = thr[0][lane];
+#pragma unroll
+                for (int w = 1; w < KNN_WAVES; ++w) t = fminf(t, thr[w][lane]);
+                tau = t;
             }
         }
     }
