@@ -7,9 +7,9 @@
 //   k3_filter_*   intensity > threshold, order-preserving compaction (a workgroup per 1024-point tile: counts, then
 //                 ballot scan + write; coalesced 16-byte reads)                        (:31-39)
 //   k3_knn        StatisticalOutlierRemoval part 1: per point the MeanK+1 = 31 smallest float32
-//                 squared distances (the query first), brute force over LDS-staged candidate
-//                 tiles; lane = point, the sorted list lives in registers (min/max insertion
-//                 chain), four waves share the candidates of 64 points                  (:43-47)
+//                 squared distances (the query first), brute force; lane = point, candidates through the
+//                 scalar cache, the sorted list lives in registers (min/max insertion chain), eight waves
+//                 share the candidates of 64 points and one admission bound          (:43-47)
 //   k3_sor        part 2: mean / (n-1)-variance in FP64, threshold, second compaction
 //   k3_cc_*       EuclideanClusterExtraction as connected components of the radius-0.2 m graph: smallest-neighbour
 //                 pointers, a snapshot of the chain tops, then a lock-free union-find for the few adjacent pairs whose
@@ -123,11 +123,11 @@ __global__ __launch_bounds__(1024) void k3_filter_write(Det3dBufs B, int N, doub
 }
 
 // ---- SOR part 1: mean distance to the MeanK nearest neighbours ---------------------------------
-// One workgroup = 64 query points (lane = point) x 4 waves, each wave sweeping a quarter of the candidate
+// One workgroup = 64 query points (lane = point) x KNN_WAVES waves, each wave sweeping its share of the candidate
 // tiles (in order of index distance from the queries' own tile: scan order is spatially coherent, so the
 // lists tighten early).  The MeanK+1 smallest squared distances live in REGISTERS as a sorted list; a
-// candidate enters through a min/max chain that runs only when some lane of the wave needs it.  The four
-// partial lists are merged through LDS by wave 0.  The multiset of the 31 smallest values is exact, so the
+// candidate enters through a min/max chain that runs only when some lane of the wave needs it.  The partial
+// lists are merged through LDS in a tree.  The multiset of the 31 smallest values is exact, so the
 // ascending-order FP64 sum below is bit-identical to the insertion-sort reference.
 constexpr int KNN = MEAN_K + 1;
 __device__ static inline void knn_insert(float (&L)[KNN], float x)
