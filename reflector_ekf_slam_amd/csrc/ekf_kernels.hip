@@ -1018,10 +1018,9 @@ __global__ __launch_bounds__(512) void k_gain(RekfDev d)
 #define DT 64
 #define DKC 64
 #define DD_STG (DKC * 32 / 256)      // 16-byte panel pieces per thread per panel
-#ifndef DD_NBUF
-#define DD_NBUF 2                    // LDS panel buffers per workgroup (2: 128 KiB, one workgroup per CU, one barrier per tile; 1: 64 KiB, two per CU)
-#endif
-#define DD_WG_PER_CU (DD_NBUF == 1 ? 2 : 1)
+#define DD_NBUF 2                    // LDS panel buffers per workgroup: 128 KiB, one workgroup per CU, one barrier per tile
+                                     // (a single-buffer variant, 64 KiB and two workgroups per CU, measured 24.2 us and was dropped)
+#define DD_WG_PER_CU 1
 
 __device__ static inline void dd_lds_barrier() { lds_barrier(); }
 
@@ -1410,7 +1409,6 @@ __device__ static void downdate_body(const RekfDev &d, double *dd_smem, DdBorder
             DMARK();
             store_tile(tile);                 // (C) drains under the next tile
             DMARK();
-            if (DD_NBUF == 1) dd_lds_barrier();       // single LDS buffer: everyone is done reading it
             write_panels(item + 1, (item + 1) & 1);   // (D) staged panels -> LDS
             DMARK();
             acc_from_pnext();
@@ -1459,7 +1457,6 @@ __device__ static void downdate_body(const RekfDev &d, double *dd_smem, DdBorder
             strip_finish(item);
             if (chunk == nchunk - 1) store_tile(tile);
             if (has_next) {
-                if (DD_NBUF == 1) dd_lds_barrier();
                 write_panels(item + 1, (item + 1) & 1);
                 if (next_new_tile) acc_from_pnext();
                 dd_lds_barrier();
