@@ -1603,19 +1603,23 @@ void rekf_launch_gain(const RekfDev &d, int n_ub, hipStream_t s)
 }
 void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s)
 {
-    // persistent: one workgroup per CU (128 KiB of LDS each), never more workgroups than tiles
-    static int n_cu = 0;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // persistent: one workgroup per CU (128 KiB of LDS each), never more workgroups than tiles.  The opt-in to more than
+    // 64 KiB of dynamic LDS and the CU count are per DEVICE: a process may hold handles on several GPUs.
+    constexpr int MAX_DEV = 64;
+    static int n_cu_of[MAX_DEV] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int slot = (dev >= 0 && dev < MAX_DEV) ? dev : 0;
+    if (n_cu_of[slot] == 0 || dev != slot) {
         hipDeviceProp_t prop;
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
+        int cu = 0;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cu = prop.multiProcessorCount;
+        if (cu <= 0) cu = 256;
         (void)hipFuncSetAttribute((const void *)k_downdate, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   DD_NBUF * 2 * DKC * 64 * (int)sizeof(double));
-        attr_set = true;
+        n_cu_of[slot] = cu;
     }
+    const int n_cu = n_cu_of[slot];
     const int T = (n_ub + DT - 1) / DT;
     const int slots = n_cu * DD_WG_PER_CU;
     int grid = (T * T < slots) ? T * T : slots;
