@@ -58,6 +58,12 @@ struct Det2dOut {
     int K, n_returns, n_runs, err;
     float centers[2 * RDET_MAX_CENTERS];
 };
+// hand-over from the single-workgroup state machine (k_det2d) to the per-beam and per-cluster launches
+struct Det2dMid {
+    int K, off, n_cloud, pad;
+    int seg[4 * RDET_MAX_CENTERS + 8];       // cluster segments: first0, last0, first1, last1
+    double inv[5];                           // inverse scan-end pose (x, y, angle), cos / sin of that angle
+};
 
 struct Det2dBufs {
     const float *ranges, *intens, *ang, *cosv, *sinv;
@@ -72,6 +78,7 @@ struct Det2dBufs {
     int *run_first, *run_last, *run_acc;
     float2 *returns;
     Det2dOut *out;
+    Det2dMid *mid;
 };
 
 // ---- Rigid2 algebra (rigid_transform.h:46-51,62-67,87-102), no FMA contraction -------------
@@ -369,74 +376,95 @@ __global__ __launch_bounds__(1024) void k_det2d(Det2dArgs A, Det2dBufs B)
         B.out->K = K; B.out->n_returns = n_cloud; B.out->n_runs = n_runs; B.out->err = err;
     }
     __syncthreads();
+    // hand-over: everything after this point is per beam or per cluster and runs as two wide launches (in this one
+    // workgroup it was FP64 trigonometry for 3600 beams on a single CU: 55 of the kernel's 95 k cycles)
+    Det2dMid *M = B.mid;
+    if (tid == 0) { M->K = s_tot[0]; M->off = s_tot[1]; M->n_cloud = n_cloud; }
+    if (tid < 5) M->inv[tid] = s_pose[tid];
+    for (int q = tid; q < 4 * RDET_MAX_CENTERS + 8; q += 1024) M->seg[q] = s_cl[q];
+}
+
+// ---- per beam: de-skew into the scan-end frame (:246-258) and, for the beams of an accepted cluster, their
+// contribution to the centre (:277-299).  A beam finds its cluster by bisection: the clusters' first segments are in
+// ascending beam order (run order); the wrapped second segment of the first cluster is tested on its own.
+__global__ __launch_bounds__(256) void k_det2d_beams(Det2dArgs A, Det2dBufs B)
+{
+    __shared__ int s_cl[4 * RDET_MAX_CENTERS + 8];
+    const Det2dMid *M = B.mid;
+    const int n_cloud = M->n_cloud;
     if (n_cloud == 0) return;
-    const R2d inv = {s_pose[0], s_pose[1], s_pose[2]};
-    const double inv_c = s_pose[3], inv_s = s_pose[4];
+    const int K = M->K, off = M->off, N = A.N;
+    for (int q = threadIdx.x; q < 4 * RDET_MAX_CENTERS + 8; q += 256) s_cl[q] = M->seg[q];
+    const R2d inv = {M->inv[0], M->inv[1], M->inv[2]};
+    const double inv_c = M->inv[3], inv_s = M->inv[4];
     const R2f to_base = r2_cast(inv);
-
-    // ---- de-skew every point into the scan-end frame (:246-258)
-    for (int i = tid; i < N; i += 1024) {
-        if (!(B.flags[i] & 1)) continue;
-        const R2d pose = extrapolator_pose(A, (double)B.pt_t[i]);
-        const R2f rel = r2_cast(r2_mul_cs(inv_c, inv_s, inv, pose));
-        const float2 p = B.pt[i];
-        B.returns[B.cloud_idx[i]] = r2f_apply(rel, p.x, p.y);
-    }
-
-    // ---- cluster centres (:277-306).  The expensive part of a member beam -- its own extrapolated pose
-    // (FP64 trigonometry) -- is computed for all member beams in parallel; the float32 running sum in beam
-    // order that the reference takes (:300-305) is then a chain of plain additions, one wave per cluster.
-    const int K = s_tot[0], off = s_tot[1];
     const float tb_c = cosf(to_base.a), tb_s = sinf(to_base.a);
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int c = wave; c < K; c += 16) {                      // mark the member beams (bit 16), one wave per cluster
-        const int k = c + off;
-        for (int seg = 0; seg < 2; ++seg) {
-            const int fi = s_cl[4 * k + 2 * seg], li = s_cl[4 * k + 2 * seg + 1];
-            if (fi < 0) continue;
-            for (int j = fi + lane; j <= li; j += 64) B.flags[j] |= 16;
-        }
-    }
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int jc = min(j, N - 1);
+    const unsigned char f = B.flags[jc];
+    const int lvj = B.lastvalid[jc], ci = B.cloud_idx[jc];
+    const float rgj = B.ranges[jc], tj = B.pt_t[jc];
+    const float2 pj = B.pt[jc];
     __syncthreads();
-    for (int j = tid; j < N; j += 1024) {
+    if (j >= N) return;
+    if (f & 1) {                                                              // de-skew (:246-258)
+        const R2d pose = extrapolator_pose(A, (double)tj);
+        const R2f rel = r2_cast(r2_mul_cs(inv_c, inv_s, inv, pose));
+        B.returns[ci] = r2f_apply(rel, pj.x, pj.y);
+    }
+    if (K <= 0) return;
+    const int k0 = off, k1 = off + K;
+    bool mem = s_cl[4 * k0 + 2] >= 0 && j >= s_cl[4 * k0 + 2] && j <= s_cl[4 * k0 + 3];
+    if (!mem) {
+        int lo = k0, hi = k1 - 1;                                             // last cluster whose first beam is <= j
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_cl[4 * mid] <= j) lo = mid; else hi = mid - 1; }
+        mem = s_cl[4 * lo] <= j && j <= s_cl[4 * lo + 1];
+    }
+    if (!mem) return;
+    {
 #pragma clang fp contract(off)
-        if (!(B.flags[j] & 16)) continue;
         float2 p; float t;
-        if (B.flags[j] & 2) { const int lvj = B.lastvalid[j]; p = B.pt[lvj]; t = B.pt_t[lvj]; }
-        else if (isinf(B.ranges[j])) continue;                             // :120-121
+        if (f & 2) { p = B.pt[lvj]; t = B.pt_t[lvj]; }
+        else if (isinf(rgj)) return;                                          // :120-121
         else t = gap_time_and_point(A, B, j, p);
-        const R2f pose = r2_cast(extrapolator_pose(A, (double)t));          // :287,:293
+        const R2f pose = r2_cast(extrapolator_pose(A, (double)t));             // :287,:293
         const float2 po = r2f_apply(pose, p.x, p.y);
         B.contrib[j] = r2f_apply_cs(tb_c, tb_s, to_base.x, to_base.y, po.x, po.y);
-        B.flags[j] |= 8;
+        B.flags[j] = f | 8;                                                   // contributes (this thread is the beam's only writer)
     }
-    __syncthreads();
-    for (int c = wave; c < K; c += 16) {
+}
+
+// ---- per cluster: the float32 running sum in beam order that the reference takes (:300-305), one wave per cluster
+__global__ __launch_bounds__(256) void k_det2d_sums(Det2dArgs A, Det2dBufs B)
+{
 #pragma clang fp contract(off)
-        const int k = c + off;
-        float cx = 0.f, cy = 0.f;
-        int count = 0;
-        for (int seg = 0; seg < 2; ++seg) {
-            const int fi = s_cl[4 * k + 2 * seg], li = s_cl[4 * k + 2 * seg + 1];
-            if (fi < 0) continue;
-            for (int j0 = fi; j0 <= li; j0 += 64) {
-                const int j = j0 + lane;
-                const bool mem = j <= li && (B.flags[j] & 8);
-                const float2 v = mem ? B.contrib[j] : make_float2(0.f, 0.f);
-                unsigned long long mask = __ballot(mem);
-                count += __popcll(mask);
-                while (mask) {
-                    const int b = __ffsll((long long)mask) - 1;
-                    mask &= mask - 1;
-                    cx += __shfl(v.x, b, 64);
-                    cy += __shfl(v.y, b, 64);
-                }
+    const Det2dMid *M = B.mid;
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (M->n_cloud == 0 || c >= M->K) return;
+    const int k = c + M->off, N = A.N;
+    float cx = 0.f, cy = 0.f;
+    int count = 0;
+    for (int seg = 0; seg < 2; ++seg) {
+        const int fi = M->seg[4 * k + 2 * seg], li = M->seg[4 * k + 2 * seg + 1];
+        if (fi < 0) continue;
+        for (int j0 = fi; j0 <= li; j0 += 64) {
+            const int j = j0 + lane;
+            const float2 cv2 = B.contrib[min(j, N - 1)];                          // both loads unconditional: one round trip
+            const bool mem = j <= li && (B.flags[min(j, N - 1)] & 8);
+            const float2 v = mem ? cv2 : make_float2(0.f, 0.f);
+            unsigned long long mask = __ballot(mem);
+            count += __popcll(mask);
+            while (mask) {
+                const int b = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                cx += __shfl(v.x, b, 64);
+                cy += __shfl(v.y, b, 64);
             }
         }
-        if (lane == 0) {
-            B.out->centers[2 * c] = cx / (float)count;                           // :305
-            B.out->centers[2 * c + 1] = cy / (float)count;
-        }
+    }
+    if (lane == 0) {
+        B.out->centers[2 * c] = cx / (float)count;                               // :305
+        B.out->centers[2 * c + 1] = cy / (float)count;
     }
 }
 
@@ -455,6 +483,7 @@ struct rdet2d {
     int *d_lastvalid, *d_cloud_idx, *d_prevb, *d_runid, *d_run_first, *d_run_last, *d_run_acc;
     unsigned char *d_flags;
     Det2dOut *d_out, *h_out;           // h_out pinned
+    Det2dMid *d_mid;
     float *h_stage;                    // pinned: ranges | intensities | ang | cos | sin
     // cached beam-angle table key
     float tab_angle_min, tab_inc;
@@ -514,6 +543,7 @@ int rdet2d_create(const rdet2d_options *opt, const double s2b[3], int max_beams,
         DET_TRY(h, hipMalloc(&h->d_run_first, 4 * nb)); DET_TRY(h, hipMalloc(&h->d_run_last, 4 * nb));
         DET_TRY(h, hipMalloc(&h->d_run_acc, 4 * nb)); DET_TRY(h, hipMalloc(&h->d_flags, nb));
         DET_TRY(h, hipMalloc(&h->d_out, sizeof(Det2dOut)));
+        DET_TRY(h, hipMalloc(&h->d_mid, sizeof(Det2dMid)));
         DET_TRY(h, hipHostMalloc(&h->h_out, sizeof(Det2dOut)));
         DET_TRY(h, hipHostMalloc(&h->h_stage, 4 * nb * 5));
         return RDET_OK;
@@ -530,7 +560,7 @@ void rdet2d_destroy(rdet2d_t *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->d_ranges, h->d_intens, h->d_ang, h->d_cos, h->d_sin, h->d_pt_t, h->d_pt, h->d_returns, h->d_contrib,
                     h->d_lastvalid, h->d_cloud_idx, h->d_prevb, h->d_runid, h->d_run_first, h->d_run_last,
-                    h->d_run_acc, h->d_flags, h->d_out};
+                    h->d_run_acc, h->d_flags, h->d_out, h->d_mid};
     for (void *p : ptrs) (void)hipFree(p);
     if (h->h_out) (void)hipHostFree(h->h_out);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -619,8 +649,10 @@ int rdet2d_handle_scan(rdet2d_t *h, double stamp, float angle_min, float angle_m
     B.pt = h->d_pt; B.pt_t = h->d_pt_t; B.lastvalid = h->d_lastvalid; B.cloud_idx = h->d_cloud_idx;
     B.prevb = h->d_prevb; B.runid = h->d_runid; B.flags = h->d_flags;
     B.run_first = h->d_run_first; B.run_last = h->d_run_last; B.run_acc = h->d_run_acc;
-    B.returns = h->d_returns; B.contrib = h->d_contrib; B.out = h->d_out;
+    B.returns = h->d_returns; B.contrib = h->d_contrib; B.out = h->d_out; B.mid = h->d_mid;
     hipLaunchKernelGGL(k_det2d, dim3(1), dim3(1024), 0, h->stream, A, B);
+    hipLaunchKernelGGL(k_det2d_beams, dim3((N + 255) / 256), dim3(256), 0, h->stream, A, B);
+    hipLaunchKernelGGL(k_det2d_sums, dim3(RDET_MAX_CENTERS / 4), dim3(256), 0, h->stream, A, B);
     DET_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, sizeof(Det2dOut), hipMemcpyDeviceToHost, h->stream));
     DET_TRY(h, hipStreamSynchronize(h->stream));
     h->last_n_returns = h->h_out->n_returns;
