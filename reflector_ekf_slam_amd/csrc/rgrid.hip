@@ -454,6 +454,35 @@ __device__ static inline void hermite(double p0, double p1, double p2, double p3
     f = p1 + x * (c + x * (b + x * a));
     dfdx = c + x * (2.0 * b + 3.0 * a * x);
 }
+// All-lanes sum of a double over the wave without touching LDS: DPP inside rows of 16 (quad permutes, half-row and row
+// mirror), then gfx950's v_permlane16_swap / v_permlane32_swap across the rows (each returns both halves of the exchange,
+// so one instruction pair per step serves the low and the high dword).  Six steps, no ds_bpermute, no waitcnt.
+template <int CTRL>
+__device__ static inline double mov_dpp_f64(double v)
+{
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ static inline double wave_sum_f64(double v)
+{
+    v += mov_dpp_f64<0xB1>(v);                          // quad_perm [1,0,3,2]: lane ^ 1
+    v += mov_dpp_f64<0x4E>(v);                          // quad_perm [2,3,0,1]: lane ^ 2
+    v += mov_dpp_f64<0x141>(v);                         // row_half_mirror: the other quad of the half row
+    v += mov_dpp_f64<0x140>(v);                         // row_mirror: the other half row
+    {
+        auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+        auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+        v = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);      // rows 0+1, 2+3
+    }
+    {
+        auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+        auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+        v = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);      // both halves of the wave
+    }
+    return v;
+}
+
 // Partial sums of this wave into part[wave][]: [0] = |r|^2, [1..3] = J'r, [4..9] = J'J (xx xy xt yy yt tt)
 #ifdef RGRID_DEBUG_TIMING
 __shared__ long long edbg[8];
@@ -514,16 +543,8 @@ __device__ static void refine_eval(const RefineArgs &A, const unsigned short *__
         ET_MARK(2);
     }
     ET_MARK(3);
-    // butterfly over the wave, the ten sums side by side: all twenty permutes of a step are in flight together (one sum
-    // at a time, every step waits for its own two)
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        double t[10];
-#pragma unroll
-        for (int k = 0; k < 10; ++k) t[k] = __shfl_xor(acc[k], off, 64);
-#pragma unroll
-        for (int k = 0; k < 10; ++k) acc[k] += t[k];
-    }
+    for (int k = 0; k < 10; ++k) acc[k] = wave_sum_f64(acc[k]);
     if (lane == 0)
         for (int k = 0; k < 10; ++k) part[wave][k] = acc[k];
     ET_MARK(4);
