@@ -134,3 +134,14 @@ def test_session_per_rank_harness_over_gloo_world_size_2(tmp_path, oracle_lib):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "GLOO_OK" in out.stdout
+
+
+@pytest.mark.parametrize("header", ["rekf.h", "rdet.h", "rgrid.h"])
+def test_c_headers_are_plain_c99(header, tmp_path):
+    """The drop-in boundary is a C ABI: every public header must compile as pedantic C99 on its own."""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text(f'#include "{header}"\nint main(void) {{ return 0; }}\n')
+    out = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                          "-o", str(tmp_path / "t.o")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
