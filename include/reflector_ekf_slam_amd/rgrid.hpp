@@ -119,6 +119,18 @@ public:
         t.cells.resize(2 * (size_t)t.width * t.height);
         return t;
     }
+    // mapping::MapBuilder::AddRangeData  (map_builder.cc:57-108) in one call; false where the reference returns nullptr
+    bool AddRangeData(const rgrid_map_builder_options &opt, const std::array<float, 2> &origin, const Cloud &returns, const Cloud &misses,
+                      const std::array<double, 3> &ekf_pose, std::array<double, 3> &local_pose, Cloud *returns_in_local = nullptr)
+    {
+        int status = 0;
+        if (returns_in_local) returns_in_local->assign(returns.size(), 0.f);
+        chk(rgrid_add_range_data(h_, &opt, origin.data(), returns.data(), (int)(returns.size() / 2), misses.data(), (int)(misses.size() / 2),
+                                 ekf_pose.data(), local_pose.data(), returns_in_local ? returns_in_local->data() : nullptr, &status),
+            "AddRangeData");
+        if (status == RGRID_SCAN_INSERTED) { const Limits l = GetLimits(); ncells_ = (size_t)l.num_x_cells * l.num_y_cells; }
+        return status == RGRID_SCAN_INSERTED;
+    }
     rgrid_t *handle() { return h_; }
 
 private:

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define RGRID_ABI_VERSION 2
+#define RGRID_ABI_VERSION 3
 
 enum {
     RGRID_OK = 0,
@@ -148,6 +148,31 @@ typedef struct rgrid_refine_summary {
 int rgrid_refine_match(rgrid_t *h, const rgrid_refine_options *opt, const double target_translation[2],
                        const double initial_pose[3], const float *points_xy, int n, double pose_estimate[3],
                        rgrid_refine_summary *summary);
+
+/* mapping::MapBuilderOptions (include/mapping/map_builder.h:22-30), flattened; defaults = src/ros_node.cc:299-396:
+ * 0.05, 0.025, {0.9, 500, 100}, {0.2, 15 deg in rad, 0.1, 0.1}, {1, 0.1, 0.4, 100, 1}, 0.55, 0.49, 1. */
+typedef struct rgrid_map_builder_options {
+    float resolution;
+    float voxel_filter_size;
+    double adaptive_max_length, adaptive_min_num_points, adaptive_max_range;
+    rgrid_match_options match;
+    rgrid_refine_options refine;
+    float hit_probability, miss_probability;
+    int insert_free_space;
+} rgrid_map_builder_options;
+
+enum { RGRID_SCAN_INSERTED = 0, RGRID_SCAN_DROPPED_EMPTY = 1, RGRID_SCAN_FILTERED_EMPTY = 2 };
+
+/* mapping::MapBuilder::AddRangeData (src/mapping/map_builder.cc:57-108) in one call, on the handle's resident grid (created
+ * on the first call as MapBuilder::CreateGrid does, :112-126: 100 x 100 cells around the first origin): gravity
+ * alignment + voxel filters (:20-32), adaptive filter (:72-73), ScanMatch = correlative match + refinement (:34-55),
+ * InsertIntoSubmap = grow + insert (:110-120).  range_data (origin, returns, misses) is in the tracking frame, ekf_pose =
+ * (x, y, yaw) as the node builds it (src/ros_node.cc:547-549).  local_pose = Project2D(MatchingResult::local_pose);
+ * returns_in_local (nullable, 2 * n_returns floats) = MatchingResult::range_data_in_local.returns.  *status tells what the
+ * reference would have returned: a result (RGRID_SCAN_INSERTED) or nullptr (the other two). */
+int rgrid_add_range_data(rgrid_t *h, const rgrid_map_builder_options *opt, const float origin_xy[2], const float *returns_xy,
+                         int n_returns, const float *misses_xy, int n_misses, const double ekf_pose[3], double local_pose[3],
+                         float *returns_in_local, int *status);
 
 const char *rgrid_strerror(int code);
 const char *rgrid_last_hip_error(rgrid_t *h);

@@ -1338,4 +1338,107 @@ int rgrid_match(rgrid_t *h, const rgrid_match_options *opt, const double initial
     return RGRID_OK;
 }
 
+// ---- mapping::MapBuilder::AddRangeData (src/mapping/map_builder.cc:57-108) as one call ------------------------------
+// Host side = what the reference's host does between the steps: a few rigid transforms (its float32 round trips
+// through Eigen quaternions restated operation by operation, as in reflector_ekf_slam_amd/map_builder.py) and the
+// decisions; every per-point / per-cell step is one of the entry points above.
+namespace {
+float yaw_of_quaternion_f32(float w, float z)          // transform::GetYaw(Quaternionf(w,0,0,z)): q * UnitX = (1 - z 2z, w 2z, 0)
+{
+#pragma clang fp contract(off)
+    const float two_z = z + z;
+    const float y = w * two_z, x = 1.f - z * two_z;
+    return (float)std::atan2((double)y, (double)x);
+}
+double yaw_of_quaternion_f64(double w, double z)
+{
+#pragma clang fp contract(off)
+    const double two_z = z + z;
+    return std::atan2(w * two_z, 1.0 - z * two_z);
+}
+void rigid2f_apply(float tx, float ty, float yaw, const float *in, int n, float *out)   // Rigid2f(t, Rotation2Df(yaw)) * p
+{
+#pragma clang fp contract(off)
+    const float c = (float)std::cos((double)yaw), s = (float)std::sin((double)yaw);
+    for (int i = 0; i < n; ++i) {
+        const float x = in[2 * i], y = in[2 * i + 1];
+        out[2 * i] = (c * x - s * y) + tx;
+        out[2 * i + 1] = (s * x + c * y) + ty;
+    }
+}
+}  // namespace
+
+int rgrid_add_range_data(rgrid_t *h, const rgrid_map_builder_options *opt, const float origin_xy[2], const float *returns_xy,
+                         int n_returns, const float *misses_xy, int n_misses, const double ekf_pose[3], double local_pose[3],
+                         float *returns_in_local, int *status)
+{
+#pragma clang fp contract(off)
+    if (!h || !opt || !origin_xy || !ekf_pose || !local_pose || n_returns < 0 || n_misses < 0 || (n_returns > 0 && !returns_xy) ||
+        (n_misses > 0 && !misses_xy))
+        return RGRID_ERR_INVALID;
+    if (status) *status = RGRID_SCAN_DROPPED_EMPTY;
+    if (n_returns == 0) return RGRID_OK;                                          // "Dropped empty horizontal range data." (:63-67)
+    if (n_returns > h->max_points || n_misses > h->max_points) return RGRID_ERR_CAPACITY;
+    const double x = ekf_pose[0], y = ekf_pose[1], theta = ekf_pose[2];
+    const double qw = std::cos(theta / 2), qz = std::sin(theta / 2);             // the caller's quaternion (src/ros_node.cc:548)
+    // TransformToGravityAlignedFrameAndFilter (:20-32): Rotation(q).cast<float>() -> Project2D -> Rigid2f(0, GetYaw)
+    const float yaw_g = yaw_of_quaternion_f32((float)qw, (float)qz);
+    std::vector<float> ret((size_t)2 * n_returns), mis((size_t)2 * (n_misses > 0 ? n_misses : 1)), fr((size_t)2 * n_returns),
+        fm((size_t)2 * (n_misses > 0 ? n_misses : 1)), av((size_t)2 * n_returns);
+    float org[2];
+    rigid2f_apply(0.f, 0.f, yaw_g, origin_xy, 1, org);
+    rigid2f_apply(0.f, 0.f, yaw_g, returns_xy, n_returns, ret.data());
+    if (n_misses > 0) rigid2f_apply(0.f, 0.f, yaw_g, misses_xy, n_misses, mis.data());
+    int nfr = 0, nfm = 0, nav = 0;
+    int rc = rgrid_voxel_filter(h, ret.data(), n_returns, opt->voxel_filter_size, fr.data(), n_returns, &nfr);
+    if (rc != RGRID_OK) return rc;
+    if (n_misses > 0) { rc = rgrid_voxel_filter(h, mis.data(), n_misses, opt->voxel_filter_size, fm.data(), n_misses, &nfm); if (rc != RGRID_OK) return rc; }
+    // pose_prediction = Project2D(ekf_pose * gravity_alignment.inverse()): the rotations cancel (:70-71)
+    const double prediction[3] = {x, y, 0.0};
+    rc = rgrid_adaptive_voxel_filter(h, fr.data(), nfr, opt->adaptive_max_length, opt->adaptive_min_num_points, opt->adaptive_max_range,
+                                     av.data(), n_returns, &nav);
+    if (rc != RGRID_OK) return rc;
+    if (status) *status = RGRID_SCAN_FILTERED_EMPTY;
+    if (nav == 0) return RGRID_OK;                                               // (:74-77)
+    double est[3] = {prediction[0], prediction[1], prediction[2]};               // ScanMatch (:34-55): no submap yet -> the prediction
+    if (h->have_grid) {
+        double coarse[3], score = 0;
+        rc = rgrid_match(h, &opt->match, prediction, av.data(), nav, coarse, &score, nullptr, nullptr);
+        if (rc != RGRID_OK) return rc;
+        rc = rgrid_refine_match(h, &opt->refine, prediction, coarse, av.data(), nav, est, nullptr);
+        if (rc != RGRID_OK) return rc;
+    }
+    // pose_estimate = Embed3D(pose_estimate_2d) * gravity_alignment: quaternion product about z, in double (:86-87)
+    const double aw = std::cos(0.5 * est[2]), az = std::sin(0.5 * est[2]);
+    const double pw = aw * qw - az * qz, pz = aw * qz + az * qw;
+    local_pose[0] = est[0]; local_pose[1] = est[1]; local_pose[2] = yaw_of_quaternion_f64(pw, pz);
+    if (returns_in_local)                                                         // range_data_in_local (:89-90), the raw returns
+        rigid2f_apply((float)est[0], (float)est[1], yaw_of_quaternion_f32((float)pw, (float)pz), returns_xy, n_returns, returns_in_local);
+    // range_data_in_local2 = TransformRangeData(gravity-aligned filtered data, Embed3D(pose_estimate_2d.cast<float>())) (:92-94)
+    const float af = (float)est[2], ha = 0.5f * af;
+    const float yaw2 = yaw_of_quaternion_f32((float)std::cos((double)ha), (float)std::sin((double)ha));
+    float org2[2];
+    rigid2f_apply((float)est[0], (float)est[1], yaw2, org, 1, org2);
+    rigid2f_apply((float)est[0], (float)est[1], yaw2, fr.data(), nfr, ret.data());
+    if (nfm > 0) rigid2f_apply((float)est[0], (float)est[1], yaw2, fm.data(), nfm, mis.data());
+    if (!h->have_grid) {                                                          // InsertIntoSubmap / CreateGrid (:110-126)
+        const int n0 = 100;                                                      // kInitialSubmapSize
+        if ((long long)n0 * n0 > h->max_cells) return RGRID_ERR_CAPACITY;
+        const double resolution = (double)opt->resolution;                       // `float resolution = options_.resolution`
+        const double half = 0.5 * n0 * resolution;
+        G_TRY(h, hipSetDevice(h->device));
+        G_TRY(h, hipMemsetAsync(h->d_cells, 0, sizeof(uint16_t) * (size_t)n0 * n0, h->stream));
+        G_TRY(h, hipStreamSynchronize(h->stream));
+        h->nx = n0; h->ny = n0; h->resolution = resolution; h->max_x = (double)org2[0] + half; h->max_y = (double)org2[1] + half;
+        h->have_grid = true;
+    }
+    rc = rgrid_grow_as_needed(h, org2, ret.data(), nfr, nfm > 0 ? mis.data() : nullptr, nfm);
+    if (rc != RGRID_OK) return rc;
+    rc = rgrid_insert(h, org2, ret.data(), nfr, nfm > 0 ? mis.data() : nullptr, nfm, opt->hit_probability, opt->miss_probability,
+                      opt->insert_free_space);
+    if (rc != RGRID_OK) return rc;
+    if (status) *status = RGRID_SCAN_INSERTED;
+    return RGRID_OK;
+}
+
 }  // extern "C"

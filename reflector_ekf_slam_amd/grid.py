@@ -54,6 +54,7 @@ def _lib_rgrid():
     L.rgrid_grow_as_needed.argtypes = [vp, vp, vp, C.c_int, vp, C.c_int]
     L.rgrid_get_limits.argtypes = [vp, ip, ip, dp, dp, dp]
     L.rgrid_draw_texture.argtypes = [vp, vp, C.c_long, ip, dp]
+    L.rgrid_add_range_data.argtypes = [vp, C.POINTER(_MapBuilderOptionsC), vp, vp, C.c_int, vp, C.c_int, dp, dp, vp, ip]
     L.rgrid_refine_match.argtypes = [vp, C.POINTER(_RefineOptions), dp, dp, vp, C.c_int, dp, C.POINTER(_RefineSummary)]
     _rgrid = L
     return L
@@ -62,6 +63,12 @@ def _lib_rgrid():
 class _RefineOptions(C.Structure):
     _fields_ = [("occupied_space_weight", C.c_double), ("translation_weight", C.c_double), ("rotation_weight", C.c_double),
                 ("max_num_iterations", C.c_int), ("use_nonmonotonic_steps", C.c_int)]
+
+
+class _MapBuilderOptionsC(C.Structure):
+    _fields_ = [("resolution", C.c_float), ("voxel_filter_size", C.c_float), ("adaptive_max_length", C.c_double),
+                ("adaptive_min_num_points", C.c_double), ("adaptive_max_range", C.c_double), ("match", _MatchOptions),
+                ("refine", _RefineOptions), ("hit_probability", C.c_float), ("miss_probability", C.c_float), ("insert_free_space", C.c_int)]
 
 
 class _RefineSummary(C.Structure):
@@ -226,6 +233,34 @@ class GridFrontEnd:
         self._chk(self._L.rgrid_refine_match(self._h, C.byref(co), tt, ip, pts.ctypes.data_as(C.c_void_p), pts.shape[0], pe,
                                              C.byref(sm)), "RefineMatch")
         return RefineResult(np.array(pe[:]), sm.initial_cost, sm.final_cost, sm.iterations, sm.termination)
+
+    # mapping::MapBuilder::AddRangeData  (map_builder.cc:57-108) as ONE C call (rgrid_add_range_data); `options` is a
+    # map_builder.MapBuilderOptions.  Returns (status, local_pose (x, y, yaw), returns in the local frame): status 0 =
+    # inserted, 1 = no returns, 2 = nothing left after the filters (the reference returns nullptr for 1 and 2).
+    def AddRangeData(self, options, origin_xy, returns_xy, misses_xy, ekf_pose):
+        o = options
+        m, r = o.real_time_scan_matcher_options, o.ceres_scan_matcher_options
+        a, ins = o.adaptive_voxel_options, o.range_data_inserter_options
+        co = _MapBuilderOptionsC(o.resolution, o.voxel_filter_size, a.max_length, a.min_num_points, a.max_range,
+                                 _MatchOptions(m.linear_search_window, m.angular_search_window, m.translation_delta_cost_weight,
+                                               m.rotation_delta_cost_weight),
+                                 _RefineOptions(r.occupied_space_weight, r.translation_weight, r.rotation_weight, int(r.max_num_iterations),
+                                                1 if r.use_nonmonotonic_steps else 0),
+                                 ins.hit_probability, ins.miss_probability, 1 if ins.insert_free_space else 0)
+        org = (C.c_float * 2)(float(origin_xy[0]), float(origin_xy[1]))
+        ret = np.ascontiguousarray(returns_xy, dtype=np.float32).reshape(-1, 2)
+        mis = np.zeros((0, 2), np.float32) if misses_xy is None else np.ascontiguousarray(misses_xy, dtype=np.float32).reshape(-1, 2)
+        pose = (C.c_double * 3)(*[float(v) for v in ekf_pose])
+        out_pose = (C.c_double * 3)()
+        in_local = np.zeros_like(ret)
+        status = C.c_int()
+        self._chk(self._L.rgrid_add_range_data(self._h, C.byref(co), org, ret.ctypes.data_as(C.c_void_p) if ret.size else None, ret.shape[0],
+                                               mis.ctypes.data_as(C.c_void_p) if mis.size else None, mis.shape[0], pose, out_pose,
+                                               in_local.ctypes.data_as(C.c_void_p) if ret.size else None, C.byref(status)), "AddRangeData")
+        if status.value == 0:
+            nx, ny, _, _, _ = self.GetLimits()
+            self._grid_shape = (ny, nx)
+        return status.value, np.array(out_pose[:]), in_local
 
     # ProbabilityGrid::DrawToSubmapTexture  (probability_grid.cc:86-131), without the gzip container
     def DrawTexture(self):

@@ -29,3 +29,16 @@ for name, mb in (("gpu", MapBuilder(MapBuilderOptions(), max_points=16384, max_c
     (cells, lim) = mb.grid()
     print(json.dumps({"backend": name, "scans": n, "returns_per_scan": 3600, "median_ms_per_scan": round(1e3 * float(np.median(times[1:])), 3),
                       "grid": [lim[0], lim[1]], "iterations_last": mb.last_summary.iterations, "pose_err_last": [float(v) for v in np.abs(r.local_pose - poses[n - 1])]}))
+
+# the same pipeline as ONE C call per scan (rgrid_add_range_data)
+from reflector_ekf_slam_amd.grid import GridFrontEnd
+fe = GridFrontEnd(max_points=16384, max_cells=2048 * 2048)
+opt = MapBuilderOptions()
+times = []
+for k in range(nscans):
+    t0 = time.perf_counter()
+    st, pose, _ = fe.AddRangeData(opt, scans[k][0].origin, scans[k][0].returns, scans[k][0].misses, scans[k][1])
+    times.append(time.perf_counter() - t0)
+lim = fe.GetLimits()
+print(json.dumps({"backend": "gpu_one_c_call", "scans": nscans, "returns_per_scan": 3600, "median_ms_per_scan": round(1e3 * float(np.median(times[1:])), 3),
+                  "grid": [lim[0], lim[1]], "pose_err_last": [float(v) for v in np.abs(pose - poses[nscans - 1])]}))

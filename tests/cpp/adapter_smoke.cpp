@@ -47,6 +47,18 @@ int main(int argc, char **)
             std::printf("FAIL grid known=%zu thin=%zu score=%f pe=%f\n", known, thin.size() / 2, score, pe[0]);
             return 1;
         }
+        {   // MapBuilder::AddRangeData as one call on a fresh handle: two scans of the same wall
+            rekfpp::GridFrontEnd mbf(4096, 512 * 512, 1 << 16);
+            rgrid_map_builder_options mo2{0.05f, 0.025f, 0.9, 100, 50.0, {0.2, 0.26, 1e-1, 1e-1}, {1.0, 0.1, 0.4, 100, 1}, 0.55f, 0.49f, 1};
+            std::array<double, 3> lp{};
+            rekfpp::GridFrontEnd::Cloud local;
+            const bool ok1 = mbf.AddRangeData(mo2, {0.f, 0.f}, wall, {}, {0.0, 0.0, 0.0}, lp, &local);
+            const bool ok2 = mbf.AddRangeData(mo2, {0.f, 0.f}, wall, {}, {0.02, -0.01, 0.0}, lp, &local);
+            if (!ok1 || !ok2 || local.size() != wall.size() || std::fabs(lp[0]) > 0.06) {
+                std::printf("FAIL add_range_data ok=%d,%d x=%f\n", (int)ok1, (int)ok2, lp[0]);
+                return 1;
+            }
+        }
         rgrid_refine_options ro{1.0, 0.1, 0.4, 100, 1};
         std::array<double, 3> refined{};
         const rgrid_refine_summary rs = gf.RefineMatch(ro, {0.1, 0.05}, pe, thin, refined);

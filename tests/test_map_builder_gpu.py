@@ -59,3 +59,30 @@ def test_add_range_data_pipeline_matches_the_oracle_composition(oracle_lib):
     ta, tb = gpu.ToSubmapTexture(), ref.ToSubmapTexture()
     assert np.array_equal(ta["cells"], tb["cells"]) and {k: v for k, v in ta.items() if k != "cells"} == {k: v for k, v in tb.items() if k != "cells"}
     assert ta["width"] * ta["height"] * 2 == ta["cells"].size and ta["resolution"] == float(np.float32(0.05))
+
+
+def test_add_range_data_c_entry_point_equals_the_python_mirror():
+    """rgrid_add_range_data (one C call per scan) against reflector_ekf_slam_amd.map_builder.MapBuilder (eight calls with
+    the host logic in Python): same device functions, same host arithmetic -- poses, returned clouds and grids must be
+    identical bit for bit."""
+    from reflector_ekf_slam_amd.grid import GridFrontEnd
+    from reflector_ekf_slam_amd.map_builder import MapBuilder, MapBuilderOptions, RangeData
+    _, _, occ = room_grid()
+    opt = MapBuilderOptions()
+    mb = MapBuilder(opt, max_points=16384, max_cells=2048 * 2048)
+    fe = GridFrontEnd(max_points=16384, max_cells=2048 * 2048)
+    st, _, _ = fe.AddRangeData(opt, np.zeros(2), np.zeros((0, 2), np.float32), None, (0.0, 0.0, 0.0))
+    assert st == 1                                                                    # no returns: dropped
+    rng = np.random.default_rng(23)
+    for k, true in enumerate(_trajectory(6)):
+        pts = scan_of(occ, true, n_points=1500, seed=500 + k).astype(np.float32)
+        ang = rng.uniform(-math.pi, math.pi, 30)
+        misses = np.stack([6.0 * np.cos(ang), 6.0 * np.sin(ang)], 1).astype(np.float32) if k % 2 == 0 else None
+        ekf_pose = true + rng.normal(0, 1, 3) * [0.03, 0.03, 0.01]
+        a = mb.AddRangeData(float(k), RangeData(np.zeros(2, np.float32), pts, np.zeros((0, 2), np.float32) if misses is None else misses), ekf_pose)
+        st, pose, in_local = fe.AddRangeData(opt, np.zeros(2, np.float32), pts, misses, ekf_pose)
+        assert st == 0 and np.array_equal(pose, a.local_pose), (k, pose - a.local_pose)
+        assert np.array_equal(in_local, a.range_data_in_local.returns)
+        ga, la = mb.grid()
+        assert fe.GetLimits() == la and np.array_equal(fe.GetGrid(), ga)
+    fe.close()
