@@ -25,6 +25,7 @@ class _MatchOptions(C.Structure):
 
 
 _rgrid = None
+RGRID_ABI_VERSION = 3            # include/rgrid.h
 
 
 def _lib_rgrid():
@@ -38,6 +39,9 @@ def _lib_rgrid():
     L = C.CDLL(path)
     vp, ip, dp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)
     L.rgrid_abi_version.restype = C.c_int
+    if L.rgrid_abi_version() != RGRID_ABI_VERSION:
+        raise _lib.LibraryMissing(f"{path} has ABI version {L.rgrid_abi_version()}, this package expects {RGRID_ABI_VERSION}: "
+                                  "rebuild it (`python __graft_entry__.py`)")
     L.rgrid_strerror.restype = C.c_char_p
     L.rgrid_strerror.argtypes = [C.c_int]
     L.rgrid_last_hip_error.restype = C.c_char_p
