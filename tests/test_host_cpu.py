@@ -145,3 +145,11 @@ def test_c_headers_are_plain_c99(header, tmp_path):
     out = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
                           "-o", str(tmp_path / "t.o")], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
+
+
+def test_rgrid_abi_version_is_consistent():
+    """include/rgrid.h, the built library and the Python loader agree on the ABI version."""
+    from reflector_ekf_slam_amd import grid
+    text = open(os.path.join(ROOT, "include", "rgrid.h")).read()
+    macro = int(re.search(r"#define\s+RGRID_ABI_VERSION\s+(\d+)", text).group(1))
+    assert macro == grid.RGRID_ABI_VERSION == grid._lib_rgrid().rgrid_abi_version()
