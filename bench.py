@@ -10,21 +10,33 @@ passed by value with the launch; nothing else crosses PCIe in the timed region.
 
     python bench.py --gpus N --steps K --warmup W
 
-For N > 1 the driver launches one rank per GPU with torch.distributed.run; ranks
-run independent sessions (seed + rank, BASELINE.json configs[4]) -- "replicas
-only", no data-path collective -- and rank 0 prints ONE JSON line.
+`--gpus N` with N > 1 and no torchrun environment re-executes itself under
+`python -m torch.distributed.run --nproc-per-node N` (one rank per GPU over RCCL);
+launched by the driver under torchrun it uses the ranks it is given.  Ranks run
+independent sessions (seed + rank, BASELINE.json configs[4]) -- "replicas only", no
+data-path collective: a start barrier, MAX over ranks of the elapsed time and one
+all-gather of a 64-byte result record per rank (reflector_ekf_slam_amd/dist.py).
+Rank 0 prints ONE JSON line.
 
-Extra objects on that line:
-  roofline      the P -= K (H P) kernel (k_downdate): algorithmic bytes per launch
-                (16 n^2 + 8 n (3+m)) / its average launch time,
-                measured with hipEvents on the handle's stream in an instrumented
-                pass over the same K steps.
-  cpu_baseline  the CPU oracle (oracle/ekf_oracle.c, "port") in LITERAL mode -- the
-                dense operation sequence the reference's Eigen expressions execute --
-                timed on this box's host, 1 thread, on a bounded sample of the same
-                steady-state steps, started from the GPU's own state.
-  multi_session aggregate updates/s of 4 independent sessions sharing GPU 0 (a secondary figure for
-                fleet serving; `value` stays the single-session rate).
+Extra objects on that line (rank 0, N = 1 unless noted):
+  roofline       the P -= K (H P) kernel (k_downdate): algorithmic bytes per launch
+                 (16 n^2 + 8 n (3+m)) / its average launch time,
+                 measured live with hipEvents on the handle's stream.  `traffic` is
+                 NOT measured in this run: it is read from the committed rocprofv3
+                 PMC summary and labelled with its source file.
+  latency_us     median / p99 of one update: hipEvent pair around each whole chain
+                 (device) and host wall time of HandleObservationMessage + GetPose.
+  with_5_predicts_per_scan   the same scans with five HandleOdometryMessage
+                 predicts in front of each (the reference's 50 Hz odometry : 10 Hz scans).
+  cpu_baseline   the CPU oracle (oracle/ekf_oracle.c, "port") in LITERAL mode -- the
+                 dense operation sequence the reference's Eigen expressions execute --
+                 timed on this box's host, 1 thread, on its own bounded sample of
+                 steady-state scans (independent of --steps), from the GPU's state.
+  secondary      the same measurement (rate + per-kernel us) at BASELINE.json
+                 configs[1] (C2) and configs[3] (C4: omni odometry; also with the 3D
+                 detector in front of the filter) -- parity-test configs, not `value`.
+  multi_session  aggregate updates/s of 4 independent sessions sharing GPU 0.
+  ranks          (N > 1) per-rank updates/s: min / median / max.
 """
 from __future__ import annotations
 
@@ -35,8 +47,9 @@ import os
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import argparse
+import dataclasses
 import json
-import os
+import socket
 import sys
 import time
 
@@ -49,48 +62,99 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_MFMA_PEAK_TF = 78.6       # MI355X datasheet FP64 matrix (v_mfma_f64_16x16x4_f64: 32 FLOP/clk/SIMD)
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4"])
+    ap.add_argument("--config", default="C3", choices=["C2", "C3", "C4", "T0"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--multi-sessions", type=int, default=4,
                     help="also report the aggregate rate of this many independent sessions sharing GPU 0 (0: skip)")
     ap.add_argument("--cpu-literal-steps", type=int, default=3)
     ap.add_argument("--cpu-structured-steps", type=int, default=60)
-    return ap.parse_args()
+    ap.add_argument("--latency-steps", type=int, default=1000, help="updates in each per-update latency pass (0: skip)")
+    ap.add_argument("--instr-steps", type=int, default=300, help="updates in the per-kernel hipEvent pass")
+    ap.add_argument("--secondary", default="C2,C4", help="comma list of other BASELINE configs to also measure (rank 0, N=1)")
+    ap.add_argument("--secondary-steps", type=int, default=1000)
+    return ap.parse_args(argv)
 
 
-def main():
-    args = parse_args()
-    import torch
+def config_by_name(name):
+    from reflector_ekf_slam_amd import synth
+    if name == "T0":       # tiny: exercises this file's plumbing in the CPU tests (gloo, stub filter)
+        return synth.SessionConfig("T0_N12_obs6", 12, 6, synth.DIFF, seed=77, speed=1.0, row_spacing=6.0)
+    return getattr(synth, name)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or os.environ.get("REKF_BENCH_FORCE_DIST") == "1":   # the env var exercises the RCCL path at world size 1
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
 
-    from reflector_ekf_slam_amd import ReflectorEKFSLAM, synth
+def metric_text(cfg):
+    return f"EKF updates/s at N={cfg.n_landmarks} landmarks, {cfg.obs_per_scan} obs/scan; pose RMSE vs reference"
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` outside torchrun: become N ranks (one per GPU) ourselves."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execvpe(cmd[0], cmd, env)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the part every rank runs (also driven by tests/test_host_cpu.py with a CPU stub filter over gloo)
+# ---------------------------------------------------------------------------------------------------
+def gpu_filter_factory(cfg, sess, device):
+    from reflector_ekf_slam_amd import ReflectorEKFSLAM
     from reflector_ekf_slam_amd import session as S
-    import dataclasses
+    return ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks, device=device)
 
-    base = getattr(synth, args.config)
+
+def build_session(cfg_name, rank, world):
+    from reflector_ekf_slam_amd import synth
+    base = config_by_name(cfg_name)
     cfg = dataclasses.replace(base, seed=base.seed + (10 + rank if world > 1 else 0),
                               name=base.name + (f"_rank{rank}" if world > 1 else ""))
-    sess = synth.make_session(cfg)
+    return base, cfg, synth.make_session(cfg)
+
+
+def timed_region(ekf, scans, warmup, steps, dist_mod, device_sync):
+    """W untimed warm-up steps, then exactly K steps between barrier + sync on both sides.
+    Returns this rank's elapsed seconds and the number of scans consumed."""
+    from reflector_ekf_slam_amd import dist as D
+    it = iter(scans)
+    for _ in range(warmup):
+        t, ob = next(it)
+        ekf.handle_observation(t, ob)
+    D.barrier(dist_mod)
+    device_sync()
+    ekf.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        t, ob = next(it)
+        ekf.handle_observation(t, ob)
+    ekf.sync()
+    device_sync()
+    elapsed = time.perf_counter() - t0
+    D.barrier(dist_mod)
+    return elapsed, warmup + steps
+
+
+def run_rank(args, dist_mod, rank, local_rank, world, make_filter=gpu_filter_factory, device_sync=lambda: None,
+             full=True):
+    """One rank's share of the bench.  `full` = also the rank-0 instrumented legs that need the HIP handle."""
+    from reflector_ekf_slam_amd import dist as D
+    from reflector_ekf_slam_amd import session as S
+    from reflector_ekf_slam_amd import synth
+
+    base, cfg, sess = build_session(args.config, rank, world)
     L = cfg.n_landmarks
     n_expect = 3 + 2 * L
-    ekf = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=L, device=local_rank)
+    ekf = make_filter(cfg, sess, local_rank)
 
     # ---- untimed: build the map (augment path) ---------------------------------
     t0 = time.time()
@@ -101,133 +165,256 @@ def main():
     if n != n_expect:
         raise SystemExit(f"warm-up ended with n={n}, expected {n_expect}")
 
-    steady = synth.steady_state_scans(sess, args.warmup + 2 * args.steps + 8)
+    n_extra = 16 + 2 * max(args.latency_steps, 0) + max(args.instr_steps, 0) + 2 * max(args.steps, 200)
+    steady = synth.steady_state_scans(sess, args.warmup + args.steps + n_extra)
     m = 2 * steady[0][1].shape[0]
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        ekf.sync()
-
-    it = iter(steady)
-    for _ in range(args.warmup):
-        t, ob = next(it)
-        ekf.handle_observation(t, ob)
-
-    # ---- timed region: exactly K steps --------------------------------------------
-    barrier()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        t, ob = next(it)
-        ekf.handle_observation(t, ob)
-    ekf.sync()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t_start
-    if dist is not None:
-        dist.barrier()
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed_max = float(tt.item())
-    else:
-        elapsed_max = elapsed
+    elapsed, used = timed_region(ekf, steady, args.warmup, args.steps, dist_mod, device_sync)
+    elapsed_max = D.max_over_ranks(dist_mod, elapsed)
     mm = ekf.last_match()
-    assert len(mm.new_ids) == 0 and len(mm.state_obs_match_ids) == m // 2, "not steady state"
+    sp = mm[0] if isinstance(mm, tuple) else mm.state_obs_match_ids
+    nw = mm[2] if isinstance(mm, tuple) else mm.new_ids
+    assert len(nw) == 0 and len(sp) == m // 2, "not steady state"
     assert ekf.n == n_expect
+    mu = ekf.mu()
+    recs = D.gather_records(dist_mod, dict(steps=args.steps, elapsed_s=elapsed, final_n=ekf.n, pose_x=mu[0], pose_y=mu[1],
+                                           pose_theta=mu[2], max_abs_err=0.0, seed=cfg.seed))
+    if rank != 0:
+        return None
+    rates = sorted(r["steps"] / r["elapsed_s"] for r in recs)
+    out = {
+        "metric": metric_text(base),
+        "value": D.aggregate_updates_per_s(recs, elapsed_max),
+        "unit": "updates/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed_max / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{base.name}: synthetic 2D session, L={L} landmarks (n={n}), "
+                               f"{m // 2} matched observations/scan (m={m}), "
+                               f"{'diff-drive' if cfg.odom_model == synth.DIFF else 'omni'} odometry, "
+                               "steady-state HandleObservationMessage",
+                   "sessions": world, "parallelism": "replicas: one independent session per GPU",
+                   "map_build_s": round(map_build_s, 3)},
+        "ranks": {"updates_per_s_min": rates[0], "updates_per_s_median": float(np.median(rates)),
+                  "updates_per_s_max": rates[-1], "final_n": [int(r["final_n"]) for r in recs],
+                  "seeds": [int(r["seed"]) for r in recs]},
+    }
+    if not full:
+        return out
+    rest = steady[used:]
+    out.update(instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, local_rank, world))
+    return out
 
-    # ---- secondary figure: several sessions on this GPU (before the instrumented pass litters the runtime with events)
-    ms_result = multi_session(args, cfg, sess, local_rank) if (rank == 0 and args.multi_sessions > 1) else None
 
-    # ---- instrumented pass: per-kernel hipEvent timing over the same number of steps
-    state_for_cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
-        state_for_cpu = ekf.GetState()
+# ---------------------------------------------------------------------------------------------------
+# rank-0 legs that need the HIP handle
+# ---------------------------------------------------------------------------------------------------
+def latency_legs(ekf, scans, steps):
+    """Per-update latency, two ways, `steps` updates each (never part of `value`)."""
+    if steps <= 0:
+        return None, 0
+    # (a) device: one hipEvent pair around each whole chain on the handle's stream, launches back to back
+    ekf.sync()
     ekf.profile_reset()
-    ekf.profile(True)
-    cpu_scans = []
-    for k in range(args.steps):
-        t, ob = next(it)
+    ekf.profile(True, only=["update"])
+    for t, ob in scans[:steps]:
         ekf.handle_observation(t, ob)
-        if k < args.cpu_literal_steps + args.cpu_structured_steps:
-            cpu_scans.append((t, ob))
+    ekf.profile(False)
+    dev = ekf.profile_update_samples()
+    ekf.profile_reset()
+    # (b) host: what the reference's caller sees -- HandleObservationMessage, then the pose (GetState's fast path)
+    host = np.zeros(steps)
+    for k, (t, ob) in enumerate(scans[steps:2 * steps]):
+        t0 = time.perf_counter()
+        ekf.handle_observation(t, ob)
+        ekf.pose()
+        host[k] = 1e6 * (time.perf_counter() - t0)
+
+    def q(a):
+        return {"median": float(np.median(a)), "p99": float(np.percentile(a, 99)), "mean": float(a.mean()), "n": int(a.size)}
+    return {"device_chain": dict(q(dev), method="hipEvent pair around each whole update chain on the handle's stream, "
+                                                  "launches back to back (includes ~4-5 us of event bracket)"),
+            "host_sync": dict(q(host), method="host wall: HandleObservationMessage + rekf_get_pose (stream sync, 96-byte D2H) per update")}, 2 * steps
+
+
+def predict_leg(ekf, cfg, scans, steps, per_scan=5):
+    """Updates/s when every scan is preceded by `per_scan` HandleOdometryMessage predicts (reference
+    src/ros_node.cc:627-660: 50 Hz odometry against 10 Hz scans)."""
+    rng = np.random.Generator(np.random.PCG64(cfg.seed + 4242))
+    odo = rng.normal(0.0, 1.0, size=(steps, per_scan, 2)) * np.array([cfg.sigma_v, cfg.sigma_w])
+    t_prev = ekf.GetLatestTime()
+    ekf.sync()
+    t0 = time.perf_counter()
+    for k, (t, ob) in enumerate(scans[:steps]):
+        for j in range(per_scan):
+            ekf.handle_odometry(t_prev + (t - t_prev) * (j + 1) / (per_scan + 1), odo[k, j, 0], 0.0, odo[k, j, 1])
+        ekf.handle_observation(t, ob)
+        t_prev = t
+    ekf.sync()
+    dt = time.perf_counter() - t0
+    ekf.handle_odometry(t_prev, 0.0, 0.0, 0.0)        # dt = 0: leaves the state alone, parks the stored velocity
+    return {"value": steps / dt, "unit": "updates/s", "us_per_scan": 1e6 * dt / steps, "predicts_per_scan": per_scan,
+            "steps": steps}, steps
+
+
+def per_kernel_leg(ekf, scans, steps):
+    ekf.profile_reset()
+    ekf.profile(True, only=["front", "gather", "solve", "gain", "downdate", "augment", "empty"])
+    for t, ob in scans[:steps]:
+        ekf.handle_observation(t, ob)
     ekf.profile(False)
     prof = ekf.profile_read()
-    kernel_us = {k: (v[0] / v[1] if v[1] else None) for k, v in prof.items()}
-    # The roofline kernel once more, without per-launch brackets: `steps` back-to-back launches between ONE
-    # pair of hipEvents on the handle's stream (operands = what the last scan left in HBM).  A bracket
-    # around every launch adds 2-3 us of command-processor time to each reading (an empty bracket reads
-    # 4-5 us); this figure does not, and agrees with rocprofv3 --kernel-trace (profiles/).  The filter
-    # state is meaningless afterwards; nothing below uses this handle again.
-    dd_batched_us = ekf.time_kernel("downdate", reps=max(args.steps, 100))
+    ekf.profile_reset()
+    return {k: (round(v[0] / v[1], 3) if v[1] else None) for k, v in prof.items() if k != "update"}
 
-    out = None
-    if rank == 0:
-        # roofline.achieved uses the un-bracketed event measurement (dd_batched_us, above); the per-launch
-        # bracket reading, the empty-bracket reading and the rocprof average of the last committed
-        # profile are reported beside it.
-        ev_overhead = kernel_us.get("empty") or 0.0
-        dd_bracket_us = kernel_us["downdate"]
-        dd_us = dd_batched_us
-        rocprof_us = None
-        try:
-            rocprof_us = json.load(open(os.path.join(ROOT, "profiles", "kernel_avg_us.json"))).get("k_downdate")
-        except Exception:
-            pass
-        bytes_alg = 16.0 * n * n + 8.0 * n * (3 + m)          # SURVEY.md 8(d) BYTES_alg(n, m)
-        flop_k7 = 2.0 * n * n * m
-        achieved = bytes_alg / (dd_us * 1e-6) / 1e9
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_downdate.json")
-        if os.path.exists(pmc_path):
+
+def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world):
+    out = {}
+    pos = 0
+    lat, used = latency_legs(ekf, rest[pos:], args.latency_steps)
+    pos += used
+    if lat is not None:
+        out["latency_us"] = lat
+    k5 = max(args.steps, 200)
+    out["with_5_predicts_per_scan"], used = predict_leg(ekf, cfg, rest[pos:], k5)
+    pos += used
+    # odometry path alone (k_front): back-to-back predicts
+    ekf.profile_reset()
+    ekf.profile(True, only=["predict"])
+    tp = ekf.GetLatestTime()
+    for j in range(200):
+        ekf.handle_odometry(tp + 1e-5 * (j + 1), 0.01, 0.0, 0.01)
+    ekf.handle_odometry(tp + 1e-5 * 200, 0.0, 0.0, 0.0)
+    ekf.profile(False)
+    pr = ekf.profile_read()["predict"]
+    ekf.profile_reset()
+
+    ms_result = multi_session(args, cfg, sess, device) if (world == 1 and args.multi_sessions > 1) else None
+
+    state_for_cpu = None
+    if not args.no_cpu_baseline:
+        state_for_cpu = ekf.GetState()
+    kernel_us = per_kernel_leg(ekf, rest[pos:], args.instr_steps)
+    kernel_us["predict"] = round(pr[0] / pr[1], 3) if pr[1] else None
+    pos += args.instr_steps
+    # The roofline kernel once more, without per-launch brackets: back-to-back launches between ONE pair of
+    # hipEvents on the handle's stream (operands = what the last scan left in HBM).  A bracket around every
+    # launch adds 2-3 us of command-processor time to each reading (an empty bracket reads 4-5 us); this figure
+    # does not, and agrees with rocprofv3 --kernel-trace (profiles/).  The filter state is meaningless afterwards;
+    # nothing below uses this handle again.
+    dd_us = ekf.time_kernel("downdate", reps=max(args.steps, 200))
+
+    bytes_alg = 16.0 * n * n + 8.0 * n * (3 + m)          # SURVEY.md 8(d) BYTES_alg(n, m)
+    flop_k7 = 2.0 * n * n * m
+    achieved = bytes_alg / (dd_us * 1e-6) / 1e9
+    rocprof_us, traffic, traffic_src, rocprof_src = None, None, None, None
+    try:
+        rocprof_us = json.load(open(os.path.join(ROOT, "profiles", "kernel_avg_us.json"))).get("k_downdate")
+        rocprof_src = "profiles/kernel_avg_us.json (committed rocprofv3 --kernel-trace summary; NOT measured in this run)"
+    except Exception:
+        pass
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_downdate.json")))
+        traffic = pj.get("hbm_bytes_per_launch")
+        traffic_src = ("profiles/pmc_downdate.json: (2*FETCH_SIZE + WRITE_SIZE) of two separate rocprofv3 --pmc passes, "
+                       "committed summary; NOT measured in this run")
+    except Exception:
+        pass
+    out["roofline"] = {
+        "kernel": "k_downdate (P -= K (H P), FP64 MFMA 16x16x4)", "bound": "hbm",
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic, "traffic_source": traffic_src,
+        "bytes_per_launch": bytes_alg, "avg_launch_us": dd_us,
+        "avg_launch_us_method": "measured in this run: back-to-back launches between one hipEvent pair on the handle's stream",
+        "per_launch_bracket_us": kernel_us.get("downdate"), "empty_event_bracket_us": kernel_us.get("empty"),
+        "rocprof_avg_launch_us": rocprof_us, "rocprof_source": rocprof_src,
+        "mfma": {"achieved_tflops": flop_k7 / (dd_us * 1e-6) / 1e12, "peak_tflops": FP64_MFMA_PEAK_TF,
+                 "frac": flop_k7 / (dd_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF}}
+    out["kernel_us"] = kernel_us
+    if ms_result is not None:
+        out["multi_session"] = ms_result
+    if world == 1 and args.secondary:
+        sec = {}
+        for name in [s for s in args.secondary.split(",") if s and s != args.config]:
             try:
-                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "EKF updates/s at N=1024 landmarks, 32 obs/scan; pose RMSE vs reference",
-            "value": world * args.steps / elapsed_max,
-            "unit": "updates/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed_max / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{base.name}: synthetic 2D session, L={L} landmarks (n={n}), "
-                                   f"{m // 2} matched observations/scan (m={m}), diff-drive odometry, "
-                                   "steady-state HandleObservationMessage",
-                       "sessions": world, "parallelism": "replicas: one independent session per GPU",
-                       "map_build_s": round(map_build_s, 3)},
-            "roofline": {"kernel": "k_downdate (P -= K (H P), FP64 MFMA 16x16x4)", "bound": "hbm",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "bytes_per_launch": bytes_alg, "avg_launch_us": dd_us,
-                         "avg_launch_us_method": "back-to-back launches between one hipEvent pair on the handle's stream",
-                         "per_launch_bracket_us": dd_bracket_us, "empty_event_bracket_us": ev_overhead,
-                         "rocprof_avg_launch_us": rocprof_us,
-                         "mfma": {"achieved_tflops": flop_k7 / (dd_us * 1e-6) / 1e12,
-                                  "peak_tflops": FP64_MFMA_PEAK_TF,
-                                  "frac": flop_k7 / (dd_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF}},
-            "kernel_us": {k: (round(v, 3) if v is not None else None) for k, v in kernel_us.items()},
-        }
-        if ms_result is not None:
-            out["multi_session"] = ms_result
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"], out["pose_rmse_vs_oracle_m"] = cpu_baseline(args, cfg, sess, state_for_cpu,
-                                                                              cpu_scans, ekf)
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+                sec[name] = secondary_config(args, name, device)
+            except Exception as e:             # a secondary figure must never take the headline down
+                sec[name] = {"error": repr(e)}
+        out["secondary"] = sec
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"], out["pose_rmse_vs_oracle_m"] = cpu_baseline(args, cfg, sess, state_for_cpu, device)
+    return out
+
+
+def secondary_config(args, name, device):
+    """Rate + per-kernel times at another BASELINE.json config (C2: N=128/16 obs, launch-latency-bound;
+    C4: N=512, omni odometry, and the 3D detector -> filter pipeline).  Single session, this GPU."""
+    from reflector_ekf_slam_amd import session as S
+    from reflector_ekf_slam_amd import synth
+    base, cfg, sess = build_session(name, 0, 1)
+    ekf = gpu_filter_factory(cfg, sess, device)
+    t0 = time.time()
+    S.replay(sess, ekf)
+    ekf.sync()
+    build_s = time.time() - t0
+    n = ekf.n
+    assert n == 3 + 2 * cfg.n_landmarks, n
+    steps = args.secondary_steps
+    scans = synth.steady_state_scans(sess, 50 + 2 * steps + 300)
+    elapsed, used = timed_region(ekf, scans, 50, steps, None, lambda: None)
+    m = 2 * scans[0][1].shape[0]
+    res = {"metric": metric_text(base), "value": steps / elapsed, "unit": "updates/s", "us_per_update": 1e6 * elapsed / steps,
+           "steps": steps, "n": n, "m": m, "odom_model": "diff" if cfg.odom_model == synth.DIFF else "omni",
+           "map_build_s": round(build_s, 3)}
+    res["with_5_predicts_per_scan"], u2 = predict_leg(ekf, cfg, scans[used:], steps)
+    res["kernel_us"] = per_kernel_leg(ekf, scans[used + u2:], 300)
+    if name == "C4":
+        res["detector_pipeline"] = c4_detector_pipeline(cfg, sess, ekf, device)
+    ekf.close()
+    return res
+
+
+def c4_detector_pipeline(cfg, sess, ekf, device, n_clouds=24, reps=8):
+    """BASELINE.json configs[3] as the reference runs it: XYZI cloud -> HandlePointCloud (3D detector, GPU)
+    -> HandleObservationMessage, per scan.  Clouds are synthesised up front (host, untimed) at the parked pose."""
+    from reflector_ekf_slam_amd import synth
+    from reflector_ekf_slam_amd.detect import PointCloudOptions, PointCloudReflectorDetect
+    rng = np.random.Generator(np.random.PCG64(cfg.seed + 555))
+    pose = sess.true_pose[-1]
+    clouds = [synth.make_point_cloud(sess.landmarks, pose, rng, max_range=synth.C4_LIDAR_RANGE) for _ in range(n_clouds)]
+    det = PointCloudReflectorDetect(PointCloudOptions(), max_points=65536, device=device)
+    t = ekf.GetLatestTime()
+    ks = []
+    for c in clouds[:4]:                      # warm-up
+        t += 0.1
+        ob = det.HandlePointCloud(t, c)
+        ekf.handle_observation(t, ob.cloud_[:64])
+    ekf.sync()
+    t0 = time.perf_counter()
+    for r in range(reps):
+        for c in clouds:
+            t += 0.1
+            ob = det.HandlePointCloud(t, c)
+            ks.append(ob.cloud_.shape[0])
+            ekf.handle_observation(t, ob.cloud_[:64])
+    ekf.sync()
+    dt = time.perf_counter() - t0
+    det.close()
+    return {"value": reps * n_clouds / dt, "unit": "scans/s (3D detect + EKF update)", "us_per_scan": 1e6 * dt / (reps * n_clouds),
+            "points_per_cloud": int(clouds[0].shape[0]), "reflectors_per_scan_mean": float(np.mean(ks)),
+            "reflectors_per_scan_max": int(np.max(ks)), "final_n": int(ekf.n)}
 
 
 def multi_session(args, cfg, sess, device):
     """Secondary figure (never `value`): S independent filter sessions of the same workload sharing ONE GPU, one handle
-    = one HIP stream each, fed round-robin by this host thread.  A single session is a latency-bound chain of five
-    kernels (one of them a single workgroup), so sessions interleave on the device: the aggregate rate is what a fleet
+    = one HIP stream each, fed round-robin by this host thread.  A single session is a latency-bound chain of
+    kernels, so sessions interleave on the device: the aggregate rate is what a fleet
     server gets per GPU.  Every session runs the same scans and must end bit-identical."""
     from reflector_ekf_slam_amd import ReflectorEKFSLAM, synth
     from reflector_ekf_slam_amd import session as S
     ns = args.multi_sessions
-    steps = min(args.steps, 1000)
+    steps = min(max(args.steps, 200), 1000)
     scans = synth.steady_state_scans(sess, 100 + steps)
     handles = []
     for _ in range(ns):
@@ -256,52 +443,86 @@ def multi_session(args, cfg, sess, device):
             "note": "independent sessions on separate streams of one GPU, one host thread; not the headline value"}
 
 
-def cpu_baseline(args, cfg, sess, st, scans, ekf):
-    """Time the CPU oracle on a bounded sample of the same steady-state steps.
+def cpu_baseline(args, cfg, sess, st, device):
+    """Time the CPU oracle on its OWN bounded sample of steady-state scans (independent of --steps).
 
-    The oracle is started from the state the GPU had at the beginning of the
-    instrumented pass (st) and fed the same scans; its poses are also compared with
-    the GPU's (pose RMSE over the structured-mode sample)."""
+    The oracle is started from the state the GPU had after the timed region (st); the structured-mode sample doubles
+    as the parity sample (pose RMSE against a scratch GPU handle replaying the same scans from the same state)."""
     from oracle.binding import OracleEKF
+    from reflector_ekf_slam_amd import ReflectorEKFSLAM, synth
+    from reflector_ekf_slam_amd import session as S
+    ns, nl = max(args.cpu_structured_steps, 1), max(args.cpu_literal_steps, 0)
+    all_scans = synth.steady_state_scans(sess, ns + nl, seed_offset=2000)
+    shift = st.time - sess.ev_time[-1]            # these scans start right after the snapshot's time
+    all_scans = [(t + shift, ob) for t, ob in all_scans]
     o = OracleEKF(cfg.odom_model, sess.init_time, sess.init_pose, cfg.sigma_v ** 2, cfg.sigma_w ** 2,
                   cfg.sigma_obs ** 2)
     vt = sess.odom[np.nonzero(sess.ev_type == 0)[0][-1]]
     o.set_state(st.time, st.mu, st.sigma, vt)
-    # structured mode first (also the parity sample), then literal on the following scans
-    ns = min(args.cpu_structured_steps, len(scans))
     t0 = time.perf_counter()
     poses = []
-    for t, ob in scans[:ns]:
+    for t, ob in all_scans[:ns]:
         o.handle_observation(t, ob)
         poses.append(o.mu()[:3].copy())
-    t_struct = (time.perf_counter() - t0) / max(ns, 1)
-    # GPU poses for the same steps: replay on a scratch handle from the same state
-    from reflector_ekf_slam_amd import ReflectorEKFSLAM
-    from reflector_ekf_slam_amd import session as S
-    g2 = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks, device=int(os.environ.get("LOCAL_RANK", "0")))
+    t_struct = (time.perf_counter() - t0) / ns
+    g2 = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks, device=device)
     g2.set_state(st.time, st.mu, st.sigma, vt)
     err2 = []
-    for (t, ob), po in zip(scans[:ns], poses):
+    for (t, ob), po in zip(all_scans[:ns], poses):
         g2.handle_observation(t, ob)
         _, pg, _ = g2.pose()
         err2.append(float(np.sum((pg[:2] - po[:2]) ** 2)))
     g2.close()
-    rmse = float(np.sqrt(np.mean(err2))) if err2 else None
+    rmse = float(np.sqrt(np.mean(err2)))
+    n = st.mu.shape[0]
+    m = 2 * all_scans[0][1].shape[0]
+    res = {"value": None, "unit": "updates/s", "cores": 1, "kind": "port",
+           "structured_value": 1.0 / t_struct, "structured_sample": f"{ns} updates, O(n^2 m) algorithm, 1 thread",
+           "host_cores": os.cpu_count()}
+    lit_scans = all_scans[ns:ns + nl]             # the scans that follow, times still increasing
+    if len(lit_scans) == 0:
+        res["sample"] = "no literal-mode update was timed (--cpu-literal-steps 0): value is null"
+        return res, rmse
     o.set_mode(True)
-    lit_scans = scans[ns:ns + args.cpu_literal_steps]      # the scans that follow, times still increasing
     t0 = time.perf_counter()
     for t, ob in lit_scans:
         o.handle_observation(t, ob)
-    t_lit = (time.perf_counter() - t0) / max(len(lit_scans), 1)
-    n = st.mu.shape[0]
-    m = 2 * scans[0][1].shape[0]
+    t_lit = (time.perf_counter() - t0) / len(lit_scans)
     lit_flop = 6.0 * n ** 3 + 10.0 * m * n * n + 8.0 * m * m * n + 4.0 * m ** 3
-    return ({"value": 1.0 / t_lit, "unit": "updates/s", "cores": 1, "kind": "port",
-             "sample": f"{len(lit_scans)} steady-state updates, oracle literal mode (dense O(n^3) sequence of the "
-                       f"reference's Eigen expressions), from the GPU state at n={n}; host has {os.cpu_count()} cores",
-             "literal_s_per_update": t_lit, "literal_gflops": lit_flop / t_lit / 1e9,
-             "structured_value": 1.0 / t_struct, "structured_sample": f"{ns} updates, O(n^2 m) algorithm, 1 thread",
-             "host_cores": os.cpu_count()}, rmse)
+    res.update({"value": 1.0 / t_lit,
+                "sample": f"{len(lit_scans)} steady-state updates, oracle literal mode (dense O(n^3) sequence of the "
+                          f"reference's Eigen expressions), from the GPU state at n={n}; 1 of {os.cpu_count()} host cores",
+                "literal_s_per_update": t_lit, "literal_gflops": lit_flop / t_lit / 1e9})
+    return res, rmse
+
+
+def main():
+    args = parse_args()
+    respawn_under_torchrun(args)
+    import torch
+
+    from reflector_ekf_slam_amd import dist as D
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if os.environ.get("REKF_BENCH_FORCE_DIST") == "1" and "WORLD_SIZE" not in os.environ:
+        # exercises the RCCL path at world size 1
+        os.environ.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        import torch.distributed as dist_mod
+        dist_mod.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        rank, world = 0, 1
+    else:
+        dist_mod, rank, local_rank, world = D.init("nccl")
+    if world != args.gpus and "WORLD_SIZE" in os.environ and world > 1:
+        args.gpus = world
+    out = run_rank(args, dist_mod, rank, local_rank, world, device_sync=torch.cuda.synchronize)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist_mod is not None:
+        dist_mod.barrier()
+        dist_mod.destroy_process_group()
 
 
 if __name__ == "__main__":

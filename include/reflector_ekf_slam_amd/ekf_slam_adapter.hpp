@@ -51,14 +51,22 @@ public:
     }
     State PredictState(const double &time) override
     {
-        // pose block from the device (96 bytes); landmark part = current state (a predict leaves it unchanged
-        // except for the pose cross-covariances, which callers of the reference never read: ros_node.cc:455-470)
-        State s = GetState();
-        double mu3[3], c9[9];
-        guard([&] { impl_.PredictPose(time, mu3, c9); });
-        for (int i = 0; i < 3; ++i) s.mu(i) = mu3[i];
-        for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) s.sigma(i, j) = c9[i + 3 * j];
+        // the full predicted State, as reflector_ekf_slam.cc:97-152 returns it: every mean, the n x n covariance with
+        // rows/columns 0, 1 and the pose block propagated on the device, and the state's own time (`State result = state_`)
+        State s;
+        std::vector<double> mu, sig;
+        guard([&] { impl_.PredictStateFull(time, s.time, mu, sig); });
+        const int n = (int)mu.size();
+        s.mu = Eigen::Map<Eigen::VectorXd>(mu.data(), n);
+        s.sigma = Eigen::Map<Eigen::MatrixXd>(sig.data(), n, n);
         return s;
+    }
+    // 96-byte fast path for the only part src/ros_node.cc:455-470 reads of it
+    void PredictPose(const double &time, Eigen::Vector3d &mu, Eigen::Matrix3d &sigma)
+    {
+        double c9[9];
+        guard([&] { impl_.PredictPose(time, mu.data(), c9); });
+        sigma = Eigen::Map<Eigen::Matrix3d>(c9);
     }
     Eigen::VectorXd &GetStateVector() override { refresh(); return mirror_.mu; }       // never called by the reference
     Eigen::MatrixXd &GetCoviarance() override { refresh(); return mirror_.sigma; }
@@ -107,6 +115,8 @@ private:
         if (mirror_valid_) return;
         std::vector<double> mu, sig;
         guard([&] { impl_.State(mirror_.time, mu, sig); });
+        // (the getters refresh the sticky device flags and librekf prints one loud line per new bit: a state that
+        // outgrew max_landmarks drops reflectors, which the reference never does -- size max_landmarks for the site)
         const int n = (int)mu.size();
         mirror_.mu = Eigen::Map<Eigen::VectorXd>(mu.data(), n);
         mirror_.sigma = Eigen::Map<Eigen::MatrixXd>(sig.data(), n, n);      // both column-major

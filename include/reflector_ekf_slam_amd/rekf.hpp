@@ -47,6 +47,17 @@ public:
     int Dim() { int n = 0; chk(rekf_get_n(h_, &n), "rekf_get_n"); return n; }
     void Pose(double mu3[3], double sigma3x3[9]) { double t; chk(rekf_get_pose(h_, &t, mu3, sigma3x3), "rekf_get_pose"); }
     void PredictPose(double t, double mu3[3], double sigma3x3[9]) { chk(rekf_predict_state(h_, t, mu3, sigma3x3), "PredictState"); }
+    // PredictState as the interface returns it (ekf_slam_interface.h:59): full mu / sigma, time = the state's own (cc:99)
+    void PredictStateFull(double t_query, double &t_state, std::vector<double> &mu, std::vector<double> &sigma)
+    {
+        int n = Dim();
+        mu.resize((size_t)n);
+        sigma.resize((size_t)n * n);
+        chk(rekf_predict_state_full(h_, t_query, &t_state, &n, mu.data(), (long)mu.size(), sigma.data(), (long)sigma.size()),
+            "PredictState");
+    }
+    // sticky REKF_FLAGBIT_* bits (capacity overflow = reflectors dropped; non-PD innovation covariance), not cleared
+    int Flags() { int f = 0; chk(rekf_get_flags(h_, &f), "rekf_get_flags"); return f; }
     // full state: mu (n) and sigma (n*n, column-major like Eigen::MatrixXd)
     void State(double &t, std::vector<double> &mu, std::vector<double> &sigma)
     {

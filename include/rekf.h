@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define REKF_ABI_VERSION 1
+#define REKF_ABI_VERSION 2
 
 /* Most observations one scan may carry (K).  m = 2*K (+3 with a pose
  * observation) innovation rows must fit the single-workgroup LDS solve. */
@@ -44,15 +44,22 @@ enum {
     REKF_ERR_CAPACITY = -4,       /* state grew past max_landmarks; extra reflectors were dropped */
     REKF_ERR_SINGULAR = -5,       /* innovation covariance had a non-positive pivot */
     REKF_ERR_BUFFER = -6,         /* caller buffer too small */
-    REKF_ERR_UNSUPPORTED = -7     /* e.g. use_imu != 0 (the reference's IMU path is empty) */
+    REKF_ERR_UNSUPPORTED = -7     /* reserved */
 };
+
+/* Sticky device-side condition bits (rekf_get_flags): the state kept growing past max_landmarks and the extra
+ * reflectors of a scan were dropped (the reference grows without bound, reflector_ekf_slam.cc:311-364); the
+ * innovation covariance S of some scan had a non-positive pivot (the update was applied as computed). */
+enum { REKF_FLAGBIT_CAPACITY = 1, REKF_FLAGBIT_SINGULAR = 2 };
 
 enum { REKF_ODOM_DIFF = 0, REKF_ODOM_OMNI = 1 };   /* sensor::OdometryModel, sensor_data.h:56-60 */
 
 /* ekf::EKFOptions (ekf_slam_interface.h:28-41).  The three *_cov fields are
  * variances: the reference's caller squares the launch-file sigmas
  * (src/ros_node.cc:207-238).  map_path is handled by the host side
- * (rekf_set_map); use_imu must be 0 (forced false at src/ros_node.cc:186). */
+ * (rekf_set_map).  use_imu != 0 is accepted and behaves like the reference: odometry
+ * messages are then ignored (reflector_ekf_slam.cc:213-223; the IMU branch is empty, and the
+ * reference's caller forces use_imu = false, src/ros_node.cc:186). */
 typedef struct rekf_options {
     int odom_model;
     int use_imu;
@@ -87,9 +94,17 @@ int rekf_handle_odometry(rekf_t *h, double t, double vx, double vy, double wz);
 int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K,
                             const double *gps_pose3);
 
-/* PredictState (reflector_ekf_slam.cc:97-152), pose block only: non-mutating.
- * Synchronises. */
+/* PredictState (reflector_ekf_slam.cc:97-152), pose block only (the only part the reference's caller
+ * reads, src/ros_node.cc:455-470): non-mutating, 96 bytes D2H.  Synchronises. */
 int rekf_predict_state(rekf_t *h, double t, double mu3[3], double sigma3x3[9]);
+
+/* PredictState as the interface returns it (ekf_slam_interface.h:59): the FULL predicted State --
+ * `State result = state_` with result.sigma = G sigma G^T + Gu Qu Gu^T over all n (rows/columns 0, 1 and the
+ * pose block change; computed on the device with Predict's own arithmetic) and result.mu[0..2] advanced;
+ * *time_out = the state's time, which the reference leaves unchanged in the copy (:99).  Buffers as in
+ * rekf_get_state.  Non-mutating.  Synchronises; an n x n D2H copy like GetState. */
+int rekf_predict_state_full(rekf_t *h, double t, double *time_out, int *n, double *mu, long mu_cap,
+                            double *sigma, long sigma_cap);
 
 /* GetLatestTime (reflector_ekf_slam.h:33-36).  No device access. */
 int rekf_get_time(rekf_t *h, double *t);
@@ -132,6 +147,12 @@ int rekf_get_last_match(rekf_t *h, int *n_state, int *state_pairs, int *n_map,
  * (REKF_ERR_CAPACITY / REKF_ERR_SINGULAR) once, then clears it. */
 int rekf_sync(rekf_t *h);
 
+/* The sticky REKF_FLAGBIT_* bits, without clearing them.  Every getter that synchronises (rekf_get_pose,
+ * rekf_get_n, rekf_get_state, rekf_get_last_match, ...) also refreshes them and prints ONE line to stderr the
+ * first time a bit appears, so a caller that never calls rekf_sync still hears about dropped reflectors.
+ * Synchronises. */
+int rekf_get_flags(rekf_t *h, int *flags);
+
 /* ---- measurement hooks (bench.py, rocprof cross-checks) -------------------- */
 enum {
     REKF_K_PREDICT = 0,   /* odometry-path covariance/mean propagate */
@@ -142,7 +163,9 @@ enum {
     REKF_K_DOWNDATE = 5,  /* P -= K W^T  (the roofline kernel)       */
     REKF_K_AUGMENT = 6,   /* new landmarks                           */
     REKF_K_EMPTY = 7,     /* an event pair around nothing: the bracket's own cost, in situ */
-    REKF_K_COUNT = 8
+    REKF_K_UPDATE = 8,    /* ONE bracket around the whole HandleObservationMessage chain (per-update latency);
+                           * its individual readings are kept, see rekf_profile_samples */
+    REKF_K_COUNT = 9
 };
 /* When on, kernel launches are bracketed by hipEvents on the handle's stream: `on` is a bit mask
  * over the REKF_K_* ids (1 << id); -1 = all.  Brackets perturb the stream (each costs a few
@@ -152,6 +175,9 @@ int rekf_profile_enable(rekf_t *h, int on);
  * last rekf_profile_reset.  Synchronises. */
 int rekf_profile_read(rekf_t *h, int k, double *total_us, long *count);
 int rekf_profile_reset(rekf_t *h);
+/* The individual REKF_K_UPDATE readings (microseconds, in call order) since the last reset: up to cap values
+ * into out_us, *count = how many exist.  For the median / p99 per-update latency of SURVEY 8(d).  Synchronises. */
+int rekf_profile_samples(rekf_t *h, float *out_us, long cap, long *count);
 /* The hipStream_t of the handle (as void*), for callers that record their own events. */
 void *rekf_stream(rekf_t *h);
 /* Leading dimension (doubles) of the device covariance and its device pointer. */

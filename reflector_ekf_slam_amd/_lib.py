@@ -11,6 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 MAX_OBS = 64
+REKF_ABI_VERSION = 2          # must equal REKF_ABI_VERSION of include/rekf.h and rekf_abi_version() of the built library
 
 
 class RekfOptions(C.Structure):
@@ -43,6 +44,10 @@ def rekf():
     L = C.CDLL(path)
     vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)
     L.rekf_abi_version.restype = C.c_int
+    have = L.rekf_abi_version()
+    if have != REKF_ABI_VERSION:
+        raise LibraryMissing(f"{path} has ABI version {have}, this package speaks {REKF_ABI_VERSION}: rebuild it "
+                             "(python __graft_entry__.py); there is no CPU fallback")
     L.rekf_strerror.restype = C.c_char_p
     L.rekf_strerror.argtypes = [C.c_int]
     L.rekf_last_hip_error.restype = C.c_char_p
@@ -54,6 +59,8 @@ def rekf():
     L.rekf_handle_odometry.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_double]
     L.rekf_handle_observation.argtypes = [vp, C.c_double, vp, C.c_int, vp]
     L.rekf_predict_state.argtypes = [vp, C.c_double, dp, dp]
+    L.rekf_predict_state_full.argtypes = [vp, C.c_double, dp, ip, vp, C.c_long, vp, C.c_long]
+    L.rekf_get_flags.argtypes = [vp, ip]
     L.rekf_get_time.argtypes = [vp, dp]
     L.rekf_get_pose.argtypes = [vp, dp, dp, dp]
     L.rekf_get_n.argtypes = [vp, ip]
@@ -65,6 +72,7 @@ def rekf():
     L.rekf_profile_enable.argtypes = [vp, C.c_int]
     L.rekf_profile_read.argtypes = [vp, C.c_int, dp, C.POINTER(C.c_long)]
     L.rekf_profile_reset.argtypes = [vp]
+    L.rekf_profile_samples.argtypes = [vp, vp, C.c_long, C.POINTER(C.c_long)]
     L.rekf_stream.restype = vp
     L.rekf_stream.argtypes = [vp]
     L.rekf_device_layout.argtypes = [vp, ip, ip, C.POINTER(vp), C.POINTER(vp)]

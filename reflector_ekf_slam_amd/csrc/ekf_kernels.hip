@@ -1575,6 +1575,46 @@ __global__ void k_predict_pose(RekfDev d, RekfFrontArgs A, double *out12)
 }
 
 // ----------------------------------------------------------------------------
+// PredictState, everything a predict changes (cc:97-152), non-mutating: the predicted rows 0,1 and columns 0,1 of
+// P (k_front's own arithmetic, elementwise), the pose and the 3x3 pose block.
+// out: row0[ld] | row1[ld] | col0[ld] | col1[ld] | mu3 | corner 3x3 column-major
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_predict_rows(RekfDev d, RekfFrontArgs A, double *out)
+{
+#pragma clang fp contract(off)
+    __shared__ Motion mo;
+    const int n = d.ctl->n;
+    const size_t ld = (size_t)d.ld;
+    const double *P = d.P;
+    if (threadIdx.x == 0) motion_terms(A, d.mu[2], mo);
+    __syncthreads();
+    const double a = mo.a, b = mo.b;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
+        if (idx < 3) continue;
+        const double p2 = P[idx + 2 * ld], q2 = P[2 + idx * ld];
+        out[2 * ld + idx] = P[idx + 0 * ld] + a * p2;            // column 0
+        out[3 * ld + idx] = P[idx + 1 * ld] + b * p2;            // column 1
+        out[0 * ld + idx] = P[0 + idx * ld] + a * q2;            // row 0
+        out[1 * ld + idx] = P[1 + idx * ld] + b * q2;            // row 1
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double C9[9];
+        for (int q = 0; q < 9; ++q) C9[q] = P[(q % 3) + (size_t)(q / 3) * ld];
+        corner_predict(C9, 3, mo);
+        double th = d.mu[2] + mo.d[2], sn, cs;
+        sincos(th, &sn, &cs);
+        th = atan2(sn, cs);
+        double *tail = out + 4 * ld;
+        tail[0] = d.mu[0] + mo.d[0]; tail[1] = d.mu[1] + mo.d[1]; tail[2] = th;
+        for (int q = 0; q < 9; ++q) tail[3 + q] = C9[q];
+    }
+}
+void rekf_launch_predict_rows(const RekfDev &d, const RekfFrontArgs &a, double *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_predict_rows, dim3(16), dim3(256), 0, s, d, a, out);
+}
+
+// ----------------------------------------------------------------------------
 // launch wrappers
 // ----------------------------------------------------------------------------
 void rekf_launch_front(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s)

@@ -43,6 +43,8 @@ struct rekf {
     double *dev_ell;           // device scratch for k_ellipses (5 doubles per landmark of capacity)
     RekfCtl *ctl_staging;      // pinned copy of the control block
     std::string hip_error;
+    int flags_seen = 0;        // sticky device flags already reported on stderr
+    double *dev_pred;          // device scratch for k_predict_rows (4 * ld + 12 doubles)
     // profiling
     bool prof_on;
     int prof_mask;
@@ -50,6 +52,7 @@ struct rekf {
     size_t prof_used;
     double prof_total_us[REKF_K_COUNT];
     long prof_count[REKF_K_COUNT];
+    std::vector<float> prof_update_us;   // every REKF_K_UPDATE reading since the last reset
 };
 
 namespace {
@@ -74,6 +77,8 @@ int prof_flush(rekf_t *h)
         HIP_TRY(h, hipEventElapsedTime(&ms, h->prof_slots[i].a, h->prof_slots[i].b));
         h->prof_total_us[h->prof_slots[i].kernel] += 1e3 * (double)ms;
         h->prof_count[h->prof_slots[i].kernel] += 1;
+        if (h->prof_slots[i].kernel == REKF_K_UPDATE && h->prof_update_us.size() < (1u << 20))
+            h->prof_update_us.push_back(1e3f * ms);
     }
     h->prof_used = 0;
     return REKF_OK;
@@ -123,6 +128,19 @@ int device_flags_to_code(int flags)
     return REKF_OK;
 }
 
+// One loud line per newly seen sticky bit: the reference never drops a reflector (cc:311-364), so a caller that only
+// uses the getters must still hear about it.
+void report_flags(rekf_t *h, int flags)
+{
+    const int fresh = flags & ~h->flags_seen;
+    if (fresh & REKF_FLAG_CAPACITY)
+        std::fprintf(stderr, "rekf: landmark capacity (max_landmarks = %d) exceeded: new reflectors are being DROPPED "
+                             "(the reference grows its state without bound)\n", h->max_landmarks);
+    if (fresh & REKF_FLAG_SINGULAR)
+        std::fprintf(stderr, "rekf: innovation covariance was not positive definite in some scan; the update was applied as computed\n");
+    h->flags_seen |= flags;
+}
+
 // Synchronise and refresh the host copy of the control block.
 int pull_ctl(rekf_t *h)
 {
@@ -131,6 +149,7 @@ int pull_ctl(rekf_t *h)
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->n_ub = h->ctl_staging->n;
     h->full = h->ctl_staging->n >= h->dev.n_max;
+    report_flags(h, h->ctl_staging->err);
     return REKF_OK;
 }
 
@@ -160,7 +179,6 @@ const char *rekf_last_hip_error(rekf_t *h) { return h ? h->hip_error.c_str() : "
 int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t **out)
 {
     if (!opt || !out || max_landmarks < 1) return REKF_ERR_INVALID;
-    if (opt->use_imu) return REKF_ERR_UNSUPPORTED;   // reference IMU path is empty (cc:222-227)
     *out = nullptr;
     rekf_t *h = new (std::nothrow) rekf();
     if (!h) return REKF_ERR_INVALID;
@@ -180,6 +198,7 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
     h->ctl_staging = nullptr;
     h->dev_out12 = nullptr;
     h->dev_ell = nullptr;
+    h->dev_pred = nullptr;
     std::memset(&h->dev, 0, sizeof(h->dev));
 
     const int n_max = 3 + 2 * max_landmarks;
@@ -198,7 +217,8 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
         HIP_TRY(h, hipMalloc(&h->dev.KnB, sizeof(double) * REKF_STRIP_MAX * REKF_MR_PAD));
         HIP_TRY(h, hipMalloc(&h->dev.HPtB, sizeof(double) * REKF_STRIP_MAX * REKF_MR_PAD));
         HIP_TRY(h, hipMalloc(&h->dev.y, sizeof(double) * REKF_MR_PAD));
-        HIP_TRY(h, hipMalloc(&h->dev_out12, sizeof(double) * 12));
+        HIP_TRY(h, hipMalloc(&h->dev_out12, sizeof(double) * 16));
+        HIP_TRY(h, hipMalloc(&h->dev_pred, sizeof(double) * (4 * (size_t)ld + 16)));
         HIP_TRY(h, hipMalloc(&h->dev_ell, sizeof(double) * 5 * (size_t)(max_landmarks > 0 ? max_landmarks : 1)));
         HIP_TRY(h, hipHostMalloc(&h->pose_staging, sizeof(double) * 16));
         HIP_TRY(h, hipHostMalloc(&h->ctl_staging, sizeof(RekfCtl)));
@@ -243,7 +263,7 @@ void rekf_destroy(rekf_t *h)
     for (auto &s : h->prof_slots) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     (void)hipFree(h->dev.ctl); (void)hipFree(h->dev.mu); (void)hipFree(h->dev.P);
     (void)hipFree(h->dev.W); (void)hipFree(h->dev.HPt); (void)hipFree(h->dev.Kn); (void)hipFree(h->dev.Sinv); (void)hipFree(h->dev.Wc); (void)hipFree(h->dev.KnB); (void)hipFree(h->dev.HPtB); (void)hipFree(h->dev.y);
-    (void)hipFree(h->dev.map_xy); (void)hipFree(h->dev.map_cov); (void)hipFree(h->dev_out12); (void)hipFree(h->dev_ell);
+    (void)hipFree(h->dev.map_xy); (void)hipFree(h->dev.map_cov); (void)hipFree(h->dev_out12); (void)hipFree(h->dev_ell); (void)hipFree(h->dev_pred);
     if (h->pose_staging) (void)hipHostFree(h->pose_staging);
     if (h->ctl_staging) (void)hipHostFree(h->ctl_staging);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -270,6 +290,7 @@ int rekf_handle_odometry(rekf_t *h, double t, double vx, double vy, double wz)
 {
     if (!h) return REKF_ERR_INVALID;
     if (t < h->time) return REKF_OK;                  // drop old data, cc:211-212
+    if (h->opt.use_imu) return REKF_OK;               // cc:213-223: the use_imu branch is empty -- nothing happens
     h->vt[0] = vx; h->vt[1] = vy; h->vt[2] = wz;      // cc:216
     RekfFrontArgs a;
     fill_front_args(h, a, t - h->time);               // cc:217
@@ -297,6 +318,7 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         a.gps[0] = gps_pose3[0]; a.gps[1] = gps_pose3[1]; a.gps[2] = gps_pose3[2];
     }
     HIP_TRY(h, hipSetDevice(h->device));
+    ProfScope upd(h, REKF_K_UPDATE);                  // one bracket around the whole chain (per-update latency)
     if (K == 0) {                                     // cc:235-236: predict only, single-workgroup kernel
         ProfScope ps(h, REKF_K_FRONT);
         rekf_launch_front(h->dev, a, h->stream);
@@ -350,7 +372,9 @@ int rekf_get_pose(rekf_t *h, double *t, double mu3[3], double sigma3x3[9])
     HIP_TRY(h, hipMemcpyAsync(h->pose_staging, h->dev.mu, sizeof(double) * 3, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpy2DAsync(h->pose_staging + 3, sizeof(double) * 3, h->dev.P, sizeof(double) * h->dev.ld,
                                 sizeof(double) * 3, 3, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->pose_staging + 12, h->dev.ctl, sizeof(int) * 2, hipMemcpyDeviceToHost, h->stream));   // n, err
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    report_flags(h, ((const int *)(h->pose_staging + 12))[1]);
     if (t) *t = h->time;
     if (mu3) std::memcpy(mu3, h->pose_staging, sizeof(double) * 3);
     if (sigma3x3) std::memcpy(sigma3x3, h->pose_staging + 3, sizeof(double) * 9);
@@ -453,6 +477,49 @@ int rekf_sync(rekf_t *h)
     return device_flags_to_code(flags);
 }
 
+int rekf_get_flags(rekf_t *h, int *flags)
+{
+    if (!h || !flags) return REKF_ERR_INVALID;
+    int rc = pull_ctl(h);
+    if (rc != REKF_OK) return rc;
+    *flags = h->ctl_staging->err;
+    return REKF_OK;
+}
+
+int rekf_predict_state_full(rekf_t *h, double t, double *time_out, int *n_out, double *mu, long mu_cap, double *sigma,
+                            long sigma_cap)
+{
+    if (!h) return REKF_ERR_INVALID;
+    int rc = pull_ctl(h);
+    if (rc != REKF_OK) return rc;
+    const int n = h->ctl_staging->n;
+    const int ld = h->dev.ld;
+    if (time_out) *time_out = h->time;                // `State result = state_` keeps the state's time (cc:99)
+    if (n_out) *n_out = n;
+    if ((mu && mu_cap < n) || (sigma && sigma_cap < (long)n * n)) return REKF_ERR_BUFFER;
+    RekfFrontArgs a;
+    fill_front_args(h, a, t - h->time);               // cc:100
+    rekf_launch_predict_rows(h->dev, a, h->dev_pred, h->stream);
+    std::vector<double> pred(4 * (size_t)ld + 16);
+    HIP_TRY(h, hipMemcpyAsync(pred.data(), h->dev_pred, sizeof(double) * pred.size(), hipMemcpyDeviceToHost, h->stream));
+    if (mu) HIP_TRY(h, hipMemcpyAsync(mu, h->dev.mu, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    if (sigma)
+        HIP_TRY(h, hipMemcpy2DAsync(sigma, sizeof(double) * n, h->dev.P, sizeof(double) * ld, sizeof(double) * n, n,
+                                    hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    // layout of pred: row0[ld] | row1[ld] | col0[ld] | col1[ld] | mu3 | corner 3x3 column-major
+    const double *row0 = pred.data(), *row1 = row0 + ld, *col0 = row1 + ld, *col1 = col0 + ld, *tail = col1 + ld;
+    if (mu) for (int i = 0; i < 3; ++i) mu[i] = tail[i];
+    if (sigma) {
+        for (int c = 3; c < n; ++c) {
+            sigma[0 + (size_t)c * n] = row0[c]; sigma[1 + (size_t)c * n] = row1[c];
+            sigma[c + (size_t)0 * n] = col0[c]; sigma[c + (size_t)1 * n] = col1[c];
+        }
+        for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) sigma[i + (size_t)j * n] = tail[3 + i + 3 * j];
+    }
+    return REKF_OK;
+}
+
 int rekf_profile_enable(rekf_t *h, int on)
 {
     if (!h) return REKF_ERR_INVALID;
@@ -478,6 +545,19 @@ int rekf_profile_reset(rekf_t *h)
     int rc = prof_flush(h);
     if (rc != REKF_OK) return rc;
     for (int k = 0; k < REKF_K_COUNT; ++k) { h->prof_total_us[k] = 0; h->prof_count[k] = 0; }
+    h->prof_update_us.clear();
+    return REKF_OK;
+}
+
+int rekf_profile_samples(rekf_t *h, float *out_us, long cap, long *count)
+{
+    if (!h || !count || cap < 0 || (cap > 0 && !out_us)) return REKF_ERR_INVALID;
+    int rc = prof_flush(h);
+    if (rc != REKF_OK) return rc;
+    const long have = (long)h->prof_update_us.size();
+    const long k = have < cap ? have : cap;
+    if (k > 0) std::memcpy(out_us, h->prof_update_us.data(), sizeof(float) * (size_t)k);
+    *count = have;
     return REKF_OK;
 }
 

@@ -17,7 +17,8 @@ from . import _lib
 
 DIFF, OMNI = 0, 1   # sensor::OdometryModel (sensor_data.h:56-60)
 
-KERNELS = {"predict": 0, "front": 1, "gather": 2, "solve": 3, "gain": 4, "downdate": 5, "augment": 6, "empty": 7}
+KERNELS = {"predict": 0, "front": 1, "gather": 2, "solve": 3, "gain": 4, "downdate": 5, "augment": 6, "empty": 7,
+           "update": 8}
 
 
 class RekfError(RuntimeError):
@@ -103,21 +104,38 @@ def load_map_txt(path: str) -> Map:
     return Map(xy, cov)
 
 
-def save_map_txt(path: str, state: State, loaded: Map | None = None) -> None:
-    """SaveReflectorResult (src/ros_node.cc:75-140) without the leading-comma bug (Q10):
-    pre-loaded map points first, then the state's landmarks with their 2x2 blocks."""
+def save_map_txt(path: str, state: State, loaded: Map | None = None, reference_bytes: bool = False) -> None:
+    """SaveReflectorResult (src/ros_node.cc:75-140): pre-loaded map points first, then the state's landmarks with
+    their 2x2 blocks, two comma-separated lines.
+
+    Default: lossless (%.17g) and without the leading-comma bug (Q10).  ``reference_bytes=True`` writes the very
+    bytes the reference's ``std::ofstream <<`` would: 6 significant digits (iostream default = %g), map points
+    formatted from their float32 values, and the "," the reference emits in front of the new landmarks even when
+    no map was pre-loaded (:97-100,:124-127) -- which its own loader then chokes on; ours skips empty fields."""
     pts, covs = [], []
+    n_loaded = 0
     if loaded is not None:
         for p, c in zip(loaded.reflector_map_, loaded.reflector_map_coviarance_):
-            pts.append((float(p[0]), float(p[1])))
+            pts.append((float(np.float32(p[0])), float(np.float32(p[1]))))
             covs.append(np.asarray(c, dtype=np.float64).reshape(4))
+            n_loaded += 1
     L = (state.mu.shape[0] - 3) // 2
     for j in range(L):
         pts.append((state.mu[3 + 2 * j], state.mu[4 + 2 * j]))
         covs.append(state.sigma[3 + 2 * j: 5 + 2 * j, 3 + 2 * j: 5 + 2 * j].reshape(4))
+    if not reference_bytes:
+        with open(path, "w") as f:
+            f.write(",".join(f"{v:.17g}" for p in pts for v in p) + "\n")
+            f.write(",".join(f"{v:.17g}" for c in covs for v in c) + "\n")
+        return
+
+    def line(groups):
+        old = ",".join("%g" % v for g in groups[:n_loaded] for v in g)
+        new = ",".join("%g" % v for g in groups[n_loaded:] for v in g)
+        return old + (("," + new) if L > 0 else "")
     with open(path, "w") as f:
-        f.write(",".join(f"{v:.17g}" for p in pts for v in p) + "\n")
-        f.write(",".join(f"{v:.17g}" for c in covs for v in c) + "\n")
+        f.write(line(pts) + "\n")
+        f.write(line(covs) + "\n")
 
 
 class ReflectorEKFSLAM:
@@ -174,11 +192,32 @@ class ReflectorEKFSLAM:
         self.handle_observation(observation.time_, observation.cloud_, observation.gps_pose_)
 
     def PredictState(self, time: float) -> State:
-        """Pose block of PredictState (cc:97-152); landmarks are unchanged by a predict."""
+        """PredictState as the interface returns it (ekf_slam_interface.h:59, cc:97-152): the full predicted
+        State -- all n means, the n x n covariance with rows/columns 0, 1 and the pose block propagated -- and,
+        like the reference's `State result = state_`, the state's own (unchanged) time.  Non-mutating.  Costs an
+        n x n device-to-host copy like GetState; `PredictPose` is the 96-byte fast path."""
+        n = self.n
+        mu = np.zeros(n)
+        sig = np.zeros((n, n), order="F")
+        t = C.c_double()
+        nn = C.c_int()
+        self._chk(self._L.rekf_predict_state_full(self._h, float(time), C.byref(t), C.byref(nn),
+                                                  mu.ctypes.data_as(C.c_void_p), n, sig.ctypes.data_as(C.c_void_p), n * n),
+                  "PredictState")
+        return State(t.value, mu, sig)
+
+    def PredictPose(self, time: float) -> State:
+        """Pose block of PredictState only (what src/ros_node.cc:455-470 reads): mu (3,), sigma (3, 3)."""
         mu3 = (C.c_double * 3)()
         s9 = (C.c_double * 9)()
         self._chk(self._L.rekf_predict_state(self._h, float(time), mu3, s9), "PredictState")
         return State(float(time), np.array(mu3[:]), np.array(s9[:]).reshape(3, 3).T.copy())
+
+    def flags(self) -> int:
+        """Sticky device-side condition bits (REKF_FLAGBIT_CAPACITY = 1, REKF_FLAGBIT_SINGULAR = 2), not cleared."""
+        f = C.c_int()
+        self._chk(self._L.rekf_get_flags(self._h, C.byref(f)), "get_flags")
+        return f.value
 
     def GetStateVector(self) -> np.ndarray:
         return self.GetState().mu
@@ -302,6 +341,16 @@ class ReflectorEKFSLAM:
             self._chk(self._L.rekf_profile_read(self._h, k, C.byref(us), C.byref(cnt)), "profile_read")
             out[name] = (us.value, cnt.value)
         return out
+
+    def profile_update_samples(self) -> np.ndarray:
+        """Every REKF_K_UPDATE reading (us) since the last profile_reset: one hipEvent pair around each whole
+        HandleObservationMessage chain on the handle's stream."""
+        cnt = C.c_long()
+        self._chk(self._L.rekf_profile_samples(self._h, None, 0, C.byref(cnt)), "profile_samples")
+        out = np.zeros(max(cnt.value, 1), np.float32)
+        self._chk(self._L.rekf_profile_samples(self._h, out.ctypes.data_as(C.c_void_p), cnt.value, C.byref(cnt)),
+                  "profile_samples")
+        return out[: cnt.value].astype(np.float64)
 
     def time_kernel(self, name: str, reps: int = 200, ablate: int = 0) -> float:
         """Average device time (us) of `reps` back-to-back launches of one kernel of the chain between ONE

@@ -51,6 +51,9 @@ class SessionConfig:
 C2 = SessionConfig("C2_N128_obs16", 128, 16, DIFF, seed=20210330)
 C3 = SessionConfig("C3_N1024_obs32", 1024, 32, DIFF, seed=20210331)
 C4 = SessionConfig("C4_N512_omni", 512, 32, OMNI, seed=20210332)
+# C4's observations come from the 3D detector run on synthetic clouds (make_point_cloud): the lidar's usable range is
+# set to the range gate the 2D configs use (range_max above), so a sweep holds about 32 detectable posts.
+C4_LIDAR_RANGE = 10.0
 
 
 @dataclass

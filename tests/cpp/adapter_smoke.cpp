@@ -27,6 +27,17 @@ int main(int argc, char **)
     const auto m = f.LastMatch();
     if (mu.size() != 7 || m.state_obs_match_ids.size() != 2 || !m.new_ids.empty()) { std::printf("FAIL\n"); return 1; }
     if (!(std::fabs(sig[0] - sig[0]) == 0.0)) return 1;
+    {   // PredictState, full (ekf_slam_interface.h:59): non-mutating, n means, state's own time, pose block = the fast path's
+        double ts = -1, mu3[3], c9[9];
+        std::vector<double> pm, ps;
+        f.PredictStateFull(0.45, ts, pm, ps);
+        f.PredictPose(0.45, mu3, c9);
+        std::vector<double> mu2, sig2;
+        double t2;
+        f.State(t2, mu2, sig2);
+        if (pm.size() != 7 || ts != t || pm[0] != mu3[0] || ps[0] != c9[0] || ps[1 + 7 * 0] != c9[1] || mu2 != mu || sig2 != sig ||
+            pm[3] != mu[3] || ps[0 + 7 * 3] == sig[0 + 7 * 3] || f.Flags() != 0) { std::printf("FAIL predict_state_full\n"); return 1; }
+    }
     const auto ell = f.MarkerEllipses();
     if (ell.size() != 2 || !(ell[0].x_len > 0.0) || std::fabs(ell[0].x - mu[3]) > 0.0) { std::printf("FAIL ellipses\n"); return 1; }
     // grid front-end: insert a short wall into an unknown grid, then find it again with the matcher

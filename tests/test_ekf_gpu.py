@@ -29,7 +29,7 @@ def _pair(cfg, sess, cap=None):
 def test_extension_is_loaded_and_there_is_no_fallback():
     from reflector_ekf_slam_amd import _lib
     assert os.path.exists(_lib.lib_path("librekf.so"))
-    assert _lib.rekf().rekf_abi_version() == 1
+    assert _lib.rekf().rekf_abi_version() == _lib.REKF_ABI_VERSION == 2
 
 
 @pytest.mark.parametrize("case", ["diff_L24_obs8", "omni_L30_obs10", "map_L24_obs8", "gps_L20_obs6", "diff_L128_obs16"])
@@ -309,9 +309,49 @@ def test_predict_state_is_non_mutating_and_matches_oracle(oracle_lib):
     after = g.GetState()
     assert np.array_equal(before.mu, after.mu) and np.array_equal(before.sigma, after.sigma)
     mu_p, P_p = o.predict_state(0.7, full=True)
-    assert np.abs(ps.mu - mu_p[:3]).max() < 1e-14 and np.abs(ps.sigma - P_p[:3, :3]).max() < 1e-16
+    # the interface's PredictState returns the FULL State (ekf_slam_interface.h:59) with the state's own time (cc:99)
+    assert ps.mu.shape == mu_p.shape == (5,) and ps.sigma.shape == (5, 5) and ps.time == before.time == 0.2
+    assert np.abs(ps.mu - mu_p).max() < 1e-14 and np.abs(ps.sigma - P_p).max() < 1e-16
+    assert np.abs(ps.sigma[:2, 3:] - before.sigma[:2, 3:]).max() > 1e-6      # the pose-landmark cross terms DID move
+    pp = g.PredictPose(0.7)                                                    # 96-byte fast path: same pose block
+    assert np.array_equal(pp.mu, ps.mu[:3]) and np.array_equal(pp.sigma, ps.sigma[:3, :3])
     t, mu3, s3 = g.pose()
     assert np.array_equal(mu3, after.mu[:3]) and np.array_equal(s3, after.sigma[:3, :3])
+    # ... and it equals what the mutating Predict then produces
+    g.handle_odometry(0.7, 1.0, 0.0, 0.3)
+    st = g.GetState()
+    assert np.array_equal(st.mu, ps.mu) and np.array_equal(st.sigma, ps.sigma)
+
+
+def test_predict_state_full_omni_with_landmarks(oracle_lib):
+    cfg = synth.SessionConfig("omni_ps", 20, 8, synth.OMNI, seed=5, speed=1.0, row_spacing=6.0)
+    sess = synth.make_session(cfg, max_scans=60)
+    g, o = _pair(cfg, sess)
+    drive_pair(sess, g, o)
+    ps = g.PredictState(g.GetLatestTime() + 0.13)
+    mu_p, P_p = o.predict_state(o.time + 0.13, full=True)
+    assert ps.mu.shape == mu_p.shape and ps.mu.shape[0] > 11
+    assert np.abs(ps.mu - mu_p).max() < 1e-12 and np.abs(ps.sigma - P_p).max() < 1e-13
+
+
+def test_use_imu_ignores_odometry_like_the_reference():
+    """reflector_ekf_slam.cc:213-223: with use_imu the odometry branch is skipped entirely (no vt, no predict, no time)."""
+    from reflector_ekf_slam_amd import EKFOptions, ReflectorEKFSLAM
+    g = ReflectorEKFSLAM(EKFOptions(use_imu=True, init_pose=(1.0, 2.0, 0.3)), max_landmarks=4)
+    g.handle_odometry(0.5, 1.0, 0.0, 0.2)
+    assert g.GetLatestTime() == 0.0
+    t, mu3, s3 = g.pose()
+    assert np.array_equal(mu3, [1.0, 2.0, 0.3]) and not s3.any()
+
+
+def test_sticky_flags_are_visible_without_sync(capfd):
+    """Capacity overflow must reach callers that only use the getters (the adapter never calls rekf_sync)."""
+    g = _simple(cap=2)
+    g.handle_observation(0.1, np.array([[2.0, 0.0], [0.0, 2.0], [-2.0, 0.0]], np.float32))   # 3 new, room for 2
+    t, mu3, s3 = g.pose()
+    assert g.flags() == 1 and g.flags() == 1                    # REKF_FLAGBIT_CAPACITY, not cleared by reading
+    assert "DROPPED" in capfd.readouterr().err
+    assert g.sync_code() == -4 and g.flags() == 0
 
 
 def test_set_state_get_state_round_trip_and_two_handles():
