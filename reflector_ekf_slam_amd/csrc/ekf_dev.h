@@ -84,6 +84,7 @@ struct RekfDev {
     int ld;
     int n_max;
     int dbg;            // ablation bits for rekf_debug_time_kernel; 0 in normal operation
+    int kc_ub;          // host bound of m_pad for the current scan, rounded up to 16 (0: unknown); columns [m, kc_ub) of HPt / Kn are zero
 };
 
 // first row of the thin border that k_downdate treats as strips, or -1 (n a multiple of 64, border wider than

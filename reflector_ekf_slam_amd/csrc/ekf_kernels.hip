@@ -24,6 +24,8 @@
 //     Eigen's partial-pivot LU.
 #include "ekf_dev.h"
 
+#include <type_traits>
+
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
@@ -577,7 +579,8 @@ __global__ __launch_bounds__(256) void k_gather(RekfDev d, RekfFrontArgs A)
     const int strip_nb = rekf_strip_base(n);          // k_downdate's border strips want rows nb.. of HPt contiguous
 
     // ---- W(c, r) = sum_k P(c,k) H(r,k)  and  HPt(c, r) = sum_k H(r,k) P(k,c) for this workgroup's row pairs
-    for (int pr = blockIdx.y; pr < m_pad / 2; pr += gridDim.y) {
+    const int fill = (d.kc_ub > m_pad) ? d.kc_ub : m_pad;   // columns [m, fill) of W / HPt are written as zeros
+    for (int pr = blockIdx.y; pr < fill / 2; pr += gridDim.y) {
         const int r0 = 2 * pr;
         double ha[2][3] = {{0, 0, 0}, {0, 0, 0}}, hb[2][2] = {{0, 0}, {0, 0}};
         int col = -1;
@@ -953,6 +956,15 @@ __global__ __launch_bounds__(512) void k_gain(RekfDev d)
     const int ntile = m_pad / 16;
     const int strip_nb = rekf_strip_base(n);          // k_downdate's border strips want rows nb.. of Kn contiguous
     const double *__restrict__ Wp = d.W + (size_t)(i0 + idx);
+    for (int jt = ntile + 1 + wave; jt <= d.kc_ub / 16; jt += 8) {           // columns [m_pad, kc_ub) of Kn: zeros (k_downdate2<kc_ub>)
+        const int j0 = 16 * (jt - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = j0 + kq + 4 * r;
+            d.Kn[(i0 + idx) + (size_t)j * ld] = 0.0;
+            if (strip_nb >= 0 && i0 + idx >= strip_nb && i0 + idx < strip_nb + REKF_STRIP_MAX) d.KnB[(i0 + idx - strip_nb) * REKF_MR_PAD + j] = 0.0;
+        }
+    }
     for (int jt = wave; jt <= ntile; jt += 8) {
         const bool is_mu = jt == ntile;
         const int j0 = 16 * jt;
@@ -1465,6 +1477,334 @@ __device__ static void downdate_body(const RekfDev &d, double *dd_smem, DdBorder
     }
 }
 
+// ----------------------------------------------------------------------------
+// k_downdate2<KC>: the rank-m downdate when the scan's innovation fits one k-chunk, m_pad <= KC <= 64 (the host picks
+// KC from its bound 2K(+3) of m; k_gather / k_gain keep the columns [m, KC) of HPt / Kn zero).  Round-2 pipeline.
+//
+// What changed against the register-staged version above (which needed 18.5 us at C3 although its
+// P traffic alone takes 11 us and its MFMAs alone 9 us -- the two did not overlap: store burst, LDS
+// panel write and barrier sat between the MFMA loops of consecutive tiles):
+//   * the Kn / HPt panels go global -> LDS by DMA (global_load_lds_dwordx4, 1 KiB per wave
+//     instruction = two k-rows of a panel, which is exactly the linear [k][64] LDS image): no staging
+//     registers, no ds_write pass;
+//   * a panel is fetched only when its tile row / column CHANGES: a workgroup's tiles run down one
+//     tile column, so HPt(J) is loaded once and only Kn(I) streams (half the panel traffic);
+//   * the accumulators start at ZERO and P is added at the end of the tile (P + sum_k, the order the
+//     reference's `sigma - K*H*sigma` has), so a tile's P block is not needed until its MFMA loop is
+//     over: it is requested during the PREVIOUS tile;
+//   * P + acc lands in the registers that held P: the stores of tile t are issued from there in the
+//     first half of tile t+1's MFMA loop, then the same registers receive the P block of tile t+2.
+//     Nothing but the DMA wait and ONE barrier sits between two MFMA loops.
+// VMEM order inside tile t: DMA of the next panels, stores of tile t-1, loads of tile t+1.  vmcnt
+// retires in order, so `s_waitcnt vmcnt(#stores + #loads)` at the end of the loop waits for exactly
+// the DMA (hipcc does not count the asm DMA; its own waits only become a little earlier than needed).
+// ----------------------------------------------------------------------------
+__device__ static inline void dd_dma16(const double *gsrc, unsigned lds_dst)
+{
+    unsigned keep;                          // M0 = wave-uniform LDS byte address; lane l lands at +16 l
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ static inline void dd_wait_vmcnt()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is 6 bits on gfx9");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int KC>
+__global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
+{
+    extern __shared__ __attribute__((aligned(16))) double dd_smem[];   // [Kn 0 | Kn 1 | HPt 0 | HPt 1] panels (+ 16 KiB strip scratch if KC < 64)
+    __shared__ __attribute__((aligned(16))) double s_border[2][DD_STRIP_MAX][REKF_MR_PAD];
+#ifdef REKF_DEBUG_TIMING
+    long long tq2[24]; int nq2 = 0;
+    const bool rec2 = blockIdx.x == 0 && threadIdx.x == 0;
+    const long long t_entry2 = clock64(), w_entry2 = wall_clock64();
+#define D2MARK() do { __builtin_amdgcn_sched_barrier(0); if (rec2 && nq2 < 24) tq2[nq2++] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define D2MARK()
+#endif
+    const RekfCtl *ctl = d.ctl;
+    if (ctl->m == 0) return;
+    const int n = ctl->n;
+    constexpr int NK = KC / 4;               // MFMA k-steps per tile
+    constexpr int ND = KC / 8;               // DMA instructions per panel per wave (2 k-rows each, 4 waves)
+    constexpr int PANEL = KC * 64;           // doubles per panel
+    static_assert(KC % 16 == 0 && KC >= 16 && KC <= 64, "one k-chunk");
+    constexpr int Q4 = NK / 4;               // k-steps per VMEM phase: [DMA Kn][stores (+ DMA HPt)][P loads][-]
+    const int rem = n % DT;
+    const bool strips = rem > 0 && rem <= DD_STRIP_MAX && n >= DT;
+    const int T = strips ? n / DT : (n + DT - 1) / DT;
+    int i_lo = 0, i_n = T, j_lo = 0, j_n = T, w = blockIdx.x, nw = gridDim.x;
+    if (gridDim.x >= 8 && (gridDim.x & 7) == 0) {           // per-XCD 2 x 4 tile regions (see downdate_body)
+        const int x = blockIdx.x & 7, ri = x >> 2, rj = x & 3;
+        i_lo = ri * T / 2; i_n = (ri + 1) * T / 2 - i_lo;
+        j_lo = rj * T / 4; j_n = (rj + 1) * T / 4 - j_lo;
+        w = blockIdx.x >> 3; nw = gridDim.x >> 3;
+    }
+    const int ntiles = i_n * j_n;
+    const int t_begin = (int)(((long long)w * ntiles) / nw);
+    const int t_end = (int)(((long long)(w + 1) * ntiles) / nw);
+    if (t_begin >= t_end) return;
+    const int nt = t_end - t_begin;
+    const size_t ld = (size_t)d.ld;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int idx = lane & 15, kq = lane >> 4;
+    const int wi = wave & 1, wj = wave >> 1;
+    const double *__restrict__ Kn = d.Kn;
+    const double *__restrict__ HPt = d.HPt;
+    double *__restrict__ P = d.P;
+
+    // a diagonal tile of the range is taken LAST (its strip work then rides on a tile that has nothing to prefetch);
+    // should a range ever hold more than one, the others are still handled where they stand (`special` below)
+    int t_diag = t_end - 1;
+    if (strips) {
+        const int dl = j_lo - i_lo;
+        for (int jj = t_begin / i_n; jj <= (t_end - 1) / i_n; ++jj) {
+            const int ii = jj + dl, t = jj * i_n + ii;
+            if (ii >= 0 && ii < i_n && jj < j_n && t >= t_begin && t < t_end) t_diag = t;
+        }
+    }
+    auto tile_IJ = [&](int pos, int &I, int &J) {
+        const int tile = t_begin + pos;
+        const int tt = (tile == t_end - 1) ? t_diag : ((tile == t_diag) ? t_end - 1 : tile);
+        const int jj = tt / i_n;
+        I = i_lo + (tt - jj * i_n); J = j_lo + jj;
+    };
+    // LDS: [Kn buffer 0 | Kn buffer 1 | HPt buffer 0 | HPt buffer 1], PANEL doubles each
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)dd_smem;
+    auto kn_buf = [&](int b) -> const double * { return dd_smem + (size_t)b * PANEL; };
+    auto hp_buf = [&](int b) -> const double * { return dd_smem + (size_t)(2 + b) * PANEL; };
+    // one DMA instruction: k-rows 2(4q + wave) + {0,1} of the panel that starts at row `row0` of `src`
+    auto dma_piece = [&](const double *src, int row0, int buf_index, int q) {
+        const int pr = 4 * q + wave;
+        const double *g = src + (size_t)(row0 + 2 * (lane & 31)) + (size_t)(2 * pr + (lane >> 5)) * ld;
+        dd_dma16(g, lds0 + (unsigned)(buf_index * PANEL * 8 + pr * 1024));
+    };
+    auto p_ptr = [&](int I, int J) -> double * {
+        return P + (size_t)(DT * I + 32 * wi + 2 * idx) + (size_t)(DT * J + 32 * wj + 2 * kq) * ld;
+    };
+
+    v2d pq[2][8];                 // P block of a tile -> P + acc -> store source; two tiles in rotation
+    v4d acc[2][2];
+    int I, J, kb = 0, hb = 0;
+    tile_IJ(0, I, J);
+
+    // ---- border strips (see "Border strips" above): same scheme as before, on whichever tile is diagonal
+    auto strip_addr = [&](int II, double *&p0, double *&p1, int &which, int &b, int &x) {
+        which = tid / (DD_STRIP_MAX * 32); const int u = tid % (DD_STRIP_MAX * 32);
+        b = u >> 5; x = 2 * (u & 31);
+        const int nb = DT * T;
+        if (which == 0) { p0 = P + (size_t)(DT * II + x) + (size_t)(nb + b) * ld; p1 = p0 + 1; }
+        else { p0 = P + (size_t)(nb + b) + (size_t)(DT * II + x) * ld; p1 = p0 + ld; }
+    };
+    static_assert(2 * DD_STRIP_MAX * 32 <= 256, "one pass of the strip mapping");
+
+    D2MARK();                                // 0: ctl read, tile assignment done
+    // ---- prologue: border rows, both panels of tile 0 by DMA, its P block
+    if (strips) {
+        const v2d b0 = ((const v2d *)d.KnB)[tid], b1 = ((const v2d *)d.HPtB)[tid];
+        ((v2d *)&s_border[0][0][0])[tid] = b0;                     // s_border[0] = Kn rows nb.., [1] = HPt rows nb..
+        ((v2d *)&s_border[1][0][0])[tid] = b1;
+    }
+#pragma unroll
+    for (int q = 0; q < ND; ++q) dma_piece(Kn, DT * I, 0, q);
+#pragma unroll
+    for (int q = 0; q < ND; ++q) dma_piece(HPt, DT * J, 2, q);
+    {
+        const double *Pw = p_ptr(I, J);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pq[0][mt * 4 + r] = *(const v2d *)(Pw + (size_t)(8 * r + mt) * ld);
+    }
+    dd_wait_vmcnt<8>();                      // the DMAs (and everything before them); the 8 P loads may still fly
+    lds_barrier();
+    D2MARK();                                // 1: panels of tile 0 landed
+
+    // ---- one tile.  PAR = which half of pq holds this tile's P block; FIRST / LAST / SPECIAL are compile-time so that
+    // every load and store of the steady-state variants is unconditional: hipcc's s_waitcnt pass then counts them exactly
+    // (with `if (pos > 0)` around the stores it had to assume the fewest, and waited vmcnt(0) for the P block it had only
+    // just requested).  SPECIAL = diagonal tile that carries the border strips; it prefetches no panels (its idle Kn
+    // buffer is the strip scratch), which costs nothing when it is the last tile -- the usual case.
+    auto tile_body = [&](auto par_c, auto first_c, auto last_c, auto special_c, int pos) {
+        constexpr int PAR = decltype(par_c)::value;
+        constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value, SPECIAL = decltype(special_c)::value;
+        int In = I, Jn = J;
+        if (!LAST) tile_IJ(pos + 1, In, Jn);
+        const bool needK = !LAST && In != I, needH = !LAST && Jn != J;
+        const double *Pn = p_ptr(In, Jn);
+        double *Po = nullptr;                               // where tile pos-1 goes
+        if (!FIRST) { int Ip, Jp; tile_IJ(pos - 1, Ip, Jp); Po = p_ptr(Ip, Jp); }
+        const double *aW = hp_buf(hb) + 32 * wj + 2 * idx + kq * 64;        // A[j][k] = HP(k,j)
+        const double *bK = kn_buf(kb) + 32 * wi + 2 * idx + kq * 64;        // B[k][i] = Kn(i,k)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0, 0, 0, 0};
+        // strip operands of a special tile: lane -> (strip, x), wave -> quarter of the k range
+        const int s_which = lane >> 5, s_x = 2 * (lane & 31), s_kb = (KC / 4) * wave;
+        const double *s_panel = (s_which ? hp_buf(hb) : kn_buf(kb)) + s_x + s_kb * 64;
+        const double *s_brow = &s_border[s_which ? 0 : 1][0][s_kb];
+        v2d sacc[DD_STRIP_MAX];
+        v2d strip_p;
+        if (SPECIAL) {
+            double *p0, *p1; int which, b, x;
+            strip_addr(I, p0, p1, which, b, x);
+            if (which < 2 && b < rem) { strip_p.x = *p0; strip_p.y = *p1; }
+#pragma unroll
+            for (int b2 = 0; b2 < DD_STRIP_MAX; ++b2) { sacc[b2].x = 0.0; sacc[b2].y = 0.0; }
+        }
+        v2d a2 = *(const v2d *)(aW), b2 = *(const v2d *)(bK);
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+            v2d a2n = a2, b2n = b2;
+            if (kk + 1 < NK) {
+                a2n = *(const v2d *)(aW + (kk + 1) * 256);
+                b2n = *(const v2d *)(bK + (kk + 1) * 256);
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.y, acc[1][1], 0, 0, 0);
+            // ---- this k-step's share of the VMEM traffic (compile-time positions)
+            const int ph = kk / Q4, off = kk % Q4;          // phase 0: DMA Kn, 1: stores then DMA HPt, 2: P loads, 3: nothing
+            if (ph == 0 && !SPECIAL && !LAST) {
+                if (needK) {
+#pragma unroll
+                    for (int q = 0; q < ND; ++q)
+                        if ((q * Q4) / ND == off) dma_piece(Kn, DT * In, kb ^ 1, q);
+                }
+            } else if (ph == 1) {
+                if (!FIRST) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if ((q * Q4) / 8 == off) *(v2d *)(Po + (size_t)(8 * (q & 3) + (q >> 2)) * ld) = pq[PAR ^ 1][q];
+                }
+                if (!SPECIAL && !LAST && needH) {
+#pragma unroll
+                    for (int q = 0; q < ND; ++q)
+                        if ((q * Q4) / ND == off) dma_piece(HPt, DT * Jn, 2 + (hb ^ 1), q);
+                }
+            } else if (ph == 2 && !LAST) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if ((q * Q4) / 8 == off) pq[PAR ^ 1][q] = *(const v2d *)(Pn + (size_t)(8 * (q & 3) + (q >> 2)) * ld);
+            }
+            if (SPECIAL && (kk & 1) == 0) {                 // strip FMAs ride under the MFMAs: k pair (kk, kk+1) of this wave's quarter
+                const v2d v0 = *(const v2d *)(s_panel + kk * 64), v1 = *(const v2d *)(s_panel + (kk + 1) * 64);
+#pragma unroll
+                for (int b3 = 0; b3 < DD_STRIP_MAX; ++b3) {
+                    const v2d bb = *(const v2d *)(s_brow + b3 * REKF_MR_PAD + kk);
+                    sacc[b3].x = fma(v0.x, bb.x, sacc[b3].x); sacc[b3].y = fma(v0.y, bb.x, sacc[b3].y);
+                    sacc[b3].x = fma(v1.x, bb.y, sacc[b3].x); sacc[b3].y = fma(v1.y, bb.y, sacc[b3].y);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            a2 = a2n; b2 = b2n;
+        }
+        D2MARK();                            // MFMA loop done
+        // P + sum_k (the P block was requested a whole tile ago)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pq[PAR][mt * 4 + r].x += acc[mt][0][r];
+                pq[PAR][mt * 4 + r].y += acc[mt][1][r];
+            }
+        if (SPECIAL) {
+            // partial strip sums of the four waves meet in the idle Kn buffer; the threads of the strip mapping finish
+            // (with KC < 64 a panel is smaller than the 16 KiB of partial sums: the launch's LDS beyond the four panels is free)
+            v2d *red = (v2d *)(dd_smem + (KC == 64 ? (size_t)(kb ^ 1) * PANEL : (size_t)4 * PANEL));
+#pragma unroll
+            for (int b3 = 0; b3 < DD_STRIP_MAX; ++b3) red[(wave * DD_STRIP_MAX + b3) * 64 + lane] = sacc[b3];
+            lds_barrier();
+            {
+                double *p0, *p1; int which, b, x;
+                strip_addr(I, p0, p1, which, b, x);
+                if (which < 2 && b < rem) {
+                    v2d t = strip_p;
+#pragma unroll
+                    for (int w4 = 0; w4 < 4; ++w4) { const v2d r = red[(w4 * DD_STRIP_MAX + b) * 64 + which * 32 + (x >> 1)]; t.x += r.x; t.y += r.y; }
+                    *p0 = t.x; *p1 = t.y;
+                }
+            }
+            if (I == 0 && tid < 64) {                   // the corner block P(nb.., nb..): 16 (a,b) slots x 4 quarters of k
+                const int a = (tid >> 2) & 3, b = tid & 3, k4 = tid >> 4;
+                const double *ra = &s_border[0][a][(KC / 4) * k4], *rb = &s_border[1][b][(KC / 4) * k4];
+                double v = 0.0;
+#pragma unroll
+                for (int k = 0; k < KC / 4; k += 2) {
+                    const v2d u = *(const v2d *)(ra + k), ww = *(const v2d *)(rb + k);
+                    v = fma(u.x, ww.x, v); v = fma(u.y, ww.y, v);
+                }
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (k4 == 0 && a < rem && b < rem) {
+                    double *pp = P + (size_t)(DT * T + a) + (size_t)(DT * T + b) * ld;
+                    *pp += v;
+                }
+            }
+        }
+        D2MARK();                            // P block there, combined (+ strips)
+        if (LAST) {
+            double *Pw = p_ptr(I, J);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) *(v2d *)(Pw + (size_t)(8 * (q & 3) + (q >> 2)) * ld) = pq[PAR][q];
+            return;
+        }
+        if (SPECIAL) {                                      // a special tile in mid-range (rare): fetch the next panels now
+            lds_barrier();                                  // every wave is done with the scratch and the old panels
+            if (needK) {
+#pragma unroll
+                for (int q = 0; q < ND; ++q) dma_piece(Kn, DT * In, kb ^ 1, q);
+            }
+            if (needH) {
+#pragma unroll
+                for (int q = 0; q < ND; ++q) dma_piece(HPt, DT * Jn, 2 + (hb ^ 1), q);
+            }
+            dd_wait_vmcnt<0>();
+        } else if (needH) dd_wait_vmcnt<8>();               // after the last HPt DMA: this tile's 8 P loads
+        else if (needK) dd_wait_vmcnt<FIRST ? 8 : 16>();    // after the last Kn DMA: (8 stores +) 8 P loads
+        if (needK || needH) lds_barrier();
+        if (needK) kb ^= 1;
+        if (needH) hb ^= 1;
+        I = In; J = Jn;
+        D2MARK();                            // next panels landed, barrier passed
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    using Tt = std::true_type;
+    using Ff = std::false_type;
+    auto run = [&](auto par_c, auto first_c, auto last_c, int pos) {
+        if (strips && I == J) tile_body(par_c, first_c, last_c, Tt(), pos);
+        else tile_body(par_c, first_c, last_c, Ff(), pos);
+    };
+    if (nt == 1) run(B0(), Tt(), Tt(), 0);
+    else {
+        run(B0(), Tt(), Ff(), 0);
+        int pos = 1;
+        for (; pos + 2 < nt; pos += 2) {                    // steady state: two tiles per trip, pq halves by name
+            run(B1(), Ff(), Ff(), pos);
+            run(B0(), Ff(), Ff(), pos + 1);
+        }
+        if (pos + 1 < nt) {
+            run(B1(), Ff(), Ff(), pos);
+            run(B0(), Ff(), Tt(), pos + 1);
+        } else run(B1(), Ff(), Tt(), pos);
+    }
+#ifdef REKF_DEBUG_TIMING
+    if (rec2) {
+        RekfCtl *c = const_cast<RekfCtl *>(d.ctl);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        c->dbg[6] = clock64() - t_entry2;               // whole body, last stores retired
+        c->dbg[5] = wall_clock64() - w_entry2;          // same in 100 MHz ticks
+        c->dbg[7] = nq2;
+        for (int i = 0; i < nq2; ++i) c->dbg[8 + i] = tq2[i] - t_entry2;
+    }
+#endif
+}
+
 __global__ __launch_bounds__(256, 2) void k_downdate(RekfDev d)
 {
     extern __shared__ __attribute__((aligned(16))) double dd_smem[];   // [2 buffers][Kn | HPt][DKC*64]
@@ -1476,7 +1816,7 @@ __global__ __launch_bounds__(256, 2) void k_downdate(RekfDev d)
     const int m_pad = ctl->m_pad;
     if (ctl->m == 0) return;
     const int n = ctl->n;
-    if (d.dbg) {                                   // ablation runs (rekf_debug_time_kernel)
+    if (d.dbg) {                                   // ablation runs (rekf_debug_time_kernel): the round-1 body
         if (m_pad == DKC) downdate_body<true, true>(d, dd_smem, s_border, n, m_pad);
         else downdate_body<false, true>(d, dd_smem, s_border, n, m_pad);
     } else if (m_pad == DKC) downdate_body<true, false>(d, dd_smem, s_border, n, m_pad);
@@ -1641,12 +1981,20 @@ void rekf_launch_gain(const RekfDev &d, int n_ub, hipStream_t s)
 {
     hipLaunchKernelGGL(k_gain, dim3((n_ub + 15) / 16), dim3(512), 0, s, d);
 }
+template <int KC> static void launch_downdate2(const RekfDev &d, int grid, hipStream_t s, bool first_on_device)
+{
+    constexpr int BYTES = 4 * KC * 64 * (int)sizeof(double) + (KC < 64 ? 16384 : 0);
+    if (first_on_device)
+        (void)hipFuncSetAttribute((const void *)k_downdate2<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+    hipLaunchKernelGGL(k_downdate2<KC>, dim3(grid), dim3(256), BYTES, s, d);
+}
 void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s)
 {
     // persistent: one workgroup per CU (128 KiB of LDS each), never more workgroups than tiles.  The opt-in to more than
     // 64 KiB of dynamic LDS and the CU count are per DEVICE: a process may hold handles on several GPUs.
     constexpr int MAX_DEV = 64;
     static int n_cu_of[MAX_DEV] = {0};
+    static unsigned attr_done[MAX_DEV] = {0};         // bit KC/16 : k_downdate2<KC> has its LDS opt-in on this device
     int dev = 0;
     (void)hipGetDevice(&dev);
     const int slot = (dev >= 0 && dev < MAX_DEV) ? dev : 0;
@@ -1658,12 +2006,24 @@ void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s)
         (void)hipFuncSetAttribute((const void *)k_downdate, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   DD_NBUF * 2 * DKC * 64 * (int)sizeof(double));
         n_cu_of[slot] = cu;
+        attr_done[slot] = 0;
     }
     const int n_cu = n_cu_of[slot];
     const int T = (n_ub + DT - 1) / DT;
     const int slots = n_cu * DD_WG_PER_CU;
     int grid = (T * T < slots) ? T * T : slots;
     if (grid >= 64) grid &= ~7;                     // multiple of 8: enables the per-XCD tile regions
+    const int kc = d.kc_ub;
+    if (kc >= 16 && kc <= 64 && !d.dbg) {           // the whole innovation fits one k-chunk: round-2 pipeline
+        const unsigned bit = 1u << (kc / 16);
+        const bool first = !(attr_done[slot] & bit) || dev != slot;
+        attr_done[slot] |= bit;
+        if (kc == 64) launch_downdate2<64>(d, grid, s, first);
+        else if (kc == 48) launch_downdate2<48>(d, grid, s, first);
+        else if (kc == 32) launch_downdate2<32>(d, grid, s, first);
+        else launch_downdate2<16>(d, grid, s, first);
+        return;
+    }
     hipLaunchKernelGGL(k_downdate, dim3(grid), dim3(256), DD_NBUF * 2 * DKC * 64 * sizeof(double), s, d);
 }
 void rekf_launch_augment(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s)

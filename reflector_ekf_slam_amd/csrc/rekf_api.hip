@@ -325,6 +325,7 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         h->time = t;
         return REKF_OK;
     }
+    h->dev.kc_ub = round_up(2 * K + (gps_pose3 ? 3 : 0), 16);
     { ProfScope ps(h, REKF_K_FRONT); rekf_launch_front_mb(h->dev, a, h->n_ub, h->stream); }
     h->time = t;                                      // cc:234
     const int n_ub = h->n_ub;

@@ -51,9 +51,12 @@ class SessionConfig:
 C2 = SessionConfig("C2_N128_obs16", 128, 16, DIFF, seed=20210330)
 C3 = SessionConfig("C3_N1024_obs32", 1024, 32, DIFF, seed=20210331)
 C4 = SessionConfig("C4_N512_omni", 512, 32, OMNI, seed=20210332)
-# C4's observations come from the 3D detector run on synthetic clouds (make_point_cloud): the lidar's usable range is
-# set to the range gate the 2D configs use (range_max above), so a sweep holds about 32 detectable posts.
-C4_LIDAR_RANGE = 10.0
+# C4's observations come from the 3D detector run on synthetic clouds (make_point_cloud(..., **C4_LIDAR)).  The usable
+# range is the range gate of the 2D configs (range_max above: a sweep then holds about 32 detectable posts); the beam
+# pattern (1 degree between rings, 0.4 degree in azimuth) keeps the hits of one post within the detector's 0.2 m
+# cluster tolerance of each other out to that range -- so that ONE post is ONE cluster, not one per ring -- and within
+# its 160-point cluster size limit down to about 2.5 m (point_cloud_reflector_detect.cc:65-74).
+C4_LIDAR = dict(rings=16, n_az=900, elev_deg=7.5, max_range=10.0)
 
 
 @dataclass
@@ -274,7 +277,7 @@ def make_laser_scan(landmarks: np.ndarray, pose, stamp: float, rng: np.random.Ge
 
 def make_point_cloud(landmarks: np.ndarray, pose, rng: np.random.Generator, rings: int = 16, n_az: int = 1800,
                      sensor_height: float = 0.7, post_radius: float = 0.09, post_z=(0.2, 1.2),
-                     max_range: float = 25.0, n_outliers: int = 40):
+                     max_range: float = 25.0, n_outliers: int = 40, elev_deg: float = 15.0):
     """One XYZI sweep of a `rings` x `n_az` spinning lidar at base_link `pose` (sensor at the base_link
     origin): reflector posts (vertical strips, intensity 200+-20) and a dim
     background (ground / far wall, intensity 20+-10), plus `n_outliers` isolated bright points that
@@ -287,7 +290,7 @@ def make_point_cloud(landmarks: np.ndarray, pose, rng: np.random.Generator, ring
     dist = np.hypot(lx, ly)
     bearing = np.arctan2(ly, lx)
     az = -math.pi + 2.0 * math.pi * np.arange(n_az) / n_az
-    elev = np.deg2rad(np.linspace(-15.0, 15.0, rings))
+    elev = np.deg2rad(np.linspace(-elev_deg, elev_deg, rings))
     near = np.argsort(dist)
     near = near[(dist[near] < max_range) & (dist[near] > 0.5)]
     hit_range = np.full(n_az, np.inf)

@@ -375,9 +375,6 @@ def test_c_abi_direct_calls_reject_bad_arguments():
     o = _lib.RekfOptions()
     h = C.c_void_p()
     assert L.rekf_create(C.byref(o), 0, 0, C.byref(h)) == -1          # max_landmarks < 1
-    o.use_imu = 1
-    assert L.rekf_create(C.byref(o), 4, 0, C.byref(h)) == -7          # unsupported (reference IMU path is empty)
-    o.use_imu = 0
     assert L.rekf_create(C.byref(o), 4, 0, C.byref(h)) == 0
     n = C.c_int()
     assert L.rekf_get_n(h, C.byref(n)) == 0 and n.value == 3
