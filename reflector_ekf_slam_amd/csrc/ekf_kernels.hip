@@ -1565,7 +1565,7 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
             if (ii >= 0 && ii < i_n && jj < j_n && t >= t_begin && t < t_end) t_diag = t;
         }
     }
-    auto tile_IJ = [&](int pos, int &I, int &J) {
+    auto tile_IJ = [&](int pos, int &I, int &J) __attribute__((always_inline)) {
         const int tile = t_begin + pos;
         const int tt = (tile == t_end - 1) ? t_diag : ((tile == t_diag) ? t_end - 1 : tile);
         const int jj = tt / i_n;
@@ -1573,25 +1573,30 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     };
     // LDS: [Kn buffer 0 | Kn buffer 1 | HPt buffer 0 | HPt buffer 1], PANEL doubles each
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)dd_smem;
-    auto kn_buf = [&](int b) -> const double * { return dd_smem + (size_t)b * PANEL; };
-    auto hp_buf = [&](int b) -> const double * { return dd_smem + (size_t)(2 + b) * PANEL; };
+    auto kn_buf = [&](int b) __attribute__((always_inline)) -> const double * { return dd_smem + (size_t)b * PANEL; };
+    auto hp_buf = [&](int b) __attribute__((always_inline)) -> const double * { return dd_smem + (size_t)(2 + b) * PANEL; };
     // one DMA instruction: k-rows 2(4q + wave) + {0,1} of the panel that starts at row `row0` of `src`
-    auto dma_piece = [&](const double *src, int row0, int buf_index, int q) {
+    auto dma_piece = [&](const double *src, int row0, int buf_index, int q) __attribute__((always_inline)) {
         const int pr = 4 * q + wave;
         const double *g = src + (size_t)(row0 + 2 * (lane & 31)) + (size_t)(2 * pr + (lane >> 5)) * ld;
         dd_dma16(g, lds0 + (unsigned)(buf_index * PANEL * 8 + pr * 1024));
     };
-    auto p_ptr = [&](int I, int J) -> double * {
+    auto p_ptr = [&](int I, int J) __attribute__((always_inline)) -> double * {
         return P + (size_t)(DT * I + 32 * wi + 2 * idx) + (size_t)(DT * J + 32 * wj + 2 * kq) * ld;
     };
 
-    v2d pq[2][8];                 // P block of a tile -> P + acc -> store source; two tiles in rotation
+    // P block of a tile -> P + acc -> store source.  NB register blocks in rotation: the read stream runs AHEAD tiles ahead
+    // of the MFMAs.  Measured at C3 (4 tiles per workgroup): AHEAD = 1 and 2 give the same kernel time (17.7 us) -- with two
+    // blocks in flight the first MFMA loop stretches from 2.3 to 3.6 us: a wave that cannot issue its load (memory queue
+    // full) cannot issue its MFMAs either.
+    constexpr int AHEAD = 1, NB = AHEAD + 1;
+    v2d pq[NB][8];
     v4d acc[2][2];
     int I, J, kb = 0, hb = 0;
     tile_IJ(0, I, J);
 
     // ---- border strips (see "Border strips" above): same scheme as before, on whichever tile is diagonal
-    auto strip_addr = [&](int II, double *&p0, double *&p1, int &which, int &b, int &x) {
+    auto strip_addr = [&](int II, double *&p0, double *&p1, int &which, int &b, int &x) __attribute__((always_inline)) {
         which = tid / (DD_STRIP_MAX * 32); const int u = tid % (DD_STRIP_MAX * 32);
         b = u >> 5; x = 2 * (u & 31);
         const int nb = DT * T;
@@ -1614,26 +1619,35 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     {
         const double *Pw = p_ptr(I, J);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pq[0][mt * 4 + r] = *(const v2d *)(Pw + (size_t)(8 * r + mt) * ld);
+        for (int q = 0; q < 8; ++q) pq[0][q] = *(const v2d *)(Pw + (size_t)(8 * (q & 3) + (q >> 2)) * ld);
     }
-    dd_wait_vmcnt<8>();                      // the DMAs (and everything before them); the 8 P loads may still fly
+    if (AHEAD > 1 && nt > 1) {               // ... and the P block of tile 1
+        int I1, J1;
+        tile_IJ(1, I1, J1);
+        const double *Pw = p_ptr(I1, J1);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pq[NB - 2][q] = *(const v2d *)(Pw + (size_t)(8 * (q & 3) + (q >> 2)) * ld);
+        dd_wait_vmcnt<16>();                 // the DMAs (and everything before them); the 16 P loads may still fly
+    } else dd_wait_vmcnt<8>();
     lds_barrier();
     D2MARK();                                // 1: panels of tile 0 landed
 
-    // ---- one tile.  PAR = which half of pq holds this tile's P block; FIRST / LAST / SPECIAL are compile-time so that
-    // every load and store of the steady-state variants is unconditional: hipcc's s_waitcnt pass then counts them exactly
-    // (with `if (pos > 0)` around the stores it had to assume the fewest, and waited vmcnt(0) for the P block it had only
-    // just requested).  SPECIAL = diagonal tile that carries the border strips; it prefetches no panels (its idle Kn
-    // buffer is the strip scratch), which costs nothing when it is the last tile -- the usual case.
-    auto tile_body = [&](auto par_c, auto first_c, auto last_c, auto special_c, int pos) {
-        constexpr int PAR = decltype(par_c)::value;
-        constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value, SPECIAL = decltype(special_c)::value;
+    // ---- one tile.  PAR = which third of pq holds this tile's P block; FIRST (no tile before it: nothing to store), LOAD2
+    // (tile pos+2 exists: request its P block), LAST and SPECIAL are compile-time so that every load and store of a variant
+    // is unconditional: hipcc's s_waitcnt pass then counts them exactly (with `if (pos > 0)` around the stores it had to
+    // assume the fewest, and waited vmcnt(0) for a P block it had only just requested).  SPECIAL = diagonal tile that carries
+    // the border strips; it prefetches no panels (its idle Kn buffer is the strip scratch), which costs nothing when it is
+    // the last tile -- the usual case.
+    auto tile_body = [&](auto par_c, auto first_c, auto load2_c, auto last_c, auto special_c, int pos) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_c)::value, PREV = (PAR + AHEAD) % NB;   // PREV: tile pos-1's block = where tile pos+AHEAD's goes
+        constexpr bool FIRST = decltype(first_c)::value, LOAD2 = decltype(load2_c)::value, LAST = decltype(last_c)::value,
+                       SPECIAL = decltype(special_c)::value;
+        static_assert(!(LAST && LOAD2), "no tile after the last");
         int In = I, Jn = J;
         if (!LAST) tile_IJ(pos + 1, In, Jn);
         const bool needK = !LAST && In != I, needH = !LAST && Jn != J;
-        const double *Pn = p_ptr(In, Jn);
+        const double *Pn = nullptr;                         // tile pos+2's P block
+        if (LOAD2) { int I2, J2; tile_IJ(pos + AHEAD, I2, J2); Pn = p_ptr(I2, J2); }
         double *Po = nullptr;                               // where tile pos-1 goes
         if (!FIRST) { int Ip, Jp; tile_IJ(pos - 1, Ip, Jp); Po = p_ptr(Ip, Jp); }
         const double *aW = hp_buf(hb) + 32 * wj + 2 * idx + kq * 64;        // A[j][k] = HP(k,j)
@@ -1679,17 +1693,17 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
                 if (!FIRST) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q)
-                        if ((q * Q4) / 8 == off) *(v2d *)(Po + (size_t)(8 * (q & 3) + (q >> 2)) * ld) = pq[PAR ^ 1][q];
+                        if ((q * Q4) / 8 == off) *(v2d *)(Po + (size_t)(8 * (q & 3) + (q >> 2)) * ld) = pq[PREV][q];
                 }
                 if (!SPECIAL && !LAST && needH) {
 #pragma unroll
                     for (int q = 0; q < ND; ++q)
                         if ((q * Q4) / ND == off) dma_piece(HPt, DT * Jn, 2 + (hb ^ 1), q);
                 }
-            } else if (ph == 2 && !LAST) {
+            } else if (ph == 2 && LOAD2) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
-                    if ((q * Q4) / 8 == off) pq[PAR ^ 1][q] = *(const v2d *)(Pn + (size_t)(8 * (q & 3) + (q >> 2)) * ld);
+                    if ((q * Q4) / 8 == off) pq[PREV][q] = *(const v2d *)(Pn + (size_t)(8 * (q & 3) + (q >> 2)) * ld);
             }
             if (SPECIAL && (kk & 1) == 0) {                 // strip FMAs ride under the MFMAs: k pair (kk, kk+1) of this wave's quarter
                 const v2d v0 = *(const v2d *)(s_panel + kk * 64), v1 = *(const v2d *)(s_panel + (kk + 1) * 64);
@@ -1704,7 +1718,7 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
             a2 = a2n; b2 = b2n;
         }
         D2MARK();                            // MFMA loop done
-        // P + sum_k (the P block was requested a whole tile ago)
+        // P + sum_k (the P block was requested two tiles ago)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -1764,34 +1778,65 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
                 for (int q = 0; q < ND; ++q) dma_piece(HPt, DT * Jn, 2 + (hb ^ 1), q);
             }
             dd_wait_vmcnt<0>();
-        } else if (needH) dd_wait_vmcnt<8>();               // after the last HPt DMA: this tile's 8 P loads
-        else if (needK) dd_wait_vmcnt<FIRST ? 8 : 16>();    // after the last Kn DMA: (8 stores +) 8 P loads
+        } else if (needH) dd_wait_vmcnt<LOAD2 ? 8 : 0>();                             // after the last HPt DMA: this tile's 8 P loads
+        else if (needK) dd_wait_vmcnt<(FIRST ? 0 : 8) + (LOAD2 ? 8 : 0)>();          // after the last Kn DMA: (8 stores +) (8 P loads)
         if (needK || needH) lds_barrier();
         if (needK) kb ^= 1;
         if (needH) hb ^= 1;
         I = In; J = Jn;
         D2MARK();                            // next panels landed, barrier passed
     };
-    using B0 = std::integral_constant<int, 0>;
-    using B1 = std::integral_constant<int, 1>;
     using Tt = std::true_type;
     using Ff = std::false_type;
-    auto run = [&](auto par_c, auto first_c, auto last_c, int pos) {
-        if (strips && I == J) tile_body(par_c, first_c, last_c, Tt(), pos);
-        else tile_body(par_c, first_c, last_c, Ff(), pos);
+    // Short ranges (the BASELINE sizes: 4 tiles per workgroup at n = 2051, 1 at n = 1027 / 259) run as STRAIGHT-LINE code,
+    // one instantiation per position: with no loop and no join in the way, hipcc's s_waitcnt pass places every wait exactly
+    // (through the generic loop below it merges the variants' states at the joins and waits for far younger loads than the
+    // P block it needs).  A diagonal tile sits at the end of its range (t_diag swap), so only the last position may be SPECIAL.
+    bool mid_special = false;
+    if (strips)
+        for (int pos = 0; pos + 1 < nt; ++pos) { int Iq, Jq; tile_IJ(pos, Iq, Jq); mid_special |= Iq == Jq; }
+    auto straight = [&](auto nt_c) __attribute__((always_inline)) {
+        constexpr int NT = decltype(nt_c)::value;
+        auto one = [&](auto pos_c) __attribute__((always_inline)) {
+            constexpr int POS = decltype(pos_c)::value;
+            using Par = std::integral_constant<int, POS % NB>;
+            using First = std::integral_constant<bool, POS == 0>;
+            using Load2 = std::integral_constant<bool, (POS + AHEAD < NT)>;
+            using Last = std::integral_constant<bool, POS == NT - 1>;
+            if (POS == NT - 1 && strips && I == J) tile_body(Par(), First(), Load2(), Last(), Tt(), POS);
+            else tile_body(Par(), First(), Load2(), Last(), Ff(), POS);
+        };
+        one(std::integral_constant<int, 0>());
+        if constexpr (NT > 1) one(std::integral_constant<int, 1>());
+        if constexpr (NT > 2) one(std::integral_constant<int, 2>());
+        if constexpr (NT > 3) one(std::integral_constant<int, 3>());
     };
-    if (nt == 1) run(B0(), Tt(), Tt(), 0);
-    else {
-        run(B0(), Tt(), Ff(), 0);
-        int pos = 1;
-        for (; pos + 2 < nt; pos += 2) {                    // steady state: two tiles per trip, pq halves by name
-            run(B1(), Ff(), Ff(), pos);
-            run(B0(), Ff(), Ff(), pos + 1);
+    if (!mid_special && nt <= 4) {
+        if (nt == 4) straight(std::integral_constant<int, 4>());
+        else if (nt == 1) straight(std::integral_constant<int, 1>());
+        else if (nt == 2) straight(std::integral_constant<int, 2>());
+        else straight(std::integral_constant<int, 3>());
+    } else {
+        auto run4 = [&](auto par_c, auto first_c, auto load2_c, auto last_c, int pos) __attribute__((always_inline)) {
+            if (strips && I == J) tile_body(par_c, first_c, load2_c, last_c, Tt(), pos);
+            else tile_body(par_c, first_c, load2_c, last_c, Ff(), pos);
+        };
+        auto run = [&](auto par_c, int pos) __attribute__((always_inline)) {               // a tile after the first
+            if (pos == nt - 1) run4(par_c, Ff(), Ff(), Tt(), pos);
+            else if (pos + AHEAD < nt) run4(par_c, Ff(), Tt(), Ff(), pos);
+            else run4(par_c, Ff(), Ff(), Ff(), pos);
+        };
+        using B0 = std::integral_constant<int, 0>;
+        using B1 = std::integral_constant<int, 1>;
+        using B2 = std::integral_constant<int, NB - 1>;
+        if (nt == 1) run4(B0(), Tt(), Ff(), Tt(), 0);
+        else if (nt <= AHEAD) run4(B0(), Tt(), Ff(), Ff(), 0);
+        else run4(B0(), Tt(), Tt(), Ff(), 0);
+        for (int pos = 1; pos < nt; pos += NB) {            // pq blocks by name: NB tiles per trip
+            run(B1(), pos);
+            if (NB == 3 && pos + 1 < nt) run(B2(), pos + 1);
+            if (pos + NB - 1 < nt) run(B0(), pos + NB - 1);
         }
-        if (pos + 1 < nt) {
-            run(B1(), Ff(), Ff(), pos);
-            run(B0(), Ff(), Tt(), pos + 1);
-        } else run(B1(), Ff(), Tt(), pos);
     }
 #ifdef REKF_DEBUG_TIMING
     if (rec2) {
