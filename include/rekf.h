@@ -165,7 +165,8 @@ enum {
     REKF_K_EMPTY = 7,     /* an event pair around nothing: the bracket's own cost, in situ */
     REKF_K_UPDATE = 8,    /* ONE bracket around the whole HandleObservationMessage chain (per-update latency);
                            * its individual readings are kept, see rekf_profile_samples */
-    REKF_K_COUNT = 9
+    REKF_K_MID = 9,       /* gather + solve + gain fused (scans with at most 32 matched observations) */
+    REKF_K_COUNT = 10
 };
 /* When on, kernel launches are bracketed by hipEvents on the handle's stream: `on` is a bit mask
  * over the REKF_K_* ids (1 << id); -1 = all.  Brackets perturb the stream (each costs a few

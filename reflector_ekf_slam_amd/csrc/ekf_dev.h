@@ -68,7 +68,8 @@ struct RekfFrontArgs {
 
 struct RekfDev {
     RekfCtl *ctl;
-    double *mu;
+    double *mu;         // the current mean
+    double *mu_out;     // k_mid writes the updated mean here; the host swaps mu / mu_out behind that launch
     double *P;
     double *W;
     double *HPt;
@@ -99,6 +100,7 @@ __host__ __device__ static inline int rekf_strip_base(int n)
 void rekf_launch_front(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);
 void rekf_launch_front_mb(const RekfDev &d, const RekfFrontArgs &a, int n_ub, hipStream_t s);
 void rekf_launch_gather(const RekfDev &d, const RekfFrontArgs &a, int n_ub, hipStream_t s);
+void rekf_launch_mid(const RekfDev &d, const RekfFrontArgs &a, int n_ub, int m_ub, hipStream_t s);
 void rekf_launch_solve(const RekfDev &d, int m_ub, hipStream_t s);
 void rekf_launch_gain(const RekfDev &d, int n_ub, hipStream_t s);
 void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s);

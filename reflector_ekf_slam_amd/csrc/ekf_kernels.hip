@@ -768,67 +768,13 @@ __device__ static inline v4d block_mma2(const v4d &At, const v4d &B, v4d acc)
     return acc + acc1;
 }
 
+// Blocked Gauss-Jordan inverse of the (16 nbr) x (16 nbr) matrix whose block column w this wave holds in S[] (C layout),
+// in place; the scheme is described above k_solve.  EVERY wave of the workgroup must call it (one s_barrier per block
+// step); waves with w >= nbr only keep the barrier count.  Returns true when a pivot block was not positive definite.
 template <int NBR>
-__global__ __launch_bounds__(64 * NBR) void k_solve(RekfDev d)
+__device__ static inline bool gj_invert_blocks(v4d (&S)[NBR], int nbr, int w, int g, int c, double (*s_col)[NBR + 1][REKF_PATCH], double *lp)
 {
-    __shared__ double s_col[2][NBR + 1][REKF_PATCH];   // pivot column blocks S(i,K), slot NBR = D^-1; ping-pong over block steps
-    __shared__ double s_leaf[NBR][REKF_LEAF_SCRATCH];  // leaf exchange scratch, private per wave
-    __shared__ __attribute__((aligned(16))) double s_coef[8 * REKF_MAX_ROWS];   // ctl->hrow staged: 64-byte packed H rows
-    RekfCtl *ctl = d.ctl;
-    const int m = ctl->m;
-    if (m == 0) return;
-    const int nbr = ctl->m_pad >> 4;                 // live blocks per side (<= NBR: the host sized the launch from 2K+3)
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g = lane >> 4, c = lane & 15;
-    if (w >= nbr) return;                            // ended waves do not take part in s_barrier
-#ifdef REKF_DEBUG_TIMING
-    const long long tsc = pinned_clock();
-#endif
-    v4d S[NBR];                                      // S[bi] = block (bi, w)
-    const int j = 16 * w + c;                        // this lane's column of S
-    {
-        // every global load below depends only on kernel arguments: ONE memory round trip
-        const int rows_state = 2 * ctl->n_state;     // rows [0, rows_state) carry landmark columns
-        const double *__restrict__ Wc = d.Wc;
-        const v2d stage = ((const v2d *)&ctl->hrow[0][0])[threadIdx.x];     // 16*nbr rows x 64 B over 64*nbr threads
-        const double w0 = Wc[j], w1 = Wc[REKF_MR_PAD + j], w2 = Wc[2 * REKF_MR_PAD + j];
-        v2d wl[NBR][4];
-#pragma unroll
-        for (int bi = 0; bi < NBR; ++bi) {
-            if (bi < nbr) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int pair = (16 * bi + g + 4 * r) >> 1;
-                    wl[bi][r] = *(const v2d *)(Wc + REKF_WC_PAIRS + ((size_t)pair * REKF_MR_PAD + j) * 2);
-                }
-            }
-        }
-        ((v2d *)s_coef)[threadIdx.x] = stage;
-        __syncthreads();
-#pragma unroll
-        for (int bi = 0; bi < NBR; ++bi) {
-            if (bi < nbr) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = 16 * bi + g + 4 * r;
-                    const v2d ha01 = *(const v2d *)(s_coef + 8 * i), ha2b0 = *(const v2d *)(s_coef + 8 * i + 2);
-                    const v2d b1q = *(const v2d *)(s_coef + 8 * i + 4);
-                    double v = ha01.x * w0;
-                    v += ha01.y * w1;
-                    v += ha2b0.x * w2;
-                    if (i < rows_state) { v += ha2b0.y * wl[bi][r].x; v += b1q.x * wl[bi][r].y; }
-                    if (i == j) v += b1q.y;
-                    if (i >= m || j >= m) v = (i == j) ? 1.0 : 0.0;
-                    S[bi][r] = v;
-                }
-            }
-        }
-    }
     bool bad = false;
-    double *lp = s_leaf[w];
-#ifdef REKF_DEBUG_TIMING
-    const long long t0c = pinned_clock(), t0w = wall_clock64();
-#endif
     const v4d zero4 = {0, 0, 0, 0};
     // wave 0 opens the chain: publish column 0, invert S(0,0)
     if (w == 0) {
@@ -843,6 +789,7 @@ __global__ __launch_bounds__(64 * NBR) void k_solve(RekfDev d)
         if (K >= nbr) break;
         double (*col)[REKF_PATCH] = s_col[K & 1];
         lds_barrier();                                // column K and D^-1 of step K are published
+        if (w >= nbr) continue;                       // a wave without a block column only keeps the barrier count
         if (w == K) {
             // S(i,K) <- -S(i,K) D^-1 ; S(K,K) = D^-1 is already in place
 #pragma unroll
@@ -900,6 +847,70 @@ __global__ __launch_bounds__(64 * NBR) void k_solve(RekfDev d)
             }
         }
     }
+    return bad;
+}
+
+template <int NBR>
+__global__ __launch_bounds__(64 * NBR) void k_solve(RekfDev d)
+{
+    __shared__ double s_col[2][NBR + 1][REKF_PATCH];   // pivot column blocks S(i,K), slot NBR = D^-1; ping-pong over block steps
+    __shared__ double s_leaf[NBR][REKF_LEAF_SCRATCH];  // leaf exchange scratch, private per wave
+    __shared__ __attribute__((aligned(16))) double s_coef[8 * REKF_MAX_ROWS];   // ctl->hrow staged: 64-byte packed H rows
+    RekfCtl *ctl = d.ctl;
+    const int m = ctl->m;
+    if (m == 0) return;
+    const int nbr = ctl->m_pad >> 4;                 // live blocks per side (<= NBR: the host sized the launch from 2K+3)
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane >> 4, c = lane & 15;
+#ifdef REKF_DEBUG_TIMING
+    const long long tsc = pinned_clock();
+#endif
+    v4d S[NBR];                                      // S[bi] = block (bi, w)
+    const int j = 16 * w + c;                        // this lane's column of S
+    {
+        // every global load below depends only on kernel arguments: ONE memory round trip
+        const int rows_state = 2 * ctl->n_state;     // rows [0, rows_state) carry landmark columns
+        const double *__restrict__ Wc = d.Wc;
+        const v2d stage = ((const v2d *)&ctl->hrow[0][0])[threadIdx.x];     // 16*nbr rows x 64 B over 64*nbr threads
+        const double w0 = Wc[j], w1 = Wc[REKF_MR_PAD + j], w2 = Wc[2 * REKF_MR_PAD + j];
+        v2d wl[NBR][4];
+#pragma unroll
+        for (int bi = 0; bi < NBR; ++bi) {
+            if (bi < nbr) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int pair = (16 * bi + g + 4 * r) >> 1;
+                    wl[bi][r] = *(const v2d *)(Wc + REKF_WC_PAIRS + ((size_t)pair * REKF_MR_PAD + j) * 2);
+                }
+            }
+        }
+        ((v2d *)s_coef)[threadIdx.x] = stage;
+        __syncthreads();
+#pragma unroll
+        for (int bi = 0; bi < NBR; ++bi) {
+            if (bi < nbr) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * bi + g + 4 * r;
+                    const v2d ha01 = *(const v2d *)(s_coef + 8 * i), ha2b0 = *(const v2d *)(s_coef + 8 * i + 2);
+                    const v2d b1q = *(const v2d *)(s_coef + 8 * i + 4);
+                    double v = ha01.x * w0;
+                    v += ha01.y * w1;
+                    v += ha2b0.x * w2;
+                    if (i < rows_state) { v += ha2b0.y * wl[bi][r].x; v += b1q.x * wl[bi][r].y; }
+                    if (i == j) v += b1q.y;
+                    if (i >= m || j >= m) v = (i == j) ? 1.0 : 0.0;
+                    S[bi][r] = v;
+                }
+            }
+        }
+    }
+    bool bad = false;
+#ifdef REKF_DEBUG_TIMING
+    const long long t0c = pinned_clock(), t0w = wall_clock64();
+#endif
+    bad = gj_invert_blocks<NBR>(S, nbr, w, g, c, s_col, s_leaf[w]);
+    if (w >= nbr) return;                            // no block column: this wave only kept the barriers company
 #ifdef REKF_DEBUG_TIMING
     const long long t1c = pinned_clock();
     if (threadIdx.x == 0) { ctl->dbg[0] = t1c - t0c; ctl->dbg[1] = wall_clock64() - t0w; ctl->dbg[2] = t0c - tsc; }
@@ -1004,6 +1015,388 @@ __global__ __launch_bounds__(512) void k_gain(RekfDev d)
             }
         }
     }
+}
+
+// ----------------------------------------------------------------------------
+// k_mid<NBR>: gather + solve + gain in ONE launch, for scans whose innovation has at most 16 NBR rows
+// (NBR = 2: up to 16 matched observations, NBR = 4: up to 32 -- every BASELINE.json configuration).
+//
+// Round 1 ran k_gather -> k_solve -> k_gain: 24.4 us of kernels at C3 plus two kernel boundaries, of which the
+// single-workgroup solve alone was 12.9 us while 255 CUs idled.  The inverse is a LATENCY chain, not work: here
+// every workgroup owns 16 state rows and redoes it for itself -- the 67 x 67 sub-block of P that S = H P H^T + Q
+// touches is 2.2 k 16-byte loads per workgroup, L2 hits for all but the first -- and then needs neither a launch
+// boundary nor a trip through memory for S^-1:
+//   A  ordered compaction of the per-observation match results (as k_gather did), H rows packed in LDS;
+//   C  all gathers in flight at once: C1 the rows {0,1,2, matched landmark rows} of W = P H^T (for S),
+//      C2 this workgroup's 16 rows of W, C3 its 16 columns' (H P)^T, which goes straight to HBM for k_downdate;
+//   E  S = H W + Q in the MFMA C layout, blocked Gauss-Jordan (gj_invert_blocks), S^-1 -> LDS;
+//   F  K(16 rows) = W S^-1 by MFMA out of LDS; Kn = -K -> HBM; mu += K (z - zhat) -- the reference's own
+//      association K_t * (z - z_hat), cc:306 (round 1 formed W (S^-1 dz)) -- pose commit, theta wrap.
+// W itself is never written.  All workgroups compute bit-identical S^-1 (same code, same inputs, no atomics).
+// Like k_gather it never symmetrises: W from the columns of P, (H P)^T from its rows.
+// ----------------------------------------------------------------------------
+typedef double v2du __attribute__((ext_vector_type(2), aligned(8)));     // a row pair that starts on an odd row: 8-byte aligned
+#define MID_ROWS 16
+template <int NBR>
+__global__ __launch_bounds__(256) void k_mid(RekfDev d, RekfFrontArgs A)
+{
+    constexpr int MP = 16 * NBR;                  // most innovation rows (padded) this instance takes
+    constexpr int NPAIR = MP / 2;
+    constexpr int LDS_S = MP + 16;                // row stride of S^-1 in LDS: = 16 mod 32 doubles, so the 4 k-rows of an MFMA operand read hit disjoint banks
+    __shared__ double s_col[2][NBR + 1][REKF_PATCH];
+    __shared__ double s_leaf[4][REKF_LEAF_SCRATCH];
+    __shared__ __attribute__((aligned(16))) double s_coef[8 * MP];          // H row r in 64 bytes, layout of RekfCtl::hrow
+    __shared__ __attribute__((aligned(16))) double s_wc0[3][MP];            // rows 0..2 of W
+    __shared__ __attribute__((aligned(16))) double s_wcp[NPAIR][MP][2];     // state pair p: its two landmark rows of W, interleaved per column
+    __shared__ __attribute__((aligned(16))) double s_wown[MP][MID_ROWS];    // this workgroup's rows of W, [column r][row]
+    __shared__ __attribute__((aligned(16))) double s_sinv[MP][LDS_S];       // S^-1, row-major
+    __shared__ double s_dmu[4][MID_ROWS];
+    __shared__ int s_pair_obs[NPAIR], s_pair_id[NPAIR], s_pair_state[NPAIR], s_pcol[NPAIR], s_cnt[4];
+
+#ifdef REKF_DEBUG_TIMING
+    long long tqm[16]; int nqm = 0;
+    const bool recm = blockIdx.x == 1 && threadIdx.x == 0;
+    const long long t_entrym = clock64(), w_entrym = wall_clock64();
+#define MMARK() do { __builtin_amdgcn_sched_barrier(0); if (recm && nqm < 16) tqm[nqm++] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define MMARK()
+#endif
+    RekfCtl *ctl = d.ctl;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = ctl->n;
+    const int K = A.K;
+    const size_t ld = (size_t)d.ld;
+    const int i0 = blockIdx.x * MID_ROWS;
+    const double *__restrict__ P = d.P;
+    const double pose[5] = {ctl->pose_pred[0], ctl->pose_pred[1], ctl->pose_pred[2], ctl->pose_pred[3], ctl->pose_pred[4]};
+    const bool pending = ctl->pose_pending != 0;
+    const bool first = blockIdx.x == 0;
+
+    // ---- A: ordered compaction (obs order preserved), wave 0; workgroup 0 also writes the record for the getters
+    if (tid < 64) {
+        const int kind = (lane < K) ? ctl->obs_kind[lane] : -1;
+        const int oidx = (lane < K) ? ctl->obs_idx[lane] : -1;
+        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        const unsigned long long ms = __ballot(kind == 1);
+        const unsigned long long mm = __ballot(kind == 0);
+        const unsigned long long mn = __ballot(kind == 2);
+        const int M = __popcll(ms), Mm = __popcll(mm);
+        int N2 = __popcll(mn);
+        const int room = (d.n_max - n) / 2;
+        if (N2 > room) {                                               // capacity guard (ours)
+            if (first && lane == 0) atomicOr(&ctl->err, REKF_FLAG_CAPACITY);
+            N2 = room;
+        }
+        if (kind == 1) {
+            const int p = __popcll(ms & lt);
+            if (p < NPAIR) { s_pair_obs[p] = lane; s_pair_id[p] = oidx; s_pair_state[p] = 1; }
+            if (first) { ctl->state_pairs[2 * p] = lane; ctl->state_pairs[2 * p + 1] = oidx; }
+        } else if (kind == 0) {
+            const int p = __popcll(mm & lt);
+            if (M + p < NPAIR) { s_pair_obs[M + p] = lane; s_pair_id[M + p] = oidx; s_pair_state[M + p] = 0; }
+            if (first) { ctl->map_pairs[2 * p] = lane; ctl->map_pairs[2 * p + 1] = oidx; }
+        } else if (kind == 2) {
+            const int p = __popcll(mn & lt);
+            if (first && p < N2) ctl->new_ids[p] = lane;
+        }
+        if (lane == 0) {
+            const int MM = M + Mm;
+            const int m = (MM > 0) ? 2 * MM + (A.has_gps ? 3 : 0) : 0;
+            s_cnt[0] = MM; s_cnt[1] = m; s_cnt[2] = (m + 15) & ~15; s_cnt[3] = M;
+            if (first) {
+                ctl->K = K; ctl->n_state = M; ctl->n_map = Mm; ctl->n_new = N2;
+                ctl->m = m; ctl->m_pad = (m + 15) & ~15;
+            }
+        }
+    }
+    __syncthreads();
+    MMARK();                                        // 0: compaction done
+    const int MM = s_cnt[0], m = s_cnt[1], m_pad = s_cnt[2], NS = s_cnt[3];
+    // The mean is double-buffered: other workgroups read landmark means from d.mu (phase B) while this one is already
+    // done, so the updated rows go to d.mu_out and the host swaps the two pointers behind this launch.
+    if (m == 0) {                                   // nothing matched: commit the predicted pose (cc:234 + Predict), no update
+        if (tid < MID_ROWS && i0 + tid < n) {
+            const int i = i0 + tid;
+            const double pp = (i == 0) ? pose[0] : ((i == 1) ? pose[1] : pose[2]);      // no dynamic indexing of pose[]
+            d.mu_out[i] = (pending && i < 3) ? pp : d.mu[i];
+        }
+        if (pending && first && tid == 0) ctl->pose_pending = 0;
+        return;
+    }
+    // (m_pad <= MP: the host picked NBR from its bound 2K(+3) of m)
+
+    // ---- B: H rows (cc:248-304, gps.cc:305-332), thread = row
+    if (tid < MP) {
+        const int r = tid, p = r >> 1, rr = r & 1;
+        double hr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int col = -1;
+        if (p < MM) {
+            const HPair h = make_hpair(d, A, pose, s_pair_obs[p], s_pair_id[p], s_pair_state[p]);
+            col = h.col;
+            if (rr == 0) { hr[0] = h.a0[0]; hr[1] = h.a0[1]; hr[2] = h.a0[2]; hr[3] = h.b0[0]; hr[4] = h.b0[1]; hr[5] = h.q0; hr[6] = h.dz0; }
+            else { hr[0] = h.a1[0]; hr[1] = h.a1[1]; hr[2] = h.a1[2]; hr[3] = h.b1[0]; hr[4] = h.b1[1]; hr[5] = h.q1; hr[6] = h.dz1; }
+            if (col < 0) { hr[3] = 0; hr[4] = 0; }                          // map rows carry no landmark block (cc:285-303)
+        } else if (A.has_gps && r >= 2 * MM && r < 2 * MM + 3) {           // pose rows: unit vectors, fixed noise, wrapped yaw innovation
+#pragma clang fp contract(off)
+            const int k = r - 2 * MM;
+            hr[0] = (k == 0); hr[1] = (k == 1); hr[2] = (k == 2);
+            hr[5] = (k == 2) ? 0.017 * 0.017 : 0.05 * 0.05;
+            const double e0 = A.gps[0] - pose[0], e1 = A.gps[1] - pose[1], e2 = yaw_innovation(A.gps[2] - pose[2]);
+            hr[6] = (k == 0) ? e0 : ((k == 1) ? e1 : e2);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s_coef[8 * r + q] = hr[q];
+        if (rr == 0) s_pcol[p] = col;
+    }
+    __syncthreads();
+    MMARK();                                        // 1: H rows in LDS
+
+    // ---- C: every gather of the launch goes in flight before anything is consumed
+    const int nq = m_pad / 2;                        // row pairs, pad rows included (their H rows are zero)
+    // C1: items (slot, q): slot < NS = state pair (its two landmark rows), slot NS = rows 0,1, slot NS+1 = row 2
+    constexpr int C1_IT = ((NPAIR + 2) * NPAIR + 255) / 256;
+    v2du c1p[C1_IT][5];
+    const int c1_items = (NS + 2) * nq;
+#pragma unroll
+    for (int it = 0; it < C1_IT; ++it) {
+        const int e = tid + 256 * it;
+        if (e < c1_items) {
+            const int slot = e / nq, q = e - slot * nq;
+            const int row = (slot < NS) ? 3 + 2 * s_pair_id[slot] : ((slot == NS) ? 0 : 2);
+            const int col = s_pcol[q];
+            const double *base = P + row;
+            if (slot <= NS) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) c1p[it][k] = *(const v2du *)(base + (size_t)k * ld);
+                if (col >= 0) { c1p[it][3] = *(const v2du *)(base + (size_t)col * ld); c1p[it][4] = *(const v2du *)(base + (size_t)(col + 1) * ld); }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) c1p[it][k].x = base[(size_t)k * ld];
+                if (col >= 0) { c1p[it][3].x = base[(size_t)col * ld]; c1p[it][4].x = base[(size_t)(col + 1) * ld]; }
+            }
+        }
+    }
+    // C2: item (own row pair pr, q): rows i0 + 2 pr, +1 of W
+    constexpr int C2_IT = (8 * NPAIR + 255) / 256;
+    v2d c2p[C2_IT][5];
+#pragma unroll
+    for (int it = 0; it < C2_IT; ++it) {
+        const int e = tid + 256 * it;
+        if (e < 8 * nq) {
+            const int pr = e & 7, q = e >> 3;
+            const int col = s_pcol[q];
+            const double *base = P + i0 + 2 * pr;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) c2p[it][k] = *(const v2d *)(base + (size_t)k * ld);
+            if (col >= 0) { c2p[it][3] = *(const v2d *)(base + (size_t)col * ld); c2p[it][4] = *(const v2d *)(base + (size_t)(col + 1) * ld); }
+        }
+    }
+    // C3: item (own column cidx, q): (H P)^T(c, 2q..2q+1) from the ROWS 0..2, col_q, col_q+1 of column c of P
+    constexpr int C3_IT = (16 * NPAIR + 255) / 256;
+    v2d c3a[C3_IT];
+    double c3b[C3_IT];
+    v2du c3l[C3_IT];
+#pragma unroll
+    for (int it = 0; it < C3_IT; ++it) {
+        const int e = tid + 256 * it;
+        if (e < 16 * nq) {
+            const int cidx = e & 15, q = e >> 4;
+            const int col = s_pcol[q];
+            const double *Pc = P + (size_t)(i0 + cidx) * ld;
+            c3a[it] = *(const v2d *)(Pc);
+            c3b[it] = Pc[2];
+            if (col >= 0) c3l[it] = *(const v2du *)(Pc + col);
+        }
+    }
+
+    MMARK();                                        // 2: gathers issued
+    // ---- D: consume.  Same operation order as k_gather: v = p0 h0; v += p1 h1; v += p2 h2; v += pl0 g0; v += pl1 g1
+#pragma unroll
+    for (int it = 0; it < C1_IT; ++it) {
+        const int e = tid + 256 * it;
+        if (e < c1_items) {
+            const int slot = e / nq, q = e - slot * nq;
+            const bool has_col = s_pcol[q] >= 0;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int r = 2 * q + rr;
+                const double *h = s_coef + 8 * r;
+                double vx = c1p[it][0].x * h[0], vy = c1p[it][0].y * h[0];
+                vx += c1p[it][1].x * h[1]; vy += c1p[it][1].y * h[1];
+                vx += c1p[it][2].x * h[2]; vy += c1p[it][2].y * h[2];
+                if (has_col) {
+                    vx += c1p[it][3].x * h[3]; vy += c1p[it][3].y * h[3];
+                    vx += c1p[it][4].x * h[4]; vy += c1p[it][4].y * h[4];
+                }
+                if (slot < NS) { s_wcp[slot][r][0] = vx; s_wcp[slot][r][1] = vy; }
+                else if (slot == NS) { s_wc0[0][r] = vx; s_wc0[1][r] = vy; }
+                else s_wc0[2][r] = vx;
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < C2_IT; ++it) {
+        const int e = tid + 256 * it;
+        if (e < 8 * nq) {
+            const int pr = e & 7, q = e >> 3;
+            const bool has_col = s_pcol[q] >= 0;
+            const int c = i0 + 2 * pr;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int r = 2 * q + rr;
+                const double *h = s_coef + 8 * r;
+                double vx = c2p[it][0].x * h[0], vy = c2p[it][0].y * h[0];
+                vx += c2p[it][1].x * h[1]; vy += c2p[it][1].y * h[1];
+                vx += c2p[it][2].x * h[2]; vy += c2p[it][2].y * h[2];
+                if (has_col) {
+                    vx += c2p[it][3].x * h[3]; vy += c2p[it][3].y * h[3];
+                    vx += c2p[it][4].x * h[4]; vy += c2p[it][4].y * h[4];
+                }
+                if (c >= n) vx = 0.0;
+                if (c + 1 >= n) vy = 0.0;
+                s_wown[r][2 * pr] = vx; s_wown[r][2 * pr + 1] = vy;
+            }
+        }
+    }
+    const int strip_nb = rekf_strip_base(n);          // k_downdate's border strips want rows nb.. of HPt / Kn contiguous
+#pragma unroll
+    for (int it = 0; it < C3_IT; ++it) {
+        const int e = tid + 256 * it;
+        if (e < 16 * nq) {
+            const int cidx = e & 15, q = e >> 4;
+            const bool has_col = s_pcol[q] >= 0;
+            const int c = i0 + cidx;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int r = 2 * q + rr;
+                const double *h = s_coef + 8 * r;
+                double u = h[0] * c3a[it].x;
+                u += h[1] * c3a[it].y;
+                u += h[2] * c3b[it];
+                if (has_col) { u += h[3] * c3l[it].x; u += h[4] * c3l[it].y; }
+                if (c >= n) u = 0.0;
+                d.HPt[c + (size_t)r * ld] = u;
+                if (strip_nb >= 0 && c >= strip_nb && c < strip_nb + REKF_STRIP_MAX) d.HPtB[(c - strip_nb) * REKF_MR_PAD + r] = u;
+            }
+        }
+    }
+    // columns [m_pad, kc_ub) of HPt / Kn are kept zero for k_downdate2<kc_ub>
+    for (int e = tid; e < 16 * (d.kc_ub - m_pad); e += 256) {
+        const int cidx = e & 15, r = m_pad + (e >> 4), c = i0 + cidx;
+        d.HPt[c + (size_t)r * ld] = 0.0;
+        d.Kn[c + (size_t)r * ld] = 0.0;
+        if (strip_nb >= 0 && c >= strip_nb && c < strip_nb + REKF_STRIP_MAX) {
+            d.HPtB[(c - strip_nb) * REKF_MR_PAD + r] = 0.0;
+            d.KnB[(c - strip_nb) * REKF_MR_PAD + r] = 0.0;
+        }
+    }
+    __syncthreads();
+    MMARK();                                        // 3: W rows in LDS, (H P)^T stored
+
+    // ---- E: S = H W + Q in the C layout (wave w = block column w), inverse, S^-1 -> LDS
+    const int nbr = m_pad >> 4;
+    const int g = lane >> 4, c = lane & 15;
+    {
+        v4d S[NBR];
+#pragma unroll
+        for (int bi = 0; bi < NBR; ++bi) S[bi] = (v4d){0, 0, 0, 0};
+        const int w = wave, j = 16 * w + c;
+        if (w < nbr) {
+            const int rows_state = 2 * NS;
+            const double w0 = s_wc0[0][j], w1 = s_wc0[1][j], w2 = s_wc0[2][j];
+#pragma unroll
+            for (int bi = 0; bi < NBR; ++bi) {
+                if (bi < nbr) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * bi + g + 4 * r;
+                        const v2d ha01 = *(const v2d *)(s_coef + 8 * i), ha2b0 = *(const v2d *)(s_coef + 8 * i + 2);
+                        const v2d b1q = *(const v2d *)(s_coef + 8 * i + 4);
+                        double v = ha01.x * w0;
+                        v += ha01.y * w1;
+                        v += ha2b0.x * w2;
+                        if (i < rows_state) {
+                            const v2d wl = *(const v2d *)&s_wcp[i >> 1][j][0];
+                            v += ha2b0.y * wl.x; v += b1q.x * wl.y;
+                        }
+                        if (i == j) v += b1q.y;
+                        if (i >= m || j >= m) v = (i == j) ? 1.0 : 0.0;
+                        S[bi][r] = v;
+                    }
+                }
+            }
+        }
+        MMARK();                                    // 4: S built
+        const bool bad = gj_invert_blocks<NBR>(S, nbr, w, g, c, s_col, s_leaf[w & 3]);
+        MMARK();                                    // 5: inverted
+        if (w < nbr) {
+            if (bad && lane == 0 && first) atomicOr(&ctl->err, REKF_FLAG_SINGULAR);
+#pragma unroll
+            for (int bi = 0; bi < NBR; ++bi) {
+                if (bi < nbr) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s_sinv[16 * bi + g + 4 * r][j] = S[bi][r];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    MMARK();                                        // 6: S^-1 in LDS
+
+    // ---- F: K = W S^-1 for this workgroup's 16 rows, transposed like k_gain (MFMA rows <-> j, columns <-> i)
+    {
+        const int idx = lane & 15, kq = lane >> 4;
+        for (int jt = wave; jt < NBR; jt += 4) {
+            const int j0 = 16 * jt;
+            double part = 0.0;
+            if (jt < nbr) {
+                v4d acc = {0, 0, 0, 0};
+#pragma unroll
+                for (int kk = 0; kk < MP / 4; ++kk) {
+                    if (kk < m_pad / 4) {
+                        const int k = 4 * kk + kq;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_sinv[k][j0 + idx], s_wown[k][idx], acc, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = j0 + kq + 4 * r;                               // D row = column of K
+                    d.Kn[(i0 + idx) + (size_t)j * ld] = -acc[r];
+                    if (strip_nb >= 0 && i0 + idx >= strip_nb && i0 + idx < strip_nb + REKF_STRIP_MAX)
+                        d.KnB[(i0 + idx - strip_nb) * REKF_MR_PAD + j] = -acc[r];
+                    part += acc[r] * s_coef[8 * j + 6];                          // K(i, j) (z - zhat)(j)
+                }
+                part += __shfl_xor(part, 16, 64);
+                part += __shfl_xor(part, 32, 64);
+            }
+            if (kq == 0) s_dmu[jt & 3][idx] = part;
+        }
+    }
+    __syncthreads();
+    MMARK();                                        // 7: K stored
+    if (tid < MID_ROWS) {
+        const int i = i0 + tid;
+        if (i < n) {
+            double dm = 0.0;
+#pragma unroll
+            for (int jt = 0; jt < NBR; ++jt) dm += s_dmu[jt][tid];
+            const double pp = (i == 0) ? pose[0] : ((i == 1) ? pose[1] : pose[2]);
+            const double base = (pending && i < 3) ? pp : d.mu[i];
+            double v = base + dm;
+            if (i == 2) v = atan2(sin(v), cos(v));                               // cc:307
+            d.mu_out[i] = v;
+            if (i == 0) ctl->pose_pending = 0;
+        }
+    }
+#ifdef REKF_DEBUG_TIMING
+    if (recm) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ctl->dbg[6] = clock64() - t_entrym;
+        ctl->dbg[5] = wall_clock64() - w_entrym;
+        ctl->dbg[7] = nqm;
+        for (int i = 0; i < nqm; ++i) ctl->dbg[8 + i] = tqm[i] - t_entrym;
+    }
+#endif
 }
 
 // ----------------------------------------------------------------------------
@@ -1518,7 +1911,11 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     __shared__ __attribute__((aligned(16))) double s_border[2][DD_STRIP_MAX][REKF_MR_PAD];
 #ifdef REKF_DEBUG_TIMING
     long long tq2[24]; int nq2 = 0;
+#ifdef REKF_DEBUG_DD2
     const bool rec2 = blockIdx.x == 0 && threadIdx.x == 0;
+#else
+    const bool rec2 = false;
+#endif
     const long long t_entry2 = clock64(), w_entry2 = wall_clock64();
 #define D2MARK() do { __builtin_amdgcn_sched_barrier(0); if (rec2 && nq2 < 24) tq2[nq2++] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -2014,6 +2411,13 @@ void rekf_launch_front_mb(const RekfDev &d, const RekfFrontArgs &a, int n_ub, hi
 void rekf_launch_gather(const RekfDev &d, const RekfFrontArgs &a, int n_ub, hipStream_t s)
 {
     hipLaunchKernelGGL(k_gather, dim3((n_ub + 255) / 256, 32), dim3(256), 0, s, d, a);
+}
+void rekf_launch_mid(const RekfDev &d, const RekfFrontArgs &a, int n_ub, int m_ub, hipStream_t s)
+{
+    // m_ub <= 64 (the host checks): one workgroup per 16 state rows
+    const int grid = (n_ub + MID_ROWS - 1) / MID_ROWS;
+    if (m_ub <= 32) hipLaunchKernelGGL(k_mid<2>, dim3(grid), dim3(256), 0, s, d, a);
+    else hipLaunchKernelGGL(k_mid<4>, dim3(grid), dim3(256), 0, s, d, a);
 }
 void rekf_launch_solve(const RekfDev &d, int m_ub, hipStream_t s)
 {

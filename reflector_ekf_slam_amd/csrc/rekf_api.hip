@@ -9,6 +9,7 @@
 #include "../../include/rekf.h"
 #include "ekf_dev.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -208,6 +209,7 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
         HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         HIP_TRY(h, hipMalloc(&h->dev.ctl, sizeof(RekfCtl)));
         HIP_TRY(h, hipMalloc(&h->dev.mu, sizeof(double) * ld));
+        HIP_TRY(h, hipMalloc(&h->dev.mu_out, sizeof(double) * ld));
         HIP_TRY(h, hipMalloc(&h->dev.P, sizeof(double) * (size_t)ld * ld));
         HIP_TRY(h, hipMalloc(&h->dev.W, sizeof(double) * (size_t)ld * REKF_MR_PAD));
         HIP_TRY(h, hipMalloc(&h->dev.HPt, sizeof(double) * (size_t)ld * REKF_MR_PAD));
@@ -227,6 +229,7 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
         h->dev.M_map = 0;
         HIP_TRY(h, hipMemsetAsync(h->dev.ctl, 0, sizeof(RekfCtl), h->stream));
         HIP_TRY(h, hipMemsetAsync(h->dev.mu, 0, sizeof(double) * ld, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->dev.mu_out, 0, sizeof(double) * ld, h->stream));
         HIP_TRY(h, hipMemsetAsync(h->dev.P, 0, sizeof(double) * (size_t)ld * ld, h->stream));   // cc:10-11
         HIP_TRY(h, hipMemsetAsync(h->dev.W, 0, sizeof(double) * (size_t)ld * REKF_MR_PAD, h->stream));
         HIP_TRY(h, hipMemsetAsync(h->dev.HPt, 0, sizeof(double) * (size_t)ld * REKF_MR_PAD, h->stream));
@@ -261,7 +264,7 @@ void rekf_destroy(rekf_t *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &s : h->prof_slots) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
-    (void)hipFree(h->dev.ctl); (void)hipFree(h->dev.mu); (void)hipFree(h->dev.P);
+    (void)hipFree(h->dev.ctl); (void)hipFree(h->dev.mu); (void)hipFree(h->dev.mu_out); (void)hipFree(h->dev.P);
     (void)hipFree(h->dev.W); (void)hipFree(h->dev.HPt); (void)hipFree(h->dev.Kn); (void)hipFree(h->dev.Sinv); (void)hipFree(h->dev.Wc); (void)hipFree(h->dev.KnB); (void)hipFree(h->dev.HPtB); (void)hipFree(h->dev.y);
     (void)hipFree(h->dev.map_xy); (void)hipFree(h->dev.map_cov); (void)hipFree(h->dev_out12); (void)hipFree(h->dev_ell); (void)hipFree(h->dev_pred);
     if (h->pose_staging) (void)hipHostFree(h->pose_staging);
@@ -329,10 +332,18 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     { ProfScope ps(h, REKF_K_FRONT); rekf_launch_front_mb(h->dev, a, h->n_ub, h->stream); }
     h->time = t;                                      // cc:234
     const int n_ub = h->n_ub;
-    { ProfScope ps(h, REKF_K_GATHER); rekf_launch_gather(h->dev, a, n_ub, h->stream); }
-    { ProfScope ps(h, REKF_K_SOLVE); rekf_launch_solve(h->dev, 2 * K + (gps_pose3 ? 3 : 0), h->stream); }
-    h->last_m_ub = 2 * K + (gps_pose3 ? 3 : 0);
-    { ProfScope ps(h, REKF_K_GAIN); rekf_launch_gain(h->dev, n_ub, h->stream); }
+    const int m_ub = 2 * K + (gps_pose3 ? 3 : 0);
+    if (m_ub <= 64) {
+        // the whole innovation fits one 64-wide chunk: gather + solve + gain as ONE launch (k_mid), which leaves the
+        // updated mean in the other mean buffer
+        { ProfScope ps(h, REKF_K_MID); rekf_launch_mid(h->dev, a, n_ub, m_ub, h->stream); }
+        std::swap(h->dev.mu, h->dev.mu_out);
+    } else {
+        { ProfScope ps(h, REKF_K_GATHER); rekf_launch_gather(h->dev, a, n_ub, h->stream); }
+        { ProfScope ps(h, REKF_K_SOLVE); rekf_launch_solve(h->dev, m_ub, h->stream); }
+        { ProfScope ps(h, REKF_K_GAIN); rekf_launch_gain(h->dev, n_ub, h->stream); }
+    }
+    h->last_m_ub = m_ub;
     { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_downdate(h->dev, n_ub, h->stream); }
     // the state only grows: once a readback has shown it full, k_augment can never have work again
     // (k_gather drops the extra reflectors and raises REKF_FLAG_CAPACITY)

@@ -1,5 +1,5 @@
 """In-kernel timeline of k_downdate2 (workgroup 0) from a -DREKF_DEBUG_TIMING build of librekf.so, C3 steady state.
-Run on the GPU box:  make -C reflector_ekf_slam_amd/csrc HIPFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -DREKF_DEBUG_TIMING"  first."""
+Run on the GPU box:  make -C reflector_ekf_slam_amd/csrc HIPFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -DREKF_DEBUG_TIMING -DREKF_DEBUG_DD2" (timeline of k_downdate2) or without -DREKF_DEBUG_DD2 (timeline of k_mid, workgroup 1)  first."""
 import sys, ctypes as C
 sys.path.insert(0, ".")
 from reflector_ekf_slam_amd import synth, session as S, ReflectorEKFSLAM, _lib
