@@ -357,8 +357,10 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
         if (idx0 >= 3 && idx0 < n) {
             P[idx0 + 0 * ld] = c0 + a * c2;
             P[idx0 + 1 * ld] = c1 + bb * c2;
+#ifndef REKF_EXP_NOROWS
             P[0 + idx0 * ld] = r0 + a * r2;
             P[1 + idx0 * ld] = r1 + bb * r2;
+#endif
         }
         for (int idx = idx0 + nb * 1024; idx < n; idx += nb * 1024) {
             const double p2 = P[idx + 2 * ld];
@@ -1042,16 +1044,24 @@ __global__ __launch_bounds__(256) void k_mid(RekfDev d, RekfFrontArgs A)
 {
     constexpr int MP = 16 * NBR;                  // most innovation rows (padded) this instance takes
     constexpr int NPAIR = MP / 2;
+    constexpr int NRS = NPAIR + 2;                // row slots of the sub-block: state pairs (sorted by landmark), rows {0,1}, row {2}
+    constexpr int NKC = 3 + MP;                   // its columns: 0,1,2, then (col_q, col_q + 1) per pair q
     constexpr int LDS_S = MP + 16;                // row stride of S^-1 in LDS: = 16 mod 32 doubles, so the 4 k-rows of an MFMA operand read hit disjoint banks
     __shared__ double s_col[2][NBR + 1][REKF_PATCH];
     __shared__ double s_leaf[4][REKF_LEAF_SCRATCH];
     __shared__ __attribute__((aligned(16))) double s_coef[8 * MP];          // H row r in 64 bytes, layout of RekfCtl::hrow
     __shared__ __attribute__((aligned(16))) double s_wc0[3][MP];            // rows 0..2 of W
     __shared__ __attribute__((aligned(16))) double s_wcp[NPAIR][MP][2];     // state pair p: its two landmark rows of W, interleaved per column
-    __shared__ __attribute__((aligned(16))) double s_wown[MP][MID_ROWS];    // this workgroup's rows of W, [column r][row]
-    __shared__ __attribute__((aligned(16))) double s_sinv[MP][LDS_S];       // S^-1, row-major
+    __shared__ __attribute__((aligned(16))) double s_wown[MP][MID_ROWS];    // this workgroup's rows of W, [column r][row]; before that, staging of (H P)^T
+    // raw P values, as gathered; s_psub is dead once W is formed and S^-1 (phase E) takes its place
+    constexpr int NKCP = NKC + 1;                 // sub-block row stride in LDS (even: 16-byte pairs start on odd columns 3 + 2q, read as 8-byte-aligned vectors)
+    __shared__ __attribute__((aligned(16))) double s_big[(NKCP * 2 * NRS > MP * LDS_S) ? NKCP * 2 * NRS : MP * LDS_S];
+    __shared__ __attribute__((aligned(16))) double s_pw[NKC][MID_ROWS];     // P(own rows, sub-block columns)
+    __shared__ __attribute__((aligned(16))) double s_ph[MID_ROWS][2 * NRS]; // P(sub-block rows, own columns)
     __shared__ double s_dmu[4][MID_ROWS];
-    __shared__ int s_pair_obs[NPAIR], s_pair_id[NPAIR], s_pair_state[NPAIR], s_pcol[NPAIR], s_cnt[4];
+    __shared__ int s_pair_obs[NPAIR], s_pair_id[NPAIR], s_pair_state[NPAIR], s_pcol[NPAIR], s_rank[NPAIR], s_rsrow[NRS], s_cnt[4];
+    double (*s_psub)[NKCP] = (double (*)[NKCP])s_big;                       // [row 2 rs + {0,1} of the sub-block][its column kc]
+    double (*s_sinv)[LDS_S] = (double (*)[LDS_S])s_big;                     // S^-1, row-major
 
 #ifdef REKF_DEBUG_TIMING
     long long tqm[16]; int nqm = 0;
@@ -1063,6 +1073,9 @@ __global__ __launch_bounds__(256) void k_mid(RekfDev d, RekfFrontArgs A)
 #endif
     RekfCtl *ctl = d.ctl;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the match results first, UNCONDITIONALLY (both arrays have 64 entries): a vector load that waits for no scalar one,
+    // so the control block costs one memory round trip, not two
+    const int kind_raw = ctl->obs_kind[lane], oidx_raw = ctl->obs_idx[lane];
     const int n = ctl->n;
     const int K = A.K;
     const size_t ld = (size_t)d.ld;
@@ -1074,10 +1087,11 @@ __global__ __launch_bounds__(256) void k_mid(RekfDev d, RekfFrontArgs A)
 
     // ---- A: ordered compaction (obs order preserved), wave 0; workgroup 0 also writes the record for the getters
     if (tid < 64) {
-        const int kind = (lane < K) ? ctl->obs_kind[lane] : -1;
-        const int oidx = (lane < K) ? ctl->obs_idx[lane] : -1;
+        const int kind = (lane < K) ? kind_raw : -1;
+        const int oidx = (lane < K) ? oidx_raw : -1;
         const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
         const unsigned long long ms = __ballot(kind == 1);
+
         const unsigned long long mm = __ballot(kind == 0);
         const unsigned long long mn = __ballot(kind == 2);
         const int M = __popcll(ms), Mm = __popcll(mm);
@@ -1087,9 +1101,24 @@ __global__ __launch_bounds__(256) void k_mid(RekfDev d, RekfFrontArgs A)
             if (first && lane == 0) atomicOr(&ctl->err, REKF_FLAG_CAPACITY);
             N2 = room;
         }
+        // position of a state pair's landmark rows among the matched ones, by landmark (ties: by lane): neighbouring
+        // landmarks share cache lines of a column of P, so the gathers below run over the row slots in this order
+        int rk = 0;
+        {
+            const int key = (kind == 1) ? oidx : 0x7fffffff;
+#pragma unroll
+            for (int q = 0; q < 2 * NPAIR; ++q) {                       // K <= 2 NPAIR observations; compile-time lanes: v_readlane
+                const int oq = __builtin_amdgcn_readlane(key, q);
+                rk += (oq < key || (oq == key && q < lane)) ? 1 : 0;
+            }
+        }
         if (kind == 1) {
             const int p = __popcll(ms & lt);
-            if (p < NPAIR) { s_pair_obs[p] = lane; s_pair_id[p] = oidx; s_pair_state[p] = 1; }
+            if (p < NPAIR) {
+                s_pair_obs[p] = lane; s_pair_id[p] = oidx; s_pair_state[p] = 1;
+                s_rank[p] = rk;
+                s_rsrow[rk] = 3 + 2 * oidx;
+            }
             if (first) { ctl->state_pairs[2 * p] = lane; ctl->state_pairs[2 * p + 1] = oidx; }
         } else if (kind == 0) {
             const int p = __popcll(mm & lt);
@@ -1103,6 +1132,7 @@ __global__ __launch_bounds__(256) void k_mid(RekfDev d, RekfFrontArgs A)
             const int MM = M + Mm;
             const int m = (MM > 0) ? 2 * MM + (A.has_gps ? 3 : 0) : 0;
             s_cnt[0] = MM; s_cnt[1] = m; s_cnt[2] = (m + 15) & ~15; s_cnt[3] = M;
+            s_rsrow[M] = 0; s_rsrow[M + 1] = 2;                       // row slot M = rows {0,1}, slot M+1 = row {2}
             if (first) {
                 ctl->K = K; ctl->n_state = M; ctl->n_map = Mm; ctl->n_new = N2;
                 ctl->m = m; ctl->m_pad = (m + 15) & ~15;
@@ -1124,6 +1154,50 @@ __global__ __launch_bounds__(256) void k_mid(RekfDev d, RekfFrontArgs A)
         return;
     }
     // (m_pad <= MP: the host picked NBR from its bound 2K(+3) of m)
+
+    // ---- C (issued before B: it needs only the match lists): the raw P values, each cache line fetched once per
+    // workgroup and by neighbouring lanes.  Sub-block P(R, R), R = {landmark rows of the state pairs, 0, 1, 2}: lane = row
+    // slot (sorted by landmark), wave + 4 it = column; own rows x R columns; R rows x own columns.  Row slot NS+1 stands
+    // for row 2 alone but is fetched as the pair (2, 3) like the others: no special case in the loops.
+    const int nrs = NS + 2, nkc = 3 + 2 * NS;
+    const unsigned ldb = (unsigned)d.ld * 8u;                              // bytes per column of P (byte offsets fit 32 bits: ld^2 * 8 < 4 GiB)
+    // column of sub-block column kc, for kc = lane and kc = 64 + lane, once: the loops fetch it with v_readlane
+    int colA = 0, colB = 0;
+    if (lane < nkc) colA = (lane < 3) ? lane : 3 + 2 * s_pair_id[(lane - 3) >> 1] + ((lane - 3) & 1);          // pairs < NS are state pairs
+    if (64 + lane < nkc) colB = 3 + 2 * s_pair_id[(61 + lane) >> 1] + ((61 + lane) & 1);
+    auto col_of = [&](int kc) -> int {                                      // kc wave-uniform
+        return (kc < 64) ? __builtin_amdgcn_readlane(colA, kc) : __builtin_amdgcn_readlane(colB, kc - 64);
+    };
+    // (indices are CLAMPED instead of branched on: a lane or an iteration past the end refetches a line its neighbour
+    // fetches anyway, and the loops stay straight-line so that all loads issue back to back; only the LDS stores are predicated)
+    constexpr int PS_IT = (NKC + 3) / 4;
+    v2du ps[PS_IT];
+    const char *my_row_ptr = (const char *)(P + s_rsrow[(lane < nrs) ? lane : nrs - 1]);
+    const int kc0 = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+    for (int it = 0; it < PS_IT; ++it) {
+        const int kc = kc0 + 4 * it;
+        ps[it] = *(const v2du *)(my_row_ptr + (unsigned)col_of((kc < nkc) ? kc : nkc - 1) * ldb);
+    }
+    constexpr int PW_IT = (NKC * 8 + 255) / 256;
+    v2d pw[PW_IT];
+    {
+        const int pr = tid & 7, sub = (tid >> 3) & 7;                       // 8 columns x 8 row pairs per wave instruction
+        const char *own_ptr = (const char *)(P + i0 + 2 * pr);
+#pragma unroll
+        for (int it = 0; it < PW_IT; ++it) {
+            int kc = 8 * (kc0 + 4 * it) + sub;
+            kc = (kc < nkc) ? kc : nkc - 1;
+            const int cA = __shfl(colA, kc & 63, 64), cB = __shfl(colB, kc & 63, 64);
+            pw[it] = *(const v2d *)(own_ptr + (unsigned)((kc < 64) ? cA : cB) * ldb);
+        }
+    }
+    constexpr int PH_IT = MID_ROWS / 4;
+    v2du ph[PH_IT];
+#pragma unroll
+    for (int it = 0; it < PH_IT; ++it)
+        ph[it] = *(const v2du *)(my_row_ptr + (unsigned)(i0 + kc0 + 4 * it) * ldb);
+    MMARK();                                        // 1: gathers issued
 
     // ---- B: H rows (cc:248-304, gps.cc:305-332), thread = row
     if (tid < MP) {
@@ -1148,135 +1222,122 @@ __global__ __launch_bounds__(256) void k_mid(RekfDev d, RekfFrontArgs A)
         for (int q = 0; q < 8; ++q) s_coef[8 * r + q] = hr[q];
         if (rr == 0) s_pcol[p] = col;
     }
+    // raw values -> LDS.  s_psub is [row 2 rs + {0,1}][sub-block column kc]: phase D reads a row pair's (col_q, col_q + 1)
+    // as ONE 16-byte value, consecutive q = consecutive addresses (no bank conflicts)
+    if (lane < nrs) {
+#pragma unroll
+        for (int it = 0; it < PS_IT; ++it) {
+            const int kc = kc0 + 4 * it;
+            if (kc < nkc) { s_psub[2 * lane][kc] = ps[it].x; s_psub[2 * lane + 1][kc] = ps[it].y; }
+        }
+#pragma unroll
+        for (int it = 0; it < PH_IT; ++it) *(v2d *)&s_ph[kc0 + 4 * it][2 * lane] = (v2d){ph[it].x, ph[it].y};
+    }
+    {
+        const int pr = tid & 7, sub = (tid >> 3) & 7;
+#pragma unroll
+        for (int it = 0; it < PW_IT; ++it) {
+            const int kc = 8 * (kc0 + 4 * it) + sub;
+            if (kc < nkc) *(v2d *)&s_pw[kc][2 * pr] = pw[it];
+        }
+    }
     __syncthreads();
-    MMARK();                                        // 1: H rows in LDS
+    MMARK();                                        // 2: H rows and raw P in LDS
 
-    // ---- C: every gather of the launch goes in flight before anything is consumed
+    // ---- D: form W (rows of S, own rows) and (H P)^T (own columns) out of LDS.
+    // Same operation order as k_gather: v = p0 h0; v += p1 h1; v += p2 h2; v += pl0 g0; v += pl1 g1
     const int nq = m_pad / 2;                        // row pairs, pad rows included (their H rows are zero)
-    // C1: items (slot, q): slot < NS = state pair (its two landmark rows), slot NS = rows 0,1, slot NS+1 = row 2
-    constexpr int C1_IT = ((NPAIR + 2) * NPAIR + 255) / 256;
-    v2du c1p[C1_IT][5];
-    const int c1_items = (NS + 2) * nq;
+    {
+        // items (slot, q): slot < NS = state pair (its two landmark rows), slot NS = rows 0,1, slot NS+1 = row 2 (its second
+        // value is row 3: computed, never stored).  q = tid mod NPAIR, slot = tid / NPAIR + (256 / NPAIR) pass
+        const int q = tid & (NPAIR - 1);
+        const bool qlive = q < nq;
+        const bool has_col = qlive && s_pcol[q] >= 0; // a state pair: q < NS, its columns are kc = 3 + 2q, 4 + 2q
+        const int kq = has_col ? 3 + 2 * q : 0;       // clamped: without a landmark block the two extra terms are multiplied by zeros
+        double h0[5], h1[5];
 #pragma unroll
-    for (int it = 0; it < C1_IT; ++it) {
-        const int e = tid + 256 * it;
-        if (e < c1_items) {
-            const int slot = e / nq, q = e - slot * nq;
-            const int row = (slot < NS) ? 3 + 2 * s_pair_id[slot] : ((slot == NS) ? 0 : 2);
-            const int col = s_pcol[q];
-            const double *base = P + row;
-            if (slot <= NS) {
+        for (int k = 0; k < 5; ++k) { h0[k] = s_coef[16 * q + k]; h1[k] = s_coef[16 * q + 8 + k]; }
+        if (!has_col) { h0[3] = 0; h0[4] = 0; h1[3] = 0; h1[4] = 0; }
+        constexpr int SL_STEP = 256 / NPAIR, SL_PASS = (NRS + SL_STEP - 1) / SL_STEP;
+        int rs2[SL_PASS];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) c1p[it][k] = *(const v2du *)(base + (size_t)k * ld);
-                if (col >= 0) { c1p[it][3] = *(const v2du *)(base + (size_t)col * ld); c1p[it][4] = *(const v2du *)(base + (size_t)(col + 1) * ld); }
-            } else {
+        for (int pass = 0; pass < SL_PASS; ++pass) {
+            const int slot = tid / NPAIR + SL_STEP * pass, sl = (slot < nrs) ? slot : nrs - 1;
+            rs2[pass] = 2 * ((sl < NS) ? s_rank[sl] : sl);
+        }
 #pragma unroll
-                for (int k = 0; k < 3; ++k) c1p[it][k].x = base[(size_t)k * ld];
-                if (col >= 0) { c1p[it][3].x = base[(size_t)col * ld]; c1p[it][4].x = base[(size_t)(col + 1) * ld]; }
+        for (int pass = 0; pass < SL_PASS; ++pass) {
+            const int slot = tid / NPAIR + SL_STEP * pass;
+            const v2d a01 = *(const v2d *)&s_psub[rs2[pass]][0], b01 = *(const v2d *)&s_psub[rs2[pass] + 1][0];
+            const double a2 = s_psub[rs2[pass]][2], b2 = s_psub[rs2[pass] + 1][2];
+            const v2d al = *(const v2du *)&s_psub[rs2[pass]][kq], bl = *(const v2du *)&s_psub[rs2[pass] + 1][kq];
+            double v0x = a01.x * h0[0], v0y = b01.x * h0[0], v1x = a01.x * h1[0], v1y = b01.x * h1[0];
+            v0x += a01.y * h0[1]; v0y += b01.y * h0[1]; v1x += a01.y * h1[1]; v1y += b01.y * h1[1];
+            v0x += a2 * h0[2]; v0y += b2 * h0[2]; v1x += a2 * h1[2]; v1y += b2 * h1[2];
+            if (has_col) {                           // (kept as a select: adding +0.0 products would turn a -0.0 sum into +0.0)
+                v0x += al.x * h0[3]; v0y += bl.x * h0[3]; v1x += al.x * h1[3]; v1y += bl.x * h1[3];
+                v0x += al.y * h0[4]; v0y += bl.y * h0[4]; v1x += al.y * h1[4]; v1y += bl.y * h1[4];
+            }
+            if (slot < nrs && qlive) {
+                if (slot < NS) { *(v2d *)&s_wcp[slot][2 * q][0] = (v2d){v0x, v0y}; *(v2d *)&s_wcp[slot][2 * q + 1][0] = (v2d){v1x, v1y}; }
+                else if (slot == NS) { *(v2d *)&s_wc0[0][2 * q] = (v2d){v0x, v1x}; *(v2d *)&s_wc0[1][2 * q] = (v2d){v0y, v1y}; }
+                else *(v2d *)&s_wc0[2][2 * q] = (v2d){v0x, v1x};
             }
         }
-    }
-    // C2: item (own row pair pr, q): rows i0 + 2 pr, +1 of W
-    constexpr int C2_IT = (8 * NPAIR + 255) / 256;
-    v2d c2p[C2_IT][5];
+        // own rows: item (row pair pr, q), q = tid / 8 (+ 32 per pass)
+        const int pr = tid & 7;
 #pragma unroll
-    for (int it = 0; it < C2_IT; ++it) {
-        const int e = tid + 256 * it;
-        if (e < 8 * nq) {
-            const int pr = e & 7, q = e >> 3;
-            const int col = s_pcol[q];
-            const double *base = P + i0 + 2 * pr;
+        for (int pass = 0; pass < (NPAIR + 31) / 32; ++pass) {
+            const int q2 = (tid >> 3) + 32 * pass;
+            if (q2 < nq) {
+                const bool hc = s_pcol[q2] >= 0;
+                const int c = i0 + 2 * pr;
+                const v2d p0 = *(const v2d *)&s_pw[0][2 * pr], p1 = *(const v2d *)&s_pw[1][2 * pr], p2 = *(const v2d *)&s_pw[2][2 * pr];
+                v2d l0 = {0, 0}, l1 = {0, 0};
+                if (hc) { l0 = *(const v2d *)&s_pw[3 + 2 * q2][2 * pr]; l1 = *(const v2d *)&s_pw[4 + 2 * q2][2 * pr]; }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) c2p[it][k] = *(const v2d *)(base + (size_t)k * ld);
-            if (col >= 0) { c2p[it][3] = *(const v2d *)(base + (size_t)col * ld); c2p[it][4] = *(const v2d *)(base + (size_t)(col + 1) * ld); }
-        }
-    }
-    // C3: item (own column cidx, q): (H P)^T(c, 2q..2q+1) from the ROWS 0..2, col_q, col_q+1 of column c of P
-    constexpr int C3_IT = (16 * NPAIR + 255) / 256;
-    v2d c3a[C3_IT];
-    double c3b[C3_IT];
-    v2du c3l[C3_IT];
-#pragma unroll
-    for (int it = 0; it < C3_IT; ++it) {
-        const int e = tid + 256 * it;
-        if (e < 16 * nq) {
-            const int cidx = e & 15, q = e >> 4;
-            const int col = s_pcol[q];
-            const double *Pc = P + (size_t)(i0 + cidx) * ld;
-            c3a[it] = *(const v2d *)(Pc);
-            c3b[it] = Pc[2];
-            if (col >= 0) c3l[it] = *(const v2du *)(Pc + col);
-        }
-    }
-
-    MMARK();                                        // 2: gathers issued
-    // ---- D: consume.  Same operation order as k_gather: v = p0 h0; v += p1 h1; v += p2 h2; v += pl0 g0; v += pl1 g1
-#pragma unroll
-    for (int it = 0; it < C1_IT; ++it) {
-        const int e = tid + 256 * it;
-        if (e < c1_items) {
-            const int slot = e / nq, q = e - slot * nq;
-            const bool has_col = s_pcol[q] >= 0;
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const int r = 2 * q + rr;
-                const double *h = s_coef + 8 * r;
-                double vx = c1p[it][0].x * h[0], vy = c1p[it][0].y * h[0];
-                vx += c1p[it][1].x * h[1]; vy += c1p[it][1].y * h[1];
-                vx += c1p[it][2].x * h[2]; vy += c1p[it][2].y * h[2];
-                if (has_col) {
-                    vx += c1p[it][3].x * h[3]; vy += c1p[it][3].y * h[3];
-                    vx += c1p[it][4].x * h[4]; vy += c1p[it][4].y * h[4];
+                for (int rr = 0; rr < 2; ++rr) {
+                    const int r = 2 * q2 + rr;
+                    const double *h = s_coef + 8 * r;
+                    double vx = p0.x * h[0], vy = p0.y * h[0];
+                    vx += p1.x * h[1]; vy += p1.y * h[1];
+                    vx += p2.x * h[2]; vy += p2.y * h[2];
+                    if (hc) {
+                        vx += l0.x * h[3]; vy += l0.y * h[3];
+                        vx += l1.x * h[4]; vy += l1.y * h[4];
+                    }
+                    if (c >= n) vx = 0.0;
+                    if (c + 1 >= n) vy = 0.0;
+                    *(v2d *)&s_wown[r][2 * pr] = (v2d){vx, vy};
                 }
-                if (slot < NS) { s_wcp[slot][r][0] = vx; s_wcp[slot][r][1] = vy; }
-                else if (slot == NS) { s_wc0[0][r] = vx; s_wc0[1][r] = vy; }
-                else s_wc0[2][r] = vx;
-            }
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < C2_IT; ++it) {
-        const int e = tid + 256 * it;
-        if (e < 8 * nq) {
-            const int pr = e & 7, q = e >> 3;
-            const bool has_col = s_pcol[q] >= 0;
-            const int c = i0 + 2 * pr;
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const int r = 2 * q + rr;
-                const double *h = s_coef + 8 * r;
-                double vx = c2p[it][0].x * h[0], vy = c2p[it][0].y * h[0];
-                vx += c2p[it][1].x * h[1]; vy += c2p[it][1].y * h[1];
-                vx += c2p[it][2].x * h[2]; vy += c2p[it][2].y * h[2];
-                if (has_col) {
-                    vx += c2p[it][3].x * h[3]; vy += c2p[it][3].y * h[3];
-                    vx += c2p[it][4].x * h[4]; vy += c2p[it][4].y * h[4];
-                }
-                if (c >= n) vx = 0.0;
-                if (c + 1 >= n) vy = 0.0;
-                s_wown[r][2 * pr] = vx; s_wown[r][2 * pr + 1] = vy;
             }
         }
     }
     const int strip_nb = rekf_strip_base(n);          // k_downdate's border strips want rows nb.. of HPt / Kn contiguous
+    {
+        // own columns: item (column cidx, q) -> (H P)^T(c, 2q..2q+1), q = tid / 16 (+ 16 per pass): 16 lanes store 128 contiguous bytes
+        const int cidx = tid & 15, c = i0 + cidx;
+        const double q0 = s_ph[cidx][2 * NS], q1 = s_ph[cidx][2 * NS + 1], q2v = s_ph[cidx][2 * NS + 2];
+        double *hp_out = d.HPt + c;
 #pragma unroll
-    for (int it = 0; it < C3_IT; ++it) {
-        const int e = tid + 256 * it;
-        if (e < 16 * nq) {
-            const int cidx = e & 15, q = e >> 4;
-            const bool has_col = s_pcol[q] >= 0;
-            const int c = i0 + cidx;
+        for (int pass = 0; pass < (NPAIR + 15) / 16; ++pass) {
+            const int q = (tid >> 4) + 16 * pass;
+            if (q < nq) {
+                const bool hc = s_pcol[q] >= 0;
+                v2d ql = {0, 0};
+                if (hc) ql = *(const v2d *)&s_ph[cidx][2 * s_rank[q]];
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const int r = 2 * q + rr;
-                const double *h = s_coef + 8 * r;
-                double u = h[0] * c3a[it].x;
-                u += h[1] * c3a[it].y;
-                u += h[2] * c3b[it];
-                if (has_col) { u += h[3] * c3l[it].x; u += h[4] * c3l[it].y; }
-                if (c >= n) u = 0.0;
-                d.HPt[c + (size_t)r * ld] = u;
-                if (strip_nb >= 0 && c >= strip_nb && c < strip_nb + REKF_STRIP_MAX) d.HPtB[(c - strip_nb) * REKF_MR_PAD + r] = u;
+                for (int rr = 0; rr < 2; ++rr) {
+                    const int r = 2 * q + rr;
+                    const double *h = s_coef + 8 * r;
+                    double u = h[0] * q0;
+                    u += h[1] * q1;
+                    u += h[2] * q2v;
+                    if (hc) { u += h[3] * ql.x; u += h[4] * ql.y; }
+                    if (c >= n) u = 0.0;
+                    hp_out[(size_t)r * ld] = u;
+                    if (strip_nb >= 0 && c >= strip_nb && c < strip_nb + REKF_STRIP_MAX) d.HPtB[(c - strip_nb) * REKF_MR_PAD + r] = u;
+                }
             }
         }
     }
@@ -1904,6 +1965,11 @@ template <int N> __device__ static inline void dd_wait_vmcnt()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+#ifdef REKF_EXP_NT_STORES
+#define DD_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define DD_STORE(p, v) (*(p) = (v))
+#endif
 template <int KC>
 __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
 {
@@ -2090,7 +2156,7 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
                 if (!FIRST) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q)
-                        if ((q * Q4) / 8 == off) *(v2d *)(Po + (size_t)(8 * (q & 3) + (q >> 2)) * ld) = pq[PREV][q];
+                        if ((q * Q4) / 8 == off) DD_STORE((v2d *)(Po + (size_t)(8 * (q & 3) + (q >> 2)) * ld), pq[PREV][q]);
                 }
                 if (!SPECIAL && !LAST && needH) {
 #pragma unroll
@@ -2161,7 +2227,7 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
         if (LAST) {
             double *Pw = p_ptr(I, J);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) *(v2d *)(Pw + (size_t)(8 * (q & 3) + (q >> 2)) * ld) = pq[PAR][q];
+            for (int q = 0; q < 8; ++q) DD_STORE((v2d *)(Pw + (size_t)(8 * (q & 3) + (q >> 2)) * ld), pq[PAR][q]);
             return;
         }
         if (SPECIAL) {                                      // a special tile in mid-range (rare): fetch the next panels now

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -344,7 +345,8 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         { ProfScope ps(h, REKF_K_GAIN); rekf_launch_gain(h->dev, n_ub, h->stream); }
     }
     h->last_m_ub = m_ub;
-    { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_downdate(h->dev, n_ub, h->stream); }
+    static const bool exp_skip_dd = std::getenv("REKF_EXP_SKIP_DD") != nullptr;      // timing experiment only: results are wrong
+    if (!exp_skip_dd) { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_downdate(h->dev, n_ub, h->stream); }
     // the state only grows: once a readback has shown it full, k_augment can never have work again
     // (k_gather drops the extra reflectors and raises REKF_FLAG_CAPACITY)
     if (!h->full) { ProfScope ps(h, REKF_K_AUGMENT); rekf_launch_augment(h->dev, a, h->stream); }
