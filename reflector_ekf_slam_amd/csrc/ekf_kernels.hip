@@ -172,7 +172,7 @@ __global__ __launch_bounds__(1024) void k_front(RekfDev d, RekfFrontArgs A)
     double *__restrict__ P = d.P;
     double *mu = d.mu;
     const size_t ld = (size_t)d.ld;
-    const int n = ctl->n;
+    const int n = (d.n_known >= 0) ? d.n_known : ctl->n;
     // ---- the covariance-predict operands and the pose block go in flight first
     double c0[COV_PF], c1[COV_PF], c2[COV_PF], r0[COV_PF], r1[COV_PF], r2[COV_PF];
 #pragma unroll
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
     double *__restrict__ P = d.P;
     const double *mu = d.mu;
     const size_t ld = (size_t)d.ld;
-    const int n = ctl->n;
+    const int n = (d.n_known >= 0) ? d.n_known : ctl->n;
     const int L = (n - 3) / 2;
     const int K = A.K;
 
@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(512) void k_gain(RekfDev d)
 typedef double v2du __attribute__((ext_vector_type(2), aligned(8)));     // a row pair that starts on an odd row: 8-byte aligned
 #define MID_ROWS 16
 template <int NBR>
-__global__ __launch_bounds__(256) void k_mid(RekfDev d, RekfFrontArgs A)
+__global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
 {
     constexpr int MP = 16 * NBR;                  // most innovation rows (padded) this instance takes
     constexpr int NPAIR = MP / 2;
@@ -1071,12 +1071,17 @@ __global__ __launch_bounds__(256) void k_mid(RekfDev d, RekfFrontArgs A)
 #else
 #define MMARK()
 #endif
+    // 512 threads = two teams of four waves (one of each per SIMD).  Waves 0..3 carry the critical chain -- sub-block
+    // gather, W rows of S, S, its inverse -- waves 4..7 everything that only this workgroup's 16 rows / columns need
+    // (H rows, own gathers, (H P)^T to HBM), off that chain; both meet at the barriers.
     RekfCtl *ctl = d.ctl;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool steam = wave < 4;                  // S team; the other is the "own" team
+    const int tt = tid & 255;                     // thread index within the team
     // the match results first, UNCONDITIONALLY (both arrays have 64 entries): a vector load that waits for no scalar one,
     // so the control block costs one memory round trip, not two
     const int kind_raw = ctl->obs_kind[lane], oidx_raw = ctl->obs_idx[lane];
-    const int n = ctl->n;
+    const int n = (d.n_known >= 0) ? d.n_known : ctl->n;
     const int K = A.K;
     const size_t ld = (size_t)d.ld;
     const int i0 = blockIdx.x * MID_ROWS;
@@ -1151,6 +1156,14 @@ __global__ __launch_bounds__(256) void k_mid(RekfDev d, RekfFrontArgs A)
             d.mu_out[i] = (pending && i < 3) ? pp : d.mu[i];
         }
         if (pending && first && tid == 0) ctl->pose_pending = 0;
+        // k_downdate2 runs without looking at the control block when the host knows n: give it zeros to add
+        const int snb = rekf_strip_base(n);
+        for (int e = tid; e < 16 * d.kc_ub; e += 512) {
+            const int cidx = e & 15, r = e >> 4, c = i0 + cidx;
+            d.HPt[c + (size_t)r * ld] = 0.0;
+            d.Kn[c + (size_t)r * ld] = 0.0;
+            if (snb >= 0 && c >= snb && c < snb + REKF_STRIP_MAX) { d.HPtB[(c - snb) * REKF_MR_PAD + r] = 0.0; d.KnB[(c - snb) * REKF_MR_PAD + r] = 0.0; }
+        }
         return;
     }
     // (m_pad <= MP: the host picked NBR from its bound 2K(+3) of m)
@@ -1173,15 +1186,19 @@ __global__ __launch_bounds__(256) void k_mid(RekfDev d, RekfFrontArgs A)
     constexpr int PS_IT = (NKC + 3) / 4;
     v2du ps[PS_IT];
     const char *my_row_ptr = (const char *)(P + s_rsrow[(lane < nrs) ? lane : nrs - 1]);
-    const int kc0 = __builtin_amdgcn_readfirstlane(wave);
+    const int kc0 = __builtin_amdgcn_readfirstlane(wave & 3);
+    if (steam) {
 #pragma unroll
-    for (int it = 0; it < PS_IT; ++it) {
-        const int kc = kc0 + 4 * it;
-        ps[it] = *(const v2du *)(my_row_ptr + (unsigned)col_of((kc < nkc) ? kc : nkc - 1) * ldb);
+        for (int it = 0; it < PS_IT; ++it) {
+            const int kc = kc0 + 4 * it;
+            ps[it] = *(const v2du *)(my_row_ptr + (unsigned)col_of((kc < nkc) ? kc : nkc - 1) * ldb);
+        }
     }
     constexpr int PW_IT = (NKC * 8 + 255) / 256;
     v2d pw[PW_IT];
-    {
+    constexpr int PH_IT = MID_ROWS / 4;
+    v2du ph[PH_IT];
+    if (!steam) {
         const int pr = tid & 7, sub = (tid >> 3) & 7;                       // 8 columns x 8 row pairs per wave instruction
         const char *own_ptr = (const char *)(P + i0 + 2 * pr);
 #pragma unroll
@@ -1191,17 +1208,15 @@ __global__ __launch_bounds__(256) void k_mid(RekfDev d, RekfFrontArgs A)
             const int cA = __shfl(colA, kc & 63, 64), cB = __shfl(colB, kc & 63, 64);
             pw[it] = *(const v2d *)(own_ptr + (unsigned)((kc < 64) ? cA : cB) * ldb);
         }
-    }
-    constexpr int PH_IT = MID_ROWS / 4;
-    v2du ph[PH_IT];
 #pragma unroll
-    for (int it = 0; it < PH_IT; ++it)
-        ph[it] = *(const v2du *)(my_row_ptr + (unsigned)(i0 + kc0 + 4 * it) * ldb);
+        for (int it = 0; it < PH_IT; ++it)
+            ph[it] = *(const v2du *)(my_row_ptr + (unsigned)(i0 + kc0 + 4 * it) * ldb);
+    }
     MMARK();                                        // 1: gathers issued
 
-    // ---- B: H rows (cc:248-304, gps.cc:305-332), thread = row
-    if (tid < MP) {
-        const int r = tid, p = r >> 1, rr = r & 1;
+    // ---- B: H rows (cc:248-304, gps.cc:305-332), thread = row (own team: its landmark-mean loads overlap the S team's gather)
+    if (!steam && tt < MP) {
+        const int r = tt, p = r >> 1, rr = r & 1;
         double hr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int col = -1;
         if (p < MM) {
@@ -1224,16 +1239,19 @@ __global__ __launch_bounds__(256) void k_mid(RekfDev d, RekfFrontArgs A)
     }
     // raw values -> LDS.  s_psub is [row 2 rs + {0,1}][sub-block column kc]: phase D reads a row pair's (col_q, col_q + 1)
     // as ONE 16-byte value, consecutive q = consecutive addresses (no bank conflicts)
-    if (lane < nrs) {
+    if (steam) {
+        if (lane < nrs) {
 #pragma unroll
-        for (int it = 0; it < PS_IT; ++it) {
-            const int kc = kc0 + 4 * it;
-            if (kc < nkc) { s_psub[2 * lane][kc] = ps[it].x; s_psub[2 * lane + 1][kc] = ps[it].y; }
+            for (int it = 0; it < PS_IT; ++it) {
+                const int kc = kc0 + 4 * it;
+                if (kc < nkc) { s_psub[2 * lane][kc] = ps[it].x; s_psub[2 * lane + 1][kc] = ps[it].y; }
+            }
         }
+    } else {
+        if (lane < nrs) {
 #pragma unroll
-        for (int it = 0; it < PH_IT; ++it) *(v2d *)&s_ph[kc0 + 4 * it][2 * lane] = (v2d){ph[it].x, ph[it].y};
-    }
-    {
+            for (int it = 0; it < PH_IT; ++it) *(v2d *)&s_ph[kc0 + 4 * it][2 * lane] = (v2d){ph[it].x, ph[it].y};
+        }
         const int pr = tid & 7, sub = (tid >> 3) & 7;
 #pragma unroll
         for (int it = 0; it < PW_IT; ++it) {
@@ -1247,10 +1265,11 @@ __global__ __launch_bounds__(256) void k_mid(RekfDev d, RekfFrontArgs A)
     // ---- D: form W (rows of S, own rows) and (H P)^T (own columns) out of LDS.
     // Same operation order as k_gather: v = p0 h0; v += p1 h1; v += p2 h2; v += pl0 g0; v += pl1 g1
     const int nq = m_pad / 2;                        // row pairs, pad rows included (their H rows are zero)
-    {
+    const int strip_nb = rekf_strip_base(n);          // k_downdate's border strips want rows nb.. of HPt / Kn contiguous
+    if (steam) {
         // items (slot, q): slot < NS = state pair (its two landmark rows), slot NS = rows 0,1, slot NS+1 = row 2 (its second
         // value is row 3: computed, never stored).  q = tid mod NPAIR, slot = tid / NPAIR + (256 / NPAIR) pass
-        const int q = tid & (NPAIR - 1);
+        const int q = tt & (NPAIR - 1);
         const bool qlive = q < nq;
         const bool has_col = qlive && s_pcol[q] >= 0; // a state pair: q < NS, its columns are kc = 3 + 2q, 4 + 2q
         const int kq = has_col ? 3 + 2 * q : 0;       // clamped: without a landmark block the two extra terms are multiplied by zeros
@@ -1262,12 +1281,12 @@ __global__ __launch_bounds__(256) void k_mid(RekfDev d, RekfFrontArgs A)
         int rs2[SL_PASS];
 #pragma unroll
         for (int pass = 0; pass < SL_PASS; ++pass) {
-            const int slot = tid / NPAIR + SL_STEP * pass, sl = (slot < nrs) ? slot : nrs - 1;
+            const int slot = tt / NPAIR + SL_STEP * pass, sl = (slot < nrs) ? slot : nrs - 1;
             rs2[pass] = 2 * ((sl < NS) ? s_rank[sl] : sl);
         }
 #pragma unroll
         for (int pass = 0; pass < SL_PASS; ++pass) {
-            const int slot = tid / NPAIR + SL_STEP * pass;
+            const int slot = tt / NPAIR + SL_STEP * pass;
             const v2d a01 = *(const v2d *)&s_psub[rs2[pass]][0], b01 = *(const v2d *)&s_psub[rs2[pass] + 1][0];
             const double a2 = s_psub[rs2[pass]][2], b2 = s_psub[rs2[pass] + 1][2];
             const v2d al = *(const v2du *)&s_psub[rs2[pass]][kq], bl = *(const v2du *)&s_psub[rs2[pass] + 1][kq];
@@ -1284,11 +1303,12 @@ __global__ __launch_bounds__(256) void k_mid(RekfDev d, RekfFrontArgs A)
                 else *(v2d *)&s_wc0[2][2 * q] = (v2d){v0x, v1x};
             }
         }
-        // own rows: item (row pair pr, q), q = tid / 8 (+ 32 per pass)
-        const int pr = tid & 7;
+    } else {
+        // own rows: item (row pair pr, q), q = tt / 8 (+ 32 per pass)
+        const int pr = tt & 7;
 #pragma unroll
         for (int pass = 0; pass < (NPAIR + 31) / 32; ++pass) {
-            const int q2 = (tid >> 3) + 32 * pass;
+            const int q2 = (tt >> 3) + 32 * pass;
             if (q2 < nq) {
                 const bool hc = s_pcol[q2] >= 0;
                 const int c = i0 + 2 * pr;
@@ -1312,16 +1332,13 @@ __global__ __launch_bounds__(256) void k_mid(RekfDev d, RekfFrontArgs A)
                 }
             }
         }
-    }
-    const int strip_nb = rekf_strip_base(n);          // k_downdate's border strips want rows nb.. of HPt / Kn contiguous
-    {
-        // own columns: item (column cidx, q) -> (H P)^T(c, 2q..2q+1), q = tid / 16 (+ 16 per pass): 16 lanes store 128 contiguous bytes
-        const int cidx = tid & 15, c = i0 + cidx;
+        // own columns: item (column cidx, q) -> (H P)^T(c, 2q..2q+1), q = tt / 16 (+ 16 per pass): 16 lanes store 128 contiguous bytes
+        const int cidx = tt & 15, c = i0 + cidx;
         const double q0 = s_ph[cidx][2 * NS], q1 = s_ph[cidx][2 * NS + 1], q2v = s_ph[cidx][2 * NS + 2];
         double *hp_out = d.HPt + c;
 #pragma unroll
         for (int pass = 0; pass < (NPAIR + 15) / 16; ++pass) {
-            const int q = (tid >> 4) + 16 * pass;
+            const int q = (tt >> 4) + 16 * pass;
             if (q < nq) {
                 const bool hc = s_pcol[q] >= 0;
                 v2d ql = {0, 0};
@@ -1340,15 +1357,15 @@ __global__ __launch_bounds__(256) void k_mid(RekfDev d, RekfFrontArgs A)
                 }
             }
         }
-    }
-    // columns [m_pad, kc_ub) of HPt / Kn are kept zero for k_downdate2<kc_ub>
-    for (int e = tid; e < 16 * (d.kc_ub - m_pad); e += 256) {
-        const int cidx = e & 15, r = m_pad + (e >> 4), c = i0 + cidx;
-        d.HPt[c + (size_t)r * ld] = 0.0;
-        d.Kn[c + (size_t)r * ld] = 0.0;
-        if (strip_nb >= 0 && c >= strip_nb && c < strip_nb + REKF_STRIP_MAX) {
-            d.HPtB[(c - strip_nb) * REKF_MR_PAD + r] = 0.0;
-            d.KnB[(c - strip_nb) * REKF_MR_PAD + r] = 0.0;
+        // columns [m_pad, kc_ub) of HPt / Kn are kept zero for k_downdate2<kc_ub>
+        for (int e = tt; e < 16 * (d.kc_ub - m_pad); e += 256) {
+            const int cidx2 = e & 15, r = m_pad + (e >> 4), c2 = i0 + cidx2;
+            d.HPt[c2 + (size_t)r * ld] = 0.0;
+            d.Kn[c2 + (size_t)r * ld] = 0.0;
+            if (strip_nb >= 0 && c2 >= strip_nb && c2 < strip_nb + REKF_STRIP_MAX) {
+                d.HPtB[(c2 - strip_nb) * REKF_MR_PAD + r] = 0.0;
+                d.KnB[(c2 - strip_nb) * REKF_MR_PAD + r] = 0.0;
+            }
         }
     }
     __syncthreads();
@@ -1363,24 +1380,30 @@ __global__ __launch_bounds__(256) void k_mid(RekfDev d, RekfFrontArgs A)
         for (int bi = 0; bi < NBR; ++bi) S[bi] = (v4d){0, 0, 0, 0};
         const int w = wave, j = 16 * w + c;
         if (w < nbr) {
-            const int rows_state = 2 * NS;
+            // straight-line on purpose (all LDS reads of a block row issue together): rows without a landmark block have
+            // zero coefficients there (phase B), so their two extra terms are computed against a clamped pair and add 0
+            const int last_pair = (NS > 0) ? NS - 1 : 0;
             const double w0 = s_wc0[0][j], w1 = s_wc0[1][j], w2 = s_wc0[2][j];
 #pragma unroll
             for (int bi = 0; bi < NBR; ++bi) {
                 if (bi < nbr) {
+                    v2d ha01[4], ha2b0[4], b1q[4], wl[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * bi + g + 4 * r, pi = (i >> 1) < NS ? (i >> 1) : last_pair;
+                        ha01[r] = *(const v2d *)(s_coef + 8 * i); ha2b0[r] = *(const v2d *)(s_coef + 8 * i + 2);
+                        b1q[r] = *(const v2d *)(s_coef + 8 * i + 4);
+                        wl[r] = *(const v2d *)&s_wcp[pi][j][0];
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int i = 16 * bi + g + 4 * r;
-                        const v2d ha01 = *(const v2d *)(s_coef + 8 * i), ha2b0 = *(const v2d *)(s_coef + 8 * i + 2);
-                        const v2d b1q = *(const v2d *)(s_coef + 8 * i + 4);
-                        double v = ha01.x * w0;
-                        v += ha01.y * w1;
-                        v += ha2b0.x * w2;
-                        if (i < rows_state) {
-                            const v2d wl = *(const v2d *)&s_wcp[i >> 1][j][0];
-                            v += ha2b0.y * wl.x; v += b1q.x * wl.y;
-                        }
-                        if (i == j) v += b1q.y;
+                        double v = ha01[r].x * w0;
+                        v += ha01[r].y * w1;
+                        v += ha2b0[r].x * w2;
+                        v += ha2b0[r].y * wl[r].x;
+                        v += b1q[r].x * wl[r].y;
+                        if (i == j) v += b1q[r].y;
                         if (i >= m || j >= m) v = (i == j) ? 1.0 : 0.0;
                         S[bi][r] = v;
                     }
@@ -1987,9 +2010,14 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
 #else
 #define D2MARK()
 #endif
+    // With n known to the host nothing here depends on the control block: k_mid leaves zero panels behind a scan without
+    // matches, so the kernel may run unconditionally and its first loads go out one memory round trip earlier.
     const RekfCtl *ctl = d.ctl;
-    if (ctl->m == 0) return;
-    const int n = ctl->n;
+    int n = d.n_known;
+    if (n < 0) {
+        if (ctl->m == 0) return;
+        n = ctl->n;
+    }
     constexpr int NK = KC / 4;               // MFMA k-steps per tile
     constexpr int ND = KC / 8;               // DMA instructions per panel per wave (2 k-rows each, 4 waves)
     constexpr int PANEL = KC * 64;           // doubles per panel
@@ -2482,8 +2510,8 @@ void rekf_launch_mid(const RekfDev &d, const RekfFrontArgs &a, int n_ub, int m_u
 {
     // m_ub <= 64 (the host checks): one workgroup per 16 state rows
     const int grid = (n_ub + MID_ROWS - 1) / MID_ROWS;
-    if (m_ub <= 32) hipLaunchKernelGGL(k_mid<2>, dim3(grid), dim3(256), 0, s, d, a);
-    else hipLaunchKernelGGL(k_mid<4>, dim3(grid), dim3(256), 0, s, d, a);
+    if (m_ub <= 32) hipLaunchKernelGGL(k_mid<2>, dim3(grid), dim3(512), 0, s, d, a);
+    else hipLaunchKernelGGL(k_mid<4>, dim3(grid), dim3(512), 0, s, d, a);
 }
 void rekf_launch_solve(const RekfDev &d, int m_ub, hipStream_t s)
 {

@@ -40,6 +40,7 @@ struct rekf {
     int n_ub;                  // host upper bound of the device-resident n
     int last_m_ub = 64;        // innovation-row bound of the last scan (sizes the k_solve launch)
     bool full;                 // a readback showed n == n_max: no landmark can ever be added again
+    bool n_exact = true;       // n_ub IS the device's n (nothing that can append landmarks was enqueued since it was read back)
     double *pose_staging;      // pinned, 12 doubles
     double *dev_out12;         // device scratch for k_predict_pose
     double *dev_ell;           // device scratch for k_ellipses (5 doubles per landmark of capacity)
@@ -150,6 +151,7 @@ int pull_ctl(rekf_t *h)
     HIP_TRY(h, hipMemcpyAsync(h->ctl_staging, h->dev.ctl, sizeof(RekfCtl), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->n_ub = h->ctl_staging->n;
+    h->n_exact = true;
     h->full = h->ctl_staging->n >= h->dev.n_max;
     report_flags(h, h->ctl_staging->err);
     return REKF_OK;
@@ -299,6 +301,7 @@ int rekf_handle_odometry(rekf_t *h, double t, double vx, double vy, double wz)
     RekfFrontArgs a;
     fill_front_args(h, a, t - h->time);               // cc:217
     a.is_obs = 0;
+    h->dev.n_known = h->n_exact ? h->n_ub : -1;
     HIP_TRY(h, hipSetDevice(h->device));
     {
         ProfScope ps(h, REKF_K_PREDICT);
@@ -321,6 +324,7 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         a.has_gps = 1;
         a.gps[0] = gps_pose3[0]; a.gps[1] = gps_pose3[1]; a.gps[2] = gps_pose3[2];
     }
+    h->dev.n_known = h->n_exact ? h->n_ub : -1;
     HIP_TRY(h, hipSetDevice(h->device));
     ProfScope upd(h, REKF_K_UPDATE);                  // one bracket around the whole chain (per-update latency)
     if (K == 0) {                                     // cc:235-236: predict only, single-workgroup kernel
@@ -330,6 +334,7 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         return REKF_OK;
     }
     h->dev.kc_ub = round_up(2 * K + (gps_pose3 ? 3 : 0), 16);
+    h->dev.n_known = h->n_exact ? h->n_ub : -1;
     { ProfScope ps(h, REKF_K_FRONT); rekf_launch_front_mb(h->dev, a, h->n_ub, h->stream); }
     h->time = t;                                      // cc:234
     const int n_ub = h->n_ub;
@@ -354,6 +359,7 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     // the scan may have appended up to K reflectors; the exact n stays on the device
     int grown = n_ub + 2 * K;
     h->n_ub = grown > h->dev.n_max ? h->dev.n_max : grown;
+    if (!h->full) h->n_exact = false;                 // k_augment may have appended: only the device knows by how much
     HIP_TRY(h, hipGetLastError());
     return REKF_OK;
 }
@@ -457,6 +463,7 @@ int rekf_set_state(rekf_t *h, double t, int n, const double *mu, const double *s
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->time = t;
     h->n_ub = n;
+    h->n_exact = true;
     h->full = n >= h->dev.n_max;
     if (vt3) { h->vt[0] = vt3[0]; h->vt[1] = vt3[1]; h->vt[2] = vt3[2]; }
     return REKF_OK;
