@@ -11,9 +11,10 @@
  * where it is double (poses, odometry).
  *
  * PARITY UNPINNED: the reference has no tests/fixtures for this path and cannot be
- * built here (ROS sensor_msgs, Eigen, glog absent).  Pinned by hand-checkable micro
- * cases in tests/ and by the independent vectorised numpy restatement in
- * tests/golden/make_golden_detect.py.
+ * built here (ROS sensor_msgs, Eigen, glog absent).  Pinned against drift and against a
+ * second implementation only: hand-checkable micro cases in tests/, and the independent
+ * data-parallel numpy statement tests/witness/detect2d_witness.py, which must agree bit for
+ * bit (tests/test_witness_cpu.py; its vectors: tests/golden/witness_frontends.npz).
  *
  * Defined behaviour where the reference has UB (DESIGN.md quirk register):
  *   Q13  no bright beam in range  -> empty observation (reference: front() on an empty deque)

@@ -25,6 +25,9 @@
  * float32 distances at rank MeanK+1) are likewise resolved by value only (the sum of the
  * MeanK+1 smallest distances does not depend on which tied point is taken).
  *
+ * Second witness: tests/witness/detect3d_witness.py (scipy kd-tree + connected components) must give the
+ * same centres bit for bit (tests/test_witness_cpu.py).
+ *
  * Compile with -ffp-contract=off.
  */
 #include <math.h>

@@ -1434,14 +1434,22 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
             const int j0 = 16 * jt;
             double part = 0.0;
             if (jt < nbr) {
-                v4d acc = {0, 0, 0, 0};
+                // two accumulation chains (a dependent MFMA costs ~100 cycles, an independent one 64), operands of a whole
+                // 16-row block of k read before its MFMAs issue
+                v4d acc = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
 #pragma unroll
-                for (int kk = 0; kk < MP / 4; ++kk) {
-                    if (kk < m_pad / 4) {
-                        const int k = 4 * kk + kq;
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s_sinv[k][j0 + idx], s_wown[k][idx], acc, 0, 0, 0);
+                for (int kb = 0; kb < NBR; ++kb) {
+                    if (kb < nbr) {
+                        double av[4], bv[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { const int k = 16 * kb + 4 * q + kq; av[q] = s_sinv[k][j0 + idx]; bv[q] = s_wown[k][idx]; }
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc1, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc1, 0, 0, 0);
                     }
                 }
+                acc = acc + acc1;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int j = j0 + kq + 4 * r;                               // D row = column of K
