@@ -30,11 +30,13 @@
 extern "C" {
 #endif
 
-#define REKF_ABI_VERSION 2
+#define REKF_ABI_VERSION 3
 
-/* Most observations one scan may carry (K).  m = 2*K (+3 with a pose
- * observation) innovation rows must fit the single-workgroup LDS solve. */
-#define REKF_MAX_OBS 64
+/* Most observations one scan may carry (K).  The reference has no limit (reflector_ekf_slam.cc:397 loops over
+ * obs.cloud_.size()); this one is a buffer size, equal to what the detectors of rdet.h can emit (RDET_MAX_CENTERS).
+ * Up to 64 observations (128 innovation rows) update jointly in one pass; wider scans are matched once and updated
+ * in exact block steps of 32 matched pairs (same posterior: see k_mid in csrc/ekf_kernels.hip). */
+#define REKF_MAX_OBS 256
 
 enum {
     REKF_OK = 0,

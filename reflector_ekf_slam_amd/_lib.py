@@ -10,8 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-MAX_OBS = 64
-REKF_ABI_VERSION = 2          # must equal REKF_ABI_VERSION of include/rekf.h and rekf_abi_version() of the built library
+MAX_OBS = 256
+REKF_ABI_VERSION = 3          # must equal REKF_ABI_VERSION of include/rekf.h and rekf_abi_version() of the built library
 
 
 class RekfOptions(C.Structure):

@@ -22,7 +22,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#define REKF_MAX_OBS_DEV 64
+#define REKF_MAX_OBS_DEV 64                          // observations of a scan that travel by value with the launch and update jointly
+#define REKF_MAX_OBS_WIDE 256                        // most observations per scan at all (wide scans: staged in HBM, updated in exact block steps)
 #define REKF_MAX_ROWS 128                           // 2 per match (+3 pose rows: then K <= 62)
 #define REKF_MR_PAD 128                             // leading dimension of Sinv
 #define REKF_STRIP_MAX 4                            // border rows (n mod 64) that k_downdate handles as strips
@@ -39,17 +40,17 @@ struct RekfCtl {
     int n_state, n_map, n_new;
     int m;                    // innovation rows = 2*(n_state+n_map) (+3 with a pose observation)
     int m_pad;                // m rounded up to 16; W/Kn columns [m, m_pad) are zero
-    int state_pairs[2 * REKF_MAX_OBS_DEV];
-    int map_pairs[2 * REKF_MAX_OBS_DEV];
-    int new_ids[REKF_MAX_OBS_DEV];
+    int state_pairs[2 * REKF_MAX_OBS_WIDE];
+    int map_pairs[2 * REKF_MAX_OBS_WIDE];
+    int new_ids[REKF_MAX_OBS_WIDE];
     // H row r packed in 64 bytes: { H(r,0), H(r,1), H(r,2), H(r,col), H(r,col+1), Q(r,r), (z - zhat)(r), 0 }
     // where col = 3 + 2*landmark for the rows of state matches (rows < 2*n_state); map and pose rows have no landmark block
     double hrow[REKF_MAX_ROWS][8];
     // ---- hand-off between the multi-workgroup front kernel and k_gather / k_gain ----
     double pose_pred[5];          // x, y, theta, cos(theta), sin(theta) after Predict (mu[0..2] is committed by k_gain)
     int pose_pending;
-    int obs_kind[REKF_MAX_OBS_DEV];   // per observation: 0 map match, 1 state match, 2 new
-    int obs_idx[REKF_MAX_OBS_DEV];
+    int obs_kind[REKF_MAX_OBS_WIDE];  // per observation: 0 map match, 1 state match, 2 new
+    int obs_idx[REKF_MAX_OBS_WIDE];
     long long dbg[32];            // scratch for in-kernel timing experiments (REKF_DEBUG_TIMING builds)
 };
 
@@ -64,12 +65,19 @@ struct RekfFrontArgs {
     int K;
     int has_gps;
     float obs[2 * REKF_MAX_OBS_DEV];
+    // wide scans (K > REKF_MAX_OBS_DEV): the observations live in HBM, and k_mid takes the matched pairs [pair0, pair0 + stride)
+    // of the record k_compact_wide left in the control block -- one exact block step of the joint update per launch
+    const float *obs_ext;     // K x 2 floats on the device, or null (obs[] above holds them)
+    int pair0;                // first pair of this block step, or -1: the whole scan (k_mid compacts the match results itself)
+    int pair_stride;          // pairs per block step (32, or 30 with a pose observation: its 3 rows ride on the last step)
 };
+__host__ __device__ static inline float rekf_obs(const RekfFrontArgs &A, int i) { return A.obs_ext ? A.obs_ext[i] : A.obs[i]; }
 
 struct RekfDev {
     RekfCtl *ctl;
     double *mu;         // the current mean
     double *mu_out;     // k_mid writes the updated mean here; the host swaps mu / mu_out behind that launch
+    const double *mu_lin; // the mean the scan is linearised at (= mu, except in the later block steps of a wide scan)
     double *P;
     double *W;
     double *HPt;
@@ -102,6 +110,7 @@ __host__ __device__ static inline int rekf_strip_base(int n)
 void rekf_launch_front(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);
 void rekf_launch_front_mb(const RekfDev &d, const RekfFrontArgs &a, int n_ub, hipStream_t s);
 void rekf_launch_gather(const RekfDev &d, const RekfFrontArgs &a, int n_ub, hipStream_t s);
+void rekf_launch_compact_wide(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);
 void rekf_launch_mid(const RekfDev &d, const RekfFrontArgs &a, int n_ub, int m_ub, hipStream_t s);
 void rekf_launch_solve(const RekfDev &d, int m_ub, hipStream_t s);
 void rekf_launch_gain(const RekfDev &d, int n_ub, hipStream_t s);

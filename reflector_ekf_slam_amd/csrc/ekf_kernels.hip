@@ -382,7 +382,7 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
     const int M_ = d.M_map;
     for (int i = b; i < K; i += nb) {
         float gx, gy;
-        obs_to_global(pose[0], pose[1], pose[3], pose[4], A.obs[2 * i], A.obs[2 * i + 1], gx, gy);
+        obs_to_global(pose[0], pose[1], pose[3], pose[4], rekf_obs(A, 2 * i), rekf_obs(A, 2 * i + 1), gx, gy);
         int kind = 2, best_j = -1;
         if (M_ > 0) {                                              // cc:401-425
 #pragma clang fp contract(off)
@@ -454,9 +454,10 @@ __device__ static HPair make_hpair(const RekfDev &d, const RekfFrontArgs &A, con
 #pragma clang fp contract(off)
     HPair h;
     const double c = pose[3], s = pose[4];                      // cc:252-253
-    const double z0 = (double)A.obs[2 * local_id], z1 = (double)A.obs[2 * local_id + 1];
+    const double z0 = (double)rekf_obs(A, 2 * local_id), z1 = (double)rekf_obs(A, 2 * local_id + 1);
     double lx, ly;
-    if (is_state) { lx = d.mu[3 + 2 * global_id]; ly = d.mu[4 + 2 * global_id]; }
+    const double *mul = d.mu_lin ? d.mu_lin : d.mu;          // the linearisation point (k_mid: later block steps of a wide scan)
+    if (is_state) { lx = mul[3 + 2 * global_id]; ly = mul[4 + 2 * global_id]; }
     else { lx = (double)d.map_xy[2 * global_id]; ly = (double)d.map_xy[2 * global_id + 1]; }
     const double dx = lx - pose[0], dy = ly - pose[1];         // cc:267-268
     const double zh0 = dx * c + dy * s, zh1 = -dx * s + dy * c; // cc:269-270
@@ -1020,6 +1021,47 @@ __global__ __launch_bounds__(512) void k_gain(RekfDev d)
 }
 
 // ----------------------------------------------------------------------------
+// k_compact_wide: the ordered compaction of the per-observation match results of a WIDE scan (more than
+// REKF_MAX_OBS_DEV observations; up to REKF_MAX_OBS_WIDE) into the ReflectorMatchResult lists of the control block
+// (cc:397-453: state matches, map matches and new observations, each in increasing observation order).  k_mid then
+// takes the matched pairs a block at a time.  One workgroup, one thread per observation.
+// ----------------------------------------------------------------------------
+__global__ __launch_bounds__(REKF_MAX_OBS_WIDE) void k_compact_wide(RekfDev d, RekfFrontArgs A)
+{
+    __shared__ int s_w[3][REKF_MAX_OBS_WIDE / 64];
+    RekfCtl *ctl = d.ctl;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = A.K;
+    const int n = (d.n_known >= 0) ? d.n_known : ctl->n;
+    const int kind = (tid < K) ? ctl->obs_kind[tid] : -1;
+    const int oidx = (tid < K) ? ctl->obs_idx[tid] : -1;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const unsigned long long ms = __ballot(kind == 1), mm = __ballot(kind == 0), mn = __ballot(kind == 2);
+    if (lane == 0) { s_w[0][wave] = __popcll(ms); s_w[1][wave] = __popcll(mm); s_w[2][wave] = __popcll(mn); }
+    __syncthreads();
+    int b0 = 0, b1 = 0, b2 = 0, M = 0, Mm = 0, N2 = 0;
+#pragma unroll
+    for (int w = 0; w < REKF_MAX_OBS_WIDE / 64; ++w) {
+        if (w < wave) { b0 += s_w[0][w]; b1 += s_w[1][w]; b2 += s_w[2][w]; }
+        M += s_w[0][w]; Mm += s_w[1][w]; N2 += s_w[2][w];
+    }
+    const int room = (d.n_max - n) / 2;
+    if (N2 > room) {                                               // capacity guard (ours)
+        if (tid == 0) atomicOr(&ctl->err, REKF_FLAG_CAPACITY);
+        N2 = room;
+    }
+    if (kind == 1) { const int p = b0 + __popcll(ms & lt); ctl->state_pairs[2 * p] = tid; ctl->state_pairs[2 * p + 1] = oidx; }
+    else if (kind == 0) { const int p = b1 + __popcll(mm & lt); ctl->map_pairs[2 * p] = tid; ctl->map_pairs[2 * p + 1] = oidx; }
+    else if (kind == 2) { const int p = b2 + __popcll(mn & lt); if (p < N2) ctl->new_ids[p] = tid; }
+    if (tid == 0) {
+        const int MM = M + Mm;
+        const int m = (MM > 0) ? 2 * MM + (A.has_gps ? 3 : 0) : 0;
+        ctl->K = K; ctl->n_state = M; ctl->n_map = Mm; ctl->n_new = N2;
+        ctl->m = m; ctl->m_pad = (m + 15) & ~15;
+    }
+}
+
+// ----------------------------------------------------------------------------
 // k_mid<NBR>: gather + solve + gain in ONE launch, for scans whose innovation has at most 16 NBR rows
 // (NBR = 2: up to 16 matched observations, NBR = 4: up to 32 -- every BASELINE.json configuration).
 //
@@ -1059,7 +1101,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
     __shared__ __attribute__((aligned(16))) double s_pw[NKC][MID_ROWS];     // P(own rows, sub-block columns)
     __shared__ __attribute__((aligned(16))) double s_ph[MID_ROWS][2 * NRS]; // P(sub-block rows, own columns)
     __shared__ double s_dmu[4][MID_ROWS];
-    __shared__ int s_pair_obs[NPAIR], s_pair_id[NPAIR], s_pair_state[NPAIR], s_pcol[NPAIR], s_rank[NPAIR], s_rsrow[NRS], s_cnt[4];
+    __shared__ int s_pair_obs[NPAIR], s_pair_id[NPAIR], s_pair_state[NPAIR], s_pcol[NPAIR], s_rank[NPAIR], s_rsrow[NRS], s_cnt[5];
     double (*s_psub)[NKCP] = (double (*)[NKCP])s_big;                       // [row 2 rs + {0,1} of the sub-block][its column kc]
     double (*s_sinv)[LDS_S] = (double (*)[LDS_S])s_big;                     // S^-1, row-major
 
@@ -1090,8 +1132,42 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
     const bool pending = ctl->pose_pending != 0;
     const bool first = blockIdx.x == 0;
 
-    // ---- A: ordered compaction (obs order preserved), wave 0; workgroup 0 also writes the record for the getters
-    if (tid < 64) {
+    // ---- A: the scan's matched pairs.  Whole scan (pair0 < 0): ordered compaction of the per-observation results (obs order
+    // preserved), wave 0; workgroup 0 also writes the record for the getters.  Block step of a wide scan (pair0 >= 0): the
+    // pairs [pair0, pair0 + stride) of the record k_compact_wide wrote, state pairs first, then map pairs.
+    if (tid < 64 && A.pair0 >= 0) {
+        const int M = ctl->n_state, MMtot = M + ctl->n_map;
+        const int left = MMtot - A.pair0;
+        const int cnt = left < 0 ? 0 : (left < A.pair_stride ? left : A.pair_stride);
+        const int gpi = A.pair0 + lane;
+        const bool live = lane < cnt, st = live && gpi < M;
+        int ob = 0, id = 0;
+        if (live) {
+            const int *pp = st ? &ctl->state_pairs[2 * gpi] : &ctl->map_pairs[2 * (gpi - M)];
+            ob = pp[0]; id = pp[1];
+        }
+        int rk = 0;
+        {
+            const int key = st ? id : 0x7fffffff;
+#pragma unroll
+            for (int q = 0; q < 2 * NPAIR; ++q) {
+                const int oq = __builtin_amdgcn_readlane(key, q);
+                rk += (oq < key || (oq == key && q < lane)) ? 1 : 0;
+            }
+        }
+        int NSl = M - A.pair0;
+        NSl = NSl < 0 ? 0 : (NSl < cnt ? NSl : cnt);
+        if (live && lane < NPAIR) {
+            s_pair_obs[lane] = ob; s_pair_id[lane] = id; s_pair_state[lane] = st ? 1 : 0;
+            if (st) { s_rank[lane] = rk; s_rsrow[rk] = 3 + 2 * id; }
+        }
+        if (lane == 0) {
+            const bool gps = A.has_gps && cnt > 0 && A.pair0 + cnt == MMtot;     // the pose rows ride on the block step that holds the last pairs
+            const int m = (cnt > 0) ? 2 * cnt + (gps ? 3 : 0) : 0;
+            s_cnt[0] = cnt; s_cnt[1] = m; s_cnt[2] = (m + 15) & ~15; s_cnt[3] = NSl; s_cnt[4] = gps ? 1 : 0;
+            s_rsrow[NSl] = 0; s_rsrow[NSl + 1] = 2;
+        }
+    } else if (tid < 64) {
         const int kind = (lane < K) ? kind_raw : -1;
         const int oidx = (lane < K) ? oidx_raw : -1;
         const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -1136,7 +1212,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
         if (lane == 0) {
             const int MM = M + Mm;
             const int m = (MM > 0) ? 2 * MM + (A.has_gps ? 3 : 0) : 0;
-            s_cnt[0] = MM; s_cnt[1] = m; s_cnt[2] = (m + 15) & ~15; s_cnt[3] = M;
+            s_cnt[0] = MM; s_cnt[1] = m; s_cnt[2] = (m + 15) & ~15; s_cnt[3] = M; s_cnt[4] = (A.has_gps && MM > 0) ? 1 : 0;
             s_rsrow[M] = 0; s_rsrow[M + 1] = 2;                       // row slot M = rows {0,1}, slot M+1 = row {2}
             if (first) {
                 ctl->K = K; ctl->n_state = M; ctl->n_map = Mm; ctl->n_new = N2;
@@ -1147,6 +1223,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
     __syncthreads();
     MMARK();                                        // 0: compaction done
     const int MM = s_cnt[0], m = s_cnt[1], m_pad = s_cnt[2], NS = s_cnt[3];
+    const bool gps_rows = s_cnt[4] != 0;
     // The mean is double-buffered: other workgroups read landmark means from d.mu (phase B) while this one is already
     // done, so the updated rows go to d.mu_out and the host swaps the two pointers behind this launch.
     if (m == 0) {                                   // nothing matched: commit the predicted pose (cc:234 + Predict), no update
@@ -1225,13 +1302,29 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
             if (rr == 0) { hr[0] = h.a0[0]; hr[1] = h.a0[1]; hr[2] = h.a0[2]; hr[3] = h.b0[0]; hr[4] = h.b0[1]; hr[5] = h.q0; hr[6] = h.dz0; }
             else { hr[0] = h.a1[0]; hr[1] = h.a1[1]; hr[2] = h.a1[2]; hr[3] = h.b1[0]; hr[4] = h.b1[1]; hr[5] = h.q1; hr[6] = h.dz1; }
             if (col < 0) { hr[3] = 0; hr[4] = 0; }                          // map rows carry no landmark block (cc:285-303)
-        } else if (A.has_gps && r >= 2 * MM && r < 2 * MM + 3) {           // pose rows: unit vectors, fixed noise, wrapped yaw innovation
+        } else if (gps_rows && r >= 2 * MM && r < 2 * MM + 3) {            // pose rows: unit vectors, fixed noise, wrapped yaw innovation
 #pragma clang fp contract(off)
             const int k = r - 2 * MM;
             hr[0] = (k == 0); hr[1] = (k == 1); hr[2] = (k == 2);
             hr[5] = (k == 2) ? 0.017 * 0.017 : 0.05 * 0.05;
             const double e0 = A.gps[0] - pose[0], e1 = A.gps[1] - pose[1], e2 = yaw_innovation(A.gps[2] - pose[2]);
             hr[6] = (k == 0) ? e0 : ((k == 1) ? e1 : e2);
+        }
+        if (A.pair0 > 0 && r < m) {
+            // A later block step of a wide scan.  The joint update of y = H x + v (v uncorrelated between rows: Q is
+            // diagonal, cc:276,302, gps.cc:312-316) equals block-sequential updates with the SAME linearisation when each
+            // step's innovation is taken against the mean the earlier steps left: dz_b - H_b (mu_now - mu_lin).
+#pragma clang fp contract(off)
+            double dth = d.mu[2] - pose[2];
+            dth = atan2(sin(dth), cos(dth));
+            double corr = hr[0] * (d.mu[0] - pose[0]);
+            corr += hr[1] * (d.mu[1] - pose[1]);
+            corr += hr[2] * dth;
+            if (col >= 0) {
+                corr += hr[3] * (d.mu[col] - d.mu_lin[col]);
+                corr += hr[4] * (d.mu[col + 1] - d.mu_lin[col + 1]);
+            }
+            hr[6] = hr[6] - corr;
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) s_coef[8 * r + q] = hr[q];
@@ -2372,7 +2465,7 @@ __global__ __launch_bounds__(256, 2) void k_downdate(RekfDev d)
 // ----------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_augment(RekfDev d, RekfFrontArgs A)
 {
-    __shared__ double Gp[REKF_MAX_OBS_DEV][6];
+    __shared__ double Gp[REKF_MAX_OBS_WIDE][6];
     __shared__ double Sxi[9];
     __shared__ double RQR[4];
     RekfCtl *ctl = d.ctl;
@@ -2389,10 +2482,10 @@ __global__ __launch_bounds__(256) void k_augment(RekfDev d, RekfFrontArgs A)
         if (tid < N2) {
             const int local_id = ctl->new_ids[tid];                 // cc:338
             float gx, gy;
-            obs_to_global(x, y, c, s, A.obs[2 * local_id], A.obs[2 * local_id + 1], gx, gy);
+            obs_to_global(x, y, c, s, rekf_obs(A, 2 * local_id), rekf_obs(A, 2 * local_id + 1), gx, gy);
             d.mu[n + 2 * tid] = (double)gx;                         // cc:341-342 (float32-rounded)
             d.mu[n + 2 * tid + 1] = (double)gy;
-            const double rx = (double)A.obs[2 * local_id], ry = (double)A.obs[2 * local_id + 1];
+            const double rx = (double)rekf_obs(A, 2 * local_id), ry = (double)rekf_obs(A, 2 * local_id + 1);
             Gp[tid][0] = 1.; Gp[tid][1] = 0.; Gp[tid][2] = -rx * s - ry * c;   // cc:347
             Gp[tid][3] = 0.; Gp[tid][4] = 1.; Gp[tid][5] = rx * c - ry * s;
         }
@@ -2513,6 +2606,10 @@ void rekf_launch_front_mb(const RekfDev &d, const RekfFrontArgs &a, int n_ub, hi
 void rekf_launch_gather(const RekfDev &d, const RekfFrontArgs &a, int n_ub, hipStream_t s)
 {
     hipLaunchKernelGGL(k_gather, dim3((n_ub + 255) / 256, 32), dim3(256), 0, s, d, a);
+}
+void rekf_launch_compact_wide(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_compact_wide, dim3(1), dim3(REKF_MAX_OBS_WIDE), 0, s, d, a);
 }
 void rekf_launch_mid(const RekfDev &d, const RekfFrontArgs &a, int n_ub, int m_ub, hipStream_t s)
 {

@@ -18,7 +18,7 @@
 #include <string>
 #include <vector>
 
-static_assert(REKF_MAX_OBS == REKF_MAX_OBS_DEV, "host/device observation capacity mismatch");
+static_assert(REKF_MAX_OBS == REKF_MAX_OBS_WIDE, "host/device observation capacity mismatch");
 
 namespace {
 
@@ -48,6 +48,8 @@ struct rekf {
     std::string hip_error;
     int flags_seen = 0;        // sticky device flags already reported on stderr
     double *dev_pred;          // device scratch for k_predict_rows (4 * ld + 12 doubles)
+    float *dev_obs = nullptr;  // a wide scan's observations (REKF_MAX_OBS_WIDE x 2 floats)
+    double *dev_mu_lin = nullptr;   // the mean a wide scan is linearised at (copy taken before its first block step)
     // profiling
     bool prof_on;
     int prof_mask;
@@ -116,6 +118,7 @@ struct ProfScope {
 void fill_front_args(const rekf_t *h, RekfFrontArgs &a, double dt)
 {
     std::memset(&a, 0, sizeof(a));
+    a.pair0 = -1;
     a.dt = dt;
     a.vt[0] = h->vt[0]; a.vt[1] = h->vt[1]; a.vt[2] = h->vt[2];
     a.lin_cov = h->opt.linear_velocity_cov;
@@ -224,6 +227,8 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
         HIP_TRY(h, hipMalloc(&h->dev.y, sizeof(double) * REKF_MR_PAD));
         HIP_TRY(h, hipMalloc(&h->dev_out12, sizeof(double) * 16));
         HIP_TRY(h, hipMalloc(&h->dev_pred, sizeof(double) * (4 * (size_t)ld + 16)));
+        HIP_TRY(h, hipMalloc(&h->dev_obs, sizeof(float) * 2 * REKF_MAX_OBS_WIDE));
+        HIP_TRY(h, hipMalloc(&h->dev_mu_lin, sizeof(double) * ld));
         HIP_TRY(h, hipMalloc(&h->dev_ell, sizeof(double) * 5 * (size_t)(max_landmarks > 0 ? max_landmarks : 1)));
         HIP_TRY(h, hipHostMalloc(&h->pose_staging, sizeof(double) * 16));
         HIP_TRY(h, hipHostMalloc(&h->ctl_staging, sizeof(RekfCtl)));
@@ -269,7 +274,7 @@ void rekf_destroy(rekf_t *h)
     for (auto &s : h->prof_slots) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     (void)hipFree(h->dev.ctl); (void)hipFree(h->dev.mu); (void)hipFree(h->dev.mu_out); (void)hipFree(h->dev.P);
     (void)hipFree(h->dev.W); (void)hipFree(h->dev.HPt); (void)hipFree(h->dev.Kn); (void)hipFree(h->dev.Sinv); (void)hipFree(h->dev.Wc); (void)hipFree(h->dev.KnB); (void)hipFree(h->dev.HPtB); (void)hipFree(h->dev.y);
-    (void)hipFree(h->dev.map_xy); (void)hipFree(h->dev.map_cov); (void)hipFree(h->dev_out12); (void)hipFree(h->dev_ell); (void)hipFree(h->dev_pred);
+    (void)hipFree(h->dev.map_xy); (void)hipFree(h->dev.map_cov); (void)hipFree(h->dev_out12); (void)hipFree(h->dev_ell); (void)hipFree(h->dev_pred); (void)hipFree(h->dev_obs); (void)hipFree(h->dev_mu_lin);
     if (h->pose_staging) (void)hipHostFree(h->pose_staging);
     if (h->ctl_staging) (void)hipHostFree(h->ctl_staging);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -314,12 +319,13 @@ int rekf_handle_odometry(rekf_t *h, double t, double vx, double vy, double wz)
 int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const double *gps_pose3)
 {
     if (!h || K < 0 || (K > 0 && !xy)) return REKF_ERR_INVALID;
-    if (K > REKF_MAX_OBS || 2 * K + (gps_pose3 ? 3 : 0) > REKF_MAX_ROWS) return REKF_ERR_TOO_MANY_OBS;
+    if (K > REKF_MAX_OBS) return REKF_ERR_TOO_MANY_OBS;
+    const bool wide = K > REKF_MAX_OBS_DEV || 2 * K + (gps_pose3 ? 3 : 0) > REKF_MAX_ROWS;
     RekfFrontArgs a;
     fill_front_args(h, a, t - h->time);               // cc:232 (dt may be negative, Q8)
     a.is_obs = 1;
     a.K = K;
-    if (K > 0) std::memcpy(a.obs, xy, sizeof(float) * 2 * (size_t)K);
+    if (K > 0 && !wide) std::memcpy(a.obs, xy, sizeof(float) * 2 * (size_t)K);
     if (gps_pose3) {
         a.has_gps = 1;
         a.gps[0] = gps_pose3[0]; a.gps[1] = gps_pose3[1]; a.gps[2] = gps_pose3[2];
@@ -335,11 +341,35 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     }
     h->dev.kc_ub = round_up(2 * K + (gps_pose3 ? 3 : 0), 16);
     h->dev.n_known = h->n_exact ? h->n_ub : -1;
+    if (wide) {                                       // the scan does not fit the launch packet: stage it in HBM (copied before this call returns)
+        HIP_TRY(h, hipMemcpyAsync(h->dev_obs, xy, sizeof(float) * 2 * (size_t)K, hipMemcpyHostToDevice, h->stream));
+        a.obs_ext = h->dev_obs;
+    }
     { ProfScope ps(h, REKF_K_FRONT); rekf_launch_front_mb(h->dev, a, h->n_ub, h->stream); }
     h->time = t;                                      // cc:234
     const int n_ub = h->n_ub;
     const int m_ub = 2 * K + (gps_pose3 ? 3 : 0);
-    if (m_ub <= 64) {
+    h->dev.mu_lin = h->dev.mu;
+    if (wide) {
+        // More than 64 observations (the reference has no limit, cc:397): matched once, then the joint update runs as
+        // exact block steps of at most 32 pairs through the same kernels (k_mid explains why that is the same update).
+        // The host cannot know how many observations matched, so it enqueues ceil(K / stride) steps; a step past the
+        // last pair only carries the mean over and adds zero panels.
+        const int stride = gps_pose3 ? 30 : 32;
+        a.pair_stride = stride;
+        h->dev.kc_ub = 64;
+        rekf_launch_compact_wide(h->dev, a, h->stream);
+        HIP_TRY(h, hipMemcpyAsync(h->dev_mu_lin, h->dev.mu, sizeof(double) * (size_t)h->dev.ld, hipMemcpyDeviceToDevice, h->stream));
+        for (int p0 = 0; p0 < K; p0 += stride) {
+            a.pair0 = p0;
+            h->dev.mu_lin = h->dev_mu_lin;
+            { ProfScope ps(h, REKF_K_MID); rekf_launch_mid(h->dev, a, n_ub, 64, h->stream); }
+            std::swap(h->dev.mu, h->dev.mu_out);
+            { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_downdate(h->dev, n_ub, h->stream); }
+        }
+        a.pair0 = -1;
+        h->dev.mu_lin = h->dev.mu;
+    } else if (m_ub <= 64) {
         // the whole innovation fits one 64-wide chunk: gather + solve + gain as ONE launch (k_mid), which leaves the
         // updated mean in the other mean buffer
         { ProfScope ps(h, REKF_K_MID); rekf_launch_mid(h->dev, a, n_ub, m_ub, h->stream); }
@@ -350,8 +380,7 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         { ProfScope ps(h, REKF_K_GAIN); rekf_launch_gain(h->dev, n_ub, h->stream); }
     }
     h->last_m_ub = m_ub;
-    static const bool exp_skip_dd = std::getenv("REKF_EXP_SKIP_DD") != nullptr;      // timing experiment only: results are wrong
-    if (!exp_skip_dd) { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_downdate(h->dev, n_ub, h->stream); }
+    if (!wide) { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_downdate(h->dev, n_ub, h->stream); }
     // the state only grows: once a readback has shown it full, k_augment can never have work again
     // (k_gather drops the extra reflectors and raises REKF_FLAG_CAPACITY)
     if (!h->full) { ProfScope ps(h, REKF_K_AUGMENT); rekf_launch_augment(h->dev, a, h->stream); }

@@ -29,7 +29,7 @@ def _pair(cfg, sess, cap=None):
 def test_extension_is_loaded_and_there_is_no_fallback():
     from reflector_ekf_slam_amd import _lib
     assert os.path.exists(_lib.lib_path("librekf.so"))
-    assert _lib.rekf().rekf_abi_version() == _lib.REKF_ABI_VERSION == 2
+    assert _lib.rekf().rekf_abi_version() == _lib.REKF_ABI_VERSION == 3
 
 
 @pytest.mark.parametrize("case", ["diff_L24_obs8", "omni_L30_obs10", "map_L24_obs8", "gps_L20_obs6", "diff_L128_obs16"])
@@ -284,7 +284,7 @@ def test_too_many_observations_is_an_error_code_not_a_crash():
     from reflector_ekf_slam_amd import RekfError
     g = _simple()
     with pytest.raises(RekfError) as e:
-        g.handle_observation(0.0, np.zeros((65, 2), np.float32))
+        g.handle_observation(0.0, np.zeros((257, 2), np.float32))              # REKF_MAX_OBS = 256 = what the detectors can emit
     assert e.value.code == -3
 
 
@@ -408,6 +408,42 @@ def test_large_innovation_blocks(oracle_lib, obs_per_scan, range_max):
     st = g.GetState()
     mo, Po = o.state()
     assert np.abs(st.sigma - Po).max() < 1e-11 and g.sync_code() == 0
+
+
+@pytest.mark.parametrize("model,gps", [(synth.DIFF, False), (synth.OMNI, True)], ids=["diff", "omni_gps"])
+def test_wide_scans_more_than_64_observations(oracle_lib, model, gps):
+    """The reference loops over however many observations a scan holds (cc:397).  Beyond 64 the HIP path matches once and
+    runs the joint update as exact block steps of 32 (30 with a pose observation) pairs: same associations, same
+    posterior as the oracle's single joint update, including scans that add dozens of landmarks at once, block steps
+    without any pair left, and the pose rows riding on the last block step."""
+    cfg = synth.SessionConfig("wide_k", 420, 150, model, seed=61, pitch=2.0, jitter=0.3, speed=1.5, row_spacing=10.0,
+                              range_max=14.0)
+    sess = synth.make_session(cfg, max_scans=90)
+    g, o = _pair(cfg, sess)
+    kmax, mmax = [0], [0]
+    rng = np.random.default_rng(3)
+    first = True
+    for e in range(sess.n_events):
+        t = sess.ev_time[e]
+        if sess.ev_type[e] == synth.EV_ODOM:
+            g.handle_odometry(t, *sess.odom[e]); o.handle_odometry(t, *sess.odom[e])
+            continue
+        if first:
+            first = False
+            continue
+        ob = sess.obs_of(e)
+        gp = (sess.true_pose[e] + rng.normal(0, 0.02, 3)) if gps else None
+        g.handle_observation(t, ob, gp); o.handle_observation(t, ob, gp)
+        a, b = norm_match(g.last_match()), norm_match(o.last_match())
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)), f"association differs at t={t}"
+        kmax[0] = max(kmax[0], ob.shape[0]); mmax[0] = max(mmax[0], a[0].shape[0])
+        assert g.n == o.n
+        assert np.abs(g.mu() - o.mu()).max() < TIGHT
+    assert kmax[0] > 100 and mmax[0] > 70                  # genuinely wide: > 64 observations, > 2 block steps of matches
+    st = g.GetState()
+    mo, Po = o.state()
+    assert np.abs(st.mu - mo).max() < TIGHT and np.abs(st.sigma - Po).max() < 1e-11 and g.sync_code() == 0
+    assert np.abs(st.sigma - st.sigma.T).max() < 1e-12
 
 
 def test_odometry_only_stretches_and_interleaving(oracle_lib):
