@@ -260,7 +260,7 @@ def predict_leg(ekf, cfg, scans, steps, per_scan=5):
 
 def per_kernel_leg(ekf, scans, steps):
     ekf.profile_reset()
-    ekf.profile(True, only=["front", "mid", "gather", "solve", "gain", "downdate", "augment", "empty"])
+    ekf.profile(True, only=["front", "mid", "downdate", "augment", "empty"])
     for t, ob in scans[:steps]:
         ekf.handle_observation(t, ob)
     ekf.profile(False)

@@ -159,15 +159,15 @@ int rekf_get_flags(rekf_t *h, int *flags);
 enum {
     REKF_K_PREDICT = 0,   /* odometry-path covariance/mean propagate */
     REKF_K_FRONT = 1,     /* predict + ReflectorMatch + H rows       */
-    REKF_K_GATHER = 2,    /* W = P H^T                               */
-    REKF_K_SOLVE = 3,     /* S = H W + Q, S^-1                       */
-    REKF_K_GAIN = 4,      /* K = W S^-1, mu += K dz                  */
-    REKF_K_DOWNDATE = 5,  /* P -= K W^T  (the roofline kernel)       */
+    REKF_K_GATHER = 2,    /* (round 1's separate kernels; never recorded since k_mid fused them) */
+    REKF_K_SOLVE = 3,
+    REKF_K_GAIN = 4,
+    REKF_K_DOWNDATE = 5,  /* P -= K (H P)  (the roofline kernel)     */
     REKF_K_AUGMENT = 6,   /* new landmarks                           */
     REKF_K_EMPTY = 7,     /* an event pair around nothing: the bracket's own cost, in situ */
     REKF_K_UPDATE = 8,    /* ONE bracket around the whole HandleObservationMessage chain (per-update latency);
                            * its individual readings are kept, see rekf_profile_samples */
-    REKF_K_MID = 9,       /* gather + solve + gain fused (scans with at most 32 matched observations) */
+    REKF_K_MID = 9,       /* gather + solve + gain in one launch: W = P H^T, (H P)^T, S^-1, K = W S^-1, mu += K dz */
     REKF_K_COUNT = 10
 };
 /* When on, kernel launches are bracketed by hipEvents on the handle's stream: `on` is a bit mask
@@ -186,17 +186,10 @@ void *rekf_stream(rekf_t *h);
 /* Leading dimension (doubles) of the device covariance and its device pointer. */
 int rekf_device_layout(rekf_t *h, int *ld, int *n_max, void **P_dev, void **mu_dev);
 
-/* Measurement hook: time `reps` back-to-back launches of one kernel of the chain (REKF_K_GATHER,
- * _SOLVE, _GAIN, _DOWNDATE) on the scratch left by the last observation; the filter state is not
- * meaningful afterwards (snapshot/restore it with rekf_get_state / rekf_set_state).
- * `ablate` = 0, or bits that switch parts of k_downdate off for bottleneck analysis
- * (1 no write-back, 2 no P reads, 4 no MFMA, 8 no panel reads). */
+/* Measurement hook: time `reps` back-to-back launches of the covariance downdate (kernel = REKF_K_DOWNDATE) on the
+ * panels left by the last observation, between ONE hipEvent pair; the filter state is not meaningful afterwards
+ * (snapshot / restore it with rekf_get_state / rekf_set_state).  `ablate` must be 0 (reserved). */
 int rekf_debug_time_kernel(rekf_t *h, int kernel, int reps, int ablate, double *avg_us);
-
-/* Measurement hook: does k_downdate overlap with the single-workgroup chain of a following update?  out_us[0] =
- * k_downdate alone, [1] = (k_solve, k_gain) alone, [2] = both on two streams, microseconds per repetition.
- * The filter state is not meaningful afterwards. */
-int rekf_debug_overlap(rekf_t *h, int reps, double out_us[3]);
 
 /* Debug builds (-DREKF_DEBUG_TIMING) let kernels drop cycle counters here; zeros otherwise. */
 int rekf_debug_counters(rekf_t *h, long long out32[32]);

@@ -3,32 +3,26 @@
 // HBM layout of one filter handle (all FP64 unless noted), sized once at
 // rekf_create for n_max = 3 + 2*max_landmarks and never reallocated:
 //
-//   mu   [ld]            state mean  [x, y, theta, l0x, l0y, l1x, ...]
+//   mu, mu_out [ld]      state mean  [x, y, theta, l0x, l0y, l1x, ...], double-buffered (k_mid reads one, writes the other)
 //   P    [ld x ld]       covariance, COLUMN-major (Eigen::MatrixXd order,
 //                        reference ekf_slam_interface.h:47), leading dimension
 //                        ld = roundup(n_max, 64) so every 64x64 tile is in bounds
 //                        and every column starts on a 512-byte boundary
-//   W    [ld x MR_PAD]   W = P H^T  (column r = P * H(r,:)^T), column-major
-//   HPt  [ld x MR_PAD]   HPt = (H P)^T gathered from the ROWS of P, column-major
-//   Kn   [ld x MR_PAD]   Kn = -K = -W S^-1, column-major
-//   Sinv [MR_PAD x MR_PAD] (row-major), y[MR_PAD] = S^-1 (z - zhat)
-//   Wc   rows {0,1,2} and the matched landmarks' rows of W, compact (k_gather -> k_solve; layout at RekfDev::Wc)
-//   ctl                  RekfCtl below: n, error flags, the scan record
-//
+//   HPt  [ld x 64]       HPt = (H P)^T gathered from the ROWS of P, column-major
+//   Kn   [ld x 64]       Kn = -K = -W S^-1, column-major
 //   KnB, HPtB [4 x MR_PAD]  copies of rows nb..nb+3 of Kn / HPt, nb = 64*floor(n/64), when n mod 64 <= 4
-//                        (written by k_gain / k_gather for k_downdate's border strips)
-// Rows/columns >= n of W, HPt and Kn are kept exactly zero so that the tile kernels
-// never need bounds checks on P.
+//                        (written by k_mid for k_downdate2's border strips)
+//   ctl                  RekfCtl below: n, error flags, the scan record
+// Rows >= n of HPt and Kn are kept exactly zero, and so are their columns [m, kc_ub), so that the tile kernel
+// never needs bounds checks on P.  W = P H^T and S^-1 never leave the chip (k_mid).
 #pragma once
 #include <hip/hip_runtime.h>
 
 #define REKF_MAX_OBS_DEV 64                          // observations of a scan that travel by value with the launch and update jointly
 #define REKF_MAX_OBS_WIDE 256                        // most observations per scan at all (wide scans: staged in HBM, updated in exact block steps)
-#define REKF_MAX_ROWS 128                           // 2 per match (+3 pose rows: then K <= 62)
-#define REKF_MR_PAD 128                             // leading dimension of Sinv
+#define REKF_MR_PAD 128                             // row stride of KnB / HPtB
+#define REKF_PANEL_COLS 64                          // columns of Kn / HPt: one block step of the update has at most 64 innovation rows
 #define REKF_STRIP_MAX 4                            // border rows (n mod 64) that k_downdate handles as strips
-#define REKF_WC_PAIRS (3 * REKF_MR_PAD)              // offset of the pair section of Wc
-#define REKF_WC_DOUBLES (3 * REKF_MR_PAD + REKF_MAX_OBS_DEV * REKF_MR_PAD * 2)
 
 enum { REKF_FLAG_CAPACITY = 1, REKF_FLAG_SINGULAR = 2 };
 
@@ -43,11 +37,8 @@ struct RekfCtl {
     int state_pairs[2 * REKF_MAX_OBS_WIDE];
     int map_pairs[2 * REKF_MAX_OBS_WIDE];
     int new_ids[REKF_MAX_OBS_WIDE];
-    // H row r packed in 64 bytes: { H(r,0), H(r,1), H(r,2), H(r,col), H(r,col+1), Q(r,r), (z - zhat)(r), 0 }
-    // where col = 3 + 2*landmark for the rows of state matches (rows < 2*n_state); map and pose rows have no landmark block
-    double hrow[REKF_MAX_ROWS][8];
     // ---- hand-off between the multi-workgroup front kernel and k_gather / k_gain ----
-    double pose_pred[5];          // x, y, theta, cos(theta), sin(theta) after Predict (mu[0..2] is committed by k_gain)
+    double pose_pred[5];          // x, y, theta, cos(theta), sin(theta) after Predict (mu[0..2] is committed by k_mid)
     int pose_pending;
     int obs_kind[REKF_MAX_OBS_WIDE];  // per observation: 0 map match, 1 state match, 2 new
     int obs_idx[REKF_MAX_OBS_WIDE];
@@ -79,14 +70,9 @@ struct RekfDev {
     double *mu_out;     // k_mid writes the updated mean here; the host swaps mu / mu_out behind that launch
     const double *mu_lin; // the mean the scan is linearised at (= mu, except in the later block steps of a wide scan)
     double *P;
-    double *W;
-    double *HPt;
-    double *Kn;
-    double *Sinv;       // S^-1, ROW-major, ld REKF_MR_PAD
-    double *Wc;         // compact rows of W for k_solve: rows 0..2 as [3][MR_PAD], then per state pair p the two
-                        // landmark rows interleaved, [p][MR_PAD][2]  (REKF_WC_DOUBLES doubles)
-    double *y;
-    double *KnB, *HPtB; // rows nb..nb+3 of Kn / HPt, [REKF_STRIP_MAX][MR_PAD] row-major (k_downdate border strips)
+    double *HPt;        // (H P)^T, column-major, REKF_PANEL_COLS columns
+    double *Kn;         // -K, column-major, REKF_PANEL_COLS columns
+    double *KnB, *HPtB; // rows nb..nb+3 of Kn / HPt, [REKF_STRIP_MAX][MR_PAD] row-major (k_downdate2 border strips)
     float *map_xy;      // M_map x 2
     double *map_cov;    // M_map x 4 row-major
     int M_map;
@@ -109,11 +95,8 @@ __host__ __device__ static inline int rekf_strip_base(int n)
 // launch wrappers (ekf_kernels.hip)
 void rekf_launch_front(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);
 void rekf_launch_front_mb(const RekfDev &d, const RekfFrontArgs &a, int n_ub, hipStream_t s);
-void rekf_launch_gather(const RekfDev &d, const RekfFrontArgs &a, int n_ub, hipStream_t s);
 void rekf_launch_compact_wide(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);
 void rekf_launch_mid(const RekfDev &d, const RekfFrontArgs &a, int n_ub, int m_ub, hipStream_t s);
-void rekf_launch_solve(const RekfDev &d, int m_ub, hipStream_t s);
-void rekf_launch_gain(const RekfDev &d, int n_ub, hipStream_t s);
 void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s);
 void rekf_launch_augment(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);
 void rekf_launch_ellipses(const RekfDev &d, double *out5, int cap, hipStream_t s);

@@ -1,16 +1,20 @@
 // ekf_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the EKF hot path.
 //
-// One HandleObservationMessage (reference reflector_ekf_slam.cc:229-368) is the
-// kernel chain   front -> gather -> solve -> gain -> downdate -> augment
-// on the handle's stream, with every size (n, m, match lists) resident in HBM
-// (RekfCtl) so the host never waits for the device between scans.
+// One HandleObservationMessage (reference reflector_ekf_slam.cc:229-368) is the kernel chain
+//     front_mb -> mid -> downdate2 (-> augment)
+// on the handle's stream, with every size (n, m, match lists) resident in HBM (RekfCtl) so the host never waits for
+// the device between scans.
 //
-//   k_front     predict (cc:154-206) + ReflectorMatch (cc:370-455) + H rows/z/zhat (cc:248-304)
-//   k_gather    W = P H^T and (H P)^T using the <=5 structural non-zeros of each H row (cc:305,308)
-//   k_solve     S = H W + Q, S^-1 by in-register Gauss-Jordan, y = S^-1 (z - zhat) (cc:305)
-//   k_gain      Kn = -W S^-1 (FP64 MFMA), mu += W y, theta wrap (cc:306-307)
-//   k_downdate  P += Kn (H P) : the FP64 MFMA, LDS-tiled rank-m downdate (cc:308) -- the roofline kernel
+//   k_front_mb  predict (cc:154-206) + ReflectorMatch (cc:370-455), one observation per workgroup
+//   k_mid       ordered compaction, H rows / z - zhat (cc:248-304); W = P H^T and (H P)^T from the <= 5 structural
+//               non-zeros of each H row (cc:305,308); S = H W + Q and S^-1 by in-register blocked Gauss-Jordan;
+//               K = W S^-1 (FP64 MFMA), mu += K (z - zhat), theta wrap (cc:305-307) -- one launch, the 64 x 64
+//               inverse redone by every workgroup rather than handed around
+//   k_downdate2 P += Kn (H P): the FP64 MFMA, LDS-tiled rank-m downdate (cc:308) -- the roofline kernel
 //   k_augment   new landmark means and covariance blocks (cc:311-364)
+//   k_front     predict alone (odometry messages, empty scans)
+// Scans with more than 32 matched pairs (or more than 64 observations: k_compact_wide) run the joint update as exact
+// block steps, k_mid + k_downdate2 per 32 pairs (see k_mid).
 //
 // Like the reference, P is never symmetrised: W = P H^T is gathered from the
 // COLUMNS of P and HP^T from its ROWS.  (Taking H P := (P H^T)^T looks harmless
@@ -18,10 +22,11 @@
 // A + (P G) A (G P) instead of the reference's contraction (I - P G) A (I - G P),
 // G = H^T S^-1 H, and grows exponentially -- measured 1e-17 -> 1e-5 in 300 scans.)
 //
-// Deliberate, stated deviation from the literal Eigen expressions (FP64 round-off
+// Deliberate, stated deviations from the literal Eigen expressions (FP64 round-off
 // level, far inside the 1e-5 m parity bar):
 //   * S^-1 by Gauss-Jordan without pivoting (S = H P H^T + Q is SPD) instead of
-//     Eigen's partial-pivot LU.
+//     Eigen's partial-pivot LU;
+//   * more than 32 matched pairs: block-sequential form of the same joint update.
 #include "ekf_dev.h"
 
 #include <type_traits>
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(1024) void k_front(RekfDev d, RekfFrontArgs A)
 // committed by k_gain together with the update -- then takes a 1/FRONT_MB slice of the
 // covariance predict and whole observations of ReflectorMatch (all 16 waves sweep disjoint
 // landmark slices, block-wide literal arg-min).  The ordered compaction and the H rows (the tail of
-// k_front) are resolved by k_gather from the per-observation results left in ctl->obs_kind/obs_idx.
+// k_front) are resolved by k_mid from the per-observation results left in ctl->obs_kind/obs_idx.
 // ----------------------------------------------------------------------------
 #define FRONT_MB 32
 
@@ -439,11 +444,8 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
 }
 
 // ----------------------------------------------------------------------------
-// k_gather: W(c, r) = sum_k P(c,k) H(r,k)  (columns of P: coalesced) and
-// HPt(c, r) = (H P)(r, c) = sum_k H(r,k) P(k,c)  (rows of P: each thread walks
-// its own column c); thread per state index c, blockIdx.y strides over row pairs.
-// ----------------------------------------------------------------------------
 // H row pair p of the scan (cc:248-304, gps.cc:305-332): coefficients of rows 2p, 2p+1.
+// ----------------------------------------------------------------------------
 struct HPair {
     double a0[3], a1[3], b0[2], b1[2], dz0, dz1, q0, q1;
     int col;
@@ -471,199 +473,20 @@ __device__ static HPair make_hpair(const RekfDev &d, const RekfFrontArgs &A, con
     return h;
 }
 
-// k_gather also resolves the scan record: every workgroup redoes the (tiny) ordered compaction of
-// the per-observation match results left by k_front_mb and derives the H rows it needs on the fly;
-// workgroup (0,0) additionally writes the full record (match lists, all H rows, z - zhat, m) for
-// k_solve / k_gain / the getters.  This replaces a separate one-wave kernel (4 us of launch floor).
-__global__ __launch_bounds__(256) void k_gather(RekfDev d, RekfFrontArgs A)
-{
-    __shared__ int s_pair_obs[REKF_MAX_OBS_DEV], s_pair_id[REKF_MAX_OBS_DEV], s_pair_state[REKF_MAX_OBS_DEV];
-    __shared__ int s_cnt[4];
-    __shared__ int s_slot[256], s_dup[256];
-    RekfCtl *ctl = d.ctl;
-    const int tid = threadIdx.x;
-    s_slot[tid] = 0x7fffffff; s_dup[tid] = 0;
-    const int n = ctl->n;
-    const int K = A.K;
-    const size_t ld = (size_t)d.ld;
-    const int c = blockIdx.x * 256 + tid;
-    const bool valid = c < n && c < d.ld;
-    const double *__restrict__ P = d.P;
-    double *__restrict__ W = d.W;
-    double *__restrict__ HPt = d.HPt;
-    const int cc = valid ? c : 0;
-    const double *__restrict__ Pc = P + (size_t)cc * ld;               // column c (rows of P for H P)
-    // operands that do not depend on the record go in flight first
-    const double p0 = P[cc], p1 = P[cc + ld], p2 = P[cc + 2 * ld];
-    const double q0 = Pc[0], q1 = Pc[1], q2 = Pc[2];
-    const double pose[5] = {ctl->pose_pred[0], ctl->pose_pred[1], ctl->pose_pred[2], ctl->pose_pred[3], ctl->pose_pred[4]};
-
-    // ---- ordered compaction (obs order preserved), wave 0
-    if (tid < 64) {
-        const int lane = tid;
-        const int kind = (lane < K) ? ctl->obs_kind[lane] : -1;
-        const int oidx = (lane < K) ? ctl->obs_idx[lane] : -1;
-        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        const unsigned long long ms = __ballot(kind == 1);
-        const unsigned long long mm = __ballot(kind == 0);
-        const unsigned long long mn = __ballot(kind == 2);
-        const int M = __popcll(ms), Mm = __popcll(mm);
-        int N2 = __popcll(mn);
-        const int room = (d.n_max - n) / 2;
-        const bool first = blockIdx.x == 0 && blockIdx.y == 0;
-        if (N2 > room) {                                               // capacity guard (ours)
-            if (first && lane == 0) atomicOr(&ctl->err, REKF_FLAG_CAPACITY);
-            N2 = room;
-        }
-        if (kind == 1) {
-            const int p = __popcll(ms & lt);
-            s_pair_obs[p] = lane; s_pair_id[p] = oidx; s_pair_state[p] = 1;
-            if (first) { ctl->state_pairs[2 * p] = lane; ctl->state_pairs[2 * p + 1] = oidx; }
-        } else if (kind == 0) {
-            const int p = __popcll(mm & lt);
-            s_pair_obs[M + p] = lane; s_pair_id[M + p] = oidx; s_pair_state[M + p] = 0;
-            if (first) { ctl->map_pairs[2 * p] = lane; ctl->map_pairs[2 * p + 1] = oidx; }
-        } else if (kind == 2) {
-            const int p = __popcll(mn & lt);
-            if (first && p < N2) ctl->new_ids[p] = lane;
-        }
-        if (lane == 0) {
-            const int MM = M + Mm;
-            const int m = (MM > 0) ? 2 * MM + (A.has_gps ? 3 : 0) : 0;
-            s_cnt[0] = MM; s_cnt[1] = m; s_cnt[2] = (m + 15) & ~15;
-            if (first) {
-                ctl->K = K; ctl->n_state = M; ctl->n_map = Mm; ctl->n_new = N2;
-                ctl->m = m; ctl->m_pad = (m + 15) & ~15;
-            }
-        }
-    }
-    __syncthreads();
-    const int MM = s_cnt[0], m = s_cnt[1], m_pad = s_cnt[2];
-    if (m == 0) return;
-
-    // ---- workgroup (0,0): the full record for the kernels downstream
-    if (blockIdx.x == 0 && blockIdx.y == 0) {
-        if (tid < MM) {
-            const HPair h = make_hpair(d, A, pose, s_pair_obs[tid], s_pair_id[tid], s_pair_state[tid]);
-            double *h0 = ctl->hrow[2 * tid], *h1 = ctl->hrow[2 * tid + 1];
-            h0[0] = h.a0[0]; h0[1] = h.a0[1]; h0[2] = h.a0[2]; h0[3] = h.b0[0]; h0[4] = h.b0[1]; h0[5] = h.q0; h0[6] = h.dz0; h0[7] = 0;
-            h1[0] = h.a1[0]; h1[1] = h.a1[1]; h1[2] = h.a1[2]; h1[3] = h.b1[0]; h1[4] = h.b1[1]; h1[5] = h.q1; h1[6] = h.dz1; h1[7] = 0;
-        }
-        if (tid < 3 && A.has_gps && MM > 0) {                          // gps.cc:305-332, pose row k = tid
-#pragma clang fp contract(off)
-            double *hr = ctl->hrow[2 * MM + tid];
-            hr[0] = (tid == 0); hr[1] = (tid == 1); hr[2] = (tid == 2); hr[3] = 0; hr[4] = 0;
-            hr[5] = (tid == 2) ? 0.017 * 0.017 : 0.05 * 0.05;
-            const double e0 = A.gps[0] - pose[0], e1 = A.gps[1] - pose[1], e2 = yaw_innovation(A.gps[2] - pose[2]);
-            hr[6] = (tid == 0) ? e0 : ((tid == 1) ? e1 : e2);             // no dynamic indexing of A / pose
-            hr[7] = 0;
-        }
-    }
-    // rows of W that S = H W needs ({0,1,2} and the matched landmarks' rows) also go to the compact,
-    // row-major copy Wc (slot 3+2p+{0,1} for state pair p) that k_solve reads coalesced
-    // (s_slot[row - chunk base] = smallest slot of a state pair on that row, filled by the pair threads;
-    // a collision = two observations matched to one landmark, which the reference allows: s_dup)
-    if (tid < MM && s_pair_state[tid]) {
-        const int cc0 = 3 + 2 * s_pair_id[tid] - (int)blockIdx.x * 256;
-#pragma unroll
-        for (int dc = 0; dc < 2; ++dc) {
-            if (cc0 + dc >= 0 && cc0 + dc < 256) {
-                const int old = atomicMin(&s_slot[cc0 + dc], 3 + 2 * tid + dc);
-                if (old != 0x7fffffff) s_dup[cc0 + dc] = 1;
-            }
-        }
-    }
-    __syncthreads();
-    if (c >= d.ld) return;
-    int slot = (valid && c < 3) ? c : -1;
-    if (valid && c >= 3 && s_slot[tid] != 0x7fffffff) slot = s_slot[tid];
-    const bool dup = s_dup[tid] != 0;
-    double *__restrict__ Wc = d.Wc;
-    const int strip_nb = rekf_strip_base(n);          // k_downdate's border strips want rows nb.. of HPt contiguous
-
-    // ---- W(c, r) = sum_k P(c,k) H(r,k)  and  HPt(c, r) = sum_k H(r,k) P(k,c) for this workgroup's row pairs
-    const int fill = (d.kc_ub > m_pad) ? d.kc_ub : m_pad;   // columns [m, fill) of W / HPt are written as zeros
-    for (int pr = blockIdx.y; pr < fill / 2; pr += gridDim.y) {
-        const int r0 = 2 * pr;
-        double ha[2][3] = {{0, 0, 0}, {0, 0, 0}}, hb[2][2] = {{0, 0}, {0, 0}};
-        int col = -1;
-        if (pr < MM) {
-            const HPair h = make_hpair(d, A, pose, s_pair_obs[pr], s_pair_id[pr], s_pair_state[pr]);
-            for (int k = 0; k < 3; ++k) { ha[0][k] = h.a0[k]; ha[1][k] = h.a1[k]; }
-            hb[0][0] = h.b0[0]; hb[0][1] = h.b0[1]; hb[1][0] = h.b1[0]; hb[1][1] = h.b1[1];
-            col = h.col;
-        } else if (A.has_gps) {                                        // pose rows: unit vectors e_k
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const int k = r0 + rr - 2 * MM;                            // no dynamic register indexing
-                ha[rr][0] = (k == 0) ? 1.0 : 0.0;
-                ha[rr][1] = (k == 1) ? 1.0 : 0.0;
-                ha[rr][2] = (k == 2) ? 1.0 : 0.0;
-            }
-        }
-        const int cl = (col >= 0) ? col : 0;
-        const double pl0 = P[cc + (size_t)cl * ld], pl1 = P[cc + (size_t)(cl + 1) * ld];
-        const double ql0 = Pc[cl], ql1 = Pc[cl + 1];
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int r = r0 + rr;
-            double v = 0, u = 0;
-            if (valid && r < m) {
-                const double h0 = ha[rr][0], h1 = ha[rr][1], h2 = ha[rr][2];
-                v = p0 * h0; v += p1 * h1; v += p2 * h2;
-                u = h0 * q0; u += h1 * q1; u += h2 * q2;
-                if (col >= 0) {
-                    const double g0 = hb[rr][0], g1 = hb[rr][1];
-                    v += pl0 * g0; v += pl1 * g1;
-                    u += g0 * ql0; u += g1 * ql1;
-                }
-            }
-            W[c + (size_t)r * ld] = v;
-            HPt[c + (size_t)r * ld] = u;
-            if (strip_nb >= 0 && c >= strip_nb && c < strip_nb + REKF_STRIP_MAX) d.HPtB[(c - strip_nb) * REKF_MR_PAD + r] = u;
-            if (slot >= 0) {
-                if (slot < 3) Wc[slot * REKF_MR_PAD + r] = v;
-                else Wc[REKF_WC_PAIRS + ((size_t)((slot - 3) >> 1) * REKF_MR_PAD + r) * 2 + ((slot - 3) & 1)] = v;
-                if (dup) {
-                    for (int p = (slot - 3) / 2 + 1; p < MM && s_pair_state[p]; ++p) {
-                        const int dc = c - (3 + 2 * s_pair_id[p]);
-                        if (dc == 0 || dc == 1) Wc[REKF_WC_PAIRS + ((size_t)p * REKF_MR_PAD + r) * 2 + dc] = v;
-                    }
-                }
-            }
-        }
-    }
-}
-
 // ----------------------------------------------------------------------------
-// k_solve: S = H W + Q (m x m), S^-1 by block Gauss-Jordan, y = S^-1 dz.
+// The m x m solve (inside k_mid): S^-1 by blocked Gauss-Jordan.
 //
-// The inverse is a chain of m sequential pivots, so the kernel is latency-bound;
-// the design minimises what sits on that chain:
-//   * S lives in registers as 16x16 blocks in the v_mfma_f64_16x16x4_f64 C/D
-//     layout (lane (g,c) = (lane>>4, lane&15), register r <-> element (g+4r, c));
-//     wave w owns block COLUMN w (one wave per SIMD for m <= 64).
-//   * Block step K: wave K publishes its column blocks S(i,K) to LDS, inverts
-//     the diagonal block entirely in-wave (2x2 pivots, 8 steps, operands
-//     broadcast with v_readlane / ds_bpermute: no LDS round trip, no barrier)
-//     and publishes D^-1: ONE LDS barrier per block step.  Every other wave j
-//     then forms its block of the pivot row, R = D^-1 S(K,j), and applies
-//     S(i,j) -= S(i,K) R with MFMA; wave K+1 does block (K+1,K+1) first and goes
-//     straight into the next leaf, so the chain per step is leaf + 2 block
-//     products -- the other 4*NBR-2 products run in the shadow of the leaf.
-//     A block in C layout is directly an MFMA B operand; the A operand is the
-//     C layout of the transposed block, read with transposed addressing from
-//     the row-major 16x17 patch the owner published.
-//   * S is built from Wc, the compact copy of the rows {0,1,2, matched
-//     landmark rows} of W that k_gather emits (coalesced, one round trip).
-// S^-1 is stored ROW-major (ld REKF_MR_PAD): coalesced here and in k_gain.
+// The inverse is a chain of m sequential pivots, so it is latency-bound; the design minimises what sits on that chain:
+//   * S lives in registers as 16x16 blocks in the v_mfma_f64_16x16x4_f64 C/D layout (lane (g,c) = (lane>>4, lane&15),
+//     register r <-> element (g+4r, c)); wave w owns block COLUMN w (one wave per SIMD for m <= 64).
+//   * Block step K: wave K publishes its column blocks S(i,K) to LDS, inverts the diagonal block entirely in-wave (2x2
+//     pivots, 8 steps, pivot rows / columns exchanged through a wave-private LDS scratch, no barrier) and publishes
+//     D^-1: ONE LDS barrier per block step.  Every other wave j then forms its block of the pivot row,
+//     R = D^-1 S(K,j), and applies S(i,j) -= S(i,K) R with MFMA; wave K+1 does block (K+1,K+1) first and goes straight
+//     into the next leaf, so the chain per step is leaf + 2 block products -- the other products run in the shadow of
+//     the leaf.  A block in C layout is directly an MFMA B operand; the A operand is the C layout of the transposed
+//     block, read with transposed addressing from the row-major 16x17 patch the owner published.
 // ----------------------------------------------------------------------------
-__device__ static inline double bperm_f64(double v, int byte_addr)
-{
-    const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v));
-    const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
 __device__ static inline void lds_barrier()
 {
     // LDS-only workgroup barrier: does not wait for outstanding global memory traffic (vmcnt)
@@ -853,173 +676,6 @@ __device__ static inline bool gj_invert_blocks(v4d (&S)[NBR], int nbr, int w, in
     return bad;
 }
 
-template <int NBR>
-__global__ __launch_bounds__(64 * NBR) void k_solve(RekfDev d)
-{
-    __shared__ double s_col[2][NBR + 1][REKF_PATCH];   // pivot column blocks S(i,K), slot NBR = D^-1; ping-pong over block steps
-    __shared__ double s_leaf[NBR][REKF_LEAF_SCRATCH];  // leaf exchange scratch, private per wave
-    __shared__ __attribute__((aligned(16))) double s_coef[8 * REKF_MAX_ROWS];   // ctl->hrow staged: 64-byte packed H rows
-    RekfCtl *ctl = d.ctl;
-    const int m = ctl->m;
-    if (m == 0) return;
-    const int nbr = ctl->m_pad >> 4;                 // live blocks per side (<= NBR: the host sized the launch from 2K+3)
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g = lane >> 4, c = lane & 15;
-#ifdef REKF_DEBUG_TIMING
-    const long long tsc = pinned_clock();
-#endif
-    v4d S[NBR];                                      // S[bi] = block (bi, w)
-    const int j = 16 * w + c;                        // this lane's column of S
-    {
-        // every global load below depends only on kernel arguments: ONE memory round trip
-        const int rows_state = 2 * ctl->n_state;     // rows [0, rows_state) carry landmark columns
-        const double *__restrict__ Wc = d.Wc;
-        const v2d stage = ((const v2d *)&ctl->hrow[0][0])[threadIdx.x];     // 16*nbr rows x 64 B over 64*nbr threads
-        const double w0 = Wc[j], w1 = Wc[REKF_MR_PAD + j], w2 = Wc[2 * REKF_MR_PAD + j];
-        v2d wl[NBR][4];
-#pragma unroll
-        for (int bi = 0; bi < NBR; ++bi) {
-            if (bi < nbr) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int pair = (16 * bi + g + 4 * r) >> 1;
-                    wl[bi][r] = *(const v2d *)(Wc + REKF_WC_PAIRS + ((size_t)pair * REKF_MR_PAD + j) * 2);
-                }
-            }
-        }
-        ((v2d *)s_coef)[threadIdx.x] = stage;
-        __syncthreads();
-#pragma unroll
-        for (int bi = 0; bi < NBR; ++bi) {
-            if (bi < nbr) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = 16 * bi + g + 4 * r;
-                    const v2d ha01 = *(const v2d *)(s_coef + 8 * i), ha2b0 = *(const v2d *)(s_coef + 8 * i + 2);
-                    const v2d b1q = *(const v2d *)(s_coef + 8 * i + 4);
-                    double v = ha01.x * w0;
-                    v += ha01.y * w1;
-                    v += ha2b0.x * w2;
-                    if (i < rows_state) { v += ha2b0.y * wl[bi][r].x; v += b1q.x * wl[bi][r].y; }
-                    if (i == j) v += b1q.y;
-                    if (i >= m || j >= m) v = (i == j) ? 1.0 : 0.0;
-                    S[bi][r] = v;
-                }
-            }
-        }
-    }
-    bool bad = false;
-#ifdef REKF_DEBUG_TIMING
-    const long long t0c = pinned_clock(), t0w = wall_clock64();
-#endif
-    bad = gj_invert_blocks<NBR>(S, nbr, w, g, c, s_col, s_leaf[w]);
-    if (w >= nbr) return;                            // no block column: this wave only kept the barriers company
-#ifdef REKF_DEBUG_TIMING
-    const long long t1c = pinned_clock();
-    if (threadIdx.x == 0) { ctl->dbg[0] = t1c - t0c; ctl->dbg[1] = wall_clock64() - t0w; ctl->dbg[2] = t0c - tsc; }
-#endif
-    if (bad && lane == 0) atomicOr(&ctl->err, REKF_FLAG_SINGULAR);
-    // S^-1 out, row-major (pad rows/cols are the identity).  y: this wave holds COLUMNS of S^-1, so it
-    // forms y(j) = sum_i Sinv(i,j) dz(i) = (S^-T dz)(j) -- equal to S^-1 dz up to the rounding-level
-    // asymmetry of the computed inverse -- with 4 FMAs per block and two cross-group adds, no LDS.
-    double acc = 0.0;
-#pragma unroll
-    for (int bi = 0; bi < NBR; ++bi) {
-        if (bi < nbr) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * bi + g + 4 * r;
-                d.Sinv[(size_t)i * REKF_MR_PAD + j] = S[bi][r];
-                acc += S[bi][r] * ((i < m) ? s_coef[8 * i + 6] : 0.0);
-            }
-        }
-    }
-    acc += bperm_f64(acc, ((lane ^ 16) << 2));
-    acc += bperm_f64(acc, ((lane ^ 32) << 2));
-    if (g == 0) d.y[j] = (j < m) ? acc : 0.0;
-#ifdef REKF_DEBUG_TIMING
-    if (threadIdx.x == 0) ctl->dbg[3] = pinned_clock() - t1c;
-#endif
-}
-
-// ----------------------------------------------------------------------------
-// k_gain: Kn(i, j) = -sum_k W(i,k) Sinv(k,j) with v_mfma_f64_16x16x4_f64,
-// computed transposed (MFMA rows <-> j, MFMA cols <-> i) so that the 16 lanes
-// of a row group store 128 contiguous bytes of a Kn column.
-// One workgroup = 16 state rows, one wave per 16-column tile of Kn; one more
-// wave computes the mean increment with the same instruction by using y as an
-// extra "column" of S^-1:  dmu(i) = sum_k W(i,k) y(k)  (cc:306), theta wrap (cc:307).
-// All operands of a 16-k-step chunk are loaded before the MFMA chain starts.
-// ----------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void k_gain(RekfDev d)
-{
-    RekfCtl *ctl = d.ctl;
-    const int m = ctl->m;
-    const bool pending = ctl->pose_pending != 0;        // multi-workgroup front: mu[0..2] still holds the old pose
-    if (m == 0) {
-        if (pending && blockIdx.x == 0 && threadIdx.x < 3) d.mu[threadIdx.x] = ctl->pose_pred[threadIdx.x];
-        if (pending && blockIdx.x == 0 && threadIdx.x == 0) ctl->pose_pending = 0;
-        return;
-    }
-    const int n = ctl->n, m_pad = ctl->m_pad;
-    const int i0 = blockIdx.x * 16;
-    if (i0 >= n) return;
-    const size_t ld = (size_t)d.ld;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int idx = lane & 15, kq = lane >> 4;
-    const int ntile = m_pad / 16;
-    const int strip_nb = rekf_strip_base(n);          // k_downdate's border strips want rows nb.. of Kn contiguous
-    const double *__restrict__ Wp = d.W + (size_t)(i0 + idx);
-    for (int jt = ntile + 1 + wave; jt <= d.kc_ub / 16; jt += 8) {           // columns [m_pad, kc_ub) of Kn: zeros (k_downdate2<kc_ub>)
-        const int j0 = 16 * (jt - 1);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = j0 + kq + 4 * r;
-            d.Kn[(i0 + idx) + (size_t)j * ld] = 0.0;
-            if (strip_nb >= 0 && i0 + idx >= strip_nb && i0 + idx < strip_nb + REKF_STRIP_MAX) d.KnB[(i0 + idx - strip_nb) * REKF_MR_PAD + j] = 0.0;
-        }
-    }
-    for (int jt = wave; jt <= ntile; jt += 8) {
-        const bool is_mu = jt == ntile;
-        const int j0 = 16 * jt;
-        v4d acc = {0, 0, 0, 0};
-        for (int kc = 0; kc < m_pad / 4; kc += 16) {
-            double a[16], b[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int kk = kc + q;
-                const int k = 4 * kk + kq;
-                const bool live = kk < m_pad / 4;
-                // A[j][k] = Sinv(k, j)   (mu tile: row 0 = y(k), other rows 0)
-                if (is_mu) a[q] = (live && idx == 0) ? d.y[k] : 0.0;
-                else a[q] = live ? d.Sinv[(size_t)k * REKF_MR_PAD + j0 + idx] : 0.0;   // row-major S^-1
-                b[q] = live ? Wp[(size_t)k * ld] : 0.0;                     // B[k][i] = W(i, k)
-            }
-#pragma unroll
-            for (int q = 0; q < 16; ++q)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
-        }
-        if (!is_mu) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int j = j0 + kq + 4 * r;                               // D row
-                d.Kn[(i0 + idx) + (size_t)j * ld] = -acc[r];                 // D col = idx
-                if (strip_nb >= 0 && i0 + idx >= strip_nb && i0 + idx < strip_nb + REKF_STRIP_MAX)
-                    d.KnB[(i0 + idx - strip_nb) * REKF_MR_PAD + j] = -acc[r];
-            }
-        } else if (kq == 0) {                                                // D row 0 = dmu
-            const int i = i0 + idx;
-            if (i < n) {
-                const double base = (pending && i < 3) ? ctl->pose_pred[i] : d.mu[i];
-                double v = base + acc[0];
-                if (i == 2) v = atan2(sin(v), cos(v));
-                d.mu[i] = v;
-                if (i == 0) ctl->pose_pending = 0;
-            }
-        }
-    }
-}
-
 // ----------------------------------------------------------------------------
 // k_compact_wide: the ordered compaction of the per-observation match results of a WIDE scan (more than
 // REKF_MAX_OBS_DEV observations; up to REKF_MAX_OBS_WIDE) into the ReflectorMatchResult lists of the control block
@@ -1062,8 +718,9 @@ __global__ __launch_bounds__(REKF_MAX_OBS_WIDE) void k_compact_wide(RekfDev d, R
 }
 
 // ----------------------------------------------------------------------------
-// k_mid<NBR>: gather + solve + gain in ONE launch, for scans whose innovation has at most 16 NBR rows
-// (NBR = 2: up to 16 matched observations, NBR = 4: up to 32 -- every BASELINE.json configuration).
+// k_mid<NBR>: gather + solve + gain in ONE launch, for at most 16 NBR innovation rows per pass (NBR = 2: up to 16
+// matched observations, NBR = 4: up to 32 -- every BASELINE.json configuration; scans with more run several passes,
+// see "block step" below).
 //
 // Round 1 ran k_gather -> k_solve -> k_gain: 24.4 us of kernels at C3 plus two kernel boundaries, of which the
 // single-workgroup solve alone was 12.9 us while 255 CUs idled.  The inverse is a LATENCY chain, not work: here
@@ -1585,475 +1242,24 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
 }
 
 // ----------------------------------------------------------------------------
-// k_downdate: P(i,j) += sum_k Kn(i,k) HPt(j,k)   (P <- P - K (H P), cc:308)
+// The rank-m downdate  P(i,j) += sum_k Kn(i,k) HPt(j,k)   (P <- P - K (H P), cc:308): k_downdate2 below.
+// 64 x 64 tiles of P; per tile the Kn row panel and the HPt row panel sit in LDS ([k][64] doubles each) and every
+// wave owns a 32 x 32 sub-tile = 2 x 2 v_mfma_f64_16x16x4_f64 accumulators.  The MFMA is evaluated transposed (MFMA
+// M <-> j, N <-> i) and MFMA tile t of a pair covers the interleaved rows i = base + 2 idx + t, so that each lane holds
+// two adjacent rows of one column: 16-byte global accesses, 256 contiguous bytes per 16 lanes, and ONE ds_read_b128 per
+// operand per k-step feeds both tiles, conflict-free on the linear [k][64] LDS image.
 //
-// Persistent, software-pipelined rank-m downdate.  One 256-thread workgroup
-// (4 waves, one per SIMD) per CU walks a contiguous range of 64x64 tiles of P.
-// Per tile the Kn row panel and the HPt row panel are staged in LDS ([k][64]
-// doubles each, 32 KiB + 32 KiB, double-buffered = 128 KiB) and every wave owns
-// a 32x32 sub-tile = 2x2 v_mfma_f64_16x16x4_f64 accumulators initialised with P
-// itself, so P is read once and written once.  While the 64 MFMAs of tile t run
-// (4096 cycles per SIMD) the panels and the P block of tile t+1 are already in
-// flight into registers, and the stores of tile t drain under tile t+1: the
-// only synchronisation is ONE LDS-only barrier per tile.
-//
-// The MFMA is evaluated transposed (MFMA M <-> j, N <-> i) and MFMA tile t of a
-// pair covers the interleaved rows i = base + 2*idx + t, so that each lane
-// holds two adjacent rows of one column: 16-byte global accesses, 256 contiguous
-// bytes per 16 lanes, and ONE ds_read_b128 per operand per k-step feeds both
-// tiles, conflict-free on the linear [k][64] LDS image.
-// m_pad > 64 (more than 32 observations) runs as several 64-wide k-chunks
-// through the same pipeline.
+// Border strips.  When n is a few rows past a multiple of the tile size (n = 3 + 2L with L a multiple of 32: three
+// rows), a last tile row/column would be 95 % padding yet cost a full tile of traffic and MFMA time -- and with
+// 33^2 = 1089 tiles on 256 workgroups, a FIFTH tile for a quarter of them.  Instead the tile grid covers [0, nb)^2,
+// nb = 64 floor(n / 64), and the strips P(nb.., :) and P(:, nb..) ride on the diagonal tiles: the workgroup that has the
+// panels Kn(I,:) and HPt(I,:) of tile (I,I) in LDS also updates P(64I.., nb..) and P(nb.., 64I..) with plain FMAs
+// against the border rows of Kn / HPt (KnB / HPtB, staged in s_border).
 // ----------------------------------------------------------------------------
 #define DT 64
-#define DKC 64
-#define DD_STG (DKC * 32 / 256)      // 16-byte panel pieces per thread per panel
-#define DD_NBUF 2                    // LDS panel buffers per workgroup: 128 KiB, one workgroup per CU, one barrier per tile
-                                     // (a single-buffer variant, 64 KiB and two workgroups per CU, measured 24.2 us and was dropped)
 #define DD_WG_PER_CU 1
-
-__device__ static inline void dd_lds_barrier() { lds_barrier(); }
-
-// Border strips.  When n is a few rows past a multiple of the tile size (n = 3 + 2L with L a multiple of
-// 32: three rows), a last tile row/column would be 95 % padding yet cost a full tile of traffic and MFMA
-// time -- and with 33^2 = 1089 tiles on 256 workgroups, a FIFTH tile for a quarter of them.  Instead the
-// tile grid covers [0, nb)^2, nb = 64*floor(n/64), and the strips P(nb.., :) and P(:, nb..) ride on the
-// diagonal tiles: the workgroup that has the panels Kn(I,:) and HPt(I,:) of tile (I,I) in LDS also updates
-// P(64I.., nb..) and P(nb.., 64I..) with plain FMAs against the border rows of Kn / HPt (s_border).
 #define DD_STRIP_MAX REKF_STRIP_MAX
-// FAST = the whole innovation fits one full 64-wide k-chunk (m_pad == 64, i.e. 25..32 matched
-// observations: BASELINE.json's N=1024 x 32 configuration).  Its loop is peeled so that every
-// prefetch/consume pair is unconditional and hipcc's waitcnt pass can count them exactly.
 typedef double DdBorder[DD_STRIP_MAX][REKF_MR_PAD];
-template <bool FAST, bool ABL>
-__device__ static void downdate_body(const RekfDev &d, double *dd_smem, DdBorder *s_border, int n, int m_pad)
-{
-    const int dbg = ABL ? d.dbg : 0;       // ablation hooks compile away in the production instance
-#ifdef REKF_DEBUG_TIMING
-    const long long t_entry = clock64();
-#endif
-    const int rem = n % DT;
-    const bool strips = rem > 0 && rem <= DD_STRIP_MAX && n >= DT;       // thin border: strips instead of padded tiles
-    const int T = strips ? n / DT : (n + DT - 1) / DT;
-    const int nchunk = FAST ? 1 : (m_pad + DKC - 1) / DKC;
-    // Tile assignment.  Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only):
-    // the tile grid is cut into 2 x 4 regions, one per XCD, so that an XCD's private L2 only ever
-    // needs 1/2 of the Kn panels and 1/4 of the HPt panels (0.8 MB instead of 2.2 MB from HBM per XCD).
-    // Inside a region the XCD's workgroups take contiguous tile ranges.  Any grid that is not a
-    // multiple of 8 falls back to one linear split (same result, placement-independent either way).
-    int i_lo = 0, i_n = T, j_lo = 0, j_n = T, w = blockIdx.x, nw = gridDim.x;
-    if (gridDim.x >= 8 && (gridDim.x & 7) == 0) {
-        const int x = blockIdx.x & 7, ri = x >> 2, rj = x & 3;
-        i_lo = ri * T / 2; i_n = (ri + 1) * T / 2 - i_lo;
-        j_lo = rj * T / 4; j_n = (rj + 1) * T / 4 - j_lo;
-        w = blockIdx.x >> 3; nw = gridDim.x >> 3;
-    }
-    const int ntiles = i_n * j_n;
-    const int t_begin = (int)(((long long)w * ntiles) / nw);
-    const int t_end = (int)(((long long)(w + 1) * ntiles) / nw);
-    if (t_begin >= t_end) return;
-    const int nitems = (t_end - t_begin) * nchunk;
-    const size_t ld = (size_t)d.ld;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int idx = lane & 15, kq = lane >> 4;
-    const int wi = wave & 1, wj = wave >> 1;
-    const double *__restrict__ Kn = d.Kn;
-    const double *__restrict__ HPt = d.HPt;
-    double *__restrict__ P = d.P;
-
-    v2d stgK[DD_STG], stgW[DD_STG], pnext[8];
-    v4d acc[2][2];
-
-    // A workgroup's diagonal tile (at most one: they are i_n + 1 apart) is taken LAST, so that its border-strip
-    // work stays out of the pipelined loop: positions t_diag and t_end - 1 of the range are swapped.
-    int t_diag = t_end - 1;
-    if (strips) {                                          // tile t = jj*i_n + ii is diagonal iff ii = jj + (j_lo - i_lo)
-        const int jj0 = t_begin / i_n, dl = j_lo - i_lo;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {                       // a range this short (< i_n) meets at most two tile columns
-            const int jj = jj0 + q, ii = jj + dl, t = jj * i_n + ii;
-            if (ii >= 0 && ii < i_n && jj < j_n && t >= t_begin && t < t_end) t_diag = t;
-        }
-    }
-    auto tile_IJ = [&](int tile, int &I, int &J) {
-        const int tt = (tile == t_end - 1) ? t_diag : ((tile == t_diag) ? t_end - 1 : tile);
-        const int jj = tt / i_n;
-        I = i_lo + (tt - jj * i_n); J = j_lo + jj;
-    };
-    auto load_panels = [&](int item) {
-        if (dbg & 8) return;                 // ablation hook: skip the panel reads
-        int I, J;
-        tile_IJ(t_begin + item / nchunk, I, J);
-        const int k0 = FAST ? 0 : (item % nchunk) * DKC;
-        const int kmax = FAST ? DKC : ((m_pad - k0 < DKC) ? (m_pad - k0) : DKC);
-        const double *kp = Kn + (size_t)(DT * I + 2 * (tid & 31)) + (size_t)(k0 + (tid >> 5)) * ld;
-        const double *wp = HPt + (size_t)(DT * J + 2 * (tid & 31)) + (size_t)(k0 + (tid >> 5)) * ld;
-#pragma unroll
-        for (int q = 0; q < DD_STG; ++q) {
-            if (FAST || 8 * q + (tid >> 5) < kmax) {
-                stgK[q] = *(const v2d *)(kp + (size_t)(8 * q) * ld);
-                stgW[q] = *(const v2d *)(wp + (size_t)(8 * q) * ld);
-            }
-        }
-    };
-    auto write_panels = [&](int item, int buf) {
-        const int k0 = FAST ? 0 : (item % nchunk) * DKC;
-        const int kmax = FAST ? DKC : ((m_pad - k0 < DKC) ? (m_pad - k0) : DKC);
-        double *sK = dd_smem + (size_t)(buf * DD_NBUF / 2) * 2 * DKC * 64 + (tid >> 5) * 64 + 2 * (tid & 31);
-        double *sW = sK + DKC * 64;
-#pragma unroll
-        for (int q = 0; q < DD_STG; ++q) {
-            if (FAST || 8 * q + (tid >> 5) < kmax) {
-                *(v2d *)(sK + 8 * q * 64) = stgK[q];
-                *(v2d *)(sW + 8 * q * 64) = stgW[q];
-            }
-        }
-    };
-    auto p_ptr = [&](int tile) -> double * {
-        int I, J;
-        tile_IJ(tile, I, J);
-        return P + (size_t)(DT * I + 32 * wi + 2 * idx) + (size_t)(DT * J + 32 * wj + 2 * kq) * ld;
-    };
-    auto load_p = [&](int tile) {
-        if (dbg & 2) {                       // ablation hook: skip the P reads
-            for (int q = 0; q < 8; ++q) { pnext[q].x = 1e-3 * tile; pnext[q].y = 2e-3; }
-            return;
-        }
-        const double *Pw = p_ptr(tile);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                pnext[mt * 4 + r] = *(const v2d *)(Pw + (size_t)(8 * r + mt) * ld);
-    };
-    auto acc_from_pnext = [&]() {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc[mt][0][r] = pnext[mt * 4 + r].x;
-                acc[mt][1][r] = pnext[mt * 4 + r].y;
-            }
-    };
-    auto mfma_chunk = [&](int item) {
-        const int k0 = FAST ? 0 : (item % nchunk) * DKC;
-        const int kmax = FAST ? DKC : ((m_pad - k0 < DKC) ? (m_pad - k0) : DKC);
-        const double *sK = dd_smem + (size_t)((item & 1) * DD_NBUF / 2) * 2 * DKC * 64, *sW = sK + DKC * 64;
-        const double *aW = sW + 32 * wj + 2 * idx + kq * 64;        // A[j][k] = HP(k,j)
-        const double *bK = sK + 32 * wi + 2 * idx + kq * 64;        // B[k][i] = Kn(i,k)
-        if (dbg & 4) return;                 // ablation hook: skip the MFMA loop
-        if (FAST) {
-            // fully unrolled, operands of k-step kk+1 are read from LDS before the MFMAs of step kk issue
-            v2d a2 = *(const v2d *)(aW), b2 = *(const v2d *)(bK);
-#pragma unroll
-            for (int kk = 0; kk < DKC / 4; ++kk) {
-                v2d a2n = a2, b2n = b2;
-                if (kk + 1 < DKC / 4) {
-                    a2n = *(const v2d *)(aW + (kk + 1) * 256);
-                    b2n = *(const v2d *)(bK + (kk + 1) * 256);
-                }
-                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.x, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.y, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.x, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.y, acc[1][1], 0, 0, 0);
-                a2 = a2n; b2 = b2n;
-            }
-        } else {
-            for (int kk = 0; kk < kmax / 4; ++kk) {
-                const v2d a2 = *(const v2d *)(aW + kk * 256);
-                const v2d b2 = *(const v2d *)(bK + kk * 256);
-                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.x, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.y, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.x, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.y, acc[1][1], 0, 0, 0);
-            }
-        }
-    };
-    auto store_tile = [&](int tile) {
-        if (dbg & 1) return;                 // ablation hook (rekf_debug_time_kernel): skip the write-back
-        double *Pw = p_ptr(tile);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v2d v;
-                v.x = acc[mt][0][r];
-                v.y = acc[mt][1][r];
-                *(v2d *)(Pw + (size_t)(8 * r + mt) * ld) = v;
-            }
-    };
-
-    // Tile (I,I) of an item: its LDS panels are Kn(64I.., k0..) and HPt(64I.., k0..); see "Border strips" above.
-    // 192 threads, two outputs each: threads [0,96) the column strip P(64I+x.., nb+b), [96,192) the row strip
-    // P(nb+b, 64I+x..), x = 2*(u%32), b = u/32.  The P operands are fetched before the tile's MFMA loop
-    // (strip_prefetch) and consumed after it (strip_finish); rem <= 3 pairs per pass, DD_STRIP_MAX rows in two.
-    v2d strip_p[(2 * DD_STRIP_MAX * 32 + 255) / 256];
-    bool strip_on = false;
-    int strip_I = 0;
-    auto strip_addr = [&](int pass, int I, double *&p0, double *&p1, int &which, int &b, int &x) {
-        const int t = tid + 256 * pass;               // fixed DD_STRIP_MAX*32 slots per strip: no runtime division
-        which = t / (DD_STRIP_MAX * 32); const int u = t % (DD_STRIP_MAX * 32);
-        b = u >> 5; x = 2 * (u & 31);
-        const int nb = DT * T;
-        if (which == 0) { p0 = P + (size_t)(DT * I + x) + (size_t)(nb + b) * ld; p1 = p0 + 1; }
-        else { p0 = P + (size_t)(nb + b) + (size_t)(DT * I + x) * ld; p1 = p0 + ld; }
-    };
-    auto strip_prefetch = [&](int item) {
-        strip_on = false;
-        if (!strips || (ABL && (dbg & 128))) return;
-        int I, J;
-        tile_IJ(t_begin + item / nchunk, I, J);
-        if (I != J) return;
-        strip_on = true; strip_I = I;
-#pragma unroll
-        for (int pass = 0; pass < (2 * DD_STRIP_MAX * 32 + 255) / 256; ++pass) {
-            {
-                double *p0, *p1; int which, b, x;
-                strip_addr(pass, I, p0, p1, which, b, x);
-                if (which < 2 && b < rem) { strip_p[pass].x = *p0; strip_p[pass].y = *p1; }
-            }
-        }
-    };
-    auto strip_finish = [&](int item) {
-        if (!strip_on) return;
-        const int I = strip_I;
-        const int k0 = FAST ? 0 : (item % nchunk) * DKC;
-        const int kmax = FAST ? DKC : ((m_pad - k0 < DKC) ? (m_pad - k0) : DKC);
-        const double *sK = dd_smem + (size_t)((item & 1) * DD_NBUF / 2) * 2 * DKC * 64, *sW = sK + DKC * 64;
-#pragma unroll
-        for (int pass = 0; pass < (2 * DD_STRIP_MAX * 32 + 255) / 256; ++pass) {
-            {
-                double *p0, *p1; int which, b, x;
-                strip_addr(pass, I, p0, p1, which, b, x);
-                if (which >= 2 || b >= rem) continue;
-                // which = 0: += sum_k Kn(64I+x, k) HPt(nb+b, k);  1: += sum_k Kn(nb+b, k) HPt(64I+x, k)
-                const double *panel = (which ? sW : sK) + x;
-                const double *brow = s_border[which ? 0 : 1][b] + k0;
-                v2d acc = strip_p[pass];
-#pragma unroll 8
-                for (int k = 0; k < kmax; k += 2) {
-                    const v2d bb = *(const v2d *)(brow + k);
-                    const v2d v0 = *(const v2d *)(panel + k * 64), v1 = *(const v2d *)(panel + (k + 1) * 64);
-                    acc.x = fma(v0.x, bb.x, acc.x); acc.y = fma(v0.y, bb.x, acc.y);
-                    acc.x = fma(v1.x, bb.y, acc.x); acc.y = fma(v1.y, bb.y, acc.y);
-                }
-                *p0 = acc.x; *p1 = acc.y;
-            }
-        }
-        if (I == 0 && tid < rem * rem) {          // the corner block P(nb.., nb..)
-            const int nb = DT * T;
-            const int a = tid / rem, b = tid - a * rem;
-            double *pp = P + (size_t)(nb + a) + (size_t)(nb + b) * ld;
-            double v = *pp;
-#pragma unroll 16
-            for (int k = 0; k < kmax; ++k) v = fma(s_border[0][a][k0 + k], s_border[1][b][k0 + k], v);
-            *pp = v;
-        }
-    };
-
-    // prologue: item 0
-    load_panels(0);
-    load_p(t_begin);
-    // FAST epilogue of a workgroup with a diagonal tile: the strip FMAs ride inside the tile's MFMA loop (the
-    // matrix pipe is the bound there, VALU and LDS have room).  The k range is split over the four waves -- each
-    // lane: two x, all DD_STRIP_MAX border rows, so the panel reads are shared -- partial sums meet in the LDS
-    // buffer that has no next tile to hold, and the threads of the prefetch mapping finish their (which, b, x).
-    auto mfma_chunk_strips = [&](int item) {
-        const double *sK = dd_smem + (size_t)((item & 1) * DD_NBUF / 2) * 2 * DKC * 64, *sW = sK + DKC * 64;
-        const double *aW = sW + 32 * wj + 2 * idx + kq * 64;        // A[j][k] = HP(k,j)
-        const double *bK = sK + 32 * wi + 2 * idx + kq * 64;        // B[k][i] = Kn(i,k)
-        const int which = lane >> 5, x = 2 * (lane & 31), kb = (DKC / 4) * wave;
-        const double *panel = (which ? sW : sK) + x + kb * 64;
-        const double *brow = &s_border[which ? 0 : 1][0][kb];
-        v2d sacc[DD_STRIP_MAX];
-#pragma unroll
-        for (int b = 0; b < DD_STRIP_MAX; ++b) { sacc[b].x = 0.0; sacc[b].y = 0.0; }
-        v2d a2 = *(const v2d *)(aW), b2 = *(const v2d *)(bK);
-#pragma unroll
-        for (int kk = 0; kk < DKC / 4; ++kk) {
-            v2d a2n = a2, b2n = b2;
-            if (kk + 1 < DKC / 4) {
-                a2n = *(const v2d *)(aW + (kk + 1) * 256);
-                b2n = *(const v2d *)(bK + (kk + 1) * 256);
-            }
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.y, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.y, acc[1][1], 0, 0, 0);
-            if ((kk & 1) == 0) {                            // k pair (kk, kk+1) of this wave's quarter of the k range
-                const v2d v0 = *(const v2d *)(panel + kk * 64), v1 = *(const v2d *)(panel + (kk + 1) * 64);
-#pragma unroll
-                for (int b = 0; b < DD_STRIP_MAX; ++b) {
-                    const v2d bb = *(const v2d *)(brow + b * REKF_MR_PAD + kk);
-                    sacc[b].x = fma(v0.x, bb.x, sacc[b].x); sacc[b].y = fma(v0.y, bb.x, sacc[b].y);
-                    sacc[b].x = fma(v1.x, bb.y, sacc[b].x); sacc[b].y = fma(v1.y, bb.y, sacc[b].y);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            a2 = a2n; b2 = b2n;
-        }
-        v2d *red = (v2d *)(dd_smem + (size_t)(((item + 1) & 1) * DD_NBUF / 2) * 2 * DKC * 64);
-#pragma unroll
-        for (int b = 0; b < DD_STRIP_MAX; ++b) red[(wave * DD_STRIP_MAX + b) * 64 + lane] = sacc[b];
-    };
-    auto strip_reduce_store = [&](int item) {
-        const int I = strip_I;
-        const v2d *red = (const v2d *)(dd_smem + (size_t)(((item + 1) & 1) * DD_NBUF / 2) * 2 * DKC * 64);
-        dd_lds_barrier();
-        {
-            double *p0, *p1; int which, b, x;
-            strip_addr(0, I, p0, p1, which, b, x);
-            if (which < 2 && b < rem) {
-                v2d t = strip_p[0];
-#pragma unroll
-                for (int w = 0; w < 4; ++w) { const v2d r = red[(w * DD_STRIP_MAX + b) * 64 + which * 32 + (x >> 1)]; t.x += r.x; t.y += r.y; }
-                *p0 = t.x; *p1 = t.y;
-            }
-        }
-        if (I == 0 && tid < 64) {                 // the corner block P(nb.., nb..): 16 (a,b) slots x 4 quarters of k
-            const int a = (tid >> 2) & 3, b = tid & 3, k4 = tid >> 4;
-            const double *ra = &s_border[0][a][(DKC / 4) * k4], *rb = &s_border[1][b][(DKC / 4) * k4];
-            double v = 0.0;
-#pragma unroll
-            for (int k = 0; k < DKC / 4; k += 2) {
-                const v2d u = *(const v2d *)(ra + k), w = *(const v2d *)(rb + k);
-                v = fma(u.x, w.x, v); v = fma(u.y, w.y, v);
-            }
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            if (k4 == 0 && a < rem && b < rem) {
-                double *pp = P + (size_t)(DT * T + a) + (size_t)(DT * T + b) * ld;
-                *pp += v;
-            }
-        }
-    };
-    static_assert(2 * DD_STRIP_MAX * 32 <= 256, "one pass of the prefetch mapping");
-
-    bool has_diag = false;
-    if (strips) { int I, J; tile_IJ(t_end - 1, I, J); has_diag = I == J; }
-    if (has_diag) {                         // border rows of Kn / HPt -> LDS (visible after the barrier below)
-        // rows nb..nb+3 of Kn and HPt, as k_gain / k_gather left them contiguous in KnB / HPtB (2 x 4 KB)
-        const v2d b0 = ((const v2d *)d.KnB)[tid], b1 = ((const v2d *)d.HPtB)[tid];
-        ((v2d *)&s_border[0][0][0])[tid] = b0;
-        ((v2d *)&s_border[1][0][0])[tid] = b1;
-    }
-    write_panels(0, 0);
-    acc_from_pnext();
-    dd_lds_barrier();
-
-    if (FAST) {
-#ifdef REKF_DEBUG_TIMING
-        long long tq[24]; int nq = 0;
-        const bool rec = blockIdx.x == 0 && tid == 0;
-#define DMARK() do { if (rec && nq < 24) tq[nq++] = clock64(); } while (0)
-#else
-#define DMARK()
-#endif
-        DMARK();
-        for (int item = 0; item < nitems - 1; ++item) {
-            const int tile = t_begin + item;
-            // The next tile's 24 loads per lane are issued BETWEEN the MFMAs of this tile (two per
-            // k-step, sched_barrier keeps them there): issuing them in one burst stalls the wave in
-            // VMEM issue for as long as the transfer takes (the per-CU queue is full whenever the chip
-            // is HBM-bound) and the matrix pipe idles; spread out, the MFMAs run in the gaps.
-            int In, Jn;
-            tile_IJ(tile + 1, In, Jn);
-            const double *kp = Kn + (size_t)(DT * In + 2 * (tid & 31)) + (size_t)(tid >> 5) * ld;
-            const double *wp = HPt + (size_t)(DT * Jn + 2 * (tid & 31)) + (size_t)(tid >> 5) * ld;
-            const double *Pn = p_ptr(tile + 1);
-            const bool no_p = (dbg & 2) != 0, no_panels = (dbg & 8) != 0, no_mfma = (dbg & 4) != 0;
-            const double *sK = dd_smem + (size_t)((item & 1) * DD_NBUF / 2) * 2 * DKC * 64, *sW = sK + DKC * 64;
-            const double *aW = sW + 32 * wj + 2 * idx + kq * 64;
-            const double *bK = sK + 32 * wi + 2 * idx + kq * 64;
-            v2d a2 = *(const v2d *)(aW), b2 = *(const v2d *)(bK);
-#pragma unroll
-            for (int kk = 0; kk < DKC / 4; ++kk) {
-                v2d a2n = a2, b2n = b2;
-                if (kk + 1 < DKC / 4) {
-                    a2n = *(const v2d *)(aW + (kk + 1) * 256);
-                    b2n = *(const v2d *)(bK + (kk + 1) * 256);
-                }
-                if (!no_mfma) {
-                    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.x, acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.y, acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.x, acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.y, acc[1][1], 0, 0, 0);
-                }
-                if (kk < DD_STG) {                       // k-steps 0..7: one Kn and one HPt panel piece each
-                    if (!no_panels) {
-                        stgK[kk] = *(const v2d *)(kp + (size_t)(8 * kk) * ld);
-                        stgW[kk] = *(const v2d *)(wp + (size_t)(8 * kk) * ld);
-                    }
-                } else if (kk < DD_STG + 4) {            // k-steps 8..11: two P pieces each
-                    const int q = 2 * (kk - DD_STG);
-                    if (!no_p) {
-                        pnext[q] = *(const v2d *)(Pn + (size_t)(8 * (q & 3) + (q >> 2)) * ld);
-                        pnext[q + 1] = *(const v2d *)(Pn + (size_t)(8 * ((q + 1) & 3) + ((q + 1) >> 2)) * ld);
-                    } else {
-                        pnext[q].x = 1e-3; pnext[q].y = 2e-3; pnext[q + 1] = pnext[q];
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                a2 = a2n; b2 = b2n;
-            }
-            DMARK();
-            store_tile(tile);                 // (C) drains under the next tile
-            DMARK();
-            write_panels(item + 1, (item + 1) & 1);   // (D) staged panels -> LDS
-            DMARK();
-            acc_from_pnext();
-            dd_lds_barrier();
-            DMARK();
-        }
-#ifdef REKF_DEBUG_TIMING
-        if (rec) for (int i = 1; i < nq; ++i) const_cast<RekfCtl *>(d.ctl)->dbg[8 + i - 1] = tq[i] - tq[0];
-        if (rec) const_cast<RekfCtl *>(d.ctl)->dbg[7] = tq[0] - t_entry;      // prologue
-#endif
-#ifdef REKF_DEBUG_TIMING
-        const long long te0 = clock64();
-#endif
-        strip_prefetch(nitems - 1);
-        if (strip_on) mfma_chunk_strips(nitems - 1);
-        else mfma_chunk(nitems - 1);
-#ifdef REKF_DEBUG_TIMING
-        __builtin_amdgcn_sched_barrier(0);
-        const long long te1 = clock64();
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        store_tile(t_begin + nitems - 1);
-#ifdef REKF_DEBUG_TIMING
-        __builtin_amdgcn_sched_barrier(0);
-        const long long te2 = clock64();
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        if (strip_on) strip_reduce_store(nitems - 1);
-#ifdef REKF_DEBUG_TIMING
-        if (rec) {
-            RekfCtl *c = const_cast<RekfCtl *>(d.ctl);
-            c->dbg[6] = clock64() - t_entry;          // whole body, stores issued
-            c->dbg[24] = te1 - te0; c->dbg[25] = te2 - te1; c->dbg[26] = clock64() - te2;
-        }
-#endif
-    } else {
-        for (int item = 0; item < nitems; ++item) {
-            const int tile = t_begin + item / nchunk;
-            const int chunk = item % nchunk;
-            const bool has_next = item + 1 < nitems;
-            const bool next_new_tile = has_next && (chunk == nchunk - 1);
-            if (has_next) load_panels(item + 1);
-            if (next_new_tile) load_p(tile + 1);
-            strip_prefetch(item);
-            mfma_chunk(item);
-            strip_finish(item);
-            if (chunk == nchunk - 1) store_tile(tile);
-            if (has_next) {
-                write_panels(item + 1, (item + 1) & 1);
-                if (next_new_tile) acc_from_pnext();
-                dd_lds_barrier();
-            }
-        }
-    }
-}
 
 // ----------------------------------------------------------------------------
 // k_downdate2<KC>: the rank-m downdate when the scan's innovation fits one k-chunk, m_pad <= KC <= 64 (the host picks
@@ -2442,24 +1648,6 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
 #endif
 }
 
-__global__ __launch_bounds__(256, 2) void k_downdate(RekfDev d)
-{
-    extern __shared__ __attribute__((aligned(16))) double dd_smem[];   // [2 buffers][Kn | HPt][DKC*64]
-    // [Kn | HPt] border rows nb.., all k -- declared once here: a copy per template instance would be summed into the
-    // kernel's static LDS (4 x 8 KiB = the whole CU with the 128 KiB of panels) and no other workgroup could ever share
-    // the CU with this one
-    __shared__ __attribute__((aligned(16))) double s_border[2][DD_STRIP_MAX][REKF_MR_PAD];
-    const RekfCtl *ctl = d.ctl;
-    const int m_pad = ctl->m_pad;
-    if (ctl->m == 0) return;
-    const int n = ctl->n;
-    if (d.dbg) {                                   // ablation runs (rekf_debug_time_kernel): the round-1 body
-        if (m_pad == DKC) downdate_body<true, true>(d, dd_smem, s_border, n, m_pad);
-        else downdate_body<false, true>(d, dd_smem, s_border, n, m_pad);
-    } else if (m_pad == DKC) downdate_body<true, false>(d, dd_smem, s_border, n, m_pad);
-    else downdate_body<false, false>(d, dd_smem, s_border, n, m_pad);
-}
-
 // ----------------------------------------------------------------------------
 // k_augment (cc:311-364): one workgroup; runs only while the map is growing.
 // ----------------------------------------------------------------------------
@@ -2603,10 +1791,6 @@ void rekf_launch_front_mb(const RekfDev &d, const RekfFrontArgs &a, int n_ub, hi
     (void)n_ub;
     hipLaunchKernelGGL(k_front_mb, dim3(FRONT_MB), dim3(1024), 0, s, d, a);
 }
-void rekf_launch_gather(const RekfDev &d, const RekfFrontArgs &a, int n_ub, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_gather, dim3((n_ub + 255) / 256, 32), dim3(256), 0, s, d, a);
-}
 void rekf_launch_compact_wide(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s)
 {
     hipLaunchKernelGGL(k_compact_wide, dim3(1), dim3(REKF_MAX_OBS_WIDE), 0, s, d, a);
@@ -2618,17 +1802,6 @@ void rekf_launch_mid(const RekfDev &d, const RekfFrontArgs &a, int n_ub, int m_u
     if (m_ub <= 32) hipLaunchKernelGGL(k_mid<2>, dim3(grid), dim3(512), 0, s, d, a);
     else hipLaunchKernelGGL(k_mid<4>, dim3(grid), dim3(512), 0, s, d, a);
 }
-void rekf_launch_solve(const RekfDev &d, int m_ub, hipStream_t s)
-{
-    // one wave per 16-row block of S; m <= m_ub = 2K (+3) is all the host knows
-    if (m_ub <= 32) hipLaunchKernelGGL(k_solve<2>, dim3(1), dim3(128), 0, s, d);
-    else if (m_ub <= 64) hipLaunchKernelGGL(k_solve<4>, dim3(1), dim3(256), 0, s, d);
-    else hipLaunchKernelGGL(k_solve<8>, dim3(1), dim3(512), 0, s, d);
-}
-void rekf_launch_gain(const RekfDev &d, int n_ub, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_gain, dim3((n_ub + 15) / 16), dim3(512), 0, s, d);
-}
 template <int KC> static void launch_downdate2(const RekfDev &d, int grid, hipStream_t s, bool first_on_device)
 {
     constexpr int BYTES = 4 * KC * 64 * (int)sizeof(double) + (KC < 64 ? 16384 : 0);
@@ -2638,8 +1811,8 @@ template <int KC> static void launch_downdate2(const RekfDev &d, int grid, hipSt
 }
 void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s)
 {
-    // persistent: one workgroup per CU (128 KiB of LDS each), never more workgroups than tiles.  The opt-in to more than
-    // 64 KiB of dynamic LDS and the CU count are per DEVICE: a process may hold handles on several GPUs.
+    // persistent: one workgroup per CU (its panels fill most of the LDS), never more workgroups than tiles.  The opt-in to
+    // more than 64 KiB of dynamic LDS and the CU count are per DEVICE: a process may hold handles on several GPUs.
     constexpr int MAX_DEV = 64;
     static int n_cu_of[MAX_DEV] = {0};
     static unsigned attr_done[MAX_DEV] = {0};         // bit KC/16 : k_downdate2<KC> has its LDS opt-in on this device
@@ -2651,8 +1824,6 @@ void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s)
         int cu = 0;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cu = prop.multiProcessorCount;
         if (cu <= 0) cu = 256;
-        (void)hipFuncSetAttribute((const void *)k_downdate, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  DD_NBUF * 2 * DKC * 64 * (int)sizeof(double));
         n_cu_of[slot] = cu;
         attr_done[slot] = 0;
     }
@@ -2661,18 +1832,14 @@ void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s)
     const int slots = n_cu * DD_WG_PER_CU;
     int grid = (T * T < slots) ? T * T : slots;
     if (grid >= 64) grid &= ~7;                     // multiple of 8: enables the per-XCD tile regions
-    const int kc = d.kc_ub;
-    if (kc >= 16 && kc <= 64 && !d.dbg) {           // the whole innovation fits one k-chunk: round-2 pipeline
-        const unsigned bit = 1u << (kc / 16);
-        const bool first = !(attr_done[slot] & bit) || dev != slot;
-        attr_done[slot] |= bit;
-        if (kc == 64) launch_downdate2<64>(d, grid, s, first);
-        else if (kc == 48) launch_downdate2<48>(d, grid, s, first);
-        else if (kc == 32) launch_downdate2<32>(d, grid, s, first);
-        else launch_downdate2<16>(d, grid, s, first);
-        return;
-    }
-    hipLaunchKernelGGL(k_downdate, dim3(grid), dim3(256), DD_NBUF * 2 * DKC * 64 * sizeof(double), s, d);
+    const int kc = (d.kc_ub < 16) ? 16 : ((d.kc_ub > 64) ? 64 : d.kc_ub);    // one k-chunk: the host never asks for more than 64 rows per step
+    const unsigned bit = 1u << (kc / 16);
+    const bool first = !(attr_done[slot] & bit) || dev != slot;
+    attr_done[slot] |= bit;
+    if (kc == 64) launch_downdate2<64>(d, grid, s, first);
+    else if (kc == 48) launch_downdate2<48>(d, grid, s, first);
+    else if (kc == 32) launch_downdate2<32>(d, grid, s, first);
+    else launch_downdate2<16>(d, grid, s, first);
 }
 void rekf_launch_augment(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s)
 {

@@ -217,14 +217,10 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
         HIP_TRY(h, hipMalloc(&h->dev.mu, sizeof(double) * ld));
         HIP_TRY(h, hipMalloc(&h->dev.mu_out, sizeof(double) * ld));
         HIP_TRY(h, hipMalloc(&h->dev.P, sizeof(double) * (size_t)ld * ld));
-        HIP_TRY(h, hipMalloc(&h->dev.W, sizeof(double) * (size_t)ld * REKF_MR_PAD));
-        HIP_TRY(h, hipMalloc(&h->dev.HPt, sizeof(double) * (size_t)ld * REKF_MR_PAD));
-        HIP_TRY(h, hipMalloc(&h->dev.Kn, sizeof(double) * (size_t)ld * REKF_MR_PAD));
-        HIP_TRY(h, hipMalloc(&h->dev.Sinv, sizeof(double) * REKF_MR_PAD * REKF_MR_PAD));
-        HIP_TRY(h, hipMalloc(&h->dev.Wc, sizeof(double) * REKF_WC_DOUBLES));
+        HIP_TRY(h, hipMalloc(&h->dev.HPt, sizeof(double) * (size_t)ld * REKF_PANEL_COLS));
+        HIP_TRY(h, hipMalloc(&h->dev.Kn, sizeof(double) * (size_t)ld * REKF_PANEL_COLS));
         HIP_TRY(h, hipMalloc(&h->dev.KnB, sizeof(double) * REKF_STRIP_MAX * REKF_MR_PAD));
         HIP_TRY(h, hipMalloc(&h->dev.HPtB, sizeof(double) * REKF_STRIP_MAX * REKF_MR_PAD));
-        HIP_TRY(h, hipMalloc(&h->dev.y, sizeof(double) * REKF_MR_PAD));
         HIP_TRY(h, hipMalloc(&h->dev_out12, sizeof(double) * 16));
         HIP_TRY(h, hipMalloc(&h->dev_pred, sizeof(double) * (4 * (size_t)ld + 16)));
         HIP_TRY(h, hipMalloc(&h->dev_obs, sizeof(float) * 2 * REKF_MAX_OBS_WIDE));
@@ -239,14 +235,10 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
         HIP_TRY(h, hipMemsetAsync(h->dev.mu, 0, sizeof(double) * ld, h->stream));
         HIP_TRY(h, hipMemsetAsync(h->dev.mu_out, 0, sizeof(double) * ld, h->stream));
         HIP_TRY(h, hipMemsetAsync(h->dev.P, 0, sizeof(double) * (size_t)ld * ld, h->stream));   // cc:10-11
-        HIP_TRY(h, hipMemsetAsync(h->dev.W, 0, sizeof(double) * (size_t)ld * REKF_MR_PAD, h->stream));
-        HIP_TRY(h, hipMemsetAsync(h->dev.HPt, 0, sizeof(double) * (size_t)ld * REKF_MR_PAD, h->stream));
-        HIP_TRY(h, hipMemsetAsync(h->dev.Kn, 0, sizeof(double) * (size_t)ld * REKF_MR_PAD, h->stream));
-        HIP_TRY(h, hipMemsetAsync(h->dev.Sinv, 0, sizeof(double) * REKF_MR_PAD * REKF_MR_PAD, h->stream));
-        HIP_TRY(h, hipMemsetAsync(h->dev.Wc, 0, sizeof(double) * REKF_WC_DOUBLES, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->dev.HPt, 0, sizeof(double) * (size_t)ld * REKF_PANEL_COLS, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->dev.Kn, 0, sizeof(double) * (size_t)ld * REKF_PANEL_COLS, h->stream));
         HIP_TRY(h, hipMemsetAsync(h->dev.KnB, 0, sizeof(double) * REKF_STRIP_MAX * REKF_MR_PAD, h->stream));
         HIP_TRY(h, hipMemsetAsync(h->dev.HPtB, 0, sizeof(double) * REKF_STRIP_MAX * REKF_MR_PAD, h->stream));
-        HIP_TRY(h, hipMemsetAsync(h->dev.y, 0, sizeof(double) * REKF_MR_PAD, h->stream));
         std::memset(h->ctl_staging, 0, sizeof(RekfCtl));
         h->ctl_staging->n = 3;
         HIP_TRY(h, hipMemcpyAsync(h->dev.ctl, h->ctl_staging, sizeof(int) * 2, hipMemcpyHostToDevice, h->stream));
@@ -273,7 +265,7 @@ void rekf_destroy(rekf_t *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &s : h->prof_slots) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     (void)hipFree(h->dev.ctl); (void)hipFree(h->dev.mu); (void)hipFree(h->dev.mu_out); (void)hipFree(h->dev.P);
-    (void)hipFree(h->dev.W); (void)hipFree(h->dev.HPt); (void)hipFree(h->dev.Kn); (void)hipFree(h->dev.Sinv); (void)hipFree(h->dev.Wc); (void)hipFree(h->dev.KnB); (void)hipFree(h->dev.HPtB); (void)hipFree(h->dev.y);
+    (void)hipFree(h->dev.HPt); (void)hipFree(h->dev.Kn); (void)hipFree(h->dev.KnB); (void)hipFree(h->dev.HPtB);
     (void)hipFree(h->dev.map_xy); (void)hipFree(h->dev.map_cov); (void)hipFree(h->dev_out12); (void)hipFree(h->dev_ell); (void)hipFree(h->dev_pred); (void)hipFree(h->dev_obs); (void)hipFree(h->dev_mu_lin);
     if (h->pose_staging) (void)hipHostFree(h->pose_staging);
     if (h->ctl_staging) (void)hipHostFree(h->ctl_staging);
@@ -320,12 +312,13 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
 {
     if (!h || K < 0 || (K > 0 && !xy)) return REKF_ERR_INVALID;
     if (K > REKF_MAX_OBS) return REKF_ERR_TOO_MANY_OBS;
-    const bool wide = K > REKF_MAX_OBS_DEV || 2 * K + (gps_pose3 ? 3 : 0) > REKF_MAX_ROWS;
+    const bool staged = K > REKF_MAX_OBS_DEV;                       // too many observations for the launch packet
+    const bool blocks = 2 * K + (gps_pose3 ? 3 : 0) > 64;           // more innovation rows than one pass of k_mid takes
     RekfFrontArgs a;
     fill_front_args(h, a, t - h->time);               // cc:232 (dt may be negative, Q8)
     a.is_obs = 1;
     a.K = K;
-    if (K > 0 && !wide) std::memcpy(a.obs, xy, sizeof(float) * 2 * (size_t)K);
+    if (K > 0 && !staged) std::memcpy(a.obs, xy, sizeof(float) * 2 * (size_t)K);
     if (gps_pose3) {
         a.has_gps = 1;
         a.gps[0] = gps_pose3[0]; a.gps[1] = gps_pose3[1]; a.gps[2] = gps_pose3[2];
@@ -341,7 +334,7 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     }
     h->dev.kc_ub = round_up(2 * K + (gps_pose3 ? 3 : 0), 16);
     h->dev.n_known = h->n_exact ? h->n_ub : -1;
-    if (wide) {                                       // the scan does not fit the launch packet: stage it in HBM (copied before this call returns)
+    if (staged) {                                     // the scan does not fit the launch packet: stage it in HBM (copied before this call returns)
         HIP_TRY(h, hipMemcpyAsync(h->dev_obs, xy, sizeof(float) * 2 * (size_t)K, hipMemcpyHostToDevice, h->stream));
         a.obs_ext = h->dev_obs;
     }
@@ -350,11 +343,11 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     const int n_ub = h->n_ub;
     const int m_ub = 2 * K + (gps_pose3 ? 3 : 0);
     h->dev.mu_lin = h->dev.mu;
-    if (wide) {
-        // More than 64 observations (the reference has no limit, cc:397): matched once, then the joint update runs as
-        // exact block steps of at most 32 pairs through the same kernels (k_mid explains why that is the same update).
-        // The host cannot know how many observations matched, so it enqueues ceil(K / stride) steps; a step past the
-        // last pair only carries the mean over and adds zero panels.
+    if (blocks) {
+        // More than 32 observations (the reference has no limit, cc:397): matched once, then the joint update runs as
+        // exact block steps of at most 32 pairs through the same two kernels (k_mid explains why that is the same
+        // update).  The host cannot know how many observations matched, so it enqueues ceil(K / stride) steps; a step
+        // past the last pair only carries the mean over and adds zero panels.
         const int stride = gps_pose3 ? 30 : 32;
         a.pair_stride = stride;
         h->dev.kc_ub = 64;
@@ -369,20 +362,16 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         }
         a.pair0 = -1;
         h->dev.mu_lin = h->dev.mu;
-    } else if (m_ub <= 64) {
-        // the whole innovation fits one 64-wide chunk: gather + solve + gain as ONE launch (k_mid), which leaves the
-        // updated mean in the other mean buffer
+    } else {
+        // the whole innovation fits one pass: gather + solve + gain as ONE launch (k_mid), which leaves the updated
+        // mean in the other mean buffer
         { ProfScope ps(h, REKF_K_MID); rekf_launch_mid(h->dev, a, n_ub, m_ub, h->stream); }
         std::swap(h->dev.mu, h->dev.mu_out);
-    } else {
-        { ProfScope ps(h, REKF_K_GATHER); rekf_launch_gather(h->dev, a, n_ub, h->stream); }
-        { ProfScope ps(h, REKF_K_SOLVE); rekf_launch_solve(h->dev, m_ub, h->stream); }
-        { ProfScope ps(h, REKF_K_GAIN); rekf_launch_gain(h->dev, n_ub, h->stream); }
+        { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_downdate(h->dev, n_ub, h->stream); }
     }
     h->last_m_ub = m_ub;
-    if (!wide) { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_downdate(h->dev, n_ub, h->stream); }
     // the state only grows: once a readback has shown it full, k_augment can never have work again
-    // (k_gather drops the extra reflectors and raises REKF_FLAG_CAPACITY)
+    // (k_mid / k_compact_wide drop the extra reflectors and raise REKF_FLAG_CAPACITY)
     if (!h->full) { ProfScope ps(h, REKF_K_AUGMENT); rekf_launch_augment(h->dev, a, h->stream); }
     { ProfScope ps(h, REKF_K_EMPTY); }
     // the scan may have appended up to K reflectors; the exact n stays on the device
@@ -628,13 +617,7 @@ int rekf_debug_time_kernel(rekf_t *h, int kernel, int reps, int ablate, double *
     HIP_TRY(h, hipEventCreate(&b));
     const int n_ub = h->n_ub;
     auto launch = [&]() {
-        switch (kernel) {
-        case REKF_K_GATHER: break;   /* needs the scan's arguments: not re-launchable standalone */
-        case REKF_K_SOLVE: rekf_launch_solve(dev, h->last_m_ub, h->stream); break;
-        case REKF_K_GAIN: rekf_launch_gain(dev, n_ub, h->stream); break;
-        case REKF_K_DOWNDATE: rekf_launch_downdate(dev, n_ub, h->stream); break;
-        default: break;
-        }
+        if (kernel == REKF_K_DOWNDATE) rekf_launch_downdate(dev, n_ub, h->stream);
     };
     for (int i = 0; i < 3; ++i) launch();
     HIP_TRY(h, hipEventRecord(a, h->stream));
@@ -645,43 +628,6 @@ int rekf_debug_time_kernel(rekf_t *h, int kernel, int reps, int ablate, double *
     HIP_TRY(h, hipEventElapsedTime(&ms, a, b));
     *avg_us = 1e3 * (double)ms / reps;
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-    return REKF_OK;
-}
-
-/* Measurement hook: can k_downdate run under the latency chain of a following update?  Times `reps` launches of
- * k_downdate alone (stream A), `reps` x (k_solve, k_gain) alone (stream B), and both streams together; out_us[0..2] =
- * microseconds per repetition.  Like rekf_debug_time_kernel it leaves the state meaningless. */
-int rekf_debug_overlap(rekf_t *h, int reps, double out_us[3])
-{
-    if (!h || !out_us || reps < 1) return REKF_ERR_INVALID;
-    HIP_TRY(h, hipSetDevice(h->device));
-    hipStream_t sb;
-    HIP_TRY(h, hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
-    hipEvent_t a0, a1, b0, b1;
-    HIP_TRY(h, hipEventCreate(&a0)); HIP_TRY(h, hipEventCreate(&a1)); HIP_TRY(h, hipEventCreate(&b0)); HIP_TRY(h, hipEventCreate(&b1));
-    const int n_ub = h->n_ub;
-    auto run_a = [&]() { for (int i = 0; i < reps; ++i) rekf_launch_downdate(h->dev, n_ub, h->stream); };
-    auto run_b = [&]() { for (int i = 0; i < reps; ++i) { rekf_launch_solve(h->dev, h->last_m_ub, sb); rekf_launch_gain(h->dev, n_ub, sb); } };
-    float ms = 0.f;
-    for (int w = 0; w < 2; ++w) {                    // first pass warms up
-        HIP_TRY(h, hipEventRecord(a0, h->stream)); run_a(); HIP_TRY(h, hipEventRecord(a1, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        HIP_TRY(h, hipEventElapsedTime(&ms, a0, a1)); out_us[0] = 1e3 * ms / reps;
-        HIP_TRY(h, hipEventRecord(b0, sb)); run_b(); HIP_TRY(h, hipEventRecord(b1, sb));
-        HIP_TRY(h, hipStreamSynchronize(sb));
-        HIP_TRY(h, hipEventElapsedTime(&ms, b0, b1)); out_us[1] = 1e3 * ms / reps;
-    }
-    HIP_TRY(h, hipDeviceSynchronize());
-    const auto t0 = std::chrono::steady_clock::now();
-    for (int i = 0; i < reps; ++i) {                 // interleaved enqueue: both queues stay fed
-        rekf_launch_downdate(h->dev, n_ub, h->stream);
-        rekf_launch_solve(h->dev, h->last_m_ub, sb); rekf_launch_gain(h->dev, n_ub, sb);
-    }
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipStreamSynchronize(sb));
-    out_us[2] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
-    (void)hipEventDestroy(a0); (void)hipEventDestroy(a1); (void)hipEventDestroy(b0); (void)hipEventDestroy(b1);
-    (void)hipStreamDestroy(sb);
     return REKF_OK;
 }
 

@@ -17,7 +17,7 @@ from . import _lib
 
 DIFF, OMNI = 0, 1   # sensor::OdometryModel (sensor_data.h:56-60)
 
-KERNELS = {"predict": 0, "front": 1, "gather": 2, "solve": 3, "gain": 4, "downdate": 5, "augment": 6, "empty": 7,
+KERNELS = {"predict": 0, "front": 1, "downdate": 5, "augment": 6, "empty": 7,
            "update": 8, "mid": 9}
 
 
