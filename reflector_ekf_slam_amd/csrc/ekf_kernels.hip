@@ -257,30 +257,11 @@ __global__ __launch_bounds__(1024) void k_front(RekfDev d, RekfFrontArgs A)
 // mean -- nobody writes mu[0..2] in this kernel: the predicted pose goes to ctl->pose_pred and is
 // committed by k_gain together with the update -- then takes a 1/FRONT_MB slice of the
 // covariance predict and whole observations of ReflectorMatch (all 16 waves sweep disjoint
-// landmark slices, block-wide literal arg-min).  The ordered compaction and the H rows (the tail of
+// landmark slices, wave-wide literal arg-min).  The ordered compaction and the H rows (the tail of
 // k_front) are resolved by k_mid from the per-observation results left in ctl->obs_kind/obs_idx.
 // ----------------------------------------------------------------------------
 #define FRONT_MB 32
 
-struct BlockArgminScratch { double d[16]; int j[16]; double rd; int rj; int cnt[16]; int rcnt; };
-
-// block-wide arg-min with the literal rule (smaller value, then smaller index); all threads get it
-__device__ static void block_argmin(double &v, int &j, BlockArgminScratch &s)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    wave_argmin(v, j);
-    if (lane == 0) { s.d[wave] = v; s.j[wave] = j; }
-    __syncthreads();
-    if (wave == 0) {
-        double x = (lane < 16) ? s.d[lane] : 0.0;
-        int y = (lane < 16) ? s.j[lane] : -1;
-        wave_argmin(x, y);
-        if (lane == 0) { s.rd = x; s.rj = y; }
-    }
-    __syncthreads();
-    v = s.rd; j = s.rj;
-    __syncthreads();
-}
 // arg-min that also carries the runner-up value: (v, j) = smallest value / its first index, v2 = the
 // second smallest value over all candidates (the lanes' own runner-ups included)
 __device__ static inline void argmin2_combine(double &a1, int &ja, double &a2, double b1, int jb, double b2)
@@ -291,37 +272,18 @@ __device__ static inline void argmin2_combine(double &a1, int &ja, double &a2, d
     if (take) { a1 = b1; ja = jb; }
     a2 = n2;
 }
-__device__ static void block_argmin2(double &v, int &j, double &v2, BlockArgminScratch &s, double *s2)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double ov = __shfl_xor(v, off, WAVE), ov2 = __shfl_xor(v2, off, WAVE);
-        const int oj = __shfl_xor(j, off, WAVE);
-        argmin2_combine(v, j, v2, ov, oj, ov2);
-    }
-    if (lane == 0) { s.d[wave] = v; s.j[wave] = j; s2[wave] = v2; }
-    __syncthreads();
-    if (wave == 0) {
-        double x = (lane < 16) ? s.d[lane] : 0.0, x2 = (lane < 16) ? s2[lane] : 1e300;
-        int y = (lane < 16) ? s.j[lane] : -1;
-        for (int off = 8; off >= 1; off >>= 1) {
-            const double ov = __shfl_xor(x, off, WAVE), ov2 = __shfl_xor(x2, off, WAVE);
-            const int oj = __shfl_xor(y, off, WAVE);
-            argmin2_combine(x, y, x2, ov, oj, ov2);
-        }
-        if (lane == 0) { s.rd = x; s.rj = y; s2[16] = x2; }
-    }
-    __syncthreads();
-    v = s.rd; j = s.rj; v2 = s2[16];
-    __syncthreads();
-}
-
 __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
 {
     __shared__ Motion mo;
     __shared__ double pose[5];
-    __shared__ BlockArgminScratch sc;
-    __shared__ double sc2[17];
+#ifdef REKF_DEBUG_FRONT
+    long long tqf[8]; int nqf = 0;
+    const bool recf = blockIdx.x == 1 && threadIdx.x == 0;
+    const long long t_entryf = clock64(), w_entryf = wall_clock64();
+#define FMARK() do { __builtin_amdgcn_sched_barrier(0); if (recf && nqf < 8) tqf[nqf++] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define FMARK()
+#endif
     const int tid = threadIdx.x;
     const int b = blockIdx.x, nb = gridDim.x;
     RekfCtl *ctl = d.ctl;
@@ -339,21 +301,36 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
         c0 = P[idx0 + 0 * ld]; c1 = P[idx0 + 1 * ld]; c2 = P[idx0 + 2 * ld];
         r0 = P[0 + idx0 * ld]; r1 = P[1 + idx0 * ld]; r2 = P[2 + idx0 * ld];
     }
-    float lmx = 0.f, lmy = 0.f;                       // this lane's first landmark (covers L <= 1024)
-    if (tid < L) { lmx = (float)mu[3 + 2 * tid]; lmy = (float)mu[4 + 2 * tid]; }
+    // the first 1024 landmarks as float32 (cc:431), one per thread, into LDS: these loads fly under the trig chain below, and
+    // the wave that matches then reads LDS instead of waiting for HBM four times in a row
+    __shared__ float s_lmx[1024], s_lmy[1024];
+    {
+        float lmx = 0.f, lmy = 0.f;
+        if (tid < L) { lmx = (float)mu[3 + 2 * tid]; lmy = (float)mu[4 + 2 * tid]; }
+        s_lmx[tid] = lmx; s_lmy[tid] = lmy;
+    }
     double C9[9];
     if (tid == 0) {
+        // theta chain (sincos -> atan2 -> sincos, cc:181 / :205) on this lane; the motion terms, which have their own sincos,
+        // meanwhile on lane 0 of the next wave: two SIMDs instead of four libm calls in a row on one
+#pragma clang fp contract(off)
         if (b == 0) for (int q = 0; q < 9; ++q) C9[q] = P[(q % 3) + (size_t)(q / 3) * ld];
+        const double mu2 = mu[2];
+        const double dth = A.vt[2] * A.dt;            // = mo.d[2] (delta_theta = w dt in both models; no FMA: same bits)
+        double th = mu2 + dth, sn, cs;
+        sincos(th, &sn, &cs);
+        th = atan2(sn, cs);
+        sincos(th, &sn, &cs);
+        pose[2] = th; pose[3] = cs; pose[4] = sn;
+        FMARK();                                      // 0: thread 0's trig chain done
+    }
+    if (tid == 64) {
         const double mu0 = mu[0], mu1 = mu[1], mu2 = mu[2];
         motion_terms(A, mu2, mo);
-        const double x = mu0 + mo.d[0], y = mu1 + mo.d[1];
-        double th = mu2 + mo.d[2], sn, cs;
-        sincos(th, &sn, &cs);
-        th = atan2(sn, cs);                           // cc:181 / :205
-        sincos(th, &sn, &cs);
-        pose[0] = x; pose[1] = y; pose[2] = th; pose[3] = cs; pose[4] = sn;
+        pose[0] = mu0 + mo.d[0]; pose[1] = mu1 + mo.d[1];
     }
     __syncthreads();
+    FMARK();                                          // 1: barrier passed
 
     // ---- Predict, covariance slice (cc:178 / :202), corner by workgroup 0
     {
@@ -383,16 +360,19 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
         }
     }
 
-    // ---- ReflectorMatch (cc:370-455): whole observations per workgroup
+    FMARK();                                          // 2: covariance slice written
+    // ---- ReflectorMatch (cc:370-455): whole observations per workgroup, ONE wave each (lanes sweep the landmarks 64 apart,
+    // wave-wide literal arg-min by shuffles: no block barrier on the way -- the 1024-thread version with two-level
+    // reductions took 3 us per observation)
     const int M_ = d.M_map;
-    for (int i = b; i < K; i += nb) {
+    if (tid < 64) for (int i = b; i < K; i += nb) {
         float gx, gy;
         obs_to_global(pose[0], pose[1], pose[3], pose[4], rekf_obs(A, 2 * i), rekf_obs(A, 2 * i + 1), gx, gy);
         int kind = 2, best_j = -1;
         if (M_ > 0) {                                              // cc:401-425
 #pragma clang fp contract(off)
             double best = 0; int bj = -1;
-            for (int j = tid; j < M_; j += 1024) {
+            for (int j = tid; j < M_; j += 64) {
                 const double *S = d.map_cov + 4 * (size_t)j;
                 const float ex = d.map_xy[2 * j] - gx;
                 const float ey = d.map_xy[2 * j + 1] - gy;
@@ -402,45 +382,63 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
                 const double dist = sqrt(t0 * dx + t1 * dy);
                 if (bj < 0 || dist < best) { best = dist; bj = j; }
             }
-            block_argmin(best, bj, sc);
+            wave_argmin(best, bj);
             if (bj >= 0 && best < 0.05) { kind = 0; best_j = bj; }
         }
         if (kind == 2 && L > 0) {                                  // cc:426-451
 #pragma clang fp contract(off)
-            auto lm_of = [&](int j, float &lx, float &ly) {
-                if (j == tid) { lx = lmx; ly = lmy; }
-                else { lx = (float)mu[3 + 2 * j]; ly = (float)mu[4 + 2 * j]; }     // cc:431
-            };
-            double b1 = 1e300, b2 = 1e300; int bj = -1;            // see k_front for the band argument
-            for (int j = tid; j < L; j += 1024) {
-                float lx, ly;
-                lm_of(j, lx, ly);
-                const float ex = gx - lx, ey = gy - ly;             // cc:433
-                const double dx = (double)ex, dy = (double)ey;
-                const double d2 = dx * dx + dy * dy;
-                b2 = vmin_f64(b2, vmax_f64(d2, b1));
-                bj = (d2 < b1) ? j : bj;
-                b1 = vmin_f64(b1, d2);
+            // smallest and second smallest SQUARED distance with the first index of the smallest: the sqrt is taken once, and
+            // only if the two are within rounding of each other does the literal scan (sqrt per candidate) decide
+            double b1 = 1e300, b2 = 1e300; int bj = -1;
+            for (int j0 = 0; j0 < L; j0 += 256) {
+                float lx[4], ly[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + 64 * u + tid, jc = j < L ? j : L - 1;
+                    if (j0 < 1024) { lx[u] = s_lmx[jc & 1023]; ly[u] = s_lmy[jc & 1023]; }                  // staged above
+                    else { lx[u] = (float)mu[3 + 2 * jc]; ly[u] = (float)mu[4 + 2 * jc]; }     // cc:431
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + 64 * u + tid;
+                    const float ex = gx - lx[u], ey = gy - ly[u];      // cc:433
+                    const double dx = (double)ex, dy = (double)ey;
+                    const double d2 = (j < L) ? dx * dx + dy * dy : 1e300;
+                    b2 = vmin_f64(b2, vmax_f64(d2, b1));
+                    bj = (d2 < b1) ? j : bj;
+                    b1 = vmin_f64(b1, d2);
+                }
             }
             double g1 = b1, g2 = b2; int gj = bj;
-            block_argmin2(g1, gj, g2, sc, sc2);                    // minimum, its first index, runner-up
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double ov = __shfl_xor(g1, off, WAVE), ov2 = __shfl_xor(g2, off, WAVE);
+                const int oj = __shfl_xor(gj, off, WAVE);
+                argmin2_combine(g1, gj, g2, ov, oj, ov2);
+            }
             double best = sqrt(g1);
             if (g2 <= g1 * 1.000000000000002) {                    // literal scan (uniform, rare)
                 best = 0; gj = -1;
-                for (int j = tid; j < L; j += 1024) {
-                    float lx, ly;
-                    lm_of(j, lx, ly);
+                for (int j = tid; j < L; j += 64) {
+                    const float lx = (float)mu[3 + 2 * j], ly = (float)mu[4 + 2 * j];
                     const float ex = gx - lx, ey = gy - ly;
                     const double dx = (double)ex, dy = (double)ey;
                     const double dist = sqrt(dx * dx + dy * dy);   // cc:437
                     if (gj < 0 || dist < best) { best = dist; gj = j; }
                 }
-                block_argmin(best, gj, sc);
+                wave_argmin(best, gj);
             }
             if (gj >= 0 && best < 0.6) { kind = 1; best_j = gj; }  // cc:446
         }
         if (tid == 0) { ctl->obs_kind[i] = kind; ctl->obs_idx[i] = best_j; }
     }
+    FMARK();                                          // 3: match done
+#ifdef REKF_DEBUG_FRONT
+    if (recf) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ctl->dbg[6] = clock64() - t_entryf; ctl->dbg[5] = wall_clock64() - w_entryf; ctl->dbg[7] = nqf;
+        for (int i = 0; i < nqf; ++i) ctl->dbg[8 + i] = tqf[i] - t_entryf;
+    }
+#endif
 }
 
 // ----------------------------------------------------------------------------
