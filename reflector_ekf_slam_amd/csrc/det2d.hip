@@ -23,6 +23,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -32,8 +33,10 @@
 
 namespace {
 
+// PoseExtrapolator sample: nav_msgs::Odometry reduced to what pose_extrapolator.cc reads; yaw = 2 atan2(q.z, q.w)
+// (:36,:53) is taken once on the host with the libm a CPU build would call
 struct Odom {
-    double time, px, py, qz, qw, vx, vy, wz;
+    double time, px, py, yaw, vx, vy, wz;
 };
 
 struct R2d { double x, y, a; };
@@ -47,6 +50,7 @@ struct Det2dArgs {
     float msg_range_min, msg_range_max, angle_increment;
     double first_point_time, point_delta_t;
     int N, is_circle, max_centers;
+    int seq;                       // call number: written to Det2dOut::seq when the centres are in host memory
     // sensor_to_base_link as Rigid2f + host-evaluated cos/sin of its angle
     float s2b_x, s2b_y, s2b_a, s2b_c, s2b_s;
     // pose extrapolator state: 0, 1 or 2 samples (front, back)
@@ -54,42 +58,64 @@ struct Det2dArgs {
     Odom front, back;
 };
 
-struct Det2dOut {
-    int K, n_returns, n_runs, err;
-    float centers[2 * RDET_MAX_CENTERS];
+struct Det2dOut {                  // written by the kernel with system-scope stores only (plain stores would sit in L2 until it ends)
+    union { struct { int K, n_returns, n_runs, err; }; unsigned long long head[2]; };
+    unsigned long long centers[RDET_MAX_CENTERS];   // float2 bits (x in the low word): written with one 8-byte store each
+    int seq;
 };
-// hand-over from the single-workgroup state machine (k_det2d) to the per-beam and per-cluster launches
-struct Det2dMid {
-    int K, off, n_cloud, pad;
-    int seg[4 * RDET_MAX_CENTERS + 8];       // cluster segments: first0, last0, first1, last1
-    double inv[5];                           // inverse scan-end pose (x, y, angle), cos / sin of that angle
-};
+
+#define RDET2D_MAX_BEAMS 8192             // workgroup 0 holds a whole scan in LDS (17 B per beam)
+#define RDET2D_GROUP 256                  // beams per per-beam workgroup
 
 struct Det2dBufs {
-    const float *ranges, *intens, *ang, *cosv, *sinv;
-    float2 *pt;            // per beam: point in base_link (valid beams)
-    float2 *contrib;       // per beam of an accepted cluster: its de-skewed point in the scan-end frame (flags bit 8)
-    float *pt_t;           // per beam: float32 point time
-    int *lastvalid;        // last valid beam <= i  (point_cloud.back() at beam i), -1 if none
-    int *cloud_idx;        // index of beam i in point_cloud (valid beams)
-    int *prevb;            // previous bright beam (< i), -1 if none
-    int *runid;            // run index of bright beam i
-    unsigned char *flags;  // 1 valid, 2 bright (after the "a point exists" guard)
-    int *run_first, *run_last, *run_acc;
-    float2 *returns;
-    Det2dOut *out;
-    Det2dMid *mid;
+    const float *ranges, *intens;      // pinned host memory, read in place (the scan never takes a copy engine)
+    const float *ang, *cosv, *sinv;    // device: the beam-angle table
+    // per-beam results, written by workgroups 1.. and read by workgroup 0 of the same launch: agent-scope atomics only
+    unsigned long long *contrib;       // float2 bits: the point a beam would add to its cluster's centre
+    unsigned long long *cmask;         // per 64 beams: which of them have a contribution
+    unsigned long long *returns_all;   // float2 bits: de-skewed return of beam j (valid beams)
+    float2 *returns;                   // de-skewed point cloud in point_cloud order (GetRangeData)
+    Det2dOut *out;                     // pinned host memory, written in place
+    int *done;                         // device: per-beam workgroups that have published
+#ifdef RDET_DEBUG_MARKS
+    unsigned long long *marks;         // pinned host: [0..15] workgroup 0, [16..31] workgroup 1 (shader clock)
+#endif
 };
+#ifdef RDET_DEBUG_MARKS
+#define DMARK(slot) do { if (threadIdx.x == 0) B.marks[slot] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DMARK(slot) do { } while (0)
+#endif
+
+// ---- inter-workgroup traffic: write-through / cache-bypassing accesses instead of fences (an agent-scope release
+// fence writes the whole L2 back: microseconds on a kernel that lives for ten) ----------------------------------
+__device__ static void publish_u64(unsigned long long *p, unsigned long long v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ static unsigned long long fetch_u64(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ static unsigned long long f2_bits(float2 v)
+{
+    return (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32);
+}
+__device__ static float2 bits_f2(unsigned long long b)
+{
+    return make_float2(__uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32)));
+}
+__device__ static void stores_landed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ---- Rigid2 algebra (rigid_transform.h:46-51,62-67,87-102), no FMA contraction -------------
-__device__ static R2d r2_inverse(R2d r)
+// inverse of r, given c = cos(r.a), s = sin(r.a): cos(-a) = c and sin(-a) = -s exactly
+__device__ static R2d r2_inverse_cs(double c, double s, R2d r)
 {
 #pragma clang fp contract(off)
     R2d o;
-    const double c = cos(-r.a), s = sin(-r.a);
     o.a = -r.a;
-    o.x = -(c * r.x + (-s) * r.y);
-    o.y = -(s * r.x + c * r.y);
+    o.x = -(c * r.x + s * r.y);
+    o.y = -((-s) * r.x + c * r.y);
     return o;
 }
 __device__ static R2d r2_mul_cs(double lc, double ls, R2d l, R2d r)   // l with cos/sin(l.a) given
@@ -115,37 +141,38 @@ __device__ static float2 r2f_apply_cs(float c, float s, float tx, float ty, floa
 }
 __device__ static float2 r2f_apply(R2f r, float px, float py)
 {
-    return r2f_apply_cs(cosf(r.a), sinf(r.a), r.x, r.y, px, py);
+    float s, c;
+    sincosf(r.a, &s, &c);
+    return r2f_apply_cs(c, s, r.x, r.y, px, py);
 }
 
 // ---- PoseExtrapolator (pose_extrapolator.cc:34-84,102-129) ------------------------------------
-__device__ static R2d interpolator(const Odom &st, double time)
+// One straight-line evaluation for both branches of Interpolator (sample before / after `time`): the branches differ
+// in the sign of the velocity terms only, and a - b == a + (-b) exactly, so lanes of a wave never split around the
+// FP64 sincos.  *c_out / *s_out = cos / sin of the returned angle.
+__device__ static R2d extrapolator_pose(const Det2dArgs &A, double time, double *c_out, double *s_out)
 {
 #pragma clang fp contract(off)
-    R2d o;
-    const double odom_yaw = 2 * atan2(st.qz, st.qw);
-    if (st.time <= time) {
-        const double delta_t = st.time - time;
-        const double now_yaw = odom_yaw - st.wz * delta_t;
-        const double c = cos(now_yaw), s = sin(now_yaw);
-        o.x = st.px - st.vx * delta_t * c + st.vy * delta_t * s;
-        o.y = st.py - st.vx * delta_t * s - st.vy * delta_t * c;
-        o.a = now_yaw;
-    } else {
-        const double delta_t = time - st.time;
-        const double now_yaw = odom_yaw - st.wz * delta_t;      // sign as in the reference (Q14)
-        const double c = cos(now_yaw), s = sin(now_yaw);
-        o.x = st.px + st.vx * delta_t * c - st.vy * delta_t * s;
-        o.y = st.py + st.vx * delta_t * s + st.vy * delta_t * c;
-        o.a = now_yaw;
-    }
+    R2d o = {0, 0, 0};
+    *c_out = 1.0; *s_out = 0.0;
+    if (A.n_odom == 0) return o;
+    // time <= front: the first sample; t >= back, or in between: always the LAST sample (:76-82, Q14)
+    const bool uf = time <= A.front.time;
+    const double st_time = uf ? A.front.time : A.back.time, px = uf ? A.front.px : A.back.px, py = uf ? A.front.py : A.back.py;
+    const double yaw = uf ? A.front.yaw : A.back.yaw, vx = uf ? A.front.vx : A.back.vx, vy = uf ? A.front.vy : A.back.vy;
+    const double wz = uf ? A.front.wz : A.back.wz;
+    const bool past = st_time <= time;                               // :36-50, else :51-66
+    const double delta_t = past ? st_time - time : time - st_time;
+    const double now_yaw = yaw - wz * delta_t;                       // sign as in the reference for both (Q14)
+    double s, c;
+    sincos(now_yaw, &s, &c);
+    const double sg = past ? -1.0 : 1.0;
+    const double ax = vx * delta_t, ay = vy * delta_t;
+    o.x = (px + sg * (ax * c)) - sg * (ay * s);
+    o.y = (py + sg * (ax * s)) + sg * (ay * c);
+    o.a = now_yaw;
+    *c_out = c; *s_out = s;
     return o;
-}
-__device__ static R2d extrapolator_pose(const Det2dArgs &A, double time)
-{
-    if (A.n_odom == 0) { R2d id = {0, 0, 0}; return id; }
-    if (time <= A.front.time) return interpolator(A.front, time);
-    return interpolator(A.back, time);    // t >= back, or in between: always the LAST sample (:76-82, Q14)
 }
 
 // ---- block-wide exclusive scans over 1024 per-thread values -----------------------------------
@@ -189,79 +216,221 @@ __device__ static int block_excl_max(int v, int *lds, int *total)
     return (lane == 0) ? base : max(base, prev);
 }
 
-__device__ static float gap_time_and_point(const Det2dArgs &A, const Det2dBufs &B, int j, float2 &p)
+// ================================================================================================
+// One launch per scan.  Workgroup 0 is the run state machine: beams -> runs -> gated clusters, entirely in LDS.
+// Workgroups 1.. own 256 beams each and do everything that does not depend on the runs: the de-skewed return of
+// every valid beam (:246-258) and, for every beam that COULD belong to a cluster (a bright beam, or a finite beam
+// with a bright beam at most three ahead -- the only beams a bridged gap can hold, :111), the point it would add
+// to its cluster's centre (:277-299).  That is all of the FP64 trigonometry, spread over N / 256 CUs.  They publish
+// through `done`; workgroup 0 waits for them once its clusters are known and takes the ordered float32 sums
+// (:300-305), one wave per cluster.  The dependency is one-way (nobody waits for workgroup 0): no deadlock.
+// ================================================================================================
+
+// ---- workgroups 1..: per-beam work.  Waves 0-3 own the beams, wave 4 the halo, wave 5 finds the last valid beam
+// and inverts the scan-end pose, wave 6 finds the first valid beam; the rest only keep the barriers company.
+__device__ static void det2d_beams(const Det2dArgs &A, const Det2dBufs &B, const int blk)
 {
+    __shared__ unsigned char s_bf[RDET2D_GROUP + 8];
+    __shared__ double s_inv[5];
+    __shared__ float s_tb[4];
+    __shared__ int s_edge[2];                       // first / last valid beam of the scan
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, N = A.N;
+    const int j = blk * RDET2D_GROUP + tid, jc = min(j, N - 1);
+    const bool owner = tid < RDET2D_GROUP;
+    if (blk == 0) DMARK(16);
+
+    float rgj = -1.f, itj = 0.f, cvj = 0.f, svj = 0.f, ang_ahead[3] = {0.f, 0.f, 0.f};
+    if (tid < RDET2D_GROUP + 4 && j < N) { rgj = B.ranges[j]; itj = B.intens[j]; }      // (-1 marks "no beam": range_min >= 0)
+    if (owner) {
+        cvj = B.cosv[jc]; svj = B.sinv[jc];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) ang_ahead[d] = B.ang[min(j + 1 + d, N - 1)];
+    }
+    if (wave == 5) {                                 // last valid beam: 64 beams at a time from the end
+        int found = -1;
+        for (int base = N - 1; base >= 0 && found < 0; base -= 64) {
+            const int i = base - lane;
+            const float r = i >= 0 ? B.ranges[i] : -1.f;
+            const unsigned long long m = __ballot(r >= A.msg_range_min && r <= A.msg_range_max);
+            if (m) found = base - (__ffsll((long long)m) - 1);
+        }
+        if (lane == 0) s_edge[1] = found;
+    }
+    if (wave == 6) {                                 // first valid beam
+        int found = 0x7fffffff;
+        for (int base = 0; base < N && found == 0x7fffffff; base += 64) {
+            const int i = base + lane;
+            const float r = i < N ? B.ranges[i] : -1.f;
+            const unsigned long long m = __ballot(r >= A.msg_range_min && r <= A.msg_range_max);
+            if (m) found = base + (__ffsll((long long)m) - 1);
+        }
+        if (lane == 0) s_edge[0] = found;
+    }
+    const bool valid = owner && rgj >= A.msg_range_min && rgj <= A.msg_range_max;                                  // :65
+    const bool cand = j < N && A.opt_range_min <= rgj && rgj <= A.opt_range_max && (double)itj > A.intensity_min;   // :73-75
+    if (tid < RDET2D_GROUP + 4) s_bf[tid] = cand ? 4 : 0;
+    if (blk == 0) DMARK(17);
+    __syncthreads();
+    if (blk == 0) DMARK(18);
+    const int first_valid_all = s_edge[0], last_valid_all = s_edge[1];
+    if (wave == 5 && last_valid_all >= 0) {          // scan-end pose (:252-253, :299) and its inverse
+        double c, s;
+        const R2d mtp = extrapolator_pose(A, (double)(float)(A.first_point_time + last_valid_all * A.point_delta_t), &c, &s);
+        const R2d inv = r2_inverse_cs(c, s, mtp);
+        const R2f tb = r2_cast(inv);
+        float tc, ts;
+        sincosf(tb.a, &ts, &tc);
+        if (lane == 0) {
+            s_inv[0] = inv.x; s_inv[1] = inv.y; s_inv[2] = inv.a; s_inv[3] = c; s_inv[4] = -s;
+            s_tb[0] = tb.x; s_tb[1] = tb.y; s_tb[2] = tc; s_tb[3] = ts;
+        }
+    }
+    const bool bright = owner && cand && first_valid_all <= j;                      // "a point exists" guard (:77)
+    // a gap beam (:115-130) is re-projected from the NEXT bright beam's accumulated angle
+    int ahead = 0;
+    if (owner && !bright && j < N && !isinf(rgj)) {
+#pragma unroll
+        for (int d = 3; d >= 1; --d)
+            if ((s_bf[tid + d] & 4) && first_valid_all <= j + d) ahead = d;
+    }
+    const float tj = (float)(A.first_point_time + j * A.point_delta_t);             // :66 (stored in a Vector3f)
+    R2d pose_j = {0, 0, 0};
+    double pc = 1.0, ps = 0.0;
+    if (wave < RDET2D_GROUP / 64 && last_valid_all >= 0) pose_j = extrapolator_pose(A, (double)tj, &pc, &ps);
+    float2 pt_j = make_float2(0.f, 0.f);
+    if (valid) {
 #pragma clang fp contract(off)
-    // gap beam j (:115-130): re-projected from the NEXT bright beam's accumulated angle
-    int inext = j + 1;
-    while (inext < A.N && !(B.flags[inext] & 2)) ++inext;
-    const float angle_gap = B.ang[inext] - A.angle_increment * (float)(inext - j);
-    const float rg = B.ranges[j];
-    p = r2f_apply_cs(A.s2b_c, A.s2b_s, A.s2b_x, A.s2b_y, rg * cosf(angle_gap), rg * sinf(angle_gap));
-    return (float)(A.first_point_time + j * A.point_delta_t);
+        pt_j = r2f_apply_cs(A.s2b_c, A.s2b_s, A.s2b_x, A.s2b_y, rgj * cvj, rgj * svj);               // :68-70
+    }
+    if (blk == 0) DMARK(19);
+    __syncthreads();
+    if (blk == 0) DMARK(20);
+    bool has = false;
+    if (owner && last_valid_all >= 0) {
+        if (valid) {                                                                // de-skew (:246-258)
+            const R2d inv = {s_inv[0], s_inv[1], s_inv[2]};
+            const R2f rel = r2_cast(r2_mul_cs(s_inv[3], s_inv[4], inv, pose_j));
+            publish_u64(B.returns_all + j, f2_bits(r2f_apply(rel, pt_j.x, pt_j.y)));
+        }
+        float2 p = pt_j;
+        R2d pose_p = pose_j;
+        if (bright) {
+            has = true;
+            if (!valid) {                       // bright beyond the message's own range limits: point_cloud.back() (:87)
+#pragma clang fp contract(off)
+                int lv = j - 1;
+                float rl = 0.f;
+                while (lv >= 0) { rl = B.ranges[lv]; if (rl >= A.msg_range_min && rl <= A.msg_range_max) break; --lv; }
+                p = r2f_apply_cs(A.s2b_c, A.s2b_s, A.s2b_x, A.s2b_y, rl * B.cosv[lv], rl * B.sinv[lv]);
+                double c2, s2;
+                pose_p = extrapolator_pose(A, (double)(float)(A.first_point_time + lv * A.point_delta_t), &c2, &s2);
+            }
+        } else if (ahead) {
+#pragma clang fp contract(off)
+            has = true;
+            const float a_next = ahead == 1 ? ang_ahead[0] : ahead == 2 ? ang_ahead[1] : ang_ahead[2];
+            const float angle_gap = a_next - A.angle_increment * (float)ahead;      // :117
+            float gs, gc;
+            sincosf(angle_gap, &gs, &gc);
+            p = r2f_apply_cs(A.s2b_c, A.s2b_s, A.s2b_x, A.s2b_y, rgj * gc, rgj * gs);
+        }
+        if (has) {
+            const R2f pose = r2_cast(pose_p);                                       // :287,:293
+            const float2 po = r2f_apply(pose, p.x, p.y);
+            publish_u64(B.contrib + j, f2_bits(r2f_apply_cs(s_tb[2], s_tb[3], s_tb[0], s_tb[1], po.x, po.y)));
+        }
+    }
+    if (owner) {
+        const unsigned long long hm = __ballot(has);
+        if (lane == 0 && j < N) publish_u64(B.cmask + (j >> 6), hm);
+    }
+    stores_landed();
+    if (blk == 0) DMARK(21);
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(B.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blk == 0) DMARK(22);
 }
 
-__global__ __launch_bounds__(1024) void k_det2d(Det2dArgs A, Det2dBufs B)
+// ---- workgroup 0: runs, gates, clusters, sums --------------------------------------------------
+__device__ static void det2d_runs(const Det2dArgs &A, const Det2dBufs &B, const int n_beam_groups)
 {
-    __shared__ int lds[1024];
+    __shared__ float s_rg[RDET2D_MAX_BEAMS];
+    __shared__ float2 s_pt[RDET2D_MAX_BEAMS];          // point in base_link (valid beams)
+    __shared__ short s_lv[RDET2D_MAX_BEAMS];           // last valid beam <= i (point_cloud.back() at beam i), -1 if none
+    __shared__ unsigned char s_fl[RDET2D_MAX_BEAMS];   // 1 valid, 2 bright (after the "a point exists" guard), 4 bright before it, 16 intensity above the gate
+    __shared__ short s_rf[RDET2D_MAX_BEAMS / 2 + 4], s_rl[RDET2D_MAX_BEAMS / 2 + 4];   // first / last beam of run r
+    __shared__ int lds[16];
     __shared__ int s_tot[4];
-    __shared__ int s_cl[4 * RDET_MAX_CENTERS + 8];   // cluster segments: first0,last0,first1,last1
-    __shared__ double s_pose[8];                     // max_time_pose (x,y,a), cos/sin of its inverse angle
+    __shared__ int s_cl[4 * RDET_MAX_CENTERS + 8];     // cluster segments: first0,last0,first1,last1
     const int tid = threadIdx.x;
     const int N = A.N;
     const int CH = (N + 1023) / 1024;
     const int b0 = tid * CH, b1 = min(N, b0 + CH);
+    constexpr int MAXCH = RDET2D_MAX_BEAMS / 1024;
+    DMARK(0);
 
-    // ---- pass 1: points, validity, brightness (:63-83).  A thread owns CH <= 8 consecutive beams through
-    // passes 1-3; their inputs and flags stay in registers (all loads of the pass in flight at once).
-    constexpr int MAXCH = 8;
-    float rg[MAXCH], cv[MAXCH], sv[MAXCH], it[MAXCH];
+    // ---- pass 1: points, validity, brightness (:63-83), beam i = tid + 1024 q so that a wave reads whole lines
+    // (the scan is in host memory: every load instruction is a PCIe read of its own)
+    {
+        float rr[MAXCH], ii[MAXCH], cc[MAXCH], ss[MAXCH];
+#pragma unroll
+        for (int q = 0; q < MAXCH; ++q) {
+            const int i = tid + 1024 * q;
+            const bool in = i < N;
+            rr[q] = in ? B.ranges[i] : 0.f; ii[q] = in ? B.intens[i] : 0.f; cc[q] = in ? B.cosv[i] : 0.f; ss[q] = in ? B.sinv[i] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < MAXCH; ++q) {
+#pragma clang fp contract(off)
+            const int i = tid + 1024 * q;
+            if (i >= N) continue;
+            const float range = rr[q];
+            unsigned char f = 0;
+            s_rg[i] = range;
+            if (range >= A.msg_range_min && range <= A.msg_range_max) {
+                f |= 1;
+                s_pt[i] = r2f_apply_cs(A.s2b_c, A.s2b_s, A.s2b_x, A.s2b_y, range * cc[q], range * ss[q]);
+            }
+            if ((double)ii[q] > A.intensity_min) {
+                f |= 16;
+                if (A.opt_range_min <= range && range <= A.opt_range_max) f |= 4;
+            }
+            s_fl[i] = f;
+        }
+    }
+    __syncthreads();
+    DMARK(1);
+    // from here a thread owns CH <= 8 consecutive beams
     unsigned char fl[MAXCH];
     int prevb_r[MAXCH];
-#pragma unroll
-    for (int q = 0; q < MAXCH; ++q) {
-        const int i = b0 + q;
-        const bool in = q < CH && i < b1;
-        rg[q] = in ? B.ranges[i] : 0.f; cv[q] = in ? B.cosv[i] : 0.f; sv[q] = in ? B.sinv[i] : 0.f; it[q] = in ? B.intens[i] : 0.f;
-    }
     int cnt_valid = 0, last_valid = -1;
 #pragma unroll
     for (int q = 0; q < MAXCH; ++q) {
-#pragma clang fp contract(off)
         const int i = b0 + q;
         fl[q] = 0;
         if (q >= CH || i >= b1) continue;
-        const float range = rg[q];
-        unsigned char f = 0;
-        if (range >= A.msg_range_min && range <= A.msg_range_max) {
-            f |= 1;
-            const float nx = range * cv[q], ny = range * sv[q];
-            B.pt[i] = r2f_apply_cs(A.s2b_c, A.s2b_s, A.s2b_x, A.s2b_y, nx, ny);
-            B.pt_t[i] = (float)(A.first_point_time + i * A.point_delta_t);
-            ++cnt_valid; last_valid = i;
-        }
-        if (A.opt_range_min <= range && range <= A.opt_range_max && (double)it[q] > A.intensity_min) f |= 4;
-        fl[q] = f;
+        fl[q] = s_fl[i];
+        if (fl[q] & 1) { ++cnt_valid; last_valid = i; }
     }
     int n_cloud;
     const int cloud_base = block_excl_sum(cnt_valid, lds, &n_cloud);
     int lv = block_excl_max(last_valid, lds, nullptr);
-    // ---- pass 2: point_cloud index / back(), guarded bright flag, previous bright beam
-    int c = cloud_base, last_bright = -1;
+    DMARK(2);
+    // ---- pass 2: point_cloud.back(), guarded bright flag, previous bright beam
+    int last_bright = -1;
 #pragma unroll
     for (int q = 0; q < MAXCH; ++q) {
         const int i = b0 + q;
         if (q >= CH || i >= b1) continue;
         unsigned char f = fl[q];
-        if (f & 1) { B.cloud_idx[i] = c++; lv = i; }
-        B.lastvalid[i] = lv;
+        if (f & 1) lv = i;
+        s_lv[i] = (short)lv;
         if ((f & 4) && lv >= 0) { f |= 2; last_bright = i; }
         fl[q] = f;
-        B.flags[i] = f;
     }
-    __syncthreads();
     int last_bright_all;
     int pb = block_excl_max(last_bright, lds, &last_bright_all);
+    DMARK(3);
     // ---- pass 3: run starts (:85-169) and run index
     int n_start = 0;
     unsigned start_mask = 0;
@@ -270,13 +439,11 @@ __global__ __launch_bounds__(1024) void k_det2d(Det2dArgs A, Det2dBufs B)
         const int i = b0 + q;
         prevb_r[q] = -1;
         if (q >= CH || i >= b1 || !(fl[q] & 2)) continue;
-        B.prevb[i] = pb;
         prevb_r[q] = pb;
         bool start = pb < 0;
         if (!start && i - pb != 1) {
             const int nx = (i + 1 < N) ? i + 1 : i;
-            const bool gap = (i - pb < 4) && (fabs((double)(rg[q] - B.ranges[pb])) < 0.3) &&
-                             ((double)B.intens[nx] > A.intensity_min);                 // :111
+            const bool gap = (i - pb < 4) && (fabs((double)(s_rg[i] - s_rg[pb])) < 0.3) && (s_fl[nx] & 16);   // :111
             start = !gap;
         }
         if (start) start_mask |= 1u << q;
@@ -285,61 +452,63 @@ __global__ __launch_bounds__(1024) void k_det2d(Det2dArgs A, Det2dBufs B)
     }
     int n_runs;
     int rid = block_excl_sum(n_start, lds, &n_runs);
+    DMARK(4);
 #pragma unroll
     for (int q = 0; q < MAXCH; ++q) {
         const int i = b0 + q;
         if (q >= CH || i >= b1 || !(fl[q] & 2)) continue;
         if (start_mask & (1u << q)) {      // start of run `rid`
-            B.run_first[rid] = i;
-            if (prevb_r[q] >= 0) B.run_last[rid - 1] = prevb_r[q];
+            s_rf[rid] = (short)i;
+            if (prevb_r[q] >= 0) s_rl[rid - 1] = (short)prevb_r[q];
             ++rid;
         }
-        B.runid[i] = rid - 1;
     }
-    if (tid == 0 && n_runs > 0) B.run_last[n_runs - 1] = last_bright_all;
+    if (tid == 0 && n_runs > 0) s_rl[n_runs - 1] = (short)last_bright_all;
     __syncthreads();
+    DMARK(5);
 
     // ---- gate the closed runs (:147-156), compact the accepted ones
     const int n_closed = (n_runs > 0) ? n_runs - 1 : 0;
     const int RCH = (n_closed + 1023) / 1024;
     const int r0 = tid * RCH, r1 = min(n_closed, r0 + RCH);
     int n_acc_local = 0;
+    unsigned acc_mask = 0;
     for (int r = r0; r < r1; ++r) {
 #pragma clang fp contract(off)
-        const int fi = B.run_first[r], li = B.run_last[r];
-        const float2 pf = B.pt[B.lastvalid[fi]], pl = B.pt[B.lastvalid[li]];
+        const int fi = s_rf[r], li = s_rl[r];
+        const float2 pf = s_pt[s_lv[fi]], pl = s_pt[s_lv[li]];
         const float len = hypotf(pf.x - pl.x, pf.y - pl.y);
         const bool ok = (A.is_circle && fi == 0) || (fabs((double)len - A.min_length) < A.length_error);
-        B.run_acc[r] = ok ? 1 : 0;
-        n_acc_local += ok ? 1 : 0;
+        if (ok) { acc_mask |= 1u << (r - r0); ++n_acc_local; }
     }
     int n_acc;
     int cidx = block_excl_sum(n_acc_local, lds, &n_acc);
+    DMARK(6);
     for (int r = r0; r < r1; ++r) {
-        if (!B.run_acc[r]) continue;
+        if (!(acc_mask & (1u << (r - r0)))) continue;
         if (cidx < RDET_MAX_CENTERS) {
-            s_cl[4 * cidx + 0] = B.run_first[r]; s_cl[4 * cidx + 1] = B.run_last[r];
+            s_cl[4 * cidx + 0] = s_rf[r]; s_cl[4 * cidx + 1] = s_rl[r];
             s_cl[4 * cidx + 2] = -1; s_cl[4 * cidx + 3] = -1;
         }
         ++cidx;
     }
     __syncthreads();
 
-    // ---- last / first reflector (:178-236) and the scan-end pose, one lane
+    // ---- last / first reflector (:178-236), one lane
     if (tid == 0) {
 #pragma clang fp contract(off)
         int n_cl = n_acc, off = 0, err = 0;
         if (n_acc > RDET_MAX_CENTERS) { err = RDET_ERR_CAPACITY; n_cl = RDET_MAX_CENTERS; }
         if (n_runs > 0 && !err) {
             const int Lr = n_runs - 1;
-            const int lf = B.run_first[Lr], ll = B.run_last[Lr];
-            const float2 last_first_pt = B.pt[B.lastvalid[lf]], last_pt = B.pt[B.lastvalid[ll]];
+            const int lf = s_rf[Lr], ll = s_rl[Lr];
+            const float2 last_first_pt = s_pt[s_lv[lf]], last_pt = s_pt[s_lv[ll]];
             const float len = hypotf(last_first_pt.x - last_pt.x, last_first_pt.y - last_pt.y);
             const bool len_ok = fabs((double)len - A.min_length) < A.length_error;
             if (n_cl > 0) {
                 const int first_id = s_cl[0];
-                const float2 first_pt = B.pt[B.lastvalid[s_cl[0]]];
-                const float2 first_last_pt = B.pt[B.lastvalid[s_cl[1]]];
+                const float2 first_pt = s_pt[s_lv[s_cl[0]]];
+                const float2 first_last_pt = s_pt[s_lv[s_cl[1]]];
                 const float dx = last_pt.x - first_pt.x, dy = last_pt.y - first_pt.y;
                 if (A.is_circle && first_id == 0 && ll == N - 1 && sqrtf(dx * dx + dy * dy) < 0.1) {   // :188-195
                     s_cl[2] = lf; s_cl[3] = ll;
@@ -363,109 +532,84 @@ __global__ __launch_bounds__(1024) void k_det2d(Det2dArgs A, Det2dBufs B)
         if (K < 0) K = 0;
         if (K > A.max_centers) { err = RDET_ERR_BUFFER; K = 0; }
         if (n_cloud == 0) K = 0;
-        s_tot[0] = K; s_tot[1] = off; s_tot[2] = err;
-        // scan-end pose (:252-253, :299)
-        if (n_cloud > 0) {
-            int last_valid_all = N - 1;
-            while (last_valid_all >= 0 && !(B.flags[last_valid_all] & 1)) --last_valid_all;
-            const R2d mtp = extrapolator_pose(A, (double)B.pt_t[last_valid_all]);
-            const R2d inv = r2_inverse(mtp);
-            s_pose[0] = inv.x; s_pose[1] = inv.y; s_pose[2] = inv.a;
-            s_pose[3] = cos(inv.a); s_pose[4] = sin(inv.a);
+        DMARK(7);
+        // the per-beam workgroups' results (bounded wait: a lost workgroup becomes an error, not a hang)
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while (__hip_atomic_load(B.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_beam_groups) {
+            __builtin_amdgcn_s_sleep(1);
+            if (__builtin_readcyclecounter() - t0 > 250000000ull) { err = RDET_ERR_HIP; K = 0; break; }   // ~0.1 s
         }
-        B.out->K = K; B.out->n_returns = n_cloud; B.out->n_runs = n_runs; B.out->err = err;
+        s_tot[0] = K; s_tot[1] = off; s_tot[2] = err;
+        DMARK(8);
     }
     __syncthreads();
-    // hand-over: everything after this point is per beam or per cluster and runs as two wide launches (in this one
-    // workgroup it was FP64 trigonometry for 3600 beams on a single CU: 55 of the kernel's 95 k cycles)
-    Det2dMid *M = B.mid;
-    if (tid == 0) { M->K = s_tot[0]; M->off = s_tot[1]; M->n_cloud = n_cloud; }
-    if (tid < 5) M->inv[tid] = s_pose[tid];
-    for (int q = tid; q < 4 * RDET_MAX_CENTERS + 8; q += 1024) M->seg[q] = s_cl[q];
-}
-
-// ---- per beam: de-skew into the scan-end frame (:246-258) and, for the beams of an accepted cluster, their
-// contribution to the centre (:277-299).  A beam finds its cluster by bisection: the clusters' first segments are in
-// ascending beam order (run order); the wrapped second segment of the first cluster is tested on its own.
-__global__ __launch_bounds__(256) void k_det2d_beams(Det2dArgs A, Det2dBufs B)
-{
-    __shared__ int s_cl[4 * RDET_MAX_CENTERS + 8];
-    const Det2dMid *M = B.mid;
-    const int n_cloud = M->n_cloud;
-    if (n_cloud == 0) return;
-    const int K = M->K, off = M->off, N = A.N;
-    for (int q = threadIdx.x; q < 4 * RDET_MAX_CENTERS + 8; q += 256) s_cl[q] = M->seg[q];
-    const R2d inv = {M->inv[0], M->inv[1], M->inv[2]};
-    const double inv_c = M->inv[3], inv_s = M->inv[4];
-    const R2f to_base = r2_cast(inv);
-    const float tb_c = cosf(to_base.a), tb_s = sinf(to_base.a);
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const int jc = min(j, N - 1);
-    const unsigned char f = B.flags[jc];
-    const int lvj = B.lastvalid[jc], ci = B.cloud_idx[jc];
-    const float rgj = B.ranges[jc], tj = B.pt_t[jc];
-    const float2 pj = B.pt[jc];
-    __syncthreads();
-    if (j >= N) return;
-    if (f & 1) {                                                              // de-skew (:246-258)
-        const R2d pose = extrapolator_pose(A, (double)tj);
-        const R2f rel = r2_cast(r2_mul_cs(inv_c, inv_s, inv, pose));
-        B.returns[ci] = r2f_apply(rel, pj.x, pj.y);
-    }
-    if (K <= 0) return;
-    const int k0 = off, k1 = off + K;
-    bool mem = s_cl[4 * k0 + 2] >= 0 && j >= s_cl[4 * k0 + 2] && j <= s_cl[4 * k0 + 3];
-    if (!mem) {
-        int lo = k0, hi = k1 - 1;                                             // last cluster whose first beam is <= j
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_cl[4 * mid] <= j) lo = mid; else hi = mid - 1; }
-        mem = s_cl[4 * lo] <= j && j <= s_cl[4 * lo + 1];
-    }
-    if (!mem) return;
+    const int K = s_tot[0], off = s_tot[1];
+    DMARK(9);
+    // ---- per cluster: the float32 running sum in beam order that the reference takes (:300-305), one wave per cluster
     {
 #pragma clang fp contract(off)
-        float2 p; float t;
-        if (f & 2) { p = B.pt[lvj]; t = B.pt_t[lvj]; }
-        else if (isinf(rgj)) return;                                          // :120-121
-        else t = gap_time_and_point(A, B, j, p);
-        const R2f pose = r2_cast(extrapolator_pose(A, (double)t));             // :287,:293
-        const float2 po = r2f_apply(pose, p.x, p.y);
-        B.contrib[j] = r2f_apply_cs(tb_c, tb_s, to_base.x, to_base.y, po.x, po.y);
-        B.flags[j] = f | 8;                                                   // contributes (this thread is the beam's only writer)
-    }
-}
-
-// ---- per cluster: the float32 running sum in beam order that the reference takes (:300-305), one wave per cluster
-__global__ __launch_bounds__(256) void k_det2d_sums(Det2dArgs A, Det2dBufs B)
-{
-#pragma clang fp contract(off)
-    const Det2dMid *M = B.mid;
-    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (M->n_cloud == 0 || c >= M->K) return;
-    const int k = c + M->off, N = A.N;
-    float cx = 0.f, cy = 0.f;
-    int count = 0;
-    for (int seg = 0; seg < 2; ++seg) {
-        const int fi = M->seg[4 * k + 2 * seg], li = M->seg[4 * k + 2 * seg + 1];
-        if (fi < 0) continue;
-        for (int j0 = fi; j0 <= li; j0 += 64) {
-            const int j = j0 + lane;
-            const float2 cv2 = B.contrib[min(j, N - 1)];                          // both loads unconditional: one round trip
-            const bool mem = j <= li && (B.flags[min(j, N - 1)] & 8);
-            const float2 v = mem ? cv2 : make_float2(0.f, 0.f);
-            unsigned long long mask = __ballot(mem);
-            count += __popcll(mask);
-            while (mask) {
-                const int b = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                cx += __shfl(v.x, b, 64);
-                cy += __shfl(v.y, b, 64);
+        const int lane = tid & 63;
+        for (int c = tid >> 6; c < K; c += 16) {
+            const int k = c + off;
+            float cx = 0.f, cy = 0.f;
+            int count = 0;
+            for (int seg = 0; seg < 2; ++seg) {
+                const int fi = s_cl[4 * k + 2 * seg], li = s_cl[4 * k + 2 * seg + 1];
+                if (fi < 0) continue;
+                for (int j0 = fi; j0 <= li; j0 += 64) {
+                    const int j = min(j0 + lane, N - 1);
+                    const unsigned long long cb = fetch_u64(B.contrib + j);          // both loads unconditional: one round trip
+                    const unsigned long long mw = fetch_u64(B.cmask + (j >> 6));
+                    const bool mem = j0 + lane <= li && ((mw >> (j & 63)) & 1ull);
+                    const float2 v = mem ? bits_f2(cb) : make_float2(0.f, 0.f);
+                    unsigned long long mask = __ballot(mem);
+                    count += __popcll(mask);
+                    while (mask) {
+                        const int b = __ffsll((long long)mask) - 1;
+                        mask &= mask - 1;
+                        cx += __shfl(v.x, b, 64);
+                        cy += __shfl(v.y, b, 64);
+                    }
+                }
             }
+            if (lane == 0)                                                           // :305, straight into host memory
+                __hip_atomic_store(B.out->centers + c, f2_bits(make_float2(cx / (float)count, cy / (float)count)),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    if (lane == 0) {
-        B.out->centers[2 * c] = cx / (float)count;                               // :305
-        B.out->centers[2 * c + 1] = cy / (float)count;
+    stores_landed();
+    __syncthreads();
+    DMARK(10);
+    if (tid == 0) {
+        __hip_atomic_store(&B.out->head[0], (unsigned long long)(unsigned)K | ((unsigned long long)(unsigned)n_cloud << 32),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&B.out->head[1], (unsigned long long)(unsigned)n_runs | ((unsigned long long)(unsigned)s_tot[2] << 32),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        stores_landed();
+        // the host polls this word: the centres are its to read while this workgroup still compacts the point cloud
+        __hip_atomic_store(&B.out->seq, A.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    // ---- GetRangeData's point cloud: the de-skewed returns in point_cloud order
+    {
+        unsigned long long rv[MAXCH];
+#pragma unroll
+        for (int q = 0; q < MAXCH; ++q) {
+            const int i = b0 + q;
+            rv[q] = (q < CH && i < b1 && (fl[q] & 1) && s_tot[2] != RDET_ERR_HIP) ? fetch_u64(B.returns_all + i) : 0ull;
+        }
+        int c = cloud_base;
+#pragma unroll
+        for (int q = 0; q < MAXCH; ++q)
+            if (q < CH && b0 + q < b1 && (fl[q] & 1)) B.returns[c++] = bits_f2(rv[q]);
+    }
+    if (tid == 0) __hip_atomic_store(B.done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next scan is stream-ordered behind this kernel
+    DMARK(11);
+}
+
+__global__ __launch_bounds__(1024) void k_det2d(Det2dArgs A, Det2dBufs B)
+{
+    if (blockIdx.x == 0) det2d_runs(A, B, (int)gridDim.x - 1);
+    else det2d_beams(A, B, (int)blockIdx.x - 1);
 }
 
 }  // namespace
@@ -478,13 +622,20 @@ struct rdet2d {
     hipStream_t stream;
     std::vector<Odom> odom;            // PoseExtrapolator::odometry_data_
     // device buffers
-    float *d_ranges, *d_intens, *d_ang, *d_cos, *d_sin, *d_pt_t;
-    float2 *d_pt, *d_returns, *d_contrib;
-    int *d_lastvalid, *d_cloud_idx, *d_prevb, *d_runid, *d_run_first, *d_run_last, *d_run_acc;
-    unsigned char *d_flags;
-    Det2dOut *d_out, *h_out;           // h_out pinned
-    Det2dMid *d_mid;
-    float *h_stage;                    // pinned: ranges | intensities | ang | cos | sin
+    float *d_ang, *d_cos, *d_sin;      // beam-angle table
+    float2 *d_returns;
+    unsigned long long *d_returns_all, *d_contrib, *d_cmask;
+    int *d_done;
+    int seq;                           // scans launched; Det2dOut::seq catches up when a scan's centres are in host memory
+    // pinned host memory the kernel reads / writes in place
+    float *h_scan;                     // ranges | intensities
+    Det2dOut *h_out;
+    const float *dv_scan;              // the device's view of h_scan / h_out
+    Det2dOut *dv_out;
+    float *h_table;                    // pinned staging of the beam-angle table: ang | cos | sin
+#ifdef RDET_DEBUG_MARKS
+    unsigned long long *h_marks;
+#endif
     // cached beam-angle table key
     float tab_angle_min, tab_inc;
     int tab_N;
@@ -534,18 +685,21 @@ int rdet2d_create(const rdet2d_options *opt, const double s2b[3], int max_beams,
     int rc = [&]() -> int {
         DET_TRY(h, hipSetDevice(device));
         DET_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-        DET_TRY(h, hipMalloc(&h->d_ranges, 4 * nb)); DET_TRY(h, hipMalloc(&h->d_intens, 4 * nb));
-        DET_TRY(h, hipMalloc(&h->d_ang, 4 * nb)); DET_TRY(h, hipMalloc(&h->d_cos, 4 * nb));
-        DET_TRY(h, hipMalloc(&h->d_sin, 4 * nb)); DET_TRY(h, hipMalloc(&h->d_pt_t, 4 * nb));
-        DET_TRY(h, hipMalloc(&h->d_pt, 8 * nb)); DET_TRY(h, hipMalloc(&h->d_returns, 8 * nb)); DET_TRY(h, hipMalloc(&h->d_contrib, 8 * nb));
-        DET_TRY(h, hipMalloc(&h->d_lastvalid, 4 * nb)); DET_TRY(h, hipMalloc(&h->d_cloud_idx, 4 * nb));
-        DET_TRY(h, hipMalloc(&h->d_prevb, 4 * nb)); DET_TRY(h, hipMalloc(&h->d_runid, 4 * nb));
-        DET_TRY(h, hipMalloc(&h->d_run_first, 4 * nb)); DET_TRY(h, hipMalloc(&h->d_run_last, 4 * nb));
-        DET_TRY(h, hipMalloc(&h->d_run_acc, 4 * nb)); DET_TRY(h, hipMalloc(&h->d_flags, nb));
-        DET_TRY(h, hipMalloc(&h->d_out, sizeof(Det2dOut)));
-        DET_TRY(h, hipMalloc(&h->d_mid, sizeof(Det2dMid)));
-        DET_TRY(h, hipHostMalloc(&h->h_out, sizeof(Det2dOut)));
-        DET_TRY(h, hipHostMalloc(&h->h_stage, 4 * nb * 5));
+        DET_TRY(h, hipMalloc(&h->d_ang, 4 * nb)); DET_TRY(h, hipMalloc(&h->d_cos, 4 * nb)); DET_TRY(h, hipMalloc(&h->d_sin, 4 * nb));
+        DET_TRY(h, hipMalloc(&h->d_returns, 8 * nb)); DET_TRY(h, hipMalloc(&h->d_contrib, 8 * nb));
+        DET_TRY(h, hipMalloc(&h->d_returns_all, 8 * nb)); DET_TRY(h, hipMalloc(&h->d_cmask, 8 * (nb / 64 + 1)));
+        DET_TRY(h, hipMalloc(&h->d_done, sizeof(int)));
+        DET_TRY(h, hipMemset(h->d_done, 0, sizeof(int)));
+        DET_TRY(h, hipHostMalloc(&h->h_scan, 4 * nb * 2, hipHostMallocMapped | hipHostMallocCoherent));
+        DET_TRY(h, hipHostMalloc(&h->h_out, sizeof(Det2dOut), hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(h->h_out, 0, sizeof(Det2dOut));
+        DET_TRY(h, hipHostMalloc(&h->h_table, 4 * nb * 3));
+#ifdef RDET_DEBUG_MARKS
+        DET_TRY(h, hipHostMalloc(&h->h_marks, 8 * 32, hipHostMallocMapped));
+#endif
+        void *dv = nullptr;
+        DET_TRY(h, hipHostGetDevicePointer(&dv, h->h_scan, 0)); h->dv_scan = (const float *)dv;
+        DET_TRY(h, hipHostGetDevicePointer(&dv, h->h_out, 0)); h->dv_out = (Det2dOut *)dv;
         return RDET_OK;
     }();
     if (rc != RDET_OK) { std::fprintf(stderr, "rdet2d_create: %s\n", h->hip_error.c_str()); rdet2d_destroy(h); return rc; }
@@ -558,12 +712,11 @@ void rdet2d_destroy(rdet2d_t *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *ptrs[] = {h->d_ranges, h->d_intens, h->d_ang, h->d_cos, h->d_sin, h->d_pt_t, h->d_pt, h->d_returns, h->d_contrib,
-                    h->d_lastvalid, h->d_cloud_idx, h->d_prevb, h->d_runid, h->d_run_first, h->d_run_last,
-                    h->d_run_acc, h->d_flags, h->d_out, h->d_mid};
+    void *ptrs[] = {h->d_ang, h->d_cos, h->d_sin, h->d_returns, h->d_contrib, h->d_returns_all, h->d_cmask, h->d_done};
     for (void *p : ptrs) (void)hipFree(p);
     if (h->h_out) (void)hipHostFree(h->h_out);
-    if (h->h_stage) (void)hipHostFree(h->h_stage);
+    if (h->h_scan) (void)hipHostFree(h->h_scan);
+    if (h->h_table) (void)hipHostFree(h->h_table);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -579,7 +732,7 @@ int rdet2d_handle_odometry(rdet2d_t *h, double t, const double pos_xy[2], const 
                            double vx, double vy, double wz)
 {
     if (!h || !pos_xy || !quat_zw) return RDET_ERR_INVALID;
-    h->odom.push_back(Odom{t, pos_xy[0], pos_xy[1], quat_zw[0], quat_zw[1], vx, vy, wz});   // pose_extrapolator.cc:28-32
+    h->odom.push_back(Odom{t, pos_xy[0], pos_xy[1], 2 * std::atan2(quat_zw[0], quat_zw[1]), vx, vy, wz});   // pose_extrapolator.cc:28-32, yaw :36
     return RDET_OK;
 }
 
@@ -594,10 +747,11 @@ int rdet2d_handle_scan(rdet2d_t *h, double stamp, float angle_min, float angle_m
     if (obs_time) *obs_time = stamp;                                           // :26 (USE_CORRECT_TIME undefined)
     if (range_min < 0 || range_max <= range_min) return RDET_ERR_BAD_SCAN;      // :27-32
     if (angle_increment < 0.f && angle_max <= angle_min) return RDET_ERR_BAD_SCAN;   // :33-38
+    DET_TRY(h, hipSetDevice(h->device));
+    DET_TRY(h, hipStreamSynchronize(h->stream));          // the previous scan's kernel may still be compacting its point cloud
     h->last_n_returns = 0;
     if (N == 0) return RDET_OK;
-    if (N > h->max_beams || N > 8192) return RDET_ERR_CAPACITY;      // k_det2d: one workgroup, <= 8 beams per thread
-    DET_TRY(h, hipSetDevice(h->device));
+    if (N > h->max_beams || N > RDET2D_MAX_BEAMS) return RDET_ERR_CAPACITY;   // k_det2d: workgroup 0 holds the scan in LDS
 
     Det2dArgs A;
     std::memset(&A, 0, sizeof(A));
@@ -611,6 +765,7 @@ int rdet2d_handle_scan(rdet2d_t *h, double stamp, float angle_min, float angle_m
     A.point_delta_t = (double)(scan_time / (float)N);                           // :49 (float / size_t)
     A.first_point_time = last_point_time - scan_time;                           // :50
     A.N = N;
+    A.seq = ++h->seq;
     A.is_circle = ((angle_max - angle_min - 2 * M_PI) < 1e-6) ? 1 : 0;          // :55
     A.max_centers = max_centers < RDET_MAX_CENTERS ? max_centers : RDET_MAX_CENTERS;
     A.s2b_x = (float)h->s2b[0]; A.s2b_y = (float)h->s2b[1]; A.s2b_a = (float)h->s2b[2];   // :54
@@ -625,14 +780,13 @@ int rdet2d_handle_scan(rdet2d_t *h, double stamp, float angle_min, float angle_m
     A.n_odom = (int)(h->odom.size() > 2 ? 2 : h->odom.size());
     if (!h->odom.empty()) { A.front = h->odom.front(); A.back = h->odom.back(); }
 
-    float *st_r = h->h_stage, *st_i = st_r + h->max_beams;
-    std::memcpy(st_r, ranges, sizeof(float) * (size_t)N);
-    std::memcpy(st_i, intensities, sizeof(float) * (size_t)N);
-    DET_TRY(h, hipMemcpyAsync(h->d_ranges, st_r, sizeof(float) * (size_t)N, hipMemcpyHostToDevice, h->stream));
-    DET_TRY(h, hipMemcpyAsync(h->d_intens, st_i, sizeof(float) * (size_t)N, hipMemcpyHostToDevice, h->stream));
+    // the scan goes into pinned memory the kernel reads in place; the centres come back the same way: one launch and
+    // one stream wait per scan, no copy engine
+    std::memcpy(h->h_scan, ranges, sizeof(float) * (size_t)N);
+    std::memcpy(h->h_scan + h->max_beams, intensities, sizeof(float) * (size_t)N);
     if (h->tab_N != N || h->tab_angle_min != angle_min || h->tab_inc != angle_increment) {
         // beam-angle table: the float32 accumulation of :51/:175 and its cos/sin (:68), host libm
-        float *ta = st_i + h->max_beams, *tc = ta + h->max_beams, *ts = tc + h->max_beams;
+        float *ta = h->h_table, *tc = ta + h->max_beams, *ts = tc + h->max_beams;
         float angle = angle_min;
         for (int i = 0; i < N; ++i) {
             ta[i] = angle; tc[i] = cosf(angle); ts[i] = sinf(angle);
@@ -641,20 +795,39 @@ int rdet2d_handle_scan(rdet2d_t *h, double stamp, float angle_min, float angle_m
         DET_TRY(h, hipMemcpyAsync(h->d_ang, ta, sizeof(float) * (size_t)N, hipMemcpyHostToDevice, h->stream));
         DET_TRY(h, hipMemcpyAsync(h->d_cos, tc, sizeof(float) * (size_t)N, hipMemcpyHostToDevice, h->stream));
         DET_TRY(h, hipMemcpyAsync(h->d_sin, ts, sizeof(float) * (size_t)N, hipMemcpyHostToDevice, h->stream));
-        DET_TRY(h, hipStreamSynchronize(h->stream));     // the staging area is reused by the next scan
         h->tab_N = N; h->tab_angle_min = angle_min; h->tab_inc = angle_increment;
     }
     Det2dBufs B;
-    B.ranges = h->d_ranges; B.intens = h->d_intens; B.ang = h->d_ang; B.cosv = h->d_cos; B.sinv = h->d_sin;
-    B.pt = h->d_pt; B.pt_t = h->d_pt_t; B.lastvalid = h->d_lastvalid; B.cloud_idx = h->d_cloud_idx;
-    B.prevb = h->d_prevb; B.runid = h->d_runid; B.flags = h->d_flags;
-    B.run_first = h->d_run_first; B.run_last = h->d_run_last; B.run_acc = h->d_run_acc;
-    B.returns = h->d_returns; B.contrib = h->d_contrib; B.out = h->d_out; B.mid = h->d_mid;
-    hipLaunchKernelGGL(k_det2d, dim3(1), dim3(1024), 0, h->stream, A, B);
-    hipLaunchKernelGGL(k_det2d_beams, dim3((N + 255) / 256), dim3(256), 0, h->stream, A, B);
-    hipLaunchKernelGGL(k_det2d_sums, dim3(RDET_MAX_CENTERS / 4), dim3(256), 0, h->stream, A, B);
-    DET_TRY(h, hipMemcpyAsync(h->h_out, h->d_out, sizeof(Det2dOut), hipMemcpyDeviceToHost, h->stream));
-    DET_TRY(h, hipStreamSynchronize(h->stream));
+    B.ranges = h->dv_scan; B.intens = h->dv_scan + h->max_beams;
+    B.ang = h->d_ang; B.cosv = h->d_cos; B.sinv = h->d_sin;
+    B.contrib = h->d_contrib; B.cmask = h->d_cmask; B.returns_all = h->d_returns_all; B.returns = h->d_returns;
+    B.out = h->dv_out; B.done = h->d_done;
+#ifdef RDET_DEBUG_MARKS
+    B.marks = h->h_marks;
+#endif
+    hipLaunchKernelGGL(k_det2d, dim3(1 + (N + RDET2D_GROUP - 1) / RDET2D_GROUP), dim3(1024), 0, h->stream, A, B);
+    DET_TRY(h, hipGetLastError());
+    // the kernel writes the centres and then this scan's number into host memory: poll for it instead of waiting for
+    // the completion signal (the kernel's tail -- the point cloud for GetRangeData -- overlaps the caller)
+    {
+        const int *seq_word = &h->h_out->seq;
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (__atomic_load_n(seq_word, __ATOMIC_ACQUIRE) != A.seq) {
+            if ((++spins & 0xfffffu) == 0) {                                      // every few hundred microseconds
+                if (hipStreamQuery(h->stream) != hipErrorNotReady) {              // finished (or failed) without publishing?
+                    DET_TRY(h, hipStreamSynchronize(h->stream));
+                    if (__atomic_load_n(seq_word, __ATOMIC_ACQUIRE) == A.seq) break;
+                    h->hip_error = "k_det2d finished without publishing its result";
+                    return RDET_ERR_HIP;
+                }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+                    h->hip_error = "k_det2d: no result after 5 s";
+                    return RDET_ERR_HIP;
+                }
+            }
+        }
+    }
     h->last_n_returns = h->h_out->n_returns;
     if (h->h_out->err) return h->h_out->err;
     *K = h->h_out->K;
@@ -671,11 +844,20 @@ int rdet2d_get_range_data(rdet2d_t *h, float origin_xy[2], float *returns_xy, in
         if (cap_points < h->last_n_returns) return RDET_ERR_BUFFER;
         if (h->last_n_returns > 0) {
             DET_TRY(h, hipSetDevice(h->device));
+            DET_TRY(h, hipStreamSynchronize(h->stream));
             DET_TRY(h, hipMemcpy(returns_xy, h->d_returns, sizeof(float) * 2 * (size_t)h->last_n_returns,
                                  hipMemcpyDeviceToHost));
         }
     }
     return RDET_OK;
 }
+
+#ifdef RDET_DEBUG_MARKS
+int rdet2d_debug_marks(rdet2d_t *h, unsigned long long *out32)
+{
+    std::memcpy(out32, h->h_marks, 8 * 32);
+    return 0;
+}
+#endif
 
 }  // extern "C"
