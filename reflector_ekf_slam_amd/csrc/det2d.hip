@@ -9,16 +9,22 @@
 //     continues the run   if i - prev == 1                                         (:96-101)
 //     bridges a gap       if i - prev < 4, |r_i - r_prev| < 0.3, beam i+1 bright   (:111-138)
 //     closes the run and starts a new one otherwise                                (:140-169)
-// so one 1024-thread workgroup resolves a whole scan with three block-wide scans
-// (last valid point, previous bright beam, run index), gates all closed runs in parallel
-// (:147-156), resolves the first/last-run wrap logic on one lane (:178-236) and then
-// de-skews every point (:239-270) and averages every accepted cluster in beam order with
-// float32 running sums (:277-306), one lane per cluster.
+// so one 1024-thread workgroup resolves the runs of a whole scan in LDS with five block-wide scans
+// (valid count, last valid point, previous bright beam, run index, accepted-run index), gates all
+// closed runs in parallel (:147-156) and resolves the first/last-run wrap logic on one lane
+// (:178-236), while N/256 other workgroups of the SAME launch de-skew every point (:239-270) and
+// compute what every candidate beam would add to a centre; workgroup 0 then averages each accepted
+// cluster in beam order with float32 running sums (:277-306), one wave per cluster.
+//
+// I/O per scan: the host writes ranges/intensities straight into fine-grained device memory (PCIe
+// BAR, posted writes), launches ONE kernel, and polls a tagged 16-byte slot in pinned host memory
+// that the kernel stores the centres into -- no copy engine, no completion-signal wait.
 //
 // cos/sin of the float32-accumulated beam angle (Q15, :51,:175) come from a table the host
-// fills with the same libm the reference would call, so run membership and gating see the
-// same float32 points as a CPU build.  Everything is float32 where the reference is
-// (geometry, point time stored in a Vector3f) and FP64 where it is (poses, odometry).
+// fills with the same libm the reference would call, as does the odometry yaw 2 atan2(q.z, q.w),
+// so run membership and gating see the same float32 points as a CPU build.  Everything is float32
+// where the reference is (geometry, point time stored in a Vector3f) and FP64 where it is (poses,
+// odometry).
 #include "../../include/rdet.h"
 
 #include <hip/hip_runtime.h>
@@ -58,10 +64,15 @@ struct Det2dArgs {
     Odom front, back;
 };
 
-struct Det2dOut {                  // written by the kernel with system-scope stores only (plain stores would sit in L2 until it ends)
-    union { struct { int K, n_returns, n_runs, err; }; unsigned long long head[2]; };
-    unsigned long long centers[RDET_MAX_CENTERS];   // float2 bits (x in the low word): written with one 8-byte store each
-    int seq;
+// What the kernel hands back, in pinned host memory.  Every slot is ONE 16-byte system-scope store that carries the
+// scan's number, so the kernel never waits for a PCIe write to be acknowledged and the host never needs an ordering
+// between slots: it polls head.seq, then takes each centre once that centre's own tag has arrived.
+struct Det2dSlot { float x, y; int seq, pad; };
+struct Det2dHead { int K, n_returns, runs_err, seq; };      // runs_err = n_runs | (-err) << 16
+struct Det2dOut {
+    Det2dHead head;
+    Det2dSlot centers[RDET_MAX_CENTERS];
+    int fin, pad[3];               // = Det2dArgs::seq once the kernel has nothing left to write
 };
 
 #define RDET2D_MAX_BEAMS 8192             // workgroup 0 holds a whole scan in LDS (17 B per beam)
@@ -106,6 +117,13 @@ __device__ static float2 bits_f2(unsigned long long b)
     return make_float2(__uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32)));
 }
 __device__ static void stores_landed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// one 16-byte write-through store to host memory (a single PCIe write: the tag in .w lands with the payload)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ static void host_store16(void *p, unsigned a, unsigned b, unsigned c, unsigned d)
+{
+    const u32x4 v = {a, b, c, d};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
 
 // ---- Rigid2 algebra (rigid_transform.h:46-51,62-67,87-102), no FMA contraction -------------
 // inverse of r, given c = cos(r.a), s = sin(r.a): cos(-a) = c and sin(-a) = -s exactly
@@ -176,44 +194,48 @@ __device__ static R2d extrapolator_pose(const Det2dArgs &A, double time, double 
 }
 
 // ---- block-wide exclusive scans over 1024 per-thread values -----------------------------------
-// in-wave scan by shuffles (no barrier), the 16 wave totals through LDS: two barriers per scan instead of
-// the twenty of a Hillis-Steele scan over 1024 LDS slots
+// in-wave inclusive scan by six DPP steps (row shifts 1/2/4/8, then row_bcast:15 / row_bcast:31 across the rows of 16),
+// the 16 wave totals through an LDS slot that each scan of the kernel uses once: ONE barrier per scan
+struct ScanSum { static constexpr int id = 0; __device__ static int f(int a, int b) { return a + b; } };
+struct ScanMax { static constexpr int id = -1; __device__ static int f(int a, int b) { return max(a, b); } };   // values >= -1
+template <class Op, int CTRL, int ROW_MASK> __device__ static int dpp_step(int v)
+{
+    return Op::f(v, __builtin_amdgcn_update_dpp(Op::id, v, CTRL, ROW_MASK, 0xf, false));
+}
+template <class Op> __device__ static int wave_incl_scan(int v)
+{
+    v = dpp_step<Op, 0x111, 0xf>(v);        // row_shr:1
+    v = dpp_step<Op, 0x112, 0xf>(v);        // row_shr:2
+    v = dpp_step<Op, 0x114, 0xf>(v);        // row_shr:4
+    v = dpp_step<Op, 0x118, 0xf>(v);        // row_shr:8
+    v = dpp_step<Op, 0x142, 0xa>(v);        // row_bcast:15 into rows 1 and 3
+    v = dpp_step<Op, 0x143, 0xc>(v);        // row_bcast:31 into rows 2 and 3
+    return v;
+}
 __device__ static int block_excl_sum(int v, int *lds, int *total)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
-    }
+    const int incl = wave_incl_scan<ScanSum>(v);
     if (lane == 63) lds[wave] = incl;
     __syncthreads();
     int base = 0, tot = 0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) { const int c = lds[w]; if (w < wave) base += c; tot += c; }
     if (total) *total = tot;
-    __syncthreads();
     return base + incl - v;
 }
 __device__ static int block_excl_max(int v, int *lds, int *total)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl = max(incl, t);
-    }
+    const int incl = wave_incl_scan<ScanMax>(v);
     if (lane == 63) lds[wave] = incl;
     __syncthreads();
     int base = -1, tot = -1;
 #pragma unroll
     for (int w = 0; w < 16; ++w) { const int c = lds[w]; if (w < wave) base = max(base, c); tot = max(tot, c); }
     if (total) *total = tot;
-    __syncthreads();
-    const int prev = __shfl_up(incl, 1, 64);                    // inclusive value of the previous lane
-    return (lane == 0) ? base : max(base, prev);
+    const int prev = __builtin_amdgcn_update_dpp(-1, incl, 0x138, 0xf, 0xf, false);   // wave_shr:1: inclusive value of the previous lane
+    return max(base, prev);
 }
 
 // ================================================================================================
@@ -359,7 +381,7 @@ __device__ static void det2d_runs(const Det2dArgs &A, const Det2dBufs &B, const 
     __shared__ short s_lv[RDET2D_MAX_BEAMS];           // last valid beam <= i (point_cloud.back() at beam i), -1 if none
     __shared__ unsigned char s_fl[RDET2D_MAX_BEAMS];   // 1 valid, 2 bright (after the "a point exists" guard), 4 bright before it, 16 intensity above the gate
     __shared__ short s_rf[RDET2D_MAX_BEAMS / 2 + 4], s_rl[RDET2D_MAX_BEAMS / 2 + 4];   // first / last beam of run r
-    __shared__ int lds[16];
+    __shared__ int lds_scan[5][16];                    // one slot per block scan (no barrier to recycle it)
     __shared__ int s_tot[4];
     __shared__ int s_cl[4 * RDET_MAX_CENTERS + 8];     // cluster segments: first0,last0,first1,last1
     const int tid = threadIdx.x;
@@ -413,8 +435,8 @@ __device__ static void det2d_runs(const Det2dArgs &A, const Det2dBufs &B, const 
         if (fl[q] & 1) { ++cnt_valid; last_valid = i; }
     }
     int n_cloud;
-    const int cloud_base = block_excl_sum(cnt_valid, lds, &n_cloud);
-    int lv = block_excl_max(last_valid, lds, nullptr);
+    const int cloud_base = block_excl_sum(cnt_valid, lds_scan[0], &n_cloud);
+    int lv = block_excl_max(last_valid, lds_scan[1], nullptr);
     DMARK(2);
     // ---- pass 2: point_cloud.back(), guarded bright flag, previous bright beam
     int last_bright = -1;
@@ -429,7 +451,7 @@ __device__ static void det2d_runs(const Det2dArgs &A, const Det2dBufs &B, const 
         fl[q] = f;
     }
     int last_bright_all;
-    int pb = block_excl_max(last_bright, lds, &last_bright_all);
+    int pb = block_excl_max(last_bright, lds_scan[2], &last_bright_all);
     DMARK(3);
     // ---- pass 3: run starts (:85-169) and run index
     int n_start = 0;
@@ -451,7 +473,7 @@ __device__ static void det2d_runs(const Det2dArgs &A, const Det2dBufs &B, const 
         pb = i;
     }
     int n_runs;
-    int rid = block_excl_sum(n_start, lds, &n_runs);
+    int rid = block_excl_sum(n_start, lds_scan[3], &n_runs);
     DMARK(4);
 #pragma unroll
     for (int q = 0; q < MAXCH; ++q) {
@@ -482,7 +504,7 @@ __device__ static void det2d_runs(const Det2dArgs &A, const Det2dBufs &B, const 
         if (ok) { acc_mask |= 1u << (r - r0); ++n_acc_local; }
     }
     int n_acc;
-    int cidx = block_excl_sum(n_acc_local, lds, &n_acc);
+    int cidx = block_excl_sum(n_acc_local, lds_scan[4], &n_acc);
     DMARK(6);
     for (int r = r0; r < r1; ++r) {
         if (!(acc_mask & (1u << (r - r0)))) continue;
@@ -545,50 +567,59 @@ __device__ static void det2d_runs(const Det2dArgs &A, const Det2dBufs &B, const 
     __syncthreads();
     const int K = s_tot[0], off = s_tot[1];
     DMARK(9);
-    // ---- per cluster: the float32 running sum in beam order that the reference takes (:300-305), one wave per cluster
+    // ---- per cluster: the float32 running sum in beam order that the reference takes (:300-305), one wave per cluster.
+    // A wave first requests the leading 64 beams of up to four of its clusters (one memory round trip for a scan of
+    // <= 64 reflectors), then adds them up; longer clusters and the wrapped segment fetch on demand.
     {
 #pragma clang fp contract(off)
-        const int lane = tid & 63;
-        for (int c = tid >> 6; c < K; c += 16) {
-            const int k = c + off;
-            float cx = 0.f, cy = 0.f;
-            int count = 0;
-            for (int seg = 0; seg < 2; ++seg) {
-                const int fi = s_cl[4 * k + 2 * seg], li = s_cl[4 * k + 2 * seg + 1];
-                if (fi < 0) continue;
-                for (int j0 = fi; j0 <= li; j0 += 64) {
-                    const int j = min(j0 + lane, N - 1);
-                    const unsigned long long cb = fetch_u64(B.contrib + j);          // both loads unconditional: one round trip
-                    const unsigned long long mw = fetch_u64(B.cmask + (j >> 6));
-                    const bool mem = j0 + lane <= li && ((mw >> (j & 63)) & 1ull);
-                    const float2 v = mem ? bits_f2(cb) : make_float2(0.f, 0.f);
-                    unsigned long long mask = __ballot(mem);
-                    count += __popcll(mask);
-                    while (mask) {
-                        const int b = __ffsll((long long)mask) - 1;
-                        mask &= mask - 1;
-                        cx += __shfl(v.x, b, 64);
-                        cy += __shfl(v.y, b, 64);
-                    }
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int c0 = wave; c0 < K; c0 += 64) {
+            unsigned long long cb0[4], mw0[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + 16 * u;
+                cb0[u] = 0; mw0[u] = 0;
+                if (c < K) {
+                    const int j = min(s_cl[4 * (c + off)] + lane, N - 1);
+                    cb0[u] = fetch_u64(B.contrib + j);
+                    mw0[u] = fetch_u64(B.cmask + (j >> 6));
                 }
             }
-            if (lane == 0)                                                           // :305, straight into host memory
-                __hip_atomic_store(B.out->centers + c, f2_bits(make_float2(cx / (float)count, cy / (float)count)),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + 16 * u;
+                if (c >= K) continue;
+                const int k = c + off;
+                float cx = 0.f, cy = 0.f;
+                int count = 0;
+                for (int seg = 0; seg < 2; ++seg) {
+                    const int fi = s_cl[4 * k + 2 * seg], li = s_cl[4 * k + 2 * seg + 1];
+                    if (fi < 0) continue;
+                    for (int j0 = fi; j0 <= li; j0 += 64) {
+                        const int j = min(j0 + lane, N - 1);
+                        const bool pre = seg == 0 && j0 == fi;
+                        const unsigned long long cb = pre ? cb0[u] : fetch_u64(B.contrib + j);
+                        const unsigned long long mw = pre ? mw0[u] : fetch_u64(B.cmask + (j >> 6));
+                        const bool mem = j0 + lane <= li && ((mw >> (j & 63)) & 1ull);
+                        const float2 v = mem ? bits_f2(cb) : make_float2(0.f, 0.f);
+                        unsigned long long mask = __ballot(mem);
+                        count += __popcll(mask);
+                        while (mask) {                      // (the ballot is wave-uniform: scalar loop, v_readlane)
+                            const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)mask) - 1);
+                            mask &= mask - 1;
+                            cx += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.x), b));
+                            cy += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.y), b));
+                        }
+                    }
+                }
+                if (lane == 0)                                                       // :305, straight into host memory
+                    host_store16(B.out->centers + c, __float_as_uint(cx / (float)count), __float_as_uint(cy / (float)count), (unsigned)A.seq, 0u);
+            }
         }
     }
-    stores_landed();
-    __syncthreads();
     DMARK(10);
-    if (tid == 0) {
-        __hip_atomic_store(&B.out->head[0], (unsigned long long)(unsigned)K | ((unsigned long long)(unsigned)n_cloud << 32),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&B.out->head[1], (unsigned long long)(unsigned)n_runs | ((unsigned long long)(unsigned)s_tot[2] << 32),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        stores_landed();
-        // the host polls this word: the centres are its to read while this workgroup still compacts the point cloud
-        __hip_atomic_store(&B.out->seq, A.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (tid == 0)      // the host polls head.seq: the centres are its to read while this workgroup still compacts the point cloud
+        host_store16(&B.out->head, (unsigned)K, (unsigned)n_cloud, (unsigned)n_runs | ((unsigned)(-s_tot[2]) << 16), (unsigned)A.seq);
     // ---- GetRangeData's point cloud: the de-skewed returns in point_cloud order
     {
         unsigned long long rv[MAXCH];
@@ -602,7 +633,13 @@ __device__ static void det2d_runs(const Det2dArgs &A, const Det2dBufs &B, const 
         for (int q = 0; q < MAXCH; ++q)
             if (q < CH && b0 + q < b1 && (fl[q] & 1)) B.returns[c++] = bits_f2(rv[q]);
     }
-    if (tid == 0) __hip_atomic_store(B.done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next scan is stream-ordered behind this kernel
+    stores_landed();
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_store(B.done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stores_landed();
+        __hip_atomic_store(&B.out->fin, A.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (the per-beam workgroups were done before the sums)
+    }
     DMARK(11);
 }
 
@@ -628,7 +665,9 @@ struct rdet2d {
     int *d_done;
     int seq;                           // scans launched; Det2dOut::seq catches up when a scan's centres are in host memory
     // pinned host memory the kernel reads / writes in place
-    float *h_scan;                     // ranges | intensities
+    float *h_scan;                     // ranges | intensities: where the host writes a scan.  Fine-grained DEVICE memory through
+                                       // the PCIe BAR when the platform maps it (posted writes, the kernel then reads HBM), else pinned host memory
+    bool scan_in_vram;
     Det2dOut *h_out;
     const float *dv_scan;              // the device's view of h_scan / h_out
     Det2dOut *dv_out;
@@ -690,7 +729,16 @@ int rdet2d_create(const rdet2d_options *opt, const double s2b[3], int max_beams,
         DET_TRY(h, hipMalloc(&h->d_returns_all, 8 * nb)); DET_TRY(h, hipMalloc(&h->d_cmask, 8 * (nb / 64 + 1)));
         DET_TRY(h, hipMalloc(&h->d_done, sizeof(int)));
         DET_TRY(h, hipMemset(h->d_done, 0, sizeof(int)));
-        DET_TRY(h, hipHostMalloc(&h->h_scan, 4 * nb * 2, hipHostMallocMapped | hipHostMallocCoherent));
+        if (hipExtMallocWithFlags((void **)&h->h_scan, 4 * nb * 2, hipDeviceMallocFinegrained) == hipSuccess) {
+            h->scan_in_vram = true;
+            h->dv_scan = h->h_scan;
+        } else {
+            (void)hipGetLastError();
+            h->scan_in_vram = false;
+            DET_TRY(h, hipHostMalloc(&h->h_scan, 4 * nb * 2, hipHostMallocMapped | hipHostMallocCoherent));
+            void *dvs = nullptr;
+            DET_TRY(h, hipHostGetDevicePointer(&dvs, h->h_scan, 0)); h->dv_scan = (const float *)dvs;
+        }
         DET_TRY(h, hipHostMalloc(&h->h_out, sizeof(Det2dOut), hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(h->h_out, 0, sizeof(Det2dOut));
         DET_TRY(h, hipHostMalloc(&h->h_table, 4 * nb * 3));
@@ -698,7 +746,6 @@ int rdet2d_create(const rdet2d_options *opt, const double s2b[3], int max_beams,
         DET_TRY(h, hipHostMalloc(&h->h_marks, 8 * 32, hipHostMallocMapped));
 #endif
         void *dv = nullptr;
-        DET_TRY(h, hipHostGetDevicePointer(&dv, h->h_scan, 0)); h->dv_scan = (const float *)dv;
         DET_TRY(h, hipHostGetDevicePointer(&dv, h->h_out, 0)); h->dv_out = (Det2dOut *)dv;
         return RDET_OK;
     }();
@@ -715,7 +762,7 @@ void rdet2d_destroy(rdet2d_t *h)
     void *ptrs[] = {h->d_ang, h->d_cos, h->d_sin, h->d_returns, h->d_contrib, h->d_returns_all, h->d_cmask, h->d_done};
     for (void *p : ptrs) (void)hipFree(p);
     if (h->h_out) (void)hipHostFree(h->h_out);
-    if (h->h_scan) (void)hipHostFree(h->h_scan);
+    if (h->h_scan) { if (h->scan_in_vram) (void)hipFree(h->h_scan); else (void)hipHostFree(h->h_scan); }
     if (h->h_table) (void)hipHostFree(h->h_table);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -748,7 +795,8 @@ int rdet2d_handle_scan(rdet2d_t *h, double stamp, float angle_min, float angle_m
     if (range_min < 0 || range_max <= range_min) return RDET_ERR_BAD_SCAN;      // :27-32
     if (angle_increment < 0.f && angle_max <= angle_min) return RDET_ERR_BAD_SCAN;   // :33-38
     DET_TRY(h, hipSetDevice(h->device));
-    DET_TRY(h, hipStreamSynchronize(h->stream));          // the previous scan's kernel may still be compacting its point cloud
+    if (__atomic_load_n(&h->h_out->fin, __ATOMIC_ACQUIRE) != h->seq)   // the previous scan's kernel may still be compacting its point cloud
+        DET_TRY(h, hipStreamSynchronize(h->stream));
     h->last_n_returns = 0;
     if (N == 0) return RDET_OK;
     if (N > h->max_beams || N > RDET2D_MAX_BEAMS) return RDET_ERR_CAPACITY;   // k_det2d: workgroup 0 holds the scan in LDS
@@ -780,10 +828,18 @@ int rdet2d_handle_scan(rdet2d_t *h, double stamp, float angle_min, float angle_m
     A.n_odom = (int)(h->odom.size() > 2 ? 2 : h->odom.size());
     if (!h->odom.empty()) { A.front = h->odom.front(); A.back = h->odom.back(); }
 
+#ifdef RDET_DEBUG_MARKS
+    const auto dbg_t0 = std::chrono::steady_clock::now();
+    auto dbg_ns = [&]() { return (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - dbg_t0).count(); };
+#endif
     // the scan goes into pinned memory the kernel reads in place; the centres come back the same way: one launch and
     // one stream wait per scan, no copy engine
     std::memcpy(h->h_scan, ranges, sizeof(float) * (size_t)N);
     std::memcpy(h->h_scan + h->max_beams, intensities, sizeof(float) * (size_t)N);
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);              // write-combined stores drained before the doorbell
+#ifdef RDET_DEBUG_MARKS
+    h->h_marks[24] = dbg_ns();
+#endif
     if (h->tab_N != N || h->tab_angle_min != angle_min || h->tab_inc != angle_increment) {
         // beam-angle table: the float32 accumulation of :51/:175 and its cos/sin (:68), host libm
         float *ta = h->h_table, *tc = ta + h->max_beams, *ts = tc + h->max_beams;
@@ -807,10 +863,13 @@ int rdet2d_handle_scan(rdet2d_t *h, double stamp, float angle_min, float angle_m
 #endif
     hipLaunchKernelGGL(k_det2d, dim3(1 + (N + RDET2D_GROUP - 1) / RDET2D_GROUP), dim3(1024), 0, h->stream, A, B);
     DET_TRY(h, hipGetLastError());
+#ifdef RDET_DEBUG_MARKS
+    h->h_marks[25] = dbg_ns();
+#endif
     // the kernel writes the centres and then this scan's number into host memory: poll for it instead of waiting for
     // the completion signal (the kernel's tail -- the point cloud for GetRangeData -- overlaps the caller)
     {
-        const int *seq_word = &h->h_out->seq;
+        const int *seq_word = &h->h_out->head.seq;
         const auto t0 = std::chrono::steady_clock::now();
         unsigned spins = 0;
         while (__atomic_load_n(seq_word, __ATOMIC_ACQUIRE) != A.seq) {
@@ -828,10 +887,24 @@ int rdet2d_handle_scan(rdet2d_t *h, double stamp, float angle_min, float angle_m
             }
         }
     }
-    h->last_n_returns = h->h_out->n_returns;
-    if (h->h_out->err) return h->h_out->err;
-    *K = h->h_out->K;
-    if (*K > 0) std::memcpy(centers_xy, h->h_out->centers, sizeof(float) * 2 * (size_t)*K);
+#ifdef RDET_DEBUG_MARKS
+    h->h_marks[26] = dbg_ns();
+#endif
+    const Det2dHead head = h->h_out->head;
+    h->last_n_returns = head.n_returns;
+    const int err = -(head.runs_err >> 16);
+    if (err) return err;
+    *K = head.K;
+    for (int c = 0; c < head.K; ++c) {
+        const Det2dSlot *slot = &h->h_out->centers[c];
+        unsigned spins = 0;
+        while (__atomic_load_n(&slot->seq, __ATOMIC_ACQUIRE) != A.seq)
+            if (++spins > 200000000u) { h->hip_error = "k_det2d: a centre never arrived"; return RDET_ERR_HIP; }
+        centers_xy[2 * c] = slot->x; centers_xy[2 * c + 1] = slot->y;
+    }
+#ifdef RDET_DEBUG_MARKS
+    h->h_marks[27] = (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - dbg_t0).count();
+#endif
     return RDET_OK;
 }
 

@@ -1,6 +1,6 @@
 """In-kernel timeline of k_det2d (workgroup 0 = runs, workgroup 1 = first beam group) from a -DRDET_DEBUG_MARKS build:
   make -C reflector_ekf_slam_amd/csrc -B ../librdet.so HIPFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -DRDET_DEBUG_MARKS"
-GPU box: python scripts/gpu_dbg_det2d.py [beams]   (marks are the 100 MHz counter: 10 ns steps)"""
+GPU box: python scripts/gpu_dbg_det2d.py [beams]   (marks: shader-clock counter; host stamps in ns)"""
 import ctypes as C, sys
 sys.path.insert(0, ".")
 from types import SimpleNamespace as NS
@@ -24,5 +24,7 @@ for rep in range(6):
         g.HandleLaserScan(scan)
     m = (C.c_ulonglong * 32)(); g._L.rdet2d_debug_marks(g._h, m)
     m = list(m); t0 = min(m[0], m[16])
-    print("runs  wg:", [round((x - t0) * 0.01, 2) for x in m[0:11]], "us")
-    print("beams wg:", [round((x - t0) * 0.01, 2) for x in m[16:23]], "us")
+    ghz = 2.4                                                     # shader clock assumed for the conversion
+    print("runs  wg:", [round((x - m[0]) / ghz * 1e-3, 2) for x in m[0:12]], "us")
+    print("beams wg:", [round((x - m[16]) / ghz * 1e-3, 2) for x in m[16:23]], "us (own clock)")
+    print("host: scan written %.2f, launched %.2f, head seen %.2f, centres out %.2f us" % tuple(x * 1e-3 for x in m[24:28]))
