@@ -29,6 +29,7 @@
 //   * more than 32 matched pairs: block-sequential form of the same joint update.
 #include "ekf_dev.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -111,6 +112,10 @@ __device__ static void corner_predict(double *P, int ld, const Motion &mo)
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j)
             P[i + (size_t)j * ld] += mo.V[i * 3 + j];
+    // the stored covariance is EXACTLY symmetric (k_downdate2 computes the lower triangle and mirrors it): the upper
+    // elements take the lower ones' bits (the reference's two differ in the last place at most)
+    for (int i = 0; i < 3; ++i)
+        for (int j = i + 1; j < 3; ++j) P[i + (size_t)j * ld] = P[j + (size_t)i * ld];
 }
 
 __device__ static void obs_to_global(double x, double y, double c, double s, float px, float py,
@@ -1298,7 +1303,14 @@ template <int N> __device__ static inline void dd_wait_vmcnt()
 #else
 #define DD_STORE(p, v) (*(p) = (v))
 #endif
-template <int KC>
+// SYM (the product path): the update K (H P) is symmetric, so only the tiles on and below the diagonal are computed --
+// half the MFMA work, half the P reads -- and an off-diagonal tile is written twice, as P(I,J) and transposed as P(J,I).
+// The transposed image needs no LDS: a lane holds rows (r, r+1) x columns (c + 8t + {0,1}), t < 4, of its block, so the
+// two columns of a pair are adjacent in the image and {pq[t].e, pq[t+4].e} is one 16-byte store (64 contiguous bytes
+// per 4 lanes).  A diagonal tile is computed in full as before (its own lower / upper halves are not forced equal) and
+// issues its normal stores twice, so that every tile has the same VMEM count (the s_waitcnt bookkeeping is static).
+// P therefore holds exactly mirrored off-diagonal tiles; the reference's (I - K H) P differs from that in the last bit only.
+template <int KC, bool SYM>
 __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
 {
     extern __shared__ __attribute__((aligned(16))) double dd_smem[];   // [Kn 0 | Kn 1 | HPt 0 | HPt 1] panels (+ 16 KiB strip scratch if KC < 64)
@@ -1332,13 +1344,16 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     const bool strips = rem > 0 && rem <= DD_STRIP_MAX && n >= DT;
     const int T = strips ? n / DT : (n + DT - 1) / DT;
     int i_lo = 0, i_n = T, j_lo = 0, j_n = T, w = blockIdx.x, nw = gridDim.x;
-    if (gridDim.x >= 8 && (gridDim.x & 7) == 0) {           // per-XCD 2 x 4 tile regions (see downdate_body)
+    if (SYM) {
+        // the triangle column by column (tile column J: I = J .. T-1); an XCD's workgroups take consecutive ranges of it
+        if (gridDim.x >= 8 && (gridDim.x & 7) == 0) w = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    } else if (gridDim.x >= 8 && (gridDim.x & 7) == 0) {    // per-XCD 2 x 4 tile regions (see downdate_body)
         const int x = blockIdx.x & 7, ri = x >> 2, rj = x & 3;
         i_lo = ri * T / 2; i_n = (ri + 1) * T / 2 - i_lo;
         j_lo = rj * T / 4; j_n = (rj + 1) * T / 4 - j_lo;
         w = blockIdx.x >> 3; nw = gridDim.x >> 3;
     }
-    const int ntiles = i_n * j_n;
+    const int ntiles = SYM ? T * (T + 1) / 2 : i_n * j_n;
     const int t_begin = (int)(((long long)w * ntiles) / nw);
     const int t_end = (int)(((long long)(w + 1) * ntiles) / nw);
     if (t_begin >= t_end) return;
@@ -1353,8 +1368,34 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
 
     // a diagonal tile of the range is taken LAST (its strip work then rides on a tile that has nothing to prefetch);
     // should a range ever hold more than one, the others are still handled where they stand (`special` below)
+    auto tri_col = [&](int Jc) __attribute__((always_inline)) -> int { return Jc * T - (Jc * (Jc - 1)) / 2; };   // first tile of column Jc
+    auto tri_IJ = [&](int tt, int &It, int &Jt) __attribute__((always_inline)) {
+        const float b = 2.0f * (float)T + 1.0f;
+        int Jg = (int)((b - sqrtf(b * b - 8.0f * (float)tt)) * 0.5f);
+        Jg = max(0, min(T - 1, Jg));
+        while (Jg + 1 < T && tri_col(Jg + 1) <= tt) ++Jg;
+        while (Jg > 0 && tri_col(Jg) > tt) --Jg;
+        Jt = Jg; It = Jg + (tt - tri_col(Jg));
+    };
+    // SYM order of the tiles: the triangle column by column, except that the last diagonal tile (T-1,T-1) is moved from the
+    // end to the middle of column 0: a diagonal tile costs more than the others, and the tail of the list would otherwise put
+    // two of them -- (T-2,T-2) and (T-1,T-1) -- into one workgroup's range.
+    const int sym_ins = (T >= 4) ? T / 2 : -1;
+    auto sym_IJ = [&](int tt, int &It, int &Jt) __attribute__((always_inline)) {
+        if (sym_ins >= 0) {
+            if (tt == sym_ins) { It = T - 1; Jt = T - 1; return; }
+            if (tt > sym_ins) tt -= 1;
+        }
+        tri_IJ(tt, It, Jt);
+    };
     int t_diag = t_end - 1;
-    if (strips) {
+    if (SYM) {                                              // a diagonal tile of the range goes last (the last one, should there be several)
+        for (int t = t_begin; t < t_end; ++t) {
+            int It, Jt;
+            sym_IJ(t, It, Jt);
+            if (It == Jt) t_diag = t;
+        }
+    } else if (strips) {
         const int dl = j_lo - i_lo;
         for (int jj = t_begin / i_n; jj <= (t_end - 1) / i_n; ++jj) {
             const int ii = jj + dl, t = jj * i_n + ii;
@@ -1364,6 +1405,7 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     auto tile_IJ = [&](int pos, int &I, int &J) __attribute__((always_inline)) {
         const int tile = t_begin + pos;
         const int tt = (tile == t_end - 1) ? t_diag : ((tile == t_diag) ? t_end - 1 : tile);
+        if (SYM) { sym_IJ(tt, I, J); return; }
         const int jj = tt / i_n;
         I = i_lo + (tt - jj * i_n); J = j_lo + jj;
     };
@@ -1379,6 +1421,21 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     };
     auto p_ptr = [&](int I, int J) __attribute__((always_inline)) -> double * {
         return P + (size_t)(DT * I + 32 * wi + 2 * idx) + (size_t)(DT * J + 32 * wj + 2 * kq) * ld;
+    };
+    // transposed image of this lane's block: element (i, j) of tile (I, J) -> P(64 J + j, 64 I + i)
+    auto pm_ptr = [&](int I, int J) __attribute__((always_inline)) -> double * {
+        return P + (size_t)(DT * J + 32 * wj + 2 * kq) + (size_t)(DT * I + 32 * wi + 2 * idx) * ld;
+    };
+    // second store x (0..7) of a finished block: the transposed pair (t = x >> 1, e = x & 1), or -- diagonal tile -- normal store x again
+    auto second_store = [&](const v2d (&blk)[8], double *Pn_, double *Pm_, bool diag, int x) __attribute__((always_inline)) {
+        const int t = x >> 1, e = x & 1;
+        v2d m;
+        m.x = e ? blk[t].y : blk[t].x;
+        m.y = e ? blk[t + 4].y : blk[t + 4].x;
+        double *pn = Pn_ + (size_t)(8 * (x & 3) + (x >> 2)) * ld;
+        double *pm = Pm_ + (size_t)(8 * t) + (size_t)e * ld;
+        const v2d val = diag ? blk[x] : m;
+        DD_STORE((v2d *)(diag ? pn : pm), val);
     };
 
     // P block of a tile -> P + acc -> store source.  NB register blocks in rotation: the read stream runs AHEAD tiles ahead
@@ -1437,21 +1494,36 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     auto tile_body = [&](auto par_c, auto first_c, auto load2_c, auto last_c, auto special_c, int pos) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_c)::value, PREV = (PAR + AHEAD) % NB;   // PREV: tile pos-1's block = where tile pos+AHEAD's goes
         constexpr bool FIRST = decltype(first_c)::value, LOAD2 = decltype(load2_c)::value, LAST = decltype(last_c)::value,
-                       SPECIAL = decltype(special_c)::value;
+                       SPECIAL = decltype(special_c)::value == 2,          // diagonal tile that carries the border strips
+                       DIAGSYM = SYM && decltype(special_c)::value >= 1,   // diagonal tile: its upper half mirrors its lower half ...
+                       DIAG_LDS = DIAGSYM && LAST,     // ... through an LDS transpose of the sums when the panels are dead after the loop (last tile)
+                       DIAG_MFMA = DIAGSYM && !LAST;   // ... by a second, role-swapped product otherwise (rare: a diagonal tile in mid-range)
         static_assert(!(LAST && LOAD2), "no tile after the last");
         int In = I, Jn = J;
         if (!LAST) tile_IJ(pos + 1, In, Jn);
         const bool needK = !LAST && In != I, needH = !LAST && Jn != J;
         const double *Pn = nullptr;                         // tile pos+2's P block
         if (LOAD2) { int I2, J2; tile_IJ(pos + AHEAD, I2, J2); Pn = p_ptr(I2, J2); }
-        double *Po = nullptr;                               // where tile pos-1 goes
-        if (!FIRST) { int Ip, Jp; tile_IJ(pos - 1, Ip, Jp); Po = p_ptr(Ip, Jp); }
+        double *Po = nullptr, *Pom = nullptr;               // where tile pos-1 goes (and its transposed image)
+        bool pdiag = false;
+        if (!FIRST) { int Ip, Jp; tile_IJ(pos - 1, Ip, Jp); Po = p_ptr(Ip, Jp); Pom = pm_ptr(Ip, Jp); pdiag = Ip == Jp; }
         const double *aW = hp_buf(hb) + 32 * wj + 2 * idx + kq * 64;        // A[j][k] = HP(k,j)
         const double *bK = kn_buf(kb) + 32 * wi + 2 * idx + kq * 64;        // B[k][i] = Kn(i,k)
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0, 0, 0, 0};
+        // a diagonal tile in SYM mode: the same product with the operands' roles swapped, accT(i,j) = sum_k Kn(j,k) HPt(i,k) =
+        // acc(j,i) in THIS lane's layout, so an upper element can take its mirror image's value without leaving the lane
+        v4d accT[2][2];
+        const double *aT = kn_buf(kb) + 32 * wj + 2 * idx + kq * 64;
+        const double *bT = hp_buf(hb) + 32 * wi + 2 * idx + kq * 64;
+        if (DIAG_MFMA) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) accT[a][b] = (v4d){0, 0, 0, 0};
+        }
         // strip operands of a special tile: lane -> (strip, x), wave -> quarter of the k range
         const int s_which = lane >> 5, s_x = 2 * (lane & 31), s_kb = (KC / 4) * wave;
         const double *s_panel = (s_which ? hp_buf(hb) : kn_buf(kb)) + s_x + s_kb * 64;
@@ -1477,10 +1549,22 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
             acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.y, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.x, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.y, acc[1][1], 0, 0, 0);
+            if (DIAG_MFMA) {
+                const v2d at = *(const v2d *)(aT + kk * 256), bt = *(const v2d *)(bT + kk * 256);
+                accT[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(at.x, bt.x, accT[0][0], 0, 0, 0);
+                accT[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(at.x, bt.y, accT[0][1], 0, 0, 0);
+                accT[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(at.y, bt.x, accT[1][0], 0, 0, 0);
+                accT[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(at.y, bt.y, accT[1][1], 0, 0, 0);
+            }
             // ---- this k-step's share of the VMEM traffic (compile-time positions)
             const int ph = kk / Q4, off = kk % Q4;          // phase 0: DMA Kn, 1: stores then DMA HPt, 2: P loads, 3: nothing
-            if (ph == 0 && !SPECIAL && !LAST) {
-                if (needK) {
+            if (ph == 0) {
+                if (SYM && !FIRST) {                        // SYM: the previous tile's normal stores here, its transposed image in phase 1
+#pragma unroll                                              // (all sixteen in one phase saturate the CU's store path and stall the MFMAs behind them)
+                    for (int x = 0; x < 8; ++x)
+                        if ((x * Q4) / 8 == off) DD_STORE((v2d *)(Po + (size_t)(8 * (x & 3) + (x >> 2)) * ld), pq[PREV][x]);
+                }
+                if (!SPECIAL && !LAST && needK) {
 #pragma unroll
                     for (int q = 0; q < ND; ++q)
                         if ((q * Q4) / ND == off) dma_piece(Kn, DT * In, kb ^ 1, q);
@@ -1488,8 +1572,11 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
             } else if (ph == 1) {
                 if (!FIRST) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        if ((q * Q4) / 8 == off) DD_STORE((v2d *)(Po + (size_t)(8 * (q & 3) + (q >> 2)) * ld), pq[PREV][q]);
+                    for (int x = 0; x < 8; ++x)
+                        if ((x * Q4) / 8 == off) {
+                            if (!SYM) DD_STORE((v2d *)(Po + (size_t)(8 * (x & 3) + (x >> 2)) * ld), pq[PREV][x]);
+                            else second_store(pq[PREV], Po, Pom, pdiag, x);
+                        }
                 }
                 if (!SPECIAL && !LAST && needH) {
 #pragma unroll
@@ -1514,13 +1601,44 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
             a2 = a2n; b2 = b2n;
         }
         D2MARK();                            // MFMA loop done
+        if (DIAG_LDS) {
+            // the sums of the whole tile through LDS, S[j][i] = acc(i,j) (row stride 66: the lanes of a 16-group differ in i);
+            // an upper element (i < j) then reads S[i][j] = acc(j,i).  Every panel is dead by now: S takes the front of the
+            // dynamic LDS (33 KiB; the smallest launch has 48 KiB).
+            lds_barrier();
+            double *S = dd_smem;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int jj = 32 * wj + 2 * kq + 8 * r + mt, ii = 32 * wi + 2 * idx;
+                    S[jj * 66 + ii] = acc[mt][0][r];
+                    S[jj * 66 + ii + 1] = acc[mt][1][r];
+                }
+            lds_barrier();
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int jj = 32 * wj + 2 * kq + 8 * r + mt, ii = 32 * wi + 2 * idx;
+                    accT[mt][0][r] = S[ii * 66 + jj];
+                    accT[mt][1][r] = S[(ii + 1) * 66 + jj];
+                }
+            lds_barrier();                                  // (the strip reduction below reuses LDS)
+        }
         // P + sum_k (the P block was requested two tiles ago)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                pq[PAR][mt * 4 + r].x += acc[mt][0][r];
-                pq[PAR][mt * 4 + r].y += acc[mt][1][r];
+                if (DIAGSYM) {                              // element (i, j) of the tile: on or below the diagonal -> its own sum, above -> its mirror image's
+                    const int dij = 32 * (wi - wj) + 2 * (idx - kq) - 8 * r - mt;      // i - j for e = 0
+                    pq[PAR][mt * 4 + r].x += (dij >= 0) ? acc[mt][0][r] : accT[mt][0][r];
+                    pq[PAR][mt * 4 + r].y += (dij + 1 >= 0) ? acc[mt][1][r] : accT[mt][1][r];
+                } else {
+                    pq[PAR][mt * 4 + r].x += acc[mt][0][r];
+                    pq[PAR][mt * 4 + r].y += acc[mt][1][r];
+                }
             }
         if (SPECIAL) {
             // partial strip sums of the four waves meet in the idle Kn buffer; the threads of the strip mapping finish
@@ -1535,13 +1653,14 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
                 if (which < 2 && b < rem) {
                     v2d t = strip_p;
 #pragma unroll
-                    for (int w4 = 0; w4 < 4; ++w4) { const v2d r = red[(w4 * DD_STRIP_MAX + b) * 64 + which * 32 + (x >> 1)]; t.x += r.x; t.y += r.y; }
+                    for (int w4 = 0; w4 < 4; ++w4) { const v2d r = red[(w4 * DD_STRIP_MAX + b) * 64 + (SYM ? 1 : which) * 32 + (x >> 1)]; t.x += r.x; t.y += r.y; }   // SYM: the row strip's sums for both strips
                     *p0 = t.x; *p1 = t.y;
                 }
             }
             if (I == 0 && tid < 64) {                   // the corner block P(nb.., nb..): 16 (a,b) slots x 4 quarters of k
                 const int a = (tid >> 2) & 3, b = tid & 3, k4 = tid >> 4;
-                const double *ra = &s_border[0][a][(KC / 4) * k4], *rb = &s_border[1][b][(KC / 4) * k4];
+                const int as = SYM ? max(a, b) : a, bs = SYM ? min(a, b) : b;      // SYM: (a,b) and (b,a) both take the lower element's sum
+                const double *ra = &s_border[0][as][(KC / 4) * k4], *rb = &s_border[1][bs][(KC / 4) * k4];
                 double v = 0.0;
 #pragma unroll
                 for (int k = 0; k < KC / 4; k += 2) {
@@ -1561,6 +1680,12 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
             double *Pw = p_ptr(I, J);
 #pragma unroll
             for (int q = 0; q < 8; ++q) DD_STORE((v2d *)(Pw + (size_t)(8 * (q & 3) + (q >> 2)) * ld), pq[PAR][q]);
+            if (SYM) {
+                double *Pwm = pm_ptr(I, J);
+                const bool diag = I == J;
+#pragma unroll
+                for (int x = 0; x < 8; ++x) second_store(pq[PAR], Pw, Pwm, diag, x);
+            }
             return;
         }
         if (SPECIAL) {                                      // a special tile in mid-range (rare): fetch the next panels now
@@ -1575,7 +1700,7 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
             }
             dd_wait_vmcnt<0>();
         } else if (needH) dd_wait_vmcnt<LOAD2 ? 8 : 0>();                             // after the last HPt DMA: this tile's 8 P loads
-        else if (needK) dd_wait_vmcnt<(FIRST ? 0 : 8) + (LOAD2 ? 8 : 0)>();          // after the last Kn DMA: (8 stores +) (8 P loads)
+        else if (needK) dd_wait_vmcnt<(FIRST ? 0 : 8) + (LOAD2 ? 8 : 0)>();          // after the last Kn DMA: (phase 1's 8 stores +) (8 P loads)
         if (needK || needH) lds_barrier();
         if (needK) kb ^= 1;
         if (needH) hb ^= 1;
@@ -1584,12 +1709,15 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     };
     using Tt = std::true_type;
     using Ff = std::false_type;
+    using C0 = std::integral_constant<int, 0>;      // tile kinds: off-diagonal / diagonal / diagonal with the border strips
+    using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>;
     // Short ranges (the BASELINE sizes: 4 tiles per workgroup at n = 2051, 1 at n = 1027 / 259) run as STRAIGHT-LINE code,
     // one instantiation per position: with no loop and no join in the way, hipcc's s_waitcnt pass places every wait exactly
     // (through the generic loop below it merges the variants' states at the joins and waits for far younger loads than the
     // P block it needs).  A diagonal tile sits at the end of its range (t_diag swap), so only the last position may be SPECIAL.
     bool mid_special = false;
-    if (strips)
+    if (strips || SYM)
         for (int pos = 0; pos + 1 < nt; ++pos) { int Iq, Jq; tile_IJ(pos, Iq, Jq); mid_special |= Iq == Jq; }
     auto straight = [&](auto nt_c) __attribute__((always_inline)) {
         constexpr int NT = decltype(nt_c)::value;
@@ -1599,8 +1727,10 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
             using First = std::integral_constant<bool, POS == 0>;
             using Load2 = std::integral_constant<bool, (POS + AHEAD < NT)>;
             using Last = std::integral_constant<bool, POS == NT - 1>;
-            if (POS == NT - 1 && strips && I == J) tile_body(Par(), First(), Load2(), Last(), Tt(), POS);
-            else tile_body(Par(), First(), Load2(), Last(), Ff(), POS);
+            if (POS == NT - 1 && I == J && (strips || SYM)) {
+                if (strips) tile_body(Par(), First(), Load2(), Last(), C2(), POS);
+                else tile_body(Par(), First(), Load2(), Last(), C1(), POS);
+            } else tile_body(Par(), First(), Load2(), Last(), C0(), POS);
         };
         one(std::integral_constant<int, 0>());
         if constexpr (NT > 1) one(std::integral_constant<int, 1>());
@@ -1614,8 +1744,10 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
         else straight(std::integral_constant<int, 3>());
     } else {
         auto run4 = [&](auto par_c, auto first_c, auto load2_c, auto last_c, int pos) __attribute__((always_inline)) {
-            if (strips && I == J) tile_body(par_c, first_c, load2_c, last_c, Tt(), pos);
-            else tile_body(par_c, first_c, load2_c, last_c, Ff(), pos);
+            if (I == J && (strips || SYM)) {
+                if (strips) tile_body(par_c, first_c, load2_c, last_c, C2(), pos);
+                else tile_body(par_c, first_c, load2_c, last_c, C1(), pos);
+            } else tile_body(par_c, first_c, load2_c, last_c, C0(), pos);
         };
         auto run = [&](auto par_c, int pos) __attribute__((always_inline)) {               // a tile after the first
             if (pos == nt - 1) run4(par_c, Ff(), Ff(), Tt(), pos);
@@ -1710,7 +1842,11 @@ __global__ __launch_bounds__(256) void k_augment(RekfDev d, RekfFrontArgs A)
                     for (int l = 0; l < 3; ++l) t += Gp[a][rr * 3 + l] * Sxi[l * 3 + k];
                     acc += t * Gp[b][cc * 3 + k];
                 }
-                P[(size_t)(n + 2 * a + rr) + (size_t)(n + 2 * b + cc) * ld] = acc + RQR[rr * 2 + cc];
+                const size_t gi = (size_t)(n + 2 * a + rr), gj = (size_t)(n + 2 * b + cc);
+                if (gi < gj) continue;                              // lower triangle + mirror: P stays exactly symmetric
+                const double v = acc + RQR[rr * 2 + cc];
+                P[gi + gj * ld] = v;
+                P[gj + gi * ld] = v;
             }
     }
     __syncthreads();
@@ -1800,12 +1936,12 @@ void rekf_launch_mid(const RekfDev &d, const RekfFrontArgs &a, int n_ub, int m_u
     if (m_ub <= 32) hipLaunchKernelGGL(k_mid<2>, dim3(grid), dim3(512), 0, s, d, a);
     else hipLaunchKernelGGL(k_mid<4>, dim3(grid), dim3(512), 0, s, d, a);
 }
-template <int KC> static void launch_downdate2(const RekfDev &d, int grid, hipStream_t s, bool first_on_device)
+template <int KC, bool SYM> static void launch_downdate2(const RekfDev &d, int grid, hipStream_t s, bool first_on_device)
 {
     constexpr int BYTES = 4 * KC * 64 * (int)sizeof(double) + (KC < 64 ? 16384 : 0);
     if (first_on_device)
-        (void)hipFuncSetAttribute((const void *)k_downdate2<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
-    hipLaunchKernelGGL(k_downdate2<KC>, dim3(grid), dim3(256), BYTES, s, d);
+        (void)hipFuncSetAttribute((const void *)k_downdate2<KC, SYM>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+    hipLaunchKernelGGL((k_downdate2<KC, SYM>), dim3(grid), dim3(256), BYTES, s, d);
 }
 void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s)
 {
@@ -1826,18 +1962,31 @@ void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s)
         attr_done[slot] = 0;
     }
     const int n_cu = n_cu_of[slot];
+    static const bool full = getenv("REKF_DD_FULL") != nullptr;      // A/B switch: the full-square variant (every tile computed)
     const int T = (n_ub + DT - 1) / DT;
     const int slots = n_cu * DD_WG_PER_CU;
-    int grid = (T * T < slots) ? T * T : slots;
-    if (grid >= 64) grid &= ~7;                     // multiple of 8: enables the per-XCD tile regions
+    int grid;
+    if (full) grid = (T * T < slots) ? T * T : slots;
+    else {                                          // the triangle: equal ranges, as few tiles per workgroup as the CUs allow
+        const int ntiles = T * (T + 1) / 2, per = (ntiles + slots - 1) / slots;
+        grid = (ntiles + per - 1) / per;
+    }
+    if (grid >= 64) grid &= ~7;                     // multiple of 8: enables the per-XCD tile ranges / regions
     const int kc = (d.kc_ub < 16) ? 16 : ((d.kc_ub > 64) ? 64 : d.kc_ub);    // one k-chunk: the host never asks for more than 64 rows per step
     const unsigned bit = 1u << (kc / 16);
     const bool first = !(attr_done[slot] & bit) || dev != slot;
     attr_done[slot] |= bit;
-    if (kc == 64) launch_downdate2<64>(d, grid, s, first);
-    else if (kc == 48) launch_downdate2<48>(d, grid, s, first);
-    else if (kc == 32) launch_downdate2<32>(d, grid, s, first);
-    else launch_downdate2<16>(d, grid, s, first);
+    if (full) {
+        if (kc == 64) launch_downdate2<64, false>(d, grid, s, first);
+        else if (kc == 48) launch_downdate2<48, false>(d, grid, s, first);
+        else if (kc == 32) launch_downdate2<32, false>(d, grid, s, first);
+        else launch_downdate2<16, false>(d, grid, s, first);
+    } else {
+        if (kc == 64) launch_downdate2<64, true>(d, grid, s, first);
+        else if (kc == 48) launch_downdate2<48, true>(d, grid, s, first);
+        else if (kc == 32) launch_downdate2<32, true>(d, grid, s, first);
+        else launch_downdate2<16, true>(d, grid, s, first);
+    }
 }
 void rekf_launch_augment(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s)
 {

@@ -116,8 +116,9 @@ def test_c3_full_size_properties(c3_built):
     n = 3 + 2 * cfg.n_landmarks
     assert st.mu.shape[0] == n and st.sigma.shape == (n, n)
     assert np.isfinite(st.mu).all() and np.isfinite(st.sigma).all()
-    scale = np.abs(st.sigma).max()
-    assert np.abs(st.sigma - st.sigma.T).max() < 1e-12 * max(scale, 1.0)
+    # the stored covariance is EXACTLY symmetric: k_downdate2 computes the lower triangle and mirrors it, the predict / augment
+    # kernels mirror theirs (partial mirroring -- tiles but not the border strips -- let the antisymmetric part grow without bound)
+    assert np.array_equal(st.sigma, st.sigma.T)
     assert np.diag(st.sigma).min() > 0
     assert -math.pi < st.mu[2] <= math.pi
     # size-independent domain property: the map is right -- every estimated landmark sits
