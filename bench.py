@@ -19,7 +19,7 @@ all-gather of a 64-byte result record per rank (reflector_ekf_slam_amd/dist.py).
 Rank 0 prints ONE JSON line.
 
 Extra objects on that line (rank 0, N = 1 unless noted):
-  roofline       the P -= K (H P) kernel (k_downdate): algorithmic bytes per launch
+  roofline       the P -= K (H P) kernel (k_downdate2): algorithmic bytes per launch
                  (16 n^2 + 8 n (3+m)) / its average launch time,
                  measured live with hipEvents on the handle's stream.  `traffic` is
                  NOT measured in this run: it is read from the committed rocprofv3
@@ -235,7 +235,7 @@ def latency_legs(ekf, scans, steps):
         return {"median": float(np.median(a)), "p99": float(np.percentile(a, 99)), "mean": float(a.mean()), "n": int(a.size)}
     return {"device_chain": dict(q(dev), method="hipEvent pair around each whole update chain on the handle's stream, "
                                                   "launches back to back (includes ~4-5 us of event bracket)"),
-            "host_sync": dict(q(host), method="host wall: HandleObservationMessage + rekf_get_pose (stream sync, 96-byte D2H) per update")}, 2 * steps
+            "host_sync": dict(q(host), method="host wall: HandleObservationMessage + rekf_get_pose per update (one publish kernel behind the chain; pose, 3x3 block and flags polled from pinned host memory)")}, 2 * steps
 
 
 def predict_leg(ekf, cfg, scans, steps, per_scan=5):
@@ -310,7 +310,8 @@ def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world):
     achieved = bytes_alg / (dd_us * 1e-6) / 1e9
     rocprof_us, traffic, traffic_src, rocprof_src = None, None, None, None
     try:
-        rocprof_us = json.load(open(os.path.join(ROOT, "profiles", "kernel_avg_us.json"))).get("k_downdate")
+        avg = json.load(open(os.path.join(ROOT, "profiles", "kernel_avg_us.json")))
+        rocprof_us = next((v for k, v in avg.items() if "k_downdate2<64" in k), None)
         rocprof_src = "profiles/kernel_avg_us.json (committed rocprofv3 --kernel-trace summary; NOT measured in this run)"
     except Exception:
         pass
@@ -322,7 +323,9 @@ def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world):
     except Exception:
         pass
     out["roofline"] = {
-        "kernel": "k_downdate (P -= K (H P), FP64 MFMA 16x16x4)", "bound": "hbm",
+        "kernel": "k_downdate2<64, SYM> (P -= K (H P): lower-triangle tiles by FP64 MFMA 16x16x4, mirrored stores)", "bound": "hbm",
+        "bytes_note": "algorithmic bytes = SURVEY 8(d): every element of P read and written once, + the panels; the kernel itself reads "
+                      "only the lower triangle (the update is symmetric), so its measured traffic is below this figure",
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "traffic": traffic, "traffic_source": traffic_src,
         "bytes_per_launch": bytes_alg, "avg_launch_us": dd_us,

@@ -100,5 +100,8 @@ void rekf_launch_mid(const RekfDev &d, const RekfFrontArgs &a, int n_ub, int m_u
 void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s);
 void rekf_launch_augment(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);
 void rekf_launch_ellipses(const RekfDev &d, double *out5, int cap, hipStream_t s);
-void rekf_launch_predict_pose(const RekfDev &d, const RekfFrontArgs &a, double *out12, hipStream_t s);
+// a value the kernels hand to the host in place: one 16-byte store, polled by its tag
+struct RekfHostSlot { double v; int seq; int aux; };
+void rekf_launch_predict_pose(const RekfDev &d, const RekfFrontArgs &a, double *out12, RekfHostSlot *hout, int seq, hipStream_t s);
+void rekf_launch_publish_pose(const RekfDev &d, RekfHostSlot *hout, int seq, hipStream_t s);
 void rekf_launch_predict_rows(const RekfDev &d, const RekfFrontArgs &a, double *out, hipStream_t s);

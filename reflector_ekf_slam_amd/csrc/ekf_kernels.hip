@@ -1442,7 +1442,10 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     // of the MFMAs.  Measured at C3 (4 tiles per workgroup): AHEAD = 1 and 2 give the same kernel time (17.7 us) -- with two
     // blocks in flight the first MFMA loop stretches from 2.3 to 3.6 us: a wave that cannot issue its load (memory queue
     // full) cannot issue its MFMAs either.
-    constexpr int AHEAD = 1, NB = AHEAD + 1;
+#ifndef REKF_DD_AHEAD
+#define REKF_DD_AHEAD 1
+#endif
+    constexpr int AHEAD = REKF_DD_AHEAD, NB = AHEAD + 1;
     v2d pq[NB][8];
     v4d acc[2][2];
     int I, J, kb = 0, hb = 0;
@@ -1856,7 +1859,27 @@ __global__ __launch_bounds__(256) void k_augment(RekfDev d, RekfFrontArgs A)
 // ----------------------------------------------------------------------------
 // PredictState, pose block (cc:97-152): non-mutating; out = mu3 | sigma3x3 col-major
 // ----------------------------------------------------------------------------
-__global__ void k_predict_pose(RekfDev d, RekfFrontArgs A, double *out12)
+// ---- results for the host without a copy engine: each value is ONE 16-byte system-scope store {double, tag, aux} into
+// pinned host memory; the host polls the tags (no hipMemcpy, no wait for the completion signal).
+typedef unsigned rekf_u32x4 __attribute__((ext_vector_type(4)));
+__device__ static void host_slot_store(RekfHostSlot *p, double v, int seq, int aux)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const rekf_u32x4 w = {(unsigned)b, (unsigned)(b >> 32), (unsigned)seq, (unsigned)aux};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(w) : "memory");
+}
+
+// GetState's pose part (ekf_slam.h GetState / ros_node.cc's pose publisher): mu[0..2], the 3 x 3 pose block, n and the error
+// flags, straight into the host's slots
+__global__ void k_publish_pose(RekfDev d, RekfHostSlot *out, int seq)
+{
+    const int l = threadIdx.x;
+    if (l < 3) host_slot_store(out + l, d.mu[l], seq, 0);
+    else if (l < 12) host_slot_store(out + l, d.P[(l - 3) % 3 + (size_t)((l - 3) / 3) * d.ld], seq, 0);
+    else if (l == 12) host_slot_store(out + 12, (double)d.ctl->n, seq, d.ctl->err);
+}
+
+__global__ void k_predict_pose(RekfDev d, RekfFrontArgs A, double *out12, RekfHostSlot *hout, int seq)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Motion mo;
@@ -1871,6 +1894,12 @@ __global__ void k_predict_pose(RekfDev d, RekfFrontArgs A, double *out12)
     out12[1] = d.mu[1] + mo.d[1];
     out12[2] = th;
     for (int q = 0; q < 9; ++q) out12[3 + q] = C[q];
+    if (hout) {
+        host_slot_store(hout + 0, d.mu[0] + mo.d[0], seq, 0);
+        host_slot_store(hout + 1, d.mu[1] + mo.d[1], seq, 0);
+        host_slot_store(hout + 2, th, seq, 0);
+        for (int q = 0; q < 9; ++q) host_slot_store(hout + 3 + q, C[q], seq, 0);
+    }
 }
 
 // ----------------------------------------------------------------------------
@@ -2036,7 +2065,11 @@ void rekf_launch_ellipses(const RekfDev &d, double *out5, int cap, hipStream_t s
     if (cap <= 0) return;
     hipLaunchKernelGGL(k_ellipses, dim3((cap + 255) / 256), dim3(256), 0, s, d, out5, cap);
 }
-void rekf_launch_predict_pose(const RekfDev &d, const RekfFrontArgs &a, double *out12, hipStream_t s)
+void rekf_launch_predict_pose(const RekfDev &d, const RekfFrontArgs &a, double *out12, RekfHostSlot *hout, int seq, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_predict_pose, dim3(1), dim3(64), 0, s, d, a, out12);
+    hipLaunchKernelGGL(k_predict_pose, dim3(1), dim3(64), 0, s, d, a, out12, hout, seq);
+}
+void rekf_launch_publish_pose(const RekfDev &d, RekfHostSlot *hout, int seq, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_publish_pose, dim3(1), dim3(64), 0, s, d, hout, seq);
 }

@@ -42,6 +42,9 @@ struct rekf {
     bool full;                 // a readback showed n == n_max: no landmark can ever be added again
     bool n_exact = true;       // n_ub IS the device's n (nothing that can append landmarks was enqueued since it was read back)
     double *pose_staging;      // pinned, 12 doubles
+    RekfHostSlot *host_slots;  // pinned + mapped: 16 tagged slots the pose kernels store into (null: copy-engine path)
+    RekfHostSlot *host_slots_dev;
+    int slot_seq;
     double *dev_out12;         // device scratch for k_predict_pose
     double *dev_ell;           // device scratch for k_ellipses (5 doubles per landmark of capacity)
     RekfCtl *ctl_staging;      // pinned copy of the control block
@@ -72,6 +75,32 @@ namespace {
     } while (0)
 
 int round_up(int x, int q) { return (x + q - 1) / q * q; }
+
+// wait until the `count` slots from `first` carry `seq` (a kernel on the handle's stream stores them).  Falls back to a stream
+// synchronisation when the stream drains without them (an earlier kernel failed) and gives up after five seconds.
+template <class H> int wait_slots(H *h, int first, int count, int seq)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    for (int k = first; k < first + count; ++k) {
+        const int *tag = &h->host_slots[k].seq;
+        while (__atomic_load_n(tag, __ATOMIC_ACQUIRE) != seq) {
+            if ((++spins & 0xfffffu) == 0) {
+                if (hipStreamQuery(h->stream) != hipErrorNotReady) {
+                    HIP_TRY(h, hipStreamSynchronize(h->stream));
+                    if (__atomic_load_n(tag, __ATOMIC_ACQUIRE) == seq) break;
+                    h->hip_error = "a pose kernel finished without publishing its result";
+                    return REKF_ERR_HIP;
+                }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+                    h->hip_error = "no pose result after 5 s";
+                    return REKF_ERR_HIP;
+                }
+            }
+        }
+    }
+    return REKF_OK;
+}
 
 int prof_flush(rekf_t *h)
 {
@@ -202,6 +231,7 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
     for (int k = 0; k < REKF_K_COUNT; ++k) { h->prof_total_us[k] = 0; h->prof_count[k] = 0; }
     h->stream = nullptr;
     h->pose_staging = nullptr;
+    h->host_slots = nullptr; h->host_slots_dev = nullptr; h->slot_seq = 0;
     h->ctl_staging = nullptr;
     h->dev_out12 = nullptr;
     h->dev_ell = nullptr;
@@ -227,6 +257,13 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
         HIP_TRY(h, hipMalloc(&h->dev_mu_lin, sizeof(double) * ld));
         HIP_TRY(h, hipMalloc(&h->dev_ell, sizeof(double) * 5 * (size_t)(max_landmarks > 0 ? max_landmarks : 1)));
         HIP_TRY(h, hipHostMalloc(&h->pose_staging, sizeof(double) * 16));
+        if (hipHostMalloc(&h->host_slots, sizeof(RekfHostSlot) * 16, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+            std::memset(h->host_slots, 0, sizeof(RekfHostSlot) * 16);
+            void *dv = nullptr;
+            if (hipHostGetDevicePointer(&dv, h->host_slots, 0) == hipSuccess) h->host_slots_dev = (RekfHostSlot *)dv;
+            else { (void)hipHostFree(h->host_slots); h->host_slots = nullptr; }
+        }
+        (void)hipGetLastError();
         HIP_TRY(h, hipHostMalloc(&h->ctl_staging, sizeof(RekfCtl)));
         h->dev.ld = ld;
         h->dev.n_max = n_max;
@@ -268,6 +305,7 @@ void rekf_destroy(rekf_t *h)
     (void)hipFree(h->dev.HPt); (void)hipFree(h->dev.Kn); (void)hipFree(h->dev.KnB); (void)hipFree(h->dev.HPtB);
     (void)hipFree(h->dev.map_xy); (void)hipFree(h->dev.map_cov); (void)hipFree(h->dev_out12); (void)hipFree(h->dev_ell); (void)hipFree(h->dev_pred); (void)hipFree(h->dev_obs); (void)hipFree(h->dev_mu_lin);
     if (h->pose_staging) (void)hipHostFree(h->pose_staging);
+    if (h->host_slots) (void)hipHostFree(h->host_slots);
     if (h->ctl_staging) (void)hipHostFree(h->ctl_staging);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -388,7 +426,17 @@ int rekf_predict_state(rekf_t *h, double t, double mu3[3], double sigma3x3[9])
     RekfFrontArgs a;
     fill_front_args(h, a, t - h->time);               // cc:100
     HIP_TRY(h, hipSetDevice(h->device));
-    rekf_launch_predict_pose(h->dev, a, h->dev_out12, h->stream);
+    if (h->host_slots) {                               // one launch; the result arrives in pinned memory, polled by tag
+        const int seq = ++h->slot_seq;
+        rekf_launch_predict_pose(h->dev, a, h->dev_out12, h->host_slots_dev, seq, h->stream);
+        HIP_TRY(h, hipGetLastError());
+        int rc = wait_slots(h, 0, 12, seq);
+        if (rc != REKF_OK) return rc;
+        for (int q = 0; q < 3; ++q) mu3[q] = h->host_slots[q].v;
+        if (sigma3x3) for (int q = 0; q < 9; ++q) sigma3x3[q] = h->host_slots[3 + q].v;
+        return REKF_OK;
+    }
+    rekf_launch_predict_pose(h->dev, a, h->dev_out12, nullptr, 0, h->stream);
     HIP_TRY(h, hipMemcpyAsync(h->pose_staging, h->dev_out12, sizeof(double) * 12, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     std::memcpy(mu3, h->pose_staging, sizeof(double) * 3);
@@ -407,6 +455,18 @@ int rekf_get_pose(rekf_t *h, double *t, double mu3[3], double sigma3x3[9])
 {
     if (!h) return REKF_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->host_slots) {                               // one small launch behind the update chain instead of three copies and a stream wait
+        const int seq = ++h->slot_seq;
+        rekf_launch_publish_pose(h->dev, h->host_slots_dev, seq, h->stream);
+        HIP_TRY(h, hipGetLastError());
+        int rc = wait_slots(h, 0, 13, seq);
+        if (rc != REKF_OK) return rc;
+        report_flags(h, h->host_slots[12].aux);
+        if (t) *t = h->time;
+        if (mu3) for (int q = 0; q < 3; ++q) mu3[q] = h->host_slots[q].v;
+        if (sigma3x3) for (int q = 0; q < 9; ++q) sigma3x3[q] = h->host_slots[3 + q].v;
+        return REKF_OK;
+    }
     HIP_TRY(h, hipMemcpyAsync(h->pose_staging, h->dev.mu, sizeof(double) * 3, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpy2DAsync(h->pose_staging + 3, sizeof(double) * 3, h->dev.P, sizeof(double) * h->dev.ld,
                                 sizeof(double) * 3, 3, hipMemcpyDeviceToHost, h->stream));

@@ -22,7 +22,7 @@ for k in sorted(set(F) | set(W)):
     f = statistics.mean(F.get(k, [0])); w = statistics.mean(W.get(k, [0]))
     hbm = (2 * f + w) * 1024
     lines.append(f"{k[:44]:44s} {f:10.1f} {w:10.1f} {hbm/1e6:8.2f}")
-    if k.startswith("void k_downdate2<64>") or k.startswith("k_downdate2<64>"):
+    if "k_downdate2<64" in k:
         out = {"kernel": k, "fetch_size_kb": f, "write_size_kb": w, "hbm_bytes_per_launch": hbm,
                "note": "2*FETCH_SIZE + WRITE_SIZE, KB->bytes; see profiles/%s_pmc.txt" % tag}
 open(f"profiles/{tag}_pmc.txt", "w").write("\n".join(lines) + "\n")
