@@ -1310,15 +1310,25 @@ template <int N> __device__ static inline void dd_wait_vmcnt()
 // per 4 lanes).  A diagonal tile is computed in full as before (its own lower / upper halves are not forced equal) and
 // issues its normal stores twice, so that every tile has the same VMEM count (the s_waitcnt bookkeeping is static).
 // P therefore holds exactly mirrored off-diagonal tiles; the reference's (I - K H) P differs from that in the last bit only.
-template <int KC, bool SYM>
+// SB ("single buffer", implies SYM; REKF_DD_SB=1): ONE tile per workgroup and only two panels in LDS (72 KiB with the border
+// scratch), so that TWO workgroups share a CU and the hardware overlaps one's memory phase with the other's MFMAs: 496
+// off-diagonal tiles + 16 pairs of diagonal tiles on 512 resident workgroups.  No pipelining inside the workgroup: panels and
+// P block in, MFMA loop, P block out (twice).  Measured: 17.3 us against 17.6 us for the persistent form -- a CU's memory
+// throughput is the same ~30 GB/s either way -- so the persistent form stays the default.
+template <int KC, bool SYM, bool SB = false>
 __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
 {
+    static_assert(!SB || SYM, "the single-buffer form is a lower-triangle form");
     extern __shared__ __attribute__((aligned(16))) double dd_smem[];   // [Kn 0 | Kn 1 | HPt 0 | HPt 1] panels (+ 16 KiB strip scratch if KC < 64)
     __shared__ __attribute__((aligned(16))) double s_border[2][DD_STRIP_MAX][REKF_MR_PAD];
 #ifdef REKF_DEBUG_TIMING
     long long tq2[24]; int nq2 = 0;
 #ifdef REKF_DEBUG_DD2
-    const bool rec2 = blockIdx.x == 0 && threadIdx.x == 0;
+#ifndef REKF_DEBUG_DD2_BLOCK
+#define REKF_DEBUG_DD2_BLOCK 0
+#endif
+    const bool rec2 = blockIdx.x == REKF_DEBUG_DD2_BLOCK && threadIdx.x == 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) const_cast<RekfCtl *>(d.ctl)->dbg[3] = wall_clock64();   // block 0's entry, for the offset of the recorded block
 #else
     const bool rec2 = false;
 #endif
@@ -1326,6 +1336,15 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
 #define D2MARK() do { __builtin_amdgcn_sched_barrier(0); if (rec2 && nq2 < 24) tq2[nq2++] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define D2MARK()
+#endif
+#ifdef REKF_DEBUG_ENTRY
+    // entry / exit wall clock (100 MHz) of a few workgroups, release-build register footprint: dbg[8+k] / dbg[16+k]
+    int eslot = -1;
+    {
+        const int bs[8] = {0, 128, 255, 256, 300, 400, 495, 511};
+        for (int k = 0; k < 8; ++k) if ((int)blockIdx.x == bs[k]) eslot = k;
+    }
+    if (eslot >= 0 && threadIdx.x == 0) const_cast<RekfCtl *>(d.ctl)->dbg[8 + eslot] = wall_clock64();
 #endif
     // With n known to the host nothing here depends on the control block: k_mid leaves zero panels behind a scan without
     // matches, so the kernel may run unconditionally and its first loads go out one memory round trip earlier.
@@ -1344,6 +1363,7 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     const bool strips = rem > 0 && rem <= DD_STRIP_MAX && n >= DT;
     const int T = strips ? n / DT : (n + DT - 1) / DT;
     int i_lo = 0, i_n = T, j_lo = 0, j_n = T, w = blockIdx.x, nw = gridDim.x;
+    const int sb_off = T * (T - 1) / 2;                     // SB: workgroups [0, sb_off) take one off-diagonal tile, the rest two diagonal tiles each
     if (SYM) {
         // the triangle column by column (tile column J: I = J .. T-1); an XCD's workgroups take consecutive ranges of it
         if (gridDim.x >= 8 && (gridDim.x & 7) == 0) w = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
@@ -1354,8 +1374,8 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
         w = blockIdx.x >> 3; nw = gridDim.x >> 3;
     }
     const int ntiles = SYM ? T * (T + 1) / 2 : i_n * j_n;
-    const int t_begin = (int)(((long long)w * ntiles) / nw);
-    const int t_end = (int)(((long long)(w + 1) * ntiles) / nw);
+    const int t_begin = SB ? 0 : (int)(((long long)w * ntiles) / nw);
+    const int t_end = SB ? ((w < sb_off) ? 1 : min(2, T - 2 * (w - sb_off))) : (int)(((long long)(w + 1) * ntiles) / nw);
     if (t_begin >= t_end) return;
     const int nt = t_end - t_begin;
     const size_t ld = (size_t)d.ld;
@@ -1368,12 +1388,13 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
 
     // a diagonal tile of the range is taken LAST (its strip work then rides on a tile that has nothing to prefetch);
     // should a range ever hold more than one, the others are still handled where they stand (`special` below)
-    auto tri_col = [&](int Jc) __attribute__((always_inline)) -> int { return Jc * T - (Jc * (Jc - 1)) / 2; };   // first tile of column Jc
+    const int TT = SB ? T - 1 : T;                          // side of the triangle that is enumerated (SB: the strictly lower one)
+    auto tri_col = [&](int Jc) __attribute__((always_inline)) -> int { return Jc * TT - (Jc * (Jc - 1)) / 2; };   // first tile of column Jc
     auto tri_IJ = [&](int tt, int &It, int &Jt) __attribute__((always_inline)) {
-        const float b = 2.0f * (float)T + 1.0f;
+        const float b = 2.0f * (float)TT + 1.0f;
         int Jg = (int)((b - sqrtf(b * b - 8.0f * (float)tt)) * 0.5f);
-        Jg = max(0, min(T - 1, Jg));
-        while (Jg + 1 < T && tri_col(Jg + 1) <= tt) ++Jg;
+        Jg = max(0, min(TT - 1, Jg));
+        while (Jg + 1 < TT && tri_col(Jg + 1) <= tt) ++Jg;
         while (Jg > 0 && tri_col(Jg) > tt) --Jg;
         Jt = Jg; It = Jg + (tt - tri_col(Jg));
     };
@@ -1389,7 +1410,8 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
         tri_IJ(tt, It, Jt);
     };
     int t_diag = t_end - 1;
-    if (SYM) {                                              // a diagonal tile of the range goes last (the last one, should there be several)
+    if (SB) {
+    } else if (SYM) {                                       // a diagonal tile of the range goes last (the last one, should there be several)
         for (int t = t_begin; t < t_end; ++t) {
             int It, Jt;
             sym_IJ(t, It, Jt);
@@ -1403,6 +1425,11 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
         }
     }
     auto tile_IJ = [&](int pos, int &I, int &J) __attribute__((always_inline)) {
+        if (SB) {
+            if (w < sb_off) { tri_IJ(w, I, J); I += 1; }    // off-diagonal tile number w of the strictly lower triangle
+            else { I = 2 * (w - sb_off) + pos; J = I; }     // the pos-th of this workgroup's diagonal tiles
+            return;
+        }
         const int tile = t_begin + pos;
         const int tt = (tile == t_end - 1) ? t_diag : ((tile == t_diag) ? t_end - 1 : tile);
         if (SYM) { sym_IJ(tt, I, J); return; }
@@ -1411,13 +1438,15 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     };
     // LDS: [Kn buffer 0 | Kn buffer 1 | HPt buffer 0 | HPt buffer 1], PANEL doubles each
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)dd_smem;
-    auto kn_buf = [&](int b) __attribute__((always_inline)) -> const double * { return dd_smem + (size_t)b * PANEL; };
-    auto hp_buf = [&](int b) __attribute__((always_inline)) -> const double * { return dd_smem + (size_t)(2 + b) * PANEL; };
+    // (SB: [Kn | HPt], one buffer each)
+    auto kn_buf = [&](int b) __attribute__((always_inline)) -> const double * { return dd_smem + (SB ? (size_t)0 : (size_t)b * PANEL); };
+    auto hp_buf = [&](int b) __attribute__((always_inline)) -> const double * { return dd_smem + (SB ? (size_t)PANEL : (size_t)(2 + b) * PANEL); };
     // one DMA instruction: k-rows 2(4q + wave) + {0,1} of the panel that starts at row `row0` of `src`
     auto dma_piece = [&](const double *src, int row0, int buf_index, int q) __attribute__((always_inline)) {
         const int pr = 4 * q + wave;
         const double *g = src + (size_t)(row0 + 2 * (lane & 31)) + (size_t)(2 * pr + (lane >> 5)) * ld;
-        dd_dma16(g, lds0 + (unsigned)(buf_index * PANEL * 8 + pr * 1024));
+        const int bi = SB ? (buf_index >= 2 ? 1 : 0) : buf_index;
+        dd_dma16(g, lds0 + (unsigned)(bi * PANEL * 8 + pr * 1024));
     };
     auto p_ptr = [&](int I, int J) __attribute__((always_inline)) -> double * {
         return P + (size_t)(DT * I + 32 * wi + 2 * idx) + (size_t)(DT * J + 32 * wj + 2 * kq) * ld;
@@ -1646,7 +1675,8 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
         if (SPECIAL) {
             // partial strip sums of the four waves meet in the idle Kn buffer; the threads of the strip mapping finish
             // (with KC < 64 a panel is smaller than the 16 KiB of partial sums: the launch's LDS beyond the four panels is free)
-            v2d *red = (v2d *)(dd_smem + (KC == 64 ? (size_t)(kb ^ 1) * PANEL : (size_t)4 * PANEL));
+            // (SB: the front of the LDS -- the panels are dead and the transpose above ended with a barrier)
+            v2d *red = (v2d *)(dd_smem + (SB ? (size_t)0 : (KC == 64 ? (size_t)(kb ^ 1) * PANEL : (size_t)4 * PANEL)));
 #pragma unroll
             for (int b3 = 0; b3 < DD_STRIP_MAX; ++b3) red[(wave * DD_STRIP_MAX + b3) * 64 + lane] = sacc[b3];
             lds_barrier();
@@ -1719,6 +1749,29 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     // one instantiation per position: with no loop and no join in the way, hipcc's s_waitcnt pass places every wait exactly
     // (through the generic loop below it merges the variants' states at the joins and waits for far younger loads than the
     // P block it needs).  A diagonal tile sits at the end of its range (t_diag swap), so only the last position may be SPECIAL.
+    if (SB) {
+        // one standalone tile after the other (at most two, both diagonal): nothing is prefetched, the co-resident workgroup fills the gaps
+        for (int pos = 0; pos < nt; ++pos) {
+            if (pos > 0) {
+                lds_barrier();                              // every wave is through with the panels and the scratch
+                tile_IJ(pos, I, J);
+#pragma unroll
+                for (int q = 0; q < ND; ++q) dma_piece(Kn, DT * I, 0, q);
+#pragma unroll
+                for (int q = 0; q < ND; ++q) dma_piece(HPt, DT * J, 2, q);
+                const double *Pw = p_ptr(I, J);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) pq[0][q] = *(const v2d *)(Pw + (size_t)(8 * (q & 3) + (q >> 2)) * ld);
+                dd_wait_vmcnt<8>();
+                lds_barrier();
+            }
+            using P0 = std::integral_constant<int, 0>;
+            if (I == J) {
+                if (strips) tile_body(P0(), Tt(), Ff(), Tt(), C2(), pos);
+                else tile_body(P0(), Tt(), Ff(), Tt(), C1(), pos);
+            } else tile_body(P0(), Tt(), Ff(), Tt(), C0(), pos);
+        }
+    } else {
     bool mid_special = false;
     if (strips || SYM)
         for (int pos = 0; pos + 1 < nt; ++pos) { int Iq, Jq; tile_IJ(pos, Iq, Jq); mid_special |= Iq == Jq; }
@@ -1769,6 +1822,10 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
             if (pos + NB - 1 < nt) run(B0(), pos + NB - 1);
         }
     }
+    }
+#ifdef REKF_DEBUG_ENTRY
+    if (eslot >= 0 && threadIdx.x == 0) const_cast<RekfCtl *>(d.ctl)->dbg[16 + eslot] = wall_clock64();
+#endif
 #ifdef REKF_DEBUG_TIMING
     if (rec2) {
         RekfCtl *c = const_cast<RekfCtl *>(d.ctl);
@@ -1776,6 +1833,7 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
         c->dbg[6] = clock64() - t_entry2;               // whole body, last stores retired
         c->dbg[5] = wall_clock64() - w_entry2;          // same in 100 MHz ticks
         c->dbg[7] = nq2;
+        c->dbg[4] = w_entry2;                           // this block's entry (100 MHz wall clock)
         for (int i = 0; i < nq2; ++i) c->dbg[8 + i] = tq2[i] - t_entry2;
     }
 #endif
@@ -1965,12 +2023,14 @@ void rekf_launch_mid(const RekfDev &d, const RekfFrontArgs &a, int n_ub, int m_u
     if (m_ub <= 32) hipLaunchKernelGGL(k_mid<2>, dim3(grid), dim3(512), 0, s, d, a);
     else hipLaunchKernelGGL(k_mid<4>, dim3(grid), dim3(512), 0, s, d, a);
 }
-template <int KC, bool SYM> static void launch_downdate2(const RekfDev &d, int grid, hipStream_t s, bool first_on_device)
+template <int KC, bool SYM, bool SB> static void launch_downdate2(const RekfDev &d, int grid, hipStream_t s, bool first_on_device)
 {
-    constexpr int BYTES = 4 * KC * 64 * (int)sizeof(double) + (KC < 64 ? 16384 : 0);
+    // SB: two panels, or the 64 x 66 transpose scratch of a diagonal tile if that is larger
+    constexpr int BYTES = SB ? (2 * KC * 64 * (int)sizeof(double) > 64 * 66 * 8 ? 2 * KC * 64 * (int)sizeof(double) : 64 * 66 * 8)
+                             : 4 * KC * 64 * (int)sizeof(double) + (KC < 64 ? 16384 : 0);
     if (first_on_device)
-        (void)hipFuncSetAttribute((const void *)k_downdate2<KC, SYM>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
-    hipLaunchKernelGGL((k_downdate2<KC, SYM>), dim3(grid), dim3(256), BYTES, s, d);
+        (void)hipFuncSetAttribute((const void *)k_downdate2<KC, SYM, SB>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+    hipLaunchKernelGGL((k_downdate2<KC, SYM, SB>), dim3(grid), dim3(256), BYTES, s, d);
 }
 void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s)
 {
@@ -1991,30 +2051,37 @@ void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s)
         attr_done[slot] = 0;
     }
     const int n_cu = n_cu_of[slot];
-    static const bool full = getenv("REKF_DD_FULL") != nullptr;      // A/B switch: the full-square variant (every tile computed)
+    static const bool full = getenv("REKF_DD_FULL") != nullptr;      // A/B switches: the full-square variant (every tile computed),
+    static const bool persistent = getenv("REKF_DD_SB") == nullptr;   // default: the persistent lower-triangle variant (one workgroup per CU);
+                                                                      // REKF_DD_SB=1: one tile per workgroup, two workgroups per CU (same speed)
     const int T = (n_ub + DT - 1) / DT;
     const int slots = n_cu * DD_WG_PER_CU;
     int grid;
     if (full) grid = (T * T < slots) ? T * T : slots;
-    else {                                          // the triangle: equal ranges, as few tiles per workgroup as the CUs allow
+    else if (persistent) {                          // the triangle: equal ranges, as few tiles per workgroup as the CUs allow
         const int ntiles = T * (T + 1) / 2, per = (ntiles + slots - 1) / slots;
         grid = (ntiles + per - 1) / per;
-    }
-    if (grid >= 64) grid &= ~7;                     // multiple of 8: enables the per-XCD tile ranges / regions
+    } else grid = T * (T - 1) / 2 + (T + 1) / 2;    // SB: one workgroup per off-diagonal tile, one per pair of diagonal tiles
+    if ((full || persistent) && grid >= 64) grid &= ~7;   // multiple of 8: enables the per-XCD tile ranges / regions
     const int kc = (d.kc_ub < 16) ? 16 : ((d.kc_ub > 64) ? 64 : d.kc_ub);    // one k-chunk: the host never asks for more than 64 rows per step
     const unsigned bit = 1u << (kc / 16);
     const bool first = !(attr_done[slot] & bit) || dev != slot;
     attr_done[slot] |= bit;
     if (full) {
-        if (kc == 64) launch_downdate2<64, false>(d, grid, s, first);
-        else if (kc == 48) launch_downdate2<48, false>(d, grid, s, first);
-        else if (kc == 32) launch_downdate2<32, false>(d, grid, s, first);
-        else launch_downdate2<16, false>(d, grid, s, first);
+        if (kc == 64) launch_downdate2<64, false, false>(d, grid, s, first);
+        else if (kc == 48) launch_downdate2<48, false, false>(d, grid, s, first);
+        else if (kc == 32) launch_downdate2<32, false, false>(d, grid, s, first);
+        else launch_downdate2<16, false, false>(d, grid, s, first);
+    } else if (persistent) {
+        if (kc == 64) launch_downdate2<64, true, false>(d, grid, s, first);
+        else if (kc == 48) launch_downdate2<48, true, false>(d, grid, s, first);
+        else if (kc == 32) launch_downdate2<32, true, false>(d, grid, s, first);
+        else launch_downdate2<16, true, false>(d, grid, s, first);
     } else {
-        if (kc == 64) launch_downdate2<64, true>(d, grid, s, first);
-        else if (kc == 48) launch_downdate2<48, true>(d, grid, s, first);
-        else if (kc == 32) launch_downdate2<32, true>(d, grid, s, first);
-        else launch_downdate2<16, true>(d, grid, s, first);
+        if (kc == 64) launch_downdate2<64, true, true>(d, grid, s, first);
+        else if (kc == 48) launch_downdate2<48, true, true>(d, grid, s, first);
+        else if (kc == 32) launch_downdate2<32, true, true>(d, grid, s, first);
+        else launch_downdate2<16, true, true>(d, grid, s, first);
     }
 }
 void rekf_launch_augment(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s)

@@ -15,4 +15,4 @@ for rep in range(3):
     out = (C.c_longlong * 32)(); L.rekf_debug_counters(g._h, out)
     o = list(out)
     ghz = o[6] / max(o[5], 1) * 0.1
-    print(f"total {o[6]} cycles = {o[5] * 10} ns wall -> {ghz:.2f} GHz; marks({o[7]}):", [round(x / ghz / 1e3, 2) for x in o[8:8 + o[7]]], "us")
+    print(f"total {o[6]} cycles = {o[5] * 10} ns wall -> {ghz:.2f} GHz; entered {(o[4] - o[3]) * 0.01:.2f} us after block 0; marks({o[7]}):", [round(x / ghz / 1e3, 2) for x in o[8:8 + o[7]]], "us")
