@@ -97,6 +97,36 @@ def test_ragged_sizes_and_many_reflectors(oracle_lib):
         _compare(g, o, sc)
 
 
+def test_invalid_stretches_and_bright_beams_outside_the_message_range(oracle_lib):
+    """What the one-launch kernel's per-beam workgroups have to find on their own: the first and the last valid beam of the
+    scan (probed 64 beams at a time from either end), the "a point exists" guard in front of the first valid beam, bright
+    beams beyond the message's own range limits (they take point_cloud.back()), an empty point cloud."""
+    n, rng_ = 3000, 5.0
+    nb = beams_for_width(0.18, rng_, n)
+    cases = []
+    sc = plate_scan(n, [(100, nb, rng_, 200.0), (900, nb, rng_, 200.0), (2000, nb, rng_, 200.0)])
+    sc.ranges[:700] = 100.0                         # first valid beam in the third 256-beam group; the plate at 100 is bright but has no point
+    cases.append(sc)
+    sc = plate_scan(n, [(900, nb, rng_, 200.0), (2000, nb, rng_, 200.0)])
+    sc.ranges[2300:] = np.inf                       # last valid beam ~700 from the end
+    cases.append(sc)
+    sc = plate_scan(n, [(900, nb, rng_, 200.0), (2000, nb, rng_, 200.0)])
+    sc.ranges[905] = 45.0; sc.ranges[2003] = 45.0   # bright (intensity 200, inside the detector's range gate) but beyond range_max = 30
+    cases.append(sc)
+    sc = plate_scan(n, [(900, nb, rng_, 200.0)])
+    sc.ranges[:] = 100.0                            # nothing valid at all
+    cases.append(sc)
+    sc = plate_scan(n, [(900, nb, rng_, 200.0)])
+    sc.ranges[:] = np.inf; sc.ranges[1500] = 7.0    # a single valid beam
+    cases.append(sc)
+    for sc in cases:
+        for with_odom in (False, True):
+            g, o = _pair(S2B, range_max=60.0)
+            if with_odom:
+                _feed_odom(g, o, odom_stream(sc.stamp - 0.3, sc.stamp + 0.05))
+            _compare(g, o, sc)
+
+
 def test_bad_scan_and_capacity_are_error_codes(oracle_lib):
     from reflector_ekf_slam_amd.detect import LaserReflectorDetect, RdetError, ReflectorDetectOptions
     g = LaserReflectorDetect(ReflectorDetectOptions(), max_beams=256)
