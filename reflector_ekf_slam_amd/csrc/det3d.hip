@@ -25,6 +25,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -44,6 +45,21 @@ struct Det3dCtl {
     int croot[RDET_MAX_CENTERS], csize[RDET_MAX_CENTERS], crank[RDET_MAX_CENTERS];   // accepted components: k3_finish -> k3_centroids
 };
 
+// what the kernels hand back, in pinned host memory: every slot is ONE 16-byte system-scope store that carries the call's
+// number, polled by the host (no D2H copy, no wait for the completion signal; same scheme as det2d.hip)
+struct Det3dSlot { float x, y; int seq, pad; };
+struct Det3dHead { int K, err, M2, seq; };
+struct Det3dHostOut {
+    Det3dHead head;
+    Det3dSlot centers[RDET_MAX_CENTERS];
+};
+typedef unsigned d3_u32x4 __attribute__((ext_vector_type(4)));
+__device__ static void d3_host_store16(void *p, unsigned a, unsigned b, unsigned c, unsigned d)
+{
+    const d3_u32x4 v = {a, b, c, d};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+
 struct Det3dBufs {
     const float *xyzi;
     float *p1;        // 3 x cap, SoA: x | y | z  after the intensity filter
@@ -54,6 +70,8 @@ struct Det3dBufs {
     int *last;        // last member index per root
     Det3dCtl *ctl;
     int cap;
+    Det3dHostOut *hout;   // pinned host memory (device view)
+    int seq;              // this call's number
 };
 
 __device__ static float d2f(float ax, float ay, float az, float bx, float by, float bz)
@@ -447,7 +465,10 @@ __global__ __launch_bounds__(1024) void k3_finish(Det3dBufs B, int max_centers)
     }
     __syncthreads();
     if (tid < n) { B.ctl->croot[tid] = s_root[tid]; B.ctl->csize[tid] = s_size[tid]; B.ctl->crank[tid] = s_rank[tid]; }
-    if (tid == 0) B.ctl->K = n;
+    if (tid == 0) {
+        B.ctl->K = n;
+        d3_host_store16(&B.hout->head, (unsigned)n, (unsigned)s_err, (unsigned)M2, (unsigned)B.seq);   // the centres follow, each with its own tag
+    }
 }
 
 // Centroids: one WAVE per accepted component, four per workgroup, spread over the CUs (inside the single workgroup of
@@ -487,8 +508,10 @@ __global__ __launch_bounds__(256) void k3_centroids(Det3dBufs B, float sx, float
         const float sz = (float)B.ctl->csize[cidx];
         cx /= sz; cy /= sz;
         const int r = B.ctl->crank[cidx];
-        B.ctl->centers[2 * r] = (cs * cx + (-sn) * cy) + sx;                    // :96 Project2D(s2b).cast<float>() * p
-        B.ctl->centers[2 * r + 1] = (sn * cx + cs * cy) + sy;
+        const float ox = (cs * cx + (-sn) * cy) + sx, oy = (sn * cx + cs * cy) + sy;   // :96 Project2D(s2b).cast<float>() * p
+        B.ctl->centers[2 * r] = ox;
+        B.ctl->centers[2 * r + 1] = oy;
+        d3_host_store16(&B.hout->centers[r], __float_as_uint(ox), __float_as_uint(oy), (unsigned)B.seq, 0u);
     }
 }
 
@@ -501,8 +524,11 @@ struct rdet3d {
     hipStream_t stream;
     float *d_xyzi, *d_p1, *d_p2, *d_dist;
     int *d_label, *d_cnt, *d_last;
-    Det3dCtl *d_ctl, *h_ctl;
+    Det3dCtl *d_ctl;
+    Det3dHostOut *h_out, *dv_out;      // pinned + mapped: polled result slots (host / device view)
+    bool xyzi_in_vram;                 // d_xyzi is fine-grained device memory the host writes through the PCIe BAR (else: pinned staging + copy)
     float *h_stage;
+    int seq;
     std::string hip_error;
 };
 
@@ -531,7 +557,13 @@ int rdet3d_create(const rdet3d_options *opt, const double s2b[3], int max_points
     int rc = [&]() -> int {
         DET3_TRY(h, hipSetDevice(device));
         DET3_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-        DET3_TRY(h, hipMalloc(&h->d_xyzi, 16 * np));
+        if (hipExtMallocWithFlags((void **)&h->d_xyzi, 16 * np, hipDeviceMallocFinegrained) == hipSuccess) h->xyzi_in_vram = true;
+        else {
+            (void)hipGetLastError();
+            h->xyzi_in_vram = false;
+            DET3_TRY(h, hipMalloc(&h->d_xyzi, 16 * np));
+            DET3_TRY(h, hipHostMalloc(&h->h_stage, 16 * np));
+        }
         // + 1024 floats: the sweeps read candidates eight at a time through the scalar cache, unclamped, up to a few groups past the end
         DET3_TRY(h, hipMalloc(&h->d_p1, 12 * np + 4096)); DET3_TRY(h, hipMemset(h->d_p1, 0, 12 * np + 4096));
         DET3_TRY(h, hipMalloc(&h->d_p2, 12 * np + 4096)); DET3_TRY(h, hipMemset(h->d_p2, 0, 12 * np + 4096));
@@ -540,8 +572,10 @@ int rdet3d_create(const rdet3d_options *opt, const double s2b[3], int max_points
         DET3_TRY(h, hipMalloc(&h->d_cnt, 4 * np));
         DET3_TRY(h, hipMalloc(&h->d_last, 4 * np));
         DET3_TRY(h, hipMalloc(&h->d_ctl, sizeof(Det3dCtl)));
-        DET3_TRY(h, hipHostMalloc(&h->h_ctl, sizeof(Det3dCtl)));
-        DET3_TRY(h, hipHostMalloc(&h->h_stage, 16 * np));
+        DET3_TRY(h, hipHostMalloc(&h->h_out, sizeof(Det3dHostOut), hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(h->h_out, 0, sizeof(Det3dHostOut));
+        void *dv = nullptr;
+        DET3_TRY(h, hipHostGetDevicePointer(&dv, h->h_out, 0)); h->dv_out = (Det3dHostOut *)dv;
         return RDET_OK;
     }();
     if (rc != RDET_OK) { std::fprintf(stderr, "rdet3d_create: %s\n", h->hip_error.c_str()); rdet3d_destroy(h); return rc; }
@@ -556,7 +590,7 @@ void rdet3d_destroy(rdet3d_t *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void *ptrs[] = {h->d_xyzi, h->d_p1, h->d_p2, h->d_dist, h->d_label, h->d_cnt, h->d_last, h->d_ctl};
     for (void *p : ptrs) (void)hipFree(p);
-    if (h->h_ctl) (void)hipHostFree(h->h_ctl);
+    if (h->h_out) (void)hipHostFree(h->h_out);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -572,11 +606,18 @@ int rdet3d_handle_cloud(rdet3d_t *h, double stamp, const float *xyzi, int N, flo
     if (N == 0) return RDET_OK;
     if (N > h->max_points) return RDET_ERR_CAPACITY;
     DET3_TRY(h, hipSetDevice(h->device));
-    std::memcpy(h->h_stage, xyzi, sizeof(float) * 4 * (size_t)N);
-    DET3_TRY(h, hipMemcpyAsync(h->d_xyzi, h->h_stage, sizeof(float) * 4 * (size_t)N, hipMemcpyHostToDevice, h->stream));
+    DET3_TRY(h, hipStreamSynchronize(h->stream));                      // (the previous call returned on its last result slot, not on the kernels' end)
+    if (h->xyzi_in_vram) {                                             // the cloud goes straight into device memory: posted writes, no copy engine
+        std::memcpy(h->d_xyzi, xyzi, sizeof(float) * 4 * (size_t)N);
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    } else {
+        std::memcpy(h->h_stage, xyzi, sizeof(float) * 4 * (size_t)N);
+        DET3_TRY(h, hipMemcpyAsync(h->d_xyzi, h->h_stage, sizeof(float) * 4 * (size_t)N, hipMemcpyHostToDevice, h->stream));
+    }
     Det3dBufs B;
     B.xyzi = h->d_xyzi; B.p1 = h->d_p1; B.p2 = h->d_p2; B.dist = h->d_dist; B.label = h->d_label; B.cnt = h->d_cnt; B.last = h->d_last;
     B.ctl = h->d_ctl; B.cap = h->max_points;
+    B.hout = h->dv_out; B.seq = ++h->seq;
     const int blocks = (N + 63) / 64;                                 // 64 query points per workgroup; M <= N stays on the device
     const int ftiles = N > 0 ? (N + 1023) / 1024 : 1;
     hipLaunchKernelGGL(k3_filter_count, dim3(ftiles), dim3(1024), 0, h->stream, B, N, h->opt.intensity_min);
@@ -590,11 +631,34 @@ int rdet3d_handle_cloud(rdet3d_t *h, double stamp, const float *xyzi, int N, flo
     const float sa = (float)h->s2b[2];
     hipLaunchKernelGGL(k3_finish, dim3(1), dim3(1024), 0, h->stream, B, max_centers < RDET_MAX_CENTERS ? max_centers : RDET_MAX_CENTERS);
     hipLaunchKernelGGL(k3_centroids, dim3(RDET_MAX_CENTERS / 4), dim3(256), 0, h->stream, B, (float)h->s2b[0], (float)h->s2b[1], cosf(sa), sinf(sa));
-    DET3_TRY(h, hipMemcpyAsync(h->h_ctl, h->d_ctl, sizeof(Det3dCtl), hipMemcpyDeviceToHost, h->stream));
-    DET3_TRY(h, hipStreamSynchronize(h->stream));
-    if (h->h_ctl->err) return h->h_ctl->err;
-    *K = h->h_ctl->K;
-    if (*K > 0) std::memcpy(centers_xy, h->h_ctl->centers, sizeof(float) * 2 * (size_t)*K);
+    DET3_TRY(h, hipGetLastError());
+    // poll the head (written by k3_finish), then each centre's own tag (k3_centroids)
+    auto wait_tag = [&](const int *tag) -> int {
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (__atomic_load_n(tag, __ATOMIC_ACQUIRE) != B.seq) {
+            if ((++spins & 0xfffffu) == 0) {
+                if (hipStreamQuery(h->stream) != hipErrorNotReady) {
+                    DET3_TRY(h, hipStreamSynchronize(h->stream));
+                    if (__atomic_load_n(tag, __ATOMIC_ACQUIRE) == B.seq) break;
+                    h->hip_error = "the 3D detector's kernels finished without publishing their result";
+                    return RDET_ERR_HIP;
+                }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) { h->hip_error = "rdet3d: no result after 10 s"; return RDET_ERR_HIP; }
+            }
+        }
+        return RDET_OK;
+    };
+    int rc = wait_tag(&h->h_out->head.seq);
+    if (rc != RDET_OK) return rc;
+    const Det3dHead head = h->h_out->head;
+    if (head.err) return head.err;
+    *K = head.K;
+    for (int c = 0; c < head.K; ++c) {
+        rc = wait_tag(&h->h_out->centers[c].seq);
+        if (rc != RDET_OK) return rc;
+        centers_xy[2 * c] = h->h_out->centers[c].x; centers_xy[2 * c + 1] = h->h_out->centers[c].y;
+    }
     return RDET_OK;
 }
 
