@@ -157,6 +157,27 @@ __device__ static inline double vmax_f64(double a, double b)
 
 // wave-wide arg-min of (d, j) with the "first minimum in index order" rule
 // (cc:414-419 sorts with '<=' and takes front(); ties are UB there).
+// one DPP step of the wave-wide (smallest, its first index, second smallest) combine
+template <int CTRL, int ROW_MASK> __device__ static inline double dpp_f64(double neutral, double v)
+{
+    const long long nb = __double_as_longlong(neutral), vb = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp((int)nb, (int)vb, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(nb >> 32), (int)(vb >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ static inline double readlane_f64(double v, int lane)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ static inline void argmin2_combine(double &a1, int &ja, double &a2, double b1, int jb, double b2);
+template <int CTRL, int ROW_MASK> __device__ static inline void argmin2_dpp_step(double &g1, int &gj, double &g2)
+{
+    const double o1 = dpp_f64<CTRL, ROW_MASK>(1e300, g1), o2 = dpp_f64<CTRL, ROW_MASK>(1e300, g2);
+    const int oj = __builtin_amdgcn_update_dpp(-1, gj, CTRL, ROW_MASK, 0xf, false);
+    argmin2_combine(g1, gj, g2, o1, oj, o2);
+}
 __device__ static void wave_argmin(double &d, int &j)
 {
     for (int off = 32; off >= 1; off >>= 1) {
@@ -414,12 +435,16 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
                     b1 = vmin_f64(b1, d2);
                 }
             }
+            // wave-wide combine by six DPP steps (row shifts 1/2/4/8, row_bcast:15, row_bcast:31: lane 63 ends up with the
+            // whole wave; a lane without a source sees the neutral triple) instead of six rounds of LDS-crossbar shuffles
             double g1 = b1, g2 = b2; int gj = bj;
-            for (int off = 32; off >= 1; off >>= 1) {
-                const double ov = __shfl_xor(g1, off, WAVE), ov2 = __shfl_xor(g2, off, WAVE);
-                const int oj = __shfl_xor(gj, off, WAVE);
-                argmin2_combine(g1, gj, g2, ov, oj, ov2);
-            }
+            argmin2_dpp_step<0x111, 0xf>(g1, gj, g2);
+            argmin2_dpp_step<0x112, 0xf>(g1, gj, g2);
+            argmin2_dpp_step<0x114, 0xf>(g1, gj, g2);
+            argmin2_dpp_step<0x118, 0xf>(g1, gj, g2);
+            argmin2_dpp_step<0x142, 0xa>(g1, gj, g2);
+            argmin2_dpp_step<0x143, 0xc>(g1, gj, g2);
+            g1 = readlane_f64(g1, 63); g2 = readlane_f64(g2, 63); gj = __builtin_amdgcn_readlane(gj, 63);
             double best = sqrt(g1);
             if (g2 <= g1 * 1.000000000000002) {                    // literal scan (uniform, rare)
                 best = 0; gj = -1;
