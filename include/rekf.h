@@ -134,7 +134,9 @@ int rekf_get_state(rekf_t *h, double *t, int *n, double *mu, long mu_cap,
 int rekf_get_marker_ellipses(rekf_t *h, double *out5, int cap, int *count);
 
 /* Restore a full state (checkpoint resume / tests).  sigma column-major, ld = n.
- * vt3 = nullable last odometry velocity. */
+ * vt3 = nullable last odometry velocity.  sigma is stored as given, but it must be symmetric for the filter to continue
+ * from it: the kernels keep the covariance EXACTLY symmetric (every writer mirrors one computed value) and read whichever
+ * half is contiguous -- Predict the columns 0..2, the downdate the lower triangle. */
 int rekf_set_state(rekf_t *h, double t, int n, const double *mu, const double *sigma,
                    const double *vt3);
 

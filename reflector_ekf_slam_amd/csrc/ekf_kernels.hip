@@ -196,7 +196,6 @@ __device__ static void wave_argmin(double &d, int &j)
 __global__ __launch_bounds__(1024) void k_front(RekfDev d, RekfFrontArgs A)
 {
     __shared__ Motion mo;
-    __shared__ double pose[5];                 // x, y, theta, cos(theta), sin(theta) after Predict
 
     const int tid = threadIdx.x;
     RekfCtl *ctl = d.ctl;
@@ -205,20 +204,31 @@ __global__ __launch_bounds__(1024) void k_front(RekfDev d, RekfFrontArgs A)
     const size_t ld = (size_t)d.ld;
     const int n = (d.n_known >= 0) ? d.n_known : ctl->n;
     // ---- the covariance-predict operands and the pose block go in flight first
-    double c0[COV_PF], c1[COV_PF], c2[COV_PF], r0[COV_PF], r1[COV_PF], r2[COV_PF];
+    // P is exactly symmetric (every kernel that writes it mirrors: k_downdate2, the corner below, k_augment), so the row part
+    // P(0..2, idx) equals the column part P(idx, 0..2) bit for bit: only the coalesced columns are read, the strided rows are
+    // written from the same values
+    double c0[COV_PF], c1[COV_PF], c2[COV_PF];
 #pragma unroll
     for (int t = 0; t < COV_PF; ++t) {
         const int idx = tid + 1024 * t;
         if (idx >= 3 && idx < n) {
             c0[t] = P[idx + 0 * ld]; c1[t] = P[idx + 1 * ld]; c2[t] = P[idx + 2 * ld];   // column part (coalesced)
-            r0[t] = P[0 + idx * ld]; r1[t] = P[1 + idx * ld]; r2[t] = P[2 + idx * ld];   // row part (strided)
         }
     }
-    double C9[9], mu0 = 0, mu1 = 0, mu2 = 0;
+    double C9[9], mu0 = 0, mu1 = 0, mu2 = 0, th_new = 0;
     if (tid == 0) {
         for (int q = 0; q < 9; ++q) C9[q] = P[(q % 3) + (size_t)(q / 3) * ld];   // pose block, column-major 3x3
         mu0 = mu[0]; mu1 = mu[1]; mu2 = mu[2];
         motion_terms(A, mu2, mo);
+    }
+    if (tid == 64) {
+        // the new heading (cc:181 / :205: theta + w dt, wrapped by atan2(sin, cos)) on a lane of another SIMD, next to the
+        // motion terms' own sincos instead of behind it
+#pragma clang fp contract(off)
+        const double dth = A.vt[2] * A.dt;            // = mo.d[2] (delta_theta = w dt in both models; no FMA: same bits)
+        double th = mu[2] + dth, sn, cs;
+        sincos(th, &sn, &cs);
+        th_new = atan2(sn, cs);
     }
     __syncthreads();
 
@@ -231,35 +241,28 @@ __global__ __launch_bounds__(1024) void k_front(RekfDev d, RekfFrontArgs A)
         for (int t = 0; t < COV_PF; ++t) {
             const int idx = tid + 1024 * t;
             if (idx >= 3 && idx < n) {
-                P[idx + 0 * ld] = c0[t] + a * c2[t];
-                P[idx + 1 * ld] = c1[t] + b * c2[t];
-                P[0 + idx * ld] = r0[t] + a * r2[t];
-                P[1 + idx * ld] = r1[t] + b * r2[t];
+                const double n0 = c0[t] + a * c2[t], n1 = c1[t] + b * c2[t];
+                P[idx + 0 * ld] = n0;
+                P[idx + 1 * ld] = n1;
+                P[0 + idx * ld] = n0;
+                P[1 + idx * ld] = n1;
             }
         }
         for (int idx = tid + 1024 * COV_PF; idx < n; idx += 1024) {
             const double p2 = P[idx + 2 * ld];
-            P[idx + 0 * ld] = P[idx + 0 * ld] + a * p2;
-            P[idx + 1 * ld] = P[idx + 1 * ld] + b * p2;
-            const double q2 = P[2 + idx * ld];
-            P[0 + idx * ld] = P[0 + idx * ld] + a * q2;
-            P[1 + idx * ld] = P[1 + idx * ld] + b * q2;
+            const double n0 = P[idx + 0 * ld] + a * p2, n1 = P[idx + 1 * ld] + b * p2;
+            P[idx + 0 * ld] = n0;
+            P[idx + 1 * ld] = n1;
+            P[0 + idx * ld] = n0;
+            P[1 + idx * ld] = n1;
         }
         if (tid == 0) {
             corner_predict(C9, 3, mo);
             for (int q = 0; q < 9; ++q) P[(q % 3) + (size_t)(q / 3) * ld] = C9[q];
             // mean (cc:180-181 / :204-205)
-            const double x = mu0 + mo.d[0], y = mu1 + mo.d[1];
-            double th = mu2 + mo.d[2], sn, cs;
-            sincos(th, &sn, &cs);
-            th = atan2(sn, cs);
-            mu[0] = x; mu[1] = y; mu[2] = th;
-            pose[0] = x; pose[1] = y; pose[2] = th;
-            // the reference re-evaluates cos/sin(mu(2)) at every use (cc:252-253, :390-391);
-            // same argument, same value: evaluate once
-            sincos(th, &sn, &cs);
-            pose[3] = cs; pose[4] = sn;
+            mu[0] = mu0 + mo.d[0]; mu[1] = mu1 + mo.d[1];
         }
+        if (tid == 64) mu[2] = th_new;            // (every read of the old mu[2] happened before the barrier)
     }
     __syncthreads();
     if (!A.is_obs) return;                    // odometry path: HandleOdometryMessage cc:208-223
@@ -322,10 +325,9 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
 
     // operands that depend only on the old state go in flight first
     const int idx0 = b * 1024 + tid;
-    double c0 = 0, c1 = 0, c2 = 0, r0 = 0, r1 = 0, r2 = 0;
+    double c0 = 0, c1 = 0, c2 = 0;            // (columns only: P is exactly symmetric, see k_front)
     if (idx0 >= 3 && idx0 < n) {
         c0 = P[idx0 + 0 * ld]; c1 = P[idx0 + 1 * ld]; c2 = P[idx0 + 2 * ld];
-        r0 = P[0 + idx0 * ld]; r1 = P[1 + idx0 * ld]; r2 = P[2 + idx0 * ld];
     }
     // the first 1024 landmarks as float32 (cc:431), one per thread, into LDS: these loads fly under the trig chain below, and
     // the wave that matches then reads LDS instead of waiting for HBM four times in a row
@@ -363,20 +365,19 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
 #pragma clang fp contract(off)
         const double a = mo.a, bb = mo.b;
         if (idx0 >= 3 && idx0 < n) {
-            P[idx0 + 0 * ld] = c0 + a * c2;
-            P[idx0 + 1 * ld] = c1 + bb * c2;
-#ifndef REKF_EXP_NOROWS
-            P[0 + idx0 * ld] = r0 + a * r2;
-            P[1 + idx0 * ld] = r1 + bb * r2;
-#endif
+            const double n0 = c0 + a * c2, n1 = c1 + bb * c2;
+            P[idx0 + 0 * ld] = n0;
+            P[idx0 + 1 * ld] = n1;
+            P[0 + idx0 * ld] = n0;                        // the row part: the same values (P is symmetric)
+            P[1 + idx0 * ld] = n1;
         }
         for (int idx = idx0 + nb * 1024; idx < n; idx += nb * 1024) {
             const double p2 = P[idx + 2 * ld];
-            P[idx + 0 * ld] = P[idx + 0 * ld] + a * p2;
-            P[idx + 1 * ld] = P[idx + 1 * ld] + bb * p2;
-            const double q2 = P[2 + idx * ld];
-            P[0 + idx * ld] = P[0 + idx * ld] + a * q2;
-            P[1 + idx * ld] = P[1 + idx * ld] + bb * q2;
+            const double n0 = P[idx + 0 * ld] + a * p2, n1 = P[idx + 1 * ld] + bb * p2;
+            P[idx + 0 * ld] = n0;
+            P[idx + 1 * ld] = n1;
+            P[0 + idx * ld] = n0;
+            P[1 + idx * ld] = n1;
         }
         if (b == 0 && tid == 0) {
             corner_predict(C9, 3, mo);
