@@ -339,18 +339,19 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
     }
     double C9[9];
     if (tid == 0) {
-        // theta chain (sincos -> atan2 -> sincos, cc:181 / :205) on this lane; the motion terms, which have their own sincos,
-        // meanwhile on lane 0 of the next wave: two SIMDs instead of four libm calls in a row on one
+        // cos / sin of the new heading on this lane; the motion terms, which have their own sincos, meanwhile on lane 0 of the
+        // next wave.  DEVIATION (round-off level): the reference wraps the heading first, theta' = atan2(sin, cos)
+        // (cc:181 / :205), and takes cos / sin of theta' wherever it needs them (cc:252-253, :390-391); here they are taken of
+        // the unwrapped angle -- the same values up to the last place -- so that the match does not wait for a chain of three
+        // libm calls (2.1 us) but for one; theta' itself (what is committed to the mean) is computed as written, after the barrier.
 #pragma clang fp contract(off)
         if (b == 0) for (int q = 0; q < 9; ++q) C9[q] = P[(q % 3) + (size_t)(q / 3) * ld];
         const double mu2 = mu[2];
         const double dth = A.vt[2] * A.dt;            // = mo.d[2] (delta_theta = w dt in both models; no FMA: same bits)
         double th = mu2 + dth, sn, cs;
         sincos(th, &sn, &cs);
-        th = atan2(sn, cs);
-        sincos(th, &sn, &cs);
         pose[2] = th; pose[3] = cs; pose[4] = sn;
-        FMARK();                                      // 0: thread 0's trig chain done
+        FMARK();                                      // 0: thread 0's sincos done
     }
     if (tid == 64) {
         const double mu0 = mu[0], mu1 = mu[1], mu2 = mu[2];
@@ -382,9 +383,10 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
         if (b == 0 && tid == 0) {
             corner_predict(C9, 3, mo);
             for (int q = 0; q < 9; ++q) P[(q % 3) + (size_t)(q / 3) * ld] = C9[q];
-            for (int q = 0; q < 5; ++q) ctl->pose_pred[q] = pose[q];
+            ctl->pose_pred[0] = pose[0]; ctl->pose_pred[1] = pose[1]; ctl->pose_pred[3] = pose[3]; ctl->pose_pred[4] = pose[4];
             ctl->pose_pending = 1;
         }
+        if (b == 0 && tid == 128) ctl->pose_pred[2] = atan2(pose[4], pose[3]);     // the wrapped heading (cc:181 / :205), off the match's path
     }
 
     FMARK();                                          // 2: covariance slice written
