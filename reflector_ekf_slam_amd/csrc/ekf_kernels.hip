@@ -165,12 +165,6 @@ template <int CTRL, int ROW_MASK> __device__ static inline double dpp_f64(double
     const int hi = __builtin_amdgcn_update_dpp((int)(nb >> 32), (int)(vb >> 32), CTRL, ROW_MASK, 0xf, false);
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
-__device__ static inline double readlane_f64(double v, int lane)
-{
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)b, lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
-}
 __device__ static inline void argmin2_combine(double &a1, int &ja, double &a2, double b1, int jb, double b2);
 template <int CTRL, int ROW_MASK> __device__ static inline void argmin2_dpp_step(double &g1, int &gj, double &g2)
 {
@@ -386,22 +380,28 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
             ctl->pose_pred[0] = pose[0]; ctl->pose_pred[1] = pose[1]; ctl->pose_pred[3] = pose[3]; ctl->pose_pred[4] = pose[4];
             ctl->pose_pending = 1;
         }
-        if (b == 0 && tid == 128) ctl->pose_pred[2] = atan2(pose[4], pose[3]);     // the wrapped heading (cc:181 / :205), off the match's path
+        if (b == 0 && tid == 512) ctl->pose_pred[2] = atan2(pose[4], pose[3]);     // the wrapped heading (cc:181 / :205), on a wave that does not match
     }
 
     FMARK();                                          // 2: covariance slice written
-    // ---- ReflectorMatch (cc:370-455): whole observations per workgroup, ONE wave each (lanes sweep the landmarks 64 apart,
-    // wave-wide literal arg-min by shuffles: no block barrier on the way -- the 1024-thread version with two-level
-    // reductions took 3 us per observation)
+    // ---- ReflectorMatch (cc:370-455): whole observations per workgroup.  The state sweep of an observation is split over FOUR
+    // waves (wave w takes the landmarks j0 + 64 w + lane: one candidate per lane and round, out of the LDS-staged means), each
+    // reduces by DPP steps, the four partial (smallest, first index, second smallest) triples meet in LDS behind ONE block
+    // barrier and wave 0 finishes (one wave alone needed 2.7 us per observation, the 1024-thread version with two-level
+    // reductions 3 us).  The map match and the literal rescan stay on wave 0.
     const int M_ = d.M_map;
-    if (tid < 64) for (int i = b; i < K; i += nb) {
-        float gx, gy;
-        obs_to_global(pose[0], pose[1], pose[3], pose[4], rekf_obs(A, 2 * i), rekf_obs(A, 2 * i + 1), gx, gy);
+    __shared__ double s_part[2][4][2];
+    __shared__ int s_partj[2][4];
+    const int mwave = tid >> 6, mlane = tid & 63;
+    int it = 0;
+    for (int i = b; i < K; i += nb, ++it) {
+        float gx = 0.f, gy = 0.f;
+        if (mwave < 4) obs_to_global(pose[0], pose[1], pose[3], pose[4], rekf_obs(A, 2 * i), rekf_obs(A, 2 * i + 1), gx, gy);
         int kind = 2, best_j = -1;
-        if (M_ > 0) {                                              // cc:401-425
+        if (mwave == 0 && M_ > 0) {                                // cc:401-425
 #pragma clang fp contract(off)
             double best = 0; int bj = -1;
-            for (int j = tid; j < M_; j += 64) {
+            for (int j = mlane; j < M_; j += 64) {
                 const double *S = d.map_cov + 4 * (size_t)j;
                 const float ex = d.map_xy[2 * j] - gx;
                 const float ey = d.map_xy[2 * j + 1] - gy;
@@ -414,32 +414,25 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
             wave_argmin(best, bj);
             if (bj >= 0 && best < 0.05) { kind = 0; best_j = bj; }
         }
-        if (kind == 2 && L > 0) {                                  // cc:426-451
+        if (mwave < 4 && L > 0) {                                  // cc:426-451, this wave's quarter of the landmarks
 #pragma clang fp contract(off)
             // smallest and second smallest SQUARED distance with the first index of the smallest: the sqrt is taken once, and
             // only if the two are within rounding of each other does the literal scan (sqrt per candidate) decide
             double b1 = 1e300, b2 = 1e300; int bj = -1;
             for (int j0 = 0; j0 < L; j0 += 256) {
-                float lx[4], ly[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = j0 + 64 * u + tid, jc = j < L ? j : L - 1;
-                    if (j0 < 1024) { lx[u] = s_lmx[jc & 1023]; ly[u] = s_lmy[jc & 1023]; }                  // staged above
-                    else { lx[u] = (float)mu[3 + 2 * jc]; ly[u] = (float)mu[4 + 2 * jc]; }     // cc:431
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = j0 + 64 * u + tid;
-                    const float ex = gx - lx[u], ey = gy - ly[u];      // cc:433
-                    const double dx = (double)ex, dy = (double)ey;
-                    const double d2 = (j < L) ? dx * dx + dy * dy : 1e300;
-                    b2 = vmin_f64(b2, vmax_f64(d2, b1));
-                    bj = (d2 < b1) ? j : bj;
-                    b1 = vmin_f64(b1, d2);
-                }
+                const int j = j0 + 64 * mwave + mlane, jc = j < L ? j : L - 1;
+                float lx, ly;
+                if (j0 < 1024) { lx = s_lmx[jc & 1023]; ly = s_lmy[jc & 1023]; }                  // staged above
+                else { lx = (float)mu[3 + 2 * jc]; ly = (float)mu[4 + 2 * jc]; }        // cc:431
+                const float ex = gx - lx, ey = gy - ly;                // cc:433
+                const double dx = (double)ex, dy = (double)ey;
+                const double d2 = (j < L) ? dx * dx + dy * dy : 1e300;
+                b2 = vmin_f64(b2, vmax_f64(d2, b1));
+                bj = (d2 < b1) ? j : bj;
+                b1 = vmin_f64(b1, d2);
             }
             // wave-wide combine by six DPP steps (row shifts 1/2/4/8, row_bcast:15, row_bcast:31: lane 63 ends up with the
-            // whole wave; a lane without a source sees the neutral triple) instead of six rounds of LDS-crossbar shuffles
+            // whole wave; a lane without a source sees the neutral triple)
             double g1 = b1, g2 = b2; int gj = bj;
             argmin2_dpp_step<0x111, 0xf>(g1, gj, g2);
             argmin2_dpp_step<0x112, 0xf>(g1, gj, g2);
@@ -447,22 +440,31 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
             argmin2_dpp_step<0x118, 0xf>(g1, gj, g2);
             argmin2_dpp_step<0x142, 0xa>(g1, gj, g2);
             argmin2_dpp_step<0x143, 0xc>(g1, gj, g2);
-            g1 = readlane_f64(g1, 63); g2 = readlane_f64(g2, 63); gj = __builtin_amdgcn_readlane(gj, 63);
-            double best = sqrt(g1);
-            if (g2 <= g1 * 1.000000000000002) {                    // literal scan (uniform, rare)
-                best = 0; gj = -1;
-                for (int j = tid; j < L; j += 64) {
-                    const float lx = (float)mu[3 + 2 * j], ly = (float)mu[4 + 2 * j];
-                    const float ex = gx - lx, ey = gy - ly;
-                    const double dx = (double)ex, dy = (double)ey;
-                    const double dist = sqrt(dx * dx + dy * dy);   // cc:437
-                    if (gj < 0 || dist < best) { best = dist; gj = j; }
-                }
-                wave_argmin(best, gj);
-            }
-            if (gj >= 0 && best < 0.6) { kind = 1; best_j = gj; }  // cc:446
+            if (mlane == 63) { s_part[it & 1][mwave][0] = g1; s_part[it & 1][mwave][1] = g2; s_partj[it & 1][mwave] = gj; }
         }
-        if (tid == 0) { ctl->obs_kind[i] = kind; ctl->obs_idx[i] = best_j; }
+        __syncthreads();        // (the buffer of round it is written again in round it + 2: the barrier of round it + 1 lies between)
+        if (mwave == 0) {
+            if (kind == 2 && L > 0) {
+#pragma clang fp contract(off)
+                double g1 = s_part[it & 1][0][0], g2 = s_part[it & 1][0][1]; int gj = s_partj[it & 1][0];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) argmin2_combine(g1, gj, g2, s_part[it & 1][w][0], s_partj[it & 1][w], s_part[it & 1][w][1]);
+                double best = sqrt(g1);
+                if (g2 <= g1 * 1.000000000000002) {                    // literal scan (uniform, rare)
+                    best = 0; gj = -1;
+                    for (int j = mlane; j < L; j += 64) {
+                        const float lx = (float)mu[3 + 2 * j], ly = (float)mu[4 + 2 * j];
+                        const float ex = gx - lx, ey = gy - ly;
+                        const double dx = (double)ex, dy = (double)ey;
+                        const double dist = sqrt(dx * dx + dy * dy);   // cc:437
+                        if (gj < 0 || dist < best) { best = dist; gj = j; }
+                    }
+                    wave_argmin(best, gj);
+                }
+                if (gj >= 0 && best < 0.6) { kind = 1; best_j = gj; }  // cc:446
+            }
+            if (mlane == 0) { ctl->obs_kind[i] = kind; ctl->obs_idx[i] = best_j; }
+        }
     }
     FMARK();                                          // 3: match done
 #ifdef REKF_DEBUG_FRONT
