@@ -317,7 +317,10 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
     const int L = (n - 3) / 2;
     const int K = A.K;
 
-    // operands that depend only on the old state go in flight first
+    // operands that depend only on the old state go in flight first -- and this workgroup's first observation: a dynamically
+    // indexed kernel argument is a scalar load of its own, issued where it is used (inside the match, it cost a memory round trip)
+    float ob0x = 0.f, ob0y = 0.f;
+    if (b < K) { ob0x = rekf_obs(A, 2 * b); ob0y = rekf_obs(A, 2 * b + 1); }
     const int idx0 = b * 1024 + tid;
     double c0 = 0, c1 = 0, c2 = 0;            // (columns only: P is exactly symmetric, see k_front)
     if (idx0 >= 3 && idx0 < n) {
@@ -396,8 +399,10 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
     int it = 0;
     for (int i = b; i < K; i += nb, ++it) {
         float gx = 0.f, gy = 0.f;
-        if (mwave < 4) obs_to_global(pose[0], pose[1], pose[3], pose[4], rekf_obs(A, 2 * i), rekf_obs(A, 2 * i + 1), gx, gy);
+        const float obx = (it == 0) ? ob0x : rekf_obs(A, 2 * i), oby = (it == 0) ? ob0y : rekf_obs(A, 2 * i + 1);
+        if (mwave < 4) obs_to_global(pose[0], pose[1], pose[3], pose[4], obx, oby, gx, gy);
         int kind = 2, best_j = -1;
+        FMARK();                                      // m0: observation in the global frame
         if (mwave == 0 && M_ > 0) {                                // cc:401-425
 #pragma clang fp contract(off)
             double best = 0; int bj = -1;
@@ -440,9 +445,11 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
             argmin2_dpp_step<0x118, 0xf>(g1, gj, g2);
             argmin2_dpp_step<0x142, 0xa>(g1, gj, g2);
             argmin2_dpp_step<0x143, 0xc>(g1, gj, g2);
+            FMARK();                                  // m1: swept and reduced
             if (mlane == 63) { s_part[it & 1][mwave][0] = g1; s_part[it & 1][mwave][1] = g2; s_partj[it & 1][mwave] = gj; }
         }
         __syncthreads();        // (the buffer of round it is written again in round it + 2: the barrier of round it + 1 lies between)
+        FMARK();                                      // m2: barrier passed
         if (mwave == 0) {
             if (kind == 2 && L > 0) {
 #pragma clang fp contract(off)
