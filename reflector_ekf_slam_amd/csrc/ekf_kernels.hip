@@ -796,7 +796,6 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
     constexpr int NKCP = NKC + 1;                 // sub-block row stride in LDS (even: 16-byte pairs start on odd columns 3 + 2q, read as 8-byte-aligned vectors)
     __shared__ __attribute__((aligned(16))) double s_big[(NKCP * 2 * NRS > MP * LDS_S) ? NKCP * 2 * NRS : MP * LDS_S];
     __shared__ __attribute__((aligned(16))) double s_pw[NKC][MID_ROWS];     // P(own rows, sub-block columns)
-    __shared__ __attribute__((aligned(16))) double s_ph[MID_ROWS][2 * NRS]; // P(sub-block rows, own columns)
     __shared__ double s_dmu[4][MID_ROWS];
     __shared__ int s_pair_obs[NPAIR], s_pair_id[NPAIR], s_pair_state[NPAIR], s_pcol[NPAIR], s_rank[NPAIR], s_rsrow[NRS], s_cnt[5];
     double (*s_psub)[NKCP] = (double (*)[NKCP])s_big;                       // [row 2 rs + {0,1} of the sub-block][its column kc]
@@ -970,8 +969,6 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
     }
     constexpr int PW_IT = (NKC * 8 + 255) / 256;
     v2d pw[PW_IT];
-    constexpr int PH_IT = MID_ROWS / 4;
-    v2du ph[PH_IT];
     if (!steam) {
         const int pr = tid & 7, sub = (tid >> 3) & 7;                       // 8 columns x 8 row pairs per wave instruction
         const char *own_ptr = (const char *)(P + i0 + 2 * pr);
@@ -982,9 +979,8 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
             const int cA = __shfl(colA, kc & 63, 64), cB = __shfl(colB, kc & 63, 64);
             pw[it] = *(const v2d *)(own_ptr + (unsigned)((kc < 64) ? cA : cB) * ldb);
         }
-#pragma unroll
-        for (int it = 0; it < PH_IT; ++it)
-            ph[it] = *(const v2du *)(my_row_ptr + (unsigned)(i0 + kc0 + 4 * it) * ldb);
+        // (no gather of P(sub-block rows, own columns) for (H P)^T: P is exactly symmetric -- every kernel that writes it mirrors --
+        // so (H P)^T(c, r) is W(c, r) bit for bit and is stored from the own-row values below)
     }
     MMARK();                                        // 1: gathers issued
 
@@ -1038,10 +1034,6 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
             }
         }
     } else {
-        if (lane < nrs) {
-#pragma unroll
-            for (int it = 0; it < PH_IT; ++it) *(v2d *)&s_ph[kc0 + 4 * it][2 * lane] = (v2d){ph[it].x, ph[it].y};
-        }
         const int pr = tid & 7, sub = (tid >> 3) & 7;
 #pragma unroll
         for (int it = 0; it < PW_IT; ++it) {
@@ -1119,31 +1111,12 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
                     if (c >= n) vx = 0.0;
                     if (c + 1 >= n) vy = 0.0;
                     *(v2d *)&s_wown[r][2 * pr] = (v2d){vx, vy};
-                }
-            }
-        }
-        // own columns: item (column cidx, q) -> (H P)^T(c, 2q..2q+1), q = tt / 16 (+ 16 per pass): 16 lanes store 128 contiguous bytes
-        const int cidx = tt & 15, c = i0 + cidx;
-        const double q0 = s_ph[cidx][2 * NS], q1 = s_ph[cidx][2 * NS + 1], q2v = s_ph[cidx][2 * NS + 2];
-        double *hp_out = d.HPt + c;
-#pragma unroll
-        for (int pass = 0; pass < (NPAIR + 15) / 16; ++pass) {
-            const int q = (tt >> 4) + 16 * pass;
-            if (q < nq) {
-                const bool hc = s_pcol[q] >= 0;
-                v2d ql = {0, 0};
-                if (hc) ql = *(const v2d *)&s_ph[cidx][2 * s_rank[q]];
-#pragma unroll
-                for (int rr = 0; rr < 2; ++rr) {
-                    const int r = 2 * q + rr;
-                    const double *h = s_coef + 8 * r;
-                    double u = h[0] * q0;
-                    u += h[1] * q1;
-                    u += h[2] * q2v;
-                    if (hc) { u += h[3] * ql.x; u += h[4] * ql.y; }
-                    if (c >= n) u = 0.0;
-                    hp_out[(size_t)r * ld] = u;
-                    if (strip_nb >= 0 && c >= strip_nb && c < strip_nb + REKF_STRIP_MAX) d.HPtB[(c - strip_nb) * REKF_MR_PAD + r] = u;
+                    // (H P)^T(c, r) = W(c, r) (symmetric P): 8 lanes store 128 contiguous bytes of column r
+                    *(v2d *)&d.HPt[(size_t)c + (size_t)r * ld] = (v2d){vx, vy};
+                    if (strip_nb >= 0) {
+                        if (c >= strip_nb && c < strip_nb + REKF_STRIP_MAX) d.HPtB[(c - strip_nb) * REKF_MR_PAD + r] = vx;
+                        if (c + 1 >= strip_nb && c + 1 < strip_nb + REKF_STRIP_MAX) d.HPtB[(c + 1 - strip_nb) * REKF_MR_PAD + r] = vy;
+                    }
                 }
             }
         }
