@@ -333,7 +333,9 @@ def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world):
         "per_launch_bracket_us": kernel_us.get("downdate"), "empty_event_bracket_us": kernel_us.get("empty"),
         "rocprof_avg_launch_us": rocprof_us, "rocprof_source": rocprof_src,
         "mfma": {"achieved_tflops": flop_k7 / (dd_us * 1e-6) / 1e12, "peak_tflops": FP64_MFMA_PEAK_TF,
-                 "frac": flop_k7 / (dd_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF}}
+                 "frac": flop_k7 / (dd_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF,
+                 "note": "algorithmic 2 n^2 m FLOP over the measured time; the mirrored kernel EXECUTES about half of them "
+                         "(lower-triangle tiles: SQ_VALU_MFMA_BUSY_CYCLES 8.65 M vs 16.78 M for the full square, profiles/r02x_pmc_mfma.txt)"}}
     out["kernel_us"] = kernel_us
     if ms_result is not None:
         out["multi_session"] = ms_result
