@@ -26,6 +26,7 @@
 // where the reference is (geometry, point time stored in a Vector3f) and FP64 where it is (poses,
 // odometry).
 #include "../../include/rdet.h"
+#include "host_visible.h"
 
 #include <hip/hip_runtime.h>
 
@@ -729,11 +730,11 @@ int rdet2d_create(const rdet2d_options *opt, const double s2b[3], int max_beams,
         DET_TRY(h, hipMalloc(&h->d_returns_all, 8 * nb)); DET_TRY(h, hipMalloc(&h->d_cmask, 8 * (nb / 64 + 1)));
         DET_TRY(h, hipMalloc(&h->d_done, sizeof(int)));
         DET_TRY(h, hipMemset(h->d_done, 0, sizeof(int)));
-        if (hipExtMallocWithFlags((void **)&h->h_scan, 4 * nb * 2, hipDeviceMallocFinegrained) == hipSuccess) {
+        h->h_scan = (float *)host_visible::alloc(4 * nb * 2);
+        if (h->h_scan) {
             h->scan_in_vram = true;
             h->dv_scan = h->h_scan;
         } else {
-            (void)hipGetLastError();
             h->scan_in_vram = false;
             DET_TRY(h, hipHostMalloc(&h->h_scan, 4 * nb * 2, hipHostMallocMapped | hipHostMallocCoherent));
             void *dvs = nullptr;

@@ -22,6 +22,7 @@
 // tree build would be pointer-chasing.  Nothing waits on the host between stages: the point
 // counts M, M2 stay on the device and every grid is sized for the capacity.
 #include "../../include/rdet.h"
+#include "host_visible.h"
 
 #include <hip/hip_runtime.h>
 
@@ -557,9 +558,9 @@ int rdet3d_create(const rdet3d_options *opt, const double s2b[3], int max_points
     int rc = [&]() -> int {
         DET3_TRY(h, hipSetDevice(device));
         DET3_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-        if (hipExtMallocWithFlags((void **)&h->d_xyzi, 16 * np, hipDeviceMallocFinegrained) == hipSuccess) h->xyzi_in_vram = true;
+        h->d_xyzi = (float *)host_visible::alloc(16 * np);
+        if (h->d_xyzi) h->xyzi_in_vram = true;
         else {
-            (void)hipGetLastError();
             h->xyzi_in_vram = false;
             DET3_TRY(h, hipMalloc(&h->d_xyzi, 16 * np));
             DET3_TRY(h, hipHostMalloc(&h->h_stage, 16 * np));

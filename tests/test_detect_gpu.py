@@ -127,6 +127,39 @@ def test_invalid_stretches_and_bright_beams_outside_the_message_range(oracle_lib
             _compare(g, o, sc)
 
 
+def test_detectors_without_the_pcie_bar_path(oracle_lib):
+    """RDET_NO_BAR=1 forces the fallback of platforms whose BAR does not cover device memory (pinned staging + copy instead
+    of the host writing the scan / cloud straight into fine-grained device memory): same results, in a fresh process."""
+    import os, subprocess, sys
+    code = (
+        "import sys; sys.path.insert(0, '.')\n"
+        "import numpy as np\n"
+        "from tests.test_detect_gpu import _pair, _compare, _feed_odom\n"
+        "from tests.detect_cases import S2B, world_scan, odom_stream\n"
+        "from reflector_ekf_slam_amd import synth\n"
+        "from reflector_ekf_slam_amd.detect import PointCloudOptions, PointCloudReflectorDetect\n"
+        "from oracle.binding import oracle_detect3d\n"
+        "sc, _ = world_scan(seed=4, pose=(12.0, 20.0, 1.0))\n"
+        "g, o = _pair(S2B)\n"
+        "_feed_odom(g, o, odom_stream(sc.stamp - 0.3, sc.stamp + 0.05))\n"
+        "for k in range(3):\n"
+        "    obs = _compare(g, o, sc); sc.stamp += 0.1\n"
+        "assert obs.cloud_.shape[0] >= 10\n"
+        "rng = np.random.Generator(np.random.PCG64(3))\n"
+        "lms = synth.make_world(synth.C4, rng)\n"
+        "cloud = synth.make_point_cloud(lms, (float(lms[:, 0].mean()), float(lms[:, 1].mean()), 0.3), rng, rings=16, n_az=900)\n"
+        "d3 = PointCloudReflectorDetect(PointCloudOptions(), max_points=cloud.shape[0])\n"
+        "for k in range(2):\n"
+        "    ob3 = d3.HandlePointCloud(1.0 + k, cloud)\n"
+        "co, _, _ = oracle_detect3d(cloud)\n"
+        "assert ob3.cloud_.shape == co.shape and np.array_equal(ob3.cloud_, co)\n"
+        "print('fallback ok', obs.cloud_.shape[0], co.shape[0])\n")
+    env = dict(os.environ, RDET_NO_BAR="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert out.returncode == 0 and "fallback ok" in out.stdout, out.stderr[-3000:]
+
+
 def test_bad_scan_and_capacity_are_error_codes(oracle_lib):
     from reflector_ekf_slam_amd.detect import LaserReflectorDetect, RdetError, ReflectorDetectOptions
     g = LaserReflectorDetect(ReflectorDetectOptions(), max_beams=256)
