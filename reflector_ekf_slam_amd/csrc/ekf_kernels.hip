@@ -1399,14 +1399,14 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     // a diagonal tile of the range is taken LAST (its strip work then rides on a tile that has nothing to prefetch);
     // should a range ever hold more than one, the others are still handled where they stand (`special` below)
     const int TT = SB ? T - 1 : T;                          // side of the triangle that is enumerated (SB: the strictly lower one)
-    auto tri_col = [&](int Jc) __attribute__((always_inline)) -> int { return Jc * TT - (Jc * (Jc - 1)) / 2; };   // first tile of column Jc
+    // tile number -> (row, column) of the triangle, with a cursor (column, its first tile number) that moves to the queried tile:
+    // a workgroup asks for a handful of neighbouring tiles, so after the first query (<= T scalar steps) every look-up is O(1).
+    // (A closed form with sqrtf + fix-up loops, evaluated afresh for each of the ~8 look-ups of the prologue, cost 0.8 us.)
+    int cur_J = 0, cur_c0 = 0;
     auto tri_IJ = [&](int tt, int &It, int &Jt) __attribute__((always_inline)) {
-        const float b = 2.0f * (float)TT + 1.0f;
-        int Jg = (int)((b - sqrtf(b * b - 8.0f * (float)tt)) * 0.5f);
-        Jg = max(0, min(TT - 1, Jg));
-        while (Jg + 1 < TT && tri_col(Jg + 1) <= tt) ++Jg;
-        while (Jg > 0 && tri_col(Jg) > tt) --Jg;
-        Jt = Jg; It = Jg + (tt - tri_col(Jg));
+        while (cur_J + 1 < TT && tt >= cur_c0 + (TT - cur_J)) { cur_c0 += TT - cur_J; ++cur_J; }
+        while (cur_J > 0 && tt < cur_c0) { --cur_J; cur_c0 -= TT - cur_J; }
+        Jt = cur_J; It = cur_J + (tt - cur_c0);
     };
     // SYM order of the tiles: the triangle column by column, except that the last diagonal tile (T-1,T-1) is moved from the
     // end to the middle of column 0: a diagonal tile costs more than the others, and the tail of the list would otherwise put
