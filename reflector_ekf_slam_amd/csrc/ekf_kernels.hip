@@ -1383,9 +1383,17 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
         j_lo = rj * T / 4; j_n = (rj + 1) * T / 4 - j_lo;
         w = blockIdx.x >> 3; nw = gridDim.x >> 3;
     }
-    const int ntiles = SYM ? T * (T + 1) / 2 : i_n * j_n;
-    const int t_begin = SB ? 0 : (int)(((long long)w * ntiles) / nw);
-    const int t_end = SB ? ((w < sb_off) ? 1 : min(2, T - 2 * (w - sb_off))) : (int)(((long long)(w + 1) * ntiles) / nw);
+    // SYM (persistent): two classes of workgroups.  Class A, workgroups [0, T): the diagonal tile (w, w) -- it costs almost two
+    // ordinary tiles: no transposed image, but the border strips and the symmetric finish -- behind the tile below it, (w+1, w),
+    // which shares its HPt panel.  Class B, the rest: the tiles with I >= J + 2, column by column, in equal ranges (3 per
+    // workgroup at T = 32).  With the diagonal tiles inside equal ranges of three, the workgroups that held one set the pace.
+    const bool classA = SYM && !SB && w < T;
+    const int nB = (T - 1) * (T - 2) / 2, nwB = nw - T;     // class B: tiles and workgroups
+    const int ntiles = SYM ? nB : i_n * j_n;
+    const int wq = SYM && !SB ? w - T : w, nwq = SYM && !SB ? (nwB > 0 ? nwB : 1) : nw;
+    const int t_begin = (SB || classA) ? 0 : (int)(((long long)wq * ntiles) / nwq);
+    const int t_end = SB ? ((w < sb_off) ? 1 : min(2, T - 2 * (w - sb_off)))
+                         : (classA ? ((w + 1 < T) ? 2 : 1) : (wq < nwq ? (int)(((long long)(wq + 1) * ntiles) / nwq) : 0));
     if (t_begin >= t_end) return;
     const int nt = t_end - t_begin;
     const size_t ld = (size_t)d.ld;
@@ -1398,7 +1406,7 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
 
     // a diagonal tile of the range is taken LAST (its strip work then rides on a tile that has nothing to prefetch);
     // should a range ever hold more than one, the others are still handled where they stand (`special` below)
-    const int TT = SB ? T - 1 : T;                          // side of the triangle that is enumerated (SB: the strictly lower one)
+    const int TT = SB ? T - 1 : T - 2;                      // side of the triangle that is enumerated (SB: I > J; class B: I >= J + 2)
     // tile number -> (row, column) of the triangle, with a cursor (column, its first tile number) that moves to the queried tile:
     // a workgroup asks for a handful of neighbouring tiles, so after the first query (<= T scalar steps) every look-up is O(1).
     // (A closed form with sqrtf + fix-up loops, evaluated afresh for each of the ~8 look-ups of the prologue, cost 0.8 us.)
@@ -1408,25 +1416,8 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
         while (cur_J > 0 && tt < cur_c0) { --cur_J; cur_c0 -= TT - cur_J; }
         Jt = cur_J; It = cur_J + (tt - cur_c0);
     };
-    // SYM order of the tiles: the triangle column by column, except that the last diagonal tile (T-1,T-1) is moved from the
-    // end to the middle of column 0: a diagonal tile costs more than the others, and the tail of the list would otherwise put
-    // two of them -- (T-2,T-2) and (T-1,T-1) -- into one workgroup's range.
-    const int sym_ins = (T >= 4) ? T / 2 : -1;
-    auto sym_IJ = [&](int tt, int &It, int &Jt) __attribute__((always_inline)) {
-        if (sym_ins >= 0) {
-            if (tt == sym_ins) { It = T - 1; Jt = T - 1; return; }
-            if (tt > sym_ins) tt -= 1;
-        }
-        tri_IJ(tt, It, Jt);
-    };
     int t_diag = t_end - 1;
-    if (SB) {
-    } else if (SYM) {                                       // a diagonal tile of the range goes last (the last one, should there be several)
-        for (int t = t_begin; t < t_end; ++t) {
-            int It, Jt;
-            sym_IJ(t, It, Jt);
-            if (It == Jt) t_diag = t;
-        }
+    if (SB || SYM) {                                        // (class A has its diagonal tile last by construction, class B has none)
     } else if (strips) {
         const int dl = j_lo - i_lo;
         for (int jj = t_begin / i_n; jj <= (t_end - 1) / i_n; ++jj) {
@@ -1442,7 +1433,11 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
         }
         const int tile = t_begin + pos;
         const int tt = (tile == t_end - 1) ? t_diag : ((tile == t_diag) ? t_end - 1 : tile);
-        if (SYM) { sym_IJ(tt, I, J); return; }
+        if (SYM) {
+            if (classA) { I = (pos == 0 && nt == 2) ? w + 1 : w; J = w; }
+            else { tri_IJ(tt, I, J); I += 2; }
+            return;
+        }
         const int jj = tt / i_n;
         I = i_lo + (tt - jj * i_n); J = j_lo + jj;
     };
@@ -1723,11 +1718,10 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
             double *Pw = p_ptr(I, J);
 #pragma unroll
             for (int q = 0; q < 8; ++q) DD_STORE((v2d *)(Pw + (size_t)(8 * (q & 3) + (q >> 2)) * ld), pq[PAR][q]);
-            if (SYM) {
+            if (SYM && I != J) {                            // (a diagonal tile has no transposed image; nothing counts VMEM operations after the last tile)
                 double *Pwm = pm_ptr(I, J);
-                const bool diag = I == J;
 #pragma unroll
-                for (int x = 0; x < 8; ++x) second_store(pq[PAR], Pw, Pwm, diag, x);
+                for (int x = 0; x < 8; ++x) second_store(pq[PAR], Pw, Pwm, false, x);
             }
             return;
         }
@@ -2068,11 +2062,13 @@ void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s)
     const int slots = n_cu * DD_WG_PER_CU;
     int grid;
     if (full) grid = (T * T < slots) ? T * T : slots;
-    else if (persistent) {                          // the triangle: equal ranges, as few tiles per workgroup as the CUs allow
-        const int ntiles = T * (T + 1) / 2, per = (ntiles + slots - 1) / slots;
-        grid = (ntiles + per - 1) / per;
+    else if (persistent) {                          // T class-A workgroups (diagonal tile + the one below) + equal ranges of the rest
+        const int nB = (T - 1) * (T - 2) / 2, room = (slots - T > 1) ? slots - T : 1;
+        const int per = (nB + room - 1) / room;
+        grid = T + (nB > 0 ? (nB + per - 1) / per : 0);
+        if (grid >= 64) grid = (grid + 7) & ~7;     // multiple of 8 for the per-XCD numbering (workgroups past the last range return at once)
     } else grid = T * (T - 1) / 2 + (T + 1) / 2;    // SB: one workgroup per off-diagonal tile, one per pair of diagonal tiles
-    if ((full || persistent) && grid >= 64) grid &= ~7;   // multiple of 8: enables the per-XCD tile ranges / regions
+    if (full && grid >= 64) grid &= ~7;             // multiple of 8: enables the per-XCD tile regions
     const int kc = (d.kc_ub < 16) ? 16 : ((d.kc_ub > 64) ? 64 : d.kc_ub);    // one k-chunk: the host never asks for more than 64 rows per step
     const unsigned bit = 1u << (kc / 16);
     const bool first = !(attr_done[slot] & bit) || dev != slot;
