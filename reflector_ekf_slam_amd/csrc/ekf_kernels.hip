@@ -1391,9 +1391,12 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     const int nB = (T - 1) * (T - 2) / 2, nwB = nw - T;     // class B: tiles and workgroups
     const int ntiles = SYM ? nB : i_n * j_n;
     const int wq = SYM && !SB ? w - T : w, nwq = SYM && !SB ? (nwB > 0 ? nwB : 1) : nw;
-    const int t_begin = (SB || classA) ? 0 : (int)(((long long)wq * ntiles) / nwq);
+    // (class B with the host's tiles-per-workgroup: plain multiples, no 64-bit divisions in the prologue)
+    const bool fixed_per = SYM && !SB && d.dd_per > 0;
+    const int t_begin = (SB || classA) ? 0 : (fixed_per ? min(wq * d.dd_per, ntiles) : (int)(((long long)wq * ntiles) / nwq));
     const int t_end = SB ? ((w < sb_off) ? 1 : min(2, T - 2 * (w - sb_off)))
-                         : (classA ? ((w + 1 < T) ? 2 : 1) : (wq < nwq ? (int)(((long long)(wq + 1) * ntiles) / nwq) : 0));
+                         : (classA ? ((w + 1 < T) ? 2 : 1)
+                                   : (fixed_per ? min((wq + 1) * d.dd_per, ntiles) : (wq < nwq ? (int)(((long long)(wq + 1) * ntiles) / nwq) : 0)));
     if (t_begin >= t_end) return;
     const int nt = t_end - t_begin;
     const size_t ld = (size_t)d.ld;
@@ -1411,6 +1414,13 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     // a workgroup asks for a handful of neighbouring tiles, so after the first query (<= T scalar steps) every look-up is O(1).
     // (A closed form with sqrtf + fix-up loops, evaluated afresh for each of the ~8 look-ups of the prologue, cost 0.8 us.)
     int cur_J = 0, cur_c0 = 0;
+    if ((SYM || SB) && TT > 0) {                            // the cursor starts at a closed-form estimate of the first tile's column (one sqrtf, once)
+        const int t0 = SB ? w : t_begin;
+        const float bq = 2.0f * (float)TT + 1.0f;
+        int Jg = (int)((bq - sqrtf(fmaxf(bq * bq - 8.0f * (float)t0, 0.0f))) * 0.5f);
+        Jg = max(0, min(TT - 1, Jg));
+        cur_J = Jg; cur_c0 = Jg * TT - (Jg * (Jg - 1)) / 2;
+    }
     auto tri_IJ = [&](int tt, int &It, int &Jt) __attribute__((always_inline)) {
         while (cur_J + 1 < TT && tt >= cur_c0 + (TT - cur_J)) { cur_c0 += TT - cur_J; ++cur_J; }
         while (cur_J > 0 && tt < cur_c0) { --cur_J; cur_c0 -= TT - cur_J; }
@@ -2060,11 +2070,12 @@ void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s)
                                                                       // REKF_DD_SB=1: one tile per workgroup, two workgroups per CU (same speed)
     const int T = (n_ub + DT - 1) / DT;
     const int slots = n_cu * DD_WG_PER_CU;
-    int grid;
+    int grid, dd_per = 0;
     if (full) grid = (T * T < slots) ? T * T : slots;
     else if (persistent) {                          // T class-A workgroups (diagonal tile + the one below) + equal ranges of the rest
         const int nB = (T - 1) * (T - 2) / 2, room = (slots - T > 1) ? slots - T : 1;
         const int per = (nB + room - 1) / room;
+        dd_per = per > 0 ? per : 1;
         grid = T + (nB > 0 ? (nB + per - 1) / per : 0);
         if (grid >= 64) grid = (grid + 7) & ~7;     // multiple of 8 for the per-XCD numbering (workgroups past the last range return at once)
     } else grid = T * (T - 1) / 2 + (T + 1) / 2;    // SB: one workgroup per off-diagonal tile, one per pair of diagonal tiles
@@ -2079,10 +2090,12 @@ void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s)
         else if (kc == 32) launch_downdate2<32, false, false>(d, grid, s, first);
         else launch_downdate2<16, false, false>(d, grid, s, first);
     } else if (persistent) {
-        if (kc == 64) launch_downdate2<64, true, false>(d, grid, s, first);
-        else if (kc == 48) launch_downdate2<48, true, false>(d, grid, s, first);
-        else if (kc == 32) launch_downdate2<32, true, false>(d, grid, s, first);
-        else launch_downdate2<16, true, false>(d, grid, s, first);
+        RekfDev dp = d;
+        dp.dd_per = dd_per;
+        if (kc == 64) launch_downdate2<64, true, false>(dp, grid, s, first);
+        else if (kc == 48) launch_downdate2<48, true, false>(dp, grid, s, first);
+        else if (kc == 32) launch_downdate2<32, true, false>(dp, grid, s, first);
+        else launch_downdate2<16, true, false>(dp, grid, s, first);
     } else {
         if (kc == 64) launch_downdate2<64, true, true>(d, grid, s, first);
         else if (kc == 48) launch_downdate2<48, true, true>(d, grid, s, first);
