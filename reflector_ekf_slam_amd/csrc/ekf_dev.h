@@ -82,6 +82,7 @@ struct RekfDev {
     int n_known;        // the exact state dimension when the host knows it (state full, or nothing enqueued since a read-back), else -1:
                         // spares the kernels a dependent read of ctl->n at their start
     int dd_per;         // k_downdate2, class B: tiles per workgroup (set by rekf_launch_downdate; 0: the kernel divides the tiles itself)
+    int dd_sub;         // k_downdate2: class B holds the tiles with I >= J + dd_sub (2: a class-A workgroup also takes the tile below its diagonal tile; 1: it does not)
     int kc_ub;          // host bound of m_pad for the current scan, rounded up to 16 (0: unknown); columns [m, kc_ub) of HPt / Kn are zero
 };
 

@@ -1387,15 +1387,18 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     // ordinary tiles: no transposed image, but the border strips and the symmetric finish -- behind the tile below it, (w+1, w),
     // which shares its HPt panel.  Class B, the rest: the tiles with I >= J + 2, column by column, in equal ranges (3 per
     // workgroup at T = 32).  With the diagonal tiles inside equal ranges of three, the workgroups that held one set the pace.
+    // (When class B gets fewer than three tiles per workgroup -- small states -- class A keeps to its diagonal tile and the tiles
+    // below the diagonal join class B: dd_sub = 1.)
     const bool classA = SYM && !SB && w < T;
-    const int nB = (T - 1) * (T - 2) / 2, nwB = nw - T;     // class B: tiles and workgroups
+    const int sub = (d.dd_sub == 1) ? 1 : 2;
+    const int nB = (T - sub + 1) * (T - sub) / 2, nwB = nw - T;     // class B: tiles and workgroups
     const int ntiles = SYM ? nB : i_n * j_n;
     const int wq = SYM && !SB ? w - T : w, nwq = SYM && !SB ? (nwB > 0 ? nwB : 1) : nw;
     // (class B with the host's tiles-per-workgroup: plain multiples, no 64-bit divisions in the prologue)
     const bool fixed_per = SYM && !SB && d.dd_per > 0;
     const int t_begin = (SB || classA) ? 0 : (fixed_per ? min(wq * d.dd_per, ntiles) : (int)(((long long)wq * ntiles) / nwq));
     const int t_end = SB ? ((w < sb_off) ? 1 : min(2, T - 2 * (w - sb_off)))
-                         : (classA ? ((w + 1 < T) ? 2 : 1)
+                         : (classA ? ((sub == 2 && w + 1 < T) ? 2 : 1)
                                    : (fixed_per ? min((wq + 1) * d.dd_per, ntiles) : (wq < nwq ? (int)(((long long)(wq + 1) * ntiles) / nwq) : 0)));
     if (t_begin >= t_end) return;
     const int nt = t_end - t_begin;
@@ -1409,7 +1412,7 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
 
     // a diagonal tile of the range is taken LAST (its strip work then rides on a tile that has nothing to prefetch);
     // should a range ever hold more than one, the others are still handled where they stand (`special` below)
-    const int TT = SB ? T - 1 : T - 2;                      // side of the triangle that is enumerated (SB: I > J; class B: I >= J + 2)
+    const int TT = SB ? T - 1 : T - sub;                    // side of the triangle that is enumerated (SB: I > J; class B: I >= J + sub)
     // tile number -> (row, column) of the triangle, with a cursor (column, its first tile number) that moves to the queried tile:
     // a workgroup asks for a handful of neighbouring tiles, so after the first query (<= T scalar steps) every look-up is O(1).
     // (A closed form with sqrtf + fix-up loops, evaluated afresh for each of the ~8 look-ups of the prologue, cost 0.8 us.)
@@ -1445,7 +1448,7 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
         const int tt = (tile == t_end - 1) ? t_diag : ((tile == t_diag) ? t_end - 1 : tile);
         if (SYM) {
             if (classA) { I = (pos == 0 && nt == 2) ? w + 1 : w; J = w; }
-            else { tri_IJ(tt, I, J); I += 2; }
+            else { tri_IJ(tt, I, J); I += sub; }
             return;
         }
         const int jj = tt / i_n;
@@ -2070,11 +2073,13 @@ void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s)
                                                                       // REKF_DD_SB=1: one tile per workgroup, two workgroups per CU (same speed)
     const int T = (n_ub + DT - 1) / DT;
     const int slots = n_cu * DD_WG_PER_CU;
-    int grid, dd_per = 0;
+    int grid, dd_per = 0, dd_sub = 2;
     if (full) grid = (T * T < slots) ? T * T : slots;
     else if (persistent) {                          // T class-A workgroups (diagonal tile + the one below) + equal ranges of the rest
-        const int nB = (T - 1) * (T - 2) / 2, room = (slots - T > 1) ? slots - T : 1;
-        const int per = (nB + room - 1) / room;
+        const int room = (slots - T > 1) ? slots - T : 1;
+        int nB = (T - 1) * (T - 2) / 2, per = (nB + room - 1) / room;
+        dd_sub = 2;
+        if (per < 3) { dd_sub = 1; nB = T * (T - 1) / 2; per = (nB + room - 1) / room; }   // small states: a class-A workgroup keeps to its diagonal tile
         dd_per = per > 0 ? per : 1;
         grid = T + (nB > 0 ? (nB + per - 1) / per : 0);
         if (grid >= 64) grid = (grid + 7) & ~7;     // multiple of 8 for the per-XCD numbering (workgroups past the last range return at once)
@@ -2091,7 +2096,7 @@ void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s)
         else launch_downdate2<16, false, false>(d, grid, s, first);
     } else if (persistent) {
         RekfDev dp = d;
-        dp.dd_per = dd_per;
+        dp.dd_per = dd_per; dp.dd_sub = dd_sub;
         if (kc == 64) launch_downdate2<64, true, false>(dp, grid, s, first);
         else if (kc == 48) launch_downdate2<48, true, false>(dp, grid, s, first);
         else if (kc == 32) launch_downdate2<32, true, false>(dp, grid, s, first);
