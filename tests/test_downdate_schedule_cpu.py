@@ -1,0 +1,90 @@
+"""The tile schedule of k_downdate2 (csrc/ekf_kernels.hip), restated in Python: for every tile count T and CU count the
+workgroups' tile lists must cover the lower triangle {(I, J): I >= J} exactly once, a class-A workgroup must end on its
+diagonal tile, class B must hold none, and a workgroup never gets more tiles than the host planned.  The HIP code is the
+product; this mirrors its index arithmetic (host: rekf_launch_downdate, device: the classA / tri_IJ / cursor logic) so that an
+off-by-one there shows up without a GPU.  The GPU suite checks the numbers; this checks the bookkeeping for sizes the GPU
+tests do not reach (T up to 64 = n up to 4096)."""
+import math
+
+import pytest
+
+
+def host_plan(T, slots=256):
+    """rekf_launch_downdate, persistent lower-triangle form: (grid, dd_per, dd_sub)."""
+    room = slots - T if slots - T > 1 else 1
+    nB = (T - 1) * (T - 2) // 2
+    per = (nB + room - 1) // room
+    sub = 2
+    if per < 3:
+        sub = 1
+        nB = T * (T - 1) // 2
+        per = (nB + room - 1) // room
+    per = per if per > 0 else 1
+    grid = T + ((nB + per - 1) // per if nB > 0 else 0)
+    if grid >= 64:
+        grid = (grid + 7) & ~7
+    return grid, per, sub
+
+
+def device_tiles(T, grid, per, sub, block):
+    """Tiles of workgroup `block`, in processing order."""
+    w = block
+    if grid >= 8 and grid % 8 == 0:
+        w = (block & 7) * (grid >> 3) + (block >> 3)          # an XCD's workgroups take consecutive ranges
+    if w < T:                                                  # class A
+        tiles = []
+        if sub == 2 and w + 1 < T:
+            tiles.append((w + 1, w))
+        tiles.append((w, w))
+        return tiles
+    TT = T - sub
+    nB = (T - sub + 1) * (T - sub) // 2
+    wq = w - T
+    t0, t1 = min(wq * per, nB), min((wq + 1) * per, nB)
+    if t0 >= t1:
+        return []
+    # cursor seeded by the closed form, then walked (tri_IJ)
+    bq = 2.0 * TT + 1.0
+    Jg = int((bq - math.sqrt(max(bq * bq - 8.0 * t0, 0.0))) * 0.5)
+    Jg = max(0, min(TT - 1, Jg))
+    cur_J, cur_c0 = Jg, Jg * TT - (Jg * (Jg - 1)) // 2
+    out = []
+    for tt in range(t0, t1):
+        while cur_J + 1 < TT and tt >= cur_c0 + (TT - cur_J):
+            cur_c0 += TT - cur_J
+            cur_J += 1
+        while cur_J > 0 and tt < cur_c0:
+            cur_J -= 1
+            cur_c0 -= TT - cur_J
+        out.append((cur_J + (tt - cur_c0) + sub, cur_J))
+    return out
+
+
+@pytest.mark.parametrize("slots", [256, 304, 64])
+def test_every_lower_triangle_tile_exactly_once(slots):
+    for T in range(1, 65):
+        grid, per, sub = host_plan(T, slots)
+        seen = {}
+        for b in range(grid):
+            tl = device_tiles(T, grid, per, sub, b)
+            assert len(tl) <= max(per, 2), (T, b, tl)
+            diag = [t for t in tl if t[0] == t[1]]
+            assert len(diag) <= 1 and (not diag or tl[-1] == diag[0]), (T, b, tl)      # the diagonal tile comes last
+            for t in tl:
+                assert t not in seen, (T, t, b, seen[t])
+                seen[t] = b
+        want = {(i, j) for i in range(T) for j in range(i + 1)}
+        assert set(seen) == want, (T, sorted(want - set(seen))[:5], sorted(set(seen) - want)[:5])
+
+
+def test_host_bound_of_T_may_exceed_the_kernels():
+    """The host sizes the grid from an upper bound of n (T_host >= T_kernel): the kernel's own T must still be covered."""
+    for T_k in range(1, 40):
+        for T_h in (T_k, T_k + 1):
+            grid, per, sub = host_plan(T_h)
+            seen = set()
+            for b in range(grid):
+                for t in device_tiles(T_k, grid, per, sub, b):
+                    assert t not in seen
+                    seen.add(t)
+            assert seen == {(i, j) for i in range(T_k) for j in range(i + 1)}, (T_k, T_h)
