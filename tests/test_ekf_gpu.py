@@ -156,6 +156,44 @@ def test_c3_full_size_steps_match_oracle(c3_built, oracle_lib):
     assert g.sync_code() == 0
 
 
+@pytest.mark.parametrize("L", [1472, 2048])
+def test_states_beyond_the_baseline_size_take_the_generic_downdate_loop(oracle_lib, L):
+    """n = 2947 / 4099 (T = 46 / 64 tile rows): class-B workgroups of k_downdate2 hold 5 / 11 tiles, i.e. the generic tile
+    loop instead of the straight-line code of the BASELINE sizes (<= 4 tiles).  A synthetic state is loaded into both paths
+    (landmarks on a grid, a random SPD covariance), then a few updates with 32 observations each."""
+    rng = np.random.default_rng(L)
+    n = 3 + 2 * L
+    side = int(math.ceil(math.sqrt(L)))
+    lm = np.array([(2.5 * (k % side), 2.5 * (k // side)) for k in range(L)], dtype=np.float64)
+    pose = np.array([2.5 * side / 2 + 0.3, 2.5 * side / 2 - 0.4, 0.3])
+    mu = np.concatenate([pose, (lm + rng.normal(0, 0.01, lm.shape)).ravel()])
+    A = rng.normal(size=(n, 40))
+    P = (A @ A.T) * 1e-5 + np.diag(rng.uniform(1e-4, 4e-4, n))
+    P = 0.5 * (P + P.T)
+    g = make_gpu(0, 0.0, pose, 0.0025, 0.0064, 0.0025, L)
+    o = make_oracle(0, 0.0, pose, 0.0025, 0.0064, 0.0025)
+    g.set_state(1.0, mu, P, (0.4, 0.0, 0.1))
+    o.set_state(1.0, mu, P, (0.4, 0.0, 0.1))
+    c, s_ = math.cos(pose[2]), math.sin(pose[2])
+    d = np.linalg.norm(lm - pose[:2], axis=1)
+    near = np.argsort(d)[:32]
+    for k in range(4):
+        rel = lm[near] - pose[:2]
+        ob = np.stack([rel[:, 0] * c + rel[:, 1] * s_, -rel[:, 0] * s_ + rel[:, 1] * c], axis=1)
+        ob = (ob + rng.normal(0, 0.01, ob.shape)).astype(np.float32)
+        t = 1.0 + 0.05 * (k + 1)
+        g.handle_observation(t, ob)
+        o.handle_observation(t, ob)
+        a, b = norm_match(g.last_match()), norm_match(o.last_match())
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)) and a[0].shape[0] >= 28
+    st = g.GetState()
+    mo, Po = o.state()
+    assert st.mu.shape[0] == n and g.sync_code() == 0
+    assert np.abs(st.mu - mo).max() < TIGHT
+    assert np.abs(st.sigma - Po).max() < 1e-11
+    assert np.array_equal(st.sigma, st.sigma.T)
+
+
 # ---------------------------------------------------------------- edge cases / API behaviour
 def _simple(cap=8, model=0, pose=(0.0, 0.0, 0.0)):
     return make_gpu(model, 0.0, np.array(pose), 0.0025, 0.0064, 0.0025, cap)
