@@ -235,7 +235,7 @@ def latency_legs(ekf, scans, steps):
         return {"median": float(np.median(a)), "p99": float(np.percentile(a, 99)), "mean": float(a.mean()), "n": int(a.size)}
     return {"device_chain": dict(q(dev), method="hipEvent pair around each whole update chain on the handle's stream, "
                                                   "launches back to back (includes ~4-5 us of event bracket)"),
-            "host_sync": dict(q(host), method="host wall: HandleObservationMessage + rekf_get_pose per update (one publish kernel behind the chain; pose, 3x3 block and flags polled from pinned host memory)")}, 2 * steps
+            "host_sync": dict(q(host), method="host wall: HandleObservationMessage + rekf_get_pose per update (the chain's last kernel stores pose, 3x3 block, n and flags as tagged slots into pinned host memory; the host polls them)")}, 2 * steps
 
 
 def predict_leg(ekf, cfg, scans, steps, per_scan=5):

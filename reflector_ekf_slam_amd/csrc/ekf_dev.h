@@ -64,6 +64,10 @@ struct RekfFrontArgs {
 };
 __host__ __device__ static inline float rekf_obs(const RekfFrontArgs &A, int i) { return A.obs_ext ? A.obs_ext[i] : A.obs[i]; }
 
+// a value the kernels hand to the host in place: one 16-byte system-scope store into pinned host memory, polled by its tag.
+// Slots 0..2 = pose mean, 3..11 = the 3 x 3 pose block (column-major), 12 = {n, aux = sticky flags}.
+struct RekfHostSlot { double v; int seq; int aux; };
+
 struct RekfDev {
     RekfCtl *ctl;
     double *mu;         // the current mean
@@ -81,6 +85,8 @@ struct RekfDev {
     int dbg;            // ablation bits for rekf_debug_time_kernel; 0 in normal operation
     int n_known;        // the exact state dimension when the host knows it (state full, or nothing enqueued since a read-back), else -1:
                         // spares the kernels a dependent read of ctl->n at their start
+    RekfHostSlot *pub;  // non-null: the kernels that commit the pose publish it (mean: k_front / k_mid; pose block: k_front / k_downdate2's tile (0,0))
+    int pub_seq;        //   ... under this tag, so that GetPose / Sync after the call need no kernel of their own
     int dd_per;         // k_downdate2, class B: tiles per workgroup (set by rekf_launch_downdate; 0: the kernel divides the tiles itself)
     int dd_sub;         // k_downdate2: class B holds the tiles with I >= J + dd_sub (2: a class-A workgroup also takes the tile below its diagonal tile; 1: it does not)
     int kc_ub;          // host bound of m_pad for the current scan, rounded up to 16 (0: unknown); columns [m, kc_ub) of HPt / Kn are zero
@@ -102,8 +108,7 @@ void rekf_launch_mid(const RekfDev &d, const RekfFrontArgs &a, int n_ub, int m_u
 void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s);
 void rekf_launch_augment(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);
 void rekf_launch_ellipses(const RekfDev &d, double *out5, int cap, hipStream_t s);
-// a value the kernels hand to the host in place: one 16-byte store, polled by its tag
-struct RekfHostSlot { double v; int seq; int aux; };
 void rekf_launch_predict_pose(const RekfDev &d, const RekfFrontArgs &a, double *out12, RekfHostSlot *hout, int seq, hipStream_t s);
+bool rekf_downdate_publishes();   // does the k_downdate2 variant in use publish the pose block (the default one does)
 void rekf_launch_publish_pose(const RekfDev &d, RekfHostSlot *hout, int seq, hipStream_t s);
 void rekf_launch_predict_rows(const RekfDev &d, const RekfFrontArgs &a, double *out, hipStream_t s);

@@ -187,6 +187,16 @@ __device__ static void wave_argmin(double &d, int &j)
 // workgroup of 16 waves.  Scans with observations use k_front_mb.
 // ----------------------------------------------------------------------------
 #define COV_PF 3              // covariance-predict operands prefetched per thread (covers n <= 3072)
+// ---- results for the host without a copy engine: each value is ONE 16-byte system-scope store {double, tag, aux} into
+// pinned host memory; the host polls the tags (no hipMemcpy, no wait for the completion signal).
+typedef unsigned rekf_u32x4 __attribute__((ext_vector_type(4)));
+__device__ static void host_slot_store(RekfHostSlot *p, double v, int seq, int aux)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const rekf_u32x4 w = {(unsigned)b, (unsigned)(b >> 32), (unsigned)seq, (unsigned)aux};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(w) : "memory");
+}
+
 __global__ __launch_bounds__(1024) void k_front(RekfDev d, RekfFrontArgs A)
 {
     __shared__ Motion mo;
@@ -254,9 +264,19 @@ __global__ __launch_bounds__(1024) void k_front(RekfDev d, RekfFrontArgs A)
             corner_predict(C9, 3, mo);
             for (int q = 0; q < 9; ++q) P[(q % 3) + (size_t)(q / 3) * ld] = C9[q];
             // mean (cc:180-181 / :204-205)
-            mu[0] = mu0 + mo.d[0]; mu[1] = mu1 + mo.d[1];
+            const double nx = mu0 + mo.d[0], ny = mu1 + mo.d[1];
+            mu[0] = nx; mu[1] = ny;
+            if (d.pub) {                          // the committed pose straight to the host's slots: GetPose / Sync need no kernel of their own
+                host_slot_store(d.pub + 0, nx, d.pub_seq, 0);
+                host_slot_store(d.pub + 1, ny, d.pub_seq, 0);
+                for (int q = 0; q < 9; ++q) host_slot_store(d.pub + 3 + q, C9[q], d.pub_seq, 0);
+                host_slot_store(d.pub + 12, (double)n, d.pub_seq, __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
         }
-        if (tid == 64) mu[2] = th_new;            // (every read of the old mu[2] happened before the barrier)
+        if (tid == 64) {
+            mu[2] = th_new;                       // (every read of the old mu[2] happened before the barrier)
+            if (d.pub) host_slot_store(d.pub + 2, th_new, d.pub_seq, 0);
+        }
     }
     __syncthreads();
     if (!A.is_obs) return;                    // odometry path: HandleOdometryMessage cc:208-223
@@ -1241,6 +1261,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
             if (i == 2) v = atan2(sin(v), cos(v));                               // cc:307
             d.mu_out[i] = v;
             if (i == 0) ctl->pose_pending = 0;
+
         }
     }
 #ifdef REKF_DEBUG_TIMING
@@ -1731,6 +1752,26 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
             double *Pw = p_ptr(I, J);
 #pragma unroll
             for (int q = 0; q < 8; ++q) DD_STORE((v2d *)(Pw + (size_t)(8 * (q & 3) + (q >> 2)) * ld), pq[PAR][q]);
+            if (SYM && !SB && d.pub && I == 0 && J == 0 && wave == 0) {
+                // the final 3 x 3 pose block sits in four lanes of wave 0 (rows 2 idx + {0,1}, columns 2 kq + {0 (q = 0), 1 (q = 4)}):
+                // straight to the host's slots 3 + r + 3 c.  The mean k_mid committed, n and the flags go with it (lanes 32..35):
+                // this workgroup ends 3 us before the kernel does, so nobody waits for the PCIe writes
+                if (lane >= 32 && lane < 35) host_slot_store(d.pub + (lane - 32), d.mu[lane - 32], d.pub_seq, 0);
+                if (lane == 35) host_slot_store(d.pub + 12, (double)n, d.pub_seq, __hip_atomic_load(&d.ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                const int c0 = 2 * kq;
+                if (idx == 0 && kq < 2) {
+                    host_slot_store(d.pub + 3 + 0 + 3 * c0, pq[PAR][0].x, d.pub_seq, 0);
+                    host_slot_store(d.pub + 3 + 1 + 3 * c0, pq[PAR][0].y, d.pub_seq, 0);
+                    if (kq == 0) {
+                        host_slot_store(d.pub + 3 + 0 + 3, pq[PAR][4].x, d.pub_seq, 0);
+                        host_slot_store(d.pub + 3 + 1 + 3, pq[PAR][4].y, d.pub_seq, 0);
+                    }
+                }
+                if (idx == 1 && kq < 2) {
+                    host_slot_store(d.pub + 3 + 2 + 3 * c0, pq[PAR][0].x, d.pub_seq, 0);
+                    if (kq == 0) host_slot_store(d.pub + 3 + 2 + 3, pq[PAR][4].x, d.pub_seq, 0);
+                }
+            }
             if (SYM && I != J) {                            // (a diagonal tile has no transposed image; nothing counts VMEM operations after the last tile)
                 double *Pwm = pm_ptr(I, J);
 #pragma unroll
@@ -1934,16 +1975,6 @@ __global__ __launch_bounds__(256) void k_augment(RekfDev d, RekfFrontArgs A)
 // ----------------------------------------------------------------------------
 // PredictState, pose block (cc:97-152): non-mutating; out = mu3 | sigma3x3 col-major
 // ----------------------------------------------------------------------------
-// ---- results for the host without a copy engine: each value is ONE 16-byte system-scope store {double, tag, aux} into
-// pinned host memory; the host polls the tags (no hipMemcpy, no wait for the completion signal).
-typedef unsigned rekf_u32x4 __attribute__((ext_vector_type(4)));
-__device__ static void host_slot_store(RekfHostSlot *p, double v, int seq, int aux)
-{
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    const rekf_u32x4 w = {(unsigned)b, (unsigned)(b >> 32), (unsigned)seq, (unsigned)aux};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(w) : "memory");
-}
-
 // GetState's pose part (ekf_slam.h GetState / ros_node.cc's pose publisher): mu[0..2], the 3 x 3 pose block, n and the error
 // flags, straight into the host's slots
 __global__ void k_publish_pose(RekfDev d, RekfHostSlot *out, int seq)
@@ -2159,6 +2190,10 @@ void rekf_launch_ellipses(const RekfDev &d, double *out5, int cap, hipStream_t s
 void rekf_launch_predict_pose(const RekfDev &d, const RekfFrontArgs &a, double *out12, RekfHostSlot *hout, int seq, hipStream_t s)
 {
     hipLaunchKernelGGL(k_predict_pose, dim3(1), dim3(64), 0, s, d, a, out12, hout, seq);
+}
+bool rekf_downdate_publishes()
+{
+    return getenv("REKF_DD_FULL") == nullptr && getenv("REKF_DD_SB") == nullptr;    // the persistent lower-triangle form: tile (0,0) ends a class-A range
 }
 void rekf_launch_publish_pose(const RekfDev &d, RekfHostSlot *hout, int seq, hipStream_t s)
 {

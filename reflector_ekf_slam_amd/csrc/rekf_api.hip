@@ -45,6 +45,9 @@ struct rekf {
     RekfHostSlot *host_slots;  // pinned + mapped: 16 tagged slots the pose kernels store into (null: copy-engine path)
     RekfHostSlot *host_slots_dev;
     int slot_seq;
+    bool pose_read;            // GetPose / Sync / GetFlags was called since the last odometry message: the caller reads the pose at odometry rate
+    bool pub_valid;            // the slots hold (or will hold, once the enqueued kernels have run) the CURRENT pose under tag pub_seq
+    int pub_seq;
     double *dev_out12;         // device scratch for k_predict_pose
     double *dev_ell;           // device scratch for k_ellipses (5 doubles per landmark of capacity)
     RekfCtl *ctl_staging;      // pinned copy of the control block
@@ -177,6 +180,20 @@ void report_flags(rekf_t *h, int flags)
 }
 
 // Synchronise and refresh the host copy of the control block.
+// the next launches publish the pose they commit (k_front; k_mid + k_downdate2) under a fresh tag
+int begin_publish(rekf_t *h)
+{
+    if (!h->host_slots) { h->pub_valid = false; return 0; }
+    h->dev.pub = h->host_slots_dev;
+    h->dev.pub_seq = ++h->slot_seq;
+    return h->dev.pub_seq;
+}
+void end_publish(rekf_t *h, int seq)
+{
+    h->dev.pub = nullptr;
+    if (seq) { h->pub_valid = true; h->pub_seq = seq; }
+}
+
 int pull_ctl(rekf_t *h)
 {
     HIP_TRY(h, hipSetDevice(h->device));
@@ -200,10 +217,15 @@ int pull_n_flags(rekf_t *h, int *flags)
         return rc;
     }
     HIP_TRY(h, hipSetDevice(h->device));
-    const int seq = ++h->slot_seq;
-    rekf_launch_publish_pose(h->dev, h->host_slots_dev, seq, h->stream);
-    HIP_TRY(h, hipGetLastError());
-    int rc = wait_slots(h, 12, 1, seq);
+    h->pose_read = true;
+    int seq = h->pub_seq;
+    if (!h->pub_valid) {                              // nothing in flight publishes: one small kernel does
+        seq = ++h->slot_seq;
+        rekf_launch_publish_pose(h->dev, h->host_slots_dev, seq, h->stream);
+        HIP_TRY(h, hipGetLastError());
+        h->pub_valid = true; h->pub_seq = seq;
+    }
+    int rc = wait_slots(h, 0, 13, seq);               // all of them: the last kernels of the call store different slots
     if (rc != REKF_OK) return rc;
     const int n = (int)h->host_slots[12].v, err = h->host_slots[12].aux;
     h->n_ub = n;
@@ -256,7 +278,7 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
     for (int k = 0; k < REKF_K_COUNT; ++k) { h->prof_total_us[k] = 0; h->prof_count[k] = 0; }
     h->stream = nullptr;
     h->pose_staging = nullptr;
-    h->host_slots = nullptr; h->host_slots_dev = nullptr; h->slot_seq = 0;
+    h->host_slots = nullptr; h->host_slots_dev = nullptr; h->slot_seq = 0; h->pub_valid = false; h->pub_seq = 0; h->pose_read = false;
     h->ctl_staging = nullptr;
     h->dev_out12 = nullptr;
     h->dev_ell = nullptr;
@@ -365,7 +387,15 @@ int rekf_handle_odometry(rekf_t *h, double t, double vx, double vy, double wz)
     HIP_TRY(h, hipSetDevice(h->device));
     {
         ProfScope ps(h, REKF_K_PREDICT);
+        // k_front publishes the pose it commits only for a caller that reads it back between odometry messages (the
+        // reference's node does: HandleOdometryMessage -> GetState, src/ros_node.cc:627-660): the kernel is one workgroup and
+        // would otherwise end 1.5 us later, waiting for its PCIe writes, for nobody
+        const bool want = h->pose_read;
+        h->pose_read = false;
+        h->pub_valid = false;
+        const int seq = want ? begin_publish(h) : 0;
         rekf_launch_front(h->dev, a, h->stream);      // cc:218 Predict(dt)
+        end_publish(h, seq);
     }
     h->time = t;                                      // cc:219
     return REKF_OK;
@@ -391,7 +421,9 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     ProfScope upd(h, REKF_K_UPDATE);                  // one bracket around the whole chain (per-update latency)
     if (K == 0) {                                     // cc:235-236: predict only, single-workgroup kernel
         ProfScope ps(h, REKF_K_FRONT);
+        const int seq = begin_publish(h);
         rekf_launch_front(h->dev, a, h->stream);
+        end_publish(h, seq);
         h->time = t;
         return REKF_OK;
     }
@@ -401,6 +433,10 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         HIP_TRY(h, hipMemcpyAsync(h->dev_obs, xy, sizeof(float) * 2 * (size_t)K, hipMemcpyHostToDevice, h->stream));
         a.obs_ext = h->dev_obs;
     }
+    h->pub_valid = false;
+    // in steady state (state full: no k_augment behind the chain) the last k_mid / k_downdate2 of the call publish the pose
+    const bool fold = h->full && h->host_slots && rekf_downdate_publishes();
+    int pub_seq = 0;
     { ProfScope ps(h, REKF_K_FRONT); rekf_launch_front_mb(h->dev, a, h->n_ub, h->stream); }
     h->time = t;                                      // cc:234
     const int n_ub = h->n_ub;
@@ -419,18 +455,22 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         for (int p0 = 0; p0 < K; p0 += stride) {
             a.pair0 = p0;
             h->dev.mu_lin = h->dev_mu_lin;
+            if (fold && p0 + stride >= K) pub_seq = begin_publish(h);          // the last step commits the final pose
             { ProfScope ps(h, REKF_K_MID); rekf_launch_mid(h->dev, a, n_ub, 64, h->stream); }
             std::swap(h->dev.mu, h->dev.mu_out);
             { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_downdate(h->dev, n_ub, h->stream); }
         }
+        end_publish(h, pub_seq);
         a.pair0 = -1;
         h->dev.mu_lin = h->dev.mu;
     } else {
         // the whole innovation fits one pass: gather + solve + gain as ONE launch (k_mid), which leaves the updated
         // mean in the other mean buffer
+        if (fold) pub_seq = begin_publish(h);
         { ProfScope ps(h, REKF_K_MID); rekf_launch_mid(h->dev, a, n_ub, m_ub, h->stream); }
         std::swap(h->dev.mu, h->dev.mu_out);
         { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_downdate(h->dev, n_ub, h->stream); }
+        end_publish(h, pub_seq);
     }
     h->last_m_ub = m_ub;
     // the state only grows: once a readback has shown it full, k_augment can never have work again
@@ -455,6 +495,7 @@ int rekf_predict_state(rekf_t *h, double t, double mu3[3], double sigma3x3[9])
         const int seq = ++h->slot_seq;
         rekf_launch_predict_pose(h->dev, a, h->dev_out12, h->host_slots_dev, seq, h->stream);
         HIP_TRY(h, hipGetLastError());
+        h->pub_valid = false;                          // the slots now hold the PREDICTED pose
         int rc = wait_slots(h, 0, 12, seq);
         if (rc != REKF_OK) return rc;
         for (int q = 0; q < 3; ++q) mu3[q] = h->host_slots[q].v;
@@ -480,10 +521,17 @@ int rekf_get_pose(rekf_t *h, double *t, double mu3[3], double sigma3x3[9])
 {
     if (!h) return REKF_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
-    if (h->host_slots) {                               // one small launch behind the update chain instead of three copies and a stream wait
-        const int seq = ++h->slot_seq;
-        rekf_launch_publish_pose(h->dev, h->host_slots_dev, seq, h->stream);
-        HIP_TRY(h, hipGetLastError());
+    if (h->host_slots) {
+        // the kernels of the last call have published (or are about to publish) the pose they committed; otherwise one small
+        // launch behind whatever is enqueued does -- either way no copy engine and no stream wait
+        h->pose_read = true;
+        int seq = h->pub_seq;
+        if (!h->pub_valid) {
+            seq = ++h->slot_seq;
+            rekf_launch_publish_pose(h->dev, h->host_slots_dev, seq, h->stream);
+            HIP_TRY(h, hipGetLastError());
+            h->pub_valid = true; h->pub_seq = seq;
+        }
         int rc = wait_slots(h, 0, 13, seq);
         if (rc != REKF_OK) return rc;
         report_flags(h, h->host_slots[12].aux);
@@ -552,6 +600,7 @@ int rekf_get_state(rekf_t *h, double *t, int *n_out, double *mu, long mu_cap, do
 int rekf_set_state(rekf_t *h, double t, int n, const double *mu, const double *sigma, const double *vt3)
 {
     if (!h || !mu || !sigma || n < 3 || n > h->dev.n_max || ((n - 3) & 1)) return REKF_ERR_INVALID;
+    h->pub_valid = false;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     const int ld = h->dev.ld;
@@ -594,8 +643,10 @@ int rekf_sync(rekf_t *h)
     int flags = 0;
     int rc = pull_n_flags(h, &flags);
     if (rc != REKF_OK) return rc;
+    // the published pose can arrive a few microseconds before the last workgroups of k_downdate2 are through: Sync means done
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (flags) {
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        h->pub_valid = false;                          // the slot that carried the flags is stale once they are cleared
         int zero = 0;
         HIP_TRY(h, hipMemcpy(&h->dev.ctl->err, &zero, sizeof(int), hipMemcpyHostToDevice));
     }
@@ -692,6 +743,7 @@ void *rekf_stream(rekf_t *h) { return h ? (void *)h->stream : nullptr; }
 int rekf_debug_time_kernel(rekf_t *h, int kernel, int reps, int ablate, double *avg_us)
 {
     if (!h || !avg_us || reps < 1) return REKF_ERR_INVALID;
+    h->pub_valid = false;
     RekfDev dev = h->dev;
     dev.dbg = ablate;
     HIP_TRY(h, hipSetDevice(h->device));
