@@ -393,6 +393,38 @@ def test_sticky_flags_are_visible_without_sync(capfd):
     assert g.sync_code() == -4 and g.flags() == 0
 
 
+def test_pose_published_by_the_chain_equals_the_state(oracle_lib):
+    """rekf_get_pose / rekf_sync read tagged slots in pinned memory that the kernels committing the pose store themselves (the
+    tile-(0,0) workgroup of the last k_downdate2 once the state is full; k_front for a caller that reads the pose back at
+    odometry rate; a publish kernel otherwise).  Whatever path served it, the pose must be the state's, bit for bit."""
+    cfg = synth.SessionConfig("pub", 12, 6, synth.DIFF, seed=5, speed=1.0, row_spacing=5.0)
+    sess = synth.make_session(cfg, max_scans=150)
+    from reflector_ekf_slam_amd import session as S
+    g = make_gpu(cfg.odom_model, sess.init_time, sess.init_pose, cfg.sigma_v ** 2, cfg.sigma_w ** 2, cfg.sigma_obs ** 2, cfg.n_landmarks)
+
+    def check():
+        t, mu3, s3 = g.pose()
+        st = g.GetState()
+        assert np.array_equal(mu3, st.mu[:3]) and np.array_equal(s3, st.sigma[:3, :3]), (mu3, st.mu[:3])
+
+    scans = 0
+    for e in range(sess.n_events):
+        if sess.ev_type[e] == synth.EV_ODOM:
+            g.handle_odometry(sess.ev_time[e], sess.odom[e, 0], sess.odom[e, 1], sess.odom[e, 2])
+            if e % 3 == 0:
+                check()                    # odometry-rate read-back: the next k_front publishes by itself
+        else:
+            g.handle_observation(sess.ev_time[e], sess.obs_of(e))
+            scans += 1
+            if scans % 2 == 0:
+                check()
+            if scans % 5 == 0:
+                g.PredictPose(sess.ev_time[e] + 0.01)     # clobbers the slots with a predicted pose
+                check()
+    assert g.n == 3 + 2 * cfg.n_landmarks and g.sync_code() == 0      # the map filled up: the folded path was exercised
+    check()
+
+
 def test_set_state_get_state_round_trip_and_two_handles():
     rng = np.random.default_rng(0)
     n = 3 + 2 * 20
