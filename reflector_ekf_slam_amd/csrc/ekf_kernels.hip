@@ -1628,13 +1628,13 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
                 accT[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(at.y, bt.y, accT[1][1], 0, 0, 0);
             }
             // ---- this k-step's share of the VMEM traffic (compile-time positions)
-            const int ph = kk / Q4, off = kk % Q4;          // phase 0: DMA Kn, 1: stores then DMA HPt, 2: P loads, 3: nothing
+            // phase 0: DMA Kn; 1: the previous tile's stores, then DMA HPt; SYM: 2: its transposed image; last phase: P loads.
+            // The DMA goes FIRST: the wait at the end of the loop is for the oldest operations only, so the sixteen stores behind
+            // the DMA stay in flight across the tile boundary instead of having to be acknowledged inside it (all sixteen in one
+            // phase would saturate the CU's store path and stall the MFMAs queued behind them)
+            const int ph = kk / Q4, off = kk % Q4;
+            constexpr int PH_LOAD = SYM ? 3 : 2;
             if (ph == 0) {
-                if (SYM && !FIRST) {                        // SYM: the previous tile's normal stores here, its transposed image in phase 1
-#pragma unroll                                              // (all sixteen in one phase saturate the CU's store path and stall the MFMAs behind them)
-                    for (int x = 0; x < 8; ++x)
-                        if ((x * Q4) / 8 == off) DD_STORE((v2d *)(Po + (size_t)(8 * (x & 3) + (x >> 2)) * ld), pq[PREV][x]);
-                }
                 if (!SPECIAL && !LAST && needK) {
 #pragma unroll
                     for (int q = 0; q < ND; ++q)
@@ -1644,17 +1644,21 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
                 if (!FIRST) {
 #pragma unroll
                     for (int x = 0; x < 8; ++x)
-                        if ((x * Q4) / 8 == off) {
-                            if (!SYM) DD_STORE((v2d *)(Po + (size_t)(8 * (x & 3) + (x >> 2)) * ld), pq[PREV][x]);
-                            else second_store(pq[PREV], Po, Pom, pdiag, x);
-                        }
+                        if ((x * Q4) / 8 == off) DD_STORE((v2d *)(Po + (size_t)(8 * (x & 3) + (x >> 2)) * ld), pq[PREV][x]);
                 }
                 if (!SPECIAL && !LAST && needH) {
 #pragma unroll
                     for (int q = 0; q < ND; ++q)
                         if ((q * Q4) / ND == off) dma_piece(HPt, DT * Jn, 2 + (hb ^ 1), q);
                 }
-            } else if (ph == 2 && LOAD2) {
+            } else if (SYM && ph == 2) {
+                if (!FIRST) {
+#pragma unroll
+                    for (int x = 0; x < 8; ++x)
+                        if ((x * Q4) / 8 == off) second_store(pq[PREV], Po, Pom, pdiag, x);
+                }
+            }
+            if (ph == PH_LOAD && LOAD2) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
                     if ((q * Q4) / 8 == off) pq[PREV][q] = *(const v2d *)(Pn + (size_t)(8 * (q & 3) + (q >> 2)) * ld);
@@ -1790,8 +1794,8 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
                 for (int q = 0; q < ND; ++q) dma_piece(HPt, DT * Jn, 2 + (hb ^ 1), q);
             }
             dd_wait_vmcnt<0>();
-        } else if (needH) dd_wait_vmcnt<LOAD2 ? 8 : 0>();                             // after the last HPt DMA: this tile's 8 P loads
-        else if (needK) dd_wait_vmcnt<(FIRST ? 0 : 8) + (LOAD2 ? 8 : 0)>();          // after the last Kn DMA: (phase 1's 8 stores +) (8 P loads)
+        } else if (needH) dd_wait_vmcnt<(SYM && !FIRST ? 8 : 0) + (LOAD2 ? 8 : 0)>();      // after the last HPt DMA: (the 8 transposed stores +) this tile's 8 P loads
+        else if (needK) dd_wait_vmcnt<(FIRST ? 0 : (SYM ? 16 : 8)) + (LOAD2 ? 8 : 0)>();   // after the last Kn DMA: (all of the previous tile's stores +) (8 P loads)
         if (needK || needH) lds_barrier();
         if (needK) kb ^= 1;
         if (needH) hb ^= 1;
