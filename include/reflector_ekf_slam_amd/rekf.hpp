@@ -25,10 +25,13 @@ struct MatchResult {   // ekf::ReflectorMatchResult (ekf_slam_interface.h:18-26)
 
 class EkfSlam {
 public:
-    EkfSlam(const rekf_options &opt, int max_landmarks, int device = 0)
+    // auto_grow: the reference never runs out of room (it resizes on every augment, reflector_ekf_slam.cc:316-363);
+    // with it max_landmarks is only the initial reservation and the capacity doubles on demand (rekf_reserve)
+    EkfSlam(const rekf_options &opt, int max_landmarks, int device = 0, bool auto_grow = true)
     {
         const int rc = rekf_create(&opt, max_landmarks, device, &h_);
         if (rc != REKF_OK) throw Error(rc, "rekf_create");
+        if (auto_grow) rekf_set_auto_grow(h_, 1);
     }
     ~EkfSlam() { rekf_destroy(h_); }
     EkfSlam(const EkfSlam &) = delete;
@@ -43,6 +46,8 @@ public:
     {
         chk(rekf_set_map(h_, xy.data(), cov.data(), (int)(xy.size() / 2)), "rekf_set_map");
     }
+    void Reserve(int max_landmarks) { chk(rekf_reserve(h_, max_landmarks), "rekf_reserve"); }
+    int Capacity() { int c = 0; chk(rekf_get_capacity(h_, &c), "rekf_get_capacity"); return c; }
     double LatestTime() const { double t = 0; rekf_get_time(h_, &t); return t; }
     int Dim() { int n = 0; chk(rekf_get_n(h_, &n), "rekf_get_n"); return n; }
     void Pose(double mu3[3], double sigma3x3[9]) { double t; chk(rekf_get_pose(h_, &t, mu3, sigma3x3), "rekf_get_pose"); }

@@ -18,8 +18,13 @@
  *  - every function returns 0 (REKF_OK) or a negative REKF_ERR_* code; nothing
  *    calls exit() or throws across this boundary (the reference LOG(ERROR)+exit(-1)s,
  *    reflector_ekf_slam.cc:373-378; the C++ adapter may restore that).
- *  - rekf_handle_odometry / rekf_handle_observation only ENQUEUE device work and
- *    return; nothing in them waits for the GPU.  Getters synchronise the stream.
+ *  - rekf_handle_observation only ENQUEUEs device work and returns.  rekf_handle_odometry launches NOTHING: Predict
+ *    (reflector_ekf_slam.cc:154-206) is O(1) on the pose and touches two rows of P, so the library keeps a host mirror
+ *    of the pose mean and the 3 x 3 pose block (current after any pose read-back), advances it with the host's libm and
+ *    hands the composite of all predicts to the next scan's first kernel.  If the last scan's pose has not been read
+ *    back yet, the first odometry message behind it waits for that pose to be published (never, in the reference's
+ *    call pattern: its node reads the pose after every scan, src/ros_node.cc:514-515).  rekf_get_pose and
+ *    rekf_predict_state between scans are answered from the mirror without touching the device.
  *  - the covariance lives in HBM for the life of the handle, column-major like
  *    Eigen::MatrixXd (ekf_slam_interface.h:47) with a fixed leading dimension.
  */
@@ -30,7 +35,7 @@
 extern "C" {
 #endif
 
-#define REKF_ABI_VERSION 3
+#define REKF_ABI_VERSION 4
 
 /* Most observations one scan may carry (K).  The reference has no limit (reflector_ekf_slam.cc:397 loops over
  * obs.cloud_.size()); this one is a buffer size, equal to what the detectors of rdet.h can emit (RDET_MAX_CENTERS).
@@ -46,7 +51,7 @@ enum {
     REKF_ERR_CAPACITY = -4,       /* state grew past max_landmarks; extra reflectors were dropped */
     REKF_ERR_SINGULAR = -5,       /* innovation covariance had a non-positive pivot */
     REKF_ERR_BUFFER = -6,         /* caller buffer too small */
-    REKF_ERR_UNSUPPORTED = -7     /* reserved */
+    REKF_ERR_UNSUPPORTED = -7     /* max_landmarks too large: P is addressed with 32-bit byte offsets (about 11.5 k landmarks) */
 };
 
 /* Sticky device-side condition bits (rekf_get_flags): the state kept growing past max_landmarks and the extra
@@ -80,24 +85,35 @@ typedef struct rekf rekf_t;
 int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t **out);
 void rekf_destroy(rekf_t *h);
 
+/* The reference resizes mu / sigma on every augment and never runs out of room (reflector_ekf_slam.cc:316-363).  Here the
+ * buffers are sized once; rekf_reserve re-lays the state out for a larger max_landmarks (new buffers with the larger
+ * leading dimension, one strided device-to-device copy of the n x n covariance, old buffers freed; no-op when the
+ * capacity already suffices).  Synchronises.  With rekf_set_auto_grow(h, 1) HandleObservationMessage calls it itself
+ * (capacity doubling) whenever a scan COULD overflow the capacity -- it then first waits for the exact n -- so that no
+ * reflector is ever dropped and REKF_FLAGBIT_CAPACITY never fires; off by default (fixed capacity, sticky flag). */
+int rekf_reserve(rekf_t *h, int new_max_landmarks);
+int rekf_set_auto_grow(rekf_t *h, int on);
+int rekf_get_capacity(rekf_t *h, int *max_landmarks);
+
 /* map_ as LoadMapFromTxtFile leaves it (reflector_ekf_slam.cc:80-94): M points
  * (float32 xy) with M row-major 2x2 covariances.  M = 0 clears the map. */
 int rekf_set_map(rekf_t *h, const float *xy, const double *cov, int M);
 
 /* HandleOdometryMessage (reflector_ekf_slam.cc:208-223): drops t < state time,
- * stores (vx, vy, wz), predicts by t - state time.  Asynchronous. */
+ * stores (vx, vy, wz), predicts by t - state time -- on the host's pose mirror, no kernel launch (see Conventions). */
 int rekf_handle_odometry(rekf_t *h, double t, double vx, double vy, double wz);
 
 /* HandleObservationMessage (reflector_ekf_slam.cc:229-368): predict to t,
  * ReflectorMatch, EKF update, landmark augmentation.  xy = K robot-frame points
  * (sensor::Observation::cloud_).  gps_pose3 = nullable (x, y, yaw): the pose
  * observation of the USE_GPS build (reflector_ekf_slam_gps.cc:305-340).
- * Asynchronous: xy is copied before the call returns. */
+ * Asynchronous: xy is copied before the call returns (an empty scan, K = 0, is a Predict: handled like an odometry message). */
 int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K,
                             const double *gps_pose3);
 
 /* PredictState (reflector_ekf_slam.cc:97-152), pose block only (the only part the reference's caller
- * reads, src/ros_node.cc:455-470): non-mutating, 96 bytes D2H.  Synchronises. */
+ * reads, src/ros_node.cc:455-470): non-mutating; evaluated on a copy of the host's pose mirror (no device access once
+ * the pose of the last scan has been read back). */
 int rekf_predict_state(rekf_t *h, double t, double mu3[3], double sigma3x3[9]);
 
 /* PredictState as the interface returns it (ekf_slam_interface.h:59): the FULL predicted State --
@@ -112,8 +128,9 @@ int rekf_predict_state_full(rekf_t *h, double t, double *time_out, int *n, doubl
 int rekf_get_time(rekf_t *h, double *t);
 
 /* Pose-only fast path for the GetState() call the reference's caller makes
- * after every callback (src/ros_node.cc:515,592,638): 96 bytes D2H.
- * sigma3x3 is column-major.  Synchronises. */
+ * after every callback (src/ros_node.cc:515,592,638): the last kernel of a scan's chain stores pose, pose block, n and the
+ * flags as tagged slots into pinned host memory and this call polls them (no copy engine, no stream wait); after an
+ * odometry message it is answered from the host mirror.  sigma3x3 is column-major. */
 int rekf_get_pose(rekf_t *h, double *t, double mu3[3], double sigma3x3[9]);
 
 /* Current state dimension n = 3 + 2*landmarks.  Synchronises. */
@@ -159,7 +176,7 @@ int rekf_get_flags(rekf_t *h, int *flags);
 
 /* ---- measurement hooks (bench.py, rocprof cross-checks) -------------------- */
 enum {
-    REKF_K_PREDICT = 0,   /* odometry-path covariance/mean propagate */
+    REKF_K_PREDICT = 0,   /* (never recorded since ABI 4: odometry messages launch nothing) */
     REKF_K_FRONT = 1,     /* predict + ReflectorMatch + H rows       */
     REKF_K_GATHER = 2,    /* (round 1's separate kernels; never recorded since k_mid fused them) */
     REKF_K_SOLVE = 3,
@@ -185,7 +202,9 @@ int rekf_profile_reset(rekf_t *h);
 int rekf_profile_samples(rekf_t *h, float *out_us, long cap, long *count);
 /* The hipStream_t of the handle (as void*), for callers that record their own events. */
 void *rekf_stream(rekf_t *h);
-/* Leading dimension (doubles) of the device covariance and its device pointer. */
+/* Leading dimension (doubles) of the device covariance and its device pointer; mu_dev is the CURRENT mean buffer (the
+ * mean is double-buffered: every update flips between two buffers).  Predicts the host has applied to its mirror but not
+ * yet to the device (see Conventions) are NOT in these buffers until the next scan or rekf_get_state. */
 int rekf_device_layout(rekf_t *h, int *ld, int *n_max, void **P_dev, void **mu_dev);
 
 /* Measurement hook: time `reps` back-to-back launches of the covariance downdate (kernel = REKF_K_DOWNDATE) on the

@@ -17,6 +17,7 @@
 // never needs bounds checks on P.  W = P H^T and S^-1 never leave the chip (k_mid).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 
 #define REKF_MAX_OBS_DEV 64                          // observations of a scan that travel by value with the launch and update jointly
 #define REKF_MAX_OBS_WIDE 256                        // most observations per scan at all (wide scans: staged in HBM, updated in exact block steps)
@@ -61,6 +62,14 @@ struct RekfFrontArgs {
     const float *obs_ext;     // K x 2 floats on the device, or null (obs[] above holds them)
     int pair0;                // first pair of this block step, or -1: the whole scan (k_mid compacts the match results itself)
     int pair_stride;          // pairs per block step (32, or 30 with a pose observation: its 3 rows ride on the last step)
+    // Predict evaluated by the HOST (rekf_api.hip keeps a mirror of the pose mean and the 3 x 3 pose block whenever the caller has
+    // read the pose back; HandleOdometryMessage then costs no launch at all).  host_pred = 1: the device evaluates no motion model --
+    // pre_pose is the predicted pose, pre_ab the composite G = I + a e0 e2^T + b e1 e2^T of every predict since the device last
+    // saw P (consecutive predicts compose exactly: e2^T (a, b, 0)^T = 0), pre_C9 the pose block after them.
+    int host_pred;
+    double pre_pose[5];       // x, y, theta (wrapped, cc:181/:205), cos(theta), sin(theta) of the WRAPPED heading as the reference takes them (cc:252-253)
+    double pre_ab[2];
+    double pre_C9[9];         // column-major 3 x 3
 };
 __host__ __device__ static inline float rekf_obs(const RekfFrontArgs &A, int i) { return A.obs_ext ? A.obs_ext[i] : A.obs[i]; }
 
@@ -85,12 +94,104 @@ struct RekfDev {
     int dbg;            // ablation bits for rekf_debug_time_kernel; 0 in normal operation
     int n_known;        // the exact state dimension when the host knows it (state full, or nothing enqueued since a read-back), else -1:
                         // spares the kernels a dependent read of ctl->n at their start
-    RekfHostSlot *pub;  // non-null: the kernels that commit the pose publish it (mean: k_front / k_mid; pose block: k_front / k_downdate2's tile (0,0))
+    RekfHostSlot *pub;  // non-null (only in the launch of the LAST kernel of a call: k_downdate2's tile (0,0) workgroup when the state is
+                        // full, else k_augment): that kernel publishes the pose mean, the 3 x 3 pose block, n and the flags ...
     int pub_seq;        //   ... under this tag, so that GetPose / Sync after the call need no kernel of their own
     int dd_per;         // k_downdate2, class B: tiles per workgroup (set by rekf_launch_downdate; 0: the kernel divides the tiles itself)
     int dd_sub;         // k_downdate2: class B holds the tiles with I >= J + dd_sub (2: a class-A workgroup also takes the tile below its diagonal tile; 1: it does not)
     int kc_ub;          // host bound of m_pad for the current scan, rounded up to 16 (0: unknown); columns [m, kc_ub) of HPt / Kn are zero
 };
+
+// ----------------------------------------------------------------------------
+// Predict's scalar part (reference reflector_ekf_slam.cc:154-206), shared by the kernels and by the host's pose mirror
+// (rekf_api.hip): the motion increment d, the entries a, b of G = I + a e0 e2^T + b e1 e2^T and V = Gu Qu Gu^T.
+// No FMA contraction: the same doubles as a plain x86-64 build of the reference.
+// ----------------------------------------------------------------------------
+// one libm call for both (device: ocml, host: glibc -- whose sincos returns exactly what sin and cos return)
+__host__ __device__ static inline void rekf_sincos(double x, double *s, double *c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincos(x, s, c);
+#else
+    ::sincos(x, s, c);
+#endif
+}
+
+struct Motion {
+    double d[3];
+    double a, b;
+    double V[9];
+};
+
+__host__ __device__ static inline void motion_terms(const RekfFrontArgs &A, double theta, Motion &mo)
+{
+#pragma clang fp contract(off)
+    const double vx = A.vt[0], vy = A.vt[1], w = A.vt[2], dt = A.dt;
+    double Gu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double Qu[3];
+    int q;
+    if (A.model == 0) {                                   // DIFF  cc:156-183
+        const double delta_theta = w * dt;
+        const double half = theta + delta_theta / 2;
+        double sh, ch;
+        rekf_sincos(half, &sh, &ch);
+        mo.d[0] = vx * dt * ch;
+        mo.d[1] = vx * dt * sh;
+        mo.d[2] = delta_theta;
+        mo.a = -vx * dt * sh;
+        mo.b = vx * dt * ch;
+        q = 2;
+        Gu[0] = dt * ch; Gu[1] = -vx * dt * dt * sh / 2;
+        Gu[3] = dt * sh; Gu[4] = vx * dt * dt * ch / 2;
+        Gu[6] = 0;       Gu[7] = dt;
+        Qu[0] = A.lin_cov; Qu[1] = A.ang_cov; Qu[2] = 0;
+    } else {                                              // OMNI  cc:184-205
+        const double delta_theta = w * dt;
+        double st, ct;
+        rekf_sincos(theta, &st, &ct);
+        mo.d[0] = vx * dt * ct - vy * dt * st;
+        mo.d[1] = vx * dt * st + vy * dt * ct;
+        mo.d[2] = delta_theta;
+        mo.a = -vx * dt * st - vy * dt * ct;
+        mo.b = vx * dt * ct - vy * dt * st;
+        q = 3;
+        Gu[0] = dt * ct; Gu[1] = -dt * st; Gu[2] = 0.;
+        Gu[3] = dt * st; Gu[4] = dt * ct;  Gu[5] = 0.;
+        Gu[6] = 0.;      Gu[7] = 0.;       Gu[8] = dt;
+        Qu[0] = A.lin_cov; Qu[1] = A.lin_cov; Qu[2] = A.ang_cov;
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < q; ++k)
+                s += Gu[i * 3 + k] * Qu[k] * Gu[j * 3 + k];
+            mo.V[i * 3 + j] = s;
+        }
+}
+
+// 3x3 pose block of G P G^T + Gu Qu Gu^T (row ops, then column ops, then + V),
+// in place on a column-major 3x3 with leading dimension ld.
+__host__ __device__ static inline void corner_predict(double *P, int ld, const Motion &mo)
+{
+#pragma clang fp contract(off)
+    for (int c = 0; c < 3; ++c) {
+        const double p2 = P[2 + (size_t)c * ld];
+        P[0 + (size_t)c * ld] = P[0 + (size_t)c * ld] + mo.a * p2;
+        P[1 + (size_t)c * ld] = P[1 + (size_t)c * ld] + mo.b * p2;
+    }
+    for (int r = 0; r < 3; ++r) {
+        const double p2 = P[r + (size_t)2 * ld];
+        P[r + (size_t)0 * ld] = P[r + (size_t)0 * ld] + mo.a * p2;
+        P[r + (size_t)1 * ld] = P[r + (size_t)1 * ld] + mo.b * p2;
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            P[i + (size_t)j * ld] += mo.V[i * 3 + j];
+    // the stored covariance is EXACTLY symmetric (k_downdate2 computes the lower triangle and mirrors it): the upper
+    // elements take the lower ones' bits (the reference's two differ in the last place at most)
+    for (int i = 0; i < 3; ++i)
+        for (int j = i + 1; j < 3; ++j) P[i + (size_t)j * ld] = P[j + (size_t)i * ld];
+}
 
 // first row of the thin border that k_downdate treats as strips, or -1 (n a multiple of 64, border wider than
 // REKF_STRIP_MAX rows, or less than one full tile)
@@ -101,14 +202,12 @@ __host__ __device__ static inline int rekf_strip_base(int n)
 }
 
 // launch wrappers (ekf_kernels.hip)
-void rekf_launch_front(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);
+void rekf_launch_apply_predict(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);
 void rekf_launch_front_mb(const RekfDev &d, const RekfFrontArgs &a, int n_ub, hipStream_t s);
 void rekf_launch_compact_wide(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);
 void rekf_launch_mid(const RekfDev &d, const RekfFrontArgs &a, int n_ub, int m_ub, hipStream_t s);
 void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s);
 void rekf_launch_augment(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);
 void rekf_launch_ellipses(const RekfDev &d, double *out5, int cap, hipStream_t s);
-void rekf_launch_predict_pose(const RekfDev &d, const RekfFrontArgs &a, double *out12, RekfHostSlot *hout, int seq, hipStream_t s);
-bool rekf_downdate_publishes();   // does the k_downdate2 variant in use publish the pose block (the default one does)
 void rekf_launch_publish_pose(const RekfDev &d, RekfHostSlot *hout, int seq, hipStream_t s);
 void rekf_launch_predict_rows(const RekfDev &d, const RekfFrontArgs &a, double *out, hipStream_t s);

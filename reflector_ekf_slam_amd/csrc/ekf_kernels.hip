@@ -12,21 +12,24 @@
 //               inverse redone by every workgroup rather than handed around
 //   k_downdate2 P += Kn (H P): the FP64 MFMA, LDS-tiled rank-m downdate (cc:308) -- the roofline kernel
 //   k_augment   new landmark means and covariance blocks (cc:311-364)
-//   k_front     predict alone (odometry messages, empty scans)
+//   k_apply_predict   odometry messages and empty scans are predicted by the HOST (pose mirror, rekf_api.hip) and cost no launch;
+//               this kernel applies their composite to P when the device state is needed before the next scan
 // Scans with more than 32 matched pairs (or more than 64 observations: k_compact_wide) run the joint update as exact
 // block steps, k_mid + k_downdate2 per 32 pairs (see k_mid).
 //
-// Like the reference, P is never symmetrised: W = P H^T is gathered from the
-// COLUMNS of P and HP^T from its ROWS.  (Taking H P := (P H^T)^T looks harmless
-// but is unstable: with it the antisymmetric round-off part A of P evolves as
-// A + (P G) A (G P) instead of the reference's contraction (I - P G) A (I - G P),
-// G = H^T S^-1 H, and grows exponentially -- measured 1e-17 -> 1e-5 in 300 scans.)
+// The stored covariance is EXACTLY symmetric, bit for bit: every kernel that writes P writes both halves from ONE computed
+// value (k_downdate2 computes the lower-triangle tiles and mirrors them, the predict corner and the augment blocks are
+// mirrored).  W = P H^T is gathered from the columns of P and (H P)^T(c, r) = W(c, r) is stored from the same values.
+// (On a P that is only NEARLY symmetric taking H P := (P H^T)^T is unstable -- the antisymmetric round-off part A then evolves
+// as A + (P G) A (G P) instead of the reference's contraction (I - P G) A (I - G P), G = H^T S^-1 H: measured 1e-17 -> 1e-5 in
+// 300 scans in round 1 -- which is why nothing here ever leaves the two halves to independent round-off)
 //
 // Deliberate, stated deviations from the literal Eigen expressions (FP64 round-off
 // level, far inside the 1e-5 m parity bar):
 //   * S^-1 by Gauss-Jordan without pivoting (S = H P H^T + Q is SPD) instead of
 //     Eigen's partial-pivot LU;
-//   * more than 32 matched pairs: block-sequential form of the same joint update.
+//   * more than 32 matched pairs: block-sequential form of the same joint update;
+//   * P exactly symmetric (above); consecutive predicts applied to P's landmark rows as their exact composite.
 #include "ekf_dev.h"
 
 #include <cstdlib>
@@ -38,86 +41,11 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 #define WAVE 64
 
 // ----------------------------------------------------------------------------
-// small scalar pieces: kept free of FMA contraction so that the float32
+// small scalar pieces (Motion / motion_terms / corner_predict live in ekf_dev.h: the host's pose mirror evaluates the very
+// same source): kept free of FMA contraction so that the float32
 // roundings the reference performs (cc:389-393, :431-433, :327-331) see the
 // same doubles as a plain x86-64 build of the reference.
 // ----------------------------------------------------------------------------
-struct Motion {
-    double d[3];
-    double a, b;
-    double V[9];
-};
-
-__device__ static void motion_terms(const RekfFrontArgs &A, double theta, Motion &mo)
-{
-#pragma clang fp contract(off)
-    const double vx = A.vt[0], vy = A.vt[1], w = A.vt[2], dt = A.dt;
-    double Gu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    double Qu[3];
-    int q;
-    if (A.model == 0) {                                   // DIFF  cc:156-183
-        const double delta_theta = w * dt;
-        const double half = theta + delta_theta / 2;
-        double sh, ch;
-        sincos(half, &sh, &ch);
-        mo.d[0] = vx * dt * ch;
-        mo.d[1] = vx * dt * sh;
-        mo.d[2] = delta_theta;
-        mo.a = -vx * dt * sh;
-        mo.b = vx * dt * ch;
-        q = 2;
-        Gu[0] = dt * ch; Gu[1] = -vx * dt * dt * sh / 2;
-        Gu[3] = dt * sh; Gu[4] = vx * dt * dt * ch / 2;
-        Gu[6] = 0;       Gu[7] = dt;
-        Qu[0] = A.lin_cov; Qu[1] = A.ang_cov; Qu[2] = 0;
-    } else {                                              // OMNI  cc:184-205
-        const double delta_theta = w * dt;
-        double st, ct;
-        sincos(theta, &st, &ct);
-        mo.d[0] = vx * dt * ct - vy * dt * st;
-        mo.d[1] = vx * dt * st + vy * dt * ct;
-        mo.d[2] = delta_theta;
-        mo.a = -vx * dt * st - vy * dt * ct;
-        mo.b = vx * dt * ct - vy * dt * st;
-        q = 3;
-        Gu[0] = dt * ct; Gu[1] = -dt * st; Gu[2] = 0.;
-        Gu[3] = dt * st; Gu[4] = dt * ct;  Gu[5] = 0.;
-        Gu[6] = 0.;      Gu[7] = 0.;       Gu[8] = dt;
-        Qu[0] = A.lin_cov; Qu[1] = A.lin_cov; Qu[2] = A.ang_cov;
-    }
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            double s = 0;
-            for (int k = 0; k < q; ++k)
-                s += Gu[i * 3 + k] * Qu[k] * Gu[j * 3 + k];
-            mo.V[i * 3 + j] = s;
-        }
-}
-
-// 3x3 pose block of G P G^T + Gu Qu Gu^T (row ops, then column ops, then + V),
-// in place on a column-major 3x3 with leading dimension ld.
-__device__ static void corner_predict(double *P, int ld, const Motion &mo)
-{
-#pragma clang fp contract(off)
-    for (int c = 0; c < 3; ++c) {
-        const double p2 = P[2 + (size_t)c * ld];
-        P[0 + (size_t)c * ld] = P[0 + (size_t)c * ld] + mo.a * p2;
-        P[1 + (size_t)c * ld] = P[1 + (size_t)c * ld] + mo.b * p2;
-    }
-    for (int r = 0; r < 3; ++r) {
-        const double p2 = P[r + (size_t)2 * ld];
-        P[r + (size_t)0 * ld] = P[r + (size_t)0 * ld] + mo.a * p2;
-        P[r + (size_t)1 * ld] = P[r + (size_t)1 * ld] + mo.b * p2;
-    }
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j)
-            P[i + (size_t)j * ld] += mo.V[i * 3 + j];
-    // the stored covariance is EXACTLY symmetric (k_downdate2 computes the lower triangle and mirrors it): the upper
-    // elements take the lower ones' bits (the reference's two differ in the last place at most)
-    for (int i = 0; i < 3; ++i)
-        for (int j = i + 1; j < 3; ++j) P[i + (size_t)j * ld] = P[j + (size_t)i * ld];
-}
-
 __device__ static void obs_to_global(double x, double y, double c, double s, float px, float py,
                                      float &gx, float &gy)
 {
@@ -183,8 +111,11 @@ __device__ static void wave_argmin(double &d, int &j)
 }
 
 // ----------------------------------------------------------------------------
-// k_front: Predict alone (odometry messages, cc:208-223, and empty scans, cc:235-236), one
-// workgroup of 16 waves.  Scans with observations use k_front_mb.
+// k_apply_predict: the covariance part of Predict for predicts the HOST evaluated (odometry messages, cc:208-223, and empty
+// scans, cc:235-236, cost no launch: rekf_api.hip advances its mirror of the pose mean and of the 3 x 3 pose block and
+// accumulates the composite G = I + a e0 e2^T + b e1 e2^T).  This kernel brings P and mu up to date when somebody needs
+// them on the device before the next scan does it in k_front_mb (GetState, PredictState, rekf_reserve): rows / columns 0, 1
+// of the landmark part (cc:178 / :202 multiply dense n x n), the pose block and the pose mean by value.  One workgroup.
 // ----------------------------------------------------------------------------
 #define COV_PF 3              // covariance-predict operands prefetched per thread (covers n <= 3072)
 // ---- results for the host without a copy engine: each value is ONE 16-byte system-scope store {double, tag, aux} into
@@ -197,111 +128,57 @@ __device__ static void host_slot_store(RekfHostSlot *p, double v, int seq, int a
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(w) : "memory");
 }
 
-__global__ __launch_bounds__(1024) void k_front(RekfDev d, RekfFrontArgs A)
+__global__ __launch_bounds__(1024) void k_apply_predict(RekfDev d, RekfFrontArgs A)
 {
-    __shared__ Motion mo;
-
+#pragma clang fp contract(off)
     const int tid = threadIdx.x;
     RekfCtl *ctl = d.ctl;
     double *__restrict__ P = d.P;
-    double *mu = d.mu;
     const size_t ld = (size_t)d.ld;
     const int n = (d.n_known >= 0) ? d.n_known : ctl->n;
-    // ---- the covariance-predict operands and the pose block go in flight first
-    // P is exactly symmetric (every kernel that writes it mirrors: k_downdate2, the corner below, k_augment), so the row part
+    // P is exactly symmetric (every kernel that writes it mirrors: k_downdate2, the pose block, k_augment), so the row part
     // P(0..2, idx) equals the column part P(idx, 0..2) bit for bit: only the coalesced columns are read, the strided rows are
     // written from the same values
+    const double a = A.pre_ab[0], b = A.pre_ab[1];
     double c0[COV_PF], c1[COV_PF], c2[COV_PF];
 #pragma unroll
     for (int t = 0; t < COV_PF; ++t) {
         const int idx = tid + 1024 * t;
-        if (idx >= 3 && idx < n) {
-            c0[t] = P[idx + 0 * ld]; c1[t] = P[idx + 1 * ld]; c2[t] = P[idx + 2 * ld];   // column part (coalesced)
-        }
+        if (idx >= 3 && idx < n) { c0[t] = P[idx + 0 * ld]; c1[t] = P[idx + 1 * ld]; c2[t] = P[idx + 2 * ld]; }
     }
-    double C9[9], mu0 = 0, mu1 = 0, mu2 = 0, th_new = 0;
-    if (tid == 0) {
-        for (int q = 0; q < 9; ++q) C9[q] = P[(q % 3) + (size_t)(q / 3) * ld];   // pose block, column-major 3x3
-        mu0 = mu[0]; mu1 = mu[1]; mu2 = mu[2];
-        motion_terms(A, mu2, mo);
-    }
-    if (tid == 64) {
-        // the new heading (cc:181 / :205: theta + w dt, wrapped by atan2(sin, cos)) on a lane of another SIMD, next to the
-        // motion terms' own sincos instead of behind it
-#pragma clang fp contract(off)
-        const double dth = A.vt[2] * A.dt;            // = mo.d[2] (delta_theta = w dt in both models; no FMA: same bits)
-        double th = mu[2] + dth, sn, cs;
-        sincos(th, &sn, &cs);
-        th_new = atan2(sn, cs);
-    }
-    __syncthreads();
-
-    // ---- Predict, covariance: P <- G P G^T + Gu Qu Gu^T.  G = I + a e0 e2^T + b e1 e2^T
-    // touches rows 0,1 and columns 0,1 only (the reference multiplies dense n x n, cc:178/202).
-    {
-#pragma clang fp contract(off)
-        const double a = mo.a, b = mo.b;
 #pragma unroll
-        for (int t = 0; t < COV_PF; ++t) {
-            const int idx = tid + 1024 * t;
-            if (idx >= 3 && idx < n) {
-                const double n0 = c0[t] + a * c2[t], n1 = c1[t] + b * c2[t];
-                P[idx + 0 * ld] = n0;
-                P[idx + 1 * ld] = n1;
-                P[0 + idx * ld] = n0;
-                P[1 + idx * ld] = n1;
-            }
-        }
-        for (int idx = tid + 1024 * COV_PF; idx < n; idx += 1024) {
-            const double p2 = P[idx + 2 * ld];
-            const double n0 = P[idx + 0 * ld] + a * p2, n1 = P[idx + 1 * ld] + b * p2;
+    for (int t = 0; t < COV_PF; ++t) {
+        const int idx = tid + 1024 * t;
+        if (idx >= 3 && idx < n) {
+            const double n0 = c0[t] + a * c2[t], n1 = c1[t] + b * c2[t];
             P[idx + 0 * ld] = n0;
             P[idx + 1 * ld] = n1;
             P[0 + idx * ld] = n0;
             P[1 + idx * ld] = n1;
         }
-        if (tid == 0) {
-            corner_predict(C9, 3, mo);
-            for (int q = 0; q < 9; ++q) P[(q % 3) + (size_t)(q / 3) * ld] = C9[q];
-            // mean (cc:180-181 / :204-205)
-            const double nx = mu0 + mo.d[0], ny = mu1 + mo.d[1];
-            mu[0] = nx; mu[1] = ny;
-            if (d.pub) {                          // the committed pose straight to the host's slots: GetPose / Sync need no kernel of their own
-                host_slot_store(d.pub + 0, nx, d.pub_seq, 0);
-                host_slot_store(d.pub + 1, ny, d.pub_seq, 0);
-                for (int q = 0; q < 9; ++q) host_slot_store(d.pub + 3 + q, C9[q], d.pub_seq, 0);
-                host_slot_store(d.pub + 12, (double)n, d.pub_seq, __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            }
-        }
-        if (tid == 64) {
-            mu[2] = th_new;                       // (every read of the old mu[2] happened before the barrier)
-            if (d.pub) host_slot_store(d.pub + 2, th_new, d.pub_seq, 0);
-        }
     }
-    __syncthreads();
-    if (!A.is_obs) return;                    // odometry path: HandleOdometryMessage cc:208-223
-
-    const int K = A.K;
-    if (K <= 0) {                             // cc:235-236 (empty cloud): record cleared
-        if (tid == 0) {
-            ctl->K = 0; ctl->n_state = 0; ctl->n_map = 0; ctl->n_new = 0; ctl->m = 0; ctl->m_pad = 0;
-        }
-        return;
+    for (int idx = tid + 1024 * COV_PF; idx < n; idx += 1024) {
+        const double p2 = P[idx + 2 * ld];
+        const double n0 = P[idx + 0 * ld] + a * p2, n1 = P[idx + 1 * ld] + b * p2;
+        P[idx + 0 * ld] = n0;
+        P[idx + 1 * ld] = n1;
+        P[0 + idx * ld] = n0;
+        P[1 + idx * ld] = n1;
     }
-
-    // scans with K > 0 never come here: the host routes them to k_front_mb + k_gather
+    if (tid < 9) P[(tid % 3) + (size_t)(tid / 3) * ld] = A.pre_C9[0 + tid];
+    if (tid >= 64 && tid < 67) d.mu[tid - 64] = A.pre_pose[tid - 64];
 }
 
 // ----------------------------------------------------------------------------
 // k_front_mb: the observation path's front end spread over FRONT_MB workgroups.
 //
-// The single-workgroup k_front is bounded by one CU's VALU and by serial reductions (15 us at
+// A single-workgroup front kernel is bounded by one CU's VALU and by serial reductions (15 us at
 // L = 1024, K = 32).  Here every workgroup recomputes the (cheap) predicted pose from the OLD
 // mean -- nobody writes mu[0..2] in this kernel: the predicted pose goes to ctl->pose_pred and is
 // committed by k_gain together with the update -- then takes a 1/FRONT_MB slice of the
 // covariance predict and whole observations of ReflectorMatch (all 16 waves sweep disjoint
 // landmark slices, wave-wide literal arg-min).  The ordered compaction and the H rows (the tail of
-// k_front) are resolved by k_mid from the per-observation results left in ctl->obs_kind/obs_idx.
+// that kernel) are resolved by k_mid from the per-observation results left in ctl->obs_kind/obs_idx.
 // ----------------------------------------------------------------------------
 #define FRONT_MB 32
 
@@ -342,7 +219,7 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
     float ob0x = 0.f, ob0y = 0.f;
     if (b < K) { ob0x = rekf_obs(A, 2 * b); ob0y = rekf_obs(A, 2 * b + 1); }
     const int idx0 = b * 1024 + tid;
-    double c0 = 0, c1 = 0, c2 = 0;            // (columns only: P is exactly symmetric, see k_front)
+    double c0 = 0, c1 = 0, c2 = 0;            // (columns only: P is exactly symmetric, see k_apply_predict)
     if (idx0 >= 3 && idx0 < n) {
         c0 = P[idx0 + 0 * ld]; c1 = P[idx0 + 1 * ld]; c2 = P[idx0 + 2 * ld];
     }
@@ -355,12 +232,23 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
         s_lmx[tid] = lmx; s_lmy[tid] = lmy;
     }
     double C9[9];
+    if (A.host_pred) {
+        // the host predicted (its pose mirror was current: rekf_api.hip): pose, cos / sin of the WRAPPED heading exactly as the
+        // reference takes them (cc:181, :252-253), the composite (a, b) of every predict since the device last saw P and the
+        // pose block come by value -- no motion model, no libm call in front of the match
+        if (tid == 0) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) pose[q] = A.pre_pose[q];
+            mo.a = A.pre_ab[0]; mo.b = A.pre_ab[1];
+        }
+    } else {
     if (tid == 0) {
         // cos / sin of the new heading on this lane; the motion terms, which have their own sincos, meanwhile on lane 0 of the
         // next wave.  DEVIATION (round-off level): the reference wraps the heading first, theta' = atan2(sin, cos)
         // (cc:181 / :205), and takes cos / sin of theta' wherever it needs them (cc:252-253, :390-391); here they are taken of
         // the unwrapped angle -- the same values up to the last place -- so that the match does not wait for a chain of three
         // libm calls (2.1 us) but for one; theta' itself (what is committed to the mean) is computed as written, after the barrier.
+        // (Only on this path: when the host predicts, above, cos / sin are the reference's own.)
 #pragma clang fp contract(off)
         if (b == 0) for (int q = 0; q < 9; ++q) C9[q] = P[(q % 3) + (size_t)(q / 3) * ld];
         const double mu2 = mu[2];
@@ -374,6 +262,7 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
         const double mu0 = mu[0], mu1 = mu[1], mu2 = mu[2];
         motion_terms(A, mu2, mo);
         pose[0] = mu0 + mo.d[0]; pose[1] = mu1 + mo.d[1];
+    }
     }
     __syncthreads();
     FMARK();                                          // 1: barrier passed
@@ -398,12 +287,16 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
             P[1 + idx * ld] = n1;
         }
         if (b == 0 && tid == 0) {
-            corner_predict(C9, 3, mo);
+            if (A.host_pred) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) C9[q] = A.pre_C9[q];
+            } else corner_predict(C9, 3, mo);
             for (int q = 0; q < 9; ++q) P[(q % 3) + (size_t)(q / 3) * ld] = C9[q];
             ctl->pose_pred[0] = pose[0]; ctl->pose_pred[1] = pose[1]; ctl->pose_pred[3] = pose[3]; ctl->pose_pred[4] = pose[4];
+            if (A.host_pred) ctl->pose_pred[2] = pose[2];
             ctl->pose_pending = 1;
         }
-        if (b == 0 && tid == 512) ctl->pose_pred[2] = atan2(pose[4], pose[3]);     // the wrapped heading (cc:181 / :205), on a wave that does not match
+        if (!A.host_pred && b == 0 && tid == 512) ctl->pose_pred[2] = atan2(pose[4], pose[3]);     // the wrapped heading (cc:181 / :205), on a wave that does not match
     }
 
     FMARK();                                          // 2: covariance slice written
@@ -844,7 +737,10 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
     const size_t ld = (size_t)d.ld;
     const int i0 = blockIdx.x * MID_ROWS;
     const double *__restrict__ P = d.P;
-    const double pose[5] = {ctl->pose_pred[0], ctl->pose_pred[1], ctl->pose_pred[2], ctl->pose_pred[3], ctl->pose_pred[4]};
+    // (a host-predicted scan carries the predicted pose in the launch packet: no read of the control block for it)
+    const bool hp = A.host_pred != 0;
+    const double pose[5] = {hp ? A.pre_pose[0] : ctl->pose_pred[0], hp ? A.pre_pose[1] : ctl->pose_pred[1], hp ? A.pre_pose[2] : ctl->pose_pred[2],
+                            hp ? A.pre_pose[3] : ctl->pose_pred[3], hp ? A.pre_pose[4] : ctl->pose_pred[4]};
     const bool pending = ctl->pose_pending != 0;
     const bool first = blockIdx.x == 0;
 
@@ -1334,22 +1230,18 @@ template <int N> __device__ static inline void dd_wait_vmcnt()
 #else
 #define DD_STORE(p, v) (*(p) = (v))
 #endif
-// SYM (the product path): the update K (H P) is symmetric, so only the tiles on and below the diagonal are computed --
-// half the MFMA work, half the P reads -- and an off-diagonal tile is written twice, as P(I,J) and transposed as P(J,I).
-// The transposed image needs no LDS: a lane holds rows (r, r+1) x columns (c + 8t + {0,1}), t < 4, of its block, so the
-// two columns of a pair are adjacent in the image and {pq[t].e, pq[t+4].e} is one 16-byte store (64 contiguous bytes
-// per 4 lanes).  A diagonal tile is computed in full as before (its own lower / upper halves are not forced equal) and
-// issues its normal stores twice, so that every tile has the same VMEM count (the s_waitcnt bookkeeping is static).
-// P therefore holds exactly mirrored off-diagonal tiles; the reference's (I - K H) P differs from that in the last bit only.
-// SB ("single buffer", implies SYM; REKF_DD_SB=1): ONE tile per workgroup and only two panels in LDS (72 KiB with the border
-// scratch), so that TWO workgroups share a CU and the hardware overlaps one's memory phase with the other's MFMAs: 496
-// off-diagonal tiles + 16 pairs of diagonal tiles on 512 resident workgroups.  No pipelining inside the workgroup: panels and
-// P block in, MFMA loop, P block out (twice).  Measured: 17.3 us against 17.6 us for the persistent form -- a CU's memory
-// throughput is the same ~30 GB/s either way -- so the persistent form stays the default.
-template <int KC, bool SYM, bool SB = false>
+// Lower triangle + mirror: the update K (H P) = P H^T S^-1 H P is symmetric, so only the tiles on and below the diagonal are
+// computed -- half the MFMA work, half the P reads -- and an off-diagonal tile is written twice, as P(I,J) and transposed as
+// P(J,I).  The transposed image needs no LDS: a lane holds rows (r, r+1) x columns (c + 8t + {0,1}), t < 4, of its block, so
+// the two columns of a pair are adjacent in the image and {pq[t].e, pq[t+4].e} is one 16-byte store (64 contiguous bytes
+// per 4 lanes).  A diagonal tile takes the sums of its upper half from its lower half (LDS transpose, or a second role-swapped
+// product in mid-range) and issues its normal stores twice, so that every tile has the same VMEM count (the s_waitcnt
+// bookkeeping is static).  The stored P is therefore EXACTLY symmetric; the reference's (I - K H) P differs from it in the
+// last bit only.  (Rounds 1-2 also carried a full-square form and a one-tile-per-workgroup form for A/B runs -- same speed
+// within 3 %, DESIGN.md section 3 -- they are gone from the product; git history has them.)
+template <int KC>
 __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
 {
-    static_assert(!SB || SYM, "the single-buffer form is a lower-triangle form");
     extern __shared__ __attribute__((aligned(16))) double dd_smem[];   // [Kn 0 | Kn 1 | HPt 0 | HPt 1] panels (+ 16 KiB strip scratch if KC < 64)
     __shared__ __attribute__((aligned(16))) double s_border[2][DD_STRIP_MAX][REKF_MR_PAD];
 #ifdef REKF_DEBUG_TIMING
@@ -1393,34 +1285,26 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     const int rem = n % DT;
     const bool strips = rem > 0 && rem <= DD_STRIP_MAX && n >= DT;
     const int T = strips ? n / DT : (n + DT - 1) / DT;
-    int i_lo = 0, i_n = T, j_lo = 0, j_n = T, w = blockIdx.x, nw = gridDim.x;
-    const int sb_off = T * (T - 1) / 2;                     // SB: workgroups [0, sb_off) take one off-diagonal tile, the rest two diagonal tiles each
-    if (SYM) {
-        // the triangle column by column (tile column J: I = J .. T-1); an XCD's workgroups take consecutive ranges of it
-        if (gridDim.x >= 8 && (gridDim.x & 7) == 0) w = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    } else if (gridDim.x >= 8 && (gridDim.x & 7) == 0) {    // per-XCD 2 x 4 tile regions (see downdate_body)
-        const int x = blockIdx.x & 7, ri = x >> 2, rj = x & 3;
-        i_lo = ri * T / 2; i_n = (ri + 1) * T / 2 - i_lo;
-        j_lo = rj * T / 4; j_n = (rj + 1) * T / 4 - j_lo;
-        w = blockIdx.x >> 3; nw = gridDim.x >> 3;
-    }
-    // SYM (persistent): two classes of workgroups.  Class A, workgroups [0, T): the diagonal tile (w, w) -- it costs almost two
+    int w = blockIdx.x;
+    const int nw = gridDim.x;
+    // the triangle column by column (tile column J: I = J .. T-1); an XCD's workgroups take consecutive ranges of it
+    if (gridDim.x >= 8 && (gridDim.x & 7) == 0) w = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    // Two classes of workgroups.  Class A, workgroups [0, T): the diagonal tile (w, w) -- it costs almost two
     // ordinary tiles: no transposed image, but the border strips and the symmetric finish -- behind the tile below it, (w+1, w),
     // which shares its HPt panel.  Class B, the rest: the tiles with I >= J + 2, column by column, in equal ranges (3 per
     // workgroup at T = 32).  With the diagonal tiles inside equal ranges of three, the workgroups that held one set the pace.
     // (When class B gets fewer than three tiles per workgroup -- small states -- class A keeps to its diagonal tile and the tiles
     // below the diagonal join class B: dd_sub = 1.)
-    const bool classA = SYM && !SB && w < T;
+    const bool classA = w < T;
     const int sub = (d.dd_sub == 1) ? 1 : 2;
     const int nB = (T - sub + 1) * (T - sub) / 2, nwB = nw - T;     // class B: tiles and workgroups
-    const int ntiles = SYM ? nB : i_n * j_n;
-    const int wq = SYM && !SB ? w - T : w, nwq = SYM && !SB ? (nwB > 0 ? nwB : 1) : nw;
+    const int ntiles = nB;
+    const int wq = w - T, nwq = nwB > 0 ? nwB : 1;
     // (class B with the host's tiles-per-workgroup: plain multiples, no 64-bit divisions in the prologue)
-    const bool fixed_per = SYM && !SB && d.dd_per > 0;
-    const int t_begin = (SB || classA) ? 0 : (fixed_per ? min(wq * d.dd_per, ntiles) : (int)(((long long)wq * ntiles) / nwq));
-    const int t_end = SB ? ((w < sb_off) ? 1 : min(2, T - 2 * (w - sb_off)))
-                         : (classA ? ((sub == 2 && w + 1 < T) ? 2 : 1)
-                                   : (fixed_per ? min((wq + 1) * d.dd_per, ntiles) : (wq < nwq ? (int)(((long long)(wq + 1) * ntiles) / nwq) : 0)));
+    const bool fixed_per = d.dd_per > 0;
+    const int t_begin = classA ? 0 : (fixed_per ? min(wq * d.dd_per, ntiles) : (int)(((long long)wq * ntiles) / nwq));
+    const int t_end = classA ? ((sub == 2 && w + 1 < T) ? 2 : 1)
+                             : (fixed_per ? min((wq + 1) * d.dd_per, ntiles) : (wq < nwq ? (int)(((long long)(wq + 1) * ntiles) / nwq) : 0));
     if (t_begin >= t_end) return;
     const int nt = t_end - t_begin;
     const size_t ld = (size_t)d.ld;
@@ -1431,15 +1315,14 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     const double *__restrict__ HPt = d.HPt;
     double *__restrict__ P = d.P;
 
-    // a diagonal tile of the range is taken LAST (its strip work then rides on a tile that has nothing to prefetch);
-    // should a range ever hold more than one, the others are still handled where they stand (`special` below)
-    const int TT = SB ? T - 1 : T - sub;                    // side of the triangle that is enumerated (SB: I > J; class B: I >= J + sub)
+    // (a class-A workgroup takes its diagonal tile LAST: the strip work then rides on a tile that has nothing to prefetch)
+    const int TT = T - sub;                                 // side of the triangle class B enumerates (I >= J + sub)
     // tile number -> (row, column) of the triangle, with a cursor (column, its first tile number) that moves to the queried tile:
     // a workgroup asks for a handful of neighbouring tiles, so after the first query (<= T scalar steps) every look-up is O(1).
     // (A closed form with sqrtf + fix-up loops, evaluated afresh for each of the ~8 look-ups of the prologue, cost 0.8 us.)
     int cur_J = 0, cur_c0 = 0;
-    if ((SYM || SB) && TT > 0) {                            // the cursor starts at a closed-form estimate of the first tile's column (one sqrtf, once)
-        const int t0 = SB ? w : t_begin;
+    if (TT > 0) {                                           // the cursor starts at a closed-form estimate of the first tile's column (one sqrtf, once)
+        const int t0 = t_begin;
         const float bq = 2.0f * (float)TT + 1.0f;
         int Jg = (int)((bq - sqrtf(fmaxf(bq * bq - 8.0f * (float)t0, 0.0f))) * 0.5f);
         Jg = max(0, min(TT - 1, Jg));
@@ -1450,42 +1333,19 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
         while (cur_J > 0 && tt < cur_c0) { --cur_J; cur_c0 -= TT - cur_J; }
         Jt = cur_J; It = cur_J + (tt - cur_c0);
     };
-    int t_diag = t_end - 1;
-    if (SB || SYM) {                                        // (class A has its diagonal tile last by construction, class B has none)
-    } else if (strips) {
-        const int dl = j_lo - i_lo;
-        for (int jj = t_begin / i_n; jj <= (t_end - 1) / i_n; ++jj) {
-            const int ii = jj + dl, t = jj * i_n + ii;
-            if (ii >= 0 && ii < i_n && jj < j_n && t >= t_begin && t < t_end) t_diag = t;
-        }
-    }
     auto tile_IJ = [&](int pos, int &I, int &J) __attribute__((always_inline)) {
-        if (SB) {
-            if (w < sb_off) { tri_IJ(w, I, J); I += 1; }    // off-diagonal tile number w of the strictly lower triangle
-            else { I = 2 * (w - sb_off) + pos; J = I; }     // the pos-th of this workgroup's diagonal tiles
-            return;
-        }
-        const int tile = t_begin + pos;
-        const int tt = (tile == t_end - 1) ? t_diag : ((tile == t_diag) ? t_end - 1 : tile);
-        if (SYM) {
-            if (classA) { I = (pos == 0 && nt == 2) ? w + 1 : w; J = w; }
-            else { tri_IJ(tt, I, J); I += sub; }
-            return;
-        }
-        const int jj = tt / i_n;
-        I = i_lo + (tt - jj * i_n); J = j_lo + jj;
+        if (classA) { I = (pos == 0 && nt == 2) ? w + 1 : w; J = w; }
+        else { tri_IJ(t_begin + pos, I, J); I += sub; }
     };
     // LDS: [Kn buffer 0 | Kn buffer 1 | HPt buffer 0 | HPt buffer 1], PANEL doubles each
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)dd_smem;
-    // (SB: [Kn | HPt], one buffer each)
-    auto kn_buf = [&](int b) __attribute__((always_inline)) -> const double * { return dd_smem + (SB ? (size_t)0 : (size_t)b * PANEL); };
-    auto hp_buf = [&](int b) __attribute__((always_inline)) -> const double * { return dd_smem + (SB ? (size_t)PANEL : (size_t)(2 + b) * PANEL); };
+    auto kn_buf = [&](int b) __attribute__((always_inline)) -> const double * { return dd_smem + (size_t)b * PANEL; };
+    auto hp_buf = [&](int b) __attribute__((always_inline)) -> const double * { return dd_smem + (size_t)(2 + b) * PANEL; };
     // one DMA instruction: k-rows 2(4q + wave) + {0,1} of the panel that starts at row `row0` of `src`
     auto dma_piece = [&](const double *src, int row0, int buf_index, int q) __attribute__((always_inline)) {
         const int pr = 4 * q + wave;
         const double *g = src + (size_t)(row0 + 2 * (lane & 31)) + (size_t)(2 * pr + (lane >> 5)) * ld;
-        const int bi = SB ? (buf_index >= 2 ? 1 : 0) : buf_index;
-        dd_dma16(g, lds0 + (unsigned)(bi * PANEL * 8 + pr * 1024));
+        dd_dma16(g, lds0 + (unsigned)(buf_index * PANEL * 8 + pr * 1024));
     };
     auto p_ptr = [&](int I, int J) __attribute__((always_inline)) -> double * {
         return P + (size_t)(DT * I + 32 * wi + 2 * idx) + (size_t)(DT * J + 32 * wj + 2 * kq) * ld;
@@ -1566,7 +1426,7 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
         constexpr int PAR = decltype(par_c)::value, PREV = (PAR + AHEAD) % NB;   // PREV: tile pos-1's block = where tile pos+AHEAD's goes
         constexpr bool FIRST = decltype(first_c)::value, LOAD2 = decltype(load2_c)::value, LAST = decltype(last_c)::value,
                        SPECIAL = decltype(special_c)::value == 2,          // diagonal tile that carries the border strips
-                       DIAGSYM = SYM && decltype(special_c)::value >= 1,   // diagonal tile: its upper half mirrors its lower half ...
+                       DIAGSYM = decltype(special_c)::value >= 1,          // diagonal tile: its upper half mirrors its lower half ...
                        DIAG_LDS = DIAGSYM && LAST,     // ... through an LDS transpose of the sums when the panels are dead after the loop (last tile)
                        DIAG_MFMA = DIAGSYM && !LAST;   // ... by a second, role-swapped product otherwise (rare: a diagonal tile in mid-range)
         static_assert(!(LAST && LOAD2), "no tile after the last");
@@ -1584,7 +1444,7 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0, 0, 0, 0};
-        // a diagonal tile in SYM mode: the same product with the operands' roles swapped, accT(i,j) = sum_k Kn(j,k) HPt(i,k) =
+        // a diagonal tile: the same product with the operands' roles swapped, accT(i,j) = sum_k Kn(j,k) HPt(i,k) =
         // acc(j,i) in THIS lane's layout, so an upper element can take its mirror image's value without leaving the lane
         v4d accT[2][2];
         const double *aT = kn_buf(kb) + 32 * wj + 2 * idx + kq * 64;
@@ -1628,12 +1488,12 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
                 accT[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(at.y, bt.y, accT[1][1], 0, 0, 0);
             }
             // ---- this k-step's share of the VMEM traffic (compile-time positions)
-            // phase 0: DMA Kn; 1: the previous tile's stores, then DMA HPt; SYM: 2: its transposed image; last phase: P loads.
+            // phase 0: DMA Kn; 1: the previous tile's stores, then DMA HPt; 2: its transposed image; 3: P loads.
             // The DMA goes FIRST: the wait at the end of the loop is for the oldest operations only, so the sixteen stores behind
             // the DMA stay in flight across the tile boundary instead of having to be acknowledged inside it (all sixteen in one
             // phase would saturate the CU's store path and stall the MFMAs queued behind them)
             const int ph = kk / Q4, off = kk % Q4;
-            constexpr int PH_LOAD = SYM ? 3 : 2;
+            constexpr int PH_LOAD = 3;
             if (ph == 0) {
                 if (!SPECIAL && !LAST && needK) {
 #pragma unroll
@@ -1651,7 +1511,7 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
                     for (int q = 0; q < ND; ++q)
                         if ((q * Q4) / ND == off) dma_piece(HPt, DT * Jn, 2 + (hb ^ 1), q);
                 }
-            } else if (SYM && ph == 2) {
+            } else if (ph == 2) {
                 if (!FIRST) {
 #pragma unroll
                     for (int x = 0; x < 8; ++x)
@@ -1718,8 +1578,7 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
         if (SPECIAL) {
             // partial strip sums of the four waves meet in the idle Kn buffer; the threads of the strip mapping finish
             // (with KC < 64 a panel is smaller than the 16 KiB of partial sums: the launch's LDS beyond the four panels is free)
-            // (SB: the front of the LDS -- the panels are dead and the transpose above ended with a barrier)
-            v2d *red = (v2d *)(dd_smem + (SB ? (size_t)0 : (KC == 64 ? (size_t)(kb ^ 1) * PANEL : (size_t)4 * PANEL)));
+            v2d *red = (v2d *)(dd_smem + (KC == 64 ? (size_t)(kb ^ 1) * PANEL : (size_t)4 * PANEL));
 #pragma unroll
             for (int b3 = 0; b3 < DD_STRIP_MAX; ++b3) red[(wave * DD_STRIP_MAX + b3) * 64 + lane] = sacc[b3];
             lds_barrier();
@@ -1729,13 +1588,13 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
                 if (which < 2 && b < rem) {
                     v2d t = strip_p;
 #pragma unroll
-                    for (int w4 = 0; w4 < 4; ++w4) { const v2d r = red[(w4 * DD_STRIP_MAX + b) * 64 + (SYM ? 1 : which) * 32 + (x >> 1)]; t.x += r.x; t.y += r.y; }   // SYM: the row strip's sums for both strips
+                    for (int w4 = 0; w4 < 4; ++w4) { const v2d r = red[(w4 * DD_STRIP_MAX + b) * 64 + 32 + (x >> 1)]; t.x += r.x; t.y += r.y; }   // the row strip's sums for both strips
                     *p0 = t.x; *p1 = t.y;
                 }
             }
             if (I == 0 && tid < 64) {                   // the corner block P(nb.., nb..): 16 (a,b) slots x 4 quarters of k
                 const int a = (tid >> 2) & 3, b = tid & 3, k4 = tid >> 4;
-                const int as = SYM ? max(a, b) : a, bs = SYM ? min(a, b) : b;      // SYM: (a,b) and (b,a) both take the lower element's sum
+                const int as = max(a, b), bs = min(a, b);      // (a,b) and (b,a) both take the lower element's sum
                 const double *ra = &s_border[0][as][(KC / 4) * k4], *rb = &s_border[1][bs][(KC / 4) * k4];
                 double v = 0.0;
 #pragma unroll
@@ -1756,7 +1615,7 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
             double *Pw = p_ptr(I, J);
 #pragma unroll
             for (int q = 0; q < 8; ++q) DD_STORE((v2d *)(Pw + (size_t)(8 * (q & 3) + (q >> 2)) * ld), pq[PAR][q]);
-            if (SYM && !SB && d.pub && I == 0 && J == 0 && wave == 0) {
+            if (d.pub && I == 0 && J == 0 && wave == 0) {
                 // the final 3 x 3 pose block sits in four lanes of wave 0 (rows 2 idx + {0,1}, columns 2 kq + {0 (q = 0), 1 (q = 4)}):
                 // straight to the host's slots 3 + r + 3 c.  The mean k_mid committed, n and the flags go with it (lanes 32..35):
                 // this workgroup ends 3 us before the kernel does, so nobody waits for the PCIe writes
@@ -1776,7 +1635,7 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
                     if (kq == 0) host_slot_store(d.pub + 3 + 2 + 3, pq[PAR][4].x, d.pub_seq, 0);
                 }
             }
-            if (SYM && I != J) {                            // (a diagonal tile has no transposed image; nothing counts VMEM operations after the last tile)
+            if (I != J) {                                   // (a diagonal tile has no transposed image; nothing counts VMEM operations after the last tile)
                 double *Pwm = pm_ptr(I, J);
 #pragma unroll
                 for (int x = 0; x < 8; ++x) second_store(pq[PAR], Pw, Pwm, false, x);
@@ -1794,8 +1653,8 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
                 for (int q = 0; q < ND; ++q) dma_piece(HPt, DT * Jn, 2 + (hb ^ 1), q);
             }
             dd_wait_vmcnt<0>();
-        } else if (needH) dd_wait_vmcnt<(SYM && !FIRST ? 8 : 0) + (LOAD2 ? 8 : 0)>();      // after the last HPt DMA: (the 8 transposed stores +) this tile's 8 P loads
-        else if (needK) dd_wait_vmcnt<(FIRST ? 0 : (SYM ? 16 : 8)) + (LOAD2 ? 8 : 0)>();   // after the last Kn DMA: (all of the previous tile's stores +) (8 P loads)
+        } else if (needH) dd_wait_vmcnt<(!FIRST ? 8 : 0) + (LOAD2 ? 8 : 0)>();      // after the last HPt DMA: (the 8 transposed stores +) this tile's 8 P loads
+        else if (needK) dd_wait_vmcnt<(FIRST ? 0 : 16) + (LOAD2 ? 8 : 0)>();   // after the last Kn DMA: (all of the previous tile's stores +) (8 P loads)
         if (needK || needH) lds_barrier();
         if (needK) kb ^= 1;
         if (needH) hb ^= 1;
@@ -1811,32 +1670,8 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     // one instantiation per position: with no loop and no join in the way, hipcc's s_waitcnt pass places every wait exactly
     // (through the generic loop below it merges the variants' states at the joins and waits for far younger loads than the
     // P block it needs).  A diagonal tile sits at the end of its range (t_diag swap), so only the last position may be SPECIAL.
-    if (SB) {
-        // one standalone tile after the other (at most two, both diagonal): nothing is prefetched, the co-resident workgroup fills the gaps
-        for (int pos = 0; pos < nt; ++pos) {
-            if (pos > 0) {
-                lds_barrier();                              // every wave is through with the panels and the scratch
-                tile_IJ(pos, I, J);
-#pragma unroll
-                for (int q = 0; q < ND; ++q) dma_piece(Kn, DT * I, 0, q);
-#pragma unroll
-                for (int q = 0; q < ND; ++q) dma_piece(HPt, DT * J, 2, q);
-                const double *Pw = p_ptr(I, J);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) pq[0][q] = *(const v2d *)(Pw + (size_t)(8 * (q & 3) + (q >> 2)) * ld);
-                dd_wait_vmcnt<8>();
-                lds_barrier();
-            }
-            using P0 = std::integral_constant<int, 0>;
-            if (I == J) {
-                if (strips) tile_body(P0(), Tt(), Ff(), Tt(), C2(), pos);
-                else tile_body(P0(), Tt(), Ff(), Tt(), C1(), pos);
-            } else tile_body(P0(), Tt(), Ff(), Tt(), C0(), pos);
-        }
-    } else {
     bool mid_special = false;
-    if (strips || SYM)
-        for (int pos = 0; pos + 1 < nt; ++pos) { int Iq, Jq; tile_IJ(pos, Iq, Jq); mid_special |= Iq == Jq; }
+    for (int pos = 0; pos + 1 < nt; ++pos) { int Iq, Jq; tile_IJ(pos, Iq, Jq); mid_special |= Iq == Jq; }
     auto straight = [&](auto nt_c) __attribute__((always_inline)) {
         constexpr int NT = decltype(nt_c)::value;
         auto one = [&](auto pos_c) __attribute__((always_inline)) {
@@ -1845,7 +1680,7 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
             using First = std::integral_constant<bool, POS == 0>;
             using Load2 = std::integral_constant<bool, (POS + AHEAD < NT)>;
             using Last = std::integral_constant<bool, POS == NT - 1>;
-            if (POS == NT - 1 && I == J && (strips || SYM)) {
+            if (POS == NT - 1 && I == J) {
                 if (strips) tile_body(Par(), First(), Load2(), Last(), C2(), POS);
                 else tile_body(Par(), First(), Load2(), Last(), C1(), POS);
             } else tile_body(Par(), First(), Load2(), Last(), C0(), POS);
@@ -1862,7 +1697,7 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
         else straight(std::integral_constant<int, 3>());
     } else {
         auto run4 = [&](auto par_c, auto first_c, auto load2_c, auto last_c, int pos) __attribute__((always_inline)) {
-            if (I == J && (strips || SYM)) {
+            if (I == J) {
                 if (strips) tile_body(par_c, first_c, load2_c, last_c, C2(), pos);
                 else tile_body(par_c, first_c, load2_c, last_c, C1(), pos);
             } else tile_body(par_c, first_c, load2_c, last_c, C0(), pos);
@@ -1883,7 +1718,6 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
             if (NB == 3 && pos + 1 < nt) run(B2(), pos + 1);
             if (pos + NB - 1 < nt) run(B0(), pos + NB - 1);
         }
-    }
     }
 #ifdef REKF_DEBUG_ENTRY
     if (eslot >= 0 && threadIdx.x == 0) const_cast<RekfCtl *>(d.ctl)->dbg[16 + eslot] = wall_clock64();
@@ -1911,11 +1745,19 @@ __global__ __launch_bounds__(256) void k_augment(RekfDev d, RekfFrontArgs A)
     __shared__ double RQR[4];
     RekfCtl *ctl = d.ctl;
     const int N2 = ctl->n_new;
-    if (N2 == 0) return;
     const int n = ctl->n;
     const int tid = threadIdx.x;
     const size_t ld = (size_t)d.ld;
     double *P = d.P;
+    // The last kernel of a call while the map may still grow: it publishes what the caller reads next -- pose mean, the
+    // 3 x 3 pose block (neither changes here), the NEW n and the flags -- as tagged slots in pinned host memory.
+    auto publish = [&](int n_after) {
+        if (!d.pub) return;
+        if (tid < 3) host_slot_store(d.pub + tid, d.mu[tid], d.pub_seq, 0);
+        else if (tid < 12) host_slot_store(d.pub + tid, P[(tid - 3) % 3 + (size_t)((tid - 3) / 3) * ld], d.pub_seq, 0);
+        else if (tid == 12) host_slot_store(d.pub + 12, (double)n_after, d.pub_seq, __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    };
+    if (N2 == 0) { publish(n); return; }
     {
 #pragma clang fp contract(off)
         const double x = d.mu[0], y = d.mu[1], th = d.mu[2];
@@ -1974,11 +1816,9 @@ __global__ __launch_bounds__(256) void k_augment(RekfDev d, RekfFrontArgs A)
     }
     __syncthreads();
     if (tid == 0) ctl->n = n + 2 * N2;                              // cc:360-363
+    publish(n + 2 * N2);
 }
 
-// ----------------------------------------------------------------------------
-// PredictState, pose block (cc:97-152): non-mutating; out = mu3 | sigma3x3 col-major
-// ----------------------------------------------------------------------------
 // GetState's pose part (ekf_slam.h GetState / ros_node.cc's pose publisher): mu[0..2], the 3 x 3 pose block, n and the error
 // flags, straight into the host's slots
 __global__ void k_publish_pose(RekfDev d, RekfHostSlot *out, int seq)
@@ -1989,62 +1829,28 @@ __global__ void k_publish_pose(RekfDev d, RekfHostSlot *out, int seq)
     else if (l == 12) host_slot_store(out + 12, (double)d.ctl->n, seq, d.ctl->err);
 }
 
-__global__ void k_predict_pose(RekfDev d, RekfFrontArgs A, double *out12, RekfHostSlot *hout, int seq)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    Motion mo;
-    motion_terms(A, d.mu[2], mo);
-    double C[9];
-    for (int j = 0; j < 3; ++j)
-        for (int i = 0; i < 3; ++i) C[i + 3 * j] = d.P[i + (size_t)j * d.ld];
-    corner_predict(C, 3, mo);
-    double th = d.mu[2] + mo.d[2];
-    th = atan2(sin(th), cos(th));
-    out12[0] = d.mu[0] + mo.d[0];
-    out12[1] = d.mu[1] + mo.d[1];
-    out12[2] = th;
-    for (int q = 0; q < 9; ++q) out12[3 + q] = C[q];
-    if (hout) {
-        host_slot_store(hout + 0, d.mu[0] + mo.d[0], seq, 0);
-        host_slot_store(hout + 1, d.mu[1] + mo.d[1], seq, 0);
-        host_slot_store(hout + 2, th, seq, 0);
-        for (int q = 0; q < 9; ++q) host_slot_store(hout + 3 + q, C[q], seq, 0);
-    }
-}
-
 // ----------------------------------------------------------------------------
-// PredictState, everything a predict changes (cc:97-152), non-mutating: the predicted rows 0,1 and columns 0,1 of
-// P (k_front's own arithmetic, elementwise), the pose and the 3x3 pose block.
-// out: row0[ld] | row1[ld] | col0[ld] | col1[ld] | mu3 | corner 3x3 column-major
+// PredictState, the O(n) part of what a predict changes (cc:97-152), non-mutating: the predicted rows 0,1 and columns 0,1 of
+// P (Predict's own arithmetic, elementwise).  The pose and the 3x3 pose block come from the host's mirror.
+// out: row0[ld] | row1[ld] | col0[ld] | col1[ld]
 // ----------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_predict_rows(RekfDev d, RekfFrontArgs A, double *out)
 {
 #pragma clang fp contract(off)
-    __shared__ Motion mo;
+    // (the motion model runs on the host's pose mirror, which also supplies the predicted pose and pose block: A.pre_ab = this
+    // predict's (a, b); the arithmetic on the rows is k_apply_predict's, elementwise, so a later mutating Predict gives these bits)
     const int n = d.ctl->n;
     const size_t ld = (size_t)d.ld;
     const double *P = d.P;
-    if (threadIdx.x == 0) motion_terms(A, d.mu[2], mo);
-    __syncthreads();
-    const double a = mo.a, b = mo.b;
+    const double a = A.pre_ab[0], b = A.pre_ab[1];
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
         if (idx < 3) continue;
-        const double p2 = P[idx + 2 * ld], q2 = P[2 + idx * ld];
-        out[2 * ld + idx] = P[idx + 0 * ld] + a * p2;            // column 0
-        out[3 * ld + idx] = P[idx + 1 * ld] + b * p2;            // column 1
-        out[0 * ld + idx] = P[0 + idx * ld] + a * q2;            // row 0
-        out[1 * ld + idx] = P[1 + idx * ld] + b * q2;            // row 1
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double C9[9];
-        for (int q = 0; q < 9; ++q) C9[q] = P[(q % 3) + (size_t)(q / 3) * ld];
-        corner_predict(C9, 3, mo);
-        double th = d.mu[2] + mo.d[2], sn, cs;
-        sincos(th, &sn, &cs);
-        th = atan2(sn, cs);
-        double *tail = out + 4 * ld;
-        tail[0] = d.mu[0] + mo.d[0]; tail[1] = d.mu[1] + mo.d[1]; tail[2] = th;
-        for (int q = 0; q < 9; ++q) tail[3 + q] = C9[q];
+        const double p2 = P[idx + 2 * ld];
+        const double n0 = P[idx + 0 * ld] + a * p2, n1 = P[idx + 1 * ld] + b * p2;
+        out[2 * ld + idx] = n0;            // column 0
+        out[3 * ld + idx] = n1;            // column 1
+        out[0 * ld + idx] = n0;            // row 0 (P is exactly symmetric)
+        out[1 * ld + idx] = n1;            // row 1
     }
 }
 void rekf_launch_predict_rows(const RekfDev &d, const RekfFrontArgs &a, double *out, hipStream_t s)
@@ -2055,9 +1861,9 @@ void rekf_launch_predict_rows(const RekfDev &d, const RekfFrontArgs &a, double *
 // ----------------------------------------------------------------------------
 // launch wrappers
 // ----------------------------------------------------------------------------
-void rekf_launch_front(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s)
+void rekf_launch_apply_predict(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_front, dim3(1), dim3(1024), 0, s, d, a);
+    hipLaunchKernelGGL(k_apply_predict, dim3(1), dim3(1024), 0, s, d, a);
 }
 void rekf_launch_front_mb(const RekfDev &d, const RekfFrontArgs &a, int n_ub, hipStream_t s)
 {
@@ -2075,14 +1881,25 @@ void rekf_launch_mid(const RekfDev &d, const RekfFrontArgs &a, int n_ub, int m_u
     if (m_ub <= 32) hipLaunchKernelGGL(k_mid<2>, dim3(grid), dim3(512), 0, s, d, a);
     else hipLaunchKernelGGL(k_mid<4>, dim3(grid), dim3(512), 0, s, d, a);
 }
-template <int KC, bool SYM, bool SB> static void launch_downdate2(const RekfDev &d, int grid, hipStream_t s, bool first_on_device)
+template <int KC> static void launch_downdate2(const RekfDev &d, int grid, hipStream_t s, bool first_on_device)
 {
-    // SB: two panels, or the 64 x 66 transpose scratch of a diagonal tile if that is larger
-    constexpr int BYTES = SB ? (2 * KC * 64 * (int)sizeof(double) > 64 * 66 * 8 ? 2 * KC * 64 * (int)sizeof(double) : 64 * 66 * 8)
-                             : 4 * KC * 64 * (int)sizeof(double) + (KC < 64 ? 16384 : 0);
+    constexpr int BYTES = 4 * KC * 64 * (int)sizeof(double) + (KC < 64 ? 16384 : 0);
     if (first_on_device)
-        (void)hipFuncSetAttribute((const void *)k_downdate2<KC, SYM, SB>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
-    hipLaunchKernelGGL((k_downdate2<KC, SYM, SB>), dim3(grid), dim3(256), BYTES, s, d);
+        (void)hipFuncSetAttribute((const void *)k_downdate2<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+    hipLaunchKernelGGL((k_downdate2<KC>), dim3(grid), dim3(256), BYTES, s, d);
+}
+// host half of the tile schedule (tests/test_downdate_schedule_cpu.py restates it): T class-A workgroups (diagonal tile + the
+// one below) + equal ranges of the rest
+static void downdate_schedule(int n_ub, int slots, int &grid, int &dd_per, int &dd_sub)
+{
+    const int T = (n_ub + DT - 1) / DT;
+    const int room = (slots - T > 1) ? slots - T : 1;
+    int nB = (T - 1) * (T - 2) / 2, per = (nB + room - 1) / room;
+    dd_sub = 2;
+    if (per < 3) { dd_sub = 1; nB = T * (T - 1) / 2; per = (nB + room - 1) / room; }   // small states: a class-A workgroup keeps to its diagonal tile
+    dd_per = per > 0 ? per : 1;
+    grid = T + (nB > 0 ? (nB + per - 1) / per : 0);
+    if (grid >= 64) grid = (grid + 7) & ~7;         // multiple of 8 for the per-XCD numbering (workgroups past the last range return at once)
 }
 void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s)
 {
@@ -2102,46 +1919,18 @@ void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s)
         n_cu_of[slot] = cu;
         attr_done[slot] = 0;
     }
-    const int n_cu = n_cu_of[slot];
-    static const bool full = getenv("REKF_DD_FULL") != nullptr;      // A/B switches: the full-square variant (every tile computed),
-    static const bool persistent = getenv("REKF_DD_SB") == nullptr;   // default: the persistent lower-triangle variant (one workgroup per CU);
-                                                                      // REKF_DD_SB=1: one tile per workgroup, two workgroups per CU (same speed)
-    const int T = (n_ub + DT - 1) / DT;
-    const int slots = n_cu * DD_WG_PER_CU;
-    int grid, dd_per = 0, dd_sub = 2;
-    if (full) grid = (T * T < slots) ? T * T : slots;
-    else if (persistent) {                          // T class-A workgroups (diagonal tile + the one below) + equal ranges of the rest
-        const int room = (slots - T > 1) ? slots - T : 1;
-        int nB = (T - 1) * (T - 2) / 2, per = (nB + room - 1) / room;
-        dd_sub = 2;
-        if (per < 3) { dd_sub = 1; nB = T * (T - 1) / 2; per = (nB + room - 1) / room; }   // small states: a class-A workgroup keeps to its diagonal tile
-        dd_per = per > 0 ? per : 1;
-        grid = T + (nB > 0 ? (nB + per - 1) / per : 0);
-        if (grid >= 64) grid = (grid + 7) & ~7;     // multiple of 8 for the per-XCD numbering (workgroups past the last range return at once)
-    } else grid = T * (T - 1) / 2 + (T + 1) / 2;    // SB: one workgroup per off-diagonal tile, one per pair of diagonal tiles
-    if (full && grid >= 64) grid &= ~7;             // multiple of 8: enables the per-XCD tile regions
+    int grid, dd_per, dd_sub;
+    downdate_schedule(n_ub, n_cu_of[slot] * DD_WG_PER_CU, grid, dd_per, dd_sub);
     const int kc = (d.kc_ub < 16) ? 16 : ((d.kc_ub > 64) ? 64 : d.kc_ub);    // one k-chunk: the host never asks for more than 64 rows per step
     const unsigned bit = 1u << (kc / 16);
     const bool first = !(attr_done[slot] & bit) || dev != slot;
     attr_done[slot] |= bit;
-    if (full) {
-        if (kc == 64) launch_downdate2<64, false, false>(d, grid, s, first);
-        else if (kc == 48) launch_downdate2<48, false, false>(d, grid, s, first);
-        else if (kc == 32) launch_downdate2<32, false, false>(d, grid, s, first);
-        else launch_downdate2<16, false, false>(d, grid, s, first);
-    } else if (persistent) {
-        RekfDev dp = d;
-        dp.dd_per = dd_per; dp.dd_sub = dd_sub;
-        if (kc == 64) launch_downdate2<64, true, false>(dp, grid, s, first);
-        else if (kc == 48) launch_downdate2<48, true, false>(dp, grid, s, first);
-        else if (kc == 32) launch_downdate2<32, true, false>(dp, grid, s, first);
-        else launch_downdate2<16, true, false>(dp, grid, s, first);
-    } else {
-        if (kc == 64) launch_downdate2<64, true, true>(d, grid, s, first);
-        else if (kc == 48) launch_downdate2<48, true, true>(d, grid, s, first);
-        else if (kc == 32) launch_downdate2<32, true, true>(d, grid, s, first);
-        else launch_downdate2<16, true, true>(d, grid, s, first);
-    }
+    RekfDev dp = d;
+    dp.dd_per = dd_per; dp.dd_sub = dd_sub;
+    if (kc == 64) launch_downdate2<64>(dp, grid, s, first);
+    else if (kc == 48) launch_downdate2<48>(dp, grid, s, first);
+    else if (kc == 32) launch_downdate2<32>(dp, grid, s, first);
+    else launch_downdate2<16>(dp, grid, s, first);
 }
 void rekf_launch_augment(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s)
 {
@@ -2190,14 +1979,6 @@ void rekf_launch_ellipses(const RekfDev &d, double *out5, int cap, hipStream_t s
 {
     if (cap <= 0) return;
     hipLaunchKernelGGL(k_ellipses, dim3((cap + 255) / 256), dim3(256), 0, s, d, out5, cap);
-}
-void rekf_launch_predict_pose(const RekfDev &d, const RekfFrontArgs &a, double *out12, RekfHostSlot *hout, int seq, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_predict_pose, dim3(1), dim3(64), 0, s, d, a, out12, hout, seq);
-}
-bool rekf_downdate_publishes()
-{
-    return getenv("REKF_DD_FULL") == nullptr && getenv("REKF_DD_SB") == nullptr;    // the persistent lower-triangle form: tile (0,0) ends a class-A range
 }
 void rekf_launch_publish_pose(const RekfDev &d, RekfHostSlot *hout, int seq, hipStream_t s)
 {

@@ -38,29 +38,47 @@ struct rekf {
     double time;
     double vt[3];
     int n_ub;                  // host upper bound of the device-resident n
-    int last_m_ub = 64;        // innovation-row bound of the last scan (sizes the k_solve launch)
-    bool full;                 // a readback showed n == n_max: no landmark can ever be added again
-    bool n_exact = true;       // n_ub IS the device's n (nothing that can append landmarks was enqueued since it was read back)
-    double *pose_staging;      // pinned, 12 doubles
-    RekfHostSlot *host_slots;  // pinned + mapped: 16 tagged slots the pose kernels store into (null: copy-engine path)
+    int last_m_ub = 64;        // innovation-row bound of the last scan
+    bool full;                 // n == n_max is known: no landmark can be added (k_augment is not launched)
+    bool n_exact = true;       // n_ub IS the device's n (nothing that can append landmarks is in flight past the last read-back)
+    bool auto_grow = false;    // rekf_set_auto_grow: re-reserve instead of dropping reflectors
+    // ---- results the kernels publish: 16 tagged slots in pinned, device-mapped host memory ----
+    RekfHostSlot *host_slots;
     RekfHostSlot *host_slots_dev;
     int slot_seq;
-    bool pose_read;            // GetPose / Sync / GetFlags was called since the last odometry message: the caller reads the pose at odometry rate
-    bool pub_valid;            // the slots hold (or will hold, once the enqueued kernels have run) the CURRENT pose under tag pub_seq
+    bool pub_valid;            // a kernel already enqueued publishes (or has published) the CURRENT device pose under tag pub_seq
     int pub_seq;
-    double *dev_out12;         // device scratch for k_predict_pose
-    double *dev_ell;           // device scratch for k_ellipses (5 doubles per landmark of capacity)
+    // every publisher's tag with the growth bound at its enqueue: lets a later call turn a published n into a bound (or the exact value)
+    // of the CURRENT n without waiting for the device
+    struct PubRec { int seq; long cum; } pub_ring[64];
+    long cum_growth = 0;       // sum of 2 K over every scan enqueued while the state could still grow
+    int last_pub_enq = 0;      // tag of the youngest publisher enqueued
+    // ---- host mirror of the pose (reference reflector_ekf_slam.cc:154-223: Predict is O(1) on the pose and O(n) on two rows of P) ----
+    // mir_mu / mir_P = pose mean and 3 x 3 pose block of the state once everything enqueued has run AND the predicts below are applied.
+    // Valid after any pose read-back; HandleOdometryMessage / an empty scan then advance it on the host (same source as the kernels,
+    // glibc libm) and only accumulate the composite G = I + a e0 e2^T + b e1 e2^T for P's landmark rows: no launch.
+    bool mir_valid = false;
+    double mir_mu[3], mir_P[9];
+    bool lazy_pending = false; // the mirror is ahead of the device by the composite (lazy_a, lazy_b)
+    double lazy_a = 0, lazy_b = 0;
+    int flags_last = 0;        // sticky device flags as of the last read-back
+    bool last_scan_empty = false;   // the last HandleObservationMessage had no points: its (empty) match record lives here, not on the device
     RekfCtl *ctl_staging;      // pinned copy of the control block
     std::string hip_error;
     int flags_seen = 0;        // sticky device flags already reported on stderr
+    double *dev_ell;           // device scratch for k_ellipses (5 doubles per landmark of capacity)
     double *dev_pred;          // device scratch for k_predict_rows (4 * ld + 12 doubles)
     float *dev_obs = nullptr;  // a wide scan's observations (REKF_MAX_OBS_WIDE x 2 floats)
+    float *obs_staging = nullptr;   // pinned: a wide scan is copied here before the call returns, and from here to the device
+    hipEvent_t obs_staging_ev = nullptr;
+    bool obs_staging_busy = false;
     double *dev_mu_lin = nullptr;   // the mean a wide scan is linearised at (copy taken before its first block step)
     // profiling
     bool prof_on;
     int prof_mask;
     std::vector<ProfSlot> prof_slots;
     size_t prof_used;
+    int prof_open = 0;         // ProfScopes currently open (they nest): the slot table is never flushed while one is
     double prof_total_us[REKF_K_COUNT];
     long prof_count[REKF_K_COUNT];
     std::vector<float> prof_update_us;   // every REKF_K_UPDATE reading since the last reset
@@ -108,8 +126,11 @@ template <class H> int wait_slots(H *h, int first, int count, int seq)
 int prof_flush(rekf_t *h)
 {
     if (h->prof_used == 0) return REKF_OK;
+    if (h->prof_open > 0) return REKF_ERR_INVALID;    // an open scope has not recorded its end event yet
+    const size_t used = h->prof_used;
+    h->prof_used = 0;                                 // whatever happens below, the table is reused from the start
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    for (size_t i = 0; i < h->prof_used; ++i) {
+    for (size_t i = 0; i < used; ++i) {
         float ms = 0.f;
         HIP_TRY(h, hipEventElapsedTime(&ms, h->prof_slots[i].a, h->prof_slots[i].b));
         h->prof_total_us[h->prof_slots[i].kernel] += 1e3 * (double)ms;
@@ -117,33 +138,40 @@ int prof_flush(rekf_t *h)
         if (h->prof_slots[i].kernel == REKF_K_UPDATE && h->prof_update_us.size() < (1u << 20))
             h->prof_update_us.push_back(1e3f * ms);
     }
-    h->prof_used = 0;
     return REKF_OK;
 }
 
 struct ProfScope {
+    // Scopes nest (REKF_K_UPDATE around the per-kernel brackets): a scope keeps the INDEX of its slot -- the vector may
+    // reallocate while it is open -- and the slot table is only flushed (which synchronises and reuses it from the
+    // start) when no scope is open; a scope that finds the table full while another is open records nothing.
     rekf_t *h;
-    ProfSlot *slot;
-    ProfScope(rekf_t *h_, int kernel) : h(h_), slot(nullptr)
+    long slot;
+    ProfScope(rekf_t *h_, int kernel) : h(h_), slot(-1)
     {
         if (!h->prof_on || !((h->prof_mask >> kernel) & 1)) return;
         if (h->prof_used == h->prof_slots.size()) {
             if (h->prof_slots.size() >= 65536) {
-                prof_flush(h);
+                if (h->prof_open > 0 || prof_flush(h) != REKF_OK || h->prof_used != 0) return;
             } else {
                 ProfSlot s;
-                if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return;
+                if (hipEventCreate(&s.a) != hipSuccess) return;
+                if (hipEventCreate(&s.b) != hipSuccess) { (void)hipEventDestroy(s.a); return; }
                 s.kernel = kernel;
                 h->prof_slots.push_back(s);
             }
         }
-        slot = &h->prof_slots[h->prof_used++];
-        slot->kernel = kernel;
-        (void)hipEventRecord(slot->a, h->stream);
+        if (h->prof_used >= h->prof_slots.size()) return;
+        slot = (long)h->prof_used++;
+        h->prof_slots[(size_t)slot].kernel = kernel;
+        ++h->prof_open;
+        (void)hipEventRecord(h->prof_slots[(size_t)slot].a, h->stream);
     }
     ~ProfScope()
     {
-        if (slot) (void)hipEventRecord(slot->b, h->stream);
+        if (slot < 0) return;
+        (void)hipEventRecord(h->prof_slots[(size_t)slot].b, h->stream);
+        --h->prof_open;
     }
 };
 
@@ -179,19 +207,34 @@ void report_flags(rekf_t *h, int flags)
     h->flags_seen |= flags;
 }
 
-// Synchronise and refresh the host copy of the control block.
-// the next launches publish the pose they commit (k_front; k_mid + k_downdate2) under a fresh tag
-int begin_publish(rekf_t *h)
+// ---- publishers and the n they carry ------------------------------------------------------------------------------
+// Every call that changes the device state ends in ONE kernel that stores pose mean, 3 x 3 pose block, n and the sticky flags as
+// tagged slots into pinned host memory (k_downdate2's tile-(0,0) workgroup when the state is known full, else k_augment, else a
+// 64-thread publish kernel).  new_publisher hands out the tag and remembers the growth bound at that point.
+int new_publisher(rekf_t *h)
 {
-    if (!h->host_slots) { h->pub_valid = false; return 0; }
-    h->dev.pub = h->host_slots_dev;
-    h->dev.pub_seq = ++h->slot_seq;
-    return h->dev.pub_seq;
+    const int seq = ++h->slot_seq;
+    h->pub_ring[seq & 63] = {seq, h->cum_growth};
+    h->last_pub_enq = seq;
+    h->pub_valid = true; h->pub_seq = seq;
+    return seq;
 }
-void end_publish(rekf_t *h, int seq)
+
+// Non-blocking: whatever n the device has published so far bounds the current n (each scan enqueued behind that publisher can
+// have appended at most its K reflectors), and IS the current n when nothing that can append was enqueued behind it.
+void peek_n(rekf_t *h)
 {
-    h->dev.pub = nullptr;
-    if (seq) { h->pub_valid = true; h->pub_seq = seq; }
+    const RekfHostSlot *s = &h->host_slots[12];
+    const int s1 = __atomic_load_n(&s->seq, __ATOMIC_ACQUIRE);
+    const double v = *(volatile const double *)&s->v;
+    const int s2 = __atomic_load_n(&s->seq, __ATOMIC_ACQUIRE);
+    if (s1 != s2 || s1 <= 0) return;
+    const rekf::PubRec &r = h->pub_ring[s1 & 63];
+    if (r.seq != s1) return;
+    const long slack = h->cum_growth - r.cum;
+    const long nb = (long)v + slack;
+    if (nb < h->n_ub || slack == 0) h->n_ub = (int)(nb < h->dev.n_max ? nb : h->dev.n_max);
+    if (slack == 0) { h->n_exact = true; h->full = h->n_ub >= h->dev.n_max; }
 }
 
 int pull_ctl(rekf_t *h)
@@ -202,38 +245,123 @@ int pull_ctl(rekf_t *h)
     h->n_ub = h->ctl_staging->n;
     h->n_exact = true;
     h->full = h->ctl_staging->n >= h->dev.n_max;
+    h->flags_last = h->ctl_staging->err;
     report_flags(h, h->ctl_staging->err);
     return REKF_OK;
 }
 
-// n and the sticky flags alone (rekf_sync, rekf_get_flags, rekf_get_n): one small kernel behind everything enqueued so far stores
-// them into pinned host memory, polled by tag -- not the 7 KB control block through a copy engine and a stream wait (31 us on an
-// idle stream; this: ~6 us).  Everything enqueued before it has finished when its slot arrives (one in-order stream).
-int pull_n_flags(rekf_t *h, int *flags)
+// ---- the pose mirror ----------------------------------------------------------------------------------------------
+// Bring the mirror up to date with the device: wait for the slots of the publisher in flight (or enqueue a publish kernel behind
+// whatever is enqueued).  No copy engine, no wait for a completion signal.  n and the flags arrive with the pose.
+int refresh_mirror(rekf_t *h)
 {
-    if (!h->host_slots) {
-        int rc = pull_ctl(h);
-        if (rc == REKF_OK && flags) *flags = h->ctl_staging->err;
-        return rc;
-    }
+    if (h->mir_valid) return REKF_OK;
     HIP_TRY(h, hipSetDevice(h->device));
-    h->pose_read = true;
-    int seq = h->pub_seq;
-    if (!h->pub_valid) {                              // nothing in flight publishes: one small kernel does
-        seq = ++h->slot_seq;
+    if (!h->pub_valid) {
+        const int seq = new_publisher(h);
         rekf_launch_publish_pose(h->dev, h->host_slots_dev, seq, h->stream);
         HIP_TRY(h, hipGetLastError());
-        h->pub_valid = true; h->pub_seq = seq;
     }
-    int rc = wait_slots(h, 0, 13, seq);               // all of them: the last kernels of the call store different slots
+    int rc = wait_slots(h, 0, 13, h->pub_seq);        // all of them: the last kernels of a call store different slots
     if (rc != REKF_OK) return rc;
-    const int n = (int)h->host_slots[12].v, err = h->host_slots[12].aux;
-    h->n_ub = n;
-    h->n_exact = true;
-    h->full = n >= h->dev.n_max;
-    report_flags(h, err);
-    if (flags) *flags = err;
+    for (int q = 0; q < 3; ++q) h->mir_mu[q] = h->host_slots[q].v;
+    for (int q = 0; q < 9; ++q) h->mir_P[q] = h->host_slots[3 + q].v;
+    peek_n(h);
+    h->flags_last = h->host_slots[12].aux;
+    report_flags(h, h->flags_last);
+    h->mir_valid = true;
+    h->lazy_pending = false; h->lazy_a = 0; h->lazy_b = 0;
     return REKF_OK;
+}
+
+// Predict (cc:154-206) on the mirror: the kernels' own source (ekf_dev.h) with the host's libm -- the same libm a CPU build of the
+// reference calls.  The O(n) part, rows / columns 0, 1 of P against row / column 2, is deferred: G_k ... G_1 =
+// I + (sum a) e0 e2^T + (sum b) e1 e2^T exactly, because e2^T (a, b, 0)^T = 0.
+Motion host_predict(rekf_t *h, const RekfFrontArgs &a, double *mu3, double *P9, bool accumulate)
+{
+#pragma clang fp contract(off)
+    Motion mo;
+    motion_terms(a, mu3[2], mo);
+    mu3[0] = mu3[0] + mo.d[0];
+    mu3[1] = mu3[1] + mo.d[1];
+    const double th = mu3[2] + mo.d[2];
+    mu3[2] = atan2(sin(th), cos(th));                  // cc:181 / :205
+    corner_predict(P9, 3, mo);
+    if (accumulate) { h->lazy_a += mo.a; h->lazy_b += mo.b; h->lazy_pending = true; }
+    return mo;
+}
+
+void put_host_prediction(const rekf_t *h, RekfFrontArgs &a)
+{
+    a.host_pred = 1;
+    a.pre_pose[0] = h->mir_mu[0]; a.pre_pose[1] = h->mir_mu[1]; a.pre_pose[2] = h->mir_mu[2];
+    a.pre_pose[3] = cos(h->mir_mu[2]); a.pre_pose[4] = sin(h->mir_mu[2]);     // cc:252-253: of the wrapped heading
+    a.pre_ab[0] = h->lazy_a; a.pre_ab[1] = h->lazy_b;
+    for (int q = 0; q < 9; ++q) a.pre_C9[q] = h->mir_P[q];
+}
+
+// The device's P / mu catch up with the mirror (needed before anything but a scan reads them there).
+int flush_lazy(rekf_t *h)
+{
+    if (!h->lazy_pending) return REKF_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    RekfFrontArgs a;
+    fill_front_args(h, a, 0.0);
+    put_host_prediction(h, a);
+    h->dev.n_known = h->n_exact ? h->n_ub : -1;
+    rekf_launch_apply_predict(h->dev, a, h->stream);
+    HIP_TRY(h, hipGetLastError());
+    h->lazy_pending = false; h->lazy_a = 0; h->lazy_b = 0;
+    h->pub_valid = false;                              // the slots hold the pose from before these predicts (the mirror is what is current)
+    return REKF_OK;
+}
+
+struct DevBuffers {            // everything whose size depends on max_landmarks (rekf_create, rekf_reserve)
+    double *mu = nullptr, *mu_out = nullptr, *P = nullptr, *HPt = nullptr, *Kn = nullptr, *dev_pred = nullptr, *dev_mu_lin = nullptr,
+           *dev_ell = nullptr;
+    int ld = 0, n_max = 0;
+};
+void free_buffers(DevBuffers &b)
+{
+    (void)hipFree(b.mu); (void)hipFree(b.mu_out); (void)hipFree(b.P); (void)hipFree(b.HPt); (void)hipFree(b.Kn);
+    (void)hipFree(b.dev_pred); (void)hipFree(b.dev_mu_lin); (void)hipFree(b.dev_ell);
+    b = DevBuffers();
+}
+int alloc_buffers(rekf_t *h, int max_landmarks, DevBuffers &b)
+{
+    const int n_max = 3 + 2 * max_landmarks;
+    const int ld = round_up(n_max, 64);
+    if ((double)ld * ld * 8.0 >= 4294967296.0) return REKF_ERR_UNSUPPORTED;   // the kernels address P with 32-bit byte offsets
+    b.ld = ld; b.n_max = n_max;
+    HIP_TRY(h, hipMalloc(&b.mu, sizeof(double) * ld));
+    HIP_TRY(h, hipMalloc(&b.mu_out, sizeof(double) * ld));
+    HIP_TRY(h, hipMalloc(&b.P, sizeof(double) * (size_t)ld * ld));
+    HIP_TRY(h, hipMalloc(&b.HPt, sizeof(double) * (size_t)ld * REKF_PANEL_COLS));
+    HIP_TRY(h, hipMalloc(&b.Kn, sizeof(double) * (size_t)ld * REKF_PANEL_COLS));
+    HIP_TRY(h, hipMalloc(&b.dev_pred, sizeof(double) * (4 * (size_t)ld + 16)));
+    HIP_TRY(h, hipMalloc(&b.dev_mu_lin, sizeof(double) * ld));
+    HIP_TRY(h, hipMalloc(&b.dev_ell, sizeof(double) * 5 * (size_t)(max_landmarks > 0 ? max_landmarks : 1)));
+    HIP_TRY(h, hipMemsetAsync(b.mu, 0, sizeof(double) * ld, h->stream));
+    HIP_TRY(h, hipMemsetAsync(b.mu_out, 0, sizeof(double) * ld, h->stream));
+    HIP_TRY(h, hipMemsetAsync(b.P, 0, sizeof(double) * (size_t)ld * ld, h->stream));              // cc:10-11
+    HIP_TRY(h, hipMemsetAsync(b.HPt, 0, sizeof(double) * (size_t)ld * REKF_PANEL_COLS, h->stream));
+    HIP_TRY(h, hipMemsetAsync(b.Kn, 0, sizeof(double) * (size_t)ld * REKF_PANEL_COLS, h->stream));
+    return REKF_OK;
+}
+void adopt_buffers(rekf_t *h, const DevBuffers &b, int max_landmarks)
+{
+    h->dev.mu = b.mu; h->dev.mu_out = b.mu_out; h->dev.P = b.P; h->dev.HPt = b.HPt; h->dev.Kn = b.Kn;
+    h->dev_pred = b.dev_pred; h->dev_mu_lin = b.dev_mu_lin; h->dev_ell = b.dev_ell;
+    h->dev.ld = b.ld; h->dev.n_max = b.n_max;
+    h->dev.mu_lin = nullptr;
+    h->max_landmarks = max_landmarks;
+}
+DevBuffers current_buffers(const rekf_t *h)
+{
+    DevBuffers b;
+    b.mu = h->dev.mu; b.mu_out = h->dev.mu_out; b.P = h->dev.P; b.HPt = h->dev.HPt; b.Kn = h->dev.Kn;
+    b.dev_pred = h->dev_pred; b.dev_mu_lin = h->dev_mu_lin; b.dev_ell = h->dev_ell; b.ld = h->dev.ld; b.n_max = h->dev.n_max;
+    return b;
 }
 
 }  // namespace
@@ -252,7 +380,7 @@ const char *rekf_strerror(int code)
     case REKF_ERR_CAPACITY: return "landmark capacity exceeded; new reflectors dropped";
     case REKF_ERR_SINGULAR: return "innovation covariance not positive definite";
     case REKF_ERR_BUFFER: return "caller buffer too small";
-    case REKF_ERR_UNSUPPORTED: return "unsupported option";
+    case REKF_ERR_UNSUPPORTED: return "unsupported size or option";
     default: return "unknown error";
     }
 }
@@ -277,67 +405,53 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
     h->prof_used = 0;
     for (int k = 0; k < REKF_K_COUNT; ++k) { h->prof_total_us[k] = 0; h->prof_count[k] = 0; }
     h->stream = nullptr;
-    h->pose_staging = nullptr;
-    h->host_slots = nullptr; h->host_slots_dev = nullptr; h->slot_seq = 0; h->pub_valid = false; h->pub_seq = 0; h->pose_read = false;
+    h->host_slots = nullptr; h->host_slots_dev = nullptr; h->slot_seq = 0; h->pub_valid = false; h->pub_seq = 0;
+    for (auto &r : h->pub_ring) r = {0, 0};
     h->ctl_staging = nullptr;
-    h->dev_out12 = nullptr;
     h->dev_ell = nullptr;
     h->dev_pred = nullptr;
     std::memset(&h->dev, 0, sizeof(h->dev));
 
-    const int n_max = 3 + 2 * max_landmarks;
-    const int ld = round_up(n_max, 64);
     int rc = [&]() -> int {
         HIP_TRY(h, hipSetDevice(device));
         HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         HIP_TRY(h, hipMalloc(&h->dev.ctl, sizeof(RekfCtl)));
-        HIP_TRY(h, hipMalloc(&h->dev.mu, sizeof(double) * ld));
-        HIP_TRY(h, hipMalloc(&h->dev.mu_out, sizeof(double) * ld));
-        HIP_TRY(h, hipMalloc(&h->dev.P, sizeof(double) * (size_t)ld * ld));
-        HIP_TRY(h, hipMalloc(&h->dev.HPt, sizeof(double) * (size_t)ld * REKF_PANEL_COLS));
-        HIP_TRY(h, hipMalloc(&h->dev.Kn, sizeof(double) * (size_t)ld * REKF_PANEL_COLS));
+        DevBuffers b;
+        int rb = alloc_buffers(h, max_landmarks, b);
+        if (rb != REKF_OK) { free_buffers(b); return rb; }
+        adopt_buffers(h, b, max_landmarks);
         HIP_TRY(h, hipMalloc(&h->dev.KnB, sizeof(double) * REKF_STRIP_MAX * REKF_MR_PAD));
         HIP_TRY(h, hipMalloc(&h->dev.HPtB, sizeof(double) * REKF_STRIP_MAX * REKF_MR_PAD));
-        HIP_TRY(h, hipMalloc(&h->dev_out12, sizeof(double) * 16));
-        HIP_TRY(h, hipMalloc(&h->dev_pred, sizeof(double) * (4 * (size_t)ld + 16)));
         HIP_TRY(h, hipMalloc(&h->dev_obs, sizeof(float) * 2 * REKF_MAX_OBS_WIDE));
-        HIP_TRY(h, hipMalloc(&h->dev_mu_lin, sizeof(double) * ld));
-        HIP_TRY(h, hipMalloc(&h->dev_ell, sizeof(double) * 5 * (size_t)(max_landmarks > 0 ? max_landmarks : 1)));
-        HIP_TRY(h, hipHostMalloc(&h->pose_staging, sizeof(double) * 16));
-        if (hipHostMalloc(&h->host_slots, sizeof(RekfHostSlot) * 16, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
-            std::memset(h->host_slots, 0, sizeof(RekfHostSlot) * 16);
-            void *dv = nullptr;
-            if (hipHostGetDevicePointer(&dv, h->host_slots, 0) == hipSuccess) h->host_slots_dev = (RekfHostSlot *)dv;
-            else { (void)hipHostFree(h->host_slots); h->host_slots = nullptr; }
-        }
-        (void)hipGetLastError();
+        HIP_TRY(h, hipHostMalloc(&h->obs_staging, sizeof(float) * 2 * REKF_MAX_OBS_WIDE));
+        HIP_TRY(h, hipEventCreateWithFlags(&h->obs_staging_ev, hipEventDisableTiming));
+        // results come back as tagged slots in pinned, device-mapped host memory (no copy engine on the pose path)
+        HIP_TRY(h, hipHostMalloc(&h->host_slots, sizeof(RekfHostSlot) * 16, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(h->host_slots, 0, sizeof(RekfHostSlot) * 16);
+        void *dv = nullptr;
+        HIP_TRY(h, hipHostGetDevicePointer(&dv, h->host_slots, 0));
+        h->host_slots_dev = (RekfHostSlot *)dv;
         HIP_TRY(h, hipHostMalloc(&h->ctl_staging, sizeof(RekfCtl)));
-        h->dev.ld = ld;
-        h->dev.n_max = n_max;
         h->dev.M_map = 0;
         HIP_TRY(h, hipMemsetAsync(h->dev.ctl, 0, sizeof(RekfCtl), h->stream));
-        HIP_TRY(h, hipMemsetAsync(h->dev.mu, 0, sizeof(double) * ld, h->stream));
-        HIP_TRY(h, hipMemsetAsync(h->dev.mu_out, 0, sizeof(double) * ld, h->stream));
-        HIP_TRY(h, hipMemsetAsync(h->dev.P, 0, sizeof(double) * (size_t)ld * ld, h->stream));   // cc:10-11
-        HIP_TRY(h, hipMemsetAsync(h->dev.HPt, 0, sizeof(double) * (size_t)ld * REKF_PANEL_COLS, h->stream));
-        HIP_TRY(h, hipMemsetAsync(h->dev.Kn, 0, sizeof(double) * (size_t)ld * REKF_PANEL_COLS, h->stream));
         HIP_TRY(h, hipMemsetAsync(h->dev.KnB, 0, sizeof(double) * REKF_STRIP_MAX * REKF_MR_PAD, h->stream));
         HIP_TRY(h, hipMemsetAsync(h->dev.HPtB, 0, sizeof(double) * REKF_STRIP_MAX * REKF_MR_PAD, h->stream));
         std::memset(h->ctl_staging, 0, sizeof(RekfCtl));
         h->ctl_staging->n = 3;
         HIP_TRY(h, hipMemcpyAsync(h->dev.ctl, h->ctl_staging, sizeof(int) * 2, hipMemcpyHostToDevice, h->stream));
-        h->pose_staging[0] = opt->init_pose[0];       // cc:9
-        h->pose_staging[1] = opt->init_pose[1];
-        h->pose_staging[2] = opt->init_pose[2];
-        HIP_TRY(h, hipMemcpyAsync(h->dev.mu, h->pose_staging, sizeof(double) * 3, hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipMemcpy(h->dev.mu, opt->init_pose, sizeof(double) * 3, hipMemcpyHostToDevice));   // cc:9
         return REKF_OK;
     }();
     if (rc != REKF_OK) {
-        std::fprintf(stderr, "rekf_create: %s\n", h->hip_error.c_str());
+        std::fprintf(stderr, "rekf_create: %s\n", rc == REKF_ERR_UNSUPPORTED ? "max_landmarks too large (P is addressed with 32-bit byte offsets)" : h->hip_error.c_str());
         rekf_destroy(h);
         return rc;
     }
+    // the mirror starts current: init_pose and a zero pose block (cc:9-11)
+    for (int q = 0; q < 3; ++q) h->mir_mu[q] = opt->init_pose[q];
+    for (int q = 0; q < 9; ++q) h->mir_P[q] = 0.0;
+    h->mir_valid = true;
     *out = h;
     return REKF_OK;
 }
@@ -348,14 +462,61 @@ void rekf_destroy(rekf_t *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &s : h->prof_slots) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
-    (void)hipFree(h->dev.ctl); (void)hipFree(h->dev.mu); (void)hipFree(h->dev.mu_out); (void)hipFree(h->dev.P);
-    (void)hipFree(h->dev.HPt); (void)hipFree(h->dev.Kn); (void)hipFree(h->dev.KnB); (void)hipFree(h->dev.HPtB);
-    (void)hipFree(h->dev.map_xy); (void)hipFree(h->dev.map_cov); (void)hipFree(h->dev_out12); (void)hipFree(h->dev_ell); (void)hipFree(h->dev_pred); (void)hipFree(h->dev_obs); (void)hipFree(h->dev_mu_lin);
-    if (h->pose_staging) (void)hipHostFree(h->pose_staging);
+    DevBuffers b = current_buffers(h);
+    free_buffers(b);
+    (void)hipFree(h->dev.ctl); (void)hipFree(h->dev.KnB); (void)hipFree(h->dev.HPtB);
+    (void)hipFree(h->dev.map_xy); (void)hipFree(h->dev.map_cov); (void)hipFree(h->dev_obs);
+    if (h->obs_staging) (void)hipHostFree(h->obs_staging);
+    if (h->obs_staging_ev) (void)hipEventDestroy(h->obs_staging_ev);
     if (h->host_slots) (void)hipHostFree(h->host_slots);
     if (h->ctl_staging) (void)hipHostFree(h->ctl_staging);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
+}
+
+int rekf_reserve(rekf_t *h, int new_max_landmarks)
+{
+    if (!h || new_max_landmarks < 1) return REKF_ERR_INVALID;
+    if (new_max_landmarks <= h->max_landmarks) return REKF_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = flush_lazy(h);
+    if (rc != REKF_OK) return rc;
+    rc = pull_ctl(h);                                  // drains the stream; n is exact afterwards
+    if (rc != REKF_OK) return rc;
+    const int n = h->ctl_staging->n;
+    DevBuffers nb;
+    rc = alloc_buffers(h, new_max_landmarks, nb);
+    if (rc != REKF_OK) { free_buffers(nb); (void)hipGetLastError(); return rc; }
+    // the re-layout: column c of P moves from stride ld to stride ld', everything past n stays zero (the reference resizes and
+    // copies on EVERY augment, cc:360-363; here once per doubling)
+    rc = [&]() -> int {
+        HIP_TRY(h, hipMemcpyAsync(nb.mu, h->dev.mu, sizeof(double) * n, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(h, hipMemcpy2DAsync(nb.P, sizeof(double) * nb.ld, h->dev.P, sizeof(double) * h->dev.ld, sizeof(double) * n, n,
+                                    hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        return REKF_OK;
+    }();
+    if (rc != REKF_OK) { free_buffers(nb); return rc; }
+    DevBuffers old = current_buffers(h);
+    adopt_buffers(h, nb, new_max_landmarks);
+    free_buffers(old);
+    h->full = false;
+    h->n_ub = n; h->n_exact = true;
+    return REKF_OK;
+}
+
+int rekf_set_auto_grow(rekf_t *h, int on)
+{
+    if (!h) return REKF_ERR_INVALID;
+    h->auto_grow = on != 0;
+    return REKF_OK;
+}
+
+int rekf_get_capacity(rekf_t *h, int *max_landmarks)
+{
+    if (!h || !max_landmarks) return REKF_ERR_INVALID;
+    *max_landmarks = h->max_landmarks;
+    return REKF_OK;
 }
 
 int rekf_set_map(rekf_t *h, const float *xy, const double *cov, int M)
@@ -379,24 +540,15 @@ int rekf_handle_odometry(rekf_t *h, double t, double vx, double vy, double wz)
     if (!h) return REKF_ERR_INVALID;
     if (t < h->time) return REKF_OK;                  // drop old data, cc:211-212
     if (h->opt.use_imu) return REKF_OK;               // cc:213-223: the use_imu branch is empty -- nothing happens
+    // Predict(dt) on the host's pose mirror: no launch.  If the pose of the last scan has not been read back yet this waits for the
+    // slots its last kernel stores (the reference's handler is synchronous anyway, and its node reads the pose after every scan,
+    // src/ros_node.cc:514-515, so in that call pattern nothing is ever waited for).
+    int rc = refresh_mirror(h);
+    if (rc != REKF_OK) return rc;
     h->vt[0] = vx; h->vt[1] = vy; h->vt[2] = wz;      // cc:216
     RekfFrontArgs a;
     fill_front_args(h, a, t - h->time);               // cc:217
-    a.is_obs = 0;
-    h->dev.n_known = h->n_exact ? h->n_ub : -1;
-    HIP_TRY(h, hipSetDevice(h->device));
-    {
-        ProfScope ps(h, REKF_K_PREDICT);
-        // k_front publishes the pose it commits only for a caller that reads it back between odometry messages (the
-        // reference's node does: HandleOdometryMessage -> GetState, src/ros_node.cc:627-660): the kernel is one workgroup and
-        // would otherwise end 1.5 us later, waiting for its PCIe writes, for nobody
-        const bool want = h->pose_read;
-        h->pose_read = false;
-        h->pub_valid = false;
-        const int seq = want ? begin_publish(h) : 0;
-        rekf_launch_front(h->dev, a, h->stream);      // cc:218 Predict(dt)
-        end_publish(h, seq);
-    }
+    host_predict(h, a, h->mir_mu, h->mir_P, true);    // cc:218 Predict(dt)
     h->time = t;                                      // cc:219
     return REKF_OK;
 }
@@ -407,41 +559,73 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     if (K > REKF_MAX_OBS) return REKF_ERR_TOO_MANY_OBS;
     const bool staged = K > REKF_MAX_OBS_DEV;                       // too many observations for the launch packet
     const bool blocks = 2 * K + (gps_pose3 ? 3 : 0) > 64;           // more innovation rows than one pass of k_mid takes
+    HIP_TRY(h, hipSetDevice(h->device));
+    peek_n(h);                                        // whatever the device has published meanwhile tightens the bound on n, for free
+    if (K == 0) {                                     // cc:235-236: Predict only -- on the mirror, like an odometry message
+        int rc = refresh_mirror(h);
+        if (rc != REKF_OK) return rc;
+        RekfFrontArgs a0;
+        fill_front_args(h, a0, t - h->time);
+        host_predict(h, a0, h->mir_mu, h->mir_P, true);
+        h->time = t;                                  // cc:234
+        h->last_scan_empty = true;
+        return REKF_OK;
+    }
+    if (h->auto_grow && h->n_ub + 2 * K > h->dev.n_max) {
+        // room for K new reflectors is not certain.  Learn the exact n (waits for the publisher in flight: only when the BOUND says
+        // so -- and a doubling leaves room for many scans), then re-reserve rather than let k_mid drop reflectors (cc:311-364 never does).
+        int rc = refresh_mirror(h);
+        if (rc != REKF_OK) return rc;
+        if (h->n_ub + 2 * K > h->dev.n_max) {
+            const int need = (h->n_ub - 3) / 2 + K;
+            rc = rekf_reserve(h, need > 2 * h->max_landmarks ? need : 2 * h->max_landmarks);
+            if (rc != REKF_OK && rc != REKF_ERR_UNSUPPORTED) return rc;     // (too large to address: fall back to the capacity flag)
+        }
+    }
+    h->last_scan_empty = false;
     RekfFrontArgs a;
     fill_front_args(h, a, t - h->time);               // cc:232 (dt may be negative, Q8)
     a.is_obs = 1;
     a.K = K;
-    if (K > 0 && !staged) std::memcpy(a.obs, xy, sizeof(float) * 2 * (size_t)K);
+    if (!staged) std::memcpy(a.obs, xy, sizeof(float) * 2 * (size_t)K);
     if (gps_pose3) {
         a.has_gps = 1;
         a.gps[0] = gps_pose3[0]; a.gps[1] = gps_pose3[1]; a.gps[2] = gps_pose3[2];
     }
-    h->dev.n_known = h->n_exact ? h->n_ub : -1;
-    HIP_TRY(h, hipSetDevice(h->device));
-    ProfScope upd(h, REKF_K_UPDATE);                  // one bracket around the whole chain (per-update latency)
-    if (K == 0) {                                     // cc:235-236: predict only, single-workgroup kernel
-        ProfScope ps(h, REKF_K_FRONT);
-        const int seq = begin_publish(h);
-        rekf_launch_front(h->dev, a, h->stream);
-        end_publish(h, seq);
-        h->time = t;
-        return REKF_OK;
+    if (h->mir_valid) {
+        // the pose is known here: this scan's own Predict (cc:233) runs on the mirror too, and the front kernel receives the
+        // predicted pose, the pose block and the composite of every predict since the device last saw P -- no motion model there
+        host_predict(h, a, h->mir_mu, h->mir_P, true);
+        put_host_prediction(h, a);
+        h->lazy_pending = false; h->lazy_a = 0; h->lazy_b = 0;
     }
-    h->dev.kc_ub = round_up(2 * K + (gps_pose3 ? 3 : 0), 16);
+    h->mir_valid = false;                             // the update moves the pose: current again after the next read-back
     h->dev.n_known = h->n_exact ? h->n_ub : -1;
-    if (staged) {                                     // the scan does not fit the launch packet: stage it in HBM (copied before this call returns)
-        HIP_TRY(h, hipMemcpyAsync(h->dev_obs, xy, sizeof(float) * 2 * (size_t)K, hipMemcpyHostToDevice, h->stream));
+    ProfScope upd(h, REKF_K_UPDATE);                  // one bracket around the whole chain (per-update latency)
+    h->dev.kc_ub = round_up(2 * K + (gps_pose3 ? 3 : 0), 16);
+    if (staged) {                                     // the scan does not fit the launch packet: through a pinned staging buffer into HBM
+        if (h->obs_staging_busy) HIP_TRY(h, hipEventSynchronize(h->obs_staging_ev));   // the previous wide scan's copy (long done)
+        std::memcpy(h->obs_staging, xy, sizeof(float) * 2 * (size_t)K);                 // the caller's buffer is free when we return
+        HIP_TRY(h, hipMemcpyAsync(h->dev_obs, h->obs_staging, sizeof(float) * 2 * (size_t)K, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipEventRecord(h->obs_staging_ev, h->stream));
+        h->obs_staging_busy = true;
         a.obs_ext = h->dev_obs;
     }
-    h->pub_valid = false;
-    // in steady state (state full: no k_augment behind the chain) the last k_mid / k_downdate2 of the call publish the pose
-    const bool fold = h->full && h->host_slots && rekf_downdate_publishes();
-    int pub_seq = 0;
+    // the call's LAST kernel publishes: k_downdate2 (tile (0,0)'s workgroup) when no landmark can be added any more, else k_augment
+    const bool aug = !h->full;
+    if (aug) h->cum_growth += 2 * K;
+    const int pub_seq = new_publisher(h);
+    RekfDev dpub = h->dev;                            // (copied again below where mu / mu_out have been swapped)
     { ProfScope ps(h, REKF_K_FRONT); rekf_launch_front_mb(h->dev, a, h->n_ub, h->stream); }
     h->time = t;                                      // cc:234
     const int n_ub = h->n_ub;
     const int m_ub = 2 * K + (gps_pose3 ? 3 : 0);
     h->dev.mu_lin = h->dev.mu;
+    auto downdate = [&](bool last) {
+        ProfScope ps(h, REKF_K_DOWNDATE);
+        if (last && !aug) { dpub = h->dev; dpub.pub = h->host_slots_dev; dpub.pub_seq = pub_seq; rekf_launch_downdate(dpub, n_ub, h->stream); }
+        else rekf_launch_downdate(h->dev, n_ub, h->stream);
+    };
     if (blocks) {
         // More than 32 observations (the reference has no limit, cc:397): matched once, then the joint update runs as
         // exact block steps of at most 32 pairs through the same two kernels (k_mid explains why that is the same
@@ -455,32 +639,34 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         for (int p0 = 0; p0 < K; p0 += stride) {
             a.pair0 = p0;
             h->dev.mu_lin = h->dev_mu_lin;
-            if (fold && p0 + stride >= K) pub_seq = begin_publish(h);          // the last step commits the final pose
             { ProfScope ps(h, REKF_K_MID); rekf_launch_mid(h->dev, a, n_ub, 64, h->stream); }
             std::swap(h->dev.mu, h->dev.mu_out);
-            { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_downdate(h->dev, n_ub, h->stream); }
+            downdate(p0 + stride >= K);               // the last step commits the final pose
         }
-        end_publish(h, pub_seq);
         a.pair0 = -1;
         h->dev.mu_lin = h->dev.mu;
     } else {
         // the whole innovation fits one pass: gather + solve + gain as ONE launch (k_mid), which leaves the updated
         // mean in the other mean buffer
-        if (fold) pub_seq = begin_publish(h);
         { ProfScope ps(h, REKF_K_MID); rekf_launch_mid(h->dev, a, n_ub, m_ub, h->stream); }
         std::swap(h->dev.mu, h->dev.mu_out);
-        { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_downdate(h->dev, n_ub, h->stream); }
-        end_publish(h, pub_seq);
+        downdate(true);
     }
     h->last_m_ub = m_ub;
-    // the state only grows: once a readback has shown it full, k_augment can never have work again
+    // the state only grows: once it is known full, k_augment can never have work again
     // (k_mid / k_compact_wide drop the extra reflectors and raise REKF_FLAG_CAPACITY)
-    if (!h->full) { ProfScope ps(h, REKF_K_AUGMENT); rekf_launch_augment(h->dev, a, h->stream); }
+    if (aug) {
+        ProfScope ps(h, REKF_K_AUGMENT);
+        dpub = h->dev; dpub.pub = h->host_slots_dev; dpub.pub_seq = pub_seq;
+        rekf_launch_augment(dpub, a, h->stream);
+    }
     { ProfScope ps(h, REKF_K_EMPTY); }
-    // the scan may have appended up to K reflectors; the exact n stays on the device
-    int grown = n_ub + 2 * K;
-    h->n_ub = grown > h->dev.n_max ? h->dev.n_max : grown;
-    if (!h->full) h->n_exact = false;                 // k_augment may have appended: only the device knows by how much
+    if (aug) {
+        // the scan may have appended up to K reflectors; the exact n stays on the device until it is published
+        const int grown = n_ub + 2 * K;
+        h->n_ub = grown > h->dev.n_max ? h->dev.n_max : grown;
+        h->n_exact = false;
+    }
     HIP_TRY(h, hipGetLastError());
     return REKF_OK;
 }
@@ -488,25 +674,16 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
 int rekf_predict_state(rekf_t *h, double t, double mu3[3], double sigma3x3[9])
 {
     if (!h || !mu3) return REKF_ERR_INVALID;
+    int rc = refresh_mirror(h);
+    if (rc != REKF_OK) return rc;
     RekfFrontArgs a;
     fill_front_args(h, a, t - h->time);               // cc:100
-    HIP_TRY(h, hipSetDevice(h->device));
-    if (h->host_slots) {                               // one launch; the result arrives in pinned memory, polled by tag
-        const int seq = ++h->slot_seq;
-        rekf_launch_predict_pose(h->dev, a, h->dev_out12, h->host_slots_dev, seq, h->stream);
-        HIP_TRY(h, hipGetLastError());
-        h->pub_valid = false;                          // the slots now hold the PREDICTED pose
-        int rc = wait_slots(h, 0, 12, seq);
-        if (rc != REKF_OK) return rc;
-        for (int q = 0; q < 3; ++q) mu3[q] = h->host_slots[q].v;
-        if (sigma3x3) for (int q = 0; q < 9; ++q) sigma3x3[q] = h->host_slots[3 + q].v;
-        return REKF_OK;
-    }
-    rekf_launch_predict_pose(h->dev, a, h->dev_out12, nullptr, 0, h->stream);
-    HIP_TRY(h, hipMemcpyAsync(h->pose_staging, h->dev_out12, sizeof(double) * 12, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    std::memcpy(mu3, h->pose_staging, sizeof(double) * 3);
-    if (sigma3x3) std::memcpy(sigma3x3, h->pose_staging + 3, sizeof(double) * 9);
+    double m3[3], P9[9];
+    for (int q = 0; q < 3; ++q) m3[q] = h->mir_mu[q];
+    for (int q = 0; q < 9; ++q) P9[q] = h->mir_P[q];
+    host_predict(h, a, m3, P9, false);                // non-mutating: on a copy of the mirror
+    for (int q = 0; q < 3; ++q) mu3[q] = m3[q];
+    if (sigma3x3) for (int q = 0; q < 9; ++q) sigma3x3[q] = P9[q];
     return REKF_OK;
 }
 
@@ -520,35 +697,13 @@ int rekf_get_time(rekf_t *h, double *t)
 int rekf_get_pose(rekf_t *h, double *t, double mu3[3], double sigma3x3[9])
 {
     if (!h) return REKF_ERR_INVALID;
-    HIP_TRY(h, hipSetDevice(h->device));
-    if (h->host_slots) {
-        // the kernels of the last call have published (or are about to publish) the pose they committed; otherwise one small
-        // launch behind whatever is enqueued does -- either way no copy engine and no stream wait
-        h->pose_read = true;
-        int seq = h->pub_seq;
-        if (!h->pub_valid) {
-            seq = ++h->slot_seq;
-            rekf_launch_publish_pose(h->dev, h->host_slots_dev, seq, h->stream);
-            HIP_TRY(h, hipGetLastError());
-            h->pub_valid = true; h->pub_seq = seq;
-        }
-        int rc = wait_slots(h, 0, 13, seq);
-        if (rc != REKF_OK) return rc;
-        report_flags(h, h->host_slots[12].aux);
-        if (t) *t = h->time;
-        if (mu3) for (int q = 0; q < 3; ++q) mu3[q] = h->host_slots[q].v;
-        if (sigma3x3) for (int q = 0; q < 9; ++q) sigma3x3[q] = h->host_slots[3 + q].v;
-        return REKF_OK;
-    }
-    HIP_TRY(h, hipMemcpyAsync(h->pose_staging, h->dev.mu, sizeof(double) * 3, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpy2DAsync(h->pose_staging + 3, sizeof(double) * 3, h->dev.P, sizeof(double) * h->dev.ld,
-                                sizeof(double) * 3, 3, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->pose_staging + 12, h->dev.ctl, sizeof(int) * 2, hipMemcpyDeviceToHost, h->stream));   // n, err
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
-    report_flags(h, ((const int *)(h->pose_staging + 12))[1]);
+    // the kernels of the last call have published (or are about to publish) the pose they committed; between scans the mirror
+    // simply is the pose -- either way no copy engine and no stream wait
+    int rc = refresh_mirror(h);
+    if (rc != REKF_OK) return rc;
     if (t) *t = h->time;
-    if (mu3) std::memcpy(mu3, h->pose_staging, sizeof(double) * 3);
-    if (sigma3x3) std::memcpy(sigma3x3, h->pose_staging + 3, sizeof(double) * 9);
+    if (mu3) for (int q = 0; q < 3; ++q) mu3[q] = h->mir_mu[q];
+    if (sigma3x3) for (int q = 0; q < 9; ++q) sigma3x3[q] = h->mir_P[q];
     return REKF_OK;
 }
 
@@ -557,7 +712,7 @@ int rekf_get_marker_ellipses(rekf_t *h, double *out5, int cap, int *count)
     if (!h || !count || cap < 0 || (cap > 0 && !out5)) return REKF_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
     const int lim = cap < h->max_landmarks ? cap : h->max_landmarks;
-    rekf_launch_ellipses(h->dev, h->dev_ell, lim, h->stream);
+    rekf_launch_ellipses(h->dev, h->dev_ell, lim, h->stream);       // (landmark blocks and means only: pending predicts do not touch them)
     int rc = pull_ctl(h);                              // synchronises the stream; n is exact afterwards
     if (rc != REKF_OK) return rc;
     const int L = (h->ctl_staging->n - 3) / 2;
@@ -570,16 +725,19 @@ int rekf_get_marker_ellipses(rekf_t *h, double *out5, int cap, int *count)
 int rekf_get_n(rekf_t *h, int *n)
 {
     if (!h || !n) return REKF_ERR_INVALID;
-    int rc = pull_ctl(h);
+    int rc = refresh_mirror(h);                        // n arrives with the pose slots
     if (rc != REKF_OK) return rc;
-    *n = h->ctl_staging->n;
+    if (!h->n_exact) { rc = pull_ctl(h); if (rc != REKF_OK) return rc; }
+    *n = h->n_ub;
     return REKF_OK;
 }
 
 int rekf_get_state(rekf_t *h, double *t, int *n_out, double *mu, long mu_cap, double *sigma, long sigma_cap)
 {
     if (!h) return REKF_ERR_INVALID;
-    int rc = pull_ctl(h);
+    int rc = flush_lazy(h);
+    if (rc != REKF_OK) return rc;
+    rc = pull_ctl(h);
     if (rc != REKF_OK) return rc;
     const int n = h->ctl_staging->n;
     if (t) *t = h->time;
@@ -601,6 +759,9 @@ int rekf_set_state(rekf_t *h, double t, int n, const double *mu, const double *s
 {
     if (!h || !mu || !sigma || n < 3 || n > h->dev.n_max || ((n - 3) & 1)) return REKF_ERR_INVALID;
     h->pub_valid = false;
+    for (auto &r : h->pub_ring) r = {0, 0};                       // an n published before this call says nothing about the new state
+    h->lazy_pending = false; h->lazy_a = 0; h->lazy_b = 0;       // whatever was pending belonged to the state being replaced
+    h->mir_valid = false;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     const int ld = h->dev.ld;
@@ -617,7 +778,12 @@ int rekf_set_state(rekf_t *h, double t, int n, const double *mu, const double *s
     h->n_ub = n;
     h->n_exact = true;
     h->full = n >= h->dev.n_max;
+    h->flags_last = 0;
+    h->last_scan_empty = false;
     if (vt3) { h->vt[0] = vt3[0]; h->vt[1] = vt3[1]; h->vt[2] = vt3[2]; }
+    for (int q = 0; q < 3; ++q) h->mir_mu[q] = mu[q];
+    for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) h->mir_P[i + 3 * j] = sigma[i + (size_t)j * n];
+    h->mir_valid = true;
     return REKF_OK;
 }
 
@@ -627,6 +793,12 @@ int rekf_get_last_match(rekf_t *h, int *n_state, int *state_pairs, int *n_map, i
     if (!h) return REKF_ERR_INVALID;
     int rc = pull_ctl(h);
     if (rc != REKF_OK) return rc;
+    if (h->last_scan_empty) {                          // cc:235-236: the record of an empty scan is empty (kept on the host)
+        if (n_state) *n_state = 0;
+        if (n_map) *n_map = 0;
+        if (n_new) *n_new = 0;
+        return REKF_OK;
+    }
     const RekfCtl *c = h->ctl_staging;
     if (n_state) *n_state = c->n_state;
     if (n_map) *n_map = c->n_map;
@@ -640,15 +812,15 @@ int rekf_get_last_match(rekf_t *h, int *n_state, int *state_pairs, int *n_map, i
 int rekf_sync(rekf_t *h)
 {
     if (!h) return REKF_ERR_INVALID;
-    int flags = 0;
-    int rc = pull_n_flags(h, &flags);
+    int rc = refresh_mirror(h);
     if (rc != REKF_OK) return rc;
     // the published pose can arrive a few microseconds before the last workgroups of k_downdate2 are through: Sync means done
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const int flags = h->flags_last;
     if (flags) {
-        h->pub_valid = false;                          // the slot that carried the flags is stale once they are cleared
         int zero = 0;
         HIP_TRY(h, hipMemcpy(&h->dev.ctl->err, &zero, sizeof(int), hipMemcpyHostToDevice));
+        h->flags_last = 0;
     }
     return device_flags_to_code(flags);
 }
@@ -656,14 +828,21 @@ int rekf_sync(rekf_t *h)
 int rekf_get_flags(rekf_t *h, int *flags)
 {
     if (!h || !flags) return REKF_ERR_INVALID;
-    return pull_n_flags(h, flags);
+    int rc = refresh_mirror(h);
+    if (rc != REKF_OK) return rc;
+    *flags = h->flags_last;
+    return REKF_OK;
 }
 
 int rekf_predict_state_full(rekf_t *h, double t, double *time_out, int *n_out, double *mu, long mu_cap, double *sigma,
                             long sigma_cap)
 {
     if (!h) return REKF_ERR_INVALID;
-    int rc = pull_ctl(h);
+    int rc = refresh_mirror(h);
+    if (rc != REKF_OK) return rc;
+    rc = flush_lazy(h);
+    if (rc != REKF_OK) return rc;
+    rc = pull_ctl(h);
     if (rc != REKF_OK) return rc;
     const int n = h->ctl_staging->n;
     const int ld = h->dev.ld;
@@ -672,23 +851,29 @@ int rekf_predict_state_full(rekf_t *h, double t, double *time_out, int *n_out, d
     if ((mu && mu_cap < n) || (sigma && sigma_cap < (long)n * n)) return REKF_ERR_BUFFER;
     RekfFrontArgs a;
     fill_front_args(h, a, t - h->time);               // cc:100
+    double m3[3], P9[9];                               // pose and pose block: on a copy of the mirror, like rekf_predict_state
+    for (int q = 0; q < 3; ++q) m3[q] = h->mir_mu[q];
+    for (int q = 0; q < 9; ++q) P9[q] = h->mir_P[q];
+    const Motion mo = host_predict(h, a, m3, P9, false);
+    a.host_pred = 1;
+    a.pre_ab[0] = mo.a; a.pre_ab[1] = mo.b;
     rekf_launch_predict_rows(h->dev, a, h->dev_pred, h->stream);
-    std::vector<double> pred(4 * (size_t)ld + 16);
+    std::vector<double> pred(4 * (size_t)ld);
     HIP_TRY(h, hipMemcpyAsync(pred.data(), h->dev_pred, sizeof(double) * pred.size(), hipMemcpyDeviceToHost, h->stream));
     if (mu) HIP_TRY(h, hipMemcpyAsync(mu, h->dev.mu, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
     if (sigma)
         HIP_TRY(h, hipMemcpy2DAsync(sigma, sizeof(double) * n, h->dev.P, sizeof(double) * ld, sizeof(double) * n, n,
                                     hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    // layout of pred: row0[ld] | row1[ld] | col0[ld] | col1[ld] | mu3 | corner 3x3 column-major
-    const double *row0 = pred.data(), *row1 = row0 + ld, *col0 = row1 + ld, *col1 = col0 + ld, *tail = col1 + ld;
-    if (mu) for (int i = 0; i < 3; ++i) mu[i] = tail[i];
+    // layout of pred: row0[ld] | row1[ld] | col0[ld] | col1[ld]
+    const double *row0 = pred.data(), *row1 = row0 + ld, *col0 = row1 + ld, *col1 = col0 + ld;
+    if (mu) for (int i = 0; i < 3; ++i) mu[i] = m3[i];
     if (sigma) {
         for (int c = 3; c < n; ++c) {
             sigma[0 + (size_t)c * n] = row0[c]; sigma[1 + (size_t)c * n] = row1[c];
             sigma[c + (size_t)0 * n] = col0[c]; sigma[c + (size_t)1 * n] = col1[c];
         }
-        for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) sigma[i + (size_t)j * n] = tail[3 + i + 3 * j];
+        for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) sigma[i + (size_t)j * n] = P9[i + 3 * j];
     }
     return REKF_OK;
 }
@@ -743,20 +928,25 @@ void *rekf_stream(rekf_t *h) { return h ? (void *)h->stream : nullptr; }
 int rekf_debug_time_kernel(rekf_t *h, int kernel, int reps, int ablate, double *avg_us)
 {
     if (!h || !avg_us || reps < 1) return REKF_ERR_INVALID;
+    if (kernel != REKF_K_DOWNDATE || ablate != 0) return REKF_ERR_INVALID;      // the only kernel this hook knows; `ablate` is reserved
+    int rc = flush_lazy(h);
+    if (rc != REKF_OK) return rc;
+    rc = pull_ctl(h);                                  // n exact: the launches below carry it
+    if (rc != REKF_OK) return rc;
     h->pub_valid = false;
+    h->mir_valid = false;                              // P is meaningless afterwards
     RekfDev dev = h->dev;
-    dev.dbg = ablate;
+    dev.dbg = 0;
+    dev.pub = nullptr;
+    dev.n_known = h->n_ub;
     HIP_TRY(h, hipSetDevice(h->device));
     hipEvent_t a, b;
     HIP_TRY(h, hipEventCreate(&a));
     HIP_TRY(h, hipEventCreate(&b));
     const int n_ub = h->n_ub;
-    auto launch = [&]() {
-        if (kernel == REKF_K_DOWNDATE) rekf_launch_downdate(dev, n_ub, h->stream);
-    };
-    for (int i = 0; i < 3; ++i) launch();
+    for (int i = 0; i < 3; ++i) rekf_launch_downdate(dev, n_ub, h->stream);
     HIP_TRY(h, hipEventRecord(a, h->stream));
-    for (int i = 0; i < reps; ++i) launch();
+    for (int i = 0; i < reps; ++i) rekf_launch_downdate(dev, n_ub, h->stream);
     HIP_TRY(h, hipEventRecord(b, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     float ms = 0.f;
@@ -782,7 +972,7 @@ int rekf_device_layout(rekf_t *h, int *ld, int *n_max, void **P_dev, void **mu_d
     if (ld) *ld = h->dev.ld;
     if (n_max) *n_max = h->dev.n_max;
     if (P_dev) *P_dev = h->dev.P;
-    if (mu_dev) *mu_dev = h->dev.mu;
+    if (mu_dev) *mu_dev = h->dev.mu;       // (double-buffered: k_mid alternates between two buffers, this is the current one)
     return REKF_OK;
 }
 

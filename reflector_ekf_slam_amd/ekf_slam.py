@@ -141,7 +141,7 @@ def save_map_txt(path: str, state: State, loaded: Map | None = None, reference_b
 class ReflectorEKFSLAM:
     """ekf::ReflectorEKFSLAM (reflector_ekf_slam.h:13-64) on one MI355X."""
 
-    def __init__(self, options: EKFOptions, max_landmarks: int = 1024, device: int = 0):
+    def __init__(self, options: EKFOptions, max_landmarks: int = 1024, device: int = 0, auto_grow: bool = False):
         self._L = _lib.rekf()
         self.options = options
         o = _lib.RekfOptions()
@@ -158,7 +158,9 @@ class ReflectorEKFSLAM:
         if rc != 0:
             raise RekfError(rc, "rekf_create")
         self._h = h
-        self.max_landmarks = int(max_landmarks)
+        self._cap0 = int(max_landmarks)
+        if auto_grow:
+            self.set_auto_grow(True)
         self._map = load_map_txt(options.map_path)          # cc:36
         if self._map.reflector_map_.shape[0] > 0:
             self.SetGlobalMap(self._map)
@@ -178,6 +180,21 @@ class ReflectorEKFSLAM:
     def _chk(self, rc, where):
         if rc != 0:
             raise RekfError(rc, where, self._L.rekf_last_hip_error(self._h).decode())
+
+    # -- capacity (the reference grows mu / sigma on every augment, cc:316-363) ----
+    @property
+    def max_landmarks(self) -> int:
+        c = C.c_int()
+        self._chk(self._L.rekf_get_capacity(self._h, C.byref(c)), "get_capacity")
+        return c.value
+
+    def reserve(self, max_landmarks: int):
+        """Re-lay the device state out for at least ``max_landmarks`` reflectors (no-op if there is room already)."""
+        self._chk(self._L.rekf_reserve(self._h, int(max_landmarks)), "reserve")
+
+    def set_auto_grow(self, on: bool = True):
+        """Double the capacity whenever a scan could overflow it, instead of dropping reflectors (sticky capacity flag)."""
+        self._chk(self._L.rekf_set_auto_grow(self._h, 1 if on else 0), "set_auto_grow")
 
     # -- reference interface --------------------------------------------------
     def HandleOdometryMessage(self, odometry: OdometryData):
@@ -356,7 +373,6 @@ class ReflectorEKFSLAM:
         """Average device time (us) of `reps` back-to-back launches of one kernel of the chain between ONE
         pair of hipEvents on the handle's stream (rekf_debug_time_kernel).  Leaves the state meaningless."""
         us = C.c_double()
-        self._L.rekf_debug_time_kernel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
         self._chk(self._L.rekf_debug_time_kernel(self._h, KERNELS[name], int(reps), int(ablate), C.byref(us)),
                   "rekf_debug_time_kernel")
         return us.value

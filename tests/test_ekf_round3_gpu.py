@@ -1,0 +1,334 @@
+"""GPU suite, round 3 additions (through the C ABI, against the CPU oracle):
+  * rekf_reserve / auto-grow: a filter that starts at 64 landmarks of capacity and meets 150 never drops one (the reference grows
+    without bound, reflector_ekf_slam.cc:311-364);
+  * the host pose mirror: HandleOdometryMessage launches nothing, GetPose / PredictState between odometry messages are exact,
+    and a session gives the same answers whether the pose is read back after every scan (host-predicted front kernel) or
+    never (device-predicted front kernel);
+  * headings at the +-pi wrap with observations on the 0.6 m association gate (the device-predicted front kernel takes cos / sin of
+    the unwrapped heading: DESIGN.md section 3 "Deliberate deviations");
+  * C3 at full size: 500 consecutive steady-state updates and checkpoints during the map build against the structured oracle.
+Tolerances as in test_ekf_gpu.py: association lists identical, |mu - oracle| < 1e-9 (north star: 1e-5 m)."""
+import math
+
+import numpy as np
+import pytest
+
+from reflector_ekf_slam_amd import synth
+from tests.helpers import drive_pair, make_gpu, make_oracle, norm_match
+
+pytestmark = pytest.mark.gpu
+TIGHT = 1e-9
+
+
+def _same_match(g, o):
+    a, b = norm_match(g.last_match()), norm_match(o.last_match())
+    return all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+# ---------------------------------------------------------------------------------------------- grow on demand
+def _grow_session():
+    cfg = synth.SessionConfig("grow150", 150, 14, synth.DIFF, seed=333, speed=1.5, row_spacing=6.0)
+    return cfg, synth.make_session(cfg)
+
+
+def test_auto_grow_from_64_to_150_reflectors_never_drops_one(oracle_lib):
+    cfg, sess = _grow_session()
+    lin, ang, obs = cfg.sigma_v ** 2, cfg.sigma_w ** 2, cfg.sigma_obs ** 2
+    g = make_gpu(cfg.odom_model, sess.init_time, sess.init_pose, lin, ang, obs, 64)
+    g.set_auto_grow(True)
+    o = make_oracle(cfg.odom_model, sess.init_time, sess.init_pose, lin, ang, obs)
+    caps = {g.max_landmarks}
+    worst = [0.0]
+
+    def chk(e, k):
+        assert _same_match(g, o), f"association differs at scan {k}"
+        caps.add(g.max_landmarks)
+        if k % 7 == 0:
+            mg, mo = g.mu(), o.mu()
+            assert mg.shape == mo.shape
+            worst[0] = max(worst[0], float(np.abs(mg - mo).max()))
+
+    drive_pair(sess, g, o, chk)
+    assert g.n == o.n == 3 + 2 * 150
+    assert g.flags() == 0 and g.sync_code() == 0            # REKF_FLAGBIT_CAPACITY never fired
+    assert max(caps) >= 150 and len(caps) >= 2              # the capacity really was extended on the way (64 -> 128 -> 256)
+    st = g.GetState()
+    mo, Po = o.state()
+    assert worst[0] < TIGHT and np.abs(st.mu - mo).max() < TIGHT
+    assert np.abs(st.sigma - Po).max() < 1e-11
+    assert np.array_equal(st.sigma, st.sigma.T)
+
+
+def test_explicit_reserve_keeps_the_state_bit_for_bit(oracle_lib):
+    cfg = synth.SessionConfig("resv", 40, 10, synth.OMNI, seed=77, speed=1.0, row_spacing=6.0)
+    sess = synth.make_session(cfg, max_scans=80)
+    lin, ang, obs = cfg.sigma_v ** 2, cfg.sigma_w ** 2, cfg.sigma_obs ** 2
+    g = make_gpu(cfg.odom_model, sess.init_time, sess.init_pose, lin, ang, obs, 40)
+    o = make_oracle(cfg.odom_model, sess.init_time, sess.init_pose, lin, ang, obs)
+    half = sess.n_events // 2
+    drive_pair(sess, g, o, max_events=half)
+    before = g.GetState()
+    g.handle_odometry(before.time + 0.01, 0.3, 0.0, 0.1)     # a predict pending on the host mirror when the layout changes
+    o.handle_odometry(before.time + 0.01, 0.3, 0.0, 0.1)
+    g.reserve(1000)                                          # ld 128 -> 2048
+    assert g.max_landmarks == 1000
+    g.reserve(10)                                            # never shrinks
+    assert g.max_landmarks == 1000
+    after = g.GetState()
+    mo, Po = o.state()
+    assert after.mu.shape == before.mu.shape
+    assert np.abs(after.mu - mo).max() < TIGHT and np.abs(after.sigma - Po).max() < 1e-12
+    assert np.array_equal(after.mu[3:], before.mu[3:])       # landmarks untouched by the predict and by the re-layout
+    # ... and the filter continues from the new layout
+    first = [False]
+    for e in range(half, sess.n_events):
+        t = sess.ev_time[e]
+        if sess.ev_type[e] == synth.EV_ODOM:
+            if t < g.GetLatestTime():
+                continue
+            g.handle_odometry(t, *sess.odom[e]); o.handle_odometry(t, *sess.odom[e])
+        else:
+            ob = sess.obs_of(e)
+            g.handle_observation(t, ob); o.handle_observation(t, ob)
+            assert _same_match(g, o)
+    st = g.GetState()
+    mo, Po = o.state()
+    assert np.abs(st.mu - mo).max() < TIGHT and np.abs(st.sigma - Po).max() < 1e-11 and g.sync_code() == 0
+
+
+def test_reserve_rejects_sizes_the_kernels_cannot_address():
+    from reflector_ekf_slam_amd import RekfError
+    g = make_gpu(0, 0.0, np.zeros(3), 0.0025, 0.0064, 0.0025, 8)
+    with pytest.raises(RekfError) as e:
+        g.reserve(20000)                                     # ld^2 * 8 bytes >= 4 GiB: 32-bit byte offsets
+    assert e.value.code == -7
+    assert g.max_landmarks == 8 and g.n == 3
+
+
+# ---------------------------------------------------------------------------------------------- the host pose mirror
+def test_pose_between_odometry_messages_is_exact_and_costs_no_launch(oracle_lib):
+    """src/ros_node.cc:627-660: HandleOdometryMessage -> GetState at odometry rate.  The pose comes from the host mirror
+    (glibc, the oracle's libm): equal to the oracle's to the last bit for the mean, and no kernel is launched for it."""
+    cfg = synth.SessionConfig("odo_pose", 24, 8, synth.DIFF, seed=9, speed=1.0, row_spacing=6.0, scan_hz=2.0)
+    sess = synth.make_session(cfg, max_scans=30)
+    lin, ang, obs = cfg.sigma_v ** 2, cfg.sigma_w ** 2, cfg.sigma_obs ** 2
+    g = make_gpu(cfg.odom_model, sess.init_time, sess.init_pose, lin, ang, obs, cfg.n_landmarks)
+    o = make_oracle(cfg.odom_model, sess.init_time, sess.init_pose, lin, ang, obs)
+    first = True
+    n_odo = 0
+    for e in range(sess.n_events):
+        t = sess.ev_time[e]
+        if sess.ev_type[e] == synth.EV_ODOM:
+            g.handle_odometry(t, *sess.odom[e]); o.handle_odometry(t, *sess.odom[e])
+            tg, mu3, s3 = g.pose()
+            mo, Po = o.state()
+            assert tg == t
+            assert np.abs(mu3 - mo[:3]).max() < 1e-12 and np.abs(s3 - Po[:3, :3]).max() < 1e-13
+            pp = g.PredictPose(t + 0.02)
+            mp, Pp = o.predict_state(t + 0.02, full=True)
+            assert np.abs(pp.mu - mp[:3]).max() < 1e-12 and np.abs(pp.sigma - Pp[:3, :3]).max() < 1e-13
+            n_odo += 1
+        else:
+            if first:
+                first = False
+                continue
+            g.handle_observation(t, sess.obs_of(e)); o.handle_observation(t, sess.obs_of(e))
+            assert _same_match(g, o)
+    assert n_odo > 100
+    st = g.GetState()
+    mo, Po = o.state()
+    assert np.abs(st.mu - mo).max() < TIGHT and np.abs(st.sigma - Po).max() < 1e-11 and g.sync_code() == 0
+
+
+@pytest.mark.parametrize("model", [synth.DIFF, synth.OMNI], ids=["diff", "omni"])
+def test_same_session_with_and_without_pose_readbacks(oracle_lib, model):
+    """Two front-kernel paths: with the pose read back after every scan the host predicts (pose, cos / sin of the wrapped
+    heading and the pose block travel in the launch packet); scans enqueued back to back are predicted on the device.  Both must
+    follow the oracle; odometry-free stretches (scan after scan) and several odometry messages per scan are in the mix."""
+    cfg = synth.SessionConfig("paths", 60, 12, model, seed=515, speed=1.2, row_spacing=6.0)
+    sess = synth.make_session(cfg, max_scans=160)
+    lin, ang, obs = cfg.sigma_v ** 2, cfg.sigma_w ** 2, cfg.sigma_obs ** 2
+    ga = make_gpu(model, sess.init_time, sess.init_pose, lin, ang, obs, cfg.n_landmarks)     # reads the pose after every call
+    gb = make_gpu(model, sess.init_time, sess.init_pose, lin, ang, obs, cfg.n_landmarks)     # never reads anything back on the way
+    o = make_oracle(model, sess.init_time, sess.init_pose, lin, ang, obs)
+    rng = np.random.default_rng(1)
+    first = True
+    k = 0
+    for e in range(sess.n_events):
+        t = sess.ev_time[e]
+        if sess.ev_type[e] == synth.EV_ODOM:
+            if rng.random() < 0.35:
+                continue                                     # thin the odometry out: some scans follow each other directly
+            for f in (ga, gb, o):
+                f.handle_odometry(t, *sess.odom[e])
+            ga.pose()
+            continue
+        if first:
+            first = False
+            continue
+        ob = sess.obs_of(e)
+        for f in (ga, gb, o):
+            f.handle_observation(t, ob)
+        ga.pose()
+        k += 1
+        if k % 3 == 0:
+            assert _same_match(ga, o), f"scan {k}"
+            assert np.abs(ga.mu() - o.mu()).max() < TIGHT
+    assert _same_match(gb, o)
+    sa, sb = ga.GetState(), gb.GetState()
+    mo, Po = o.state()
+    assert sa.mu.shape == sb.mu.shape == mo.shape
+    assert np.abs(sa.mu - mo).max() < TIGHT and np.abs(sb.mu - mo).max() < TIGHT
+    assert np.abs(sa.sigma - Po).max() < 1e-11 and np.abs(sb.sigma - Po).max() < 1e-11
+    assert ga.sync_code() == 0 and gb.sync_code() == 0
+
+
+# ---------------------------------------------------------------------------------------------- +-pi wrap x association gate
+def _ulp_step(x, k):
+    x = np.float32(x)
+    for _ in range(abs(k)):
+        x = np.nextafter(x, np.float32(np.inf if k > 0 else -np.inf), dtype=np.float32)
+    return x
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_heading_at_the_wrap_and_observations_on_the_gate(oracle_lib, seed):
+    """Headings within 1e-3 of +-pi whose predicted value crosses the wrap (|theta + w dt| > pi), observations whose global
+    point lies on the 0.6 m state gate +- a few float32 ulps (cc:446), and a far observation that must start a new landmark.
+    Scan 1 is host-predicted (set_state leaves the mirror current), scans 2.. are device-predicted (cos / sin of the unwrapped
+    angle); times go backwards once (Q8) so that the wrap is crossed in both directions."""
+    rng = np.random.default_rng(1000 + seed)
+    L = 24
+    sign = 1.0 if seed % 2 == 0 else -1.0
+    theta0 = sign * (math.pi - float(rng.uniform(0.0, 1e-3)))
+    pose = np.array([float(rng.uniform(-2, 2)), float(rng.uniform(-2, 2)), theta0])
+    lm = np.array([(3.0 * (k % 6) - 7.0, 3.0 * (k // 6) - 4.0) for k in range(L)], dtype=np.float64) + rng.uniform(-0.3, 0.3, (L, 2))
+    lm = lm.astype(np.float32).astype(np.float64)            # landmark means are float32-valued in a real state (Q4)
+    n = 3 + 2 * L
+    mu = np.concatenate([pose, lm.ravel()])
+    A = rng.normal(size=(n, 12))
+    P = (A @ A.T) * 1e-6 + np.diag(rng.uniform(1e-5, 4e-5, n))
+    P = 0.5 * (P + P.T)
+    w = sign * 0.4                                           # turning INTO the wrap
+    vt = (0.5, 0.0, w)
+    g = make_gpu(0, 0.0, pose, 0.0025, 0.0064, 0.0025, L + 8)
+    o = make_oracle(0, 0.0, pose, 0.0025, 0.0064, 0.0025)
+    g.set_state(1.0, mu, P, vt)
+    o.set_state(1.0, mu, P, vt)
+    times = [1.01, 1.02, 1.0, 1.03, 1.012]                   # dt = +0.01, +0.01, -0.02 (Q8), +0.03, -0.018
+    crossed = 0
+    for t in times:
+        # the pose both filters will predict (oracle's own PredictState): build the observations against it
+        mp, _ = o.predict_state(t)
+        th_unwrapped = o.mu()[2] + w * (t - o.time)
+        crossed += abs(th_unwrapped) > math.pi
+        c, s_ = math.cos(mp[2]), math.sin(mp[2])
+        ids = rng.choice(L, size=10, replace=False)
+        obs = []
+        for q, j in enumerate(ids):
+            lmj = o.mu()[3 + 2 * j: 5 + 2 * j]
+            if q < 7:                                        # on the gate: 0.6 m from landmark j, in a random direction
+                phi = float(rng.uniform(-math.pi, math.pi))
+                tgt = lmj + 0.6 * np.array([math.cos(phi), math.sin(phi)])
+            else:                                            # a comfortable match
+                tgt = lmj + rng.normal(0, 0.02, 2)
+            rel = tgt - mp[:2]
+            p = np.array([rel[0] * c + rel[1] * s_, -rel[0] * s_ + rel[1] * c])
+            pf = p.astype(np.float32)
+            if q < 7:                                        # +- a few float32 ulps around the gate
+                pf[0] = _ulp_step(pf[0], int(rng.integers(-3, 4)))
+                pf[1] = _ulp_step(pf[1], int(rng.integers(-3, 4)))
+            obs.append(pf)
+        obs = np.stack(obs).astype(np.float32)
+        g.handle_observation(t, obs)
+        o.handle_observation(t, obs)
+        assert _same_match(g, o), f"seed {seed}, t = {t}"
+        mg, mo = g.mu(), o.mu()
+        assert mg.shape == mo.shape and np.abs(mg - mo).max() < TIGHT
+        assert -math.pi <= mg[2] <= math.pi
+        if g.n >= 3 + 2 * (L + 8) - 14:
+            break
+    assert crossed >= 1
+    assert g.sync_code() in (0, -4)
+
+
+# ---------------------------------------------------------------------------------------------- C3 at full size
+def test_c3_500_steady_state_updates_match_the_structured_oracle(oracle_lib):
+    """BASELINE.json configs[2] at full size: 500 consecutive steady-state updates (k_front_mb device-predicted, k_mid<4>,
+    k_downdate2<64> on all tile classes) against the oracle from the same state -- associations every scan, the mean every 25."""
+    from reflector_ekf_slam_amd import session as S
+    cfg = synth.C3
+    sess = synth.make_session(cfg)
+    g = make_gpu(cfg.odom_model, sess.init_time, sess.init_pose, cfg.sigma_v ** 2, cfg.sigma_w ** 2, cfg.sigma_obs ** 2,
+                 cfg.n_landmarks)
+    S.replay(sess, g)
+    st = g.GetState()
+    assert st.mu.shape[0] == 3 + 2 * cfg.n_landmarks
+    o = make_oracle(cfg.odom_model, sess.init_time, sess.init_pose, cfg.sigma_v ** 2, cfg.sigma_w ** 2, cfg.sigma_obs ** 2)
+    vt = sess.odom[np.nonzero(sess.ev_type == synth.EV_ODOM)[0][-1]]
+    o.set_state(st.time, st.mu, st.sigma, vt)
+    worst = 0.0
+    for k, (t, ob) in enumerate(synth.steady_state_scans(sess, 500)):
+        g.handle_observation(t, ob)
+        o.handle_observation(t, ob)
+        if k % 25 == 24 or k < 3:
+            assert _same_match(g, o), f"association differs at update {k}"
+            worst = max(worst, float(np.abs(g.mu() - o.mu()).max()))
+    assert _same_match(g, o)
+    assert worst < TIGHT
+    st2 = g.GetState()
+    mo, Po = o.state()
+    assert np.abs(st2.mu - mo).max() < TIGHT and np.abs(st2.sigma - Po).max() < 1e-12
+    assert np.array_equal(st2.sigma, st2.sigma.T) and g.sync_code() == 0
+
+
+def test_c3_map_build_checkpoints_match_the_oracle(oracle_lib):
+    """The 5.3 k-scan map build of C3 (1024 augment steps, n growing 3 -> 2051): at four points of the build the oracle is
+    restarted from the GPU's state and both run the next 40 scans (odometry, match, update, AUGMENT) in lock-step."""
+    cfg = synth.C3
+    sess = synth.make_session(cfg)
+    lin, ang, obs = cfg.sigma_v ** 2, cfg.sigma_w ** 2, cfg.sigma_obs ** 2
+    g = make_gpu(cfg.odom_model, sess.init_time, sess.init_pose, lin, ang, obs, cfg.n_landmarks)
+    scan_events = np.nonzero(sess.ev_type != synth.EV_ODOM)[0]
+    n_scans = scan_events.size
+    starts = [int(n_scans * f) for f in (0.1, 0.35, 0.6, 0.85)]
+    span = 40
+    o = None
+    o_until = -1
+    first = True
+    scans = 0
+    grew = 0
+    last_vt = np.zeros(3)
+    for e in range(sess.n_events):
+        t = sess.ev_time[e]
+        if sess.ev_type[e] == synth.EV_ODOM:
+            g.handle_odometry(t, *sess.odom[e])
+            last_vt = sess.odom[e]
+            if o is not None:
+                o.handle_odometry(t, *sess.odom[e])
+            continue
+        if first:
+            first = False
+            continue
+        if scans in starts:
+            st = g.GetState()
+            o = make_oracle(cfg.odom_model, sess.init_time, sess.init_pose, lin, ang, obs)
+            o.set_state(st.time, st.mu, st.sigma, last_vt)
+            o_until = scans + span
+            n0 = st.mu.shape[0]
+        ob = sess.obs_of(e)
+        g.handle_observation(t, ob)
+        scans += 1
+        if o is not None:
+            o.handle_observation(t, ob)
+            assert _same_match(g, o), f"association differs at scan {scans}"
+            if scans == o_until:
+                st = g.GetState()
+                mo, Po = o.state()
+                assert st.mu.shape == mo.shape
+                grew += st.mu.shape[0] - n0
+                assert np.abs(st.mu - mo).max() < TIGHT and np.abs(st.sigma - Po).max() < 1e-12
+                assert np.array_equal(st.sigma, st.sigma.T)
+                o = None
+    assert grew > 0                                          # the windows did include augment steps
+    assert g.n == 3 + 2 * cfg.n_landmarks and g.sync_code() == 0
