@@ -19,11 +19,19 @@ all-gather of a 64-byte result record per rank (reflector_ekf_slam_amd/dist.py).
 Rank 0 prints ONE JSON line.
 
 Extra objects on that line (rank 0, N = 1 unless noted):
-  roofline       the P -= K (H P) kernel (k_downdate2): algorithmic bytes per launch
-                 (16 n^2 + 8 n (3+m)) / its average launch time,
-                 measured live with hipEvents on the handle's stream.  `traffic` is
-                 NOT measured in this run: it is read from the committed rocprofv3
-                 PMC summary and labelled with its source file.
+  roofline       the P -= K (H P) kernel (k_downdate2), average launch time measured live
+                 with hipEvents on the handle's stream.  The kernel computes the LOWER
+                 TRIANGLE and mirrors it, so ("scale both FLOP and BYTES by the
+                 executed tile fraction") `achieved` / `frac` count the bytes that algorithm
+                 must move -- lower triangle read, all of P written, the two panels -- and
+                 `mfma.frac` the MFMA FLOP actually executed; the full-square SURVEY figure
+                 (16 n^2 + 8 n (3+m)) is kept as `frac_fullsquare`, the PMC-measured bytes as
+                 `frac_moved`.  `traffic` is NOT measured in this run: it is read from the
+                 committed rocprofv3 PMC summary and labelled with its source file.
+  not_full       the same steady state on a filter created with max_landmarks = 2 L (the
+                 state a deployed node is in: capacity is a cap, not the map size):
+                 k_augment is launched behind every chain and publishes, n is not known
+                 to the host while it runs ahead of the device.
   latency_us     median / p99 of one update: hipEvent pair around each whole chain
                  (device) and host wall time of HandleObservationMessage + GetPose.
   with_5_predicts_per_scan   the same scans with five HandleOdometryMessage
@@ -108,10 +116,10 @@ def respawn_under_torchrun(args):
 # ---------------------------------------------------------------------------------------------------
 # the part every rank runs (also driven by tests/test_host_cpu.py with a CPU stub filter over gloo)
 # ---------------------------------------------------------------------------------------------------
-def gpu_filter_factory(cfg, sess, device):
+def gpu_filter_factory(cfg, sess, device, capacity=None):
     from reflector_ekf_slam_amd import ReflectorEKFSLAM
     from reflector_ekf_slam_amd import session as S
-    return ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks, device=device)
+    return ReflectorEKFSLAM(S.options_for(sess), max_landmarks=capacity or cfg.n_landmarks, device=device)
 
 
 def build_session(cfg_name, rank, world):
@@ -279,16 +287,15 @@ def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world):
     k5 = max(args.steps, 200)
     out["with_5_predicts_per_scan"], used = predict_leg(ekf, cfg, rest[pos:], k5)
     pos += used
-    # odometry path alone (k_front): back-to-back predicts
-    ekf.profile_reset()
-    ekf.profile(True, only=["predict"])
+    # odometry path alone: HandleOdometryMessage + GetPose at odometry rate (src/ros_node.cc:627-660) -- no launch, host mirror
+    ekf.pose()
     tp = ekf.GetLatestTime()
-    for j in range(200):
-        ekf.handle_odometry(tp + 1e-5 * (j + 1), 0.01, 0.0, 0.01)
-    ekf.handle_odometry(tp + 1e-5 * 200, 0.0, 0.0, 0.0)
-    ekf.profile(False)
-    pr = ekf.profile_read()["predict"]
-    ekf.profile_reset()
+    t0 = time.perf_counter()
+    for j in range(2000):
+        ekf.handle_odometry(tp + 1e-6 * (j + 1), 0.01, 0.0, 0.01)
+        ekf.pose()
+    odo_us = 1e6 * (time.perf_counter() - t0) / 2000
+    ekf.handle_odometry(tp + 1e-6 * 2001, 0.0, 0.0, 0.0)
 
     ms_result = multi_session(args, cfg, sess, device) if (world == 1 and args.multi_sessions > 1) else None
 
@@ -296,7 +303,7 @@ def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world):
     if not args.no_cpu_baseline:
         state_for_cpu = ekf.GetState()
     kernel_us = per_kernel_leg(ekf, rest[pos:], args.instr_steps)
-    kernel_us["predict"] = round(pr[0] / pr[1], 3) if pr[1] else None
+    kernel_us["odometry_message_plus_get_pose_host_us"] = round(odo_us, 3)     # no kernel: Predict runs on the host's pose mirror
     pos += args.instr_steps
     # The roofline kernel once more, without per-launch brackets: back-to-back launches between ONE pair of
     # hipEvents on the handle's stream (operands = what the last scan left in HBM).  A bracket around every
@@ -305,9 +312,15 @@ def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world):
     # nothing below uses this handle again.
     dd_us = ekf.time_kernel("downdate", reps=max(args.steps, 200))
 
-    bytes_alg = 16.0 * n * n + 8.0 * n * (3 + m)          # SURVEY.md 8(d) BYTES_alg(n, m)
-    flop_k7 = 2.0 * n * n * m
-    achieved = bytes_alg / (dd_us * 1e-6) / 1e9
+    bytes_full = 16.0 * n * n + 8.0 * n * (3 + m)         # SURVEY.md 8(d) BYTES_alg(n, m): every element of P read and written once
+    # what the EXECUTED algorithm must move (SURVEY 8(d) for a lower-triangular builder): lower triangle read, all of P
+    # written (the mirror image is part of the product's layout), the panels once
+    bytes_exec = 8.0 * (n * (n + 1) / 2.0) + 8.0 * n * n + 8.0 * n * (3 + m)
+    T = n // 64 if 0 < n % 64 <= 4 else -(-n // 64)
+    tiles_exec = T * (T + 1) // 2
+    flop_exec = tiles_exec * 2.0 * 64 * 64 * (16 * -(-m // 16))          # MFMA FLOP actually issued (16x16x4 tiles over the padded k range)
+    flop_k7 = 2.0 * n * n * m                              # the reference's full-square count
+    achieved = bytes_exec / (dd_us * 1e-6) / 1e9
     rocprof_us, traffic, traffic_src, rocprof_src = None, None, None, None
     try:
         avg = json.load(open(os.path.join(ROOT, "profiles", "kernel_avg_us.json")))
@@ -322,23 +335,33 @@ def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world):
                        "committed summary; NOT measured in this run")
     except Exception:
         pass
+    moved = (traffic / (dd_us * 1e-6) / 1e9) if traffic else None
     out["roofline"] = {
-        "kernel": "k_downdate2<64, SYM> (P -= K (H P): lower-triangle tiles by FP64 MFMA 16x16x4, mirrored stores)", "bound": "hbm",
-        "bytes_note": "algorithmic bytes = SURVEY 8(d): every element of P read and written once, + the panels; the kernel itself reads "
-                      "only the lower triangle (the update is symmetric), so its measured traffic is below this figure",
+        "kernel": "k_downdate2<64> (P -= K (H P): lower-triangle tiles by FP64 MFMA 16x16x4, mirrored stores)", "bound": "hbm",
+        "bytes_note": "achieved / frac = bytes the executed (lower-triangle + mirror) algorithm must move: 8 n(n+1)/2 read + 8 n^2 written "
+                      "+ 8 n (3+m) panels; frac_fullsquare = SURVEY 8(d)'s 16 n^2 + 8 n (3+m) over the same time (what a full-square "
+                      "kernel would have had to move); frac_moved = HBM bytes by PMC counters (committed summary) over the same time",
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "frac_fullsquare": bytes_full / (dd_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+        "frac_moved": (moved / HBM_PEAK_GBS) if moved else None,
         "traffic": traffic, "traffic_source": traffic_src,
-        "bytes_per_launch": bytes_alg, "avg_launch_us": dd_us,
+        "bytes_per_launch": bytes_exec, "bytes_per_launch_fullsquare": bytes_full, "avg_launch_us": dd_us,
         "avg_launch_us_method": "measured in this run: back-to-back launches between one hipEvent pair on the handle's stream",
         "per_launch_bracket_us": kernel_us.get("downdate"), "empty_event_bracket_us": kernel_us.get("empty"),
         "rocprof_avg_launch_us": rocprof_us, "rocprof_source": rocprof_src,
-        "mfma": {"achieved_tflops": flop_k7 / (dd_us * 1e-6) / 1e12, "peak_tflops": FP64_MFMA_PEAK_TF,
-                 "frac": flop_k7 / (dd_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF,
-                 "note": "algorithmic 2 n^2 m FLOP over the measured time; the mirrored kernel EXECUTES about half of them "
-                         "(lower-triangle tiles: SQ_VALU_MFMA_BUSY_CYCLES 8.65 M vs 16.78 M for the full square, profiles/r02x_pmc_mfma.txt)"}}
+        "mfma": {"achieved_tflops": flop_exec / (dd_us * 1e-6) / 1e12, "peak_tflops": FP64_MFMA_PEAK_TF,
+                 "frac": flop_exec / (dd_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF,
+                 "frac_fullsquare_flop": flop_k7 / (dd_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF,
+                 "note": f"frac = EXECUTED MFMA FLOP ({tiles_exec} lower-triangle tiles x 2*64*64*{16 * -(-m // 16)}) over the measured time; "
+                         "frac_fullsquare_flop = the reference's 2 n^2 m over the same time (the mirrored kernel executes half of them)"}}
     out["kernel_us"] = kernel_us
     if ms_result is not None:
         out["multi_session"] = ms_result
+    if world == 1:
+        try:
+            out["not_full"] = not_full_leg(args, base, cfg, sess, device, out_value=None)
+        except Exception as e:                 # a secondary figure must never take the headline down
+            out["not_full"] = {"error": repr(e)}
     if world == 1 and args.secondary:
         sec = {}
         for name in [s for s in args.secondary.split(",") if s and s != args.config]:
@@ -350,6 +373,34 @@ def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world):
     if not args.no_cpu_baseline:
         out["cpu_baseline"], out["pose_rmse_vs_oracle_m"] = cpu_baseline(args, cfg, sess, state_for_cpu, device)
     return out
+
+
+def not_full_leg(args, base, cfg, sess, device, out_value=None):
+    """The same steady state on a filter whose capacity is a CAP (max_landmarks = 2 L), not the map size: what a deployed
+    node runs all session long (src/ros_node.cc:440 constructs once, landmarks keep arriving).  k_augment is launched
+    behind every chain (and publishes the pose), and while the host runs ahead of the device it does not know n."""
+    from reflector_ekf_slam_amd import session as S
+    from reflector_ekf_slam_amd import synth
+    ekf = gpu_filter_factory(cfg, sess, device, capacity=2 * cfg.n_landmarks)
+    S.replay(sess, ekf)
+    ekf.sync()
+    assert ekf.n == 3 + 2 * cfg.n_landmarks
+    steps = max(args.steps, 500)
+    scans = synth.steady_state_scans(sess, 100 + 2 * steps + 300, seed_offset=3000)
+    elapsed, used = timed_region(ekf, scans, 100, steps, None, lambda: None)
+    res = {"value": steps / elapsed, "unit": "updates/s", "us_per_update": 1e6 * elapsed / steps, "steps": steps,
+           "max_landmarks": 2 * cfg.n_landmarks, "n": ekf.n,
+           "note": "capacity 2 L: k_front_mb -> k_mid -> k_downdate2 -> k_augment (early-out, publishes) per update"}
+    # ... and as the reference's node drives it: the pose read back after every scan (the host then knows n exactly and predicts itself)
+    t0 = time.perf_counter()
+    for t, ob in scans[used:used + steps]:
+        ekf.handle_observation(t, ob)
+        ekf.pose()
+    dt = time.perf_counter() - t0
+    res["with_pose_readback"] = {"value": steps / dt, "unit": "updates/s", "us_per_update": 1e6 * dt / steps}
+    res["kernel_us"] = per_kernel_leg(ekf, scans[used + steps:], 300)
+    ekf.close()
+    return res
 
 
 def secondary_config(args, name, device):

@@ -33,6 +33,10 @@ def _check_contract(d, steps, warmup):
         assert k in r
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.1 < r["frac"] < 1.0
     assert r["traffic"] is None or "NOT measured in this run" in r["traffic_source"]
+    # honest accounting: frac counts what the lower-triangle algorithm must move; the full-square figure rides along
+    assert r["frac_fullsquare"] > r["frac"] and r["bytes_per_launch"] < r["bytes_per_launch_fullsquare"]
+    assert r["frac_moved"] is None or 0.05 < r["frac_moved"] < 1.0
+    assert r["mfma"]["frac"] < r["mfma"]["frac_fullsquare_flop"] and 0.02 < r["mfma"]["frac"] < 1.0
     assert d["value"] > 5000                                                   # the north-star bar is 10 k; 20-step runs are noisy
 
 
@@ -53,7 +57,12 @@ def test_driver_command_steps20_warmup5_has_every_object():
         assert lat[leg]["n"] == 1000 and 5.0 < lat[leg]["median"] <= lat[leg]["p99"] < 5000.0
     p5 = d["with_5_predicts_per_scan"]
     assert p5["predicts_per_scan"] == 5 and 1000 < p5["value"] < d["value"] * 1.2
-    assert d["kernel_us"]["predict"] is not None and d["kernel_us"]["downdate"] > 1.0
+    assert d["kernel_us"]["downdate"] > 1.0
+    assert 0.05 < d["kernel_us"]["odometry_message_plus_get_pose_host_us"] < 50.0     # no launch: host pose mirror
+    nf = d["not_full"]
+    assert "error" not in nf, nf
+    assert nf["max_landmarks"] == 2048 and nf["n"] == 2051 and nf["value"] > 5000 and nf["with_pose_readback"]["value"] > 3000
+    assert nf["kernel_us"]["augment"] is not None
     assert d["multi_session"]["sessions_bit_identical"] is True
     sec = d["secondary"]
     assert set(sec) == {"C2", "C4"} and all("error" not in v for v in sec.values()), sec
