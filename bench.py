@@ -390,7 +390,7 @@ def not_full_leg(args, base, cfg, sess, device, out_value=None):
     elapsed, used = timed_region(ekf, scans, 100, steps, None, lambda: None)
     res = {"value": steps / elapsed, "unit": "updates/s", "us_per_update": 1e6 * elapsed / steps, "steps": steps,
            "max_landmarks": 2 * cfg.n_landmarks, "n": ekf.n,
-           "note": "capacity 2 L: k_front_mb -> k_mid -> k_downdate2 -> k_augment (early-out, publishes) per update"}
+           "note": "capacity 2 L: k_front_mb -> k_mid -> k_downdate2 -> k_augment (early-out) per update; the last k_downdate2 publishes pose and the post-augment n"}
     # ... and as the reference's node drives it: the pose read back after every scan (the host then knows n exactly and predicts itself)
     t0 = time.perf_counter()
     for t, ob in scans[used:used + steps]:

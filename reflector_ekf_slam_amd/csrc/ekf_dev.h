@@ -94,9 +94,10 @@ struct RekfDev {
     int dbg;            // ablation bits for rekf_debug_time_kernel; 0 in normal operation
     int n_known;        // the exact state dimension when the host knows it (state full, or nothing enqueued since a read-back), else -1:
                         // spares the kernels a dependent read of ctl->n at their start
-    RekfHostSlot *pub;  // non-null (only in the launch of the LAST kernel of a call: k_downdate2's tile (0,0) workgroup when the state is
-                        // full, else k_augment): that kernel publishes the pose mean, the 3 x 3 pose block, n and the flags ...
+    RekfHostSlot *pub;  // non-null (only in the launch of the LAST k_downdate2 of a call): its tile-(0,0) workgroup publishes the pose
+                        // mean, the 3 x 3 pose block, n and the flags ...
     int pub_seq;        //   ... under this tag, so that GetPose / Sync after the call need no kernel of their own
+    int pub_aug;        //   ... and a k_augment follows: the n to publish is n + 2 ctl->n_new (neither pose nor pose block change there)
     int dd_per;         // k_downdate2, class B: tiles per workgroup (set by rekf_launch_downdate; 0: the kernel divides the tiles itself)
     int dd_sub;         // k_downdate2: class B holds the tiles with I >= J + dd_sub (2: a class-A workgroup also takes the tile below its diagonal tile; 1: it does not)
     int kc_ub;          // host bound of m_pad for the current scan, rounded up to 16 (0: unknown); columns [m, kc_ub) of HPt / Kn are zero

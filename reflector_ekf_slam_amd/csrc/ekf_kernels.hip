@@ -736,6 +736,10 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
     const int K = A.K;
     const size_t ld = (size_t)d.ld;
     const int i0 = blockIdx.x * MID_ROWS;
+    // the host sizes the grid by its BOUND of n (it may run several scans ahead of the device, each of which can append K
+    // reflectors): a workgroup past the real n has nothing to do -- and with one workgroup per CU (121 KB of LDS) a grid of more
+    // than 256 would otherwise cost a second round of the whole inverse
+    if (i0 >= n) return;
     const double *__restrict__ P = d.P;
     // (a host-predicted scan carries the predicted pose in the launch packet: no read of the control block for it)
     const bool hp = A.host_pred != 0;
@@ -1274,8 +1278,17 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     const RekfCtl *ctl = d.ctl;
     int n = d.n_known;
     if (n < 0) {
-        if (ctl->m == 0) return;
         n = ctl->n;
+        if (ctl->m == 0) {                   // nothing matched: P stays as Predict left it -- but the caller still gets its pose
+            if (d.pub && blockIdx.x == 0) {
+                const int l = threadIdx.x;
+                if (l < 3) host_slot_store(d.pub + l, d.mu[l], d.pub_seq, 0);
+                else if (l < 12) host_slot_store(d.pub + l, d.P[(l - 3) % 3 + (size_t)((l - 3) / 3) * d.ld], d.pub_seq, 0);
+                else if (l == 12) host_slot_store(d.pub + 12, (double)(n + (d.pub_aug ? 2 * ctl->n_new : 0)), d.pub_seq,
+                                                  __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
+            return;
+        }
     }
     constexpr int NK = KC / 4;               // MFMA k-steps per tile
     constexpr int ND = KC / 8;               // DMA instructions per panel per wave (2 k-rows each, 4 waves)
@@ -1296,15 +1309,22 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     // (When class B gets fewer than three tiles per workgroup -- small states -- class A keeps to its diagonal tile and the tiles
     // below the diagonal join class B: dd_sub = 1.)
     const bool classA = w < T;
-    const int sub = (d.dd_sub == 1) ? 1 : 2;
-    const int nB = (T - sub + 1) * (T - sub) / 2, nwB = nw - T;     // class B: tiles and workgroups
+    // tiles per class-B workgroup: from the host when it knows n exactly (no division in the prologue), else derived here from
+    // the real T and the grid the host sized by its bound of n (downdate_schedule below, same arithmetic)
+    int sub = (d.dd_sub == 1) ? 1 : 2, per = d.dd_per;
+    if (per <= 0) {
+        const unsigned room = (unsigned)((nw - T > 1) ? nw - T : 1);
+        unsigned nBq = (unsigned)((T - 1) * (T - 2) / 2);
+        sub = 2;
+        per = (int)((nBq + room - 1) / room);
+        if (per < 3) { sub = 1; nBq = (unsigned)(T * (T - 1) / 2); per = (int)((nBq + room - 1) / room); }
+        if (per < 1) per = 1;
+    }
+    const int nB = (T - sub + 1) * (T - sub) / 2;                  // class B: its tiles
     const int ntiles = nB;
-    const int wq = w - T, nwq = nwB > 0 ? nwB : 1;
-    // (class B with the host's tiles-per-workgroup: plain multiples, no 64-bit divisions in the prologue)
-    const bool fixed_per = d.dd_per > 0;
-    const int t_begin = classA ? 0 : (fixed_per ? min(wq * d.dd_per, ntiles) : (int)(((long long)wq * ntiles) / nwq));
-    const int t_end = classA ? ((sub == 2 && w + 1 < T) ? 2 : 1)
-                             : (fixed_per ? min((wq + 1) * d.dd_per, ntiles) : (wq < nwq ? (int)(((long long)(wq + 1) * ntiles) / nwq) : 0));
+    const int wq = w - T;
+    const int t_begin = classA ? 0 : min(wq * per, ntiles);
+    const int t_end = classA ? ((sub == 2 && w + 1 < T) ? 2 : 1) : min((wq + 1) * per, ntiles);
     if (t_begin >= t_end) return;
     const int nt = t_end - t_begin;
     const size_t ld = (size_t)d.ld;
@@ -1620,7 +1640,10 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
                 // straight to the host's slots 3 + r + 3 c.  The mean k_mid committed, n and the flags go with it (lanes 32..35):
                 // this workgroup ends 3 us before the kernel does, so nobody waits for the PCIe writes
                 if (lane >= 32 && lane < 35) host_slot_store(d.pub + (lane - 32), d.mu[lane - 32], d.pub_seq, 0);
-                if (lane == 35) host_slot_store(d.pub + 12, (double)n, d.pub_seq, __hip_atomic_load(&d.ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                // n as it will be once the k_augment enqueued behind this kernel has run (k_mid has left the number of new
+                // reflectors, already clamped to the capacity, in the control block): nobody has to publish after k_augment
+                if (lane == 35) host_slot_store(d.pub + 12, (double)(n + (d.pub_aug ? 2 * d.ctl->n_new : 0)), d.pub_seq,
+                                                __hip_atomic_load(&d.ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 const int c0 = 2 * kq;
                 if (idx == 0 && kq < 2) {
                     host_slot_store(d.pub + 3 + 0 + 3 * c0, pq[PAR][0].x, d.pub_seq, 0);
@@ -1749,15 +1772,7 @@ __global__ __launch_bounds__(256) void k_augment(RekfDev d, RekfFrontArgs A)
     const int tid = threadIdx.x;
     const size_t ld = (size_t)d.ld;
     double *P = d.P;
-    // The last kernel of a call while the map may still grow: it publishes what the caller reads next -- pose mean, the
-    // 3 x 3 pose block (neither changes here), the NEW n and the flags -- as tagged slots in pinned host memory.
-    auto publish = [&](int n_after) {
-        if (!d.pub) return;
-        if (tid < 3) host_slot_store(d.pub + tid, d.mu[tid], d.pub_seq, 0);
-        else if (tid < 12) host_slot_store(d.pub + tid, P[(tid - 3) % 3 + (size_t)((tid - 3) / 3) * ld], d.pub_seq, 0);
-        else if (tid == 12) host_slot_store(d.pub + 12, (double)n_after, d.pub_seq, __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    };
-    if (N2 == 0) { publish(n); return; }
+    if (N2 == 0) return;
     {
 #pragma clang fp contract(off)
         const double x = d.mu[0], y = d.mu[1], th = d.mu[2];
@@ -1816,7 +1831,6 @@ __global__ __launch_bounds__(256) void k_augment(RekfDev d, RekfFrontArgs A)
     }
     __syncthreads();
     if (tid == 0) ctl->n = n + 2 * N2;                              // cc:360-363
-    publish(n + 2 * N2);
 }
 
 // GetState's pose part (ekf_slam.h GetState / ros_node.cc's pose publisher): mu[0..2], the 3 x 3 pose block, n and the error
@@ -1927,6 +1941,7 @@ void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s)
     attr_done[slot] |= bit;
     RekfDev dp = d;
     dp.dd_per = dd_per; dp.dd_sub = dd_sub;
+    if (d.n_known < 0) { dp.dd_per = 0; dp.dd_sub = 0; }          // n_ub is only a bound: the kernel derives the schedule from the real n
     if (kc == 64) launch_downdate2<64>(dp, grid, s, first);
     else if (kc == 48) launch_downdate2<48>(dp, grid, s, first);
     else if (kc == 32) launch_downdate2<32>(dp, grid, s, first);

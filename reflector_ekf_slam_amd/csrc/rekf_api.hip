@@ -209,8 +209,7 @@ void report_flags(rekf_t *h, int flags)
 
 // ---- publishers and the n they carry ------------------------------------------------------------------------------
 // Every call that changes the device state ends in ONE kernel that stores pose mean, 3 x 3 pose block, n and the sticky flags as
-// tagged slots into pinned host memory (k_downdate2's tile-(0,0) workgroup when the state is known full, else k_augment, else a
-// 64-thread publish kernel).  new_publisher hands out the tag and remembers the growth bound at that point.
+// tagged slots into pinned host memory (the tile-(0,0) workgroup of a scan's last k_downdate2, else a 64-thread publish kernel).  new_publisher hands out the tag and remembers the growth bound at that point.
 int new_publisher(rekf_t *h)
 {
     const int seq = ++h->slot_seq;
@@ -611,7 +610,8 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         h->obs_staging_busy = true;
         a.obs_ext = h->dev_obs;
     }
-    // the call's LAST kernel publishes: k_downdate2 (tile (0,0)'s workgroup) when no landmark can be added any more, else k_augment
+    // the call's last k_downdate2 publishes (tile (0,0)'s workgroup, ~3 us before that kernel ends): pose, pose block, flags and
+    // the n the state will have once the k_augment behind it has run (which changes none of the others)
     const bool aug = !h->full;
     if (aug) h->cum_growth += 2 * K;
     const int pub_seq = new_publisher(h);
@@ -623,7 +623,7 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     h->dev.mu_lin = h->dev.mu;
     auto downdate = [&](bool last) {
         ProfScope ps(h, REKF_K_DOWNDATE);
-        if (last && !aug) { dpub = h->dev; dpub.pub = h->host_slots_dev; dpub.pub_seq = pub_seq; rekf_launch_downdate(dpub, n_ub, h->stream); }
+        if (last) { dpub = h->dev; dpub.pub = h->host_slots_dev; dpub.pub_seq = pub_seq; dpub.pub_aug = aug ? 1 : 0; rekf_launch_downdate(dpub, n_ub, h->stream); }
         else rekf_launch_downdate(h->dev, n_ub, h->stream);
     };
     if (blocks) {
@@ -657,8 +657,7 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     // (k_mid / k_compact_wide drop the extra reflectors and raise REKF_FLAG_CAPACITY)
     if (aug) {
         ProfScope ps(h, REKF_K_AUGMENT);
-        dpub = h->dev; dpub.pub = h->host_slots_dev; dpub.pub_seq = pub_seq;
-        rekf_launch_augment(dpub, a, h->stream);
+        rekf_launch_augment(h->dev, a, h->stream);
     }
     { ProfScope ps(h, REKF_K_EMPTY); }
     if (aug) {
