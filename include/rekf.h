@@ -26,7 +26,8 @@
  *    call pattern: its node reads the pose after every scan, src/ros_node.cc:514-515).  rekf_get_pose and
  *    rekf_predict_state between scans are answered from the mirror without touching the device.
  *  - the covariance lives in HBM for the life of the handle, column-major like
- *    Eigen::MatrixXd (ekf_slam_interface.h:47) with a fixed leading dimension.
+ *    Eigen::MatrixXd (ekf_slam_interface.h:47) with a fixed leading dimension, as its LOWER TRIANGLE (element (i, j) is
+ *    valid iff i >= j; nothing reads the memory above the diagonal); the getters mirror it into the caller's n x n buffer.
  */
 #ifndef REKF_H_
 #define REKF_H_
@@ -150,10 +151,10 @@ int rekf_get_state(rekf_t *h, double *t, int *n, double *mu, long mu_cap,
  * out5 holds cap landmarks (5*cap doubles); *count = landmarks written.  Synchronises. */
 int rekf_get_marker_ellipses(rekf_t *h, double *out5, int cap, int *count);
 
-/* Restore a full state (checkpoint resume / tests).  sigma column-major, ld = n.
- * vt3 = nullable last odometry velocity.  sigma is stored as given, but it must be symmetric for the filter to continue
- * from it: the kernels keep the covariance EXACTLY symmetric (every writer mirrors one computed value) and read whichever
- * half is contiguous -- Predict the columns 0..2, the downdate the lower triangle. */
+/* Restore a full state (checkpoint resume / tests).  sigma column-major, ld = n.  vt3 = nullable last odometry velocity.
+ * Only the LOWER triangle of sigma (i >= j) is used: the device stores the covariance as its lower triangle -- the rank-m
+ * downdate then reads and writes half the bytes, and the stored covariance cannot be anything but exactly symmetric -- and
+ * rekf_get_state / rekf_predict_state_full return that triangle mirrored. */
 int rekf_set_state(rekf_t *h, double t, int n, const double *mu, const double *sigma,
                    const double *vt3);
 
@@ -202,7 +203,7 @@ int rekf_profile_reset(rekf_t *h);
 int rekf_profile_samples(rekf_t *h, float *out_us, long cap, long *count);
 /* The hipStream_t of the handle (as void*), for callers that record their own events. */
 void *rekf_stream(rekf_t *h);
-/* Leading dimension (doubles) of the device covariance and its device pointer; mu_dev is the CURRENT mean buffer (the
+/* Leading dimension (doubles) of the device covariance (lower triangle valid, see Conventions) and its device pointer; mu_dev is the CURRENT mean buffer (the
  * mean is double-buffered: every update flips between two buffers).  Predicts the host has applied to its mirror but not
  * yet to the device (see Conventions) are NOT in these buffers until the next scan or rekf_get_state. */
 int rekf_device_layout(rekf_t *h, int *ld, int *n_max, void **P_dev, void **mu_dev);

@@ -7,7 +7,11 @@
 //   P    [ld x ld]       covariance, COLUMN-major (Eigen::MatrixXd order,
 //                        reference ekf_slam_interface.h:47), leading dimension
 //                        ld = roundup(n_max, 64) so every 64x64 tile is in bounds
-//                        and every column starts on a 512-byte boundary
+//                        and every column starts on a 512-byte boundary.
+//                        Stored as its LOWER TRIANGLE: element (i, j) is valid iff i >= j; no kernel ever reads the memory
+//                        above the diagonal (k_downdate2 happens to leave mirror images there inside its diagonal tiles,
+//                        rekf_set_state uploads whatever the caller passes): the covariance cannot be anything but exactly
+//                        symmetric, and the rank-m downdate moves half the bytes.  The host getters mirror on the way out.
 //   HPt  [ld x 64]       HPt = (H P)^T gathered from the ROWS of P, column-major
 //   Kn   [ld x 64]       Kn = -K = -W S^-1, column-major
 //   KnB, HPtB [4 x MR_PAD]  copies of rows nb..nb+3 of Kn / HPt, nb = 64*floor(n/64), when n mod 64 <= 4
@@ -192,6 +196,12 @@ __host__ __device__ static inline void corner_predict(double *P, int ld, const M
     // elements take the lower ones' bits (the reference's two differ in the last place at most)
     for (int i = 0; i < 3; ++i)
         for (int j = i + 1; j < 3; ++j) P[i + (size_t)j * ld] = P[j + (size_t)i * ld];
+}
+
+// sigma(i, j) of the lower-triangle storage
+__host__ __device__ static inline double rekf_plower(const double *P, int ld, int i, int j)
+{
+    return (i >= j) ? P[(size_t)i + (size_t)j * (size_t)ld] : P[(size_t)j + (size_t)i * (size_t)ld];
 }
 
 // first row of the thin border that k_downdate treats as strips, or -1 (n a multiple of 64, border wider than

@@ -136,9 +136,8 @@ __global__ __launch_bounds__(1024) void k_apply_predict(RekfDev d, RekfFrontArgs
     double *__restrict__ P = d.P;
     const size_t ld = (size_t)d.ld;
     const int n = (d.n_known >= 0) ? d.n_known : ctl->n;
-    // P is exactly symmetric (every kernel that writes it mirrors: k_downdate2, the pose block, k_augment), so the row part
-    // P(0..2, idx) equals the column part P(idx, 0..2) bit for bit: only the coalesced columns are read, the strided rows are
-    // written from the same values
+    // P is stored as its lower triangle (ekf_dev.h): Predict touches the coalesced columns P(idx, 0..1) against P(idx, 2); the rows
+    // P(0..1, idx) are the same numbers and exist nowhere else
     const double a = A.pre_ab[0], b = A.pre_ab[1];
     double c0[COV_PF], c1[COV_PF], c2[COV_PF];
 #pragma unroll
@@ -153,8 +152,6 @@ __global__ __launch_bounds__(1024) void k_apply_predict(RekfDev d, RekfFrontArgs
             const double n0 = c0[t] + a * c2[t], n1 = c1[t] + b * c2[t];
             P[idx + 0 * ld] = n0;
             P[idx + 1 * ld] = n1;
-            P[0 + idx * ld] = n0;
-            P[1 + idx * ld] = n1;
         }
     }
     for (int idx = tid + 1024 * COV_PF; idx < n; idx += 1024) {
@@ -162,8 +159,6 @@ __global__ __launch_bounds__(1024) void k_apply_predict(RekfDev d, RekfFrontArgs
         const double n0 = P[idx + 0 * ld] + a * p2, n1 = P[idx + 1 * ld] + b * p2;
         P[idx + 0 * ld] = n0;
         P[idx + 1 * ld] = n1;
-        P[0 + idx * ld] = n0;
-        P[1 + idx * ld] = n1;
     }
     if (tid < 9) P[(tid % 3) + (size_t)(tid / 3) * ld] = A.pre_C9[0 + tid];
     if (tid >= 64 && tid < 67) d.mu[tid - 64] = A.pre_pose[tid - 64];
@@ -219,7 +214,7 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
     float ob0x = 0.f, ob0y = 0.f;
     if (b < K) { ob0x = rekf_obs(A, 2 * b); ob0y = rekf_obs(A, 2 * b + 1); }
     const int idx0 = b * 1024 + tid;
-    double c0 = 0, c1 = 0, c2 = 0;            // (columns only: P is exactly symmetric, see k_apply_predict)
+    double c0 = 0, c1 = 0, c2 = 0;            // (the columns: P is stored as its lower triangle, see k_apply_predict)
     if (idx0 >= 3 && idx0 < n) {
         c0 = P[idx0 + 0 * ld]; c1 = P[idx0 + 1 * ld]; c2 = P[idx0 + 2 * ld];
     }
@@ -250,7 +245,7 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
         // libm calls (2.1 us) but for one; theta' itself (what is committed to the mean) is computed as written, after the barrier.
         // (Only on this path: when the host predicts, above, cos / sin are the reference's own.)
 #pragma clang fp contract(off)
-        if (b == 0) for (int q = 0; q < 9; ++q) C9[q] = P[(q % 3) + (size_t)(q / 3) * ld];
+        if (b == 0) for (int q = 0; q < 9; ++q) C9[q] = rekf_plower(P, (int)ld, q % 3, q / 3);
         const double mu2 = mu[2];
         const double dth = A.vt[2] * A.dt;            // = mo.d[2] (delta_theta = w dt in both models; no FMA: same bits)
         double th = mu2 + dth, sn, cs;
@@ -275,16 +270,12 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
             const double n0 = c0 + a * c2, n1 = c1 + bb * c2;
             P[idx0 + 0 * ld] = n0;
             P[idx0 + 1 * ld] = n1;
-            P[0 + idx0 * ld] = n0;                        // the row part: the same values (P is symmetric)
-            P[1 + idx0 * ld] = n1;
         }
         for (int idx = idx0 + nb * 1024; idx < n; idx += nb * 1024) {
             const double p2 = P[idx + 2 * ld];
             const double n0 = P[idx + 0 * ld] + a * p2, n1 = P[idx + 1 * ld] + bb * p2;
             P[idx + 0 * ld] = n0;
             P[idx + 1 * ld] = n1;
-            P[0 + idx * ld] = n0;
-            P[1 + idx * ld] = n1;
         }
         if (b == 0 && tid == 0) {
             if (A.host_pred) {
@@ -710,7 +701,10 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
     __shared__ __attribute__((aligned(16))) double s_big[(NKCP * 2 * NRS > MP * LDS_S) ? NKCP * 2 * NRS : MP * LDS_S];
     __shared__ __attribute__((aligned(16))) double s_pw[NKC][MID_ROWS];     // P(own rows, sub-block columns)
     __shared__ double s_dmu[4][MID_ROWS];
-    __shared__ int s_pair_obs[NPAIR], s_pair_id[NPAIR], s_pair_state[NPAIR], s_pcol[NPAIR], s_rank[NPAIR], s_rsrow[NRS], s_cnt[5];
+    __shared__ int s_pair_obs[NPAIR], s_pair_id[NPAIR], s_pair_state[NPAIR], s_pcol[NPAIR], s_rank[NPAIR], s_cnt[5];
+    // the sub-block's slots in ascending global order -- u = 0: rows / columns {0,1}, u = 1: {2}, u = 2 + rank: a state pair's
+    // landmark -- with the first global row (= column) of each and the first sub-block column kc it stands for
+    __shared__ int s_urow[NRS], s_ukc[NRS];
     double (*s_psub)[NKCP] = (double (*)[NKCP])s_big;                       // [row 2 rs + {0,1} of the sub-block][its column kc]
     double (*s_sinv)[LDS_S] = (double (*)[LDS_S])s_big;                     // S^-1, row-major
 
@@ -775,13 +769,13 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
         NSl = NSl < 0 ? 0 : (NSl < cnt ? NSl : cnt);
         if (live && lane < NPAIR) {
             s_pair_obs[lane] = ob; s_pair_id[lane] = id; s_pair_state[lane] = st ? 1 : 0;
-            if (st) { s_rank[lane] = rk; s_rsrow[rk] = 3 + 2 * id; }
+            if (st) { s_rank[lane] = rk; s_urow[2 + rk] = 3 + 2 * id; s_ukc[2 + rk] = 3 + 2 * lane; }
         }
         if (lane == 0) {
             const bool gps = A.has_gps && cnt > 0 && A.pair0 + cnt == MMtot;     // the pose rows ride on the block step that holds the last pairs
             const int m = (cnt > 0) ? 2 * cnt + (gps ? 3 : 0) : 0;
             s_cnt[0] = cnt; s_cnt[1] = m; s_cnt[2] = (m + 15) & ~15; s_cnt[3] = NSl; s_cnt[4] = gps ? 1 : 0;
-            s_rsrow[NSl] = 0; s_rsrow[NSl + 1] = 2;
+            s_urow[0] = 0; s_ukc[0] = 0; s_urow[1] = 2; s_ukc[1] = 2;
         }
     } else if (tid < 64) {
         const int kind = (lane < K) ? kind_raw : -1;
@@ -814,7 +808,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
             if (p < NPAIR) {
                 s_pair_obs[p] = lane; s_pair_id[p] = oidx; s_pair_state[p] = 1;
                 s_rank[p] = rk;
-                s_rsrow[rk] = 3 + 2 * oidx;
+                s_urow[2 + rk] = 3 + 2 * oidx; s_ukc[2 + rk] = 3 + 2 * p;
             }
             if (first) { ctl->state_pairs[2 * p] = lane; ctl->state_pairs[2 * p + 1] = oidx; }
         } else if (kind == 0) {
@@ -829,7 +823,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
             const int MM = M + Mm;
             const int m = (MM > 0) ? 2 * MM + (A.has_gps ? 3 : 0) : 0;
             s_cnt[0] = MM; s_cnt[1] = m; s_cnt[2] = (m + 15) & ~15; s_cnt[3] = M; s_cnt[4] = (A.has_gps && MM > 0) ? 1 : 0;
-            s_rsrow[M] = 0; s_rsrow[M + 1] = 2;                       // row slot M = rows {0,1}, slot M+1 = row {2}
+            s_urow[0] = 0; s_ukc[0] = 0; s_urow[1] = 2; s_ukc[1] = 2;   // (their rows of s_psub stay M and M+1: row slot M = rows {0,1}, M+1 = row {2})
             if (first) {
                 ctl->K = K; ctl->n_state = M; ctl->n_map = Mm; ctl->n_new = N2;
                 ctl->m = m; ctl->m_pad = (m + 15) & ~15;
@@ -861,46 +855,58 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
     }
     // (m_pad <= MP: the host picked NBR from its bound 2K(+3) of m)
 
-    // ---- C (issued before B: it needs only the match lists): the raw P values, each cache line fetched once per
-    // workgroup and by neighbouring lanes.  Sub-block P(R, R), R = {landmark rows of the state pairs, 0, 1, 2}: lane = row
-    // slot (sorted by landmark), wave + 4 it = column; own rows x R columns; R rows x own columns.  Row slot NS+1 stands
-    // for row 2 alone but is fetched as the pair (2, 3) like the others: no special case in the loops.
+    // ---- C (issued before B: it needs only the match lists): the raw P values.  P is stored as its LOWER triangle (ekf_dev.h).
+    // Sub-block P(R, R), R = {0, 1, 2, landmark rows of the state pairs}: only its lower block-triangle is fetched -- blocks
+    // (row slot u, column slot u' <= u) in ascending global order, column slot major, so that neighbouring lanes hit neighbouring
+    // rows of one column (the 32 nearest reflectors are a handful of runs of consecutive ids): 2 x 16 bytes per block, ~4.7 loads per
+    // thread (round 2 fetched the full square: 17) -- and mirrored into the upper block-triangle on the way into LDS.
+    // Own rows x R columns: element (i, c) comes from P(i, c) or P(c, i), whichever lies below the diagonal.
     const int nrs = NS + 2, nkc = 3 + 2 * NS;
     const unsigned ldb = (unsigned)d.ld * 8u;                              // bytes per column of P (byte offsets fit 32 bits: ld^2 * 8 < 4 GiB)
     // column of sub-block column kc, for kc = lane and kc = 64 + lane, once: the loops fetch it with v_readlane
     int colA = 0, colB = 0;
     if (lane < nkc) colA = (lane < 3) ? lane : 3 + 2 * s_pair_id[(lane - 3) >> 1] + ((lane - 3) & 1);          // pairs < NS are state pairs
     if (64 + lane < nkc) colB = 3 + 2 * s_pair_id[(61 + lane) >> 1] + ((61 + lane) & 1);
-    auto col_of = [&](int kc) -> int {                                      // kc wave-uniform
-        return (kc < 64) ? __builtin_amdgcn_readlane(colA, kc) : __builtin_amdgcn_readlane(colB, kc - 64);
-    };
-    // (indices are CLAMPED instead of branched on: a lane or an iteration past the end refetches a line its neighbour
-    // fetches anyway, and the loops stay straight-line so that all loads issue back to back; only the LDS stores are predicated)
-    constexpr int PS_IT = (NKC + 3) / 4;
-    v2du ps[PS_IT];
-    const char *my_row_ptr = (const char *)(P + s_rsrow[(lane < nrs) ? lane : nrs - 1]);
-    const int kc0 = __builtin_amdgcn_readfirstlane(wave & 3);
+    constexpr int NBLK = NRS * (NRS + 1) / 2, PS_IT = (NBLK + 255) / 256;
+    v2du ps[PS_IT][2];
+    int blk_u[PS_IT], blk_v[PS_IT];                                         // row slot u, column slot u' of this thread's blocks (-1: none)
+    const int nblk = nrs * (nrs + 1) / 2;
     if (steam) {
 #pragma unroll
         for (int it = 0; it < PS_IT; ++it) {
-            const int kc = kc0 + 4 * it;
-            ps[it] = *(const v2du *)(my_row_ptr + (unsigned)col_of((kc < nkc) ? kc : nkc - 1) * ldb);
+            const int t = tt + 256 * it;
+            const int tc = (t < nblk) ? t : nblk - 1;                       // clamped: a thread past the end refetches the last block
+            // column slot v of block tc in the column-major enumeration of the lower block-triangle: v columns hold
+            // v nrs - v (v - 1) / 2 blocks
+            const float bq = 2.0f * (float)nrs + 1.0f;
+            int v = (int)((bq - sqrtf(fmaxf(bq * bq - 8.0f * (float)tc, 0.0f))) * 0.5f);
+            v = max(0, min(nrs - 1, v));
+            while (v > 0 && v * nrs - (v * (v - 1)) / 2 > tc) --v;
+            while (v + 1 < nrs && (v + 1) * nrs - ((v + 1) * v) / 2 <= tc) ++v;
+            const int u = v + (tc - (v * nrs - (v * (v - 1)) / 2));
+            blk_u[it] = (t < nblk) ? u : -1; blk_v[it] = v;
+            const char *rp = (const char *)(P + s_urow[u]) + (unsigned)s_urow[v] * ldb;
+            ps[it][0] = *(const v2du *)rp;                                  // rows (r, r+1) of column c
+            ps[it][1] = *(const v2du *)(rp + ldb);                          // ... of column c + 1
         }
     }
     constexpr int PW_IT = (NKC * 8 + 255) / 256;
     v2d pw[PW_IT];
     if (!steam) {
         const int pr = tid & 7, sub = (tid >> 3) & 7;                       // 8 columns x 8 row pairs per wave instruction
-        const char *own_ptr = (const char *)(P + i0 + 2 * pr);
+        const int kc0 = __builtin_amdgcn_readfirstlane(wave & 3);
+        const int i = i0 + 2 * pr;
 #pragma unroll
         for (int it = 0; it < PW_IT; ++it) {
             int kc = 8 * (kc0 + 4 * it) + sub;
             kc = (kc < nkc) ? kc : nkc - 1;
             const int cA = __shfl(colA, kc & 63, 64), cB = __shfl(colB, kc & 63, 64);
-            pw[it] = *(const v2d *)(own_ptr + (unsigned)((kc < 64) ? cA : cB) * ldb);
+            const int cc = (kc < 64) ? cA : cB;
+            // (i, cc) and (i + 1, cc), each from below the diagonal
+            const double *e0 = (i >= cc) ? P + (size_t)i + (size_t)cc * ld : P + (size_t)cc + (size_t)i * ld;
+            const double *e1 = (i + 1 >= cc) ? P + (size_t)(i + 1) + (size_t)cc * ld : P + (size_t)cc + (size_t)(i + 1) * ld;
+            pw[it].x = *e0; pw[it].y = *e1;
         }
-        // (no gather of P(sub-block rows, own columns) for (H P)^T: P is exactly symmetric -- every kernel that writes it mirrors --
-        // so (H P)^T(c, r) is W(c, r) bit for bit and is stored from the own-row values below)
     }
     MMARK();                                        // 1: gathers issued
 
@@ -943,18 +949,31 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
         for (int q = 0; q < 8; ++q) s_coef[8 * r + q] = hr[q];
         if (rr == 0) s_pcol[p] = col;
     }
-    // raw values -> LDS.  s_psub is [row 2 rs + {0,1}][sub-block column kc]: phase D reads a row pair's (col_q, col_q + 1)
-    // as ONE 16-byte value, consecutive q = consecutive addresses (no bank conflicts)
+    // raw values -> LDS.  s_psub is [row 2 rs + {0,1}][sub-block column kc] (rs = the pair's rank among the state pairs; NS for
+    // rows {0,1}, NS + 1 for row {2}): phase D reads a row pair's (col_q, col_q + 1) as ONE 16-byte value, consecutive q =
+    // consecutive addresses (no bank conflicts).  A block goes in twice: as fetched and transposed (the upper block-triangle).
     if (steam) {
-        if (lane < nrs) {
 #pragma unroll
-            for (int it = 0; it < PS_IT; ++it) {
-                const int kc = kc0 + 4 * it;
-                if (kc < nkc) { s_psub[2 * lane][kc] = ps[it].x; s_psub[2 * lane + 1][kc] = ps[it].y; }
+        for (int it = 0; it < PS_IT; ++it) {
+            const int u = blk_u[it], v = blk_v[it];
+            if (u >= 0) {
+                const int ru = (u >= 2) ? u - 2 : NS + u, rv = (v >= 2) ? v - 2 : NS + v;       // their row slots in s_psub
+                const int ku = s_ukc[u], kv = s_ukc[v];
+                double b00 = ps[it][0].x, b10 = ps[it][0].y, b01 = ps[it][1].x, b11 = ps[it][1].y;   // b[a][e] = P(r + a, c + e)
+                if (s_urow[u] == s_urow[v]) b01 = b10;                      // a diagonal block (also: two pairs on ONE landmark, Q6): (r, r+1) lies above the diagonal
+                // slot 1 stands for row / column 2 ALONE: its second row (3) is fetched but never used, its second column does not exist
+                s_psub[2 * ru][kv] = b00; s_psub[2 * ru + 1][kv] = b10;
+                if (v != 1) { s_psub[2 * ru][kv + 1] = b01; s_psub[2 * ru + 1][kv + 1] = b11; }
+                if (u != v) {
+                    s_psub[2 * rv][ku] = b00;
+                    if (v != 1) s_psub[2 * rv + 1][ku] = b01;
+                    if (u != 1) { s_psub[2 * rv][ku + 1] = b10; if (v != 1) s_psub[2 * rv + 1][ku + 1] = b11; }
+                }
             }
         }
     } else {
         const int pr = tid & 7, sub = (tid >> 3) & 7;
+        const int kc0 = __builtin_amdgcn_readfirstlane(wave & 3);
 #pragma unroll
         for (int it = 0; it < PW_IT; ++it) {
             const int kc = 8 * (kc0 + 4 * it) + sub;
@@ -1234,15 +1253,13 @@ template <int N> __device__ static inline void dd_wait_vmcnt()
 #else
 #define DD_STORE(p, v) (*(p) = (v))
 #endif
-// Lower triangle + mirror: the update K (H P) = P H^T S^-1 H P is symmetric, so only the tiles on and below the diagonal are
-// computed -- half the MFMA work, half the P reads -- and an off-diagonal tile is written twice, as P(I,J) and transposed as
-// P(J,I).  The transposed image needs no LDS: a lane holds rows (r, r+1) x columns (c + 8t + {0,1}), t < 4, of its block, so
-// the two columns of a pair are adjacent in the image and {pq[t].e, pq[t+4].e} is one 16-byte store (64 contiguous bytes
-// per 4 lanes).  A diagonal tile takes the sums of its upper half from its lower half (LDS transpose, or a second role-swapped
-// product in mid-range) and issues its normal stores twice, so that every tile has the same VMEM count (the s_waitcnt
-// bookkeeping is static).  The stored P is therefore EXACTLY symmetric; the reference's (I - K H) P differs from it in the
-// last bit only.  (Rounds 1-2 also carried a full-square form and a one-tile-per-workgroup form for A/B runs -- same speed
-// within 3 %, DESIGN.md section 3 -- they are gone from the product; git history has them.)
+// LOWER TRIANGLE ONLY (round 3).  The update K (H P) = P H^T S^-1 H P is symmetric and the filter stores P as its lower triangle
+// (element (i, j) is valid iff i >= j; the memory above the diagonal is never read by any kernel -- ekf_dev.h): only the tiles on and
+// below the diagonal are computed, read and written: half the MFMA work, half the P reads AND half the P writes of the full
+// square (round 2 wrote every off-diagonal tile twice, as P(I,J) and transposed as P(J,I): 59.5 MB per launch; now ~43 MB).
+// A diagonal tile computes all of its sums, adds them to its P block and then mirrors its own lower half into its upper half
+// (an LDS transpose of the RESULT: the values above the diagonal are written for free but never read back), so nothing ever
+// depends on two independently rounded halves -- the property that keeps the filter stable.
 template <int KC>
 __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
 {
@@ -1283,7 +1300,7 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
             if (d.pub && blockIdx.x == 0) {
                 const int l = threadIdx.x;
                 if (l < 3) host_slot_store(d.pub + l, d.mu[l], d.pub_seq, 0);
-                else if (l < 12) host_slot_store(d.pub + l, d.P[(l - 3) % 3 + (size_t)((l - 3) / 3) * d.ld], d.pub_seq, 0);
+                else if (l < 12) host_slot_store(d.pub + l, rekf_plower(d.P, d.ld, (l - 3) % 3, (l - 3) / 3), d.pub_seq, 0);
                 else if (l == 12) host_slot_store(d.pub + 12, (double)(n + (d.pub_aug ? 2 * ctl->n_new : 0)), d.pub_seq,
                                                   __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             }
@@ -1370,22 +1387,6 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     auto p_ptr = [&](int I, int J) __attribute__((always_inline)) -> double * {
         return P + (size_t)(DT * I + 32 * wi + 2 * idx) + (size_t)(DT * J + 32 * wj + 2 * kq) * ld;
     };
-    // transposed image of this lane's block: element (i, j) of tile (I, J) -> P(64 J + j, 64 I + i)
-    auto pm_ptr = [&](int I, int J) __attribute__((always_inline)) -> double * {
-        return P + (size_t)(DT * J + 32 * wj + 2 * kq) + (size_t)(DT * I + 32 * wi + 2 * idx) * ld;
-    };
-    // second store x (0..7) of a finished block: the transposed pair (t = x >> 1, e = x & 1), or -- diagonal tile -- normal store x again
-    auto second_store = [&](const v2d (&blk)[8], double *Pn_, double *Pm_, bool diag, int x) __attribute__((always_inline)) {
-        const int t = x >> 1, e = x & 1;
-        v2d m;
-        m.x = e ? blk[t].y : blk[t].x;
-        m.y = e ? blk[t + 4].y : blk[t + 4].x;
-        double *pn = Pn_ + (size_t)(8 * (x & 3) + (x >> 2)) * ld;
-        double *pm = Pm_ + (size_t)(8 * t) + (size_t)e * ld;
-        const v2d val = diag ? blk[x] : m;
-        DD_STORE((v2d *)(diag ? pn : pm), val);
-    };
-
     // P block of a tile -> P + acc -> store source.  NB register blocks in rotation: the read stream runs AHEAD tiles ahead
     // of the MFMAs.  Measured at C3 (4 tiles per workgroup): AHEAD = 1 and 2 give the same kernel time (17.7 us) -- with two
     // blocks in flight the first MFMA loop stretches from 2.3 to 3.6 us: a wave that cannot issue its load (memory queue
@@ -1446,35 +1447,22 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
         constexpr int PAR = decltype(par_c)::value, PREV = (PAR + AHEAD) % NB;   // PREV: tile pos-1's block = where tile pos+AHEAD's goes
         constexpr bool FIRST = decltype(first_c)::value, LOAD2 = decltype(load2_c)::value, LAST = decltype(last_c)::value,
                        SPECIAL = decltype(special_c)::value == 2,          // diagonal tile that carries the border strips
-                       DIAGSYM = decltype(special_c)::value >= 1,          // diagonal tile: its upper half mirrors its lower half ...
-                       DIAG_LDS = DIAGSYM && LAST,     // ... through an LDS transpose of the sums when the panels are dead after the loop (last tile)
-                       DIAG_MFMA = DIAGSYM && !LAST;   // ... by a second, role-swapped product otherwise (rare: a diagonal tile in mid-range)
+                       DIAGSYM = decltype(special_c)::value >= 1;          // diagonal tile: its upper half := mirror of its (new) lower half
         static_assert(!(LAST && LOAD2), "no tile after the last");
+        static_assert(!DIAGSYM || LAST, "a diagonal tile ends its workgroup's range (class A)");
         int In = I, Jn = J;
         if (!LAST) tile_IJ(pos + 1, In, Jn);
         const bool needK = !LAST && In != I, needH = !LAST && Jn != J;
         const double *Pn = nullptr;                         // tile pos+2's P block
         if (LOAD2) { int I2, J2; tile_IJ(pos + AHEAD, I2, J2); Pn = p_ptr(I2, J2); }
-        double *Po = nullptr, *Pom = nullptr;               // where tile pos-1 goes (and its transposed image)
-        bool pdiag = false;
-        if (!FIRST) { int Ip, Jp; tile_IJ(pos - 1, Ip, Jp); Po = p_ptr(Ip, Jp); Pom = pm_ptr(Ip, Jp); pdiag = Ip == Jp; }
+        double *Po = nullptr;                               // where tile pos-1 goes
+        if (!FIRST) { int Ip, Jp; tile_IJ(pos - 1, Ip, Jp); Po = p_ptr(Ip, Jp); }
         const double *aW = hp_buf(hb) + 32 * wj + 2 * idx + kq * 64;        // A[j][k] = HP(k,j)
         const double *bK = kn_buf(kb) + 32 * wi + 2 * idx + kq * 64;        // B[k][i] = Kn(i,k)
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0, 0, 0, 0};
-        // a diagonal tile: the same product with the operands' roles swapped, accT(i,j) = sum_k Kn(j,k) HPt(i,k) =
-        // acc(j,i) in THIS lane's layout, so an upper element can take its mirror image's value without leaving the lane
-        v4d accT[2][2];
-        const double *aT = kn_buf(kb) + 32 * wj + 2 * idx + kq * 64;
-        const double *bT = hp_buf(hb) + 32 * wi + 2 * idx + kq * 64;
-        if (DIAG_MFMA) {
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) accT[a][b] = (v4d){0, 0, 0, 0};
-        }
         // strip operands of a special tile: lane -> (strip, x), wave -> quarter of the k range
         const int s_which = lane >> 5, s_x = 2 * (lane & 31), s_kb = (KC / 4) * wave;
         const double *s_panel = (s_which ? hp_buf(hb) : kn_buf(kb)) + s_x + s_kb * 64;
@@ -1484,7 +1472,7 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
         if (SPECIAL) {
             double *p0, *p1; int which, b, x;
             strip_addr(I, p0, p1, which, b, x);
-            if (which < 2 && b < rem) { strip_p.x = *p0; strip_p.y = *p1; }
+            if (which == 1 && b < rem) { strip_p.x = *p0; strip_p.y = *p1; }      // the ROW strip P(nb.., 64 I ..): the column strip lies above the diagonal
 #pragma unroll
             for (int b2 = 0; b2 < DD_STRIP_MAX; ++b2) { sacc[b2].x = 0.0; sacc[b2].y = 0.0; }
         }
@@ -1500,22 +1488,15 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
             acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.y, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.x, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.y, acc[1][1], 0, 0, 0);
-            if (DIAG_MFMA) {
-                const v2d at = *(const v2d *)(aT + kk * 256), bt = *(const v2d *)(bT + kk * 256);
-                accT[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(at.x, bt.x, accT[0][0], 0, 0, 0);
-                accT[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(at.x, bt.y, accT[0][1], 0, 0, 0);
-                accT[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(at.y, bt.x, accT[1][0], 0, 0, 0);
-                accT[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(at.y, bt.y, accT[1][1], 0, 0, 0);
-            }
             // ---- this k-step's share of the VMEM traffic (compile-time positions)
-            // phase 0: DMA Kn; 1: the previous tile's stores, then DMA HPt; 2: its transposed image; 3: P loads.
-            // The DMA goes FIRST: the wait at the end of the loop is for the oldest operations only, so the sixteen stores behind
-            // the DMA stay in flight across the tile boundary instead of having to be acknowledged inside it (all sixteen in one
-            // phase would saturate the CU's store path and stall the MFMAs queued behind them)
+            // phase 0: DMA Kn; 1: the first half of the previous tile's stores, then DMA HPt; 2: the second half; 3: P loads.
+            // The DMA goes FIRST: the wait at the end of the loop is for the oldest operations only, so the stores behind the DMA
+            // stay in flight across the tile boundary instead of having to be acknowledged inside it (all eight stores in one
+            // phase stall the MFMAs queued behind them on the CU's store path)
             const int ph = kk / Q4, off = kk % Q4;
             constexpr int PH_LOAD = 3;
             if (ph == 0) {
-                if (!SPECIAL && !LAST && needK) {
+                if (!LAST && needK) {
 #pragma unroll
                     for (int q = 0; q < ND; ++q)
                         if ((q * Q4) / ND == off) dma_piece(Kn, DT * In, kb ^ 1, q);
@@ -1523,10 +1504,10 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
             } else if (ph == 1) {
                 if (!FIRST) {
 #pragma unroll
-                    for (int x = 0; x < 8; ++x)
-                        if ((x * Q4) / 8 == off) DD_STORE((v2d *)(Po + (size_t)(8 * (x & 3) + (x >> 2)) * ld), pq[PREV][x]);
+                    for (int x = 0; x < 4; ++x)
+                        if ((x * Q4) / 4 == off) DD_STORE((v2d *)(Po + (size_t)(8 * (x & 3) + (x >> 2)) * ld), pq[PREV][x]);
                 }
-                if (!SPECIAL && !LAST && needH) {
+                if (!LAST && needH) {
 #pragma unroll
                     for (int q = 0; q < ND; ++q)
                         if ((q * Q4) / ND == off) dma_piece(HPt, DT * Jn, 2 + (hb ^ 1), q);
@@ -1534,8 +1515,8 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
             } else if (ph == 2) {
                 if (!FIRST) {
 #pragma unroll
-                    for (int x = 0; x < 8; ++x)
-                        if ((x * Q4) / 8 == off) second_store(pq[PREV], Po, Pom, pdiag, x);
+                    for (int x = 4; x < 8; ++x)
+                        if (((x - 4) * Q4) / 4 == off) DD_STORE((v2d *)(Po + (size_t)(8 * (x & 3) + (x >> 2)) * ld), pq[PREV][x]);
                 }
             }
             if (ph == PH_LOAD && LOAD2) {
@@ -1556,10 +1537,19 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
             a2 = a2n; b2 = b2n;
         }
         D2MARK();                            // MFMA loop done
-        if (DIAG_LDS) {
-            // the sums of the whole tile through LDS, S[j][i] = acc(i,j) (row stride 66: the lanes of a 16-group differ in i);
-            // an upper element (i < j) then reads S[i][j] = acc(j,i).  Every panel is dead by now: S takes the front of the
-            // dynamic LDS (33 KiB; the smallest launch has 48 KiB).
+        // P + sum_k (the P block was requested a tile ago)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pq[PAR][mt * 4 + r].x += acc[mt][0][r];
+                pq[PAR][mt * 4 + r].y += acc[mt][1][r];
+            }
+        if (DIAGSYM) {
+            // the NEW tile through LDS, S[j][i] = element (i, j) (row stride 66: the lanes of a 16-group differ in i); an element
+            // above the diagonal (i < j) then takes S[i][j] = the new element (j, i): the upper half is the mirror image of the
+            // lower half whatever the memory above the diagonal held.  Every panel is dead by now (a diagonal tile is the last of
+            // its range): S takes the front of the dynamic LDS (33 KiB; the smallest launch has 48 KiB).
             lds_barrier();
             double *S = dd_smem;
 #pragma unroll
@@ -1567,8 +1557,8 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int jj = 32 * wj + 2 * kq + 8 * r + mt, ii = 32 * wi + 2 * idx;
-                    S[jj * 66 + ii] = acc[mt][0][r];
-                    S[jj * 66 + ii + 1] = acc[mt][1][r];
+                    S[jj * 66 + ii] = pq[PAR][mt * 4 + r].x;
+                    S[jj * 66 + ii + 1] = pq[PAR][mt * 4 + r].y;
                 }
             lds_barrier();
 #pragma unroll
@@ -1576,25 +1566,12 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int jj = 32 * wj + 2 * kq + 8 * r + mt, ii = 32 * wi + 2 * idx;
-                    accT[mt][0][r] = S[ii * 66 + jj];
-                    accT[mt][1][r] = S[(ii + 1) * 66 + jj];
+                    const int dij = ii - jj;                                          // i - j for the .x element
+                    if (dij < 0) pq[PAR][mt * 4 + r].x = S[ii * 66 + jj];
+                    if (dij + 1 < 0) pq[PAR][mt * 4 + r].y = S[(ii + 1) * 66 + jj];
                 }
             lds_barrier();                                  // (the strip reduction below reuses LDS)
         }
-        // P + sum_k (the P block was requested two tiles ago)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (DIAGSYM) {                              // element (i, j) of the tile: on or below the diagonal -> its own sum, above -> its mirror image's
-                    const int dij = 32 * (wi - wj) + 2 * (idx - kq) - 8 * r - mt;      // i - j for e = 0
-                    pq[PAR][mt * 4 + r].x += (dij >= 0) ? acc[mt][0][r] : accT[mt][0][r];
-                    pq[PAR][mt * 4 + r].y += (dij + 1 >= 0) ? acc[mt][1][r] : accT[mt][1][r];
-                } else {
-                    pq[PAR][mt * 4 + r].x += acc[mt][0][r];
-                    pq[PAR][mt * 4 + r].y += acc[mt][1][r];
-                }
-            }
         if (SPECIAL) {
             // partial strip sums of the four waves meet in the idle Kn buffer; the threads of the strip mapping finish
             // (with KC < 64 a panel is smaller than the 16 KiB of partial sums: the launch's LDS beyond the four panels is free)
@@ -1605,10 +1582,10 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
             {
                 double *p0, *p1; int which, b, x;
                 strip_addr(I, p0, p1, which, b, x);
-                if (which < 2 && b < rem) {
+                if (which == 1 && b < rem) {
                     v2d t = strip_p;
 #pragma unroll
-                    for (int w4 = 0; w4 < 4; ++w4) { const v2d r = red[(w4 * DD_STRIP_MAX + b) * 64 + 32 + (x >> 1)]; t.x += r.x; t.y += r.y; }   // the row strip's sums for both strips
+                    for (int w4 = 0; w4 < 4; ++w4) { const v2d r = red[(w4 * DD_STRIP_MAX + b) * 64 + 32 + (x >> 1)]; t.x += r.x; t.y += r.y; }
                     *p0 = t.x; *p1 = t.y;
                 }
             }
@@ -1624,7 +1601,7 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
                 }
                 v += __shfl_xor(v, 16, 64);
                 v += __shfl_xor(v, 32, 64);
-                if (k4 == 0 && a < rem && b < rem) {
+                if (k4 == 0 && a < rem && b < rem && a >= b) {      // lower triangle of the corner block
                     double *pp = P + (size_t)(DT * T + a) + (size_t)(DT * T + b) * ld;
                     *pp += v;
                 }
@@ -1658,26 +1635,10 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
                     if (kq == 0) host_slot_store(d.pub + 3 + 2 + 3, pq[PAR][4].x, d.pub_seq, 0);
                 }
             }
-            if (I != J) {                                   // (a diagonal tile has no transposed image; nothing counts VMEM operations after the last tile)
-                double *Pwm = pm_ptr(I, J);
-#pragma unroll
-                for (int x = 0; x < 8; ++x) second_store(pq[PAR], Pw, Pwm, false, x);
-            }
             return;
         }
-        if (SPECIAL) {                                      // a special tile in mid-range (rare): fetch the next panels now
-            lds_barrier();                                  // every wave is done with the scratch and the old panels
-            if (needK) {
-#pragma unroll
-                for (int q = 0; q < ND; ++q) dma_piece(Kn, DT * In, kb ^ 1, q);
-            }
-            if (needH) {
-#pragma unroll
-                for (int q = 0; q < ND; ++q) dma_piece(HPt, DT * Jn, 2 + (hb ^ 1), q);
-            }
-            dd_wait_vmcnt<0>();
-        } else if (needH) dd_wait_vmcnt<(!FIRST ? 8 : 0) + (LOAD2 ? 8 : 0)>();      // after the last HPt DMA: (the 8 transposed stores +) this tile's 8 P loads
-        else if (needK) dd_wait_vmcnt<(FIRST ? 0 : 16) + (LOAD2 ? 8 : 0)>();   // after the last Kn DMA: (all of the previous tile's stores +) (8 P loads)
+        if (needH) dd_wait_vmcnt<(!FIRST ? 4 : 0) + (LOAD2 ? 8 : 0)>();             // after the last HPt DMA: (the second half of the stores +) this tile's 8 P loads
+        else if (needK) dd_wait_vmcnt<(FIRST ? 0 : 8) + (LOAD2 ? 8 : 0)>();          // after the last Kn DMA: (all of the previous tile's stores +) (8 P loads)
         if (needK || needH) lds_barrier();
         if (needK) kb ^= 1;
         if (needH) hb ^= 1;
@@ -1692,9 +1653,7 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     // Short ranges (the BASELINE sizes: 4 tiles per workgroup at n = 2051, 1 at n = 1027 / 259) run as STRAIGHT-LINE code,
     // one instantiation per position: with no loop and no join in the way, hipcc's s_waitcnt pass places every wait exactly
     // (through the generic loop below it merges the variants' states at the joins and waits for far younger loads than the
-    // P block it needs).  A diagonal tile sits at the end of its range (t_diag swap), so only the last position may be SPECIAL.
-    bool mid_special = false;
-    for (int pos = 0; pos + 1 < nt; ++pos) { int Iq, Jq; tile_IJ(pos, Iq, Jq); mid_special |= Iq == Jq; }
+    // P block it needs).  A diagonal tile ends its (class A) range, so only the last position has the diagonal variants.
     auto straight = [&](auto nt_c) __attribute__((always_inline)) {
         constexpr int NT = decltype(nt_c)::value;
         auto one = [&](auto pos_c) __attribute__((always_inline)) {
@@ -1703,9 +1662,11 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
             using First = std::integral_constant<bool, POS == 0>;
             using Load2 = std::integral_constant<bool, (POS + AHEAD < NT)>;
             using Last = std::integral_constant<bool, POS == NT - 1>;
-            if (POS == NT - 1 && I == J) {
-                if (strips) tile_body(Par(), First(), Load2(), Last(), C2(), POS);
-                else tile_body(Par(), First(), Load2(), Last(), C1(), POS);
+            if constexpr (POS == NT - 1) {
+                if (I == J) {
+                    if (strips) tile_body(Par(), First(), Load2(), Last(), C2(), POS);
+                    else tile_body(Par(), First(), Load2(), Last(), C1(), POS);
+                } else tile_body(Par(), First(), Load2(), Last(), C0(), POS);
             } else tile_body(Par(), First(), Load2(), Last(), C0(), POS);
         };
         one(std::integral_constant<int, 0>());
@@ -1713,16 +1674,18 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
         if constexpr (NT > 2) one(std::integral_constant<int, 2>());
         if constexpr (NT > 3) one(std::integral_constant<int, 3>());
     };
-    if (!mid_special && nt <= 4) {
+    if (nt <= 4) {
         if (nt == 4) straight(std::integral_constant<int, 4>());
         else if (nt == 1) straight(std::integral_constant<int, 1>());
         else if (nt == 2) straight(std::integral_constant<int, 2>());
         else straight(std::integral_constant<int, 3>());
     } else {
         auto run4 = [&](auto par_c, auto first_c, auto load2_c, auto last_c, int pos) __attribute__((always_inline)) {
-            if (I == J) {
-                if (strips) tile_body(par_c, first_c, load2_c, last_c, C2(), pos);
-                else tile_body(par_c, first_c, load2_c, last_c, C1(), pos);
+            if constexpr (decltype(last_c)::value) {
+                if (I == J) {
+                    if (strips) tile_body(par_c, first_c, load2_c, last_c, C2(), pos);
+                    else tile_body(par_c, first_c, load2_c, last_c, C1(), pos);
+                } else tile_body(par_c, first_c, load2_c, last_c, C0(), pos);
             } else tile_body(par_c, first_c, load2_c, last_c, C0(), pos);
         };
         auto run = [&](auto par_c, int pos) __attribute__((always_inline)) {               // a tile after the first
@@ -1789,25 +1752,25 @@ __global__ __launch_bounds__(256) void k_augment(RekfDev d, RekfFrontArgs A)
         }
         if (tid == 0) {
             for (int i = 0; i < 3; ++i)
-                for (int j = 0; j < 3; ++j) Sxi[i * 3 + j] = P[i + (size_t)j * ld];   // cc:322
+                for (int j = 0; j < 3; ++j) Sxi[i * 3 + j] = rekf_plower(P, (int)ld, i, j);   // cc:322
             const double q = A.obs_cov;                             // Gz Qt Gz^T, Gz = R(theta) (cc:326,354)
             RQR[0] = c * q * c + (-s) * q * (-s); RQR[1] = c * q * s + (-s) * q * c;
             RQR[2] = s * q * c + c * q * (-s);    RQR[3] = s * q * s + c * q * c;
         }
     }
     __syncthreads();
-    // sigma_mx = G_fx * sigma (cc:355-357): rows n+2a+rr, all old columns, and the mirror
+    // sigma_mx = G_fx * sigma (cc:355-357): rows n+2a+rr, all old columns (below the diagonal: the only copy that is stored);
+    // sigma(0..2, col) is read as sigma(col, 0..2) -- the coalesced columns
     for (int e = tid; e < n * N2; e += 256) {
 #pragma clang fp contract(off)
         const int a = e / n, col = e - a * n;
-        const double q0 = P[0 + (size_t)col * ld], q1 = P[1 + (size_t)col * ld], q2 = P[2 + (size_t)col * ld];
+        const double q0 = rekf_plower(P, (int)ld, col, 0), q1 = rekf_plower(P, (int)ld, col, 1), q2 = rekf_plower(P, (int)ld, col, 2);
         for (int rr = 0; rr < 2; ++rr) {
             double acc = 0;
             acc += Gp[a][rr * 3 + 0] * q0;
             acc += Gp[a][rr * 3 + 1] * q1;
             acc += Gp[a][rr * 3 + 2] * q2;
             P[(size_t)(n + 2 * a + rr) + (size_t)col * ld] = acc;
-            P[(size_t)col + (size_t)(n + 2 * a + rr) * ld] = acc;
         }
     }
     // sigma_mm (cc:354,358): every (a,b) block, a != b included, gets + R Qt R^T
@@ -1823,10 +1786,9 @@ __global__ __launch_bounds__(256) void k_augment(RekfDev d, RekfFrontArgs A)
                     acc += t * Gp[b][cc * 3 + k];
                 }
                 const size_t gi = (size_t)(n + 2 * a + rr), gj = (size_t)(n + 2 * b + cc);
-                if (gi < gj) continue;                              // lower triangle + mirror: P stays exactly symmetric
+                if (gi < gj) continue;                              // the lower triangle is what is stored
                 const double v = acc + RQR[rr * 2 + cc];
                 P[gi + gj * ld] = v;
-                P[gj + gi * ld] = v;
             }
     }
     __syncthreads();
@@ -1839,7 +1801,7 @@ __global__ void k_publish_pose(RekfDev d, RekfHostSlot *out, int seq)
 {
     const int l = threadIdx.x;
     if (l < 3) host_slot_store(out + l, d.mu[l], seq, 0);
-    else if (l < 12) host_slot_store(out + l, d.P[(l - 3) % 3 + (size_t)((l - 3) / 3) * d.ld], seq, 0);
+    else if (l < 12) host_slot_store(out + l, rekf_plower(d.P, d.ld, (l - 3) % 3, (l - 3) / 3), seq, 0);
     else if (l == 12) host_slot_store(out + 12, (double)d.ctl->n, seq, d.ctl->err);
 }
 
@@ -1968,8 +1930,8 @@ __global__ __launch_bounds__(256) void k_ellipses(RekfDev d, double *out5, int c
     if (i >= L || i >= cap) return;
     const size_t ld = (size_t)d.ld;
     const int id = 3 + 2 * i;
-    const double a = d.P[id + id * ld], b = d.P[id + (id + 1) * ld];
-    const double c = d.P[(id + 1) + id * ld], dd = d.P[(id + 1) + (id + 1) * ld];
+    const double a = d.P[id + id * ld], c = d.P[(id + 1) + id * ld], dd = d.P[(id + 1) + (id + 1) * ld];
+    const double b = c;                               // sigma(id, id+1): P is stored as its lower triangle
     double d0, d1, vx, vy;
     if (fabs(c) <= 2.220446049250313e-16 * (fabs(a) + fabs(dd))) {
         d0 = a; d1 = dd; vx = 1.0; vy = 0.0;

@@ -315,6 +315,19 @@ int flush_lazy(rekf_t *h)
     return REKF_OK;
 }
 
+// The device keeps P as its lower triangle (ekf_dev.h): the callers' n x n copies get the upper triangle from it (blocked: the
+// strided side of the transpose stays in cache).
+void mirror_lower(double *sg, int n)
+{
+    constexpr int B = 32;
+    for (int j0 = 0; j0 < n; j0 += B)
+        for (int i0 = 0; i0 <= j0; i0 += B) {
+            const int j1 = j0 + B < n ? j0 + B : n, i1 = i0 + B < n ? i0 + B : n;
+            for (int j = j0; j < j1; ++j)
+                for (int i = i0; i < i1 && i < j; ++i) sg[(size_t)i + (size_t)j * n] = sg[(size_t)j + (size_t)i * n];
+        }
+}
+
 struct DevBuffers {            // everything whose size depends on max_landmarks (rekf_create, rekf_reserve)
     double *mu = nullptr, *mu_out = nullptr, *P = nullptr, *HPt = nullptr, *Kn = nullptr, *dev_pred = nullptr, *dev_mu_lin = nullptr,
            *dev_ell = nullptr;
@@ -751,6 +764,7 @@ int rekf_get_state(rekf_t *h, double *t, int *n_out, double *mu, long mu_cap, do
                                     sizeof(double) * n, n, hipMemcpyDeviceToHost, h->stream));
     }
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (sigma) mirror_lower(sigma, n);
     return REKF_OK;
 }
 
@@ -781,7 +795,7 @@ int rekf_set_state(rekf_t *h, double t, int n, const double *mu, const double *s
     h->last_scan_empty = false;
     if (vt3) { h->vt[0] = vt3[0]; h->vt[1] = vt3[1]; h->vt[2] = vt3[2]; }
     for (int q = 0; q < 3; ++q) h->mir_mu[q] = mu[q];
-    for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) h->mir_P[i + 3 * j] = sigma[i + (size_t)j * n];
+    for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) h->mir_P[i + 3 * j] = rekf_plower(sigma, n, i, j);   // (the lower triangle is what counts)
     h->mir_valid = true;
     return REKF_OK;
 }
@@ -868,6 +882,7 @@ int rekf_predict_state_full(rekf_t *h, double t, double *time_out, int *n_out, d
     const double *row0 = pred.data(), *row1 = row0 + ld, *col0 = row1 + ld, *col1 = col0 + ld;
     if (mu) for (int i = 0; i < 3; ++i) mu[i] = m3[i];
     if (sigma) {
+        mirror_lower(sigma, n);
         for (int c = 3; c < n; ++c) {
             sigma[0 + (size_t)c * n] = row0[c]; sigma[1 + (size_t)c * n] = row1[c];
             sigma[c + (size_t)0 * n] = col0[c]; sigma[c + (size_t)1 * n] = col1[c];

@@ -426,18 +426,25 @@ def test_pose_published_by_the_chain_equals_the_state(oracle_lib):
 
 
 def test_set_state_get_state_round_trip_and_two_handles():
+    """The device keeps the covariance as its LOWER triangle (column-major, Eigen's order): what comes back is the lower triangle
+    of what went in, mirrored.  The witness element sits below the diagonal, so a transposed upload / download would show."""
     rng = np.random.default_rng(0)
     n = 3 + 2 * 20
     A = rng.normal(size=(n, n))
     P = A @ A.T * 1e-3
-    P[0, 5] += 1e-9                      # deliberately NOT symmetric: layout/transposition witness
+    P[5, 0] += 1e-9                      # deliberately NOT symmetric: layout/transposition witness (kept: it is below the diagonal)
+    P[1, 7] += 1e-9                      # ... and one above the diagonal, which the filter never looks at
     mu = rng.normal(size=n)
     g1, g2 = _simple(cap=32), _simple(cap=24)
     g1.set_state(3.5, mu, P, (0.1, 0.0, 0.2))
     g2.set_state(1.5, 2 * mu, 2 * P)
     s1, s2 = g1.GetState(), g2.GetState()
-    assert s1.time == 3.5 and np.array_equal(s1.mu, mu) and np.array_equal(s1.sigma, P)
-    assert np.array_equal(s2.mu, 2 * mu) and np.array_equal(s2.sigma, 2 * P)
+    Pl = np.tril(P) + np.tril(P, -1).T
+    assert Pl[0, 5] == P[5, 0] != P[0, 5] and Pl[1, 7] == P[7, 1] != P[1, 7]
+    assert s1.time == 3.5 and np.array_equal(s1.mu, mu) and np.array_equal(s1.sigma, Pl)
+    assert np.array_equal(s2.mu, 2 * mu) and np.array_equal(s2.sigma, 2 * Pl)
+    t, mu3, s3 = g1.pose()
+    assert np.array_equal(mu3, mu[:3]) and np.array_equal(s3, Pl[:3, :3])
 
 
 def test_c_abi_direct_calls_reject_bad_arguments():
