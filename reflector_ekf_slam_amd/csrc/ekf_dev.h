@@ -102,8 +102,9 @@ struct RekfDev {
                         // mean, the 3 x 3 pose block, n and the flags ...
     int pub_seq;        //   ... under this tag, so that GetPose / Sync after the call need no kernel of their own
     int pub_aug;        //   ... and a k_augment follows: the n to publish is n + 2 ctl->n_new (neither pose nor pose block change there)
-    int dd_per;         // k_downdate2, class B: tiles per workgroup (set by rekf_launch_downdate; 0: the kernel divides the tiles itself)
-    int dd_sub;         // k_downdate2: class B holds the tiles with I >= J + dd_sub (2: a class-A workgroup also takes the tile below its diagonal tile; 1: it does not)
+    int dd_lo, dd_x;    // k_downdate2, class B: tiles per workgroup -- dd_lo each, the first dd_x workgroups one more (set by rekf_launch_downdate)
+    int dd_sub;         // k_downdate2: class B holds the tiles with I >= J + dd_sub (2: a class-A workgroup also takes the tile below its
+                        // diagonal tile; 1: it does not; 0: the host does not know n exactly -- the kernel derives the schedule itself)
     int kc_ub;          // host bound of m_pad for the current scan, rounded up to 16 (0: unknown); columns [m, kc_ub) of HPt / Kn are zero
 };
 

@@ -1326,22 +1326,22 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     // (When class B gets fewer than three tiles per workgroup -- small states -- class A keeps to its diagonal tile and the tiles
     // below the diagonal join class B: dd_sub = 1.)
     const bool classA = w < T;
-    // tiles per class-B workgroup: from the host when it knows n exactly (no division in the prologue), else derived here from
-    // the real T and the grid the host sized by its bound of n (downdate_schedule below, same arithmetic)
-    int sub = (d.dd_sub == 1) ? 1 : 2, per = d.dd_per;
-    if (per <= 0) {
+    // class B: every free workgroup takes tiles -- lo each, the first x of them one more (2 or 3 at T = 32: 465 tiles on 224
+    // workgroups; round 2 gave three tiles to 155 workgroups and left 69 CUs idle).  (lo, x) come from the host when it knows n
+    // exactly (no division in the prologue), else they are derived here from the real T and the grid the host sized by its
+    // bound of n (downdate_schedule below, same arithmetic)
+    int sub = (d.dd_sub == 1) ? 1 : 2, lo = d.dd_lo, xhi = d.dd_x;
+    if (d.dd_sub == 0) {
         const unsigned room = (unsigned)((nw - T > 1) ? nw - T : 1);
         unsigned nBq = (unsigned)((T - 1) * (T - 2) / 2);
         sub = 2;
-        per = (int)((nBq + room - 1) / room);
-        if (per < 3) { sub = 1; nBq = (unsigned)(T * (T - 1) / 2); per = (int)((nBq + room - 1) / room); }
-        if (per < 1) per = 1;
+        if ((nBq + room - 1) / room < 3) { sub = 1; nBq = (unsigned)(T * (T - 1) / 2); }
+        lo = (int)(nBq / room); xhi = (int)(nBq - (unsigned)lo * room);
     }
-    const int nB = (T - sub + 1) * (T - sub) / 2;                  // class B: its tiles
-    const int ntiles = nB;
     const int wq = w - T;
-    const int t_begin = classA ? 0 : min(wq * per, ntiles);
-    const int t_end = classA ? ((sub == 2 && w + 1 < T) ? 2 : 1) : min((wq + 1) * per, ntiles);
+    const int nB = (T - sub + 1) * (T - sub) / 2;                  // class B: its tiles (the ranges are clamped to them whatever the host planned)
+    const int t_begin = classA ? 0 : min(wq * lo + min(wq, xhi), nB);
+    const int t_end = classA ? ((sub == 2 && w + 1 < T) ? 2 : 1) : min(wq * lo + min(wq, xhi) + lo + (wq < xhi ? 1 : 0), nB);
     if (t_begin >= t_end) return;
     const int nt = t_end - t_begin;
     const size_t ld = (size_t)d.ld;
@@ -1411,12 +1411,13 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     static_assert(2 * DD_STRIP_MAX * 32 <= 256, "one pass of the strip mapping");
 
     D2MARK();                                // 0: ctl read, tile assignment done
-    // ---- prologue: border rows, both panels of tile 0 by DMA, its P block
-    if (strips) {
-        const v2d b0 = ((const v2d *)d.KnB)[tid], b1 = ((const v2d *)d.HPtB)[tid];
-        ((v2d *)&s_border[0][0][0])[tid] = b0;                     // s_border[0] = Kn rows nb.., [1] = HPt rows nb..
-        ((v2d *)&s_border[1][0][0])[tid] = b1;
-    }
+    // ---- prologue: border rows, both panels of tile 0 by DMA, its P block.  Only a class-A workgroup (the one with a diagonal
+    // tile) needs the border rows, and their way into LDS must not stand in front of the DMA: the loads go out first, the
+    // ds_writes wait behind the DMA issue (round 2 had load -> wait -> ds_write -> DMA: a whole memory round trip, for every
+    // workgroup, before its first panel was even requested)
+    v2d bdr0 = {0, 0}, bdr1 = {0, 0};
+    const bool want_border = strips && classA;
+    if (want_border) { bdr0 = ((const v2d *)d.KnB)[tid]; bdr1 = ((const v2d *)d.HPtB)[tid]; }
 #pragma unroll
     for (int q = 0; q < ND; ++q) dma_piece(Kn, DT * I, 0, q);
 #pragma unroll
@@ -1434,6 +1435,10 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
         for (int q = 0; q < 8; ++q) pq[NB - 2][q] = *(const v2d *)(Pw + (size_t)(8 * (q & 3) + (q >> 2)) * ld);
         dd_wait_vmcnt<16>();                 // the DMAs (and everything before them); the 16 P loads may still fly
     } else dd_wait_vmcnt<8>();
+    if (want_border) {                       // (older than the DMAs: arrived)
+        ((v2d *)&s_border[0][0][0])[tid] = bdr0;                   // s_border[0] = Kn rows nb.., [1] = HPt rows nb..
+        ((v2d *)&s_border[1][0][0])[tid] = bdr1;
+    }
     lds_barrier();
     D2MARK();                                // 1: panels of tile 0 landed
 
@@ -1866,15 +1871,15 @@ template <int KC> static void launch_downdate2(const RekfDev &d, int grid, hipSt
 }
 // host half of the tile schedule (tests/test_downdate_schedule_cpu.py restates it): T class-A workgroups (diagonal tile + the
 // one below) + equal ranges of the rest
-static void downdate_schedule(int n_ub, int slots, int &grid, int &dd_per, int &dd_sub)
+static void downdate_schedule(int n_ub, int slots, int &grid, int &dd_lo, int &dd_x, int &dd_sub)
 {
-    const int T = (n_ub + DT - 1) / DT;
+    const int T = (rekf_strip_base(n_ub) >= 0) ? n_ub / DT : (n_ub + DT - 1) / DT;      // the kernel's own T: a thin border rides on the diagonal tiles as strips
     const int room = (slots - T > 1) ? slots - T : 1;
-    int nB = (T - 1) * (T - 2) / 2, per = (nB + room - 1) / room;
+    int nB = (T - 1) * (T - 2) / 2;
     dd_sub = 2;
-    if (per < 3) { dd_sub = 1; nB = T * (T - 1) / 2; per = (nB + room - 1) / room; }   // small states: a class-A workgroup keeps to its diagonal tile
-    dd_per = per > 0 ? per : 1;
-    grid = T + (nB > 0 ? (nB + per - 1) / per : 0);
+    if ((nB + room - 1) / room < 3) { dd_sub = 1; nB = T * (T - 1) / 2; }   // small states: a class-A workgroup keeps to its diagonal tile
+    dd_lo = nB / room; dd_x = nB - dd_lo * room;          // the first dd_x class-B workgroups take dd_lo + 1 tiles, the others dd_lo
+    grid = T + (dd_lo > 0 ? room : dd_x);
     if (grid >= 64) grid = (grid + 7) & ~7;         // multiple of 8 for the per-XCD numbering (workgroups past the last range return at once)
 }
 void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s)
@@ -1895,15 +1900,15 @@ void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s)
         n_cu_of[slot] = cu;
         attr_done[slot] = 0;
     }
-    int grid, dd_per, dd_sub;
-    downdate_schedule(n_ub, n_cu_of[slot] * DD_WG_PER_CU, grid, dd_per, dd_sub);
+    int grid, dd_lo, dd_x, dd_sub;
+    downdate_schedule(n_ub, n_cu_of[slot] * DD_WG_PER_CU, grid, dd_lo, dd_x, dd_sub);
     const int kc = (d.kc_ub < 16) ? 16 : ((d.kc_ub > 64) ? 64 : d.kc_ub);    // one k-chunk: the host never asks for more than 64 rows per step
     const unsigned bit = 1u << (kc / 16);
     const bool first = !(attr_done[slot] & bit) || dev != slot;
     attr_done[slot] |= bit;
     RekfDev dp = d;
-    dp.dd_per = dd_per; dp.dd_sub = dd_sub;
-    if (d.n_known < 0) { dp.dd_per = 0; dp.dd_sub = 0; }          // n_ub is only a bound: the kernel derives the schedule from the real n
+    dp.dd_lo = dd_lo; dp.dd_x = dd_x; dp.dd_sub = dd_sub;
+    if (d.n_known < 0) { dp.dd_lo = 0; dp.dd_x = 0; dp.dd_sub = 0; }   // n_ub is only a bound: the kernel derives the schedule from the real n
     if (kc == 64) launch_downdate2<64>(dp, grid, s, first);
     else if (kc == 48) launch_downdate2<48>(dp, grid, s, first);
     else if (kc == 32) launch_downdate2<32>(dp, grid, s, first);

@@ -10,23 +10,32 @@ import pytest
 
 
 def host_plan(T, slots=256):
-    """rekf_launch_downdate, persistent lower-triangle form: (grid, dd_per, dd_sub)."""
+    """downdate_schedule (csrc/ekf_kernels.hip): (grid, lo, x, sub) -- class-B workgroups take lo tiles, the first x one more."""
     room = slots - T if slots - T > 1 else 1
     nB = (T - 1) * (T - 2) // 2
-    per = (nB + room - 1) // room
     sub = 2
-    if per < 3:
+    if (nB + room - 1) // room < 3:
         sub = 1
         nB = T * (T - 1) // 2
-        per = (nB + room - 1) // room
-    per = per if per > 0 else 1
-    grid = T + ((nB + per - 1) // per if nB > 0 else 0)
+    lo, x = nB // room, nB % room
+    grid = T + (room if lo > 0 else x)
     if grid >= 64:
         grid = (grid + 7) & ~7
-    return grid, per, sub
+    return grid, lo, x, sub
 
 
-def device_tiles(T, grid, per, sub, block):
+def kernel_plan(T, grid):
+    """What k_downdate2 derives itself when the host only has a bound of n (dd_sub = 0)."""
+    room = grid - T if grid - T > 1 else 1
+    nB = (T - 1) * (T - 2) // 2
+    sub = 2
+    if (nB + room - 1) // room < 3:
+        sub = 1
+        nB = T * (T - 1) // 2
+    return nB // room, nB % room, sub
+
+
+def device_tiles(T, grid, lo, x, sub, block):
     """Tiles of workgroup `block`, in processing order."""
     w = block
     if grid >= 8 and grid % 8 == 0:
@@ -40,7 +49,9 @@ def device_tiles(T, grid, per, sub, block):
     TT = T - sub
     nB = (T - sub + 1) * (T - sub) // 2
     wq = w - T
-    t0, t1 = min(wq * per, nB), min((wq + 1) * per, nB)
+    t0 = wq * lo + min(wq, x)
+    t1 = t0 + lo + (1 if wq < x else 0)
+    t0, t1 = min(t0, nB), min(t1, nB)
     if t0 >= t1:
         return []
     # cursor seeded by the closed form, then walked (tri_IJ)
@@ -63,11 +74,13 @@ def device_tiles(T, grid, per, sub, block):
 @pytest.mark.parametrize("slots", [256, 304, 64])
 def test_every_lower_triangle_tile_exactly_once(slots):
     for T in range(1, 65):
-        grid, per, sub = host_plan(T, slots)
+        grid, lo, x, sub = host_plan(T, slots)
         seen = {}
+        busy = 0
         for b in range(grid):
-            tl = device_tiles(T, grid, per, sub, b)
-            assert len(tl) <= max(per, 2), (T, b, tl)
+            tl = device_tiles(T, grid, lo, x, sub, b)
+            busy += bool(tl)
+            assert len(tl) <= max(lo + 1, 2), (T, b, tl)
             diag = [t for t in tl if t[0] == t[1]]
             assert len(diag) <= 1 and (not diag or tl[-1] == diag[0]), (T, b, tl)      # the diagonal tile comes last
             for t in tl:
@@ -75,16 +88,20 @@ def test_every_lower_triangle_tile_exactly_once(slots):
                 seen[t] = b
         want = {(i, j) for i in range(T) for j in range(i + 1)}
         assert set(seen) == want, (T, sorted(want - set(seen))[:5], sorted(set(seen) - want)[:5])
+        if T >= 24 and slots >= T + 8:
+            assert busy >= min(slots, len(want) // 2) - 8, (T, busy)                   # no CU is left idle once there is work for all
 
 
 def test_host_bound_of_T_may_exceed_the_kernels():
-    """The host sizes the grid from an upper bound of n (T_host >= T_kernel): the kernel's own T must still be covered."""
+    """The host sizes the grid from an upper bound of n (T_host >= T_kernel) and then passes no schedule: the kernel derives
+    (lo, x, sub) from its own T and the grid it finds; its own T must still be covered exactly once."""
     for T_k in range(1, 40):
-        for T_h in (T_k, T_k + 1):
-            grid, per, sub = host_plan(T_h)
+        for T_h in (T_k, T_k + 1, T_k + 7, 2 * T_k):
+            grid, _, _, _ = host_plan(T_h)
+            lo, x, sub = kernel_plan(T_k, grid)
             seen = set()
             for b in range(grid):
-                for t in device_tiles(T_k, grid, per, sub, b):
+                for t in device_tiles(T_k, grid, lo, x, sub, b):
                     assert t not in seen
                     seen.add(t)
             assert seen == {(i, j) for i in range(T_k) for j in range(i + 1)}, (T_k, T_h)
