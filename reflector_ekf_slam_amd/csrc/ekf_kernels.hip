@@ -983,6 +983,10 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
     __syncthreads();
     MMARK();                                        // 2: H rows and raw P in LDS
 
+    // (phase E multiplies the landmark rows of W of a CLAMPED pair by the zero coefficients of rows that have no landmark block:
+    // with no state pair at all -- a scan that matched the pre-loaded map only -- that pair does not exist, and whatever the
+    // last kernel left in LDS there must not be a NaN)
+    if (NS == 0 && tid < MP) { s_wcp[0][tid][0] = 0.0; s_wcp[0][tid][1] = 0.0; }
     // ---- D: form W (rows of S, own rows) and (H P)^T (own columns) out of LDS.
     // Same operation order as k_gather: v = p0 h0; v += p1 h1; v += p2 h2; v += pl0 g0; v += pl1 g1
     const int nq = m_pad / 2;                        // row pairs, pad rows included (their H rows are zero)

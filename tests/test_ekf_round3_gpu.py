@@ -332,3 +332,29 @@ def test_c3_map_build_checkpoints_match_the_oracle(oracle_lib):
                 o = None
     assert grew > 0                                          # the windows did include augment steps
     assert g.n == 3 + 2 * cfg.n_landmarks and g.sync_code() == 0
+
+
+# ---------------------------------------------------------------------------------------------- map-only localisation
+def test_localisation_against_a_preloaded_map_only(oracle_lib):
+    """Every observation matches the pre-loaded map (cc:401-425) and none enters the state (n stays 3): the update has no state
+    pair at all.  (Found by the config-1 harness in round 3: k_mid multiplied an uninitialised LDS row by zero coefficients.)"""
+    cfg = synth.SessionConfig("maponly", 30, 10, synth.DIFF, seed=8, speed=1.0, row_spacing=6.0)
+    sess = synth.make_session(cfg, max_scans=60)
+    lin, ang, obs = cfg.sigma_v ** 2, cfg.sigma_w ** 2, cfg.sigma_obs ** 2
+    g = make_gpu(cfg.odom_model, sess.init_time, sess.init_pose, lin, ang, obs, 8)
+    o = make_oracle(cfg.odom_model, sess.init_time, sess.init_pose, lin, ang, obs)
+    mxy = sess.landmarks.astype(np.float32)
+    mcov = np.tile(np.array([0.01, 0.0, 0.0, 0.01]), (mxy.shape[0], 1))
+    g.set_map(mxy, mcov); o.set_map(mxy, mcov)
+    seen = [0]
+
+    def chk(e, k):
+        assert _same_match(g, o), f"association differs at scan {k}"
+        seen[0] += norm_match(g.last_match())[1].shape[0]
+        assert np.abs(g.mu() - o.mu()).max() < TIGHT
+
+    drive_pair(sess, g, o, chk)
+    assert g.n == o.n == 3 and seen[0] > 100 and g.sync_code() == 0
+    st = g.GetState()
+    mo, Po = o.state()
+    assert np.abs(st.sigma - Po).max() < 1e-12
