@@ -150,6 +150,8 @@ __device__ static R2f r2_cast(R2d r)
 {
     R2f o; o.x = (float)r.x; o.y = (float)r.y; o.a = (float)r.a; return o;
 }
+#include "glibc_sincosf.h"     // float32 sin / cos with the host libm's bits (the reference calls std::sin / std::cos on floats)
+
 __device__ static float2 r2f_apply_cs(float c, float s, float tx, float ty, float px, float py)
 {
 #pragma clang fp contract(off)
@@ -161,7 +163,7 @@ __device__ static float2 r2f_apply_cs(float c, float s, float tx, float ty, floa
 __device__ static float2 r2f_apply(R2f r, float px, float py)
 {
     float s, c;
-    sincosf(r.a, &s, &c);
+    glibc_sincosf(r.a, &s, &c);
     return r2f_apply_cs(c, s, r.x, r.y, px, py);
 }
 
@@ -302,7 +304,7 @@ __device__ static void det2d_beams(const Det2dArgs &A, const Det2dBufs &B, const
         const R2d inv = r2_inverse_cs(c, s, mtp);
         const R2f tb = r2_cast(inv);
         float tc, ts;
-        sincosf(tb.a, &ts, &tc);
+        glibc_sincosf(tb.a, &ts, &tc);
         if (lane == 0) {
             s_inv[0] = inv.x; s_inv[1] = inv.y; s_inv[2] = inv.a; s_inv[3] = c; s_inv[4] = -s;
             s_tb[0] = tb.x; s_tb[1] = tb.y; s_tb[2] = tc; s_tb[3] = ts;
@@ -354,7 +356,7 @@ __device__ static void det2d_beams(const Det2dArgs &A, const Det2dBufs &B, const
             const float a_next = ahead == 1 ? ang_ahead[0] : ahead == 2 ? ang_ahead[1] : ang_ahead[2];
             const float angle_gap = a_next - A.angle_increment * (float)ahead;      // :117
             float gs, gc;
-            sincosf(angle_gap, &gs, &gc);
+            glibc_sincosf(angle_gap, &gs, &gc);
             p = r2f_apply_cs(A.s2b_c, A.s2b_s, A.s2b_x, A.s2b_y, rgj * gc, rgj * gs);
         }
         if (has) {

@@ -16,8 +16,8 @@ n2d = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 n3d = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 TOL = 1e-5
 fails = []
-worst2 = worst3 = 0.0
-refl2 = refl3 = 0
+worst2 = worst3 = worst_ret2 = 0.0
+refl2 = refl3 = exact2 = far2 = 0
 for seed in range(n2d):
     rng = np.random.Generator(np.random.PCG64(5000 + seed))
     lms = synth.make_world(synth.C2, rng)
@@ -38,9 +38,13 @@ for seed in range(n2d):
     o2 = OracleDetect2D(sensor_to_base_link=S2B)
     g = LaserReflectorDetect(ReflectorDetectOptions(), max_beams=8192, sensor_to_base_link=S2B)   # fresh odometry deque per scan
     if rng.random() < 0.6:
+        # every third odometer runs far from its origin (|coordinates| > 128 m: the reference's float32 Rigid2f then carries
+        # 1.5e-5 m per ulp through the de-skew -- both sides must still agree bit for bit)
+        ox, oy = (float(rng.uniform(150, 400)), float(rng.uniform(-400, -150))) if seed % 3 == 0 else (0.0, 0.0)
+        far2 += seed % 3 == 0
         for (t, px, py, qz, qw, vx, vy, wz) in odom_stream(sc.stamp - 0.3, sc.stamp + 0.05, v=float(rng.uniform(0, 2)), w=float(rng.uniform(-1, 1))):
-            g.HandleOdometryData(OdometryData(t, (vx, vy, 0.0), (0.0, 0.0, wz), (px, py, 0.0), (qw, 0.0, 0.0, qz)))
-            o2.handle_odometry(t, px, py, qz, qw, vx, vy, wz)
+            g.HandleOdometryData(OdometryData(t, (vx, vy, 0.0), (0.0, 0.0, wz), (px + ox, py + oy, 0.0), (qw, 0.0, 0.0, qz)))
+            o2.handle_odometry(t, px + ox, py + oy, qz, qw, vx, vy, wz)
     obs = g.HandleLaserScan(LaserScan(sc.stamp, sc.angle_min, sc.angle_max, sc.angle_increment, sc.scan_time, sc.range_min, sc.range_max,
                                       sc.ranges, sc.intensities))
     t, c = o2.handle_scan(sc)
@@ -49,7 +53,9 @@ for seed in range(n2d):
     if ok and c.size:
         d = float(np.abs(obs.cloud_ - c).max()); worst2 = max(worst2, d); ok = d < TOL
     if ok and ro.size:
-        ok = float(np.abs(rg - ro).max()) < 2e-5 * max(1.0, float(np.abs(ro).max()))
+        dr = float(np.abs(rg - ro).max()); worst_ret2 = max(worst_ret2, dr)
+        ok = dr < 2e-5 * max(1.0, float(np.abs(ro).max()))
+    exact2 += bool(ok and np.array_equal(obs.cloud_, c) and np.array_equal(rg, ro))
     refl2 += c.shape[0]
     if not ok:
         fails.append({"kind": "2d", "seed": seed, "beams": nb, "gpu": list(obs.cloud_.shape), "oracle": list(c.shape)})
@@ -81,4 +87,5 @@ for seed in range(n3d):
 for f in fails:
     print(json.dumps(f))
 print(json.dumps({"summary": True, "scans_2d": n2d, "clouds_3d": n3d, "failed": len(fails), "reflectors_2d": refl2, "clusters_3d": refl3,
-                  "worst_centre_diff_2d_m": worst2, "worst_centre_diff_3d_m": worst3}))
+                  "worst_centre_diff_2d_m": worst2, "worst_return_diff_2d_m": worst_ret2, "scans_2d_bit_identical": exact2,
+                  "scans_2d_with_far_odometry": int(far2), "worst_centre_diff_3d_m": worst3}))

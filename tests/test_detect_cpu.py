@@ -151,3 +151,26 @@ def test_detect3d_world_cloud(oracle_lib):
     gt = np.stack([cc * rel[:, 0] + ss * rel[:, 1], -ss * rel[:, 0] + cc * rel[:, 1]], -1)
     d = np.linalg.norm(gt[None] - c[:, None], axis=-1).min(1)
     assert c.shape[0] >= 40 and d.max() < 0.05 and m2 < m1        # the planted outliers are gone
+
+
+def test_device_sincosf_restatement_equals_the_host_libm_bit_for_bit(tmp_path):
+    """csrc/glibc_sincosf.h is what the 2D detector's kernels evaluate float32 sin / cos with: glibc's own algorithm (Arm Optimized
+    Routines), FMA build.  Compiled for the HOST here and compared with the host's sinf / cosf on 6e6 arguments up to |x| = 110:
+    zero mismatches, which is what makes the detector's centres bit-identical to the CPU oracle's (tests/test_detect_gpu.py).
+    Needs a CPU with FMA (glibc's ifunc then runs the same fused sequence); skipped otherwise."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    try:
+        if " fma " not in open("/proc/cpuinfo").read().replace("\n", " "):
+            pytest.skip("host CPU without FMA: glibc takes its non-fused path")
+    except OSError:
+        pass
+    exe = str(tmp_path / "sincosf_check")
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-I", os.path.join(root, "reflector_ekf_slam_amd", "csrc"),
+                    os.path.join(root, "tests", "cpp", "sincosf_check.cpp"), "-o", exe, "-lm"], check=True)
+    bad_s, bad_c, n = (int(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split())
+    assert n == 6000000 and bad_s == 0 and bad_c == 0

@@ -1,7 +1,8 @@
 """GPU suite for the 2D/3D reflector detectors: the HIP path through the C ABI (librdet.so)
-against the CPU oracle on the same scans.  Run membership / reflector count must be IDENTICAL;
-centres and de-skewed returns agree to float32 round-off (device cosf/sinf of per-point angles
-differ from glibc's in the last bit): tolerance 1e-5 m, the north-star bar."""
+against the CPU oracle on the same scans.  2D: centres and de-skewed returns are BIT-IDENTICAL to the oracle's
+(since round 3 the device evaluates float32 sin / cos with glibc's own algorithm, csrc/glibc_sincosf.h; the host must have
+FMA, as every x86-64-v3 CPU does, for its libm to take the same path).  3D: identical clusters in identical order; TOL (the
+north-star 1e-5 m) is what the 3D centres and the pipeline tests are held to."""
 import math
 
 import numpy as np
@@ -39,13 +40,10 @@ def _compare(g, o, sc, check_returns=True):
     t, c = o.handle_scan(sc)
     assert obs.time_ == t
     assert obs.cloud_.shape == c.shape, (obs.cloud_.shape, c.shape)
-    if c.size:
-        assert np.abs(obs.cloud_ - c).max() < TOL
+    assert np.array_equal(obs.cloud_, c), float(np.abs(obs.cloud_ - c).max())          # bit for bit
     if check_returns:
         rg, ro = g.GetRangeData().returns, o.returns()
-        assert rg.shape == ro.shape
-        if ro.size:
-            assert np.abs(rg - ro).max() < 2e-5 * max(1.0, float(np.abs(ro).max()))
+        assert rg.shape == ro.shape and np.array_equal(rg, ro)
     return obs
 
 
@@ -200,13 +198,13 @@ def test_detector_feeds_the_filter_end_to_end(oracle_lib):
                                                                          n_beams=2880))
         og = g.HandleLaserScan(_scan_msg(sc))
         to, co = o.handle_scan(sc)
-        assert og.cloud_.shape == co.shape and np.abs(og.cloud_ - co).max() < TOL
+        assert og.cloud_.shape == co.shape and np.array_equal(og.cloud_, co)
         if first:
             first = False
             continue
         fg.handle_observation(og.time_, og.cloud_[:64]); fo.handle_observation(to, co[:64])
     assert fg.n == fo.n and fg.n > 3 + 2 * 10
-    assert np.abs(fg.mu() - fo.mu()).max() < 1e-4          # detector float32 round-off propagates (1e-6 m inputs)
+    assert np.abs(fg.mu() - fo.mu()).max() < 1e-9          # identical observations in: the filters agree to FP64 round-off
 
 
 # ---------------------------------------------------------------------------- 3D detector
