@@ -58,6 +58,8 @@ struct Det2dArgs {
     double first_point_time, point_delta_t;
     int N, is_circle, max_centers;
     int seq;                       // call number: written to Det2dOut::seq when the centres are in host memory
+    unsigned done_target;          // value the monotonic counter of published per-beam workgroups reaches with THIS scan (the counter is
+                                   // never reset by the kernel: a straggler of a scan that timed out cannot satisfy the next scan's wait)
     // sensor_to_base_link as Rigid2f + host-evaluated cos/sin of its angle
     float s2b_x, s2b_y, s2b_a, s2b_c, s2b_s;
     // pose extrapolator state: 0, 1 or 2 samples (front, back)
@@ -560,7 +562,7 @@ __device__ static void det2d_runs(const Det2dArgs &A, const Det2dBufs &B, const 
         DMARK(7);
         // the per-beam workgroups' results (bounded wait: a lost workgroup becomes an error, not a hang)
         const unsigned long long t0 = __builtin_readcyclecounter();
-        while (__hip_atomic_load(B.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_beam_groups) {
+        while ((int)((unsigned)__hip_atomic_load(B.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - A.done_target) < 0) {
             __builtin_amdgcn_s_sleep(1);
             if (__builtin_readcyclecounter() - t0 > 250000000ull) { err = RDET_ERR_HIP; K = 0; break; }   // ~0.1 s
         }
@@ -639,7 +641,6 @@ __device__ static void det2d_runs(const Det2dArgs &A, const Det2dBufs &B, const 
     stores_landed();
     __syncthreads();
     if (tid == 0) {
-        __hip_atomic_store(B.done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         stores_landed();
         __hip_atomic_store(&B.out->fin, A.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (the per-beam workgroups were done before the sums)
     }
@@ -666,6 +667,7 @@ struct rdet2d {
     float2 *d_returns;
     unsigned long long *d_returns_all, *d_contrib, *d_cmask;
     int *d_done;
+    unsigned done_total = 0;           // per-beam workgroups launched so far (the device counter catches up with it)
     int seq;                           // scans launched; Det2dOut::seq catches up when a scan's centres are in host memory
     // pinned host memory the kernel reads / writes in place
     float *h_scan;                     // ranges | intensities: where the host writes a scan.  Fine-grained DEVICE memory through
@@ -817,6 +819,8 @@ int rdet2d_handle_scan(rdet2d_t *h, double stamp, float angle_min, float angle_m
     A.first_point_time = last_point_time - scan_time;                           // :50
     A.N = N;
     A.seq = ++h->seq;
+    h->done_total += (unsigned)((N + RDET2D_GROUP - 1) / RDET2D_GROUP);
+    A.done_target = h->done_total;
     A.is_circle = ((angle_max - angle_min - 2 * M_PI) < 1e-6) ? 1 : 0;          // :55
     A.max_centers = max_centers < RDET_MAX_CENTERS ? max_centers : RDET_MAX_CENTERS;
     A.s2b_x = (float)h->s2b[0]; A.s2b_y = (float)h->s2b[1]; A.s2b_a = (float)h->s2b[2];   // :54
@@ -896,6 +900,11 @@ int rdet2d_handle_scan(rdet2d_t *h, double stamp, float angle_min, float angle_m
     const Det2dHead head = h->h_out->head;
     h->last_n_returns = head.n_returns;
     const int err = -(head.runs_err >> 16);
+    if (err == RDET_ERR_HIP) {         // the kernel gave up waiting for its per-beam workgroups: drain, and start the counter afresh
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipMemset(h->d_done, 0, sizeof(int));
+        h->done_total = 0;
+    }
     if (err) return err;
     *K = head.K;
     for (int c = 0; c < head.K; ++c) {
