@@ -85,6 +85,9 @@ def parse_args(argv=None):
     ap.add_argument("--instr-steps", type=int, default=300, help="updates in the per-kernel hipEvent pass")
     ap.add_argument("--secondary", default="C2,C4", help="comma list of other BASELINE configs to also measure (rank 0, N=1)")
     ap.add_argument("--secondary-steps", type=int, default=1000)
+    ap.add_argument("--timed-only", action="store_true",
+                    help="map build, warm-up and the timed steps only (no instrumented legs): what scripts/gpu_profile_round.sh "
+                         "runs under rocprofv3, so that the LAST dispatches of every kernel are the timed region's")
     return ap.parse_args(argv)
 
 
@@ -208,7 +211,7 @@ def run_rank(args, dist_mod, rank, local_rank, world, make_filter=gpu_filter_fac
                   "updates_per_s_max": rates[-1], "final_n": [int(r["final_n"]) for r in recs],
                   "seeds": [int(r["seed"]) for r in recs]},
     }
-    if not full:
+    if not full or args.timed_only:
         return out
     rest = steady[used:]
     out.update(instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, local_rank, world))
@@ -313,9 +316,9 @@ def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world):
     dd_us = ekf.time_kernel("downdate", reps=max(args.steps, 200))
 
     bytes_full = 16.0 * n * n + 8.0 * n * (3 + m)         # SURVEY.md 8(d) BYTES_alg(n, m): every element of P read and written once
-    # what the EXECUTED algorithm must move (SURVEY 8(d) for a lower-triangular builder): lower triangle read, all of P
-    # written (the mirror image is part of the product's layout), the panels once
-    bytes_exec = 8.0 * (n * (n + 1) / 2.0) + 8.0 * n * n + 8.0 * n * (3 + m)
+    # what the EXECUTED algorithm must move (SURVEY 8(d) for a lower-triangular builder): P is STORED as its lower triangle
+    # (round 3), so the triangle is read and written once, the panels once
+    bytes_exec = 2.0 * 8.0 * (n * (n + 1) / 2.0) + 8.0 * n * (3 + m)
     T = n // 64 if 0 < n % 64 <= 4 else -(-n // 64)
     tiles_exec = T * (T + 1) // 2
     flop_exec = tiles_exec * 2.0 * 64 * 64 * (16 * -(-m // 16))          # MFMA FLOP actually issued (16x16x4 tiles over the padded k range)
@@ -337,13 +340,17 @@ def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world):
         pass
     moved = (traffic / (dd_us * 1e-6) / 1e9) if traffic else None
     out["roofline"] = {
-        "kernel": "k_downdate2<64> (P -= K (H P): lower-triangle tiles by FP64 MFMA 16x16x4, mirrored stores)", "bound": "hbm",
-        "bytes_note": "achieved / frac = bytes the executed (lower-triangle + mirror) algorithm must move: 8 n(n+1)/2 read + 8 n^2 written "
+        "kernel": "k_downdate2<64> (P -= K (H P) on the lower triangle P is stored as: FP64 MFMA 16x16x4 tiles, panels by LDS DMA)", "bound": "hbm",
+        "bytes_note": "achieved / frac = bytes the executed lower-triangle algorithm must move: 2 * 8 n(n+1)/2 (triangle read and written) "
                       "+ 8 n (3+m) panels; frac_fullsquare = SURVEY 8(d)'s 16 n^2 + 8 n (3+m) over the same time (what a full-square "
-                      "kernel would have had to move); frac_moved = HBM bytes by PMC counters (committed summary) over the same time",
+                      "kernel would have had to move); frac_moved = HBM bytes by PMC counters (committed summary) over the same time; "
+                      "*_inchain = the same over the committed rocprofv3 average of the kernel INSIDE the update chain (its panels come "
+                      "fresh from k_mid; back to back they are L2-warm)",
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "frac_fullsquare": bytes_full / (dd_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
         "frac_moved": (moved / HBM_PEAK_GBS) if moved else None,
+        "frac_inchain": (bytes_exec / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if rocprof_us else None,
+        "frac_moved_inchain": (traffic / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if (traffic and rocprof_us) else None,
         "traffic": traffic, "traffic_source": traffic_src,
         "bytes_per_launch": bytes_exec, "bytes_per_launch_fullsquare": bytes_full, "avg_launch_us": dd_us,
         "avg_launch_us_method": "measured in this run: back-to-back launches between one hipEvent pair on the handle's stream",
@@ -352,6 +359,7 @@ def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world):
         "mfma": {"achieved_tflops": flop_exec / (dd_us * 1e-6) / 1e12, "peak_tflops": FP64_MFMA_PEAK_TF,
                  "frac": flop_exec / (dd_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF,
                  "frac_fullsquare_flop": flop_k7 / (dd_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF,
+                 "frac_inchain": (flop_exec / (rocprof_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF) if rocprof_us else None,
                  "note": f"frac = EXECUTED MFMA FLOP ({tiles_exec} lower-triangle tiles x 2*64*64*{16 * -(-m // 16)}) over the measured time; "
                          "frac_fullsquare_flop = the reference's 2 n^2 m over the same time (the mirrored kernel executes half of them)"}}
     out["kernel_us"] = kernel_us

@@ -31,10 +31,11 @@ def _check_contract(d, steps, warmup):
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "avg_launch_us_method"):
         assert k in r
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.1 < r["frac"] < 1.0
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.05 < r["frac"] < 1.0
     assert r["traffic"] is None or "NOT measured in this run" in r["traffic_source"]
     # honest accounting: frac counts what the lower-triangle algorithm must move; the full-square figure rides along
-    assert r["frac_fullsquare"] > r["frac"] and r["bytes_per_launch"] < r["bytes_per_launch_fullsquare"]
+    assert r["frac_fullsquare"] > 1.5 * r["frac"] and r["bytes_per_launch"] < 0.55 * r["bytes_per_launch_fullsquare"]   # triangle read + written
+    assert r["frac_inchain"] is None or 0.05 < r["frac_inchain"] <= r["frac"] * 1.3
     assert r["frac_moved"] is None or 0.05 < r["frac_moved"] < 1.0
     assert r["mfma"]["frac"] < r["mfma"]["frac_fullsquare_flop"] and 0.02 < r["mfma"]["frac"] < 1.0
     assert d["value"] > 5000                                                   # the north-star bar is 10 k; 20-step runs are noisy
