@@ -1264,13 +1264,21 @@ template <int N> __device__ static inline void dd_wait_vmcnt()
 // A diagonal tile computes all of its sums, adds them to its P block and then mirrors its own lower half into its upper half
 // (an LDS transpose of the RESULT: the values above the diagonal are written for free but never read back), so nothing ever
 // depends on two independently rounded halves -- the property that keeps the filter stable.
+#ifdef REKF_DEBUG_ENTRY
+__device__ long long g_dd_times[1024][2];
+extern "C" int rekf_debug_dd_times(long long *out, int n_wg)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dd_times), sizeof(long long) * 2 * (size_t)(n_wg < 1024 ? n_wg : 1024));
+}
+#endif
 template <int KC>
 __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
 {
     extern __shared__ __attribute__((aligned(16))) double dd_smem[];   // [Kn 0 | Kn 1 | HPt 0 | HPt 1] panels (+ 16 KiB strip scratch if KC < 64)
     __shared__ __attribute__((aligned(16))) double s_border[2][DD_STRIP_MAX][REKF_MR_PAD];
 #ifdef REKF_DEBUG_TIMING
-    long long tq2[24]; int nq2 = 0;
+    __shared__ long long tq2[24];          // (in LDS: a register array costs every thread 48 VGPRs and changes what is being measured)
+    int nq2 = 0;
 #ifdef REKF_DEBUG_DD2
 #ifndef REKF_DEBUG_DD2_BLOCK
 #define REKF_DEBUG_DD2_BLOCK 0
@@ -1286,13 +1294,8 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
 #define D2MARK()
 #endif
 #ifdef REKF_DEBUG_ENTRY
-    // entry / exit wall clock (100 MHz) of a few workgroups, release-build register footprint: dbg[8+k] / dbg[16+k]
-    int eslot = -1;
-    {
-        const int bs[8] = {0, 128, 255, 256, 300, 400, 495, 511};
-        for (int k = 0; k < 8; ++k) if ((int)blockIdx.x == bs[k]) eslot = k;
-    }
-    if (eslot >= 0 && threadIdx.x == 0) const_cast<RekfCtl *>(d.ctl)->dbg[8 + eslot] = wall_clock64();
+    // entry / exit wall clock (100 MHz) of EVERY workgroup, release-build register footprint (scripts/gpu_dbg_entry.py)
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_dd_times[blockIdx.x][0] = wall_clock64();
 #endif
     // With n known to the host nothing here depends on the control block: k_mid leaves zero panels behind a scan without
     // matches, so the kernel may run unconditionally and its first loads go out one memory round trip earlier.
@@ -1403,6 +1406,30 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     v4d acc[2][2];
     int I, J, kb = 0, hb = 0;
     tile_IJ(0, I, J);
+    // The tile list of a short range, ONCE, in scalar registers: the straight-line forms below index it with compile-time
+    // positions.  (Until round 3 every tile body looked its neighbours up through the cursor -- three look-ups per tile, each a
+    // pair of scalar loops -- and the serial scalar code between two MFMA loops cost a lone wave per SIMD most of a microsecond.)
+    int tI[4] = {I, I, I, I}, tJ[4] = {J, J, J, J};
+    if (nt <= 4) {
+        if (classA) { tI[1] = w; tI[2] = w; tI[3] = w; }                      // (w + 1, w) then (w, w), or (w, w) alone
+        else {
+            int ii = I - sub, jj = J;                                         // triangle coordinates: column jj holds ii = jj .. TT - 1
+#pragma unroll
+            for (int q = 1; q < 4; ++q) {
+                if (ii + 1 < TT) ++ii; else { ++jj; ii = jj; }
+                tI[q] = ii + sub; tJ[q] = jj;
+            }
+        }
+    }
+    // position -> tile: an integral_constant position reads the list, a run-time position (the generic loop) asks the cursor
+    auto coords = [&](auto pos_c, int &Iq, int &Jq) __attribute__((always_inline)) {
+        if constexpr (std::is_integral<decltype(pos_c)>::value) tile_IJ(pos_c, Iq, Jq);
+        else { constexpr int q = decltype(pos_c)::value; static_assert(q >= 0 && q < 4, "short ranges only"); Iq = tI[q]; Jq = tJ[q]; }
+    };
+    auto shift = [](auto pos_c, auto delta_c) __attribute__((always_inline)) {
+        if constexpr (std::is_integral<decltype(pos_c)>::value) return pos_c + decltype(delta_c)::value;
+        else return std::integral_constant<int, decltype(pos_c)::value + decltype(delta_c)::value>();
+    };
 
     // ---- border strips (see "Border strips" above): same scheme as before, on whichever tile is diagonal
     auto strip_addr = [&](int II, double *&p0, double *&p1, int &which, int &b, int &x) __attribute__((always_inline)) {
@@ -1452,7 +1479,10 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     // assume the fewest, and waited vmcnt(0) for a P block it had only just requested).  SPECIAL = diagonal tile that carries
     // the border strips; it prefetches no panels (its idle Kn buffer is the strip scratch), which costs nothing when it is
     // the last tile -- the usual case.
-    auto tile_body = [&](auto par_c, auto first_c, auto load2_c, auto last_c, auto special_c, int pos) __attribute__((always_inline)) {
+    auto tile_body = [&](auto par_c, auto first_c, auto load2_c, auto last_c, auto special_c, auto pos) __attribute__((always_inline)) {
+        using Plus1 = std::integral_constant<int, 1>;
+        using PlusA = std::integral_constant<int, AHEAD>;
+        using Minus1 = std::integral_constant<int, -1>;
         constexpr int PAR = decltype(par_c)::value, PREV = (PAR + AHEAD) % NB;   // PREV: tile pos-1's block = where tile pos+AHEAD's goes
         constexpr bool FIRST = decltype(first_c)::value, LOAD2 = decltype(load2_c)::value, LAST = decltype(last_c)::value,
                        SPECIAL = decltype(special_c)::value == 2,          // diagonal tile that carries the border strips
@@ -1460,12 +1490,12 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
         static_assert(!(LAST && LOAD2), "no tile after the last");
         static_assert(!DIAGSYM || LAST, "a diagonal tile ends its workgroup's range (class A)");
         int In = I, Jn = J;
-        if (!LAST) tile_IJ(pos + 1, In, Jn);
+        if constexpr (!LAST) coords(shift(pos, Plus1()), In, Jn);
         const bool needK = !LAST && In != I, needH = !LAST && Jn != J;
         const double *Pn = nullptr;                         // tile pos+2's P block
-        if (LOAD2) { int I2, J2; tile_IJ(pos + AHEAD, I2, J2); Pn = p_ptr(I2, J2); }
+        if constexpr (LOAD2) { int I2, J2; coords(shift(pos, PlusA()), I2, J2); Pn = p_ptr(I2, J2); }
         double *Po = nullptr;                               // where tile pos-1 goes
-        if (!FIRST) { int Ip, Jp; tile_IJ(pos - 1, Ip, Jp); Po = p_ptr(Ip, Jp); }
+        if constexpr (!FIRST) { int Ip, Jp; coords(shift(pos, Minus1()), Ip, Jp); Po = p_ptr(Ip, Jp); }
         const double *aW = hp_buf(hb) + 32 * wj + 2 * idx + kq * 64;        // A[j][k] = HP(k,j)
         const double *bK = kn_buf(kb) + 32 * wi + 2 * idx + kq * 64;        // B[k][i] = Kn(i,k)
 #pragma unroll
@@ -1493,6 +1523,9 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
                 a2n = *(const v2d *)(aW + (kk + 1) * 256);
                 b2n = *(const v2d *)(bK + (kk + 1) * 256);
             }
+            // the operand reads of step kk+1 are ISSUED before this step's MFMAs: without the fence hipcc gives a2n / b2n the registers
+            // of a2 / b2 and sinks the ds_reads below the MFMAs that still read them (seen in the ISA, round 3)
+            __builtin_amdgcn_sched_barrier(0);
             acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.x, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.x, b2.y, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2.y, b2.x, acc[1][0], 0, 0, 0);
@@ -1663,39 +1696,37 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     // one instantiation per position: with no loop and no join in the way, hipcc's s_waitcnt pass places every wait exactly
     // (through the generic loop below it merges the variants' states at the joins and waits for far younger loads than the
     // P block it needs).  A diagonal tile ends its (class A) range, so only the last position has the diagonal variants.
-    auto straight = [&](auto nt_c) __attribute__((always_inline)) {
+    // The two classes take separate code: class A ends on its diagonal tile (mirror, strips, publication), class B never sees one.
+    auto straight = [&](auto nt_c, auto cls_a) __attribute__((always_inline)) {
         constexpr int NT = decltype(nt_c)::value;
+        constexpr bool CLS_A = decltype(cls_a)::value;
         auto one = [&](auto pos_c) __attribute__((always_inline)) {
             constexpr int POS = decltype(pos_c)::value;
             using Par = std::integral_constant<int, POS % NB>;
             using First = std::integral_constant<bool, POS == 0>;
             using Load2 = std::integral_constant<bool, (POS + AHEAD < NT)>;
             using Last = std::integral_constant<bool, POS == NT - 1>;
-            if constexpr (POS == NT - 1) {
-                if (I == J) {
-                    if (strips) tile_body(Par(), First(), Load2(), Last(), C2(), POS);
-                    else tile_body(Par(), First(), Load2(), Last(), C1(), POS);
-                } else tile_body(Par(), First(), Load2(), Last(), C0(), POS);
-            } else tile_body(Par(), First(), Load2(), Last(), C0(), POS);
+            if constexpr (POS == NT - 1 && CLS_A) {
+                if (strips) tile_body(Par(), First(), Load2(), Last(), C2(), pos_c);
+                else tile_body(Par(), First(), Load2(), Last(), C1(), pos_c);
+            } else tile_body(Par(), First(), Load2(), Last(), C0(), pos_c);
         };
         one(std::integral_constant<int, 0>());
         if constexpr (NT > 1) one(std::integral_constant<int, 1>());
         if constexpr (NT > 2) one(std::integral_constant<int, 2>());
         if constexpr (NT > 3) one(std::integral_constant<int, 3>());
     };
-    if (nt <= 4) {
-        if (nt == 4) straight(std::integral_constant<int, 4>());
-        else if (nt == 1) straight(std::integral_constant<int, 1>());
-        else if (nt == 2) straight(std::integral_constant<int, 2>());
-        else straight(std::integral_constant<int, 3>());
+    if (classA) {
+        if (nt == 2) straight(std::integral_constant<int, 2>(), Tt());
+        else straight(std::integral_constant<int, 1>(), Tt());
+    } else if (nt <= 4) {
+        if (nt == 3) straight(std::integral_constant<int, 3>(), Ff());
+        else if (nt == 2) straight(std::integral_constant<int, 2>(), Ff());
+        else if (nt == 4) straight(std::integral_constant<int, 4>(), Ff());
+        else straight(std::integral_constant<int, 1>(), Ff());
     } else {
         auto run4 = [&](auto par_c, auto first_c, auto load2_c, auto last_c, int pos) __attribute__((always_inline)) {
-            if constexpr (decltype(last_c)::value) {
-                if (I == J) {
-                    if (strips) tile_body(par_c, first_c, load2_c, last_c, C2(), pos);
-                    else tile_body(par_c, first_c, load2_c, last_c, C1(), pos);
-                } else tile_body(par_c, first_c, load2_c, last_c, C0(), pos);
-            } else tile_body(par_c, first_c, load2_c, last_c, C0(), pos);
+            tile_body(par_c, first_c, load2_c, last_c, C0(), pos);
         };
         auto run = [&](auto par_c, int pos) __attribute__((always_inline)) {               // a tile after the first
             if (pos == nt - 1) run4(par_c, Ff(), Ff(), Tt(), pos);
@@ -1705,8 +1736,7 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
         using B0 = std::integral_constant<int, 0>;
         using B1 = std::integral_constant<int, 1>;
         using B2 = std::integral_constant<int, NB - 1>;
-        if (nt == 1) run4(B0(), Tt(), Ff(), Tt(), 0);
-        else if (nt <= AHEAD) run4(B0(), Tt(), Ff(), Ff(), 0);
+        if (nt <= AHEAD) run4(B0(), Tt(), Ff(), Ff(), 0);
         else run4(B0(), Tt(), Tt(), Ff(), 0);
         for (int pos = 1; pos < nt; pos += NB) {            // pq blocks by name: NB tiles per trip
             run(B1(), pos);
@@ -1715,7 +1745,8 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
         }
     }
 #ifdef REKF_DEBUG_ENTRY
-    if (eslot >= 0 && threadIdx.x == 0) const_cast<RekfCtl *>(d.ctl)->dbg[16 + eslot] = wall_clock64();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (this wave's last stores acknowledged)
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_dd_times[blockIdx.x][1] = wall_clock64();
 #endif
 #ifdef REKF_DEBUG_TIMING
     if (rec2) {

@@ -1,18 +1,43 @@
-"""Entry / exit wall-clock times of eight k_downdate2 workgroups (blocks 0, 128, 255, 256, 300, 400, 495, 511) relative to block 0,
-from a -DREKF_DEBUG_ENTRY build (release register footprint: the -DREKF_DEBUG_TIMING build holds its marks in 48 VGPRs and
-loses the second workgroup per CU).  GPU box: make -C reflector_ekf_slam_amd/csrc -B ../librekf.so HIPFLAGS="... -DREKF_DEBUG_ENTRY";
-[REKF_DD_SB=1] python scripts/gpu_dbg_entry.py"""
+"""Entry / exit wall clock (100 MHz) of every workgroup of k_downdate2, inside the update chain, from a -DREKF_DEBUG_ENTRY build
+(release register footprint; the exit stamp waits for the wave's own stores):
+    python scripts/gpu_dbg_entry.py path/to/variant.so ...
+Per variant, medians over 20 C3 updates, in us after the earliest entry: entry spread, exit by number of tiles / class, last exit."""
+import subprocess, sys, os
+CHILD = r'''
 import sys, ctypes as C
 sys.path.insert(0, ".")
-from reflector_ekf_slam_amd import synth, session as S, ReflectorEKFSLAM, _lib
+import numpy as np
+from reflector_ekf_slam_amd import _lib
+path = sys.argv[1]
+_lib.lib_path = lambda name, _p=path: _p if name == "librekf.so" else __import__("os").path.join(_lib._HERE, name)
+from reflector_ekf_slam_amd import synth, session as S, ReflectorEKFSLAM
 cfg = synth.C3
 sess = synth.make_session(cfg)
 g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks)
 S.replay(sess, g); g.sync()
-L = _lib.rekf(); L.rekf_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
-for rep in range(3):
-    for t, ob in synth.steady_state_scans(sess, 20)[rep * 5:rep * 5 + 5]:
-        g.handle_observation(t, ob)
-    out = (C.c_longlong * 32)(); L.rekf_debug_counters(g._h, out)
-    o = list(out)
-    print("entry us:", [round((x - o[8]) * 0.01, 2) for x in o[8:16]], " exit us:", [round((x - o[8]) * 0.01, 2) for x in o[16:24]])
+L = _lib.rekf()
+L.rekf_debug_dd_times.argtypes = [C.c_void_p, C.c_int]
+scans = synth.steady_state_scans(sess, 40)
+G = 256
+rows = []
+for t, ob in scans[10:30]:
+    g.handle_observation(t, ob); g.sync()
+    buf = (C.c_longlong * (2 * G))()
+    L.rekf_debug_dd_times(buf, G)
+    a = np.array(list(buf), float).reshape(G, 2) * 0.01
+    rows.append(a - a[:, 0].min())
+m = np.median(np.array(rows), axis=0)
+dur = m[:, 1]
+w = np.array([(b & 7) * (G >> 3) + (b >> 3) for b in range(G)])
+T = 32
+A = w < T
+order = np.argsort(dur)
+print(path.split("/")[-1], f"entries {m[:, 0].min():.2f}..{m[:, 0].max():.2f}; exits: class A median {np.median(dur[A]):.2f} max {dur[A].max():.2f} (block 0: {dur[0]:.2f}); "
+      f"class B quartiles {np.percentile(dur[~A], 25):.2f} {np.percentile(dur[~A], 50):.2f} {np.percentile(dur[~A], 75):.2f} max {dur[~A].max():.2f}; "
+      f"last exit {dur.max():.2f}; sum of bodies {np.sum(m[:, 1] - m[:, 0]):.0f} us; latest 6 (w, exit): " + " ".join(f"({w[i]},{dur[i]:.2f})" for i in order[-6:]))
+'''
+for p in sys.argv[1:]:
+    r = subprocess.run([sys.executable, "-c", CHILD, os.path.abspath(p)], capture_output=True, text=True)
+    print((r.stdout.strip().splitlines() or ["(no output)"])[-1])
+    if r.returncode != 0:
+        print(r.stderr[-800:])

@@ -37,7 +37,7 @@ for t, ob in scans[:3]:
     out = (C.c_longlong * 32)(); L.rekf_debug_counters(g._h, out)
     o = list(out)
     ghz = o[6] / max(o[5], 1) * 0.1
-    res.append((o[5] * 0.01, ghz, [round(x / ghz / 1e3, 2) for x in o[8:8 + o[7]]] if o[7] else []))
+    res.append((o[5] * 0.01, ghz, [round(x / ghz / 1e3, 2) for x in o[8:8 + o[7]]] if o[7] else [], (o[4] - o[3]) * 0.01))
 g.set_state(float(z["t"]), z["mu"], z["sigma"], (0.0, 0.0, 0.0))
 g.sync_code()
 t0 = time.perf_counter()
@@ -45,7 +45,7 @@ for t, ob in scans[100:600]:
     g.handle_observation(t, ob)
 g.sync_code()
 dt = (time.perf_counter() - t0) / 500
-print(f"{path.split('/')[-1]}: {1e6 * dt:.2f} us/update (meaningless for ablations); first update: kernel {res[0][0]:.2f} us @ {res[0][1]:.2f} GHz, marks {res[0][2]}; second: {res[1][2]}")
+print(f"{path.split('/')[-1]}: {1e6 * dt:.2f} us/update (meaningless for ablations); first update: kernel {res[0][0]:.2f} us @ {res[0][1]:.2f} GHz, marks {res[0][2]}; second: {res[1][2]}; entry of the recorded workgroup after workgroup 0's (k_downdate2 builds): {res[1][3]:.2f} us, body {res[1][0]:.2f} us")
 '''
 subprocess.run([sys.executable, "-c", BUILD], check=True)
 for p in sys.argv[1:]:
