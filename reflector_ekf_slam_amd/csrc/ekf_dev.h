@@ -47,6 +47,12 @@ struct RekfCtl {
     int pose_pending;
     int obs_kind[REKF_MAX_OBS_WIDE];  // per observation: 0 map match, 1 state match, 2 new
     int obs_idx[REKF_MAX_OBS_WIDE];
+    // ---- the pending Predict of a scan (round 3): Predict's O(n) part -- columns 0, 1 of P against column 2 -- is not a pass over
+    // memory any more.  The front kernel leaves (a, b) of G = I + a e0 e2^T + b e1 e2^T and the predicted 3 x 3 pose block here, and
+    // the two kernels that read P before the scan's downdate has rewritten it apply them to what they read: k_mid to its gathers,
+    // k_downdate2 to its tiles of column 0 (which then STORE predicted-and-updated values: the scan's downdate commits its Predict).
+    // Two slots, by scan parity: the front kernel of scan t+1 may run beside the downdate of scan t (lazy downdate, rekf_api.hip).
+    struct Pred { double ab[2]; double C9[9]; } pred[2];
     long long dbg[32];            // scratch for in-kernel timing experiments (REKF_DEBUG_TIMING builds)
 };
 
@@ -70,6 +76,8 @@ struct RekfFrontArgs {
     // read the pose back; HandleOdometryMessage then costs no launch at all).  host_pred = 1: the device evaluates no motion model --
     // pre_pose is the predicted pose, pre_ab the composite G = I + a e0 e2^T + b e1 e2^T of every predict since the device last
     // saw P (consecutive predicts compose exactly: e2^T (a, b, 0)^T = 0), pre_C9 the pose block after them.
+    int pred_slot;            // which RekfCtl::pred slot this scan's Predict goes through (front kernel writes, k_mid reads)
+    int apply_pred;           // k_mid: apply the pending Predict to the gathered P (whole scan or FIRST block step of a wide scan)
     int host_pred;
     double pre_pose[5];       // x, y, theta (wrapped, cc:181/:205), cos(theta), sin(theta) of the WRAPPED heading as the reference takes them (cc:252-253)
     double pre_ab[2];
@@ -105,6 +113,8 @@ struct RekfDev {
     int dd_lo, dd_x;    // k_downdate2, class B: tiles per workgroup -- dd_lo each, the first dd_x workgroups one more (set by rekf_launch_downdate)
     int dd_sub;         // k_downdate2: class B holds the tiles with I >= J + dd_sub (2: a class-A workgroup also takes the tile below its
                         // diagonal tile; 1: it does not; 0: the host does not know n exactly -- the kernel derives the schedule itself)
+    int pred_slot;      // k_downdate2: >= 0: the scan's pending Predict (RekfCtl::pred[pred_slot]) is applied to the tiles of column 0 as they are
+                        // read (and so committed by this launch); -1: nothing pending (later block steps of a wide scan, timing hook)
     int kc_ub;          // host bound of m_pad for the current scan, rounded up to 16 (0: unknown); columns [m, kc_ub) of HPt / Kn are zero
 };
 

@@ -213,11 +213,6 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
     // indexed kernel argument is a scalar load of its own, issued where it is used (inside the match, it cost a memory round trip)
     float ob0x = 0.f, ob0y = 0.f;
     if (b < K) { ob0x = rekf_obs(A, 2 * b); ob0y = rekf_obs(A, 2 * b + 1); }
-    const int idx0 = b * 1024 + tid;
-    double c0 = 0, c1 = 0, c2 = 0;            // (the columns: P is stored as its lower triangle, see k_apply_predict)
-    if (idx0 >= 3 && idx0 < n) {
-        c0 = P[idx0 + 0 * ld]; c1 = P[idx0 + 1 * ld]; c2 = P[idx0 + 2 * ld];
-    }
     // the first 1024 landmarks as float32 (cc:431), one per thread, into LDS: these loads fly under the trig chain below, and
     // the wave that matches then reads LDS instead of waiting for HBM four times in a row
     __shared__ float s_lmx[1024], s_lmy[1024];
@@ -262,27 +257,18 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
     __syncthreads();
     FMARK();                                          // 1: barrier passed
 
-    // ---- Predict, covariance slice (cc:178 / :202), corner by workgroup 0
+    // ---- Predict's covariance part (cc:178 / :202) is NOT applied here: (a, b) and the predicted pose block go to the control block,
+    // k_mid and k_downdate2 apply them to what they read of P (RekfCtl::pred), and the scan's downdate commits them
     {
 #pragma clang fp contract(off)
-        const double a = mo.a, bb = mo.b;
-        if (idx0 >= 3 && idx0 < n) {
-            const double n0 = c0 + a * c2, n1 = c1 + bb * c2;
-            P[idx0 + 0 * ld] = n0;
-            P[idx0 + 1 * ld] = n1;
-        }
-        for (int idx = idx0 + nb * 1024; idx < n; idx += nb * 1024) {
-            const double p2 = P[idx + 2 * ld];
-            const double n0 = P[idx + 0 * ld] + a * p2, n1 = P[idx + 1 * ld] + bb * p2;
-            P[idx + 0 * ld] = n0;
-            P[idx + 1 * ld] = n1;
-        }
         if (b == 0 && tid == 0) {
             if (A.host_pred) {
 #pragma unroll
                 for (int q = 0; q < 9; ++q) C9[q] = A.pre_C9[q];
             } else corner_predict(C9, 3, mo);
-            for (int q = 0; q < 9; ++q) P[(q % 3) + (size_t)(q / 3) * ld] = C9[q];
+            RekfCtl::Pred *pr = &ctl->pred[A.pred_slot & 1];
+            pr->ab[0] = mo.a; pr->ab[1] = mo.b;
+            for (int q = 0; q < 9; ++q) pr->C9[q] = C9[q];
             ctl->pose_pred[0] = pose[0]; ctl->pose_pred[1] = pose[1]; ctl->pose_pred[3] = pose[3]; ctl->pose_pred[4] = pose[4];
             if (A.host_pred) ctl->pose_pred[2] = pose[2];
             ctl->pose_pending = 1;
@@ -741,6 +727,12 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
                             hp ? A.pre_pose[3] : ctl->pose_pred[3], hp ? A.pre_pose[4] : ctl->pose_pred[4]};
     const bool pending = ctl->pose_pending != 0;
     const bool first = blockIdx.x == 0;
+    // the scan's pending Predict (RekfCtl::pred): applied to the gathered P in phase D.  (a, b) = 0 and the pose block as gathered
+    // when nothing is pending (later block steps of a wide scan: the first step's downdate has committed it)
+    // (through LDS, not registers: eleven uniform doubles held from here to phase D cost this 512-thread kernel its residency)
+    const bool do_pred = A.apply_pred != 0;
+    __shared__ double s_pred[12];
+    if (do_pred && tid >= 64 && tid < 64 + 11) s_pred[tid - 64] = ((const double *)&ctl->pred[A.pred_slot & 1])[tid - 64];   // ab[0], ab[1], C9[0..8]
 
     // ---- A: the scan's matched pairs.  Whole scan (pair0 < 0): ordered compaction of the per-observation results (obs order
     // preserved), wave 0; workgroup 0 also writes the record for the getters.  Block step of a wide scan (pair0 >= 0): the
@@ -1012,9 +1004,30 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
 #pragma unroll
         for (int pass = 0; pass < SL_PASS; ++pass) {
             const int slot = tt / NPAIR + SL_STEP * pass;
-            const v2d a01 = *(const v2d *)&s_psub[rs2[pass]][0], b01 = *(const v2d *)&s_psub[rs2[pass] + 1][0];
-            const double a2 = s_psub[rs2[pass]][2], b2 = s_psub[rs2[pass] + 1][2];
-            const v2d al = *(const v2du *)&s_psub[rs2[pass]][kq], bl = *(const v2du *)&s_psub[rs2[pass] + 1][kq];
+            v2d a01 = *(const v2d *)&s_psub[rs2[pass]][0], b01 = *(const v2d *)&s_psub[rs2[pass] + 1][0];
+            double a2 = s_psub[rs2[pass]][2], b2 = s_psub[rs2[pass] + 1][2];
+            v2d al = *(const v2du *)&s_psub[rs2[pass]][kq], bl = *(const v2du *)&s_psub[rs2[pass] + 1][kq];
+            if (do_pred) {
+                // the pending Predict, G P G^T + V restricted to the sub-block (G = I + a e0 e2^T + b e1 e2^T): a landmark row takes
+                // P(r, 0) + a P(r, 2) and P(r, 1) + b P(r, 2) (the same single operations the old covariance pass did in memory);
+                // rows 0, 1 take the predicted pose block and, against a landmark column c, P(0, c) + a P(2, c) / P(1, c) + b P(2, c);
+                // row 2 takes the predicted pose block and keeps its landmark columns
+#pragma clang fp contract(off)
+                const double pa = s_pred[0], pb = s_pred[1];
+                const double *pC9 = s_pred + 2;
+                if (slot < NS) {
+                    a01.x = a01.x + pa * a2; a01.y = a01.y + pb * a2;
+                    b01.x = b01.x + pa * b2; b01.y = b01.y + pb * b2;
+                } else if (slot == NS) {
+                    const v2d r2 = *(const v2du *)&s_psub[2 * (NS + 1)][kq];           // P(2, c), P(2, c + 1)
+                    a01.x = pC9[0]; a01.y = pC9[3]; a2 = pC9[6];                        // row 0 of the predicted block: (0,0) (0,1) (0,2)
+                    b01.x = pC9[1]; b01.y = pC9[4]; b2 = pC9[7];                        // row 1
+                    al.x = al.x + pa * r2.x; al.y = al.y + pa * r2.y;
+                    bl.x = bl.x + pb * r2.x; bl.y = bl.y + pb * r2.y;
+                } else {
+                    a01.x = pC9[2]; a01.y = pC9[5]; a2 = pC9[8];                        // row 2
+                }
+            }
             double v0x = a01.x * h0[0], v0y = b01.x * h0[0], v1x = a01.x * h1[0], v1y = b01.x * h1[0];
             v0x += a01.y * h0[1]; v0y += b01.y * h0[1]; v1x += a01.y * h1[1]; v1y += b01.y * h1[1];
             v0x += a2 * h0[2]; v0y += b2 * h0[2]; v1x += a2 * h1[2]; v1y += b2 * h1[2];
@@ -1037,9 +1050,28 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
             if (q2 < nq) {
                 const bool hc = s_pcol[q2] >= 0;
                 const int c = i0 + 2 * pr;
-                const v2d p0 = *(const v2d *)&s_pw[0][2 * pr], p1 = *(const v2d *)&s_pw[1][2 * pr], p2 = *(const v2d *)&s_pw[2][2 * pr];
+                v2d p0 = *(const v2d *)&s_pw[0][2 * pr], p1 = *(const v2d *)&s_pw[1][2 * pr], p2 = *(const v2d *)&s_pw[2][2 * pr];
                 v2d l0 = {0, 0}, l1 = {0, 0};
                 if (hc) { l0 = *(const v2d *)&s_pw[3 + 2 * q2][2 * pr]; l1 = *(const v2d *)&s_pw[4 + 2 * q2][2 * pr]; }
+                if (do_pred) {                        // the pending Predict on this workgroup's rows (see the S team above)
+#pragma clang fp contract(off)
+                    const double pa = s_pred[0], pb = s_pred[1];
+                    const double *pC9 = s_pred + 2;
+                    if (c >= 3) {
+                        p0.x = p0.x + pa * p2.x; p1.x = p1.x + pb * p2.x;
+                        p0.y = p0.y + pa * p2.y; p1.y = p1.y + pb * p2.y;
+                    } else if (c == 0) {              // rows 0, 1 (workgroup 0): the predicted block; landmark columns against row 2's
+                        p0.x = pC9[0]; p0.y = pC9[1]; p1.x = pC9[3]; p1.y = pC9[4]; p2.x = pC9[6]; p2.y = pC9[7];
+                        if (hc) {
+                            const double r20 = s_pw[3 + 2 * q2][2], r21 = s_pw[4 + 2 * q2][2];
+                            l0.x = l0.x + pa * r20; l0.y = l0.y + pb * r20;
+                            l1.x = l1.x + pa * r21; l1.y = l1.y + pb * r21;
+                        }
+                    } else {                          // c == 2: row 2 (the predicted block), row 3 (an ordinary row)
+                        p0.y = p0.y + pa * p2.y; p1.y = p1.y + pb * p2.y;
+                        p0.x = pC9[2]; p1.x = pC9[5]; p2.x = pC9[8];
+                    }
+                }
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr) {
                     const int r = 2 * q2 + rr;
@@ -1300,10 +1332,18 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     // With n known to the host nothing here depends on the control block: k_mid leaves zero panels behind a scan without
     // matches, so the kernel may run unconditionally and its first loads go out one memory round trip earlier.
     const RekfCtl *ctl = d.ctl;
+    // the scan's pending Predict (RekfCtl::pred, see there): applied to the tiles of column 0 as they are read, so that what this
+    // launch stores there is predicted AND updated.  Fetched here, used after the first MFMA loop at the earliest.
+    // (through LDS like the border rows: requested now, written behind the prologue's DMA wait)
+    const bool pred_on = d.pred_slot >= 0;
+    __shared__ double s_pred[12];
+    double pred_v = 0.0;
+    if (pred_on && threadIdx.x >= 64 && threadIdx.x < 64 + 11) pred_v = ((const double *)&ctl->pred[d.pred_slot & 1])[threadIdx.x - 64];   // ab[0], ab[1], C9[0..8]
     int n = d.n_known;
     if (n < 0) {
         n = ctl->n;
-        if (ctl->m == 0) {                   // nothing matched: P stays as Predict left it -- but the caller still gets its pose
+        // (with a Predict pending the kernel runs even so: k_mid has left zero panels, and the tiles of column 0 commit the Predict)
+        if (ctl->m == 0 && !pred_on) {       // nothing matched: P stays as it is -- but the caller still gets its pose
             if (d.pub && blockIdx.x == 0) {
                 const int l = threadIdx.x;
                 if (l < 3) host_slot_store(d.pub + l, d.mu[l], d.pub_seq, 0);
@@ -1466,6 +1506,7 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
         for (int q = 0; q < 8; ++q) pq[NB - 2][q] = *(const v2d *)(Pw + (size_t)(8 * (q & 3) + (q >> 2)) * ld);
         dd_wait_vmcnt<16>();                 // the DMAs (and everything before them); the 16 P loads may still fly
     } else dd_wait_vmcnt<8>();
+    if (pred_on && tid >= 64 && tid < 64 + 11) s_pred[tid - 64] = pred_v;
     if (want_border) {                       // (older than the DMAs: arrived)
         ((v2d *)&s_border[0][0][0])[tid] = bdr0;                   // s_border[0] = Kn rows nb.., [1] = HPt rows nb..
         ((v2d *)&s_border[1][0][0])[tid] = bdr1;
@@ -1507,7 +1548,7 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
         const double *s_panel = (s_which ? hp_buf(hb) : kn_buf(kb)) + s_x + s_kb * 64;
         const double *s_brow = &s_border[s_which ? 0 : 1][0][s_kb];
         v2d sacc[DD_STRIP_MAX];
-        v2d strip_p;
+        v2d strip_p = {0.0, 0.0};
         if (SPECIAL) {
             double *p0, *p1; int which, b, x;
             strip_addr(I, p0, p1, which, b, x);
@@ -1579,6 +1620,30 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
             a2 = a2n; b2 = b2n;
         }
         D2MARK();                            // MFMA loop done
+        if (pred_on && J == 0) {
+            // the pending Predict on the tile as read: columns 0, 1 against column 2 (register 0 of the lanes 16 up: kq = 1), the same
+            // single operations the covariance pass of the front kernel used to do in memory; the 3 x 3 pose block by value
+#pragma clang fp contract(off)
+            const double pa = s_pred[0], pb = s_pred[1];
+            const double *pC9 = s_pred + 2;
+            const double c2x = __shfl_down(pq[PAR][0].x, 16, 64), c2y = __shfl_down(pq[PAR][0].y, 16, 64);
+            if (wj == 0 && kq == 0) {
+                const int r0 = DT * I + 32 * wi + 2 * idx;              // this lane's rows r0, r0 + 1; register 0 = column 0, register 4 = column 1
+                if (r0 >= 4) {
+                    pq[PAR][0].x = pq[PAR][0].x + pa * c2x; pq[PAR][4].x = pq[PAR][4].x + pb * c2x;
+                    pq[PAR][0].y = pq[PAR][0].y + pa * c2y; pq[PAR][4].y = pq[PAR][4].y + pb * c2y;
+                } else if (r0 == 0) {                                    // (0,0) (1,0) | (0,1) (1,1)
+                    pq[PAR][0].x = pC9[0]; pq[PAR][0].y = pC9[1]; pq[PAR][4].x = pC9[3]; pq[PAR][4].y = pC9[4];
+                } else {                                                 // rows 2, 3: (2,0) (2,1) of the block, row 3 ordinary
+                    pq[PAR][0].y = pq[PAR][0].y + pa * c2y; pq[PAR][4].y = pq[PAR][4].y + pb * c2y;
+                    pq[PAR][0].x = pC9[2]; pq[PAR][4].x = pC9[5];
+                }
+            }
+            if (wj == 0 && kq == 1 && I == 0 && wi == 0 && idx < 2) {     // column 2 of the pose block
+                if (idx == 0) { pq[PAR][0].x = pC9[6]; pq[PAR][0].y = pC9[7]; }
+                else pq[PAR][0].x = pC9[8];
+            }
+        }
         // P + sum_k (the P block was requested a tile ago)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -1624,6 +1689,12 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
             {
                 double *p0, *p1; int which, b, x;
                 strip_addr(I, p0, p1, which, b, x);
+                // (a pending Predict on the row strip of tile column 0: columns 0, 1 in the thread x = 0, column 2 in its neighbour)
+                const double s_c2 = __shfl_down(strip_p.x, 1, 64);
+                if (pred_on && I == 0 && which == 1 && b < rem && x == 0) {
+#pragma clang fp contract(off)
+                    strip_p.x = strip_p.x + s_pred[0] * s_c2; strip_p.y = strip_p.y + s_pred[1] * s_c2;
+                }
                 if (which == 1 && b < rem) {
                     v2d t = strip_p;
 #pragma unroll
@@ -1942,7 +2013,7 @@ void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s)
     const bool first = !(attr_done[slot] & bit) || dev != slot;
     attr_done[slot] |= bit;
     RekfDev dp = d;
-    dp.dd_lo = dd_lo; dp.dd_x = dd_x; dp.dd_sub = dd_sub;
+    dp.dd_lo = dd_lo; dp.dd_x = dd_x; dp.dd_sub = dd_sub;                 // (dp.pred_slot: the caller's)
     if (d.n_known < 0) { dp.dd_lo = 0; dp.dd_x = 0; dp.dd_sub = 0; }   // n_ub is only a bound: the kernel derives the schedule from the real n
     if (kc == 64) launch_downdate2<64>(dp, grid, s, first);
     else if (kc == 48) launch_downdate2<48>(dp, grid, s, first);

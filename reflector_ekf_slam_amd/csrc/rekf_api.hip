@@ -62,6 +62,7 @@ struct rekf {
     bool lazy_pending = false; // the mirror is ahead of the device by the composite (lazy_a, lazy_b)
     double lazy_a = 0, lazy_b = 0;
     int flags_last = 0;        // sticky device flags as of the last read-back
+    unsigned long scan_count = 0;   // parity = the RekfCtl::pred slot of the scan's Predict
     bool last_scan_empty = false;   // the last HandleObservationMessage had no points: its (empty) match record lives here, not on the device
     RekfCtl *ctl_staging;      // pinned copy of the control block
     std::string hip_error;
@@ -613,6 +614,11 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     }
     h->mir_valid = false;                             // the update moves the pose: current again after the next read-back
     h->dev.n_known = h->n_exact ? h->n_ub : -1;
+    // this scan's Predict travels through the control block (RekfCtl::pred): the front kernel writes the slot, k_mid and the scan's
+    // (first) k_downdate2 apply it to what they read of P
+    const int pred_slot = (int)(h->scan_count++ & 1);
+    a.pred_slot = pred_slot; a.apply_pred = 1;
+    h->dev.pred_slot = -1;
     ProfScope upd(h, REKF_K_UPDATE);                  // one bracket around the whole chain (per-update latency)
     h->dev.kc_ub = round_up(2 * K + (gps_pose3 ? 3 : 0), 16);
     if (staged) {                                     // the scan does not fit the launch packet: through a pinned staging buffer into HBM
@@ -628,16 +634,17 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     const bool aug = !h->full;
     if (aug) h->cum_growth += 2 * K;
     const int pub_seq = new_publisher(h);
-    RekfDev dpub = h->dev;                            // (copied again below where mu / mu_out have been swapped)
     { ProfScope ps(h, REKF_K_FRONT); rekf_launch_front_mb(h->dev, a, h->n_ub, h->stream); }
     h->time = t;                                      // cc:234
     const int n_ub = h->n_ub;
     const int m_ub = 2 * K + (gps_pose3 ? 3 : 0);
     h->dev.mu_lin = h->dev.mu;
-    auto downdate = [&](bool last) {
+    auto downdate = [&](bool first, bool last) {
         ProfScope ps(h, REKF_K_DOWNDATE);
-        if (last) { dpub = h->dev; dpub.pub = h->host_slots_dev; dpub.pub_seq = pub_seq; dpub.pub_aug = aug ? 1 : 0; rekf_launch_downdate(dpub, n_ub, h->stream); }
-        else rekf_launch_downdate(h->dev, n_ub, h->stream);
+        RekfDev dd = h->dev;
+        dd.pred_slot = first ? pred_slot : -1;        // the scan's first downdate commits its Predict
+        if (last) { dd.pub = h->host_slots_dev; dd.pub_seq = pub_seq; dd.pub_aug = aug ? 1 : 0; }
+        rekf_launch_downdate(dd, n_ub, h->stream);
     };
     if (blocks) {
         // More than 32 observations (the reference has no limit, cc:397): matched once, then the joint update runs as
@@ -651,10 +658,11 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         HIP_TRY(h, hipMemcpyAsync(h->dev_mu_lin, h->dev.mu, sizeof(double) * (size_t)h->dev.ld, hipMemcpyDeviceToDevice, h->stream));
         for (int p0 = 0; p0 < K; p0 += stride) {
             a.pair0 = p0;
+            a.apply_pred = (p0 == 0) ? 1 : 0;
             h->dev.mu_lin = h->dev_mu_lin;
             { ProfScope ps(h, REKF_K_MID); rekf_launch_mid(h->dev, a, n_ub, 64, h->stream); }
             std::swap(h->dev.mu, h->dev.mu_out);
-            downdate(p0 + stride >= K);               // the last step commits the final pose
+            downdate(p0 == 0, p0 + stride >= K);      // the last step commits the final pose
         }
         a.pair0 = -1;
         h->dev.mu_lin = h->dev.mu;
@@ -663,7 +671,7 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         // mean in the other mean buffer
         { ProfScope ps(h, REKF_K_MID); rekf_launch_mid(h->dev, a, n_ub, m_ub, h->stream); }
         std::swap(h->dev.mu, h->dev.mu_out);
-        downdate(true);
+        downdate(true, true);
     }
     h->last_m_ub = m_ub;
     // the state only grows: once it is known full, k_augment can never have work again
@@ -952,6 +960,7 @@ int rekf_debug_time_kernel(rekf_t *h, int kernel, int reps, int ablate, double *
     RekfDev dev = h->dev;
     dev.dbg = 0;
     dev.pub = nullptr;
+    dev.pred_slot = -1;
     dev.n_known = h->n_ub;
     HIP_TRY(h, hipSetDevice(h->device));
     hipEvent_t a, b;
