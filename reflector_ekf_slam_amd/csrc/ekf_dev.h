@@ -113,6 +113,7 @@ struct RekfDev {
     int dd_lo, dd_x;    // k_downdate2, class B: tiles per workgroup -- dd_lo each, the first dd_x workgroups one more (set by rekf_launch_downdate)
     int dd_sub;         // k_downdate2: class B holds the tiles with I >= J + dd_sub (2: a class-A workgroup also takes the tile below its
                         // diagonal tile; 1: it does not; 0: the host does not know n exactly -- the kernel derives the schedule itself)
+    int dd_grid;        // k_dd_front: workgroups [0, dd_grid) are the downdate, the rest the next scan's front end (0: k_downdate2, the whole grid)
     int pred_slot;      // k_downdate2: >= 0: the scan's pending Predict (RekfCtl::pred[pred_slot]) is applied to the tiles of column 0 as they are
                         // read (and so committed by this launch); -1: nothing pending (later block steps of a wide scan, timing hook)
     int kc_ub;          // host bound of m_pad for the current scan, rounded up to 16 (0: unknown); columns [m, kc_ub) of HPt / Kn are zero
@@ -229,6 +230,7 @@ void rekf_launch_front_mb(const RekfDev &d, const RekfFrontArgs &a, int n_ub, hi
 void rekf_launch_compact_wide(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);
 void rekf_launch_mid(const RekfDev &d, const RekfFrontArgs &a, int n_ub, int m_ub, hipStream_t s);
 void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s);
+void rekf_launch_dd_front(const RekfDev &d, int n_ub, const RekfDev &dn, const RekfFrontArgs &an, hipStream_t s);
 void rekf_launch_augment(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);
 void rekf_launch_ellipses(const RekfDev &d, double *out5, int cap, hipStream_t s);
 void rekf_launch_publish_pose(const RekfDev &d, RekfHostSlot *hout, int seq, hipStream_t s);

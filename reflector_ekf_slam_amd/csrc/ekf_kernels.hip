@@ -187,22 +187,26 @@ __device__ static inline void argmin2_combine(double &a1, int &ja, double &a2, d
     if (take) { a1 = b1; ja = jb; }
     a2 = n2;
 }
-__global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
+// The front end as a ROLE of a workgroup of NT threads (a multiple of 256): k_front_mb below is nothing else; the fused kernel
+// k_dd_front runs it in the workgroups behind its downdate workgroups.  pred_elsewhere: the scan's RekfCtl::pred slot is written by
+// somebody else (the tile-(0,0) workgroup of the downdate running beside this role, which is the one that knows the pose block).
+template <int NT>
+__device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs &A, const int b, const int nb, const bool pred_elsewhere)
 {
+    static_assert(NT >= 256 && NT % 256 == 0, "four waves match, lane 0 of wave 1 evaluates the motion model");
     __shared__ Motion mo;
     __shared__ double pose[5];
 #ifdef REKF_DEBUG_FRONT
     long long tqf[8]; int nqf = 0;
-    const bool recf = blockIdx.x == 1 && threadIdx.x == 0;
+    const bool recf = b == 1 && threadIdx.x == 0;
     const long long t_entryf = clock64(), w_entryf = wall_clock64();
 #define FMARK() do { __builtin_amdgcn_sched_barrier(0); if (recf && nqf < 8) tqf[nqf++] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define FMARK()
 #endif
     const int tid = threadIdx.x;
-    const int b = blockIdx.x, nb = gridDim.x;
     RekfCtl *ctl = d.ctl;
-    double *__restrict__ P = d.P;
+    const double *__restrict__ P = d.P;
     const double *mu = d.mu;
     const size_t ld = (size_t)d.ld;
     const int n = (d.n_known >= 0) ? d.n_known : ctl->n;
@@ -213,13 +217,19 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
     // indexed kernel argument is a scalar load of its own, issued where it is used (inside the match, it cost a memory round trip)
     float ob0x = 0.f, ob0y = 0.f;
     if (b < K) { ob0x = rekf_obs(A, 2 * b); ob0y = rekf_obs(A, 2 * b + 1); }
-    // the first 1024 landmarks as float32 (cc:431), one per thread, into LDS: these loads fly under the trig chain below, and
-    // the wave that matches then reads LDS instead of waiting for HBM four times in a row
+    // the first 1024 landmarks as float32 (cc:431) into LDS: these loads fly under the trig chain below, and the waves that match
+    // then read LDS instead of waiting for HBM four times in a row
     __shared__ float s_lmx[1024], s_lmy[1024];
     {
-        float lmx = 0.f, lmy = 0.f;
-        if (tid < L) { lmx = (float)mu[3 + 2 * tid]; lmy = (float)mu[4 + 2 * tid]; }
-        s_lmx[tid] = lmx; s_lmy[tid] = lmy;
+        float lmx[1024 / NT], lmy[1024 / NT];
+#pragma unroll
+        for (int q = 0; q < 1024 / NT; ++q) {
+            const int j = tid + NT * q;
+            lmx[q] = 0.f; lmy[q] = 0.f;
+            if (j < L) { lmx[q] = (float)mu[3 + 2 * j]; lmy[q] = (float)mu[4 + 2 * j]; }
+        }
+#pragma unroll
+        for (int q = 0; q < 1024 / NT; ++q) { s_lmx[tid + NT * q] = lmx[q]; s_lmy[tid + NT * q] = lmy[q]; }
     }
     double C9[9];
     if (A.host_pred) {
@@ -240,7 +250,7 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
         // libm calls (2.1 us) but for one; theta' itself (what is committed to the mean) is computed as written, after the barrier.
         // (Only on this path: when the host predicts, above, cos / sin are the reference's own.)
 #pragma clang fp contract(off)
-        if (b == 0) for (int q = 0; q < 9; ++q) C9[q] = rekf_plower(P, (int)ld, q % 3, q / 3);
+        if (b == 0 && !pred_elsewhere) for (int q = 0; q < 9; ++q) C9[q] = rekf_plower(P, (int)ld, q % 3, q / 3);
         const double mu2 = mu[2];
         const double dth = A.vt[2] * A.dt;            // = mo.d[2] (delta_theta = w dt in both models; no FMA: same bits)
         double th = mu2 + dth, sn, cs;
@@ -265,15 +275,17 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
             if (A.host_pred) {
 #pragma unroll
                 for (int q = 0; q < 9; ++q) C9[q] = A.pre_C9[q];
-            } else corner_predict(C9, 3, mo);
-            RekfCtl::Pred *pr = &ctl->pred[A.pred_slot & 1];
-            pr->ab[0] = mo.a; pr->ab[1] = mo.b;
-            for (int q = 0; q < 9; ++q) pr->C9[q] = C9[q];
+            } else if (!pred_elsewhere) corner_predict(C9, 3, mo);
+            if (!pred_elsewhere) {
+                RekfCtl::Pred *pr = &ctl->pred[A.pred_slot & 1];
+                pr->ab[0] = mo.a; pr->ab[1] = mo.b;
+                for (int q = 0; q < 9; ++q) pr->C9[q] = C9[q];
+            }
             ctl->pose_pred[0] = pose[0]; ctl->pose_pred[1] = pose[1]; ctl->pose_pred[3] = pose[3]; ctl->pose_pred[4] = pose[4];
             if (A.host_pred) ctl->pose_pred[2] = pose[2];
             ctl->pose_pending = 1;
         }
-        if (!A.host_pred && b == 0 && tid == 512) ctl->pose_pred[2] = atan2(pose[4], pose[3]);     // the wrapped heading (cc:181 / :205), on a wave that does not match
+        if (!A.host_pred && b == 0 && tid == NT - 64) ctl->pose_pred[2] = atan2(pose[4], pose[3]);     // the wrapped heading (cc:181 / :205), on the last wave
     }
 
     FMARK();                                          // 2: covariance slice written
@@ -371,6 +383,10 @@ __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
         for (int i = 0; i < nqf; ++i) ctl->dbg[8 + i] = tqf[i] - t_entryf;
     }
 #endif
+}
+__global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
+{
+    front_role<1024>(d, A, (int)blockIdx.x, (int)gridDim.x, false);     // (1024 threads: one landmark each to stage; 256 do it in 1.1 us more)
 }
 
 // ----------------------------------------------------------------------------
@@ -1303,8 +1319,13 @@ extern "C" int rekf_debug_dd_times(long long *out, int n_wg)
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dd_times), sizeof(long long) * 2 * (size_t)(n_wg < 1024 ? n_wg : 1024));
 }
 #endif
+// The body is shared by two kernels: k_downdate2 (the downdate alone) and k_dd_front (LAZY DOWNDATE, rekf_api.hip: the downdate of scan
+// t enqueued with scan t+1, whose front end -- Predict's pose and ReflectorMatch, which need the mean k_mid(t) left but nothing of P --
+// runs in extra workgroups beside it).  dn / An = the device view and the launch packet of scan t+1 in the fused kernel, else null: the
+// workgroup that ends on tile (0, 0) then also evaluates scan t+1's predicted pose block from the block it has just committed and
+// leaves it, with (a, b), in scan t+1's RekfCtl::pred slot (the front role beside it cannot: the block does not exist before this tile).
 template <int KC>
-__global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
+__device__ __forceinline__ void dd_body(const RekfDev &d, const RekfDev *dn, const RekfFrontArgs *An)
 {
     extern __shared__ __attribute__((aligned(16))) double dd_smem[];   // [Kn 0 | Kn 1 | HPt 0 | HPt 1] panels (+ 16 KiB strip scratch if KC < 64)
     __shared__ __attribute__((aligned(16))) double s_border[2][DD_STRIP_MAX][REKF_MR_PAD];
@@ -1363,9 +1384,9 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     const bool strips = rem > 0 && rem <= DD_STRIP_MAX && n >= DT;
     const int T = strips ? n / DT : (n + DT - 1) / DT;
     int w = blockIdx.x;
-    const int nw = gridDim.x;
+    const int nw = d.dd_grid > 0 ? d.dd_grid : (int)gridDim.x;      // (k_dd_front: the workgroups behind dd_grid are the front end)
     // the triangle column by column (tile column J: I = J .. T-1); an XCD's workgroups take consecutive ranges of it
-    if (gridDim.x >= 8 && (gridDim.x & 7) == 0) w = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (nw >= 8 && (nw & 7) == 0) w = (blockIdx.x & 7) * (nw >> 3) + (blockIdx.x >> 3);
     // Two classes of workgroups.  Class A, workgroups [0, T): the diagonal tile (w, w) -- it costs almost two
     // ordinary tiles: no transposed image, but the border strips and the symmetric finish -- behind the tile below it, (w+1, w),
     // which shares its HPt panel.  Class B, the rest: the tiles with I >= J + 2, column by column, in equal ranges (3 per
@@ -1373,6 +1394,11 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
     // (When class B gets fewer than three tiles per workgroup -- small states -- class A keeps to its diagonal tile and the tiles
     // below the diagonal join class B: dd_sub = 1.)
     const bool classA = w < T;
+    // fused kernel, the workgroup of tile (0, 0): the motion terms of scan t+1's Predict (one sincos), on an idle lane, now
+    __shared__ Motion s_mo;
+    __shared__ double s_c9[9];
+    const bool next_corner = An != nullptr && classA && w == 0;
+    if (next_corner && threadIdx.x == 192) motion_terms(*An, dn->mu[2], s_mo);
     // class B: every free workgroup takes tiles -- lo each, the first x of them one more (2 or 3 at T = 32: 465 tiles on 224
     // workgroups; round 2 gave three tiles to 155 workgroups and left 69 CUs idle).  (lo, x) come from the host when it knows n
     // exactly (no division in the prologue), else they are derived here from the real T and the grid the host sized by its
@@ -1748,6 +1774,25 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
                     if (kq == 0) host_slot_store(d.pub + 3 + 2 + 3, pq[PAR][4].x, d.pub_seq, 0);
                 }
             }
+            if (next_corner && I == 0 && J == 0 && wave == 0) {
+                // scan t+1's Predict on the pose block this tile has just committed (cc:178 / :202): the six lower elements meet in
+                // LDS (one wave: no barrier), lane 0 evaluates G P G^T + V and hands block and (a, b) to scan t+1's slot
+                if (idx == 0 && kq == 0) { s_c9[0] = pq[PAR][0].x; s_c9[1] = pq[PAR][0].y; s_c9[4] = pq[PAR][4].y; }
+                if (idx == 1 && kq == 0) { s_c9[2] = pq[PAR][0].x; s_c9[5] = pq[PAR][4].x; }
+                if (idx == 1 && kq == 1) s_c9[8] = pq[PAR][0].x;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) {
+                    double C[9];
+                    C[0] = s_c9[0]; C[1] = s_c9[1]; C[2] = s_c9[2]; C[4] = s_c9[4]; C[5] = s_c9[5]; C[8] = s_c9[8];
+                    C[3] = C[1]; C[6] = C[2]; C[7] = C[5];
+                    const Motion mo = s_mo;
+                    corner_predict(C, 3, mo);
+                    RekfCtl::Pred *pr = &dn->ctl->pred[An->pred_slot & 1];
+                    pr->ab[0] = mo.a; pr->ab[1] = mo.b;
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) pr->C9[q] = C[q];
+                }
+            }
             return;
         }
         if (needH) dd_wait_vmcnt<(!FIRST ? 4 : 0) + (LOAD2 ? 8 : 0)>();             // after the last HPt DMA: (the second half of the stores +) this tile's 8 P loads
@@ -1830,6 +1875,21 @@ __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
         for (int i = 0; i < nq2; ++i) c->dbg[8 + i] = tq2[i] - t_entry2;
     }
 #endif
+}
+
+template <int KC>
+__global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
+{
+    dd_body<KC>(d, nullptr, nullptr);
+}
+template <int KC>
+__global__ __launch_bounds__(256) void k_dd_front(RekfDev d, RekfDev dn, RekfFrontArgs A)
+{
+    if ((int)blockIdx.x >= d.dd_grid) {               // the front end of the NEXT scan: workgroups of their own, nothing of P read or written
+        front_role<256>(dn, A, (int)blockIdx.x - d.dd_grid, (int)gridDim.x - d.dd_grid, true);
+        return;
+    }
+    dd_body<KC>(d, &dn, &A);
 }
 
 // ----------------------------------------------------------------------------
@@ -1968,12 +2028,15 @@ void rekf_launch_mid(const RekfDev &d, const RekfFrontArgs &a, int n_ub, int m_u
     if (m_ub <= 32) hipLaunchKernelGGL(k_mid<2>, dim3(grid), dim3(512), 0, s, d, a);
     else hipLaunchKernelGGL(k_mid<4>, dim3(grid), dim3(512), 0, s, d, a);
 }
-template <int KC> static void launch_downdate2(const RekfDev &d, int grid, hipStream_t s, bool first_on_device)
+template <int KC> static void launch_downdate2(const RekfDev &d, int grid, hipStream_t s, bool first_on_device, const RekfDev *dn, const RekfFrontArgs *an, int n_front)
 {
     constexpr int BYTES = 4 * KC * 64 * (int)sizeof(double) + (KC < 64 ? 16384 : 0);
-    if (first_on_device)
+    if (first_on_device) {
         (void)hipFuncSetAttribute((const void *)k_downdate2<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
-    hipLaunchKernelGGL((k_downdate2<KC>), dim3(grid), dim3(256), BYTES, s, d);
+        (void)hipFuncSetAttribute((const void *)k_dd_front<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+    }
+    if (dn) hipLaunchKernelGGL((k_dd_front<KC>), dim3(grid + n_front), dim3(256), BYTES, s, d, *dn, *an);
+    else hipLaunchKernelGGL((k_downdate2<KC>), dim3(grid), dim3(256), BYTES, s, d);
 }
 // host half of the tile schedule (tests/test_downdate_schedule_cpu.py restates it): T class-A workgroups (diagonal tile + the
 // one below) + equal ranges of the rest
@@ -1988,7 +2051,9 @@ static void downdate_schedule(int n_ub, int slots, int &grid, int &dd_lo, int &d
     grid = T + (dd_lo > 0 ? room : dd_x);
     if (grid >= 64) grid = (grid + 7) & ~7;         // multiple of 8 for the per-XCD numbering (workgroups past the last range return at once)
 }
-void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s)
+// dn / an non-null: the fused form k_dd_front -- scan t's downdate with the front end of scan t+1 (dn, an) in FRONT_MB further workgroups,
+// which take their CUs out of the downdate's schedule
+static void launch_downdate_any(const RekfDev &d, int n_ub, hipStream_t s, const RekfDev *dn, const RekfFrontArgs *an)
 {
     // persistent: one workgroup per CU (its panels fill most of the LDS), never more workgroups than tiles.  The opt-in to
     // more than 64 KiB of dynamic LDS and the CU count are per DEVICE: a process may hold handles on several GPUs.
@@ -2007,19 +2072,26 @@ void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s)
         attr_done[slot] = 0;
     }
     int grid, dd_lo, dd_x, dd_sub;
-    downdate_schedule(n_ub, n_cu_of[slot] * DD_WG_PER_CU, grid, dd_lo, dd_x, dd_sub);
+    int n_front = 0;
+    if (dn) { n_front = an->K < FRONT_MB ? (an->K > 0 ? an->K : 1) : FRONT_MB; }
+    int slots = n_cu_of[slot] * DD_WG_PER_CU - n_front;
+    if (slots < 8) slots = 8;
+    downdate_schedule(n_ub, slots, grid, dd_lo, dd_x, dd_sub);
     const int kc = (d.kc_ub < 16) ? 16 : ((d.kc_ub > 64) ? 64 : d.kc_ub);    // one k-chunk: the host never asks for more than 64 rows per step
     const unsigned bit = 1u << (kc / 16);
     const bool first = !(attr_done[slot] & bit) || dev != slot;
     attr_done[slot] |= bit;
     RekfDev dp = d;
     dp.dd_lo = dd_lo; dp.dd_x = dd_x; dp.dd_sub = dd_sub;                 // (dp.pred_slot: the caller's)
+    dp.dd_grid = dn ? grid : 0;
     if (d.n_known < 0) { dp.dd_lo = 0; dp.dd_x = 0; dp.dd_sub = 0; }   // n_ub is only a bound: the kernel derives the schedule from the real n
-    if (kc == 64) launch_downdate2<64>(dp, grid, s, first);
-    else if (kc == 48) launch_downdate2<48>(dp, grid, s, first);
-    else if (kc == 32) launch_downdate2<32>(dp, grid, s, first);
-    else launch_downdate2<16>(dp, grid, s, first);
+    if (kc == 64) launch_downdate2<64>(dp, grid, s, first, dn, an, n_front);
+    else if (kc == 48) launch_downdate2<48>(dp, grid, s, first, dn, an, n_front);
+    else if (kc == 32) launch_downdate2<32>(dp, grid, s, first, dn, an, n_front);
+    else launch_downdate2<16>(dp, grid, s, first, dn, an, n_front);
 }
+void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s) { launch_downdate_any(d, n_ub, s, nullptr, nullptr); }
+void rekf_launch_dd_front(const RekfDev &d, int n_ub, const RekfDev &dn, const RekfFrontArgs &an, hipStream_t s) { launch_downdate_any(d, n_ub, s, &dn, &an); }
 void rekf_launch_augment(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s)
 {
     hipLaunchKernelGGL(k_augment, dim3(1), dim3(256), 0, s, d, a);

@@ -63,6 +63,14 @@ struct rekf {
     double lazy_a = 0, lazy_b = 0;
     int flags_last = 0;        // sticky device flags as of the last read-back
     unsigned long scan_count = 0;   // parity = the RekfCtl::pred slot of the scan's Predict
+    // LAZY DOWNDATE.  A scan's last k_downdate2 is not enqueued with the scan but held back: if the next call is another scan, it goes
+    // out as k_dd_front, with that scan's front end (Predict's pose, ReflectorMatch: they need the mean, nothing of P) in workgroups of
+    // its own beside it -- two launches per scan instead of three, and the match off the critical path.  Anything else that looks at
+    // the device state enqueues it first (flush_dd).
+    bool dd_pending = false;
+    RekfDev dd_dev;                 // the held-back launch: device view (publisher tag included) ...
+    int dd_n_ub = 0;                // ... and the bound of n it was planned with
+    bool lazy_dd = true;            // REKF_LAZY_DD=0 in the environment turns it off (A/B measurements)
     bool last_scan_empty = false;   // the last HandleObservationMessage had no points: its (empty) match record lives here, not on the device
     RekfCtl *ctl_staging;      // pinned copy of the control block
     std::string hip_error;
@@ -237,9 +245,21 @@ void peek_n(rekf_t *h)
     if (slack == 0) { h->n_exact = true; h->full = h->n_ub >= h->dev.n_max; }
 }
 
+// the held-back downdate (struct rekf: LAZY DOWNDATE) goes out on its own
+int flush_dd(rekf_t *h)
+{
+    if (!h->dd_pending) return REKF_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    h->dd_pending = false;
+    { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_downdate(h->dd_dev, h->dd_n_ub, h->stream); }
+    HIP_TRY(h, hipGetLastError());
+    return REKF_OK;
+}
+
 int pull_ctl(rekf_t *h)
 {
     HIP_TRY(h, hipSetDevice(h->device));
+    { int rcf = flush_dd(h); if (rcf != REKF_OK) return rcf; }
     HIP_TRY(h, hipMemcpyAsync(h->ctl_staging, h->dev.ctl, sizeof(RekfCtl), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->n_ub = h->ctl_staging->n;
@@ -257,6 +277,7 @@ int refresh_mirror(rekf_t *h)
 {
     if (h->mir_valid) return REKF_OK;
     HIP_TRY(h, hipSetDevice(h->device));
+    { int rcf = flush_dd(h); if (rcf != REKF_OK) return rcf; }      // (its tile-(0,0) workgroup is the publisher being waited for)
     if (!h->pub_valid) {
         const int seq = new_publisher(h);
         rekf_launch_publish_pose(h->dev, h->host_slots_dev, seq, h->stream);
@@ -303,6 +324,7 @@ void put_host_prediction(const rekf_t *h, RekfFrontArgs &a)
 // The device's P / mu catch up with the mirror (needed before anything but a scan reads them there).
 int flush_lazy(rekf_t *h)
 {
+    { int rcf = flush_dd(h); if (rcf != REKF_OK) return rcf; }
     if (!h->lazy_pending) return REKF_OK;
     HIP_TRY(h, hipSetDevice(h->device));
     RekfFrontArgs a;
@@ -413,6 +435,7 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
     h->vt[0] = h->vt[1] = h->vt[2] = 0.0;             // cc:6
     h->n_ub = 3;
     h->full = false;
+    { const char *e = std::getenv("REKF_LAZY_DD"); h->lazy_dd = !(e && e[0] == '0'); }
     h->prof_on = false;
     h->prof_mask = -1;
     h->prof_used = 0;
@@ -634,16 +657,29 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     const bool aug = !h->full;
     if (aug) h->cum_growth += 2 * K;
     const int pub_seq = new_publisher(h);
-    { ProfScope ps(h, REKF_K_FRONT); rekf_launch_front_mb(h->dev, a, h->n_ub, h->stream); }
+    if (h->dd_pending && !a.host_pred) {
+        // the previous scan's downdate and this scan's front end as ONE launch (k_dd_front)
+        h->dd_pending = false;
+        ProfScope ps(h, REKF_K_DOWNDATE);
+        rekf_launch_dd_front(h->dd_dev, h->dd_n_ub, h->dev, a, h->stream);
+    } else {
+        int rcf = flush_dd(h);
+        if (rcf != REKF_OK) return rcf;
+        ProfScope ps(h, REKF_K_FRONT);
+        rekf_launch_front_mb(h->dev, a, h->n_ub, h->stream);
+    }
     h->time = t;                                      // cc:234
     const int n_ub = h->n_ub;
     const int m_ub = 2 * K + (gps_pose3 ? 3 : 0);
     h->dev.mu_lin = h->dev.mu;
+    // lazy downdate: only where nothing has to run behind the downdate inside this call (k_augment while the state can still grow)
+    const bool hold_back = h->lazy_dd && !aug;
     auto downdate = [&](bool first, bool last) {
-        ProfScope ps(h, REKF_K_DOWNDATE);
         RekfDev dd = h->dev;
         dd.pred_slot = first ? pred_slot : -1;        // the scan's first downdate commits its Predict
         if (last) { dd.pub = h->host_slots_dev; dd.pub_seq = pub_seq; dd.pub_aug = aug ? 1 : 0; }
+        if (last && hold_back) { h->dd_pending = true; h->dd_dev = dd; h->dd_n_ub = n_ub; return; }     // (lazy downdate: with the next call)
+        ProfScope ps(h, REKF_K_DOWNDATE);
         rekf_launch_downdate(dd, n_ub, h->stream);
     };
     if (blocks) {
@@ -731,6 +767,7 @@ int rekf_get_marker_ellipses(rekf_t *h, double *out5, int cap, int *count)
 {
     if (!h || !count || cap < 0 || (cap > 0 && !out5)) return REKF_ERR_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
+    { int rcf = flush_dd(h); if (rcf != REKF_OK) return rcf; }
     const int lim = cap < h->max_landmarks ? cap : h->max_landmarks;
     rekf_launch_ellipses(h->dev, h->dev_ell, lim, h->stream);       // (landmark blocks and means only: pending predicts do not touch them)
     int rc = pull_ctl(h);                              // synchronises the stream; n is exact afterwards
@@ -783,6 +820,7 @@ int rekf_set_state(rekf_t *h, double t, int n, const double *mu, const double *s
     for (auto &r : h->pub_ring) r = {0, 0};                       // an n published before this call says nothing about the new state
     h->lazy_pending = false; h->lazy_a = 0; h->lazy_b = 0;       // whatever was pending belonged to the state being replaced
     h->mir_valid = false;
+    h->dd_pending = false;                                         // (a held-back downdate belonged to the state being replaced)
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     const int ld = h->dev.ld;
@@ -992,6 +1030,7 @@ int rekf_debug_counters(rekf_t *h, long long out8[32])
 int rekf_device_layout(rekf_t *h, int *ld, int *n_max, void **P_dev, void **mu_dev)
 {
     if (!h) return REKF_ERR_INVALID;
+    { int rcf = flush_dd(h); if (rcf != REKF_OK) return rcf; }      // (the caller is about to look at P)
     if (ld) *ld = h->dev.ld;
     if (n_max) *n_max = h->dev.n_max;
     if (P_dev) *P_dev = h->dev.P;
