@@ -77,6 +77,8 @@ struct RekfFrontArgs {
     // pre_pose is the predicted pose, pre_ab the composite G = I + a e0 e2^T + b e1 e2^T of every predict since the device last
     // saw P (consecutive predicts compose exactly: e2^T (a, b, 0)^T = 0), pre_C9 the pose block after them.
     int pred_slot;            // which RekfCtl::pred slot this scan's Predict goes through (front kernel writes, k_mid reads)
+    int aug_pending;          // front role inside k_dd_front: the previous scan's k_augment has not run yet -- the state the match sees has
+                              // n + 2 n_new rows (the new reflectors' means are there: k_mid writes them)
     int apply_pred;           // k_mid: apply the pending Predict to the gathered P (whole scan or FIRST block step of a wide scan)
     int host_pred;
     double pre_pose[5];       // x, y, theta (wrapped, cc:181/:205), cos(theta), sin(theta) of the WRAPPED heading as the reference takes them (cc:252-253)

@@ -209,7 +209,7 @@ __device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs
     const double *__restrict__ P = d.P;
     const double *mu = d.mu;
     const size_t ld = (size_t)d.ld;
-    const int n = (d.n_known >= 0) ? d.n_known : ctl->n;
+    const int n = (d.n_known >= 0) ? d.n_known : ctl->n + (A.aug_pending ? 2 * ctl->n_new : 0);
     const int L = (n - 3) / 2;
     const int K = A.K;
 
@@ -703,7 +703,9 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
     __shared__ __attribute__((aligned(16))) double s_big[(NKCP * 2 * NRS > MP * LDS_S) ? NKCP * 2 * NRS : MP * LDS_S];
     __shared__ __attribute__((aligned(16))) double s_pw[NKC][MID_ROWS];     // P(own rows, sub-block columns)
     __shared__ double s_dmu[4][MID_ROWS];
-    __shared__ int s_pair_obs[NPAIR], s_pair_id[NPAIR], s_pair_state[NPAIR], s_pcol[NPAIR], s_rank[NPAIR], s_cnt[5];
+    __shared__ int s_pair_obs[NPAIR], s_pair_id[NPAIR], s_pair_state[NPAIR], s_pcol[NPAIR], s_rank[NPAIR], s_cnt[6];
+    __shared__ int s_newid[2 * NPAIR];            // the scan's new reflectors (observation indices), s_cnt[5] of them
+    __shared__ double s_np[3];                    // the committed pose, for their means
     // the sub-block's slots in ascending global order -- u = 0: rows / columns {0,1}, u = 1: {2}, u = 2 + rank: a state pair's
     // landmark -- with the first global row (= column) of each and the first sub-block column kc it stands for
     __shared__ int s_urow[NRS], s_ukc[NRS];
@@ -783,6 +785,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
             const bool gps = A.has_gps && cnt > 0 && A.pair0 + cnt == MMtot;     // the pose rows ride on the block step that holds the last pairs
             const int m = (cnt > 0) ? 2 * cnt + (gps ? 3 : 0) : 0;
             s_cnt[0] = cnt; s_cnt[1] = m; s_cnt[2] = (m + 15) & ~15; s_cnt[3] = NSl; s_cnt[4] = gps ? 1 : 0;
+            s_cnt[5] = (A.pair0 + A.pair_stride >= A.K) ? ctl->n_new : 0;       // the LAST block step appends the new reflectors' means
             s_urow[0] = 0; s_ukc[0] = 0; s_urow[1] = 2; s_ukc[1] = 2;
         }
     } else if (tid < 64) {
@@ -825,12 +828,14 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
             if (first) { ctl->map_pairs[2 * p] = lane; ctl->map_pairs[2 * p + 1] = oidx; }
         } else if (kind == 2) {
             const int p = __popcll(mn & lt);
+            if (p < N2 && p < 2 * NPAIR) s_newid[p] = lane;
             if (first && p < N2) ctl->new_ids[p] = lane;
         }
         if (lane == 0) {
             const int MM = M + Mm;
             const int m = (MM > 0) ? 2 * MM + (A.has_gps ? 3 : 0) : 0;
             s_cnt[0] = MM; s_cnt[1] = m; s_cnt[2] = (m + 15) & ~15; s_cnt[3] = M; s_cnt[4] = (A.has_gps && MM > 0) ? 1 : 0;
+            s_cnt[5] = N2;
             s_urow[0] = 0; s_ukc[0] = 0; s_urow[1] = 2; s_ukc[1] = 2;   // (their rows of s_psub stay M and M+1: row slot M = rows {0,1}, M+1 = row {2})
             if (first) {
                 ctl->K = K; ctl->n_state = M; ctl->n_map = Mm; ctl->n_new = N2;
@@ -842,15 +847,35 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
     MMARK();                                        // 0: compaction done
     const int MM = s_cnt[0], m = s_cnt[1], m_pad = s_cnt[2], NS = s_cnt[3];
     const bool gps_rows = s_cnt[4] != 0;
+    // The means of the scan's NEW reflectors (cc:323-342: the observation through the UPDATED pose, float32-rounded) are written
+    // here, by workgroup 0 behind its pose commit, not by k_augment: the next scan's match may then run before k_augment has
+    // appended their covariance rows (lazy downdate, rekf_api.hip).  s_np = the committed pose; call with the whole workgroup.
+    auto append_new_means = [&]() __attribute__((always_inline)) {
+        __syncthreads();
+        const int N2w = s_cnt[5];
+        if (tid < N2w) {
+#pragma clang fp contract(off)
+            const double x = s_np[0], y = s_np[1], th = s_np[2];
+            const double sn = sin(th), cs = cos(th);                    // cc:323-324
+            const int local_id = (A.pair0 >= 0) ? ctl->new_ids[tid] : s_newid[tid];   // cc:338 (block steps: k_compact_wide's record)
+            float gx, gy;
+            obs_to_global(x, y, cs, sn, rekf_obs(A, 2 * local_id), rekf_obs(A, 2 * local_id + 1), gx, gy);
+            d.mu_out[n + 2 * tid] = (double)gx;                         // cc:341-342
+            d.mu_out[n + 2 * tid + 1] = (double)gy;
+        }
+    };
     // The mean is double-buffered: other workgroups read landmark means from d.mu (phase B) while this one is already
     // done, so the updated rows go to d.mu_out and the host swaps the two pointers behind this launch.
     if (m == 0) {                                   // nothing matched: commit the predicted pose (cc:234 + Predict), no update
         if (tid < MID_ROWS && i0 + tid < n) {
             const int i = i0 + tid;
             const double pp = (i == 0) ? pose[0] : ((i == 1) ? pose[1] : pose[2]);      // no dynamic indexing of pose[]
-            d.mu_out[i] = (pending && i < 3) ? pp : d.mu[i];
+            const double vv = (pending && i < 3) ? pp : d.mu[i];
+            d.mu_out[i] = vv;
+            if (first && i < 3) s_np[i] = vv;
         }
         if (pending && first && tid == 0) ctl->pose_pending = 0;
+        if (first) append_new_means();
         // k_downdate2 runs without looking at the control block when the host knows n: give it zeros to add
         const int snb = rekf_strip_base(n);
         for (int e = tid; e < 16 * d.kc_ub; e += 512) {
@@ -1232,9 +1257,10 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
             if (i == 2) v = atan2(sin(v), cos(v));                               // cc:307
             d.mu_out[i] = v;
             if (i == 0) ctl->pose_pending = 0;
-
+            if (first && i < 3) s_np[i] = v;
         }
     }
+    if (first) append_new_means();
 #ifdef REKF_DEBUG_TIMING
     if (recm) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1909,14 +1935,11 @@ __global__ __launch_bounds__(256) void k_augment(RekfDev d, RekfFrontArgs A)
     if (N2 == 0) return;
     {
 #pragma clang fp contract(off)
-        const double x = d.mu[0], y = d.mu[1], th = d.mu[2];
+        const double th = d.mu[2];
         const double s = sin(th), c = cos(th);                      // cc:323-324
         if (tid < N2) {
             const int local_id = ctl->new_ids[tid];                 // cc:338
-            float gx, gy;
-            obs_to_global(x, y, c, s, rekf_obs(A, 2 * local_id), rekf_obs(A, 2 * local_id + 1), gx, gy);
-            d.mu[n + 2 * tid] = (double)gx;                         // cc:341-342 (float32-rounded)
-            d.mu[n + 2 * tid + 1] = (double)gy;
+            // (the means of the new reflectors, cc:341-342, are already there: k_mid's workgroup 0 writes them behind its pose commit)
             const double rx = (double)rekf_obs(A, 2 * local_id), ry = (double)rekf_obs(A, 2 * local_id + 1);
             Gp[tid][0] = 1.; Gp[tid][1] = 0.; Gp[tid][2] = -rx * s - ry * c;   // cc:347
             Gp[tid][3] = 0.; Gp[tid][4] = 1.; Gp[tid][5] = rx * c - ry * s;

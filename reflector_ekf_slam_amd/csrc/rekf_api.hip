@@ -70,6 +70,8 @@ struct rekf {
     bool dd_pending = false;
     RekfDev dd_dev;                 // the held-back launch: device view (publisher tag included) ...
     int dd_n_ub = 0;                // ... and the bound of n it was planned with
+    bool dd_aug = false;            // the scan's k_augment is held back with it (the state can still grow): it runs right behind the downdate
+    RekfFrontArgs dd_aug_args;      // ... with the scan's launch packet (the new reflectors' observations)
     bool lazy_dd = true;            // REKF_LAZY_DD=0 in the environment turns it off (A/B measurements)
     bool last_scan_empty = false;   // the last HandleObservationMessage had no points: its (empty) match record lives here, not on the device
     RekfCtl *ctl_staging;      // pinned copy of the control block
@@ -252,6 +254,7 @@ int flush_dd(rekf_t *h)
     HIP_TRY(h, hipSetDevice(h->device));
     h->dd_pending = false;
     { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_downdate(h->dd_dev, h->dd_n_ub, h->stream); }
+    if (h->dd_aug) { ProfScope ps(h, REKF_K_AUGMENT); rekf_launch_augment(h->dd_dev, h->dd_aug_args, h->stream); h->dd_aug = false; }
     HIP_TRY(h, hipGetLastError());
     return REKF_OK;
 }
@@ -660,8 +663,10 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     if (h->dd_pending && !a.host_pred) {
         // the previous scan's downdate and this scan's front end as ONE launch (k_dd_front)
         h->dd_pending = false;
-        ProfScope ps(h, REKF_K_DOWNDATE);
-        rekf_launch_dd_front(h->dd_dev, h->dd_n_ub, h->dev, a, h->stream);
+        a.aug_pending = h->dd_aug ? 1 : 0;
+        { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_dd_front(h->dd_dev, h->dd_n_ub, h->dev, a, h->stream); }
+        if (h->dd_aug) { ProfScope ps(h, REKF_K_AUGMENT); rekf_launch_augment(h->dd_dev, h->dd_aug_args, h->stream); h->dd_aug = false; }
+        a.aug_pending = 0;
     } else {
         int rcf = flush_dd(h);
         if (rcf != REKF_OK) return rcf;
@@ -672,8 +677,9 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     const int n_ub = h->n_ub;
     const int m_ub = 2 * K + (gps_pose3 ? 3 : 0);
     h->dev.mu_lin = h->dev.mu;
-    // lazy downdate: only where nothing has to run behind the downdate inside this call (k_augment while the state can still grow)
-    const bool hold_back = h->lazy_dd && !aug;
+    // lazy downdate (struct rekf): the scan's last downdate -- and its k_augment -- go out with the next call.  (Not for a staged scan:
+    // its k_augment reads the observations from a device buffer the next staged scan overwrites.)
+    const bool hold_back = h->lazy_dd && !staged;
     auto downdate = [&](bool first, bool last) {
         RekfDev dd = h->dev;
         dd.pred_slot = first ? pred_slot : -1;        // the scan's first downdate commits its Predict
@@ -713,8 +719,11 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     // the state only grows: once it is known full, k_augment can never have work again
     // (k_mid / k_compact_wide drop the extra reflectors and raise REKF_FLAG_CAPACITY)
     if (aug) {
-        ProfScope ps(h, REKF_K_AUGMENT);
-        rekf_launch_augment(h->dev, a, h->stream);
+        if (h->dd_pending) { h->dd_aug = true; h->dd_aug_args = a; }      // (held back with the scan's downdate)
+        else {
+            ProfScope ps(h, REKF_K_AUGMENT);
+            rekf_launch_augment(h->dev, a, h->stream);
+        }
     }
     { ProfScope ps(h, REKF_K_EMPTY); }
     if (aug) {
@@ -820,7 +829,7 @@ int rekf_set_state(rekf_t *h, double t, int n, const double *mu, const double *s
     for (auto &r : h->pub_ring) r = {0, 0};                       // an n published before this call says nothing about the new state
     h->lazy_pending = false; h->lazy_a = 0; h->lazy_b = 0;       // whatever was pending belonged to the state being replaced
     h->mir_valid = false;
-    h->dd_pending = false;                                         // (a held-back downdate belonged to the state being replaced)
+    h->dd_pending = false; h->dd_aug = false;                      // (a held-back downdate belonged to the state being replaced)
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     const int ld = h->dev.ld;
