@@ -53,6 +53,10 @@ struct RekfCtl {
     // k_downdate2 to its tiles of column 0 (which then STORE predicted-and-updated values: the scan's downdate commits its Predict).
     // Two slots, by scan parity: the front kernel of scan t+1 may run beside the downdate of scan t (lazy downdate, rekf_api.hip).
     struct Pred { double ab[2]; double C9[9]; } pred[2];
+    // ---- the 3 x 3 pose block AFTER the update (round 3): evaluated once, by k_mid's workgroup 0 (which has K's pose rows and the pose
+    // columns of H P in LDS), published to the host from there -- GetPose does not wait for the downdate -- and taken over BY VALUE by
+    // the downdate's tile (0, 0), so that the published block and the stored one are the same bits
+    double post_C9[9];
     long long dbg[32];            // scratch for in-kernel timing experiments (REKF_DEBUG_TIMING builds)
 };
 
@@ -108,10 +112,10 @@ struct RekfDev {
     int dbg;            // ablation bits for rekf_debug_time_kernel; 0 in normal operation
     int n_known;        // the exact state dimension when the host knows it (state full, or nothing enqueued since a read-back), else -1:
                         // spares the kernels a dependent read of ctl->n at their start
-    RekfHostSlot *pub;  // non-null (only in the launch of the LAST k_downdate2 of a call): its tile-(0,0) workgroup publishes the pose
-                        // mean, the 3 x 3 pose block, n and the flags ...
+    RekfHostSlot *pub;  // non-null (only in the launch of the LAST k_mid of a call): its workgroup 0 publishes the pose mean, the 3 x 3 pose
+                        // block after the update, the n the state will have once k_augment has run, and the flags ...
     int pub_seq;        //   ... under this tag, so that GetPose / Sync after the call need no kernel of their own
-    int pub_aug;        //   ... and a k_augment follows: the n to publish is n + 2 ctl->n_new (neither pose nor pose block change there)
+    int pub_aug;        //   (unused since k_mid publishes: it knows the number of new reflectors itself)
     int dd_lo, dd_x;    // k_downdate2, class B: tiles per workgroup -- dd_lo each, the first dd_x workgroups one more (set by rekf_launch_downdate)
     int dd_sub;         // k_downdate2: class B holds the tiles with I >= J + dd_sub (2: a class-A workgroup also takes the tile below its
                         // diagonal tile; 1: it does not; 0: the host does not know n exactly -- the kernel derives the schedule itself)

@@ -188,10 +188,11 @@ __device__ static inline void argmin2_combine(double &a1, int &ja, double &a2, d
     a2 = n2;
 }
 // The front end as a ROLE of a workgroup of NT threads (a multiple of 256): k_front_mb below is nothing else; the fused kernel
-// k_dd_front runs it in the workgroups behind its downdate workgroups.  pred_elsewhere: the scan's RekfCtl::pred slot is written by
-// somebody else (the tile-(0,0) workgroup of the downdate running beside this role, which is the one that knows the pose block).
+// k_dd_front runs it in the workgroups behind its downdate workgroups.  corner_in_ctl: the pose block to predict from is
+// RekfCtl::post_C9 (what k_mid evaluated for the previous scan) -- in k_dd_front the previous scan's downdate, which stores that block
+// into P, is running beside this role; in k_front_mb it is read from P (set_state, reserve, a flushed host predict may have changed it).
 template <int NT>
-__device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs &A, const int b, const int nb, const bool pred_elsewhere)
+__device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs &A, const int b, const int nb, const bool corner_in_ctl)
 {
     static_assert(NT >= 256 && NT % 256 == 0, "four waves match, lane 0 of wave 1 evaluates the motion model");
     __shared__ Motion mo;
@@ -250,7 +251,7 @@ __device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs
         // libm calls (2.1 us) but for one; theta' itself (what is committed to the mean) is computed as written, after the barrier.
         // (Only on this path: when the host predicts, above, cos / sin are the reference's own.)
 #pragma clang fp contract(off)
-        if (b == 0 && !pred_elsewhere) for (int q = 0; q < 9; ++q) C9[q] = rekf_plower(P, (int)ld, q % 3, q / 3);
+        if (b == 0) for (int q = 0; q < 9; ++q) C9[q] = corner_in_ctl ? ctl->post_C9[q] : rekf_plower(P, (int)ld, q % 3, q / 3);
         const double mu2 = mu[2];
         const double dth = A.vt[2] * A.dt;            // = mo.d[2] (delta_theta = w dt in both models; no FMA: same bits)
         double th = mu2 + dth, sn, cs;
@@ -275,12 +276,10 @@ __device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs
             if (A.host_pred) {
 #pragma unroll
                 for (int q = 0; q < 9; ++q) C9[q] = A.pre_C9[q];
-            } else if (!pred_elsewhere) corner_predict(C9, 3, mo);
-            if (!pred_elsewhere) {
-                RekfCtl::Pred *pr = &ctl->pred[A.pred_slot & 1];
-                pr->ab[0] = mo.a; pr->ab[1] = mo.b;
-                for (int q = 0; q < 9; ++q) pr->C9[q] = C9[q];
-            }
+            } else corner_predict(C9, 3, mo);
+            RekfCtl::Pred *pr = &ctl->pred[A.pred_slot & 1];
+            pr->ab[0] = mo.a; pr->ab[1] = mo.b;
+            for (int q = 0; q < 9; ++q) pr->C9[q] = C9[q];
             ctl->pose_pred[0] = pose[0]; ctl->pose_pred[1] = pose[1]; ctl->pose_pred[3] = pose[3]; ctl->pose_pred[4] = pose[4];
             if (A.host_pred) ctl->pose_pred[2] = pose[2];
             ctl->pose_pending = 1;
@@ -706,6 +705,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
     __shared__ int s_pair_obs[NPAIR], s_pair_id[NPAIR], s_pair_state[NPAIR], s_pcol[NPAIR], s_rank[NPAIR], s_cnt[6];
     __shared__ int s_newid[2 * NPAIR];            // the scan's new reflectors (observation indices), s_cnt[5] of them
     __shared__ double s_np[3];                    // the committed pose, for their means
+    __shared__ double s_dc[4][3][MID_ROWS];       // workgroup 0: partial sums of (K H P)(i, jc), jc = 0..2, per wave of phase F
     // the sub-block's slots in ascending global order -- u = 0: rows / columns {0,1}, u = 1: {2}, u = 2 + rank: a state pair's
     // landmark -- with the first global row (= column) of each and the first sub-block column kc it stands for
     __shared__ int s_urow[NRS], s_ukc[NRS];
@@ -875,7 +875,22 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
             if (first && i < 3) s_np[i] = vv;
         }
         if (pending && first && tid == 0) ctl->pose_pending = 0;
-        if (first) append_new_means();
+        if (first) {
+            // nothing to update: the pose block is the predicted one (or, in a later block step of a wide scan, what the previous
+            // step's downdate left in memory)
+            if (tid < 9) {
+                const int pi = tid % 3, pj = tid / 3, hi = pi > pj ? pi : pj, lo = pi > pj ? pj : pi;
+                const double v9 = do_pred ? ((const double *)&ctl->pred[A.pred_slot & 1])[2 + hi + 3 * lo] : rekf_plower(P, (int)ld, hi, lo);
+                ctl->post_C9[tid] = v9;
+                if (d.pub) host_slot_store(d.pub + 3 + tid, v9, d.pub_seq, 0);
+            }
+            append_new_means();                 // (a barrier inside: s_np is complete behind it)
+            if (d.pub) {
+                if (tid < 3) host_slot_store(d.pub + tid, s_np[tid], d.pub_seq, 0);
+                if (tid == 3) host_slot_store(d.pub + 12, (double)(n + 2 * s_cnt[5]), d.pub_seq,
+                                              __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
+        }
         // k_downdate2 runs without looking at the control block when the host knows n: give it zeros to add
         const int snb = rekf_strip_base(n);
         for (int e = tid; e < 16 * d.kc_ub; e += 512) {
@@ -1211,7 +1226,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
         const int idx = lane & 15, kq = lane >> 4;
         for (int jt = wave; jt < NBR; jt += 4) {
             const int j0 = 16 * jt;
-            double part = 0.0;
+            double part = 0.0, pc0 = 0.0, pc1 = 0.0, pc2 = 0.0;
             if (jt < nbr) {
                 // two accumulation chains (a dependent MFMA costs ~100 cycles, an independent one 64), operands of a whole
                 // 16-row block of k read before its MFMAs issue
@@ -1236,11 +1251,20 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
                     if (strip_nb >= 0 && i0 + idx >= strip_nb && i0 + idx < strip_nb + REKF_STRIP_MAX)
                         d.KnB[(i0 + idx - strip_nb) * REKF_MR_PAD + j] = -acc[r];
                     part += acc[r] * s_coef[8 * j + 6];                          // K(i, j) (z - zhat)(j)
+                    if (first) {                                                 // (K H P)(i, jc) = sum_j K(i, j) W(jc, j), jc = 0..2
+                        pc0 += acc[r] * s_wown[j][0]; pc1 += acc[r] * s_wown[j][1]; pc2 += acc[r] * s_wown[j][2];
+                    }
                 }
                 part += __shfl_xor(part, 16, 64);
                 part += __shfl_xor(part, 32, 64);
+                if (first) {
+                    pc0 += __shfl_xor(pc0, 16, 64); pc0 += __shfl_xor(pc0, 32, 64);
+                    pc1 += __shfl_xor(pc1, 16, 64); pc1 += __shfl_xor(pc1, 32, 64);
+                    pc2 += __shfl_xor(pc2, 16, 64); pc2 += __shfl_xor(pc2, 32, 64);
+                }
             }
             if (kq == 0) s_dmu[jt & 3][idx] = part;
+            if (first && kq == 0) { s_dc[jt & 3][0][idx] = pc0; s_dc[jt & 3][1][idx] = pc1; s_dc[jt & 3][2][idx] = pc2; }
         }
     }
     __syncthreads();
@@ -1260,7 +1284,27 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
             if (first && i < 3) s_np[i] = v;
         }
     }
-    if (first) append_new_means();
+    if (first) {
+        // the pose block after the update, P'(i, j) - (K H P)(i, j), lower element for both halves (RekfCtl::post_C9): to the control
+        // block for the downdate's tile (0, 0), and to the host
+        if (tid >= 64 && tid < 64 + 9) {
+#pragma clang fp contract(off)
+            const int e = tid - 64, pi = e % 3, pj = e / 3, hi = pi > pj ? pi : pj, lo = pi > pj ? pj : pi;
+            double khp = 0.0;
+#pragma unroll
+            for (int jt = 0; jt < NBR; ++jt) khp += s_dc[jt][lo][hi];
+            const double base = do_pred ? s_pred[2 + hi + 3 * lo] : s_pw[lo][hi];
+            const double v9 = base - khp;
+            ctl->post_C9[e] = v9;
+            if (d.pub) host_slot_store(d.pub + 3 + e, v9, d.pub_seq, 0);
+        }
+        append_new_means();                     // (a barrier inside: s_np is complete behind it)
+        if (d.pub) {
+            if (tid < 3) host_slot_store(d.pub + tid, s_np[tid], d.pub_seq, 0);
+            if (tid == 3) host_slot_store(d.pub + 12, (double)(n + 2 * s_cnt[5]), d.pub_seq,
+                                          __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+    }
 #ifdef REKF_DEBUG_TIMING
     if (recm) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1346,12 +1390,10 @@ extern "C" int rekf_debug_dd_times(long long *out, int n_wg)
 }
 #endif
 // The body is shared by two kernels: k_downdate2 (the downdate alone) and k_dd_front (LAZY DOWNDATE, rekf_api.hip: the downdate of scan
-// t enqueued with scan t+1, whose front end -- Predict's pose and ReflectorMatch, which need the mean k_mid(t) left but nothing of P --
-// runs in extra workgroups beside it).  dn / An = the device view and the launch packet of scan t+1 in the fused kernel, else null: the
-// workgroup that ends on tile (0, 0) then also evaluates scan t+1's predicted pose block from the block it has just committed and
-// leaves it, with (a, b), in scan t+1's RekfCtl::pred slot (the front role beside it cannot: the block does not exist before this tile).
+// t enqueued with scan t+1, whose front end -- Predict's pose and ReflectorMatch, which need the mean and the pose block k_mid(t) left
+// but nothing else of P -- runs in extra workgroups beside it).
 template <int KC>
-__device__ __forceinline__ void dd_body(const RekfDev &d, const RekfDev *dn, const RekfFrontArgs *An)
+__device__ __forceinline__ void dd_body(const RekfDev &d)
 {
     extern __shared__ __attribute__((aligned(16))) double dd_smem[];   // [Kn 0 | Kn 1 | HPt 0 | HPt 1] panels (+ 16 KiB strip scratch if KC < 64)
     __shared__ __attribute__((aligned(16))) double s_border[2][DD_STRIP_MAX][REKF_MR_PAD];
@@ -1386,20 +1428,15 @@ __device__ __forceinline__ void dd_body(const RekfDev &d, const RekfDev *dn, con
     __shared__ double s_pred[12];
     double pred_v = 0.0;
     if (pred_on && threadIdx.x >= 64 && threadIdx.x < 64 + 11) pred_v = ((const double *)&ctl->pred[d.pred_slot & 1])[threadIdx.x - 64];   // ab[0], ab[1], C9[0..8]
+    // the pose block after this update, as k_mid evaluated and published it (RekfCtl::post_C9): tile (0, 0) stores THOSE bits
+    __shared__ double s_post[9];
+    double post_v = 0.0;
+    if (blockIdx.x == 0 && threadIdx.x >= 128 && threadIdx.x < 128 + 9) post_v = ctl->post_C9[threadIdx.x - 128];
     int n = d.n_known;
     if (n < 0) {
         n = ctl->n;
         // (with a Predict pending the kernel runs even so: k_mid has left zero panels, and the tiles of column 0 commit the Predict)
-        if (ctl->m == 0 && !pred_on) {       // nothing matched: P stays as it is -- but the caller still gets its pose
-            if (d.pub && blockIdx.x == 0) {
-                const int l = threadIdx.x;
-                if (l < 3) host_slot_store(d.pub + l, d.mu[l], d.pub_seq, 0);
-                else if (l < 12) host_slot_store(d.pub + l, rekf_plower(d.P, d.ld, (l - 3) % 3, (l - 3) / 3), d.pub_seq, 0);
-                else if (l == 12) host_slot_store(d.pub + 12, (double)(n + (d.pub_aug ? 2 * ctl->n_new : 0)), d.pub_seq,
-                                                  __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            }
-            return;
-        }
+        if (ctl->m == 0 && !pred_on) return;   // nothing matched and nothing pending: P stays as it is (k_mid has published the pose)
     }
     constexpr int NK = KC / 4;               // MFMA k-steps per tile
     constexpr int ND = KC / 8;               // DMA instructions per panel per wave (2 k-rows each, 4 waves)
@@ -1420,11 +1457,7 @@ __device__ __forceinline__ void dd_body(const RekfDev &d, const RekfDev *dn, con
     // (When class B gets fewer than three tiles per workgroup -- small states -- class A keeps to its diagonal tile and the tiles
     // below the diagonal join class B: dd_sub = 1.)
     const bool classA = w < T;
-    // fused kernel, the workgroup of tile (0, 0): the motion terms of scan t+1's Predict (one sincos), on an idle lane, now
-    __shared__ Motion s_mo;
-    __shared__ double s_c9[9];
-    const bool next_corner = An != nullptr && classA && w == 0;
-    if (next_corner && threadIdx.x == 192) motion_terms(*An, dn->mu[2], s_mo);
+
     // class B: every free workgroup takes tiles -- lo each, the first x of them one more (2 or 3 at T = 32: 465 tiles on 224
     // workgroups; round 2 gave three tiles to 155 workgroups and left 69 CUs idle).  (lo, x) come from the host when it knows n
     // exactly (no division in the prologue), else they are derived here from the real T and the grid the host sized by its
@@ -1559,6 +1592,7 @@ __device__ __forceinline__ void dd_body(const RekfDev &d, const RekfDev *dn, con
         dd_wait_vmcnt<16>();                 // the DMAs (and everything before them); the 16 P loads may still fly
     } else dd_wait_vmcnt<8>();
     if (pred_on && tid >= 64 && tid < 64 + 11) s_pred[tid - 64] = pred_v;
+    if (blockIdx.x == 0 && tid >= 128 && tid < 128 + 9) s_post[tid - 128] = post_v;
     if (want_border) {                       // (older than the DMAs: arrived)
         ((v2d *)&s_border[0][0][0])[tid] = bdr0;                   // s_border[0] = Kn rows nb.., [1] = HPt rows nb..
         ((v2d *)&s_border[1][0][0])[tid] = bdr1;
@@ -1677,23 +1711,15 @@ __device__ __forceinline__ void dd_body(const RekfDev &d, const RekfDev *dn, con
             // single operations the covariance pass of the front kernel used to do in memory; the 3 x 3 pose block by value
 #pragma clang fp contract(off)
             const double pa = s_pred[0], pb = s_pred[1];
-            const double *pC9 = s_pred + 2;
             const double c2x = __shfl_down(pq[PAR][0].x, 16, 64), c2y = __shfl_down(pq[PAR][0].y, 16, 64);
             if (wj == 0 && kq == 0) {
                 const int r0 = DT * I + 32 * wi + 2 * idx;              // this lane's rows r0, r0 + 1; register 0 = column 0, register 4 = column 1
                 if (r0 >= 4) {
                     pq[PAR][0].x = pq[PAR][0].x + pa * c2x; pq[PAR][4].x = pq[PAR][4].x + pb * c2x;
                     pq[PAR][0].y = pq[PAR][0].y + pa * c2y; pq[PAR][4].y = pq[PAR][4].y + pb * c2y;
-                } else if (r0 == 0) {                                    // (0,0) (1,0) | (0,1) (1,1)
-                    pq[PAR][0].x = pC9[0]; pq[PAR][0].y = pC9[1]; pq[PAR][4].x = pC9[3]; pq[PAR][4].y = pC9[4];
-                } else {                                                 // rows 2, 3: (2,0) (2,1) of the block, row 3 ordinary
-                    pq[PAR][0].y = pq[PAR][0].y + pa * c2y; pq[PAR][4].y = pq[PAR][4].y + pb * c2y;
-                    pq[PAR][0].x = pC9[2]; pq[PAR][4].x = pC9[5];
+                } else if (r0 == 2) {                                    // row 3 is an ordinary row; rows 0..2 are the pose block, which
+                    pq[PAR][0].y = pq[PAR][0].y + pa * c2y; pq[PAR][4].y = pq[PAR][4].y + pb * c2y;     // tile (0, 0) takes by value below
                 }
-            }
-            if (wj == 0 && kq == 1 && I == 0 && wi == 0 && idx < 2) {     // column 2 of the pose block
-                if (idx == 0) { pq[PAR][0].x = pC9[6]; pq[PAR][0].y = pC9[7]; }
-                else pq[PAR][0].x = pC9[8];
             }
         }
         // P + sum_k (the P block was requested a tile ago)
@@ -1704,6 +1730,12 @@ __device__ __forceinline__ void dd_body(const RekfDev &d, const RekfDev *dn, con
                 pq[PAR][mt * 4 + r].x += acc[mt][0][r];
                 pq[PAR][mt * 4 + r].y += acc[mt][1][r];
             }
+        if (DIAGSYM && I == 0 && wave == 0 && idx < 2 && kq < 2) {
+            // the pose block: the values k_mid evaluated and published (lower triangle; the mirror below fills the rest)
+            if (idx == 0 && kq == 0) { pq[PAR][0].x = s_post[0]; pq[PAR][0].y = s_post[1]; pq[PAR][4].y = s_post[4]; }
+            if (idx == 1 && kq == 0) { pq[PAR][0].x = s_post[2]; pq[PAR][4].x = s_post[5]; }
+            if (idx == 1 && kq == 1) pq[PAR][0].x = s_post[8];
+        }
         if (DIAGSYM) {
             // the NEW tile through LDS, S[j][i] = element (i, j) (row stride 66: the lanes of a 16-group differ in i); an element
             // above the diagonal (i < j) then takes S[i][j] = the new element (j, i): the upper half is the mirror image of the
@@ -1777,48 +1809,6 @@ __device__ __forceinline__ void dd_body(const RekfDev &d, const RekfDev *dn, con
             double *Pw = p_ptr(I, J);
 #pragma unroll
             for (int q = 0; q < 8; ++q) DD_STORE((v2d *)(Pw + (size_t)(8 * (q & 3) + (q >> 2)) * ld), pq[PAR][q]);
-            if (d.pub && I == 0 && J == 0 && wave == 0) {
-                // the final 3 x 3 pose block sits in four lanes of wave 0 (rows 2 idx + {0,1}, columns 2 kq + {0 (q = 0), 1 (q = 4)}):
-                // straight to the host's slots 3 + r + 3 c.  The mean k_mid committed, n and the flags go with it (lanes 32..35):
-                // this workgroup ends 3 us before the kernel does, so nobody waits for the PCIe writes
-                if (lane >= 32 && lane < 35) host_slot_store(d.pub + (lane - 32), d.mu[lane - 32], d.pub_seq, 0);
-                // n as it will be once the k_augment enqueued behind this kernel has run (k_mid has left the number of new
-                // reflectors, already clamped to the capacity, in the control block): nobody has to publish after k_augment
-                if (lane == 35) host_slot_store(d.pub + 12, (double)(n + (d.pub_aug ? 2 * d.ctl->n_new : 0)), d.pub_seq,
-                                                __hip_atomic_load(&d.ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                const int c0 = 2 * kq;
-                if (idx == 0 && kq < 2) {
-                    host_slot_store(d.pub + 3 + 0 + 3 * c0, pq[PAR][0].x, d.pub_seq, 0);
-                    host_slot_store(d.pub + 3 + 1 + 3 * c0, pq[PAR][0].y, d.pub_seq, 0);
-                    if (kq == 0) {
-                        host_slot_store(d.pub + 3 + 0 + 3, pq[PAR][4].x, d.pub_seq, 0);
-                        host_slot_store(d.pub + 3 + 1 + 3, pq[PAR][4].y, d.pub_seq, 0);
-                    }
-                }
-                if (idx == 1 && kq < 2) {
-                    host_slot_store(d.pub + 3 + 2 + 3 * c0, pq[PAR][0].x, d.pub_seq, 0);
-                    if (kq == 0) host_slot_store(d.pub + 3 + 2 + 3, pq[PAR][4].x, d.pub_seq, 0);
-                }
-            }
-            if (next_corner && I == 0 && J == 0 && wave == 0) {
-                // scan t+1's Predict on the pose block this tile has just committed (cc:178 / :202): the six lower elements meet in
-                // LDS (one wave: no barrier), lane 0 evaluates G P G^T + V and hands block and (a, b) to scan t+1's slot
-                if (idx == 0 && kq == 0) { s_c9[0] = pq[PAR][0].x; s_c9[1] = pq[PAR][0].y; s_c9[4] = pq[PAR][4].y; }
-                if (idx == 1 && kq == 0) { s_c9[2] = pq[PAR][0].x; s_c9[5] = pq[PAR][4].x; }
-                if (idx == 1 && kq == 1) s_c9[8] = pq[PAR][0].x;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane == 0) {
-                    double C[9];
-                    C[0] = s_c9[0]; C[1] = s_c9[1]; C[2] = s_c9[2]; C[4] = s_c9[4]; C[5] = s_c9[5]; C[8] = s_c9[8];
-                    C[3] = C[1]; C[6] = C[2]; C[7] = C[5];
-                    const Motion mo = s_mo;
-                    corner_predict(C, 3, mo);
-                    RekfCtl::Pred *pr = &dn->ctl->pred[An->pred_slot & 1];
-                    pr->ab[0] = mo.a; pr->ab[1] = mo.b;
-#pragma unroll
-                    for (int q = 0; q < 9; ++q) pr->C9[q] = C[q];
-                }
-            }
             return;
         }
         if (needH) dd_wait_vmcnt<(!FIRST ? 4 : 0) + (LOAD2 ? 8 : 0)>();             // after the last HPt DMA: (the second half of the stores +) this tile's 8 P loads
@@ -1906,7 +1896,7 @@ __device__ __forceinline__ void dd_body(const RekfDev &d, const RekfDev *dn, con
 template <int KC>
 __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
 {
-    dd_body<KC>(d, nullptr, nullptr);
+    dd_body<KC>(d);
 }
 template <int KC>
 __global__ __launch_bounds__(256) void k_dd_front(RekfDev d, RekfDev dn, RekfFrontArgs A)
@@ -1915,7 +1905,7 @@ __global__ __launch_bounds__(256) void k_dd_front(RekfDev d, RekfDev dn, RekfFro
         front_role<256>(dn, A, (int)blockIdx.x - d.dd_grid, (int)gridDim.x - d.dd_grid, true);
         return;
     }
-    dd_body<KC>(d, &dn, &A);
+    dd_body<KC>(d);
 }
 
 // ----------------------------------------------------------------------------

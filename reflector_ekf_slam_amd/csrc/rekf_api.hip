@@ -683,7 +683,6 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     auto downdate = [&](bool first, bool last) {
         RekfDev dd = h->dev;
         dd.pred_slot = first ? pred_slot : -1;        // the scan's first downdate commits its Predict
-        if (last) { dd.pub = h->host_slots_dev; dd.pub_seq = pub_seq; dd.pub_aug = aug ? 1 : 0; }
         if (last && hold_back) { h->dd_pending = true; h->dd_dev = dd; h->dd_n_ub = n_ub; return; }     // (lazy downdate: with the next call)
         ProfScope ps(h, REKF_K_DOWNDATE);
         rekf_launch_downdate(dd, n_ub, h->stream);
@@ -702,7 +701,12 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
             a.pair0 = p0;
             a.apply_pred = (p0 == 0) ? 1 : 0;
             h->dev.mu_lin = h->dev_mu_lin;
-            { ProfScope ps(h, REKF_K_MID); rekf_launch_mid(h->dev, a, n_ub, 64, h->stream); }
+            {
+                RekfDev dm = h->dev;                   // the scan's last k_mid publishes pose, pose block, n and flags
+                if (p0 + stride >= K) { dm.pub = h->host_slots_dev; dm.pub_seq = pub_seq; }
+                ProfScope ps(h, REKF_K_MID);
+                rekf_launch_mid(dm, a, n_ub, 64, h->stream);
+            }
             std::swap(h->dev.mu, h->dev.mu_out);
             downdate(p0 == 0, p0 + stride >= K);      // the last step commits the final pose
         }
@@ -711,7 +715,12 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     } else {
         // the whole innovation fits one pass: gather + solve + gain as ONE launch (k_mid), which leaves the updated
         // mean in the other mean buffer
-        { ProfScope ps(h, REKF_K_MID); rekf_launch_mid(h->dev, a, n_ub, m_ub, h->stream); }
+        {
+            RekfDev dm = h->dev;                       // k_mid's workgroup 0 publishes pose, pose block, n and flags
+            dm.pub = h->host_slots_dev; dm.pub_seq = pub_seq;
+            ProfScope ps(h, REKF_K_MID);
+            rekf_launch_mid(dm, a, n_ub, m_ub, h->stream);
+        }
         std::swap(h->dev.mu, h->dev.mu_out);
         downdate(true, true);
     }
