@@ -19,19 +19,20 @@ all-gather of a 64-byte result record per rank (reflector_ekf_slam_amd/dist.py).
 Rank 0 prints ONE JSON line.
 
 Extra objects on that line (rank 0, N = 1 unless noted):
-  roofline       the P -= K (H P) kernel (k_downdate2), average launch time measured live
-                 with hipEvents on the handle's stream.  The kernel computes the LOWER
-                 TRIANGLE and mirrors it, so ("scale both FLOP and BYTES by the
+  roofline       the P -= K (H P) kernel (k_downdate2; inside the chain it goes out with the
+                 NEXT scan as k_dd_front, the same body plus that scan's front end in 32
+                 further workgroups), average launch time measured live with hipEvents on
+                 the handle's stream.  P is stored as its LOWER TRIANGLE, so ("scale both FLOP and BYTES by the
                  executed tile fraction") `achieved` / `frac` count the bytes that algorithm
-                 must move -- lower triangle read, all of P written, the two panels -- and
+                 must move -- the triangle read and written, the two panels -- and
                  `mfma.frac` the MFMA FLOP actually executed; the full-square SURVEY figure
                  (16 n^2 + 8 n (3+m)) is kept as `frac_fullsquare`, the PMC-measured bytes as
                  `frac_moved`.  `traffic` is NOT measured in this run: it is read from the
                  committed rocprofv3 PMC summary and labelled with its source file.
   not_full       the same steady state on a filter created with max_landmarks = 2 L (the
                  state a deployed node is in: capacity is a cap, not the map size):
-                 k_augment is launched behind every chain and publishes, n is not known
-                 to the host while it runs ahead of the device.
+                 k_augment is launched for every scan, n is not known to the host while
+                 it runs ahead of the device.
   latency_us     median / p99 of one update: hipEvent pair around each whole chain
                  (device) and host wall time of HandleObservationMessage + GetPose.
   with_5_predicts_per_scan   the same scans with five HandleOdometryMessage
@@ -327,7 +328,8 @@ def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world):
     rocprof_us, traffic, traffic_src, rocprof_src = None, None, None, None
     try:
         avg = json.load(open(os.path.join(ROOT, "profiles", "kernel_avg_us.json")))
-        rocprof_us = next((v for k, v in avg.items() if "k_downdate2<64" in k), None)
+        # inside the chain the downdate runs as k_dd_front<64> (lazy downdate: the next scan's front end in 32 further workgroups)
+        rocprof_us = next((v for k, v in avg.items() if "k_dd_front<64" in k), None) or next((v for k, v in avg.items() if "k_downdate2<64" in k), None)
         rocprof_src = "profiles/kernel_avg_us.json (committed rocprofv3 --kernel-trace summary; NOT measured in this run)"
     except Exception:
         pass
@@ -340,12 +342,13 @@ def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world):
         pass
     moved = (traffic / (dd_us * 1e-6) / 1e9) if traffic else None
     out["roofline"] = {
-        "kernel": "k_downdate2<64> (P -= K (H P) on the lower triangle P is stored as: FP64 MFMA 16x16x4 tiles, panels by LDS DMA)", "bound": "hbm",
+        "kernel": "k_downdate2<64> / k_dd_front<64> (P -= K (H P) on the lower triangle P is stored as: FP64 MFMA 16x16x4 tiles, panels by LDS DMA; "
+                  "inside the chain it is enqueued with the NEXT scan as k_dd_front, whose last 32 workgroups are that scan's front end)", "bound": "hbm",
         "bytes_note": "achieved / frac = bytes the executed lower-triangle algorithm must move: 2 * 8 n(n+1)/2 (triangle read and written) "
                       "+ 8 n (3+m) panels; frac_fullsquare = SURVEY 8(d)'s 16 n^2 + 8 n (3+m) over the same time (what a full-square "
                       "kernel would have had to move); frac_moved = HBM bytes by PMC counters (committed summary) over the same time; "
-                      "*_inchain = the same over the committed rocprofv3 average of the kernel INSIDE the update chain (its panels come "
-                      "fresh from k_mid; back to back they are L2-warm)",
+                      "*_inchain = the same over the committed rocprofv3 average of the kernel INSIDE the update chain, where it runs as "
+                      "k_dd_front<64> on 224 CUs beside the next scan's front end (its panels come fresh from k_mid; back to back they are L2-warm)",
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "frac_fullsquare": bytes_full / (dd_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
         "frac_moved": (moved / HBM_PEAK_GBS) if moved else None,
@@ -398,7 +401,7 @@ def not_full_leg(args, base, cfg, sess, device, out_value=None):
     elapsed, used = timed_region(ekf, scans, 100, steps, None, lambda: None)
     res = {"value": steps / elapsed, "unit": "updates/s", "us_per_update": 1e6 * elapsed / steps, "steps": steps,
            "max_landmarks": 2 * cfg.n_landmarks, "n": ekf.n,
-           "note": "capacity 2 L: k_front_mb -> k_mid -> k_downdate2 -> k_augment (early-out) per update; the last k_downdate2 publishes pose and the post-augment n"}
+           "note": "capacity 2 L: k_dd_front (the previous scan's downdate + this scan's front end) -> k_augment (the previous scan's; early-out) -> k_mid per update; k_mid publishes pose and the post-augment n"}
     # ... and as the reference's node drives it: the pose read back after every scan (the host then knows n exactly and predicts itself)
     t0 = time.perf_counter()
     for t, ob in scans[used:used + steps]:

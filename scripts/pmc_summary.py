@@ -22,7 +22,9 @@ for k in sorted(set(F) | set(W)):
     f = statistics.mean(F.get(k, [0])); w = statistics.mean(W.get(k, [0]))
     hbm = (2 * f + w) * 1024
     lines.append(f"{k[:44]:44s} {f:10.1f} {w:10.1f} {hbm/1e6:8.2f}")
-    if "k_downdate2<64" in k:
+    # the downdate inside the update chain: k_dd_front<64> (lazy downdate: with the next scan's front end in 32 further workgroups,
+    # which move a few KB); the stand-alone k_downdate2<64> only where nothing runs as k_dd_front
+    if "k_dd_front<64" in k or ("k_downdate2<64" in k and not out):
         out = {"kernel": k, "fetch_size_kb": f, "write_size_kb": w, "hbm_bytes_per_launch": hbm,
                "note": "2*FETCH_SIZE + WRITE_SIZE, KB->bytes; see profiles/%s_pmc.txt" % tag}
 open(f"profiles/{tag}_pmc.txt", "w").write("\n".join(lines) + "\n")
