@@ -112,10 +112,10 @@ struct RekfDev {
     int dbg;            // ablation bits for rekf_debug_time_kernel; 0 in normal operation
     int n_known;        // the exact state dimension when the host knows it (state full, or nothing enqueued since a read-back), else -1:
                         // spares the kernels a dependent read of ctl->n at their start
-    RekfHostSlot *pub;  // non-null (only in the launch of the LAST k_mid of a call): its workgroup 0 publishes the pose mean, the 3 x 3 pose
-                        // block after the update, the n the state will have once k_augment has run, and the flags ...
+    RekfHostSlot *pub;  // non-null (only in the launch of the LAST k_downdate2 / k_dd_front of a call): its first workgroup publishes, at its
+                        // START, the pose mean, the 3 x 3 pose block after the update (RekfCtl::post_C9), n and the flags ...
     int pub_seq;        //   ... under this tag, so that GetPose / Sync after the call need no kernel of their own
-    int pub_aug;        //   (unused since k_mid publishes: it knows the number of new reflectors itself)
+    int pub_aug;        //   ... and a k_augment follows: the n to publish is n + 2 ctl->n_new (neither pose nor pose block change there)
     int dd_lo, dd_x;    // k_downdate2, class B: tiles per workgroup -- dd_lo each, the first dd_x workgroups one more (set by rekf_launch_downdate)
     int dd_sub;         // k_downdate2: class B holds the tiles with I >= J + dd_sub (2: a class-A workgroup also takes the tile below its
                         // diagonal tile; 1: it does not; 0: the host does not know n exactly -- the kernel derives the schedule itself)

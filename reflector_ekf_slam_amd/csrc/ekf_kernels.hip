@@ -885,7 +885,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
                 if (d.pub) host_slot_store(d.pub + 3 + tid, v9, d.pub_seq, 0);
             }
             append_new_means();                 // (a barrier inside: s_np is complete behind it)
-            if (d.pub) {
+            if (d.pub) {                        // (the early publisher, see the end of the kernel)
                 if (tid < 3) host_slot_store(d.pub + tid, s_np[tid], d.pub_seq, 0);
                 if (tid == 3) host_slot_store(d.pub + 12, (double)(n + 2 * s_cnt[5]), d.pub_seq,
                                               __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -1286,7 +1286,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
     }
     if (first) {
         // the pose block after the update, P'(i, j) - (K H P)(i, j), lower element for both halves (RekfCtl::post_C9): to the control
-        // block for the downdate's tile (0, 0), and to the host
+        // block: the downdate's tile (0, 0) stores it
         if (tid >= 64 && tid < 64 + 9) {
 #pragma clang fp contract(off)
             const int e = tid - 64, pi = e % 3, pj = e / 3, hi = pi > pj ? pi : pj, lo = pi > pj ? pj : pi;
@@ -1299,6 +1299,9 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
             if (d.pub) host_slot_store(d.pub + 3 + e, v9, d.pub_seq, 0);
         }
         append_new_means();                     // (a barrier inside: s_np is complete behind it)
+        // The EARLY publisher (d.pub set on this launch: the caller has been reading the pose back after its scans, rekf_api.hip): pose,
+        // block, n and flags go to the host from here, a kernel before the downdate -- at the price of 0.8 us at the end of this kernel
+        // (it ends when the PCIe writes are through).  Otherwise the downdate's first workgroup publishes, at its start.
         if (d.pub) {
             if (tid < 3) host_slot_store(d.pub + tid, s_np[tid], d.pub_seq, 0);
             if (tid == 3) host_slot_store(d.pub + 12, (double)(n + 2 * s_cnt[5]), d.pub_seq,
@@ -1436,8 +1439,18 @@ __device__ __forceinline__ void dd_body(const RekfDev &d)
     if (n < 0) {
         n = ctl->n;
         // (with a Predict pending the kernel runs even so: k_mid has left zero panels, and the tiles of column 0 commit the Predict)
-        if (ctl->m == 0 && !pred_on) return;   // nothing matched and nothing pending: P stays as it is (k_mid has published the pose)
     }
+    // The publisher (the scan's last downdate): pose mean, the pose block AFTER this update (RekfCtl::post_C9: k_mid evaluated it; tile
+    // (0, 0) below stores the same bits), the n the state will have once the k_augment behind this kernel has run, and the flags --
+    // at the START of the kernel: everything is known, and the stores are long through when the kernel ends
+    if (d.pub && blockIdx.x == 0) {
+        const int l = threadIdx.x;
+        if (l < 3) host_slot_store(d.pub + l, d.mu[l], d.pub_seq, 0);
+        else if (l < 12) host_slot_store(d.pub + l, ctl->post_C9[l - 3], d.pub_seq, 0);
+        else if (l == 12) host_slot_store(d.pub + 12, (double)(n + (d.pub_aug ? 2 * ctl->n_new : 0)), d.pub_seq,
+                                          __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    if (d.n_known < 0 && ctl->m == 0 && !pred_on) return;   // nothing matched and nothing pending: P stays as it is
     constexpr int NK = KC / 4;               // MFMA k-steps per tile
     constexpr int ND = KC / 8;               // DMA instructions per panel per wave (2 k-rows each, 4 waves)
     constexpr int PANEL = KC * 64;           // doubles per panel

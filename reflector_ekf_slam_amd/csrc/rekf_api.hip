@@ -73,6 +73,11 @@ struct rekf {
     bool dd_aug = false;            // the scan's k_augment is held back with it (the state can still grow): it runs right behind the downdate
     RekfFrontArgs dd_aug_args;      // ... with the scan's launch packet (the new reflectors' observations)
     bool lazy_dd = true;            // REKF_LAZY_DD=0 in the environment turns it off (A/B measurements)
+    // WHO PUBLISHES pose, pose block, n and flags of a scan.  A caller that reads the pose back after its scans (the reference's node,
+    // src/ros_node.cc:514-515) gets them from k_mid's workgroup 0 -- a kernel earlier: GetPose does not wait for the downdate -- which
+    // costs that kernel 0.8 us (it ends when the PCIe writes are through); a caller that enqueues scan after scan gets them from the
+    // first workgroup of the downdate, at its start, off every critical path.  Decided per scan from what the caller did since the last one.
+    bool pose_read_since_scan = true;
     bool last_scan_empty = false;   // the last HandleObservationMessage had no points: its (empty) match record lives here, not on the device
     RekfCtl *ctl_staging;      // pinned copy of the control block
     std::string hip_error;
@@ -286,6 +291,7 @@ int refresh_mirror(rekf_t *h)
         rekf_launch_publish_pose(h->dev, h->host_slots_dev, seq, h->stream);
         HIP_TRY(h, hipGetLastError());
     }
+    h->pose_read_since_scan = true;
     int rc = wait_slots(h, 0, 13, h->pub_seq);        // all of them: the last kernels of a call store different slots
     if (rc != REKF_OK) return rc;
     for (int q = 0; q < 3; ++q) h->mir_mu[q] = h->host_slots[q].v;
@@ -680,9 +686,12 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     // lazy downdate (struct rekf): the scan's last downdate -- and its k_augment -- go out with the next call.  (Not for a staged scan:
     // its k_augment reads the observations from a device buffer the next staged scan overwrites.)
     const bool hold_back = h->lazy_dd && !staged;
+    const bool early_pub = h->pose_read_since_scan;   // (struct rekf: WHO PUBLISHES)
+    h->pose_read_since_scan = false;
     auto downdate = [&](bool first, bool last) {
         RekfDev dd = h->dev;
         dd.pred_slot = first ? pred_slot : -1;        // the scan's first downdate commits its Predict
+        if (last && !early_pub) { dd.pub = h->host_slots_dev; dd.pub_seq = pub_seq; dd.pub_aug = aug ? 1 : 0; }     // ... its last one publishes (at its start)
         if (last && hold_back) { h->dd_pending = true; h->dd_dev = dd; h->dd_n_ub = n_ub; return; }     // (lazy downdate: with the next call)
         ProfScope ps(h, REKF_K_DOWNDATE);
         rekf_launch_downdate(dd, n_ub, h->stream);
@@ -702,8 +711,8 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
             a.apply_pred = (p0 == 0) ? 1 : 0;
             h->dev.mu_lin = h->dev_mu_lin;
             {
-                RekfDev dm = h->dev;                   // the scan's last k_mid publishes pose, pose block, n and flags
-                if (p0 + stride >= K) { dm.pub = h->host_slots_dev; dm.pub_seq = pub_seq; }
+                RekfDev dm = h->dev;
+                if (early_pub && p0 + stride >= K) { dm.pub = h->host_slots_dev; dm.pub_seq = pub_seq; }
                 ProfScope ps(h, REKF_K_MID);
                 rekf_launch_mid(dm, a, n_ub, 64, h->stream);
             }
@@ -716,8 +725,8 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         // the whole innovation fits one pass: gather + solve + gain as ONE launch (k_mid), which leaves the updated
         // mean in the other mean buffer
         {
-            RekfDev dm = h->dev;                       // k_mid's workgroup 0 publishes pose, pose block, n and flags
-            dm.pub = h->host_slots_dev; dm.pub_seq = pub_seq;
+            RekfDev dm = h->dev;
+            if (early_pub) { dm.pub = h->host_slots_dev; dm.pub_seq = pub_seq; }
             ProfScope ps(h, REKF_K_MID);
             rekf_launch_mid(dm, a, n_ub, m_ub, h->stream);
         }
