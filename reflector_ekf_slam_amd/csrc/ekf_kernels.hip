@@ -1,25 +1,28 @@
 // ekf_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the EKF hot path.
 //
-// One HandleObservationMessage (reference reflector_ekf_slam.cc:229-368) is the kernel chain
-//     front_mb -> mid -> downdate2 (-> augment)
+// One HandleObservationMessage (reference reflector_ekf_slam.cc:229-368) is the arithmetic
+//     front end -> mid -> downdate (-> augment)
 // on the handle's stream, with every size (n, m, match lists) resident in HBM (RekfCtl) so the host never waits for
-// the device between scans.
+// the device between scans.  Launches (round 3, rekf_api.hip "lazy downdate"): a scan's downdate (and augment) are held back and go
+// out with the next call; scan after scan that is  k_dd_front (previous downdate + this scan's front end) [-> k_augment] -> k_mid.
 //
-//   k_front_mb  predict (cc:154-206) + ReflectorMatch (cc:370-455), one observation per workgroup
+//   front_role  Predict's pose (cc:154-206) + ReflectorMatch (cc:370-455), one observation per workgroup: k_front_mb on its own, the
+//               last workgroups of k_dd_front beside the previous scan's downdate.  Predict's O(n) covariance part is not applied to
+//               memory: it travels as (a, b) + predicted pose block (RekfCtl::pred) and k_mid / the downdate apply it to what they read
 //   k_mid       ordered compaction, H rows / z - zhat (cc:248-304); W = P H^T and (H P)^T from the <= 5 structural
 //               non-zeros of each H row (cc:305,308); S = H W + Q and S^-1 by in-register blocked Gauss-Jordan;
 //               K = W S^-1 (FP64 MFMA), mu += K (z - zhat), theta wrap (cc:305-307) -- one launch, the 64 x 64
 //               inverse redone by every workgroup rather than handed around
-//   k_downdate2 P += Kn (H P): the FP64 MFMA, LDS-tiled rank-m downdate (cc:308) -- the roofline kernel
-//   k_augment   new landmark means and covariance blocks (cc:311-364)
+//               (workgroup 0 also: the pose block after the update, RekfCtl::post_C9, and the new reflectors' means, cc:323-342)
+//   k_downdate2 / k_dd_front   P += Kn (H P): the FP64 MFMA, LDS-tiled rank-m downdate (cc:308) -- the roofline kernel
+//   k_augment   the new landmarks' covariance rows (cc:343-364)
 //   k_apply_predict   odometry messages and empty scans are predicted by the HOST (pose mirror, rekf_api.hip) and cost no launch;
 //               this kernel applies their composite to P when the device state is needed before the next scan
 // Scans with more than 32 matched pairs (or more than 64 observations: k_compact_wide) run the joint update as exact
 // block steps, k_mid + k_downdate2 per 32 pairs (see k_mid).
 //
 // The stored covariance is EXACTLY symmetric, bit for bit: every kernel that writes P writes both halves from ONE computed
-// value (k_downdate2 computes the lower-triangle tiles and mirrors them, the predict corner and the augment blocks are
-// mirrored).  W = P H^T is gathered from the columns of P and (H P)^T(c, r) = W(c, r) is stored from the same values.
+// value (P is STORED as its lower triangle, ekf_dev.h: nothing ever reads the other half).  W = P H^T is gathered from the columns of P and (H P)^T(c, r) = W(c, r) is stored from the same values.
 // (On a P that is only NEARLY symmetric taking H P := (P H^T)^T is unstable -- the antisymmetric round-off part A then evolves
 // as A + (P G) A (G P) instead of the reference's contraction (I - P G) A (I - G P), G = H^T S^-1 H: measured 1e-17 -> 1e-5 in
 // 300 scans in round 1 -- which is why nothing here ever leaves the two halves to independent round-off)
