@@ -403,3 +403,69 @@ def test_lazy_downdate_gives_the_eager_chains_bits(oracle_lib, monkeypatch, L, o
     assert np.array_equal(sa.mu, sb.mu) and np.array_equal(sa.sigma, sb.sigma)
     assert np.abs(sa.mu - mo).max() < TIGHT and np.abs(sa.sigma - Po).max() < 1e-11
     assert ga.sync_code() == 0 and gb.sync_code() == 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_call_patterns_around_the_held_back_downdate(oracle_lib, seed):
+    """Everything a caller can do between two scans, in random order, on a filter that is still growing (capacity as a cap): scans
+    back to back (k_dd_front + the held-back k_augment), pose / state / predicted-state read-backs, odometry, empty scans, a wide
+    scan, rekf_reserve, a look at the device layout, set_state from the filter's own state.  Whatever is held back must have been
+    enqueued before anybody looks: the final state, the association of every checked scan and every value read on the way agree
+    with the oracle."""
+    rng = np.random.default_rng(900 + seed)
+    cfg = synth.SessionConfig("patterns", 120, 14, synth.DIFF if seed % 2 == 0 else synth.OMNI, seed=600 + seed, speed=1.3, row_spacing=5.0)
+    sess = synth.make_session(cfg, max_scans=130)
+    lin, ang, oc = cfg.sigma_v ** 2, cfg.sigma_w ** 2, cfg.sigma_obs ** 2
+    g = make_gpu(cfg.odom_model, sess.init_time, sess.init_pose, lin, ang, oc, 2 * cfg.n_landmarks)
+    o = make_oracle(cfg.odom_model, sess.init_time, sess.init_pose, lin, ang, oc)
+    first = True
+    checked = 0
+    for e in range(sess.n_events):
+        t = sess.ev_time[e]
+        if sess.ev_type[e] == synth.EV_ODOM:
+            if rng.random() < 0.5:
+                continue
+            for f in (g, o):
+                f.handle_odometry(t, *sess.odom[e])
+            continue
+        if first:
+            first = False
+            continue
+        ob = sess.obs_of(e)
+        r = rng.random()
+        if r < 0.06:
+            ob = ob[:0]                                                    # empty scan
+        elif r < 0.12 and ob.shape[0] >= 4:                                # a wide scan: the same reflectors seen several times over
+            ob = np.concatenate([ob + rng.normal(0, 1e-3, ob.shape).astype(np.float32) for _ in range(5)])[:100]
+        for f in (g, o):
+            f.handle_observation(t, ob)
+        a = rng.random()
+        if a < 0.10:
+            _, mu3, s33 = g.pose()
+            mo, Po = o.state()
+            assert np.abs(mu3 - mo[:3]).max() < TIGHT and np.abs(s33 - Po[:3, :3]).max() < 1e-11
+        elif a < 0.16:
+            st = g.GetState()
+            mo, Po = o.state()
+            assert st.mu.shape == mo.shape and np.abs(st.mu - mo).max() < TIGHT and np.abs(st.sigma - Po).max() < 1e-11
+        elif a < 0.20:
+            ps = g.PredictState(t + 0.03)
+            pm, pP = o.predict_state(t + 0.03, full=True)
+            assert np.abs(ps.mu - pm).max() < TIGHT and np.abs(ps.sigma - pP).max() < 1e-11
+        elif a < 0.23:
+            g.reserve(g.max_landmarks + 16)
+        elif a < 0.26:
+            g.device_layout()
+        elif a < 0.29:
+            st = g.GetState()
+            vt = sess.odom[np.nonzero(sess.ev_type[:e + 1] == synth.EV_ODOM)[0][-1]] if np.any(sess.ev_type[:e + 1] == synth.EV_ODOM) else (0.0, 0.0, 0.0)
+            g.set_state(st.time, st.mu, st.sigma, vt)
+            o.set_state(st.time, st.mu, st.sigma, vt)
+        elif a < 0.45:
+            assert _same_match(g, o), f"event {e}"
+            checked += 1
+    st = g.GetState()
+    mo, Po = o.state()
+    assert checked > 5 and st.mu.shape == mo.shape
+    assert np.abs(st.mu - mo).max() < TIGHT and np.abs(st.sigma - Po).max() < 1e-11
+    assert np.array_equal(st.sigma, st.sigma.T) and g.sync_code() == 0
