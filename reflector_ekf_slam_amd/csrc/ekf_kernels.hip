@@ -128,9 +128,27 @@ __device__ static void host_slot_store(RekfHostSlot *p, double v, int seq, int a
 {
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);
     const rekf_u32x4 w = {(unsigned)b, (unsigned)(b >> 32), (unsigned)seq, (unsigned)aux};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(w) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");     // (s_nop: see dd_store_sc1)
 }
 
+// write-through (agent scope) stores for what the NEXT kernel reads from other XCDs: see DD_STORE at k_downdate2
+__device__ static inline void store_wt(double *p, double v)
+{
+#ifdef REKF_EXP_PLAIN_PANEL_STORES
+    *p = v;
+#else
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#endif
+}
+typedef double rekf_v2d __attribute__((ext_vector_type(2)));
+__device__ static inline void store_wt2(double *p, rekf_v2d v)
+{
+#ifdef REKF_EXP_PLAIN_PANEL_STORES
+    *(rekf_v2d *)p = v;
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#endif
+}
 __global__ __launch_bounds__(1024) void k_apply_predict(RekfDev d, RekfFrontArgs A)
 {
 #pragma clang fp contract(off)
@@ -1146,7 +1164,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
                     if (c + 1 >= n) vy = 0.0;
                     *(v2d *)&s_wown[r][2 * pr] = (v2d){vx, vy};
                     // (H P)^T(c, r) = W(c, r) (symmetric P): 8 lanes store 128 contiguous bytes of column r
-                    *(v2d *)&d.HPt[(size_t)c + (size_t)r * ld] = (v2d){vx, vy};
+                    store_wt2(&d.HPt[(size_t)c + (size_t)r * ld], (rekf_v2d){vx, vy});
                     if (strip_nb >= 0) {
                         if (c >= strip_nb && c < strip_nb + REKF_STRIP_MAX) d.HPtB[(c - strip_nb) * REKF_MR_PAD + r] = vx;
                         if (c + 1 >= strip_nb && c + 1 < strip_nb + REKF_STRIP_MAX) d.HPtB[(c + 1 - strip_nb) * REKF_MR_PAD + r] = vy;
@@ -1250,7 +1268,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int j = j0 + kq + 4 * r;                               // D row = column of K
-                    d.Kn[(i0 + idx) + (size_t)j * ld] = -acc[r];
+                    store_wt(&d.Kn[(i0 + idx) + (size_t)j * ld], -acc[r]);
                     if (strip_nb >= 0 && i0 + idx >= strip_nb && i0 + idx < strip_nb + REKF_STRIP_MAX)
                         d.KnB[(i0 + idx - strip_nb) * REKF_MR_PAD + j] = -acc[r];
                     part += acc[r] * s_coef[8 * j + 6];                          // K(i, j) (z - zhat)(j)
@@ -1376,10 +1394,19 @@ template <int N> __device__ static inline void dd_wait_vmcnt()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// The P tiles are stored WRITE-THROUGH at agent scope (sc1): a kernel ends when its dirty lines have left the L2s (each XCD has its
+// own; the next kernel's workgroups read these tiles from other XCDs), and with plain write-back stores most of the 17 MB this kernel
+// writes was still in the L2s at its end.  Written through as they are produced, under the MFMA loops: 11.9 -> 10.7 us back to back,
+// 35.7 -> 35.0 us per update (A/B in one session; non-temporal stores: 11.5 / 35.2).  -DREKF_EXP_PLAIN_STORES / _NT_STORES for A/B builds.
 #ifdef REKF_EXP_NT_STORES
 #define DD_STORE(p, v) __builtin_nontemporal_store((v), (p))
-#else
+#elif defined(REKF_EXP_PLAIN_STORES)
 #define DD_STORE(p, v) (*(p) = (v))
+#else
+// (s_nop: the hazard recogniser does not see into the asm -- a VALU write to the data registers of a 128-bit store needs wait states
+// behind it, and the registers here are often temporaries the compiler refills at once: without them the tiles came out corrupted)
+__device__ static inline void dd_store_sc1(v2d *p, v2d v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
+#define DD_STORE(p, v) dd_store_sc1((p), (v))
 #endif
 // LOWER TRIANGLE ONLY (round 3).  The update K (H P) = P H^T S^-1 H P is symmetric and the filter stores P as its lower triangle
 // (element (i, j) is valid iff i >= j; the memory above the diagonal is never read by any kernel -- ekf_dev.h): only the tiles on and
