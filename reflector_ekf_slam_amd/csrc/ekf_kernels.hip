@@ -1398,6 +1398,13 @@ template <int N> __device__ static inline void dd_wait_vmcnt()
 // own; the next kernel's workgroups read these tiles from other XCDs), and with plain write-back stores most of the 17 MB this kernel
 // writes was still in the L2s at its end.  Written through as they are produced, under the MFMA loops: 11.9 -> 10.7 us back to back,
 // 35.7 -> 35.0 us per update (A/B in one session; non-temporal stores: 11.5 / 35.2).  -DREKF_EXP_PLAIN_STORES / _NT_STORES for A/B builds.
+// ... and the tiles are READ non-temporally: every tile is read exactly once, by one workgroup -- it need not push the panels (which
+// several workgroups share) out of the L2 (34.4 -> 34.1 us per update).  -DREKF_EXP_PLAIN_LOADS for A/B builds.
+#ifdef REKF_EXP_PLAIN_LOADS
+#define DD_LOAD(p) (*(p))
+#else
+#define DD_LOAD(p) __builtin_nontemporal_load(p)
+#endif
 #ifdef REKF_EXP_NT_STORES
 #define DD_STORE(p, v) __builtin_nontemporal_store((v), (p))
 #elif defined(REKF_EXP_PLAIN_STORES)
@@ -1624,14 +1631,14 @@ __device__ __forceinline__ void dd_body(const RekfDev &d)
     {
         const double *Pw = p_ptr(I, J);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) pq[0][q] = *(const v2d *)(Pw + (size_t)(8 * (q & 3) + (q >> 2)) * ld);
+        for (int q = 0; q < 8; ++q) pq[0][q] = DD_LOAD((const v2d *)(Pw + (size_t)(8 * (q & 3) + (q >> 2)) * ld));
     }
     if (AHEAD > 1 && nt > 1) {               // ... and the P block of tile 1
         int I1, J1;
         tile_IJ(1, I1, J1);
         const double *Pw = p_ptr(I1, J1);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) pq[NB - 2][q] = *(const v2d *)(Pw + (size_t)(8 * (q & 3) + (q >> 2)) * ld);
+        for (int q = 0; q < 8; ++q) pq[NB - 2][q] = DD_LOAD((const v2d *)(Pw + (size_t)(8 * (q & 3) + (q >> 2)) * ld));
         dd_wait_vmcnt<16>();                 // the DMAs (and everything before them); the 16 P loads may still fly
     } else dd_wait_vmcnt<8>();
     if (pred_on && tid >= 64 && tid < 64 + 11) s_pred[tid - 64] = pred_v;
@@ -1734,7 +1741,7 @@ __device__ __forceinline__ void dd_body(const RekfDev &d)
             if (ph == PH_LOAD && LOAD2) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
-                    if ((q * Q4) / 8 == off) pq[PREV][q] = *(const v2d *)(Pn + (size_t)(8 * (q & 3) + (q >> 2)) * ld);
+                    if ((q * Q4) / 8 == off) pq[PREV][q] = DD_LOAD((const v2d *)(Pn + (size_t)(8 * (q & 3) + (q >> 2)) * ld));
             }
             if (SPECIAL && (kk & 1) == 0) {                 // strip FMAs ride under the MFMAs: k pair (kk, kk+1) of this wave's quarter
                 const v2d v0 = *(const v2d *)(s_panel + kk * 64), v1 = *(const v2d *)(s_panel + (kk + 1) * 64);
