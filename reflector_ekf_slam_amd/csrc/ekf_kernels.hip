@@ -1952,7 +1952,14 @@ template <int KC>
 __global__ __launch_bounds__(256) void k_dd_front(RekfDev d, RekfDev dn, RekfFrontArgs A)
 {
     if ((int)blockIdx.x >= d.dd_grid) {               // the front end of the NEXT scan: workgroups of their own, nothing of P read or written
+#ifdef REKF_DEBUG_ENTRY
+        if (threadIdx.x == 0 && blockIdx.x < 1024) g_dd_times[blockIdx.x][0] = wall_clock64();
+#endif
         front_role<256>(dn, A, (int)blockIdx.x - d.dd_grid, (int)gridDim.x - d.dd_grid, true);
+#ifdef REKF_DEBUG_ENTRY
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0 && blockIdx.x < 1024) g_dd_times[blockIdx.x][1] = wall_clock64();
+#endif
         return;
     }
     dd_body<KC>(d);

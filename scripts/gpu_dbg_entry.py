@@ -17,20 +17,29 @@ g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks)
 S.replay(sess, g); g.sync()
 L = _lib.rekf()
 L.rekf_debug_dd_times.argtypes = [C.c_void_p, C.c_int]
-scans = synth.steady_state_scans(sess, 40)
+scans = synth.steady_state_scans(sess, 100)
 G = 256
 rows = []
-for t, ob in scans[10:30]:
-    g.handle_observation(t, ob); g.sync()
+hip = C.CDLL("libamdhip64.so")
+it = iter(scans[10:])
+for rep in range(20):
+    for _ in range(3):                       # scan after scan: the second and third run as k_dd_front + k_mid
+        t, ob = next(it); g.handle_observation(t, ob)
+    hip.hipDeviceSynchronize()               # (not g.sync(): that would enqueue the held-back downdate as k_downdate2 and overwrite the stamps)
     buf = (C.c_longlong * (2 * G))()
     L.rekf_debug_dd_times(buf, G)
     a = np.array(list(buf), float).reshape(G, 2) * 0.01
     rows.append(a - a[:, 0].min())
 m = np.median(np.array(rows), axis=0)
 dur = m[:, 1]
-w = np.array([(b & 7) * (G >> 3) + (b >> 3) for b in range(G)])
+GD = 224                       # k_dd_front at C3: 224 downdate workgroups, then 32 front-end workgroups (k_downdate2 alone: GD = G)
+if "--alone" in sys.argv: GD = G
+front = dur[GD:]
+dur = dur[:GD]; m = m[:GD]
+w = np.array([(b & 7) * (GD >> 3) + (b >> 3) for b in range(GD)])
 T = 32
 A = w < T
+if front.size: print("front-end workgroups: exits median %.2f max %.2f us" % (np.median(front), front.max()))
 order = np.argsort(dur)
 print(path.split("/")[-1], f"entries {m[:, 0].min():.2f}..{m[:, 0].max():.2f}; exits: class A median {np.median(dur[A]):.2f} max {dur[A].max():.2f} (block 0: {dur[0]:.2f}); "
       f"class B quartiles {np.percentile(dur[~A], 25):.2f} {np.percentile(dur[~A], 50):.2f} {np.percentile(dur[~A], 75):.2f} max {dur[~A].max():.2f}; "
@@ -38,6 +47,6 @@ print(path.split("/")[-1], f"entries {m[:, 0].min():.2f}..{m[:, 0].max():.2f}; e
 '''
 for p in sys.argv[1:]:
     r = subprocess.run([sys.executable, "-c", CHILD, os.path.abspath(p)], capture_output=True, text=True)
-    print((r.stdout.strip().splitlines() or ["(no output)"])[-1])
+    print("\n".join((r.stdout.strip().splitlines() or ["(no output)"])[-2:]))
     if r.returncode != 0:
         print(r.stderr[-800:])
