@@ -705,8 +705,10 @@ __global__ __launch_bounds__(REKF_MAX_OBS_WIDE) void k_compact_wide(RekfDev d, R
 typedef double v2du __attribute__((ext_vector_type(2), aligned(8)));     // a row pair that starts on an odd row: 8-byte aligned
 #define MID_ROWS 16
 template <int NBR>
-__global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
+__global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, RekfFrontArgs A)
 {
+    // ctl_first = d.ctl, as a leading pointer argument of its own: built with -mllvm -amdgpu-kernarg-preload-count the wave starts with it
+    // in SGPRs, and the kernel's first loads (the match results) do not wait for the kernel-argument fetch
     constexpr int MP = 16 * NBR;                  // most innovation rows (padded) this instance takes
     constexpr int NPAIR = MP / 2;
     constexpr int NRS = NPAIR + 2;                // row slots of the sub-block: state pairs (sorted by landmark), rows {0,1}, row {2}
@@ -744,7 +746,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfDev d, RekfFrontArgs A)
     // 512 threads = two teams of four waves (one of each per SIMD).  Waves 0..3 carry the critical chain -- sub-block
     // gather, W rows of S, S, its inverse -- waves 4..7 everything that only this workgroup's 16 rows / columns need
     // (H rows, own gathers, (H P)^T to HBM), off that chain; both meet at the barriers.
-    RekfCtl *ctl = d.ctl;
+    RekfCtl *ctl = ctl_first;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool steam = wave < 4;                  // S team; the other is the "own" team
     const int tt = tid & 255;                     // thread index within the team
@@ -2095,8 +2097,8 @@ void rekf_launch_mid(const RekfDev &d, const RekfFrontArgs &a, int n_ub, int m_u
 {
     // m_ub <= 64 (the host checks): one workgroup per 16 state rows
     const int grid = (n_ub + MID_ROWS - 1) / MID_ROWS;
-    if (m_ub <= 32) hipLaunchKernelGGL(k_mid<2>, dim3(grid), dim3(512), 0, s, d, a);
-    else hipLaunchKernelGGL(k_mid<4>, dim3(grid), dim3(512), 0, s, d, a);
+    if (m_ub <= 32) hipLaunchKernelGGL(k_mid<2>, dim3(grid), dim3(512), 0, s, d.ctl, d, a);
+    else hipLaunchKernelGGL(k_mid<4>, dim3(grid), dim3(512), 0, s, d.ctl, d, a);
 }
 template <int KC> static void launch_downdate2(const RekfDev &d, int grid, hipStream_t s, bool first_on_device, const RekfDev *dn, const RekfFrontArgs *an, int n_front)
 {
