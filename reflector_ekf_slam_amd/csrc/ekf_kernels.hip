@@ -753,6 +753,11 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     // the match results first, UNCONDITIONALLY (both arrays have 64 entries): a vector load that waits for no scalar one,
     // so the control block costs one memory round trip, not two
     const int kind_raw = ctl->obs_kind[lane], oidx_raw = ctl->obs_idx[lane];
+#ifdef REKF_DEBUG_MID_FIRST
+    MMARK();                                        // (x0: first loads issued)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MMARK();                                        // (x1: ... arrived)
+#endif
     const int n = (d.n_known >= 0) ? d.n_known : ctl->n;
     const int K = A.K;
     const size_t ld = (size_t)d.ld;
@@ -775,6 +780,31 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     __shared__ double s_pred[12];
     if (do_pred && tid >= 64 && tid < 64 + 11) s_pred[tid - 64] = ((const double *)&ctl->pred[A.pred_slot & 1])[tid - 64];   // ab[0], ab[1], C9[0..8]
 
+    // (whole scan) the rank of every state pair's landmark among the matched ones -- 64 keys against 64 keys -- is shared out: each of
+    // the eight waves counts against its eighth of the lanes (all of them hold the match results), wave 0 adds the partial counts up
+    // behind a barrier.  On wave 0 alone the 64 dependent v_readlane steps took 1.1 us of the kernel's critical path.
+    __shared__ int s_rkp[8][64];
+    if (A.pair0 < 0) {
+        const int kind0 = (lane < A.K) ? kind_raw : -1;
+        const int key0 = (kind0 == 1) ? ((lane < A.K) ? oidx_raw : -1) : 0x7fffffff;
+        constexpr int QW = (2 * NPAIR) / 8;
+        const int q0 = __builtin_amdgcn_readfirstlane(wave) * QW;
+        int rkp = 0;
+#pragma unroll
+        for (int qq = 0; qq < QW; ++qq) {
+            const int q = q0 + qq;
+            const int oq = __builtin_amdgcn_readlane(key0, q);
+            rkp += (oq < key0 || (oq == key0 && q < lane)) ? 1 : 0;
+        }
+        s_rkp[wave][lane] = rkp;
+#ifdef REKF_DEBUG_MID_FIRST
+        MMARK();                                    // (x2: partial ranks done)
+#endif
+        __syncthreads();
+#ifdef REKF_DEBUG_MID_FIRST
+        MMARK();                                    // (x3: ... barrier passed)
+#endif
+    }
     // ---- A: the scan's matched pairs.  Whole scan (pair0 < 0): ordered compaction of the per-observation results (obs order
     // preserved), wave 0; workgroup 0 also writes the record for the getters.  Block step of a wide scan (pair0 >= 0): the
     // pairs [pair0, pair0 + stride) of the record k_compact_wide wrote, state pairs first, then map pairs.
@@ -829,14 +859,8 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
         // position of a state pair's landmark rows among the matched ones, by landmark (ties: by lane): neighbouring
         // landmarks share cache lines of a column of P, so the gathers below run over the row slots in this order
         int rk = 0;
-        {
-            const int key = (kind == 1) ? oidx : 0x7fffffff;
 #pragma unroll
-            for (int q = 0; q < 2 * NPAIR; ++q) {                       // K <= 2 NPAIR observations; compile-time lanes: v_readlane
-                const int oq = __builtin_amdgcn_readlane(key, q);
-                rk += (oq < key || (oq == key && q < lane)) ? 1 : 0;
-            }
-        }
+        for (int w8 = 0; w8 < 8; ++w8) rk += s_rkp[w8][lane];            // (the eight waves' partial counts, above)
         if (kind == 1) {
             const int p = __popcll(ms & lt);
             if (p < NPAIR) {
@@ -866,6 +890,9 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
             }
         }
     }
+#ifdef REKF_DEBUG_MID_FIRST
+    MMARK();                                        // (x4: wave 0 through the compaction)
+#endif
     __syncthreads();
     MMARK();                                        // 0: compaction done
     const int MM = s_cnt[0], m = s_cnt[1], m_pad = s_cnt[2], NS = s_cnt[3];
@@ -949,12 +976,14 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
             const int tc = (t < nblk) ? t : nblk - 1;                       // clamped: a thread past the end refetches the last block
             // column slot v of block tc in the column-major enumeration of the lower block-triangle: v columns hold
             // v nrs - v (v - 1) / 2 blocks
+            // (the hardware's approximate square root + 24-bit multiplies here: measured 0.65 us SLOWER per update, A/B in one session)
             const float bq = 2.0f * (float)nrs + 1.0f;
             int v = (int)((bq - sqrtf(fmaxf(bq * bq - 8.0f * (float)tc, 0.0f))) * 0.5f);
             v = max(0, min(nrs - 1, v));
-            while (v > 0 && v * nrs - (v * (v - 1)) / 2 > tc) --v;
-            while (v + 1 < nrs && (v + 1) * nrs - ((v + 1) * v) / 2 <= tc) ++v;
-            const int u = v + (tc - (v * nrs - (v * (v - 1)) / 2));
+            auto c0 = [&](int vv) __attribute__((always_inline)) { return vv * nrs - (vv * (vv - 1)) / 2; };   // blocks in columns < vv
+            while (v > 0 && c0(v) > tc) --v;
+            while (v + 1 < nrs && c0(v + 1) <= tc) ++v;
+            const int u = v + (tc - c0(v));
             blk_u[it] = (t < nblk) ? u : -1; blk_v[it] = v;
             const char *rp = (const char *)(P + s_urow[u]) + (unsigned)s_urow[v] * ldb;
             ps[it][0] = *(const v2du *)rp;                                  // rows (r, r+1) of column c
