@@ -57,6 +57,18 @@ struct RekfCtl {
     // columns of H P in LDS), published to the host from there -- GetPose does not wait for the downdate -- and taken over BY VALUE by
     // the downdate's tile (0, 0), so that the published block and the stored one are the same bits
     double post_C9[9];
+    // ---- the scan's match results in the form k_mid works with (round 3): ordered compaction of the per-observation results, the rank of
+    // every matched landmark among the matched ones, the slots of the sub-block.  Written by the front end -- the workgroup whose
+    // observation is the last to be matched (front_count reaches the launch's front_target) -- so that k_mid starts with one load of
+    // this record instead of a control-block round trip, ballots and a 64 x 64 rank count on its critical path.  Whole scans only
+    // (at most 32 observations); the block steps of a wide scan build theirs in k_mid from k_compact_wide's lists.
+    struct Rec {
+        int cnt[8];                   // pairs, m, m_pad, state pairs, pose rows?, new reflectors (clamped to the capacity), -, -
+        int pair_obs[32], pair_id[32], pair_state[32], rank[32];
+        int urow[36], ukc[36];        // slot -> first global row / first sub-block column (slots 0, 1 = rows {0,1}, {2}; 2 + rank = a state pair)
+        int newid[64];                // observation indices of the new reflectors
+    } rec;
+    unsigned front_count;             // observations matched so far, over the life of the handle (never reset)
     long long dbg[32];            // scratch for in-kernel timing experiments (REKF_DEBUG_TIMING builds)
 };
 
@@ -81,6 +93,8 @@ struct RekfFrontArgs {
     // pre_pose is the predicted pose, pre_ab the composite G = I + a e0 e2^T + b e1 e2^T of every predict since the device last
     // saw P (consecutive predicts compose exactly: e2^T (a, b, 0)^T = 0), pre_C9 the pose block after them.
     int pred_slot;            // which RekfCtl::pred slot this scan's Predict goes through (front kernel writes, k_mid reads)
+    unsigned front_target;    // RekfCtl::front_count once all K observations of THIS scan are matched: the workgroup that reaches it compacts
+    int compact_in_front;     // 1: whole scan (K <= 32, one pass of k_mid): the front end leaves RekfCtl::rec; 0: wide scan (k_compact_wide)
     int aug_pending;          // front role inside k_dd_front: the previous scan's k_augment has not run yet -- the state the match sees has
                               // n + 2 n_new rows (the new reflectors' means are there: k_mid writes them)
     int apply_pred;           // k_mid: apply the pending Predict to the gathered P (whole scan or FIRST block step of a wide scan)

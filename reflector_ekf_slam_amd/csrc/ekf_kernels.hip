@@ -218,6 +218,8 @@ __device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs
     static_assert(NT >= 256 && NT % 256 == 0, "four waves match, lane 0 of wave 1 evaluates the motion model");
     __shared__ Motion mo;
     __shared__ double pose[5];
+    __shared__ int s_last;                            // this workgroup matched the scan's last outstanding observation
+    if (threadIdx.x == 0) s_last = 0;
 #ifdef REKF_DEBUG_FRONT
     long long tqf[8]; int nqf = 0;
     const bool recf = b == 1 && threadIdx.x == 0;
@@ -392,10 +394,70 @@ __device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs
                 }
                 if (gj >= 0 && best < 0.6) { kind = 1; best_j = gj; }  // cc:446
             }
-            if (mlane == 0) { ctl->obs_kind[i] = kind; ctl->obs_idx[i] = best_j; }
+            if (mlane == 0) {
+                // the result, coherently at agent scope (another workgroup -- on another XCD, behind another L2 -- may be the one that
+                // compacts), then the count: whoever sees it reach the scan's target has every result in memory behind it
+                __hip_atomic_store(&ctl->obs_kind[i], kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ctl->obs_idx[i], best_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned old = __hip_atomic_fetch_add(&ctl->front_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old + 1u == A.front_target) s_last = 1;
+            }
         }
     }
     FMARK();                                          // 3: match done
+    // ---- the last workgroup to finish compacts the scan's results for k_mid (RekfCtl::rec): ordered compaction by observation, the
+    // rank of every matched landmark among the matched ones (ties by observation), the slots of the sub-block, the getters' counts
+    __syncthreads();
+    if (A.compact_in_front && s_last && tid < 64) {
+        RekfCtl::Rec *rec = &ctl->rec;
+        const int lane = tid;
+        const int kind = (lane < K) ? __hip_atomic_load(&ctl->obs_kind[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+        const int oidx = (lane < K) ? __hip_atomic_load(&ctl->obs_idx[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        const unsigned long long ms = __ballot(kind == 1);
+        const unsigned long long mm = __ballot(kind == 0);
+        const unsigned long long mn = __ballot(kind == 2);
+        const int M = __popcll(ms), Mm = __popcll(mm);
+        int N2 = __popcll(mn);
+        const int room = (d.n_max - n) / 2;
+        if (N2 > room) {                                               // capacity guard (ours)
+            if (lane == 0) atomicOr(&ctl->err, REKF_FLAG_CAPACITY);
+            N2 = room;
+        }
+        // position of a state pair's landmark rows among the matched ones, by landmark (ties: by lane): neighbouring landmarks share
+        // cache lines of a column of P, so k_mid's gathers run over the row slots in this order
+        int rk = 0;
+        {
+            const int key = (kind == 1) ? oidx : 0x7fffffff;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) {                               // K <= 32 observations in a whole scan
+                const int oq = __builtin_amdgcn_readlane(key, q);
+                rk += (oq < key || (oq == key && q < lane)) ? 1 : 0;
+            }
+        }
+        if (kind == 1) {
+            const int p = __popcll(ms & lt);
+            if (p < 32) {
+                rec->pair_obs[p] = lane; rec->pair_id[p] = oidx; rec->pair_state[p] = 1;
+                rec->rank[p] = rk;
+                rec->urow[2 + rk] = 3 + 2 * oidx; rec->ukc[2 + rk] = 3 + 2 * p;
+            }
+        } else if (kind == 0) {
+            const int p = __popcll(mm & lt);
+            if (M + p < 32) { rec->pair_obs[M + p] = lane; rec->pair_id[M + p] = oidx; rec->pair_state[M + p] = 0; }
+        } else if (kind == 2) {
+            const int p = __popcll(mn & lt);
+            if (p < N2) rec->newid[p] = lane;
+        }
+        if (lane == 0) {
+            const int MM = M + Mm;
+            const int m = (MM > 0) ? 2 * MM + (A.has_gps ? 3 : 0) : 0;
+            rec->cnt[0] = MM; rec->cnt[1] = m; rec->cnt[2] = (m + 15) & ~15; rec->cnt[3] = M; rec->cnt[4] = (A.has_gps && MM > 0) ? 1 : 0;
+            rec->cnt[5] = N2; rec->cnt[6] = Mm; rec->cnt[7] = K;
+            rec->urow[0] = 0; rec->ukc[0] = 0; rec->urow[1] = 2; rec->ukc[1] = 2;
+        }
+    }
 #ifdef REKF_DEBUG_FRONT
     if (recf) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -725,13 +787,18 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     __shared__ __attribute__((aligned(16))) double s_big[(NKCP * 2 * NRS > MP * LDS_S) ? NKCP * 2 * NRS : MP * LDS_S];
     __shared__ __attribute__((aligned(16))) double s_pw[NKC][MID_ROWS];     // P(own rows, sub-block columns)
     __shared__ double s_dmu[4][MID_ROWS];
-    __shared__ int s_pair_obs[NPAIR], s_pair_id[NPAIR], s_pair_state[NPAIR], s_pcol[NPAIR], s_rank[NPAIR], s_cnt[6];
-    __shared__ int s_newid[2 * NPAIR];            // the scan's new reflectors (observation indices), s_cnt[5] of them
+    // the scan's match record (RekfCtl::Rec: pairs, ranks, slots, counts, the new reflectors' observation indices = s_cnt[5] of them):
+    // a whole scan's comes ready-made from the front end, a block step of a wide scan builds it here
+    __shared__ RekfCtl::Rec s_rec;
+    int *const s_pair_obs = s_rec.pair_obs, *const s_pair_id = s_rec.pair_id, *const s_pair_state = s_rec.pair_state,
+        *const s_rank = s_rec.rank, *const s_cnt = s_rec.cnt, *const s_newid = s_rec.newid;
+    __shared__ int s_pcol[NPAIR];
     __shared__ double s_np[3];                    // the committed pose, for their means
     __shared__ double s_dc[4][3][MID_ROWS];       // workgroup 0: partial sums of (K H P)(i, jc), jc = 0..2, per wave of phase F
     // the sub-block's slots in ascending global order -- u = 0: rows / columns {0,1}, u = 1: {2}, u = 2 + rank: a state pair's
     // landmark -- with the first global row (= column) of each and the first sub-block column kc it stands for
-    __shared__ int s_urow[NRS], s_ukc[NRS];
+    int *const s_urow = s_rec.urow, *const s_ukc = s_rec.ukc;
+    static_assert(NRS <= 36 && NPAIR <= 32, "RekfCtl::Rec holds a whole scan");
     double (*s_psub)[NKCP] = (double (*)[NKCP])s_big;                       // [row 2 rs + {0,1} of the sub-block][its column kc]
     double (*s_sinv)[LDS_S] = (double (*)[LDS_S])s_big;                     // S^-1, row-major
 
@@ -750,16 +817,17 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool steam = wave < 4;                  // S team; the other is the "own" team
     const int tt = tid & 255;                     // thread index within the team
-    // the match results first, UNCONDITIONALLY (both arrays have 64 entries): a vector load that waits for no scalar one,
-    // so the control block costs one memory round trip, not two
-    const int kind_raw = ctl->obs_kind[lane], oidx_raw = ctl->obs_idx[lane];
+    // the scan's match record first, UNCONDITIONALLY (a block step of a wide scan does not use it): a vector load that waits for no
+    // scalar one, so the control block costs one memory round trip, not two
+    constexpr int NREC = (int)(sizeof(RekfCtl::Rec) / sizeof(int));
+    static_assert(NREC <= 512, "one load per thread");
+    const int rec_raw = (tid < NREC) ? ((const int *)&ctl->rec)[tid] : 0;
 #ifdef REKF_DEBUG_MID_FIRST
     MMARK();                                        // (x0: first loads issued)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MMARK();                                        // (x1: ... arrived)
 #endif
     const int n = (d.n_known >= 0) ? d.n_known : ctl->n;
-    const int K = A.K;
     const size_t ld = (size_t)d.ld;
     const int i0 = blockIdx.x * MID_ROWS;
     // the host sizes the grid by its BOUND of n (it may run several scans ahead of the device, each of which can append K
@@ -780,31 +848,6 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     __shared__ double s_pred[12];
     if (do_pred && tid >= 64 && tid < 64 + 11) s_pred[tid - 64] = ((const double *)&ctl->pred[A.pred_slot & 1])[tid - 64];   // ab[0], ab[1], C9[0..8]
 
-    // (whole scan) the rank of every state pair's landmark among the matched ones -- 64 keys against 64 keys -- is shared out: each of
-    // the eight waves counts against its eighth of the lanes (all of them hold the match results), wave 0 adds the partial counts up
-    // behind a barrier.  On wave 0 alone the 64 dependent v_readlane steps took 1.1 us of the kernel's critical path.
-    __shared__ int s_rkp[8][64];
-    if (A.pair0 < 0) {
-        const int kind0 = (lane < A.K) ? kind_raw : -1;
-        const int key0 = (kind0 == 1) ? ((lane < A.K) ? oidx_raw : -1) : 0x7fffffff;
-        constexpr int QW = (2 * NPAIR) / 8;
-        const int q0 = __builtin_amdgcn_readfirstlane(wave) * QW;
-        int rkp = 0;
-#pragma unroll
-        for (int qq = 0; qq < QW; ++qq) {
-            const int q = q0 + qq;
-            const int oq = __builtin_amdgcn_readlane(key0, q);
-            rkp += (oq < key0 || (oq == key0 && q < lane)) ? 1 : 0;
-        }
-        s_rkp[wave][lane] = rkp;
-#ifdef REKF_DEBUG_MID_FIRST
-        MMARK();                                    // (x2: partial ranks done)
-#endif
-        __syncthreads();
-#ifdef REKF_DEBUG_MID_FIRST
-        MMARK();                                    // (x3: ... barrier passed)
-#endif
-    }
     // ---- A: the scan's matched pairs.  Whole scan (pair0 < 0): ordered compaction of the per-observation results (obs order
     // preserved), wave 0; workgroup 0 also writes the record for the getters.  Block step of a wide scan (pair0 >= 0): the
     // pairs [pair0, pair0 + stride) of the record k_compact_wide wrote, state pairs first, then map pairs.
@@ -841,54 +884,9 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
             s_cnt[5] = (A.pair0 + A.pair_stride >= A.K) ? ctl->n_new : 0;       // the LAST block step appends the new reflectors' means
             s_urow[0] = 0; s_ukc[0] = 0; s_urow[1] = 2; s_ukc[1] = 2;
         }
-    } else if (tid < 64) {
-        const int kind = (lane < K) ? kind_raw : -1;
-        const int oidx = (lane < K) ? oidx_raw : -1;
-        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        const unsigned long long ms = __ballot(kind == 1);
-
-        const unsigned long long mm = __ballot(kind == 0);
-        const unsigned long long mn = __ballot(kind == 2);
-        const int M = __popcll(ms), Mm = __popcll(mm);
-        int N2 = __popcll(mn);
-        const int room = (d.n_max - n) / 2;
-        if (N2 > room) {                                               // capacity guard (ours)
-            if (first && lane == 0) atomicOr(&ctl->err, REKF_FLAG_CAPACITY);
-            N2 = room;
-        }
-        // position of a state pair's landmark rows among the matched ones, by landmark (ties: by lane): neighbouring
-        // landmarks share cache lines of a column of P, so the gathers below run over the row slots in this order
-        int rk = 0;
-#pragma unroll
-        for (int w8 = 0; w8 < 8; ++w8) rk += s_rkp[w8][lane];            // (the eight waves' partial counts, above)
-        if (kind == 1) {
-            const int p = __popcll(ms & lt);
-            if (p < NPAIR) {
-                s_pair_obs[p] = lane; s_pair_id[p] = oidx; s_pair_state[p] = 1;
-                s_rank[p] = rk;
-                s_urow[2 + rk] = 3 + 2 * oidx; s_ukc[2 + rk] = 3 + 2 * p;
-            }
-            if (first) { ctl->state_pairs[2 * p] = lane; ctl->state_pairs[2 * p + 1] = oidx; }
-        } else if (kind == 0) {
-            const int p = __popcll(mm & lt);
-            if (M + p < NPAIR) { s_pair_obs[M + p] = lane; s_pair_id[M + p] = oidx; s_pair_state[M + p] = 0; }
-            if (first) { ctl->map_pairs[2 * p] = lane; ctl->map_pairs[2 * p + 1] = oidx; }
-        } else if (kind == 2) {
-            const int p = __popcll(mn & lt);
-            if (p < N2 && p < 2 * NPAIR) s_newid[p] = lane;
-            if (first && p < N2) ctl->new_ids[p] = lane;
-        }
-        if (lane == 0) {
-            const int MM = M + Mm;
-            const int m = (MM > 0) ? 2 * MM + (A.has_gps ? 3 : 0) : 0;
-            s_cnt[0] = MM; s_cnt[1] = m; s_cnt[2] = (m + 15) & ~15; s_cnt[3] = M; s_cnt[4] = (A.has_gps && MM > 0) ? 1 : 0;
-            s_cnt[5] = N2;
-            s_urow[0] = 0; s_ukc[0] = 0; s_urow[1] = 2; s_ukc[1] = 2;   // (their rows of s_psub stay M and M+1: row slot M = rows {0,1}, M+1 = row {2})
-            if (first) {
-                ctl->K = K; ctl->n_state = M; ctl->n_map = Mm; ctl->n_new = N2;
-                ctl->m = m; ctl->m_pad = (m + 15) & ~15;
-            }
-        }
+    } else if (A.pair0 < 0) {
+        // whole scan: the record the front end left (its last workgroup compacted the results, front_role) -- one load, one LDS store
+        if (tid < NREC) ((int *)&s_rec)[tid] = rec_raw;
     }
 #ifdef REKF_DEBUG_MID_FIRST
     MMARK();                                        // (x4: wave 0 through the compaction)
@@ -897,6 +895,17 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     MMARK();                                        // 0: compaction done
     const int MM = s_cnt[0], m = s_cnt[1], m_pad = s_cnt[2], NS = s_cnt[3];
     const bool gps_rows = s_cnt[4] != 0;
+    if (first && A.pair0 < 0) {
+        // ReflectorMatchResult for the getters (and n_new / m for the kernels behind this one), out of the record
+        const int Mm = s_cnt[6], N2r = s_cnt[5];
+        if (tid < NS) { ctl->state_pairs[2 * tid] = s_pair_obs[tid]; ctl->state_pairs[2 * tid + 1] = s_pair_id[tid]; }
+        else if (tid < MM) { ctl->map_pairs[2 * (tid - NS)] = s_pair_obs[tid]; ctl->map_pairs[2 * (tid - NS) + 1] = s_pair_id[tid]; }
+        if (tid >= 64 && tid < 64 + N2r) ctl->new_ids[tid - 64] = s_newid[tid - 64];
+        if (tid == 128) {
+            ctl->K = s_cnt[7]; ctl->n_state = NS; ctl->n_map = Mm; ctl->n_new = N2r;
+            ctl->m = m; ctl->m_pad = m_pad;
+        }
+    }
     // The means of the scan's NEW reflectors (cc:323-342: the observation through the UPDATED pose, float32-rounded) are written
     // here, by workgroup 0 behind its pose commit, not by k_augment: the next scan's match may then run before k_augment has
     // appended their covariance rows (lazy downdate, rekf_api.hip).  s_np = the committed pose; call with the whole workgroup.

@@ -63,6 +63,7 @@ struct rekf {
     double lazy_a = 0, lazy_b = 0;
     int flags_last = 0;        // sticky device flags as of the last read-back
     unsigned long scan_count = 0;   // parity = the RekfCtl::pred slot of the scan's Predict
+    unsigned front_total = 0;       // observations handed to the front end so far = RekfCtl::front_count once they are all matched
     // LAZY DOWNDATE.  A scan's last k_downdate2 is not enqueued with the scan but held back: if the next call is another scan, it goes
     // out as k_dd_front, with that scan's front end (Predict's pose, ReflectorMatch: they need the mean, nothing of P) in workgroups of
     // its own beside it -- two launches per scan instead of three, and the match off the critical path.  Anything else that looks at
@@ -650,6 +651,11 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     // (first) k_downdate2 apply it to what they read of P
     const int pred_slot = (int)(h->scan_count++ & 1);
     a.pred_slot = pred_slot; a.apply_pred = 1;
+    // the front end counts matched observations (RekfCtl::front_count); the workgroup that reaches this scan's target compacts the
+    // results into the record k_mid starts from (whole scans only: a wide scan goes through k_compact_wide)
+    h->front_total += (unsigned)K;
+    a.front_target = h->front_total;
+    a.compact_in_front = blocks ? 0 : 1;
     h->dev.pred_slot = -1;
     ProfScope upd(h, REKF_K_UPDATE);                  // one bracket around the whole chain (per-update latency)
     h->dev.kc_ub = round_up(2 * K + (gps_pose3 ? 3 : 0), 16);
@@ -858,6 +864,7 @@ int rekf_set_state(rekf_t *h, double t, int n, const double *mu, const double *s
                                 hipMemcpyHostToDevice, h->stream));
     std::memset(h->ctl_staging, 0, sizeof(RekfCtl));
     h->ctl_staging->n = n;
+    h->ctl_staging->front_count = h->front_total;                  // (the front end's count of matched observations goes on)
     HIP_TRY(h, hipMemcpyAsync(h->dev.ctl, h->ctl_staging, sizeof(RekfCtl), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->time = t;
