@@ -243,11 +243,26 @@ def latency_legs(ekf, scans, steps):
         ekf.pose()
         host[k] = 1e6 * (time.perf_counter() - t0)
 
+    # (c) the same from an IDLE device -- a robot's scans arrive milliseconds apart, long after the previous update's downdate is
+    # through: what it waits for between handing a scan over and having its pose
+    n_idle = min(steps, 300)
+    idle = np.zeros(n_idle)
+    for k, (t, ob) in enumerate(scans[2 * steps:2 * steps + n_idle]):
+        ekf.sync()
+        t0 = time.perf_counter()
+        ekf.handle_observation(t, ob)
+        ekf.pose()
+        idle[k] = 1e6 * (time.perf_counter() - t0)
+
     def q(a):
         return {"median": float(np.median(a)), "p99": float(np.percentile(a, 99)), "mean": float(a.mean()), "n": int(a.size)}
     return {"device_chain": dict(q(dev), method="hipEvent pair around each whole update chain on the handle's stream, "
                                                   "launches back to back (includes ~4-5 us of event bracket)"),
-            "host_sync": dict(q(host), method="host wall: HandleObservationMessage + rekf_get_pose per update (the chain's last kernel stores pose, 3x3 block, n and flags as tagged slots into pinned host memory; the host polls them)")}, 2 * steps
+            "host_sync": dict(q(host), method="host wall: HandleObservationMessage + rekf_get_pose per update, back to back (includes what is left "
+                                              "of the previous update's downdate; pose, 3x3 block, n and flags arrive as tagged slots in pinned "
+                                              "host memory from k_mid, the host polls them)"),
+            "host_sync_idle_device": dict(q(idle), method="the same with the device idle when the scan is handed over (rekf_sync in front, untimed): "
+                                                          "front end + k_mid + the PCIe write")}, 2 * steps + n_idle
 
 
 def predict_leg(ekf, cfg, scans, steps, per_scan=5):
