@@ -361,8 +361,8 @@ def test_localisation_against_a_preloaded_map_only(oracle_lib):
 
 
 # ---------------------------------------------------------------------------------------------- lazy downdate (k_dd_front)
-@pytest.mark.parametrize("L,obs", [(96, 12), (130, 20)], ids=["n195_strips", "n263_generic"])
-def test_lazy_downdate_gives_the_eager_chains_bits(oracle_lib, monkeypatch, L, obs):
+@pytest.mark.parametrize("L,obs,capf", [(96, 12, 1), (130, 20, 1), (96, 12, 2)], ids=["n195_strips", "n263_generic", "n195_below_capacity"])
+def test_lazy_downdate_gives_the_eager_chains_bits(oracle_lib, monkeypatch, L, obs, capf):
     """Scans enqueued back to back on a filter at capacity run as k_dd_front (the previous scan's downdate + this scan's front end
     in one launch) + k_mid; with REKF_LAZY_DD=0 the same calls run as k_front_mb + k_mid + k_downdate2.  Both are the same
     arithmetic in the same order: the states must agree BIT FOR BIT, and with the oracle to the usual bounds -- with odometry
@@ -374,9 +374,9 @@ def test_lazy_downdate_gives_the_eager_chains_bits(oracle_lib, monkeypatch, L, o
 
     def run(lazy):
         monkeypatch.setenv("REKF_LAZY_DD", "1" if lazy else "0")
-        g = make_gpu(cfg.odom_model, sess.init_time, sess.init_pose, lin, ang, oc, cfg.n_landmarks)
-        S.replay(sess, g)
-        assert g.GetState().mu.shape[0] == 3 + 2 * L                      # at capacity: nothing can be appended any more
+        g = make_gpu(cfg.odom_model, sess.init_time, sess.init_pose, lin, ang, oc, capf * cfg.n_landmarks)
+        S.replay(sess, g)                                                 # (capf = 2: the map build itself runs with k_augment held back)
+        assert g.GetState().mu.shape[0] == 3 + 2 * L                      # capf = 1: at capacity, nothing can be appended any more
         return g
 
     ga, gb = run(True), run(False)
