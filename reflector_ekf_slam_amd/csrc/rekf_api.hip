@@ -667,13 +667,14 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         h->obs_staging_busy = true;
         a.obs_ext = h->dev_obs;
     }
-    // the call's last k_downdate2 publishes (tile (0,0)'s workgroup, ~3 us before that kernel ends): pose, pose block, flags and
-    // the n the state will have once the k_augment behind it has run (which changes none of the others)
+    // one kernel of the call publishes pose, pose block, flags and the n the state will have once the k_augment behind the chain has run
+    // (which changes none of the others): k_mid, or the first workgroup of the call's last downdate (struct rekf: WHO PUBLISHES)
     const bool aug = !h->full;
     if (aug) h->cum_growth += 2 * K;
     const int pub_seq = new_publisher(h);
     if (h->dd_pending && !a.host_pred) {
-        // the previous scan's downdate and this scan's front end as ONE launch (k_dd_front)
+        // the previous scan's downdate and this scan's front end as ONE launch (k_dd_front).  (host_pred means the caller has read the
+        // pose since the last scan -- which enqueued the downdate: nothing is pending then; the test is belt and braces)
         h->dd_pending = false;
         a.aug_pending = h->dd_aug ? 1 : 0;
         { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_dd_front(h->dd_dev, h->dd_n_ub, h->dev, a, h->stream); }
