@@ -18,8 +18,9 @@
 //   k3_cc_*       EuclideanClusterExtraction as connected components of the radius-0.2 m graph: smallest-neighbour
 //                 pointers, a snapshot of the chain tops, then a lock-free union-find for the few adjacent pairs whose
 //                 tops differ (roots are only ever hooked under smaller roots: the label is the smallest index) (:65-74)
-//   k3_finish_a/b component sizes (over the CUs), size gate [4,160], order (size desc, first index asc)
-//   k3_centroids  float32 centroids in index order (one wave per component, spread over the CUs), Rigid2f to base_link (:77-97)
+//   k3_finish_a   final roots, component sizes and extents in the sorted copy, the list of roots (over the CUs)
+//   k3_clusters   size gate [4,160], order (size desc, first index asc), float32 centroids in index order (one wave
+//                 per component, spread over the CUs), Rigid2f to base_link             (:70-71, :77-97)
 //
 // No kd-tree: after the intensity gate a cloud holds 10^2..10^4 points; a counting sort into Morton order and a box per
 // 32 points prune as well as a tree would at this size and stay coalesced, data-parallel and free of pointer chasing.
@@ -61,8 +62,7 @@ constexpr float BOX_MARGIN = 0.9999f;   // box distance^2 * margin < bound  <=> 
 
 struct Det3dCtl {
     int M, M2, K, err;
-    float centers[2 * RDET_MAX_CENTERS];
-    int croot[RDET_MAX_CENTERS], csize[RDET_MAX_CENTERS], crank[RDET_MAX_CENTERS];   // accepted components: k3_finish_b -> k3_centroids
+    int nroots;                     // length of Det3dBufs::roots (k3_finish_a)
     // the grid the NEXT cloud is sorted on = this cloud's survivor bounding box (clouds of one sensor look alike; only
     // the sweeps' pruning, never a result, depends on it).  bb = this cloud's box, ordered-int encoded, by atomics.
     int bb[4];
@@ -92,15 +92,24 @@ struct Det3dBufs {
     float *box;       // 8 floats per BOX_PTS sorted points: min x, y, z, max x, y, z
     int *hist;        // GRID_CELLS cell counts (zero between calls)
     int *cursor;      // GRID_CELLS scatter cursors
-    float *dist;      // per node: SOR mean neighbour distance; later, per sorted position: snapshot roots
+    float *dist;      // per node: SOR mean neighbour distance; later, per sorted position: the final root (k3_finish_a)
     int *label;       // per node: union-find parent, -1 = removed by SOR
-    int *cnt;
-    int *last;        // last member index per root
+    int *cnt;         // per root: component size
+    int *first, *last;   // per root: first / last member's sorted position
+    int *roots;       // all roots, in no particular order
     Det3dCtl *ctl;
     int cap;
     Det3dHostOut *hout;   // pinned host memory (device view)
     int seq;              // this call's number
 };
+
+#ifdef RDET_DEBUG_MARKS
+// in-kernel timeline of k3_knn: wall_clock64() (100 MHz) per workgroup and phase; scripts/gpu_dbg_det3d.py
+__device__ unsigned long long d3_marks[2048][8];
+#define D3_MARK(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) d3_marks[blockIdx.x][i] = wall_clock64(); } while (0)
+#else
+#define D3_MARK(i) do { } while (0)
+#endif
 
 __device__ static float d2f(float ax, float ay, float az, float bx, float by, float bz)
 {
@@ -170,8 +179,18 @@ __global__ __launch_bounds__(1024) void k3_filter_count(Det3dBufs B, int N, doub
     const unsigned long long bal = __ballot(keep);
     if (lane == 0) wsum[wave] = __popcll(bal);
     __syncthreads();
+    {   // one atomic per (wave, cell): neighbours in arrival order hit the same post, i.e. the same cell
+        const int code = keep ? cell_code(cur.x, cur.y, B.ctl->gx0, B.ctl->gy0, B.ctl->ginv) : -1;
+        unsigned long long todo = bal;
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            const int c0 = __shfl(code, src, 64);
+            const unsigned long long grp = __ballot(code == c0);
+            if (lane == src) atomicAdd(&B.hist[c0], __popcll(grp));
+            todo &= ~grp;
+        }
+    }
     if (keep) {
-        atomicAdd(&B.hist[cell_code(cur.x, cur.y, B.ctl->gx0, B.ctl->gy0, B.ctl->ginv)], 1);
         if (fabsf(cur.x) < 1e30f && fabsf(cur.y) < 1e30f) {
             const int ex = enc_ord(cur.x), ey = enc_ord(cur.y);
             atomicMin(&s_bb[0], ex); atomicMin(&s_bb[1], ey); atomicMax(&s_bb[2], ex); atomicMax(&s_bb[3], ey);
@@ -224,7 +243,7 @@ __global__ __launch_bounds__(1024) void k3_filter_write(Det3dBufs B, int N, doub
     const bool keep = i < N && (double)cur.w > intensity_min;
     const int pos = tile_compact_pos(keep, wsum, &base);
     if (keep) { B.p1[pos] = cur.x; B.p1[B.cap + pos] = cur.y; B.p1[2 * B.cap + pos] = cur.z; }
-    if ((int)blockIdx.x == ftiles - 1 && tid == 0) { B.ctl->M = base; B.ctl->M2 = 0; B.ctl->K = 0; B.ctl->err = 0; }   // base now includes this tile
+    if ((int)blockIdx.x == ftiles - 1 && tid == 0) { B.ctl->M = base; B.ctl->M2 = 0; B.ctl->K = 0; B.ctl->err = 0; B.ctl->nroots = 0; }   // base now includes this tile
 }
 
 // bounding boxes of BOX_PTS consecutive sorted points: lane = point, 32-lane halves reduce by shuffles.  NaN coordinates
@@ -257,14 +276,28 @@ __device__ static inline void tile_boxes(const Det3dBufs &B, int s, int M)
 __global__ __launch_bounds__(1024) void k3_scatter(Det3dBufs B)
 {
     const int M = B.ctl->M;
-    const int gid = blockIdx.x * 1024 + threadIdx.x;
+    const int gid = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63;
     for (int k = gid; k < GRID_CELLS; k += gridDim.x * 1024) B.hist[k] = 0;
-    if (gid >= M) return;
-    const float x = B.p1[gid], y = B.p1[B.cap + gid], z = B.p1[2 * B.cap + gid];
-    const int pos = atomicAdd(&B.cursor[cell_code(x, y, B.ctl->gx0, B.ctl->gy0, B.ctl->ginv)], 1);
+    if ((int)blockIdx.x * 1024 >= M) return;
+    const bool v = gid < M;
+    const float x = v ? B.p1[gid] : 0.f, y = v ? B.p1[B.cap + gid] : 0.f, z = v ? B.p1[2 * B.cap + gid] : 0.f;
+    const int code = v ? cell_code(x, y, B.ctl->gx0, B.ctl->gy0, B.ctl->ginv) : -1;
+    int pos = 0;
+    unsigned long long todo = __ballot(v);
+    while (todo) {                                               // one cursor bump per (wave, cell)
+        const int src = __ffsll((long long)todo) - 1;
+        const int c0 = __shfl(code, src, 64);
+        const unsigned long long grp = __ballot(code == c0);
+        int base = 0;
+        if (lane == src) base = atomicAdd(&B.cursor[c0], __popcll(grp));
+        base = __shfl(base, src, 64);
+        if (code == c0) pos = base + __popcll(grp & ((1ull << lane) - 1));
+        todo &= ~grp;
+    }
+    if (!v) return;
     B.s1[pos] = x; B.s1[B.cap + pos] = y; B.s1[2 * B.cap + pos] = z;
     B.perm[pos] = gid;
-    B.cnt[gid] = 0; B.last[gid] = 0;
+    B.cnt[gid] = 0; B.first[gid] = 0x7fffffff; B.last[gid] = 0;
 }
 __global__ __launch_bounds__(256) void k3_boxes(Det3dBufs B)
 {
@@ -273,111 +306,148 @@ __global__ __launch_bounds__(256) void k3_boxes(Det3dBufs B)
     tile_boxes(B, blockIdx.x * 256 + threadIdx.x, M);
 }
 
-// ---- SOR part 1: mean distance to the MeanK nearest neighbours ---------------------------------
-// One workgroup = 64 query points, consecutive in the spatial order (lane = point) x KNN_WAVES waves, each wave taking
-// its share of the candidate tiles in order of index distance from the queries' own tile (near in Morton order is
-// near in space, so the lists tighten at once) and skipping every tile whose box no lane can use.  The MeanK+1
-// smallest squared distances live in REGISTERS as a sorted list; a candidate enters through a min/max chain that runs
-// only when some lane of the wave needs it.  The partial lists are merged through LDS in a tree.  The multiset of the 31
-// smallest values is exact, so the ascending-order FP64 sum below is bit-identical to the insertion-sort reference.
+// ---- the three neighbour sweeps: ONE WAVE PER QUERY, lane = candidate ----------------------------------------
+// (Round 4.  Earlier forms, all exact, all parity-green: lane = query with the candidates through the scalar cache and a
+// sorted list per lane -- 142 us all-pairs, 104 us with the boxes below; the same with LDS-staged tiles, per-lane tile
+// selection and bitonic merges on register arrays -- 42 us: the work of a workgroup of 64 queries is what its neediest
+// lane needs, and 56 workgroups leave 200 CUs idle.)  A wave takes one query of the sorted copy.  Its 64 lanes hold 64
+// candidates: the aligned 64 points around the query first, then every tile of 32 whose BOX lies within the query's
+// current bound (all boxes are tested 64 at a time, one per lane), two tiles per step, four steps' loads in flight.  No
+// LDS, no barrier, every load coalesced, a few thousand independent waves: the whole chip works, and each wave only on
+// what its own query needs.
 constexpr int KNN = MEAN_K + 1;
-__device__ static inline void knn_insert(float (&L)[KNN], float x)
-{
-#pragma unroll
-    for (int q = 0; q < KNN; ++q) {
-        const float lo = fminf(L[q], x);
-        x = fmaxf(L[q], x);
-        L[q] = lo;
-    }
-}
-constexpr int KNN_WAVES = 8;        // waves sharing the candidates of 64 queries
 
-__global__ __launch_bounds__(64 * KNN_WAVES) void k3_knn(Det3dBufs B)
+// lane ^ J exchanges without the LDS crossbar (scripts/probe/lane_xor.hip checks them): DPP quad permutes, row shifts
+// under bank masks, gfx950's v_permlane16_swap / v_permlane32_swap
+template <int CTRL, int BANK>
+__device__ static inline int d3_dpp(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, BANK, false); }
+template <int J>
+__device__ static inline float lane_xor(float f, int lane)
 {
-    __shared__ float part[KNN_WAVES / 2][KNN][64];   // hand-over buffers of the merge tree
-    __shared__ float thr[KNN_WAVES][64];             // every wave's current 31st-smallest distance per query (see below)
+    const int v = __float_as_int(f);
+    int r;
+    if (J == 1) r = d3_dpp<0xB1, 0xf>(v, v);
+    else if (J == 2) r = d3_dpp<0x4E, 0xf>(v, v);
+    else if (J == 4) r = d3_dpp<0x114, 0xA>(d3_dpp<0x104, 0x5>(v, v), v);
+    else if (J == 8) r = d3_dpp<0x118, 0xC>(d3_dpp<0x108, 0x3>(v, v), v);
+    else if (J == 16) { const auto p = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false); r = (int)((lane & 16) ? p[0] : p[1]); }
+    else { const auto p = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false); r = (int)((lane & 32) ? p[0] : p[1]); }
+    return __int_as_float(r);
+}
+// one compare-exchange stage of a bitonic network over the lanes: blocks of K lanes alternate direction (K = 64: one
+// block), partners are J apart.  min or max as ONE v_med3_f32 against -inf / +inf (no NaN ever enters).
+template <int K, int J, bool DESC>
+__device__ static inline float bitonic_stage(float v, int lane)
+{
+    const float o = lane_xor<J>(v, lane);
+    const bool asc = (K == 64) ? !DESC : (((lane & K) == 0) != DESC);
+    return __builtin_amdgcn_fmed3f(v, o, (asc == ((lane & J) == 0)) ? -INFINITY : INFINITY);
+}
+// sort one value per lane: ascending by lane, or descending
+template <bool DESC>
+__device__ static inline float wave_sort64(float v, int lane)
+{
+#define D3_STG(K, J) v = bitonic_stage<K, J, DESC>(v, lane);
+    D3_STG(2, 1)
+    D3_STG(4, 2) D3_STG(4, 1)
+    D3_STG(8, 4) D3_STG(8, 2) D3_STG(8, 1)
+    D3_STG(16, 8) D3_STG(16, 4) D3_STG(16, 2) D3_STG(16, 1)
+    D3_STG(32, 16) D3_STG(32, 8) D3_STG(32, 4) D3_STG(32, 2) D3_STG(32, 1)
+    D3_STG(64, 32) D3_STG(64, 16) D3_STG(64, 8) D3_STG(64, 4) D3_STG(64, 2) D3_STG(64, 1)
+#undef D3_STG
+    return v;
+}
+// S ascending, D DESCENDING by lane -> the 64 smallest of both, ascending by lane
+__device__ static inline float wave_merge64(float S, float D, int lane)
+{
+    float c = fminf(S, D);                                        // bitonic: an ascending run against a descending one
+    c = bitonic_stage<64, 32, false>(c, lane); c = bitonic_stage<64, 16, false>(c, lane); c = bitonic_stage<64, 8, false>(c, lane);
+    c = bitonic_stage<64, 4, false>(c, lane); c = bitonic_stage<64, 2, false>(c, lane); c = bitonic_stage<64, 1, false>(c, lane);
+    return c;
+}
+// the boxes of tiles r0 + lane: squared distance from the query (inf past the last tile)
+__device__ static inline float lane_box_d2(const Det3dBufs &B, int t, int ntiles, float qx, float qy, float qz)
+{
+    if (t >= ntiles) return INFINITY;
+    const float4 lo = *(const float4 *)(B.box + 8 * t), hi = *(const float4 *)(B.box + 8 * t + 4);   // x0 y0 z0 x1 | y1 z1 . .
+    return box_d2(qx, qy, qz, lo.x, lo.y, lo.z, lo.w, hi.x, hi.y);
+}
+constexpr int QW = 4;               // queries (waves) per workgroup
+constexpr int Q_GRID = 2048;        // workgroups: the queries are dealt round-robin
+constexpr int KNN_AHEAD = 4;        // steps (pairs of tiles) whose loads are issued together
+constexpr int KNN_FEW = 6;          // a step with at most this many admissible candidates inserts them one by one
+
+// ---- SOR part 1: mean distance to the MeanK nearest neighbours (:43-47).  The 64 smallest squared distances seen so
+// far live one per lane, ascending.  A step with many admissible candidates sorts its 64 across the lanes and merges
+// (bitonic networks on DPP / permlane swaps, one v_med3 per stage); one with few inserts them one at a time (ballot,
+// popcount, wave_shr:1).  The bound is lane 30's value: a tile is opened only while its box is nearer than that.  The
+// multiset of the 31 smallest values is exact, so the ascending-order FP64 sum is bit-identical to the reference's.
+__global__ __launch_bounds__(64 * QW) void k3_knn(Det3dBufs B)
+{
     const int M = B.ctl->M;
-    const int q0 = blockIdx.x * 64;
-    if (q0 >= M) return;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int s = q0 + lane;
-    const bool live = s < M;
+    const int lane = threadIdx.x & 63;
+    const int ntiles = (M + BOX_PTS - 1) / BOX_PTS;
     const float *__restrict__ X = B.s1, *__restrict__ Y = B.s1 + B.cap, *__restrict__ Z = B.s1 + 2 * B.cap;
-    const float px = live ? X[s] : 0.f, py = live ? Y[s] : 0.f, pz = live ? Z[s] : 0.f;
-    float L[KNN];
-#pragma unroll
-    for (int q = 0; q < KNN; ++q) L[q] = INFINITY;
-    // The waves see disjoint candidates, so each one's list alone tightens slower than the true one would -- and the
-    // insertion chain runs for every candidate that ANY lane still admits.  But a wave's 31st-smallest value is an
-    // upper bound of the final one whatever subset it has seen, so the waves publish theirs and admit only below the
-    // smallest: no barrier needed, a stale (larger) bound is still a bound; the merged multiset stays exact.
-    thr[wave][lane] = INFINITY;
-    float tau = INFINITY;
-    // tiles by distance from the queries' tile: qt, qt+1, qt-1, qt+2, ... (one-sided once a border is reached); wave w
-    // takes the w-th, (w + KNN_WAVES)-th ... of them.  A candidate is the same for all 64 lanes: its box and its
-    // coordinates come through the SCALAR cache (uniform addresses -> s_load) and enter the VALU as SGPR operands.
-    const int ntiles = (M + BOX_PTS - 1) / BOX_PTS, qt = q0 / BOX_PTS;
-    const int na = qt, nb = ntiles - 1 - qt, nm = min(na, nb);
-    for (int v = wave; v < ntiles; v += KNN_WAVES) {
-        int t;
-        if (v <= 2 * nm) t = (v & 1) ? qt + (v + 1) / 2 : qt - v / 2;
-        else t = (nb > na) ? qt + (v - nm) : qt - (v - nm);
-        const float *__restrict__ bx = B.box + 8 * t;
-        const float db = box_d2(px, py, pz, bx[0], bx[1], bx[2], bx[3], bx[4], bx[5]);
-        if (!__any(live && db * BOX_MARGIN < fminf(L[KNN - 1], tau))) continue;
-        const int j0 = BOX_PTS * t, jn = min(BOX_PTS, M - j0);
-        float nx[8], ny[8], nz[8];                            // the next group of eight is loaded while this one is used
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int j = j0 + u; nx[u] = X[j]; ny[u] = Y[j]; nz[u] = Z[j]; }   // contiguous: ONE s_load_dwordx8 per array (a clamp per element would split it); reads past M stay inside the padded buffers
-        for (int c0 = 0; c0 < jn; c0 += 8) {
-            float cx[8], cy[8], cz[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { cx[u] = nx[u]; cy[u] = ny[u]; cz[u] = nz[u]; }
-            if (c0 + 8 < jn) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { const int j = j0 + c0 + 8 + u; nx[u] = X[j]; ny[u] = Y[j]; nz[u] = Z[j]; }
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float d2 = d2f(px, py, pz, cx[u], cy[u], cz[u]);
-                const bool need = live && (c0 + u < jn) && d2 < L[KNN - 1] && d2 < tau;
-                if (__any(need)) knn_insert(L, need ? d2 : INFINITY);
-            }
+    for (int q = __builtin_amdgcn_readfirstlane(blockIdx.x * QW + (threadIdx.x >> 6)); q < M; q += gridDim.x * QW) {
+        const float qx = X[q], qy = Y[q], qz = Z[q];
+        const int a0 = q & ~63;                                  // the aligned 64 points around the query = tiles a0/32, a0/32 + 1
+        float S;
+        {
+            const int j = a0 + lane;
+            const float d2 = d2f(qx, qy, qz, X[j], Y[j], Z[j]);  // (past M: padding, masked)
+            S = wave_sort64<false>((j < M && d2 == d2) ? d2 : INFINITY, lane);
         }
-        thr[wave][lane] = L[KNN - 1];                            // every tile: publish / refresh the shared bound
-        float tm = thr[0][lane];
+        float bound = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S), KNN - 1));
+        for (int r0 = 0; r0 < ntiles; r0 += 64) {
+            const int t = r0 + lane;
+            const float db = ((t >> 1) == (a0 >> 6)) ? INFINITY : lane_box_d2(B, t, ntiles, qx, qy, qz) * BOX_MARGIN;
+            unsigned long long todo = __ballot(db < bound);
+            while (todo) {
+                float cx[KNN_AHEAD], cy[KNN_AHEAD], cz[KNN_AHEAD];
+                bool ok[KNN_AHEAD];
+                int nstep = 0;
 #pragma unroll
-        for (int w = 1; w < KNN_WAVES; ++w) tm = fminf(tm, thr[w][lane]);
-        tau = tm;
-    }
-    // merge tree: in every round the upper half of the remaining waves hands its list to the lower half
-    for (int half = KNN_WAVES / 2; half >= 1; half >>= 1) {
-        if (wave >= half && wave < 2 * half) {
+                for (int u = 0; u < KNN_AHEAD; ++u) {
+                    int ta = -1, tb = -1;
+                    if (todo) { ta = __ffsll((long long)todo) - 1; todo &= todo - 1; ++nstep; }
+                    if (todo) { tb = __ffsll((long long)todo) - 1; todo &= todo - 1; }
+                    const int tile = (lane < 32) ? ta : tb;
+                    const int j = BOX_PTS * (r0 + tile) + (lane & 31);
+                    ok[u] = tile >= 0 && j < M;
+                    const int jj = ok[u] ? j : 0;
+                    cx[u] = X[jj]; cy[u] = Y[jj]; cz[u] = Z[jj];
+                }
 #pragma unroll
-            for (int q = 0; q < KNN; ++q) part[wave - half][q][lane] = L[q];
-        }
-        __syncthreads();
-        if (wave < half) {
-            for (int q = 0; q < KNN; ++q) {                   // the partner's list is ascending: stop once it cannot improve
-                const float v = part[wave][q][lane];
-                const bool need = v < L[KNN - 1];
-                if (!__any(need)) break;
-                knn_insert(L, need ? v : INFINITY);
+                for (int u = 0; u < KNN_AHEAD; ++u) {
+                    if (u >= nstep) break;
+                    const float d2 = d2f(qx, qy, qz, cx[u], cy[u], cz[u]);
+                    const float d = (ok[u] && d2 == d2) ? d2 : INFINITY;
+                    unsigned long long adm = __ballot(d < bound);
+                    if (adm == 0ull) continue;
+                    if (__popcll(adm) <= KNN_FEW) {
+                        while (adm) {
+                            const int l = __ffsll((long long)adm) - 1;
+                            adm &= adm - 1;
+                            const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), l));
+                            if (!(x < bound)) continue;
+                            const int pos = __popcll(__ballot(S <= x));           // S is ascending: a prefix of the lanes keeps its place
+                            const float sh = __int_as_float(d3_dpp<0x138, 0xf>(__float_as_int(S), __float_as_int(S)));   // wave_shr:1
+                            S = (lane < pos) ? S : ((lane == pos) ? x : sh);
+                            bound = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S), KNN - 1));
+                        }
+                    } else {
+                        S = wave_merge64(S, wave_sort64<true>(d, lane), lane);
+                        bound = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S), KNN - 1));
+                    }
+                }
+                todo &= __ballot(db < bound);
             }
         }
-        __syncthreads();
-    }
-    if (wave == 0) {
-        if (live) {
-            float dst = 0.f;                                      // search "failed": fewer than MeanK+1 points
-            if (M >= KNN) {
-                double dist_sum = 0;
+        const float sq = sqrtf(S);
+        double dist_sum = 0;
 #pragma unroll
-                for (int k = 1; k < KNN; ++k) dist_sum += sqrtf(L[k]);   // k = 0 is the query itself
-                dst = (float)(dist_sum / MEAN_K);
-            }
-            B.dist[B.perm[s]] = dst;
-        }
+        for (int k = 1; k < KNN; ++k) dist_sum += (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(sq), k));   // k = 0 is the query itself
+        if (lane == 0) B.dist[B.perm[q]] = (M >= KNN) ? (float)(dist_sum / MEAN_K) : 0.f;   // fewer than MeanK+1 points: the search "failed"
     }
 }
 
@@ -452,101 +522,68 @@ __device__ static int uf_find(int *parent, int x)
     }
     return x;
 }
-// Three passes.  Doing every union inside the sweep serialises: a candidate that is adjacent to ANY lane of the
-// wave makes the whole wave walk through a dependent chain of memory operations (finds, CAS), ~100 such candidates per
-// wave = 150 us.  Instead:
-//   k3_cc_min   sweep 1, registers only: parent[i] = smallest index among i and its neighbours.  That alone puts nearly
+// Three passes.  Doing every union inside one sweep serialises on chains of finds and compare-and-swaps.  Instead:
+//   k3_cc_min   registers only: parent[i] = smallest index among i and its neighbours.  That alone puts nearly
 //               every point of a compact cluster in one tree (the chains run towards the cluster's first point);
-//   k3_cc_jump  root[i] = top of i's chain (a snapshot; plain loads);
-//   k3_cc_link  sweep 2: the candidate's snapshot root arrives through the scalar cache with its coordinates, and only
-//               an adjacent pair whose snapshot roots differ goes into the union code -- a few per cluster.
-// Both sweeps run over the sorted copy and skip every candidate tile whose box is farther than 0.2 m from all 64 queries.
-constexpr int CC_WAVES = 8;         // waves per 64 queries in the two sweeps
-__global__ __launch_bounds__(64 * CC_WAVES) void k3_cc_min(Det3dBufs B)
+//   k3_cc_link  every neighbour found earlier in the sorted copy is looked up with the top of its chain as it stands (equal
+//               tops mean "same tree already", and a stale top is still an ancestor, so the filter never drops a needed
+//               union), and only an adjacent pair whose tops differ goes into the union code -- a few per cluster.
+// Both as one wave per query over the tiles whose box lies within 0.2 m of it, like k3_knn.
+__global__ __launch_bounds__(64 * QW) void k3_cc_min(Det3dBufs B)
 {
-    __shared__ int s_min[CC_WAVES][64];
     const int M = B.ctl->M;
+    const int lane = threadIdx.x & 63;
     const int ntiles = (M + BOX_PTS - 1) / BOX_PTS;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float *__restrict__ X = B.s1, *__restrict__ Y = B.s1 + B.cap, *__restrict__ Z = B.s1 + 2 * B.cap;
-    const int *__restrict__ P = B.perm;
-    const float qn = __int_as_float(0x7fc00000);
-    for (int q0 = blockIdx.x * 64; q0 < M; q0 += gridDim.x * 64) {        // the grid is capped: tiles of 64 queries, strided
-        const int s = q0 + lane;
-        const bool live = s < M;
-        const float px = live ? X[s] : qn, py = live ? Y[s] : 0.f, pz = live ? Z[s] : 0.f;   // a masked / dead query is adjacent to nothing
-        const int own = live ? P[s] : 0x7fffffff;
+    for (int q = __builtin_amdgcn_readfirstlane(blockIdx.x * QW + (threadIdx.x >> 6)); q < M; q += gridDim.x * QW) {
+        const float qx = X[q], qy = Y[q], qz = Z[q];
+        if (!(qx == qx)) continue;                               // masked by k3_sor: label stays -1
+        const int own = B.perm[q];
         int mi = own;
-        for (int t = wave; t < ntiles; t += CC_WAVES) {
-            const float *__restrict__ bx = B.box + 8 * t;
-            if (!__any(box_d2(px, py, pz, bx[0], bx[1], bx[2], bx[3], bx[4], bx[5]) * BOX_MARGIN < TOL2)) continue;
-            const int j0 = BOX_PTS * t, jn = min(BOX_PTS, M - j0);
-#pragma unroll 1
-            for (int c0 = 0; c0 < BOX_PTS; c0 += 8) {
-                float cx[8], cy[8], cz[8];
-                int ci[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { const int j = j0 + c0 + u; cx[u] = X[j]; cy[u] = Y[j]; cz[u] = Z[j]; ci[u] = P[j]; }   // contiguous -> s_load_dwordx8; past M: padding, masked below
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const bool adj = (c0 + u < jn) && d2f(px, py, pz, cx[u], cy[u], cz[u]) < TOL2;
-                    mi = adj ? min(mi, ci[u]) : mi;
-                }
+        for (int r0 = 0; r0 < ntiles; r0 += 64) {
+            unsigned long long todo = __ballot(lane_box_d2(B, r0 + lane, ntiles, qx, qy, qz) * BOX_MARGIN < TOL2);
+            while (todo) {
+                const int ta = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                int tb = -1;
+                if (todo) { tb = __ffsll((long long)todo) - 1; todo &= todo - 1; }
+                const int tile = (lane < 32) ? ta : tb;
+                const int j = BOX_PTS * (r0 + tile) + (lane & 31);
+                if (tile >= 0 && j < M && d2f(qx, qy, qz, X[j], Y[j], Z[j]) < TOL2) mi = min(mi, B.perm[j]);
             }
         }
-        s_min[wave][lane] = mi;
-        __syncthreads();
-        if (wave == 0 && live && px == px) {
-            int m = s_min[0][lane];
-#pragma unroll
-            for (int w = 1; w < CC_WAVES; ++w) m = min(m, s_min[w][lane]);
-            B.label[own] = m;
-        }
-        __syncthreads();
+        for (int off = 32; off > 0; off >>= 1) mi = min(mi, __shfl_xor(mi, off, 64));
+        if (lane == 0) B.label[own] = mi;
     }
 }
-__global__ __launch_bounds__(256) void k3_cc_jump(Det3dBufs B)
+__global__ __launch_bounds__(64 * QW) void k3_cc_link(Det3dBufs B)
 {
     const int M = B.ctl->M;
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= M) return;
-    const int *parent = B.label;
-    int r = parent[B.perm[s]];
-    if (r >= 0)
-        for (int p = parent[r]; p != r; p = parent[r]) r = p;     // parent[] is constant during this kernel
-    reinterpret_cast<int *>(B.dist)[s] = r;                       // the SOR distances are dead: snapshot roots live there, by sorted position
-}
-__global__ __launch_bounds__(64 * CC_WAVES) void k3_cc_link(Det3dBufs B)
-{
-    const int M = B.ctl->M;
+    const int lane = threadIdx.x & 63;
     const int ntiles = (M + BOX_PTS - 1) / BOX_PTS;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float *__restrict__ X = B.s1, *__restrict__ Y = B.s1 + B.cap, *__restrict__ Z = B.s1 + 2 * B.cap;
-    const int *__restrict__ root = reinterpret_cast<const int *>(B.dist);
-    const float qn = __int_as_float(0x7fc00000);
     int *parent = B.label;
-    for (int q0 = blockIdx.x * 64; q0 < M; q0 += gridDim.x * 64) {
-        const int s = q0 + lane;
-        const bool live = s < M;
-        const float px = live ? X[s] : qn, py = live ? Y[s] : 0.f, pz = live ? Z[s] : 0.f;
-        const int rs = live ? root[s] : -1;                       // snapshot root of the query
-        int ri = rs;                                              // a (possibly stale) ancestor of it
-        int rm = rs;                                              // snapshot root of the tree merged last
-        for (int t = wave; t < ntiles; t += CC_WAVES) {
-            const float *__restrict__ bx = B.box + 8 * t;
-            if (!__any(box_d2(px, py, pz, bx[0], bx[1], bx[2], bx[3], bx[4], bx[5]) * BOX_MARGIN < TOL2)) continue;
-            const int j0 = BOX_PTS * t;
-#pragma unroll 1
-            for (int c0 = 0; c0 < BOX_PTS; c0 += 8) {
-                float cx[8], cy[8], cz[8];
-                int cr[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { const int j = j0 + c0 + u; cx[u] = X[j]; cy[u] = Y[j]; cz[u] = Z[j]; cr[u] = root[j]; }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int j = j0 + c0 + u;                    // every edge is handled by its later end (j < s also keeps j < M)
-                    if (rs >= 0 && j < s && cr[u] >= 0 && cr[u] != rs && cr[u] != rm && d2f(px, py, pz, cx[u], cy[u], cz[u]) < TOL2) {
-                        int a = uf_find<false>(parent, ri), b = uf_find<false>(parent, cr[u]);
+    for (int q = __builtin_amdgcn_readfirstlane(blockIdx.x * QW + (threadIdx.x >> 6)); q < M; q += gridDim.x * QW) {
+        const float qx = X[q], qy = Y[q], qz = Z[q];
+        if (!(qx == qx)) continue;
+        int rs = *(const volatile int *)&parent[B.perm[q]];      // top of the query's chain as it stands
+        for (int p = *(const volatile int *)&parent[rs]; p != rs; p = *(const volatile int *)&parent[rs]) rs = p;
+        int ri = rs;                                              // (per lane) a possibly stale ancestor of the query
+        for (int r0 = 0; r0 < ntiles; r0 += 64) {
+            unsigned long long todo = __ballot(lane_box_d2(B, r0 + lane, ntiles, qx, qy, qz) * BOX_MARGIN < TOL2);
+            while (todo) {
+                const int ta = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                int tb = -1;
+                if (todo) { tb = __ffsll((long long)todo) - 1; todo &= todo - 1; }
+                const int tile = (lane < 32) ? ta : tb;
+                const int j = BOX_PTS * (r0 + tile) + (lane & 31);
+                // every edge is handled by its later end (j < q also keeps j < M); a masked neighbour's x is NaN
+                if (tile >= 0 && j < q && d2f(qx, qy, qz, X[j], Y[j], Z[j]) < TOL2) {
+                    int cr = *(const volatile int *)&parent[B.perm[j]];
+                    for (int p = *(const volatile int *)&parent[cr]; p != cr; p = *(const volatile int *)&parent[cr]) cr = p;
+                    if (cr != rs) {
+                        int a = uf_find<false>(parent, ri), b = uf_find<false>(parent, cr);
                         while (a != b) {
                             const int hi = max(a, b), lo = min(a, b);
                             const int old = atomicCAS(&parent[hi], hi, lo);
@@ -554,7 +591,6 @@ __global__ __launch_bounds__(64 * CC_WAVES) void k3_cc_link(Det3dBufs B)
                             a = uf_find<true>(parent, a); b = uf_find<true>(parent, b);
                         }
                         ri = a;
-                        rm = cr[u];
                     }
                 }
             }
@@ -563,70 +599,81 @@ __global__ __launch_bounds__(64 * CC_WAVES) void k3_cc_link(Det3dBufs B)
 }
 
 // ---- sizes, gate, order, centroids ------------------------------------------------------------------
-// k3_finish_a (thread = node, over the CUs): final roots, component sizes and last members -- one atomic pair per
-// (wave, component) instead of one per point: consecutive arrival indices mostly share their component.
+// k3_finish_a (thread = sorted position, over the CUs): final roots, component sizes, the stretch of the sorted copy
+// each component lives in, and the list of roots.  One atomic group per (wave, component) instead of one per point:
+// neighbours in the spatial order mostly share their component.
 __global__ __launch_bounds__(256) void k3_finish_a(Det3dBufs B)
 {
     const int M = B.ctl->M;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int s = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
     if ((int)blockIdx.x * 256 >= M) return;
-    int r = -1;
-    if (i < M) {
-        r = B.label[i];
+    int r = -1, node = -1;
+    if (s < M) {
+        node = B.perm[s];
+        r = B.label[node];
         if (r >= 0) {
             while (true) { const int p = *(const volatile int *)&B.label[r]; if (p == r) break; r = p; }   // parents are final: no union runs any more
-            B.label[i] = r;                                                   // (a root's own entry is left alone; others only move up)
         }
+        reinterpret_cast<int *>(B.dist)[s] = r;                  // the SOR distances are dead: final roots live there, by sorted position
+    }
+    const unsigned long long isroot = __ballot(r >= 0 && r == node);
+    if (isroot) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&B.ctl->nroots, __popcll(isroot));
+        base = __shfl(base, 0, 64);
+        if (r >= 0 && r == node) B.roots[base + __popcll(isroot & ((1ull << lane) - 1))] = r;
     }
     unsigned long long todo = __ballot(r >= 0);
     while (todo) {
         const int src = __ffsll((long long)todo) - 1;
         const int r0 = __shfl(r, src, 64);
         const unsigned long long grp = __ballot(r == r0);
-        if ((int)(threadIdx.x & 63) == src) {
+        if (lane == src) {
+            const int sbase = blockIdx.x * 256 + (threadIdx.x & ~63u);
             atomicAdd(&B.cnt[r0], __popcll(grp));
-            atomicMax(&B.last[r0], (int)(blockIdx.x * 256 + (threadIdx.x & ~63u)) + 63 - __clzll((long long)grp));
+            atomicMin(&B.first[r0], sbase + src);
+            atomicMax(&B.last[r0], sbase + 63 - __clzll((long long)grp));
         }
         todo &= ~grp;
     }
 }
-__global__ __launch_bounds__(1024) void k3_finish_b(Det3dBufs B, int max_centers)
+// k3_clusters: EVERY workgroup gates and ranks the components for itself (a few hundred roots: cheaper than a launch in
+// between), then each of its four waves takes one accepted component: its members out of the stretch of the sorted copy
+// it lives in, brought into ARRIVAL order (the float32 sums of compute3DCentroid run in index order, :94), summed,
+// divided, moved to base_link and published.  Order: size descending, then first member (= root) ascending.
+__global__ __launch_bounds__(256) void k3_clusters(Det3dBufs B, int max_centers, float sx, float sy, float cs, float sn)
 {
-    __shared__ int s_root[RDET_MAX_CENTERS], s_size[RDET_MAX_CENTERS], s_rank[RDET_MAX_CENTERS];
-    __shared__ int wsum[16];
-    __shared__ int base;
-    __shared__ int s_err;
-    const int tid = threadIdx.x;
-    const int M = B.ctl->M;
-    if (tid == 0) { base = 0; s_err = 0; }
+#pragma clang fp contract(off)
+    __shared__ int s_root[RDET_MAX_CENTERS], s_size[RDET_MAX_CENTERS], s_byrank[RDET_MAX_CENTERS];
+    __shared__ int s_n, s_err;
+    __shared__ int m_id[4][MAX_SZ];
+    __shared__ float m_x[4][MAX_SZ], m_y[4][MAX_SZ], o_x[4][MAX_SZ], o_y[4][MAX_SZ];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { s_n = 0; s_err = 0; }
     __syncthreads();
-    // accepted components, in ascending root (= first member) order
-    for (int t0 = 0; t0 < M; t0 += 1024) {
-        const int i = t0 + tid;
-        const int c = (i < M) ? B.cnt[i] : 0;
-        const bool ok = i < M && c >= MIN_SZ && c <= MAX_SZ && B.label[i] == i;   // :70-71 (cnt is non-zero at roots only)
-        const int pos = tile_compact_pos(ok, wsum, &base);
-        if (ok) {
-            if (pos < RDET_MAX_CENTERS) { s_root[pos] = i; s_size[pos] = c; }
+    const int nroots = B.ctl->nroots;
+    for (int k = tid; k < nroots; k += 256) {
+        const int r = B.roots[k], c = B.cnt[r];
+        if (c >= MIN_SZ && c <= MAX_SZ) {                                         // :70-71
+            const int pos = atomicAdd(&s_n, 1);
+            if (pos < RDET_MAX_CENTERS) { s_root[pos] = r; s_size[pos] = c; }
             else s_err = RDET_ERR_CAPACITY;
         }
     }
     __syncthreads();
-    int n = min(base, RDET_MAX_CENTERS);
-    if (n > max_centers) { if (tid == 0) s_err = RDET_ERR_BUFFER; n = 0; }
-    __syncthreads();
-    if (tid == 0 && s_err) B.ctl->err = s_err;
-    if (tid < n) {          // rank: size descending, then first member index ascending (roots are already ascending)
+    int n = min(s_n, RDET_MAX_CENTERS);
+    int err = s_err;
+    if (n > max_centers) { err = RDET_ERR_BUFFER; n = 0; }
+    if (tid < n) {
         int rank = 0;
-        for (int k = 0; k < n; ++k)
-            if (s_size[k] > s_size[tid] || (s_size[k] == s_size[tid] && k < tid)) ++rank;
-        s_rank[tid] = rank;
+        const int sz = s_size[tid], rt = s_root[tid];
+        for (int k = 0; k < n; ++k) rank += (s_size[k] > sz || (s_size[k] == sz && s_root[k] < rt)) ? 1 : 0;
+        s_byrank[rank] = tid;
     }
     __syncthreads();
-    if (tid < n) { B.ctl->croot[tid] = s_root[tid]; B.ctl->csize[tid] = s_size[tid]; B.ctl->crank[tid] = s_rank[tid]; }
-    if (tid == 0) {
-        B.ctl->K = n;
-        d3_host_store16(&B.hout->head, (unsigned)n, (unsigned)s_err, (unsigned)B.ctl->M2, (unsigned)B.seq);   // the centres follow, each with its own tag
+    if (blockIdx.x == 0 && tid == 0) {
+        B.ctl->K = n; B.ctl->err = err;
+        d3_host_store16(&B.hout->head, (unsigned)n, (unsigned)err, (unsigned)B.ctl->M2, (unsigned)B.seq);   // the centres follow, each with its own tag
         // the next cloud's grid: this cloud's survivor box, a little wider, at least 1/8 m per cell
         if (B.ctl->bb[0] != 0x7fffffff) {
             const float x0 = dec_ord(B.ctl->bb[0]), y0 = dec_ord(B.ctl->bb[1]), x1 = dec_ord(B.ctl->bb[2]), y1 = dec_ord(B.ctl->bb[3]);
@@ -635,49 +682,37 @@ __global__ __launch_bounds__(1024) void k3_finish_b(Det3dBufs B, int max_centers
         }
         B.ctl->bb[0] = B.ctl->bb[1] = 0x7fffffff; B.ctl->bb[2] = B.ctl->bb[3] = (int)0x80000000;
     }
-}
-
-// Centroids: one WAVE per accepted component, four per workgroup, spread over the CUs (inside the single workgroup of
-// k3_finish sixteen waves took turns on up to 256 components).  Members are found 64 at a time; the float32 sums run in
-// index order (:94).
-__global__ __launch_bounds__(256) void k3_centroids(Det3dBufs B, float sx, float sy, float cs, float sn)
-{
-#pragma clang fp contract(off)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cidx = blockIdx.x * 4 + wave;
-    if (cidx >= B.ctl->K) return;
-    const float *X = B.p1, *Y = B.p1 + B.cap;
-    const int root = B.ctl->croot[cidx], last = B.last[root];
-    float cx = 0.f, cy = 0.f;
-    // a component's members sit in one stripe per scan ring, far apart in index: most 64-point chunks hold none, so
-    // four chunks' labels are fetched per round trip and only the chunks with members pay for the coordinates
-    for (int b0 = root; b0 <= last; b0 += 256) {
-        int lab[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { const int i = b0 + 64 * u + lane; lab[u] = (i <= last) ? B.label[i] : -1; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = b0 + 64 * u + lane;
-            const bool mem = lab[u] == root;
-            unsigned long long mask = __ballot(mem);
-            if (mask == 0ull) continue;
-            const float x = mem ? X[i] : 0.f, y = mem ? Y[i] : 0.f;
-            while (mask) {
-                const int b = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                cx += __shfl(x, b, 64);
-                cy += __shfl(y, b, 64);
-            }
+    const int rank = blockIdx.x * 4 + wave;
+    if (rank >= n) return;
+    const int e = s_byrank[rank], root = s_root[e], size = s_size[e];
+    const int *slabel = reinterpret_cast<const int *>(B.dist);
+    int have = 0;
+    for (int b0 = B.first[root]; b0 <= B.last[root] && have < size; b0 += 64) {
+        const int s = b0 + lane;
+        const bool mem = s <= B.last[root] && slabel[s] == root;
+        const unsigned long long mask = __ballot(mem);
+        if (mem) {
+            const int k = have + __popcll(mask & ((1ull << lane) - 1));
+            m_id[wave][k] = B.perm[s]; m_x[wave][k] = B.s1[s]; m_y[wave][k] = B.s1[B.cap + s];   // (a member's x is never masked)
         }
+        have += __popcll(mask);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // arrival order: a member's place = the number of members with a smaller node id
+    for (int k = lane; k < size; k += 64) {
+        const int id = m_id[wave][k];
+        int place = 0;
+        for (int q = 0; q < size; ++q) place += (m_id[wave][q] < id) ? 1 : 0;
+        o_x[wave][place] = m_x[wave][k]; o_y[wave][place] = m_y[wave][k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float cx = 0.f, cy = 0.f;
+    for (int q = 0; q < size; ++q) { cx += o_x[wave][q]; cy += o_y[wave][q]; }
     if (lane == 0) {
-        const float sz = (float)B.ctl->csize[cidx];
+        const float sz = (float)size;
         cx /= sz; cy /= sz;
-        const int r = B.ctl->crank[cidx];
         const float ox = (cs * cx + (-sn) * cy) + sx, oy = (sn * cx + cs * cy) + sy;   // :96 Project2D(s2b).cast<float>() * p
-        B.ctl->centers[2 * r] = ox;
-        B.ctl->centers[2 * r + 1] = oy;
-        d3_host_store16(&B.hout->centers[r], __float_as_uint(ox), __float_as_uint(oy), (unsigned)B.seq, 0u);
+        d3_host_store16(&B.hout->centers[rank], __float_as_uint(ox), __float_as_uint(oy), (unsigned)B.seq, 0u);
     }
 }
 
@@ -689,7 +724,7 @@ struct rdet3d {
     int max_points, device;
     hipStream_t stream;
     float *d_xyzi, *d_p1, *d_s1, *d_dist, *d_box;
-    int *d_label, *d_cnt, *d_last, *d_perm, *d_hist, *d_cursor;
+    int *d_label, *d_cnt, *d_first, *d_last, *d_roots, *d_perm, *d_hist, *d_cursor;
     Det3dCtl *d_ctl;
     Det3dHostOut *h_out, *dv_out;      // pinned + mapped: polled result slots (host / device view)
     bool xyzi_in_vram;                 // d_xyzi is fine-grained device memory the host writes through the PCIe BAR (else: pinned staging + copy)
@@ -741,6 +776,8 @@ int rdet3d_create(const rdet3d_options *opt, const double s2b[3], int max_points
         DET3_TRY(h, hipMalloc(&h->d_label, 4 * np));
         DET3_TRY(h, hipMalloc(&h->d_cnt, 4 * np));
         DET3_TRY(h, hipMalloc(&h->d_last, 4 * np));
+        DET3_TRY(h, hipMalloc(&h->d_first, 4 * np));
+        DET3_TRY(h, hipMalloc(&h->d_roots, 4 * np));
         DET3_TRY(h, hipMalloc(&h->d_ctl, sizeof(Det3dCtl)));
         {   // the first cloud is sorted on a 64 m x 64 m grid around the sensor; every later one on its predecessor's box
             Det3dCtl c0;
@@ -765,7 +802,7 @@ void rdet3d_destroy(rdet3d_t *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *ptrs[] = {h->d_xyzi, h->d_p1, h->d_s1, h->d_dist, h->d_box, h->d_label, h->d_cnt, h->d_last, h->d_perm, h->d_hist, h->d_cursor, h->d_ctl};
+    void *ptrs[] = {h->d_xyzi, h->d_p1, h->d_s1, h->d_dist, h->d_box, h->d_label, h->d_cnt, h->d_first, h->d_last, h->d_roots, h->d_perm, h->d_hist, h->d_cursor, h->d_ctl};
     for (void *p : ptrs) (void)hipFree(p);
     if (h->h_out) (void)hipHostFree(h->h_out);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -793,27 +830,25 @@ int rdet3d_handle_cloud(rdet3d_t *h, double stamp, const float *xyzi, int N, flo
     }
     Det3dBufs B;
     B.xyzi = h->d_xyzi; B.p1 = h->d_p1; B.s1 = h->d_s1; B.perm = h->d_perm; B.box = h->d_box; B.hist = h->d_hist; B.cursor = h->d_cursor;
-    B.dist = h->d_dist; B.label = h->d_label; B.cnt = h->d_cnt; B.last = h->d_last;
+    B.dist = h->d_dist; B.label = h->d_label; B.cnt = h->d_cnt; B.first = h->d_first; B.last = h->d_last; B.roots = h->d_roots;
     B.ctl = h->d_ctl; B.cap = h->max_points;
     B.hout = h->dv_out; B.seq = ++h->seq;
-    const int blocks = (N + 63) / 64;                                 // 64 query points per workgroup; M <= N stays on the device
     const int ftiles = (N + 1023) / 1024, b256 = (N + 255) / 256;
     hipLaunchKernelGGL(k3_filter_count, dim3(ftiles), dim3(1024), 0, h->stream, B, N, h->opt.intensity_min);
     hipLaunchKernelGGL(k3_filter_write, dim3(ftiles + GRID_CELLS / 1024), dim3(1024), 0, h->stream, B, N, h->opt.intensity_min, ftiles);
     hipLaunchKernelGGL(k3_scatter, dim3(ftiles), dim3(1024), 0, h->stream, B);
     hipLaunchKernelGGL(k3_boxes, dim3(b256), dim3(256), 0, h->stream, B);
-    hipLaunchKernelGGL(k3_knn, dim3(blocks), dim3(64 * KNN_WAVES), 0, h->stream, B);
+    const int qblocks = (N + QW - 1) / QW < Q_GRID ? (N + QW - 1) / QW : Q_GRID;   // a wave per query, dealt round-robin: M <= N stays on the device
+    hipLaunchKernelGGL(k3_knn, dim3(qblocks), dim3(64 * QW), 0, h->stream, B);
     hipLaunchKernelGGL(k3_sor, dim3(1), dim3(1024), 0, h->stream, B);
-    const int cc_blocks = blocks < 1024 ? blocks : 1024;               // grid-stride over the query tiles: M is only known on the device
-    hipLaunchKernelGGL(k3_cc_min, dim3(cc_blocks), dim3(64 * CC_WAVES), 0, h->stream, B);
-    hipLaunchKernelGGL(k3_cc_jump, dim3(b256), dim3(256), 0, h->stream, B);
-    hipLaunchKernelGGL(k3_cc_link, dim3(cc_blocks), dim3(64 * CC_WAVES), 0, h->stream, B);
+    hipLaunchKernelGGL(k3_cc_min, dim3(qblocks), dim3(64 * QW), 0, h->stream, B);
+    hipLaunchKernelGGL(k3_cc_link, dim3(qblocks), dim3(64 * QW), 0, h->stream, B);
     const float sa = (float)h->s2b[2];
     hipLaunchKernelGGL(k3_finish_a, dim3(b256), dim3(256), 0, h->stream, B);
-    hipLaunchKernelGGL(k3_finish_b, dim3(1), dim3(1024), 0, h->stream, B, max_centers < RDET_MAX_CENTERS ? max_centers : RDET_MAX_CENTERS);
-    hipLaunchKernelGGL(k3_centroids, dim3(RDET_MAX_CENTERS / 4), dim3(256), 0, h->stream, B, (float)h->s2b[0], (float)h->s2b[1], cosf(sa), sinf(sa));
+    hipLaunchKernelGGL(k3_clusters, dim3(RDET_MAX_CENTERS / 4), dim3(256), 0, h->stream, B, max_centers < RDET_MAX_CENTERS ? max_centers : RDET_MAX_CENTERS,
+                       (float)h->s2b[0], (float)h->s2b[1], cosf(sa), sinf(sa));
     DET3_TRY(h, hipGetLastError());
-    // poll the head (written by k3_finish_b), then each centre's own tag (k3_centroids)
+    // poll the head, then each centre's own tag (k3_clusters)
     auto wait_tag = [&](const int *tag) -> int {
         const auto t0 = std::chrono::steady_clock::now();
         unsigned spins = 0;
@@ -842,5 +877,14 @@ int rdet3d_handle_cloud(rdet3d_t *h, double stamp, const float *xyzi, int N, flo
     }
     return RDET_OK;
 }
+
+#ifdef RDET_DEBUG_MARKS
+int rdet3d_debug_marks(rdet3d_t *h, unsigned long long *out)   // 2048 x 8
+{
+    DET3_TRY(h, hipStreamSynchronize(h->stream));
+    DET3_TRY(h, hipMemcpyFromSymbol(out, HIP_SYMBOL(d3_marks), sizeof(unsigned long long) * 2048 * 8));
+    return RDET_OK;
+}
+#endif
 
 }  // extern "C"
