@@ -35,6 +35,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <new>
 #include <string>
 
@@ -63,9 +64,8 @@ constexpr float BOX_MARGIN = 0.9999f;   // box distance^2 * margin < bound  <=> 
 struct Det3dCtl {
     int M, M2, K, err;
     int nroots;                     // length of Det3dBufs::roots (k3_finish_a)
-    // the grid the NEXT cloud is sorted on = this cloud's survivor bounding box (clouds of one sensor look alike; only
-    // the sweeps' pruning, never a result, depends on it).  bb = this cloud's box, ordered-int encoded, by atomics.
-    int bb[4];
+    // the grid the NEXT cloud is sorted on = the bounding box of this cloud's inliers (clouds of one sensor look alike;
+    // only the sweeps' pruning, never a result, depends on it): k3_clusters takes it from the tiles' boxes
     float gx0, gy0, ginv;
 };
 
@@ -130,8 +130,6 @@ __device__ static inline float box_d2(float px, float py, float pz, float x0, fl
     return dx * dx + dy * dy + dz * dz;
 }
 
-__device__ static inline int enc_ord(float f) { const int b = __float_as_int(f); return b >= 0 ? b : b ^ 0x7fffffff; }
-__device__ static inline float dec_ord(int e) { return __int_as_float(e >= 0 ? e : e ^ 0x7fffffff); }
 
 // Morton code of the grid cell of (x, y); non-finite and out-of-grid coordinates are clamped to the border cells (the
 // clamp is monotone, which is all the sort has to be: locality is a matter of speed, never of the result)
@@ -163,38 +161,58 @@ __device__ static int tile_compact_pos(bool flag, int *wsum, int *base)
     return off + __popcll(bal & lt);
 }
 
+// lane ^ J exchanges without the LDS crossbar (scripts/probe/lane_xor.hip checks them): DPP quad permutes, row shifts
+// under bank masks, gfx950's v_permlane16_swap / v_permlane32_swap
+template <int CTRL, int BANK>
+__device__ static inline int d3_dpp(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, BANK, false); }
+template <int J>
+__device__ static inline float lane_xor(float f, int lane)
+{
+    const int v = __float_as_int(f);
+    int r;
+    if (J == 1) r = d3_dpp<0xB1, 0xf>(v, v);
+    else if (J == 2) r = d3_dpp<0x4E, 0xf>(v, v);
+    else if (J == 4) r = d3_dpp<0x114, 0xA>(d3_dpp<0x104, 0x5>(v, v), v);
+    else if (J == 8) r = d3_dpp<0x118, 0xC>(d3_dpp<0x108, 0x3>(v, v), v);
+    else if (J == 16) { const auto p = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false); r = (int)((lane & 16) ? p[0] : p[1]); }
+    else { const auto p = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false); r = (int)((lane & 32) ? p[0] : p[1]); }
+    return __int_as_float(r);
+}
+// lanes of a wave that hold the same cell code (< 0: none): the lowest such lane, how many there are, and this lane's rank
+// among them -- so that ONE lane per (wave, cell) talks to memory, and all of a wave's leaders do so in one instruction
+// (arrival order runs along the rings: neighbours hit the same post, i.e. the same cell; a returning atomic per distinct
+// cell in turn cost a wave ten dependent round trips)
+__device__ static inline void wave_groups(int code, int lane, int &leader, int &count, int &rank)
+{
+    leader = lane; count = 0; rank = 0;
+    unsigned long long todo = __ballot(code >= 0);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        const int c0 = __builtin_amdgcn_readlane(code, src);
+        const unsigned long long grp = __ballot(code == c0);
+        if (code == c0) { leader = src; count = __popcll(grp); rank = __popcll(grp & ((1ull << lane) - 1)); }
+        todo &= ~grp;
+    }
+}
+
 // ---- intensity filter + order-preserving compaction, one workgroup per 1024-point tile: the tiles' survivor counts
 // first (k3_filter_count), then every tile adds up the counts in front of it and writes (k3_filter_write).  One
 // workgroup walking all tiles with two barriers each took 45 us for 29 k points; coalesced 16-byte reads.
-// Round 4: the survivors' grid-cell histogram and bounding box are taken beside the count, the cell scan beside the write.
+// Round 4: the survivors' grid-cell histogram is taken beside the count, the cell scan beside the write.
 __global__ __launch_bounds__(1024) void k3_filter_count(Det3dBufs B, int N, double intensity_min)
 {
     __shared__ int wsum[16];
-    __shared__ int s_bb[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = blockIdx.x * 1024 + tid;
-    if (tid < 4) s_bb[tid] = (tid < 2) ? 0x7fffffff : (int)0x80000000;
     const float4 cur = (i < N) ? ((const float4 *)B.xyzi)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     const bool keep = i < N && (double)cur.w > intensity_min;      // :33
     const unsigned long long bal = __ballot(keep);
     if (lane == 0) wsum[wave] = __popcll(bal);
-    __syncthreads();
-    {   // one atomic per (wave, cell): neighbours in arrival order hit the same post, i.e. the same cell
+    if (bal) {
         const int code = keep ? cell_code(cur.x, cur.y, B.ctl->gx0, B.ctl->gy0, B.ctl->ginv) : -1;
-        unsigned long long todo = bal;
-        while (todo) {
-            const int src = __ffsll((long long)todo) - 1;
-            const int c0 = __shfl(code, src, 64);
-            const unsigned long long grp = __ballot(code == c0);
-            if (lane == src) atomicAdd(&B.hist[c0], __popcll(grp));
-            todo &= ~grp;
-        }
-    }
-    if (keep) {
-        if (fabsf(cur.x) < 1e30f && fabsf(cur.y) < 1e30f) {
-            const int ex = enc_ord(cur.x), ey = enc_ord(cur.y);
-            atomicMin(&s_bb[0], ex); atomicMin(&s_bb[1], ey); atomicMax(&s_bb[2], ex); atomicMax(&s_bb[3], ey);
-        }
+        int leader, count, rank;
+        wave_groups(code, lane, leader, count, rank);
+        if (keep && lane == leader) atomicAdd(&B.hist[code], count);
     }
     __syncthreads();
     if (tid == 0) {
@@ -202,8 +220,6 @@ __global__ __launch_bounds__(1024) void k3_filter_count(Det3dBufs B, int N, doub
         for (int w = 0; w < 16; ++w) c += wsum[w];
         B.cnt[blockIdx.x] = c;                                                   // B.cnt is rebuilt by k3_scatter for its own use
     }
-    if (tid < 2 && s_bb[tid] != 0x7fffffff) atomicMin(&B.ctl->bb[tid], s_bb[tid]);
-    else if (tid >= 2 && tid < 4 && s_bb[tid] != (int)0x80000000) atomicMax(&B.ctl->bb[tid], s_bb[tid]);
 }
 // workgroups [0, ftiles): the compaction; workgroups [ftiles, ftiles + GRID_CELLS / 1024): the exclusive scan of the cell
 // histogram into the scatter cursors, 1024 cells each (a chunk adds up the chunks in front of it by itself)
@@ -246,28 +262,29 @@ __global__ __launch_bounds__(1024) void k3_filter_write(Det3dBufs B, int N, doub
     if ((int)blockIdx.x == ftiles - 1 && tid == 0) { B.ctl->M = base; B.ctl->M2 = 0; B.ctl->K = 0; B.ctl->err = 0; B.ctl->nroots = 0; }   // base now includes this tile
 }
 
-// bounding boxes of BOX_PTS consecutive sorted points: lane = point, 32-lane halves reduce by shuffles.  NaN coordinates
-// (the outliers k3_sor masks) are ignored by fminf / fmaxf; a tile without any number gets an empty box (+inf, -inf).
-__device__ static inline void tile_boxes(const Det3dBufs &B, int s, int M)
+// bounding boxes of BOX_PTS consecutive sorted points: lane = point (x, y, z in registers), 32-lane halves reduce by
+// shuffles.  NaN coordinates (the outliers k3_sor masks: x) are ignored by fminf / fmaxf; a tile without any number gets an
+// empty box (+inf, -inf).
+__device__ static inline void tile_boxes(const Det3dBufs &B, int s, int M, float x, float y, float z)
 {
-    const float *X = B.s1, *Y = B.s1 + B.cap, *Z = B.s1 + 2 * B.cap;
-    const bool v = s < M;
     const float qn = __int_as_float(0x7fc00000);
-    const float x = v ? X[s] : qn, y = v ? Y[s] : qn, z = v ? Z[s] : qn;
-    const bool ok = x == x;                                                       // x carries the mask
+    const bool ok = s < M && x == x;                                              // x carries the mask
     float m[6] = {ok ? x : qn, ok ? y : qn, ok ? z : qn, ok ? x : qn, ok ? y : qn, ok ? z : qn};
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { m[k] = fminf(m[k], __shfl_xor(m[k], off, 64)); m[3 + k] = fmaxf(m[3 + k], __shfl_xor(m[3 + k], off, 64)); }
+    for (int k = 0; k < 3; ++k) {
+        m[k] = fminf(m[k], lane_xor<16>(m[k], lane)); m[3 + k] = fmaxf(m[3 + k], lane_xor<16>(m[3 + k], lane));
+        m[k] = fminf(m[k], lane_xor<8>(m[k], lane)); m[3 + k] = fmaxf(m[3 + k], lane_xor<8>(m[3 + k], lane));
+        m[k] = fminf(m[k], lane_xor<4>(m[k], lane)); m[3 + k] = fmaxf(m[3 + k], lane_xor<4>(m[3 + k], lane));
+        m[k] = fminf(m[k], lane_xor<2>(m[k], lane)); m[3 + k] = fmaxf(m[3 + k], lane_xor<2>(m[3 + k], lane));
+        m[k] = fminf(m[k], lane_xor<1>(m[k], lane)); m[3 + k] = fmaxf(m[3 + k], lane_xor<1>(m[3 + k], lane));
     }
     if ((threadIdx.x & 31) == 0 && (s & ~31) < M) {
-        float *b = B.box + 8 * (s >> 5);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            b[k] = (m[k] == m[k]) ? m[k] : INFINITY;
-            b[3 + k] = (m[3 + k] == m[3 + k]) ? m[3 + k] : -INFINITY;
-        }
+        float4 lo, hi;
+        lo.x = (m[0] == m[0]) ? m[0] : INFINITY; lo.y = (m[1] == m[1]) ? m[1] : INFINITY; lo.z = (m[2] == m[2]) ? m[2] : INFINITY;
+        lo.w = (m[3] == m[3]) ? m[3] : -INFINITY; hi.x = (m[4] == m[4]) ? m[4] : -INFINITY; hi.y = (m[5] == m[5]) ? m[5] : -INFINITY;
+        hi.z = hi.w = 0.f;
+        *(float4 *)(B.box + 8 * (s >> 5)) = lo; *(float4 *)(B.box + 8 * (s >> 5) + 4) = hi;
     }
 }
 
@@ -282,19 +299,13 @@ __global__ __launch_bounds__(1024) void k3_scatter(Det3dBufs B)
     const bool v = gid < M;
     const float x = v ? B.p1[gid] : 0.f, y = v ? B.p1[B.cap + gid] : 0.f, z = v ? B.p1[2 * B.cap + gid] : 0.f;
     const int code = v ? cell_code(x, y, B.ctl->gx0, B.ctl->gy0, B.ctl->ginv) : -1;
-    int pos = 0;
-    unsigned long long todo = __ballot(v);
-    while (todo) {                                               // one cursor bump per (wave, cell)
-        const int src = __ffsll((long long)todo) - 1;
-        const int c0 = __shfl(code, src, 64);
-        const unsigned long long grp = __ballot(code == c0);
-        int base = 0;
-        if (lane == src) base = atomicAdd(&B.cursor[c0], __popcll(grp));
-        base = __shfl(base, src, 64);
-        if (code == c0) pos = base + __popcll(grp & ((1ull << lane) - 1));
-        todo &= ~grp;
-    }
+    int leader, count, rank;
+    wave_groups(code, lane, leader, count, rank);
+    int base = 0;
+    if (v && lane == leader) base = atomicAdd(&B.cursor[code], count);        // one cursor bump per (wave, cell), all of them in flight together
+    base = __shfl(base, leader, 64);
     if (!v) return;
+    const int pos = base + rank;
     B.s1[pos] = x; B.s1[B.cap + pos] = y; B.s1[2 * B.cap + pos] = z;
     B.perm[pos] = gid;
     B.cnt[gid] = 0; B.first[gid] = 0x7fffffff; B.last[gid] = 0;
@@ -303,7 +314,9 @@ __global__ __launch_bounds__(256) void k3_boxes(Det3dBufs B)
 {
     const int M = B.ctl->M;
     if ((int)blockIdx.x * 256 >= M) return;
-    tile_boxes(B, blockIdx.x * 256 + threadIdx.x, M);
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int ss = s < M ? s : 0;
+    tile_boxes(B, s, M, B.s1[ss], B.s1[B.cap + ss], B.s1[2 * B.cap + ss]);
 }
 
 // ---- the three neighbour sweeps: ONE WAVE PER QUERY, lane = candidate ----------------------------------------
@@ -317,23 +330,6 @@ __global__ __launch_bounds__(256) void k3_boxes(Det3dBufs B)
 // what its own query needs.
 constexpr int KNN = MEAN_K + 1;
 
-// lane ^ J exchanges without the LDS crossbar (scripts/probe/lane_xor.hip checks them): DPP quad permutes, row shifts
-// under bank masks, gfx950's v_permlane16_swap / v_permlane32_swap
-template <int CTRL, int BANK>
-__device__ static inline int d3_dpp(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, BANK, false); }
-template <int J>
-__device__ static inline float lane_xor(float f, int lane)
-{
-    const int v = __float_as_int(f);
-    int r;
-    if (J == 1) r = d3_dpp<0xB1, 0xf>(v, v);
-    else if (J == 2) r = d3_dpp<0x4E, 0xf>(v, v);
-    else if (J == 4) r = d3_dpp<0x114, 0xA>(d3_dpp<0x104, 0x5>(v, v), v);
-    else if (J == 8) r = d3_dpp<0x118, 0xC>(d3_dpp<0x108, 0x3>(v, v), v);
-    else if (J == 16) { const auto p = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false); r = (int)((lane & 16) ? p[0] : p[1]); }
-    else { const auto p = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false); r = (int)((lane & 32) ? p[0] : p[1]); }
-    return __int_as_float(r);
-}
 // one compare-exchange stage of a bitonic network over the lanes: blocks of K lanes alternate direction (K = 64: one
 // block), partners are J apart.  min or max as ONE v_med3_f32 against -inf / +inf (no NaN ever enters).
 template <int K, int J, bool DESC>
@@ -372,9 +368,20 @@ __device__ static inline float lane_box_d2(const Det3dBufs &B, int t, int ntiles
     const float4 lo = *(const float4 *)(B.box + 8 * t), hi = *(const float4 *)(B.box + 8 * t + 4);   // x0 y0 z0 x1 | y1 z1 . .
     return box_d2(qx, qy, qz, lo.x, lo.y, lo.z, lo.w, hi.x, hi.y);
 }
+// the lane with the smallest v among the lanes of `set` (nearest tile first: the bound tightens at once and most of the
+// other tiles are never opened)
+__device__ static inline int nearest_of(unsigned long long set, float v, int lane)
+{
+    const bool in = (set >> lane) & 1ull;
+    float m = in ? v : INFINITY;
+    m = fminf(m, lane_xor<1>(m, lane)); m = fminf(m, lane_xor<2>(m, lane)); m = fminf(m, lane_xor<4>(m, lane));
+    m = fminf(m, lane_xor<8>(m, lane)); m = fminf(m, lane_xor<16>(m, lane)); m = fminf(m, lane_xor<32>(m, lane));
+    return __ffsll((long long)__ballot(in && v == m)) - 1;
+}
 constexpr int QW = 4;               // queries (waves) per workgroup
 constexpr int Q_GRID = 2048;        // workgroups: the queries are dealt round-robin
 constexpr int KNN_AHEAD = 4;        // steps (pairs of tiles) whose loads are issued together
+constexpr int CC_AHEAD = 4;         // the same in the radius-graph sweeps
 constexpr int KNN_FEW = 6;          // a step with at most this many admissible candidates inserts them one by one
 
 // ---- SOR part 1: mean distance to the MeanK nearest neighbours (:43-47).  The 64 smallest squared distances seen so
@@ -409,8 +416,8 @@ __global__ __launch_bounds__(64 * QW) void k3_knn(Det3dBufs B)
 #pragma unroll
                 for (int u = 0; u < KNN_AHEAD; ++u) {
                     int ta = -1, tb = -1;
-                    if (todo) { ta = __ffsll((long long)todo) - 1; todo &= todo - 1; ++nstep; }
-                    if (todo) { tb = __ffsll((long long)todo) - 1; todo &= todo - 1; }
+                    if (todo) { ta = nearest_of(todo, db, lane); todo &= ~(1ull << ta); ++nstep; }
+                    if (todo) { tb = nearest_of(todo, db, lane); todo &= ~(1ull << tb); }
                     const int tile = (lane < 32) ? ta : tb;
                     const int j = BOX_PTS * (r0 + tile) + (lane & 31);
                     ok[u] = tile >= 0 && j < M;
@@ -455,22 +462,30 @@ __global__ __launch_bounds__(64 * QW) void k3_knn(Det3dBufs B)
 // compares false), the union-find parents are initialised (removed node: -1), the boxes are rebuilt without them.  Node
 // ids stay the arrival indices after the intensity gate -- the reference renumbers the survivors, but only the ORDER of
 // the indices is ever used (smallest member, centroid summation), and the renumbering keeps the order.
-__global__ __launch_bounds__(1024) void k3_sor(Det3dBufs B)
+// Thread = sorted position.  EVERY workgroup takes the statistics for itself (M floats: cheaper than a launch in between,
+// and the one-workgroup form spent 11 us walking its dependent loads): 1024 chunk sums in index order, then the pairwise tree
+// -- the very operations, in the very order, of the one-workgroup form, so the threshold's bits do not depend on the grid.
+__global__ __launch_bounds__(256) void k3_sor(Det3dBufs B)
 {
     __shared__ double red[2][1024];
     __shared__ double s_thr;
-    __shared__ int s_m2;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int M = B.ctl->M;
+    if ((int)blockIdx.x * 256 >= M) return;
+    const int s = blockIdx.x * 256 + tid, ss = s < M ? s : 0;
+    const int node = B.perm[ss];                                                  // (in flight under the statistics)
+    const float mydist = B.dist[node];
+    const float x = B.s1[ss], y = B.s1[B.cap + ss], z = B.s1[2 * B.cap + ss];
     const int CH = (M + 1023) / 1024;
-    const int b0 = tid * CH, b1 = min(M, b0 + CH);
-    double sum = 0, sq = 0;
-    for (int i = b0; i < b1; ++i) { const double v = B.dist[i]; sum += v; sq += v * v; }   // chunked like the serial loop's partial sums
-    red[0][tid] = sum; red[1][tid] = sq;
-    if (tid == 0) s_m2 = 0;
+    for (int c = tid; c < 1024; c += 256) {
+        const int b0 = c * CH, b1 = min(M, b0 + CH);
+        double sum = 0, sq = 0;
+        for (int i = b0; i < b1; ++i) { const double v = B.dist[i]; sum += v; sq += v * v; }   // chunked like the serial loop's partial sums
+        red[0][c] = sum; red[1][c] = sq;
+    }
     __syncthreads();
     for (int off = 512; off >= 1; off >>= 1) {
-        if (tid < off) { red[0][tid] += red[0][tid + off]; red[1][tid] += red[1][tid + off]; }
+        for (int i = tid; i < off; i += 256) { red[0][i] += red[0][i + off]; red[1][i] += red[1][i + off]; }
         __syncthreads();
     }
     if (tid == 0) {
@@ -480,20 +495,14 @@ __global__ __launch_bounds__(1024) void k3_sor(Det3dBufs B)
         s_thr = mean + STD_MUL * sqrt(variance);
     }
     __syncthreads();
-    const double thr = s_thr;
-    int kept = 0;
-    for (int s = tid; s < M; s += 1024) {
-        const int node = B.perm[s];
-        const bool keep = !((double)B.dist[node] > thr);                        // NaN threshold keeps everything
+    const bool keep = s < M && !((double)mydist > s_thr);                        // NaN threshold keeps everything
+    if (s < M) {
         B.label[node] = keep ? node : -1;
         if (!keep) B.s1[s] = __int_as_float(0x7fc00000);
-        kept += keep;
     }
-    for (int off = 32; off > 0; off >>= 1) kept += __shfl_xor(kept, off, 64);
-    if ((tid & 63) == 0) atomicAdd(&s_m2, kept);
-    __syncthreads();                                                              // (also: the masked s1 is visible to the workgroup)
-    if (tid == 0) B.ctl->M2 = s_m2;
-    for (int s0 = 0; s0 < M; s0 += 1024) tile_boxes(B, s0 + tid, M);
+    const unsigned long long kept = __ballot(keep);
+    if (lane == 0 && kept) atomicAdd(&B.ctl->M2, __popcll(kept));
+    tile_boxes(B, s, M, keep ? x : __int_as_float(0x7fc00000), y, z);
 }
 
 // ---- connected components of the radius graph: lock-free union-find ------------------------------
@@ -543,13 +552,23 @@ __global__ __launch_bounds__(64 * QW) void k3_cc_min(Det3dBufs B)
         for (int r0 = 0; r0 < ntiles; r0 += 64) {
             unsigned long long todo = __ballot(lane_box_d2(B, r0 + lane, ntiles, qx, qy, qz) * BOX_MARGIN < TOL2);
             while (todo) {
-                const int ta = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                int tb = -1;
-                if (todo) { tb = __ffsll((long long)todo) - 1; todo &= todo - 1; }
-                const int tile = (lane < 32) ? ta : tb;
-                const int j = BOX_PTS * (r0 + tile) + (lane & 31);
-                if (tile >= 0 && j < M && d2f(qx, qy, qz, X[j], Y[j], Z[j]) < TOL2) mi = min(mi, B.perm[j]);
+                float cx[CC_AHEAD], cy[CC_AHEAD], cz[CC_AHEAD];
+                int pj[CC_AHEAD];
+                bool ok[CC_AHEAD];
+#pragma unroll
+                for (int u = 0; u < CC_AHEAD; ++u) {                        // four steps' loads in flight
+                    int ta = -1, tb = -1;
+                    if (todo) { ta = __ffsll((long long)todo) - 1; todo &= todo - 1; }
+                    if (todo) { tb = __ffsll((long long)todo) - 1; todo &= todo - 1; }
+                    const int tile = (lane < 32) ? ta : tb;
+                    const int j = BOX_PTS * (r0 + tile) + (lane & 31);
+                    ok[u] = tile >= 0 && j < M;
+                    const int jj = ok[u] ? j : 0;
+                    cx[u] = X[jj]; cy[u] = Y[jj]; cz[u] = Z[jj]; pj[u] = B.perm[jj];   // (the id with the coordinates, not behind the test)
+                }
+#pragma unroll
+                for (int u = 0; u < CC_AHEAD; ++u)
+                    if (ok[u] && d2f(qx, qy, qz, cx[u], cy[u], cz[u]) < TOL2) mi = min(mi, pj[u]);
             }
         }
         for (int off = 32; off > 0; off >>= 1) mi = min(mi, __shfl_xor(mi, off, 64));
@@ -566,35 +585,62 @@ __global__ __launch_bounds__(64 * QW) void k3_cc_link(Det3dBufs B)
     for (int q = __builtin_amdgcn_readfirstlane(blockIdx.x * QW + (threadIdx.x >> 6)); q < M; q += gridDim.x * QW) {
         const float qx = X[q], qy = Y[q], qz = Z[q];
         if (!(qx == qx)) continue;
+#ifdef RDET_DEBUG_MARKS
+        const bool dbg = q == (int)blockIdx.x * QW;
+        if (dbg) D3_MARK(0);
+#endif
+        float db = lane_box_d2(B, lane, ntiles, qx, qy, qz) * BOX_MARGIN;   // (in flight under the chase below)
         int rs = *(const volatile int *)&parent[B.perm[q]];      // top of the query's chain as it stands
         for (int p = *(const volatile int *)&parent[rs]; p != rs; p = *(const volatile int *)&parent[rs]) rs = p;
         int ri = rs;                                              // (per lane) a possibly stale ancestor of the query
+#ifdef RDET_DEBUG_MARKS
+        if (dbg) D3_MARK(1);
+#endif
         for (int r0 = 0; r0 < ntiles; r0 += 64) {
-            unsigned long long todo = __ballot(lane_box_d2(B, r0 + lane, ntiles, qx, qy, qz) * BOX_MARGIN < TOL2);
+            if (r0) db = lane_box_d2(B, r0 + lane, ntiles, qx, qy, qz) * BOX_MARGIN;
+            unsigned long long todo = __ballot(db < TOL2 && BOX_PTS * (r0 + lane) < q);   // (a tile behind the query holds no earlier point)
+#ifdef RDET_DEBUG_MARKS
+            if (dbg && r0 == 0) { D3_MARK(2); if (threadIdx.x == 0 && blockIdx.x < 2048) d3_marks[blockIdx.x][6] = __popcll(todo); }
+#endif
             while (todo) {
-                const int ta = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                int tb = -1;
-                if (todo) { tb = __ffsll((long long)todo) - 1; todo &= todo - 1; }
-                const int tile = (lane < 32) ? ta : tb;
-                const int j = BOX_PTS * (r0 + tile) + (lane & 31);
-                // every edge is handled by its later end (j < q also keeps j < M); a masked neighbour's x is NaN
-                if (tile >= 0 && j < q && d2f(qx, qy, qz, X[j], Y[j], Z[j]) < TOL2) {
-                    int cr = *(const volatile int *)&parent[B.perm[j]];
-                    for (int p = *(const volatile int *)&parent[cr]; p != cr; p = *(const volatile int *)&parent[cr]) cr = p;
-                    if (cr != rs) {
-                        int a = uf_find<false>(parent, ri), b = uf_find<false>(parent, cr);
-                        while (a != b) {
-                            const int hi = max(a, b), lo = min(a, b);
-                            const int old = atomicCAS(&parent[hi], hi, lo);
-                            if (old == hi) { a = lo; break; }
-                            a = uf_find<true>(parent, a); b = uf_find<true>(parent, b);
+                float cx[CC_AHEAD], cy[CC_AHEAD], cz[CC_AHEAD];
+                int cr0[CC_AHEAD];
+                bool ok[CC_AHEAD];
+#pragma unroll
+                for (int u = 0; u < CC_AHEAD; ++u) {                        // four steps' loads in flight
+                    int ta = -1, tb = -1;
+                    if (todo) { ta = __ffsll((long long)todo) - 1; todo &= todo - 1; }
+                    if (todo) { tb = __ffsll((long long)todo) - 1; todo &= todo - 1; }
+                    const int tile = (lane < 32) ? ta : tb;
+                    const int j = BOX_PTS * (r0 + tile) + (lane & 31);
+                    // every edge is handled by its later end (j < q also keeps j < M); a masked neighbour's x is NaN
+                    ok[u] = tile >= 0 && j < q;
+                    const int jj = ok[u] ? j : 0;
+                    cx[u] = X[jj]; cy[u] = Y[jj]; cz[u] = Z[jj];
+                    cr0[u] = *(const volatile int *)&parent[B.perm[jj]];       // (with the coordinates, not behind the test)
+                }
+#pragma unroll
+                for (int u = 0; u < CC_AHEAD; ++u) {
+                    if (ok[u] && d2f(qx, qy, qz, cx[u], cy[u], cz[u]) < TOL2) {
+                        int cr = cr0[u];
+                        for (int p = *(const volatile int *)&parent[cr]; p != cr; p = *(const volatile int *)&parent[cr]) cr = p;
+                        if (cr != rs) {
+                            int a = uf_find<false>(parent, ri), b = uf_find<false>(parent, cr);
+                            while (a != b) {
+                                const int hi = max(a, b), lo = min(a, b);
+                                const int old = atomicCAS(&parent[hi], hi, lo);
+                                if (old == hi) { a = lo; break; }
+                                a = uf_find<true>(parent, a); b = uf_find<true>(parent, b);
+                            }
+                            ri = a;
                         }
-                        ri = a;
                     }
                 }
             }
         }
+#ifdef RDET_DEBUG_MARKS
+        if (dbg) D3_MARK(3);
+#endif
     }
 }
 
@@ -644,12 +690,15 @@ __global__ __launch_bounds__(256) void k3_finish_a(Det3dBufs B)
 __global__ __launch_bounds__(256) void k3_clusters(Det3dBufs B, int max_centers, float sx, float sy, float cs, float sn)
 {
 #pragma clang fp contract(off)
-    __shared__ int s_root[RDET_MAX_CENTERS], s_size[RDET_MAX_CENTERS], s_byrank[RDET_MAX_CENTERS];
+    __shared__ __attribute__((aligned(16))) int s_root[RDET_MAX_CENTERS], s_size[RDET_MAX_CENTERS];
+    __shared__ int s_byrank[RDET_MAX_CENTERS];
     __shared__ int s_n, s_err;
-    __shared__ int m_id[4][MAX_SZ];
-    __shared__ float m_x[4][MAX_SZ], m_y[4][MAX_SZ], o_x[4][MAX_SZ], o_y[4][MAX_SZ];
+    __shared__ __attribute__((aligned(16))) int m_id[4][MAX_SZ + 4];
+    __shared__ __attribute__((aligned(16))) float m_x[4][MAX_SZ], m_y[4][MAX_SZ], o_x[4][MAX_SZ], o_y[4][MAX_SZ];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    D3_MARK(0);
     if (tid == 0) { s_n = 0; s_err = 0; }
+    s_root[tid] = 0x7fffffff; s_size[tid] = -1;                                   // (the ranking below reads four entries at a time)
     __syncthreads();
     const int nroots = B.ctl->nroots;
     for (int k = tid; k < nroots; k += 256) {
@@ -661,59 +710,114 @@ __global__ __launch_bounds__(256) void k3_clusters(Det3dBufs B, int max_centers,
         }
     }
     __syncthreads();
+    D3_MARK(1);
     int n = min(s_n, RDET_MAX_CENTERS);
     int err = s_err;
     if (n > max_centers) { err = RDET_ERR_BUFFER; n = 0; }
     if (tid < n) {
         int rank = 0;
         const int sz = s_size[tid], rt = s_root[tid];
-        for (int k = 0; k < n; ++k) rank += (s_size[k] > sz || (s_size[k] == sz && s_root[k] < rt)) ? 1 : 0;
+        for (int k = 0; k < n; k += 4) {                                            // (one LDS round trip per entry made this 6 us)
+            const int4 zs = *(const int4 *)&s_size[k], rs = *(const int4 *)&s_root[k];
+            rank += (zs.x > sz || (zs.x == sz && rs.x < rt)) + (zs.y > sz || (zs.y == sz && rs.y < rt)) +
+                    (zs.z > sz || (zs.z == sz && rs.z < rt)) + (zs.w > sz || (zs.w == sz && rs.w < rt));
+        }
         s_byrank[rank] = tid;
     }
     __syncthreads();
-    if (blockIdx.x == 0 && tid == 0) {
-        B.ctl->K = n; B.ctl->err = err;
-        d3_host_store16(&B.hout->head, (unsigned)n, (unsigned)err, (unsigned)B.ctl->M2, (unsigned)B.seq);   // the centres follow, each with its own tag
-        // the next cloud's grid: this cloud's survivor box, a little wider, at least 1/8 m per cell
-        if (B.ctl->bb[0] != 0x7fffffff) {
-            const float x0 = dec_ord(B.ctl->bb[0]), y0 = dec_ord(B.ctl->bb[1]), x1 = dec_ord(B.ctl->bb[2]), y1 = dec_ord(B.ctl->bb[3]);
-            const float ext = fmaxf(fmaxf(x1 - x0, y1 - y0) * 1.05f, 0.125f * GRID_G);
-            B.ctl->gx0 = 0.5f * (x0 + x1) - 0.5f * ext; B.ctl->gy0 = 0.5f * (y0 + y1) - 0.5f * ext; B.ctl->ginv = (float)GRID_G / ext;
+    if (blockIdx.x == 0) {
+        if (tid == 0) {
+            B.ctl->K = n; B.ctl->err = err;
+            d3_host_store16(&B.hout->head, (unsigned)n, (unsigned)err, (unsigned)B.ctl->M2, (unsigned)B.seq);   // the centres follow, each with its own tag
         }
-        B.ctl->bb[0] = B.ctl->bb[1] = 0x7fffffff; B.ctl->bb[2] = B.ctl->bb[3] = (int)0x80000000;
+        // the next cloud's grid: the box of this cloud's inliers (= of the tiles' boxes), a little wider, at least 1/8 m per cell
+        if (wave == 0) {
+            const int ntiles = (B.ctl->M + BOX_PTS - 1) / BOX_PTS;
+            float x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY;
+            for (int t = lane; t < ntiles; t += 64) {
+                const float4 lo = *(const float4 *)(B.box + 8 * t), hi = *(const float4 *)(B.box + 8 * t + 4);
+                x0 = fminf(x0, lo.x); y0 = fminf(y0, lo.y); x1 = fmaxf(x1, lo.w); y1 = fmaxf(y1, hi.x);
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                x0 = fminf(x0, __shfl_xor(x0, off, 64)); y0 = fminf(y0, __shfl_xor(y0, off, 64));
+                x1 = fmaxf(x1, __shfl_xor(x1, off, 64)); y1 = fmaxf(y1, __shfl_xor(y1, off, 64));
+            }
+            if (lane == 0 && x0 <= x1 && y0 <= y1 && fabsf(x0) < 1e30f && fabsf(x1) < 1e30f && fabsf(y0) < 1e30f && fabsf(y1) < 1e30f) {
+                const float ext = fmaxf(fmaxf(x1 - x0, y1 - y0) * 1.05f, 0.125f * GRID_G);
+                B.ctl->gx0 = 0.5f * (x0 + x1) - 0.5f * ext; B.ctl->gy0 = 0.5f * (y0 + y1) - 0.5f * ext; B.ctl->ginv = (float)GRID_G / ext;
+            }
+        }
     }
+    D3_MARK(2);
     const int rank = blockIdx.x * 4 + wave;
     if (rank >= n) return;
     const int e = s_byrank[rank], root = s_root[e], size = s_size[e];
     const int *slabel = reinterpret_cast<const int *>(B.dist);
+    const int first = B.first[root], last = B.last[root];
     int have = 0;
-    for (int b0 = B.first[root]; b0 <= B.last[root] && have < size; b0 += 64) {
-        const int s = b0 + lane;
-        const bool mem = s <= B.last[root] && slabel[s] == root;
-        const unsigned long long mask = __ballot(mem);
-        if (mem) {
-            const int k = have + __popcll(mask & ((1ull << lane) - 1));
-            m_id[wave][k] = B.perm[s]; m_x[wave][k] = B.s1[s]; m_y[wave][k] = B.s1[B.cap + s];   // (a member's x is never masked)
+    // a component's members sit close together in the sorted copy -- except when it straddles a major Morton boundary
+    // (stretches of a few thousand positions occur): sixteen chunks' labels per round trip, then the members' data
+    for (int b0 = first; b0 <= last && have < size; b0 += 1024) {
+        int sl[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int s = b0 + 64 * u + lane; sl[u] = (s <= last) ? slabel[s] : -2; }
+        int id[16];
+        float mx[16], my[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int s = b0 + 64 * u + lane;
+            if (sl[u] == root) { id[u] = B.perm[s]; mx[u] = B.s1[s]; my[u] = B.s1[B.cap + s]; }   // (a member's x is never masked)
         }
-        have += __popcll(mask);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const bool mem = sl[u] == root;
+            const unsigned long long mask = __ballot(mem);
+            if (mem) {
+                const int k = have + __popcll(mask & ((1ull << lane) - 1));
+                m_id[wave][k] = id[u]; m_x[wave][k] = mx[u]; m_y[wave][k] = my[u];
+            }
+            have += __popcll(mask);
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // arrival order: a member's place = the number of members with a smaller node id
-    for (int k = lane; k < size; k += 64) {
-        const int id = m_id[wave][k];
-        int place = 0;
-        for (int q = 0; q < size; ++q) place += (m_id[wave][q] < id) ? 1 : 0;
-        o_x[wave][place] = m_x[wave][k]; o_y[wave][place] = m_y[wave][k];
+    D3_MARK(3);
+#ifdef RDET_DEBUG_MARKS
+    if (threadIdx.x == 0 && blockIdx.x < 2048) { d3_marks[blockIdx.x][6] = (unsigned long long)(last - first + 1); d3_marks[blockIdx.x][7] = (unsigned long long)size; }
+#endif
+    // arrival order: a member's place = the number of members with a smaller node id (ids four at a time: the list is
+    // padded with ids no member is above)
+    if (lane < 4) m_id[wave][size + lane] = 0x7fffffff;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+        const int k0 = lane, k1 = lane + 64, k2 = lane + 128;
+        const int i0 = (k0 < size) ? m_id[wave][k0] : 0, i1 = (k1 < size) ? m_id[wave][k1] : 0, i2 = (k2 < size) ? m_id[wave][k2] : 0;
+        int p0 = 0, p1 = 0, p2 = 0;
+        for (int q = 0; q < size; q += 4) {
+            const int4 o = *(const int4 *)&m_id[wave][q];
+            p0 += (o.x < i0) + (o.y < i0) + (o.z < i0) + (o.w < i0);
+            p1 += (o.x < i1) + (o.y < i1) + (o.z < i1) + (o.w < i1);
+            p2 += (o.x < i2) + (o.y < i2) + (o.z < i2) + (o.w < i2);
+        }
+        if (k0 < size) { o_x[wave][p0] = m_x[wave][k0]; o_y[wave][p0] = m_y[wave][k0]; }
+        if (k1 < size) { o_x[wave][p1] = m_x[wave][k1]; o_y[wave][p1] = m_y[wave][k1]; }
+        if (k2 < size) { o_x[wave][p2] = m_x[wave][k2]; o_y[wave][p2] = m_y[wave][k2]; }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     float cx = 0.f, cy = 0.f;
-    for (int q = 0; q < size; ++q) { cx += o_x[wave][q]; cy += o_y[wave][q]; }
+    int q = 0;
+    for (; q + 4 <= size; q += 4) {
+        const float4 vx = *(const float4 *)&o_x[wave][q], vy = *(const float4 *)&o_y[wave][q];
+        cx += vx.x; cx += vx.y; cx += vx.z; cx += vx.w;
+        cy += vy.x; cy += vy.y; cy += vy.z; cy += vy.w;
+    }
+    for (; q < size; ++q) { cx += o_x[wave][q]; cy += o_y[wave][q]; }
     if (lane == 0) {
         const float sz = (float)size;
         cx /= sz; cy /= sz;
         const float ox = (cs * cx + (-sn) * cy) + sx, oy = (sn * cx + cs * cy) + sy;   // :96 Project2D(s2b).cast<float>() * p
         d3_host_store16(&B.hout->centers[rank], __float_as_uint(ox), __float_as_uint(oy), (unsigned)B.seq, 0u);
     }
+    D3_MARK(4);
 }
 
 }  // namespace
@@ -727,6 +831,7 @@ struct rdet3d {
     int *d_label, *d_cnt, *d_first, *d_last, *d_roots, *d_perm, *d_hist, *d_cursor;
     Det3dCtl *d_ctl;
     Det3dHostOut *h_out, *dv_out;      // pinned + mapped: polled result slots (host / device view)
+    bool in_flight;                    // a call returned before its kernels had published everything
     bool xyzi_in_vram;                 // d_xyzi is fine-grained device memory the host writes through the PCIe BAR (else: pinned staging + copy)
     float *h_stage;
     int seq;
@@ -782,7 +887,6 @@ int rdet3d_create(const rdet3d_options *opt, const double s2b[3], int max_points
         {   // the first cloud is sorted on a 64 m x 64 m grid around the sensor; every later one on its predecessor's box
             Det3dCtl c0;
             std::memset(&c0, 0, sizeof(c0));
-            c0.bb[0] = c0.bb[1] = 0x7fffffff; c0.bb[2] = c0.bb[3] = (int)0x80000000;
             c0.gx0 = c0.gy0 = -32.f; c0.ginv = (float)GRID_G / 64.f;
             DET3_TRY(h, hipMemcpy(h->d_ctl, &c0, sizeof(c0), hipMemcpyHostToDevice));
         }
@@ -819,8 +923,20 @@ int rdet3d_handle_cloud(rdet3d_t *h, double stamp, const float *xyzi, int N, flo
     if (obs_time) *obs_time = stamp;                                  // :16
     if (N == 0) return RDET_OK;
     if (N > h->max_points) return RDET_ERR_CAPACITY;
+#ifdef RDET_DEBUG_MARKS
+    const auto dbg_t0 = std::chrono::steady_clock::now();
+    auto dbg_us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t0).count(); };
+    double dbg_t[6] = {0, 0, 0, 0, 0, 0};
+#endif
     DET3_TRY(h, hipSetDevice(h->device));
-    DET3_TRY(h, hipStreamSynchronize(h->stream));                      // (the previous call returned on its last result slot, not on the kernels' end)
+    // The previous call returned on its last result slot.  Every slot is written by the LAST kernel of the chain, which
+    // starts when all others have ended, so by then nothing reads the cloud buffer any more and the host may overwrite it;
+    // the kernels enqueued below are ordered behind whatever is left of that kernel by the stream.  (hipStreamSynchronize on
+    // an idle stream costs 15 us.)  Only a call that gave up waiting leaves kernels in flight.
+    if (h->in_flight) { DET3_TRY(h, hipStreamSynchronize(h->stream)); h->in_flight = false; }
+#ifdef RDET_DEBUG_MARKS
+    dbg_t[0] = dbg_us();
+#endif
     if (h->xyzi_in_vram) {                                             // the cloud goes straight into device memory: posted writes, no copy engine
         std::memcpy(h->d_xyzi, xyzi, sizeof(float) * 4 * (size_t)N);
         __atomic_thread_fence(__ATOMIC_SEQ_CST);
@@ -828,11 +944,15 @@ int rdet3d_handle_cloud(rdet3d_t *h, double stamp, const float *xyzi, int N, flo
         std::memcpy(h->h_stage, xyzi, sizeof(float) * 4 * (size_t)N);
         DET3_TRY(h, hipMemcpyAsync(h->d_xyzi, h->h_stage, sizeof(float) * 4 * (size_t)N, hipMemcpyHostToDevice, h->stream));
     }
+#ifdef RDET_DEBUG_MARKS
+    dbg_t[1] = dbg_us();
+#endif
     Det3dBufs B;
     B.xyzi = h->d_xyzi; B.p1 = h->d_p1; B.s1 = h->d_s1; B.perm = h->d_perm; B.box = h->d_box; B.hist = h->d_hist; B.cursor = h->d_cursor;
     B.dist = h->d_dist; B.label = h->d_label; B.cnt = h->d_cnt; B.first = h->d_first; B.last = h->d_last; B.roots = h->d_roots;
     B.ctl = h->d_ctl; B.cap = h->max_points;
     B.hout = h->dv_out; B.seq = ++h->seq;
+    h->in_flight = true;
     const int ftiles = (N + 1023) / 1024, b256 = (N + 255) / 256;
     hipLaunchKernelGGL(k3_filter_count, dim3(ftiles), dim3(1024), 0, h->stream, B, N, h->opt.intensity_min);
     hipLaunchKernelGGL(k3_filter_write, dim3(ftiles + GRID_CELLS / 1024), dim3(1024), 0, h->stream, B, N, h->opt.intensity_min, ftiles);
@@ -840,7 +960,7 @@ int rdet3d_handle_cloud(rdet3d_t *h, double stamp, const float *xyzi, int N, flo
     hipLaunchKernelGGL(k3_boxes, dim3(b256), dim3(256), 0, h->stream, B);
     const int qblocks = (N + QW - 1) / QW < Q_GRID ? (N + QW - 1) / QW : Q_GRID;   // a wave per query, dealt round-robin: M <= N stays on the device
     hipLaunchKernelGGL(k3_knn, dim3(qblocks), dim3(64 * QW), 0, h->stream, B);
-    hipLaunchKernelGGL(k3_sor, dim3(1), dim3(1024), 0, h->stream, B);
+    hipLaunchKernelGGL(k3_sor, dim3(b256), dim3(256), 0, h->stream, B);
     hipLaunchKernelGGL(k3_cc_min, dim3(qblocks), dim3(64 * QW), 0, h->stream, B);
     hipLaunchKernelGGL(k3_cc_link, dim3(qblocks), dim3(64 * QW), 0, h->stream, B);
     const float sa = (float)h->s2b[2];
@@ -848,6 +968,9 @@ int rdet3d_handle_cloud(rdet3d_t *h, double stamp, const float *xyzi, int N, flo
     hipLaunchKernelGGL(k3_clusters, dim3(RDET_MAX_CENTERS / 4), dim3(256), 0, h->stream, B, max_centers < RDET_MAX_CENTERS ? max_centers : RDET_MAX_CENTERS,
                        (float)h->s2b[0], (float)h->s2b[1], cosf(sa), sinf(sa));
     DET3_TRY(h, hipGetLastError());
+#ifdef RDET_DEBUG_MARKS
+    dbg_t[2] = dbg_us();
+#endif
     // poll the head, then each centre's own tag (k3_clusters)
     auto wait_tag = [&](const int *tag) -> int {
         const auto t0 = std::chrono::steady_clock::now();
@@ -867,6 +990,9 @@ int rdet3d_handle_cloud(rdet3d_t *h, double stamp, const float *xyzi, int N, flo
     };
     int rc = wait_tag(&h->h_out->head.seq);
     if (rc != RDET_OK) return rc;
+#ifdef RDET_DEBUG_MARKS
+    dbg_t[3] = dbg_us();
+#endif
     const Det3dHead head = h->h_out->head;
     if (head.err) return head.err;
     *K = head.K;
@@ -875,6 +1001,11 @@ int rdet3d_handle_cloud(rdet3d_t *h, double stamp, const float *xyzi, int N, flo
         if (rc != RDET_OK) return rc;
         centers_xy[2 * c] = h->h_out->centers[c].x; centers_xy[2 * c + 1] = h->h_out->centers[c].y;
     }
+    h->in_flight = false;
+#ifdef RDET_DEBUG_MARKS
+    dbg_t[4] = dbg_us();
+    if (getenv("RDET3_HOST_MARKS")) std::fprintf(stderr, "rdet3d host us: synced %.1f cloud written %.1f launched %.1f head %.1f centres %.1f\n", dbg_t[0], dbg_t[1], dbg_t[2], dbg_t[3], dbg_t[4]);
+#endif
     return RDET_OK;
 }
 
