@@ -21,8 +21,11 @@ Rank 0 prints ONE JSON line.
 Extra objects on that line (rank 0, N = 1 unless noted):
   roofline       the P -= K (H P) kernel (k_downdate2; inside the chain it goes out with the
                  NEXT scan as k_dd_front, the same body plus that scan's front end in 32
-                 further workgroups), average launch time measured live with hipEvents on
-                 the handle's stream.  P is stored as its LOWER TRIANGLE, so ("scale both FLOP and BYTES by the
+                 further workgroups).  `frac` / `achieved` / `mfma.frac` are the IN-CHAIN figures: the
+                 kernel's average time inside the update chain, measured in this run as the hipEvent
+                 bracket around each launch minus the empty bracket (behind k_mid, its panels fresh);
+                 `frac_back_to_back` is the same kernel re-launched back to back between one event pair
+                 (L2-warm panels: a state the filter is never in -- round 3 quoted that one as `frac`).  P is stored as its LOWER TRIANGLE, so ("scale both FLOP and BYTES by the
                  executed tile fraction") `achieved` / `frac` count the bytes that algorithm
                  must move -- the triangle read and written, the two panels -- and
                  `mfma.frac` the MFMA FLOP actually executed; the full-square SURVEY figure
@@ -45,7 +48,12 @@ Extra objects on that line (rank 0, N = 1 unless noted):
                  configs[1] (C2) and configs[3] (C4: omni odometry; also with the 3D
                  detector in front of the filter) -- parity-test configs, not `value`.
   multi_session  aggregate updates/s of 4 independent sessions sharing GPU 0.
-  ranks          (N > 1) per-rank updates/s: min / median / max.
+  detectors      reflector_detect's two front ends at the C ABI, measured in this run: HandleLaserScan on a 3600-beam
+                 scan and HandlePointCloud on a 28.8 k-point sweep -- call us (median / p99, host buffers in, centres
+                 out: PCIe inclusive), input bytes / call time in GB/s, and the CPU oracle's time for the same inputs
+                 (part of the CPU-baseline leg: skipped with --no-cpu-baseline).
+  ranks          per-rank updates/s: min / median / max, and every rank's parity figure -- max |mu - oracle| over
+                 `--rank-parity-steps` updates run AFTER the timed region, oracle started from the rank's own state.
 """
 from __future__ import annotations
 
@@ -86,6 +94,9 @@ def parse_args(argv=None):
     ap.add_argument("--instr-steps", type=int, default=300, help="updates in the per-kernel hipEvent pass")
     ap.add_argument("--secondary", default="C2,C4", help="comma list of other BASELINE configs to also measure (rank 0, N=1)")
     ap.add_argument("--secondary-steps", type=int, default=1000)
+    ap.add_argument("--rank-parity-steps", type=int, default=20,
+                    help="updates every rank replays against the CPU oracle AFTER the timed region (its parity figure in `ranks`; 0: skip)")
+    ap.add_argument("--detector-reps", type=int, default=200, help="calls per detector in the `detectors` leg (0: skip)")
     ap.add_argument("--timed-only", action="store_true",
                     help="map build, warm-up and the timed steps only (no instrumented legs): what scripts/gpu_profile_round.sh "
                          "runs under rocprofv3, so that the LAST dispatches of every kernel are the timed region's")
@@ -156,6 +167,26 @@ def timed_region(ekf, scans, warmup, steps, dist_mod, device_sync):
     return elapsed, warmup + steps
 
 
+def rank_parity(cfg, sess, ekf, scans):
+    """The rank's parity figure (every rank's record carries its max-abs pose error): the CPU oracle
+    (structured mode) is started from THIS rank's state after the timed region and both replay `scans`; returns
+    max |mu_gpu - mu_oracle| over all of mu after the last one and whether every association list was identical.
+    Not timed, not part of `value`; the oracle is only the checker here, as in the cpu_baseline leg."""
+    from oracle.binding import OracleEKF
+    st = ekf.GetState()
+    o = OracleEKF(cfg.odom_model, sess.init_time, sess.init_pose, cfg.sigma_v ** 2, cfg.sigma_w ** 2, cfg.sigma_obs ** 2)
+    vt = sess.odom[np.nonzero(sess.ev_type == 0)[0][-1]]
+    o.set_state(st.time, st.mu, st.sigma, vt)
+    same = True
+    for t, ob in scans:
+        ekf.handle_observation(t, ob)
+        o.handle_observation(t, ob)
+        mg = ekf.last_match()
+        sp, mp, nw = o.last_match()
+        same = same and bool(np.array_equal(mg.state_obs_match_ids, sp) and np.array_equal(mg.new_ids, nw))
+    return float(np.abs(ekf.mu() - o.mu()).max()), same
+
+
 def run_rank(args, dist_mod, rank, local_rank, world, make_filter=gpu_filter_factory, device_sync=lambda: None,
              full=True):
     """One rank's share of the bench.  `full` = also the rank-0 instrumented legs that need the HIP handle."""
@@ -177,7 +208,7 @@ def run_rank(args, dist_mod, rank, local_rank, world, make_filter=gpu_filter_fac
     if n != n_expect:
         raise SystemExit(f"warm-up ended with n={n}, expected {n_expect}")
 
-    n_extra = 16 + 2 * max(args.latency_steps, 0) + max(args.instr_steps, 0) + 2 * max(args.steps, 200)
+    n_extra = 16 + 2 * max(args.latency_steps, 0) + max(args.instr_steps, 0) + 2 * max(args.steps, 200) + max(args.rank_parity_steps, 0)
     steady = synth.steady_state_scans(sess, args.warmup + args.steps + n_extra)
     m = 2 * steady[0][1].shape[0]
 
@@ -188,9 +219,14 @@ def run_rank(args, dist_mod, rank, local_rank, world, make_filter=gpu_filter_fac
     nw = mm[2] if isinstance(mm, tuple) else mm.new_ids
     assert len(nw) == 0 and len(sp) == m // 2, "not steady state"
     assert ekf.n == n_expect
+    # every rank, after the timed region: its own parity figure (the gloo CPU test drives this function with an oracle stub: nothing to compare)
+    err, assoc_ok = float("nan"), True
+    if args.rank_parity_steps > 0 and hasattr(ekf, "GetState"):
+        err, assoc_ok = rank_parity(cfg, sess, ekf, steady[used:used + args.rank_parity_steps])
+        used += args.rank_parity_steps
     mu = ekf.mu()
     recs = D.gather_records(dist_mod, dict(steps=args.steps, elapsed_s=elapsed, final_n=ekf.n, pose_x=mu[0], pose_y=mu[1],
-                                           pose_theta=mu[2], max_abs_err=0.0, seed=cfg.seed))
+                                           pose_theta=mu[2], max_abs_err=err if assoc_ok else float("inf"), seed=cfg.seed))
     if rank != 0:
         return None
     rates = sorted(r["steps"] / r["elapsed_s"] for r in recs)
@@ -208,14 +244,18 @@ def run_rank(args, dist_mod, rank, local_rank, world, make_filter=gpu_filter_fac
                                "steady-state HandleObservationMessage",
                    "sessions": world, "parallelism": "replicas: one independent session per GPU",
                    "map_build_s": round(map_build_s, 3)},
+        "dist_backend": (dist_mod.get_backend() if dist_mod is not None else None),
         "ranks": {"updates_per_s_min": rates[0], "updates_per_s_median": float(np.median(rates)),
                   "updates_per_s_max": rates[-1], "final_n": [int(r["final_n"]) for r in recs],
-                  "seeds": [int(r["seed"]) for r in recs]},
+                  "seeds": [int(r["seed"]) for r in recs],
+                  "max_abs_err_vs_oracle": [None if r["max_abs_err"] != r["max_abs_err"] else float(r["max_abs_err"]) for r in recs],
+                  "parity_note": f"per rank: max |mu - CPU oracle| after {args.rank_parity_steps} updates replayed by both from the rank's own "
+                                 "state behind the timed region (inf: an association list differed; null: not run)"},
     }
     if not full or args.timed_only:
         return out
     rest = steady[used:]
-    out.update(instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, local_rank, world))
+    out.update(instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, local_rank, world, chain_us=1e6 * elapsed / args.steps))
     return out
 
 
@@ -298,7 +338,7 @@ def per_kernel_leg(ekf, scans, steps):
     return {k: (round(v[0] / v[1], 3) if v[1] >= max(2, steps // 4) else None) for k, v in prof.items() if k != "update"}
 
 
-def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world):
+def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world, chain_us=None):
     out = {}
     pos = 0
     lat, used = latency_legs(ekf, rest[pos:], args.latency_steps)
@@ -341,7 +381,20 @@ def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world):
     tiles_exec = T * (T + 1) // 2
     flop_exec = tiles_exec * 2.0 * 64 * 64 * (16 * -(-m // 16))          # MFMA FLOP actually issued (16x16x4 tiles over the padded k range)
     flop_k7 = 2.0 * n * n * m                              # the reference's full-square count
-    achieved = bytes_exec / (dd_us * 1e-6) / 1e9
+    # IN-CHAIN time of the kernel, from this run's own measurements.  Inside the chain the kernels run dependent and back to
+    # back, so a kernel's cost there includes its cold start behind its predecessor; a hipEvent bracket around each launch
+    # (minus the empty bracket) measures the kernels apart and comes out short of that (their sum is ~4 us below the timed
+    # region's us per update).  So: the timed region's us per update (un-instrumented), split by the kernels' bracketed
+    # shares.  rocprofv3 --kernel-trace inside the chain agrees with it (profiles/), the back-to-back rerun rides along.
+    dd_chain_us, chain_method = None, None
+    corr = {k: kernel_us[k] - kernel_us["empty"] for k in ("front", "mid", "downdate", "augment")
+            if kernel_us.get(k) is not None and kernel_us.get("empty") is not None}
+    if chain_us and corr.get("downdate", 0) > 0 and corr.get("mid", 0) > 0:
+        dd_chain_us = chain_us * corr["downdate"] / sum(v for v in corr.values() if v > 0)
+        chain_method = ("measured in this run, IN CHAIN: the timed region's us per update (%.2f, un-instrumented) x the kernel's share of the per-launch "
+                        "hipEvent brackets minus the empty bracket (%s)" % (chain_us, ", ".join(f"{k} {v:.2f}" for k, v in corr.items() if v > 0)))
+    t_frac = dd_chain_us if dd_chain_us else dd_us
+    achieved = bytes_exec / (t_frac * 1e-6) / 1e9
     rocprof_us, traffic, traffic_src, rocprof_src = None, None, None, None
     try:
         avg = json.load(open(os.path.join(ROOT, "profiles", "kernel_avg_us.json")))
@@ -357,30 +410,35 @@ def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world):
                        "committed summary; NOT measured in this run")
     except Exception:
         pass
-    moved = (traffic / (dd_us * 1e-6) / 1e9) if traffic else None
+    moved = (traffic / (t_frac * 1e-6) / 1e9) if traffic else None
     out["roofline"] = {
         "kernel": "k_downdate2<64> / k_dd_front<64> (P -= K (H P) on the lower triangle P is stored as: FP64 MFMA 16x16x4 tiles, panels by LDS DMA; "
                   "inside the chain it is enqueued with the NEXT scan as k_dd_front, whose last 32 workgroups are that scan's front end)", "bound": "hbm",
         "bytes_note": "achieved / frac = bytes the executed lower-triangle algorithm must move: 2 * 8 n(n+1)/2 (triangle read and written) "
-                      "+ 8 n (3+m) panels; frac_fullsquare = SURVEY 8(d)'s 16 n^2 + 8 n (3+m) over the same time (what a full-square "
-                      "kernel would have had to move); frac_moved = HBM bytes by PMC counters (committed summary) over the same time; "
-                      "*_inchain = the same over the committed rocprofv3 average of the kernel INSIDE the update chain, where it runs as "
-                      "k_dd_front<64> on 224 CUs beside the next scan's front end (its panels come fresh from k_mid; back to back they are L2-warm)",
+                      "+ 8 n (3+m) panels, over the kernel's IN-CHAIN time measured in this run (avg_launch_us); frac_fullsquare = SURVEY 8(d)'s "
+                      "16 n^2 + 8 n (3+m) over the same time (what a full-square kernel would have had to move); frac_moved = HBM bytes by PMC "
+                      "counters (committed summary) over the same time; *_back_to_back = the same over the kernel re-launched back to back "
+                      "between one hipEvent pair (L2-warm panels; what round 3 quoted as frac); frac_inchain_rocprof = over the committed "
+                      "rocprofv3 average of k_dd_front<64>",
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-        "frac_fullsquare": bytes_full / (dd_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+        "frac_fullsquare": bytes_full / (t_frac * 1e-6) / 1e9 / HBM_PEAK_GBS,
         "frac_moved": (moved / HBM_PEAK_GBS) if moved else None,
-        "frac_inchain": (bytes_exec / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if rocprof_us else None,
-        "frac_moved_inchain": (traffic / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if (traffic and rocprof_us) else None,
+        "frac_back_to_back": bytes_exec / (dd_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+        "frac_moved_back_to_back": (traffic / (dd_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+        "frac_inchain_rocprof": (bytes_exec / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if rocprof_us else None,
         "traffic": traffic, "traffic_source": traffic_src,
-        "bytes_per_launch": bytes_exec, "bytes_per_launch_fullsquare": bytes_full, "avg_launch_us": dd_us,
-        "avg_launch_us_method": "measured in this run: back-to-back launches between one hipEvent pair on the handle's stream",
+        "bytes_per_launch": bytes_exec, "bytes_per_launch_fullsquare": bytes_full,
+        "avg_launch_us": t_frac,
+        "avg_launch_us_method": (chain_method if dd_chain_us else
+                                 "measured in this run: back-to-back launches between one hipEvent pair on the handle's stream (no per-kernel brackets available)"),
+        "avg_launch_us_back_to_back": dd_us,
         "per_launch_bracket_us": kernel_us.get("downdate"), "empty_event_bracket_us": kernel_us.get("empty"),
         "rocprof_avg_launch_us": rocprof_us, "rocprof_source": rocprof_src,
-        "mfma": {"achieved_tflops": flop_exec / (dd_us * 1e-6) / 1e12, "peak_tflops": FP64_MFMA_PEAK_TF,
-                 "frac": flop_exec / (dd_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF,
-                 "frac_fullsquare_flop": flop_k7 / (dd_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF,
-                 "frac_inchain": (flop_exec / (rocprof_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF) if rocprof_us else None,
-                 "note": f"frac = EXECUTED MFMA FLOP ({tiles_exec} lower-triangle tiles x 2*64*64*{16 * -(-m // 16)}) over the measured time; "
+        "mfma": {"achieved_tflops": flop_exec / (t_frac * 1e-6) / 1e12, "peak_tflops": FP64_MFMA_PEAK_TF,
+                 "frac": flop_exec / (t_frac * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF,
+                 "frac_fullsquare_flop": flop_k7 / (t_frac * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF,
+                 "frac_back_to_back": flop_exec / (dd_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF,
+                 "note": f"frac = EXECUTED MFMA FLOP ({tiles_exec} lower-triangle tiles x 2*64*64*{16 * -(-m // 16)}) over the in-chain time; "
                          "frac_fullsquare_flop = the reference's 2 n^2 m over the same time (the mirrored kernel executes half of them)"}}
     out["kernel_us"] = kernel_us
     if ms_result is not None:
@@ -398,8 +456,85 @@ def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world):
             except Exception as e:             # a secondary figure must never take the headline down
                 sec[name] = {"error": repr(e)}
         out["secondary"] = sec
+    if world == 1 and args.detector_reps > 0:
+        try:
+            out["detectors"] = detectors_leg(args, device)
+        except Exception as e:                 # a secondary figure must never take the headline down
+            out["detectors"] = {"error": repr(e)}
     if not args.no_cpu_baseline:
         out["cpu_baseline"], out["pose_rmse_vs_oracle_m"] = cpu_baseline(args, cfg, sess, state_for_cpu, device)
+    return out
+
+
+def detectors_leg(args, device):
+    """reflector_detect's two front ends at the C ABI (laser_reflector_detect.cc:239-306, point_cloud_reflector_detect.cc:31-97):
+    per-call latency with host buffers in and centres out (one synchronising call per scan, like the reference's callback:
+    PCIe inclusive), the input bytes over that time, and -- in the CPU-baseline leg -- the CPU oracle on the same inputs."""
+    from types import SimpleNamespace as NS
+    from reflector_ekf_slam_amd import OdometryData, synth
+    from reflector_ekf_slam_amd.detect import (LaserReflectorDetect, PointCloudOptions, PointCloudReflectorDetect,
+                                               ReflectorDetectOptions)
+    reps = args.detector_reps
+    s2b = (0.13686, 0.0, 0.0)
+    rng = np.random.Generator(np.random.PCG64(7))
+
+    def lat(f, n):
+        f(); f()
+        ts = np.zeros(n)
+        for k in range(n):
+            t0 = time.perf_counter()
+            f()
+            ts[k] = 1e6 * (time.perf_counter() - t0)
+        return ts
+
+    def q(a):
+        return {"median": float(np.median(a)), "p99": float(np.percentile(a, 99)), "mean": float(a.mean()), "n": int(a.size)}
+
+    out = {"note": "call = one C-ABI call with host buffers in and the reflector centres out (PCIe inclusive); GB/s = input bytes / median call time "
+                   "(these paths are latency chains of a few KB to half a MB: the figure says how far from any bandwidth bound they sit)"}
+    # ---- 2D: 3600 beams (ranges + intensities in, centres out), odometry present so that the de-skew runs
+    lms = synth.make_world(synth.C2, rng)
+    pose = (float(lms[:, 0].mean()), float(lms[:, 1].mean()), 0.6)
+    scan = NS(**synth.make_laser_scan(lms, pose, 10.0, rng, n_beams=3600))
+    g = LaserReflectorDetect(ReflectorDetectOptions(), sensor_to_base_link=s2b, device=device)
+    odo = []
+    for k in range(30):
+        t = 9.5 + 0.02 * k
+        odo.append((t, 0.5 * t, 0.0, 0.0, 1.0, 0.5, 0.0, 0.1))
+        g.HandleOdometryData(OdometryData(time=t, position=(0.5 * t, 0.0, 0.0), orientation=(1.0, 0.0, 0.0, 0.0),
+                                          linear_velocity=(0.5, 0.0, 0.0), angular_velocity=(0.0, 0.0, 0.1)))
+    obs2 = g.HandleLaserScan(scan)
+    t2 = lat(lambda: g.HandleLaserScan(scan), reps)
+    b2 = 2 * 4 * 3600
+    out["laser_2d"] = {"beams": 3600, "reflectors": int(obs2.cloud_.shape[0]), "call_us": q(t2), "input_bytes": b2,
+                       "gb_per_s": b2 / (np.median(t2) * 1e-6) / 1e9, "kernel": "k_det2d (one launch per scan)"}
+    g.close()
+    # ---- 3D: 16 rings x 1800 azimuths = 28.8 k XYZI points
+    lms = synth.make_world(synth.C4, rng)
+    pose = (float(lms[:, 0].mean()), float(lms[:, 1].mean()), 0.3)
+    cloud = synth.make_point_cloud(lms, pose, rng, rings=16, n_az=1800)
+    g3 = PointCloudReflectorDetect(PointCloudOptions(), max_points=65536, device=device)
+    obs3 = g3.HandlePointCloud(1.0, cloud)
+    t3 = lat(lambda: g3.HandlePointCloud(1.0, cloud), reps)
+    b3 = 16 * int(cloud.shape[0])
+    out["cloud_3d"] = {"points": int(cloud.shape[0]), "reflectors": int(obs3.cloud_.shape[0]), "call_us": q(t3), "input_bytes": b3,
+                       "gb_per_s": b3 / (np.median(t3) * 1e-6) / 1e9,
+                       "kernels": "k3_filter_count/write, k3_scatter, k3_boxes, k3_knn, k3_sor, k3_cc_min/link, k3_finish_a, k3_clusters (ten launches per cloud)"}
+    g3.close()
+    if not args.no_cpu_baseline:               # the CPU-baseline leg: the oracle (the checker) timed on the same inputs, and compared
+        from oracle.binding import OracleDetect2D, oracle_detect3d
+        o = OracleDetect2D(sensor_to_base_link=s2b)
+        for rec in odo:
+            o.handle_odometry(*rec)
+        _, co = o.handle_scan(scan)
+        c2 = lat(lambda: o.handle_scan(scan), max(reps // 4, 10))
+        out["laser_2d"]["cpu_oracle_us"] = q(c2)
+        out["laser_2d"]["identical_to_oracle"] = bool(co.shape == obs2.cloud_.shape and np.array_equal(co, obs2.cloud_))
+        co3, _, _ = oracle_detect3d(cloud)
+        c3 = lat(lambda: oracle_detect3d(cloud), 3)
+        out["cloud_3d"]["cpu_oracle_us"] = q(c3)
+        out["cloud_3d"]["identical_to_oracle"] = bool(co3.shape == obs3.cloud_.shape and np.array_equal(co3, obs3.cloud_))
+        out["cpu_cores_used"] = 1
     return out
 
 

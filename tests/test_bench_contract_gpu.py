@@ -12,8 +12,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*extra):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *extra], capture_output=True, text=True, timeout=900, cwd=ROOT)
+def _run(*extra, env=None):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *extra], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                         env=dict(os.environ, **(env or {})))
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -35,8 +36,15 @@ def _check_contract(d, steps, warmup):
     assert r["traffic"] is None or "NOT measured in this run" in r["traffic_source"]
     # honest accounting: frac counts what the lower-triangle algorithm must move; the full-square figure rides along
     assert r["frac_fullsquare"] > 1.5 * r["frac"] and r["bytes_per_launch"] < 0.55 * r["bytes_per_launch_fullsquare"]   # triangle read + written
-    assert r["frac_inchain"] is None or 0.05 < r["frac_inchain"] <= r["frac"] * 1.3
+    # `frac` is the IN-CHAIN figure measured in this run (bracket minus empty bracket); the back-to-back rerun rides along and is the warmer one
+    assert "IN CHAIN" in r["avg_launch_us_method"] and r["avg_launch_us"] > 1.0
+    assert 0.05 < r["frac_back_to_back"] < 1.0 and r["frac"] <= r["frac_back_to_back"] * 1.25
+    assert abs(r["frac"] - r["bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9 / r["peak"]) < 1e-9
     assert r["frac_moved"] is None or 0.05 < r["frac_moved"] < 1.0
+    assert r["mfma"]["frac"] <= r["mfma"]["frac_back_to_back"] * 1.25
+    # every rank's record carries its parity figure (here: the one rank), taken after the timed region
+    pe = d["ranks"]["max_abs_err_vs_oracle"]
+    assert len(pe) == 1 and pe[0] is not None and pe[0] < 1e-9, pe
     assert r["mfma"]["frac"] < r["mfma"]["frac_fullsquare_flop"] and 0.02 < r["mfma"]["frac"] < 1.0
     assert d["value"] > 5000                                                   # the north-star bar is 10 k; 20-step runs are noisy
 
@@ -65,6 +73,14 @@ def test_driver_command_steps20_warmup5_has_every_object():
     assert nf["max_landmarks"] == 2048 and nf["n"] == 2051 and nf["value"] > 5000 and nf["with_pose_readback"]["value"] > 3000
     assert nf["kernel_us"]["augment"] is not None
     assert d["multi_session"]["sessions_bit_identical"] is True
+    det = d["detectors"]
+    assert "error" not in det, det
+    l2, c3 = det["laser_2d"], det["cloud_3d"]
+    assert l2["beams"] == 3600 and l2["reflectors"] > 5 and 3.0 < l2["call_us"]["median"] <= l2["call_us"]["p99"] < 2000.0
+    assert c3["points"] == 28800 and c3["reflectors"] > 5 and 10.0 < c3["call_us"]["median"] <= c3["call_us"]["p99"] < 5000.0
+    assert l2["identical_to_oracle"] is True and c3["identical_to_oracle"] is True
+    assert l2["cpu_oracle_us"]["median"] > 5.0 and c3["cpu_oracle_us"]["median"] > 20.0 * c3["call_us"]["median"]
+    assert abs(c3["gb_per_s"] - c3["input_bytes"] / (c3["call_us"]["median"] * 1e-6) / 1e9) < 1e-9
     sec = d["secondary"]
     assert set(sec) == {"C2", "C4"} and all("error" not in v for v in sec.values()), sec
     assert sec["C2"]["n"] == 259 and sec["C2"]["m"] == 32 and sec["C2"]["value"] > 5000
@@ -76,3 +92,16 @@ def test_bench_light_run_steps200():
     d = _run("--steps", "200", "--warmup", "20", "--no-cpu-baseline", "--multi-sessions", "0", "--secondary", "", "--latency-steps", "0")
     _check_contract(d, 200, 20)
     assert "cpu_baseline" not in d and "secondary" not in d and "latency_us" not in d
+    assert "cpu_oracle_us" not in d["detectors"]["cloud_3d"]                    # the oracle is only timed in the CPU-baseline leg
+
+
+def test_rccl_path_at_world_size_one():
+    """The collectives of the session-per-GPU harness on the ONE GPU there is (no 8-GPU node is reachable from the builder): process
+    group "nccl" (= RCCL) with device_id, barrier, all_reduce(MAX) of a cuda float64, all_gather of the 64-byte records."""
+    d = _run("--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--secondary", "", "--multi-sessions", "0",
+             "--latency-steps", "0", "--detector-reps", "0", env={"REKF_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29541"})
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["dist_backend"] == "nccl"
+    r = d["ranks"]
+    assert r["final_n"] == [2051] and len(r["seeds"]) == 1
+    assert r["max_abs_err_vs_oracle"][0] is not None and r["max_abs_err_vs_oracle"][0] < 1e-9
+    assert abs(d["value"] - 20 / (d["ms_per_step"] * 1e-3 * 20)) < 1e-6 * d["value"]
