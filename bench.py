@@ -134,7 +134,7 @@ def respawn_under_torchrun(args):
 def gpu_filter_factory(cfg, sess, device, capacity=None):
     from reflector_ekf_slam_amd import ReflectorEKFSLAM
     from reflector_ekf_slam_amd import session as S
-    return ReflectorEKFSLAM(S.options_for(sess), max_landmarks=capacity or cfg.n_landmarks, device=device)
+    return ReflectorEKFSLAM(S.options_for(sess), max_landmarks=capacity or cfg.n_landmarks, device=device, auto_grow=False)
 
 
 def build_session(cfg_name, rank, world):
@@ -637,7 +637,7 @@ def multi_session(args, cfg, sess, device):
     scans = synth.steady_state_scans(sess, 100 + steps)
     handles = []
     for _ in range(ns):
-        g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks, device=device)
+        g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks, device=device, auto_grow=False)
         S.replay(sess, g)
         g.sync()
         handles.append(g)
@@ -684,7 +684,7 @@ def cpu_baseline(args, cfg, sess, st, device):
         o.handle_observation(t, ob)
         poses.append(o.mu()[:3].copy())
     t_struct = (time.perf_counter() - t0) / ns
-    g2 = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks, device=device)
+    g2 = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks, device=device, auto_grow=False)
     g2.set_state(st.time, st.mu, st.sigma, vt)
     err2 = []
     for (t, ob), po in zip(all_scans[:ns], poses):

@@ -31,7 +31,8 @@ public:
     {
         const int rc = rekf_create(&opt, max_landmarks, device, &h_);
         if (rc != REKF_OK) throw Error(rc, "rekf_create");
-        if (auto_grow) rekf_set_auto_grow(h_, 1);
+        const int rg = rekf_set_auto_grow(h_, auto_grow ? 1 : 0);
+        if (rg != REKF_OK) { rekf_destroy(h_); h_ = nullptr; throw Error(rg, "rekf_set_auto_grow"); }
     }
     ~EkfSlam() { rekf_destroy(h_); }
     EkfSlam(const EkfSlam &) = delete;

@@ -97,7 +97,10 @@ void rekf_destroy(rekf_t *h);
  * leading dimension, one strided device-to-device copy of the n x n covariance, old buffers freed; no-op when the
  * capacity already suffices).  Synchronises.  With rekf_set_auto_grow(h, 1) HandleObservationMessage calls it itself
  * (capacity doubling) whenever a scan COULD overflow the capacity -- it then first waits for the exact n -- so that no
- * reflector is ever dropped and REKF_FLAGBIT_CAPACITY never fires; off by default (fixed capacity, sticky flag). */
+ * reflector is ever dropped and REKF_FLAGBIT_CAPACITY never fires.  At THIS level it is off until switched on (a handle fresh from
+ * rekf_create has a fixed capacity and the sticky flag); every wrapper shipped with the library -- the C++ EkfSlam / adapter classes,
+ * the Python ReflectorEKFSLAM, the replay node -- switches it on by default, because that is the reference's behaviour (max_landmarks
+ * is then the INITIAL capacity), and takes auto_grow = false for a fixed one. */
 int rekf_reserve(rekf_t *h, int new_max_landmarks);
 int rekf_set_auto_grow(rekf_t *h, int on);
 int rekf_get_capacity(rekf_t *h, int *max_landmarks);
@@ -181,46 +184,16 @@ int rekf_sync(rekf_t *h);
  * Synchronises. */
 int rekf_get_flags(rekf_t *h, int *flags);
 
-/* ---- measurement hooks (bench.py, rocprof cross-checks) -------------------- */
-enum {
-    REKF_K_PREDICT = 0,   /* (never recorded since ABI 4: odometry messages launch nothing) */
-    REKF_K_FRONT = 1,     /* predict + ReflectorMatch + H rows       */
-    REKF_K_GATHER = 2,    /* (round 1's separate kernels; never recorded since k_mid fused them) */
-    REKF_K_SOLVE = 3,
-    REKF_K_GAIN = 4,
-    REKF_K_DOWNDATE = 5,  /* P -= K (H P)  (the roofline kernel)     */
-    REKF_K_AUGMENT = 6,   /* new landmarks                           */
-    REKF_K_EMPTY = 7,     /* an event pair around nothing: the bracket's own cost, in situ */
-    REKF_K_UPDATE = 8,    /* ONE bracket around the whole HandleObservationMessage chain (per-update latency);
-                           * its individual readings are kept, see rekf_profile_samples */
-    REKF_K_MID = 9,       /* gather + solve + gain in one launch: W = P H^T, (H P)^T, S^-1, K = W S^-1, mu += K dz */
-    REKF_K_COUNT = 10
-};
-/* When on, kernel launches are bracketed by hipEvents on the handle's stream: `on` is a bit mask
- * over the REKF_K_* ids (1 << id); -1 = all.  Brackets perturb the stream (each costs a few
- * microseconds of command-processor time), so measure one kernel at a time for absolute numbers. */
-int rekf_profile_enable(rekf_t *h, int on);
-/* Sum (microseconds) and count of the recorded launches of kernel k since the
- * last rekf_profile_reset.  Synchronises. */
-int rekf_profile_read(rekf_t *h, int k, double *total_us, long *count);
-int rekf_profile_reset(rekf_t *h);
-/* The individual REKF_K_UPDATE readings (microseconds, in call order) since the last reset: up to cap values
- * into out_us, *count = how many exist.  For the median / p99 per-update latency of SURVEY 8(d).  Synchronises. */
-int rekf_profile_samples(rekf_t *h, float *out_us, long cap, long *count);
-/* The hipStream_t of the handle (as void*), for callers that record their own events. */
+/* The hipStream_t of the handle (as void*), for callers that enqueue their own work behind the filter's. */
 void *rekf_stream(rekf_t *h);
 /* Leading dimension (doubles) of the device covariance (lower triangle valid, see Conventions) and its device pointer; mu_dev is the CURRENT mean buffer (the
- * mean is double-buffered: every update flips between two buffers).  Predicts the host has applied to its mirror but not
- * yet to the device (see Conventions) are NOT in these buffers until the next scan or rekf_get_state. */
+ * mean is double-buffered: every update flips between two buffers).  Enqueues whatever is held back or pending -- the last scan's
+ * downdate / augmentation and the predicts the host has applied to its pose mirror only -- so that the buffers, once the stream has
+ * drained (rekf_sync), hold the very state the getters return. */
 int rekf_device_layout(rekf_t *h, int *ld, int *n_max, void **P_dev, void **mu_dev);
 
-/* Measurement hook: time `reps` back-to-back launches of the covariance downdate (kernel = REKF_K_DOWNDATE) on the
- * panels left by the last observation, between ONE hipEvent pair; the filter state is not meaningful afterwards
- * (snapshot / restore it with rekf_get_state / rekf_set_state).  `ablate` must be 0 (reserved). */
-int rekf_debug_time_kernel(rekf_t *h, int kernel, int reps, int ablate, double *avg_us);
-
-/* Debug builds (-DREKF_DEBUG_TIMING) let kernels drop cycle counters here; zeros otherwise. */
-int rekf_debug_counters(rekf_t *h, long long out32[32]);
+/* Measurement hooks (per-kernel hipEvent brackets, kernel timing, debug counters, fault injection) live in rekf_debug.h: they are
+ * for bench.py, the profiling scripts and the tests, not part of the drop-in surface. */
 
 const char *rekf_strerror(int code);
 const char *rekf_last_hip_error(rekf_t *h);

@@ -1,0 +1,57 @@
+/*
+ * rekf_debug.h -- measurement and test hooks of librekf.so (bench.py, scripts/, tests/).  NOT part of the drop-in boundary
+ * (include/rekf.h): nothing a replacement of ekf::ReflectorEKFSLAMInterface needs is declared here.
+ */
+#ifndef REKF_DEBUG_H_
+#define REKF_DEBUG_H_
+
+#include "rekf.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    REKF_K_PREDICT = 0,   /* (never recorded since ABI 4: odometry messages launch nothing) */
+    REKF_K_FRONT = 1,     /* predict + ReflectorMatch + H rows       */
+    REKF_K_GATHER = 2,    /* (round 1's separate kernels; never recorded since k_mid fused them) */
+    REKF_K_SOLVE = 3,
+    REKF_K_GAIN = 4,
+    REKF_K_DOWNDATE = 5,  /* P -= K (H P)  (the roofline kernel)     */
+    REKF_K_AUGMENT = 6,   /* new landmarks                           */
+    REKF_K_EMPTY = 7,     /* an event pair around nothing: the bracket's own cost, in situ */
+    REKF_K_UPDATE = 8,    /* ONE bracket around the whole HandleObservationMessage chain (per-update latency);
+                           * its individual readings are kept, see rekf_profile_samples */
+    REKF_K_MID = 9,       /* gather + solve + gain in one launch: W = P H^T, (H P)^T, S^-1, K = W S^-1, mu += K dz */
+    REKF_K_COUNT = 10
+};
+/* When on, kernel launches are bracketed by hipEvents on the handle's stream: `on` is a bit mask
+ * over the REKF_K_* ids (1 << id); -1 = all.  Brackets perturb the stream (each costs a few
+ * microseconds of command-processor time), so measure one kernel at a time for absolute numbers. */
+int rekf_profile_enable(rekf_t *h, int on);
+/* Sum (microseconds) and count of the recorded launches of kernel k since the
+ * last rekf_profile_reset.  Synchronises. */
+int rekf_profile_read(rekf_t *h, int k, double *total_us, long *count);
+int rekf_profile_reset(rekf_t *h);
+/* The individual REKF_K_UPDATE readings (microseconds, in call order) since the last reset: up to cap values
+ * into out_us, *count = how many exist.  For the median / p99 per-update latency of SURVEY 8(d).  Synchronises. */
+int rekf_profile_samples(rekf_t *h, float *out_us, long cap, long *count);
+
+/* Time `reps` back-to-back launches of the covariance downdate (kernel = REKF_K_DOWNDATE) on the
+ * panels left by the last observation, between ONE hipEvent pair; the filter state is not meaningful afterwards
+ * (snapshot / restore it with rekf_get_state / rekf_set_state).  `ablate` must be 0 (reserved). */
+int rekf_debug_time_kernel(rekf_t *h, int kernel, int reps, int ablate, double *avg_us);
+
+/* Debug builds (-DREKF_DEBUG_TIMING) let kernels drop cycle counters here; zeros otherwise. */
+int rekf_debug_counters(rekf_t *h, long long out32[32]);
+
+/* Fault injection (tests): the NEXT rekf_handle_observation fails with REKF_ERR_HIP at `stage` as if a HIP call had:
+ *   1 = while staging a wide scan's observations, 2 = while enqueueing the held-back downdate, 3 = at the launch check behind the
+ * chain (the kernels HAVE been enqueued).  The contract under test: the state stays valid -- after stages 1 and 2 the scan was not
+ * applied at all (hand it over again), after stage 3 it was. */
+int rekf_debug_inject_failure(rekf_t *h, int stage);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REKF_DEBUG_H_ */

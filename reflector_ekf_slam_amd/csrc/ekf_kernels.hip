@@ -36,6 +36,7 @@
 #include "ekf_dev.h"
 
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -134,20 +135,12 @@ __device__ static void host_slot_store(RekfHostSlot *p, double v, int seq, int a
 // write-through (agent scope) stores for what the NEXT kernel reads from other XCDs: see DD_STORE at k_downdate2
 __device__ static inline void store_wt(double *p, double v)
 {
-#ifdef REKF_EXP_PLAIN_PANEL_STORES
-    *p = v;
-#else
     asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-#endif
 }
 typedef double rekf_v2d __attribute__((ext_vector_type(2)));
 __device__ static inline void store_wt2(double *p, rekf_v2d v)
 {
-#ifdef REKF_EXP_PLAIN_PANEL_STORES
-    *(rekf_v2d *)p = v;
-#else
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-#endif
 }
 __global__ __launch_bounds__(1024) void k_apply_predict(RekfDev d, RekfFrontArgs A)
 {
@@ -1437,24 +1430,14 @@ template <int N> __device__ static inline void dd_wait_vmcnt()
 // The P tiles are stored WRITE-THROUGH at agent scope (sc1): a kernel ends when its dirty lines have left the L2s (each XCD has its
 // own; the next kernel's workgroups read these tiles from other XCDs), and with plain write-back stores most of the 17 MB this kernel
 // writes was still in the L2s at its end.  Written through as they are produced, under the MFMA loops: 11.9 -> 10.7 us back to back,
-// 35.7 -> 35.0 us per update (A/B in one session; non-temporal stores: 11.5 / 35.2).  -DREKF_EXP_PLAIN_STORES / _NT_STORES for A/B builds.
+// 35.7 -> 35.0 us per update (A/B in one session; non-temporal stores: 11.5 / 35.2; profiles/r03_downdate_experiments.txt).
 // ... and the tiles are READ non-temporally: every tile is read exactly once, by one workgroup -- it need not push the panels (which
-// several workgroups share) out of the L2 (34.4 -> 34.1 us per update).  -DREKF_EXP_PLAIN_LOADS for A/B builds.
-#ifdef REKF_EXP_PLAIN_LOADS
-#define DD_LOAD(p) (*(p))
-#else
+// several workgroups share) out of the L2 (34.4 -> 34.1 us per update).
 #define DD_LOAD(p) __builtin_nontemporal_load(p)
-#endif
-#ifdef REKF_EXP_NT_STORES
-#define DD_STORE(p, v) __builtin_nontemporal_store((v), (p))
-#elif defined(REKF_EXP_PLAIN_STORES)
-#define DD_STORE(p, v) (*(p) = (v))
-#else
 // (s_nop: the hazard recogniser does not see into the asm -- a VALU write to the data registers of a 128-bit store needs wait states
 // behind it, and the registers here are often temporaries the compiler refills at once: without them the tiles came out corrupted)
 __device__ static inline void dd_store_sc1(v2d *p, v2d v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory"); }
 #define DD_STORE(p, v) dd_store_sc1((p), (v))
-#endif
 // LOWER TRIANGLE ONLY (round 3).  The update K (H P) = P H^T S^-1 H P is symmetric and the filter stores P as its lower triangle
 // (element (i, j) is valid iff i >= j; the memory above the diagonal is never read by any kernel -- ekf_dev.h): only the tiles on and
 // below the diagonal are computed, read and written: half the MFMA work, half the P reads AND half the P writes of the full
@@ -2169,7 +2152,11 @@ static void launch_downdate_any(const RekfDev &d, int n_ub, hipStream_t s, const
     // more than 64 KiB of dynamic LDS and the CU count are per DEVICE: a process may hold handles on several GPUs.
     constexpr int MAX_DEV = 64;
     static int n_cu_of[MAX_DEV] = {0};
-    static unsigned attr_done[MAX_DEV] = {0};         // bit KC/16 : k_downdate2<KC> has its LDS opt-in on this device
+    static unsigned attr_done[MAX_DEV] = {0};         // bit KC/16 : k_downdate2<KC> / k_dd_front<KC> have their LDS opt-in on this device
+    // handles are independent (multi-session servers drive them from several host threads) but this cache is per process: the lock
+    // is held across the launch, so that no thread launches a variant before the thread that first needed it has opted it in
+    static std::mutex cache_mu;
+    std::lock_guard<std::mutex> guard(cache_mu);
     int dev = 0;
     (void)hipGetDevice(&dev);
     const int slot = (dev >= 0 && dev < MAX_DEV) ? dev : 0;

@@ -7,6 +7,7 @@
 // size that depends on device results (n, m, the match lists) stays on the
 // device so no call here waits for the GPU except the getters.
 #include "../../include/rekf.h"
+#include "../../include/rekf_debug.h"
 #include "ekf_dev.h"
 
 #include <algorithm>
@@ -16,6 +17,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 static_assert(REKF_MAX_OBS == REKF_MAX_OBS_WIDE, "host/device observation capacity mismatch");
@@ -83,6 +85,7 @@ struct rekf {
     RekfCtl *ctl_staging;      // pinned copy of the control block
     std::string hip_error;
     int flags_seen = 0;        // sticky device flags already reported on stderr
+    int inject_failure = 0;    // rekf_debug_inject_failure: the next HandleObservationMessage fails at this stage
     double *dev_ell;           // device scratch for k_ellipses (5 doubles per landmark of capacity)
     double *dev_pred;          // device scratch for k_predict_rows (4 * ld + 12 doubles)
     float *dev_obs = nullptr;  // a wide scan's observations (REKF_MAX_OBS_WIDE x 2 floats)
@@ -114,8 +117,10 @@ namespace {
 
 int round_up(int x, int q) { return (x + q - 1) / q * q; }
 
-// wait until the `count` slots from `first` carry `seq` (a kernel on the handle's stream stores them).  Falls back to a stream
-// synchronisation when the stream drains without them (an earlier kernel failed) and gives up after five seconds.
+// wait until the `count` slots from `first` carry `seq` (a kernel on the handle's stream stores them).  Polls with a pause; when
+// the stream drains without them, or after two seconds of polling (a shared or oversubscribed GPU, a profiler, a debugger: the
+// kernel is merely slow), it waits for the stream instead and looks once more -- only a stream that HAS drained without the
+// slots is an error.
 template <class H> int wait_slots(H *h, int first, int count, int seq)
 {
     const auto t0 = std::chrono::steady_clock::now();
@@ -123,17 +128,16 @@ template <class H> int wait_slots(H *h, int first, int count, int seq)
     for (int k = first; k < first + count; ++k) {
         const int *tag = &h->host_slots[k].seq;
         while (__atomic_load_n(tag, __ATOMIC_ACQUIRE) != seq) {
-            if ((++spins & 0xfffffu) == 0) {
-                if (hipStreamQuery(h->stream) != hipErrorNotReady) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xffffu) == 0) {
+                const bool drained = hipStreamQuery(h->stream) != hipErrorNotReady;
+                if (drained || std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
                     HIP_TRY(h, hipStreamSynchronize(h->stream));
                     if (__atomic_load_n(tag, __ATOMIC_ACQUIRE) == seq) break;
                     h->hip_error = "a pose kernel finished without publishing its result";
                     return REKF_ERR_HIP;
                 }
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
-                    h->hip_error = "no pose result after 5 s";
-                    return REKF_ERR_HIP;
-                }
+                if ((spins & 0xfffffu) == 0) std::this_thread::yield();
             }
         }
     }
@@ -628,12 +632,34 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
             if (rc != REKF_OK && rc != REKF_ERR_UNSUPPORTED) return rc;     // (too large to address: fall back to the capacity flag)
         }
     }
+    // ---- everything that can FAIL comes first, so that a failing call leaves the handle exactly as it found it: the host's counters
+    // (scan parity, front-end target, growth bound, publisher tags), the pose mirror and the time all move only once nothing but
+    // kernel launches is left (the ABI's promise: an error code, and the state stays valid -- hand the scan over again)
+    ProfScope upd(h, REKF_K_UPDATE);                  // one bracket around the whole chain (per-update latency)
+    if (h->inject_failure == 1) { h->inject_failure = 0; h->hip_error = "injected failure (staging)"; return REKF_ERR_HIP; }
+    if (staged) {                                     // the scan does not fit the launch packet: through a pinned staging buffer into HBM
+        if (h->obs_staging_busy) HIP_TRY(h, hipEventSynchronize(h->obs_staging_ev));   // the previous wide scan's copy (long done)
+        std::memcpy(h->obs_staging, xy, sizeof(float) * 2 * (size_t)K);                 // the caller's buffer is free when we return
+        HIP_TRY(h, hipMemcpyAsync(h->dev_obs, h->obs_staging, sizeof(float) * 2 * (size_t)K, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipEventRecord(h->obs_staging_ev, h->stream));
+        h->obs_staging_busy = true;
+    }
+    // the previous scan's downdate and this scan's front end go out as ONE launch (k_dd_front) when the caller has not read the pose
+    // since (a read-back enqueues the downdate: nothing is pending then; the mirror test is belt and braces); else it goes out first
+    const bool with_dd = h->dd_pending && !h->mir_valid;
+    if (!with_dd) {
+        if (h->inject_failure == 2) { h->inject_failure = 0; h->hip_error = "injected failure (held-back downdate)"; return REKF_ERR_HIP; }
+        int rcf = flush_dd(h);
+        if (rcf != REKF_OK) return rcf;
+    }
+    // ---- from here on: host bookkeeping and launches only
     h->last_scan_empty = false;
     RekfFrontArgs a;
     fill_front_args(h, a, t - h->time);               // cc:232 (dt may be negative, Q8)
     a.is_obs = 1;
     a.K = K;
     if (!staged) std::memcpy(a.obs, xy, sizeof(float) * 2 * (size_t)K);
+    else a.obs_ext = h->dev_obs;
     if (gps_pose3) {
         a.has_gps = 1;
         a.gps[0] = gps_pose3[0]; a.gps[1] = gps_pose3[1]; a.gps[2] = gps_pose3[2];
@@ -657,32 +683,19 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     a.front_target = h->front_total;
     a.compact_in_front = blocks ? 0 : 1;
     h->dev.pred_slot = -1;
-    ProfScope upd(h, REKF_K_UPDATE);                  // one bracket around the whole chain (per-update latency)
     h->dev.kc_ub = round_up(2 * K + (gps_pose3 ? 3 : 0), 16);
-    if (staged) {                                     // the scan does not fit the launch packet: through a pinned staging buffer into HBM
-        if (h->obs_staging_busy) HIP_TRY(h, hipEventSynchronize(h->obs_staging_ev));   // the previous wide scan's copy (long done)
-        std::memcpy(h->obs_staging, xy, sizeof(float) * 2 * (size_t)K);                 // the caller's buffer is free when we return
-        HIP_TRY(h, hipMemcpyAsync(h->dev_obs, h->obs_staging, sizeof(float) * 2 * (size_t)K, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipEventRecord(h->obs_staging_ev, h->stream));
-        h->obs_staging_busy = true;
-        a.obs_ext = h->dev_obs;
-    }
     // one kernel of the call publishes pose, pose block, flags and the n the state will have once the k_augment behind the chain has run
     // (which changes none of the others): k_mid, or the first workgroup of the call's last downdate (struct rekf: WHO PUBLISHES)
     const bool aug = !h->full;
     if (aug) h->cum_growth += 2 * K;
     const int pub_seq = new_publisher(h);
-    if (h->dd_pending && !a.host_pred) {
-        // the previous scan's downdate and this scan's front end as ONE launch (k_dd_front).  (host_pred means the caller has read the
-        // pose since the last scan -- which enqueued the downdate: nothing is pending then; the test is belt and braces)
+    if (with_dd) {
         h->dd_pending = false;
         a.aug_pending = h->dd_aug ? 1 : 0;
         { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_dd_front(h->dd_dev, h->dd_n_ub, h->dev, a, h->stream); }
         if (h->dd_aug) { ProfScope ps(h, REKF_K_AUGMENT); rekf_launch_augment(h->dd_dev, h->dd_aug_args, h->stream); h->dd_aug = false; }
         a.aug_pending = 0;
     } else {
-        int rcf = flush_dd(h);
-        if (rcf != REKF_OK) return rcf;
         ProfScope ps(h, REKF_K_FRONT);
         rekf_launch_front_mb(h->dev, a, h->n_ub, h->stream);
     }
@@ -693,6 +706,7 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     // lazy downdate (struct rekf): the scan's last downdate -- and its k_augment -- go out with the next call.  (Not for a staged scan:
     // its k_augment reads the observations from a device buffer the next staged scan overwrites.)
     const bool hold_back = h->lazy_dd && !staged;
+    hipError_t enq_err = hipSuccess;
     const bool early_pub = h->pose_read_since_scan;   // (struct rekf: WHO PUBLISHES)
     h->pose_read_since_scan = false;
     auto downdate = [&](bool first, bool last) {
@@ -712,7 +726,7 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         a.pair_stride = stride;
         h->dev.kc_ub = 64;
         rekf_launch_compact_wide(h->dev, a, h->stream);
-        HIP_TRY(h, hipMemcpyAsync(h->dev_mu_lin, h->dev.mu, sizeof(double) * (size_t)h->dev.ld, hipMemcpyDeviceToDevice, h->stream));
+        enq_err = hipMemcpyAsync(h->dev_mu_lin, h->dev.mu, sizeof(double) * (size_t)h->dev.ld, hipMemcpyDeviceToDevice, h->stream);   // (checked behind the chain)
         for (int p0 = 0; p0 < K; p0 += stride) {
             a.pair0 = p0;
             a.apply_pred = (p0 == 0) ? 1 : 0;
@@ -757,7 +771,22 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         h->n_ub = grown > h->dev.n_max ? h->dev.n_max : grown;
         h->n_exact = false;
     }
-    HIP_TRY(h, hipGetLastError());
+    hipError_t le = hipGetLastError();
+    if (le == hipSuccess) le = enq_err;
+    if (h->inject_failure == 3) { h->inject_failure = 0; le = hipErrorLaunchFailure; }
+    if (le != hipSuccess) {
+        // a launch was refused: which kernels of the chain run is no longer what the host planned.  Let the stream drain and take the
+        // counters the kernels keep (n, the front end's count) from the device, so that the next scan starts from what really happened
+        h->hip_error = std::string("kernel launch: ") + hipGetErrorString(le);
+        (void)hipStreamSynchronize(h->stream);
+        if (hipMemcpy(h->ctl_staging, h->dev.ctl, sizeof(RekfCtl), hipMemcpyDeviceToHost) == hipSuccess) {
+            h->front_total = h->ctl_staging->front_count;
+            h->n_ub = h->ctl_staging->n; h->n_exact = true; h->full = h->n_ub >= h->dev.n_max;
+        }
+        (void)hipGetLastError();
+        h->pub_valid = false; h->mir_valid = false;
+        return REKF_ERR_HIP;
+    }
     return REKF_OK;
 }
 
@@ -907,6 +936,8 @@ int rekf_sync(rekf_t *h)
 {
     if (!h) return REKF_ERR_INVALID;
     int rc = refresh_mirror(h);
+    if (rc != REKF_OK) return rc;
+    rc = flush_lazy(h);                                // predicts the host applied to its mirror only: the device state catches up (one small kernel, only when pending)
     if (rc != REKF_OK) return rc;
     // the published pose can arrive a few microseconds before the last workgroups of k_downdate2 are through: Sync means done
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1062,10 +1093,18 @@ int rekf_debug_counters(rekf_t *h, long long out8[32])
     return REKF_OK;
 }
 
+int rekf_debug_inject_failure(rekf_t *h, int stage)
+{
+    if (!h || stage < 0 || stage > 3) return REKF_ERR_INVALID;
+    h->inject_failure = stage;
+    return REKF_OK;
+}
+
 int rekf_device_layout(rekf_t *h, int *ld, int *n_max, void **P_dev, void **mu_dev)
 {
     if (!h) return REKF_ERR_INVALID;
-    { int rcf = flush_dd(h); if (rcf != REKF_OK) return rcf; }      // (the caller is about to look at P)
+    // the caller is about to look at P / mu: the held-back downdate AND the predicts the host has applied to its mirror only go out
+    { int rcf = flush_lazy(h); if (rcf != REKF_OK) return rcf; }
     if (ld) *ld = h->dev.ld;
     if (n_max) *n_max = h->dev.n_max;
     if (P_dev) *P_dev = h->dev.P;

@@ -141,7 +141,7 @@ def save_map_txt(path: str, state: State, loaded: Map | None = None, reference_b
 class ReflectorEKFSLAM:
     """ekf::ReflectorEKFSLAM (reflector_ekf_slam.h:13-64) on one MI355X."""
 
-    def __init__(self, options: EKFOptions, max_landmarks: int = 1024, device: int = 0, auto_grow: bool = False):
+    def __init__(self, options: EKFOptions, max_landmarks: int = 1024, device: int = 0, auto_grow: bool = True):
         self._L = _lib.rekf()
         self.options = options
         o = _lib.RekfOptions()
@@ -159,8 +159,10 @@ class ReflectorEKFSLAM:
             raise RekfError(rc, "rekf_create")
         self._h = h
         self._cap0 = int(max_landmarks)
-        if auto_grow:
-            self.set_auto_grow(True)
+        # max_landmarks is the INITIAL capacity: like the reference (which resizes on every augment and never drops a reflector,
+        # cc:316-363) the filter grows on demand -- the default of every wrapper (C++ EkfSlam, node_replay, this class); pass
+        # auto_grow=False for a fixed capacity (overflow = sticky REKF_FLAGBIT_CAPACITY, the extra reflectors dropped)
+        self.set_auto_grow(bool(auto_grow))
         self._map = load_map_txt(options.map_path)          # cc:36
         if self._map.reflector_map_.shape[0] > 0:
             self.SetGlobalMap(self._map)
@@ -368,6 +370,10 @@ class ReflectorEKFSLAM:
         self._chk(self._L.rekf_profile_samples(self._h, out.ctypes.data_as(C.c_void_p), cnt.value, C.byref(cnt)),
                   "profile_samples")
         return out[: cnt.value].astype(np.float64)
+
+    def inject_failure(self, stage: int):
+        """Test hook (include/rekf_debug.h): the next HandleObservationMessage fails at `stage` as if a HIP call had."""
+        self._chk(self._L.rekf_debug_inject_failure(self._h, int(stage)), "rekf_debug_inject_failure")
 
     def time_kernel(self, name: str, reps: int = 200, ablate: int = 0) -> float:
         """Average device time (us) of `reps` back-to-back launches of one kernel of the chain between ONE

@@ -10,7 +10,7 @@ import numpy as np
 from reflector_ekf_slam_amd import synth, session as S, ReflectorEKFSLAM
 cfg = synth.C3
 sess = synth.make_session(cfg)
-g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks)
+g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks, auto_grow=False)
 S.replay(sess, g); g.sync()
 st = g.GetState()
 np.savez("/tmp/c3_state.npz", t=st.time, mu=st.mu, sigma=st.sigma)
@@ -26,7 +26,7 @@ from reflector_ekf_slam_amd import synth, session as S, ReflectorEKFSLAM
 cfg = synth.C3
 sess = synth.make_session(cfg)
 z = np.load("/tmp/c3_state.npz")
-g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks)
+g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks, auto_grow=False)
 g.set_state(float(z["t"]), z["mu"], z["sigma"], (0.0, 0.0, 0.0))
 scans = synth.steady_state_scans(sess, 1200)
 for t, ob in scans[:100]:

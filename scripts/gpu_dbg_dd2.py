@@ -6,7 +6,7 @@ from reflector_ekf_slam_amd import synth, session as S, ReflectorEKFSLAM, _lib
 name = sys.argv[1] if len(sys.argv) > 1 else "C3"
 cfg = getattr(synth, name)
 sess = synth.make_session(cfg)
-g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks)
+g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks, auto_grow=False)
 S.replay(sess, g); g.sync()
 L = _lib.rekf(); L.rekf_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 for rep in range(3):

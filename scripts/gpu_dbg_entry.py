@@ -13,7 +13,7 @@ _lib.lib_path = lambda name, _p=path: _p if name == "librekf.so" else __import__
 from reflector_ekf_slam_amd import synth, session as S, ReflectorEKFSLAM
 cfg = synth.C3
 sess = synth.make_session(cfg)
-g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks)
+g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks, auto_grow=False)
 S.replay(sess, g); g.sync()
 L = _lib.rekf()
 L.rekf_debug_dd_times.argtypes = [C.c_void_p, C.c_int]

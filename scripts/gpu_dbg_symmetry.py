@@ -7,7 +7,7 @@ import numpy as np
 from reflector_ekf_slam_amd import ReflectorEKFSLAM, synth, session as S
 cfg = synth.C3
 sess = synth.make_session(cfg)
-g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks)
+g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks, auto_grow=False)
 state = {"last": None}
 def on_scan(e, k):
     try:

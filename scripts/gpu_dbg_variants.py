@@ -11,7 +11,7 @@ import numpy as np
 from reflector_ekf_slam_amd import synth, session as S, ReflectorEKFSLAM
 cfg = synth.C3
 sess = synth.make_session(cfg)
-g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks)
+g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks, auto_grow=False)
 S.replay(sess, g); g.sync()
 st = g.GetState()
 np.savez("/tmp/c3_state.npz", t=st.time, mu=st.mu, sigma=st.sigma)
@@ -27,7 +27,7 @@ from reflector_ekf_slam_amd import synth, session as S, ReflectorEKFSLAM
 cfg = synth.C3
 sess = synth.make_session(cfg)
 z = np.load("/tmp/c3_state.npz")
-g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks)
+g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks, auto_grow=False)
 g.set_state(float(z["t"]), z["mu"], z["sigma"], (0.0, 0.0, 0.0))
 L = _lib.rekf(); L.rekf_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 scans = synth.steady_state_scans(sess, 1300)

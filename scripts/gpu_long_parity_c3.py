@@ -11,7 +11,7 @@ from tests.helpers import norm_match
 n_upd = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 cfg = synth.C3
 sess = synth.make_session(cfg)
-g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks)
+g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks, auto_grow=False)
 S.replay(sess, g); g.sync()
 st = g.GetState()
 o = OracleEKF(cfg.odom_model, sess.init_time, sess.init_pose, cfg.sigma_v ** 2, cfg.sigma_w ** 2, cfg.sigma_obs ** 2)

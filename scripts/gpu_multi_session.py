@@ -11,7 +11,7 @@ scans = synth.steady_state_scans(sess, steps + 100)
 for nsess in (1, 2, 3, 4, 6, 8):
     gs = []
     for _ in range(nsess):
-        g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks)
+        g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks, auto_grow=False)
         S.replay(sess, g); g.sync()
         gs.append(g)
     for t, ob in scans[:100]:

@@ -27,7 +27,7 @@ def make_gpu(odom_model, init_time, init_pose, lin, ang, obs, max_landmarks):
     opt = EKFOptions(use_imu=False, init_time=float(init_time), init_pose=tuple(float(v) for v in init_pose),
                      odom_model=int(odom_model), linear_velocity_cov=float(lin), angular_velocity_cov=float(ang),
                      observation_cov=float(obs))
-    return ReflectorEKFSLAM(opt, max_landmarks=max_landmarks, device=0)
+    return ReflectorEKFSLAM(opt, max_landmarks=max_landmarks, device=0, auto_grow=False)
 
 
 def replay_golden(g, filt, check_every=1):

@@ -183,7 +183,7 @@ def test_detector_feeds_the_filter_end_to_end(oracle_lib):
     opt = EKFOptions(init_time=0.0, init_pose=tuple(sess.init_pose), odom_model=cfg.odom_model,
                      linear_velocity_cov=cfg.sigma_v ** 2, angular_velocity_cov=cfg.sigma_w ** 2,
                      observation_cov=cfg.sigma_obs ** 2)
-    fg = ReflectorEKFSLAM(opt, max_landmarks=64)
+    fg = ReflectorEKFSLAM(opt, max_landmarks=64, auto_grow=False)
     fo = OracleEKF(cfg.odom_model, 0.0, sess.init_pose, opt.linear_velocity_cov, opt.angular_velocity_cov,
                    opt.observation_cov)
     first = True
@@ -268,7 +268,7 @@ def test_c4_short_cloud_to_filter_omni(oracle_lib):
     opt = EKFOptions(init_time=0.0, init_pose=tuple(sess.init_pose), odom_model=cfg.odom_model,
                      linear_velocity_cov=cfg.sigma_v ** 2, angular_velocity_cov=cfg.sigma_w ** 2,
                      observation_cov=cfg.sigma_obs ** 2)
-    fg = ReflectorEKFSLAM(opt, max_landmarks=cfg.n_landmarks)
+    fg = ReflectorEKFSLAM(opt, max_landmarks=cfg.n_landmarks, auto_grow=False)
     fo = OracleEKF(cfg.odom_model, 0.0, sess.init_pose, opt.linear_velocity_cov, opt.angular_velocity_cov,
                    opt.observation_cov)
     first = True
@@ -309,7 +309,7 @@ def c4_built():
     opt = EKFOptions(init_time=0.0, init_pose=tuple(sess.init_pose), odom_model=cfg.odom_model,
                      linear_velocity_cov=cfg.sigma_v ** 2, angular_velocity_cov=cfg.sigma_w ** 2,
                      observation_cov=cfg.sigma_obs ** 2)
-    g = ReflectorEKFSLAM(opt, max_landmarks=cfg.n_landmarks)
+    g = ReflectorEKFSLAM(opt, max_landmarks=cfg.n_landmarks, auto_grow=False)
     first, kmax, scans = True, 0, 0
     for e in range(sess.n_events):
         t = sess.ev_time[e]

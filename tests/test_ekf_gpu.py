@@ -376,7 +376,7 @@ def test_predict_state_full_omni_with_landmarks(oracle_lib):
 def test_use_imu_ignores_odometry_like_the_reference():
     """reflector_ekf_slam.cc:213-223: with use_imu the odometry branch is skipped entirely (no vt, no predict, no time)."""
     from reflector_ekf_slam_amd import EKFOptions, ReflectorEKFSLAM
-    g = ReflectorEKFSLAM(EKFOptions(use_imu=True, init_pose=(1.0, 2.0, 0.3)), max_landmarks=4)
+    g = ReflectorEKFSLAM(EKFOptions(use_imu=True, init_pose=(1.0, 2.0, 0.3)), max_landmarks=4, auto_grow=False)
     g.handle_odometry(0.5, 1.0, 0.0, 0.2)
     assert g.GetLatestTime() == 0.0
     t, mu3, s3 = g.pose()

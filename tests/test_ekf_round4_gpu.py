@@ -1,0 +1,138 @@
+"""GPU suite, round 4 additions (through the C ABI, against the CPU oracle):
+  * a failing HandleObservationMessage leaves the handle as it found it (fault injection, include/rekf_debug.h): the scan handed
+    over again gives the oracle's state -- the host's counters (scan parity, front-end target, growth bound, publisher tags),
+    the pose mirror and the time only move once nothing but kernel launches is left;
+  * every wrapper's default is the reference's behaviour: max_landmarks is the INITIAL capacity, no reflector is ever dropped
+    (reflector_ekf_slam.cc:316-363 resizes on every augment);
+  * rekf_device_layout / rekf_sync hand out a device state that includes the predicts the host applied to its pose mirror only.
+Tolerances as in test_ekf_gpu.py: association lists identical, |mu - oracle| < 1e-9 (north star: 1e-5 m)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from reflector_ekf_slam_amd import synth
+from reflector_ekf_slam_amd.ekf_slam import RekfError
+from tests.helpers import make_gpu, make_oracle, norm_match
+
+pytestmark = pytest.mark.gpu
+TIGHT = 1e-9
+
+
+def _same_match(g, o):
+    a, b = norm_match(g.last_match()), norm_match(o.last_match())
+    return all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def _session(L=60, obs=10, seed=4401):
+    cfg = synth.SessionConfig(f"r4_L{L}", L, obs, synth.DIFF, seed=seed, speed=1.2, row_spacing=6.0)
+    return cfg, synth.make_session(cfg)
+
+
+@pytest.mark.parametrize("readback", [False, True], ids=["pipelined", "pose_read_back"])
+def test_a_failing_scan_leaves_the_handle_as_it_found_it(oracle_lib, readback):
+    """Stages 1 (staging a wide scan) and 2 (enqueueing the held-back downdate) fail BEFORE anything of the handle has moved: the
+    call returns REKF_ERR_HIP, the same scan handed over again is applied once, and the session ends on the oracle's state.  Stage
+    3 fails at the launch check BEHIND the chain: the scan has been applied, the handle resynchronises with the device."""
+    cfg, sess = _session()
+    lin, ang, ob2 = cfg.sigma_v ** 2, cfg.sigma_w ** 2, cfg.sigma_obs ** 2
+    g = make_gpu(cfg.odom_model, sess.init_time, sess.init_pose, lin, ang, ob2, cfg.n_landmarks)
+    o = make_oracle(cfg.odom_model, sess.init_time, sess.init_pose, lin, ang, ob2)
+    first, scans, injected = True, 0, {1: 0, 2: 0, 3: 0}
+    for e in range(sess.n_events):
+        t = sess.ev_time[e]
+        if sess.ev_type[e] == synth.EV_ODOM:
+            g.handle_odometry(t, *sess.odom[e]); o.handle_odometry(t, *sess.odom[e])
+            continue
+        if first:
+            first = False
+            continue
+        ob = sess.obs_of(e)
+        scans += 1
+        stage = {5: 1, 9: 2, 14: 3, 40: 2, 41: 1, 57: 3, 58: 2}.get(scans, 0)
+        if stage:
+            if stage == 2:
+                g.pose()                                 # (a call that sends the held-back downdate out WITH its front end never gets to stage 2)
+            g.inject_failure(stage)
+            with pytest.raises(RekfError) as err:
+                g.handle_observation(t, ob)
+            assert err.value.code == -2
+            injected[stage] += 1
+            if stage != 3:
+                g.handle_observation(t, ob)              # not applied: hand it over again
+        else:
+            g.handle_observation(t, ob)
+        o.handle_observation(t, ob)
+        if readback:
+            _, pg, _ = g.pose()
+            assert np.abs(pg - o.mu()[:3]).max() < TIGHT, f"pose differs at scan {scans}"
+        if scans % 5 == 0 or stage:
+            assert _same_match(g, o), f"association differs at scan {scans}"
+            assert np.abs(g.mu() - o.mu()).max() < TIGHT, f"mean differs at scan {scans}"
+    assert all(v > 0 for v in injected.values()) and g.n == o.n
+    st = g.GetState()
+    mo, Po = o.state()
+    assert np.abs(st.mu - mo).max() < TIGHT and np.abs(st.sigma - Po).max() < 1e-11
+    assert g.sync_code() == 0
+
+
+def test_inject_stage_2_is_armed_until_a_call_reaches_it(oracle_lib):
+    """A call that sends the held-back downdate out together with its own front end (k_dd_front) never reaches stage 2; the
+    injection then stays armed for the first call that does -- here the scan behind a pose read-back."""
+    cfg, sess = _session(L=30, obs=8, seed=4402)
+    lin, ang, ob2 = cfg.sigma_v ** 2, cfg.sigma_w ** 2, cfg.sigma_obs ** 2
+    g = make_gpu(cfg.odom_model, sess.init_time, sess.init_pose, lin, ang, ob2, cfg.n_landmarks)
+    scans = [(sess.ev_time[e], sess.obs_of(e)) for e in range(sess.n_events) if sess.ev_type[e] != synth.EV_ODOM][1:8]
+    g.handle_observation(*scans[0])
+    g.inject_failure(2)
+    g.handle_observation(*scans[1])                      # pipelined: goes out as k_dd_front, stage 2 not reached
+    g.pose()                                             # read-back: the held-back downdate goes out on its own
+    with pytest.raises(RekfError):
+        g.handle_observation(*scans[2])                  # nothing held back, mirror valid -> flush path -> injected
+    g.handle_observation(*scans[2])
+    assert g.sync_code() == 0 and np.isfinite(g.mu()).all()
+
+
+def test_default_wrapper_capacity_grows_like_the_reference(oracle_lib):
+    """ReflectorEKFSLAM() with default arguments: max_landmarks is where the buffers START (every wrapper's default, rekf.h)."""
+    from reflector_ekf_slam_amd import EKFOptions, ReflectorEKFSLAM
+    cfg, sess = _session(L=40, obs=9, seed=4403)
+    lin, ang, ob2 = cfg.sigma_v ** 2, cfg.sigma_w ** 2, cfg.sigma_obs ** 2
+    opt = EKFOptions(use_imu=False, init_time=float(sess.init_time), init_pose=tuple(float(v) for v in sess.init_pose),
+                     odom_model=int(cfg.odom_model), linear_velocity_cov=lin, angular_velocity_cov=ang, observation_cov=ob2)
+    g = ReflectorEKFSLAM(opt, max_landmarks=8)           # far too small on purpose
+    o = make_oracle(cfg.odom_model, sess.init_time, sess.init_pose, lin, ang, ob2)
+    from tests.helpers import drive_pair
+    drive_pair(sess, g, o)
+    assert g.n == o.n == 3 + 2 * 40 and g.flags() == 0 and g.max_landmarks >= 40
+    assert np.abs(g.mu() - o.mu()).max() < TIGHT
+
+
+def test_device_layout_includes_the_predicts_the_host_applied_to_its_mirror(oracle_lib):
+    """Odometry messages launch nothing (host pose mirror).  rekf_device_layout / rekf_sync must still hand raw-pointer users the
+    state the getters return: P's columns 0, 1, the pose block and mu[0..2] with those predicts applied."""
+    cfg, sess = _session(L=20, obs=6, seed=4404)
+    lin, ang, ob2 = cfg.sigma_v ** 2, cfg.sigma_w ** 2, cfg.sigma_obs ** 2
+    g = make_gpu(cfg.odom_model, sess.init_time, sess.init_pose, lin, ang, ob2, cfg.n_landmarks)
+    o = make_oracle(cfg.odom_model, sess.init_time, sess.init_pose, lin, ang, ob2)
+    from tests.helpers import drive_pair
+    drive_pair(sess, g, o, max_events=sess.n_events // 2)
+    t = g.GetLatestTime()
+    for k in range(3):                                   # predicts on the mirror only
+        g.handle_odometry(t + 0.02 * (k + 1), 0.4, 0.0, 0.2); o.handle_odometry(t + 0.02 * (k + 1), 0.4, 0.0, 0.2)
+    ld, nmax, Pp, mup = C.c_int(), C.c_int(), C.c_void_p(), C.c_void_p()
+    assert g._L.rekf_device_layout(g._h, C.byref(ld), C.byref(nmax), C.byref(Pp), C.byref(mup)) == 0
+    assert g.sync_code() == 0
+    n = g.n
+    mu_raw = np.zeros(n)
+    P_raw = np.zeros((ld.value, ld.value))
+    hip = C.CDLL("libamdhip64.so")                       # (already mapped: librekf.so links it)
+    assert hip.hipMemcpy(mu_raw.ctypes.data_as(C.c_void_p), mup, C.c_size_t(8 * n), 2) == 0
+    assert hip.hipMemcpy(P_raw.ctypes.data_as(C.c_void_p), Pp, C.c_size_t(8 * ld.value * ld.value), 2) == 0
+    Pcol = P_raw.reshape(ld.value, ld.value).T            # column-major on the device
+    mo, Po = o.state()
+    assert np.abs(mu_raw - mo).max() < TIGHT
+    low = np.tril_indices(n)
+    assert np.abs(Pcol[:n, :n][low] - Po[low]).max() < 1e-11
+    st = g.GetState()
+    assert np.array_equal(st.mu, mu_raw)
