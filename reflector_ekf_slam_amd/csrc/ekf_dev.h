@@ -69,6 +69,13 @@ struct RekfCtl {
         int newid[64];                // observation indices of the new reflectors
     } rec;
     unsigned front_count;             // observations matched so far, over the life of the handle (never reset)
+    // ---- a scan's landmark augmentation deferred into the NEXT scan's k_mid (round 4): while the state can grow, every scan used to
+    // be followed by a k_augment launch that found nothing to do (2.4 us of kernel boundary per scan).  k_mid's workgroup 0 leaves what
+    // the augmentation needs here -- the state dimension it appends to, the number of new reflectors, their observations -- by scan
+    // parity (the record of scan t is read all through k_mid of scan t + 1, while that kernel's workgroup 0 writes scan t + 1's), and the
+    // next k_mid's workgroup 0 does the appending first thing; the other workgroups wait for aug_done only when there IS something
+    struct AugRec { int n_before, n2; float obs[2 * REKF_MAX_OBS_DEV]; } augrec[2];
+    unsigned aug_done;                // scan id of the last k_mid whose workgroup 0 has appended its predecessor's new reflectors
     long long dbg[32];            // scratch for in-kernel timing experiments (REKF_DEBUG_TIMING builds)
 };
 
@@ -97,6 +104,8 @@ struct RekfFrontArgs {
     int compact_in_front;     // 1: whole scan (K <= 32, one pass of k_mid): the front end leaves RekfCtl::rec; 0: wide scan (k_compact_wide)
     int aug_pending;          // front role inside k_dd_front: the previous scan's k_augment has not run yet -- the state the match sees has
                               // n + 2 n_new rows (the new reflectors' means are there: k_mid writes them)
+    int aug_in_mid;           // k_mid: the previous scan's augmentation has not run: workgroup 0 appends its rows first (RekfCtl::augrec), n = n_before + 2 n2
+    unsigned scan_id;         // running number of the scan (RekfCtl::aug_done)
     int apply_pred;           // k_mid: apply the pending Predict to the gathered P (whole scan or FIRST block step of a wide scan)
     int host_pred;
     double pre_pose[5];       // x, y, theta (wrapped, cc:181/:205), cos(theta), sin(theta) of the WRAPPED heading as the reference takes them (cc:252-253)

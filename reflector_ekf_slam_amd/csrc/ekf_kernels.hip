@@ -739,6 +739,73 @@ __global__ __launch_bounds__(REKF_MAX_OBS_WIDE) void k_compact_wide(RekfDev d, R
 }
 
 // ----------------------------------------------------------------------------
+// Landmark augmentation (cc:311-364), the covariance rows of a scan's new reflectors: by k_augment (one workgroup, behind the
+// scan's downdate) or by workgroup 0 of the NEXT scan's k_mid (RekfCtl::augrec).
+// ----------------------------------------------------------------------------
+// The rows: every thread of the calling workgroup (nt of them).  Gp [N2][6], Sxi [9], RQR [4] are the caller's LDS; obs(k, rx, ry)
+// yields the k-th new reflector's observation.  Ends on a workgroup barrier; the caller commits n.
+template <class Obs>
+__device__ static inline void augment_rows(const RekfDev &d, int n, int N2, double obs_cov, double (*Gp)[6], double *Sxi, double *RQR, int nt, Obs &&obs)
+{
+    const int tid = threadIdx.x;
+    const size_t ld = (size_t)d.ld;
+    double *P = d.P;
+    {
+#pragma clang fp contract(off)
+        const double th = d.mu[2];
+        const double s = sin(th), c = cos(th);                      // cc:323-324
+        if (tid < N2) {
+            // (the means of the new reflectors, cc:341-342, are already there: k_mid's workgroup 0 writes them behind its pose commit)
+            float fx, fy;
+            obs(tid, fx, fy);                                       // cc:338
+            const double rx = (double)fx, ry = (double)fy;
+            Gp[tid][0] = 1.; Gp[tid][1] = 0.; Gp[tid][2] = -rx * s - ry * c;   // cc:347
+            Gp[tid][3] = 0.; Gp[tid][4] = 1.; Gp[tid][5] = rx * c - ry * s;
+        }
+        if (tid == 0) {
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) Sxi[i * 3 + j] = rekf_plower(P, (int)ld, i, j);   // cc:322
+            const double q = obs_cov;                               // Gz Qt Gz^T, Gz = R(theta) (cc:326,354)
+            RQR[0] = c * q * c + (-s) * q * (-s); RQR[1] = c * q * s + (-s) * q * c;
+            RQR[2] = s * q * c + c * q * (-s);    RQR[3] = s * q * s + c * q * c;
+        }
+    }
+    __syncthreads();
+    // sigma_mx = G_fx * sigma (cc:355-357): rows n+2a+rr, all old columns (below the diagonal: the only copy that is stored);
+    // sigma(0..2, col) is read as sigma(col, 0..2) -- the coalesced columns
+    for (int e = tid; e < n * N2; e += nt) {
+#pragma clang fp contract(off)
+        const int a = e / n, col = e - a * n;
+        const double q0 = rekf_plower(P, (int)ld, col, 0), q1 = rekf_plower(P, (int)ld, col, 1), q2 = rekf_plower(P, (int)ld, col, 2);
+        for (int rr = 0; rr < 2; ++rr) {
+            double acc = 0;
+            acc += Gp[a][rr * 3 + 0] * q0;
+            acc += Gp[a][rr * 3 + 1] * q1;
+            acc += Gp[a][rr * 3 + 2] * q2;
+            P[(size_t)(n + 2 * a + rr) + (size_t)col * ld] = acc;
+        }
+    }
+    // sigma_mm (cc:354,358): every (a,b) block, a != b included, gets + R Qt R^T
+    for (int e = tid; e < N2 * N2; e += nt) {
+#pragma clang fp contract(off)
+        const int a = e / N2, b = e - a * N2;
+        for (int rr = 0; rr < 2; ++rr)
+            for (int cc = 0; cc < 2; ++cc) {
+                double acc = 0;
+                for (int k = 0; k < 3; ++k) {
+                    double t = 0;
+                    for (int l = 0; l < 3; ++l) t += Gp[a][rr * 3 + l] * Sxi[l * 3 + k];
+                    acc += t * Gp[b][cc * 3 + k];
+                }
+                const size_t gi = (size_t)(n + 2 * a + rr), gj = (size_t)(n + 2 * b + cc);
+                if (gi < gj) continue;                              // the lower triangle is what is stored
+                const double v = acc + RQR[rr * 2 + cc];
+                P[gi + gj * ld] = v;
+            }
+    }
+    __syncthreads();
+}
+// ----------------------------------------------------------------------------
 // k_mid<NBR>: gather + solve + gain in ONE launch, for at most 16 NBR innovation rows per pass (NBR = 2: up to 16
 // matched observations, NBR = 4: up to 32 -- every BASELINE.json configuration; scans with more run several passes,
 // see "block step" below).
@@ -820,13 +887,45 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     MMARK();                                        // (x1: ... arrived)
 #endif
-    const int n = (d.n_known >= 0) ? d.n_known : ctl->n;
+    // the previous scan's augmentation, when it was deferred into this launch (RekfCtl::augrec, by scan parity): the state this scan
+    // works on has n_before + 2 n2 rows, of which the last 2 n2 are being appended by workgroup 0 right now
+    int ar_n = 0, ar_n2 = 0;
+    if (A.aug_in_mid) {
+        const RekfCtl::AugRec *ar = &ctl->augrec[(A.pred_slot ^ 1) & 1];
+        ar_n = __hip_atomic_load(&ar->n_before, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ar_n2 = __hip_atomic_load(&ar->n2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int n = (d.n_known >= 0) ? d.n_known : (A.aug_in_mid ? ar_n + 2 * ar_n2 : ctl->n);
     const size_t ld = (size_t)d.ld;
     const int i0 = blockIdx.x * MID_ROWS;
     // the host sizes the grid by its BOUND of n (it may run several scans ahead of the device, each of which can append K
     // reflectors): a workgroup past the real n has nothing to do -- and with one workgroup per CU (121 KB of LDS) a grid of more
     // than 256 would otherwise cost a second round of the whole inverse
     if (i0 >= n) return;
+    if (A.aug_in_mid && ar_n2 > 0) {
+        // (rare: the previous scan met new reflectors.)  Workgroup 0 appends their covariance rows -- what k_augment would have done in
+        // a launch of its own between the two scans -- and says so; everybody else waits for that before touching P: one poll loop on
+        // one lane, one agent-scope acquire, a barrier (the grid's workgroups are resident together up to 256 x 16 rows, workgroup 0 is
+        // dispatched first; the wait is bounded all the same and turns into the sticky SINGULAR-free error path: garbage, not a hang)
+        if (blockIdx.x == 0) {
+            double *scr = s_big;
+            const float *ao = ctl->augrec[(A.pred_slot ^ 1) & 1].obs;
+            augment_rows(d, ar_n, ar_n2, A.obs_cov, (double (*)[6])scr, scr + 6 * REKF_MAX_OBS_DEV, scr + 6 * REKF_MAX_OBS_DEV + 9, 512,
+                         [&](int k, float &rx, float &ry) { rx = ao[2 * k]; ry = ao[2 * k + 1]; });
+            if (tid == 0) {
+                ctl->n = ar_n + 2 * ar_n2;                                      // cc:360-363
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&ctl->aug_done, A.scan_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else if (tid == 0) {
+            unsigned spins = 0;
+            while ((int)(__hip_atomic_load(&ctl->aug_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - A.scan_id) < 0 && ++spins < (1u << 22))
+                __builtin_amdgcn_s_sleep(4);
+        }
+        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+    }
     const double *__restrict__ P = d.P;
     // (a host-predicted scan carries the predicted pose in the launch packet: no read of the control block for it)
     const bool hp = A.host_pred != 0;
@@ -897,6 +996,15 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
         if (tid == 128) {
             ctl->K = s_cnt[7]; ctl->n_state = NS; ctl->n_map = Mm; ctl->n_new = N2r;
             ctl->m = m; ctl->m_pad = m_pad;
+        }
+        // ... and what this scan's augmentation needs, should it be deferred into the next scan's k_mid (RekfCtl::augrec)
+        if (A.K <= REKF_MAX_OBS_DEV) {
+            RekfCtl::AugRec *aw = &ctl->augrec[A.pred_slot & 1];
+            if (tid >= 192 && tid < 192 + N2r) {
+                const int lid = s_newid[tid - 192];
+                aw->obs[2 * (tid - 192)] = rekf_obs(A, 2 * lid); aw->obs[2 * (tid - 192) + 1] = rekf_obs(A, 2 * lid + 1);
+            }
+            if (tid == 129) { aw->n_before = n; aw->n2 = N2r; }
         }
     }
     // The means of the scan's NEW reflectors (cc:323-342: the observation through the UPDATED pose, float32-rounded) are written
@@ -1999,64 +2107,12 @@ __global__ __launch_bounds__(256) void k_augment(RekfDev d, RekfFrontArgs A)
     RekfCtl *ctl = d.ctl;
     const int N2 = ctl->n_new;
     const int n = ctl->n;
-    const int tid = threadIdx.x;
-    const size_t ld = (size_t)d.ld;
-    double *P = d.P;
     if (N2 == 0) return;
-    {
-#pragma clang fp contract(off)
-        const double th = d.mu[2];
-        const double s = sin(th), c = cos(th);                      // cc:323-324
-        if (tid < N2) {
-            const int local_id = ctl->new_ids[tid];                 // cc:338
-            // (the means of the new reflectors, cc:341-342, are already there: k_mid's workgroup 0 writes them behind its pose commit)
-            const double rx = (double)rekf_obs(A, 2 * local_id), ry = (double)rekf_obs(A, 2 * local_id + 1);
-            Gp[tid][0] = 1.; Gp[tid][1] = 0.; Gp[tid][2] = -rx * s - ry * c;   // cc:347
-            Gp[tid][3] = 0.; Gp[tid][4] = 1.; Gp[tid][5] = rx * c - ry * s;
-        }
-        if (tid == 0) {
-            for (int i = 0; i < 3; ++i)
-                for (int j = 0; j < 3; ++j) Sxi[i * 3 + j] = rekf_plower(P, (int)ld, i, j);   // cc:322
-            const double q = A.obs_cov;                             // Gz Qt Gz^T, Gz = R(theta) (cc:326,354)
-            RQR[0] = c * q * c + (-s) * q * (-s); RQR[1] = c * q * s + (-s) * q * c;
-            RQR[2] = s * q * c + c * q * (-s);    RQR[3] = s * q * s + c * q * c;
-        }
-    }
-    __syncthreads();
-    // sigma_mx = G_fx * sigma (cc:355-357): rows n+2a+rr, all old columns (below the diagonal: the only copy that is stored);
-    // sigma(0..2, col) is read as sigma(col, 0..2) -- the coalesced columns
-    for (int e = tid; e < n * N2; e += 256) {
-#pragma clang fp contract(off)
-        const int a = e / n, col = e - a * n;
-        const double q0 = rekf_plower(P, (int)ld, col, 0), q1 = rekf_plower(P, (int)ld, col, 1), q2 = rekf_plower(P, (int)ld, col, 2);
-        for (int rr = 0; rr < 2; ++rr) {
-            double acc = 0;
-            acc += Gp[a][rr * 3 + 0] * q0;
-            acc += Gp[a][rr * 3 + 1] * q1;
-            acc += Gp[a][rr * 3 + 2] * q2;
-            P[(size_t)(n + 2 * a + rr) + (size_t)col * ld] = acc;
-        }
-    }
-    // sigma_mm (cc:354,358): every (a,b) block, a != b included, gets + R Qt R^T
-    for (int e = tid; e < N2 * N2; e += 256) {
-#pragma clang fp contract(off)
-        const int a = e / N2, b = e - a * N2;
-        for (int rr = 0; rr < 2; ++rr)
-            for (int cc = 0; cc < 2; ++cc) {
-                double acc = 0;
-                for (int k = 0; k < 3; ++k) {
-                    double t = 0;
-                    for (int l = 0; l < 3; ++l) t += Gp[a][rr * 3 + l] * Sxi[l * 3 + k];
-                    acc += t * Gp[b][cc * 3 + k];
-                }
-                const size_t gi = (size_t)(n + 2 * a + rr), gj = (size_t)(n + 2 * b + cc);
-                if (gi < gj) continue;                              // the lower triangle is what is stored
-                const double v = acc + RQR[rr * 2 + cc];
-                P[gi + gj * ld] = v;
-            }
-    }
-    __syncthreads();
-    if (tid == 0) ctl->n = n + 2 * N2;                              // cc:360-363
+    augment_rows(d, n, N2, A.obs_cov, Gp, Sxi, RQR, 256, [&](int k, float &rx, float &ry) {
+        const int local_id = ctl->new_ids[k];
+        rx = rekf_obs(A, 2 * local_id); ry = rekf_obs(A, 2 * local_id + 1);
+    });
+    if (threadIdx.x == 0) ctl->n = n + 2 * N2;                      // cc:360-363
 }
 
 // GetState's pose part (ekf_slam.h GetState / ros_node.cc's pose publisher): mu[0..2], the 3 x 3 pose block, n and the error

@@ -75,6 +75,8 @@ struct rekf {
     int dd_n_ub = 0;                // ... and the bound of n it was planned with
     bool dd_aug = false;            // the scan's k_augment is held back with it (the state can still grow): it runs right behind the downdate
     RekfFrontArgs dd_aug_args;      // ... with the scan's launch packet (the new reflectors' observations)
+    bool dd_aug_inline_ok = false;  // ... and it may run inside the next scan's k_mid instead of a launch of its own (RekfCtl::augrec: whole scans only)
+    bool aug_in_mid = true;         // REKF_AUG_IN_MID=0 in the environment turns that off (A/B measurements)
     bool lazy_dd = true;            // REKF_LAZY_DD=0 in the environment turns it off (A/B measurements)
     // WHO PUBLISHES pose, pose block, n and flags of a scan.  A caller that reads the pose back after its scans (the reference's node,
     // src/ros_node.cc:514-515) gets them from k_mid's workgroup 0 -- a kernel earlier: GetPose does not wait for the downdate -- which
@@ -450,6 +452,7 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
     h->n_ub = 3;
     h->full = false;
     { const char *e = std::getenv("REKF_LAZY_DD"); h->lazy_dd = !(e && e[0] == '0'); }
+    { const char *e = std::getenv("REKF_AUG_IN_MID"); h->aug_in_mid = !(e && e[0] == '0'); }
     h->prof_on = false;
     h->prof_mask = -1;
     h->prof_used = 0;
@@ -689,12 +692,18 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     const bool aug = !h->full;
     if (aug) h->cum_growth += 2 * K;
     const int pub_seq = new_publisher(h);
+    a.scan_id = (unsigned)h->scan_count;
     if (with_dd) {
         h->dd_pending = false;
         a.aug_pending = h->dd_aug ? 1 : 0;
         { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_dd_front(h->dd_dev, h->dd_n_ub, h->dev, a, h->stream); }
-        if (h->dd_aug) { ProfScope ps(h, REKF_K_AUGMENT); rekf_launch_augment(h->dd_dev, h->dd_aug_args, h->stream); h->dd_aug = false; }
+        // the previous scan's augmentation: inside this scan's k_mid (its workgroup 0 appends the rows first thing -- no launch of its
+        // own between the two scans; whole scans on both sides), else as k_augment right behind the downdate
+        const bool inline_aug = h->dd_aug && h->aug_in_mid && h->dd_aug_inline_ok && !blocks;
+        if (h->dd_aug && !inline_aug) { ProfScope ps(h, REKF_K_AUGMENT); rekf_launch_augment(h->dd_dev, h->dd_aug_args, h->stream); }
+        h->dd_aug = false;
         a.aug_pending = 0;
+        a.aug_in_mid = inline_aug ? 1 : 0;
     } else {
         ProfScope ps(h, REKF_K_FRONT);
         rekf_launch_front_mb(h->dev, a, h->n_ub, h->stream);
@@ -758,7 +767,7 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     // the state only grows: once it is known full, k_augment can never have work again
     // (k_mid / k_compact_wide drop the extra reflectors and raise REKF_FLAG_CAPACITY)
     if (aug) {
-        if (h->dd_pending) { h->dd_aug = true; h->dd_aug_args = a; }      // (held back with the scan's downdate)
+        if (h->dd_pending) { h->dd_aug = true; h->dd_aug_args = a; h->dd_aug_args.aug_in_mid = 0; h->dd_aug_inline_ok = !blocks && !staged; }      // (held back with the scan's downdate)
         else {
             ProfScope ps(h, REKF_K_AUGMENT);
             rekf_launch_augment(h->dev, a, h->stream);

@@ -71,7 +71,7 @@ def test_driver_command_steps20_warmup5_has_every_object():
     nf = d["not_full"]
     assert "error" not in nf, nf
     assert nf["max_landmarks"] == 2048 and nf["n"] == 2051 and nf["value"] > 5000 and nf["with_pose_readback"]["value"] > 3000
-    assert nf["kernel_us"]["augment"] is not None
+    assert nf["kernel_us"]["augment"] is None          # a growing filter's augmentation runs inside the next scan's k_mid: no launch of its own
     assert d["multi_session"]["sessions_bit_identical"] is True
     det = d["detectors"]
     assert "error" not in det, det
