@@ -244,6 +244,42 @@ def test_detect3d_micro_cases_match(oracle_lib):
     _compare3d(chain.astype(np.float32))
 
 
+def test_detect3d_results_do_not_depend_on_the_sorting_grid(oracle_lib):
+    """Round 4 sorts the bright points on a 128 x 128 grid whose extent is the PREVIOUS cloud's bounding box (the first cloud's: 64 m
+    around the sensor) and prunes the neighbour searches with per-tile boxes.  Nothing of the result may depend on that grid: one
+    detector handle is fed clouds whose extents have nothing to do with each other -- 400 m from the sensor (every point clamped into
+    border cells), millimetres across, all in one cell, a lone point far outside -- and every answer must be the oracle's, bit for bit."""
+    from oracle.binding import oracle_detect3d
+    from reflector_ekf_slam_amd.detect import PointCloudOptions, PointCloudReflectorDetect
+    rng = np.random.default_rng(11)
+    g = PointCloudReflectorDetect(PointCloudOptions(), max_points=65536)
+
+    def scene(centre, scale, n_clusters, rng, per=(8, 60), spread=0.03, outliers=20):
+        parts = [_blob(centre, 400, 4.0 * scale, rng, intensity=20.0)]
+        for _ in range(n_clusters):
+            c = np.asarray(centre) + rng.uniform(-10 * scale, 10 * scale, 3) * np.array([1, 1, 0.05])
+            parts.append(_blob(c, int(rng.integers(*per)), spread, rng))
+        if outliers:
+            o = np.asarray(centre) + rng.uniform(-12 * scale, 12 * scale, (outliers, 3)) * np.array([1, 1, 0.05])
+            parts.append(np.concatenate([o, np.full((outliers, 1), 230.0)], -1))
+        c = np.concatenate(parts).astype(np.float32)
+        return c[rng.permutation(c.shape[0])]                                     # arrival order has nothing to do with space either
+
+    clouds = [scene((0, 0, 0.5), 1.0, 30, rng),
+              scene((400.0, -250.0, 0.5), 1.0, 30, rng),                           # far outside the first grid: all clamped
+              scene((0.3, 0.2, 0.5), 0.01, 6, rng, spread=0.002, outliers=5),      # centimetres across: one or two cells
+              scene((0, 0, 0.5), 3.0, 60, rng),                                    # the grid left by the tiny cloud is useless here
+              np.concatenate([scene((5, 5, 0.5), 0.5, 10, rng), np.array([[9000.0, -9000.0, 0.0, 250.0]], np.float32)]),   # a lone far point
+              scene((0, 0, 0.5), 1.0, 30, rng)]
+    for k, cloud in enumerate(clouds):
+        obs = g.HandlePointCloud(1.0 + k, cloud)
+        c, m1, m2 = oracle_detect3d(cloud)
+        assert obs.cloud_.shape == c.shape, (k, obs.cloud_.shape, c.shape)
+        assert np.array_equal(obs.cloud_, c), f"cloud {k}: centres differ from the oracle's"
+        assert c.shape[0] >= 3 or k == 2, k                                      # (the centimetre-sized scene is ONE oversize cluster: dropped)
+    g.close()
+
+
 def test_detect3d_world_clouds_match(oracle_lib):
     from reflector_ekf_slam_amd import synth
     for seed, pose in ((3, (34.4, 34.0, 1.15)), (4, (10.0, 50.0, -0.4))):
