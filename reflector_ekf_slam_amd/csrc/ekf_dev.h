@@ -76,6 +76,7 @@ struct RekfCtl {
     // next k_mid's workgroup 0 does the appending first thing; the other workgroups wait for aug_done only when there IS something
     struct AugRec { int n_before, n2; float obs[2 * REKF_MAX_OBS_DEV]; } augrec[2];
     unsigned aug_done;                // scan id of the last k_mid whose workgroup 0 has appended its predecessor's new reflectors
+    unsigned rec_seq;                 // scan id of the last scan whose match record (rec) the front role INSIDE k_mid's grid has completed
     long long dbg[32];            // scratch for in-kernel timing experiments (REKF_DEBUG_TIMING builds)
 };
 
@@ -104,6 +105,8 @@ struct RekfFrontArgs {
     int compact_in_front;     // 1: whole scan (K <= 32, one pass of k_mid): the front end leaves RekfCtl::rec; 0: wide scan (k_compact_wide)
     int aug_pending;          // front role inside k_dd_front: the previous scan's k_augment has not run yet -- the state the match sees has
                               // n + 2 n_new rows (the new reflectors' means are there: k_mid writes them)
+    int front_in_mid;         // k_mid: the first front_in_mid workgroups of its grid are this scan's front end (a host-predicted scan behind a
+                              // pose read-back: no launch of its own for the match); the others wait for RekfCtl::rec_seq
     int aug_in_mid;           // k_mid: the previous scan's augmentation has not run: workgroup 0 appends its rows first (RekfCtl::augrec), n = n_before + 2 n2
     unsigned scan_id;         // running number of the scan (RekfCtl::aug_done)
     int apply_pred;           // k_mid: apply the pending Predict to the gathered P (whole scan or FIRST block step of a wide scan)

@@ -298,7 +298,7 @@ __device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs
             for (int q = 0; q < 9; ++q) pr->C9[q] = C9[q];
             ctl->pose_pred[0] = pose[0]; ctl->pose_pred[1] = pose[1]; ctl->pose_pred[3] = pose[3]; ctl->pose_pred[4] = pose[4];
             if (A.host_pred) ctl->pose_pred[2] = pose[2];
-            ctl->pose_pending = 1;
+            if (!A.front_in_mid) ctl->pose_pending = 1;       // (inside k_mid's grid nobody reads it, and that kernel's workgroup 0 clears it beside us)
         }
         if (!A.host_pred && b == 0 && tid == NT - 64) ctl->pose_pred[2] = atan2(pose[4], pose[3]);     // the wrapped heading (cc:181 / :205), on the last wave
     }
@@ -429,26 +429,38 @@ __device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs
                 rk += (oq < key || (oq == key && q < lane)) ? 1 : 0;
             }
         }
+        // (inside k_mid's grid the record is taken over within the launch: written through at agent scope -- no release fence, which
+        // writes the whole L2 back -- and flagged below; elsewhere these are plain stores and the kernel boundary publishes them)
+        const bool wt = A.front_in_mid != 0;
+        auto put = [&](int *p_, int v_) __attribute__((always_inline)) {
+            if (wt) __hip_atomic_store(p_, v_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p_ = v_;
+        };
         if (kind == 1) {
             const int p = __popcll(ms & lt);
             if (p < 32) {
-                rec->pair_obs[p] = lane; rec->pair_id[p] = oidx; rec->pair_state[p] = 1;
-                rec->rank[p] = rk;
-                rec->urow[2 + rk] = 3 + 2 * oidx; rec->ukc[2 + rk] = 3 + 2 * p;
+                put(&rec->pair_obs[p], lane); put(&rec->pair_id[p], oidx); put(&rec->pair_state[p], 1);
+                put(&rec->rank[p], rk);
+                put(&rec->urow[2 + rk], 3 + 2 * oidx); put(&rec->ukc[2 + rk], 3 + 2 * p);
             }
         } else if (kind == 0) {
             const int p = __popcll(mm & lt);
-            if (M + p < 32) { rec->pair_obs[M + p] = lane; rec->pair_id[M + p] = oidx; rec->pair_state[M + p] = 0; }
+            if (M + p < 32) { put(&rec->pair_obs[M + p], lane); put(&rec->pair_id[M + p], oidx); put(&rec->pair_state[M + p], 0); }
         } else if (kind == 2) {
             const int p = __popcll(mn & lt);
-            if (p < N2) rec->newid[p] = lane;
+            if (p < N2) put(&rec->newid[p], lane);
         }
         if (lane == 0) {
             const int MM = M + Mm;
             const int m = (MM > 0) ? 2 * MM + (A.has_gps ? 3 : 0) : 0;
-            rec->cnt[0] = MM; rec->cnt[1] = m; rec->cnt[2] = (m + 15) & ~15; rec->cnt[3] = M; rec->cnt[4] = (A.has_gps && MM > 0) ? 1 : 0;
-            rec->cnt[5] = N2; rec->cnt[6] = Mm; rec->cnt[7] = K;
-            rec->urow[0] = 0; rec->ukc[0] = 0; rec->urow[1] = 2; rec->ukc[1] = 2;
+            put(&rec->cnt[0], MM); put(&rec->cnt[1], m); put(&rec->cnt[2], (m + 15) & ~15); put(&rec->cnt[3], M); put(&rec->cnt[4], (A.has_gps && MM > 0) ? 1 : 0);
+            put(&rec->cnt[5], N2); put(&rec->cnt[6], Mm); put(&rec->cnt[7], K);
+            put(&rec->urow[0], 0); put(&rec->ukc[0], 0); put(&rec->urow[1], 2); put(&rec->ukc[1], 2);
+        }
+        if (A.front_in_mid) {
+            // inside k_mid's grid: the workgroups that take the record from here are waiting in this very launch (other CUs, other
+            // XCDs) -- the record out of this CU's caches, then the scan's number as the flag
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // (every lane's write-through stores have left)
+            if (__ballot(true) && lane == 0) __hip_atomic_store(&ctl->rec_seq, A.scan_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 #ifdef REKF_DEBUG_FRONT
@@ -864,7 +876,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
 
 #ifdef REKF_DEBUG_TIMING
     long long tqm[16]; int nqm = 0;
-    const bool recm = blockIdx.x == 1 && threadIdx.x == 0;
+    const bool recm = blockIdx.x == 1 && threadIdx.x == 0;      // (debug builds: without the in-grid front role)
     const long long t_entrym = clock64(), w_entrym = wall_clock64();
 #define MMARK() do { __builtin_amdgcn_sched_barrier(0); if (recm && nqm < 16) tqm[nqm++] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -874,14 +886,33 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     // gather, W rows of S, S, its inverse -- waves 4..7 everything that only this workgroup's 16 rows / columns need
     // (H rows, own gathers, (H P)^T to HBM), off that chain; both meet at the barriers.
     RekfCtl *ctl = ctl_first;
+    // A host-predicted scan behind a pose read-back (A.front_in_mid workgroups): its front end -- ReflectorMatch only, pose and pose
+    // block came by value -- runs as the FIRST workgroups of this grid instead of a launch of its own (7.5 us + a kernel boundary in
+    // front of k_mid, on the path every read-back caller waits for); everybody else waits for the record below.  One-way: the
+    // front role waits for nobody, its workgroups are dispatched first and the grid's first 256 workgroups are resident together.
+    if (A.front_in_mid > 0 && (int)blockIdx.x < A.front_in_mid) {
+        front_role<512>(d, A, (int)blockIdx.x, A.front_in_mid, false);
+        return;
+    }
+    const int bx = (int)blockIdx.x - (A.front_in_mid > 0 ? A.front_in_mid : 0);      // this workgroup's number among the mid workgroups
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool steam = wave < 4;                  // S team; the other is the "own" team
     const int tt = tid & 255;                     // thread index within the team
+    if (A.front_in_mid > 0) {
+        if (tid == 0) {
+            unsigned spins = 0;
+            while ((int)(__hip_atomic_load(&ctl->rec_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - A.scan_id) < 0 && ++spins < (1u << 22))
+                __builtin_amdgcn_s_sleep(2);
+        }
+        __syncthreads();
+    }
     // the scan's match record first, UNCONDITIONALLY (a block step of a wide scan does not use it): a vector load that waits for no
     // scalar one, so the control block costs one memory round trip, not two
     constexpr int NREC = (int)(sizeof(RekfCtl::Rec) / sizeof(int));
     static_assert(NREC <= 512, "one load per thread");
-    const int rec_raw = (tid < NREC) ? ((const int *)&ctl->rec)[tid] : 0;
+    // (behind an in-grid front role: past this CU's L1 -- the record was written through by another CU a moment ago)
+    const int rec_raw = (tid < NREC) ? ((A.front_in_mid > 0) ? __hip_atomic_load(&((const int *)&ctl->rec)[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                               : ((const int *)&ctl->rec)[tid]) : 0;
 #ifdef REKF_DEBUG_MID_FIRST
     MMARK();                                        // (x0: first loads issued)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -897,7 +928,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     }
     const int n = (d.n_known >= 0) ? d.n_known : (A.aug_in_mid ? ar_n + 2 * ar_n2 : ctl->n);
     const size_t ld = (size_t)d.ld;
-    const int i0 = blockIdx.x * MID_ROWS;
+    const int i0 = bx * MID_ROWS;
     // the host sizes the grid by its BOUND of n (it may run several scans ahead of the device, each of which can append K
     // reflectors): a workgroup past the real n has nothing to do -- and with one workgroup per CU (121 KB of LDS) a grid of more
     // than 256 would otherwise cost a second round of the whole inverse
@@ -907,7 +938,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
         // a launch of its own between the two scans -- and says so; everybody else waits for that before touching P: one poll loop on
         // one lane, one agent-scope acquire, a barrier (the grid's workgroups are resident together up to 256 x 16 rows, workgroup 0 is
         // dispatched first; the wait is bounded all the same and turns into the sticky SINGULAR-free error path: garbage, not a hang)
-        if (blockIdx.x == 0) {
+        if (bx == 0) {
             double *scr = s_big;
             const float *ao = ctl->augrec[(A.pred_slot ^ 1) & 1].obs;
             augment_rows(d, ar_n, ar_n2, A.obs_cov, (double (*)[6])scr, scr + 6 * REKF_MAX_OBS_DEV, scr + 6 * REKF_MAX_OBS_DEV + 9, 512,
@@ -931,14 +962,18 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     const bool hp = A.host_pred != 0;
     const double pose[5] = {hp ? A.pre_pose[0] : ctl->pose_pred[0], hp ? A.pre_pose[1] : ctl->pose_pred[1], hp ? A.pre_pose[2] : ctl->pose_pred[2],
                             hp ? A.pre_pose[3] : ctl->pose_pred[3], hp ? A.pre_pose[4] : ctl->pose_pred[4]};
-    const bool pending = ctl->pose_pending != 0;
-    const bool first = blockIdx.x == 0;
+    const bool pending = (A.front_in_mid > 0) ? true : ctl->pose_pending != 0;      // (the in-grid front role sets it beside us: a host-predicted scan always has one)
+    const bool first = bx == 0;
     // the scan's pending Predict (RekfCtl::pred): applied to the gathered P in phase D.  (a, b) = 0 and the pose block as gathered
     // when nothing is pending (later block steps of a wide scan: the first step's downdate has committed it)
     // (through LDS, not registers: eleven uniform doubles held from here to phase D cost this 512-thread kernel its residency)
     const bool do_pred = A.apply_pred != 0;
     __shared__ double s_pred[12];
-    if (do_pred && tid >= 64 && tid < 64 + 11) s_pred[tid - 64] = ((const double *)&ctl->pred[A.pred_slot & 1])[tid - 64];   // ab[0], ab[1], C9[0..8]
+    if (do_pred && tid >= 64 && tid < 64 + 11) {                                   // ab[0], ab[1], C9[0..8]
+        // (with the front role in this grid the control block's copy is being written beside us: a host-predicted scan carries the values)
+        const int e = tid - 64;
+        s_pred[e] = (A.front_in_mid > 0) ? (e < 2 ? A.pre_ab[e] : A.pre_C9[e - 2]) : ((const double *)&ctl->pred[A.pred_slot & 1])[e];
+    }
 
     // ---- A: the scan's matched pairs.  Whole scan (pair0 < 0): ordered compaction of the per-observation results (obs order
     // preserved), wave 0; workgroup 0 also writes the record for the getters.  Block step of a wide scan (pair0 >= 0): the
@@ -1040,7 +1075,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
             // step's downdate left in memory)
             if (tid < 9) {
                 const int pi = tid % 3, pj = tid / 3, hi = pi > pj ? pi : pj, lo = pi > pj ? pj : pi;
-                const double v9 = do_pred ? ((const double *)&ctl->pred[A.pred_slot & 1])[2 + hi + 3 * lo] : rekf_plower(P, (int)ld, hi, lo);
+                const double v9 = do_pred ? s_pred[2 + hi + 3 * lo] : rekf_plower(P, (int)ld, hi, lo);
                 ctl->post_C9[tid] = v9;
                 if (d.pub) host_slot_store(d.pub + 3 + tid, v9, d.pub_seq, 0);
             }
@@ -2173,7 +2208,7 @@ void rekf_launch_compact_wide(const RekfDev &d, const RekfFrontArgs &a, hipStrea
 void rekf_launch_mid(const RekfDev &d, const RekfFrontArgs &a, int n_ub, int m_ub, hipStream_t s)
 {
     // m_ub <= 64 (the host checks): one workgroup per 16 state rows
-    const int grid = (n_ub + MID_ROWS - 1) / MID_ROWS;
+    const int grid = (n_ub + MID_ROWS - 1) / MID_ROWS + (a.front_in_mid > 0 ? a.front_in_mid : 0);
     if (m_ub <= 32) hipLaunchKernelGGL(k_mid<2>, dim3(grid), dim3(512), 0, s, d.ctl, d, a);
     else hipLaunchKernelGGL(k_mid<4>, dim3(grid), dim3(512), 0, s, d.ctl, d, a);
 }

@@ -77,6 +77,7 @@ struct rekf {
     RekfFrontArgs dd_aug_args;      // ... with the scan's launch packet (the new reflectors' observations)
     bool dd_aug_inline_ok = false;  // ... and it may run inside the next scan's k_mid instead of a launch of its own (RekfCtl::augrec: whole scans only)
     bool aug_in_mid = true;         // REKF_AUG_IN_MID=0 in the environment turns that off (A/B measurements)
+    bool front_in_mid = true;       // a host-predicted scan's front end runs inside k_mid's grid (REKF_FRONT_IN_MID=0: as k_front_mb, a launch of its own)
     bool lazy_dd = true;            // REKF_LAZY_DD=0 in the environment turns it off (A/B measurements)
     // WHO PUBLISHES pose, pose block, n and flags of a scan.  A caller that reads the pose back after its scans (the reference's node,
     // src/ros_node.cc:514-515) gets them from k_mid's workgroup 0 -- a kernel earlier: GetPose does not wait for the downdate -- which
@@ -453,6 +454,7 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
     h->full = false;
     { const char *e = std::getenv("REKF_LAZY_DD"); h->lazy_dd = !(e && e[0] == '0'); }
     { const char *e = std::getenv("REKF_AUG_IN_MID"); h->aug_in_mid = !(e && e[0] == '0'); }
+    { const char *e = std::getenv("REKF_FRONT_IN_MID"); h->front_in_mid = !(e && e[0] == '0'); }
     h->prof_on = false;
     h->prof_mask = -1;
     h->prof_used = 0;
@@ -704,6 +706,10 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         h->dd_aug = false;
         a.aug_pending = 0;
         a.aug_in_mid = inline_aug ? 1 : 0;
+    } else if (h->front_in_mid && a.host_pred && !blocks && !staged && K <= 32) {
+        // behind a pose read-back the front end is a match only (pose, cos / sin, pose block go by value): it runs as the first
+        // workgroups of k_mid's own grid, one observation each, and hands the record over inside the launch
+        a.front_in_mid = K;
     } else {
         ProfScope ps(h, REKF_K_FRONT);
         rekf_launch_front_mb(h->dev, a, h->n_ub, h->stream);
