@@ -80,6 +80,7 @@ def rekf():
     L.rekf_set_auto_grow.argtypes = [vp, C.c_int]
     L.rekf_get_capacity.argtypes = [vp, ip]
     L.rekf_debug_time_kernel.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
-    L.rekf_debug_inject_failure.argtypes = [vp, C.c_int]
+    if hasattr(L, "rekf_debug_inject_failure"):           # (absent from older builds that scripts/gpu_ab.py compares against)
+        L.rekf_debug_inject_failure.argtypes = [vp, C.c_int]
     _rekf = L
     return L

@@ -838,9 +838,15 @@ __device__ static inline void augment_rows(const RekfDev &d, int n, int N2, doub
 // ----------------------------------------------------------------------------
 typedef double v2du __attribute__((ext_vector_type(2), aligned(8)));     // a row pair that starts on an odd row: 8-byte aligned
 #define MID_ROWS 16
-template <int NBR>
+// MODE picks what else the launch hosts (separate instantiations: the steady state of a full filter, MODE 0, carries none of it --
+// the front role's LDS and the extra prologue cost that path 0.6 us per update when they were runtime branches):
+//   0  nothing;  1  a filter that can still grow: workgroup 0 leaves the scan's augmentation record (RekfCtl::augrec) and, with
+//   A.aug_in_mid, first appends the PREVIOUS scan's new reflectors;  2  the scan's front end runs as the first A.front_in_mid
+//   workgroups of this grid (a host-predicted scan behind a pose read-back); also leaves the augmentation record.
+template <int NBR, int MODE>
 __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, RekfFrontArgs A)
 {
+    constexpr bool FRONT = MODE == 2, AUGR = MODE == 1, AUGW = MODE >= 1;
     // ctl_first = d.ctl, as a leading pointer argument of its own: built with -mllvm -amdgpu-kernarg-preload-count the wave starts with it
     // in SGPRs, and the kernel's first loads (the match results) do not wait for the kernel-argument fetch
     constexpr int MP = 16 * NBR;                  // most innovation rows (padded) this instance takes
@@ -890,15 +896,15 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     // block came by value -- runs as the FIRST workgroups of this grid instead of a launch of its own (7.5 us + a kernel boundary in
     // front of k_mid, on the path every read-back caller waits for); everybody else waits for the record below.  One-way: the
     // front role waits for nobody, its workgroups are dispatched first and the grid's first 256 workgroups are resident together.
-    if (A.front_in_mid > 0 && (int)blockIdx.x < A.front_in_mid) {
+    if (FRONT && (int)blockIdx.x < A.front_in_mid) {
         front_role<512>(d, A, (int)blockIdx.x, A.front_in_mid, false);
         return;
     }
-    const int bx = (int)blockIdx.x - (A.front_in_mid > 0 ? A.front_in_mid : 0);      // this workgroup's number among the mid workgroups
+    const int bx = (int)blockIdx.x - (FRONT ? A.front_in_mid : 0);      // this workgroup's number among the mid workgroups
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool steam = wave < 4;                  // S team; the other is the "own" team
     const int tt = tid & 255;                     // thread index within the team
-    if (A.front_in_mid > 0) {
+    if (FRONT) {
         if (tid == 0) {
             unsigned spins = 0;
             while ((int)(__hip_atomic_load(&ctl->rec_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - A.scan_id) < 0 && ++spins < (1u << 22))
@@ -911,7 +917,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     constexpr int NREC = (int)(sizeof(RekfCtl::Rec) / sizeof(int));
     static_assert(NREC <= 512, "one load per thread");
     // (behind an in-grid front role: past this CU's L1 -- the record was written through by another CU a moment ago)
-    const int rec_raw = (tid < NREC) ? ((A.front_in_mid > 0) ? __hip_atomic_load(&((const int *)&ctl->rec)[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+    const int rec_raw = (tid < NREC) ? (FRONT ? __hip_atomic_load(&((const int *)&ctl->rec)[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                                                : ((const int *)&ctl->rec)[tid]) : 0;
 #ifdef REKF_DEBUG_MID_FIRST
     MMARK();                                        // (x0: first loads issued)
@@ -921,19 +927,19 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     // the previous scan's augmentation, when it was deferred into this launch (RekfCtl::augrec, by scan parity): the state this scan
     // works on has n_before + 2 n2 rows, of which the last 2 n2 are being appended by workgroup 0 right now
     int ar_n = 0, ar_n2 = 0;
-    if (A.aug_in_mid) {
+    if (AUGR && A.aug_in_mid) {
         const RekfCtl::AugRec *ar = &ctl->augrec[(A.pred_slot ^ 1) & 1];
         ar_n = __hip_atomic_load(&ar->n_before, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ar_n2 = __hip_atomic_load(&ar->n2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    const int n = (d.n_known >= 0) ? d.n_known : (A.aug_in_mid ? ar_n + 2 * ar_n2 : ctl->n);
+    const int n = (d.n_known >= 0) ? d.n_known : ((AUGR && A.aug_in_mid) ? ar_n + 2 * ar_n2 : ctl->n);
     const size_t ld = (size_t)d.ld;
     const int i0 = bx * MID_ROWS;
     // the host sizes the grid by its BOUND of n (it may run several scans ahead of the device, each of which can append K
     // reflectors): a workgroup past the real n has nothing to do -- and with one workgroup per CU (121 KB of LDS) a grid of more
     // than 256 would otherwise cost a second round of the whole inverse
     if (i0 >= n) return;
-    if (A.aug_in_mid && ar_n2 > 0) {
+    if (AUGR && A.aug_in_mid && ar_n2 > 0) {
         // (rare: the previous scan met new reflectors.)  Workgroup 0 appends their covariance rows -- what k_augment would have done in
         // a launch of its own between the two scans -- and says so; everybody else waits for that before touching P: one poll loop on
         // one lane, one agent-scope acquire, a barrier (the grid's workgroups are resident together up to 256 x 16 rows, workgroup 0 is
@@ -962,7 +968,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     const bool hp = A.host_pred != 0;
     const double pose[5] = {hp ? A.pre_pose[0] : ctl->pose_pred[0], hp ? A.pre_pose[1] : ctl->pose_pred[1], hp ? A.pre_pose[2] : ctl->pose_pred[2],
                             hp ? A.pre_pose[3] : ctl->pose_pred[3], hp ? A.pre_pose[4] : ctl->pose_pred[4]};
-    const bool pending = (A.front_in_mid > 0) ? true : ctl->pose_pending != 0;      // (the in-grid front role sets it beside us: a host-predicted scan always has one)
+    const bool pending = FRONT ? true : ctl->pose_pending != 0;      // (the in-grid front role sets it beside us: a host-predicted scan always has one)
     const bool first = bx == 0;
     // the scan's pending Predict (RekfCtl::pred): applied to the gathered P in phase D.  (a, b) = 0 and the pose block as gathered
     // when nothing is pending (later block steps of a wide scan: the first step's downdate has committed it)
@@ -972,7 +978,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     if (do_pred && tid >= 64 && tid < 64 + 11) {                                   // ab[0], ab[1], C9[0..8]
         // (with the front role in this grid the control block's copy is being written beside us: a host-predicted scan carries the values)
         const int e = tid - 64;
-        s_pred[e] = (A.front_in_mid > 0) ? (e < 2 ? A.pre_ab[e] : A.pre_C9[e - 2]) : ((const double *)&ctl->pred[A.pred_slot & 1])[e];
+        s_pred[e] = FRONT ? (e < 2 ? A.pre_ab[e] : A.pre_C9[e - 2]) : ((const double *)&ctl->pred[A.pred_slot & 1])[e];
     }
 
     // ---- A: the scan's matched pairs.  Whole scan (pair0 < 0): ordered compaction of the per-observation results (obs order
@@ -1033,7 +1039,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
             ctl->m = m; ctl->m_pad = m_pad;
         }
         // ... and what this scan's augmentation needs, should it be deferred into the next scan's k_mid (RekfCtl::augrec)
-        if (A.K <= REKF_MAX_OBS_DEV) {
+        if (AUGW && A.K <= REKF_MAX_OBS_DEV) {
             RekfCtl::AugRec *aw = &ctl->augrec[A.pred_slot & 1];
             if (tid >= 192 && tid < 192 + N2r) {
                 const int lid = s_newid[tid - 192];
@@ -2205,12 +2211,20 @@ void rekf_launch_compact_wide(const RekfDev &d, const RekfFrontArgs &a, hipStrea
 {
     hipLaunchKernelGGL(k_compact_wide, dim3(1), dim3(REKF_MAX_OBS_WIDE), 0, s, d, a);
 }
-void rekf_launch_mid(const RekfDev &d, const RekfFrontArgs &a, int n_ub, int m_ub, hipStream_t s)
+void rekf_launch_mid(const RekfDev &d, const RekfFrontArgs &a, int n_ub, int m_ub, bool mode_grow, hipStream_t s)
 {
     // m_ub <= 64 (the host checks): one workgroup per 16 state rows
     const int grid = (n_ub + MID_ROWS - 1) / MID_ROWS + (a.front_in_mid > 0 ? a.front_in_mid : 0);
-    if (m_ub <= 32) hipLaunchKernelGGL(k_mid<2>, dim3(grid), dim3(512), 0, s, d.ctl, d, a);
-    else hipLaunchKernelGGL(k_mid<4>, dim3(grid), dim3(512), 0, s, d.ctl, d, a);
+    const int mode = (a.front_in_mid > 0) ? 2 : (mode_grow ? 1 : 0);
+    if (m_ub <= 32) {
+        if (mode == 0) hipLaunchKernelGGL((k_mid<2, 0>), dim3(grid), dim3(512), 0, s, d.ctl, d, a);
+        else if (mode == 1) hipLaunchKernelGGL((k_mid<2, 1>), dim3(grid), dim3(512), 0, s, d.ctl, d, a);
+        else hipLaunchKernelGGL((k_mid<2, 2>), dim3(grid), dim3(512), 0, s, d.ctl, d, a);
+    } else {
+        if (mode == 0) hipLaunchKernelGGL((k_mid<4, 0>), dim3(grid), dim3(512), 0, s, d.ctl, d, a);
+        else if (mode == 1) hipLaunchKernelGGL((k_mid<4, 1>), dim3(grid), dim3(512), 0, s, d.ctl, d, a);
+        else hipLaunchKernelGGL((k_mid<4, 2>), dim3(grid), dim3(512), 0, s, d.ctl, d, a);
+    }
 }
 template <int KC> static void launch_downdate2(const RekfDev &d, int grid, hipStream_t s, bool first_on_device, const RekfDev *dn, const RekfFrontArgs *an, int n_front)
 {

@@ -750,7 +750,7 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
                 RekfDev dm = h->dev;
                 if (early_pub && p0 + stride >= K) { dm.pub = h->host_slots_dev; dm.pub_seq = pub_seq; }
                 ProfScope ps(h, REKF_K_MID);
-                rekf_launch_mid(dm, a, n_ub, 64, h->stream);
+                rekf_launch_mid(dm, a, n_ub, 64, aug, h->stream);
             }
             std::swap(h->dev.mu, h->dev.mu_out);
             downdate(p0 == 0, p0 + stride >= K);      // the last step commits the final pose
@@ -764,7 +764,7 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
             RekfDev dm = h->dev;
             if (early_pub) { dm.pub = h->host_slots_dev; dm.pub_seq = pub_seq; }
             ProfScope ps(h, REKF_K_MID);
-            rekf_launch_mid(dm, a, n_ub, m_ub, h->stream);
+            rekf_launch_mid(dm, a, n_ub, m_ub, aug || a.aug_in_mid != 0, h->stream);
         }
         std::swap(h->dev.mu, h->dev.mu_out);
         downdate(true, true);
