@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define REKF_ABI_VERSION 4
+#define REKF_ABI_VERSION 5
 
 /* Most observations one scan may carry (K).  The reference has no limit (reflector_ekf_slam.cc:397 loops over
  * obs.cloud_.size()); this one is a buffer size, equal to what the detectors of rdet.h can emit (RDET_MAX_CENTERS).
