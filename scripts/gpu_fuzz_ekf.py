@@ -1,7 +1,10 @@
 """Randomised soak of the EKF path against the CPU oracle (wider than tests/test_ekf_gpu.py's randomised test):
 random model, landmark count (state sizes across several 64-column tile boundaries), observations per scan up to 32,
 ragged / empty scans, pre-loaded map, pose observations, negative dt.  One JSON line per seed + a summary.
-GPU box: python scripts/gpu_fuzz_ekf.py [n_seeds] [first_seed]"""
+GPU box: python scripts/gpu_fuzz_ekf.py [n_seeds] [first_seed] [burst]
+With `burst` the scans are enqueued in bursts of 2..12 without any read-back in between (the pipelined chain: k_dd_front, the previous
+scan's augmentation inside k_mid) on filters that can grow all session long (capacity 2 L, or L / 2 with auto-grow), compared with the
+oracle at the end of every burst."""
 import json, sys, time
 sys.path.insert(0, ".")
 import numpy as np
@@ -10,6 +13,7 @@ from tests.helpers import make_gpu, make_oracle, norm_match
 
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+burst_mode = len(sys.argv) > 3 and sys.argv[3] == "burst"
 bad = 0
 t_start = time.time()
 for seed in range(first, first + n_seeds):
@@ -24,7 +28,12 @@ for seed in range(first, first + n_seeds):
     sess = synth.make_session(cfg, max_scans=int(rng.integers(60, 220)) if L < 140 else int(rng.integers(300, 900)))
     lin, ang, obs = cfg.sigma_v ** 2, cfg.sigma_w ** 2, cfg.sigma_obs ** 2
     cap = L if rng.random() < 0.7 else max(4, L // 2)                     # sometimes a capacity the session overflows
+    if burst_mode:
+        cap = 2 * L if rng.random() < 0.5 else max(4, L // 2)
     g = make_gpu(model, sess.init_time, sess.init_pose, lin, ang, obs, cap)
+    if burst_mode and cap < L:
+        g.set_auto_grow(True)
+    burst_left = 0
     o = make_oracle(model, sess.init_time, sess.init_pose, lin, ang, obs)
     use_map, use_gps = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
     if use_map:
@@ -51,11 +60,22 @@ for seed in range(first, first + n_seeds):
             t -= 0.05
         gps = (sess.true_pose[e] + rng.normal(0, [0.03, 0.03, 0.01])) if (use_gps and rng.random() < 0.5) else None
         g.handle_observation(t, ob, gps)
-        if g.sync_code() != 0:                                             # capacity overflow: reported, state stays valid
-            overflow = True
-            break
-        o.handle_observation(t, ob, gps)
-        scans += 1
+        if burst_mode:
+            o.handle_observation(t, ob, gps)
+            scans += 1
+            if burst_left > 0:
+                burst_left -= 1
+                continue                                                       # no read-back of any kind inside a burst
+            burst_left = int(rng.integers(1, 12))
+            if g.sync_code() != 0:
+                overflow = True
+                break
+        else:
+            if g.sync_code() != 0:                                             # capacity overflow: reported, state stays valid
+                overflow = True
+                break
+            o.handle_observation(t, ob, gps)
+            scans += 1
         a, b = norm_match(g.last_match()), norm_match(o.last_match())
         if not all(np.array_equal(x, y) for x, y in zip(a, b)):
             assoc_bad += 1
