@@ -182,8 +182,9 @@ def rank_parity(cfg, sess, ekf, scans):
         ekf.handle_observation(t, ob)
         o.handle_observation(t, ob)
         mg = ekf.last_match()
+        gs, gn = (mg[0], mg[2]) if isinstance(mg, tuple) else (mg.state_obs_match_ids, mg.new_ids)
         sp, mp, nw = o.last_match()
-        same = same and bool(np.array_equal(mg.state_obs_match_ids, sp) and np.array_equal(mg.new_ids, nw))
+        same = same and bool(np.array_equal(np.asarray(gs).reshape(-1, 2), np.asarray(sp).reshape(-1, 2)) and np.array_equal(gn, nw))
     return float(np.abs(ekf.mu() - o.mu()).max()), same
 
 

@@ -175,6 +175,10 @@ class Stub:
     def sync(self): pass
     def mu(self): return self.o.mu()
     def last_match(self): return self.o.last_match()
+    def GetState(self):
+        from types import SimpleNamespace
+        mu, P = self.o.state()
+        return SimpleNamespace(time=self.o.time, mu=mu, sigma=P)
     n = property(lambda self: self.o.n)
 
 dist, rank, local_rank, world = D.init("gloo")
@@ -186,6 +190,8 @@ if rank == 0:
     r = out["ranks"]
     assert len(r["seeds"]) == 2 and r["seeds"][0] != r["seeds"][1] and r["final_n"] == [27, 27]
     assert r["updates_per_s_min"] <= r["updates_per_s_median"] <= r["updates_per_s_max"]
+    # every rank's record carries its parity figure (SURVEY 8(e)); here the oracle replays against itself on both ranks
+    assert r["max_abs_err_vs_oracle"] == [0.0, 0.0]
     # whole-job value = all ranks' steps / the slowest rank's time  <=  sum of the per-rank rates
     assert 0 < out["value"] <= 2 * r["updates_per_s_max"] * (1 + 1e-9)
     assert abs(out["value"] - 2 * 7 / (out["ms_per_step"] * 1e-3 * 7)) < 1e-6 * out["value"]
