@@ -201,6 +201,55 @@ __device__ static inline void argmin2_combine(double &a1, int &ja, double &a2, d
     if (take) { a1 = b1; ja = jb; }
     a2 = n2;
 }
+// One wave: the scan's per-observation match results (kind, landmark / map index; lane = observation, K <= 32) -> the record k_mid
+// works with (RekfCtl::Rec): ordered compaction by observation, the rank of every matched landmark among the matched ones (ties by
+// observation: neighbouring landmarks share cache lines of a column of P, k_mid's gathers run over the row slots in this order), the
+// slots of the sub-block, the getters' counts.  `rec` is global memory (the front end's last workgroup, for the k_mid behind the
+// kernel boundary) or LDS (every mid workgroup for itself, when the front end runs inside k_mid's own grid).
+__device__ static inline void compact_record(RekfCtl::Rec *rec, RekfCtl *ctl, int kind, int oidx, int lane, int K, int n, int n_max, int has_gps)
+{
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const unsigned long long ms = __ballot(kind == 1);
+    const unsigned long long mm = __ballot(kind == 0);
+    const unsigned long long mn = __ballot(kind == 2);
+    const int M = __popcll(ms), Mm = __popcll(mm);
+    int N2 = __popcll(mn);
+    const int room = (n_max - n) / 2;
+    if (N2 > room) {                                               // capacity guard (ours)
+        if (lane == 0) atomicOr(&ctl->err, REKF_FLAG_CAPACITY);
+        N2 = room;
+    }
+    int rk = 0;
+    {
+        const int key = (kind == 1) ? oidx : 0x7fffffff;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {                               // K <= 32 observations in a whole scan
+            const int oq = __builtin_amdgcn_readlane(key, q);
+            rk += (oq < key || (oq == key && q < lane)) ? 1 : 0;
+        }
+    }
+    if (kind == 1) {
+        const int p = __popcll(ms & lt);
+        if (p < 32) {
+            rec->pair_obs[p] = lane; rec->pair_id[p] = oidx; rec->pair_state[p] = 1;
+            rec->rank[p] = rk;
+            rec->urow[2 + rk] = 3 + 2 * oidx; rec->ukc[2 + rk] = 3 + 2 * p;
+        }
+    } else if (kind == 0) {
+        const int p = __popcll(mm & lt);
+        if (M + p < 32) { rec->pair_obs[M + p] = lane; rec->pair_id[M + p] = oidx; rec->pair_state[M + p] = 0; }
+    } else if (kind == 2) {
+        const int p = __popcll(mn & lt);
+        if (p < N2) rec->newid[p] = lane;
+    }
+    if (lane == 0) {
+        const int MM = M + Mm;
+        const int m = (MM > 0) ? 2 * MM + (has_gps ? 3 : 0) : 0;
+        rec->cnt[0] = MM; rec->cnt[1] = m; rec->cnt[2] = (m + 15) & ~15; rec->cnt[3] = M; rec->cnt[4] = (has_gps && MM > 0) ? 1 : 0;
+        rec->cnt[5] = N2; rec->cnt[6] = Mm; rec->cnt[7] = K;
+        rec->urow[0] = 0; rec->ukc[0] = 0; rec->urow[1] = 2; rec->ukc[1] = 2;
+    }
+}
 // The front end as a ROLE of a workgroup of NT threads (a multiple of 256): k_front_mb below is nothing else; the fused kernel
 // k_dd_front runs it in the workgroups behind its downdate workgroups.  corner_in_ctl: the pose block to predict from is
 // RekfCtl::post_C9 (what k_mid evaluated for the previous scan) -- in k_dd_front the previous scan's downdate, which stores that block
@@ -393,75 +442,23 @@ __device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs
                 __hip_atomic_store(&ctl->obs_kind[i], kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&ctl->obs_idx[i], best_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const unsigned old = __hip_atomic_fetch_add(&ctl->front_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (old + 1u == A.front_target) s_last = 1;
+                if (A.front_in_mid) (void)__hip_atomic_fetch_add(&ctl->front_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (nobody to elect: no returning round trip)
+                else {
+                    const unsigned old = __hip_atomic_fetch_add(&ctl->front_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (old + 1u == A.front_target) s_last = 1;
+                }
             }
         }
     }
     FMARK();                                          // 3: match done
-    // ---- the last workgroup to finish compacts the scan's results for k_mid (RekfCtl::rec): ordered compaction by observation, the
-    // rank of every matched landmark among the matched ones (ties by observation), the slots of the sub-block, the getters' counts
+    // ---- the last workgroup to finish compacts the scan's results for the k_mid behind the kernel boundary (RekfCtl::rec).  Inside
+    // k_mid's own grid (A.front_in_mid) nobody does: the mid workgroups wait for front_count and compact for themselves
     __syncthreads();
-    if (A.compact_in_front && s_last && tid < 64) {
-        RekfCtl::Rec *rec = &ctl->rec;
+    if (A.compact_in_front && !A.front_in_mid && s_last && tid < 64) {
         const int lane = tid;
         const int kind = (lane < K) ? __hip_atomic_load(&ctl->obs_kind[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
         const int oidx = (lane < K) ? __hip_atomic_load(&ctl->obs_idx[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
-        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        const unsigned long long ms = __ballot(kind == 1);
-        const unsigned long long mm = __ballot(kind == 0);
-        const unsigned long long mn = __ballot(kind == 2);
-        const int M = __popcll(ms), Mm = __popcll(mm);
-        int N2 = __popcll(mn);
-        const int room = (d.n_max - n) / 2;
-        if (N2 > room) {                                               // capacity guard (ours)
-            if (lane == 0) atomicOr(&ctl->err, REKF_FLAG_CAPACITY);
-            N2 = room;
-        }
-        // position of a state pair's landmark rows among the matched ones, by landmark (ties: by lane): neighbouring landmarks share
-        // cache lines of a column of P, so k_mid's gathers run over the row slots in this order
-        int rk = 0;
-        {
-            const int key = (kind == 1) ? oidx : 0x7fffffff;
-#pragma unroll
-            for (int q = 0; q < 32; ++q) {                               // K <= 32 observations in a whole scan
-                const int oq = __builtin_amdgcn_readlane(key, q);
-                rk += (oq < key || (oq == key && q < lane)) ? 1 : 0;
-            }
-        }
-        // (inside k_mid's grid the record is taken over within the launch: written through at agent scope -- no release fence, which
-        // writes the whole L2 back -- and flagged below; elsewhere these are plain stores and the kernel boundary publishes them)
-        const bool wt = A.front_in_mid != 0;
-        auto put = [&](int *p_, int v_) __attribute__((always_inline)) {
-            if (wt) __hip_atomic_store(p_, v_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p_ = v_;
-        };
-        if (kind == 1) {
-            const int p = __popcll(ms & lt);
-            if (p < 32) {
-                put(&rec->pair_obs[p], lane); put(&rec->pair_id[p], oidx); put(&rec->pair_state[p], 1);
-                put(&rec->rank[p], rk);
-                put(&rec->urow[2 + rk], 3 + 2 * oidx); put(&rec->ukc[2 + rk], 3 + 2 * p);
-            }
-        } else if (kind == 0) {
-            const int p = __popcll(mm & lt);
-            if (M + p < 32) { put(&rec->pair_obs[M + p], lane); put(&rec->pair_id[M + p], oidx); put(&rec->pair_state[M + p], 0); }
-        } else if (kind == 2) {
-            const int p = __popcll(mn & lt);
-            if (p < N2) put(&rec->newid[p], lane);
-        }
-        if (lane == 0) {
-            const int MM = M + Mm;
-            const int m = (MM > 0) ? 2 * MM + (A.has_gps ? 3 : 0) : 0;
-            put(&rec->cnt[0], MM); put(&rec->cnt[1], m); put(&rec->cnt[2], (m + 15) & ~15); put(&rec->cnt[3], M); put(&rec->cnt[4], (A.has_gps && MM > 0) ? 1 : 0);
-            put(&rec->cnt[5], N2); put(&rec->cnt[6], Mm); put(&rec->cnt[7], K);
-            put(&rec->urow[0], 0); put(&rec->ukc[0], 0); put(&rec->urow[1], 2); put(&rec->ukc[1], 2);
-        }
-        if (A.front_in_mid) {
-            // inside k_mid's grid: the workgroups that take the record from here are waiting in this very launch (other CUs, other
-            // XCDs) -- the record out of this CU's caches, then the scan's number as the flag
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // (every lane's write-through stores have left)
-            if (__ballot(true) && lane == 0) __hip_atomic_store(&ctl->rec_seq, A.scan_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        compact_record(&ctl->rec, ctl, kind, oidx, lane, K, n, d.n_max, A.has_gps);
     }
 #ifdef REKF_DEBUG_FRONT
     if (recf) {
@@ -905,10 +902,20 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     const bool steam = wave < 4;                  // S team; the other is the "own" team
     const int tt = tid & 255;                     // thread index within the team
     if (FRONT) {
-        if (tid == 0) {
-            unsigned spins = 0;
-            while ((int)(__hip_atomic_load(&ctl->rec_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - A.scan_id) < 0 && ++spins < (1u << 22))
-                __builtin_amdgcn_s_sleep(2);
+        // every observation's result is in memory once the front end's count has reached the scan's target (each front workgroup
+        // writes its result through, drains, then counts): wave 0 polls on one lane, takes the K results past this CU's L1 and
+        // compacts them into the record for itself -- no compacting workgroup, no second hand-over
+        if (tid < 64) {
+            if (tid == 0) {
+                unsigned spins = 0;
+                while ((int)(__hip_atomic_load(&ctl->front_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - A.front_target) < 0 && ++spins < (1u << 22))
+                    __builtin_amdgcn_s_sleep(2);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int kind = (tid < A.K) ? __hip_atomic_load(&ctl->obs_kind[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+            const int oidx = (tid < A.K) ? __hip_atomic_load(&ctl->obs_idx[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+            const int n_rec = (d.n_known >= 0) ? d.n_known : ctl->n;             // (the front role's own n: a scan behind a read-back knows it)
+            compact_record(&s_rec, ctl, kind, oidx, tid, A.K, n_rec, d.n_max, A.has_gps);
         }
         __syncthreads();
     }
@@ -916,9 +923,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     // scalar one, so the control block costs one memory round trip, not two
     constexpr int NREC = (int)(sizeof(RekfCtl::Rec) / sizeof(int));
     static_assert(NREC <= 512, "one load per thread");
-    // (behind an in-grid front role: past this CU's L1 -- the record was written through by another CU a moment ago)
-    const int rec_raw = (tid < NREC) ? (FRONT ? __hip_atomic_load(&((const int *)&ctl->rec)[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                                               : ((const int *)&ctl->rec)[tid]) : 0;
+    const int rec_raw = (!FRONT && tid < NREC) ? ((const int *)&ctl->rec)[tid] : 0;
 #ifdef REKF_DEBUG_MID_FIRST
     MMARK();                                        // (x0: first loads issued)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1019,7 +1024,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
         }
     } else if (A.pair0 < 0) {
         // whole scan: the record the front end left (its last workgroup compacted the results, front_role) -- one load, one LDS store
-        if (tid < NREC) ((int *)&s_rec)[tid] = rec_raw;
+        if (!FRONT && tid < NREC) ((int *)&s_rec)[tid] = rec_raw;                 // (FRONT: compacted above)
     }
 #ifdef REKF_DEBUG_MID_FIRST
     MMARK();                                        // (x4: wave 0 through the compaction)
