@@ -63,8 +63,12 @@ enum {
 
 /* Sticky device-side condition bits (rekf_get_flags): the state kept growing past max_landmarks and the extra
  * reflectors of a scan were dropped (the reference grows without bound, reflector_ekf_slam.cc:311-364); the
- * innovation covariance S of some scan had a non-positive pivot (the update was applied as computed). */
-enum { REKF_FLAGBIT_CAPACITY = 1, REKF_FLAGBIT_SINGULAR = 2 };
+ * innovation covariance S of some scan had a non-positive pivot (the update was applied as computed); a hand-over INSIDE a launch
+ * (workgroups of k_mid waiting for the scan's front end or the previous scan's augmentation, which run as other workgroups of the same
+ * launch when this handle is the only one at work on the GPU) gave up waiting -- the state is no longer meaningful; rekf_sync returns
+ * REKF_ERR_HIP.  Cannot happen unless other work holds the GPU's CUs for a fraction of a second (several PROCESSES sharing the GPU:
+ * set REKF_FRONT_IN_MID=0 and REKF_AUG_IN_MID=0 in their environment; handles of ONE process are noticed and handled). */
+enum { REKF_FLAGBIT_CAPACITY = 1, REKF_FLAGBIT_SINGULAR = 2, REKF_FLAGBIT_STARVED = 4 };
 
 enum { REKF_ODOM_DIFF = 0, REKF_ODOM_OMNI = 1 };   /* sensor::OdometryModel, sensor_data.h:56-60 */
 

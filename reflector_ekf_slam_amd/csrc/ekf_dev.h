@@ -29,7 +29,7 @@
 #define REKF_PANEL_COLS 64                          // columns of Kn / HPt: one block step of the update has at most 64 innovation rows
 #define REKF_STRIP_MAX 4                            // border rows (n mod 64) that k_downdate handles as strips
 
-enum { REKF_FLAG_CAPACITY = 1, REKF_FLAG_SINGULAR = 2 };
+enum { REKF_FLAG_CAPACITY = 1, REKF_FLAG_SINGULAR = 2, REKF_FLAG_STARVED = 4 };
 
 struct RekfCtl {
     int n;                    // committed state dimension (3 + 2 L)

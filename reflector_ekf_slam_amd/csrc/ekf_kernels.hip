@@ -910,6 +910,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
                 unsigned spins = 0;
                 while ((int)(__hip_atomic_load(&ctl->front_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - A.front_target) < 0 && ++spins < (1u << 22))
                     __builtin_amdgcn_s_sleep(2);
+                if (spins >= (1u << 22)) atomicOr(&ctl->err, REKF_FLAG_STARVED);       // (never alone on the GPU: see rekf_api.hip, in_grid_ok)
             }
             __builtin_amdgcn_wave_barrier();
             const int kind = (tid < A.K) ? __hip_atomic_load(&ctl->obs_kind[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
@@ -964,6 +965,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
             unsigned spins = 0;
             while ((int)(__hip_atomic_load(&ctl->aug_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - A.scan_id) < 0 && ++spins < (1u << 22))
                 __builtin_amdgcn_s_sleep(4);
+            if (spins >= (1u << 22)) atomicOr(&ctl->err, REKF_FLAG_STARVED);
         }
         if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __syncthreads();

@@ -11,6 +11,7 @@
 #include "ekf_dev.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -88,6 +89,7 @@ struct rekf {
     RekfCtl *ctl_staging;      // pinned copy of the control block
     std::string hip_error;
     int flags_seen = 0;        // sticky device flags already reported on stderr
+    int activity_slot = -1;    // this handle's entry in the process-wide activity table (WHO ELSE IS AT WORK ON THE GPU)
     int inject_failure = 0;    // rekf_debug_inject_failure: the next HandleObservationMessage fails at this stage
     double *dev_ell;           // device scratch for k_ellipses (5 doubles per landmark of capacity)
     double *dev_pred;          // device scratch for k_predict_rows (4 * ld + 12 doubles)
@@ -108,6 +110,36 @@ struct rekf {
 };
 
 namespace {
+
+// WHO ELSE IS AT WORK ON THE GPU.  Two of the round-4 launches contain workgroups that WAIT for other workgroups of the same launch
+// (k_mid's mid workgroups for the scan's front end / the previous scan's augmentation).  That is deadlock-free while the launch's
+// waiting workgroups cannot keep its working ones off the CUs: alone on the GPU the grid's first 256 workgroups are resident
+// together.  With several sessions enqueueing at once it is not -- each XCD places its share of a grid by itself, the waiting
+// workgroups of one session can hold the CUs another session's front workgroups need, and vice versa (found by
+// scripts/gpu_stress_sessions.py: six sessions, timeouts).  So every handle stamps its enqueues here, and a handle uses the in-launch
+// hand-overs only when no OTHER handle of this process has enqueued anything for a while; otherwise it falls back to the separate
+// launches (k_front_mb, k_augment).  Other processes cannot be seen: REKF_FRONT_IN_MID=0 / REKF_AUG_IN_MID=0 there (rekf.h).
+constexpr int ACTIVITY_SLOTS = 256;
+std::atomic<long long> g_activity[ACTIVITY_SLOTS];      // steady-clock ns of a handle's last enqueue; 0 = slot free
+long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+int activity_claim()
+{
+    for (int i = 0; i < ACTIVITY_SLOTS; ++i) { long long z = 0; if (g_activity[i].compare_exchange_strong(z, 1)) return i; }
+    return -1;
+}
+// stamps this handle's slot; true if no other handle has enqueued within the last 5 ms
+bool alone_on_gpu(int slot)
+{
+    const long long t = now_ns();
+    if (slot < 0) return false;
+    g_activity[slot].store(t, std::memory_order_relaxed);
+    for (int i = 0; i < ACTIVITY_SLOTS; ++i) {
+        if (i == slot) continue;
+        const long long o = g_activity[i].load(std::memory_order_relaxed);
+        if (o > 1 && t - o < 5000000LL) return false;
+    }
+    return true;
+}
 
 #define HIP_TRY(h, expr)                                                         \
     do {                                                                         \
@@ -213,6 +245,7 @@ void fill_front_args(const rekf_t *h, RekfFrontArgs &a, double dt)
 
 int device_flags_to_code(int flags)
 {
+    if (flags & REKF_FLAG_STARVED) return REKF_ERR_HIP;
     if (flags & REKF_FLAG_SINGULAR) return REKF_ERR_SINGULAR;
     if (flags & REKF_FLAG_CAPACITY) return REKF_ERR_CAPACITY;
     return REKF_OK;
@@ -226,6 +259,11 @@ void report_flags(rekf_t *h, int flags)
     if (fresh & REKF_FLAG_CAPACITY)
         std::fprintf(stderr, "rekf: landmark capacity (max_landmarks = %d) exceeded: new reflectors are being DROPPED "
                              "(the reference grows its state without bound)\n", h->max_landmarks);
+    if (fresh & REKF_FLAG_STARVED) {
+        std::fprintf(stderr, "rekf: a hand-over inside a launch gave up waiting (other work held the GPU's CUs): the filter state is not meaningful any more; "
+                             "set REKF_FRONT_IN_MID=0 REKF_AUG_IN_MID=0 when several processes share the GPU\n");
+        h->hip_error = "an in-launch hand-over starved (REKF_FLAGBIT_STARVED)";
+    }
     if (fresh & REKF_FLAG_SINGULAR)
         std::fprintf(stderr, "rekf: innovation covariance was not positive definite in some scan; the update was applied as computed\n");
     h->flags_seen |= flags;
@@ -448,6 +486,7 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
     h->opt = *opt;
     h->device = device;
     h->max_landmarks = max_landmarks;
+    h->activity_slot = activity_claim();
     h->time = opt->init_time;                         // cc:8
     h->vt[0] = h->vt[1] = h->vt[2] = 0.0;             // cc:6
     h->n_ub = 3;
@@ -514,6 +553,7 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
 void rekf_destroy(rekf_t *h)
 {
     if (!h) return;
+    if (h->activity_slot >= 0) g_activity[h->activity_slot].store(0);
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &s : h->prof_slots) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
@@ -658,6 +698,7 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         if (rcf != REKF_OK) return rcf;
     }
     // ---- from here on: host bookkeeping and launches only
+    const bool alone = alone_on_gpu(h->activity_slot);     // (in-launch hand-overs only then: see WHO ELSE IS AT WORK ON THE GPU)
     h->last_scan_empty = false;
     RekfFrontArgs a;
     fill_front_args(h, a, t - h->time);               // cc:232 (dt may be negative, Q8)
@@ -701,12 +742,12 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_dd_front(h->dd_dev, h->dd_n_ub, h->dev, a, h->stream); }
         // the previous scan's augmentation: inside this scan's k_mid (its workgroup 0 appends the rows first thing -- no launch of its
         // own between the two scans; whole scans on both sides), else as k_augment right behind the downdate
-        const bool inline_aug = h->dd_aug && h->aug_in_mid && h->dd_aug_inline_ok && !blocks;
+        const bool inline_aug = alone && h->dd_aug && h->aug_in_mid && h->dd_aug_inline_ok && !blocks;
         if (h->dd_aug && !inline_aug) { ProfScope ps(h, REKF_K_AUGMENT); rekf_launch_augment(h->dd_dev, h->dd_aug_args, h->stream); }
         h->dd_aug = false;
         a.aug_pending = 0;
         a.aug_in_mid = inline_aug ? 1 : 0;
-    } else if (h->front_in_mid && a.host_pred && !blocks && !staged && K <= 32) {
+    } else if (alone && h->front_in_mid && a.host_pred && !blocks && !staged && K <= 32) {
         // behind a pose read-back the front end is a match only (pose, cos / sin, pose block go by value): it runs as the first
         // workgroups of k_mid's own grid, one observation each, and hands the record over inside the launch
         a.front_in_mid = K;

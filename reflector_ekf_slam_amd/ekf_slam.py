@@ -233,7 +233,7 @@ class ReflectorEKFSLAM:
         return State(float(time), np.array(mu3[:]), np.array(s9[:]).reshape(3, 3).T.copy())
 
     def flags(self) -> int:
-        """Sticky device-side condition bits (REKF_FLAGBIT_CAPACITY = 1, REKF_FLAGBIT_SINGULAR = 2), not cleared."""
+        """Sticky device-side condition bits (REKF_FLAGBIT_CAPACITY = 1, REKF_FLAGBIT_SINGULAR = 2, REKF_FLAGBIT_STARVED = 4), not cleared."""
         f = C.c_int()
         self._chk(self._L.rekf_get_flags(self._h, C.byref(f)), "get_flags")
         return f.value

@@ -136,3 +136,44 @@ def test_device_layout_includes_the_predicts_the_host_applied_to_its_mirror(orac
     assert np.abs(Pcol[:n, :n][low] - Po[low]).max() < 1e-11
     st = g.GetState()
     assert np.array_equal(st.mu, mu_raw)
+
+
+@pytest.mark.parametrize("readback", [True, False], ids=["pose_read_back", "pipelined"])
+def test_several_sessions_on_one_gpu_end_bit_identical_to_a_lone_one(readback):
+    """Two of the round-4 launches contain workgroups that WAIT for other workgroups of the same launch (k_mid's mid workgroups for the
+    scan's front end / for the previous scan's augmentation).  Alone on the GPU that is deadlock-free; with several sessions enqueueing at
+    once the waiting workgroups of one can hold the CUs another one's working workgroups need (scripts/gpu_stress_sessions.py found it:
+    six sessions, timed-out waits, garbage).  The library therefore uses the in-launch hand-overs only while no other handle of the
+    process is at work (rekf_api.hip: WHO ELSE IS AT WORK ON THE GPU): six handles driven round-robin -- growing filters, with and without
+    read-backs -- must each end bit-identical to a handle that ran the same session alone, without a sticky flag."""
+    from reflector_ekf_slam_amd import ReflectorEKFSLAM
+    from reflector_ekf_slam_amd import session as S
+    cfg = synth.SessionConfig("r4_sessions", 160, 20, synth.DIFF, seed=4410, speed=1.5, row_spacing=6.0)
+    sess = synth.make_session(cfg)
+
+    def run(handles):
+        first = True
+        for e in range(sess.n_events):
+            t = float(sess.ev_time[e])
+            if sess.ev_type[e] == synth.EV_ODOM:
+                for g in handles:
+                    g.handle_odometry(t, *sess.odom[e])
+                continue
+            if first:
+                first = False
+                continue
+            ob = sess.obs_of(e)
+            for g in handles:
+                g.handle_observation(t, ob)
+            if readback:
+                for g in handles:
+                    g.pose()
+        for g in handles:
+            assert g.sync_code() == 0 and g.flags() == 0
+        return [g.GetState() for g in handles]
+
+    lone = run([ReflectorEKFSLAM(S.options_for(sess), max_landmarks=8)])[0]          # (default wrapper: grows 8 -> 16 -> ... on the way)
+    many = run([ReflectorEKFSLAM(S.options_for(sess), max_landmarks=8) for _ in range(6)])
+    assert lone.mu.shape[0] == 3 + 2 * 160
+    for st in many:
+        assert np.array_equal(st.mu, lone.mu) and np.array_equal(st.sigma, lone.sigma)
