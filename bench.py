@@ -209,7 +209,7 @@ def run_rank(args, dist_mod, rank, local_rank, world, make_filter=gpu_filter_fac
     if n != n_expect:
         raise SystemExit(f"warm-up ended with n={n}, expected {n_expect}")
 
-    n_extra = 16 + 2 * max(args.latency_steps, 0) + max(args.instr_steps, 0) + 2 * max(args.steps, 200) + max(args.rank_parity_steps, 0) + 600
+    n_extra = 16 + 3 * max(args.latency_steps, 0) + max(args.instr_steps, 0) + 2 * max(args.steps, 200) + max(args.rank_parity_steps, 0) + 700
     steady = synth.steady_state_scans(sess, args.warmup + args.steps + n_extra)
     m = 2 * steady[0][1].shape[0]
 
@@ -369,7 +369,7 @@ def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world, cha
     pos += args.instr_steps
     # (the chain's us per update from a window of its own, 500 updates: the driver's 20-step timed region carries its pipeline fill and
     # its closing synchronisations 25 times harder, which is not kernel time)
-    if len(rest) - pos >= 550:
+    if len(rest) - pos >= 500:
         ekf.sync()
         t0c = time.perf_counter()
         for t, ob in rest[pos:pos + 500]:
