@@ -9,15 +9,15 @@
 //                 and its scan                                                          (:31-39)
 //   k3_scatter,   the survivors in Morton order of a 128 x 128 grid over (x, y) + the bounding box of every 32
 //   k3_boxes      consecutive ones: what lets the two neighbour searches below skip almost everything
-//   k3_knn        StatisticalOutlierRemoval part 1: per point the MeanK+1 = 31 smallest float32
-//                 squared distances (the query first); lane = point, candidates through the
-//                 scalar cache, the sorted list lives in registers (min/max insertion chain), eight waves
-//                 share the candidate tiles of 64 points and one admission bound; a tile whose box is farther
-//                 than every lane's bound is skipped                                   (:43-47)
+//   k3_knn        StatisticalOutlierRemoval part 1: per point the MeanK+1 = 31 smallest float32 squared distances (the
+//                 query first).  ONE WAVE PER QUERY, lane = candidate: the 64 smallest distances so far live one per lane
+//                 (wave-level bitonic networks on DPP / permlane swaps), tiles are opened nearest first and only while
+//                 their box is nearer than the query's current 31st distance                (:43-47)
 //   k3_sor        part 2: mean / (n-1)-variance in FP64, threshold; outliers masked in the sorted copy
-//   k3_cc_*       EuclideanClusterExtraction as connected components of the radius-0.2 m graph: smallest-neighbour
-//                 pointers, a snapshot of the chain tops, then a lock-free union-find for the few adjacent pairs whose
-//                 tops differ (roots are only ever hooked under smaller roots: the label is the smallest index) (:65-74)
+//   k3_cc_min,    EuclideanClusterExtraction as connected components of the radius-0.2 m graph, one wave per query over the
+//   k3_cc_link    tiles whose box lies within 0.2 m: smallest-neighbour pointers, then a lock-free union-find for the few
+//                 adjacent pairs whose chain tops differ (roots are only ever hooked under smaller roots: the label is the
+//                 smallest arrival index)                                                 (:65-74)
 //   k3_finish_a   final roots, component sizes and extents in the sorted copy, the list of roots (over the CUs)
 //   k3_clusters   size gate [4,160], order (size desc, first index asc), float32 centroids in index order (one wave
 //                 per component, spread over the CUs), Rigid2f to base_link             (:70-71, :77-97)
@@ -51,10 +51,9 @@ constexpr int MIN_SZ = 4, MAX_SZ = 160;      // :70-71
 // ring by ring: one post is spread over all rings, so in arrival order every 64 points needed every other point.  The
 // survivors of the intensity gate are therefore brought into MORTON ORDER of a GRID_G x GRID_G grid over (x, y) (one
 // counting sort: histogram beside the gate, scan beside the compaction, scatter), every BOX_PTS consecutive points get
-// their bounding box, and the sweeps -- unchanged otherwise: lane = query, candidates through the scalar cache -- first
-// test a candidate tile's box against each lane's own bound and skip it when no lane can use it.  Nothing of the result
-// depends on the order: the k-NN multiset is exact (a tile is skipped only if its box is farther than the lane's current
-// 31st distance, with a margin far above the float32 rounding of both sides), node ids stay the ARRIVAL indices (labels =
+// their bounding box, and the sweeps test a candidate tile's box against the query's own bound before they open it.  Nothing
+// of the result depends on the order: the k-NN multiset is exact (a tile is skipped only if its box is farther than the query's
+// current 31st distance, with a margin far above the float32 rounding of both sides), node ids stay the ARRIVAL indices (labels =
 // smallest arrival index, centroids summed in arrival order), so neither the grid's placement nor the order of the
 // points inside a cell (atomic cursors: not deterministic) is visible in the output.
 constexpr int GRID_G = 128, GRID_CELLS = GRID_G * GRID_G;
@@ -104,7 +103,7 @@ struct Det3dBufs {
 };
 
 #ifdef RDET_DEBUG_MARKS
-// in-kernel timeline of k3_knn: wall_clock64() (100 MHz) per workgroup and phase; scripts/gpu_dbg_det3d.py
+// in-kernel timelines (k3_clusters, k3_cc_link): wall_clock64() (100 MHz) per workgroup and phase; scripts/gpu_dbg_det3d.py
 __device__ unsigned long long d3_marks[2048][8];
 #define D3_MARK(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) d3_marks[blockIdx.x][i] = wall_clock64(); } while (0)
 #else
