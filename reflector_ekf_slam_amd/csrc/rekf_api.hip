@@ -38,6 +38,10 @@ struct rekf {
     int max_landmarks;
     hipStream_t stream;
     RekfDev dev;
+    // the Kn / HPt panels (and their border copies) exist twice, by scan parity: k_mid of scan t writes one set, the held-back downdate of
+    // scan t reads it -- possibly inside the launch in which scan t+1's k_mid role writes the other (one-launch small states)
+    double *panel_base[4] = {nullptr, nullptr, nullptr, nullptr};     // HPt, Kn (2 x ld x 64 each), HPtB, KnB (2 x STRIP_MAX x MR_PAD each)
+    int panel_par = 0;
     double time;
     double vt[3];
     int n_ub;                  // host upper bound of the device-resident n
@@ -426,30 +430,41 @@ int alloc_buffers(rekf_t *h, int max_landmarks, DevBuffers &b)
     HIP_TRY(h, hipMalloc(&b.mu, sizeof(double) * ld));
     HIP_TRY(h, hipMalloc(&b.mu_out, sizeof(double) * ld));
     HIP_TRY(h, hipMalloc(&b.P, sizeof(double) * (size_t)ld * ld));
-    HIP_TRY(h, hipMalloc(&b.HPt, sizeof(double) * (size_t)ld * REKF_PANEL_COLS));
-    HIP_TRY(h, hipMalloc(&b.Kn, sizeof(double) * (size_t)ld * REKF_PANEL_COLS));
+    HIP_TRY(h, hipMalloc(&b.HPt, sizeof(double) * 2 * (size_t)ld * REKF_PANEL_COLS));      // (both parities, struct rekf)
+    HIP_TRY(h, hipMalloc(&b.Kn, sizeof(double) * 2 * (size_t)ld * REKF_PANEL_COLS));
     HIP_TRY(h, hipMalloc(&b.dev_pred, sizeof(double) * (4 * (size_t)ld + 16)));
     HIP_TRY(h, hipMalloc(&b.dev_mu_lin, sizeof(double) * ld));
     HIP_TRY(h, hipMalloc(&b.dev_ell, sizeof(double) * 5 * (size_t)(max_landmarks > 0 ? max_landmarks : 1)));
     HIP_TRY(h, hipMemsetAsync(b.mu, 0, sizeof(double) * ld, h->stream));
     HIP_TRY(h, hipMemsetAsync(b.mu_out, 0, sizeof(double) * ld, h->stream));
     HIP_TRY(h, hipMemsetAsync(b.P, 0, sizeof(double) * (size_t)ld * ld, h->stream));              // cc:10-11
-    HIP_TRY(h, hipMemsetAsync(b.HPt, 0, sizeof(double) * (size_t)ld * REKF_PANEL_COLS, h->stream));
-    HIP_TRY(h, hipMemsetAsync(b.Kn, 0, sizeof(double) * (size_t)ld * REKF_PANEL_COLS, h->stream));
+    HIP_TRY(h, hipMemsetAsync(b.HPt, 0, sizeof(double) * 2 * (size_t)ld * REKF_PANEL_COLS, h->stream));
+    HIP_TRY(h, hipMemsetAsync(b.Kn, 0, sizeof(double) * 2 * (size_t)ld * REKF_PANEL_COLS, h->stream));
     return REKF_OK;
 }
 void adopt_buffers(rekf_t *h, const DevBuffers &b, int max_landmarks)
 {
     h->dev.mu = b.mu; h->dev.mu_out = b.mu_out; h->dev.P = b.P; h->dev.HPt = b.HPt; h->dev.Kn = b.Kn;
+    h->panel_base[0] = b.HPt; h->panel_base[1] = b.Kn;
+    h->panel_par = 0;
+    if (h->panel_base[2]) { h->dev.HPtB = h->panel_base[2]; h->dev.KnB = h->panel_base[3]; }
     h->dev_pred = b.dev_pred; h->dev_mu_lin = b.dev_mu_lin; h->dev_ell = b.dev_ell;
     h->dev.ld = b.ld; h->dev.n_max = b.n_max;
     h->dev.mu_lin = nullptr;
     h->max_landmarks = max_landmarks;
 }
+// the other set of panels for the next k_mid (call once the scan's downdate has taken its copy of the device view)
+void flip_panels(rekf_t *h)
+{
+    h->panel_par ^= 1;
+    const size_t po = (size_t)h->panel_par * (size_t)h->dev.ld * REKF_PANEL_COLS, bo = (size_t)h->panel_par * REKF_STRIP_MAX * REKF_MR_PAD;
+    h->dev.HPt = h->panel_base[0] + po; h->dev.Kn = h->panel_base[1] + po;
+    h->dev.HPtB = h->panel_base[2] + bo; h->dev.KnB = h->panel_base[3] + bo;
+}
 DevBuffers current_buffers(const rekf_t *h)
 {
     DevBuffers b;
-    b.mu = h->dev.mu; b.mu_out = h->dev.mu_out; b.P = h->dev.P; b.HPt = h->dev.HPt; b.Kn = h->dev.Kn;
+    b.mu = h->dev.mu; b.mu_out = h->dev.mu_out; b.P = h->dev.P; b.HPt = h->panel_base[0]; b.Kn = h->panel_base[1];
     b.dev_pred = h->dev_pred; b.dev_mu_lin = h->dev_mu_lin; b.dev_ell = h->dev_ell; b.ld = h->dev.ld; b.n_max = h->dev.n_max;
     return b;
 }
@@ -514,8 +529,9 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
         int rb = alloc_buffers(h, max_landmarks, b);
         if (rb != REKF_OK) { free_buffers(b); return rb; }
         adopt_buffers(h, b, max_landmarks);
-        HIP_TRY(h, hipMalloc(&h->dev.KnB, sizeof(double) * REKF_STRIP_MAX * REKF_MR_PAD));
-        HIP_TRY(h, hipMalloc(&h->dev.HPtB, sizeof(double) * REKF_STRIP_MAX * REKF_MR_PAD));
+        HIP_TRY(h, hipMalloc(&h->panel_base[3], sizeof(double) * 2 * REKF_STRIP_MAX * REKF_MR_PAD));
+        HIP_TRY(h, hipMalloc(&h->panel_base[2], sizeof(double) * 2 * REKF_STRIP_MAX * REKF_MR_PAD));
+        h->dev.KnB = h->panel_base[3]; h->dev.HPtB = h->panel_base[2];
         HIP_TRY(h, hipMalloc(&h->dev_obs, sizeof(float) * 2 * REKF_MAX_OBS_WIDE));
         HIP_TRY(h, hipHostMalloc(&h->obs_staging, sizeof(float) * 2 * REKF_MAX_OBS_WIDE));
         HIP_TRY(h, hipEventCreateWithFlags(&h->obs_staging_ev, hipEventDisableTiming));
@@ -528,8 +544,8 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
         HIP_TRY(h, hipHostMalloc(&h->ctl_staging, sizeof(RekfCtl)));
         h->dev.M_map = 0;
         HIP_TRY(h, hipMemsetAsync(h->dev.ctl, 0, sizeof(RekfCtl), h->stream));
-        HIP_TRY(h, hipMemsetAsync(h->dev.KnB, 0, sizeof(double) * REKF_STRIP_MAX * REKF_MR_PAD, h->stream));
-        HIP_TRY(h, hipMemsetAsync(h->dev.HPtB, 0, sizeof(double) * REKF_STRIP_MAX * REKF_MR_PAD, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->dev.KnB, 0, sizeof(double) * 2 * REKF_STRIP_MAX * REKF_MR_PAD, h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->dev.HPtB, 0, sizeof(double) * 2 * REKF_STRIP_MAX * REKF_MR_PAD, h->stream));
         std::memset(h->ctl_staging, 0, sizeof(RekfCtl));
         h->ctl_staging->n = 3;
         HIP_TRY(h, hipMemcpyAsync(h->dev.ctl, h->ctl_staging, sizeof(int) * 2, hipMemcpyHostToDevice, h->stream));
@@ -559,7 +575,7 @@ void rekf_destroy(rekf_t *h)
     for (auto &s : h->prof_slots) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     DevBuffers b = current_buffers(h);
     free_buffers(b);
-    (void)hipFree(h->dev.ctl); (void)hipFree(h->dev.KnB); (void)hipFree(h->dev.HPtB);
+    (void)hipFree(h->dev.ctl); (void)hipFree(h->panel_base[3]); (void)hipFree(h->panel_base[2]);
     (void)hipFree(h->dev.map_xy); (void)hipFree(h->dev.map_cov); (void)hipFree(h->dev_obs);
     if (h->obs_staging) (void)hipHostFree(h->obs_staging);
     if (h->obs_staging_ev) (void)hipEventDestroy(h->obs_staging_ev);
@@ -769,6 +785,7 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         RekfDev dd = h->dev;
         dd.pred_slot = first ? pred_slot : -1;        // the scan's first downdate commits its Predict
         if (last && !early_pub) { dd.pub = h->host_slots_dev; dd.pub_seq = pub_seq; dd.pub_aug = aug ? 1 : 0; }     // ... its last one publishes (at its start)
+        flip_panels(h);                               // (dd has its own copy of the view: the next k_mid writes the other set)
         if (last && hold_back) { h->dd_pending = true; h->dd_dev = dd; h->dd_n_ub = n_ub; return; }     // (lazy downdate: with the next call)
         ProfScope ps(h, REKF_K_DOWNDATE);
         rekf_launch_downdate(dd, n_ub, h->stream);

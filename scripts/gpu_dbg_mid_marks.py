@@ -1,3 +1,7 @@
+"""k_mid's in-kernel timeline (workgroup 1, s_memtime marks) at a BASELINE configuration, from a -DREKF_DEBUG_TIMING build of librekf.so:
+    hipcc ... -DREKF_DEBUG_TIMING ... -o scripts/probe/librekf_dbg.so      (flags as in csrc/Makefile)
+    gpurun -- 'python scripts/gpu_dbg_mid_marks.py scripts/probe/librekf_dbg.so C2'
+Marks (us from the kernel's entry): record in, compaction, gathers issued, W, S built | inverse | gain, stores."""
 import sys, ctypes as C
 sys.path.insert(0, ".")
 import numpy as np

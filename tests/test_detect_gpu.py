@@ -280,6 +280,33 @@ def test_detect3d_results_do_not_depend_on_the_sorting_grid(oracle_lib):
     g.close()
 
 
+def test_detect3d_non_finite_and_coincident_points(oracle_lib):
+    """What a LiDAR driver really sends: no-return points as NaN / inf (bright ones included), NaN intensities, and returns that coincide
+    exactly (distance 0 between many neighbours: the 31-NN multiset, the SOR statistics and the 0.2 m clustering all see ties).  The answer
+    must be the oracle's -- and the call must come back (no lane may spin on a NaN distance)."""
+    from oracle.binding import oracle_detect3d
+    from reflector_ekf_slam_amd.detect import PointCloudOptions, PointCloudReflectorDetect
+    rng = np.random.default_rng(5)
+    parts = [_blob((0, 0, 0), 2000, 5.0, rng, intensity=20.0)]
+    parts += [_blob(rng.uniform(-10, 10, 3) * np.array([1, 1, 0.05]), 40, 0.03, rng) for _ in range(20)]
+    base = np.concatenate(parts).astype(np.float32)
+    g = PointCloudReflectorDetect(PointCloudOptions(), max_points=65536)
+    cases = {"nan_xyz": lambda c: c.__setitem__((slice(2100, 2110), slice(0, 3)), np.nan),
+             "inf_x": lambda c: c.__setitem__((slice(2100, 2105), 0), np.inf),
+             "nan_intensity": lambda c: c.__setitem__((slice(2100, 2110), 3), np.nan),
+             "forty_coincident": lambda c: c.__setitem__((slice(2100, 2140), slice(0, 3)), c[2100, :3].copy()),
+             "all_coincident": lambda c: c.__setitem__((slice(2000, 2800), slice(0, 3)), c[2100, :3].copy()),
+             "clean": lambda c: None}
+    for name, mod in cases.items():
+        c = base.copy()
+        mod(c)
+        obs = g.HandlePointCloud(1.0, c)
+        oc, _, _ = oracle_detect3d(c)
+        assert obs.cloud_.shape == oc.shape and np.array_equal(obs.cloud_, oc), name
+        assert np.isfinite(obs.cloud_).all(), name
+    g.close()
+
+
 def test_detect3d_world_clouds_match(oracle_lib):
     from reflector_ekf_slam_amd import synth
     for seed, pose in ((3, (34.4, 34.0, 1.15)), (4, (10.0, 50.0, -0.4))):
