@@ -77,6 +77,8 @@ struct RekfCtl {
     struct AugRec { int n_before, n2; float obs[2 * REKF_MAX_OBS_DEV]; } augrec[2];
     unsigned aug_done;                // scan id of the last k_mid whose workgroup 0 has appended its predecessor's new reflectors
     unsigned rec_seq;                 // scan id of the last scan whose match record (rec) the front role INSIDE k_mid's grid has completed
+    unsigned dd_done;                 // workgroups of a downdate role INSIDE k_mid's grid (small states: one launch per scan) that have finished,
+                                      // over the life of the handle; the mid role waits for RekfFrontArgs::dd_target before it touches P
     long long dbg[32];            // scratch for in-kernel timing experiments (REKF_DEBUG_TIMING builds)
 };
 
@@ -107,6 +109,9 @@ struct RekfFrontArgs {
                               // n + 2 n_new rows (the new reflectors' means are there: k_mid writes them)
     int front_in_mid;         // k_mid: the first front_in_mid workgroups of its grid are this scan's front end (a host-predicted scan behind a
                               // pose read-back: no launch of its own for the match); the others wait for RekfCtl::rec_seq
+    int dd_in_mid;            // k_mid (one launch per scan, small states): the first dd_in_mid workgroups of its grid are the PREVIOUS scan's downdate
+                              // (four of their eight waves), then front_in_mid workgroups of front end, then the mid workgroups
+    unsigned dd_target;       // RekfCtl::dd_done once that downdate role is through
     int aug_in_mid;           // k_mid: the previous scan's augmentation has not run: workgroup 0 appends its rows first (RekfCtl::augrec), n = n_before + 2 n2
     unsigned scan_id;         // running number of the scan (RekfCtl::aug_done)
     int apply_pred;           // k_mid: apply the pending Predict to the gathered P (whole scan or FIRST block step of a wide scan)
@@ -263,6 +268,8 @@ void rekf_launch_compact_wide(const RekfDev &d, const RekfFrontArgs &a, hipStrea
 void rekf_launch_mid(const RekfDev &d, const RekfFrontArgs &a, int n_ub, int m_ub, bool mode_grow, hipStream_t s);   // mode_grow: the filter can still grow, or the previous scan's augmentation rides in this launch
 void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s);
 void rekf_launch_dd_front(const RekfDev &d, int n_ub, const RekfDev &dn, const RekfFrontArgs &an, hipStream_t s);
+int rekf_one_launch_fits(int dd_n_ub, int n_ub, int K);
+int rekf_launch_one(const RekfDev &dd, int dd_n_ub, const RekfDev &d, RekfFrontArgs &a, int n_ub, int m_ub, bool mode_grow, unsigned dd_done_before, hipStream_t s);   // small states: one launch per scan (k_mid<2, MODE, KC>); 0: no such form for this shape
 void rekf_launch_augment(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);
 void rekf_launch_ellipses(const RekfDev &d, double *out5, int cap, hipStream_t s);
 void rekf_launch_publish_pose(const RekfDev &d, RekfHostSlot *hout, int seq, hipStream_t s);

@@ -60,7 +60,7 @@ __device__ static void obs_to_global(double x, double y, double c, double s, flo
     gy = (float)((double)px * s + (double)py * c + y);
 }
 
-__device__ static double yaw_innovation(double delta_theta)
+__device__ static __forceinline__ double yaw_innovation(double delta_theta)
 {
 #pragma clang fp contract(off)
     // quaternion (w,0,0,z) -> angle-axis z: reference transform.h:46-70 via gps.cc:320-322
@@ -275,9 +275,18 @@ __device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs
     const double *__restrict__ P = d.P;
     const double *mu = d.mu;
     const size_t ld = (size_t)d.ld;
-    const int n = (d.n_known >= 0) ? d.n_known : ctl->n + (A.aug_pending ? 2 * ctl->n_new : 0);
+    int n = (d.n_known >= 0) ? d.n_known : ctl->n + (A.aug_pending ? 2 * ctl->n_new : 0);
+    if (d.n_known < 0 && A.front_in_mid && A.aug_in_mid) {
+        // inside k_mid's grid beside the mid role whose workgroup 0 is appending the previous scan's reflectors (and moving ctl->n) right
+        // now: the dimension comes from that scan's augmentation record, as the mid role takes it
+        const RekfCtl::AugRec *ar = &ctl->augrec[(A.pred_slot ^ 1) & 1];
+        n = ar->n_before + 2 * ar->n2;
+    }
     const int L = (n - 3) / 2;
     const int K = A.K;
+    // inside k_mid's grid with the motion model evaluated here (one launch per scan): what the mid role reads of this role's Predict goes
+    // THROUGH to memory and is complete before this workgroup counts its observation (the mid role's wait for the count orders the rest)
+    const bool wt_pred = A.front_in_mid != 0 && !A.host_pred;
 
     // operands that depend only on the old state go in flight first -- and this workgroup's first observation: a dynamically
     // indexed kernel argument is a scalar load of its own, issued where it is used (inside the match, it cost a memory round trip)
@@ -343,13 +352,26 @@ __device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs
                 for (int q = 0; q < 9; ++q) C9[q] = A.pre_C9[q];
             } else corner_predict(C9, 3, mo);
             RekfCtl::Pred *pr = &ctl->pred[A.pred_slot & 1];
-            pr->ab[0] = mo.a; pr->ab[1] = mo.b;
-            for (int q = 0; q < 9; ++q) pr->C9[q] = C9[q];
-            ctl->pose_pred[0] = pose[0]; ctl->pose_pred[1] = pose[1]; ctl->pose_pred[3] = pose[3]; ctl->pose_pred[4] = pose[4];
-            if (A.host_pred) ctl->pose_pred[2] = pose[2];
+            if (wt_pred) {
+                store_wt(&pr->ab[0], mo.a); store_wt(&pr->ab[1], mo.b);
+                for (int q = 0; q < 9; ++q) store_wt(&pr->C9[q], C9[q]);
+                store_wt(&ctl->pose_pred[0], pose[0]); store_wt(&ctl->pose_pred[1], pose[1]);
+                store_wt(&ctl->pose_pred[3], pose[3]); store_wt(&ctl->pose_pred[4], pose[4]);     // (drained in front of this lane's count, below)
+            } else {
+                pr->ab[0] = mo.a; pr->ab[1] = mo.b;
+                for (int q = 0; q < 9; ++q) pr->C9[q] = C9[q];
+                ctl->pose_pred[0] = pose[0]; ctl->pose_pred[1] = pose[1]; ctl->pose_pred[3] = pose[3]; ctl->pose_pred[4] = pose[4];
+                if (A.host_pred) ctl->pose_pred[2] = pose[2];
+            }
             if (!A.front_in_mid) ctl->pose_pending = 1;       // (inside k_mid's grid nobody reads it, and that kernel's workgroup 0 clears it beside us)
         }
-        if (!A.host_pred && b == 0 && tid == NT - 64) ctl->pose_pred[2] = atan2(pose[4], pose[3]);     // the wrapped heading (cc:181 / :205), on the last wave
+        if (!A.host_pred && b == 0 && tid == NT - 64) {        // the wrapped heading (cc:181 / :205), on the last wave
+            const double thw = atan2(pose[4], pose[3]);
+            if (wt_pred) {
+                store_wt(&ctl->pose_pred[2], thw);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (complete in front of the match's barrier, which lane 0 passes before it counts)
+            } else ctl->pose_pred[2] = thw;
+        }
     }
 
     FMARK();                                          // 2: covariance slice written
@@ -480,7 +502,7 @@ struct HPair {
     double a0[3], a1[3], b0[2], b1[2], dz0, dz1, q0, q1;
     int col;
 };
-__device__ static HPair make_hpair(const RekfDev &d, const RekfFrontArgs &A, const double *pose,
+__device__ static __forceinline__ HPair make_hpair(const RekfDev &d, const RekfFrontArgs &A, const double *pose,
                                    int local_id, int global_id, int is_state)
 {
 #pragma clang fp contract(off)
@@ -840,10 +862,17 @@ typedef double v2du __attribute__((ext_vector_type(2), aligned(8)));     // a ro
 //   0  nothing;  1  a filter that can still grow: workgroup 0 leaves the scan's augmentation record (RekfCtl::augrec) and, with
 //   A.aug_in_mid, first appends the PREVIOUS scan's new reflectors;  2  the scan's front end runs as the first A.front_in_mid
 //   workgroups of this grid (a host-predicted scan behind a pose read-back); also leaves the augmentation record.
-template <int NBR, int MODE>
-__global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, RekfFrontArgs A)
+//   KCDD > 0 (small states, ONE launch per scan): the PREVIOUS scan's downdate (dd_body<KCDD>, on four of the eight waves) runs as the first
+//   A.dd_in_mid workgroups of the grid, the scan's front end (MODE bit 2; the motion model evaluated there) as the next A.front_in_mid; the
+//   mid workgroups wait for both inside the launch -- one-way: neither role waits for anybody, their workgroups are dispatched first.
+//   MODE there: 2 a full filter, 3 one that can still grow (bit 1: reads / appends the previous scan's augmentation record).
+//   dp: the downdate role's device view (that scan's panels); unused -- and never loaded -- when KCDD = 0.
+template <int KC> __device__ __forceinline__ void dd_body(const RekfDev &d);
+template <int NBR, int MODE, int KCDD = 0>
+__global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, RekfFrontArgs A, RekfDev dp)
 {
-    constexpr bool FRONT = MODE == 2, AUGR = MODE == 1, AUGW = MODE >= 1;
+    constexpr bool FRONT = (MODE & 2) != 0, AUGR = (MODE & 1) != 0, AUGW = MODE >= 1, DDIN = KCDD > 0;
+    static_assert(!DDIN || FRONT, "the one-launch form hosts the front end too");
     // ctl_first = d.ctl, as a leading pointer argument of its own: built with -mllvm -amdgpu-kernarg-preload-count the wave starts with it
     // in SGPRs, and the kernel's first loads (the match results) do not wait for the kernel-argument fetch
     constexpr int MP = 16 * NBR;                  // most innovation rows (padded) this instance takes
@@ -879,7 +908,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
 
 #ifdef REKF_DEBUG_TIMING
     long long tqm[16]; int nqm = 0;
-    const bool recm = blockIdx.x == 1 && threadIdx.x == 0;      // (debug builds: without the in-grid front role)
+    const bool recm = (int)blockIdx.x == 1 + (DDIN ? A.dd_in_mid : 0) + (FRONT ? A.front_in_mid : 0) && threadIdx.x == 0;      // (the second mid workgroup)
     const long long t_entrym = clock64(), w_entrym = wall_clock64();
 #define MMARK() do { __builtin_amdgcn_sched_barrier(0); if (recm && nqm < 16) tqm[nqm++] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -893,11 +922,44 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     // block came by value -- runs as the FIRST workgroups of this grid instead of a launch of its own (7.5 us + a kernel boundary in
     // front of k_mid, on the path every read-back caller waits for); everybody else waits for the record below.  One-way: the
     // front role waits for nobody, its workgroups are dispatched first and the grid's first 256 workgroups are resident together.
-    if (FRONT && (int)blockIdx.x < A.front_in_mid) {
-        front_role<512>(d, A, (int)blockIdx.x, A.front_in_mid, false);
+    if constexpr (DDIN) {
+        if ((int)blockIdx.x < A.dd_in_mid) {
+            // the previous scan's downdate: waves 0..3 (the body is cut for 256 threads; a barrier counts the waves that have not ended).
+            // Its tiles go through to memory (DD_STORE); the release covers the plain stores of strips and corner; then the count
+            if (threadIdx.x < 256) {
+#ifdef REKF_DEBUG_TIMING
+                if (threadIdx.x == 0 && blockIdx.x == 0) ctl->dbg[26] = wall_clock64();
+#endif
+                dd_body<KCDD>(dp);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (threadIdx.x == 0) {
+#ifdef REKF_DEBUG_TIMING
+                    if (blockIdx.x == 0) ctl->dbg[27] = wall_clock64();
+#endif
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    (void)__hip_atomic_fetch_add(&ctl->dd_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef REKF_DEBUG_TIMING
+                    if (blockIdx.x == 0) ctl->dbg[28] = wall_clock64();
+#endif
+                }
+            }
+            return;
+        }
+    }
+    const int bxf = (int)blockIdx.x - (DDIN ? A.dd_in_mid : 0);
+    if (FRONT && bxf < A.front_in_mid) {
+#ifdef REKF_DEBUG_TIMING
+        if (threadIdx.x == 0 && bxf == 0) ctl->dbg[29] = wall_clock64();
+#endif
+        front_role<512>(d, A, bxf, A.front_in_mid, DDIN);      // (DDIN: the pose block from RekfCtl::post_C9 -- the downdate beside us is storing it into P)
+#ifdef REKF_DEBUG_TIMING
+        if (threadIdx.x == 0 && bxf == 0) ctl->dbg[30] = wall_clock64();
+#endif
         return;
     }
-    const int bx = (int)blockIdx.x - (FRONT ? A.front_in_mid : 0);      // this workgroup's number among the mid workgroups
+    const int bx = bxf - (FRONT ? A.front_in_mid : 0);          // this workgroup's number among the mid workgroups
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool steam = wave < 4;                  // S team; the other is the "own" team
     const int tt = tid & 255;                     // thread index within the team
@@ -915,10 +977,28 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
             __builtin_amdgcn_wave_barrier();
             const int kind = (tid < A.K) ? __hip_atomic_load(&ctl->obs_kind[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
             const int oidx = (tid < A.K) ? __hip_atomic_load(&ctl->obs_idx[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
-            const int n_rec = (d.n_known >= 0) ? d.n_known : ctl->n;             // (the front role's own n: a scan behind a read-back knows it)
+            int n_rec = (d.n_known >= 0) ? d.n_known : ctl->n;                   // (the front role's own n: a scan behind a read-back knows it)
+            if (AUGR && A.aug_in_mid && d.n_known < 0) {                           // (... or, while the filter grows, the previous scan's record: front_role)
+                const RekfCtl::AugRec *arr = &ctl->augrec[(A.pred_slot ^ 1) & 1];
+                n_rec = arr->n_before + 2 * arr->n2;
+            }
             compact_record(&s_rec, ctl, kind, oidx, tid, A.K, n_rec, d.n_max, A.has_gps);
         }
+        if (DDIN && tid == 64) {
+            // ... and P is the previous scan's once its downdate role is through (count, then one acquire for the workgroup: what the two
+            // roles wrote went through to memory, nothing below needs a coherent load of its own)
+            unsigned spins = 0;
+            while ((int)(__hip_atomic_load(&ctl->dd_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - A.dd_target) < 0 && ++spins < (1u << 22))
+                __builtin_amdgcn_s_sleep(2);
+            if (spins >= (1u << 22)) atomicOr(&ctl->err, REKF_FLAG_STARVED);
+        }
         __syncthreads();
+        MMARK();                                    // (in-grid roles: front end and downdate through)
+        if (DDIN) {
+            if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __syncthreads();
+            MMARK();                                // (... acquired)
+        }
     }
     // the scan's match record first, UNCONDITIONALLY (a block step of a wide scan does not use it): a vector load that waits for no
     // scalar one, so the control block costs one memory round trip, not two
@@ -985,7 +1065,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     if (do_pred && tid >= 64 && tid < 64 + 11) {                                   // ab[0], ab[1], C9[0..8]
         // (with the front role in this grid the control block's copy is being written beside us: a host-predicted scan carries the values)
         const int e = tid - 64;
-        s_pred[e] = FRONT ? (e < 2 ? A.pre_ab[e] : A.pre_C9[e - 2]) : ((const double *)&ctl->pred[A.pred_slot & 1])[e];
+        s_pred[e] = (FRONT && hp) ? (e < 2 ? A.pre_ab[e] : A.pre_C9[e - 2]) : ((const double *)&ctl->pred[A.pred_slot & 1])[e];
     }
 
     // ---- A: the scan's matched pairs.  Whole scan (pair0 < 0): ordered compaction of the per-observation results (obs order
@@ -1518,11 +1598,12 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
                                           __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         }
     }
-#ifdef REKF_DEBUG_TIMING
+#if defined(REKF_DEBUG_TIMING) && !defined(REKF_DEBUG_DD2)
     if (recm) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ctl->dbg[6] = clock64() - t_entrym;
         ctl->dbg[5] = wall_clock64() - w_entrym;
+        ctl->dbg[4] = w_entrym; ctl->dbg[31] = wall_clock64();
         ctl->dbg[7] = nqm;
         for (int i = 0; i < nqm; ++i) ctl->dbg[8 + i] = tqm[i] - t_entrym;
     }
@@ -2224,13 +2305,13 @@ void rekf_launch_mid(const RekfDev &d, const RekfFrontArgs &a, int n_ub, int m_u
     const int grid = (n_ub + MID_ROWS - 1) / MID_ROWS + (a.front_in_mid > 0 ? a.front_in_mid : 0);
     const int mode = (a.front_in_mid > 0) ? 2 : (mode_grow ? 1 : 0);
     if (m_ub <= 32) {
-        if (mode == 0) hipLaunchKernelGGL((k_mid<2, 0>), dim3(grid), dim3(512), 0, s, d.ctl, d, a);
-        else if (mode == 1) hipLaunchKernelGGL((k_mid<2, 1>), dim3(grid), dim3(512), 0, s, d.ctl, d, a);
-        else hipLaunchKernelGGL((k_mid<2, 2>), dim3(grid), dim3(512), 0, s, d.ctl, d, a);
+        if (mode == 0) hipLaunchKernelGGL((k_mid<2, 0>), dim3(grid), dim3(512), 0, s, d.ctl, d, a, d);          // (the last argument: the downdate role's view, one-launch form only)
+        else if (mode == 1) hipLaunchKernelGGL((k_mid<2, 1>), dim3(grid), dim3(512), 0, s, d.ctl, d, a, d);
+        else hipLaunchKernelGGL((k_mid<2, 2>), dim3(grid), dim3(512), 0, s, d.ctl, d, a, d);
     } else {
-        if (mode == 0) hipLaunchKernelGGL((k_mid<4, 0>), dim3(grid), dim3(512), 0, s, d.ctl, d, a);
-        else if (mode == 1) hipLaunchKernelGGL((k_mid<4, 1>), dim3(grid), dim3(512), 0, s, d.ctl, d, a);
-        else hipLaunchKernelGGL((k_mid<4, 2>), dim3(grid), dim3(512), 0, s, d.ctl, d, a);
+        if (mode == 0) hipLaunchKernelGGL((k_mid<4, 0>), dim3(grid), dim3(512), 0, s, d.ctl, d, a, d);
+        else if (mode == 1) hipLaunchKernelGGL((k_mid<4, 1>), dim3(grid), dim3(512), 0, s, d.ctl, d, a, d);
+        else hipLaunchKernelGGL((k_mid<4, 2>), dim3(grid), dim3(512), 0, s, d.ctl, d, a, d);
     }
 }
 template <int KC> static void launch_downdate2(const RekfDev &d, int grid, hipStream_t s, bool first_on_device, const RekfDev *dn, const RekfFrontArgs *an, int n_front)
@@ -2256,30 +2337,42 @@ static void downdate_schedule(int n_ub, int slots, int &grid, int &dd_lo, int &d
     grid = T + (dd_lo > 0 ? room : dd_x);
     if (grid >= 64) grid = (grid + 7) & ~7;         // multiple of 8 for the per-XCD numbering (workgroups past the last range return at once)
 }
+// per-DEVICE facts the launches below need: the CU count, and which kernel variants have their opt-in to more than 64 KiB of dynamic LDS
+constexpr int DD_MAX_DEV = 64;
+static struct {
+    int n_cu_of[DD_MAX_DEV] = {0};
+    unsigned attr_done[DD_MAX_DEV] = {0};     // bit KC/16 : k_downdate2<KC> / k_dd_front<KC>
+    unsigned attr_one[DD_MAX_DEV] = {0};      // bit 2 (KC/16 - 1) + (MODE - 2) : k_mid<2, MODE, KC>, the one-launch form
+    std::mutex mu;
+} g_dd_cache;
+static int dd_cache_slot(int &dev)            // (call with g_dd_cache.mu held)
+{
+    (void)hipGetDevice(&dev);
+    const int slot = (dev >= 0 && dev < DD_MAX_DEV) ? dev : 0;
+    if (g_dd_cache.n_cu_of[slot] == 0 || dev != slot) {
+        hipDeviceProp_t prop;
+        int cu = 0;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cu = prop.multiProcessorCount;
+        if (cu <= 0) cu = 256;
+        g_dd_cache.n_cu_of[slot] = cu;
+        g_dd_cache.attr_done[slot] = 0;
+        g_dd_cache.attr_one[slot] = 0;
+    }
+    return slot;
+}
 // dn / an non-null: the fused form k_dd_front -- scan t's downdate with the front end of scan t+1 (dn, an) in FRONT_MB further workgroups,
 // which take their CUs out of the downdate's schedule
 static void launch_downdate_any(const RekfDev &d, int n_ub, hipStream_t s, const RekfDev *dn, const RekfFrontArgs *an)
 {
     // persistent: one workgroup per CU (its panels fill most of the LDS), never more workgroups than tiles.  The opt-in to
     // more than 64 KiB of dynamic LDS and the CU count are per DEVICE: a process may hold handles on several GPUs.
-    constexpr int MAX_DEV = 64;
-    static int n_cu_of[MAX_DEV] = {0};
-    static unsigned attr_done[MAX_DEV] = {0};         // bit KC/16 : k_downdate2<KC> / k_dd_front<KC> have their LDS opt-in on this device
     // handles are independent (multi-session servers drive them from several host threads) but this cache is per process: the lock
     // is held across the launch, so that no thread launches a variant before the thread that first needed it has opted it in
-    static std::mutex cache_mu;
-    std::lock_guard<std::mutex> guard(cache_mu);
+    std::lock_guard<std::mutex> guard(g_dd_cache.mu);
     int dev = 0;
-    (void)hipGetDevice(&dev);
-    const int slot = (dev >= 0 && dev < MAX_DEV) ? dev : 0;
-    if (n_cu_of[slot] == 0 || dev != slot) {
-        hipDeviceProp_t prop;
-        int cu = 0;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cu = prop.multiProcessorCount;
-        if (cu <= 0) cu = 256;
-        n_cu_of[slot] = cu;
-        attr_done[slot] = 0;
-    }
+    const int slot = dd_cache_slot(dev);
+    int *const n_cu_of = g_dd_cache.n_cu_of;
+    unsigned *const attr_done = g_dd_cache.attr_done;
     int grid, dd_lo, dd_x, dd_sub;
     int n_front = 0;
     if (dn) { n_front = an->K < FRONT_MB ? (an->K > 0 ? an->K : 1) : FRONT_MB; }
@@ -2298,6 +2391,56 @@ static void launch_downdate_any(const RekfDev &d, int n_ub, hipStream_t s, const
     else if (kc == 48) launch_downdate2<48>(dp, grid, s, first, dn, an, n_front);
     else if (kc == 32) launch_downdate2<32>(dp, grid, s, first, dn, an, n_front);
     else launch_downdate2<16>(dp, grid, s, first, dn, an, n_front);
+}
+// ONE launch per scan for small states (k_mid<2, MODE, KC>): the previous scan's downdate (dd: its device view, the panels of ITS k_mid), this
+// scan's front end (one observation per workgroup) and its mid role.  Returns the number of downdate workgroups (the host's share of the
+// RekfCtl::dd_done bookkeeping).
+template <int MODE, int KC> static void launch_one(const RekfDev &dp, const RekfDev &d, const RekfFrontArgs &a, int grid, bool first_on_device, hipStream_t s)
+{
+    constexpr int BYTES = 4 * KC * 64 * (int)sizeof(double) + 16384;
+    if (first_on_device) (void)hipFuncSetAttribute((const void *)k_mid<2, MODE, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+    hipLaunchKernelGGL((k_mid<2, MODE, KC>), dim3(grid), dim3(512), BYTES, s, d.ctl, d, a, dp);
+}
+// does a state of at most n_ub rows (its held-back downdate: dd_n_ub) with K observations have the one-launch form on this device?
+// (every workgroup of that launch holds a CU: all of them must be resident together)
+int rekf_one_launch_fits(int dd_n_ub, int n_ub, int K)
+{
+    std::lock_guard<std::mutex> guard(g_dd_cache.mu);
+    int dev = 0;
+    const int slot = dd_cache_slot(dev);
+    const int slots = g_dd_cache.n_cu_of[slot] - K - (n_ub + MID_ROWS - 1) / MID_ROWS;
+    if (K < 1 || K > 32 || slots < 8) return 0;
+    int grid_dd, dd_lo, dd_x, dd_sub;
+    downdate_schedule(dd_n_ub, slots, grid_dd, dd_lo, dd_x, dd_sub);
+    return grid_dd <= slots ? 1 : 0;
+}
+int rekf_launch_one(const RekfDev &dd, int dd_n_ub, const RekfDev &d, RekfFrontArgs &a, int n_ub, int m_ub, bool mode_grow, unsigned dd_done_before, hipStream_t s)
+{
+    const int kc = (dd.kc_ub < 16) ? 16 : dd.kc_ub;
+    if (m_ub > 32 || kc > 32 || a.K < 1 || a.K > 32) return 0;
+    std::lock_guard<std::mutex> guard(g_dd_cache.mu);
+    int dev = 0;
+    const int slot = dd_cache_slot(dev);
+    const int n_mid = (n_ub + MID_ROWS - 1) / MID_ROWS;
+    int slots = g_dd_cache.n_cu_of[slot] - a.K - n_mid;              // one workgroup per CU (the launch's LDS), everybody resident at once
+    if (slots < 8) return 0;
+    int grid_dd, dd_lo, dd_x, dd_sub;
+    downdate_schedule(dd_n_ub, slots, grid_dd, dd_lo, dd_x, dd_sub);
+    if (grid_dd > slots) return 0;
+    RekfDev dp = dd;
+    dp.dd_lo = dd_lo; dp.dd_x = dd_x; dp.dd_sub = dd_sub; dp.dd_grid = grid_dd;
+    if (dd.n_known < 0) { dp.dd_lo = 0; dp.dd_x = 0; dp.dd_sub = 0; }   // (a bound only: the kernel derives the schedule from the real n)
+    a.dd_in_mid = grid_dd;
+    a.dd_target = dd_done_before + (unsigned)grid_dd;
+    a.front_in_mid = a.K;
+    const int mode = mode_grow ? 3 : 2;
+    const unsigned bit = 1u << (2 * (kc / 16 - 1) + (mode - 2));
+    const bool first = !(g_dd_cache.attr_one[slot] & bit) || dev != slot;
+    g_dd_cache.attr_one[slot] |= bit;
+    const int grid = grid_dd + a.K + n_mid;
+    if (kc == 32) { if (mode == 3) launch_one<3, 32>(dp, d, a, grid, first, s); else launch_one<2, 32>(dp, d, a, grid, first, s); }
+    else { if (mode == 3) launch_one<3, 16>(dp, d, a, grid, first, s); else launch_one<2, 16>(dp, d, a, grid, first, s); }
+    return grid_dd;
 }
 void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s) { launch_downdate_any(d, n_ub, s, nullptr, nullptr); }
 void rekf_launch_dd_front(const RekfDev &d, int n_ub, const RekfDev &dn, const RekfFrontArgs &an, hipStream_t s) { launch_downdate_any(d, n_ub, s, &dn, &an); }

@@ -83,6 +83,12 @@ struct rekf {
     bool dd_aug_inline_ok = false;  // ... and it may run inside the next scan's k_mid instead of a launch of its own (RekfCtl::augrec: whole scans only)
     bool aug_in_mid = true;         // REKF_AUG_IN_MID=0 in the environment turns that off (A/B measurements)
     bool front_in_mid = true;       // a host-predicted scan's front end runs inside k_mid's grid (REKF_FRONT_IN_MID=0: as k_front_mb, a launch of its own)
+    // SMALL STATES, ONE LAUNCH PER SCAN: the held-back downdate, the front end and k_mid as roles of ONE grid (k_mid<2, MODE, KC>) when the
+    // scan has at most 16 observations, the state at most one_nmax rows and nobody else is at work on the GPU (the mid role waits for the other
+    // two INSIDE the launch).  REKF_ONE_LAUNCH=0 turns it off, REKF_ONE_LAUNCH_NMAX moves the bound.
+    bool one_launch = true;
+    int one_nmax = 643;
+    unsigned dd_total = 0;          // RekfCtl::dd_done once every downdate role enqueued so far is through
     bool lazy_dd = true;            // REKF_LAZY_DD=0 in the environment turns it off (A/B measurements)
     // WHO PUBLISHES pose, pose block, n and flags of a scan.  A caller that reads the pose back after its scans (the reference's node,
     // src/ros_node.cc:514-515) gets them from k_mid's workgroup 0 -- a kernel earlier: GetPose does not wait for the downdate -- which
@@ -509,6 +515,8 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
     { const char *e = std::getenv("REKF_LAZY_DD"); h->lazy_dd = !(e && e[0] == '0'); }
     { const char *e = std::getenv("REKF_AUG_IN_MID"); h->aug_in_mid = !(e && e[0] == '0'); }
     { const char *e = std::getenv("REKF_FRONT_IN_MID"); h->front_in_mid = !(e && e[0] == '0'); }
+    { const char *e = std::getenv("REKF_ONE_LAUNCH"); h->one_launch = !(e && e[0] == '0'); }
+    { const char *e = std::getenv("REKF_ONE_LAUNCH_NMAX"); if (e && std::atoi(e) > 0) h->one_nmax = std::atoi(e); }
     h->prof_on = false;
     h->prof_mask = -1;
     h->prof_used = 0;
@@ -752,7 +760,15 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     if (aug) h->cum_growth += 2 * K;
     const int pub_seq = new_publisher(h);
     a.scan_id = (unsigned)h->scan_count;
-    if (with_dd) {
+    const int m_ub_scan = 2 * K + (gps_pose3 ? 3 : 0);
+    // small states: the whole scan as ONE launch (struct rekf); its downdate role is the held-back downdate, sent at the k_mid launch below
+    const bool one = with_dd && alone && h->one_launch && !blocks && !staged && m_ub_scan <= 32 && h->dd_dev.kc_ub <= 32 && h->n_ub <= h->one_nmax &&
+                     (!h->dd_aug || (h->aug_in_mid && h->dd_aug_inline_ok)) && rekf_one_launch_fits(h->dd_n_ub, h->n_ub, K);
+    if (one) {
+        h->dd_pending = false;
+        a.aug_in_mid = h->dd_aug ? 1 : 0;             // (the previous scan's new reflectors: appended by this launch's mid role, behind the downdate role)
+        h->dd_aug = false;
+    } else if (with_dd) {
         h->dd_pending = false;
         a.aug_pending = h->dd_aug ? 1 : 0;
         { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_dd_front(h->dd_dev, h->dd_n_ub, h->dev, a, h->stream); }
@@ -822,7 +838,8 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
             RekfDev dm = h->dev;
             if (early_pub) { dm.pub = h->host_slots_dev; dm.pub_seq = pub_seq; }
             ProfScope ps(h, REKF_K_MID);
-            rekf_launch_mid(dm, a, n_ub, m_ub, aug || a.aug_in_mid != 0, h->stream);
+            if (one) h->dd_total += (unsigned)rekf_launch_one(h->dd_dev, h->dd_n_ub, dm, a, n_ub, m_ub, aug || a.aug_in_mid != 0, h->dd_total, h->stream);
+            else rekf_launch_mid(dm, a, n_ub, m_ub, aug || a.aug_in_mid != 0, h->stream);
         }
         std::swap(h->dev.mu, h->dev.mu_out);
         downdate(true, true);
@@ -854,6 +871,7 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         (void)hipStreamSynchronize(h->stream);
         if (hipMemcpy(h->ctl_staging, h->dev.ctl, sizeof(RekfCtl), hipMemcpyDeviceToHost) == hipSuccess) {
             h->front_total = h->ctl_staging->front_count;
+            h->dd_total = h->ctl_staging->dd_done;
             h->n_ub = h->ctl_staging->n; h->n_exact = true; h->full = h->n_ub >= h->dev.n_max;
         }
         (void)hipGetLastError();
@@ -968,6 +986,7 @@ int rekf_set_state(rekf_t *h, double t, int n, const double *mu, const double *s
     std::memset(h->ctl_staging, 0, sizeof(RekfCtl));
     h->ctl_staging->n = n;
     h->ctl_staging->front_count = h->front_total;                  // (the front end's count of matched observations goes on)
+    h->ctl_staging->dd_done = h->dd_total;                         // (... and so does the in-grid downdate roles')
     HIP_TRY(h, hipMemcpyAsync(h->dev.ctl, h->ctl_staging, sizeof(RekfCtl), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->time = t;

@@ -1,14 +1,14 @@
 """A/B timing of builds of librekf.so in ONE GPU session (same box, same clocks), interleaved repetitions:
     python scripts/gpu_ab.py [--reps 3] path/to/A.so path/to/B.so ...
 Per variant and repetition: us per update of the C3 steady state (1000 updates, host clock around enqueue + sync) and the
-back-to-back k_downdate2 time (rekf_debug_time_kernel, 400 launches between one event pair).  Prints the medians."""
+back-to-back k_downdate2 time (rekf_debug_time_kernel, 400 launches between one event pair).  Prints the medians.  REKF_AB_CFG=C2 (or C4) in the environment picks another BASELINE configuration."""
 import subprocess, sys, os, statistics
 BUILD = r'''
 import sys
 sys.path.insert(0, ".")
 import numpy as np
 from reflector_ekf_slam_amd import synth, session as S, ReflectorEKFSLAM
-cfg = synth.C3
+cfg = getattr(synth, __import__('os').environ.get('REKF_AB_CFG', 'C3'))
 sess = synth.make_session(cfg)
 g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks, auto_grow=False)
 S.replay(sess, g); g.sync()
@@ -23,7 +23,7 @@ from reflector_ekf_slam_amd import _lib
 path = sys.argv[1]
 _lib.lib_path = lambda name, _p=path: _p if name == "librekf.so" else __import__("os").path.join(_lib._HERE, name)
 from reflector_ekf_slam_amd import synth, session as S, ReflectorEKFSLAM
-cfg = synth.C3
+cfg = getattr(synth, __import__('os').environ.get('REKF_AB_CFG', 'C3'))
 sess = synth.make_session(cfg)
 z = np.load("/tmp/c3_state.npz")
 g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks, auto_grow=False)

@@ -22,3 +22,7 @@ for k, (t, ob) in enumerate(scans[:6]):
         o = list(out)
         ghz = o[6] / max(o[5], 1) * 0.1
         print("kernel %.2f us @ %.2f GHz marks(us):" % (o[5] * 0.01, ghz), [round(x / ghz / 1e3, 2) for x in o[8:8 + o[7]]])
+        if o[26]:                                     # the one-launch form: wall clock (100 MHz) of the roles, relative to the downdate role's entry
+            t0 = o[26]
+            print("   one launch: downdate role wg 0: body done %.2f, counted %.2f | front role wg 0: entry %.2f, exit %.2f | mid wg 1: entry %.2f, exit %.2f us"
+                  % tuple((o[k] - t0) * 0.01 for k in (27, 28, 29, 30, 4, 31)))
