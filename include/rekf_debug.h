@@ -42,7 +42,9 @@ int rekf_profile_samples(rekf_t *h, float *out_us, long cap, long *count);
  * (snapshot / restore it with rekf_get_state / rekf_set_state).  `ablate` must be 0 (reserved). */
 int rekf_debug_time_kernel(rekf_t *h, int kernel, int reps, int ablate, double *avg_us);
 
-/* Debug builds (-DREKF_DEBUG_TIMING) let kernels drop cycle counters here; zeros otherwise. */
+/* Debug builds (-DREKF_DEBUG_TIMING) let kernels drop cycle counters here; zeros otherwise -- except out32[24] of a release build:
+ * the number of downdate workgroups that ran as roles INSIDE k_mid's grid so far (the opt-in one-launch form for small states,
+ * REKF_ONE_LAUNCH=1 in the environment when the handle is created; rekf_api.hip, struct rekf). */
 int rekf_debug_counters(rekf_t *h, long long out32[32]);
 
 /* Fault injection (tests): the NEXT rekf_handle_observation fails with REKF_ERR_HIP at `stage` as if a HIP call had:

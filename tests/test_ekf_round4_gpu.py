@@ -177,3 +177,50 @@ def test_several_sessions_on_one_gpu_end_bit_identical_to_a_lone_one(readback):
     assert lone.mu.shape[0] == 3 + 2 * 160
     for st in many:
         assert np.array_equal(st.mu, lone.mu) and np.array_equal(st.sigma, lone.sigma)
+
+
+@pytest.mark.parametrize("grow", [True, False], ids=["growing_filter", "full_filter"])
+def test_small_states_as_one_launch_per_scan_give_the_same_bits(oracle_lib, grow, monkeypatch):
+    """REKF_ONE_LAUNCH=1 (opt-in, read at rekf_create): for small states, scan after scan (nothing read back in between: the previous
+    scan's downdate is still held back), the downdate, the scan's front end and k_mid run as roles of ONE grid, the mid workgroups
+    waiting for the other two inside the launch (ask 5; measured equal to the two launches it replaces,
+    profiles/r04_chain_experiments.txt item 7).  Same arithmetic: the run must end on the bits of a handle that sent two launches per
+    scan -- new reflectors met on the way included (the previous scan's are appended by the mid role, behind the downdate role) -- and
+    on the oracle's state; and the form must really have been used."""
+    import ctypes as C
+    from reflector_ekf_slam_amd import ReflectorEKFSLAM
+    from reflector_ekf_slam_amd import session as S
+    cfg = synth.SessionConfig("r4_one_launch", 100, 14, synth.DIFF, seed=4420, speed=1.4, row_spacing=6.0)
+    sess = synth.make_session(cfg)
+    lin, ang, ob2 = cfg.sigma_v ** 2, cfg.sigma_w ** 2, cfg.sigma_obs ** 2
+    scans = synth.steady_state_scans(sess, 240)
+    if grow:                                                # a reflector nobody has seen yet, every ninth scan
+        rng = np.random.default_rng(7)
+        scans = [(t, np.concatenate([ob, rng.uniform(-9.0, 9.0, (1, 2)).astype(np.float32)]) if k % 9 == 4 else ob) for k, (t, ob) in enumerate(scans)]
+
+    def run(one):
+        if one: monkeypatch.setenv("REKF_ONE_LAUNCH", "1")
+        else: monkeypatch.delenv("REKF_ONE_LAUNCH", raising=False)
+        # (a fixed capacity in both cases: with auto_grow the calls at which the host re-learns n -- and the next scan is host-predicted, a
+        # round-off-level difference, DESIGN.md 3 -- depend on how far the device has got, i.e. on timing, whichever form runs)
+        g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=300 if grow else cfg.n_landmarks, auto_grow=False)
+        S.replay(sess, g)                                   # the map (odometry between the scans: host-predicted scans, two launches either way)
+        for k, (t, ob) in enumerate(scans):
+            g.handle_observation(t, ob)
+            if k % 53 == 52: g.pose()                       # (a read-back now and then: the next scan is host-predicted again)
+        out = (C.c_longlong * 32)()
+        assert g._L.rekf_debug_counters(g._h, out) == 0
+        assert g.sync_code() == 0 and g.flags() == 0
+        return g.GetState(), int(out[24])
+
+    two, roles_two = run(False)
+    one, roles_one = run(True)
+    assert roles_two == 0 and roles_one > 200                   # (several downdate workgroups per scan)
+    assert one.mu.shape[0] > (3 + 2 * 100 if grow else 0)
+    assert np.array_equal(one.mu, two.mu) and np.array_equal(one.sigma, two.sigma)
+    o = make_oracle(cfg.odom_model, sess.init_time, sess.init_pose, lin, ang, ob2)
+    S.replay(sess, o)
+    for t, ob in scans:
+        o.handle_observation(t, ob)
+    mo, Po = o.state()
+    assert one.mu.shape == mo.shape and np.abs(one.mu - mo).max() < TIGHT and np.abs(one.sigma - Po).max() < 1e-11
