@@ -841,8 +841,20 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
             RekfDev dm = h->dev;
             if (early_pub) { dm.pub = h->host_slots_dev; dm.pub_seq = pub_seq; }
             ProfScope ps(h, REKF_K_MID);
-            if (one) h->dd_total += (unsigned)rekf_launch_one(h->dd_dev, h->dd_n_ub, dm, a, n_ub, m_ub, aug || a.aug_in_mid != 0, h->dd_total, h->stream);
-            else rekf_launch_mid(dm, a, n_ub, m_ub, aug || a.aug_in_mid != 0, h->stream);
+            int roles = 0;
+            if (one) {
+                roles = rekf_launch_one(h->dd_dev, h->dd_n_ub, dm, a, n_ub, m_ub, aug || a.aug_in_mid != 0, h->dd_total, h->stream);
+                h->dd_total += (unsigned)roles;
+                if (roles == 0) {
+                    // (rekf_one_launch_fits said yes a moment ago: only a device switched under us gets here.)  The plain chain, nothing held
+                    // back: the previous scan's downdate and augmentation as launches of their own, then this scan's front end
+                    rekf_launch_downdate(h->dd_dev, h->dd_n_ub, h->stream);
+                    if (a.aug_in_mid) rekf_launch_augment(h->dd_dev, h->dd_aug_args, h->stream);
+                    a.aug_in_mid = 0;
+                    rekf_launch_front_mb(h->dev, a, n_ub, h->stream);
+                }
+            }
+            if (roles == 0) rekf_launch_mid(dm, a, n_ub, m_ub, aug || a.aug_in_mid != 0, h->stream);
         }
         std::swap(h->dev.mu, h->dev.mu_out);
         downdate(true, true);
