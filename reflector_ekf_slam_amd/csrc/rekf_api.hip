@@ -45,6 +45,10 @@ struct rekf {
     double time;
     double vt[3];
     int n_ub;                  // host upper bound of the device-resident n
+    int n_det = 3;             // the same bound WITHOUT what peek_n learns on the way: it moves only where the call sequence says so (a scan adds its
+                               // 2K, a wait for the device makes it exact).  Decisions that change the ARITHMETIC a scan sees -- auto-grow's wait for the
+                               // exact n makes the next scan host-predicted: cos / sin of the wrapped heading, a last-place difference -- go by this one,
+                               // so that results do not depend on how far the device happens to have got when the host looks
     int last_m_ub = 64;        // innovation-row bound of the last scan
     bool full;                 // n == n_max is known: no landmark can be added (k_augment is not launched)
     bool n_exact = true;       // n_ub IS the device's n (nothing that can append landmarks is in flight past the last read-back)
@@ -330,6 +334,7 @@ int pull_ctl(rekf_t *h)
     HIP_TRY(h, hipMemcpyAsync(h->ctl_staging, h->dev.ctl, sizeof(RekfCtl), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->n_ub = h->ctl_staging->n;
+    h->n_det = h->n_ub;
     h->n_exact = true;
     h->full = h->ctl_staging->n >= h->dev.n_max;
     h->flags_last = h->ctl_staging->err;
@@ -356,6 +361,7 @@ int refresh_mirror(rekf_t *h)
     for (int q = 0; q < 3; ++q) h->mir_mu[q] = h->host_slots[q].v;
     for (int q = 0; q < 9; ++q) h->mir_P[q] = h->host_slots[3 + q].v;
     peek_n(h);
+    if (h->n_exact) h->n_det = h->n_ub;              // (the publisher just waited for is the last one enqueued: n is exact here, by construction)
     h->flags_last = h->host_slots[12].aux;
     report_flags(h, h->flags_last);
     h->mir_valid = true;
@@ -623,7 +629,7 @@ int rekf_reserve(rekf_t *h, int new_max_landmarks)
     adopt_buffers(h, nb, new_max_landmarks);
     free_buffers(old);
     h->full = false;
-    h->n_ub = n; h->n_exact = true;
+    h->n_ub = n; h->n_det = n; h->n_exact = true;
     return REKF_OK;
 }
 
@@ -693,7 +699,8 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         h->last_scan_empty = true;
         return REKF_OK;
     }
-    if (h->auto_grow && h->n_ub + 2 * K > h->dev.n_max) {
+    if (h->mir_valid && h->n_exact) h->n_det = h->n_ub;
+    if (h->auto_grow && h->n_det + 2 * K > h->dev.n_max) {
         // room for K new reflectors is not certain.  Learn the exact n (waits for the publisher in flight: only when the BOUND says
         // so -- and a doubling leaves room for many scans), then re-reserve rather than let k_mid drop reflectors (cc:311-364 never does).
         int rc = refresh_mirror(h);
@@ -874,6 +881,7 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         // the scan may have appended up to K reflectors; the exact n stays on the device until it is published
         const int grown = n_ub + 2 * K;
         h->n_ub = grown > h->dev.n_max ? h->dev.n_max : grown;
+        h->n_det = (h->n_det + 2 * K > h->dev.n_max) ? h->dev.n_max : h->n_det + 2 * K;
         h->n_exact = false;
     }
     hipError_t le = hipGetLastError();
@@ -887,7 +895,7 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         if (hipMemcpy(h->ctl_staging, h->dev.ctl, sizeof(RekfCtl), hipMemcpyDeviceToHost) == hipSuccess) {
             h->front_total = h->ctl_staging->front_count;
             h->dd_total = h->ctl_staging->dd_done;
-            h->n_ub = h->ctl_staging->n; h->n_exact = true; h->full = h->n_ub >= h->dev.n_max;
+            h->n_ub = h->ctl_staging->n; h->n_det = h->n_ub; h->n_exact = true; h->full = h->n_ub >= h->dev.n_max;
         }
         (void)hipGetLastError();
         h->pub_valid = false; h->mir_valid = false;
@@ -1006,6 +1014,7 @@ int rekf_set_state(rekf_t *h, double t, int n, const double *mu, const double *s
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->time = t;
     h->n_ub = n;
+    h->n_det = n;
     h->n_exact = true;
     h->full = n >= h->dev.n_max;
     h->flags_last = 0;
