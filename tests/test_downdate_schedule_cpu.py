@@ -71,7 +71,7 @@ def device_tiles(T, grid, lo, x, sub, block):
     return out
 
 
-@pytest.mark.parametrize("slots", [256, 304, 64])
+@pytest.mark.parametrize("slots", [256, 304, 64, 239, 223, 199])     # (the odd ones: the downdate as a ROLE of k_mid's grid, 256 - K - mid workgroups)
 def test_every_lower_triangle_tile_exactly_once(slots):
     for T in range(1, 65):
         grid, lo, x, sub = host_plan(T, slots)
@@ -96,8 +96,8 @@ def test_host_bound_of_T_may_exceed_the_kernels():
     """The host sizes the grid from an upper bound of n (T_host >= T_kernel) and then passes no schedule: the kernel derives
     (lo, x, sub) from its own T and the grid it finds; its own T must still be covered exactly once."""
     for T_k in range(1, 40):
-        for T_h in (T_k, T_k + 1, T_k + 7, 2 * T_k):
-            grid, _, _, _ = host_plan(T_h)
+        for T_h, slots in [(T_k, 256), (T_k + 1, 256), (T_k + 7, 256), (2 * T_k, 256), (T_k + 1, 223), (T_k + 3, 199)]:
+            grid, _, _, _ = host_plan(T_h, slots)
             lo, x, sub = kernel_plan(T_k, grid)
             seen = set()
             for b in range(grid):
