@@ -62,7 +62,7 @@ def rekf():
     L.rekf_predict_state_full.argtypes = [vp, C.c_double, dp, ip, vp, C.c_long, vp, C.c_long]
     L.rekf_get_flags.argtypes = [vp, ip]
     L.rekf_get_time.argtypes = [vp, dp]
-    L.rekf_get_pose.argtypes = [vp, dp, dp, dp]
+    L.rekf_get_pose.argtypes = [vp, vp, vp, vp]          # (double *: plain addresses of a preallocated buffer, ekf_slam.py -- the per-call path)
     L.rekf_get_n.argtypes = [vp, ip]
     L.rekf_get_marker_ellipses.argtypes = [vp, vp, C.c_int, ip]
     L.rekf_get_state.argtypes = [vp, dp, ip, vp, C.c_long, vp, C.c_long]

@@ -268,13 +268,18 @@ class ReflectorEKFSLAM:
                   "handle_odometry")
 
     def handle_observation(self, t, cloud, gps_pose=None):
-        cloud = np.ascontiguousarray(cloud, dtype=np.float32).reshape(-1, 2)
+        # (the per-scan path: a float32 C-contiguous array goes through as it is, by address -- marshalling was 3 us of a 36 us scan-to-pose)
+        if not (type(cloud) is np.ndarray and cloud.dtype == np.float32 and cloud.flags.c_contiguous):
+            cloud = np.ascontiguousarray(cloud, dtype=np.float32)
+        if cloud.size & 1:
+            raise ValueError("observations are (x, y) pairs")
         gp = None
         if gps_pose is not None:
             g = np.ascontiguousarray(gps_pose, dtype=np.float64)
-            gp = g.ctypes.data_as(C.c_void_p)
-        self._chk(self._L.rekf_handle_observation(self._h, float(t), cloud.ctypes.data_as(C.c_void_p),
-                                                  cloud.shape[0], gp), "HandleObservationMessage")
+            gp = g.ctypes.data
+        rc = self._L.rekf_handle_observation(self._h, t, cloud.ctypes.data, cloud.size >> 1, gp)
+        if rc != 0:
+            self._chk(rc, "HandleObservationMessage")
 
     def SetGlobalMap(self, m: Map):
         xy = np.ascontiguousarray(m.reflector_map_, dtype=np.float32).reshape(-1, 2)
@@ -293,11 +298,16 @@ class ReflectorEKFSLAM:
         return n.value
 
     def pose(self):
-        t = C.c_double()
-        mu3 = (C.c_double * 3)()
-        s9 = (C.c_double * 9)()
-        self._chk(self._L.rekf_get_pose(self._h, C.byref(t), mu3, s9), "get_pose")
-        return t.value, np.array(mu3[:]), np.array(s9[:]).reshape(3, 3).T.copy()
+        b = self.__dict__.get("_pose_buf")
+        if b is None:                                   # time, mu[3], sigma[9] (column-major), reused by every call
+            b = self._pose_buf = np.zeros(13)
+            a = b.ctypes.data
+            self._pose_ptr = (a, a + 8, a + 32)
+        p = self._pose_ptr
+        rc = self._L.rekf_get_pose(self._h, p[0], p[1], p[2])
+        if rc != 0:
+            self._chk(rc, "get_pose")
+        return float(b[0]), b[1:4].copy(), b[4:13].reshape(3, 3).T.copy()
 
     def marker_ellipses(self, max_landmarks: int | None = None) -> np.ndarray:
         """Node::ReflectorToRosMarkers' per-landmark numbers (src/ros_node.cc:750-765), computed on the device:
