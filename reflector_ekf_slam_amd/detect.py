@@ -52,13 +52,13 @@ def _rdet():
     L.rdet2d_set_sensor_to_base_link.argtypes = [vp, dp]
     L.rdet2d_handle_odometry.argtypes = [vp, C.c_double, dp, dp, C.c_double, C.c_double, C.c_double]
     L.rdet2d_handle_scan.argtypes = [vp, C.c_double, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
-                                     C.c_float, vp, vp, C.c_int, vp, C.c_int, ip, dp]
+                                     C.c_float, vp, vp, C.c_int, vp, C.c_int, vp, vp]     # (int *K, double *t: addresses of per-handle result slots)
     L.rdet2d_get_range_data.argtypes = [vp, fp, vp, C.c_int, ip]
     if hasattr(L, "rdet3d_create"):
         L.rdet3d_create.argtypes = [C.POINTER(Rdet3dOptions), dp, C.c_int, C.c_int, C.POINTER(vp)]
         L.rdet3d_destroy.argtypes = [vp]
         L.rdet3d_destroy.restype = None
-        L.rdet3d_handle_cloud.argtypes = [vp, C.c_double, vp, C.c_int, vp, C.c_int, ip, dp]
+        L.rdet3d_handle_cloud.argtypes = [vp, C.c_double, vp, C.c_int, vp, C.c_int, vp, vp]
     _lib_rdet = L
     return L
 
@@ -111,6 +111,22 @@ def project2d(translation_xyz, quat_wxyz):
     return np.array([translation_xyz[0], translation_xyz[1], math.atan2(dy, dx)], dtype=np.float64)
 
 
+def _as_f32(a):
+    """A float32 C-contiguous ndarray as it is, anything else converted."""
+    if type(a) is np.ndarray and a.dtype == np.float32 and a.flags.c_contiguous:
+        return a
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _result_slots(det):
+    """Per-handle result buffers of the detectors' per-scan calls and their addresses: (centres, K, time, &centres, &K, &time)."""
+    out = det.__dict__.get("_out")
+    if out is None:
+        c, k, t = np.zeros((MAX_CENTERS, 2), np.float32), np.zeros(1, np.int32), np.zeros(1, np.float64)
+        out = det._out = (c, k, t, c.ctypes.data, k.ctypes.data, t.ctypes.data)
+    return out
+
+
 class LaserReflectorDetect:
     """reflector_detect::LaserReflectorDetect (laser_reflector_detect.h:17-31)."""
 
@@ -159,20 +175,18 @@ class LaserReflectorDetect:
         return None
 
     def HandleLaserScan(self, msg: LaserScan) -> Observation:
-        ranges = np.ascontiguousarray(msg.ranges, dtype=np.float32)
-        inten = np.ascontiguousarray(msg.intensities, dtype=np.float32)
-        assert ranges.shape == inten.shape
-        centers = np.zeros((MAX_CENTERS, 2), np.float32)
-        K = C.c_int()
-        t = C.c_double()
-        rc = self._L.rdet2d_handle_scan(self._h, float(msg.stamp), msg.angle_min, msg.angle_max, msg.angle_increment,
-                                        msg.scan_time, msg.range_min, msg.range_max,
-                                        ranges.ctypes.data_as(C.c_void_p), inten.ctypes.data_as(C.c_void_p),
-                                        ranges.shape[0], centers.ctypes.data_as(C.c_void_p), MAX_CENTERS,
-                                        C.byref(K), C.byref(t))
+        # (the per-scan path: float32 C-contiguous arrays go through by address, the result slots are the handle's -- the marshalling
+        # of fresh ctypes objects and a zeroed centre array per call was 8 us of a 24 us call)
+        ranges, inten = _as_f32(msg.ranges), _as_f32(msg.intensities)
+        if ranges.shape != inten.shape:
+            raise ValueError("ranges and intensities differ in length")
+        out = _result_slots(self)
+        rc = self._L.rdet2d_handle_scan(self._h, msg.stamp, msg.angle_min, msg.angle_max, msg.angle_increment,
+                                        msg.scan_time, msg.range_min, msg.range_max, ranges.ctypes.data, inten.ctypes.data,
+                                        ranges.shape[0], out[3], MAX_CENTERS, out[4], out[5])
         if rc != 0:
             raise RdetError(rc, "HandleLaserScan")
-        return Observation(t.value, centers[: K.value].copy())
+        return Observation(float(out[2][0]), out[0][: int(out[1][0])].copy())
 
     def GetRangeData(self) -> RangeData:
         n = C.c_int()
@@ -212,12 +226,11 @@ class PointCloudReflectorDetect:
             pass
 
     def HandlePointCloud(self, stamp: float, xyzi) -> Observation:
-        pts = np.ascontiguousarray(xyzi, dtype=np.float32).reshape(-1, 4)
-        centers = np.zeros((MAX_CENTERS, 2), np.float32)
-        K = C.c_int()
-        t = C.c_double()
-        rc = self._L.rdet3d_handle_cloud(self._h, float(stamp), pts.ctypes.data_as(C.c_void_p), pts.shape[0],
-                                         centers.ctypes.data_as(C.c_void_p), MAX_CENTERS, C.byref(K), C.byref(t))
+        pts = _as_f32(xyzi)
+        if pts.size & 3:
+            raise ValueError("points are (x, y, z, intensity) quadruples")
+        out = _result_slots(self)
+        rc = self._L.rdet3d_handle_cloud(self._h, stamp, pts.ctypes.data, pts.size >> 2, out[3], MAX_CENTERS, out[4], out[5])
         if rc != 0:
             raise RdetError(rc, "HandlePointCloud")
-        return Observation(t.value, centers[: K.value].copy())
+        return Observation(float(out[2][0]), out[0][: int(out[1][0])].copy())
