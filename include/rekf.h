@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define REKF_ABI_VERSION 5
+#define REKF_ABI_VERSION 6
 
 /* Most observations one scan may carry (K).  The reference has no limit (reflector_ekf_slam.cc:397 loops over
  * obs.cloud_.size()); this one is a buffer size, equal to what the detectors of rdet.h can emit (RDET_MAX_CENTERS).
@@ -65,11 +65,9 @@ enum {
  * reflectors of a scan were dropped (the reference grows without bound, reflector_ekf_slam.cc:311-364); the
  * innovation covariance S of some scan had a non-positive pivot (the update was applied as computed); a hand-over INSIDE a launch
  * (workgroups of k_mid waiting for the scan's front end or the previous scan's augmentation, which run as other workgroups of the same
- * launch when this handle is the only one at work on the GPU) gave up waiting -- the state is no longer meaningful; rekf_sync returns
- * REKF_ERR_HIP.  Cannot happen unless other work holds the GPU's CUs for a fraction of a second (several PROCESSES sharing the GPU:
- * set REKF_FRONT_IN_MID=0 and REKF_AUG_IN_MID=0 in their environment; handles of ONE process are noticed and handled).
- * REKF_ONE_LAUNCH=1 (read at rekf_create) opts small states into one launch per scan -- downdate, front end and update as roles of one
- * grid; same results, same speed on MI355X, same alone-on-the-GPU rule. */
+ * launch) gave up waiting -- the state is no longer meaningful; rekf_sync returns REKF_ERR_HIP.  Such hand-overs exist ONLY on a handle
+ * the caller has declared EXCLUSIVE (rekf_set_exclusive, below): by default no launch of this library contains a workgroup that waits
+ * for another one. */
 enum { REKF_FLAGBIT_CAPACITY = 1, REKF_FLAGBIT_SINGULAR = 2, REKF_FLAGBIT_STARVED = 4 };
 
 enum { REKF_ODOM_DIFF = 0, REKF_ODOM_OMNI = 1 };   /* sensor::OdometryModel, sensor_data.h:56-60 */
@@ -109,6 +107,13 @@ void rekf_destroy(rekf_t *h);
  * is then the INITIAL capacity), and takes auto_grow = false for a fixed one. */
 int rekf_reserve(rekf_t *h, int new_max_landmarks);
 int rekf_set_auto_grow(rekf_t *h, int on);
+/* EXCLUSIVE (off by default; REKF_EXCLUSIVE=1 in the environment at rekf_create switches it on): the caller promises that this handle
+ * has the GPU to itself -- no other process, no other stream of this process keeps its CUs busy.  The library then lets a scan's front
+ * end (Predict's pose, ReflectorMatch) run as the first workgroups of the scan's own launch, with the update's workgroups waiting for it
+ * INSIDE the launch (one launch per scan, the match off the launch boundary).  Safe only under that promise: with other work on the
+ * GPU the waiting workgroups can hold the CUs the working ones need (REKF_FLAGBIT_STARVED).  Even on an exclusive handle the
+ * hand-overs are used only while it is the process's only live handle.  Results are the same bits either way. */
+int rekf_set_exclusive(rekf_t *h, int on);
 int rekf_get_capacity(rekf_t *h, int *max_landmarks);
 
 /* map_ as LoadMapFromTxtFile leaves it (reflector_ekf_slam.cc:80-94): M points

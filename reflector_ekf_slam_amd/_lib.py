@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 MAX_OBS = 256
-REKF_ABI_VERSION = 5          # must equal REKF_ABI_VERSION of include/rekf.h and rekf_abi_version() of the built library
+REKF_ABI_VERSION = 6          # must equal REKF_ABI_VERSION of include/rekf.h and rekf_abi_version() of the built library
 
 
 class RekfOptions(C.Structure):
@@ -78,6 +78,7 @@ def rekf():
     L.rekf_device_layout.argtypes = [vp, ip, ip, C.POINTER(vp), C.POINTER(vp)]
     L.rekf_reserve.argtypes = [vp, C.c_int]
     L.rekf_set_auto_grow.argtypes = [vp, C.c_int]
+    L.rekf_set_exclusive.argtypes = [vp, C.c_int]
     L.rekf_get_capacity.argtypes = [vp, ip]
     L.rekf_debug_time_kernel.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
     if hasattr(L, "rekf_debug_inject_failure"):           # (absent from older builds that scripts/gpu_ab.py compares against)

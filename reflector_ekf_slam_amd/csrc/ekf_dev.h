@@ -4,7 +4,7 @@
 // rekf_create for n_max = 3 + 2*max_landmarks and never reallocated:
 //
 //   mu, mu_out [ld]      state mean  [x, y, theta, l0x, l0y, l1x, ...], double-buffered (k_mid reads one, writes the other)
-//   P    [ld x ld]       covariance, COLUMN-major (Eigen::MatrixXd order,
+//   P    [ld x ld] x 2   covariance, COLUMN-major (Eigen::MatrixXd order,
 //                        reference ekf_slam_interface.h:47), leading dimension
 //                        ld = roundup(n_max, 64) so every 64x64 tile is in bounds
 //                        and every column starts on a 512-byte boundary.
@@ -14,8 +14,9 @@
 //                        symmetric, and the rank-m downdate moves half the bytes.  The host getters mirror on the way out.
 //   HPt  [ld x 64]       HPt = (H P)^T gathered from the ROWS of P, column-major
 //   Kn   [ld x 64]       Kn = -K = -W S^-1, column-major
-//   KnB, HPtB [4 x MR_PAD]  copies of rows nb..nb+3 of Kn / HPt, nb = 64*floor(n/64), when n mod 64 <= 4
-//                        (written by k_mid for k_downdate2's border strips)
+//                        TWO buffers (round 5): the stored covariance is ONE SCAN BEHIND the filter -- a scan's rank-m downdate (and its
+//                        Predict) stay PENDING as the panels below and are applied by the NEXT scan's launch, whose downdate role reads one
+//                        buffer and writes the other while its mid role reads the first and corrects what it gathers (k_mid)
 //   ctl                  RekfCtl below: n, error flags, the scan record
 // Rows >= n of HPt and Kn are kept exactly zero, and so are their columns [m, kc_ub), so that the tile kernel
 // never needs bounds checks on P.  W = P H^T and S^-1 never leave the chip (k_mid).
@@ -25,9 +26,8 @@
 
 #define REKF_MAX_OBS_DEV 64                          // observations of a scan that travel by value with the launch and update jointly
 #define REKF_MAX_OBS_WIDE 256                        // most observations per scan at all (wide scans: staged in HBM, updated in exact block steps)
-#define REKF_MR_PAD 128                             // row stride of KnB / HPtB
+#define REKF_CP_LD 68                               // row stride (and rows) of a write-ahead correction panel: sub-block rows 0 .. 66
 #define REKF_PANEL_COLS 64                          // columns of Kn / HPt: one block step of the update has at most 64 innovation rows
-#define REKF_STRIP_MAX 4                            // border rows (n mod 64) that k_downdate handles as strips
 
 enum { REKF_FLAG_CAPACITY = 1, REKF_FLAG_SINGULAR = 2, REKF_FLAG_STARVED = 4 };
 
@@ -56,16 +56,18 @@ struct RekfCtl {
     // ---- the 3 x 3 pose block AFTER the update (round 3): evaluated once, by k_mid's workgroup 0 (which has K's pose rows and the pose
     // columns of H P in LDS), published to the host from there -- GetPose does not wait for the downdate -- and taken over BY VALUE by
     // the downdate's tile (0, 0), so that the published block and the stored one are the same bits
-    double post_C9[9];
+    double post_C9[2][9];             // (by scan parity: the held-back downdate of scan t reads scan t's block while scan t + 1's k_mid writes its own)
     // ---- the scan's match results in the form k_mid works with (round 3): ordered compaction of the per-observation results, the rank of
     // every matched landmark among the matched ones, the slots of the sub-block.  Written by the front end -- the workgroup whose
     // observation is the last to be matched (front_count reaches the launch's front_target) -- so that k_mid starts with one load of
     // this record instead of a control-block round trip, ballots and a 64 x 64 rank count on its critical path.  Whole scans only
     // (at most 32 observations); the block steps of a wide scan build theirs in k_mid from k_compact_wide's lists.
     struct Rec {
-        int cnt[8];                   // pairs, m, m_pad, state pairs, pose rows?, new reflectors (clamped to the capacity), -, -
-        int pair_obs[32], pair_id[32], pair_state[32], rank[32];
-        int urow[36], ukc[36];        // slot -> first global row / first sub-block column (slots 0, 1 = rows {0,1}, {2}; 2 + rank = a state pair)
+        int cnt[8];                   // pairs, m, m_pad, state pairs, pose rows?, new reflectors (clamped to the capacity), map pairs, K
+        int pair_obs[32], pair_id[32], pair_state[32];
+        int urank[32];                // state pair -> rank of its landmark among the DISTINCT matched landmarks (two observations on one landmark, Q6, share it)
+        int uid[32];                  // the distinct matched landmarks in ascending order (uid[urank] = landmark id)
+        int nu, pad_[3];              // how many: the sub-block k_mid gathers has 3 + 2 nu rows, in ascending global order
         int newid[64];                // observation indices of the new reflectors
     } rec;
     unsigned front_count;             // observations matched so far, over the life of the handle (never reset)
@@ -77,8 +79,15 @@ struct RekfCtl {
     struct AugRec { int n_before, n2; float obs[2 * REKF_MAX_OBS_DEV]; } augrec[2];
     unsigned aug_done;                // scan id of the last k_mid whose workgroup 0 has appended its predecessor's new reflectors
     unsigned rec_seq;                 // scan id of the last scan whose match record (rec) the front role INSIDE k_mid's grid has completed
-    unsigned dd_done;                 // workgroups of a downdate role INSIDE k_mid's grid (small states: one launch per scan) that have finished,
-                                      // over the life of the handle; the mid role waits for RekfFrontArgs::dd_target before it touches P
+    // WRITE-AHEAD CORRECTION (round 5): at the end of a scan's k_mid the workgroups that own rows of the scan's sub-block R write the scan's
+    // rank-m correction of P(R, R) -- sum_k HPt(lo, k) Kn(hi, k), the downdate's own arithmetic -- to RekfDev::cp (by scan parity).  The
+    // next scan's k_mid, which meets the stored P one scan behind, adds it to what it gathers when its own R is the same set of landmarks
+    // (usually: the 32 nearest reflectors change every 5-10 scans); else it computes the correction itself
+    int cp_uid[2][32];                // the landmarks the panel of that parity covers, ascending
+    int cp_nu[2];
+    unsigned cp_scan[2];              // ... and the scan (RekfFrontArgs::scan_id) that wrote it
+    unsigned dd_queue[2];             // the downdate role INSIDE k_mid's grid takes its tiles from a queue: next work item, by launch parity (the
+                                      // mid role's workgroup 0 zeroes the other parity's counter for the next launch)
     long long dbg[32];            // scratch for in-kernel timing experiments (REKF_DEBUG_TIMING builds)
 };
 
@@ -109,9 +118,15 @@ struct RekfFrontArgs {
                               // n + 2 n_new rows (the new reflectors' means are there: k_mid writes them)
     int front_in_mid;         // k_mid: the first front_in_mid workgroups of its grid are this scan's front end (a host-predicted scan behind a
                               // pose read-back: no launch of its own for the match); the others wait for RekfCtl::rec_seq
-    int dd_in_mid;            // k_mid (one launch per scan, small states): the first dd_in_mid workgroups of its grid are the PREVIOUS scan's downdate
-                              // (four of their eight waves), then front_in_mid workgroups of front end, then the mid workgroups
-    unsigned dd_target;       // RekfCtl::dd_done once that downdate role is through
+    int dd_in_mid;            // k_mid: the workgroups from dd_first on are the PREVIOUS scan's downdate (four of their eight waves; tiles from
+    int dd_first;             // RekfCtl::dd_queue[dd_par]); 0: none.  The front role's workgroups join them when their observation is matched
+    int dd_par;
+    int n_mid;                // k_mid: workgroups of the mid role (behind the front_in_mid front workgroups)
+    int corr;                 // k_mid: the stored P is one scan behind -- what is gathered takes the pending downdate (dp's panels, kc_ub columns) ...
+    int corr_pred;            // ... and, first, the pending Predict (RekfCtl::pred[corr_pred], -1: none); the pose block is RekfCtl::post_C9[corr_post]
+    int corr_post;
+    unsigned corr_scan;       // ... and that scan's id (its write-ahead correction, RekfCtl::cp_scan, must carry it)
+    int cp_write;             // k_mid: leave this scan's write-ahead correction (whole scans)
     int aug_in_mid;           // k_mid: the previous scan's augmentation has not run: workgroup 0 appends its rows first (RekfCtl::augrec), n = n_before + 2 n2
     unsigned scan_id;         // running number of the scan (RekfCtl::aug_done)
     int apply_pred;           // k_mid: apply the pending Predict to the gathered P (whole scan or FIRST block step of a wide scan)
@@ -131,10 +146,11 @@ struct RekfDev {
     double *mu;         // the current mean
     double *mu_out;     // k_mid writes the updated mean here; the host swaps mu / mu_out behind that launch
     const double *mu_lin; // the mean the scan is linearised at (= mu, except in the later block steps of a wide scan)
-    double *P;
+    double *P;          // the stored covariance (every reader's source)
+    double *P_out;      // k_downdate2 / the downdate role: where the downdated tiles go (= P: in place; the other buffer: one launch per scan)
+    double *cp;         // write-ahead corrections, 2 x REKF_CP_LD x REKF_CP_LD (by scan parity; RekfCtl::cp_*)
     double *HPt;        // (H P)^T, column-major, REKF_PANEL_COLS columns
     double *Kn;         // -K, column-major, REKF_PANEL_COLS columns
-    double *KnB, *HPtB; // rows nb..nb+3 of Kn / HPt, [REKF_STRIP_MAX][MR_PAD] row-major (k_downdate2 border strips)
     float *map_xy;      // M_map x 2
     double *map_cov;    // M_map x 4 row-major
     int M_map;
@@ -151,6 +167,7 @@ struct RekfDev {
     int dd_sub;         // k_downdate2: class B holds the tiles with I >= J + dd_sub (2: a class-A workgroup also takes the tile below its
                         // diagonal tile; 1: it does not; 0: the host does not know n exactly -- the kernel derives the schedule itself)
     int dd_grid;        // k_dd_front: workgroups [0, dd_grid) are the downdate, the rest the next scan's front end (0: k_downdate2, the whole grid)
+    int post_slot;      // k_downdate2 / k_mid: the RekfCtl::post_C9 slot of the scan this view belongs to (k_mid writes it, the scan's downdate stores it)
     int pred_slot;      // k_downdate2: >= 0: the scan's pending Predict (RekfCtl::pred[pred_slot]) is applied to the tiles of column 0 as they are
                         // read (and so committed by this launch); -1: nothing pending (later block steps of a wide scan, timing hook)
     int kc_ub;          // host bound of m_pad for the current scan, rounded up to 16 (0: unknown); columns [m, kc_ub) of HPt / Kn are zero
@@ -253,23 +270,14 @@ __host__ __device__ static inline double rekf_plower(const double *P, int ld, in
     return (i >= j) ? P[(size_t)i + (size_t)j * (size_t)ld] : P[(size_t)j + (size_t)i * (size_t)ld];
 }
 
-// first row of the thin border that k_downdate treats as strips, or -1 (n a multiple of 64, border wider than
-// REKF_STRIP_MAX rows, or less than one full tile)
-__host__ __device__ static inline int rekf_strip_base(int n)
-{
-    const int rem = n % 64;
-    return (rem > 0 && rem <= REKF_STRIP_MAX && n >= 64) ? n - rem : -1;
-}
-
 // launch wrappers (ekf_kernels.hip)
 void rekf_launch_apply_predict(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);
 void rekf_launch_front_mb(const RekfDev &d, const RekfFrontArgs &a, int n_ub, hipStream_t s);
 void rekf_launch_compact_wide(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);
-void rekf_launch_mid(const RekfDev &d, const RekfFrontArgs &a, int n_ub, int m_ub, bool mode_grow, hipStream_t s);   // mode_grow: the filter can still grow, or the previous scan's augmentation rides in this launch
+void rekf_launch_mid(const RekfDev &d, RekfFrontArgs &a, int n_ub, int m_ub, bool mode_grow, hipStream_t s);   // mode_grow: the filter can still grow, or the previous scan's augmentation rides in this launch
 void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s);
 void rekf_launch_dd_front(const RekfDev &d, int n_ub, const RekfDev &dn, const RekfFrontArgs &an, hipStream_t s);
-int rekf_one_launch_fits(int dd_n_ub, int n_ub, int K);
-int rekf_launch_one(const RekfDev &dd, int dd_n_ub, const RekfDev &d, RekfFrontArgs &a, int n_ub, int m_ub, bool mode_grow, unsigned dd_done_before, hipStream_t s);   // small states: one launch per scan (k_mid<2, MODE, KC>); 0: no such form for this shape
+int rekf_launch_scan(const RekfDev &dd, const RekfDev &d, RekfFrontArgs &a, int n_ub, int m_ub, int front_wgs, hipStream_t s);   // ONE launch per scan: [front end |] mid role (corrects what it gathers by dd's pending panels) | dd's downdate from dd.P into dd.P_out
 void rekf_launch_augment(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);
 void rekf_launch_ellipses(const RekfDev &d, double *out5, int cap, hipStream_t s);
 void rekf_launch_publish_pose(const RekfDev &d, RekfHostSlot *hout, int seq, hipStream_t s);

@@ -202,10 +202,21 @@ __device__ static inline void argmin2_combine(double &a1, int &ja, double &a2, d
     a2 = n2;
 }
 // One wave: the scan's per-observation match results (kind, landmark / map index; lane = observation, K <= 32) -> the record k_mid
-// works with (RekfCtl::Rec): ordered compaction by observation, the rank of every matched landmark among the matched ones (ties by
-// observation: neighbouring landmarks share cache lines of a column of P, k_mid's gathers run over the row slots in this order), the
-// slots of the sub-block, the getters' counts.  `rec` is global memory (the front end's last workgroup, for the k_mid behind the
+// works with (RekfCtl::Rec): ordered compaction by observation, and the DISTINCT matched landmarks in ascending order -- the rows of
+// the sub-block of P that S = H P H^T + Q touches: rows 0, 1, 2, then (3 + 2 id, 4 + 2 id) per distinct landmark; two observations
+// matched to ONE landmark (Q6) share its rows.  `rec` is global memory (the front end's last workgroup, for the k_mid behind the
 // kernel boundary) or LDS (every mid workgroup for itself, when the front end runs inside k_mid's own grid).
+// distinct_ranks: key = landmark id of a matched lane (0x7fffffff otherwise), rk = its rank among the keys (ties by lane), M matched
+// lanes -> this lane's rank among the DISTINCT keys; lane r < M also learns the r-th smallest key and whether it repeats its predecessor
+__device__ static inline int distinct_ranks(int key, int rk, int M, int lane, int &sorted, bool &dup, int &nu)
+{
+    sorted = __builtin_amdgcn_ds_permute(rk << 2, key);            // lane r: the r-th smallest key (r < M; unmatched lanes collide above M)
+    const int prev = __shfl_up(sorted, 1, WAVE);
+    dup = lane > 0 && lane < M && sorted == prev;
+    const unsigned long long D = __ballot(dup);
+    nu = M - __popcll(D);
+    return rk - __popcll(D & ((2ull << (rk & 63)) - 1ull));       // repeats at sorted positions <= rk
+}
 __device__ static inline void compact_record(RekfCtl::Rec *rec, RekfCtl *ctl, int kind, int oidx, int lane, int K, int n, int n_max, int has_gps)
 {
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -220,21 +231,21 @@ __device__ static inline void compact_record(RekfCtl::Rec *rec, RekfCtl *ctl, in
         N2 = room;
     }
     int rk = 0;
-    {
-        const int key = (kind == 1) ? oidx : 0x7fffffff;
+    const int key = (kind == 1) ? oidx : 0x7fffffff;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {                               // K <= 32 observations in a whole scan
-            const int oq = __builtin_amdgcn_readlane(key, q);
-            rk += (oq < key || (oq == key && q < lane)) ? 1 : 0;
-        }
+    for (int q = 0; q < 32; ++q) {                                   // K <= 32 observations in a whole scan
+        const int oq = __builtin_amdgcn_readlane(key, q);
+        rk += (oq < key || (oq == key && q < lane)) ? 1 : 0;
+    }
+    int sorted, nu; bool dup;
+    const int ur = distinct_ranks(key, rk, M, lane, sorted, dup, nu);
+    {
+        const unsigned long long D = __ballot(dup);                  // the sorted position `lane` holds a distinct landmark: its id, by distinct rank
+        if (lane < M && lane < 32 && !dup) rec->uid[lane - __popcll(D & ((1ull << lane) - 1ull))] = sorted;
     }
     if (kind == 1) {
         const int p = __popcll(ms & lt);
-        if (p < 32) {
-            rec->pair_obs[p] = lane; rec->pair_id[p] = oidx; rec->pair_state[p] = 1;
-            rec->rank[p] = rk;
-            rec->urow[2 + rk] = 3 + 2 * oidx; rec->ukc[2 + rk] = 3 + 2 * p;
-        }
+        if (p < 32) { rec->pair_obs[p] = lane; rec->pair_id[p] = oidx; rec->pair_state[p] = 1; rec->urank[p] = ur; }
     } else if (kind == 0) {
         const int p = __popcll(mm & lt);
         if (M + p < 32) { rec->pair_obs[M + p] = lane; rec->pair_id[M + p] = oidx; rec->pair_state[M + p] = 0; }
@@ -247,7 +258,7 @@ __device__ static inline void compact_record(RekfCtl::Rec *rec, RekfCtl *ctl, in
         const int m = (MM > 0) ? 2 * MM + (has_gps ? 3 : 0) : 0;
         rec->cnt[0] = MM; rec->cnt[1] = m; rec->cnt[2] = (m + 15) & ~15; rec->cnt[3] = M; rec->cnt[4] = (has_gps && MM > 0) ? 1 : 0;
         rec->cnt[5] = N2; rec->cnt[6] = Mm; rec->cnt[7] = K;
-        rec->urow[0] = 0; rec->ukc[0] = 0; rec->urow[1] = 2; rec->ukc[1] = 2;
+        rec->nu = nu;
     }
 }
 // The front end as a ROLE of a workgroup of NT threads (a multiple of 256): k_front_mb below is nothing else; the fused kernel
@@ -325,7 +336,7 @@ __device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs
         // libm calls (2.1 us) but for one; theta' itself (what is committed to the mean) is computed as written, after the barrier.
         // (Only on this path: when the host predicts, above, cos / sin are the reference's own.)
 #pragma clang fp contract(off)
-        if (b == 0) for (int q = 0; q < 9; ++q) C9[q] = corner_in_ctl ? ctl->post_C9[q] : rekf_plower(P, (int)ld, q % 3, q / 3);
+        if (b == 0) for (int q = 0; q < 9; ++q) C9[q] = corner_in_ctl ? ctl->post_C9[(A.pred_slot ^ 1) & 1][q] : rekf_plower(P, (int)ld, q % 3, q / 3);
         const double mu2 = mu[2];
         const double dth = A.vt[2] * A.dt;            // = mo.d[2] (delta_theta = w dt in both models; no FMA: same bits)
         double th = mu2 + dth, sn, cs;
@@ -492,7 +503,9 @@ __device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs
 }
 __global__ __launch_bounds__(1024) void k_front_mb(RekfDev d, RekfFrontArgs A)
 {
-    front_role<1024>(d, A, (int)blockIdx.x, (int)gridDim.x, false);     // (1024 threads: one landmark each to stage; 256 do it in 1.1 us more)
+    // (1024 threads: one landmark each to stage; 256 do it in 1.1 us more.  A.corr: the stored P is a scan behind -- the pose block to
+    // predict from is the pending scan's RekfCtl::post_C9)
+    front_role<1024>(d, A, (int)blockIdx.x, (int)gridDim.x, A.corr != 0);
 }
 
 // ----------------------------------------------------------------------------
@@ -649,11 +662,14 @@ __device__ static inline v4d block_mma2(const v4d &At, const v4d &B, v4d acc)
 // Blocked Gauss-Jordan inverse of the (16 nbr) x (16 nbr) matrix whose block column w this wave holds in S[] (C layout),
 // in place; the scheme is described above k_solve.  EVERY wave of the workgroup must call it (one s_barrier per block
 // step); waves with w >= nbr only keep the barrier count.  Returns true when a pivot block was not positive definite.
-template <int NBR>
-__device__ static inline bool gj_invert_blocks(v4d (&S)[NBR], int nbr, int w, int g, int c, double (*s_col)[NBR + 1][REKF_PATCH], double *lp)
+template <int NBR, class Idle>
+__device__ static inline bool gj_invert_blocks(v4d (&S)[NBR], int nbr, int w, int g, int c, double (*s_col)[NBR + 1][REKF_PATCH], double *lp, Idle &&idle)
 {
+    // idle(slot): the waves 4.. (no block column; they only keep the barrier count) are called back before the first barrier (slot 0) and
+    // behind each one (slot K + 1) with work of the caller that must not sit on the pivot chain
     bool bad = false;
     const v4d zero4 = {0, 0, 0, 0};
+    if (w >= 4) idle(0);
     // wave 0 opens the chain: publish column 0, invert S(0,0)
     if (w == 0) {
 #pragma unroll
@@ -667,7 +683,7 @@ __device__ static inline bool gj_invert_blocks(v4d (&S)[NBR], int nbr, int w, in
         if (K >= nbr) break;
         double (*col)[REKF_PATCH] = s_col[K & 1];
         lds_barrier();                                // column K and D^-1 of step K are published
-        if (w >= nbr) continue;                       // a wave without a block column only keeps the barrier count
+        if (w >= nbr) { if (w >= 4) idle(K + 1); continue; }      // a wave without a block column only keeps the barrier count
         if (w == K) {
             // S(i,K) <- -S(i,K) D^-1 ; S(K,K) = D^-1 is already in place
 #pragma unroll
@@ -837,78 +853,98 @@ __device__ static inline void augment_rows(const RekfDev &d, int n, int N2, doub
     __syncthreads();
 }
 // ----------------------------------------------------------------------------
-// k_mid<NBR>: gather + solve + gain in ONE launch, for at most 16 NBR innovation rows per pass (NBR = 2: up to 16
+// k_mid<NBR, MODE>: gather + solve + gain in ONE launch, for at most 16 NBR innovation rows per pass (NBR = 2: up to 16
 // matched observations, NBR = 4: up to 32 -- every BASELINE.json configuration; scans with more run several passes,
 // see "block step" below).
 //
 // Round 1 ran k_gather -> k_solve -> k_gain: 24.4 us of kernels at C3 plus two kernel boundaries, of which the
 // single-workgroup solve alone was 12.9 us while 255 CUs idled.  The inverse is a LATENCY chain, not work: here
 // every workgroup owns 16 state rows and redoes it for itself -- the 67 x 67 sub-block of P that S = H P H^T + Q
-// touches is 2.2 k 16-byte loads per workgroup, L2 hits for all but the first -- and then needs neither a launch
-// boundary nor a trip through memory for S^-1:
-//   A  ordered compaction of the per-observation match results (as k_gather did), H rows packed in LDS;
-//   C  all gathers in flight at once: C1 the rows {0,1,2, matched landmark rows} of W = P H^T (for S),
-//      C2 this workgroup's 16 rows of W, C3 its 16 columns' (H P)^T, which goes straight to HBM for k_downdate;
+// touches is L2 hits for all but the first -- and then needs neither a launch boundary nor a trip through memory for S^-1:
+//   A  the scan's match record (ordered pairs, the distinct matched landmarks in ascending order), H rows packed in LDS;
+//   C  the sub-block P(R, R), R = {0, 1, 2, rows of the distinct matched landmarks}, and this workgroup's rows P(own, R), gathered
+//      IN THE MFMA C LAYOUT (round 5): the stored covariance is ONE SCAN BEHIND the filter (ekf_dev.h) -- a scan's downdate stays
+//      pending as its Kn / HPt panels and runs as a ROLE of the next scan's launch, beside this one, from one P buffer into the
+//      other -- so every gathered element takes, in the downdate's own arithmetic (the same v_mfma_f64_16x16x4 chain over k, then
+//      P + sum), the pending Predict and the pending rank-m correction sum_k HPt(min, k) Kn(max, k): the bits the downdate stores;
+//   D  W = P H^T (rows of S, own rows) and (H P)^T (own columns, straight to HBM for the downdate) out of LDS;
 //   E  S = H W + Q in the MFMA C layout, blocked Gauss-Jordan (gj_invert_blocks), S^-1 -> LDS;
 //   F  K(16 rows) = W S^-1 by MFMA out of LDS; Kn = -K -> HBM; mu += K (z - zhat) -- the reference's own
-//      association K_t * (z - z_hat), cc:306 (round 1 formed W (S^-1 dz)) -- pose commit, theta wrap.
+//      association K_t * (z - z_hat), cc:306 -- pose commit, theta wrap.
 // W itself is never written.  All workgroups compute bit-identical S^-1 (same code, same inputs, no atomics).
-// Like k_gather it never symmetrises: W from the columns of P, (H P)^T from its rows.
 // ----------------------------------------------------------------------------
 typedef double v2du __attribute__((ext_vector_type(2), aligned(8)));     // a row pair that starts on an odd row: 8-byte aligned
 #define MID_ROWS 16
-// MODE picks what else the launch hosts (separate instantiations: the steady state of a full filter, MODE 0, carries none of it --
-// the front role's LDS and the extra prologue cost that path 0.6 us per update when they were runtime branches):
+// All of k_mid's LDS is ONE dynamic arena (the downdate role and the mid role of a launch lay their own structures over it)
+template <int NBR> struct MidLds {
+    static constexpr int MP = 16 * NBR;           // most innovation rows (padded) this instance takes
+    static constexpr int NPAIR = MP / 2;
+    static constexpr int NUS = 3 + 2 * NPAIR;     // rows of the sub-block: 0, 1, 2, then two per DISTINCT matched landmark, ascending
+    static constexpr int NUSP = NUS + 1;          // its row stride in LDS (even: 16-byte pairs start on the odd columns 3 + 2 u, read as 8-byte-aligned vectors)
+    static constexpr int NBU = (NUS + 15) / 16;   // 16 x 16 blocks per side
+    static constexpr int LDS_S = MP + 16;         // row stride of S^-1 in LDS: = 16 mod 32 doubles, so the 4 k-rows of an MFMA operand read hit disjoint banks
+    static constexpr int SS = 16 * NBU + 4;       // row stride of the staged panel rows ([k][sub-block row]; the MFMA lanes of a padded block read past NUS)
+    struct Work {                                 // phases D .. F
+        double s_col[2][NBR + 1][REKF_PATCH];
+        double s_leaf[4][REKF_LEAF_SCRATCH];
+        alignas(16) double s_wc0[3][MP];          // rows 0..2 of W
+        alignas(16) double s_wcp[NPAIR][MP][2];   // state pair p: its two landmark rows of W, interleaved per column
+        alignas(16) double s_wown[MP][MID_ROWS];  // this workgroup's rows of W, [column r][row]
+        double s_dmu[4][MID_ROWS];
+        double s_dc[4][3][MID_ROWS];              // workgroup 0: partial sums of (K H P)(i, jc), jc = 0..2, per wave of phase F
+    };
+    union U {
+        Work w;
+        double s_stage[2][REKF_PANEL_COLS][SS];   // phase C: rows R of the pending HPt [0] / Kn [1] panels, [k][sub-block row]
+    } u;
+    alignas(16) double s_coef[8 * MP];            // H row r in 64 bytes
+    // the sub-block as gathered (+ pending Predict, + pending correction), both triangles; dead once W is formed: S^-1 (phase E) takes its place
+    alignas(16) double s_big[((NUS + 1) * NUSP > MP * LDS_S) ? (NUS + 1) * NUSP : MP * LDS_S];
+    alignas(16) double s_pw[16 * NBU][MID_ROWS];  // P(own rows, sub-block row s), [s][own row]
+    RekfCtl::Rec s_rec;                           // the scan's match record
+    int s_pcol[NPAIR];                            // pair -> its landmark's first sub-block row (3 + 2 urank), or -1 (map pair)
+    int s_upair[NPAIR];                           // distinct landmark (by rank) -> a state pair that observes it
+    int s_ownsub[MID_ROWS];                       // own row -> its sub-block row, or -1
+    double s_np[3];                               // the committed pose, for the new reflectors' means
+    double s_pred[12];                            // this scan's Predict: ab[0], ab[1], C9[0..8]
+    double s_cpred[12];                           // the PENDING scan's (a, b) [0..1] and its pose block after the update [2..10]
+};
+constexpr int REKF_DD_LDS_BYTES = 4 * 64 * 64 * (int)sizeof(double);      // the downdate role's four panels (KC = 64)
+
+// MODE picks what else the launch hosts (separate instantiations: the steady state of a full filter, MODE 0, carries none of it):
 //   0  nothing;  1  a filter that can still grow: workgroup 0 leaves the scan's augmentation record (RekfCtl::augrec) and, with
 //   A.aug_in_mid, first appends the PREVIOUS scan's new reflectors;  2  the scan's front end runs as the first A.front_in_mid
-//   workgroups of this grid (a host-predicted scan behind a pose read-back); also leaves the augmentation record.
-//   KCDD > 0 (small states, ONE launch per scan): the PREVIOUS scan's downdate (dd_body<KCDD>, on four of the eight waves) runs as the first
-//   A.dd_in_mid workgroups of the grid, the scan's front end (MODE bit 2; the motion model evaluated there) as the next A.front_in_mid; the
-//   mid workgroups wait for both inside the launch -- one-way: neither role waits for anybody, their workgroups are dispatched first.
-//   MODE there: 2 a full filter, 3 one that can still grow (bit 1: reads / appends the previous scan's augmentation record).
-//   dp: the downdate role's device view (that scan's panels); unused -- and never loaded -- when KCDD = 0.
-template <int KC> __device__ __forceinline__ void dd_body(const RekfDev &d);
-template <int NBR, int MODE, int KCDD = 0>
+//   workgroups of this grid; also leaves the augmentation record.
+// ONE LAUNCH PER SCAN (round 5, MODE 0 and 2): with A.dd_in_mid the workgroups from A.dd_first on are the PREVIOUS scan's downdate
+// (dd_body<64> on four of their eight waves, tiles from a queue, from dp.P into dp.P_out); the mid role reads dp.P = d.P and takes
+// the pending correction from dp's panels (A.corr); nobody waits for anybody inside the launch except the mid role for an in-grid
+// front end (MODE 2: exclusive handles only, rekf_api.hip).
+template <int KC, bool QUEUE> __device__ __forceinline__ void dd_body(const RekfDev &d, double *dd_smem, int wg, int nwg, unsigned *queue, bool pub_wg);
+template <int NBR, int MODE>
 __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, RekfFrontArgs A, RekfDev dp)
 {
-    constexpr bool FRONT = (MODE & 2) != 0, AUGR = (MODE & 1) != 0, AUGW = MODE >= 1, DDIN = KCDD > 0;
-    static_assert(!DDIN || FRONT, "the one-launch form hosts the front end too");
+    constexpr bool FRONT = (MODE & 2) != 0, AUGR = (MODE & 1) != 0, AUGW = MODE >= 1, DDROLE = MODE != 1;
     // ctl_first = d.ctl, as a leading pointer argument of its own: built with -mllvm -amdgpu-kernarg-preload-count the wave starts with it
     // in SGPRs, and the kernel's first loads (the match results) do not wait for the kernel-argument fetch
-    constexpr int MP = 16 * NBR;                  // most innovation rows (padded) this instance takes
-    constexpr int NPAIR = MP / 2;
-    constexpr int NRS = NPAIR + 2;                // row slots of the sub-block: state pairs (sorted by landmark), rows {0,1}, row {2}
-    constexpr int NKC = 3 + MP;                   // its columns: 0,1,2, then (col_q, col_q + 1) per pair q
-    constexpr int LDS_S = MP + 16;                // row stride of S^-1 in LDS: = 16 mod 32 doubles, so the 4 k-rows of an MFMA operand read hit disjoint banks
-    __shared__ double s_col[2][NBR + 1][REKF_PATCH];
-    __shared__ double s_leaf[4][REKF_LEAF_SCRATCH];
-    __shared__ __attribute__((aligned(16))) double s_coef[8 * MP];          // H row r in 64 bytes, layout of RekfCtl::hrow
-    __shared__ __attribute__((aligned(16))) double s_wc0[3][MP];            // rows 0..2 of W
-    __shared__ __attribute__((aligned(16))) double s_wcp[NPAIR][MP][2];     // state pair p: its two landmark rows of W, interleaved per column
-    __shared__ __attribute__((aligned(16))) double s_wown[MP][MID_ROWS];    // this workgroup's rows of W, [column r][row]; before that, staging of (H P)^T
-    // raw P values, as gathered; s_psub is dead once W is formed and S^-1 (phase E) takes its place
-    constexpr int NKCP = NKC + 1;                 // sub-block row stride in LDS (even: 16-byte pairs start on odd columns 3 + 2q, read as 8-byte-aligned vectors)
-    __shared__ __attribute__((aligned(16))) double s_big[(NKCP * 2 * NRS > MP * LDS_S) ? NKCP * 2 * NRS : MP * LDS_S];
-    __shared__ __attribute__((aligned(16))) double s_pw[NKC][MID_ROWS];     // P(own rows, sub-block columns)
-    __shared__ double s_dmu[4][MID_ROWS];
-    // the scan's match record (RekfCtl::Rec: pairs, ranks, slots, counts, the new reflectors' observation indices = s_cnt[5] of them):
-    // a whole scan's comes ready-made from the front end, a block step of a wide scan builds it here
-    __shared__ RekfCtl::Rec s_rec;
+    using LT = MidLds<NBR>;
+    constexpr int MP = LT::MP, NPAIR = LT::NPAIR, NUSP = LT::NUSP, NBU = LT::NBU, LDS_S = LT::LDS_S;
+    extern __shared__ __attribute__((aligned(16))) double k_mid_arena[];
+    LT &L = *reinterpret_cast<LT *>(k_mid_arena);
+    auto &s_col = L.u.w.s_col; auto &s_leaf = L.u.w.s_leaf; auto &s_coef = L.s_coef; auto &s_wc0 = L.u.w.s_wc0; auto &s_wcp = L.u.w.s_wcp;
+    auto &s_wown = L.u.w.s_wown; auto &s_pw = L.s_pw; auto &s_dmu = L.u.w.s_dmu; auto &s_rec = L.s_rec; auto &s_pcol = L.s_pcol;
+    auto &s_np = L.s_np; auto &s_dc = L.u.w.s_dc; auto &s_pred = L.s_pred; auto &s_cpred = L.s_cpred; auto &s_stage = L.u.s_stage;
+    auto &s_upair = L.s_upair; auto &s_ownsub = L.s_ownsub;
+    double (*s_kown)[MID_ROWS] = (double (*)[MID_ROWS])&L.u.w.s_col[0][0][0];      // phase F / G: -K of the own rows, [k][row] (the inverse's patches are dead by then)
+    static_assert(sizeof(L.u.w.s_col) >= sizeof(double) * MP * MID_ROWS, "s_kown fits the inverse's patches");
     int *const s_pair_obs = s_rec.pair_obs, *const s_pair_id = s_rec.pair_id, *const s_pair_state = s_rec.pair_state,
-        *const s_rank = s_rec.rank, *const s_cnt = s_rec.cnt, *const s_newid = s_rec.newid;
-    __shared__ int s_pcol[NPAIR];
-    __shared__ double s_np[3];                    // the committed pose, for their means
-    __shared__ double s_dc[4][3][MID_ROWS];       // workgroup 0: partial sums of (K H P)(i, jc), jc = 0..2, per wave of phase F
-    // the sub-block's slots in ascending global order -- u = 0: rows / columns {0,1}, u = 1: {2}, u = 2 + rank: a state pair's
-    // landmark -- with the first global row (= column) of each and the first sub-block column kc it stands for
-    int *const s_urow = s_rec.urow, *const s_ukc = s_rec.ukc;
-    static_assert(NRS <= 36 && NPAIR <= 32, "RekfCtl::Rec holds a whole scan");
-    double (*s_psub)[NKCP] = (double (*)[NKCP])s_big;                       // [row 2 rs + {0,1} of the sub-block][its column kc]
-    double (*s_sinv)[LDS_S] = (double (*)[LDS_S])s_big;                     // S^-1, row-major
+        *const s_urank = s_rec.urank, *const s_uid = s_rec.uid, *const s_cnt = s_rec.cnt, *const s_newid = s_rec.newid;
+    static_assert(NPAIR <= 32, "RekfCtl::Rec holds a whole scan");
+    double (*s_pu)[NUSP] = (double (*)[NUSP])L.s_big;                       // [sub-block row s][sub-block row s']: P(R, R)
+    double (*s_sinv)[LDS_S] = (double (*)[LDS_S])L.s_big;                   // S^-1, row-major
 
 #ifdef REKF_DEBUG_TIMING
     long long tqm[16]; int nqm = 0;
-    const bool recm = (int)blockIdx.x == 1 + (DDIN ? A.dd_in_mid : 0) + (FRONT ? A.front_in_mid : 0) && threadIdx.x == 0;      // (the second mid workgroup)
+    const bool recm = (int)blockIdx.x == 1 + (FRONT ? A.front_in_mid : 0) && threadIdx.x == 0;      // (the second mid workgroup)
     const long long t_entrym = clock64(), w_entrym = wall_clock64();
 #define MMARK() do { __builtin_amdgcn_sched_barrier(0); if (recm && nqm < 16) tqm[nqm++] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -918,51 +954,47 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     // gather, W rows of S, S, its inverse -- waves 4..7 everything that only this workgroup's 16 rows / columns need
     // (H rows, own gathers, (H P)^T to HBM), off that chain; both meet at the barriers.
     RekfCtl *ctl = ctl_first;
-    // A host-predicted scan behind a pose read-back (A.front_in_mid workgroups): its front end -- ReflectorMatch only, pose and pose
-    // block came by value -- runs as the FIRST workgroups of this grid instead of a launch of its own (7.5 us + a kernel boundary in
-    // front of k_mid, on the path every read-back caller waits for); everybody else waits for the record below.  One-way: the
-    // front role waits for nobody, its workgroups are dispatched first and the grid's first 256 workgroups are resident together.
-    if constexpr (DDIN) {
-        if ((int)blockIdx.x < A.dd_in_mid) {
-            // the previous scan's downdate: waves 0..3 (the body is cut for 256 threads; a barrier counts the waves that have not ended).
-            // Its tiles go through to memory (DD_STORE); the release covers the plain stores of strips and corner; then the count
+    // ---- roles of the grid: [front end: A.front_in_mid workgroups][mid: A.n_mid][(idle up to A.dd_first)][downdate: the rest]
+    if constexpr (DDROLE) {
+        if (A.dd_in_mid && (int)blockIdx.x >= A.dd_first) {
+            // the previous scan's downdate: waves 0..3 (the body is cut for 256 threads; a barrier counts the waves that have not ended)
             if (threadIdx.x < 256) {
 #ifdef REKF_DEBUG_TIMING
-                if (threadIdx.x == 0 && blockIdx.x == 0) ctl->dbg[26] = wall_clock64();
+                if (threadIdx.x == 0 && (int)blockIdx.x == A.dd_first) ctl->dbg[26] = wall_clock64();
 #endif
-                dd_body<KCDD>(dp);
+                dd_body<64, true>(dp, k_mid_arena, (int)blockIdx.x - A.dd_first, A.dd_in_mid, &ctl->dd_queue[A.dd_par & 1], (int)blockIdx.x == A.dd_first);
+#ifdef REKF_DEBUG_TIMING
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
                 if (threadIdx.x == 0) {
-#ifdef REKF_DEBUG_TIMING
-                    if (blockIdx.x == 0) ctl->dbg[27] = wall_clock64();
-#endif
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    (void)__hip_atomic_fetch_add(&ctl->dd_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef REKF_DEBUG_TIMING
-                    if (blockIdx.x == 0) ctl->dbg[28] = wall_clock64();
-#endif
+                    atomicMax((unsigned long long *)&ctl->dbg[27], (unsigned long long)wall_clock64());      // the last downdate workgroup's exit
+                    if ((int)blockIdx.x == A.dd_first) ctl->dbg[28] = wall_clock64();
                 }
+#endif
             }
             return;
         }
     }
-    const int bxf = (int)blockIdx.x - (DDIN ? A.dd_in_mid : 0);
+    const int bxf = (int)blockIdx.x;
     if (FRONT && bxf < A.front_in_mid) {
-#ifdef REKF_DEBUG_TIMING
-        if (threadIdx.x == 0 && bxf == 0) ctl->dbg[29] = wall_clock64();
-#endif
-        front_role<512>(d, A, bxf, A.front_in_mid, DDIN);      // (DDIN: the pose block from RekfCtl::post_C9 -- the downdate beside us is storing it into P)
-#ifdef REKF_DEBUG_TIMING
-        if (threadIdx.x == 0 && bxf == 0) ctl->dbg[30] = wall_clock64();
-#endif
+        // A scan's front end as the FIRST workgroups of this grid instead of a launch of its own (7.5 us + a kernel boundary in front
+        // of k_mid, on the path every read-back caller waits for); the mid workgroups wait for its count below.  One-way: the front
+        // role waits for nobody, its workgroups are dispatched first and the grid's first 256 workgroups are resident together.
+        front_role<512>(d, A, bxf, A.front_in_mid, A.corr != 0);      // (A.corr: the pose block from RekfCtl::post_C9 -- the stored P is a scan behind)
+        if constexpr (DDROLE) {
+            // ... and then helps the downdate role out of the same queue
+            if (A.dd_in_mid && threadIdx.x < 256) {
+                __builtin_amdgcn_s_barrier();         // (waves 0..3: everybody is through with the front role's LDS)
+                dd_body<64, true>(dp, k_mid_arena, -1, A.dd_in_mid, &ctl->dd_queue[A.dd_par & 1], false);
+            }
+        }
         return;
     }
     const int bx = bxf - (FRONT ? A.front_in_mid : 0);          // this workgroup's number among the mid workgroups
+    if (bx >= A.n_mid) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool steam = wave < 4;                  // S team; the other is the "own" team
     const int tt = tid & 255;                     // thread index within the team
+    if (bx == 0 && tid == 511) ctl->dd_queue[(A.dd_par ^ 1) & 1] = 0u;     // the next launch's tile queue starts empty
     if (FRONT) {
         // every observation's result is in memory once the front end's count has reached the scan's target (each front workgroup
         // writes its result through, drains, then counts): wave 0 polls on one lane, takes the K results past this CU's L1 and
@@ -972,7 +1004,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
                 unsigned spins = 0;
                 while ((int)(__hip_atomic_load(&ctl->front_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - A.front_target) < 0 && ++spins < (1u << 22))
                     __builtin_amdgcn_s_sleep(2);
-                if (spins >= (1u << 22)) atomicOr(&ctl->err, REKF_FLAG_STARVED);       // (never alone on the GPU: see rekf_api.hip, in_grid_ok)
+                if (spins >= (1u << 22)) atomicOr(&ctl->err, REKF_FLAG_STARVED);       // (never on an exclusive handle: rekf_api.hip)
             }
             __builtin_amdgcn_wave_barrier();
             const int kind = (tid < A.K) ? __hip_atomic_load(&ctl->obs_kind[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
@@ -984,27 +1016,19 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
             }
             compact_record(&s_rec, ctl, kind, oidx, tid, A.K, n_rec, d.n_max, A.has_gps);
         }
-        if (DDIN && tid == 64) {
-            // ... and P is the previous scan's once its downdate role is through (count, then one acquire for the workgroup: what the two
-            // roles wrote went through to memory, nothing below needs a coherent load of its own)
-            unsigned spins = 0;
-            while ((int)(__hip_atomic_load(&ctl->dd_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - A.dd_target) < 0 && ++spins < (1u << 22))
-                __builtin_amdgcn_s_sleep(2);
-            if (spins >= (1u << 22)) atomicOr(&ctl->err, REKF_FLAG_STARVED);
-        }
         __syncthreads();
-        MMARK();                                    // (in-grid roles: front end and downdate through)
-        if (DDIN) {
-            if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __syncthreads();
-            MMARK();                                // (... acquired)
-        }
+        MMARK();                                    // (in-grid front end through)
     }
     // the scan's match record first, UNCONDITIONALLY (a block step of a wide scan does not use it): a vector load that waits for no
     // scalar one, so the control block costs one memory round trip, not two
     constexpr int NREC = (int)(sizeof(RekfCtl::Rec) / sizeof(int));
     static_assert(NREC <= 512, "one load per thread");
     const int rec_raw = (!FRONT && tid < NREC) ? ((const int *)&ctl->rec)[tid] : 0;
+    // ... and the pending scan's WRITE-AHEAD CORRECTION (RekfCtl::cp_*, RekfDev::cp; phase G below): which landmarks it covers
+    int cp_uid_l = -1, cp_nu_l = -1;
+    unsigned cp_scan_l = 0u;
+    if (A.corr && lane < 32) cp_uid_l = ctl->cp_uid[A.corr_post & 1][lane];
+    if (A.corr) { cp_nu_l = ctl->cp_nu[A.corr_post & 1]; cp_scan_l = ctl->cp_scan[A.corr_post & 1]; }
 #ifdef REKF_DEBUG_MID_FIRST
     MMARK();                                        // (x0: first loads issued)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1029,9 +1053,9 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
         // (rare: the previous scan met new reflectors.)  Workgroup 0 appends their covariance rows -- what k_augment would have done in
         // a launch of its own between the two scans -- and says so; everybody else waits for that before touching P: one poll loop on
         // one lane, one agent-scope acquire, a barrier (the grid's workgroups are resident together up to 256 x 16 rows, workgroup 0 is
-        // dispatched first; the wait is bounded all the same and turns into the sticky SINGULAR-free error path: garbage, not a hang)
+        // dispatched first; the wait is bounded all the same and turns into the sticky STARVED error path: garbage, not a hang)
         if (bx == 0) {
-            double *scr = s_big;
+            double *scr = L.s_big;
             const float *ao = ctl->augrec[(A.pred_slot ^ 1) & 1].obs;
             augment_rows(d, ar_n, ar_n2, A.obs_cov, (double (*)[6])scr, scr + 6 * REKF_MAX_OBS_DEV, scr + 6 * REKF_MAX_OBS_DEV + 9, 512,
                          [&](int k, float &rx, float &ry) { rx = ao[2 * k]; ry = ao[2 * k + 1]; });
@@ -1053,24 +1077,33 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     const double *__restrict__ P = d.P;
     // (a host-predicted scan carries the predicted pose in the launch packet: no read of the control block for it)
     const bool hp = A.host_pred != 0;
-    const double pose[5] = {hp ? A.pre_pose[0] : ctl->pose_pred[0], hp ? A.pre_pose[1] : ctl->pose_pred[1], hp ? A.pre_pose[2] : ctl->pose_pred[2],
-                            hp ? A.pre_pose[3] : ctl->pose_pred[3], hp ? A.pre_pose[4] : ctl->pose_pred[4]};
+    // (the front role inside this grid has written its Predict THROUGH to memory before it counted: coherent loads past this CU's L1)
+    auto ctl_f64 = [&](const double *p) __attribute__((always_inline)) -> double {
+        if constexpr (FRONT) return __longlong_as_double(__hip_atomic_load((const long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        else return *p;
+    };
+    const double pose[5] = {hp ? A.pre_pose[0] : ctl_f64(&ctl->pose_pred[0]), hp ? A.pre_pose[1] : ctl_f64(&ctl->pose_pred[1]), hp ? A.pre_pose[2] : ctl_f64(&ctl->pose_pred[2]),
+                            hp ? A.pre_pose[3] : ctl_f64(&ctl->pose_pred[3]), hp ? A.pre_pose[4] : ctl_f64(&ctl->pose_pred[4])};
     const bool pending = FRONT ? true : ctl->pose_pending != 0;      // (the in-grid front role sets it beside us: a host-predicted scan always has one)
     const bool first = bx == 0;
     // the scan's pending Predict (RekfCtl::pred): applied to the gathered P in phase D.  (a, b) = 0 and the pose block as gathered
     // when nothing is pending (later block steps of a wide scan: the first step's downdate has committed it)
     // (through LDS, not registers: eleven uniform doubles held from here to phase D cost this 512-thread kernel its residency)
     const bool do_pred = A.apply_pred != 0;
-    __shared__ double s_pred[12];
     if (do_pred && tid >= 64 && tid < 64 + 11) {                                   // ab[0], ab[1], C9[0..8]
         // (with the front role in this grid the control block's copy is being written beside us: a host-predicted scan carries the values)
         const int e = tid - 64;
-        s_pred[e] = (FRONT && hp) ? (e < 2 ? A.pre_ab[e] : A.pre_C9[e - 2]) : ((const double *)&ctl->pred[A.pred_slot & 1])[e];
+        s_pred[e] = (FRONT && hp) ? (e < 2 ? A.pre_ab[e] : A.pre_C9[e - 2]) : ctl_f64(&((const double *)&ctl->pred[A.pred_slot & 1])[e]);
+    }
+    // ... and what is PENDING on the stored P (A.corr): the previous scan's (a, b) and its pose block after the update
+    const bool corr = A.corr != 0, cpred = corr && A.corr_pred >= 0;
+    if (corr && tid >= 128 && tid < 128 + 11) {
+        const int e = tid - 128;
+        s_cpred[e] = (e < 2) ? (cpred ? ctl->pred[A.corr_pred & 1].ab[e] : 0.0) : ctl->post_C9[A.corr_post & 1][e - 2];
     }
 
-    // ---- A: the scan's matched pairs.  Whole scan (pair0 < 0): ordered compaction of the per-observation results (obs order
-    // preserved), wave 0; workgroup 0 also writes the record for the getters.  Block step of a wide scan (pair0 >= 0): the
-    // pairs [pair0, pair0 + stride) of the record k_compact_wide wrote, state pairs first, then map pairs.
+    // ---- A: the scan's matched pairs.  Whole scan (pair0 < 0): the record the front end left.  Block step of a wide scan (pair0 >= 0): the
+    // pairs [pair0, pair0 + stride) of the record k_compact_wide wrote, state pairs first, then map pairs, compacted here.
     if (tid < 64 && A.pair0 >= 0) {
         const int M = ctl->n_state, MMtot = M + ctl->n_map;
         const int left = MMtot - A.pair0;
@@ -1083,26 +1116,28 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
             ob = pp[0]; id = pp[1];
         }
         int rk = 0;
-        {
-            const int key = st ? id : 0x7fffffff;
+        const int key = st ? id : 0x7fffffff;
 #pragma unroll
-            for (int q = 0; q < 2 * NPAIR; ++q) {
-                const int oq = __builtin_amdgcn_readlane(key, q);
-                rk += (oq < key || (oq == key && q < lane)) ? 1 : 0;
-            }
+        for (int q = 0; q < 2 * NPAIR; ++q) {
+            const int oq = __builtin_amdgcn_readlane(key, q);
+            rk += (oq < key || (oq == key && q < lane)) ? 1 : 0;
         }
         int NSl = M - A.pair0;
         NSl = NSl < 0 ? 0 : (NSl < cnt ? NSl : cnt);
+        int sorted, nu_l; bool dup;
+        const int ur = distinct_ranks(key, rk, NSl, lane, sorted, dup, nu_l);
+        const unsigned long long D = __ballot(dup);
+        if (lane < NSl && lane < NPAIR && !dup) s_uid[lane - __popcll(D & ((1ull << lane) - 1ull))] = sorted;
         if (live && lane < NPAIR) {
             s_pair_obs[lane] = ob; s_pair_id[lane] = id; s_pair_state[lane] = st ? 1 : 0;
-            if (st) { s_rank[lane] = rk; s_urow[2 + rk] = 3 + 2 * id; s_ukc[2 + rk] = 3 + 2 * lane; }
+            if (st) s_urank[lane] = ur;
         }
         if (lane == 0) {
             const bool gps = A.has_gps && cnt > 0 && A.pair0 + cnt == MMtot;     // the pose rows ride on the block step that holds the last pairs
             const int m = (cnt > 0) ? 2 * cnt + (gps ? 3 : 0) : 0;
             s_cnt[0] = cnt; s_cnt[1] = m; s_cnt[2] = (m + 15) & ~15; s_cnt[3] = NSl; s_cnt[4] = gps ? 1 : 0;
             s_cnt[5] = (A.pair0 + A.pair_stride >= A.K) ? ctl->n_new : 0;       // the LAST block step appends the new reflectors' means
-            s_urow[0] = 0; s_ukc[0] = 0; s_urow[1] = 2; s_ukc[1] = 2;
+            s_rec.nu = nu_l;
         }
     } else if (A.pair0 < 0) {
         // whole scan: the record the front end left (its last workgroup compacted the results, front_role) -- one load, one LDS store
@@ -1115,6 +1150,13 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     MMARK();                                        // 0: compaction done
     const int MM = s_cnt[0], m = s_cnt[1], m_pad = s_cnt[2], NS = s_cnt[3];
     const bool gps_rows = s_cnt[4] != 0;
+    // the pending scan's write-ahead correction serves this scan when it covers exactly this scan's landmarks
+    bool use_cp = false;
+    {
+        const int nu0 = (NS > 0) ? s_rec.nu : 0;
+        const bool eq = lane >= 32 || lane >= nu0 || cp_uid_l == s_uid[lane];
+        use_cp = A.corr != 0 && A.pair0 < 0 && cp_scan_l == A.corr_scan && cp_nu_l == nu0 && __ballot(eq) == ~0ull;
+    }
     if (first && A.pair0 < 0) {
         // ReflectorMatchResult for the getters (and n_new / m for the kernels behind this one), out of the record
         const int Mm = s_cnt[6], N2r = s_cnt[5];
@@ -1124,6 +1166,11 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
         if (tid == 128) {
             ctl->K = s_cnt[7]; ctl->n_state = NS; ctl->n_map = Mm; ctl->n_new = N2r;
             ctl->m = m; ctl->m_pad = m_pad;
+        }
+        if (A.cp_write) {                               // which landmarks this scan's write-ahead correction covers (phase G)
+            const int nu0 = (NS > 0) ? s_rec.nu : 0;
+            if (tid >= 256 && tid < 256 + 32) ctl->cp_uid[d.post_slot & 1][tid - 256] = (tid - 256 < nu0) ? s_uid[tid - 256] : -1;
+            if (tid == 288) { ctl->cp_nu[d.post_slot & 1] = nu0; ctl->cp_scan[d.post_slot & 1] = A.scan_id; }
         }
         // ... and what this scan's augmentation needs, should it be deferred into the next scan's k_mid (RekfCtl::augrec)
         if (AUGW && A.K <= REKF_MAX_OBS_DEV) {
@@ -1152,6 +1199,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
             d.mu_out[n + 2 * tid + 1] = (double)gy;
         }
     };
+    double *const post_out = ctl->post_C9[d.post_slot & 1];
     // The mean is double-buffered: other workgroups read landmark means from d.mu (phase B) while this one is already
     // done, so the updated rows go to d.mu_out and the host swaps the two pointers behind this launch.
     if (m == 0) {                                   // nothing matched: commit the predicted pose (cc:234 + Predict), no update
@@ -1165,11 +1213,11 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
         if (pending && first && tid == 0) ctl->pose_pending = 0;
         if (first) {
             // nothing to update: the pose block is the predicted one (or, in a later block step of a wide scan, what the previous
-            // step's downdate left in memory)
+            // step's downdate left in memory -- or will leave: the pending scan's block)
             if (tid < 9) {
                 const int pi = tid % 3, pj = tid / 3, hi = pi > pj ? pi : pj, lo = pi > pj ? pj : pi;
-                const double v9 = do_pred ? s_pred[2 + hi + 3 * lo] : rekf_plower(P, (int)ld, hi, lo);
-                ctl->post_C9[tid] = v9;
+                const double v9 = do_pred ? s_pred[2 + hi + 3 * lo] : (corr ? ctl->post_C9[A.corr_post & 1][hi + 3 * lo] : rekf_plower(P, (int)ld, hi, lo));
+                post_out[tid] = v9;
                 if (d.pub) host_slot_store(d.pub + 3 + tid, v9, d.pub_seq, 0);
             }
             append_new_means();                 // (a barrier inside: s_np is complete behind it)
@@ -1179,42 +1227,80 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
                                               __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             }
         }
-        // k_downdate2 runs without looking at the control block when the host knows n: give it zeros to add
-        const int snb = rekf_strip_base(n);
-        for (int e = tid; e < 16 * d.kc_ub; e += 512) {
+        // the downdate runs without looking at the control block when the host knows n: give it zeros to add
+        for (int e = tid; e < 16 * REKF_PANEL_COLS; e += 512) {
             const int cidx = e & 15, r = e >> 4, c = i0 + cidx;
             d.HPt[c + (size_t)r * ld] = 0.0;
             d.Kn[c + (size_t)r * ld] = 0.0;
-            if (snb >= 0 && c >= snb && c < snb + REKF_STRIP_MAX) { d.HPtB[(c - snb) * REKF_MR_PAD + r] = 0.0; d.KnB[(c - snb) * REKF_MR_PAD + r] = 0.0; }
         }
         return;
     }
     // (m_pad <= MP: the host picked NBR from its bound 2K(+3) of m)
 
-    // ---- C (issued before B: it needs only the match lists): the raw P values.  P is stored as its LOWER triangle (ekf_dev.h).
-    // Sub-block P(R, R), R = {0, 1, 2, landmark rows of the state pairs}: only its lower block-triangle is fetched -- blocks
-    // (row slot u, column slot u' <= u) in ascending global order, column slot major, so that neighbouring lanes hit neighbouring
-    // rows of one column (the 32 nearest reflectors are a handful of runs of consecutive ids): 2 x 16 bytes per block, ~4.7 loads per
-    // thread (round 2 fetched the full square: 17) -- and mirrored into the upper block-triangle on the way into LDS.
-    // Own rows x R columns: element (i, c) comes from P(i, c) or P(c, i), whichever lies below the diagonal.
-    const int nrs = NS + 2, nkc = 3 + 2 * NS;
+    // ---- C (issued before B: it needs only the match record): P(R, R) and P(own, R).  R in ascending global order: sub-block row
+    // s < 3 is global row s, s = 3 + 2 u + e is row e of the u-th distinct matched landmark.  P is stored as its LOWER triangle and ONE
+    // SCAN BEHIND: element (hi, lo), hi >= lo, of the covariance this scan sees is
+    //     stored(hi, lo)  [+ a stored(hi, 2) | + b stored(hi, 2)   for lo = 0 | 1, hi >= 3: the pending Predict]
+    //                     + sum_k HPt(lo, k) Kn(hi, k)              the pending downdate, dd_body's own MFMA chain over k
+    // and the pose block is the pending scan's RekfCtl::post_C9 -- the very bits that scan's downdate stores (it runs beside us, from
+    // this buffer into the other).
+    // C0: the stored values, as rounds 3-4 gathered them -- the sub-block's lower block-triangle as 2 x 2 blocks (row slot u, column
+    // slot v <= u; slots: rows {0,1}, row {2}, then the distinct landmarks), column slot major so that neighbouring lanes hit neighbouring
+    // rows of one column, two 16-byte loads per block, mirrored on the way into LDS; own rows x R as row pairs -- and, for the correction,
+    // the rows R of the pending Kn / HPt panels into LDS ([k][s], lane = slot, wave = k: 16-byte loads down a column of the panel).
+    const int nu = (NS > 0) ? s_rec.nu : 0;
+    const int nus = 3 + 2 * nu, nbu = (nus + 15) >> 4, nrs = nu + 2;
+    auto ug_of = [&](int s) __attribute__((always_inline)) -> int {          // global row of sub-block row s (s < nus)
+        return (s < 3) ? s : 3 + 2 * s_uid[(s - 3) >> 1] + ((s - 3) & 1);
+    };
+    auto slot_row = [&](int u) __attribute__((always_inline)) -> int { return (u < 2) ? 2 * u : 3 + 2 * s_uid[u - 2]; };      // first global row of a slot
     const unsigned ldb = (unsigned)d.ld * 8u;                              // bytes per column of P (byte offsets fit 32 bits: ld^2 * 8 < 4 GiB)
-    // column of sub-block column kc, for kc = lane and kc = 64 + lane, once: the loops fetch it with v_readlane
-    int colA = 0, colB = 0;
-    if (lane < nkc) colA = (lane < 3) ? lane : 3 + 2 * s_pair_id[(lane - 3) >> 1] + ((lane - 3) & 1);          // pairs < NS are state pairs
-    if (64 + lane < nkc) colB = 3 + 2 * s_pair_id[(61 + lane) >> 1] + ((61 + lane) & 1);
-    constexpr int NBLK = NRS * (NRS + 1) / 2, PS_IT = (NBLK + 255) / 256;
-    v2du ps[PS_IT][2];
-    int blk_u[PS_IT], blk_v[PS_IT];                                         // row slot u, column slot u' of this thread's blocks (-1: none)
-    const int nblk = nrs * (nrs + 1) / 2;
+    const double *__restrict__ cHPt = dp.HPt;
+    const double *__restrict__ cKn = dp.Kn;
+    const int ckc = corr ? dp.kc_ub : 0, cnk = ckc >> 2;                     // columns / k-steps of the pending panels (their columns [m, 64) are zero)
+    const int g4 = lane >> 4, c16 = lane & 15;
+    constexpr int NRS = NPAIR + 2, NBLK = NRS * (NRS + 1) / 2, PS_IT = (NBLK + 255) / 256;
+    constexpr int NBLK_MAX = NBU * (NBU + 1) / 2, SB_MAX = (NBLK_MAX + 7) / 8;   // 16 x 16 blocks of the lower block-triangle; per wave (all eight take some)
+    constexpr int OI_MAX = (NBU + 2 + 3) / 4;                                 // (block, orientation) items per own-team wave
+    constexpr int PW_IT = (LT::NUS * 8 + 255) / 256;
+    constexpr int ST_IT = 8;                                                  // stage: k = wave + 8 j
+    // own team: its (block, orientation) items.  Orientation 1: own row = `hi` (the Kn side, MFMA column c), sub-block row = `lo`;
+    // 2: own row = `lo` (the HPt side, MFMA row g + 4 r), sub-block row = `hi`; a block takes the orientations its global rows call for
+    int it_bv[OI_MAX], it_or[OI_MAX];
+    double own_op[OI_MAX][16];                                                // the own rows' operand of each item, straight from the panel
+    double so[OI_MAX][16];                                                    // ... and the sub-block rows' operand, out of the staged panels
+    {
+#pragma unroll
+        for (int q = 0; q < OI_MAX; ++q) { it_bv[q] = -1; it_or[q] = 0; }
+    }
+    // the panels' rows R -> LDS (all eight waves): lane = slot, k = wave + 8 j
+    v2du stv[2][ST_IT];
+    const bool slow_corr = corr && !use_cp;          // the correction is computed here (C1) instead of taken from the write-ahead panel
+    if (first && tid == 0 && corr) { ctl->dbg[22] += 1; if (slow_corr) ctl->dbg[23] += 1; }      // (scans that met a pending downdate / computed its correction themselves)
+    const bool st_live = slow_corr && lane < nrs;
+    const int st_row = st_live ? slot_row(lane) : 0;
+    if (slow_corr) {
+#pragma unroll
+        for (int j = 0; j < ST_IT; ++j) {
+            const int k = wave + 8 * j;
+            stv[0][j] = (v2du){0, 0}; stv[1][j] = (v2du){0, 0};
+            if (st_live && k < ckc) {
+                stv[0][j] = *(const v2du *)(cHPt + (size_t)st_row + (size_t)k * ld);
+                stv[1][j] = *(const v2du *)(cKn + (size_t)st_row + (size_t)k * ld);
+            }
+        }
+    }
+    v2du ps[PS_IT][2], cpv[PS_IT][2], raw2v[PS_IT];
+    const double *__restrict__ cpP = d.cp + (size_t)(A.corr_post & 1) * REKF_CP_LD * REKF_CP_LD;
+    int blk_u[PS_IT], blk_v[PS_IT];                                           // row slot u, column slot v of this thread's blocks (-1: none)
+    v2d pw[PW_IT];
     if (steam) {
+        const int nblk = nrs * (nrs + 1) / 2;
 #pragma unroll
         for (int it = 0; it < PS_IT; ++it) {
             const int t = tt + 256 * it;
             const int tc = (t < nblk) ? t : nblk - 1;                       // clamped: a thread past the end refetches the last block
-            // column slot v of block tc in the column-major enumeration of the lower block-triangle: v columns hold
-            // v nrs - v (v - 1) / 2 blocks
-            // (the hardware's approximate square root + 24-bit multiplies here: measured 0.65 us SLOWER per update, A/B in one session)
+            // column slot v of block tc in the column-major enumeration of the lower block-triangle: v columns hold v nrs - v (v - 1) / 2 blocks
             const float bq = 2.0f * (float)nrs + 1.0f;
             int v = (int)((bq - sqrtf(fmaxf(bq * bq - 8.0f * (float)tc, 0.0f))) * 0.5f);
             v = max(0, min(nrs - 1, v));
@@ -1223,21 +1309,32 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
             while (v + 1 < nrs && c0(v + 1) <= tc) ++v;
             const int u = v + (tc - c0(v));
             blk_u[it] = (t < nblk) ? u : -1; blk_v[it] = v;
-            const char *rp = (const char *)(P + s_urow[u]) + (unsigned)s_urow[v] * ldb;
+            const char *rp = (const char *)(P + slot_row(u)) + (unsigned)slot_row(v) * ldb;
             ps[it][0] = *(const v2du *)rp;                                  // rows (r, r+1) of column c
             ps[it][1] = *(const v2du *)(rp + ldb);                          // ... of column c + 1
+            cpv[it][0] = (v2du){0, 0}; cpv[it][1] = (v2du){0, 0}; raw2v[it] = (v2du){0, 0};
+            if (use_cp) {
+                // the write-ahead correction of the block (rows su, su + 1 of the panel, columns sv, sv + 1) and, for the columns 0, 1 the
+                // pending Predict touches, column 2 of the block's rows
+                const int su = (u < 2) ? 2 * u : 2 * u - 1, sv = (v < 2) ? 2 * v : 2 * v - 1;
+                const double *cq = cpP + (size_t)su * REKF_CP_LD + sv;
+                cpv[it][0] = *(const v2du *)cq;
+                cpv[it][1] = *(const v2du *)(cq + REKF_CP_LD);
+                if (cpred && v == 0 && u >= 2) raw2v[it] = *(const v2du *)((const char *)(P + slot_row(u)) + 2u * ldb);
+            }
         }
-    }
-    constexpr int PW_IT = (NKC * 8 + 255) / 256;
-    v2d pw[PW_IT];
-    if (!steam) {
-        const int pr = tid & 7, sub = (tid >> 3) & 7;                       // 8 columns x 8 row pairs per wave instruction
+    } else {
+        // sub-block row s -> its global row, for s = lane and s = 64 + lane, once: the loop fetches it with a shuffle
+        int colA = 0, colB = 0;
+        if (lane < nus) colA = ug_of(lane);
+        if (64 + lane < nus) colB = ug_of(64 + lane);
+        const int pr = tid & 7, sub = (tid >> 3) & 7;                       // 8 sub-block rows x 8 own row pairs per wave instruction
         const int kc0 = __builtin_amdgcn_readfirstlane(wave & 3);
         const int i = i0 + 2 * pr;
 #pragma unroll
         for (int it = 0; it < PW_IT; ++it) {
             int kc = 8 * (kc0 + 4 * it) + sub;
-            kc = (kc < nkc) ? kc : nkc - 1;
+            kc = (kc < nus) ? kc : nus - 1;
             const int cA = __shfl(colA, kc & 63, 64), cB = __shfl(colB, kc & 63, 64);
             const int cc = (kc < 64) ? cA : cB;
             // (i, cc) and (i + 1, cc), each from below the diagonal
@@ -1245,10 +1342,29 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
             const double *e1 = (i + 1 >= cc) ? P + (size_t)(i + 1) + (size_t)cc * ld : P + (size_t)cc + (size_t)(i + 1) * ld;
             pw[it].x = *e0; pw[it].y = *e1;
         }
+        if (corr) {
+            const int ow = wave & 3;
+            int cnt_it = 0;
+            for (int bv = 0; bv < nbu; ++bv) {
+                const int s_lo = 16 * bv, s_hi = (16 * bv + 15 < nus) ? 16 * bv + 15 : nus - 1;
+                const int umin = ug_of(s_lo), umax = ug_of(s_hi);
+#pragma unroll
+                for (int o = 1; o <= 2; ++o) {
+                    const bool want = (o == 1) ? (umin <= i0 + MID_ROWS - 1) : (umax > i0);
+                    if (want) {
+                        if ((cnt_it & 3) == ow) {
+#pragma unroll
+                            for (int q = 0; q < OI_MAX; ++q) if (q == (cnt_it >> 2)) { it_bv[q] = bv; it_or[q] = o; }
+                        }
+                        ++cnt_it;
+                    }
+                }
+            }
+        }
     }
     MMARK();                                        // 1: gathers issued
 
-    // ---- B: H rows (cc:248-304, gps.cc:305-332), thread = row (own team: its landmark-mean loads overlap the S team's gather)
+    // ---- B: H rows (cc:248-304, gps.cc:305-332), thread = row (own team)
     if (!steam && tt < MP) {
         const int r = tt, p = r >> 1, rr = r & 1;
         double hr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1274,38 +1390,57 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
 #pragma clang fp contract(off)
             double dth = d.mu[2] - pose[2];
             dth = atan2(sin(dth), cos(dth));
-            double corr = hr[0] * (d.mu[0] - pose[0]);
-            corr += hr[1] * (d.mu[1] - pose[1]);
-            corr += hr[2] * dth;
+            double corr_dz = hr[0] * (d.mu[0] - pose[0]);
+            corr_dz += hr[1] * (d.mu[1] - pose[1]);
+            corr_dz += hr[2] * dth;
             if (col >= 0) {
-                corr += hr[3] * (d.mu[col] - d.mu_lin[col]);
-                corr += hr[4] * (d.mu[col + 1] - d.mu_lin[col + 1]);
+                corr_dz += hr[3] * (d.mu[col] - d.mu_lin[col]);
+                corr_dz += hr[4] * (d.mu[col + 1] - d.mu_lin[col + 1]);
             }
-            hr[6] = hr[6] - corr;
+            hr[6] = hr[6] - corr_dz;
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) s_coef[8 * r + q] = hr[q];
-        if (rr == 0) s_pcol[p] = col;
+        if (rr == 0) {
+            s_pcol[p] = (col >= 0) ? 3 + 2 * s_urank[p] : -1;               // (the pair's landmark as sub-block rows)
+            if (col >= 0) s_upair[s_urank[p]] = p;                           // (two observations on one landmark: either)
+        }
     }
-    // raw values -> LDS.  s_psub is [row 2 rs + {0,1}][sub-block column kc] (rs = the pair's rank among the state pairs; NS for
-    // rows {0,1}, NS + 1 for row {2}): phase D reads a row pair's (col_q, col_q + 1) as ONE 16-byte value, consecutive q =
-    // consecutive addresses (no bank conflicts).  A block goes in twice: as fetched and transposed (the upper block-triangle).
+    // stored values -> LDS.  s_pu is [sub-block row][sub-block row], both triangles: a block goes in twice, as fetched and transposed.
+    // Slot 1 stands for row / column 2 ALONE: its second row (3) is fetched but not used.
+    auto slot_s = [](int u) __attribute__((always_inline)) -> int { return (u < 2) ? 2 * u : 2 * u - 1; };     // first sub-block row of a slot
     if (steam) {
 #pragma unroll
         for (int it = 0; it < PS_IT; ++it) {
             const int u = blk_u[it], v = blk_v[it];
             if (u >= 0) {
-                const int ru = (u >= 2) ? u - 2 : NS + u, rv = (v >= 2) ? v - 2 : NS + v;       // their row slots in s_psub
-                const int ku = s_ukc[u], kv = s_ukc[v];
+                const int su = slot_s(u), sv = slot_s(v);
+                const bool ua = u != 1, ve = v != 1;
                 double b00 = ps[it][0].x, b10 = ps[it][0].y, b01 = ps[it][1].x, b11 = ps[it][1].y;   // b[a][e] = P(r + a, c + e)
-                if (s_urow[u] == s_urow[v]) b01 = b10;                      // a diagonal block (also: two pairs on ONE landmark, Q6): (r, r+1) lies above the diagonal
-                // slot 1 stands for row / column 2 ALONE: its second row (3) is fetched but never used, its second column does not exist
-                s_psub[2 * ru][kv] = b00; s_psub[2 * ru + 1][kv] = b10;
-                if (v != 1) { s_psub[2 * ru][kv + 1] = b01; s_psub[2 * ru + 1][kv + 1] = b11; }
+                if (use_cp) {
+                    // stored (+ pending Predict) + write-ahead correction; the pose block by value (the pending scan's post_C9)
+#pragma clang fp contract(off)
+                    auto fix = [&](double raw, double r2, double cc, int row_s, int col_s) __attribute__((always_inline)) -> double {
+                        if (row_s < 3) return s_cpred[2 + (row_s > col_s ? row_s : col_s) + 3 * (row_s > col_s ? col_s : row_s)];
+                        double val = raw;
+                        if (cpred && col_s < 2) val = val + s_cpred[col_s] * r2;
+                        return val + cc;
+                    };
+                    b00 = fix(b00, raw2v[it].x, cpv[it][0].x, su, sv);
+                    b10 = fix(b10, raw2v[it].y, cpv[it][1].x, su + 1, sv);
+                    b01 = fix(b01, raw2v[it].x, cpv[it][0].y, su, sv + 1);
+                    b11 = fix(b11, raw2v[it].y, cpv[it][1].y, su + 1, sv + 1);
+                }
+                if (u == v) b01 = b10;                                      // a diagonal block: (r, r+1) lies above the diagonal
+                s_pu[su][sv] = b00;
+                if (ua) s_pu[su + 1][sv] = b10;
+                if (ve) s_pu[su][sv + 1] = b01;
+                if (ua && ve) s_pu[su + 1][sv + 1] = b11;
                 if (u != v) {
-                    s_psub[2 * rv][ku] = b00;
-                    if (v != 1) s_psub[2 * rv + 1][ku] = b01;
-                    if (u != 1) { s_psub[2 * rv][ku + 1] = b10; if (v != 1) s_psub[2 * rv + 1][ku + 1] = b11; }
+                    s_pu[sv][su] = b00;
+                    if (ua) s_pu[sv][su + 1] = b10;
+                    if (ve) s_pu[sv + 1][su] = b01;
+                    if (ua && ve) s_pu[sv + 1][su + 1] = b11;
                 }
             }
         }
@@ -1315,11 +1450,107 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
 #pragma unroll
         for (int it = 0; it < PW_IT; ++it) {
             const int kc = 8 * (kc0 + 4 * it) + sub;
-            if (kc < nkc) *(v2d *)&s_pw[kc][2 * pr] = pw[it];
+            if (kc < nus) *(v2d *)&s_pw[kc][2 * pr] = pw[it];
+        }
+    }
+    if (slow_corr) {
+        if (st_live) {
+            const int s0 = slot_s(lane);
+#pragma unroll
+            for (int j = 0; j < ST_IT; ++j) {
+                const int k = wave + 8 * j;
+                if (k < ckc) {
+                    s_stage[0][k][s0] = stv[0][j].x; s_stage[1][k][s0] = stv[1][j].x;
+                    if (lane != 1) { s_stage[0][k][s0 + 1] = stv[0][j].y; s_stage[1][k][s0 + 1] = stv[1][j].y; }
+                }
+            }
+        }
+        __syncthreads();
+        MMARK();                                    // (stored values and the pending panels' rows in LDS)
+        // C1: the pending correction of the SUB-BLOCK, 16 x 16 blocks, on all eight waves: MFMA rows <-> sub-block rows 16 bv + g + 4 r
+        // (the `lo` side: the HPt operand), columns <-> 16 bu + c (the `hi` side: Kn); ONE chain over k from zero, in k order -- dd_body's
+        // accumulation -- two blocks' chains interleaved.  Every element has one owner: it reads the stored value, adds, writes both
+        // triangles.  (This workgroup's own rows take theirs later, off the critical chain: under the inverse, phase E.)
+        {
+            const int nblk16 = nbu * (nbu + 1) / 2, chunk = (nblk16 + 7) >> 3;
+            int sb_hi[SB_MAX], sb_lo0[SB_MAX];           // per block: this lane's `hi` sub-block row (-1: none), the block's first `lo` row (-1: no block)
+            int sb_bu[SB_MAX];
+            v4d acc[SB_MAX];
+#pragma unroll
+            for (int b = 0; b < SB_MAX; ++b) {
+                const int t = wave * chunk + b;
+                const bool live = b < chunk && t < nblk16;
+                int bu = nbu - 1, rem = live ? t : 0;    // block t of the enumeration (bu descending, bv ascending)
+                while (rem > bu) { rem -= bu + 1; --bu; }
+                const int sB = 16 * bu + c16;
+                sb_bu[b] = bu;
+                sb_hi[b] = (live && sB < nus) ? sB : -1;
+                sb_lo0[b] = live ? 16 * rem : -1;
+                acc[b] = (v4d){0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int b0 = 0; b0 < SB_MAX; b0 += 2) {
+                // both blocks' operands of all 16 k-steps first (the LDS reads issue together), then the two chains, interleaved.  No branch
+                // in here: a wave without a block in this position multiplies whatever block 0's addresses hold and never looks at the sums;
+                // k-steps past the pending panels' columns take zero operands (as the downdate reads the panels' zero columns)
+                double oa[2][16], ob[2][16];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int b = (b0 + h < SB_MAX) ? b0 + h : b0;
+                    const int sa = (sb_lo0[b] >= 0 ? sb_lo0[b] : 0) + c16, sbb = 16 * sb_bu[b] + c16;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const double ra = s_stage[0][4 * q + g4][sa], rb = s_stage[1][4 * q + g4][sbb];
+                        oa[h][q] = (q < cnk) ? ra : 0.0; ob[h][q] = (q < cnk) ? rb : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int b = b0 + h;
+                        if (b < SB_MAX) {
+#ifndef REKF_ABL_SC1
+                            acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(oa[h][q], ob[h][q], acc[b], 0, 0, 0);
+#else
+                            acc[b][0] += oa[h][q] * ob[h][q];
+#endif
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < SB_MAX; ++b) {
+                if (sb_hi[b] >= 0) {
+#pragma clang fp contract(off)
+                    const int sB = sb_hi[b];
+                    double vv[4];
+                    const double raw2 = s_pu[sB][2];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int sj = sb_lo0[b] + g4 + 4 * r;
+                        vv[r] = (sj <= sB) ? s_pu[sB][sj] : 0.0;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int sj = sb_lo0[b] + g4 + 4 * r;
+                        if (sj <= sB) {
+                            double v = vv[r];
+                            if (sB < 3) v = s_cpred[2 + sB + 3 * sj];                 // the pose block: the pending scan's post_C9 (hi + 3 lo)
+                            else {
+                                if (cpred && sj < 2) v = v + s_cpred[sj] * raw2;      // the pending Predict: columns 0, 1 against column 2
+                                v = v + acc[b][r];
+                            }
+                            s_pu[sB][sj] = v;
+                            s_pu[sj][sB] = v;
+                        }
+                    }
+                }
+            }
         }
     }
     __syncthreads();
-    MMARK();                                        // 2: H rows and raw P in LDS
+    MMARK();                                        // 2: H rows and P values in LDS
 
     // (phase E multiplies the landmark rows of W of a CLAMPED pair by the zero coefficients of rows that have no landmark block:
     // with no state pair at all -- a scan that matched the pre-loaded map only -- that pair does not exist, and whatever the
@@ -1328,33 +1559,34 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     // ---- D: form W (rows of S, own rows) and (H P)^T (own columns) out of LDS.
     // Same operation order as k_gather: v = p0 h0; v += p1 h1; v += p2 h2; v += pl0 g0; v += pl1 g1
     const int nq = m_pad / 2;                        // row pairs, pad rows included (their H rows are zero)
-    const int strip_nb = rekf_strip_base(n);          // k_downdate's border strips want rows nb.. of HPt / Kn contiguous
     if (steam) {
         // items (slot, q): slot < NS = state pair (its two landmark rows), slot NS = rows 0,1, slot NS+1 = row 2 (its second
         // value is row 3: computed, never stored).  q = tid mod NPAIR, slot = tid / NPAIR + (256 / NPAIR) pass
         const int q = tt & (NPAIR - 1);
         const bool qlive = q < nq;
-        const bool has_col = qlive && s_pcol[q] >= 0; // a state pair: q < NS, its columns are kc = 3 + 2q, 4 + 2q
-        const int kq = has_col ? 3 + 2 * q : 0;       // clamped: without a landmark block the two extra terms are multiplied by zeros
+        const int pc = qlive ? s_pcol[q] : -1;
+        const bool has_col = pc >= 0;                 // a state pair: its landmark's columns are sub-block rows pc, pc + 1
+        const int kq = has_col ? pc : 0;              // clamped: without a landmark block the two extra terms are multiplied by zeros
         double h0[5], h1[5];
 #pragma unroll
         for (int k = 0; k < 5; ++k) { h0[k] = s_coef[16 * q + k]; h1[k] = s_coef[16 * q + 8 + k]; }
         if (!has_col) { h0[3] = 0; h0[4] = 0; h1[3] = 0; h1[4] = 0; }
-        constexpr int SL_STEP = 256 / NPAIR, SL_PASS = (NRS + SL_STEP - 1) / SL_STEP;
+        constexpr int NRS = NPAIR + 2, SL_STEP = 256 / NPAIR, SL_PASS = (NRS + SL_STEP - 1) / SL_STEP;
+        const int nrs = NS + 2;
         int rs2[SL_PASS];
 #pragma unroll
         for (int pass = 0; pass < SL_PASS; ++pass) {
             const int slot = tt / NPAIR + SL_STEP * pass, sl = (slot < nrs) ? slot : nrs - 1;
-            rs2[pass] = 2 * ((sl < NS) ? s_rank[sl] : sl);
+            rs2[pass] = (sl < NS) ? 3 + 2 * s_urank[sl] : ((sl == NS) ? 0 : 2);          // first sub-block row of the slot
         }
 #pragma unroll
         for (int pass = 0; pass < SL_PASS; ++pass) {
             const int slot = tt / NPAIR + SL_STEP * pass;
-            v2d a01 = *(const v2d *)&s_psub[rs2[pass]][0], b01 = *(const v2d *)&s_psub[rs2[pass] + 1][0];
-            double a2 = s_psub[rs2[pass]][2], b2 = s_psub[rs2[pass] + 1][2];
-            v2d al = *(const v2du *)&s_psub[rs2[pass]][kq], bl = *(const v2du *)&s_psub[rs2[pass] + 1][kq];
+            v2d a01 = *(const v2d *)&s_pu[rs2[pass]][0], b01 = *(const v2d *)&s_pu[rs2[pass] + 1][0];
+            double a2 = s_pu[rs2[pass]][2], b2 = s_pu[rs2[pass] + 1][2];
+            v2d al = *(const v2du *)&s_pu[rs2[pass]][kq], bl = *(const v2du *)&s_pu[rs2[pass] + 1][kq];
             if (do_pred) {
-                // the pending Predict, G P G^T + V restricted to the sub-block (G = I + a e0 e2^T + b e1 e2^T): a landmark row takes
+                // the scan's Predict, G P G^T + V restricted to the sub-block (G = I + a e0 e2^T + b e1 e2^T): a landmark row takes
                 // P(r, 0) + a P(r, 2) and P(r, 1) + b P(r, 2) (the same single operations the old covariance pass did in memory);
                 // rows 0, 1 take the predicted pose block and, against a landmark column c, P(0, c) + a P(2, c) / P(1, c) + b P(2, c);
                 // row 2 takes the predicted pose block and keeps its landmark columns
@@ -1365,7 +1597,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
                     a01.x = a01.x + pa * a2; a01.y = a01.y + pb * a2;
                     b01.x = b01.x + pa * b2; b01.y = b01.y + pb * b2;
                 } else if (slot == NS) {
-                    const v2d r2 = *(const v2du *)&s_psub[2 * (NS + 1)][kq];           // P(2, c), P(2, c + 1)
+                    const v2d r2 = *(const v2du *)&s_pu[2][kq];                         // P(2, c), P(2, c + 1)
                     a01.x = pC9[0]; a01.y = pC9[3]; a2 = pC9[6];                        // row 0 of the predicted block: (0,0) (0,1) (0,2)
                     b01.x = pC9[1]; b01.y = pC9[4]; b2 = pC9[7];                        // row 1
                     al.x = al.x + pa * r2.x; al.y = al.y + pa * r2.y;
@@ -1387,19 +1619,97 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
                 else *(v2d *)&s_wc0[2][2 * q] = (v2d){v0x, v1x};
             }
         }
-    } else {
+    }
+    // ---- the own team's share, OFF the critical chain: it runs under the inverse (phase E: gj_invert_blocks calls the idle waves back between
+    // its barriers).  First the pending correction of P(own rows, R) -- the MFMA chains, then every element's owner reads the stored value,
+    // adds, writes -- then W for the own rows and (H P)^T to HBM.
+    if (!steam && corr) {                              // (the operands of this workgroup's own rows' correction: in flight across phase D)
+#pragma unroll
+        for (int q = 0; q < OI_MAX; ++q) {
+            // the own rows' side: 16 consecutive rows of one panel; the sub-block rows' side: rows R of the other
+            const int sc = 16 * (it_bv[q] >= 0 ? it_bv[q] : 0) + c16;
+            const int gsr = (it_bv[q] >= 0 && sc < nus) ? ug_of(sc) : 0;
+            const double *po = ((it_or[q] == 2) ? cHPt : cKn) + (size_t)(i0 + c16) + (size_t)g4 * ld;
+            const double *pr2 = ((it_or[q] == 2) ? cKn : cHPt) + (size_t)gsr + (size_t)g4 * ld;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                own_op[q][k] = 0.0; so[q][k] = 0.0;
+                if (k < cnk && it_bv[q] >= 0) { own_op[q][k] = po[(size_t)(4 * k) * ld]; so[q][k] = pr2[(size_t)(4 * k) * ld]; }
+            }
+        }
+    }
+    auto own_correct = [&]() __attribute__((always_inline)) {
+        if (!corr) return;
+        v4d acc[OI_MAX];
+#pragma unroll
+        for (int q = 0; q < OI_MAX; ++q) acc[q] = (v4d){0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+#pragma unroll
+            for (int q = 0; q < OI_MAX; ++q) {
+                // (orientation by select of the operands, not by branch; an empty position's sums are never looked at)
+                const double oa1 = (it_or[q] == 2) ? own_op[q][k] : so[q][k], ob1 = (it_or[q] == 2) ? so[q][k] : own_op[q][k];
+#ifndef REKF_ABL_OWNC1
+                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(oa1, ob1, acc[q], 0, 0, 0);
+#else
+                acc[q][0] += oa1 * ob1;
+#endif
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < OI_MAX; ++q) {
+            if (it_bv[q] >= 0) {
+#pragma clang fp contract(off)
+                int hi_g[4], lo_g[4], s_dst[4], row_dst[4];
+                bool ok[4];
+                double vv[4], r2[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (it_or[q] == 1) {
+                        const int sj = 16 * it_bv[q] + g4 + 4 * r;
+                        const int gj = (sj < nus) ? ug_of(sj) : 0x7fffffff;
+                        hi_g[r] = i0 + c16; lo_g[r] = gj; s_dst[r] = sj; row_dst[r] = c16; ok[r] = sj < nus && gj <= hi_g[r];
+                    } else {
+                        const int sx = 16 * it_bv[q] + c16, io = i0 + g4 + 4 * r;
+                        const int gs = (sx < nus) ? ug_of(sx) : -1;
+                        hi_g[r] = gs; lo_g[r] = io; s_dst[r] = sx; row_dst[r] = g4 + 4 * r; ok[r] = gs > io;
+                    }
+                    vv[r] = 0.0; r2[r] = 0.0;
+                    if (ok[r]) {
+                        vv[r] = s_pw[s_dst[r]][row_dst[r]];
+                        // (hi, 2) of this workgroup's gather: orientation 1: own row hi against sub-block row 2; 2 (workgroup 0, own rows 0, 1): sub-block row against own row 2
+                        r2[r] = (it_or[q] == 1) ? s_pw[2][row_dst[r]] : s_pw[s_dst[r]][2];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (ok[r]) {
+                        double v = vv[r];
+                        if (hi_g[r] < 3) v = s_cpred[2 + hi_g[r] + 3 * lo_g[r]];
+                        else {
+                            if (cpred && lo_g[r] < 2) v = v + s_cpred[lo_g[r]] * r2[r];
+                            v = v + acc[q][r];
+                        }
+                        s_pw[s_dst[r]][row_dst[r]] = v;
+                    }
+                }
+            }
+        }
+    };
+    auto own_w = [&]() __attribute__((always_inline)) {
         // own rows: item (row pair pr, q), q = tt / 8 (+ 32 per pass)
         const int pr = tt & 7;
 #pragma unroll
         for (int pass = 0; pass < (NPAIR + 31) / 32; ++pass) {
             const int q2 = (tt >> 3) + 32 * pass;
             if (q2 < nq) {
-                const bool hc = s_pcol[q2] >= 0;
+                const int pc2 = s_pcol[q2];
+                const bool hc = pc2 >= 0;
                 const int c = i0 + 2 * pr;
                 v2d p0 = *(const v2d *)&s_pw[0][2 * pr], p1 = *(const v2d *)&s_pw[1][2 * pr], p2 = *(const v2d *)&s_pw[2][2 * pr];
                 v2d l0 = {0, 0}, l1 = {0, 0};
-                if (hc) { l0 = *(const v2d *)&s_pw[3 + 2 * q2][2 * pr]; l1 = *(const v2d *)&s_pw[4 + 2 * q2][2 * pr]; }
-                if (do_pred) {                        // the pending Predict on this workgroup's rows (see the S team above)
+                if (hc) { l0 = *(const v2d *)&s_pw[pc2][2 * pr]; l1 = *(const v2d *)&s_pw[pc2 + 1][2 * pr]; }
+                if (do_pred) {                        // the scan's Predict on this workgroup's rows (see the S team above)
 #pragma clang fp contract(off)
                     const double pa = s_pred[0], pb = s_pred[1];
                     const double *pC9 = s_pred + 2;
@@ -1409,7 +1719,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
                     } else if (c == 0) {              // rows 0, 1 (workgroup 0): the predicted block; landmark columns against row 2's
                         p0.x = pC9[0]; p0.y = pC9[1]; p1.x = pC9[3]; p1.y = pC9[4]; p2.x = pC9[6]; p2.y = pC9[7];
                         if (hc) {
-                            const double r20 = s_pw[3 + 2 * q2][2], r21 = s_pw[4 + 2 * q2][2];
+                            const double r20 = s_pw[pc2][2], r21 = s_pw[pc2 + 1][2];
                             l0.x = l0.x + pa * r20; l0.y = l0.y + pb * r20;
                             l1.x = l1.x + pa * r21; l1.y = l1.y + pb * r21;
                         }
@@ -1434,24 +1744,26 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
                     *(v2d *)&s_wown[r][2 * pr] = (v2d){vx, vy};
                     // (H P)^T(c, r) = W(c, r) (symmetric P): 8 lanes store 128 contiguous bytes of column r
                     store_wt2(&d.HPt[(size_t)c + (size_t)r * ld], (rekf_v2d){vx, vy});
-                    if (strip_nb >= 0) {
-                        if (c >= strip_nb && c < strip_nb + REKF_STRIP_MAX) d.HPtB[(c - strip_nb) * REKF_MR_PAD + r] = vx;
-                        if (c + 1 >= strip_nb && c + 1 < strip_nb + REKF_STRIP_MAX) d.HPtB[(c + 1 - strip_nb) * REKF_MR_PAD + r] = vy;
-                    }
                 }
             }
         }
-        // columns [m_pad, kc_ub) of HPt / Kn are kept zero for k_downdate2<kc_ub>
-        for (int e = tt; e < 16 * (d.kc_ub - m_pad); e += 256) {
+        // columns [m_pad, 64) of HPt / Kn are kept zero for the downdate (whichever KC it runs with)
+        for (int e = tt; e < 16 * (REKF_PANEL_COLS - m_pad); e += 256) {
             const int cidx2 = e & 15, r = m_pad + (e >> 4), c2 = i0 + cidx2;
             d.HPt[c2 + (size_t)r * ld] = 0.0;
             d.Kn[c2 + (size_t)r * ld] = 0.0;
-            if (strip_nb >= 0 && c2 >= strip_nb && c2 < strip_nb + REKF_STRIP_MAX) {
-                d.HPtB[(c2 - strip_nb) * REKF_MR_PAD + r] = 0.0;
-                d.KnB[(c2 - strip_nb) * REKF_MR_PAD + r] = 0.0;
+        }
+        // which of this workgroup's rows are sub-block rows (phase G); one wave: its LDS operations execute in order
+        if (wave == 4) {
+            if (lane < MID_ROWS) s_ownsub[lane] = -1;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int sx = lane + 64 * h;
+                if (sx < nus) { const int gr = ug_of(sx) - i0; if (gr >= 0 && gr < MID_ROWS) s_ownsub[gr] = sx; }
             }
         }
-    }
+    };
     __syncthreads();
     MMARK();                                        // 3: W rows in LDS, (H P)^T stored
 
@@ -1495,7 +1807,10 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
             }
         }
         MMARK();                                    // 4: S built
-        const bool bad = gj_invert_blocks<NBR>(S, nbr, w, g, c, s_col, s_leaf[w & 3]);
+        const bool bad = gj_invert_blocks<NBR>(S, nbr, w, g, c, s_col, s_leaf[w & 3], [&](int slot) __attribute__((always_inline)) {
+            if (slot == 0) own_correct();             // (every element of s_pw has one owner; the barrier behind slot 0 orders it in front of own_w)
+            else if (slot == 1) own_w();
+        });
         MMARK();                                    // 5: inverted
         if (w < nbr) {
             if (bad && lane == 0 && first) atomicOr(&ctl->err, REKF_FLAG_SINGULAR);
@@ -1538,8 +1853,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
                 for (int r = 0; r < 4; ++r) {
                     const int j = j0 + kq + 4 * r;                               // D row = column of K
                     store_wt(&d.Kn[(i0 + idx) + (size_t)j * ld], -acc[r]);
-                    if (strip_nb >= 0 && i0 + idx >= strip_nb && i0 + idx < strip_nb + REKF_STRIP_MAX)
-                        d.KnB[(i0 + idx - strip_nb) * REKF_MR_PAD + j] = -acc[r];
+                    s_kown[j][idx] = -acc[r];                                    // (phase G)
                     part += acc[r] * s_coef[8 * j + 6];                          // K(i, j) (z - zhat)(j)
                     if (first) {                                                 // (K H P)(i, jc) = sum_j K(i, j) W(jc, j), jc = 0..2
                         pc0 += acc[r] * s_wown[j][0]; pc1 += acc[r] * s_wown[j][1]; pc2 += acc[r] * s_wown[j][2];
@@ -1585,7 +1899,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
             for (int jt = 0; jt < NBR; ++jt) khp += s_dc[jt][lo][hi];
             const double base = do_pred ? s_pred[2 + hi + 3 * lo] : s_pw[lo][hi];
             const double v9 = base - khp;
-            ctl->post_C9[e] = v9;
+            post_out[e] = v9;
             if (d.pub) host_slot_store(d.pub + 3 + e, v9, d.pub_seq, 0);
         }
         append_new_means();                     // (a barrier inside: s_np is complete behind it)
@@ -1596,6 +1910,41 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
             if (tid < 3) host_slot_store(d.pub + tid, s_np[tid], d.pub_seq, 0);
             if (tid == 3) host_slot_store(d.pub + 12, (double)(n + 2 * s_cnt[5]), d.pub_seq,
                                           __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+    }
+    // ---- G: this scan's WRITE-AHEAD CORRECTION.  The next scan meets the stored P one scan behind and needs, of this scan's rank-m downdate,
+    // what falls on ITS sub-block -- almost always this scan's (RekfCtl::cp_*).  Element (hi, lo) of it, sum_k HPt(lo, k) Kn(hi, k), is
+    // computed here by the workgroup that owns row hi: Kn(hi, :) is its own (phase F), HPt(lo, :) = W(lo, :) sits in LDS for every lo in R
+    // (phase D built it for S) -- the downdate's own MFMA chain over k, so the sum is the one the downdate will add.  One 16 x 16 block
+    // product per wave and block of sub-block rows at or below this workgroup's.
+    if (A.cp_write) {
+        const int s_hi = s_ownsub[c16];
+        // (blocks whose first row lies above every sub-block row this workgroup owns have nothing for it)
+        int smax = s_hi;
+        smax = max(smax, __shfl_xor(smax, 1, 64)); smax = max(smax, __shfl_xor(smax, 2, 64));
+        smax = max(smax, __shfl_xor(smax, 4, 64)); smax = max(smax, __shfl_xor(smax, 8, 64));
+        const int bvw = wave;
+        if (smax >= 0 && bvw < nbu && 16 * bvw <= smax) {
+            const int sa = 16 * bvw + c16;               // this lane's `lo` row of the HPt operand
+            const int ua = (sa >= 3 && sa < nus) ? s_upair[(sa - 3) >> 1] : 0, ea = (sa - 3) & 1;
+            v4d acc = {0, 0, 0, 0};
+            double oa[16], ob[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int k = 4 * q + g4;
+                const int kk = (k < m_pad) ? k : 0;
+                const double wa = (sa < 3) ? s_wc0[sa < 3 ? sa : 0][kk] : s_wcp[ua][kk][ea];
+                const double kb = s_kown[kk][c16];
+                oa[q] = (k < m_pad && sa < nus) ? wa : 0.0; ob[q] = (k < m_pad) ? kb : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(oa[q], ob[q], acc, 0, 0, 0);
+            double *cpo = d.cp + (size_t)(d.post_slot & 1) * REKF_CP_LD * REKF_CP_LD;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int sj = 16 * bvw + g4 + 4 * r;
+                if (s_hi >= 0 && sj <= s_hi) store_wt(&cpo[(size_t)s_hi * REKF_CP_LD + sj], acc[r]);
+            }
         }
     }
 #if defined(REKF_DEBUG_TIMING) && !defined(REKF_DEBUG_DD2)
@@ -1617,18 +1966,9 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
 // M <-> j, N <-> i) and MFMA tile t of a pair covers the interleaved rows i = base + 2 idx + t, so that each lane holds
 // two adjacent rows of one column: 16-byte global accesses, 256 contiguous bytes per 16 lanes, and ONE ds_read_b128 per
 // operand per k-step feeds both tiles, conflict-free on the linear [k][64] LDS image.
-//
-// Border strips.  When n is a few rows past a multiple of the tile size (n = 3 + 2L with L a multiple of 32: three
-// rows), a last tile row/column would be 95 % padding yet cost a full tile of traffic and MFMA time -- and with
-// 33^2 = 1089 tiles on 256 workgroups, a FIFTH tile for a quarter of them.  Instead the tile grid covers [0, nb)^2,
-// nb = 64 floor(n / 64), and the strips P(nb.., :) and P(:, nb..) ride on the diagonal tiles: the workgroup that has the
-// panels Kn(I,:) and HPt(I,:) of tile (I,I) in LDS also updates P(64I.., nb..) and P(nb.., 64I..) with plain FMAs
-// against the border rows of Kn / HPt (KnB / HPtB, staged in s_border).
 // ----------------------------------------------------------------------------
 #define DT 64
 #define DD_WG_PER_CU 1
-#define DD_STRIP_MAX REKF_STRIP_MAX
-typedef double DdBorder[DD_STRIP_MAX][REKF_MR_PAD];
 
 // ----------------------------------------------------------------------------
 // k_downdate2<KC>: the rank-m downdate when the scan's innovation fits one k-chunk, m_pad <= KC <= 64 (the host picks
@@ -1689,14 +2029,18 @@ extern "C" int rekf_debug_dd_times(long long *out, int n_wg)
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dd_times), sizeof(long long) * 2 * (size_t)(n_wg < 1024 ? n_wg : 1024));
 }
 #endif
-// The body is shared by two kernels: k_downdate2 (the downdate alone) and k_dd_front (LAZY DOWNDATE, rekf_api.hip: the downdate of scan
-// t enqueued with scan t+1, whose front end -- Predict's pose and ReflectorMatch, which need the mean and the pose block k_mid(t) left
-// but nothing else of P -- runs in extra workgroups beside it).
-template <int KC>
-__device__ __forceinline__ void dd_body(const RekfDev &d)
+// The body is shared by three kernels: k_downdate2 (the downdate alone), k_dd_front (the downdate of scan t enqueued with scan t+1,
+// whose front end runs in extra workgroups beside it) -- both with a STATIC tile schedule over their nwg workgroups -- and k_mid (one
+// launch per scan, round 5: the downdate of scan t as a role beside scan t+1's mid role, from d.P into d.P_out, its tiles handed out
+// by a QUEUE, RekfCtl::dd_queue, to whichever workgroup is free: the pure downdate workgroups from the start, the front role's
+// workgroups once their observation is matched).
+// No border strips any more (rounds 1-4 treated a border of <= 4 rows past a multiple of 64 as strips on the diagonal tiles; the
+// downdate has left the update's critical path, and a last tile row that is mostly padding costs a few tiles of a launch that waits
+// for nobody): the tile grid covers roundup(n, 64)^2, rows >= n of the panels are zero.
+template <int KC, bool QUEUE>
+__device__ __forceinline__ void dd_body(const RekfDev &d, double *dd_smem, int wg, int nwg, unsigned *queue, bool pub_wg)
 {
-    extern __shared__ __attribute__((aligned(16))) double dd_smem[];   // [Kn 0 | Kn 1 | HPt 0 | HPt 1] panels (+ 16 KiB strip scratch if KC < 64)
-    __shared__ __attribute__((aligned(16))) double s_border[2][DD_STRIP_MAX][REKF_MR_PAD];
+    // dd_smem: [Kn 0 | Kn 1 | HPt 0 | HPt 1] panels, KC x 64 doubles each (>= 33 KiB in all: a diagonal tile's transpose goes through it)
 #ifdef REKF_DEBUG_TIMING
     __shared__ long long tq2[24];          // (in LDS: a register array costs every thread 48 VGPRs and changes what is being measured)
     int nq2 = 0;
@@ -1704,8 +2048,8 @@ __device__ __forceinline__ void dd_body(const RekfDev &d)
 #ifndef REKF_DEBUG_DD2_BLOCK
 #define REKF_DEBUG_DD2_BLOCK 0
 #endif
-    const bool rec2 = blockIdx.x == REKF_DEBUG_DD2_BLOCK && threadIdx.x == 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) const_cast<RekfCtl *>(d.ctl)->dbg[3] = wall_clock64();   // block 0's entry, for the offset of the recorded block
+    const bool rec2 = wg == REKF_DEBUG_DD2_BLOCK && threadIdx.x == 0;
+    if (wg == 0 && threadIdx.x == 0) const_cast<RekfCtl *>(d.ctl)->dbg[3] = wall_clock64();   // block 0's entry, for the offset of the recorded block
 #else
     const bool rec2 = false;
 #endif
@@ -1723,15 +2067,14 @@ __device__ __forceinline__ void dd_body(const RekfDev &d)
     const RekfCtl *ctl = d.ctl;
     // the scan's pending Predict (RekfCtl::pred, see there): applied to the tiles of column 0 as they are read, so that what this
     // launch stores there is predicted AND updated.  Fetched here, used after the first MFMA loop at the earliest.
-    // (through LDS like the border rows: requested now, written behind the prologue's DMA wait)
     const bool pred_on = d.pred_slot >= 0;
     __shared__ double s_pred[12];
     double pred_v = 0.0;
     if (pred_on && threadIdx.x >= 64 && threadIdx.x < 64 + 11) pred_v = ((const double *)&ctl->pred[d.pred_slot & 1])[threadIdx.x - 64];   // ab[0], ab[1], C9[0..8]
     // the pose block after this update, as k_mid evaluated and published it (RekfCtl::post_C9): tile (0, 0) stores THOSE bits
     __shared__ double s_post[9];
-    double post_v = 0.0;
-    if (blockIdx.x == 0 && threadIdx.x >= 128 && threadIdx.x < 128 + 9) post_v = ctl->post_C9[threadIdx.x - 128];
+    __shared__ int s_item;
+    const double *post_src = ctl->post_C9[d.post_slot & 1];
     int n = d.n_known;
     if (n < 0) {
         n = ctl->n;
@@ -1740,10 +2083,10 @@ __device__ __forceinline__ void dd_body(const RekfDev &d)
     // The publisher (the scan's last downdate): pose mean, the pose block AFTER this update (RekfCtl::post_C9: k_mid evaluated it; tile
     // (0, 0) below stores the same bits), the n the state will have once the k_augment behind this kernel has run, and the flags --
     // at the START of the kernel: everything is known, and the stores are long through when the kernel ends
-    if (d.pub && blockIdx.x == 0) {
+    if (d.pub && pub_wg) {
         const int l = threadIdx.x;
         if (l < 3) host_slot_store(d.pub + l, d.mu[l], d.pub_seq, 0);
-        else if (l < 12) host_slot_store(d.pub + l, ctl->post_C9[l - 3], d.pub_seq, 0);
+        else if (l < 12) host_slot_store(d.pub + l, post_src[l - 3], d.pub_seq, 0);
         else if (l == 12) host_slot_store(d.pub + 12, (double)(n + (d.pub_aug ? 2 * ctl->n_new : 0)), d.pub_seq,
                                           __hip_atomic_load(&ctl->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
@@ -1753,52 +2096,40 @@ __device__ __forceinline__ void dd_body(const RekfDev &d)
     constexpr int PANEL = KC * 64;           // doubles per panel
     static_assert(KC % 16 == 0 && KC >= 16 && KC <= 64, "one k-chunk");
     constexpr int Q4 = NK / 4;               // k-steps per VMEM phase: [DMA Kn][stores (+ DMA HPt)][P loads][-]
-    const int rem = n % DT;
-    const bool strips = rem > 0 && rem <= DD_STRIP_MAX && n >= DT;
-    const int T = strips ? n / DT : (n + DT - 1) / DT;
-    int w = blockIdx.x;
-    const int nw = d.dd_grid > 0 ? d.dd_grid : (int)gridDim.x;      // (k_dd_front: the workgroups behind dd_grid are the front end)
-    // the triangle column by column (tile column J: I = J .. T-1); an XCD's workgroups take consecutive ranges of it
-    if (nw >= 8 && (nw & 7) == 0) w = (blockIdx.x & 7) * (nw >> 3) + (blockIdx.x >> 3);
-    // Two classes of workgroups.  Class A, workgroups [0, T): the diagonal tile (w, w) -- it costs almost two
-    // ordinary tiles: no transposed image, but the border strips and the symmetric finish -- behind the tile below it, (w+1, w),
-    // which shares its HPt panel.  Class B, the rest: the tiles with I >= J + 2, column by column, in equal ranges (3 per
-    // workgroup at T = 32).  With the diagonal tiles inside equal ranges of three, the workgroups that held one set the pace.
-    // (When class B gets fewer than three tiles per workgroup -- small states -- class A keeps to its diagonal tile and the tiles
-    // below the diagonal join class B: dd_sub = 1.)
-    const bool classA = w < T;
-
-    // class B: every free workgroup takes tiles -- lo each, the first x of them one more (2 or 3 at T = 32: 465 tiles on 224
-    // workgroups; round 2 gave three tiles to 155 workgroups and left 69 CUs idle).  (lo, x) come from the host when it knows n
-    // exactly (no division in the prologue), else they are derived here from the real T and the grid the host sized by its
-    // bound of n (downdate_schedule below, same arithmetic)
-    int sub = (d.dd_sub == 1) ? 1 : 2, lo = d.dd_lo, xhi = d.dd_x;
-    if (d.dd_sub == 0) {
-        const unsigned room = (unsigned)((nw - T > 1) ? nw - T : 1);
-        unsigned nBq = (unsigned)((T - 1) * (T - 2) / 2);
-        sub = 2;
-        if ((nBq + room - 1) / room < 3) { sub = 1; nBq = (unsigned)(T * (T - 1) / 2); }
-        lo = (int)(nBq / room); xhi = (int)(nBq - (unsigned)lo * room);
-    }
-    const int wq = w - T;
-    const int nB = (T - sub + 1) * (T - sub) / 2;                  // class B: its tiles (the ranges are clamped to them whatever the host planned)
-    const int t_begin = classA ? 0 : min(wq * lo + min(wq, xhi), nB);
-    const int t_end = classA ? ((sub == 2 && w + 1 < T) ? 2 : 1) : min(wq * lo + min(wq, xhi) + lo + (wq < xhi ? 1 : 0), nB);
-    if (t_begin >= t_end) return;
-    const int nt = t_end - t_begin;
+    const int T = (n + DT - 1) / DT;
     const size_t ld = (size_t)d.ld;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int idx = lane & 15, kq = lane >> 4;
     const int wi = wave & 1, wj = wave >> 1;
     const double *__restrict__ Kn = d.Kn;
     const double *__restrict__ HPt = d.HPt;
-    double *__restrict__ P = d.P;
+    const double *__restrict__ P = d.P;
+    double *__restrict__ Pout = d.P_out;
+    if (pred_on && tid >= 64 && tid < 64 + 11) s_pred[tid - 64] = pred_v;      // (read behind the first item's barriers)
 
-    // (a class-A workgroup takes its diagonal tile LAST: the strip work then rides on a tile that has nothing to prefetch)
+    // LDS: [Kn buffer 0 | Kn buffer 1 | HPt buffer 0 | HPt buffer 1], PANEL doubles each
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)dd_smem;
+    auto kn_buf = [&](int b) __attribute__((always_inline)) -> const double * { return dd_smem + (size_t)b * PANEL; };
+    auto hp_buf = [&](int b) __attribute__((always_inline)) -> const double * { return dd_smem + (size_t)(2 + b) * PANEL; };
+    // one DMA instruction: k-rows 2(4q + wave) + {0,1} of the panel that starts at row `row0` of `src`
+    auto dma_piece = [&](const double *src, int row0, int buf_index, int q) __attribute__((always_inline)) {
+        const int pr = 4 * q + wave;
+        const double *g = src + (size_t)(row0 + 2 * (lane & 31)) + (size_t)(2 * pr + (lane >> 5)) * ld;
+        dd_dma16(g, lds0 + (unsigned)(buf_index * PANEL * 8 + pr * 1024));
+    };
+    auto p_off = [&](int I, int J) __attribute__((always_inline)) -> size_t {
+        return (size_t)(DT * I + 32 * wi + 2 * idx) + (size_t)(DT * J + 32 * wj + 2 * kq) * ld;
+    };
+
+    // ---- one work item: class A (classA: the tile below the diagonal tile (w, w), then that tile) or a run [t_begin, t_end) of the
+    // tiles with I >= J + sub, column by column.  The straight-line forms below need short runs (<= 4 tiles).
+    auto run_item = [&](const bool classA, const int w, const int sub, const int t_begin, const int t_end, const bool again) __attribute__((always_inline)) {
+    if (t_begin >= t_end) return;
+    const int nt = t_end - t_begin;
+    // (a class-A workgroup takes its diagonal tile LAST: the mirror then rides on a tile that has nothing to prefetch)
     const int TT = T - sub;                                 // side of the triangle class B enumerates (I >= J + sub)
     // tile number -> (row, column) of the triangle, with a cursor (column, its first tile number) that moves to the queried tile:
     // a workgroup asks for a handful of neighbouring tiles, so after the first query (<= T scalar steps) every look-up is O(1).
-    // (A closed form with sqrtf + fix-up loops, evaluated afresh for each of the ~8 look-ups of the prologue, cost 0.8 us.)
     int cur_J = 0, cur_c0 = 0;
     if (TT > 0) {                                           // the cursor starts at a closed-form estimate of the first tile's column (one sqrtf, once)
         const int t0 = t_begin;
@@ -1816,23 +2147,8 @@ __device__ __forceinline__ void dd_body(const RekfDev &d)
         if (classA) { I = (pos == 0 && nt == 2) ? w + 1 : w; J = w; }
         else { tri_IJ(t_begin + pos, I, J); I += sub; }
     };
-    // LDS: [Kn buffer 0 | Kn buffer 1 | HPt buffer 0 | HPt buffer 1], PANEL doubles each
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)dd_smem;
-    auto kn_buf = [&](int b) __attribute__((always_inline)) -> const double * { return dd_smem + (size_t)b * PANEL; };
-    auto hp_buf = [&](int b) __attribute__((always_inline)) -> const double * { return dd_smem + (size_t)(2 + b) * PANEL; };
-    // one DMA instruction: k-rows 2(4q + wave) + {0,1} of the panel that starts at row `row0` of `src`
-    auto dma_piece = [&](const double *src, int row0, int buf_index, int q) __attribute__((always_inline)) {
-        const int pr = 4 * q + wave;
-        const double *g = src + (size_t)(row0 + 2 * (lane & 31)) + (size_t)(2 * pr + (lane >> 5)) * ld;
-        dd_dma16(g, lds0 + (unsigned)(buf_index * PANEL * 8 + pr * 1024));
-    };
-    auto p_ptr = [&](int I, int J) __attribute__((always_inline)) -> double * {
-        return P + (size_t)(DT * I + 32 * wi + 2 * idx) + (size_t)(DT * J + 32 * wj + 2 * kq) * ld;
-    };
     // P block of a tile -> P + acc -> store source.  NB register blocks in rotation: the read stream runs AHEAD tiles ahead
-    // of the MFMAs.  Measured at C3 (4 tiles per workgroup): AHEAD = 1 and 2 give the same kernel time (17.7 us) -- with two
-    // blocks in flight the first MFMA loop stretches from 2.3 to 3.6 us: a wave that cannot issue its load (memory queue
-    // full) cannot issue its MFMAs either.
+    // of the MFMAs.
 #ifndef REKF_DD_AHEAD
 #define REKF_DD_AHEAD 1
 #endif
@@ -1841,9 +2157,7 @@ __device__ __forceinline__ void dd_body(const RekfDev &d)
     v4d acc[2][2];
     int I, J, kb = 0, hb = 0;
     tile_IJ(0, I, J);
-    // The tile list of a short range, ONCE, in scalar registers: the straight-line forms below index it with compile-time
-    // positions.  (Until round 3 every tile body looked its neighbours up through the cursor -- three look-ups per tile, each a
-    // pair of scalar loops -- and the serial scalar code between two MFMA loops cost a lone wave per SIMD most of a microsecond.)
+    // The tile list of a short range, ONCE, in scalar registers: the straight-line forms below index it with compile-time positions.
     int tI[4] = {I, I, I, I}, tJ[4] = {J, J, J, J};
     if (nt <= 4) {
         if (classA) { tI[1] = w; tI[2] = w; tI[3] = w; }                      // (w + 1, w) then (w, w), or (w, w) alone
@@ -1866,63 +2180,44 @@ __device__ __forceinline__ void dd_body(const RekfDev &d)
         else return std::integral_constant<int, decltype(pos_c)::value + decltype(delta_c)::value>();
     };
 
-    // ---- border strips (see "Border strips" above): same scheme as before, on whichever tile is diagonal
-    auto strip_addr = [&](int II, double *&p0, double *&p1, int &which, int &b, int &x) __attribute__((always_inline)) {
-        which = tid / (DD_STRIP_MAX * 32); const int u = tid % (DD_STRIP_MAX * 32);
-        b = u >> 5; x = 2 * (u & 31);
-        const int nb = DT * T;
-        if (which == 0) { p0 = P + (size_t)(DT * II + x) + (size_t)(nb + b) * ld; p1 = p0 + 1; }
-        else { p0 = P + (size_t)(nb + b) + (size_t)(DT * II + x) * ld; p1 = p0 + ld; }
-    };
-    static_assert(2 * DD_STRIP_MAX * 32 <= 256, "one pass of the strip mapping");
-
-    D2MARK();                                // 0: ctl read, tile assignment done
-    // ---- prologue: border rows, both panels of tile 0 by DMA, its P block.  Only a class-A workgroup (the one with a diagonal
-    // tile) needs the border rows, and their way into LDS must not stand in front of the DMA: the loads go out first, the
-    // ds_writes wait behind the DMA issue (round 2 had load -> wait -> ds_write -> DMA: a whole memory round trip, for every
-    // workgroup, before its first panel was even requested)
-    v2d bdr0 = {0, 0}, bdr1 = {0, 0};
-    const bool want_border = strips && classA;
-    if (want_border) { bdr0 = ((const v2d *)d.KnB)[tid]; bdr1 = ((const v2d *)d.HPtB)[tid]; }
+    D2MARK();                                // 0: tile assignment done
+    // ---- prologue: both panels of tile 0 by DMA, its P block.  (A further item of a queue-fed workgroup: every wave must be through
+    // with the panels -- and the transpose scratch -- of the last one first.)
+    if (again) lds_barrier();
+    double post_v = 0.0;
+    const bool has00 = classA && w == 0;                    // this item ends on tile (0, 0): the pose block by value
+    if (has00 && tid >= 128 && tid < 128 + 9) post_v = post_src[tid - 128];
 #pragma unroll
     for (int q = 0; q < ND; ++q) dma_piece(Kn, DT * I, 0, q);
 #pragma unroll
     for (int q = 0; q < ND; ++q) dma_piece(HPt, DT * J, 2, q);
     {
-        const double *Pw = p_ptr(I, J);
+        const double *Pw = P + p_off(I, J);
 #pragma unroll
         for (int q = 0; q < 8; ++q) pq[0][q] = DD_LOAD((const v2d *)(Pw + (size_t)(8 * (q & 3) + (q >> 2)) * ld));
     }
     if (AHEAD > 1 && nt > 1) {               // ... and the P block of tile 1
         int I1, J1;
         tile_IJ(1, I1, J1);
-        const double *Pw = p_ptr(I1, J1);
+        const double *Pw = P + p_off(I1, J1);
 #pragma unroll
         for (int q = 0; q < 8; ++q) pq[NB - 2][q] = DD_LOAD((const v2d *)(Pw + (size_t)(8 * (q & 3) + (q >> 2)) * ld));
         dd_wait_vmcnt<16>();                 // the DMAs (and everything before them); the 16 P loads may still fly
     } else dd_wait_vmcnt<8>();
-    if (pred_on && tid >= 64 && tid < 64 + 11) s_pred[tid - 64] = pred_v;
-    if (blockIdx.x == 0 && tid >= 128 && tid < 128 + 9) s_post[tid - 128] = post_v;
-    if (want_border) {                       // (older than the DMAs: arrived)
-        ((v2d *)&s_border[0][0][0])[tid] = bdr0;                   // s_border[0] = Kn rows nb.., [1] = HPt rows nb..
-        ((v2d *)&s_border[1][0][0])[tid] = bdr1;
-    }
+    if (has00 && tid >= 128 && tid < 128 + 9) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); s_post[tid - 128] = post_v; }
     lds_barrier();
     D2MARK();                                // 1: panels of tile 0 landed
 
     // ---- one tile.  PAR = which third of pq holds this tile's P block; FIRST (no tile before it: nothing to store), LOAD2
-    // (tile pos+2 exists: request its P block), LAST and SPECIAL are compile-time so that every load and store of a variant
+    // (tile pos+2 exists: request its P block), LAST and DIAGSYM are compile-time so that every load and store of a variant
     // is unconditional: hipcc's s_waitcnt pass then counts them exactly (with `if (pos > 0)` around the stores it had to
-    // assume the fewest, and waited vmcnt(0) for a P block it had only just requested).  SPECIAL = diagonal tile that carries
-    // the border strips; it prefetches no panels (its idle Kn buffer is the strip scratch), which costs nothing when it is
-    // the last tile -- the usual case.
+    // assume the fewest, and waited vmcnt(0) for a P block it had only just requested).
     auto tile_body = [&](auto par_c, auto first_c, auto load2_c, auto last_c, auto special_c, auto pos) __attribute__((always_inline)) {
         using Plus1 = std::integral_constant<int, 1>;
         using PlusA = std::integral_constant<int, AHEAD>;
         using Minus1 = std::integral_constant<int, -1>;
         constexpr int PAR = decltype(par_c)::value, PREV = (PAR + AHEAD) % NB;   // PREV: tile pos-1's block = where tile pos+AHEAD's goes
         constexpr bool FIRST = decltype(first_c)::value, LOAD2 = decltype(load2_c)::value, LAST = decltype(last_c)::value,
-                       SPECIAL = decltype(special_c)::value == 2,          // diagonal tile that carries the border strips
                        DIAGSYM = decltype(special_c)::value >= 1;          // diagonal tile: its upper half := mirror of its (new) lower half
         static_assert(!(LAST && LOAD2), "no tile after the last");
         static_assert(!DIAGSYM || LAST, "a diagonal tile ends its workgroup's range (class A)");
@@ -1930,28 +2225,15 @@ __device__ __forceinline__ void dd_body(const RekfDev &d)
         if constexpr (!LAST) coords(shift(pos, Plus1()), In, Jn);
         const bool needK = !LAST && In != I, needH = !LAST && Jn != J;
         const double *Pn = nullptr;                         // tile pos+2's P block
-        if constexpr (LOAD2) { int I2, J2; coords(shift(pos, PlusA()), I2, J2); Pn = p_ptr(I2, J2); }
+        if constexpr (LOAD2) { int I2, J2; coords(shift(pos, PlusA()), I2, J2); Pn = P + p_off(I2, J2); }
         double *Po = nullptr;                               // where tile pos-1 goes
-        if constexpr (!FIRST) { int Ip, Jp; coords(shift(pos, Minus1()), Ip, Jp); Po = p_ptr(Ip, Jp); }
+        if constexpr (!FIRST) { int Ip, Jp; coords(shift(pos, Minus1()), Ip, Jp); Po = Pout + p_off(Ip, Jp); }
         const double *aW = hp_buf(hb) + 32 * wj + 2 * idx + kq * 64;        // A[j][k] = HP(k,j)
         const double *bK = kn_buf(kb) + 32 * wi + 2 * idx + kq * 64;        // B[k][i] = Kn(i,k)
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int b = 0; b < 2; ++b) acc[a][b] = (v4d){0, 0, 0, 0};
-        // strip operands of a special tile: lane -> (strip, x), wave -> quarter of the k range
-        const int s_which = lane >> 5, s_x = 2 * (lane & 31), s_kb = (KC / 4) * wave;
-        const double *s_panel = (s_which ? hp_buf(hb) : kn_buf(kb)) + s_x + s_kb * 64;
-        const double *s_brow = &s_border[s_which ? 0 : 1][0][s_kb];
-        v2d sacc[DD_STRIP_MAX];
-        v2d strip_p = {0.0, 0.0};
-        if (SPECIAL) {
-            double *p0, *p1; int which, b, x;
-            strip_addr(I, p0, p1, which, b, x);
-            if (which == 1 && b < rem) { strip_p.x = *p0; strip_p.y = *p1; }      // the ROW strip P(nb.., 64 I ..): the column strip lies above the diagonal
-#pragma unroll
-            for (int b2 = 0; b2 < DD_STRIP_MAX; ++b2) { sacc[b2].x = 0.0; sacc[b2].y = 0.0; }
-        }
         v2d a2 = *(const v2d *)(aW), b2 = *(const v2d *)(bK);
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk) {
@@ -2003,15 +2285,6 @@ __device__ __forceinline__ void dd_body(const RekfDev &d)
                 for (int q = 0; q < 8; ++q)
                     if ((q * Q4) / 8 == off) pq[PREV][q] = DD_LOAD((const v2d *)(Pn + (size_t)(8 * (q & 3) + (q >> 2)) * ld));
             }
-            if (SPECIAL && (kk & 1) == 0) {                 // strip FMAs ride under the MFMAs: k pair (kk, kk+1) of this wave's quarter
-                const v2d v0 = *(const v2d *)(s_panel + kk * 64), v1 = *(const v2d *)(s_panel + (kk + 1) * 64);
-#pragma unroll
-                for (int b3 = 0; b3 < DD_STRIP_MAX; ++b3) {
-                    const v2d bb = *(const v2d *)(s_brow + b3 * REKF_MR_PAD + kk);
-                    sacc[b3].x = fma(v0.x, bb.x, sacc[b3].x); sacc[b3].y = fma(v0.y, bb.x, sacc[b3].y);
-                    sacc[b3].x = fma(v1.x, bb.y, sacc[b3].x); sacc[b3].y = fma(v1.y, bb.y, sacc[b3].y);
-                }
-            }
             __builtin_amdgcn_sched_barrier(0);
             a2 = a2n; b2 = b2n;
         }
@@ -2050,7 +2323,7 @@ __device__ __forceinline__ void dd_body(const RekfDev &d)
             // the NEW tile through LDS, S[j][i] = element (i, j) (row stride 66: the lanes of a 16-group differ in i); an element
             // above the diagonal (i < j) then takes S[i][j] = the new element (j, i): the upper half is the mirror image of the
             // lower half whatever the memory above the diagonal held.  Every panel is dead by now (a diagonal tile is the last of
-            // its range): S takes the front of the dynamic LDS (33 KiB; the smallest launch has 48 KiB).
+            // its item): S takes the front of the LDS arena (33 KiB; the smallest launch has 32 KiB of panels + scratch).
             lds_barrier();
             double *S = dd_smem;
 #pragma unroll
@@ -2071,52 +2344,10 @@ __device__ __forceinline__ void dd_body(const RekfDev &d)
                     if (dij < 0) pq[PAR][mt * 4 + r].x = S[ii * 66 + jj];
                     if (dij + 1 < 0) pq[PAR][mt * 4 + r].y = S[(ii + 1) * 66 + jj];
                 }
-            lds_barrier();                                  // (the strip reduction below reuses LDS)
         }
-        if (SPECIAL) {
-            // partial strip sums of the four waves meet in the idle Kn buffer; the threads of the strip mapping finish
-            // (with KC < 64 a panel is smaller than the 16 KiB of partial sums: the launch's LDS beyond the four panels is free)
-            v2d *red = (v2d *)(dd_smem + (KC == 64 ? (size_t)(kb ^ 1) * PANEL : (size_t)4 * PANEL));
-#pragma unroll
-            for (int b3 = 0; b3 < DD_STRIP_MAX; ++b3) red[(wave * DD_STRIP_MAX + b3) * 64 + lane] = sacc[b3];
-            lds_barrier();
-            {
-                double *p0, *p1; int which, b, x;
-                strip_addr(I, p0, p1, which, b, x);
-                // (a pending Predict on the row strip of tile column 0: columns 0, 1 in the thread x = 0, column 2 in its neighbour)
-                const double s_c2 = __shfl_down(strip_p.x, 1, 64);
-                if (pred_on && I == 0 && which == 1 && b < rem && x == 0) {
-#pragma clang fp contract(off)
-                    strip_p.x = strip_p.x + s_pred[0] * s_c2; strip_p.y = strip_p.y + s_pred[1] * s_c2;
-                }
-                if (which == 1 && b < rem) {
-                    v2d t = strip_p;
-#pragma unroll
-                    for (int w4 = 0; w4 < 4; ++w4) { const v2d r = red[(w4 * DD_STRIP_MAX + b) * 64 + 32 + (x >> 1)]; t.x += r.x; t.y += r.y; }
-                    *p0 = t.x; *p1 = t.y;
-                }
-            }
-            if (I == 0 && tid < 64) {                   // the corner block P(nb.., nb..): 16 (a,b) slots x 4 quarters of k
-                const int a = (tid >> 2) & 3, b = tid & 3, k4 = tid >> 4;
-                const int as = max(a, b), bs = min(a, b);      // (a,b) and (b,a) both take the lower element's sum
-                const double *ra = &s_border[0][as][(KC / 4) * k4], *rb = &s_border[1][bs][(KC / 4) * k4];
-                double v = 0.0;
-#pragma unroll
-                for (int k = 0; k < KC / 4; k += 2) {
-                    const v2d u = *(const v2d *)(ra + k), ww = *(const v2d *)(rb + k);
-                    v = fma(u.x, ww.x, v); v = fma(u.y, ww.y, v);
-                }
-                v += __shfl_xor(v, 16, 64);
-                v += __shfl_xor(v, 32, 64);
-                if (k4 == 0 && a < rem && b < rem && a >= b) {      // lower triangle of the corner block
-                    double *pp = P + (size_t)(DT * T + a) + (size_t)(DT * T + b) * ld;
-                    *pp += v;
-                }
-            }
-        }
-        D2MARK();                            // P block there, combined (+ strips)
+        D2MARK();                            // P block there, combined
         if (LAST) {
-            double *Pw = p_ptr(I, J);
+            double *Pw = Pout + p_off(I, J);
 #pragma unroll
             for (int q = 0; q < 8; ++q) DD_STORE((v2d *)(Pw + (size_t)(8 * (q & 3) + (q >> 2)) * ld), pq[PAR][q]);
             return;
@@ -2131,14 +2362,12 @@ __device__ __forceinline__ void dd_body(const RekfDev &d)
     };
     using Tt = std::true_type;
     using Ff = std::false_type;
-    using C0 = std::integral_constant<int, 0>;      // tile kinds: off-diagonal / diagonal / diagonal with the border strips
+    using C0 = std::integral_constant<int, 0>;      // tile kinds: off-diagonal / diagonal
     using C1 = std::integral_constant<int, 1>;
-    using C2 = std::integral_constant<int, 2>;
-    // Short ranges (the BASELINE sizes: 4 tiles per workgroup at n = 2051, 1 at n = 1027 / 259) run as STRAIGHT-LINE code,
-    // one instantiation per position: with no loop and no join in the way, hipcc's s_waitcnt pass places every wait exactly
-    // (through the generic loop below it merges the variants' states at the joins and waits for far younger loads than the
-    // P block it needs).  A diagonal tile ends its (class A) range, so only the last position has the diagonal variants.
-    // The two classes take separate code: class A ends on its diagonal tile (mirror, strips, publication), class B never sees one.
+    // Short ranges (the BASELINE sizes) run as STRAIGHT-LINE code, one instantiation per position: with no loop and no join in the
+    // way, hipcc's s_waitcnt pass places every wait exactly (through the generic loop below it merges the variants' states at the
+    // joins and waits for far younger loads than the P block it needs).  A diagonal tile ends its (class A) range, so only the last
+    // position has the diagonal variant.  The two classes take separate code.
     auto straight = [&](auto nt_c, auto cls_a) __attribute__((always_inline)) {
         constexpr int NT = decltype(nt_c)::value;
         constexpr bool CLS_A = decltype(cls_a)::value;
@@ -2148,10 +2377,8 @@ __device__ __forceinline__ void dd_body(const RekfDev &d)
             using First = std::integral_constant<bool, POS == 0>;
             using Load2 = std::integral_constant<bool, (POS + AHEAD < NT)>;
             using Last = std::integral_constant<bool, POS == NT - 1>;
-            if constexpr (POS == NT - 1 && CLS_A) {
-                if (strips) tile_body(Par(), First(), Load2(), Last(), C2(), pos_c);
-                else tile_body(Par(), First(), Load2(), Last(), C1(), pos_c);
-            } else tile_body(Par(), First(), Load2(), Last(), C0(), pos_c);
+            if constexpr (POS == NT - 1 && CLS_A) tile_body(Par(), First(), Load2(), Last(), C1(), pos_c);
+            else tile_body(Par(), First(), Load2(), Last(), C0(), pos_c);
         };
         one(std::integral_constant<int, 0>());
         if constexpr (NT > 1) one(std::integral_constant<int, 1>());
@@ -2186,6 +2413,51 @@ __device__ __forceinline__ void dd_body(const RekfDev &d)
             if (pos + NB - 1 < nt) run(B0(), pos + NB - 1);
         }
     }
+    };      // run_item
+
+    if constexpr (QUEUE) {
+        // ---- tiles from the queue: items 0 .. T-1 = class A (diagonal tile w behind the tile below it), then runs of DD_RUN tiles of
+        // the triangle I >= J + 2, column by column
+        constexpr int DD_RUN = 3;
+        const int nB = (T - 1) * (T - 2) / 2, n_items = T + (nB + DD_RUN - 1) / DD_RUN;
+        bool again = false;
+        for (;;) {
+            if (tid == 0) s_item = (int)atomicAdd(queue, 1u);
+            __syncthreads();
+            const int it = __builtin_amdgcn_readfirstlane(s_item);
+            __syncthreads();
+            if (it >= n_items) break;
+            const bool cla = it < T;
+            run_item(cla, cla ? it : 0, 2, cla ? 0 : DD_RUN * (it - T), cla ? ((it + 1 < T) ? 2 : 1) : min(DD_RUN * (it - T) + DD_RUN, nB), again);
+            again = true;
+        }
+    } else {
+        int w = wg;
+        const int nw = nwg;
+        // the triangle column by column (tile column J: I = J .. T-1); an XCD's workgroups take consecutive ranges of it
+        if (nw >= 8 && (nw & 7) == 0) w = (wg & 7) * (nw >> 3) + (wg >> 3);
+        // Two classes of workgroups.  Class A, workgroups [0, T): the diagonal tile (w, w) -- it costs more than an ordinary tile: the
+        // symmetric finish -- behind the tile below it, (w+1, w), which shares its HPt panel.  Class B, the rest: the tiles with
+        // I >= J + 2, column by column, in equal ranges.  (When class B gets fewer than three tiles per workgroup -- small states --
+        // class A keeps to its diagonal tile and the tiles below the diagonal join class B: dd_sub = 1.)
+        const bool classA = w < T;
+        // class B: every free workgroup takes tiles -- lo each, the first x of them one more.  (lo, x) come from the host when it knows n
+        // exactly (no division in the prologue), else they are derived here from the real T and the grid the host sized by its
+        // bound of n (downdate_schedule below, same arithmetic)
+        int sub = (d.dd_sub == 1) ? 1 : 2, lo = d.dd_lo, xhi = d.dd_x;
+        if (d.dd_sub == 0) {
+            const unsigned room = (unsigned)((nw - T > 1) ? nw - T : 1);
+            unsigned nBq = (unsigned)((T - 1) * (T - 2) / 2);
+            sub = 2;
+            if ((nBq + room - 1) / room < 3) { sub = 1; nBq = (unsigned)(T * (T - 1) / 2); }
+            lo = (int)(nBq / room); xhi = (int)(nBq - (unsigned)lo * room);
+        }
+        const int wq = w - T;
+        const int nB = (T - sub + 1) * (T - sub) / 2;                  // class B: its tiles (the ranges are clamped to them whatever the host planned)
+        const int t_begin = classA ? 0 : min(wq * lo + min(wq, xhi), nB);
+        const int t_end = classA ? ((sub == 2 && w + 1 < T) ? 2 : 1) : min(wq * lo + min(wq, xhi) + lo + (wq < xhi ? 1 : 0), nB);
+        run_item(classA, w, sub, t_begin, t_end, false);
+    }
 #ifdef REKF_DEBUG_ENTRY
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (this wave's last stores acknowledged)
     if (threadIdx.x == 0 && blockIdx.x < 1024) g_dd_times[blockIdx.x][1] = wall_clock64();
@@ -2206,7 +2478,8 @@ __device__ __forceinline__ void dd_body(const RekfDev &d)
 template <int KC>
 __global__ __launch_bounds__(256) void k_downdate2(RekfDev d)
 {
-    dd_body<KC>(d);
+    extern __shared__ __attribute__((aligned(16))) double dd_smem_k[];
+    dd_body<KC, false>(d, dd_smem_k, (int)blockIdx.x, (int)gridDim.x, nullptr, blockIdx.x == 0);
 }
 template <int KC>
 __global__ __launch_bounds__(256) void k_dd_front(RekfDev d, RekfDev dn, RekfFrontArgs A)
@@ -2222,7 +2495,8 @@ __global__ __launch_bounds__(256) void k_dd_front(RekfDev d, RekfDev dn, RekfFro
 #endif
         return;
     }
-    dd_body<KC>(d);
+    extern __shared__ __attribute__((aligned(16))) double dd_smem_k[];
+    dd_body<KC, false>(d, dd_smem_k, (int)blockIdx.x, d.dd_grid, nullptr, blockIdx.x == 0);
 }
 
 // ----------------------------------------------------------------------------
@@ -2299,50 +2573,12 @@ void rekf_launch_compact_wide(const RekfDev &d, const RekfFrontArgs &a, hipStrea
 {
     hipLaunchKernelGGL(k_compact_wide, dim3(1), dim3(REKF_MAX_OBS_WIDE), 0, s, d, a);
 }
-void rekf_launch_mid(const RekfDev &d, const RekfFrontArgs &a, int n_ub, int m_ub, bool mode_grow, hipStream_t s)
-{
-    // m_ub <= 64 (the host checks): one workgroup per 16 state rows
-    const int grid = (n_ub + MID_ROWS - 1) / MID_ROWS + (a.front_in_mid > 0 ? a.front_in_mid : 0);
-    const int mode = (a.front_in_mid > 0) ? 2 : (mode_grow ? 1 : 0);
-    if (m_ub <= 32) {
-        if (mode == 0) hipLaunchKernelGGL((k_mid<2, 0>), dim3(grid), dim3(512), 0, s, d.ctl, d, a, d);          // (the last argument: the downdate role's view, one-launch form only)
-        else if (mode == 1) hipLaunchKernelGGL((k_mid<2, 1>), dim3(grid), dim3(512), 0, s, d.ctl, d, a, d);
-        else hipLaunchKernelGGL((k_mid<2, 2>), dim3(grid), dim3(512), 0, s, d.ctl, d, a, d);
-    } else {
-        if (mode == 0) hipLaunchKernelGGL((k_mid<4, 0>), dim3(grid), dim3(512), 0, s, d.ctl, d, a, d);
-        else if (mode == 1) hipLaunchKernelGGL((k_mid<4, 1>), dim3(grid), dim3(512), 0, s, d.ctl, d, a, d);
-        else hipLaunchKernelGGL((k_mid<4, 2>), dim3(grid), dim3(512), 0, s, d.ctl, d, a, d);
-    }
-}
-template <int KC> static void launch_downdate2(const RekfDev &d, int grid, hipStream_t s, bool first_on_device, const RekfDev *dn, const RekfFrontArgs *an, int n_front)
-{
-    constexpr int BYTES = 4 * KC * 64 * (int)sizeof(double) + (KC < 64 ? 16384 : 0);
-    if (first_on_device) {
-        (void)hipFuncSetAttribute((const void *)k_downdate2<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
-        (void)hipFuncSetAttribute((const void *)k_dd_front<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
-    }
-    if (dn) hipLaunchKernelGGL((k_dd_front<KC>), dim3(grid + n_front), dim3(256), BYTES, s, d, *dn, *an);
-    else hipLaunchKernelGGL((k_downdate2<KC>), dim3(grid), dim3(256), BYTES, s, d);
-}
-// host half of the tile schedule (tests/test_downdate_schedule_cpu.py restates it): T class-A workgroups (diagonal tile + the
-// one below) + equal ranges of the rest
-static void downdate_schedule(int n_ub, int slots, int &grid, int &dd_lo, int &dd_x, int &dd_sub)
-{
-    const int T = (rekf_strip_base(n_ub) >= 0) ? n_ub / DT : (n_ub + DT - 1) / DT;      // the kernel's own T: a thin border rides on the diagonal tiles as strips
-    const int room = (slots - T > 1) ? slots - T : 1;
-    int nB = (T - 1) * (T - 2) / 2;
-    dd_sub = 2;
-    if ((nB + room - 1) / room < 3) { dd_sub = 1; nB = T * (T - 1) / 2; }   // small states: a class-A workgroup keeps to its diagonal tile
-    dd_lo = nB / room; dd_x = nB - dd_lo * room;          // the first dd_x class-B workgroups take dd_lo + 1 tiles, the others dd_lo
-    grid = T + (dd_lo > 0 ? room : dd_x);
-    if (grid >= 64) grid = (grid + 7) & ~7;         // multiple of 8 for the per-XCD numbering (workgroups past the last range return at once)
-}
 // per-DEVICE facts the launches below need: the CU count, and which kernel variants have their opt-in to more than 64 KiB of dynamic LDS
 constexpr int DD_MAX_DEV = 64;
 static struct {
     int n_cu_of[DD_MAX_DEV] = {0};
     unsigned attr_done[DD_MAX_DEV] = {0};     // bit KC/16 : k_downdate2<KC> / k_dd_front<KC>
-    unsigned attr_one[DD_MAX_DEV] = {0};      // bit 2 (KC/16 - 1) + (MODE - 2) : k_mid<2, MODE, KC>, the one-launch form
+    unsigned attr_mid[DD_MAX_DEV] = {0};      // bit 3 (NBR / 2 - 1) + MODE : k_mid<NBR, MODE>
     std::mutex mu;
 } g_dd_cache;
 static int dd_cache_slot(int &dev)            // (call with g_dd_cache.mu held)
@@ -2356,9 +2592,97 @@ static int dd_cache_slot(int &dev)            // (call with g_dd_cache.mu held)
         if (cu <= 0) cu = 256;
         g_dd_cache.n_cu_of[slot] = cu;
         g_dd_cache.attr_done[slot] = 0;
-        g_dd_cache.attr_one[slot] = 0;
+        g_dd_cache.attr_mid[slot] = 0;
     }
     return slot;
+}
+// k_mid<NBR, MODE> with `bytes` of dynamic LDS (all of its LDS is one arena: MidLds, and the downdate role's panels over it)
+template <int NBR, int MODE> static void launch_mid_as(int grid, int with_dd, hipStream_t s, const RekfDev &d, const RekfFrontArgs &a, const RekfDev &dp)
+{
+    constexpr int MID_BYTES = (int)sizeof(MidLds<NBR>);
+    constexpr int BYTES = (MODE != 1 && MID_BYTES < REKF_DD_LDS_BYTES) ? REKF_DD_LDS_BYTES : MID_BYTES;     // (one size per kernel: the opt-in is per function)
+    static_assert(BYTES <= 160 * 1024 - 12 * 1024, "the front role's and the downdate role's static LDS ride on top");
+    (void)with_dd;
+    {
+        std::lock_guard<std::mutex> guard(g_dd_cache.mu);
+        int dev = 0;
+        const int slot = dd_cache_slot(dev);
+        const unsigned bit = 1u << (3 * (NBR / 2 - 1) + MODE);
+        if (!(g_dd_cache.attr_mid[slot] & bit) || dev != slot) {
+            (void)hipFuncSetAttribute((const void *)k_mid<NBR, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+            g_dd_cache.attr_mid[slot] |= bit;
+        }
+    }
+    hipLaunchKernelGGL((k_mid<NBR, MODE>), dim3(grid), dim3(512), BYTES, s, d.ctl, d, a, dp);
+}
+void rekf_launch_mid(const RekfDev &d, RekfFrontArgs &a, int n_ub, int m_ub, bool mode_grow, hipStream_t s)
+{
+    // m_ub <= 64 (the host checks): one workgroup per 16 state rows
+    a.n_mid = (n_ub + MID_ROWS - 1) / MID_ROWS;
+    a.dd_in_mid = 0; a.dd_first = 0;
+    const int grid = a.n_mid + (a.front_in_mid > 0 ? a.front_in_mid : 0);
+    const int mode = (a.front_in_mid > 0) ? 2 : (mode_grow ? 1 : 0);
+    if (m_ub <= 32) {
+        if (mode == 0) launch_mid_as<2, 0>(grid, 0, s, d, a, d);          // (the last argument: the downdate role's view, one launch per scan only)
+        else if (mode == 1) launch_mid_as<2, 1>(grid, 0, s, d, a, d);
+        else launch_mid_as<2, 2>(grid, 0, s, d, a, d);
+    } else {
+        if (mode == 0) launch_mid_as<4, 0>(grid, 0, s, d, a, d);
+        else if (mode == 1) launch_mid_as<4, 1>(grid, 0, s, d, a, d);
+        else launch_mid_as<4, 2>(grid, 0, s, d, a, d);
+    }
+}
+// ONE launch per scan (round 5): [the scan's front end, front_wgs workgroups (0: it ran before this launch) | its mid role, which takes the
+// pending downdate dd as a correction of what it gathers | dd itself, from dd.P into dd.P_out, on the CUs the others leave free, tiles from
+// RekfCtl::dd_queue].  The caller has set a.corr / corr_pred / corr_post / dd_par.  Returns the launch's grid.
+int rekf_launch_scan(const RekfDev &dd, const RekfDev &d, RekfFrontArgs &a, int n_ub, int m_ub, int front_wgs, hipStream_t s)
+{
+    int n_cu;
+    {
+        std::lock_guard<std::mutex> guard(g_dd_cache.mu);
+        int dev = 0;
+        n_cu = g_dd_cache.n_cu_of[dd_cache_slot(dev)];
+    }
+    a.n_mid = (n_ub + MID_ROWS - 1) / MID_ROWS;
+    a.front_in_mid = front_wgs;
+    a.dd_first = (front_wgs + a.n_mid + 7) & ~7;          // (the queue does not care; a multiple of 8 keeps block number mod 8 = XCD for everybody)
+    const int n_dd = (dd.n_known >= 0) ? dd.n_known : dd.n_max;
+    const int T = (n_dd + DT - 1) / DT, nB = (T - 1) * (T - 2) / 2, items = T + (nB + 2) / 3;
+    int wgs = n_cu - a.dd_first;                          // one workgroup per CU (the arena), everybody resident from the start
+    if (wgs < 8) wgs = 8;
+    if (wgs > items) wgs = items;
+    a.dd_in_mid = wgs;
+    const int grid = a.dd_first + wgs;
+    const int mode = front_wgs > 0 ? 2 : 0;
+    if (m_ub <= 32) {
+        if (mode == 0) launch_mid_as<2, 0>(grid, 1, s, d, a, dd); else launch_mid_as<2, 2>(grid, 1, s, d, a, dd);
+    } else {
+        if (mode == 0) launch_mid_as<4, 0>(grid, 1, s, d, a, dd); else launch_mid_as<4, 2>(grid, 1, s, d, a, dd);
+    }
+    return grid;
+}
+template <int KC> static void launch_downdate2(const RekfDev &d, int grid, hipStream_t s, bool first_on_device, const RekfDev *dn, const RekfFrontArgs *an, int n_front)
+{
+    constexpr int BYTES = 4 * KC * 64 * (int)sizeof(double) + (KC < 64 ? 16384 : 0);      // (a diagonal tile's transpose needs 33 KiB)
+    if (first_on_device) {
+        (void)hipFuncSetAttribute((const void *)k_downdate2<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+        (void)hipFuncSetAttribute((const void *)k_dd_front<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+    }
+    if (dn) hipLaunchKernelGGL((k_dd_front<KC>), dim3(grid + n_front), dim3(256), BYTES, s, d, *dn, *an);
+    else hipLaunchKernelGGL((k_downdate2<KC>), dim3(grid), dim3(256), BYTES, s, d);
+}
+// host half of the STATIC tile schedule (tests/test_downdate_schedule_cpu.py restates it): T class-A workgroups (diagonal tile + the
+// one below) + equal ranges of the rest
+static void downdate_schedule(int n_ub, int slots, int &grid, int &dd_lo, int &dd_x, int &dd_sub)
+{
+    const int T = (n_ub + DT - 1) / DT;
+    const int room = (slots - T > 1) ? slots - T : 1;
+    int nB = (T - 1) * (T - 2) / 2;
+    dd_sub = 2;
+    if ((nB + room - 1) / room < 3) { dd_sub = 1; nB = T * (T - 1) / 2; }   // small states: a class-A workgroup keeps to its diagonal tile
+    dd_lo = nB / room; dd_x = nB - dd_lo * room;          // the first dd_x class-B workgroups take dd_lo + 1 tiles, the others dd_lo
+    grid = T + (dd_lo > 0 ? room : dd_x);
+    if (grid >= 64) grid = (grid + 7) & ~7;         // multiple of 8 for the per-XCD numbering (workgroups past the last range return at once)
 }
 // dn / an non-null: the fused form k_dd_front -- scan t's downdate with the front end of scan t+1 (dn, an) in FRONT_MB further workgroups,
 // which take their CUs out of the downdate's schedule
@@ -2391,56 +2715,6 @@ static void launch_downdate_any(const RekfDev &d, int n_ub, hipStream_t s, const
     else if (kc == 48) launch_downdate2<48>(dp, grid, s, first, dn, an, n_front);
     else if (kc == 32) launch_downdate2<32>(dp, grid, s, first, dn, an, n_front);
     else launch_downdate2<16>(dp, grid, s, first, dn, an, n_front);
-}
-// ONE launch per scan for small states (k_mid<2, MODE, KC>): the previous scan's downdate (dd: its device view, the panels of ITS k_mid), this
-// scan's front end (one observation per workgroup) and its mid role.  Returns the number of downdate workgroups (the host's share of the
-// RekfCtl::dd_done bookkeeping).
-template <int MODE, int KC> static void launch_one(const RekfDev &dp, const RekfDev &d, const RekfFrontArgs &a, int grid, bool first_on_device, hipStream_t s)
-{
-    constexpr int BYTES = 4 * KC * 64 * (int)sizeof(double) + 16384;
-    if (first_on_device) (void)hipFuncSetAttribute((const void *)k_mid<2, MODE, KC>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
-    hipLaunchKernelGGL((k_mid<2, MODE, KC>), dim3(grid), dim3(512), BYTES, s, d.ctl, d, a, dp);
-}
-// does a state of at most n_ub rows (its held-back downdate: dd_n_ub) with K observations have the one-launch form on this device?
-// (every workgroup of that launch holds a CU: all of them must be resident together)
-int rekf_one_launch_fits(int dd_n_ub, int n_ub, int K)
-{
-    std::lock_guard<std::mutex> guard(g_dd_cache.mu);
-    int dev = 0;
-    const int slot = dd_cache_slot(dev);
-    const int slots = g_dd_cache.n_cu_of[slot] - K - (n_ub + MID_ROWS - 1) / MID_ROWS;
-    if (K < 1 || K > 32 || slots < 8) return 0;
-    int grid_dd, dd_lo, dd_x, dd_sub;
-    downdate_schedule(dd_n_ub, slots, grid_dd, dd_lo, dd_x, dd_sub);
-    return grid_dd <= slots ? 1 : 0;
-}
-int rekf_launch_one(const RekfDev &dd, int dd_n_ub, const RekfDev &d, RekfFrontArgs &a, int n_ub, int m_ub, bool mode_grow, unsigned dd_done_before, hipStream_t s)
-{
-    const int kc = (dd.kc_ub < 16) ? 16 : dd.kc_ub;
-    if (m_ub > 32 || kc > 32 || a.K < 1 || a.K > 32) return 0;
-    std::lock_guard<std::mutex> guard(g_dd_cache.mu);
-    int dev = 0;
-    const int slot = dd_cache_slot(dev);
-    const int n_mid = (n_ub + MID_ROWS - 1) / MID_ROWS;
-    int slots = g_dd_cache.n_cu_of[slot] - a.K - n_mid;              // one workgroup per CU (the launch's LDS), everybody resident at once
-    if (slots < 8) return 0;
-    int grid_dd, dd_lo, dd_x, dd_sub;
-    downdate_schedule(dd_n_ub, slots, grid_dd, dd_lo, dd_x, dd_sub);
-    if (grid_dd > slots) return 0;
-    RekfDev dp = dd;
-    dp.dd_lo = dd_lo; dp.dd_x = dd_x; dp.dd_sub = dd_sub; dp.dd_grid = grid_dd;
-    if (dd.n_known < 0) { dp.dd_lo = 0; dp.dd_x = 0; dp.dd_sub = 0; }   // (a bound only: the kernel derives the schedule from the real n)
-    a.dd_in_mid = grid_dd;
-    a.dd_target = dd_done_before + (unsigned)grid_dd;
-    a.front_in_mid = a.K;
-    const int mode = mode_grow ? 3 : 2;
-    const unsigned bit = 1u << (2 * (kc / 16 - 1) + (mode - 2));
-    const bool first = !(g_dd_cache.attr_one[slot] & bit) || dev != slot;
-    g_dd_cache.attr_one[slot] |= bit;
-    const int grid = grid_dd + a.K + n_mid;
-    if (kc == 32) { if (mode == 3) launch_one<3, 32>(dp, d, a, grid, first, s); else launch_one<2, 32>(dp, d, a, grid, first, s); }
-    else { if (mode == 3) launch_one<3, 16>(dp, d, a, grid, first, s); else launch_one<2, 16>(dp, d, a, grid, first, s); }
-    return grid_dd;
 }
 void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s) { launch_downdate_any(d, n_ub, s, nullptr, nullptr); }
 void rekf_launch_dd_front(const RekfDev &d, int n_ub, const RekfDev &dn, const RekfFrontArgs &an, hipStream_t s) { launch_downdate_any(d, n_ub, s, &dn, &an); }

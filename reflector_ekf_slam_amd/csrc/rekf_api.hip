@@ -38,10 +38,12 @@ struct rekf {
     int max_landmarks;
     hipStream_t stream;
     RekfDev dev;
-    // the Kn / HPt panels (and their border copies) exist twice, by scan parity: k_mid of scan t writes one set, the held-back downdate of
-    // scan t reads it -- possibly inside the launch in which scan t+1's k_mid role writes the other (one-launch small states)
-    double *panel_base[4] = {nullptr, nullptr, nullptr, nullptr};     // HPt, Kn (2 x ld x 64 each), HPtB, KnB (2 x STRIP_MAX x MR_PAD each)
+    // the Kn / HPt panels exist twice, by scan parity: k_mid of scan t writes one set, the held-back downdate of scan t reads it --
+    // inside the launch in which scan t+1's mid role writes the other (one launch per scan)
+    double *panel_base[2] = {nullptr, nullptr};     // HPt, Kn (2 x ld x 64 each)
     int panel_par = 0;
+    // ... and so does P: dev.P is the STORED covariance (what every reader reads), P_alt the buffer the next in-launch downdate writes
+    double *P_alt = nullptr;
     double time;
     double vt[3];
     int n_ub;                  // host upper bound of the device-resident n
@@ -80,22 +82,25 @@ struct rekf {
     // its own beside it -- two launches per scan instead of three, and the match off the critical path.  Anything else that looks at
     // the device state enqueues it first (flush_dd).
     bool dd_pending = false;
+    unsigned dd_scan = 0;           // ... the scan it belongs to (its write-ahead correction carries the id) ...
     RekfDev dd_dev;                 // the held-back launch: device view (publisher tag included) ...
     int dd_n_ub = 0;                // ... and the bound of n it was planned with
     bool dd_aug = false;            // the scan's k_augment is held back with it (the state can still grow): it runs right behind the downdate
     RekfFrontArgs dd_aug_args;      // ... with the scan's launch packet (the new reflectors' observations)
     bool dd_aug_inline_ok = false;  // ... and it may run inside the next scan's k_mid instead of a launch of its own (RekfCtl::augrec: whole scans only)
     bool aug_in_mid = true;         // REKF_AUG_IN_MID=0 in the environment turns that off (A/B measurements)
-    bool front_in_mid = true;       // a host-predicted scan's front end runs inside k_mid's grid (REKF_FRONT_IN_MID=0: as k_front_mb, a launch of its own)
-    // SMALL STATES, ONE LAUNCH PER SCAN (opt-in: REKF_ONE_LAUNCH=1): the held-back downdate, the front end and k_mid as roles of ONE grid
-    // (k_mid<2, MODE, KC>) when the scan has at most 16 observations, the state at most one_nmax rows (REKF_ONE_LAUNCH_NMAX) and nobody else
-    // is at work on the GPU (the mid role waits for the other two INSIDE the launch).  Built for VERDICT round 1-3's "C2 in one launch" and
-    // measured on MI355X (profiles/r04_chain_experiments.txt, item 7): 19.92 us per update against 8.45 + 11.46 = 19.91 us as two launches --
-    // the stream runs its kernels back to back, so the launch boundary the form removes costs nothing; what counts, max(front end, the
-    // downdate's diagonal-tile workgroup) followed by k_mid's dependent chain, is the same in both.  Bit-identical results; off by default.
-    bool one_launch = false;
-    int one_nmax = 643;
-    unsigned dd_total = 0;          // RekfCtl::dd_done once every downdate role enqueued so far is through
+    bool front_in_mid = true;       // a scan's front end runs inside k_mid's grid (REKF_FRONT_IN_MID=0: as k_front_mb, a launch of its own)
+    // ONE LAUNCH PER SCAN (round 5; REKF_SCAN_LAUNCH=0 turns it off): the held-back downdate is not applied in front of the next scan's
+    // k_mid but BESIDE it -- as a role of the same launch, from the stored P into the other P buffer -- while the mid role corrects what
+    // it gathers by the pending panels (k_mid): the rank-m downdate is off the update's critical path.  For a filter that cannot grow
+    // (h->full) and whole scans; everything else goes through the two-launch chain (k_dd_front, k_mid).
+    bool scan_launch = true;
+    // EXCLUSIVE (opt-in: rekf_set_exclusive / REKF_EXCLUSIVE=1): two hand-overs put WAITING workgroups into a launch (the mid role waits for
+    // an in-grid front end; for the previous scan's in-grid augmentation).  That is deadlock-free only while nothing else competes for the
+    // GPU's CUs, which a library cannot see: the caller says so, and even then the hand-overs are used only while this is the process's
+    // only live handle.  Off: the front end is a launch of its own (k_front_mb / k_dd_front), the augmentation k_augment.
+    bool exclusive = false;
+    bool live_counted = false;      // this handle is in g_live_handles
     bool lazy_dd = true;            // REKF_LAZY_DD=0 in the environment turns it off (A/B measurements)
     // WHO PUBLISHES pose, pose block, n and flags of a scan.  A caller that reads the pose back after its scans (the reference's node,
     // src/ros_node.cc:514-515) gets them from k_mid's workgroup 0 -- a kernel earlier: GetPose does not wait for the downdate -- which
@@ -106,7 +111,6 @@ struct rekf {
     RekfCtl *ctl_staging;      // pinned copy of the control block
     std::string hip_error;
     int flags_seen = 0;        // sticky device flags already reported on stderr
-    int activity_slot = -1;    // this handle's entry in the process-wide activity table (WHO ELSE IS AT WORK ON THE GPU)
     int inject_failure = 0;    // rekf_debug_inject_failure: the next HandleObservationMessage fails at this stage
     double *dev_ell;           // device scratch for k_ellipses (5 doubles per landmark of capacity)
     double *dev_pred;          // device scratch for k_predict_rows (4 * ld + 12 doubles)
@@ -128,35 +132,9 @@ struct rekf {
 
 namespace {
 
-// WHO ELSE IS AT WORK ON THE GPU.  Two of the round-4 launches contain workgroups that WAIT for other workgroups of the same launch
-// (k_mid's mid workgroups for the scan's front end / the previous scan's augmentation).  That is deadlock-free while the launch's
-// waiting workgroups cannot keep its working ones off the CUs: alone on the GPU the grid's first 256 workgroups are resident
-// together.  With several sessions enqueueing at once it is not -- each XCD places its share of a grid by itself, the waiting
-// workgroups of one session can hold the CUs another session's front workgroups need, and vice versa (found by
-// scripts/gpu_stress_sessions.py: six sessions, timeouts).  So every handle stamps its enqueues here, and a handle uses the in-launch
-// hand-overs only when no OTHER handle of this process has enqueued anything for a while; otherwise it falls back to the separate
-// launches (k_front_mb, k_augment).  Other processes cannot be seen: REKF_FRONT_IN_MID=0 / REKF_AUG_IN_MID=0 there (rekf.h).
-constexpr int ACTIVITY_SLOTS = 256;
-std::atomic<long long> g_activity[ACTIVITY_SLOTS];      // steady-clock ns of a handle's last enqueue; 0 = slot free
-long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-int activity_claim()
-{
-    for (int i = 0; i < ACTIVITY_SLOTS; ++i) { long long z = 0; if (g_activity[i].compare_exchange_strong(z, 1)) return i; }
-    return -1;
-}
-// stamps this handle's slot; true if no other handle has enqueued within the last 5 ms
-bool alone_on_gpu(int slot)
-{
-    const long long t = now_ns();
-    if (slot < 0) return false;
-    g_activity[slot].store(t, std::memory_order_relaxed);
-    for (int i = 0; i < ACTIVITY_SLOTS; ++i) {
-        if (i == slot) continue;
-        const long long o = g_activity[i].load(std::memory_order_relaxed);
-        if (o > 1 && t - o < 5000000LL) return false;
-    }
-    return true;
-}
+// How many handles this process holds: the in-launch hand-overs of an EXCLUSIVE handle (struct rekf) are used only while it is the only one
+std::atomic<int> g_live_handles{0};
+bool in_grid_ok(const rekf_t *h) { return h->exclusive && g_live_handles.load(std::memory_order_seq_cst) == 1; }
 
 #define HIP_TRY(h, expr)                                                         \
     do {                                                                         \
@@ -169,24 +147,38 @@ bool alone_on_gpu(int slot)
 
 int round_up(int x, int q) { return (x + q - 1) / q * q; }
 
-// wait until the `count` slots from `first` carry `seq` (a kernel on the handle's stream stores them).  Polls with a pause; when
-// the stream drains without them, or after two seconds of polling (a shared or oversubscribed GPU, a profiler, a debugger: the
-// kernel is merely slow), it waits for the stream instead and looks once more -- only a stream that HAS drained without the
-// slots is an error.
+static inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("isb" ::: "memory");
+#else
+    std::this_thread::yield();
+#endif
+}
+// wait until the `count` slots from `first` carry `seq` (a kernel on the handle's stream stores them).  Polls with a pause; a stream
+// that has drained without them is an error at once; a stream that is still busy (a shared or oversubscribed GPU, a profiler, a
+// debugger: the kernel is merely slow) is polled up to a hard bound of REKF_WAIT_SECONDS (default 30) -- never an unbounded
+// hipStreamSynchronize: a hung kernel must come back as REKF_ERR_HIP, not block GetPose and odometry for ever.
 template <class H> int wait_slots(H *h, int first, int count, int seq)
 {
+    static const double limit_s = [] { const char *e = std::getenv("REKF_WAIT_SECONDS"); const double v = e ? std::atof(e) : 0.0; return v > 0.0 ? v : 30.0; }();
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
     for (int k = first; k < first + count; ++k) {
         const int *tag = &h->host_slots[k].seq;
         while (__atomic_load_n(tag, __ATOMIC_ACQUIRE) != seq) {
-            __builtin_ia32_pause();
+            cpu_relax();
             if ((++spins & 0xffffu) == 0) {
                 const bool drained = hipStreamQuery(h->stream) != hipErrorNotReady;
-                if (drained || std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
-                    HIP_TRY(h, hipStreamSynchronize(h->stream));
+                if (drained) {
                     if (__atomic_load_n(tag, __ATOMIC_ACQUIRE) == seq) break;
                     h->hip_error = "a pose kernel finished without publishing its result";
+                    return REKF_ERR_HIP;
+                }
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s) {
+                    h->hip_error = "timed out waiting for a kernel to publish the pose (REKF_WAIT_SECONDS)";
                     return REKF_ERR_HIP;
                 }
                 if ((spins & 0xfffffu) == 0) std::this_thread::yield();
@@ -278,7 +270,7 @@ void report_flags(rekf_t *h, int flags)
                              "(the reference grows its state without bound)\n", h->max_landmarks);
     if (fresh & REKF_FLAG_STARVED) {
         std::fprintf(stderr, "rekf: a hand-over inside a launch gave up waiting (other work held the GPU's CUs): the filter state is not meaningful any more; "
-                             "set REKF_FRONT_IN_MID=0 REKF_AUG_IN_MID=0 when several processes share the GPU\n");
+                             "an EXCLUSIVE handle (rekf_set_exclusive / REKF_EXCLUSIVE=1) must have the GPU to itself\n");
         h->hip_error = "an in-launch hand-over starved (REKF_FLAGBIT_STARVED)";
     }
     if (fresh & REKF_FLAG_SINGULAR)
@@ -321,6 +313,7 @@ int flush_dd(rekf_t *h)
     if (!h->dd_pending) return REKF_OK;
     HIP_TRY(h, hipSetDevice(h->device));
     h->dd_pending = false;
+    h->dd_dev.P_out = h->dd_dev.P;                     // in place (the stored P catches up with the filter)
     { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_downdate(h->dd_dev, h->dd_n_ub, h->stream); }
     if (h->dd_aug) { ProfScope ps(h, REKF_K_AUGMENT); rekf_launch_augment(h->dd_dev, h->dd_aug_args, h->stream); h->dd_aug = false; }
     HIP_TRY(h, hipGetLastError());
@@ -349,7 +342,9 @@ int refresh_mirror(rekf_t *h)
 {
     if (h->mir_valid) return REKF_OK;
     HIP_TRY(h, hipSetDevice(h->device));
-    { int rcf = flush_dd(h); if (rcf != REKF_OK) return rcf; }      // (its tile-(0,0) workgroup is the publisher being waited for)
+    // the held-back downdate goes out only if IT is the publisher being waited for (a caller that reads the pose after every scan gets it
+    // from k_mid: the downdate then stays pending across the read-back and runs beside the next scan's k_mid) or nothing publishes at all
+    if (h->dd_pending && (h->dd_dev.pub || !h->pub_valid)) { int rcf = flush_dd(h); if (rcf != REKF_OK) return rcf; }
     if (!h->pub_valid) {
         const int seq = new_publisher(h);
         rekf_launch_publish_pose(h->dev, h->host_slots_dev, seq, h->stream);
@@ -426,13 +421,13 @@ void mirror_lower(double *sg, int n)
 }
 
 struct DevBuffers {            // everything whose size depends on max_landmarks (rekf_create, rekf_reserve)
-    double *mu = nullptr, *mu_out = nullptr, *P = nullptr, *HPt = nullptr, *Kn = nullptr, *dev_pred = nullptr, *dev_mu_lin = nullptr,
+    double *mu = nullptr, *mu_out = nullptr, *P = nullptr, *P2 = nullptr, *HPt = nullptr, *Kn = nullptr, *dev_pred = nullptr, *dev_mu_lin = nullptr,
            *dev_ell = nullptr;
     int ld = 0, n_max = 0;
 };
 void free_buffers(DevBuffers &b)
 {
-    (void)hipFree(b.mu); (void)hipFree(b.mu_out); (void)hipFree(b.P); (void)hipFree(b.HPt); (void)hipFree(b.Kn);
+    (void)hipFree(b.mu); (void)hipFree(b.mu_out); (void)hipFree(b.P); (void)hipFree(b.P2); (void)hipFree(b.HPt); (void)hipFree(b.Kn);
     (void)hipFree(b.dev_pred); (void)hipFree(b.dev_mu_lin); (void)hipFree(b.dev_ell);
     b = DevBuffers();
 }
@@ -445,6 +440,7 @@ int alloc_buffers(rekf_t *h, int max_landmarks, DevBuffers &b)
     HIP_TRY(h, hipMalloc(&b.mu, sizeof(double) * ld));
     HIP_TRY(h, hipMalloc(&b.mu_out, sizeof(double) * ld));
     HIP_TRY(h, hipMalloc(&b.P, sizeof(double) * (size_t)ld * ld));
+    HIP_TRY(h, hipMalloc(&b.P2, sizeof(double) * (size_t)ld * ld));     // (the in-launch downdate's destination: 2 x 36 MB at C3 of 288 GB)
     HIP_TRY(h, hipMalloc(&b.HPt, sizeof(double) * 2 * (size_t)ld * REKF_PANEL_COLS));      // (both parities, struct rekf)
     HIP_TRY(h, hipMalloc(&b.Kn, sizeof(double) * 2 * (size_t)ld * REKF_PANEL_COLS));
     HIP_TRY(h, hipMalloc(&b.dev_pred, sizeof(double) * (4 * (size_t)ld + 16)));
@@ -453,16 +449,16 @@ int alloc_buffers(rekf_t *h, int max_landmarks, DevBuffers &b)
     HIP_TRY(h, hipMemsetAsync(b.mu, 0, sizeof(double) * ld, h->stream));
     HIP_TRY(h, hipMemsetAsync(b.mu_out, 0, sizeof(double) * ld, h->stream));
     HIP_TRY(h, hipMemsetAsync(b.P, 0, sizeof(double) * (size_t)ld * ld, h->stream));              // cc:10-11
+    HIP_TRY(h, hipMemsetAsync(b.P2, 0, sizeof(double) * (size_t)ld * ld, h->stream));             // (rows >= n stay zero in both: the tiles are read whole)
     HIP_TRY(h, hipMemsetAsync(b.HPt, 0, sizeof(double) * 2 * (size_t)ld * REKF_PANEL_COLS, h->stream));
     HIP_TRY(h, hipMemsetAsync(b.Kn, 0, sizeof(double) * 2 * (size_t)ld * REKF_PANEL_COLS, h->stream));
     return REKF_OK;
 }
 void adopt_buffers(rekf_t *h, const DevBuffers &b, int max_landmarks)
 {
-    h->dev.mu = b.mu; h->dev.mu_out = b.mu_out; h->dev.P = b.P; h->dev.HPt = b.HPt; h->dev.Kn = b.Kn;
+    h->dev.mu = b.mu; h->dev.mu_out = b.mu_out; h->dev.P = b.P; h->dev.P_out = b.P; h->P_alt = b.P2; h->dev.HPt = b.HPt; h->dev.Kn = b.Kn;
     h->panel_base[0] = b.HPt; h->panel_base[1] = b.Kn;
     h->panel_par = 0;
-    if (h->panel_base[2]) { h->dev.HPtB = h->panel_base[2]; h->dev.KnB = h->panel_base[3]; }
     h->dev_pred = b.dev_pred; h->dev_mu_lin = b.dev_mu_lin; h->dev_ell = b.dev_ell;
     h->dev.ld = b.ld; h->dev.n_max = b.n_max;
     h->dev.mu_lin = nullptr;
@@ -472,14 +468,13 @@ void adopt_buffers(rekf_t *h, const DevBuffers &b, int max_landmarks)
 void flip_panels(rekf_t *h)
 {
     h->panel_par ^= 1;
-    const size_t po = (size_t)h->panel_par * (size_t)h->dev.ld * REKF_PANEL_COLS, bo = (size_t)h->panel_par * REKF_STRIP_MAX * REKF_MR_PAD;
+    const size_t po = (size_t)h->panel_par * (size_t)h->dev.ld * REKF_PANEL_COLS;
     h->dev.HPt = h->panel_base[0] + po; h->dev.Kn = h->panel_base[1] + po;
-    h->dev.HPtB = h->panel_base[2] + bo; h->dev.KnB = h->panel_base[3] + bo;
 }
 DevBuffers current_buffers(const rekf_t *h)
 {
     DevBuffers b;
-    b.mu = h->dev.mu; b.mu_out = h->dev.mu_out; b.P = h->dev.P; b.HPt = h->panel_base[0]; b.Kn = h->panel_base[1];
+    b.mu = h->dev.mu; b.mu_out = h->dev.mu_out; b.P = h->dev.P; b.P2 = h->P_alt; b.HPt = h->panel_base[0]; b.Kn = h->panel_base[1];
     b.dev_pred = h->dev_pred; b.dev_mu_lin = h->dev_mu_lin; b.dev_ell = h->dev_ell; b.ld = h->dev.ld; b.n_max = h->dev.n_max;
     return b;
 }
@@ -516,7 +511,6 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
     h->opt = *opt;
     h->device = device;
     h->max_landmarks = max_landmarks;
-    h->activity_slot = activity_claim();
     h->time = opt->init_time;                         // cc:8
     h->vt[0] = h->vt[1] = h->vt[2] = 0.0;             // cc:6
     h->n_ub = 3;
@@ -524,8 +518,8 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
     { const char *e = std::getenv("REKF_LAZY_DD"); h->lazy_dd = !(e && e[0] == '0'); }
     { const char *e = std::getenv("REKF_AUG_IN_MID"); h->aug_in_mid = !(e && e[0] == '0'); }
     { const char *e = std::getenv("REKF_FRONT_IN_MID"); h->front_in_mid = !(e && e[0] == '0'); }
-    { const char *e = std::getenv("REKF_ONE_LAUNCH"); h->one_launch = e && e[0] == '1'; }
-    { const char *e = std::getenv("REKF_ONE_LAUNCH_NMAX"); if (e && std::atoi(e) > 0) h->one_nmax = std::atoi(e); }
+    { const char *e = std::getenv("REKF_SCAN_LAUNCH"); h->scan_launch = !(e && e[0] == '0'); }
+    { const char *e = std::getenv("REKF_EXCLUSIVE"); h->exclusive = e && e[0] == '1'; }
     h->prof_on = false;
     h->prof_mask = -1;
     h->prof_used = 0;
@@ -546,9 +540,8 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
         int rb = alloc_buffers(h, max_landmarks, b);
         if (rb != REKF_OK) { free_buffers(b); return rb; }
         adopt_buffers(h, b, max_landmarks);
-        HIP_TRY(h, hipMalloc(&h->panel_base[3], sizeof(double) * 2 * REKF_STRIP_MAX * REKF_MR_PAD));
-        HIP_TRY(h, hipMalloc(&h->panel_base[2], sizeof(double) * 2 * REKF_STRIP_MAX * REKF_MR_PAD));
-        h->dev.KnB = h->panel_base[3]; h->dev.HPtB = h->panel_base[2];
+        HIP_TRY(h, hipMalloc(&h->dev.cp, sizeof(double) * 2 * REKF_CP_LD * REKF_CP_LD));      // (write-ahead correction panels, RekfCtl::cp_*)
+        HIP_TRY(h, hipMemsetAsync(h->dev.cp, 0, sizeof(double) * 2 * REKF_CP_LD * REKF_CP_LD, h->stream));
         HIP_TRY(h, hipMalloc(&h->dev_obs, sizeof(float) * 2 * REKF_MAX_OBS_WIDE));
         HIP_TRY(h, hipHostMalloc(&h->obs_staging, sizeof(float) * 2 * REKF_MAX_OBS_WIDE));
         HIP_TRY(h, hipEventCreateWithFlags(&h->obs_staging_ev, hipEventDisableTiming));
@@ -561,8 +554,6 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
         HIP_TRY(h, hipHostMalloc(&h->ctl_staging, sizeof(RekfCtl)));
         h->dev.M_map = 0;
         HIP_TRY(h, hipMemsetAsync(h->dev.ctl, 0, sizeof(RekfCtl), h->stream));
-        HIP_TRY(h, hipMemsetAsync(h->dev.KnB, 0, sizeof(double) * 2 * REKF_STRIP_MAX * REKF_MR_PAD, h->stream));
-        HIP_TRY(h, hipMemsetAsync(h->dev.HPtB, 0, sizeof(double) * 2 * REKF_STRIP_MAX * REKF_MR_PAD, h->stream));
         std::memset(h->ctl_staging, 0, sizeof(RekfCtl));
         h->ctl_staging->n = 3;
         HIP_TRY(h, hipMemcpyAsync(h->dev.ctl, h->ctl_staging, sizeof(int) * 2, hipMemcpyHostToDevice, h->stream));
@@ -579,6 +570,8 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
     for (int q = 0; q < 3; ++q) h->mir_mu[q] = opt->init_pose[q];
     for (int q = 0; q < 9; ++q) h->mir_P[q] = 0.0;
     h->mir_valid = true;
+    g_live_handles.fetch_add(1, std::memory_order_seq_cst);
+    h->live_counted = true;
     *out = h;
     return REKF_OK;
 }
@@ -586,13 +579,13 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
 void rekf_destroy(rekf_t *h)
 {
     if (!h) return;
-    if (h->activity_slot >= 0) g_activity[h->activity_slot].store(0);
+    if (h->live_counted) g_live_handles.fetch_sub(1, std::memory_order_seq_cst);
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &s : h->prof_slots) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     DevBuffers b = current_buffers(h);
     free_buffers(b);
-    (void)hipFree(h->dev.ctl); (void)hipFree(h->panel_base[3]); (void)hipFree(h->panel_base[2]);
+    (void)hipFree(h->dev.ctl); (void)hipFree(h->dev.cp);
     (void)hipFree(h->dev.map_xy); (void)hipFree(h->dev.map_cov); (void)hipFree(h->dev_obs);
     if (h->obs_staging) (void)hipHostFree(h->obs_staging);
     if (h->obs_staging_ev) (void)hipEventDestroy(h->obs_staging_ev);
@@ -630,6 +623,13 @@ int rekf_reserve(rekf_t *h, int new_max_landmarks)
     free_buffers(old);
     h->full = false;
     h->n_ub = n; h->n_det = n; h->n_exact = true;
+    return REKF_OK;
+}
+
+int rekf_set_exclusive(rekf_t *h, int on)
+{
+    if (!h) return REKF_ERR_INVALID;
+    h->exclusive = on != 0;
     return REKF_OK;
 }
 
@@ -723,16 +723,19 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         HIP_TRY(h, hipEventRecord(h->obs_staging_ev, h->stream));
         h->obs_staging_busy = true;
     }
-    // the previous scan's downdate and this scan's front end go out as ONE launch (k_dd_front) when the caller has not read the pose
-    // since (a read-back enqueues the downdate: nothing is pending then; the mirror test is belt and braces); else it goes out first
-    const bool with_dd = h->dd_pending && !h->mir_valid;
+    // ONE LAUNCH PER SCAN (struct rekf): the held-back downdate runs beside this scan's k_mid, from the stored P into the other buffer, and
+    // the mid role corrects what it gathers -- for a filter that cannot grow, with n known, whole scans on this side
+    const bool fast = h->dd_pending && h->scan_launch && h->full && h->n_exact && !h->dd_aug && !blocks && !staged && K <= 32;
+    // else the previous scan's downdate and this scan's front end go out as ONE launch (k_dd_front) when the caller has not read the pose
+    // since; after a read-back (the scan is host-predicted) it goes out first
+    const bool with_dd = h->dd_pending && (fast || !h->mir_valid);
     if (!with_dd) {
         if (h->inject_failure == 2) { h->inject_failure = 0; h->hip_error = "injected failure (held-back downdate)"; return REKF_ERR_HIP; }
         int rcf = flush_dd(h);
         if (rcf != REKF_OK) return rcf;
     }
     // ---- from here on: host bookkeeping and launches only
-    const bool alone = alone_on_gpu(h->activity_slot);     // (in-launch hand-overs only then: see WHO ELSE IS AT WORK ON THE GPU)
+    const bool alone = in_grid_ok(h);                 // (in-launch hand-overs only on an exclusive, lone handle: struct rekf, EXCLUSIVE)
     h->last_scan_empty = false;
     RekfFrontArgs a;
     fill_front_args(h, a, t - h->time);               // cc:232 (dt may be negative, Q8)
@@ -757,12 +760,16 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     // (first) k_downdate2 apply it to what they read of P
     const int pred_slot = (int)(h->scan_count++ & 1);
     a.pred_slot = pred_slot; a.apply_pred = 1;
+    a.dd_par = pred_slot;                             // (RekfCtl::dd_queue: every k_mid zeroes the OTHER parity's counter for the next launch)
     // the front end counts matched observations (RekfCtl::front_count); the workgroup that reaches this scan's target compacts the
     // results into the record k_mid starts from (whole scans only: a wide scan goes through k_compact_wide)
     h->front_total += (unsigned)K;
     a.front_target = h->front_total;
     a.compact_in_front = blocks ? 0 : 1;
+    a.cp_write = blocks ? 0 : 1;                      // (whole scans leave their write-ahead correction: k_mid phase G)
     h->dev.pred_slot = -1;
+    h->dev.post_slot = pred_slot;                     // (RekfCtl::post_C9: k_mid writes the scan's slot, the scan's downdate stores it)
+    h->dev.P_out = h->dev.P;
     h->dev.kc_ub = round_up(2 * K + (gps_pose3 ? 3 : 0), 16);
     // one kernel of the call publishes pose, pose block, flags and the n the state will have once the k_augment behind the chain has run
     // (which changes none of the others): k_mid, or the first workgroup of the call's last downdate (struct rekf: WHO PUBLISHES)
@@ -770,17 +777,16 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     if (aug) h->cum_growth += 2 * K;
     const int pub_seq = new_publisher(h);
     a.scan_id = (unsigned)h->scan_count;
-    const int m_ub_scan = 2 * K + (gps_pose3 ? 3 : 0);
-    // small states: the whole scan as ONE launch (struct rekf); its downdate role is the held-back downdate, sent at the k_mid launch below
-    const bool one = with_dd && alone && h->one_launch && !blocks && !staged && m_ub_scan <= 32 && h->dd_dev.kc_ub <= 32 && h->n_ub <= h->one_nmax &&
-                     (!h->dd_aug || (h->aug_in_mid && h->dd_aug_inline_ok)) && rekf_one_launch_fits(h->dd_n_ub, h->n_ub, K);
-    if (one) {
-        h->dd_pending = false;
-        a.aug_in_mid = h->dd_aug ? 1 : 0;             // (the previous scan's new reflectors: appended by this launch's mid role, behind the downdate role)
-        h->dd_aug = false;
+    int front_wgs = 0;                                // (fast: the front end's workgroups inside the scan's launch)
+    if (fast) {
+        // the pending downdate stays pending until the k_mid launch below takes it along; the mid role sees it as a correction
+        a.corr = 1; a.corr_pred = h->dd_dev.pred_slot; a.corr_post = h->dd_dev.post_slot; a.corr_scan = h->dd_scan;
+        if (alone && h->front_in_mid) front_wgs = K;
+        else { ProfScope ps(h, REKF_K_FRONT); rekf_launch_front_mb(h->dev, a, h->n_ub, h->stream); }
     } else if (with_dd) {
         h->dd_pending = false;
         a.aug_pending = h->dd_aug ? 1 : 0;
+        h->dd_dev.P_out = h->dd_dev.P;                // (in place)
         { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_dd_front(h->dd_dev, h->dd_n_ub, h->dev, a, h->stream); }
         // the previous scan's augmentation: inside this scan's k_mid (its workgroup 0 appends the rows first thing -- no launch of its
         // own between the two scans; whole scans on both sides), else as k_augment right behind the downdate
@@ -812,7 +818,7 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         dd.pred_slot = first ? pred_slot : -1;        // the scan's first downdate commits its Predict
         if (last && !early_pub) { dd.pub = h->host_slots_dev; dd.pub_seq = pub_seq; dd.pub_aug = aug ? 1 : 0; }     // ... its last one publishes (at its start)
         flip_panels(h);                               // (dd has its own copy of the view: the next k_mid writes the other set)
-        if (last && hold_back) { h->dd_pending = true; h->dd_dev = dd; h->dd_n_ub = n_ub; return; }     // (lazy downdate: with the next call)
+        if (last && hold_back) { h->dd_pending = true; h->dd_dev = dd; h->dd_n_ub = n_ub; h->dd_scan = a.scan_id; return; }     // (lazy downdate: with the next call)
         ProfScope ps(h, REKF_K_DOWNDATE);
         rekf_launch_downdate(dd, n_ub, h->stream);
     };
@@ -848,20 +854,15 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
             RekfDev dm = h->dev;
             if (early_pub) { dm.pub = h->host_slots_dev; dm.pub_seq = pub_seq; }
             ProfScope ps(h, REKF_K_MID);
-            int roles = 0;
-            if (one) {
-                roles = rekf_launch_one(h->dd_dev, h->dd_n_ub, dm, a, n_ub, m_ub, aug || a.aug_in_mid != 0, h->dd_total, h->stream);
-                h->dd_total += (unsigned)roles;
-                if (roles == 0) {
-                    // (rekf_one_launch_fits said yes a moment ago: only a device switched under us gets here.)  The plain chain, nothing held
-                    // back: the previous scan's downdate and augmentation as launches of their own, then this scan's front end
-                    rekf_launch_downdate(h->dd_dev, h->dd_n_ub, h->stream);
-                    if (a.aug_in_mid) rekf_launch_augment(h->dd_dev, h->dd_aug_args, h->stream);
-                    a.aug_in_mid = 0;
-                    rekf_launch_front_mb(h->dev, a, n_ub, h->stream);
-                }
-            }
-            if (roles == 0) rekf_launch_mid(dm, a, n_ub, m_ub, aug || a.aug_in_mid != 0, h->stream);
+            if (fast) {
+                // [front end |] mid role | the held-back downdate, from the stored P into the other buffer -- which then IS the stored P
+                h->dd_pending = false;
+                RekfDev ddv = h->dd_dev;
+                ddv.P_out = h->P_alt;
+                (void)rekf_launch_scan(ddv, dm, a, n_ub, m_ub, front_wgs, h->stream);
+                std::swap(h->dev.P, h->P_alt);
+                h->dev.P_out = h->dev.P;
+            } else rekf_launch_mid(dm, a, n_ub, m_ub, aug || a.aug_in_mid != 0, h->stream);
         }
         std::swap(h->dev.mu, h->dev.mu_out);
         downdate(true, true);
@@ -894,7 +895,6 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
         (void)hipStreamSynchronize(h->stream);
         if (hipMemcpy(h->ctl_staging, h->dev.ctl, sizeof(RekfCtl), hipMemcpyDeviceToHost) == hipSuccess) {
             h->front_total = h->ctl_staging->front_count;
-            h->dd_total = h->ctl_staging->dd_done;
             h->n_ub = h->ctl_staging->n; h->n_det = h->n_ub; h->n_exact = true; h->full = h->n_ub >= h->dev.n_max;
         }
         (void)hipGetLastError();
@@ -1009,7 +1009,6 @@ int rekf_set_state(rekf_t *h, double t, int n, const double *mu, const double *s
     std::memset(h->ctl_staging, 0, sizeof(RekfCtl));
     h->ctl_staging->n = n;
     h->ctl_staging->front_count = h->front_total;                  // (the front end's count of matched observations goes on)
-    h->ctl_staging->dd_done = h->dd_total;                         // (... and so does the in-grid downdate roles')
     HIP_TRY(h, hipMemcpyAsync(h->dev.ctl, h->ctl_staging, sizeof(RekfCtl), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->time = t;
@@ -1207,7 +1206,7 @@ int rekf_debug_counters(rekf_t *h, long long out8[32])
     if (rc != REKF_OK) return rc;
     for (int i = 0; i < 32; ++i) out8[i] = h->ctl_staging->dbg[i];
 #ifndef REKF_DEBUG_TIMING
-    out8[24] = (long long)h->ctl_staging->dd_done;    // downdate workgroups that ran as roles inside k_mid's grid (REKF_ONE_LAUNCH=1), over the handle's life
+    out8[24] = (long long)h->ctl_staging->dd_queue[0] + (long long)h->ctl_staging->dd_queue[1];    // work items the in-launch downdate roles of the last two launches asked for
 #endif
     return REKF_OK;
 }

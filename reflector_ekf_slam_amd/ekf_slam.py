@@ -194,6 +194,11 @@ class ReflectorEKFSLAM:
         """Re-lay the device state out for at least ``max_landmarks`` reflectors (no-op if there is room already)."""
         self._chk(self._L.rekf_reserve(self._h, int(max_landmarks)), "reserve")
 
+    def set_exclusive(self, on: bool = True):
+        """The caller promises that this handle has the GPU to itself (include/rekf.h, rekf_set_exclusive): a scan's front end then runs
+        inside the scan's own launch.  Off by default; same results either way."""
+        self._chk(self._L.rekf_set_exclusive(self._h, 1 if on else 0), "set_exclusive")
+
     def set_auto_grow(self, on: bool = True):
         """Double the capacity whenever a scan could overflow it, instead of dropping reflectors (sticky capacity flag)."""
         self._chk(self._L.rekf_set_auto_grow(self._h, 1 if on else 0), "set_auto_grow")

@@ -179,45 +179,44 @@ def test_several_sessions_on_one_gpu_end_bit_identical_to_a_lone_one(readback):
         assert np.array_equal(st.mu, lone.mu) and np.array_equal(st.sigma, lone.sigma)
 
 
-@pytest.mark.parametrize("grow", [True, False], ids=["growing_filter", "full_filter"])
-def test_small_states_as_one_launch_per_scan_give_the_same_bits(oracle_lib, grow, monkeypatch):
-    """REKF_ONE_LAUNCH=1 (opt-in, read at rekf_create): for small states, scan after scan (nothing read back in between: the previous
-    scan's downdate is still held back), the downdate, the scan's front end and k_mid run as roles of ONE grid, the mid workgroups
-    waiting for the other two inside the launch (ask 5; measured equal to the two launches it replaces,
-    profiles/r04_chain_experiments.txt item 7).  Same arithmetic: the run must end on the bits of a handle that sent two launches per
-    scan -- new reflectors met on the way included (the previous scan's are appended by the mid role, behind the downdate role) -- and
-    on the oracle's state; and the form must really have been used."""
+@pytest.mark.parametrize("exclusive", [False, True], ids=["front_end_as_a_launch", "exclusive_front_end_in_the_grid"])
+@pytest.mark.parametrize("L,obs", [(100, 14), (160, 30)], ids=["n203_m28", "n323_m60"])
+def test_one_launch_per_scan_gives_the_two_launch_chains_bits(oracle_lib, L, obs, exclusive, monkeypatch):
+    """Round 5: on a filter that cannot grow the held-back downdate of scan t runs as a ROLE of scan t+1's k_mid launch (from the stored
+    P into the other P buffer, tiles from a queue) while that launch's mid role corrects what it gathers by the pending panels, in the
+    downdate's own arithmetic.  REKF_SCAN_LAUNCH=0 sends the round-4 chain instead (k_dd_front in place, then k_mid on the downdated
+    P).  Same bits -- scan after scan, with pose read-backs and full-state read-backs in between -- and the oracle's state; and the
+    in-launch form must really have been used (the tile queue counted)."""
     import ctypes as C
     from reflector_ekf_slam_amd import ReflectorEKFSLAM
     from reflector_ekf_slam_amd import session as S
-    cfg = synth.SessionConfig("r4_one_launch", 100, 14, synth.DIFF, seed=4420, speed=1.4, row_spacing=6.0)
+    cfg = synth.SessionConfig("r5_scan_launch", L, obs, synth.DIFF, seed=5500 + L, speed=1.4, row_spacing=6.0)
     sess = synth.make_session(cfg)
     lin, ang, ob2 = cfg.sigma_v ** 2, cfg.sigma_w ** 2, cfg.sigma_obs ** 2
-    scans = synth.steady_state_scans(sess, 240)
-    if grow:                                                # a reflector nobody has seen yet, every ninth scan
-        rng = np.random.default_rng(7)
-        scans = [(t, np.concatenate([ob, rng.uniform(-9.0, 9.0, (1, 2)).astype(np.float32)]) if k % 9 == 4 else ob) for k, (t, ob) in enumerate(scans)]
+    scans = synth.steady_state_scans(sess, 200)
 
-    def run(one):
-        if one: monkeypatch.setenv("REKF_ONE_LAUNCH", "1")
-        else: monkeypatch.delenv("REKF_ONE_LAUNCH", raising=False)
-        # (the growing filter is every wrapper's default one: capacity 8, doubling on the way.  The calls at which auto-grow waits for the
-        # exact n -- the next scan is then host-predicted, a last-place difference -- are fixed by the call sequence, rekf_api.hip n_det)
-        g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=8 if grow else cfg.n_landmarks, auto_grow=grow)
-        S.replay(sess, g)                                   # the map (odometry between the scans: host-predicted scans, two launches either way)
+    def run(scan_launch):
+        monkeypatch.setenv("REKF_SCAN_LAUNCH", "1" if scan_launch else "0")
+        g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks, auto_grow=False)
+        g.set_exclusive(exclusive)
+        S.replay(sess, g)                                   # the map; the filter is full afterwards
+        mids = []
         for k, (t, ob) in enumerate(scans):
             g.handle_observation(t, ob)
-            if k % 53 == 52: g.pose()                       # (a read-back now and then: the next scan is host-predicted again)
+            if k % 37 == 36: g.pose()                       # a pose read-back: the next scan is host-predicted, the downdate stays pending
+            if k % 61 == 60: mids.append(g.GetState())      # a full read-back: the pending downdate is applied in place first
         out = (C.c_longlong * 32)()
         assert g._L.rekf_debug_counters(g._h, out) == 0
         assert g.sync_code() == 0 and g.flags() == 0
-        return g.GetState(), int(out[24])
+        return g.GetState(), mids, int(out[24])
 
-    two, roles_two = run(False)
-    one, roles_one = run(True)
-    assert roles_two == 0 and roles_one > 200                   # (several downdate workgroups per scan that took the form)
-    assert one.mu.shape[0] > (3 + 2 * 100 if grow else 0)
+    two, mids_two, q_two = run(False)
+    one, mids_one, q_one = run(True)
+    assert q_two == 0 and q_one > 0
+    assert one.mu.shape[0] == 3 + 2 * L
     assert np.array_equal(one.mu, two.mu) and np.array_equal(one.sigma, two.sigma)
+    for a, b in zip(mids_one, mids_two):
+        assert np.array_equal(a.mu, b.mu) and np.array_equal(a.sigma, b.sigma)
     o = make_oracle(cfg.odom_model, sess.init_time, sess.init_pose, lin, ang, ob2)
     S.replay(sess, o)
     for t, ob in scans:
