@@ -69,7 +69,14 @@ struct RekfCtl {
         int uid[32];                  // the distinct matched landmarks in ascending order (uid[urank] = landmark id)
         int nu, pad_[3];              // how many: the sub-block k_mid gathers has 3 + 2 nu rows, in ascending global order
         int newid[64];                // observation indices of the new reflectors
-    } rec;
+    } rec[2];                         // (by scan parity: the SPECULATIVE front end of scan t + 1 runs inside scan t's launch, beside the mid role that reads scan t's)
+    // SPECULATIVE MATCH (round 5): scan t + 1's ReflectorMatch runs inside scan t's launch, against the mean and pose scan t STARTS from (the
+    // update it would have to wait for moves them by millimetres).  Per observation it leaves the result, the distance to the nearest
+    // reflector and to the runner-up; scan t + 1's k_mid accepts the record when every decision is PROVABLY the one the exact match would
+    // take -- |d1 - gate| and d2 - d1 against a bound of how far the update moved the pose and the reflectors -- and re-matches the
+    // observations that do not pass
+    struct Spec { int kind[32], idx[32]; double d1[32], d2[32]; double pose[3]; int n; unsigned scan; } spec[2];
+    unsigned long long dmmax[2];      // bits of max |mu_new - mu_old| over the landmark rows of a scan's update (by scan parity; the next k_mid zeroes the other)
     unsigned front_count;             // observations matched so far, over the life of the handle (never reset)
     // ---- a scan's landmark augmentation deferred into the NEXT scan's k_mid (round 4): while the state can grow, every scan used to
     // be followed by a k_augment launch that found nothing to do (2.4 us of kernel boundary per scan).  k_mid's workgroup 0 leaves what
@@ -127,6 +134,9 @@ struct RekfFrontArgs {
     int corr_post;
     unsigned corr_scan;       // ... and that scan's id (its write-ahead correction, RekfCtl::cp_scan, must carry it)
     int cp_write;             // k_mid: leave this scan's write-ahead correction (whole scans)
+    int spec;                 // k_mid: the scan's match record is SPECULATIVE (RekfCtl::spec[pred_slot]): prove it or re-match; Predict is evaluated here
+    int spec_front;           // k_mid: that many workgroups behind the mid role are the NEXT scan's speculative front end (its launch packet: An)
+    double prev_dt, prev_vt[3];   // front role as speculation for scan t + 1 inside scan t's launch: scan t's own motion comes first
     int aug_in_mid;           // k_mid: the previous scan's augmentation has not run: workgroup 0 appends its rows first (RekfCtl::augrec), n = n_before + 2 n2
     unsigned scan_id;         // running number of the scan (RekfCtl::aug_done)
     int apply_pred;           // k_mid: apply the pending Predict to the gathered P (whole scan or FIRST block step of a wide scan)
@@ -277,7 +287,7 @@ void rekf_launch_compact_wide(const RekfDev &d, const RekfFrontArgs &a, hipStrea
 void rekf_launch_mid(const RekfDev &d, RekfFrontArgs &a, int n_ub, int m_ub, bool mode_grow, hipStream_t s);   // mode_grow: the filter can still grow, or the previous scan's augmentation rides in this launch
 void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s);
 void rekf_launch_dd_front(const RekfDev &d, int n_ub, const RekfDev &dn, const RekfFrontArgs &an, hipStream_t s);
-int rekf_launch_scan(const RekfDev &dd, const RekfDev &d, RekfFrontArgs &a, int n_ub, int m_ub, int front_wgs, hipStream_t s);   // ONE launch per scan: [front end |] mid role (corrects what it gathers by dd's pending panels) | dd's downdate from dd.P into dd.P_out
+int rekf_launch_scan(const RekfDev &dd, const RekfDev &d, RekfFrontArgs &a, int n_ub, int m_ub, int front_wgs, const RekfFrontArgs *an, hipStream_t s);   // ONE launch per scan: [front end |] mid role (corrects what it gathers by dd's pending panels) | dd's downdate from dd.P into dd.P_out
 void rekf_launch_augment(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);
 void rekf_launch_ellipses(const RekfDev &d, double *out5, int cap, hipStream_t s);
 void rekf_launch_publish_pose(const RekfDev &d, RekfHostSlot *hout, int seq, hipStream_t s);

@@ -265,7 +265,10 @@ __device__ static inline void compact_record(RekfCtl::Rec *rec, RekfCtl *ctl, in
 // k_dd_front runs it in the workgroups behind its downdate workgroups.  corner_in_ctl: the pose block to predict from is
 // RekfCtl::post_C9 (what k_mid evaluated for the previous scan) -- in k_dd_front the previous scan's downdate, which stores that block
 // into P, is running beside this role; in k_front_mb it is read from P (set_state, reserve, a flushed host predict may have changed it).
-template <int NT>
+// SPEC: the role runs for scan t + 1 inside scan t's launch (RekfCtl::spec): pose = the OLD mean moved by scan t's odometry (A.prev_*) and
+// then its own; nothing of Predict is written (scan t + 1's k_mid evaluates its own); per observation the result AND the distances to the
+// nearest reflector and the runner-up go to RekfCtl::spec[A.pred_slot], the compacted record to RekfCtl::rec[A.pred_slot].
+template <int NT, bool SPEC = false>
 __device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs &A, const int b, const int nb, const bool corner_in_ctl)
 {
     static_assert(NT >= 256 && NT % 256 == 0, "four waves match, lane 0 of wave 1 evaluates the motion model");
@@ -297,7 +300,8 @@ __device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs
     const int K = A.K;
     // inside k_mid's grid with the motion model evaluated here (one launch per scan): what the mid role reads of this role's Predict goes
     // THROUGH to memory and is complete before this workgroup counts its observation (the mid role's wait for the count orders the rest)
-    const bool wt_pred = A.front_in_mid != 0 && !A.host_pred;
+    const bool wt_pred = !SPEC && A.front_in_mid != 0 && !A.host_pred;
+    RekfCtl::Spec *const sp = &ctl->spec[A.pred_slot & 1];
 
     // operands that depend only on the old state go in flight first -- and this workgroup's first observation: a dynamically
     // indexed kernel argument is a scalar load of its own, issued where it is used (inside the match, it cost a memory round trip)
@@ -318,7 +322,26 @@ __device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs
         for (int q = 0; q < 1024 / NT; ++q) { s_lmx[tid + NT * q] = lmx[q]; s_lmy[tid + NT * q] = lmy[q]; }
     }
     double C9[9];
-    if (A.host_pred) {
+    if (SPEC) {
+        // two motion steps from the old pose: scan t's (A.prev_dt, A.prev_vt), then this scan's
+        if (tid == 0) {
+#pragma clang fp contract(off)
+            const double th = mu[2] + A.prev_vt[2] * A.prev_dt + A.vt[2] * A.dt;
+            double sn, cs;
+            sincos(th, &sn, &cs);
+            pose[2] = th; pose[3] = cs; pose[4] = sn;
+        }
+        if (tid == 64) {
+#pragma clang fp contract(off)
+            RekfFrontArgs Ap = A;
+            Ap.dt = A.prev_dt; Ap.vt[0] = A.prev_vt[0]; Ap.vt[1] = A.prev_vt[1]; Ap.vt[2] = A.prev_vt[2];
+            Motion m1;
+            motion_terms(Ap, mu[2], m1);
+            const double x1 = mu[0] + m1.d[0], y1 = mu[1] + m1.d[1], th1 = mu[2] + m1.d[2];
+            motion_terms(A, th1, mo);
+            pose[0] = x1 + mo.d[0]; pose[1] = y1 + mo.d[1];
+        }
+    } else if (A.host_pred) {
         // the host predicted (its pose mirror was current: rekf_api.hip): pose, cos / sin of the WRAPPED heading exactly as the
         // reference takes them (cc:181, :252-253), the composite (a, b) of every predict since the device last saw P and the
         // pose block come by value -- no motion model, no libm call in front of the match
@@ -357,7 +380,9 @@ __device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs
     // k_mid and k_downdate2 apply them to what they read of P (RekfCtl::pred), and the scan's downdate commits them
     {
 #pragma clang fp contract(off)
-        if (b == 0 && tid == 0) {
+        if (SPEC) {
+            if (b == 0 && tid == 0) { sp->pose[0] = pose[0]; sp->pose[1] = pose[1]; sp->pose[2] = pose[2]; sp->n = n; sp->scan = A.scan_id; }
+        } else if (b == 0 && tid == 0) {
             if (A.host_pred) {
 #pragma unroll
                 for (int q = 0; q < 9; ++q) C9[q] = A.pre_C9[q];
@@ -376,7 +401,7 @@ __device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs
             }
             if (!A.front_in_mid) ctl->pose_pending = 1;       // (inside k_mid's grid nobody reads it, and that kernel's workgroup 0 clears it beside us)
         }
-        if (!A.host_pred && b == 0 && tid == NT - 64) {        // the wrapped heading (cc:181 / :205), on the last wave
+        if (!SPEC && !A.host_pred && b == 0 && tid == NT - 64) {        // the wrapped heading (cc:181 / :205), on the last wave
             const double thw = atan2(pose[4], pose[3]);
             if (wt_pred) {
                 store_wt(&ctl->pose_pred[2], thw);
@@ -450,13 +475,16 @@ __device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs
         __syncthreads();        // (the buffer of round it is written again in round it + 2: the barrier of round it + 1 lies between)
         FMARK();                                      // m2: barrier passed
         if (mwave == 0) {
+            double d1v = 1e300, d2v = 1e300;                           // SPEC: distance to the nearest reflector and to the runner-up
             if (kind == 2 && L > 0) {
 #pragma clang fp contract(off)
                 double g1 = s_part[it & 1][0][0], g2 = s_part[it & 1][0][1]; int gj = s_partj[it & 1][0];
 #pragma unroll
                 for (int w = 1; w < 4; ++w) argmin2_combine(g1, gj, g2, s_part[it & 1][w][0], s_partj[it & 1][w], s_part[it & 1][w][1]);
                 double best = sqrt(g1);
+                d1v = best; d2v = (g2 < 1e299) ? sqrt(g2) : 1e300;
                 if (g2 <= g1 * 1.000000000000002) {                    // literal scan (uniform, rare)
+                    d2v = d1v;                                         // (two candidates within rounding: nothing a margin could prove)
                     best = 0; gj = -1;
                     for (int j = mlane; j < L; j += 64) {
                         const float lx = (float)mu[3 + 2 * j], ly = (float)mu[4 + 2 * j];
@@ -472,8 +500,14 @@ __device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs
             if (mlane == 0) {
                 // the result, coherently at agent scope (another workgroup -- on another XCD, behind another L2 -- may be the one that
                 // compacts), then the count: whoever sees it reach the scan's target has every result in memory behind it
-                __hip_atomic_store(&ctl->obs_kind[i], kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&ctl->obs_idx[i], best_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (SPEC) {
+                    __hip_atomic_store(&sp->kind[i & 31], kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&sp->idx[i & 31], best_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    store_wt(&sp->d1[i & 31], d1v); store_wt(&sp->d2[i & 31], d2v);
+                } else {
+                    __hip_atomic_store(&ctl->obs_kind[i], kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&ctl->obs_idx[i], best_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (A.front_in_mid) (void)__hip_atomic_fetch_add(&ctl->front_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (nobody to elect: no returning round trip)
                 else {
@@ -489,9 +523,10 @@ __device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs
     __syncthreads();
     if (A.compact_in_front && !A.front_in_mid && s_last && tid < 64) {
         const int lane = tid;
-        const int kind = (lane < K) ? __hip_atomic_load(&ctl->obs_kind[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
-        const int oidx = (lane < K) ? __hip_atomic_load(&ctl->obs_idx[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
-        compact_record(&ctl->rec, ctl, kind, oidx, lane, K, n, d.n_max, A.has_gps);
+        const int *kp = SPEC ? &sp->kind[lane & 31] : &ctl->obs_kind[lane], *ip = SPEC ? &sp->idx[lane & 31] : &ctl->obs_idx[lane];
+        const int kind = (lane < K) ? __hip_atomic_load(kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+        const int oidx = (lane < K) ? __hip_atomic_load(ip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+        compact_record(&ctl->rec[A.pred_slot & 1], ctl, kind, oidx, lane, K, n, d.n_max, A.has_gps);
     }
 #ifdef REKF_DEBUG_FRONT
     if (recf) {
@@ -852,6 +887,64 @@ __device__ static inline void augment_rows(const RekfDev &d, int n, int N2, doub
     }
     __syncthreads();
 }
+// ReflectorMatch's state branch (cc:426-451) for ONE observation, by a whole workgroup of >= 256 threads (waves 0..3 sweep the landmarks,
+// every thread must call; two workgroup barriers): the exact re-match of an observation whose speculative result k_mid could not prove
+// (RekfCtl::spec).  Same arithmetic as front_role's sweep -- smallest and second smallest squared distance, the literal scan on a tie.
+__device__ static inline void rematch_obs(const double *mu, int L, float gx, float gy, int &kind, int &best_j)
+{
+    __shared__ double s_rp[4][2];
+    __shared__ int s_rj[4], s_rk[2];
+    const int tid = threadIdx.x, mwave = tid >> 6, mlane = tid & 63;
+    if (mwave < 4) {
+#pragma clang fp contract(off)
+        double b1 = 1e300, b2 = 1e300; int bj = -1;
+        for (int j0 = 0; j0 < L; j0 += 256) {
+            const int j = j0 + 64 * mwave + mlane, jc = j < L ? j : L - 1;
+            const float lx = (float)mu[3 + 2 * jc], ly = (float)mu[4 + 2 * jc];        // cc:431
+            const float ex = gx - lx, ey = gy - ly;                                   // cc:433
+            const double dx = (double)ex, dy = (double)ey;
+            const double d2 = (j < L) ? dx * dx + dy * dy : 1e300;
+            b2 = vmin_f64(b2, vmax_f64(d2, b1));
+            bj = (d2 < b1) ? j : bj;
+            b1 = vmin_f64(b1, d2);
+        }
+        double g1 = b1, g2 = b2; int gj = bj;
+        argmin2_dpp_step<0x111, 0xf>(g1, gj, g2);
+        argmin2_dpp_step<0x112, 0xf>(g1, gj, g2);
+        argmin2_dpp_step<0x114, 0xf>(g1, gj, g2);
+        argmin2_dpp_step<0x118, 0xf>(g1, gj, g2);
+        argmin2_dpp_step<0x142, 0xa>(g1, gj, g2);
+        argmin2_dpp_step<0x143, 0xc>(g1, gj, g2);
+        if (mlane == 63) { s_rp[mwave][0] = g1; s_rp[mwave][1] = g2; s_rj[mwave] = gj; }
+    }
+    __syncthreads();
+    if (mwave == 0) {
+#pragma clang fp contract(off)
+        int kd = 2, bjj = -1;
+        if (L > 0) {
+            double g1 = s_rp[0][0], g2 = s_rp[0][1]; int gj = s_rj[0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) argmin2_combine(g1, gj, g2, s_rp[w][0], s_rj[w], s_rp[w][1]);
+            double best = sqrt(g1);
+            if (g2 <= g1 * 1.000000000000002) {                    // literal scan (uniform, rare)
+                best = 0; gj = -1;
+                for (int j = mlane; j < L; j += 64) {
+                    const float lx = (float)mu[3 + 2 * j], ly = (float)mu[4 + 2 * j];
+                    const float ex = gx - lx, ey = gy - ly;
+                    const double dx = (double)ex, dy = (double)ey;
+                    const double dist = sqrt(dx * dx + dy * dy);   // cc:437
+                    if (gj < 0 || dist < best) { best = dist; gj = j; }
+                }
+                wave_argmin(best, gj);
+            }
+            if (gj >= 0 && best < 0.6) { kd = 1; bjj = gj; }      // cc:446
+        }
+        if (mlane == 0) { s_rk[0] = kd; s_rk[1] = bjj; }
+    }
+    __syncthreads();
+    kind = s_rk[0]; best_j = s_rk[1];
+}
+
 // ----------------------------------------------------------------------------
 // k_mid<NBR, MODE>: gather + solve + gain in ONE launch, for at most 16 NBR innovation rows per pass (NBR = 2: up to 16
 // matched observations, NBR = 4: up to 32 -- every BASELINE.json configuration; scans with more run several passes,
@@ -905,6 +998,8 @@ template <int NBR> struct MidLds {
     int s_pcol[NPAIR];                            // pair -> its landmark's first sub-block row (3 + 2 urank), or -1 (map pair)
     int s_upair[NPAIR];                           // distinct landmark (by rank) -> a state pair that observes it
     int s_ownsub[MID_ROWS];                       // own row -> its sub-block row, or -1
+    double s_pose[5];                             // a speculative scan's Predict is evaluated here: x, y, wrapped theta, cos, sin
+    int s_fk[32], s_fi[32];                       // ... and the exact results of the observations whose speculative match could not be proved
     double s_np[3];                               // the committed pose, for the new reflectors' means
     double s_pred[12];                            // this scan's Predict: ab[0], ab[1], C9[0..8]
     double s_cpred[12];                           // the PENDING scan's (a, b) [0..1] and its pose block after the update [2..10]
@@ -921,7 +1016,7 @@ constexpr int REKF_DD_LDS_BYTES = 4 * 64 * 64 * (int)sizeof(double);      // the
 // front end (MODE 2: exclusive handles only, rekf_api.hip).
 template <int KC, bool QUEUE> __device__ __forceinline__ void dd_body(const RekfDev &d, double *dd_smem, int wg, int nwg, unsigned *queue, bool pub_wg);
 template <int NBR, int MODE>
-__global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, RekfFrontArgs A, RekfDev dp)
+__global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, RekfFrontArgs A, RekfDev dp, RekfFrontArgs An)
 {
     constexpr bool FRONT = (MODE & 2) != 0, AUGR = (MODE & 1) != 0, AUGW = MODE >= 1, DDROLE = MODE != 1;
     // ctl_first = d.ctl, as a leading pointer argument of its own: built with -mllvm -amdgpu-kernarg-preload-count the wave starts with it
@@ -933,7 +1028,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     auto &s_col = L.u.w.s_col; auto &s_leaf = L.u.w.s_leaf; auto &s_coef = L.s_coef; auto &s_wc0 = L.u.w.s_wc0; auto &s_wcp = L.u.w.s_wcp;
     auto &s_wown = L.u.w.s_wown; auto &s_pw = L.s_pw; auto &s_dmu = L.u.w.s_dmu; auto &s_rec = L.s_rec; auto &s_pcol = L.s_pcol;
     auto &s_np = L.s_np; auto &s_dc = L.u.w.s_dc; auto &s_pred = L.s_pred; auto &s_cpred = L.s_cpred; auto &s_stage = L.u.s_stage;
-    auto &s_upair = L.s_upair; auto &s_ownsub = L.s_ownsub;
+    auto &s_upair = L.s_upair; auto &s_ownsub = L.s_ownsub; auto &s_pose = L.s_pose; auto &s_fk = L.s_fk; auto &s_fi = L.s_fi;
     double (*s_kown)[MID_ROWS] = (double (*)[MID_ROWS])&L.u.w.s_col[0][0][0];      // phase F / G: -K of the own rows, [k][row] (the inverse's patches are dead by then)
     static_assert(sizeof(L.u.w.s_col) >= sizeof(double) * MP * MID_ROWS, "s_kown fits the inverse's patches");
     int *const s_pair_obs = s_rec.pair_obs, *const s_pair_id = s_rec.pair_id, *const s_pair_state = s_rec.pair_state,
@@ -990,11 +1085,23 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
         return;
     }
     const int bx = bxf - (FRONT ? A.front_in_mid : 0);          // this workgroup's number among the mid workgroups
+    if constexpr (DDROLE && !FRONT) {
+        if (A.spec_front > 0 && bx >= A.n_mid && bx < A.n_mid + A.spec_front) {
+            // the NEXT scan's front end, speculatively (RekfCtl::spec): against the mean this launch's mid role starts from; nobody in
+            // this launch waits for it.  Then it helps the downdate role.
+            front_role<512, true>(d, An, bx - A.n_mid, A.spec_front, false);
+            if (A.dd_in_mid && threadIdx.x < 256) {
+                __builtin_amdgcn_s_barrier();
+                dd_body<64, true>(dp, k_mid_arena, -1, A.dd_in_mid, &ctl->dd_queue[A.dd_par & 1], false);
+            }
+            return;
+        }
+    }
     if (bx >= A.n_mid) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool steam = wave < 4;                  // S team; the other is the "own" team
     const int tt = tid & 255;                     // thread index within the team
-    if (bx == 0 && tid == 511) ctl->dd_queue[(A.dd_par ^ 1) & 1] = 0u;     // the next launch's tile queue starts empty
+    if (bx == 0 && tid == 511) { ctl->dd_queue[(A.dd_par ^ 1) & 1] = 0u; ctl->dmmax[(A.dd_par ^ 1) & 1] = 0ull; }     // the next launch's tile queue (and mean-shift bound) start empty
     if (FRONT) {
         // every observation's result is in memory once the front end's count has reached the scan's target (each front workgroup
         // writes its result through, drains, then counts): wave 0 polls on one lane, takes the K results past this CU's L1 and
@@ -1023,7 +1130,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     // scalar one, so the control block costs one memory round trip, not two
     constexpr int NREC = (int)(sizeof(RekfCtl::Rec) / sizeof(int));
     static_assert(NREC <= 512, "one load per thread");
-    const int rec_raw = (!FRONT && tid < NREC) ? ((const int *)&ctl->rec)[tid] : 0;
+    const int rec_raw = (!FRONT && tid < NREC) ? ((const int *)&ctl->rec[A.pred_slot & 1])[tid] : 0;
     // ... and the pending scan's WRITE-AHEAD CORRECTION (RekfCtl::cp_*, RekfDev::cp; phase G below): which landmarks it covers
     int cp_uid_l = -1, cp_nu_l = -1;
     unsigned cp_scan_l = 0u;
@@ -1082,15 +1189,51 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
         if constexpr (FRONT) return __longlong_as_double(__hip_atomic_load((const long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         else return *p;
     };
-    const double pose[5] = {hp ? A.pre_pose[0] : ctl_f64(&ctl->pose_pred[0]), hp ? A.pre_pose[1] : ctl_f64(&ctl->pose_pred[1]), hp ? A.pre_pose[2] : ctl_f64(&ctl->pose_pred[2]),
-                            hp ? A.pre_pose[3] : ctl_f64(&ctl->pose_pred[3]), hp ? A.pre_pose[4] : ctl_f64(&ctl->pose_pred[4])};
-    const bool pending = FRONT ? true : ctl->pose_pending != 0;      // (the in-grid front role sets it beside us: a host-predicted scan always has one)
+    const bool spec = DDROLE && !FRONT && A.spec != 0;            // the record is speculative (RekfCtl::spec): no front end has run for this scan
+    double pose[5] = {hp ? A.pre_pose[0] : ctl_f64(&ctl->pose_pred[0]), hp ? A.pre_pose[1] : ctl_f64(&ctl->pose_pred[1]), hp ? A.pre_pose[2] : ctl_f64(&ctl->pose_pred[2]),
+                      hp ? A.pre_pose[3] : ctl_f64(&ctl->pose_pred[3]), hp ? A.pre_pose[4] : ctl_f64(&ctl->pose_pred[4])};
+    const bool pending = (FRONT || spec) ? true : ctl->pose_pending != 0;      // (the in-grid front role sets it beside us: a host-predicted scan always has one)
     const bool first = bx == 0;
+    // a speculative scan: its per-observation results with their margins (lane = observation), and Predict (cc:154-206) evaluated HERE --
+    // the front end's own source (front_role, device-predicted path), by every workgroup for itself: cos / sin of the new heading and the
+    // wrapped heading on one lane, the motion terms and the predicted pose block on lane 0 of the next wave; workgroup 0 leaves (a, b) and
+    // the block in RekfCtl::pred for the scan's downdate
+    int sp_kind = -1, sp_idx = -1;
+    double sp_d1 = 0.0, sp_d2 = 0.0;
+    if (spec) {
+        const RekfCtl::Spec *sq = &ctl->spec[A.pred_slot & 1];
+        if (lane < A.K) { sp_kind = sq->kind[lane & 31]; sp_idx = sq->idx[lane & 31]; sp_d1 = sq->d1[lane & 31]; sp_d2 = sq->d2[lane & 31]; }
+        if (tid == 256) {
+#pragma clang fp contract(off)
+            const double th = d.mu[2] + A.vt[2] * A.dt;
+            double sn, cs;
+            sincos(th, &sn, &cs);
+            s_pose[3] = cs; s_pose[4] = sn;
+            s_pose[2] = atan2(sn, cs);                     // the wrapped heading (cc:181 / :205)
+        }
+        if (tid == 320) {
+#pragma clang fp contract(off)
+            Motion mo;
+            const double mu0 = d.mu[0], mu1 = d.mu[1], mu2 = d.mu[2];
+            double C9[9];
+            for (int q = 0; q < 9; ++q) C9[q] = A.corr ? ctl->post_C9[A.corr_post & 1][q] : rekf_plower(P, (int)ld, q % 3, q / 3);
+            motion_terms(A, mu2, mo);
+            s_pose[0] = mu0 + mo.d[0]; s_pose[1] = mu1 + mo.d[1];
+            corner_predict(C9, 3, mo);
+            s_pred[0] = mo.a; s_pred[1] = mo.b;
+            for (int q = 0; q < 9; ++q) s_pred[2 + q] = C9[q];
+            if (first) {
+                RekfCtl::Pred *pr = &ctl->pred[A.pred_slot & 1];
+                pr->ab[0] = mo.a; pr->ab[1] = mo.b;
+                for (int q = 0; q < 9; ++q) pr->C9[q] = C9[q];
+            }
+        }
+    }
     // the scan's pending Predict (RekfCtl::pred): applied to the gathered P in phase D.  (a, b) = 0 and the pose block as gathered
     // when nothing is pending (later block steps of a wide scan: the first step's downdate has committed it)
     // (through LDS, not registers: eleven uniform doubles held from here to phase D cost this 512-thread kernel its residency)
     const bool do_pred = A.apply_pred != 0;
-    if (do_pred && tid >= 64 && tid < 64 + 11) {                                   // ab[0], ab[1], C9[0..8]
+    if (do_pred && !spec && tid >= 64 && tid < 64 + 11) {                          // ab[0], ab[1], C9[0..8]
         // (with the front role in this grid the control block's copy is being written beside us: a host-predicted scan carries the values)
         const int e = tid - 64;
         s_pred[e] = (FRONT && hp) ? (e < 2 ? A.pre_ab[e] : A.pre_C9[e - 2]) : ctl_f64(&((const double *)&ctl->pred[A.pred_slot & 1])[e]);
@@ -1148,6 +1291,55 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
 #endif
     __syncthreads();
     MMARK();                                        // 0: compaction done
+    if (spec) {
+        // ---- the speculative record, proved or repaired.  The front role matched this scan against the pose (sq->pose) and the means
+        // scan t - 1's launch STARTED from; since then that scan's update has moved the pose (by what s_pose - sq->pose says: both are
+        // known) and every reflector mean by at most dmmax.  An observation's distance to ANY reflector has therefore changed by at most
+        //     delta = |dxy| + range * |dtheta| + sqrt(2) dmmax + (float32 roundings of the two evaluations),
+        // and its decision stands if it has that much room: matched (d1 < 0.6): d1 + delta < 0.6 and d2 - d1 > 2 delta (the nearest stays
+        // the nearest, first-index ties cannot arise); unmatched: d1 - delta > 0.6.  Every wave decides for itself from the same numbers.
+        const RekfCtl::Spec *sq = &ctl->spec[A.pred_slot & 1];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) pose[q] = s_pose[q];
+        bool okv = true;
+        {
+#pragma clang fp contract(off)
+            const double dxp = pose[0] - sq->pose[0], dyp = pose[1] - sq->pose[1];
+            double dth = pose[2] - sq->pose[2];
+            dth = dth - 6.283185307179586 * rint(dth / 6.283185307179586);
+            const double dmm = __longlong_as_double((long long)ctl->dmmax[(A.pred_slot ^ 1) & 1]);
+            if (lane < A.K) {
+                const double px = (double)rekf_obs(A, 2 * lane), py = (double)rekf_obs(A, 2 * lane + 1);
+                const double rng = sqrt(px * px + py * py);
+                const double delta = sqrt(dxp * dxp + dyp * dyp) + rng * fabs(dth) + 1.5 * dmm
+                                   + 3e-7 * (fabs(pose[0]) + fabs(pose[1]) + rng + 1.0);
+                if (sp_kind == 1) okv = (sp_d1 + delta < 0.6) && (sp_d2 - sp_d1 > 2.0 * delta);
+                else if (sp_kind == 2) okv = sp_d1 - delta > 0.6;
+                else okv = false;
+                if (!(delta == delta)) okv = false;
+            }
+        }
+        const bool rec_ok = sq->scan == A.scan_id && sq->n == n;
+        unsigned long long bad = __ballot(!okv);
+        if (!rec_ok) bad = (A.K >= 64) ? ~0ull : ((1ull << A.K) - 1ull);
+        if (first && tid == 0) { ctl->dbg[20] += 1; if (bad) ctl->dbg[21] += 1; }      // (speculative scans / those with observations re-matched)
+        if (bad) {
+            // (rare) the exact match of the observations that did not pass, one at a time by the whole workgroup; then the record again
+            if (tid < 32) { s_fk[tid] = sp_kind; s_fi[tid] = sp_idx; }
+            for (int i = 0; i < A.K && i < 32; ++i) {
+                if ((bad >> i) & 1ull) {
+                    float gx, gy;
+                    obs_to_global(pose[0], pose[1], pose[3], pose[4], rekf_obs(A, 2 * i), rekf_obs(A, 2 * i + 1), gx, gy);
+                    int kd, bj;
+                    rematch_obs(d.mu, (n - 3) / 2, gx, gy, kd, bj);
+                    if (tid == 0) { s_fk[i] = kd; s_fi[i] = bj; }
+                }
+            }
+            __syncthreads();
+            if (tid < 64) compact_record(&s_rec, ctl, (tid < A.K && tid < 32) ? s_fk[tid] : -1, (tid < A.K && tid < 32) ? s_fi[tid] : -1, tid, A.K, n, d.n_max, A.has_gps);
+            __syncthreads();
+        }
+    }
     const int MM = s_cnt[0], m = s_cnt[1], m_pad = s_cnt[2], NS = s_cnt[3];
     const bool gps_rows = s_cnt[4] != 0;
     // the pending scan's write-ahead correction serves this scan when it covers exactly this scan's landmarks
@@ -1875,6 +2067,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     MMARK();                                        // 7: K stored
     if (tid < MID_ROWS) {
         const int i = i0 + tid;
+        double adm = 0.0;                               // |mu_new - mu_old| of a landmark row (the next scan's speculation bound, RekfCtl::dmmax)
         if (i < n) {
             double dm = 0.0;
 #pragma unroll
@@ -1884,8 +2077,14 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
             double v = base + dm;
             if (i == 2) v = atan2(sin(v), cos(v));                               // cc:307
             d.mu_out[i] = v;
+            if (i >= 3) adm = fabs(dm);
             if (i == 0) ctl->pose_pending = 0;
             if (first && i < 3) s_np[i] = v;
+        }
+        if (DDROLE) {
+            adm = vmax_f64(adm, __shfl_xor(adm, 1, 64)); adm = vmax_f64(adm, __shfl_xor(adm, 2, 64));
+            adm = vmax_f64(adm, __shfl_xor(adm, 4, 64)); adm = vmax_f64(adm, __shfl_xor(adm, 8, 64));
+            if (tid == 0 && adm > 0.0) atomicMax(&ctl->dmmax[A.pred_slot & 1], (unsigned long long)__double_as_longlong(adm));
         }
     }
     if (first) {
@@ -2597,7 +2796,7 @@ static int dd_cache_slot(int &dev)            // (call with g_dd_cache.mu held)
     return slot;
 }
 // k_mid<NBR, MODE> with `bytes` of dynamic LDS (all of its LDS is one arena: MidLds, and the downdate role's panels over it)
-template <int NBR, int MODE> static void launch_mid_as(int grid, int with_dd, hipStream_t s, const RekfDev &d, const RekfFrontArgs &a, const RekfDev &dp)
+template <int NBR, int MODE> static void launch_mid_as(int grid, int with_dd, hipStream_t s, const RekfDev &d, const RekfFrontArgs &a, const RekfDev &dp, const RekfFrontArgs &an)
 {
     constexpr int MID_BYTES = (int)sizeof(MidLds<NBR>);
     constexpr int BYTES = (MODE != 1 && MID_BYTES < REKF_DD_LDS_BYTES) ? REKF_DD_LDS_BYTES : MID_BYTES;     // (one size per kernel: the opt-in is per function)
@@ -2613,29 +2812,29 @@ template <int NBR, int MODE> static void launch_mid_as(int grid, int with_dd, hi
             g_dd_cache.attr_mid[slot] |= bit;
         }
     }
-    hipLaunchKernelGGL((k_mid<NBR, MODE>), dim3(grid), dim3(512), BYTES, s, d.ctl, d, a, dp);
+    hipLaunchKernelGGL((k_mid<NBR, MODE>), dim3(grid), dim3(512), BYTES, s, d.ctl, d, a, dp, an);
 }
 void rekf_launch_mid(const RekfDev &d, RekfFrontArgs &a, int n_ub, int m_ub, bool mode_grow, hipStream_t s)
 {
     // m_ub <= 64 (the host checks): one workgroup per 16 state rows
     a.n_mid = (n_ub + MID_ROWS - 1) / MID_ROWS;
-    a.dd_in_mid = 0; a.dd_first = 0;
+    a.dd_in_mid = 0; a.dd_first = 0; a.spec_front = 0;
     const int grid = a.n_mid + (a.front_in_mid > 0 ? a.front_in_mid : 0);
     const int mode = (a.front_in_mid > 0) ? 2 : (mode_grow ? 1 : 0);
     if (m_ub <= 32) {
-        if (mode == 0) launch_mid_as<2, 0>(grid, 0, s, d, a, d);          // (the last argument: the downdate role's view, one launch per scan only)
-        else if (mode == 1) launch_mid_as<2, 1>(grid, 0, s, d, a, d);
-        else launch_mid_as<2, 2>(grid, 0, s, d, a, d);
+        if (mode == 0) launch_mid_as<2, 0>(grid, 0, s, d, a, d, a);          // (the last argument: the downdate role's view, one launch per scan only)
+        else if (mode == 1) launch_mid_as<2, 1>(grid, 0, s, d, a, d, a);
+        else launch_mid_as<2, 2>(grid, 0, s, d, a, d, a);
     } else {
-        if (mode == 0) launch_mid_as<4, 0>(grid, 0, s, d, a, d);
-        else if (mode == 1) launch_mid_as<4, 1>(grid, 0, s, d, a, d);
-        else launch_mid_as<4, 2>(grid, 0, s, d, a, d);
+        if (mode == 0) launch_mid_as<4, 0>(grid, 0, s, d, a, d, a);
+        else if (mode == 1) launch_mid_as<4, 1>(grid, 0, s, d, a, d, a);
+        else launch_mid_as<4, 2>(grid, 0, s, d, a, d, a);
     }
 }
 // ONE launch per scan (round 5): [the scan's front end, front_wgs workgroups (0: it ran before this launch) | its mid role, which takes the
 // pending downdate dd as a correction of what it gathers | dd itself, from dd.P into dd.P_out, on the CUs the others leave free, tiles from
 // RekfCtl::dd_queue].  The caller has set a.corr / corr_pred / corr_post / dd_par.  Returns the launch's grid.
-int rekf_launch_scan(const RekfDev &dd, const RekfDev &d, RekfFrontArgs &a, int n_ub, int m_ub, int front_wgs, hipStream_t s)
+int rekf_launch_scan(const RekfDev &dd, const RekfDev &d, RekfFrontArgs &a, int n_ub, int m_ub, int front_wgs, const RekfFrontArgs *an, hipStream_t s)
 {
     int n_cu;
     {
@@ -2645,7 +2844,8 @@ int rekf_launch_scan(const RekfDev &dd, const RekfDev &d, RekfFrontArgs &a, int 
     }
     a.n_mid = (n_ub + MID_ROWS - 1) / MID_ROWS;
     a.front_in_mid = front_wgs;
-    a.dd_first = (front_wgs + a.n_mid + 7) & ~7;          // (the queue does not care; a multiple of 8 keeps block number mod 8 = XCD for everybody)
+    a.spec_front = (an && front_wgs == 0) ? an->K : 0;    // the NEXT scan's speculative front end: workgroups behind the mid role's
+    a.dd_first = (front_wgs + a.n_mid + a.spec_front + 7) & ~7;          // (the queue does not care; a multiple of 8 keeps block number mod 8 = XCD for everybody)
     const int n_dd = (dd.n_known >= 0) ? dd.n_known : dd.n_max;
     const int T = (n_dd + DT - 1) / DT, nB = (T - 1) * (T - 2) / 2, items = T + (nB + 2) / 3;
     int wgs = n_cu - a.dd_first;                          // one workgroup per CU (the arena), everybody resident from the start
@@ -2655,9 +2855,9 @@ int rekf_launch_scan(const RekfDev &dd, const RekfDev &d, RekfFrontArgs &a, int 
     const int grid = a.dd_first + wgs;
     const int mode = front_wgs > 0 ? 2 : 0;
     if (m_ub <= 32) {
-        if (mode == 0) launch_mid_as<2, 0>(grid, 1, s, d, a, dd); else launch_mid_as<2, 2>(grid, 1, s, d, a, dd);
+        if (mode == 0) launch_mid_as<2, 0>(grid, 1, s, d, a, dd, an ? *an : a); else launch_mid_as<2, 2>(grid, 1, s, d, a, dd, a);
     } else {
-        if (mode == 0) launch_mid_as<4, 0>(grid, 1, s, d, a, dd); else launch_mid_as<4, 2>(grid, 1, s, d, a, dd);
+        if (mode == 0) launch_mid_as<4, 0>(grid, 1, s, d, a, dd, an ? *an : a); else launch_mid_as<4, 2>(grid, 1, s, d, a, dd, a);
     }
     return grid;
 }

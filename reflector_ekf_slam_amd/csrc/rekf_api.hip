@@ -102,6 +102,21 @@ struct rekf {
     bool exclusive = false;
     bool live_counted = false;      // this handle is in g_live_handles
     bool lazy_dd = true;            // REKF_LAZY_DD=0 in the environment turns it off (A/B measurements)
+    // SPECULATIVE MATCH (round 5; REKF_SPEC=0 turns it off).  What a scan's update waits for -- Predict's pose and ReflectorMatch against the
+    // mean the PREVIOUS update left -- cannot start before that update has ended; run one scan EARLY it can: scan t + 1's front end as a
+    // role of scan t's launch, against the mean that launch starts from, with the margins that let scan t + 1's k_mid prove (or repair)
+    // every decision (RekfCtl::spec).  That needs scan t + 1's observations when scan t is launched: a caller that enqueues scan after
+    // scan (no read-back in between) has its newest scan HELD on the host until the next call brings the one after it; every other
+    // call (getters, odometry, sync) sends the held scan first.  Same results, bit for bit, as the exact front end.
+    bool spec_enable = true;
+    bool held = false;              // a scan waits on the host: ...
+    double held_t = 0;
+    int held_K = 0;
+    bool held_gps = false;
+    double held_gps3[3] = {0, 0, 0};
+    float held_xy[2 * 32];
+    bool spec_ready = false;        // the last launch ran the speculative front end of scan spec_scan
+    unsigned spec_scan = 0;
     // WHO PUBLISHES pose, pose block, n and flags of a scan.  A caller that reads the pose back after its scans (the reference's node,
     // src/ros_node.cc:514-515) gets them from k_mid's workgroup 0 -- a kernel earlier: GetPose does not wait for the downdate -- which
     // costs that kernel 0.8 us (it ends when the PCIe writes are through); a caller that enqueues scan after scan gets them from the
@@ -483,6 +498,10 @@ DevBuffers current_buffers(const rekf_t *h)
 
 extern "C" {
 
+struct NextScan;
+static int flush_held(rekf_t *h);
+#define FLUSH_HELD(h) do { if ((h)->held) { int rch_ = flush_held(h); if (rch_ != REKF_OK) return rch_; } } while (0)
+
 int rekf_abi_version(void) { return REKF_ABI_VERSION; }
 
 const char *rekf_strerror(int code)
@@ -520,6 +539,7 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
     { const char *e = std::getenv("REKF_FRONT_IN_MID"); h->front_in_mid = !(e && e[0] == '0'); }
     { const char *e = std::getenv("REKF_SCAN_LAUNCH"); h->scan_launch = !(e && e[0] == '0'); }
     { const char *e = std::getenv("REKF_EXCLUSIVE"); h->exclusive = e && e[0] == '1'; }
+    { const char *e = std::getenv("REKF_SPEC"); h->spec_enable = !(e && e[0] == '0'); }
     h->prof_on = false;
     h->prof_mask = -1;
     h->prof_used = 0;
@@ -579,6 +599,7 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
 void rekf_destroy(rekf_t *h)
 {
     if (!h) return;
+    h->held = false;
     if (h->live_counted) g_live_handles.fetch_sub(1, std::memory_order_seq_cst);
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -599,6 +620,7 @@ int rekf_reserve(rekf_t *h, int new_max_landmarks)
 {
     if (!h || new_max_landmarks < 1) return REKF_ERR_INVALID;
     if (new_max_landmarks <= h->max_landmarks) return REKF_OK;
+    FLUSH_HELD(h);
     HIP_TRY(h, hipSetDevice(h->device));
     int rc = flush_lazy(h);
     if (rc != REKF_OK) return rc;
@@ -650,6 +672,7 @@ int rekf_get_capacity(rekf_t *h, int *max_landmarks)
 int rekf_set_map(rekf_t *h, const float *xy, const double *cov, int M)
 {
     if (!h || M < 0 || (M > 0 && (!xy || !cov))) return REKF_ERR_INVALID;
+    FLUSH_HELD(h);
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     (void)hipFree(h->dev.map_xy); (void)hipFree(h->dev.map_cov);
@@ -666,6 +689,7 @@ int rekf_set_map(rekf_t *h, const float *xy, const double *cov, int M)
 int rekf_handle_odometry(rekf_t *h, double t, double vx, double vy, double wz)
 {
     if (!h) return REKF_ERR_INVALID;
+    FLUSH_HELD(h);
     if (t < h->time) return REKF_OK;                  // drop old data, cc:211-212
     if (h->opt.use_imu) return REKF_OK;               // cc:213-223: the use_imu branch is empty -- nothing happens
     // Predict(dt) on the host's pose mirror: no launch.  If the pose of the last scan has not been read back yet this waits for the
@@ -681,10 +705,40 @@ int rekf_handle_odometry(rekf_t *h, double t, double vx, double vy, double wz)
     return REKF_OK;
 }
 
+// the scan a held scan's launch speculates for (struct rekf: SPECULATIVE MATCH)
+struct NextScan { double t; const float *xy; int K; bool gps; };
+static int process_scan(rekf_t *h, double t, const float *xy, int K, const double *gps_pose3, const NextScan *next);
+// the held scan goes out (without a successor to speculate for)
+static int flush_held(rekf_t *h)
+{
+    if (!h->held) return REKF_OK;
+    h->held = false;
+    return process_scan(h, h->held_t, h->held_xy, h->held_K, h->held_gps ? h->held_gps3 : nullptr, nullptr);
+}
+
 int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const double *gps_pose3)
 {
     if (!h || K < 0 || (K > 0 && !xy)) return REKF_ERR_INVALID;
     if (K > REKF_MAX_OBS) return REKF_ERR_TOO_MANY_OBS;
+    // a scan that can take part in the speculation pipeline: a whole scan on a filter that cannot grow, no pre-loaded map (its branch of the
+    // match has no margin proof), handed over without a pose read-back since the last scan
+    const bool holdable = h->spec_enable && h->scan_launch && h->lazy_dd && h->full && K >= 1 && K <= 32 && h->dev.M_map == 0 &&
+                          !h->mir_valid && !h->prof_on;
+    if (h->held) {
+        if (!holdable) { FLUSH_HELD(h); return process_scan(h, t, xy, K, gps_pose3, nullptr); }
+        const NextScan nx = {t, xy, K, gps_pose3 != nullptr};
+        h->held = false;
+        const int rc = process_scan(h, h->held_t, h->held_xy, h->held_K, h->held_gps ? h->held_gps3 : nullptr, &nx);
+        if (rc != REKF_OK) { (void)process_scan(h, t, xy, K, gps_pose3, nullptr); return rc; }      // (the held scan's error is reported; this one still goes out)
+    } else if (!holdable || !h->dd_pending) return process_scan(h, t, xy, K, gps_pose3, nullptr);
+    h->held = true; h->held_t = t; h->held_K = K; h->held_gps = gps_pose3 != nullptr;
+    if (gps_pose3) { h->held_gps3[0] = gps_pose3[0]; h->held_gps3[1] = gps_pose3[1]; h->held_gps3[2] = gps_pose3[2]; }
+    std::memcpy(h->held_xy, xy, sizeof(float) * 2 * (size_t)K);
+    return REKF_OK;
+}
+
+static int process_scan(rekf_t *h, double t, const float *xy, int K, const double *gps_pose3, const NextScan *next)
+{
     const bool staged = K > REKF_MAX_OBS_DEV;                       // too many observations for the launch packet
     const bool blocks = 2 * K + (gps_pose3 ? 3 : 0) > 64;           // more innovation rows than one pass of k_mid takes
     HIP_TRY(h, hipSetDevice(h->device));
@@ -763,8 +817,12 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     a.dd_par = pred_slot;                             // (RekfCtl::dd_queue: every k_mid zeroes the OTHER parity's counter for the next launch)
     // the front end counts matched observations (RekfCtl::front_count); the workgroup that reaches this scan's target compacts the
     // results into the record k_mid starts from (whole scans only: a wide scan goes through k_compact_wide)
-    h->front_total += (unsigned)K;
+    // SPECULATIVE MATCH (struct rekf): the previous launch has run this scan's front end -- no front end now; k_mid proves the record
+    const bool use_spec = fast && h->spec_ready && h->spec_scan == (unsigned)h->scan_count && !a.host_pred;
+    h->spec_ready = false;
+    if (!use_spec) h->front_total += (unsigned)K;    // (the front end counts the observations it matches; the speculative one has counted these)
     a.front_target = h->front_total;
+    a.spec = use_spec ? 1 : 0;
     a.compact_in_front = blocks ? 0 : 1;
     a.cp_write = blocks ? 0 : 1;                      // (whole scans leave their write-ahead correction: k_mid phase G)
     h->dev.pred_slot = -1;
@@ -781,7 +839,8 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
     if (fast) {
         // the pending downdate stays pending until the k_mid launch below takes it along; the mid role sees it as a correction
         a.corr = 1; a.corr_pred = h->dd_dev.pred_slot; a.corr_post = h->dd_dev.post_slot; a.corr_scan = h->dd_scan;
-        if (alone && h->front_in_mid) front_wgs = K;
+        if (use_spec) { /* nothing: the record is there */ }
+        else if (alone && h->front_in_mid && !next) front_wgs = K;
         else { ProfScope ps(h, REKF_K_FRONT); rekf_launch_front_mb(h->dev, a, h->n_ub, h->stream); }
     } else if (with_dd) {
         h->dd_pending = false;
@@ -859,7 +918,22 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
                 h->dd_pending = false;
                 RekfDev ddv = h->dd_dev;
                 ddv.P_out = h->P_alt;
-                (void)rekf_launch_scan(ddv, dm, a, n_ub, m_ub, front_wgs, h->stream);
+                // ... and, for a caller that enqueues scan after scan, the NEXT scan's front end, speculatively (struct rekf)
+                RekfFrontArgs an;
+                const bool with_next = next && front_wgs == 0 && h->spec_enable;
+                if (with_next) {
+                    fill_front_args(h, an, next->t - t);
+                    an.is_obs = 1; an.K = next->K;
+                    std::memcpy(an.obs, next->xy, sizeof(float) * 2 * (size_t)next->K);
+                    an.has_gps = next->gps ? 1 : 0;
+                    an.pred_slot = pred_slot ^ 1; an.scan_id = a.scan_id + 1u;
+                    an.compact_in_front = 1;
+                    an.prev_dt = a.dt; an.prev_vt[0] = a.vt[0]; an.prev_vt[1] = a.vt[1]; an.prev_vt[2] = a.vt[2];
+                    h->front_total += (unsigned)next->K;
+                    an.front_target = h->front_total;
+                    h->spec_ready = true; h->spec_scan = an.scan_id;
+                }
+                (void)rekf_launch_scan(ddv, dm, a, n_ub, m_ub, front_wgs, with_next ? &an : nullptr, h->stream);
                 std::swap(h->dev.P, h->P_alt);
                 h->dev.P_out = h->dev.P;
             } else rekf_launch_mid(dm, a, n_ub, m_ub, aug || a.aug_in_mid != 0, h->stream);
@@ -907,6 +981,7 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
 int rekf_predict_state(rekf_t *h, double t, double mu3[3], double sigma3x3[9])
 {
     if (!h || !mu3) return REKF_ERR_INVALID;
+    FLUSH_HELD(h);
     int rc = refresh_mirror(h);
     if (rc != REKF_OK) return rc;
     RekfFrontArgs a;
@@ -923,6 +998,7 @@ int rekf_predict_state(rekf_t *h, double t, double mu3[3], double sigma3x3[9])
 int rekf_get_time(rekf_t *h, double *t)
 {
     if (!h || !t) return REKF_ERR_INVALID;
+    FLUSH_HELD(h);
     *t = h->time;
     return REKF_OK;
 }
@@ -930,6 +1006,7 @@ int rekf_get_time(rekf_t *h, double *t)
 int rekf_get_pose(rekf_t *h, double *t, double mu3[3], double sigma3x3[9])
 {
     if (!h) return REKF_ERR_INVALID;
+    FLUSH_HELD(h);
     // the kernels of the last call have published (or are about to publish) the pose they committed; between scans the mirror
     // simply is the pose -- either way no copy engine and no stream wait
     int rc = refresh_mirror(h);
@@ -943,6 +1020,7 @@ int rekf_get_pose(rekf_t *h, double *t, double mu3[3], double sigma3x3[9])
 int rekf_get_marker_ellipses(rekf_t *h, double *out5, int cap, int *count)
 {
     if (!h || !count || cap < 0 || (cap > 0 && !out5)) return REKF_ERR_INVALID;
+    FLUSH_HELD(h);
     HIP_TRY(h, hipSetDevice(h->device));
     { int rcf = flush_dd(h); if (rcf != REKF_OK) return rcf; }
     const int lim = cap < h->max_landmarks ? cap : h->max_landmarks;
@@ -959,6 +1037,7 @@ int rekf_get_marker_ellipses(rekf_t *h, double *out5, int cap, int *count)
 int rekf_get_n(rekf_t *h, int *n)
 {
     if (!h || !n) return REKF_ERR_INVALID;
+    FLUSH_HELD(h);
     int rc = refresh_mirror(h);                        // n arrives with the pose slots
     if (rc != REKF_OK) return rc;
     if (!h->n_exact) { rc = pull_ctl(h); if (rc != REKF_OK) return rc; }
@@ -969,6 +1048,7 @@ int rekf_get_n(rekf_t *h, int *n)
 int rekf_get_state(rekf_t *h, double *t, int *n_out, double *mu, long mu_cap, double *sigma, long sigma_cap)
 {
     if (!h) return REKF_ERR_INVALID;
+    FLUSH_HELD(h);
     int rc = flush_lazy(h);
     if (rc != REKF_OK) return rc;
     rc = pull_ctl(h);
@@ -993,6 +1073,8 @@ int rekf_get_state(rekf_t *h, double *t, int *n_out, double *mu, long mu_cap, do
 int rekf_set_state(rekf_t *h, double t, int n, const double *mu, const double *sigma, const double *vt3)
 {
     if (!h || !mu || !sigma || n < 3 || n > h->dev.n_max || ((n - 3) & 1)) return REKF_ERR_INVALID;
+    if (h->held) (void)flush_held(h);
+    h->spec_ready = false;
     h->pub_valid = false;
     for (auto &r : h->pub_ring) r = {0, 0};                       // an n published before this call says nothing about the new state
     h->lazy_pending = false; h->lazy_a = 0; h->lazy_b = 0;       // whatever was pending belonged to the state being replaced
@@ -1029,6 +1111,7 @@ int rekf_get_last_match(rekf_t *h, int *n_state, int *state_pairs, int *n_map, i
                         int *new_ids)
 {
     if (!h) return REKF_ERR_INVALID;
+    FLUSH_HELD(h);
     int rc = pull_ctl(h);
     if (rc != REKF_OK) return rc;
     if (h->last_scan_empty) {                          // cc:235-236: the record of an empty scan is empty (kept on the host)
@@ -1050,6 +1133,7 @@ int rekf_get_last_match(rekf_t *h, int *n_state, int *state_pairs, int *n_map, i
 int rekf_sync(rekf_t *h)
 {
     if (!h) return REKF_ERR_INVALID;
+    FLUSH_HELD(h);
     int rc = refresh_mirror(h);
     if (rc != REKF_OK) return rc;
     rc = flush_lazy(h);                                // predicts the host applied to its mirror only: the device state catches up (one small kernel, only when pending)
@@ -1068,6 +1152,7 @@ int rekf_sync(rekf_t *h)
 int rekf_get_flags(rekf_t *h, int *flags)
 {
     if (!h || !flags) return REKF_ERR_INVALID;
+    FLUSH_HELD(h);
     int rc = refresh_mirror(h);
     if (rc != REKF_OK) return rc;
     *flags = h->flags_last;
@@ -1078,6 +1163,7 @@ int rekf_predict_state_full(rekf_t *h, double t, double *time_out, int *n_out, d
                             long sigma_cap)
 {
     if (!h) return REKF_ERR_INVALID;
+    FLUSH_HELD(h);
     int rc = refresh_mirror(h);
     if (rc != REKF_OK) return rc;
     rc = flush_lazy(h);
@@ -1122,6 +1208,7 @@ int rekf_predict_state_full(rekf_t *h, double t, double *time_out, int *n_out, d
 int rekf_profile_enable(rekf_t *h, int on)
 {
     if (!h) return REKF_ERR_INVALID;
+    FLUSH_HELD(h);
     if (!on) { int rc = prof_flush(h); if (rc != REKF_OK) return rc; }
     h->prof_on = on != 0;
     h->prof_mask = on;
@@ -1131,6 +1218,7 @@ int rekf_profile_enable(rekf_t *h, int on)
 int rekf_profile_read(rekf_t *h, int k, double *total_us, long *count)
 {
     if (!h || k < 0 || k >= REKF_K_COUNT) return REKF_ERR_INVALID;
+    FLUSH_HELD(h);
     int rc = prof_flush(h);
     if (rc != REKF_OK) return rc;
     if (total_us) *total_us = h->prof_total_us[k];
@@ -1141,6 +1229,7 @@ int rekf_profile_read(rekf_t *h, int k, double *total_us, long *count)
 int rekf_profile_reset(rekf_t *h)
 {
     if (!h) return REKF_ERR_INVALID;
+    FLUSH_HELD(h);
     int rc = prof_flush(h);
     if (rc != REKF_OK) return rc;
     for (int k = 0; k < REKF_K_COUNT; ++k) { h->prof_total_us[k] = 0; h->prof_count[k] = 0; }
@@ -1151,6 +1240,7 @@ int rekf_profile_reset(rekf_t *h)
 int rekf_profile_samples(rekf_t *h, float *out_us, long cap, long *count)
 {
     if (!h || !count || cap < 0 || (cap > 0 && !out_us)) return REKF_ERR_INVALID;
+    FLUSH_HELD(h);
     int rc = prof_flush(h);
     if (rc != REKF_OK) return rc;
     const long have = (long)h->prof_update_us.size();
@@ -1169,6 +1259,7 @@ void *rekf_stream(rekf_t *h) { return h ? (void *)h->stream : nullptr; }
 int rekf_debug_time_kernel(rekf_t *h, int kernel, int reps, int ablate, double *avg_us)
 {
     if (!h || !avg_us || reps < 1) return REKF_ERR_INVALID;
+    FLUSH_HELD(h);
     if (kernel != REKF_K_DOWNDATE || ablate != 0) return REKF_ERR_INVALID;      // the only kernel this hook knows; `ablate` is reserved
     int rc = flush_lazy(h);
     if (rc != REKF_OK) return rc;
@@ -1202,6 +1293,7 @@ int rekf_debug_time_kernel(rekf_t *h, int kernel, int reps, int ablate, double *
 int rekf_debug_counters(rekf_t *h, long long out8[32])
 {
     if (!h || !out8) return REKF_ERR_INVALID;
+    FLUSH_HELD(h);
     int rc = pull_ctl(h);
     if (rc != REKF_OK) return rc;
     for (int i = 0; i < 32; ++i) out8[i] = h->ctl_staging->dbg[i];
@@ -1221,6 +1313,7 @@ int rekf_debug_inject_failure(rekf_t *h, int stage)
 int rekf_device_layout(rekf_t *h, int *ld, int *n_max, void **P_dev, void **mu_dev)
 {
     if (!h) return REKF_ERR_INVALID;
+    FLUSH_HELD(h);
     // the caller is about to look at P / mu: the held-back downdate AND the predicts the host has applied to its mirror only go out
     { int rcf = flush_lazy(h); if (rcf != REKF_OK) return rcf; }
     if (ld) *ld = h->dev.ld;

@@ -24,5 +24,5 @@ for fast, excl in CFGS:
     dt = time.perf_counter() - t0
     import ctypes as C
     out = (C.c_longlong * 32)(); g._L.rekf_debug_counters(g._h, out)
-    print(f"scan_launch={fast} exclusive={excl}: {dt / 2000 * 1e6:.2f} us/update  ({2000 / dt:.0f} updates/s) flags={g.flags()}  corrected scans {out[22]}, of which computed in k_mid {out[23]}")
+    print(f"scan_launch={fast} exclusive={excl}: {dt / 2000 * 1e6:.2f} us/update  ({2000 / dt:.0f} updates/s) flags={g.flags()}  corrected scans {out[22]}, of which computed in k_mid {out[23]}; speculative records {out[20]}, with re-matched observations {out[21]}")
     g.close()
