@@ -44,6 +44,7 @@ struct RekfCtl {
     int new_ids[REKF_MAX_OBS_WIDE];
     // ---- hand-off between the multi-workgroup front kernel and k_gather / k_gain ----
     double pose_pred[5];          // x, y, theta, cos(theta), sin(theta) after Predict (mu[0..2] is committed by k_mid)
+    double pose_next[2][5];       // ... of a SPECULATIVE scan (by scan parity): evaluated by workgroup 0 of the PREVIOUS scan's k_mid, at its end
     int pose_pending;
     int obs_kind[REKF_MAX_OBS_WIDE];  // per observation: 0 map match, 1 state match, 2 new
     int obs_idx[REKF_MAX_OBS_WIDE];
@@ -204,14 +205,18 @@ struct Motion {
     double V[9];
 };
 
+__host__ __device__ static inline void motion_terms_of(int model, double dt, double vx, double vy, double w, double lin_cov, double ang_cov, double theta, Motion &mo);
 __host__ __device__ static inline void motion_terms(const RekfFrontArgs &A, double theta, Motion &mo)
 {
+    motion_terms_of(A.model, A.dt, A.vt[0], A.vt[1], A.vt[2], A.lin_cov, A.ang_cov, theta, mo);
+}
+__host__ __device__ static inline void motion_terms_of(int model, double dt, double vx, double vy, double w, double lin_cov, double ang_cov, double theta, Motion &mo)
+{
 #pragma clang fp contract(off)
-    const double vx = A.vt[0], vy = A.vt[1], w = A.vt[2], dt = A.dt;
     double Gu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     double Qu[3];
     int q;
-    if (A.model == 0) {                                   // DIFF  cc:156-183
+    if (model == 0) {                                     // DIFF  cc:156-183
         const double delta_theta = w * dt;
         const double half = theta + delta_theta / 2;
         double sh, ch;
@@ -225,7 +230,7 @@ __host__ __device__ static inline void motion_terms(const RekfFrontArgs &A, doub
         Gu[0] = dt * ch; Gu[1] = -vx * dt * dt * sh / 2;
         Gu[3] = dt * sh; Gu[4] = vx * dt * dt * ch / 2;
         Gu[6] = 0;       Gu[7] = dt;
-        Qu[0] = A.lin_cov; Qu[1] = A.ang_cov; Qu[2] = 0;
+        Qu[0] = lin_cov; Qu[1] = ang_cov; Qu[2] = 0;
     } else {                                              // OMNI  cc:184-205
         const double delta_theta = w * dt;
         double st, ct;
@@ -239,7 +244,7 @@ __host__ __device__ static inline void motion_terms(const RekfFrontArgs &A, doub
         Gu[0] = dt * ct; Gu[1] = -dt * st; Gu[2] = 0.;
         Gu[3] = dt * st; Gu[4] = dt * ct;  Gu[5] = 0.;
         Gu[6] = 0.;      Gu[7] = 0.;       Gu[8] = dt;
-        Qu[0] = A.lin_cov; Qu[1] = A.lin_cov; Qu[2] = A.ang_cov;
+        Qu[0] = lin_cov; Qu[1] = lin_cov; Qu[2] = ang_cov;
     }
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) {

@@ -333,10 +333,8 @@ __device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs
         }
         if (tid == 64) {
 #pragma clang fp contract(off)
-            RekfFrontArgs Ap = A;
-            Ap.dt = A.prev_dt; Ap.vt[0] = A.prev_vt[0]; Ap.vt[1] = A.prev_vt[1]; Ap.vt[2] = A.prev_vt[2];
             Motion m1;
-            motion_terms(Ap, mu[2], m1);
+            motion_terms_of(A.model, A.prev_dt, A.prev_vt[0], A.prev_vt[1], A.prev_vt[2], A.lin_cov, A.ang_cov, mu[2], m1);
             const double x1 = mu[0] + m1.d[0], y1 = mu[1] + m1.d[1], th1 = mu[2] + m1.d[2];
             motion_terms(A, th1, mo);
             pose[0] = x1 + mo.d[0]; pose[1] = y1 + mo.d[1];
@@ -998,7 +996,6 @@ template <int NBR> struct MidLds {
     int s_pcol[NPAIR];                            // pair -> its landmark's first sub-block row (3 + 2 urank), or -1 (map pair)
     int s_upair[NPAIR];                           // distinct landmark (by rank) -> a state pair that observes it
     int s_ownsub[MID_ROWS];                       // own row -> its sub-block row, or -1
-    double s_pose[5];                             // a speculative scan's Predict is evaluated here: x, y, wrapped theta, cos, sin
     int s_fk[32], s_fi[32];                       // ... and the exact results of the observations whose speculative match could not be proved
     double s_np[3];                               // the committed pose, for the new reflectors' means
     double s_pred[12];                            // this scan's Predict: ab[0], ab[1], C9[0..8]
@@ -1028,7 +1025,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     auto &s_col = L.u.w.s_col; auto &s_leaf = L.u.w.s_leaf; auto &s_coef = L.s_coef; auto &s_wc0 = L.u.w.s_wc0; auto &s_wcp = L.u.w.s_wcp;
     auto &s_wown = L.u.w.s_wown; auto &s_pw = L.s_pw; auto &s_dmu = L.u.w.s_dmu; auto &s_rec = L.s_rec; auto &s_pcol = L.s_pcol;
     auto &s_np = L.s_np; auto &s_dc = L.u.w.s_dc; auto &s_pred = L.s_pred; auto &s_cpred = L.s_cpred; auto &s_stage = L.u.s_stage;
-    auto &s_upair = L.s_upair; auto &s_ownsub = L.s_ownsub; auto &s_pose = L.s_pose; auto &s_fk = L.s_fk; auto &s_fi = L.s_fi;
+    auto &s_upair = L.s_upair; auto &s_ownsub = L.s_ownsub; auto &s_fk = L.s_fk; auto &s_fi = L.s_fi;
     double (*s_kown)[MID_ROWS] = (double (*)[MID_ROWS])&L.u.w.s_col[0][0][0];      // phase F / G: -K of the own rows, [k][row] (the inverse's patches are dead by then)
     static_assert(sizeof(L.u.w.s_col) >= sizeof(double) * MP * MID_ROWS, "s_kown fits the inverse's patches");
     int *const s_pair_obs = s_rec.pair_obs, *const s_pair_id = s_rec.pair_id, *const s_pair_state = s_rec.pair_state,
@@ -1134,8 +1131,8 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     // ... and the pending scan's WRITE-AHEAD CORRECTION (RekfCtl::cp_*, RekfDev::cp; phase G below): which landmarks it covers
     int cp_uid_l = -1, cp_nu_l = -1;
     unsigned cp_scan_l = 0u;
-    if (A.corr && lane < 32) cp_uid_l = ctl->cp_uid[A.corr_post & 1][lane];
-    if (A.corr) { cp_nu_l = ctl->cp_nu[A.corr_post & 1]; cp_scan_l = ctl->cp_scan[A.corr_post & 1]; }
+    if (DDROLE && A.corr && lane < 32) cp_uid_l = ctl->cp_uid[A.corr_post & 1][lane];
+    if (DDROLE && A.corr) { cp_nu_l = ctl->cp_nu[A.corr_post & 1]; cp_scan_l = ctl->cp_scan[A.corr_post & 1]; }
 #ifdef REKF_DEBUG_MID_FIRST
     MMARK();                                        // (x0: first loads issued)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1190,56 +1187,39 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
         else return *p;
     };
     const bool spec = DDROLE && !FRONT && A.spec != 0;            // the record is speculative (RekfCtl::spec): no front end has run for this scan
-    double pose[5] = {hp ? A.pre_pose[0] : ctl_f64(&ctl->pose_pred[0]), hp ? A.pre_pose[1] : ctl_f64(&ctl->pose_pred[1]), hp ? A.pre_pose[2] : ctl_f64(&ctl->pose_pred[2]),
-                      hp ? A.pre_pose[3] : ctl_f64(&ctl->pose_pred[3]), hp ? A.pre_pose[4] : ctl_f64(&ctl->pose_pred[4])};
+    // (a speculative scan's Predict -- pose, (a, b), pose block -- was evaluated by workgroup 0 of the PREVIOUS scan's k_mid, at its end)
+    const double *pp_src = spec ? ctl->pose_next[A.pred_slot & 1] : ctl->pose_pred;
+    const double pose[5] = {hp ? A.pre_pose[0] : ctl_f64(&pp_src[0]), hp ? A.pre_pose[1] : ctl_f64(&pp_src[1]), hp ? A.pre_pose[2] : ctl_f64(&pp_src[2]),
+                            hp ? A.pre_pose[3] : ctl_f64(&pp_src[3]), hp ? A.pre_pose[4] : ctl_f64(&pp_src[4])};
     const bool pending = (FRONT || spec) ? true : ctl->pose_pending != 0;      // (the in-grid front role sets it beside us: a host-predicted scan always has one)
     const bool first = bx == 0;
-    // a speculative scan: its per-observation results with their margins (lane = observation), and Predict (cc:154-206) evaluated HERE --
-    // the front end's own source (front_role, device-predicted path), by every workgroup for itself: cos / sin of the new heading and the
-    // wrapped heading on one lane, the motion terms and the predicted pose block on lane 0 of the next wave; workgroup 0 leaves (a, b) and
-    // the block in RekfCtl::pred for the scan's downdate
+    // a speculative scan: its per-observation results with their margins (lane = observation)
     int sp_kind = -1, sp_idx = -1;
-    double sp_d1 = 0.0, sp_d2 = 0.0;
+    double sp_d1 = 0.0, sp_d2 = 0.0, sp_rng = 0.0, sp_pose0 = 0.0, sp_pose1 = 0.0, sp_pose2 = 0.0, sp_dmm = 0.0;
+    bool sp_rec_ok = false;
     if (spec) {
+        // (everything the proof needs goes in flight now: behind the barrier only arithmetic is left)
         const RekfCtl::Spec *sq = &ctl->spec[A.pred_slot & 1];
-        if (lane < A.K) { sp_kind = sq->kind[lane & 31]; sp_idx = sq->idx[lane & 31]; sp_d1 = sq->d1[lane & 31]; sp_d2 = sq->d2[lane & 31]; }
-        if (tid == 256) {
-#pragma clang fp contract(off)
-            const double th = d.mu[2] + A.vt[2] * A.dt;
-            double sn, cs;
-            sincos(th, &sn, &cs);
-            s_pose[3] = cs; s_pose[4] = sn;
-            s_pose[2] = atan2(sn, cs);                     // the wrapped heading (cc:181 / :205)
+        if (lane < A.K) {
+            sp_kind = sq->kind[lane & 31]; sp_idx = sq->idx[lane & 31]; sp_d1 = sq->d1[lane & 31]; sp_d2 = sq->d2[lane & 31];
+            const double px = (double)rekf_obs(A, 2 * lane), py = (double)rekf_obs(A, 2 * lane + 1);
+            sp_rng = sqrt(px * px + py * py);
         }
-        if (tid == 320) {
-#pragma clang fp contract(off)
-            Motion mo;
-            const double mu0 = d.mu[0], mu1 = d.mu[1], mu2 = d.mu[2];
-            double C9[9];
-            for (int q = 0; q < 9; ++q) C9[q] = A.corr ? ctl->post_C9[A.corr_post & 1][q] : rekf_plower(P, (int)ld, q % 3, q / 3);
-            motion_terms(A, mu2, mo);
-            s_pose[0] = mu0 + mo.d[0]; s_pose[1] = mu1 + mo.d[1];
-            corner_predict(C9, 3, mo);
-            s_pred[0] = mo.a; s_pred[1] = mo.b;
-            for (int q = 0; q < 9; ++q) s_pred[2 + q] = C9[q];
-            if (first) {
-                RekfCtl::Pred *pr = &ctl->pred[A.pred_slot & 1];
-                pr->ab[0] = mo.a; pr->ab[1] = mo.b;
-                for (int q = 0; q < 9; ++q) pr->C9[q] = C9[q];
-            }
-        }
+        sp_pose0 = sq->pose[0]; sp_pose1 = sq->pose[1]; sp_pose2 = sq->pose[2];
+        sp_dmm = __longlong_as_double((long long)ctl->dmmax[(A.pred_slot ^ 1) & 1]);
+        sp_rec_ok = sq->scan == A.scan_id && sq->n == ((d.n_known >= 0) ? d.n_known : -1);
     }
     // the scan's pending Predict (RekfCtl::pred): applied to the gathered P in phase D.  (a, b) = 0 and the pose block as gathered
     // when nothing is pending (later block steps of a wide scan: the first step's downdate has committed it)
     // (through LDS, not registers: eleven uniform doubles held from here to phase D cost this 512-thread kernel its residency)
     const bool do_pred = A.apply_pred != 0;
-    if (do_pred && !spec && tid >= 64 && tid < 64 + 11) {                          // ab[0], ab[1], C9[0..8]
+    if (do_pred && tid >= 64 && tid < 64 + 11) {                          // ab[0], ab[1], C9[0..8]
         // (with the front role in this grid the control block's copy is being written beside us: a host-predicted scan carries the values)
         const int e = tid - 64;
         s_pred[e] = (FRONT && hp) ? (e < 2 ? A.pre_ab[e] : A.pre_C9[e - 2]) : ctl_f64(&((const double *)&ctl->pred[A.pred_slot & 1])[e]);
     }
     // ... and what is PENDING on the stored P (A.corr): the previous scan's (a, b) and its pose block after the update
-    const bool corr = A.corr != 0, cpred = corr && A.corr_pred >= 0;
+    const bool corr = DDROLE && A.corr != 0, cpred = corr && A.corr_pred >= 0;     // (MODE 1, the two-launch chain of a filter that can still grow: never)
     if (corr && tid >= 128 && tid < 128 + 11) {
         const int e = tid - 128;
         s_cpred[e] = (e < 2) ? (cpred ? ctl->pred[A.corr_pred & 1].ab[e] : 0.0) : ctl->post_C9[A.corr_post & 1][e - 2];
@@ -1293,24 +1273,20 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     MMARK();                                        // 0: compaction done
     if (spec) {
         // ---- the speculative record, proved or repaired.  The front role matched this scan against the pose (sq->pose) and the means
-        // scan t - 1's launch STARTED from; since then that scan's update has moved the pose (by what s_pose - sq->pose says: both are
+        // scan t - 1's launch STARTED from; since then that scan's update has moved the pose (by what pose - sq->pose says: both are
         // known) and every reflector mean by at most dmmax.  An observation's distance to ANY reflector has therefore changed by at most
         //     delta = |dxy| + range * |dtheta| + sqrt(2) dmmax + (float32 roundings of the two evaluations),
         // and its decision stands if it has that much room: matched (d1 < 0.6): d1 + delta < 0.6 and d2 - d1 > 2 delta (the nearest stays
         // the nearest, first-index ties cannot arise); unmatched: d1 - delta > 0.6.  Every wave decides for itself from the same numbers.
-        const RekfCtl::Spec *sq = &ctl->spec[A.pred_slot & 1];
-#pragma unroll
-        for (int q = 0; q < 5; ++q) pose[q] = s_pose[q];
         bool okv = true;
         {
 #pragma clang fp contract(off)
-            const double dxp = pose[0] - sq->pose[0], dyp = pose[1] - sq->pose[1];
-            double dth = pose[2] - sq->pose[2];
+            const double dxp = pose[0] - sp_pose0, dyp = pose[1] - sp_pose1;
+            double dth = pose[2] - sp_pose2;
             dth = dth - 6.283185307179586 * rint(dth / 6.283185307179586);
-            const double dmm = __longlong_as_double((long long)ctl->dmmax[(A.pred_slot ^ 1) & 1]);
+            const double dmm = sp_dmm;
             if (lane < A.K) {
-                const double px = (double)rekf_obs(A, 2 * lane), py = (double)rekf_obs(A, 2 * lane + 1);
-                const double rng = sqrt(px * px + py * py);
+                const double rng = sp_rng;
                 const double delta = sqrt(dxp * dxp + dyp * dyp) + rng * fabs(dth) + 1.5 * dmm
                                    + 3e-7 * (fabs(pose[0]) + fabs(pose[1]) + rng + 1.0);
                 if (sp_kind == 1) okv = (sp_d1 + delta < 0.6) && (sp_d2 - sp_d1 > 2.0 * delta);
@@ -1319,7 +1295,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
                 if (!(delta == delta)) okv = false;
             }
         }
-        const bool rec_ok = sq->scan == A.scan_id && sq->n == n;
+        const bool rec_ok = sp_rec_ok && d.n_known == n;
         unsigned long long bad = __ballot(!okv);
         if (!rec_ok) bad = (A.K >= 64) ? ~0ull : ((1ull << A.K) - 1ull);
         if (first && tid == 0) { ctl->dbg[20] += 1; if (bad) ctl->dbg[21] += 1; }      // (speculative scans / those with observations re-matched)
@@ -1340,6 +1316,9 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
             __syncthreads();
         }
     }
+#ifdef REKF_DEBUG_MID_FINE
+    MMARK();                                        // (f0: speculative record proved)
+#endif
     const int MM = s_cnt[0], m = s_cnt[1], m_pad = s_cnt[2], NS = s_cnt[3];
     const bool gps_rows = s_cnt[4] != 0;
     // the pending scan's write-ahead correction serves this scan when it covers exactly this scan's landmarks
@@ -1347,7 +1326,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     {
         const int nu0 = (NS > 0) ? s_rec.nu : 0;
         const bool eq = lane >= 32 || lane >= nu0 || cp_uid_l == s_uid[lane];
-        use_cp = A.corr != 0 && A.pair0 < 0 && cp_scan_l == A.corr_scan && cp_nu_l == nu0 && __ballot(eq) == ~0ull;
+        use_cp = DDROLE && A.corr != 0 && A.pair0 < 0 && cp_scan_l == A.corr_scan && cp_nu_l == nu0 && __ballot(eq) == ~0ull;
     }
     if (first && A.pair0 < 0) {
         // ReflectorMatchResult for the getters (and n_new / m for the kernels behind this one), out of the record
@@ -1359,7 +1338,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
             ctl->K = s_cnt[7]; ctl->n_state = NS; ctl->n_map = Mm; ctl->n_new = N2r;
             ctl->m = m; ctl->m_pad = m_pad;
         }
-        if (A.cp_write) {                               // which landmarks this scan's write-ahead correction covers (phase G)
+        if (DDROLE && A.cp_write) {                     // which landmarks this scan's write-ahead correction covers (phase G)
             const int nu0 = (NS > 0) ? s_rec.nu : 0;
             if (tid >= 256 && tid < 256 + 32) ctl->cp_uid[d.post_slot & 1][tid - 256] = (tid - 256 < nu0) ? s_uid[tid - 256] : -1;
             if (tid == 288) { ctl->cp_nu[d.post_slot & 1] = nu0; ctl->cp_scan[d.post_slot & 1] = A.scan_id; }
@@ -1428,6 +1407,9 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
         return;
     }
     // (m_pad <= MP: the host picked NBR from its bound 2K(+3) of m)
+#ifdef REKF_DEBUG_MID_FINE
+    MMARK();                                        // (f1: in front of phase C)
+#endif
 
     // ---- C (issued before B: it needs only the match record): P(R, R) and P(own, R).  R in ascending global order: sub-block row
     // s < 3 is global row s, s = 3 + 2 u + e is row e of the u-th distinct matched landmark.  P is stored as its LOWER triangle and ONE
@@ -1482,6 +1464,9 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
             }
         }
     }
+#ifdef REKF_DEBUG_MID_FINE
+    MMARK();                                        // (f2: stage loads issued (slow path), tables set up)
+#endif
     v2du ps[PS_IT][2], cpv[PS_IT][2], raw2v[PS_IT];
     const double *__restrict__ cpP = d.cp + (size_t)(A.corr_post & 1) * REKF_CP_LD * REKF_CP_LD;
     int blk_u[PS_IT], blk_v[PS_IT];                                           // row slot u, column slot v of this thread's blocks (-1: none)
@@ -1946,13 +1931,13 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
             d.Kn[c2 + (size_t)r * ld] = 0.0;
         }
         // which of this workgroup's rows are sub-block rows (phase G); one wave: its LDS operations execute in order
-        if (wave == 4) {
+        if (DDROLE && wave == 4) {
             if (lane < MID_ROWS) s_ownsub[lane] = -1;
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int sx = lane + 64 * h;
-                if (sx < nus) { const int gr = ug_of(sx) - i0; if (gr >= 0 && gr < MID_ROWS) s_ownsub[gr] = sx; }
+                if (sx >= 3 && sx < nus) { const int gr = ug_of(sx) - i0; if (gr >= 0 && gr < MID_ROWS) s_ownsub[gr] = sx; }      // (the pose rows' elements are the pose block: taken by value)
             }
         }
     };
@@ -2045,7 +2030,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
                 for (int r = 0; r < 4; ++r) {
                     const int j = j0 + kq + 4 * r;                               // D row = column of K
                     store_wt(&d.Kn[(i0 + idx) + (size_t)j * ld], -acc[r]);
-                    s_kown[j][idx] = -acc[r];                                    // (phase G)
+                    if (DDROLE) s_kown[j][idx] = -acc[r];                        // (phase G)
                     part += acc[r] * s_coef[8 * j + 6];                          // K(i, j) (z - zhat)(j)
                     if (first) {                                                 // (K H P)(i, jc) = sum_j K(i, j) W(jc, j), jc = 0..2
                         pc0 += acc[r] * s_wown[j][0]; pc1 += acc[r] * s_wown[j][1]; pc2 += acc[r] * s_wown[j][2];
@@ -2099,9 +2084,39 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
             const double base = do_pred ? s_pred[2 + hi + 3 * lo] : s_pw[lo][hi];
             const double v9 = base - khp;
             post_out[e] = v9;
+            s_cpred[2 + e] = v9;                // (the pending scan's block is dead by now: this scan's, for the next scan's Predict below)
             if (d.pub) host_slot_store(d.pub + 3 + e, v9, d.pub_seq, 0);
         }
         append_new_means();                     // (a barrier inside: s_np is complete behind it)
+        if constexpr (DDROLE && !FRONT) {
+            if (A.spec_front > 0) {
+                // the NEXT scan is in the speculation pipeline (its launch packet An came with this launch): its Predict (cc:154-206) is
+                // evaluated here -- the front end's own source (front_role, device-predicted path) on the pose just committed and the
+                // pose block just evaluated -- while the other workgroups write their share of the write-ahead correction: the next
+                // k_mid starts with one load of it
+                const int ns = (A.pred_slot ^ 1) & 1;
+                if (tid == 0) {
+#pragma clang fp contract(off)
+                    const double th = s_np[2] + An.vt[2] * An.dt;
+                    double sn, cs;
+                    sincos(th, &sn, &cs);
+                    ctl->pose_next[ns][3] = cs; ctl->pose_next[ns][4] = sn;
+                    ctl->pose_next[ns][2] = atan2(sn, cs);                     // the wrapped heading (cc:181 / :205)
+                }
+                if (tid == 64) {
+#pragma clang fp contract(off)
+                    Motion mo;
+                    double C9[9];
+                    for (int q = 0; q < 9; ++q) C9[q] = s_cpred[2 + q];
+                    motion_terms(An, s_np[2], mo);
+                    ctl->pose_next[ns][0] = s_np[0] + mo.d[0]; ctl->pose_next[ns][1] = s_np[1] + mo.d[1];
+                    corner_predict(C9, 3, mo);
+                    RekfCtl::Pred *pr = &ctl->pred[ns];
+                    pr->ab[0] = mo.a; pr->ab[1] = mo.b;
+                    for (int q = 0; q < 9; ++q) pr->C9[q] = C9[q];
+                }
+            }
+        }
         // The EARLY publisher (d.pub set on this launch: the caller has been reading the pose back after its scans, rekf_api.hip): pose,
         // block, n and flags go to the host from here, a kernel before the downdate -- at the price of 0.8 us at the end of this kernel
         // (it ends when the PCIe writes are through).  Otherwise the downdate's first workgroup publishes, at its start.
@@ -2116,7 +2131,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     // computed here by the workgroup that owns row hi: Kn(hi, :) is its own (phase F), HPt(lo, :) = W(lo, :) sits in LDS for every lo in R
     // (phase D built it for S) -- the downdate's own MFMA chain over k, so the sum is the one the downdate will add.  One 16 x 16 block
     // product per wave and block of sub-block rows at or below this workgroup's.
-    if (A.cp_write) {
+    if (DDROLE && A.cp_write) {
         const int s_hi = s_ownsub[c16];
         // (blocks whose first row lies above every sub-block row this workgroup owns have nothing for it)
         int smax = s_hi;

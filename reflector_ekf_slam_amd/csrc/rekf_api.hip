@@ -109,6 +109,7 @@ struct rekf {
     // scan (no read-back in between) has its newest scan HELD on the host until the next call brings the one after it; every other
     // call (getters, odometry, sync) sends the held scan first.  Same results, bit for bit, as the exact front end.
     bool spec_enable = true;
+    bool cp_enable = true;          // REKF_CP_WRITE=0: no write-ahead correction panels (A/B measurements)
     bool held = false;              // a scan waits on the host: ...
     double held_t = 0;
     int held_K = 0;
@@ -540,6 +541,7 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
     { const char *e = std::getenv("REKF_SCAN_LAUNCH"); h->scan_launch = !(e && e[0] == '0'); }
     { const char *e = std::getenv("REKF_EXCLUSIVE"); h->exclusive = e && e[0] == '1'; }
     { const char *e = std::getenv("REKF_SPEC"); h->spec_enable = !(e && e[0] == '0'); }
+    { const char *e = std::getenv("REKF_CP_WRITE"); h->cp_enable = !(e && e[0] == '0'); }
     h->prof_on = false;
     h->prof_mask = -1;
     h->prof_used = 0;
@@ -824,7 +826,7 @@ static int process_scan(rekf_t *h, double t, const float *xy, int K, const doubl
     a.front_target = h->front_total;
     a.spec = use_spec ? 1 : 0;
     a.compact_in_front = blocks ? 0 : 1;
-    a.cp_write = blocks ? 0 : 1;                      // (whole scans leave their write-ahead correction: k_mid phase G)
+    a.cp_write = (blocks || !h->cp_enable) ? 0 : 1;   // (whole scans leave their write-ahead correction: k_mid phase G)
     h->dev.pred_slot = -1;
     h->dev.post_slot = pred_slot;                     // (RekfCtl::post_C9: k_mid writes the scan's slot, the scan's downdate stores it)
     h->dev.P_out = h->dev.P;
