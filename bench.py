@@ -377,80 +377,88 @@ def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world, cha
         ekf.sync()
         chain_us = 1e6 * (time.perf_counter() - t0c) / 500
         pos += 500
-    # The roofline kernel once more, without per-launch brackets: back-to-back launches between ONE pair of
-    # hipEvents on the handle's stream (operands = what the last scan left in HBM).  A bracket around every
-    # launch adds 2-3 us of command-processor time to each reading (an empty bracket reads 4-5 us); this figure
-    # does not, and agrees with rocprofv3 --kernel-trace (profiles/).  The filter state is meaningless afterwards;
-    # nothing below uses this handle again.
+    # ---- the roofline kernel.  Since round 5 a steady-state update is ONE launch, k_mid<4, 0>: the scan's mid role (gather + 64 x 64
+    # inverse + gain: a latency chain), the PREVIOUS scan's rank-m downdate P -= K (H P) as a role beside it (the HBM work: the stored lower
+    # triangle read from one P buffer and written to the other, tiles from a queue) and the NEXT scan's speculative front end.  Its average
+    # duration is measured in this run as the update period of an un-instrumented window (one launch per update on the handle's stream, back
+    # to back: period = launch + launch boundary, so the figure is an upper bound of the kernel time; rocprofv3 --kernel-trace of the same
+    # loop is committed under profiles/).  The downdate ROLE's own span inside that launch comes from two device time stamps (its first
+    # workgroup's start, its last workgroup's end).  The old stand-alone kernel (k_downdate2<64>: same body, whole GPU) is re-timed back to
+    # back between one hipEvent pair for comparison; the filter state is meaningless afterwards, nothing below uses this handle again.
+    import ctypes as _C
+    dd_role_us = None
+    try:
+        cnt = (_C.c_longlong * 32)()
+        ekf.sync()
+        for t, ob in rest[pos:pos + 8]:
+            ekf.handle_observation(t, ob)
+        pos += 8
+        if ekf._L.rekf_debug_counters(ekf._h, cnt) == 0 and cnt[26] > 0 and cnt[27] > cnt[26]:
+            dd_role_us = (cnt[27] - cnt[26]) * 0.01
+    except Exception:
+        pass
     dd_us = ekf.time_kernel("downdate", reps=max(args.steps, 200))
 
     bytes_full = 16.0 * n * n + 8.0 * n * (3 + m)         # SURVEY.md 8(d) BYTES_alg(n, m): every element of P read and written once
     # what the EXECUTED algorithm must move (SURVEY 8(d) for a lower-triangular builder): P is STORED as its lower triangle
     # (round 3), so the triangle is read and written once, the panels once
     bytes_exec = 2.0 * 8.0 * (n * (n + 1) / 2.0) + 8.0 * n * (3 + m)
-    T = n // 64 if 0 < n % 64 <= 4 else -(-n // 64)
+    T = -(-n // 64)
     tiles_exec = T * (T + 1) // 2
-    flop_exec = tiles_exec * 2.0 * 64 * 64 * (16 * -(-m // 16))          # MFMA FLOP actually issued (16x16x4 tiles over the padded k range)
+    flop_exec = tiles_exec * 2.0 * 64 * 64 * 64            # MFMA FLOP the downdate role issues (16x16x4 tiles, KC = 64)
     flop_k7 = 2.0 * n * n * m                              # the reference's full-square count
-    # IN-CHAIN time of the kernel, from this run's own measurements.  Inside the chain the kernels run dependent and back to
-    # back, so a kernel's cost there includes its cold start behind its predecessor; a hipEvent bracket around each launch
-    # (minus the empty bracket) measures the kernels apart and comes out short of that (their sum is ~4 us below the timed
-    # region's us per update).  So: the us per update of an un-instrumented window (500 updates), split by the kernels' bracketed
-    # shares.  rocprofv3 --kernel-trace inside the chain agrees with it (profiles/), the back-to-back rerun rides along.
-    dd_chain_us, chain_method = None, None
-    corr = {k: kernel_us[k] - kernel_us["empty"] for k in ("front", "mid", "downdate", "augment")
-            if kernel_us.get(k) is not None and kernel_us.get("empty") is not None}
-    if chain_us and corr.get("downdate", 0) > 0 and corr.get("mid", 0) > 0:
-        dd_chain_us = chain_us * corr["downdate"] / sum(v for v in corr.values() if v > 0)
-        chain_method = ("measured in this run, IN CHAIN: us per update of an un-instrumented 500-update window (%.2f) x the kernel's share of the per-launch "
-                        "hipEvent brackets minus the empty bracket (%s)" % (chain_us, ", ".join(f"{k} {v:.2f}" for k, v in corr.items() if v > 0)))
-    t_frac = dd_chain_us if dd_chain_us else dd_us
+    t_frac = chain_us if chain_us else dd_us
     achieved = bytes_exec / (t_frac * 1e-6) / 1e9
     rocprof_us, traffic, traffic_src, rocprof_src = None, None, None, None
     try:
         avg = json.load(open(os.path.join(ROOT, "profiles", "kernel_avg_us.json")))
-        # inside the chain the downdate runs as k_dd_front<64> (lazy downdate: the next scan's front end in 32 further workgroups)
-        rocprof_us = next((v for k, v in avg.items() if "k_dd_front<64" in k), None) or next((v for k, v in avg.items() if "k_downdate2<64" in k), None)
-        rocprof_src = "profiles/kernel_avg_us.json (committed rocprofv3 --kernel-trace summary; NOT measured in this run)"
+        rocprof_us = next((v for k, v in avg.items() if "k_mid<4, 0>" in k), None)
+        rocprof_src = "profiles/kernel_avg_us.json (committed rocprofv3 --kernel-trace summary of bench.py's timed loop; NOT measured in this run)"
     except Exception:
         pass
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_downdate.json")))
         traffic = pj.get("hbm_bytes_per_launch")
-        traffic_src = ("profiles/pmc_downdate.json: (2*FETCH_SIZE + WRITE_SIZE) of two separate rocprofv3 --pmc passes, "
+        traffic_src = ("profiles/pmc_downdate.json: (2*FETCH_SIZE + WRITE_SIZE) of two separate rocprofv3 --pmc passes over k_mid<4, 0>, "
                        "committed summary; NOT measured in this run")
     except Exception:
         pass
     moved = (traffic / (t_frac * 1e-6) / 1e9) if traffic else None
     out["roofline"] = {
-        "kernel": "k_downdate2<64> / k_dd_front<64> (P -= K (H P) on the lower triangle P is stored as: FP64 MFMA 16x16x4 tiles, panels by LDS DMA; "
-                  "inside the chain it is enqueued with the NEXT scan as k_dd_front, whose last 32 workgroups are that scan's front end)", "bound": "hbm",
-        "bytes_note": "achieved / frac = bytes the executed lower-triangle algorithm must move: 2 * 8 n(n+1)/2 (triangle read and written) "
-                      "+ 8 n (3+m) panels, over the kernel's IN-CHAIN time measured in this run (avg_launch_us); frac_fullsquare = SURVEY 8(d)'s "
-                      "16 n^2 + 8 n (3+m) over the same time (what a full-square kernel would have had to move); frac_moved = HBM bytes by PMC "
-                      "counters (committed summary) over the same time; *_back_to_back = the same over the kernel re-launched back to back "
-                      "between one hipEvent pair (L2-warm panels; what round 3 quoted as frac); frac_inchain_rocprof = over the committed "
-                      "rocprofv3 average of k_dd_front<64>",
+        "kernel": "k_mid<4, 0>: ONE launch per update -- the scan's mid role (gather, 64 x 64 inverse, gain: the latency chain that sets the "
+                  "launch's length), the PREVIOUS scan's downdate P -= K (H P) as a role on the CUs beside it (FP64 MFMA 16x16x4 tiles of the "
+                  "stored lower triangle, panels by LDS DMA, one P buffer read, the other written) and the NEXT scan's speculative front end",
+        "bound": "hbm",
+        "bytes_note": "achieved / frac = bytes the executed lower-triangle algorithm must move per launch: 2 * 8 n(n+1)/2 (triangle read and written) "
+                      "+ 8 n (3+m) panels, over the launch's average duration measured in this run (avg_launch_us: the update period of an "
+                      "un-instrumented window, one launch per update -- an upper bound of the kernel time).  The launch is NOT HBM-bound by "
+                      "design: the downdate has left the update's critical path and fills the CUs the latency chain leaves free; "
+                      "frac_downdate_role = the same bytes over the role's own span inside the launch (device time stamps); "
+                      "frac_back_to_back = over the stand-alone kernel k_downdate2<64> (same body, all CUs) re-launched back to back; "
+                      "frac_fullsquare = SURVEY 8(d)'s 16 n^2 + 8 n (3+m) over avg_launch_us; frac_moved = HBM bytes by PMC counters (committed summary)",
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "frac_fullsquare": bytes_full / (t_frac * 1e-6) / 1e9 / HBM_PEAK_GBS,
         "frac_moved": (moved / HBM_PEAK_GBS) if moved else None,
+        "downdate_role_us": dd_role_us,
+        "frac_downdate_role": (bytes_exec / (dd_role_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if dd_role_us else None,
         "frac_back_to_back": bytes_exec / (dd_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-        "frac_moved_back_to_back": (traffic / (dd_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None,
         "frac_inchain_rocprof": (bytes_exec / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if rocprof_us else None,
         "traffic": traffic, "traffic_source": traffic_src,
         "bytes_per_launch": bytes_exec, "bytes_per_launch_fullsquare": bytes_full,
         "avg_launch_us": t_frac,
-        "avg_launch_us_method": (chain_method if dd_chain_us else
-                                 "measured in this run: back-to-back launches between one hipEvent pair on the handle's stream (no per-kernel brackets available)"),
+        "avg_launch_us_method": ("measured in this run: the update period of an un-instrumented 500-update window on the handle's stream, ONE launch "
+                                 "(k_mid<4, 0>) per update, back to back -- launch + launch boundary, an upper bound of the kernel's duration"
+                                 if chain_us else "measured in this run: k_downdate2<64> back to back between one hipEvent pair"),
         "avg_launch_us_back_to_back": dd_us,
-        "per_launch_bracket_us": kernel_us.get("downdate"), "empty_event_bracket_us": kernel_us.get("empty"),
         "rocprof_avg_launch_us": rocprof_us, "rocprof_source": rocprof_src,
         "mfma": {"achieved_tflops": flop_exec / (t_frac * 1e-6) / 1e12, "peak_tflops": FP64_MFMA_PEAK_TF,
                  "frac": flop_exec / (t_frac * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF,
+                 "frac_downdate_role": (flop_exec / (dd_role_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF) if dd_role_us else None,
                  "frac_fullsquare_flop": flop_k7 / (t_frac * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF,
                  "frac_back_to_back": flop_exec / (dd_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF,
-                 "note": f"frac = EXECUTED MFMA FLOP ({tiles_exec} lower-triangle tiles x 2*64*64*{16 * -(-m // 16)}) over the in-chain time; "
-                         "frac_fullsquare_flop = the reference's 2 n^2 m over the same time (the mirrored kernel executes half of them)"}}
+                 "note": f"frac = the downdate role's EXECUTED MFMA FLOP ({tiles_exec} lower-triangle tiles x 2*64*64*64) over avg_launch_us (the mid "
+                         "role's MFMAs -- correction, inverse, gain -- are not counted); frac_downdate_role over the role's own span; "
+                         "frac_fullsquare_flop = the reference's 2 n^2 m over avg_launch_us"}}
     out["kernel_us"] = kernel_us
     if ms_result is not None:
         out["multi_session"] = ms_result

@@ -53,7 +53,7 @@ struct RekfCtl {
     // the two kernels that read P before the scan's downdate has rewritten it apply them to what they read: k_mid to its gathers,
     // k_downdate2 to its tiles of column 0 (which then STORE predicted-and-updated values: the scan's downdate commits its Predict).
     // Two slots, by scan parity: the front kernel of scan t+1 may run beside the downdate of scan t (lazy downdate, rekf_api.hip).
-    struct Pred { double ab[2]; double C9[9]; } pred[2];
+    struct Pred { double ab[2]; double C9[9]; } pred[4];      // (by scan id mod 4, RekfFrontArgs::pred_ix: one launch may read the pending scan's, the current scan's, and write the next scan's)
     // ---- the 3 x 3 pose block AFTER the update (round 3): evaluated once, by k_mid's workgroup 0 (which has K's pose rows and the pose
     // columns of H P in LDS), published to the host from there -- GetPose does not wait for the downdate -- and taken over BY VALUE by
     // the downdate's tile (0, 0), so that the published block and the stored one are the same bits
@@ -77,7 +77,7 @@ struct RekfCtl {
     // take -- |d1 - gate| and d2 - d1 against a bound of how far the update moved the pose and the reflectors -- and re-matches the
     // observations that do not pass
     struct Spec { int kind[32], idx[32]; double d1[32], d2[32]; double pose[3]; int n; unsigned scan; } spec[2];
-    unsigned long long dmmax[2];      // bits of max |mu_new - mu_old| over the landmark rows of a scan's update (by scan parity; the next k_mid zeroes the other)
+    unsigned long long dmmax[4];      // bits of max |mu_new - mu_old| over the landmark rows of a scan's update (by scan id mod 4: a launch writes its own, reads the previous scan's, zeroes the next one's)
     unsigned front_count;             // observations matched so far, over the life of the handle (never reset)
     // ---- a scan's landmark augmentation deferred into the NEXT scan's k_mid (round 4): while the state can grow, every scan used to
     // be followed by a k_augment launch that found nothing to do (2.4 us of kernel boundary per scan).  k_mid's workgroup 0 leaves what
@@ -133,6 +133,8 @@ struct RekfFrontArgs {
     int corr;                 // k_mid: the stored P is one scan behind -- what is gathered takes the pending downdate (dp's panels, kc_ub columns) ...
     int corr_pred;            // ... and, first, the pending Predict (RekfCtl::pred[corr_pred], -1: none); the pose block is RekfCtl::post_C9[corr_post]
     int corr_post;
+    int corr_pred_ix;         // ... (its RekfCtl::pred index)
+    int pred_ix;              // this scan's RekfCtl::pred / dmmax index (scan id mod 4)
     unsigned corr_scan;       // ... and that scan's id (its write-ahead correction, RekfCtl::cp_scan, must carry it)
     int cp_write;             // k_mid: leave this scan's write-ahead correction (whole scans)
     int spec;                 // k_mid: the scan's match record is SPECULATIVE (RekfCtl::spec[pred_slot]): prove it or re-match; Predict is evaluated here
@@ -178,6 +180,7 @@ struct RekfDev {
     int dd_sub;         // k_downdate2: class B holds the tiles with I >= J + dd_sub (2: a class-A workgroup also takes the tile below its
                         // diagonal tile; 1: it does not; 0: the host does not know n exactly -- the kernel derives the schedule itself)
     int dd_grid;        // k_dd_front: workgroups [0, dd_grid) are the downdate, the rest the next scan's front end (0: k_downdate2, the whole grid)
+    int pred_ix;        // the RekfCtl::pred index of the scan this view belongs to (scan id mod 4)
     int post_slot;      // k_downdate2 / k_mid: the RekfCtl::post_C9 slot of the scan this view belongs to (k_mid writes it, the scan's downdate stores it)
     int pred_slot;      // k_downdate2: >= 0: the scan's pending Predict (RekfCtl::pred[pred_slot]) is applied to the tiles of column 0 as they are
                         // read (and so committed by this launch); -1: nothing pending (later block steps of a wide scan, timing hook)

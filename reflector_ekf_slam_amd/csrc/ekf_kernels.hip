@@ -385,7 +385,7 @@ __device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs
 #pragma unroll
                 for (int q = 0; q < 9; ++q) C9[q] = A.pre_C9[q];
             } else corner_predict(C9, 3, mo);
-            RekfCtl::Pred *pr = &ctl->pred[A.pred_slot & 1];
+            RekfCtl::Pred *pr = &ctl->pred[A.pred_ix & 3];
             if (wt_pred) {
                 store_wt(&pr->ab[0], mo.a); store_wt(&pr->ab[1], mo.b);
                 for (int q = 0; q < 9; ++q) store_wt(&pr->C9[q], C9[q]);
@@ -1051,17 +1051,11 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
         if (A.dd_in_mid && (int)blockIdx.x >= A.dd_first) {
             // the previous scan's downdate: waves 0..3 (the body is cut for 256 threads; a barrier counts the waves that have not ended)
             if (threadIdx.x < 256) {
-#ifdef REKF_DEBUG_TIMING
+                // (two device time stamps, 100 MHz, for the bench's roofline: when the role's first workgroup starts, when its last one ends)
                 if (threadIdx.x == 0 && (int)blockIdx.x == A.dd_first) ctl->dbg[26] = wall_clock64();
-#endif
                 dd_body<64, true>(dp, k_mid_arena, (int)blockIdx.x - A.dd_first, A.dd_in_mid, &ctl->dd_queue[A.dd_par & 1], (int)blockIdx.x == A.dd_first);
-#ifdef REKF_DEBUG_TIMING
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (threadIdx.x == 0) {
-                    atomicMax((unsigned long long *)&ctl->dbg[27], (unsigned long long)wall_clock64());      // the last downdate workgroup's exit
-                    if ((int)blockIdx.x == A.dd_first) ctl->dbg[28] = wall_clock64();
-                }
-#endif
+                if (threadIdx.x == 0) atomicMax((unsigned long long *)&ctl->dbg[27], (unsigned long long)wall_clock64());
             }
             return;
         }
@@ -1098,7 +1092,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool steam = wave < 4;                  // S team; the other is the "own" team
     const int tt = tid & 255;                     // thread index within the team
-    if (bx == 0 && tid == 511) { ctl->dd_queue[(A.dd_par ^ 1) & 1] = 0u; ctl->dmmax[(A.dd_par ^ 1) & 1] = 0ull; }     // the next launch's tile queue (and mean-shift bound) start empty
+    if (bx == 0 && tid == 511) { ctl->dd_queue[(A.dd_par ^ 1) & 1] = 0u; ctl->dmmax[(A.pred_ix + 1) & 3] = 0ull; }     // the next launch's tile queue (and mean-shift bound) start empty
     if (FRONT) {
         // every observation's result is in memory once the front end's count has reached the scan's target (each front workgroup
         // writes its result through, drains, then counts): wave 0 polls on one lane, takes the K results past this CU's L1 and
@@ -1206,7 +1200,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
             sp_rng = sqrt(px * px + py * py);
         }
         sp_pose0 = sq->pose[0]; sp_pose1 = sq->pose[1]; sp_pose2 = sq->pose[2];
-        sp_dmm = __longlong_as_double((long long)ctl->dmmax[(A.pred_slot ^ 1) & 1]);
+        sp_dmm = __longlong_as_double((long long)ctl->dmmax[(A.pred_ix + 3) & 3]);
         sp_rec_ok = sq->scan == A.scan_id && sq->n == ((d.n_known >= 0) ? d.n_known : -1);
     }
     // the scan's pending Predict (RekfCtl::pred): applied to the gathered P in phase D.  (a, b) = 0 and the pose block as gathered
@@ -1216,13 +1210,13 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     if (do_pred && tid >= 64 && tid < 64 + 11) {                          // ab[0], ab[1], C9[0..8]
         // (with the front role in this grid the control block's copy is being written beside us: a host-predicted scan carries the values)
         const int e = tid - 64;
-        s_pred[e] = (FRONT && hp) ? (e < 2 ? A.pre_ab[e] : A.pre_C9[e - 2]) : ctl_f64(&((const double *)&ctl->pred[A.pred_slot & 1])[e]);
+        s_pred[e] = (FRONT && hp) ? (e < 2 ? A.pre_ab[e] : A.pre_C9[e - 2]) : ctl_f64(&((const double *)&ctl->pred[A.pred_ix & 3])[e]);
     }
     // ... and what is PENDING on the stored P (A.corr): the previous scan's (a, b) and its pose block after the update
     const bool corr = DDROLE && A.corr != 0, cpred = corr && A.corr_pred >= 0;     // (MODE 1, the two-launch chain of a filter that can still grow: never)
     if (corr && tid >= 128 && tid < 128 + 11) {
         const int e = tid - 128;
-        s_cpred[e] = (e < 2) ? (cpred ? ctl->pred[A.corr_pred & 1].ab[e] : 0.0) : ctl->post_C9[A.corr_post & 1][e - 2];
+        s_cpred[e] = (e < 2) ? (cpred ? ctl->pred[A.corr_pred_ix & 3].ab[e] : 0.0) : ctl->post_C9[A.corr_post & 1][e - 2];
     }
 
     // ---- A: the scan's matched pairs.  Whole scan (pair0 < 0): the record the front end left.  Block step of a wide scan (pair0 >= 0): the
@@ -2069,7 +2063,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
         if (DDROLE) {
             adm = vmax_f64(adm, __shfl_xor(adm, 1, 64)); adm = vmax_f64(adm, __shfl_xor(adm, 2, 64));
             adm = vmax_f64(adm, __shfl_xor(adm, 4, 64)); adm = vmax_f64(adm, __shfl_xor(adm, 8, 64));
-            if (tid == 0 && adm > 0.0) atomicMax(&ctl->dmmax[A.pred_slot & 1], (unsigned long long)__double_as_longlong(adm));
+            if (tid == 0 && adm > 0.0) atomicMax(&ctl->dmmax[A.pred_ix & 3], (unsigned long long)__double_as_longlong(adm));
         }
     }
     if (first) {
@@ -2111,7 +2105,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
                     motion_terms(An, s_np[2], mo);
                     ctl->pose_next[ns][0] = s_np[0] + mo.d[0]; ctl->pose_next[ns][1] = s_np[1] + mo.d[1];
                     corner_predict(C9, 3, mo);
-                    RekfCtl::Pred *pr = &ctl->pred[ns];
+                    RekfCtl::Pred *pr = &ctl->pred[(A.pred_ix + 1) & 3];
                     pr->ab[0] = mo.a; pr->ab[1] = mo.b;
                     for (int q = 0; q < 9; ++q) pr->C9[q] = C9[q];
                 }
@@ -2284,7 +2278,7 @@ __device__ __forceinline__ void dd_body(const RekfDev &d, double *dd_smem, int w
     const bool pred_on = d.pred_slot >= 0;
     __shared__ double s_pred[12];
     double pred_v = 0.0;
-    if (pred_on && threadIdx.x >= 64 && threadIdx.x < 64 + 11) pred_v = ((const double *)&ctl->pred[d.pred_slot & 1])[threadIdx.x - 64];   // ab[0], ab[1], C9[0..8]
+    if (pred_on && threadIdx.x >= 64 && threadIdx.x < 64 + 11) pred_v = ((const double *)&ctl->pred[d.pred_ix & 3])[threadIdx.x - 64];   // ab[0], ab[1], C9[0..8]
     // the pose block after this update, as k_mid evaluated and published it (RekfCtl::post_C9): tile (0, 0) stores THOSE bits
     __shared__ double s_post[9];
     __shared__ int s_item;

@@ -816,6 +816,8 @@ static int process_scan(rekf_t *h, double t, const float *xy, int K, const doubl
     // (first) k_downdate2 apply it to what they read of P
     const int pred_slot = (int)(h->scan_count++ & 1);
     a.pred_slot = pred_slot; a.apply_pred = 1;
+    a.pred_ix = (int)(h->scan_count & 3);             // (scan id mod 4: RekfCtl::pred, dmmax)
+    h->dev.pred_ix = a.pred_ix;
     a.dd_par = pred_slot;                             // (RekfCtl::dd_queue: every k_mid zeroes the OTHER parity's counter for the next launch)
     // the front end counts matched observations (RekfCtl::front_count); the workgroup that reaches this scan's target compacts the
     // results into the record k_mid starts from (whole scans only: a wide scan goes through k_compact_wide)
@@ -840,7 +842,7 @@ static int process_scan(rekf_t *h, double t, const float *xy, int K, const doubl
     int front_wgs = 0;                                // (fast: the front end's workgroups inside the scan's launch)
     if (fast) {
         // the pending downdate stays pending until the k_mid launch below takes it along; the mid role sees it as a correction
-        a.corr = 1; a.corr_pred = h->dd_dev.pred_slot; a.corr_post = h->dd_dev.post_slot; a.corr_scan = h->dd_scan;
+        a.corr = 1; a.corr_pred = h->dd_dev.pred_slot; a.corr_post = h->dd_dev.post_slot; a.corr_pred_ix = h->dd_dev.pred_ix; a.corr_scan = h->dd_scan;
         if (use_spec) { /* nothing: the record is there */ }
         else if (alone && h->front_in_mid && !next) front_wgs = K;
         else { ProfScope ps(h, REKF_K_FRONT); rekf_launch_front_mb(h->dev, a, h->n_ub, h->stream); }
@@ -928,7 +930,7 @@ static int process_scan(rekf_t *h, double t, const float *xy, int K, const doubl
                     an.is_obs = 1; an.K = next->K;
                     std::memcpy(an.obs, next->xy, sizeof(float) * 2 * (size_t)next->K);
                     an.has_gps = next->gps ? 1 : 0;
-                    an.pred_slot = pred_slot ^ 1; an.scan_id = a.scan_id + 1u;
+                    an.pred_slot = pred_slot ^ 1; an.pred_ix = (a.pred_ix + 1) & 3; an.scan_id = a.scan_id + 1u;
                     an.compact_in_front = 1;
                     an.prev_dt = a.dt; an.prev_vt[0] = a.vt[0]; an.prev_vt[1] = a.vt[1]; an.prev_vt[2] = a.vt[2];
                     h->front_total += (unsigned)next->K;

@@ -105,3 +105,41 @@ def test_host_bound_of_T_may_exceed_the_kernels():
                     assert t not in seen
                     seen.add(t)
             assert seen == {(i, j) for i in range(T_k) for j in range(i + 1)}, (T_k, T_h)
+
+
+def queue_items(T, run=3):
+    """The work items of the downdate ROLE inside k_mid's grid (dd_body<KC, true>, round 5): items 0 .. T-1 are class A (the tile below
+    diagonal tile w, then that tile), then runs of `run` tiles of the triangle I >= J + 2, column by column; whoever is free takes the
+    next item from RekfCtl::dd_queue."""
+    nB = (T - 1) * (T - 2) // 2
+    n_items = T + (nB + run - 1) // run
+    items = []
+    for it in range(n_items):
+        if it < T:
+            items.append(device_tiles(T, T + 1, 0, 0, 2, it) if False else ([(it + 1, it)] if it + 1 < T else []) + [(it, it)])
+        else:
+            t0, t1 = run * (it - T), min(run * (it - T) + run, nB)
+            TT = T - 2
+            out = []
+            for tt in range(t0, t1):
+                J = 0
+                c0 = 0
+                while tt >= c0 + (TT - J):
+                    c0 += TT - J
+                    J += 1
+                out.append((J + (tt - c0) + 2, J))
+            items.append(out)
+    return items
+
+
+def test_the_queue_hands_every_tile_out_exactly_once():
+    for T in range(1, 70):
+        seen = set()
+        for tl in queue_items(T):
+            assert 1 <= len(tl) <= 3
+            diag = [t for t in tl if t[0] == t[1]]
+            assert len(diag) <= 1 and (not diag or tl[-1] == diag[0])      # a diagonal tile ends its item (the mirror reuses the panels' LDS)
+            for t in tl:
+                assert t not in seen, (T, t)
+                seen.add(t)
+        assert seen == {(i, j) for i in range(T) for j in range(i + 1)}, T
