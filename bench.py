@@ -209,7 +209,7 @@ def run_rank(args, dist_mod, rank, local_rank, world, make_filter=gpu_filter_fac
     if n != n_expect:
         raise SystemExit(f"warm-up ended with n={n}, expected {n_expect}")
 
-    n_extra = 16 + 3 * max(args.latency_steps, 0) + max(args.instr_steps, 0) + 2 * max(args.steps, 200) + max(args.rank_parity_steps, 0) + 700
+    n_extra = 16 + 3 * max(args.latency_steps, 0) + 700 + max(args.instr_steps, 0) + 2 * max(args.steps, 200) + max(args.rank_parity_steps, 0) + 700
     steady = synth.steady_state_scans(sess, args.warmup + args.steps + n_extra)
     m = 2 * steady[0][1].shape[0]
 
@@ -346,6 +346,22 @@ def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world, cha
     pos += used
     if lat is not None:
         out["latency_us"] = lat
+        # ... and on an EXCLUSIVE handle (rekf_set_exclusive: the caller promises the GPU is this handle's alone -- a bench process is):
+        # the scan's front end then runs inside the scan's launch, the update's workgroups waiting for it in there
+        try:
+            ekf.set_exclusive(True)
+            k_ex = min(args.latency_steps, 300)
+            hx, ix = np.zeros(k_ex), np.zeros(k_ex)
+            for k, (t, ob) in enumerate(rest[pos:pos + k_ex]):
+                t0 = time.perf_counter(); ekf.handle_observation(t, ob); ekf.pose(); hx[k] = 1e6 * (time.perf_counter() - t0)
+            for k, (t, ob) in enumerate(rest[pos + k_ex:pos + 2 * k_ex]):
+                ekf.sync()
+                t0 = time.perf_counter(); ekf.handle_observation(t, ob); ekf.pose(); ix[k] = 1e6 * (time.perf_counter() - t0)
+            pos += 2 * k_ex
+            out["latency_us"]["exclusive_handle"] = {"host_sync_median": float(np.median(hx)), "host_sync_p99": float(np.percentile(hx, 99)),
+                                                     "host_sync_idle_device_median": float(np.median(ix)), "host_sync_idle_device_p99": float(np.percentile(ix, 99)), "n": k_ex}
+        finally:
+            ekf.set_exclusive(False)
     k5 = max(args.steps, 200)
     out["with_5_predicts_per_scan"], used = predict_leg(ekf, cfg, rest[pos:], k5)
     pos += used
@@ -568,7 +584,7 @@ def not_full_leg(args, base, cfg, sess, device, out_value=None):
     ekf.sync()
     assert ekf.n == 3 + 2 * cfg.n_landmarks
     steps = max(args.steps, 500)
-    scans = synth.steady_state_scans(sess, 100 + 2 * steps + 300, seed_offset=3000)
+    scans = synth.steady_state_scans(sess, 100 + 2 * steps + 300 + 520, seed_offset=3000)
     elapsed, used = timed_region(ekf, scans, 100, steps, None, lambda: None)
     res = {"value": steps / elapsed, "unit": "updates/s", "us_per_update": 1e6 * elapsed / steps, "steps": steps,
            "max_landmarks": 2 * cfg.n_landmarks, "n": ekf.n,
@@ -581,6 +597,19 @@ def not_full_leg(args, base, cfg, sess, device, out_value=None):
     dt = time.perf_counter() - t0
     res["with_pose_readback"] = {"value": steps / dt, "unit": "updates/s", "us_per_update": 1e6 * dt / steps}
     res["kernel_us"] = per_kernel_leg(ekf, scans[used + steps:], 300)
+    # ... and on an EXCLUSIVE handle: the previous scan's augmentation rides in the next scan's k_mid (its other workgroups wait for it)
+    try:
+        ekf.set_exclusive(True)
+        base_i = used + steps + 300
+        ekf.sync()
+        t0 = time.perf_counter()
+        for t, ob in scans[base_i:base_i + 500]:
+            ekf.handle_observation(t, ob)
+        ekf.sync()
+        dtx = time.perf_counter() - t0
+        res["exclusive_handle"] = {"value": 500 / dtx, "unit": "updates/s", "us_per_update": 1e6 * dtx / 500}
+    except Exception as e:
+        res["exclusive_handle"] = {"error": repr(e)}
     ekf.close()
     return res
 
@@ -690,7 +719,7 @@ def cpu_baseline(args, cfg, sess, st, device):
     from reflector_ekf_slam_amd import ReflectorEKFSLAM, synth
     from reflector_ekf_slam_amd import session as S
     ns, nl = max(args.cpu_structured_steps, 1), max(args.cpu_literal_steps, 0)
-    all_scans = synth.steady_state_scans(sess, ns + nl, seed_offset=2000)
+    all_scans = synth.steady_state_scans(sess, ns + nl + min(ns, 40), seed_offset=2000)
     shift = st.time - sess.ev_time[-1]            # these scans start right after the snapshot's time
     all_scans = [(t + shift, ob) for t, ob in all_scans]
     o = OracleEKF(cfg.odom_model, sess.init_time, sess.init_pose, cfg.sigma_v ** 2, cfg.sigma_w ** 2,
@@ -703,6 +732,16 @@ def cpu_baseline(args, cfg, sess, st, device):
         o.handle_observation(t, ob)
         poses.append(o.mu()[:3].copy())
     t_struct = (time.perf_counter() - t0) / ns
+    # ... and the same algorithm on ALL host cores ("--mode structured --threads <all cores>"): the column-parallel loops of
+    # the structured update (P H^T gather, H P gather, P -= K (H P)) under OpenMP; bit-identical to the 1-thread run by construction
+    ncores = os.cpu_count() or 1
+    o.set_threads(ncores)
+    n_all = min(ns, 40)
+    t0 = time.perf_counter()
+    for t, ob in all_scans[ns:ns + n_all]:
+        o.handle_observation(t, ob)
+    t_all = (time.perf_counter() - t0) / max(n_all, 1)
+    o.set_threads(1)
     g2 = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks, device=device, auto_grow=False)
     g2.set_state(st.time, st.mu, st.sigma, vt)
     err2 = []
@@ -716,8 +755,10 @@ def cpu_baseline(args, cfg, sess, st, device):
     m = 2 * all_scans[0][1].shape[0]
     res = {"value": None, "unit": "updates/s", "cores": 1, "kind": "port",
            "structured_value": 1.0 / t_struct, "structured_sample": f"{ns} updates, O(n^2 m) algorithm, 1 thread",
+           "structured_all_cores_value": 1.0 / t_all, "structured_all_cores": ncores,
+           "structured_all_cores_sample": f"{n_all} further updates, the same O(n^2 m) algorithm with its column loops on {ncores} OpenMP threads",
            "host_cores": os.cpu_count()}
-    lit_scans = all_scans[ns:ns + nl]             # the scans that follow, times still increasing
+    lit_scans = all_scans[ns + n_all:ns + n_all + nl]             # the scans that follow, times still increasing
     if len(lit_scans) == 0:
         res["sample"] = "no literal-mode update was timed (--cpu-literal-steps 0): value is null"
         return res, rmse

@@ -43,6 +43,8 @@ def lib():
     L.oekf_create.argtypes = [C.c_int, C.c_double, _f64p, C.c_double, C.c_double, C.c_double]
     L.oekf_destroy.argtypes = [C.c_void_p]
     L.oekf_set_mode.argtypes = [C.c_void_p, C.c_int]
+    L.od_set_threads.argtypes = [C.c_int]
+    L.od_get_threads.restype = C.c_int
     L.oekf_set_map.argtypes = [C.c_void_p, _f32p, _f64p, C.c_int]
     L.oekf_handle_odometry.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]
     L.oekf_handle_observation.restype = C.c_int
@@ -112,6 +114,10 @@ class OracleEKF:
             self.close()
         except Exception:
             pass
+
+    def set_threads(self, n: int):
+        """Threads of the structured mode's column-parallel loops (process-wide; 1 = the reference's own build).  Bit-identical results."""
+        self._L.od_set_threads(int(n))
 
     def set_mode(self, literal: bool):
         self._L.oekf_set_mode(self._h, 1 if literal else 0)

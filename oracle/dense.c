@@ -16,10 +16,33 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* Threads for the structured-mode baseline's row/column-parallel loops (bench.py's "all cores" figure).  1 = the
+ * reference's own build (no OpenMP, CMakeLists.txt:4).  Columns of C are dealt out in chunks that start on multiples of four, so every
+ * element sees the same operations in the same order whatever the thread count: results are bit-identical. */
+static int od_threads = 1;
+void od_set_threads(int n) { od_threads = n < 1 ? 1 : n; }
+int od_get_threads(void) { return od_threads; }
+
+static void od_gemm_acc_1(int M, int N, int K, double alpha,
+                          const double *A, int lda, const double *B, int ldb,
+                          double *C, int ldc);
 /* C(MxN) += alpha * A(MxK) * B(KxN), all column-major. */
 void od_gemm_acc(int M, int N, int K, double alpha,
                  const double *A, int lda, const double *B, int ldb,
                  double *C, int ldc)
+{
+    if (od_threads <= 1 || N < 16) { od_gemm_acc_1(M, N, K, alpha, A, lda, B, ldb, C, ldc); return; }
+    const int W = 16;                                    /* columns per chunk: a multiple of the kernel's four */
+    const int chunks = (N + W - 1) / W;
+#pragma omp parallel for schedule(static) num_threads(od_threads)
+    for (int c = 0; c < chunks; ++c) {
+        const int j0 = c * W, nj = (N - j0 < W) ? (N - j0) : W;
+        od_gemm_acc_1(M, nj, K, alpha, A, lda, B + (size_t)j0 * ldb, ldb, C + (size_t)j0 * ldc, ldc);
+    }
+}
+static void od_gemm_acc_1(int M, int N, int K, double alpha,
+                          const double *A, int lda, const double *B, int ldb,
+                          double *C, int ldc)
 {
     enum { MB = 256, KB = 128 };
     for (int k0 = 0; k0 < K; k0 += KB) {

@@ -38,6 +38,7 @@ void od_gemm(int M, int N, int K, const double *A, int lda, const double *B,
              int ldb, double *C, int ldc);
 void od_transpose(int M, int N, const double *A, int lda, double *B, int ldb);
 int od_lu_inverse(int m, double *A, int lda);
+int od_get_threads(void);
 
 enum { OEKF_DIFF = 0, OEKF_OMNI = 1 };
 
@@ -399,6 +400,7 @@ int oekf_handle_observation(oekf_t *e, double t, const float *obs, int K,
                 od_gemm(m, m, N, H, m, PHt, N, S, m);                 /* H * (sigma H^T) */
             } else {
                 /* column gather: (P H^T)(r, j) = sum over the <=5 nonzeros of H row j */
+#pragma omp parallel for schedule(static) num_threads(od_get_threads()) if (od_get_threads() > 1)
                 for (int j = 0; j < m; ++j) {
                     double *w = PHt + (size_t)j * N;
                     memset(w, 0, sizeof(double) * (size_t)N);
@@ -443,6 +445,7 @@ int oekf_handle_observation(oekf_t *e, double t, const float *obs, int K,
         } else {
             /* HP from rows of P, then P -= K * HP */
             double *HP = (double *)malloc(sizeof(double) * (size_t)m * N);
+#pragma omp parallel for schedule(static) num_threads(od_get_threads()) if (od_get_threads() > 1)
             for (int cidx = 0; cidx < N; ++cidx) {
                 const double *pc = e->P + (size_t)cidx * N;
                 for (int i = 0; i < m; ++i) {

@@ -7,6 +7,8 @@ which calibrates it.  Usage: python scripts/pmc_summary.py fetch.db write.db tag
 import json, sqlite3, sys, statistics
 fdb, wdb, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 last = int(sys.argv[4]) if len(sys.argv) > 4 else 50
+outdir = sys.argv[5] if len(sys.argv) > 5 else "profiles"
+commit = sys.argv[6] if len(sys.argv) > 6 else None
 def per_kernel(path, counter):
     db = sqlite3.connect(path)
     rows = db.execute("select kernel_name, value, start from counters_collection where counter_name=? order by start", (counter,)).fetchall()
@@ -22,11 +24,11 @@ for k in sorted(set(F) | set(W)):
     f = statistics.mean(F.get(k, [0])); w = statistics.mean(W.get(k, [0]))
     hbm = (2 * f + w) * 1024
     lines.append(f"{k[:44]:44s} {f:10.1f} {w:10.1f} {hbm/1e6:8.2f}")
-    # the downdate inside the update chain: k_dd_front<64> (lazy downdate: with the next scan's front end in 32 further workgroups,
-    # which move a few KB); the stand-alone k_downdate2<64> only where nothing runs as k_dd_front
-    if "k_dd_front<64" in k or ("k_downdate2<64" in k and not out):
-        out = {"kernel": k, "fetch_size_kb": f, "write_size_kb": w, "hbm_bytes_per_launch": hbm,
+    # since round 5 an update is ONE launch, k_mid<4, 0> (mid role + the previous scan's downdate role + the next scan's speculative
+    # front end): its traffic is the downdate's plus a few MB of gathers and panels
+    if "k_mid<4, 0>" in k:
+        out = {"kernel": k, "fetch_size_kb": f, "write_size_kb": w, "hbm_bytes_per_launch": hbm, "_commit": commit,
                "note": "2*FETCH_SIZE + WRITE_SIZE, KB->bytes; see profiles/%s_pmc.txt" % tag}
-open(f"profiles/{tag}_pmc.txt", "w").write("\n".join(lines) + "\n")
-json.dump(out, open("profiles/pmc_downdate.json", "w"), indent=1)
+open(f"{outdir}/{tag}_pmc.txt", "w").write("\n".join(lines) + "\n")
+json.dump(out, open(f"{outdir}/pmc_downdate.json", "w"), indent=1)
 print("\n".join(lines)); print(out)

@@ -23,4 +23,8 @@ print(f"total kernel time {tot:.1f} us over {len(rows)} dispatches" + (f" (last 
 if "--json" in sys.argv:
     import json
     path = sys.argv[sys.argv.index("--json") + 1]
-    json.dump({name.split("(")[0]: round(a, 3) for t, name, c, a, med, mn, mx, r in out}, open(path, "w"), indent=1)
+    commit = sys.argv[sys.argv.index("--commit") + 1] if "--commit" in sys.argv else None
+    js = {name.split("(")[0]: round(a, 3) for t, name, c, a, med, mn, mx, r in out}
+    js["_commit"] = commit                     # the tree these averages were measured on (tests/test_profiles_gpu.py checks it against the built library)
+    js["_last"] = last
+    json.dump(js, open(path, "w"), indent=1)
