@@ -439,6 +439,13 @@ def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world, cha
                        "committed summary; NOT measured in this run")
     except Exception:
         pass
+    mfma_busy, mfma_src = None, None
+    try:
+        mj = json.load(open(os.path.join(ROOT, "profiles", "pmc_mfma.json")))
+        mfma_busy = mj.get("sq_valu_mfma_busy_cycles_median")
+        mfma_src = "profiles/pmc_mfma.json (committed rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES summary of k_mid<4, 0>; NOT measured in this run)"
+    except Exception:
+        pass
     moved = (traffic / (t_frac * 1e-6) / 1e9) if traffic else None
     out["roofline"] = {
         "kernel": "k_mid<4, 0>: ONE launch per update -- the scan's mid role (gather, 64 x 64 inverse, gain: the latency chain that sets the "
@@ -472,9 +479,12 @@ def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world, cha
                  "frac_downdate_role": (flop_exec / (dd_role_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF) if dd_role_us else None,
                  "frac_fullsquare_flop": flop_k7 / (t_frac * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF,
                  "frac_back_to_back": flop_exec / (dd_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF,
+                 "counter_busy_cycles": mfma_busy, "counter_source": mfma_src,
+                 "frac_by_counter": (mfma_busy / (1024.0 * t_frac * 1e-6 * 2.4e9)) if mfma_busy else None,
                  "note": f"frac = the downdate role's EXECUTED MFMA FLOP ({tiles_exec} lower-triangle tiles x 2*64*64*64) over avg_launch_us (the mid "
                          "role's MFMAs -- correction, inverse, gain -- are not counted); frac_downdate_role over the role's own span; "
-                         "frac_fullsquare_flop = the reference's 2 n^2 m over avg_launch_us"}}
+                         "frac_fullsquare_flop = the reference's 2 n^2 m over avg_launch_us; frac_by_counter = SQ_VALU_MFMA_BUSY_CYCLES of the whole launch (both roles; "
+                         "committed counter pass) over 1024 SIMDs x avg_launch_us at 2.4 GHz"}}
     out["kernel_us"] = kernel_us
     if ms_result is not None:
         out["multi_session"] = ms_result
