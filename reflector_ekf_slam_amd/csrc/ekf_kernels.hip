@@ -1461,11 +1461,21 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
 #ifdef REKF_DEBUG_MID_FINE
     MMARK();                                        // (f2: stage loads issued (slow path), tables set up)
 #endif
-    v2du ps[PS_IT][2], cpv[PS_IT][2], raw2v[PS_IT];
+    v2du ps[PS_IT][2];
     const double *__restrict__ cpP = d.cp + (size_t)(A.corr_post & 1) * REKF_CP_LD * REKF_CP_LD;
+    constexpr int FP_IT = (LT::NUS * (REKF_CP_LD / 2) + 255) / 256;           // the write-ahead panel, 16 bytes per thread and pass
+    v2d fpv[FP_IT];
     int blk_u[PS_IT], blk_v[PS_IT];                                           // row slot u, column slot v of this thread's blocks (-1: none)
     v2d pw[PW_IT];
-    if (steam) {
+    if (steam && use_cp) {
+        // the sub-block AFTER the pending scan's update is in that scan's write-ahead panel (phase G of its k_mid): 36 KB, read linearly
+#pragma unroll
+        for (int it = 0; it < FP_IT; ++it) {
+            const int e = tt + 256 * it, row = e / (REKF_CP_LD / 2), c2 = 2 * (e - row * (REKF_CP_LD / 2));
+            fpv[it] = (v2d){0, 0};
+            if (row < nus && c2 <= row) fpv[it] = *(const v2d *)(cpP + (size_t)row * REKF_CP_LD + c2);
+        }
+    } else if (steam) {
         const int nblk = nrs * (nrs + 1) / 2;
 #pragma unroll
         for (int it = 0; it < PS_IT; ++it) {
@@ -1483,16 +1493,6 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
             const char *rp = (const char *)(P + slot_row(u)) + (unsigned)slot_row(v) * ldb;
             ps[it][0] = *(const v2du *)rp;                                  // rows (r, r+1) of column c
             ps[it][1] = *(const v2du *)(rp + ldb);                          // ... of column c + 1
-            cpv[it][0] = (v2du){0, 0}; cpv[it][1] = (v2du){0, 0}; raw2v[it] = (v2du){0, 0};
-            if (use_cp) {
-                // the write-ahead correction of the block (rows su, su + 1 of the panel, columns sv, sv + 1) and, for the columns 0, 1 the
-                // pending Predict touches, column 2 of the block's rows
-                const int su = (u < 2) ? 2 * u : 2 * u - 1, sv = (v < 2) ? 2 * v : 2 * v - 1;
-                const double *cq = cpP + (size_t)su * REKF_CP_LD + sv;
-                cpv[it][0] = *(const v2du *)cq;
-                cpv[it][1] = *(const v2du *)(cq + REKF_CP_LD);
-                if (cpred && v == 0 && u >= 2) raw2v[it] = *(const v2du *)((const char *)(P + slot_row(u)) + 2u * ldb);
-            }
         }
     } else {
         // sub-block row s -> its global row, for s = lane and s = 64 + lane, once: the loop fetches it with a shuffle
@@ -1580,7 +1580,19 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     // stored values -> LDS.  s_pu is [sub-block row][sub-block row], both triangles: a block goes in twice, as fetched and transposed.
     // Slot 1 stands for row / column 2 ALONE: its second row (3) is fetched but not used.
     auto slot_s = [](int u) __attribute__((always_inline)) -> int { return (u < 2) ? 2 * u : 2 * u - 1; };     // first sub-block row of a slot
-    if (steam) {
+    if (steam && use_cp) {
+        // elements (row, c2), (row, c2 + 1) of the lower triangle, mirrored; the pose block by value (the pending scan's post_C9)
+#pragma unroll
+        for (int it = 0; it < FP_IT; ++it) {
+            const int e = tt + 256 * it, row = e / (REKF_CP_LD / 2), c2 = 2 * (e - row * (REKF_CP_LD / 2));
+            if (row < nus && c2 <= row) {
+                double v0 = fpv[it].x, v1 = fpv[it].y;
+                if (row < 3) { v0 = s_cpred[2 + row + 3 * c2]; v1 = (c2 + 1 <= row) ? s_cpred[2 + row + 3 * (c2 + 1)] : 0.0; }
+                s_pu[row][c2] = v0; s_pu[c2][row] = v0;
+                if (c2 + 1 <= row) { s_pu[row][c2 + 1] = v1; s_pu[c2 + 1][row] = v1; }
+            }
+        }
+    } else if (steam) {
 #pragma unroll
         for (int it = 0; it < PS_IT; ++it) {
             const int u = blk_u[it], v = blk_v[it];
@@ -1588,20 +1600,6 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
                 const int su = slot_s(u), sv = slot_s(v);
                 const bool ua = u != 1, ve = v != 1;
                 double b00 = ps[it][0].x, b10 = ps[it][0].y, b01 = ps[it][1].x, b11 = ps[it][1].y;   // b[a][e] = P(r + a, c + e)
-                if (use_cp) {
-                    // stored (+ pending Predict) + write-ahead correction; the pose block by value (the pending scan's post_C9)
-#pragma clang fp contract(off)
-                    auto fix = [&](double raw, double r2, double cc, int row_s, int col_s) __attribute__((always_inline)) -> double {
-                        if (row_s < 3) return s_cpred[2 + (row_s > col_s ? row_s : col_s) + 3 * (row_s > col_s ? col_s : row_s)];
-                        double val = raw;
-                        if (cpred && col_s < 2) val = val + s_cpred[col_s] * r2;
-                        return val + cc;
-                    };
-                    b00 = fix(b00, raw2v[it].x, cpv[it][0].x, su, sv);
-                    b10 = fix(b10, raw2v[it].y, cpv[it][1].x, su + 1, sv);
-                    b01 = fix(b01, raw2v[it].x, cpv[it][0].y, su, sv + 1);
-                    b11 = fix(b11, raw2v[it].y, cpv[it][1].y, su + 1, sv + 1);
-                }
                 if (u == v) b01 = b10;                                      // a diagonal block: (r, r+1) lies above the diagonal
                 s_pu[su][sv] = b00;
                 if (ua) s_pu[su + 1][sv] = b10;
@@ -2150,8 +2148,14 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
             double *cpo = d.cp + (size_t)(d.post_slot & 1) * REKF_CP_LD * REKF_CP_LD;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+#pragma clang fp contract(off)
+                // the element AFTER this scan's update, in the downdate's own order: (stored [+ this scan's Predict on columns 0, 1]) + sum_k
                 const int sj = 16 * bvw + g4 + 4 * r;
-                if (s_hi >= 0 && sj <= s_hi) store_wt(&cpo[(size_t)s_hi * REKF_CP_LD + sj], acc[r]);
+                if (s_hi >= 0 && sj <= s_hi) {
+                    double base = s_pw[sj][c16];
+                    if (do_pred && sj < 2) base = base + s_pred[sj] * s_pw[2][c16];
+                    store_wt(&cpo[(size_t)s_hi * REKF_CP_LD + sj], base + acc[r]);
+                }
             }
         }
     }
