@@ -1013,8 +1013,18 @@ constexpr int REKF_DD_LDS_BYTES = 4 * 64 * 64 * (int)sizeof(double);      // the
 // front end (MODE 2: exclusive handles only, rekf_api.hip).
 template <int KC, bool QUEUE> __device__ __forceinline__ void dd_body(const RekfDev &d, double *dd_smem, int wg, int nwg, unsigned *queue, bool pub_wg);
 template <int NBR, int MODE>
-__global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, RekfFrontArgs A, RekfDev dp, RekfFrontArgs An)
+__global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d_arg, RekfFrontArgs A_arg, RekfDev dp_arg, RekfFrontArgs An_arg)
 {
+    // The four argument structs are read THROUGH the kernel-argument segment, where a role needs a field: named as parameters, every field
+    // any role uses is fetched into SGPRs (and spilled) by every wave at the kernel's entry -- in front of the mid role's first loads, the
+    // head of the update's critical chain
+    static_assert(sizeof(RekfDev) % 8 == 0 && sizeof(RekfFrontArgs) % 8 == 0, "kernel-argument offsets below");
+    const char *const kargs = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
+    const RekfDev &d = *(const RekfDev *)(kargs + 8);
+    const RekfFrontArgs &A = *(const RekfFrontArgs *)(kargs + 8 + sizeof(RekfDev));
+    const RekfDev &dp = *(const RekfDev *)(kargs + 8 + sizeof(RekfDev) + sizeof(RekfFrontArgs));
+    const RekfFrontArgs &An = *(const RekfFrontArgs *)(kargs + 8 + 2 * sizeof(RekfDev) + sizeof(RekfFrontArgs));
+    (void)d_arg; (void)A_arg; (void)dp_arg; (void)An_arg;
     constexpr bool FRONT = (MODE & 2) != 0, AUGR = (MODE & 1) != 0, AUGW = MODE >= 1, DDROLE = MODE != 1;
     // ctl_first = d.ctl, as a leading pointer argument of its own: built with -mllvm -amdgpu-kernarg-preload-count the wave starts with it
     // in SGPRs, and the kernel's first loads (the match results) do not wait for the kernel-argument fetch
@@ -1046,6 +1056,13 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
     // gather, W rows of S, S, its inverse -- waves 4..7 everything that only this workgroup's 16 rows / columns need
     // (H rows, own gathers, (H P)^T to HBM), off that chain; both meet at the barriers.
     RekfCtl *ctl = ctl_first;
+#ifdef REKF_DEBUG_TIMING
+    if (threadIdx.x == 0) {                         // (launch-level timeline: first entry of any workgroup, over the handle's life)
+        const long long wnow = wall_clock64();
+        if (ctl->dbg[28] == 0) ctl->dbg[28] = wnow;
+        atomicMin((unsigned long long *)&ctl->dbg[28], (unsigned long long)wnow);
+    }
+#endif
     // ---- roles of the grid: [front end: A.front_in_mid workgroups][mid: A.n_mid][(idle up to A.dd_first)][downdate: the rest]
     if constexpr (DDROLE) {
         if (A.dd_in_mid && (int)blockIdx.x >= A.dd_first) {
@@ -1613,14 +1630,6 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
                 }
             }
         }
-    } else {
-        const int pr = tid & 7, sub = (tid >> 3) & 7;
-        const int kc0 = __builtin_amdgcn_readfirstlane(wave & 3);
-#pragma unroll
-        for (int it = 0; it < PW_IT; ++it) {
-            const int kc = 8 * (kc0 + 4 * it) + sub;
-            if (kc < nus) *(v2d *)&s_pw[kc][2 * pr] = pw[it];
-        }
     }
     if (slow_corr) {
         if (st_live) {
@@ -1718,8 +1727,18 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
             }
         }
     }
-    __syncthreads();
-    MMARK();                                        // 2: H rows and P values in LDS
+    lds_barrier();                                  // (LDS only: the own team's gathers may still be in flight -- nobody needs them before phase E)
+    MMARK();                                        // 2: H rows and the sub-block in LDS
+    if (!steam) {
+        // the own rows' stored values -> LDS (read by the own team itself, behind the next barrier: own_correct / own_w under the inverse)
+        const int pr = tid & 7, sub = (tid >> 3) & 7;
+        const int kc0 = __builtin_amdgcn_readfirstlane(wave & 3);
+#pragma unroll
+        for (int it = 0; it < PW_IT; ++it) {
+            const int kc = 8 * (kc0 + 4 * it) + sub;
+            if (kc < nus) *(v2d *)&s_pw[kc][2 * pr] = pw[it];
+        }
+    }
 
     // (phase E multiplies the landmark rows of W of a CLAMPED pair by the zero coefficients of rows that have no landmark block:
     // with no state pair at all -- a scan that matched the pre-loaded map only -- that pair does not exist, and whatever the
@@ -1933,8 +1952,8 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
             }
         }
     };
-    __syncthreads();
-    MMARK();                                        // 3: W rows in LDS, (H P)^T stored
+    lds_barrier();                                  // (LDS only: the own team's operand loads stay in flight)
+    MMARK();                                        // 3: W rows of S in LDS
 
     // ---- E: S = H W + Q in the C layout (wave w = block column w), inverse, S^-1 -> LDS
     const int nbr = m_pad >> 4;
@@ -2160,6 +2179,12 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d, Rekf
         }
     }
 #if defined(REKF_DEBUG_TIMING) && !defined(REKF_DEBUG_DD2)
+    if (tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        atomicMax((unsigned long long *)&ctl->dbg[30], (unsigned long long)wall_clock64());      // last exit of a mid workgroup
+        if (first) ctl->dbg[29] = wall_clock64();                                                 // workgroup 0's exit
+        if (bx == A.n_mid - 1) ctl->dbg[25] = w_entrym;                                           // the last mid workgroup's entry
+    }
     if (recm) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ctl->dbg[6] = clock64() - t_entrym;

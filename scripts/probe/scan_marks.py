@@ -24,6 +24,9 @@ for rep in range(3):
     o = list(out)
     ghz = o[6] / max(o[5], 1) * 0.1
     print("mid wg 1: %.2f us @ %.2f GHz marks(us):" % (o[5] * 0.01, ghz), [round(x / ghz / 1e3, 2) for x in o[8:8 + o[7]]])
+    if o[28]:
+        print("   launch timeline (us after the first workgroup's entry): mid wg 1 in %.2f out %.2f | last mid wg in %.2f | wg 0 out %.2f | last mid out %.2f | dd role first in %.2f, last out %.2f"
+              % tuple((o[q] - o[28]) * 0.01 for q in (4, 31, 25, 29, 30, 26, 27)))
     if o[26]:
         t0 = o[4]
         print("   relative to mid wg 1's entry: its exit %.2f | first downdate wg: entry %.2f exit %.2f | LAST downdate wg exit %.2f us"
