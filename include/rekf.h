@@ -25,12 +25,17 @@
  *    back yet, the first odometry message behind it waits for that pose to be published (never, in the reference's
  *    call pattern: its node reads the pose after every scan, src/ros_node.cc:514-515).  rekf_get_pose and
  *    rekf_predict_state between scans are answered from the mirror without touching the device.
- *  - LAZY DOWNDATE: of the work a scan enqueues, the covariance downdate (reflector_ekf_slam.cc:308) and the landmark augmentation
- *    (:311-364) are held back and enqueued with the NEXT call -- with the next scan they share a launch with that scan's front end
- *    (Predict's pose and ReflectorMatch need the mean and the pose block of this scan's update, nothing else of P).  Every entry
- *    point that reads the device state (the getters, rekf_handle_odometry, rekf_sync, rekf_predict_state*, rekf_reserve,
- *    rekf_device_layout) enqueues them first: no caller can observe a state without them.  Callers that read device memory through
- *    their own HIP calls must call rekf_device_layout or rekf_sync each time.  REKF_LAZY_DD=0 in the environment turns it off.
+ *  - PENDING WORK (rounds 3-5).  Of the work a scan enqueues, the covariance downdate (reflector_ekf_slam.cc:308) and the landmark
+ *    augmentation (:311-364) are held back and go out with the NEXT call: with the next scan they run beside that scan's update (the
+ *    stored covariance is kept one scan behind the filter; the update corrects what it reads of it -- same bits).  A caller that hands
+ *    scan after scan over WITHOUT reading anything back in between also has its NEWEST SCAN held on the host until the next call:
+ *    that scan's launch then carries the next scan's ReflectorMatch with it, speculatively, one launch early (proved or repaired by
+ *    the next scan's update: identical association lists by construction).  Every entry point that reads the state (the getters,
+ *    rekf_handle_odometry, rekf_sync, rekf_predict_state*, rekf_reserve, rekf_device_layout, ...) sends whatever is held first: no
+ *    caller can observe a state without it, and a caller that reads the pose after every scan (the reference's node) is never held.
+ *    An error of a held scan is reported by the call that sends it.  Callers that read device memory through their own HIP calls must
+ *    call rekf_device_layout or rekf_sync each time.  REKF_LAZY_DD=0 / REKF_SPEC=0 / REKF_SCAN_LAUNCH=0 in the environment turn the
+ *    pieces off (A/B measurements; same results).
  *  - the covariance lives in HBM for the life of the handle, column-major like
  *    Eigen::MatrixXd (ekf_slam_interface.h:47) with a fixed leading dimension, as its LOWER TRIANGLE (element (i, j) is
  *    valid iff i >= j; nothing reads the memory above the diagonal); the getters mirror it into the caller's n x n buffer.
