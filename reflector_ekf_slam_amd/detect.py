@@ -181,8 +181,8 @@ class LaserReflectorDetect:
         if ranges.shape != inten.shape:
             raise ValueError("ranges and intensities differ in length")
         out = _result_slots(self)
-        rc = self._L.rdet2d_handle_scan(self._h, msg.stamp, msg.angle_min, msg.angle_max, msg.angle_increment,
-                                        msg.scan_time, msg.range_min, msg.range_max, ranges.ctypes.data, inten.ctypes.data,
+        rc = self._L.rdet2d_handle_scan(self._h, float(msg.stamp), float(msg.angle_min), float(msg.angle_max), float(msg.angle_increment),
+                                        float(msg.scan_time), float(msg.range_min), float(msg.range_max), ranges.ctypes.data, inten.ctypes.data,
                                         ranges.shape[0], out[3], MAX_CENTERS, out[4], out[5])
         if rc != 0:
             raise RdetError(rc, "HandleLaserScan")
@@ -230,7 +230,7 @@ class PointCloudReflectorDetect:
         if pts.size & 3:
             raise ValueError("points are (x, y, z, intensity) quadruples")
         out = _result_slots(self)
-        rc = self._L.rdet3d_handle_cloud(self._h, stamp, pts.ctypes.data, pts.size >> 2, out[3], MAX_CENTERS, out[4], out[5])
+        rc = self._L.rdet3d_handle_cloud(self._h, float(stamp), pts.ctypes.data, pts.size >> 2, out[3], MAX_CENTERS, out[4], out[5])
         if rc != 0:
             raise RdetError(rc, "HandlePointCloud")
         return Observation(float(out[2][0]), out[0][: int(out[1][0])].copy())
