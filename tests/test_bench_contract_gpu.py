@@ -69,12 +69,16 @@ def test_driver_command_steps20_warmup5_has_every_object():
         assert lat[leg]["n"] == 1000 and 5.0 < lat[leg]["median"] <= lat[leg]["p99"] < 5000.0
     p5 = d["with_5_predicts_per_scan"]
     assert p5["predicts_per_scan"] == 5 and 1000 < p5["value"] < d["value"] * 1.2
-    assert d["kernel_us"]["downdate"] > 1.0
+    assert d["kernel_us"]["mid"] > 1.0 and d["kernel_us"]["downdate"] is None   # (the downdate is a role of k_mid's launch: no launch of its own in the steady state)
+    ex = lat["exclusive_handle"]
+    assert 5.0 < ex["host_sync_median"] < 5000.0 and 5.0 < ex["host_sync_idle_device_median"] < 5000.0
+    assert c["structured_all_cores"] >= 1 and c["structured_all_cores_value"] > 1.0
     assert 0.05 < d["kernel_us"]["odometry_message_plus_get_pose_host_us"] < 50.0     # no launch: host pose mirror
     nf = d["not_full"]
     assert "error" not in nf, nf
     assert nf["max_landmarks"] == 2048 and nf["n"] == 2051 and nf["value"] > 5000 and nf["with_pose_readback"]["value"] > 3000
     assert nf["kernel_us"]["augment"] is not None      # no launch of this library contains a waiting workgroup by default: k_augment is a launch of its own again
+    assert nf["exclusive_handle"]["value"] > 5000
     assert d["multi_session"]["sessions_bit_identical"] is True
     det = d["detectors"]
     assert "error" not in det, det
