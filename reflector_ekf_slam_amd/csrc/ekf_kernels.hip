@@ -1013,17 +1013,27 @@ constexpr int REKF_DD_LDS_BYTES = 4 * 64 * 64 * (int)sizeof(double);      // the
 // front end (MODE 2: exclusive handles only, rekf_api.hip).
 template <int KC, bool QUEUE> __device__ __forceinline__ void dd_body(const RekfDev &d, double *dd_smem, int wg, int nwg, unsigned *queue, bool pub_wg);
 template <int NBR, int MODE>
-__global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d_arg, RekfFrontArgs A_arg, RekfDev dp_arg, RekfFrontArgs An_arg)
+__global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, int h0, int h1, int h2, int h3, int h4, int h5, RekfDev d_arg, RekfFrontArgs A_arg, RekfDev dp_arg, RekfFrontArgs An_arg)
 {
+    // h0 .. h5: the handful of launch-packet fields the kernel's FIRST instructions need (which role a workgroup has; which parity slots of
+    // the control block the mid role's first loads read), packed by mid_head() into six leading scalar arguments: with
+    // -amdgpu-kernarg-preload-count they arrive in SGPRs with the wave, so those loads issue without a trip to the kernel-argument segment
+    const int hd_pred_slot = h0 & 1, hd_pred_ix = (h0 >> 1) & 3, hd_corr = (h0 >> 3) & 1, hd_corr_post = (h0 >> 4) & 1, hd_corr_pred_ix = (h0 >> 5) & 3,
+              hd_spec = (h0 >> 7) & 1, hd_cpred = (h0 >> 8) & 1, hd_dd_par = (h0 >> 9) & 1;
+    const int hd_K = h1;
+    const unsigned hd_scan_id = (unsigned)h2, hd_corr_scan = (unsigned)h3;
+    const int hd_dd_first = h4 & 0xfff, hd_n_mid = (h4 >> 12) & 0xfff, hd_spec_front = (h4 >> 24) & 0xff;
+    const int hd_dd_in_mid = h5 & 0xfff, hd_front_in_mid = (h5 >> 12) & 0xff;
     // The four argument structs are read THROUGH the kernel-argument segment, where a role needs a field: named as parameters, every field
     // any role uses is fetched into SGPRs (and spilled) by every wave at the kernel's entry -- in front of the mid role's first loads, the
     // head of the update's critical chain
     static_assert(sizeof(RekfDev) % 8 == 0 && sizeof(RekfFrontArgs) % 8 == 0, "kernel-argument offsets below");
     const char *const kargs = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
-    const RekfDev &d = *(const RekfDev *)(kargs + 8);
-    const RekfFrontArgs &A = *(const RekfFrontArgs *)(kargs + 8 + sizeof(RekfDev));
-    const RekfDev &dp = *(const RekfDev *)(kargs + 8 + sizeof(RekfDev) + sizeof(RekfFrontArgs));
-    const RekfFrontArgs &An = *(const RekfFrontArgs *)(kargs + 8 + 2 * sizeof(RekfDev) + sizeof(RekfFrontArgs));
+    constexpr int KOFF = 8 + 6 * 4;               // ctl pointer + six ints (= 32: the structs keep their 8-byte alignment)
+    const RekfDev &d = *(const RekfDev *)(kargs + KOFF);
+    const RekfFrontArgs &A = *(const RekfFrontArgs *)(kargs + KOFF + sizeof(RekfDev));
+    const RekfDev &dp = *(const RekfDev *)(kargs + KOFF + sizeof(RekfDev) + sizeof(RekfFrontArgs));
+    const RekfFrontArgs &An = *(const RekfFrontArgs *)(kargs + KOFF + 2 * sizeof(RekfDev) + sizeof(RekfFrontArgs));
     (void)d_arg; (void)A_arg; (void)dp_arg; (void)An_arg;
     constexpr bool FRONT = (MODE & 2) != 0, AUGR = (MODE & 1) != 0, AUGW = MODE >= 1, DDROLE = MODE != 1;
     // ctl_first = d.ctl, as a leading pointer argument of its own: built with -mllvm -amdgpu-kernarg-preload-count the wave starts with it
@@ -1065,7 +1075,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d_arg, 
 #endif
     // ---- roles of the grid: [front end: A.front_in_mid workgroups][mid: A.n_mid][(idle up to A.dd_first)][downdate: the rest]
     if constexpr (DDROLE) {
-        if (A.dd_in_mid && (int)blockIdx.x >= A.dd_first) {
+        if (hd_dd_in_mid && (int)blockIdx.x >= hd_dd_first) {
             // the previous scan's downdate: waves 0..3 (the body is cut for 256 threads; a barrier counts the waves that have not ended)
             if (threadIdx.x < 256) {
                 // (two device time stamps, 100 MHz, for the bench's roofline: when the role's first workgroup starts, when its last one ends)
@@ -1078,7 +1088,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d_arg, 
         }
     }
     const int bxf = (int)blockIdx.x;
-    if (FRONT && bxf < A.front_in_mid) {
+    if (FRONT && bxf < hd_front_in_mid) {
         // A scan's front end as the FIRST workgroups of this grid instead of a launch of its own (7.5 us + a kernel boundary in front
         // of k_mid, on the path every read-back caller waits for); the mid workgroups wait for its count below.  One-way: the front
         // role waits for nobody, its workgroups are dispatched first and the grid's first 256 workgroups are resident together.
@@ -1092,9 +1102,9 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d_arg, 
         }
         return;
     }
-    const int bx = bxf - (FRONT ? A.front_in_mid : 0);          // this workgroup's number among the mid workgroups
+    const int bx = bxf - (FRONT ? hd_front_in_mid : 0);          // this workgroup's number among the mid workgroups
     if constexpr (DDROLE && !FRONT) {
-        if (A.spec_front > 0 && bx >= A.n_mid && bx < A.n_mid + A.spec_front) {
+        if (hd_spec_front > 0 && bx >= hd_n_mid && bx < hd_n_mid + hd_spec_front) {
             // the NEXT scan's front end, speculatively (RekfCtl::spec): against the mean this launch's mid role starts from; nobody in
             // this launch waits for it.  Then it helps the downdate role.
             front_role<512, true>(d, An, bx - A.n_mid, A.spec_front, false);
@@ -1105,11 +1115,11 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d_arg, 
             return;
         }
     }
-    if (bx >= A.n_mid) return;
+    if (bx >= hd_n_mid) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool steam = wave < 4;                  // S team; the other is the "own" team
     const int tt = tid & 255;                     // thread index within the team
-    if (bx == 0 && tid == 511) { ctl->dd_queue[(A.dd_par ^ 1) & 1] = 0u; ctl->dmmax[(A.pred_ix + 1) & 3] = 0ull; }     // the next launch's tile queue (and mean-shift bound) start empty
+    if (bx == 0 && tid == 511) { ctl->dd_queue[(hd_dd_par ^ 1) & 1] = 0u; ctl->dmmax[(hd_pred_ix + 1) & 3] = 0ull; }     // the next launch's tile queue (and mean-shift bound) start empty
     if (FRONT) {
         // every observation's result is in memory once the front end's count has reached the scan's target (each front workgroup
         // writes its result through, drains, then counts): wave 0 polls on one lane, takes the K results past this CU's L1 and
@@ -1138,12 +1148,12 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d_arg, 
     // scalar one, so the control block costs one memory round trip, not two
     constexpr int NREC = (int)(sizeof(RekfCtl::Rec) / sizeof(int));
     static_assert(NREC <= 512, "one load per thread");
-    const int rec_raw = (!FRONT && tid < NREC) ? ((const int *)&ctl->rec[A.pred_slot & 1])[tid] : 0;
+    const int rec_raw = (!FRONT && tid < NREC) ? ((const int *)&ctl->rec[hd_pred_slot])[tid] : 0;
     // ... and the pending scan's WRITE-AHEAD CORRECTION (RekfCtl::cp_*, RekfDev::cp; phase G below): which landmarks it covers
     int cp_uid_l = -1, cp_nu_l = -1;
     unsigned cp_scan_l = 0u;
-    if (DDROLE && A.corr && lane < 32) cp_uid_l = ctl->cp_uid[A.corr_post & 1][lane];
-    if (DDROLE && A.corr) { cp_nu_l = ctl->cp_nu[A.corr_post & 1]; cp_scan_l = ctl->cp_scan[A.corr_post & 1]; }
+    if (DDROLE && hd_corr && lane < 32) cp_uid_l = ctl->cp_uid[hd_corr_post][lane];
+    if (DDROLE && hd_corr) { cp_nu_l = ctl->cp_nu[hd_corr_post]; cp_scan_l = ctl->cp_scan[hd_corr_post]; }
 #ifdef REKF_DEBUG_MID_FIRST
     MMARK();                                        // (x0: first loads issued)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1197,9 +1207,9 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d_arg, 
         if constexpr (FRONT) return __longlong_as_double(__hip_atomic_load((const long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         else return *p;
     };
-    const bool spec = DDROLE && !FRONT && A.spec != 0;            // the record is speculative (RekfCtl::spec): no front end has run for this scan
+    const bool spec = DDROLE && !FRONT && hd_spec != 0;            // the record is speculative (RekfCtl::spec): no front end has run for this scan
     // (a speculative scan's Predict -- pose, (a, b), pose block -- was evaluated by workgroup 0 of the PREVIOUS scan's k_mid, at its end)
-    const double *pp_src = spec ? ctl->pose_next[A.pred_slot & 1] : ctl->pose_pred;
+    const double *pp_src = spec ? ctl->pose_next[hd_pred_slot] : ctl->pose_pred;
     const double pose[5] = {hp ? A.pre_pose[0] : ctl_f64(&pp_src[0]), hp ? A.pre_pose[1] : ctl_f64(&pp_src[1]), hp ? A.pre_pose[2] : ctl_f64(&pp_src[2]),
                             hp ? A.pre_pose[3] : ctl_f64(&pp_src[3]), hp ? A.pre_pose[4] : ctl_f64(&pp_src[4])};
     const bool pending = (FRONT || spec) ? true : ctl->pose_pending != 0;      // (the in-grid front role sets it beside us: a host-predicted scan always has one)
@@ -1210,15 +1220,15 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d_arg, 
     bool sp_rec_ok = false;
     if (spec) {
         // (everything the proof needs goes in flight now: behind the barrier only arithmetic is left)
-        const RekfCtl::Spec *sq = &ctl->spec[A.pred_slot & 1];
-        if (lane < A.K) {
+        const RekfCtl::Spec *sq = &ctl->spec[hd_pred_slot];
+        if (lane < hd_K) {
             sp_kind = sq->kind[lane & 31]; sp_idx = sq->idx[lane & 31]; sp_d1 = sq->d1[lane & 31]; sp_d2 = sq->d2[lane & 31];
             const double px = (double)rekf_obs(A, 2 * lane), py = (double)rekf_obs(A, 2 * lane + 1);
             sp_rng = sqrt(px * px + py * py);
         }
         sp_pose0 = sq->pose[0]; sp_pose1 = sq->pose[1]; sp_pose2 = sq->pose[2];
-        sp_dmm = __longlong_as_double((long long)ctl->dmmax[(A.pred_ix + 3) & 3]);
-        sp_rec_ok = sq->scan == A.scan_id && sq->n == ((d.n_known >= 0) ? d.n_known : -1);
+        sp_dmm = __longlong_as_double((long long)ctl->dmmax[(hd_pred_ix + 3) & 3]);
+        sp_rec_ok = sq->scan == hd_scan_id && sq->n == ((d.n_known >= 0) ? d.n_known : -1);
     }
     // the scan's pending Predict (RekfCtl::pred): applied to the gathered P in phase D.  (a, b) = 0 and the pose block as gathered
     // when nothing is pending (later block steps of a wide scan: the first step's downdate has committed it)
@@ -1227,13 +1237,13 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d_arg, 
     if (do_pred && tid >= 64 && tid < 64 + 11) {                          // ab[0], ab[1], C9[0..8]
         // (with the front role in this grid the control block's copy is being written beside us: a host-predicted scan carries the values)
         const int e = tid - 64;
-        s_pred[e] = (FRONT && hp) ? (e < 2 ? A.pre_ab[e] : A.pre_C9[e - 2]) : ctl_f64(&((const double *)&ctl->pred[A.pred_ix & 3])[e]);
+        s_pred[e] = (FRONT && hp) ? (e < 2 ? A.pre_ab[e] : A.pre_C9[e - 2]) : ctl_f64(&((const double *)&ctl->pred[hd_pred_ix])[e]);
     }
     // ... and what is PENDING on the stored P (A.corr): the previous scan's (a, b) and its pose block after the update
-    const bool corr = DDROLE && A.corr != 0, cpred = corr && A.corr_pred >= 0;     // (MODE 1, the two-launch chain of a filter that can still grow: never)
+    const bool corr = DDROLE && hd_corr != 0, cpred = corr && hd_cpred != 0;     // (MODE 1, the two-launch chain of a filter that can still grow: never)
     if (corr && tid >= 128 && tid < 128 + 11) {
         const int e = tid - 128;
-        s_cpred[e] = (e < 2) ? (cpred ? ctl->pred[A.corr_pred_ix & 3].ab[e] : 0.0) : ctl->post_C9[A.corr_post & 1][e - 2];
+        s_cpred[e] = (e < 2) ? (cpred ? ctl->pred[hd_corr_pred_ix].ab[e] : 0.0) : ctl->post_C9[hd_corr_post][e - 2];
     }
 
     // ---- A: the scan's matched pairs.  Whole scan (pair0 < 0): the record the front end left.  Block step of a wide scan (pair0 >= 0): the
@@ -1337,7 +1347,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, RekfDev d_arg, 
     {
         const int nu0 = (NS > 0) ? s_rec.nu : 0;
         const bool eq = lane >= 32 || lane >= nu0 || cp_uid_l == s_uid[lane];
-        use_cp = DDROLE && A.corr != 0 && A.pair0 < 0 && cp_scan_l == A.corr_scan && cp_nu_l == nu0 && __ballot(eq) == ~0ull;
+        use_cp = DDROLE && hd_corr != 0 && A.pair0 < 0 && cp_scan_l == hd_corr_scan && cp_nu_l == nu0 && __ballot(eq) == ~0ull;
     }
     if (first && A.pair0 < 0) {
         // ReflectorMatchResult for the getters (and n_new / m for the kernels behind this one), out of the record
@@ -2850,7 +2860,12 @@ template <int NBR, int MODE> static void launch_mid_as(int grid, int with_dd, hi
             g_dd_cache.attr_mid[slot] |= bit;
         }
     }
-    hipLaunchKernelGGL((k_mid<NBR, MODE>), dim3(grid), dim3(512), BYTES, s, d.ctl, d, a, dp, an);
+    // (the fields the kernel's first instructions need, as leading scalars: k_mid)
+    const int h0 = (a.pred_slot & 1) | ((a.pred_ix & 3) << 1) | ((a.corr ? 1 : 0) << 3) | ((a.corr_post & 1) << 4) | ((a.corr_pred_ix & 3) << 5) |
+                   ((a.spec ? 1 : 0) << 7) | ((a.corr && a.corr_pred >= 0 ? 1 : 0) << 8) | ((a.dd_par & 1) << 9);
+    const int h4 = (a.dd_first & 0xfff) | ((a.n_mid & 0xfff) << 12) | ((a.spec_front & 0xff) << 24);
+    const int h5 = (a.dd_in_mid & 0xfff) | ((a.front_in_mid & 0xff) << 12);
+    hipLaunchKernelGGL((k_mid<NBR, MODE>), dim3(grid), dim3(512), BYTES, s, d.ctl, h0, a.K, (int)a.scan_id, (int)a.corr_scan, h4, h5, d, a, dp, an);
 }
 void rekf_launch_mid(const RekfDev &d, RekfFrontArgs &a, int n_ub, int m_ub, bool mode_grow, hipStream_t s)
 {

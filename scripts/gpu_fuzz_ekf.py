@@ -4,7 +4,11 @@ ragged / empty scans, pre-loaded map, pose observations, negative dt.  One JSON 
 GPU box: python scripts/gpu_fuzz_ekf.py [n_seeds] [first_seed] [burst]
 With `burst` the scans are enqueued in bursts of 2..12 without any read-back in between (the pipelined chain: k_dd_front, the previous
 scan's augmentation inside k_mid) on filters that can grow all session long (capacity 2 L, or L / 2 with auto-grow), compared with the
-oracle at the end of every burst."""
+oracle at the end of every burst.
+With `steady` every session whose filter ends FULL (cap = L, every reflector seen) is followed by 60-200 steady-state scans handed over in
+bursts of 1..15 WITHOUT odometry or read-backs in between -- ragged (1..K observations), some with a pose observation, some with an observation
+pushed onto the 0.6 m gate: the one-launch-per-scan form with its speculative match, write-ahead panel hits and misses, proof failures --
+compared with the oracle (associations, mean, covariance) at the end of every burst."""
 import json, sys, time
 sys.path.insert(0, ".")
 import numpy as np
@@ -14,6 +18,7 @@ from tests.helpers import make_gpu, make_oracle, norm_match
 n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 burst_mode = len(sys.argv) > 3 and sys.argv[3] == "burst"
+steady_mode = len(sys.argv) > 3 and sys.argv[3] == "steady"
 bad = 0
 t_start = time.time()
 for seed in range(first, first + n_seeds):
@@ -27,7 +32,7 @@ for seed in range(first, first + n_seeds):
                               range_max=float(rng.choice([8.0, 10.0, 14.0])), extra_scans=int(rng.integers(0, 30)))
     sess = synth.make_session(cfg, max_scans=int(rng.integers(60, 220)) if L < 140 else int(rng.integers(300, 900)))
     lin, ang, obs = cfg.sigma_v ** 2, cfg.sigma_w ** 2, cfg.sigma_obs ** 2
-    cap = L if rng.random() < 0.7 else max(4, L // 2)                     # sometimes a capacity the session overflows
+    cap = L if (rng.random() < 0.7 or steady_mode) else max(4, L // 2)   # sometimes a capacity the session overflows
     if burst_mode:
         cap = 2 * L if rng.random() < 0.5 else max(4, L // 2)
     g = make_gpu(model, sess.init_time, sess.init_pose, lin, ang, obs, cap)
@@ -85,6 +90,33 @@ for seed in range(first, first + n_seeds):
             assoc_bad += 1
             break
         worst = max(worst, float(np.abs(mg - mo).max()))
+    steady_scans = 0
+    if steady_mode and not overflow and not assoc_bad and g.mu().shape[0] == 3 + 2 * L:
+        tail = synth.steady_state_scans(sess, int(rng.integers(60, 200)), seed_offset=seed)
+        left = 0
+        for t, ob in tail:
+            ob = np.array(ob[: int(rng.integers(1, ob.shape[0] + 1))] if rng.random() < 0.3 else ob, np.float32, copy=True)
+            if rng.random() < 0.03 and ob.shape[0] > 0:                      # onto the gate: the margin proof must fail there
+                j = int(rng.integers(0, ob.shape[0])); phi = rng.uniform(0, 2 * np.pi)
+                ob[j] += np.float32(0.6 + rng.choice([-2e-3, -2e-4, 2e-4, 2e-3])) * np.array([np.cos(phi), np.sin(phi)], np.float32)
+            gps = None
+            if use_gps and rng.random() < 0.3:
+                gps = np.concatenate([g_true_pose(sess, t)[:2] + rng.normal(0, 0.03, 2), [g_true_pose(sess, t)[2] + rng.normal(0, 0.01)]]) if False else None
+            g.handle_observation(t, ob, gps); o.handle_observation(t, ob, gps)
+            steady_scans += 1
+            if left > 0:
+                left -= 1
+                continue
+            left = int(rng.integers(0, 15))
+            code = g.sync_code()
+            if code not in (0, -4):
+                assoc_bad += 1; break
+            if code == -4 or o.mu().shape[0] != g.mu().shape[0]:             # the oracle grew where the full filter dropped: stop comparing
+                overflow = True; break
+            a, b = norm_match(g.last_match()), norm_match(o.last_match())
+            if not all(np.array_equal(x, y) for x, y in zip(a, b)):
+                assoc_bad += 1; break
+            worst = max(worst, float(np.abs(g.mu() - o.mu()).max()))
     cov = 0.0
     if not overflow and not assoc_bad:
         st = g.GetState()
@@ -95,5 +127,5 @@ for seed in range(first, first + n_seeds):
     ok = assoc_bad == 0 and worst < 1e-9 and cov < 1e-10
     bad += 0 if ok else 1
     print(json.dumps({"seed": seed, "model": model, "L": L, "K": K, "cap": cap, "map": use_map, "gps": use_gps, "scans": scans,
-                      "n_final": int(g.mu().shape[0]), "overflow": overflow, "assoc_bad": assoc_bad, "worst_mu": worst, "worst_cov": cov, "ok": ok}))
+                      "n_final": int(g.mu().shape[0]), "steady_scans": steady_scans, "overflow": overflow, "assoc_bad": assoc_bad, "worst_mu": worst, "worst_cov": cov, "ok": ok}))
 print(json.dumps({"summary": True, "seeds": n_seeds, "failed": bad, "seconds": round(time.time() - t_start, 1)}))
