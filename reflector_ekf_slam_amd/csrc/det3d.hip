@@ -13,18 +13,25 @@
 //                 query first).  ONE WAVE PER QUERY, lane = candidate: the 64 smallest distances so far live one per lane
 //                 (wave-level bitonic networks on DPP / permlane swaps), tiles are opened nearest first and only while
 //                 their box is nearer than the query's current 31st distance                (:43-47)
-//   k3_sor        part 2: mean / (n-1)-variance in FP64, threshold; outliers masked in the sorted copy
-//   k3_cc_min,    EuclideanClusterExtraction as connected components of the radius-0.2 m graph, one wave per query over the
-//   k3_cc_link    tiles whose box lies within 0.2 m: smallest-neighbour pointers, then a lock-free union-find for the few
-//                 adjacent pairs whose chain tops differ (roots are only ever hooked under smaller roots: the label is the
-//                 smallest arrival index)                                                 (:65-74)
+//   k3_cc_min,    part 2 -- mean / (n-1)-variance in FP64, threshold: every workgroup for itself -- and EuclideanClusterExtraction as
+//   k3_cc_link    connected components of the radius-0.2 m graph, one wave per query over the tiles whose box lies within 0.2 m:
+//                 smallest-neighbour pointers (outliers: out of the graph, and out of the boxes), then a lock-free union-find
+//                 for the few adjacent pairs whose chain tops differ (roots are only ever hooked under smaller roots: the
+//                 label is the smallest arrival index)                                    (:43-47, :65-74)
 //   k3_finish_a   final roots, component sizes and extents in the sorted copy, the list of roots (over the CUs)
 //   k3_clusters   size gate [4,160], order (size desc, first index asc), float32 centroids in index order (one wave
 //                 per component, spread over the CUs), Rigid2f to base_link             (:70-71, :77-97)
 //
+// NINE launches per cloud, each a short chain of dependent trips to memory.  Round 5 tried FIVE -- gate + sort + boxes as one launch
+// whose scatter workgroups wait for its tile workgroups, k-NN with the statistics by its last workgroup, finish + clusters likewise
+// -- bit-identical, and SLOWER (120 us against 88): every edge of this chain is all-to-all, and a hand-over inside a launch that
+// crosses the XCDs' L2s (device-scope stores, a counter, a poll, device-scope loads; or release / acquire fences, which the L2
+// serialises at 13 ns a wave) costs 3 - 5 us where a kernel boundary costs 1.5 - 2 (profiles/r05_chain_experiments.txt, item 12).
+// What did pay is inside the kernels: first loads asked for together instead of one behind the other, the union-find's reads through
+// the caches, one union per distinct neighbour tree, the statistics inside k3_cc_min.
 // No kd-tree: after the intensity gate a cloud holds 10^2..10^4 points; a counting sort into Morton order and a box per
 // 32 points prune as well as a tree would at this size and stay coalesced, data-parallel and free of pointer chasing.
-// Nothing waits on the host between stages: the point counts M, M2 stay on the device and every grid is sized for the
+// Nothing waits on the host between stages: the point count M stays on the device and every grid is sized for the
 // number of points that came in.
 #include "../../include/rdet.h"
 #include "host_visible.h"
@@ -62,16 +69,16 @@ constexpr float BOX_MARGIN = 0.9999f;   // box distance^2 * margin < bound  <=> 
 
 struct Det3dCtl {
     int M, M2, K, err;
-    int nroots;                     // length of Det3dBufs::roots (k3_finish_a)
+    int nroots;                     // length of Det3dBufs::roots (k3_finish)
     // the grid the NEXT cloud is sorted on = the bounding box of this cloud's inliers (clouds of one sensor look alike;
-    // only the sweeps' pruning, never a result, depends on it): k3_clusters takes it from the tiles' boxes
+    // only the sweeps' pruning, never a result, depends on it): k3_finish
     float gx0, gy0, ginv;
 };
 
 // what the kernels hand back, in pinned host memory: every slot is ONE 16-byte system-scope store that carries the call's
 // number, polled by the host (no D2H copy, no wait for the completion signal; same scheme as det2d.hip)
 struct Det3dSlot { float x, y; int seq, pad; };
-struct Det3dHead { int K, err, M2, seq; };
+struct Det3dHead { int K, err, M, seq; };      // (M: the survivors of the intensity gate -- the next call's hint for how many queries to expect)
 struct Det3dHostOut {
     Det3dHead head;
     Det3dSlot centers[RDET_MAX_CENTERS];
@@ -86,12 +93,13 @@ __device__ static void d3_host_store16(void *p, unsigned a, unsigned b, unsigned
 struct Det3dBufs {
     const float *xyzi;
     float *p1;        // 3 x cap, SoA: x | y | z  after the intensity filter, arrival order ("node" numbering)
-    float *s1;        // the same points in Morton order; k3_sor overwrites the outliers' x with NaN
-    int *perm;        // sorted position -> node
+    float *s1;        // the same points in Morton order
+    int *perm;        // sorted position -> node (= arrival index among the survivors: the reference's point index)
     float *box;       // 8 floats per BOX_PTS sorted points: min x, y, z, max x, y, z
     int *hist;        // GRID_CELLS cell counts (zero between calls)
     int *cursor;      // GRID_CELLS scatter cursors
-    float *dist;      // per node: SOR mean neighbour distance; later, per sorted position: the final root (k3_finish_a)
+    float *dist;      // per node: SOR mean neighbour distance
+    float *dist_s;    // the same per sorted position; later the final root (k3_finish)
     int *label;       // per node: union-find parent, -1 = removed by SOR
     int *cnt;         // per root: component size
     int *first, *last;   // per root: first / last member's sorted position
@@ -142,24 +150,6 @@ __device__ static inline int cell_code(float x, float y, float gx0, float gy0, f
     return (int)(cx | (cy << 1));
 }
 
-// order-preserving block compaction step for one tile of 1024 candidates: returns this thread's output
-// position (valid when flag) and adds the tile's count to *base (all threads see the new value afterwards)
-__device__ static int tile_compact_pos(bool flag, int *wsum, int *base)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned long long bal = __ballot(flag);
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    if (lane == 0) wsum[wave] = __popcll(bal);
-    __syncthreads();
-    int off = *base, tot = 0;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) { const int c = wsum[w]; if (w < wave) off += c; tot += c; }
-    __syncthreads();
-    if (tid == 0) *base += tot;
-    __syncthreads();
-    return off + __popcll(bal & lt);
-}
-
 // lane ^ J exchanges without the LDS crossbar (scripts/probe/lane_xor.hip checks them): DPP quad permutes, row shifts
 // under bank masks, gfx950's v_permlane16_swap / v_permlane32_swap
 template <int CTRL, int BANK>
@@ -192,6 +182,24 @@ __device__ static inline void wave_groups(int code, int lane, int &leader, int &
         if (code == c0) { leader = src; count = __popcll(grp); rank = __popcll(grp & ((1ull << lane) - 1)); }
         todo &= ~grp;
     }
+}
+
+// order-preserving block compaction step for one tile of 1024 candidates: returns this thread's output
+// position (valid when flag) and adds the tile's count to *base (all threads see the new value afterwards)
+__device__ static int tile_compact_pos(bool flag, int *wsum, int *base)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long bal = __ballot(flag);
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int off = *base, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const int c = wsum[w]; if (w < wave) off += c; tot += c; }
+    __syncthreads();
+    if (tid == 0) *base += tot;
+    __syncthreads();
+    return off + __popcll(bal & lt);
 }
 
 // ---- intensity filter + order-preserving compaction, one workgroup per 1024-point tile: the tiles' survivor counts
@@ -246,6 +254,8 @@ __global__ __launch_bounds__(1024) void k3_filter_write(Det3dBufs B, int N, doub
         B.cursor[c * 1024 + tid] = off + incl - v;
         return;
     }
+    const int i = blockIdx.x * 1024 + tid;
+    const float4 cur = (i < N) ? ((const float4 *)B.xyzi)[i] : make_float4(0.f, 0.f, 0.f, 0.f);   // (in flight under the counts)
     if (tid < 64) {                                                              // survivors in the tiles before this one
         int c = 0;
         for (int w = tid; w < (int)blockIdx.x; w += 64) c += B.cnt[w];
@@ -253,8 +263,6 @@ __global__ __launch_bounds__(1024) void k3_filter_write(Det3dBufs B, int N, doub
         if (tid == 0) base = c;
     }
     __syncthreads();
-    const int i = blockIdx.x * 1024 + tid;
-    const float4 cur = (i < N) ? ((const float4 *)B.xyzi)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     const bool keep = i < N && (double)cur.w > intensity_min;
     const int pos = tile_compact_pos(keep, wsum, &base);
     if (keep) { B.p1[pos] = cur.x; B.p1[B.cap + pos] = cur.y; B.p1[2 * B.cap + pos] = cur.z; }
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(1024) void k3_filter_write(Det3dBufs B, int N, doub
 }
 
 // bounding boxes of BOX_PTS consecutive sorted points: lane = point (x, y, z in registers), 32-lane halves reduce by
-// shuffles.  NaN coordinates (the outliers k3_sor masks: x) are ignored by fminf / fmaxf; a tile without any number gets an
+// shuffles.  NaN coordinates (the outliers k3_cc_min masks: x) are ignored by fminf / fmaxf; a tile without any number gets an
 // empty box (+inf, -inf).
 __device__ static inline void tile_boxes(const Det3dBufs &B, int s, int M, float x, float y, float z)
 {
@@ -289,15 +297,19 @@ __device__ static inline void tile_boxes(const Det3dBufs &B, int s, int M, float
 
 // ---- the counting sort's scatter (thread = node): sorted coordinates + the permutation; also clears what the next
 // stages and the next call expect cleared
-__global__ __launch_bounds__(1024) void k3_scatter(Det3dBufs B)
+__global__ __launch_bounds__(1024) void k3_scatter(Det3dBufs B, int N)
 {
+    // (every first load is asked for at once -- M, the grid, the node's coordinates whether or not it exists -- and waited for once:
+    // right behind a kernel boundary each dependent load is a trip to memory, ~1 us)
     const int M = B.ctl->M;
+    const float gx0 = B.ctl->gx0, gy0 = B.ctl->gy0, ginv = B.ctl->ginv;
     const int gid = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63;
+    const bool v0 = gid < N;
+    const float x = v0 ? B.p1[gid] : 0.f, y = v0 ? B.p1[B.cap + gid] : 0.f, z = v0 ? B.p1[2 * B.cap + gid] : 0.f;
     for (int k = gid; k < GRID_CELLS; k += gridDim.x * 1024) B.hist[k] = 0;
     if ((int)blockIdx.x * 1024 >= M) return;
     const bool v = gid < M;
-    const float x = v ? B.p1[gid] : 0.f, y = v ? B.p1[B.cap + gid] : 0.f, z = v ? B.p1[2 * B.cap + gid] : 0.f;
-    const int code = v ? cell_code(x, y, B.ctl->gx0, B.ctl->gy0, B.ctl->ginv) : -1;
+    const int code = v ? cell_code(x, y, gx0, gy0, ginv) : -1;
     int leader, count, rank;
     wave_groups(code, lane, leader, count, rank);
     int base = 0;
@@ -309,13 +321,14 @@ __global__ __launch_bounds__(1024) void k3_scatter(Det3dBufs B)
     B.perm[pos] = gid;
     B.cnt[gid] = 0; B.first[gid] = 0x7fffffff; B.last[gid] = 0;
 }
-__global__ __launch_bounds__(256) void k3_boxes(Det3dBufs B)
+__global__ __launch_bounds__(256) void k3_boxes(Det3dBufs B, int N)
 {
     const int M = B.ctl->M;
-    if ((int)blockIdx.x * 256 >= M) return;
     const int s = blockIdx.x * 256 + threadIdx.x;
-    const int ss = s < M ? s : 0;
-    tile_boxes(B, s, M, B.s1[ss], B.s1[B.cap + ss], B.s1[2 * B.cap + ss]);
+    const int ss = s < N ? s : 0;
+    const float x = B.s1[ss], y = B.s1[B.cap + ss], z = B.s1[2 * B.cap + ss];    // (beside M, not behind it; past M: masked)
+    if ((int)blockIdx.x * 256 >= M) return;
+    tile_boxes(B, s, M, x, y, z);
 }
 
 // ---- the three neighbour sweeps: ONE WAVE PER QUERY, lane = candidate ----------------------------------------
@@ -360,13 +373,6 @@ __device__ static inline float wave_merge64(float S, float D, int lane)
     c = bitonic_stage<64, 4, false>(c, lane); c = bitonic_stage<64, 2, false>(c, lane); c = bitonic_stage<64, 1, false>(c, lane);
     return c;
 }
-// the boxes of tiles r0 + lane: squared distance from the query (inf past the last tile)
-__device__ static inline float lane_box_d2(const Det3dBufs &B, int t, int ntiles, float qx, float qy, float qz)
-{
-    if (t >= ntiles) return INFINITY;
-    const float4 lo = *(const float4 *)(B.box + 8 * t), hi = *(const float4 *)(B.box + 8 * t + 4);   // x0 y0 z0 x1 | y1 z1 . .
-    return box_d2(qx, qy, qz, lo.x, lo.y, lo.z, lo.w, hi.x, hi.y);
-}
 // the lane with the smallest v among the lanes of `set` (nearest tile first: the bound tightens at once and most of the
 // other tiles are never opened)
 __device__ static inline int nearest_of(unsigned long long set, float v, int lane)
@@ -383,30 +389,62 @@ constexpr int KNN_AHEAD = 4;        // steps (pairs of tiles) whose loads are is
 constexpr int CC_AHEAD = 4;         // the same in the radius-graph sweeps
 constexpr int KNN_FEW = 6;          // a step with at most this many admissible candidates inserts them one by one
 
+// What a sweep can ask for before it knows anything but its query's number: the boxes of the first 128 tiles (two per lane).  All of a
+// query's first loads -- M, the query, its aligned 64 neighbours, these boxes -- are issued together and waited for once (each used to
+// wait for the one before: four round trips to a memory that is a microsecond away right after a kernel boundary).
+struct BoxPre { float4 lo0, hi0, lo1, hi1; };
+__device__ static inline void box_prefetch(const Det3dBufs &B, int lane, int ntiles_ub, BoxPre &P)
+{
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    P.lo0 = P.hi0 = P.lo1 = P.hi1 = z;
+    if (lane < ntiles_ub) { P.lo0 = *(const float4 *)(B.box + 8 * lane); P.hi0 = *(const float4 *)(B.box + 8 * lane + 4); }
+    if (lane + 64 < ntiles_ub) { P.lo1 = *(const float4 *)(B.box + 8 * (lane + 64)); P.hi1 = *(const float4 *)(B.box + 8 * (lane + 64) + 4); }
+}
+// squared distance from the query to the box of tile r0 + lane (inf past the last tile)
+__device__ static inline float round_box_d2(const Det3dBufs &B, const BoxPre &P, int r0, int lane, int ntiles, float qx, float qy, float qz)
+{
+    const int t = r0 + lane;
+    if (t >= ntiles) return INFINITY;
+    float4 lo, hi;
+    if (r0 == 0) { lo = P.lo0; hi = P.hi0; }
+    else if (r0 == 64) { lo = P.lo1; hi = P.hi1; }
+    else { lo = *(const float4 *)(B.box + 8 * t); hi = *(const float4 *)(B.box + 8 * t + 4); }
+    return box_d2(qx, qy, qz, lo.x, lo.y, lo.z, lo.w, hi.x, hi.y);
+}
+
 // ---- SOR part 1: mean distance to the MeanK nearest neighbours (:43-47).  The 64 smallest squared distances seen so
 // far live one per lane, ascending.  A step with many admissible candidates sorts its 64 across the lanes and merges
 // (bitonic networks on DPP / permlane swaps, one v_med3 per stage); one with few inserts them one at a time (ballot,
 // popcount, wave_shr:1).  The bound is lane 30's value: a tile is opened only while its box is nearer than that.  The
 // multiset of the 31 smallest values is exact, so the ascending-order FP64 sum is bit-identical to the reference's.
-__global__ __launch_bounds__(64 * QW) void k3_knn(Det3dBufs B)
+// m_hint: the previous cloud's M (clouds of one sensor look alike).  A wave whose query number is below it asks for everything at once;
+// one above it (most of the grid: the grid is sized for N, the gate leaves an eighth) first waits for M -- 5000 idle waves asking for
+// eleven loads each cost the working ones 6 us.  A wrong hint costs time, never a result.
+__global__ __launch_bounds__(64 * QW) void k3_knn(Det3dBufs B, int N, int ntiles_ub, int m_hint)
 {
-    const int M = B.ctl->M;
     const int lane = threadIdx.x & 63;
-    const int ntiles = (M + BOX_PTS - 1) / BOX_PTS;
+    const int M = B.ctl->M;                                                       // (the first load out: waited for behind the query's own)
     const float *__restrict__ X = B.s1, *__restrict__ Y = B.s1 + B.cap, *__restrict__ Z = B.s1 + 2 * B.cap;
-    for (int q = __builtin_amdgcn_readfirstlane(blockIdx.x * QW + (threadIdx.x >> 6)); q < M; q += gridDim.x * QW) {
+    for (int q = __builtin_amdgcn_readfirstlane(blockIdx.x * QW + (threadIdx.x >> 6)); q < N; q += gridDim.x * QW) {
+        if (q >= m_hint && q >= M) break;
         const float qx = X[q], qy = Y[q], qz = Z[q];
         const int a0 = q & ~63;                                  // the aligned 64 points around the query = tiles a0/32, a0/32 + 1
+        const int ja = a0 + lane;
+        const float ax = X[ja], ay = Y[ja], az = Z[ja];          // (past M: padding, masked)
+        const int node = B.perm[q];
+        BoxPre P;
+        box_prefetch(B, lane, ntiles_ub, P);
+        if (q >= M) break;
+        const int ntiles = (M + BOX_PTS - 1) / BOX_PTS;
         float S;
         {
-            const int j = a0 + lane;
-            const float d2 = d2f(qx, qy, qz, X[j], Y[j], Z[j]);  // (past M: padding, masked)
-            S = wave_sort64<false>((j < M && d2 == d2) ? d2 : INFINITY, lane);
+            const float d2 = d2f(qx, qy, qz, ax, ay, az);
+            S = wave_sort64<false>((ja < M && d2 == d2) ? d2 : INFINITY, lane);
         }
         float bound = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S), KNN - 1));
         for (int r0 = 0; r0 < ntiles; r0 += 64) {
             const int t = r0 + lane;
-            const float db = ((t >> 1) == (a0 >> 6)) ? INFINITY : lane_box_d2(B, t, ntiles, qx, qy, qz) * BOX_MARGIN;
+            const float db = ((t >> 1) == (a0 >> 6)) ? INFINITY : round_box_d2(B, P, r0, lane, ntiles, qx, qy, qz) * BOX_MARGIN;
             unsigned long long todo = __ballot(db < bound);
             while (todo) {
                 float cx[KNN_AHEAD], cy[KNN_AHEAD], cz[KNN_AHEAD];
@@ -453,105 +491,134 @@ __global__ __launch_bounds__(64 * QW) void k3_knn(Det3dBufs B)
         double dist_sum = 0;
 #pragma unroll
         for (int k = 1; k < KNN; ++k) dist_sum += (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(sq), k));   // k = 0 is the query itself
-        if (lane == 0) B.dist[B.perm[q]] = (M >= KNN) ? (float)(dist_sum / MEAN_K) : 0.f;   // fewer than MeanK+1 points: the search "failed"
+        if (lane == 0) {
+            const float md = (M >= KNN) ? (float)(dist_sum / MEAN_K) : 0.f;      // fewer than MeanK+1 points: the search "failed"
+            B.dist[node] = md; B.dist_s[q] = md;                    // (by node: the statistics' order; by sorted position: the sweeps')
+        }
     }
-}
-
-// ---- SOR part 2: statistics, threshold; the outliers are masked in the sorted copy (x := NaN: every distance to them
-// compares false), the union-find parents are initialised (removed node: -1), the boxes are rebuilt without them.  Node
-// ids stay the arrival indices after the intensity gate -- the reference renumbers the survivors, but only the ORDER of
-// the indices is ever used (smallest member, centroid summation), and the renumbering keeps the order.
-// Thread = sorted position.  EVERY workgroup takes the statistics for itself (M floats: cheaper than a launch in between,
-// and the one-workgroup form spent 11 us walking its dependent loads): 1024 chunk sums in index order, then the pairwise tree
-// -- the very operations, in the very order, of the one-workgroup form, so the threshold's bits do not depend on the grid.
-__global__ __launch_bounds__(256) void k3_sor(Det3dBufs B)
-{
-    __shared__ double red[2][1024];
-    __shared__ double s_thr;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int M = B.ctl->M;
-    if ((int)blockIdx.x * 256 >= M) return;
-    const int s = blockIdx.x * 256 + tid, ss = s < M ? s : 0;
-    const int node = B.perm[ss];                                                  // (in flight under the statistics)
-    const float mydist = B.dist[node];
-    const float x = B.s1[ss], y = B.s1[B.cap + ss], z = B.s1[2 * B.cap + ss];
-    const int CH = (M + 1023) / 1024;
-    for (int c = tid; c < 1024; c += 256) {
-        const int b0 = c * CH, b1 = min(M, b0 + CH);
-        double sum = 0, sq = 0;
-        for (int i = b0; i < b1; ++i) { const double v = B.dist[i]; sum += v; sq += v * v; }   // chunked like the serial loop's partial sums
-        red[0][c] = sum; red[1][c] = sq;
-    }
-    __syncthreads();
-    for (int off = 512; off >= 1; off >>= 1) {
-        for (int i = tid; i < off; i += 256) { red[0][i] += red[0][i + off]; red[1][i] += red[1][i + off]; }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        const double valid = (M >= MEAN_K + 1) ? (double)M : 0.0;
-        const double mean = red[0][0] / valid;
-        const double variance = (red[1][0] - red[0][0] * red[0][0] / valid) / (valid - 1);
-        s_thr = mean + STD_MUL * sqrt(variance);
-    }
-    __syncthreads();
-    const bool keep = s < M && !((double)mydist > s_thr);                        // NaN threshold keeps everything
-    if (s < M) {
-        B.label[node] = keep ? node : -1;
-        if (!keep) B.s1[s] = __int_as_float(0x7fc00000);
-    }
-    const unsigned long long kept = __ballot(keep);
-    if (lane == 0 && kept) atomicAdd(&B.ctl->M2, __popcll(kept));
-    tile_boxes(B, s, M, keep ? x : __int_as_float(0x7fc00000), y, z);
 }
 
 // ---- connected components of the radius graph: lock-free union-find ------------------------------
 // parent = B.label.  Only roots are ever hooked (CAS root -> a SMALLER root), so the final root of a
 // component is its smallest index whatever the interleaving: deterministic labels from one all-pairs pass
-// (the previous version needed up to 64 propagation launches).  The XCDs' L2 caches are not coherent with each other
+// (the first version needed up to 64 propagation launches).  The XCDs' L2 caches are not coherent with each other
 // for plain loads, and a device-scope atomic load is a ~1.5 us round trip, so the finds read parent[] through the
 // caches: every value parent[x] has ever held is an ancestor of x for good (hooks attach roots under smaller indices,
 // halving only shortcuts upwards), hence a stale read can only return an ancestor that is no longer the root -- never a
-// wrong one.  What must be exact is the hook itself: the CAS on the larger root goes to memory and fails when that
-// node has stopped being a root, and only then the finds are repeated with device-scope loads (FRESH).
-template <bool FRESH>
-__device__ static inline int uf_load(const int *p)
-{
-    if (FRESH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return *(const volatile int *)p;
-}
-template <bool FRESH>
+// wrong one.  What must be exact is the hook itself: the CAS on the larger root goes to memory, and when that node has stopped
+// being a root it fails AND returns the node's parent as memory has it -- the walk goes on from there (round 5; round 4 repeated
+// both finds with device-scope loads: the 10 us tail of the slowest waves).
+// parent[] as the caches have it: a plain load the compiler may neither tear nor invent (wavefront-scope relaxed: no cache-control bits).
+// Round 4 read it `volatile` -- which is a SYSTEM-scope load on this target: every one of them past the L1, and the few hundred waves
+// of a big cluster, all asking for the same few parents, queued up on the same lines for 10 us.
+__device__ static inline int uf_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 __device__ static int uf_find(int *parent, int x)
 {
-    int p = uf_load<FRESH>(&parent[x]);
+    int p = uf_ld(&parent[x]);
     while (p != x) {
-        const int gp = uf_load<FRESH>(&parent[p]);
+        const int gp = uf_ld(&parent[p]);
         if (gp != p) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // path halving
         x = p; p = gp;
     }
     return x;
 }
-// Three passes.  Doing every union inside one sweep serialises on chains of finds and compare-and-swaps.  Instead:
+// joins the trees of a and b; returns the root as far as this thread knows it
+__device__ static int uf_union(int *parent, int a, int b)
+{
+    a = uf_find(parent, a); b = uf_find(parent, b);
+    while (a != b) {
+        const int hi = max(a, b), lo = min(a, b);
+        const int old = atomicCAS(&parent[hi], hi, lo);
+        if (old == hi) return lo;
+        const int up = uf_find(parent, old);                     // hi has a parent (< hi): on from there
+        if (hi == a) a = up; else b = up;
+    }
+    return a;
+}
+// Two passes.  Doing every union inside one sweep serialises on chains of finds and compare-and-swaps.  Instead:
 //   k3_cc_min   registers only: parent[i] = smallest index among i and its neighbours.  That alone puts nearly
-//               every point of a compact cluster in one tree (the chains run towards the cluster's first point);
+//               every point of a compact cluster in one tree (the chains run towards the cluster's first point).  Round 5: also
+//               SOR part 2 -- a query farther than the threshold gets parent -1, a candidate farther than it is no neighbour
+//               (round 4: a kernel of its own, k3_sor, that masked the outliers' x and rebuilt the boxes without them);
 //   k3_cc_link  every neighbour found earlier in the sorted copy is looked up with the top of its chain as it stands (equal
 //               tops mean "same tree already", and a stale top is still an ancestor, so the filter never drops a needed
-//               union), and only an adjacent pair whose tops differ goes into the union code -- a few per cluster.
+//               union), and only adjacent pairs whose tops differ go into the union code -- once per DISTINCT top of a query's
+//               neighbours, by one lane (round 4: every lane for itself, dozens of compare-and-swaps on the same root).
 // Both as one wave per query over the tiles whose box lies within 0.2 m of it, like k3_knn.
-__global__ __launch_bounds__(64 * QW) void k3_cc_min(Det3dBufs B)
+__global__ __launch_bounds__(64 * QW) void k3_cc_min(Det3dBufs B, int N, int ntiles_ub, int m_hint)
 {
+    __shared__ double red[2][1024];
     const int M = B.ctl->M;
-    const int lane = threadIdx.x & 63;
-    const int ntiles = (M + BOX_PTS - 1) / BOX_PTS;
-    const float *__restrict__ X = B.s1, *__restrict__ Y = B.s1 + B.cap, *__restrict__ Z = B.s1 + 2 * B.cap;
-    for (int q = __builtin_amdgcn_readfirstlane(blockIdx.x * QW + (threadIdx.x >> 6)); q < M; q += gridDim.x * QW) {
-        const float qx = X[q], qy = Y[q], qz = Z[q];
-        if (!(qx == qx)) continue;                               // masked by k3_sor: label stays -1
-        const int own = B.perm[q];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const float *__restrict__ X = B.s1, *__restrict__ Y = B.s1 + B.cap, *__restrict__ Z = B.s1 + 2 * B.cap, *__restrict__ DS = B.dist_s;
+    // the first query's loads go out before the statistics (which wait for M, then for M distances)
+    int q = __builtin_amdgcn_readfirstlane(blockIdx.x * QW + (threadIdx.x >> 6));
+    if ((int)blockIdx.x * QW >= m_hint && (int)blockIdx.x * QW >= M) return;      // (the whole workgroup: no query; k3_knn on m_hint)
+    const int q0 = q < N ? q : 0;
+    float qx = X[q0], qy = Y[q0], qz = Z[q0], qd = DS[q0];
+    int own = B.perm[q0];
+    // every 64th query also looks after the boxes of the two tiles it starts: see below
+    const bool boxer = (q & 63) == 0 && q < N;
+    float tx = 0.f, ty = 0.f, tz = 0.f, td = 0.f;
+    if (boxer) { tx = X[q + lane]; ty = Y[q + lane]; tz = Z[q + lane]; td = DS[q + lane]; }
+    BoxPre P;
+    box_prefetch(B, lane, ntiles_ub, P);
+    if ((int)blockIdx.x * QW >= M) return;                                        // (the whole workgroup: no query)
+    // ---- SOR part 2 (:43-47 setStddevMulThresh): mean and (n-1)-variance of the M distances in FP64.  EVERY workgroup takes them for
+    // itself (M floats out of L2: cheaper than a launch in between, and than any hand-over inside one): 1024 chunk sums in node
+    // order, then the pairwise tree -- the operations, in the order, of the serial loop's partial sums, so the threshold's bits do not
+    // depend on the grid.  Which points are outliers is never stored: the sweeps compare dist_s with the threshold as they go.
+    double thr;
+    {
+        const int CH = (M + 1023) / 1024;
+        for (int c = tid; c < 1024; c += 64 * QW) {
+            const int b0 = c * CH, b1 = min(M, b0 + CH);
+            double sum = 0, sq = 0;
+            for (int i = b0; i < b1; ++i) { const double v = B.dist[i]; sum += v; sq += v * v; }   // chunked like the serial loop's partial sums
+            red[0][c] = sum; red[1][c] = sq;
+        }
+        __syncthreads();
+        for (int off = 512; off >= 64; off >>= 1) {
+            for (int i = tid; i < off; i += 64 * QW) { red[0][i] += red[0][i + off]; red[1][i] += red[1][i + off]; }
+            __syncthreads();
+        }
+        // (the last six levels: entries 0 .. 63, one per lane, every wave for itself -- the same additions of the same pairs, by shuffles)
+        double r0 = red[0][lane], r1 = red[1][lane];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { r0 += __shfl_down(r0, off, 64); r1 += __shfl_down(r1, off, 64); }
+        r0 = __shfl(r0, 0, 64); r1 = __shfl(r1, 0, 64);
+        const double valid = (M >= MEAN_K + 1) ? (double)M : 0.0;
+        const double mean = r0 / valid;
+        const double variance = (r1 - r0 * r0 / valid) / (valid - 1);
+        thr = mean + STD_MUL * sqrt(variance);                                   // (every thread: the same bits; NaN keeps everything)
+    }
+    for (bool first = true; q < N; q += gridDim.x * QW, first = false) {
+        bool bx = boxer;
+        if (!first) {
+            if (q >= M) break;
+            qx = X[q]; qy = Y[q]; qz = Z[q]; qd = DS[q];
+            own = B.perm[q];
+            bx = (q & 63) == 0;
+            if (bx) { tx = X[q + lane]; ty = Y[q + lane]; tz = Z[q + lane]; td = DS[q + lane]; }
+            box_prefetch(B, lane, ntiles_ub, P);
+        }
+        if (q >= M) break;
+        // The boxes so far are those of ALL survivors of the gate; SOR's outliers -- a quarter of them, the sparse fringes -- blow them
+        // up (twenty tiles within 0.2 m of a query instead of two).  The wave that starts a pair of tiles rewrites their boxes without
+        // the outliers, IN PLACE, while other waves read them: a reader sees the old box, the new one or any mix of their
+        // components, and each of those contains every inlier of the tile -- all a sweep asks of a box (outliers are nobody's
+        // neighbours).  k3_cc_link, a launch later, sees the tight ones throughout.  (Round 4: a kernel of its own.)
+        if (bx) tile_boxes(B, q + lane, M, ((double)td > thr) ? __int_as_float(0x7fc00000) : tx, ty, tz);
+        if ((double)qd > thr) {                                  // :47 -- an outlier: out of the graph
+            if (lane == 0) B.label[own] = -1;
+            continue;
+        }
+        const int ntiles = (M + BOX_PTS - 1) / BOX_PTS;
         int mi = own;
         for (int r0 = 0; r0 < ntiles; r0 += 64) {
-            unsigned long long todo = __ballot(lane_box_d2(B, r0 + lane, ntiles, qx, qy, qz) * BOX_MARGIN < TOL2);
+            unsigned long long todo = __ballot(round_box_d2(B, P, r0, lane, ntiles, qx, qy, qz) * BOX_MARGIN < TOL2);
             while (todo) {
-                float cx[CC_AHEAD], cy[CC_AHEAD], cz[CC_AHEAD];
+                float cx[CC_AHEAD], cy[CC_AHEAD], cz[CC_AHEAD], cd[CC_AHEAD];
                 int pj[CC_AHEAD];
                 bool ok[CC_AHEAD];
 #pragma unroll
@@ -563,47 +630,51 @@ __global__ __launch_bounds__(64 * QW) void k3_cc_min(Det3dBufs B)
                     const int j = BOX_PTS * (r0 + tile) + (lane & 31);
                     ok[u] = tile >= 0 && j < M;
                     const int jj = ok[u] ? j : 0;
-                    cx[u] = X[jj]; cy[u] = Y[jj]; cz[u] = Z[jj]; pj[u] = B.perm[jj];   // (the id with the coordinates, not behind the test)
+                    cx[u] = X[jj]; cy[u] = Y[jj]; cz[u] = Z[jj]; cd[u] = DS[jj]; pj[u] = B.perm[jj];   // (the id with the coordinates, not behind the test)
                 }
 #pragma unroll
                 for (int u = 0; u < CC_AHEAD; ++u)
-                    if (ok[u] && d2f(qx, qy, qz, cx[u], cy[u], cz[u]) < TOL2) mi = min(mi, pj[u]);
+                    if (ok[u] && !((double)cd[u] > thr) && d2f(qx, qy, qz, cx[u], cy[u], cz[u]) < TOL2) mi = min(mi, pj[u]);
             }
         }
         for (int off = 32; off > 0; off >>= 1) mi = min(mi, __shfl_xor(mi, off, 64));
         if (lane == 0) B.label[own] = mi;
     }
 }
-__global__ __launch_bounds__(64 * QW) void k3_cc_link(Det3dBufs B)
+__global__ __launch_bounds__(64 * QW) void k3_cc_link(Det3dBufs B, int N, int ntiles_ub, int m_hint)
 {
     const int M = B.ctl->M;
     const int lane = threadIdx.x & 63;
-    const int ntiles = (M + BOX_PTS - 1) / BOX_PTS;
     const float *__restrict__ X = B.s1, *__restrict__ Y = B.s1 + B.cap, *__restrict__ Z = B.s1 + 2 * B.cap;
     int *parent = B.label;
-    for (int q = __builtin_amdgcn_readfirstlane(blockIdx.x * QW + (threadIdx.x >> 6)); q < M; q += gridDim.x * QW) {
+    for (int q = __builtin_amdgcn_readfirstlane(blockIdx.x * QW + (threadIdx.x >> 6)); q < N; q += gridDim.x * QW) {
+        if (q >= m_hint && q >= M) break;
         const float qx = X[q], qy = Y[q], qz = Z[q];
-        if (!(qx == qx)) continue;
+        const int own = B.perm[q];
+        BoxPre P;
+        box_prefetch(B, lane, ntiles_ub, P);
+        if (q >= M) break;
 #ifdef RDET_DEBUG_MARKS
         const bool dbg = q == (int)blockIdx.x * QW;
         if (dbg) D3_MARK(0);
 #endif
-        float db = lane_box_d2(B, lane, ntiles, qx, qy, qz) * BOX_MARGIN;   // (in flight under the chase below)
-        int rs = *(const volatile int *)&parent[B.perm[q]];      // top of the query's chain as it stands
-        for (int p = *(const volatile int *)&parent[rs]; p != rs; p = *(const volatile int *)&parent[rs]) rs = p;
-        int ri = rs;                                              // (per lane) a possibly stale ancestor of the query
+        int rs = uf_ld(&parent[own]);           // top of the query's chain as it stands
+        if (rs < 0) continue;                                    // removed by SOR (k3_cc_min)
+        for (int p = uf_ld(&parent[rs]); p != rs; p = uf_ld(&parent[rs])) rs = p;
+        int ri = rs;                                             // (uniform) the query's root as far as this wave knows it
 #ifdef RDET_DEBUG_MARKS
         if (dbg) D3_MARK(1);
 #endif
+        const int ntiles = (M + BOX_PTS - 1) / BOX_PTS;
         for (int r0 = 0; r0 < ntiles; r0 += 64) {
-            if (r0) db = lane_box_d2(B, r0 + lane, ntiles, qx, qy, qz) * BOX_MARGIN;
+            const float db = round_box_d2(B, P, r0, lane, ntiles, qx, qy, qz) * BOX_MARGIN;
             unsigned long long todo = __ballot(db < TOL2 && BOX_PTS * (r0 + lane) < q);   // (a tile behind the query holds no earlier point)
 #ifdef RDET_DEBUG_MARKS
             if (dbg && r0 == 0) { D3_MARK(2); if (threadIdx.x == 0 && blockIdx.x < 2048) d3_marks[blockIdx.x][6] = __popcll(todo); }
 #endif
             while (todo) {
                 float cx[CC_AHEAD], cy[CC_AHEAD], cz[CC_AHEAD];
-                int cr0[CC_AHEAD];
+                int top[CC_AHEAD];
                 bool ok[CC_AHEAD];
 #pragma unroll
                 for (int u = 0; u < CC_AHEAD; ++u) {                        // four steps' loads in flight
@@ -612,28 +683,59 @@ __global__ __launch_bounds__(64 * QW) void k3_cc_link(Det3dBufs B)
                     if (todo) { tb = __ffsll((long long)todo) - 1; todo &= todo - 1; }
                     const int tile = (lane < 32) ? ta : tb;
                     const int j = BOX_PTS * (r0 + tile) + (lane & 31);
-                    // every edge is handled by its later end (j < q also keeps j < M); a masked neighbour's x is NaN
+                    // every edge is handled by its later end (j < q also keeps j < M)
                     ok[u] = tile >= 0 && j < q;
                     const int jj = ok[u] ? j : 0;
                     cx[u] = X[jj]; cy[u] = Y[jj]; cz[u] = Z[jj];
-                    cr0[u] = *(const volatile int *)&parent[B.perm[jj]];       // (with the coordinates, not behind the test)
+                    top[u] = uf_ld(&parent[B.perm[jj]]);       // (with the coordinates, not behind the test; -1: an outlier)
                 }
+                // the tops of the neighbours' chains, all lanes and steps together (a lane without a neighbour rides along on the query's own top)
 #pragma unroll
-                for (int u = 0; u < CC_AHEAD; ++u) {
-                    if (ok[u] && d2f(qx, qy, qz, cx[u], cy[u], cz[u]) < TOL2) {
-                        int cr = cr0[u];
-                        for (int p = *(const volatile int *)&parent[cr]; p != cr; p = *(const volatile int *)&parent[cr]) cr = p;
-                        if (cr != rs) {
-                            int a = uf_find<false>(parent, ri), b = uf_find<false>(parent, cr);
-                            while (a != b) {
-                                const int hi = max(a, b), lo = min(a, b);
-                                const int old = atomicCAS(&parent[hi], hi, lo);
-                                if (old == hi) { a = lo; break; }
-                                a = uf_find<true>(parent, a); b = uf_find<true>(parent, b);
-                            }
-                            ri = a;
+                for (int u = 0; u < CC_AHEAD; ++u)
+                    if (!(ok[u] && top[u] >= 0 && d2f(qx, qy, qz, cx[u], cy[u], cz[u]) < TOL2)) top[u] = rs;
+#ifdef RDET_DEBUG_MARKS
+                int dbg_hops = 0, dbg_rounds = 0;
+                if (dbg) D3_MARK(4);
+#endif
+                bool moving = true;
+                while (__ballot(moving)) {
+#ifdef RDET_DEBUG_MARKS
+                    ++dbg_hops;
+#endif
+                    int p[CC_AHEAD];
+#pragma unroll
+                    for (int u = 0; u < CC_AHEAD; ++u) p[u] = uf_ld(&parent[top[u]]);
+                    moving = false;
+#pragma unroll
+                    for (int u = 0; u < CC_AHEAD; ++u) { moving |= p[u] != top[u]; top[u] = p[u]; }
+                }
+#ifdef RDET_DEBUG_MARKS
+                if (dbg) D3_MARK(5);
+#endif
+                // one union per DISTINCT top that is not the query's: the k-th distinct one is lane k's, all of them at once (64 per round)
+                while (true) {
+                    int mine = -1, nd = 0;
+#pragma unroll
+                    for (int u = 0; u < CC_AHEAD; ++u) {
+                        unsigned long long need = __ballot(top[u] != rs && top[u] != ri);
+                        while (need && nd < 64) {
+                            const int c = __builtin_amdgcn_readlane(top[u], __ffsll((long long)need) - 1);
+                            need &= ~__ballot(top[u] == c);
+#pragma unroll
+                            for (int v = 0; v < CC_AHEAD; ++v) top[v] = (top[v] == c) ? rs : top[v];   // (handled, in whichever step it turns up)
+                            if (lane == nd) mine = c;
+                            ++nd;
                         }
                     }
+                    if (nd == 0) break;
+#ifdef RDET_DEBUG_MARKS
+                    ++dbg_rounds;
+                    if (dbg && threadIdx.x == 0 && blockIdx.x < 2048) d3_marks[blockIdx.x][7] = (unsigned long long)(dbg_hops * 10000 + dbg_rounds * 100 + nd);
+#endif
+                    int a = ri;
+                    if (mine >= 0) a = uf_union(parent, ri, mine);
+                    for (int off = 32; off > 0; off >>= 1) a = min(a, __shfl_xor(a, off, 64));
+                    ri = a;                                                 // (the smallest root any lane has seen: a hint, like rs)
                 }
             }
         }
@@ -647,19 +749,20 @@ __global__ __launch_bounds__(64 * QW) void k3_cc_link(Det3dBufs B)
 // k3_finish_a (thread = sorted position, over the CUs): final roots, component sizes, the stretch of the sorted copy
 // each component lives in, and the list of roots.  One atomic group per (wave, component) instead of one per point:
 // neighbours in the spatial order mostly share their component.
-__global__ __launch_bounds__(256) void k3_finish_a(Det3dBufs B)
+__global__ __launch_bounds__(256) void k3_finish_a(Det3dBufs B, int N)
 {
     const int M = B.ctl->M;
     const int s = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    const int node0 = B.perm[s < N ? s : 0];                      // (beside M, not behind it)
     if ((int)blockIdx.x * 256 >= M) return;
     int r = -1, node = -1;
     if (s < M) {
-        node = B.perm[s];
+        node = node0;
         r = B.label[node];
         if (r >= 0) {
-            while (true) { const int p = *(const volatile int *)&B.label[r]; if (p == r) break; r = p; }   // parents are final: no union runs any more
+            while (true) { const int p = uf_ld(&B.label[r]); if (p == r) break; r = p; }   // parents are final: no union runs any more
         }
-        reinterpret_cast<int *>(B.dist)[s] = r;                  // the SOR distances are dead: final roots live there, by sorted position
+        reinterpret_cast<int *>(B.dist_s)[s] = r;                // the SOR distances are dead: final roots live there, by sorted position
     }
     const unsigned long long isroot = __ballot(r >= 0 && r == node);
     if (isroot) {
@@ -686,26 +789,43 @@ __global__ __launch_bounds__(256) void k3_finish_a(Det3dBufs B)
 // between), then each of its four waves takes one accepted component: its members out of the stretch of the sorted copy
 // it lives in, brought into ARRIVAL order (the float32 sums of compute3DCentroid run in index order, :94), summed,
 // divided, moved to base_link and published.  Order: size descending, then first member (= root) ascending.
+template <int NS>
+__device__ static inline void arrival_places(const int *ids, int size, int lane, int (&place)[3])
+{
+    // a member's place = the number of members with a smaller node id (ids four at a time: the list is padded with ids no member is above)
+    int mine[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { mine[s] = (lane + 64 * s < size) ? ids[lane + 64 * s] : 0; place[s] = 0; }
+#pragma unroll 4
+    for (int q = 0; q < size; q += 4) {                           // (unrolled: the reads of four rounds in flight, not one LDS round trip per round)
+        const int4 o = *(const int4 *)&ids[q];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) place[s] += (o.x < mine[s]) + (o.y < mine[s]) + (o.z < mine[s]) + (o.w < mine[s]);
+    }
+}
 __global__ __launch_bounds__(256) void k3_clusters(Det3dBufs B, int max_centers, float sx, float sy, float cs, float sn)
 {
 #pragma clang fp contract(off)
-    __shared__ __attribute__((aligned(16))) int s_root[RDET_MAX_CENTERS], s_size[RDET_MAX_CENTERS];
+    __shared__ __attribute__((aligned(16))) unsigned long long s_key[RDET_MAX_CENTERS];
+    __shared__ int s_root[RDET_MAX_CENTERS], s_size[RDET_MAX_CENTERS], s_first[RDET_MAX_CENTERS], s_lastp[RDET_MAX_CENTERS];
     __shared__ int s_byrank[RDET_MAX_CENTERS];
     __shared__ int s_n, s_err;
     __shared__ __attribute__((aligned(16))) int m_id[4][MAX_SZ + 4];
     __shared__ __attribute__((aligned(16))) float m_x[4][MAX_SZ], m_y[4][MAX_SZ], o_x[4][MAX_SZ], o_y[4][MAX_SZ];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     D3_MARK(0);
-    if (tid == 0) { s_n = 0; s_err = 0; }
-    s_root[tid] = 0x7fffffff; s_size[tid] = -1;                                   // (the ranking below reads four entries at a time)
-    __syncthreads();
     const int nroots = B.ctl->nroots;
+    if (tid == 0) { s_n = 0; s_err = 0; }
+    s_key[tid] = ~0ull;                                                           // (no real key is above it)
+    __syncthreads();
     for (int k = tid; k < nroots; k += 256) {
-        const int r = B.roots[k], c = B.cnt[r];
+        const int r = B.roots[k], c = B.cnt[r], f = B.first[r], l = B.last[r];   // (extents with the size, not behind the ranking)
         if (c >= MIN_SZ && c <= MAX_SZ) {                                         // :70-71
             const int pos = atomicAdd(&s_n, 1);
-            if (pos < RDET_MAX_CENTERS) { s_root[pos] = r; s_size[pos] = c; }
-            else s_err = RDET_ERR_CAPACITY;
+            if (pos < RDET_MAX_CENTERS) {
+                s_root[pos] = r; s_size[pos] = c; s_first[pos] = f; s_lastp[pos] = l;
+                s_key[pos] = ((unsigned long long)(unsigned)(MAX_SZ - c) << 32) | (unsigned)r;
+            } else s_err = RDET_ERR_CAPACITY;
         }
     }
     __syncthreads();
@@ -713,46 +833,49 @@ __global__ __launch_bounds__(256) void k3_clusters(Det3dBufs B, int max_centers,
     int n = min(s_n, RDET_MAX_CENTERS);
     int err = s_err;
     if (n > max_centers) { err = RDET_ERR_BUFFER; n = 0; }
-    if (tid < n) {
+    // rank = the number of keys below one's own ((MAX_SZ - size, root): size descending, root ascending); four threads per entry, two
+    // keys per LDS read (round 4: one thread per entry, size and root apart: 3 us for 76 entries)
+    for (int e0 = 0; e0 < n; e0 += 64) {
+        const int e = e0 + (tid >> 2), sub = tid & 3;
+        const unsigned long long me = s_key[e];
         int rank = 0;
-        const int sz = s_size[tid], rt = s_root[tid];
-        for (int k = 0; k < n; k += 4) {                                            // (one LDS round trip per entry made this 6 us)
-            const int4 zs = *(const int4 *)&s_size[k], rs = *(const int4 *)&s_root[k];
-            rank += (zs.x > sz || (zs.x == sz && rs.x < rt)) + (zs.y > sz || (zs.y == sz && rs.y < rt)) +
-                    (zs.z > sz || (zs.z == sz && rs.z < rt)) + (zs.w > sz || (zs.w == sz && rs.w < rt));
+#pragma unroll 4
+        for (int k = 2 * sub; k < n; k += 8) {
+            const ulonglong2 kk = *(const ulonglong2 *)&s_key[k];
+            rank += (kk.x < me) + (kk.y < me);
         }
-        s_byrank[rank] = tid;
+        rank += __shfl_xor(rank, 1, 64); rank += __shfl_xor(rank, 2, 64);
+        if (sub == 0 && e < n) s_byrank[rank] = e;
     }
     __syncthreads();
-    if (blockIdx.x == 0) {
-        if (tid == 0) {
-            B.ctl->K = n; B.ctl->err = err;
-            d3_host_store16(&B.hout->head, (unsigned)n, (unsigned)err, (unsigned)B.ctl->M2, (unsigned)B.seq);   // the centres follow, each with its own tag
+    if (blockIdx.x == 0 && tid == 0) {
+        B.ctl->K = n; B.ctl->err = err;
+        d3_host_store16(&B.hout->head, (unsigned)n, (unsigned)err, (unsigned)B.ctl->M, (unsigned)B.seq);   // the centres follow, each with its own tag
+    }
+    // the next cloud's grid: the box of this cloud's survivors (= of the tiles' boxes), a little wider, at least 1/8 m per cell -- by the LAST
+    // workgroup, the one least likely to have a component to sum (round 4: the first one, which has the largest)
+    if (blockIdx.x == gridDim.x - 1 && wave == 3) {
+        const int ntiles = (B.ctl->M + BOX_PTS - 1) / BOX_PTS;
+        float x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY;
+        for (int t = lane; t < ntiles; t += 64) {
+            const float4 lo = *(const float4 *)(B.box + 8 * t), hi = *(const float4 *)(B.box + 8 * t + 4);
+            x0 = fminf(x0, lo.x); y0 = fminf(y0, lo.y); x1 = fmaxf(x1, lo.w); y1 = fmaxf(y1, hi.x);
         }
-        // the next cloud's grid: the box of this cloud's inliers (= of the tiles' boxes), a little wider, at least 1/8 m per cell
-        if (wave == 0) {
-            const int ntiles = (B.ctl->M + BOX_PTS - 1) / BOX_PTS;
-            float x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY;
-            for (int t = lane; t < ntiles; t += 64) {
-                const float4 lo = *(const float4 *)(B.box + 8 * t), hi = *(const float4 *)(B.box + 8 * t + 4);
-                x0 = fminf(x0, lo.x); y0 = fminf(y0, lo.y); x1 = fmaxf(x1, lo.w); y1 = fmaxf(y1, hi.x);
-            }
-            for (int off = 32; off > 0; off >>= 1) {
-                x0 = fminf(x0, __shfl_xor(x0, off, 64)); y0 = fminf(y0, __shfl_xor(y0, off, 64));
-                x1 = fmaxf(x1, __shfl_xor(x1, off, 64)); y1 = fmaxf(y1, __shfl_xor(y1, off, 64));
-            }
-            if (lane == 0 && x0 <= x1 && y0 <= y1 && fabsf(x0) < 1e30f && fabsf(x1) < 1e30f && fabsf(y0) < 1e30f && fabsf(y1) < 1e30f) {
-                const float ext = fmaxf(fmaxf(x1 - x0, y1 - y0) * 1.05f, 0.125f * GRID_G);
-                B.ctl->gx0 = 0.5f * (x0 + x1) - 0.5f * ext; B.ctl->gy0 = 0.5f * (y0 + y1) - 0.5f * ext; B.ctl->ginv = (float)GRID_G / ext;
-            }
+        for (int off = 32; off > 0; off >>= 1) {
+            x0 = fminf(x0, __shfl_xor(x0, off, 64)); y0 = fminf(y0, __shfl_xor(y0, off, 64));
+            x1 = fmaxf(x1, __shfl_xor(x1, off, 64)); y1 = fmaxf(y1, __shfl_xor(y1, off, 64));
+        }
+        if (lane == 0 && x0 <= x1 && y0 <= y1 && fabsf(x0) < 1e30f && fabsf(x1) < 1e30f && fabsf(y0) < 1e30f && fabsf(y1) < 1e30f) {
+            const float ext = fmaxf(fmaxf(x1 - x0, y1 - y0) * 1.05f, 0.125f * GRID_G);
+            B.ctl->gx0 = 0.5f * (x0 + x1) - 0.5f * ext; B.ctl->gy0 = 0.5f * (y0 + y1) - 0.5f * ext; B.ctl->ginv = (float)GRID_G / ext;
         }
     }
     D3_MARK(2);
     const int rank = blockIdx.x * 4 + wave;
     if (rank >= n) return;
     const int e = s_byrank[rank], root = s_root[e], size = s_size[e];
-    const int *slabel = reinterpret_cast<const int *>(B.dist);
-    const int first = B.first[root], last = B.last[root];
+    const int *slabel = reinterpret_cast<const int *>(B.dist_s);
+    const int first = s_first[e], last = s_lastp[e];
     int have = 0;
     // a component's members sit close together in the sorted copy -- except when it straddles a major Morton boundary
     // (stretches of a few thousand positions occur): sixteen chunks' labels per round trip, then the members' data
@@ -765,7 +888,7 @@ __global__ __launch_bounds__(256) void k3_clusters(Det3dBufs B, int max_centers,
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int s = b0 + 64 * u + lane;
-            if (sl[u] == root) { id[u] = B.perm[s]; mx[u] = B.s1[s]; my[u] = B.s1[B.cap + s]; }   // (a member's x is never masked)
+            if (sl[u] == root) { id[u] = B.perm[s]; mx[u] = B.s1[s]; my[u] = B.s1[B.cap + s]; }
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
@@ -783,27 +906,23 @@ __global__ __launch_bounds__(256) void k3_clusters(Det3dBufs B, int max_centers,
 #ifdef RDET_DEBUG_MARKS
     if (threadIdx.x == 0 && blockIdx.x < 2048) { d3_marks[blockIdx.x][6] = (unsigned long long)(last - first + 1); d3_marks[blockIdx.x][7] = (unsigned long long)size; }
 #endif
-    // arrival order: a member's place = the number of members with a smaller node id (ids four at a time: the list is
-    // padded with ids no member is above)
     if (lane < 4) m_id[wave][size + lane] = 0x7fffffff;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     {
-        const int k0 = lane, k1 = lane + 64, k2 = lane + 128;
-        const int i0 = (k0 < size) ? m_id[wave][k0] : 0, i1 = (k1 < size) ? m_id[wave][k1] : 0, i2 = (k2 < size) ? m_id[wave][k2] : 0;
-        int p0 = 0, p1 = 0, p2 = 0;
-        for (int q = 0; q < size; q += 4) {
-            const int4 o = *(const int4 *)&m_id[wave][q];
-            p0 += (o.x < i0) + (o.y < i0) + (o.z < i0) + (o.w < i0);
-            p1 += (o.x < i1) + (o.y < i1) + (o.z < i1) + (o.w < i1);
-            p2 += (o.x < i2) + (o.y < i2) + (o.z < i2) + (o.w < i2);
+        int place[3] = {0, 0, 0};
+        if (size <= 64) arrival_places<1>(m_id[wave], size, lane, place);
+        else if (size <= 128) arrival_places<2>(m_id[wave], size, lane, place);
+        else arrival_places<3>(m_id[wave], size, lane, place);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int k = lane + 64 * s;
+            if (k < size) { o_x[wave][place[s]] = m_x[wave][k]; o_y[wave][place[s]] = m_y[wave][k]; }
         }
-        if (k0 < size) { o_x[wave][p0] = m_x[wave][k0]; o_y[wave][p0] = m_y[wave][k0]; }
-        if (k1 < size) { o_x[wave][p1] = m_x[wave][k1]; o_y[wave][p1] = m_y[wave][k1]; }
-        if (k2 < size) { o_x[wave][p2] = m_x[wave][k2]; o_y[wave][p2] = m_y[wave][k2]; }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     float cx = 0.f, cy = 0.f;
     int q = 0;
+#pragma unroll 4
     for (; q + 4 <= size; q += 4) {
         const float4 vx = *(const float4 *)&o_x[wave][q], vy = *(const float4 *)&o_y[wave][q];
         cx += vx.x; cx += vx.y; cx += vx.z; cx += vx.w;
@@ -826,7 +945,7 @@ struct rdet3d {
     double s2b[3];
     int max_points, device;
     hipStream_t stream;
-    float *d_xyzi, *d_p1, *d_s1, *d_dist, *d_box;
+    float *d_xyzi, *d_p1, *d_s1, *d_dist, *d_dist_s, *d_box;
     int *d_label, *d_cnt, *d_first, *d_last, *d_roots, *d_perm, *d_hist, *d_cursor;
     Det3dCtl *d_ctl;
     Det3dHostOut *h_out, *dv_out;      // pinned + mapped: polled result slots (host / device view)
@@ -834,6 +953,7 @@ struct rdet3d {
     bool xyzi_in_vram;                 // d_xyzi is fine-grained device memory the host writes through the PCIe BAR (else: pinned staging + copy)
     float *h_stage;
     int seq;
+    int m_hint;                        // the previous cloud's survivors of the gate (k3_knn: m_hint)
     std::string hip_error;
 };
 
@@ -869,7 +989,7 @@ int rdet3d_create(const rdet3d_options *opt, const double s2b[3], int max_points
             DET3_TRY(h, hipMalloc(&h->d_xyzi, 16 * np));
             DET3_TRY(h, hipHostMalloc(&h->h_stage, 16 * np));
         }
-        // + 1024 floats: the sweeps read candidates eight at a time through the scalar cache, unclamped, up to a few groups past the end
+        // + 1024 floats: the sweeps ask for the aligned 64 points around a query before they know M (up to 63 past the end)
         DET3_TRY(h, hipMalloc(&h->d_p1, 12 * np + 4096)); DET3_TRY(h, hipMemset(h->d_p1, 0, 12 * np + 4096));
         DET3_TRY(h, hipMalloc(&h->d_s1, 12 * np + 4096)); DET3_TRY(h, hipMemset(h->d_s1, 0, 12 * np + 4096));
         DET3_TRY(h, hipMalloc(&h->d_perm, 4 * np + 4096)); DET3_TRY(h, hipMemset(h->d_perm, 0, 4 * np + 4096));
@@ -877,6 +997,7 @@ int rdet3d_create(const rdet3d_options *opt, const double s2b[3], int max_points
         DET3_TRY(h, hipMalloc(&h->d_hist, 4 * GRID_CELLS)); DET3_TRY(h, hipMemset(h->d_hist, 0, 4 * GRID_CELLS));
         DET3_TRY(h, hipMalloc(&h->d_cursor, 4 * GRID_CELLS));
         DET3_TRY(h, hipMalloc(&h->d_dist, 4 * np + 4096)); DET3_TRY(h, hipMemset(h->d_dist, 0, 4 * np + 4096));
+        DET3_TRY(h, hipMalloc(&h->d_dist_s, 4 * np + 4096)); DET3_TRY(h, hipMemset(h->d_dist_s, 0, 4 * np + 4096));
         DET3_TRY(h, hipMalloc(&h->d_label, 4 * np));
         DET3_TRY(h, hipMalloc(&h->d_cnt, 4 * np));
         DET3_TRY(h, hipMalloc(&h->d_last, 4 * np));
@@ -905,7 +1026,7 @@ void rdet3d_destroy(rdet3d_t *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *ptrs[] = {h->d_xyzi, h->d_p1, h->d_s1, h->d_dist, h->d_box, h->d_label, h->d_cnt, h->d_first, h->d_last, h->d_roots, h->d_perm, h->d_hist, h->d_cursor, h->d_ctl};
+    void *ptrs[] = {h->d_xyzi, h->d_p1, h->d_s1, h->d_dist, h->d_dist_s, h->d_box, h->d_label, h->d_cnt, h->d_first, h->d_last, h->d_roots, h->d_perm, h->d_hist, h->d_cursor, h->d_ctl};
     for (void *p : ptrs) (void)hipFree(p);
     if (h->h_out) (void)hipHostFree(h->h_out);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -947,23 +1068,22 @@ int rdet3d_handle_cloud(rdet3d_t *h, double stamp, const float *xyzi, int N, flo
     dbg_t[1] = dbg_us();
 #endif
     Det3dBufs B;
-    B.xyzi = h->d_xyzi; B.p1 = h->d_p1; B.s1 = h->d_s1; B.perm = h->d_perm; B.box = h->d_box; B.hist = h->d_hist; B.cursor = h->d_cursor;
+    B.xyzi = h->d_xyzi; B.p1 = h->d_p1; B.s1 = h->d_s1; B.dist_s = h->d_dist_s; B.perm = h->d_perm; B.box = h->d_box; B.hist = h->d_hist; B.cursor = h->d_cursor;
     B.dist = h->d_dist; B.label = h->d_label; B.cnt = h->d_cnt; B.first = h->d_first; B.last = h->d_last; B.roots = h->d_roots;
     B.ctl = h->d_ctl; B.cap = h->max_points;
     B.hout = h->dv_out; B.seq = ++h->seq;
     h->in_flight = true;
-    const int ftiles = (N + 1023) / 1024, b256 = (N + 255) / 256;
+    const int ftiles = (N + 1023) / 1024, b256 = (N + 255) / 256, ntiles_ub = (N + BOX_PTS - 1) / BOX_PTS;
     hipLaunchKernelGGL(k3_filter_count, dim3(ftiles), dim3(1024), 0, h->stream, B, N, h->opt.intensity_min);
     hipLaunchKernelGGL(k3_filter_write, dim3(ftiles + GRID_CELLS / 1024), dim3(1024), 0, h->stream, B, N, h->opt.intensity_min, ftiles);
-    hipLaunchKernelGGL(k3_scatter, dim3(ftiles), dim3(1024), 0, h->stream, B);
-    hipLaunchKernelGGL(k3_boxes, dim3(b256), dim3(256), 0, h->stream, B);
+    hipLaunchKernelGGL(k3_scatter, dim3(ftiles), dim3(1024), 0, h->stream, B, N);
+    hipLaunchKernelGGL(k3_boxes, dim3(b256), dim3(256), 0, h->stream, B, N);
     const int qblocks = (N + QW - 1) / QW < Q_GRID ? (N + QW - 1) / QW : Q_GRID;   // a wave per query, dealt round-robin: M <= N stays on the device
-    hipLaunchKernelGGL(k3_knn, dim3(qblocks), dim3(64 * QW), 0, h->stream, B);
-    hipLaunchKernelGGL(k3_sor, dim3(b256), dim3(256), 0, h->stream, B);
-    hipLaunchKernelGGL(k3_cc_min, dim3(qblocks), dim3(64 * QW), 0, h->stream, B);
-    hipLaunchKernelGGL(k3_cc_link, dim3(qblocks), dim3(64 * QW), 0, h->stream, B);
+    hipLaunchKernelGGL(k3_knn, dim3(qblocks), dim3(64 * QW), 0, h->stream, B, N, ntiles_ub, h->m_hint);
+    hipLaunchKernelGGL(k3_cc_min, dim3(qblocks), dim3(64 * QW), 0, h->stream, B, N, ntiles_ub, h->m_hint);
+    hipLaunchKernelGGL(k3_cc_link, dim3(qblocks), dim3(64 * QW), 0, h->stream, B, N, ntiles_ub, h->m_hint);
     const float sa = (float)h->s2b[2];
-    hipLaunchKernelGGL(k3_finish_a, dim3(b256), dim3(256), 0, h->stream, B);
+    hipLaunchKernelGGL(k3_finish_a, dim3(b256), dim3(256), 0, h->stream, B, N);
     hipLaunchKernelGGL(k3_clusters, dim3(RDET_MAX_CENTERS / 4), dim3(256), 0, h->stream, B, max_centers < RDET_MAX_CENTERS ? max_centers : RDET_MAX_CENTERS,
                        (float)h->s2b[0], (float)h->s2b[1], cosf(sa), sinf(sa));
     DET3_TRY(h, hipGetLastError());
@@ -993,7 +1113,8 @@ int rdet3d_handle_cloud(rdet3d_t *h, double stamp, const float *xyzi, int N, flo
     dbg_t[3] = dbg_us();
 #endif
     const Det3dHead head = h->h_out->head;
-    if (head.err) return head.err;
+    h->m_hint = head.M;
+    if (head.err) { h->in_flight = true; return head.err; }          // (whatever is left of the chain: synchronised by the next call)
     *K = head.K;
     for (int c = 0; c < head.K; ++c) {
         rc = wait_tag(&h->h_out->centers[c].seq);

@@ -34,9 +34,9 @@ if len(sys.argv) > 2 and sys.argv[2] == "link":        # k3_cc_link: first query
     live = m[:, 3] > 0
     live[:64] = False                                   # (k3_clusters has overwritten those)
     t0 = m[live, 0].min()
-    rows = [((r[0] - t0) / 100, (r[1] - r[0]) / 100, (r[2] - r[1]) / 100, (r[3] - r[2]) / 100, (r[3] - t0) / 100, r[6]) for r in m[live]]
+    rows = [((r[0] - t0) / 100, (r[1] - r[0]) / 100, (r[2] - r[1]) / 100, (r[3] - r[2]) / 100, (r[3] - t0) / 100, r[6], (r[5] - r[4]) / 100 if r[5] > r[4] else 0, (r[3] - r[5]) / 100 if r[5] > 0 else 0, r[7]) for r in m[live]]
     rows.sort(key=lambda x: -x[4])
-    print("k3_cc_link: start  chase  boxes  sweep  end(us)  tiles   (%d workgroups)" % len(rows))
+    print("k3_cc_link: start  chase  boxes  sweep  end(us)  tiles  last batch: tops(us) unions+rest(us) hops*10000+rounds*100+distinct  (%d workgroups)" % len(rows))
     print('starts: median %.2f p90 %.2f max %.2f' % tuple(np.percentile([r[0] for r in rows], [50, 90, 100])))
     for r in rows[:10] + rows[-3:]:
-        print("          %6.2f %6.2f %6.2f %6.2f %7.2f %5d" % r)
+        print("          %6.2f %6.2f %6.2f %6.2f %7.2f %5d %6.2f %6.2f %7d" % r)
