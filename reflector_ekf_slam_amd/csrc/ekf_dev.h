@@ -122,6 +122,10 @@ struct RekfFrontArgs {
     int pred_slot;            // which RekfCtl::pred slot this scan's Predict goes through (front kernel writes, k_mid reads)
     unsigned front_target;    // RekfCtl::front_count once all K observations of THIS scan are matched: the workgroup that reaches it compacts
     int compact_in_front;     // 1: whole scan (K <= 32, one pass of k_mid): the front end leaves RekfCtl::rec; 0: wide scan (k_compact_wide)
+    int compact_in_mid;       // whole scan whose front end is a LAUNCH in front of k_mid (k_front_mb, k_dd_front): its workgroups leave their results in
+                              // RekfCtl::obs_kind / obs_idx and end -- no count, no compacting workgroup; k_mid, behind the kernel boundary, compacts them
+                              // for itself (every workgroup: 2 loads + one wave's ballots).  The count-and-elect scheme put a 255 -> 1 fan-in and a
+                              // second pass through memory (~4 us) on the path of every scan that is not speculated
     int aug_pending;          // front role inside k_dd_front: the previous scan's k_augment has not run yet -- the state the match sees has
                               // n + 2 n_new rows (the new reflectors' means are there: k_mid writes them)
     int front_in_mid;         // k_mid: the first front_in_mid workgroups of its grid are this scan's front end (a host-predicted scan behind a

@@ -506,6 +506,7 @@ __device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs
                     __hip_atomic_store(&ctl->obs_kind[i], kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&ctl->obs_idx[i], best_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                if (!SPEC && A.compact_in_mid) continue;                // (the kernel boundary hands the results over: RekfFrontArgs::compact_in_mid)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (A.front_in_mid) (void)__hip_atomic_fetch_add(&ctl->front_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (nobody to elect: no returning round trip)
                 else {
@@ -1148,7 +1149,9 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, int h0, int h1,
     // scalar one, so the control block costs one memory round trip, not two
     constexpr int NREC = (int)(sizeof(RekfCtl::Rec) / sizeof(int));
     static_assert(NREC <= 512, "one load per thread");
-    const int rec_raw = (!FRONT && tid < NREC) ? ((const int *)&ctl->rec[hd_pred_slot])[tid] : 0;
+    const bool cim = !FRONT && A.compact_in_mid != 0 && A.pair0 < 0;            // the front end's raw results instead (RekfFrontArgs::compact_in_mid)
+    const int rec_raw = (!FRONT && !cim && tid < NREC) ? ((const int *)&ctl->rec[hd_pred_slot])[tid] : 0;
+    const int cim_kind = (cim && tid < A.K && tid < 32) ? ctl->obs_kind[tid] : -1, cim_idx = (cim && tid < A.K && tid < 32) ? ctl->obs_idx[tid] : -1;
     // ... and the pending scan's WRITE-AHEAD CORRECTION (RekfCtl::cp_*, RekfDev::cp; phase G below): which landmarks it covers
     int cp_uid_l = -1, cp_nu_l = -1;
     unsigned cp_scan_l = 0u;
@@ -1285,7 +1288,8 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, int h0, int h1,
         }
     } else if (A.pair0 < 0) {
         // whole scan: the record the front end left (its last workgroup compacted the results, front_role) -- one load, one LDS store
-        if (!FRONT && tid < NREC) ((int *)&s_rec)[tid] = rec_raw;                 // (FRONT: compacted above)
+        if (cim) { if (tid < 64) compact_record(&s_rec, ctl, cim_kind, cim_idx, tid, A.K, n, d.n_max, A.has_gps); }
+        else if (!FRONT && tid < NREC) ((int *)&s_rec)[tid] = rec_raw;            // (FRONT: compacted above)
     }
 #ifdef REKF_DEBUG_MID_FIRST
     MMARK();                                        // (x4: wave 0 through the compaction)

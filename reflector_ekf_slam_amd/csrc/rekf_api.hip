@@ -90,6 +90,7 @@ struct rekf {
     bool dd_aug_inline_ok = false;  // ... and it may run inside the next scan's k_mid instead of a launch of its own (RekfCtl::augrec: whole scans only)
     bool aug_in_mid = true;         // REKF_AUG_IN_MID=0 in the environment turns that off (A/B measurements)
     bool front_in_mid = true;       // a scan's front end runs inside k_mid's grid (REKF_FRONT_IN_MID=0: as k_front_mb, a launch of its own)
+    bool compact_in_mid = true;     // RekfFrontArgs::compact_in_mid (REKF_COMPACT_IN_MID=0: the front end counts, its last workgroup compacts)
     // ONE LAUNCH PER SCAN (round 5; REKF_SCAN_LAUNCH=0 turns it off): the held-back downdate is not applied in front of the next scan's
     // k_mid but BESIDE it -- as a role of the same launch, from the stored P into the other P buffer -- while the mid role corrects what
     // it gathers by the pending panels (k_mid): the rank-m downdate is off the update's critical path.  For a filter that cannot grow
@@ -538,6 +539,7 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
     { const char *e = std::getenv("REKF_LAZY_DD"); h->lazy_dd = !(e && e[0] == '0'); }
     { const char *e = std::getenv("REKF_AUG_IN_MID"); h->aug_in_mid = !(e && e[0] == '0'); }
     { const char *e = std::getenv("REKF_FRONT_IN_MID"); h->front_in_mid = !(e && e[0] == '0'); }
+    { const char *e = std::getenv("REKF_COMPACT_IN_MID"); h->compact_in_mid = !(e && e[0] == '0'); }
     { const char *e = std::getenv("REKF_SCAN_LAUNCH"); h->scan_launch = !(e && e[0] == '0'); }
     { const char *e = std::getenv("REKF_EXCLUSIVE"); h->exclusive = e && e[0] == '1'; }
     { const char *e = std::getenv("REKF_SPEC"); h->spec_enable = !(e && e[0] == '0'); }
@@ -824,7 +826,15 @@ static int process_scan(rekf_t *h, double t, const float *xy, int K, const doubl
     // SPECULATIVE MATCH (struct rekf): the previous launch has run this scan's front end -- no front end now; k_mid proves the record
     const bool use_spec = fast && h->spec_ready && h->spec_scan == (unsigned)h->scan_count && !a.host_pred;
     h->spec_ready = false;
-    if (!use_spec) h->front_total += (unsigned)K;    // (the front end counts the observations it matches; the speculative one has counted these)
+    // a whole scan whose front end is a launch in front of k_mid leaves its raw results; k_mid compacts for itself (RekfFrontArgs::compact_in_mid).
+    // (Decided further down -- where the front end goes -- but the count it would have added to belongs here.)
+    const bool front_in_grid = !use_spec && alone && h->front_in_mid &&
+                               ((fast && !next) || (!fast && !with_dd && a.host_pred && !blocks && !staged && K <= 32));   // (as decided below)
+    // (not when the front end rides inside k_dd_front: there the previous scan's downdate sets the launch's length, the election is hidden,
+    // and k_mid would pay 0.9 us for the compaction)
+    const bool cim = h->compact_in_mid && !use_spec && !blocks && !staged && K <= 32 && !front_in_grid && (fast || !with_dd);
+    a.compact_in_mid = cim ? 1 : 0;
+    if (!use_spec && !cim) h->front_total += (unsigned)K;    // (the front end counts the observations it matches; the speculative one has counted these)
     a.front_target = h->front_total;
     a.spec = use_spec ? 1 : 0;
     a.compact_in_front = blocks ? 0 : 1;
