@@ -254,8 +254,10 @@ def test_heading_at_the_wrap_and_observations_on_the_gate(oracle_lib, seed):
 
 # ---------------------------------------------------------------------------------------------- C3 at full size
 def test_c3_500_steady_state_updates_match_the_structured_oracle(oracle_lib):
-    """BASELINE.json configs[2] at full size: 500 consecutive steady-state updates (k_front_mb device-predicted, k_mid<4>,
-    k_downdate2<64> on all tile classes) against the oracle from the same state -- associations every scan, the mean every 25."""
+    """BASELINE.json configs[2] at full size: 500 consecutive steady-state updates against the oracle from the same state --
+    associations every scan, the mean every 25.  (Since round 5 the steady-state chain of a full filter is ONE launch per update,
+    k_mid<4, 0>: the scan's mid role, the previous scan's downdate role over all tile classes and the next scan's speculative front
+    end; the scans whose pose is read back here go out as k_front_mb + the same launch.)"""
     from reflector_ekf_slam_amd import session as S
     cfg = synth.C3
     sess = synth.make_session(cfg)

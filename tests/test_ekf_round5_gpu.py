@@ -157,3 +157,82 @@ def test_handles_driven_from_threads_that_fire_together(full):
         assert g.sync_code() == 0 and g.flags() == 0
         st = g.GetState()
         assert np.array_equal(st.mu, ref.mu) and np.array_equal(st.sigma, ref.sigma)
+
+
+def test_every_entry_point_in_the_middle_of_the_pipeline(monkeypatch):
+    """Scan after scan on a full filter the newest scan is HELD on the host (it goes out with its successor, whose front end it carries),
+    the covariance in memory is one downdate behind and the newest landmark means live in the other buffer.  Every entry point of the C ABI
+    must see none of that: called between two scans it returns -- and leaves behind -- exactly what it does on a twin handle that has no
+    pipeline at all (REKF_SPEC=0, REKF_SCAN_LAUNCH=0: every scan goes out when it is handed over, as front end + k_mid with the previous
+    scan's downdate in front).  Same calls at the same places on both (a call that reads the pose makes the next scan host-predicted --
+    the reference's own cos / sin instead of the device's, a round-off level difference DESIGN 3 documents -- so the twin must read
+    where the pipelined handle reads).  Wide scans (40 observations: block steps), an empty scan and odometry in between."""
+    from reflector_ekf_slam_amd import ReflectorEKFSLAM
+    from reflector_ekf_slam_amd import session as S
+    cfg = synth.SessionConfig("r5_api", 140, 24, synth.DIFF, seed=5711, speed=1.4, row_spacing=6.0)
+    sess = synth.make_session(cfg)
+    scans = synth.steady_state_scans(sess, 240)
+    wide = {37, 91, 140}                                       # these scans carry 40 observations: block steps through the same kernels
+
+    def run(pipelined):
+        monkeypatch.setenv("REKF_SPEC", "1" if pipelined else "0")
+        monkeypatch.setenv("REKF_SCAN_LAUNCH", "1" if pipelined else "0")
+        g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks, auto_grow=False)
+        S.replay(sess, g)
+        assert g.sync_code() == 0
+        seen = []
+        t_prev = None
+        for k, (t, ob) in enumerate(scans):
+            ob = np.array(ob, np.float32, copy=True)
+            if k in wide:
+                ob = np.concatenate([ob, ob[:16] + np.float32(0.01)])      # (sixteen reflectors seen twice: duplicates in the joint update)
+            if k == 61:
+                g.handle_observation(t, np.zeros((0, 2), np.float32))      # an empty scan: Predict only (cc:235-236)
+            else:
+                g.handle_observation(t, ob)
+            op = (k // 3) % 16 if k % 3 == 2 else -1          # (two scans in a row run through the pipeline, the third is followed by a call)
+            if op == 1: seen.append(("pose", g.pose()))
+            elif op == 2: seen.append(("n", g.n))
+            elif op == 3: seen.append(("match", norm_match(g.last_match())))
+            elif op == 4: st = g.GetState(); seen.append(("state", st.time, st.mu.copy(), st.sigma.copy()))
+            elif op == 5: seen.append(("ellipses", g.marker_ellipses().copy()))
+            elif op == 6: p = g.PredictState(t + 0.013); seen.append(("predict", p.time, p.mu.copy(), p.sigma.copy()))
+            elif op == 7: seen.append(("time", g.GetLatestTime()))
+            elif op == 8: seen.append(("flags", g.flags()))
+            elif op == 9:
+                if t_prev is not None: g.handle_odometry(0.5 * (t + scans[min(k + 1, len(scans) - 1)][0]), 0.02, 0.0, 0.003)
+            elif op == 10: seen.append(("mu", g.mu().copy()))
+            elif op == 11: seen.append(("pose3", g.PredictPose(t + 0.002).mu.copy()))
+            elif op == 12: assert g.sync_code() == 0
+            elif op == 13 and k == 119:
+                st = g.GetState()                                          # the state out and in again: the pipeline starts over from it
+                g.set_state(st.time, st.mu, st.sigma)
+            elif op == 14: seen.append(("layout", g.device_layout()[:2]))
+            t_prev = t
+        code = g.sync_code()
+        fin = g.GetState()
+        cnt = _counters(g)
+        g.close()
+        return seen, fin, code, cnt
+
+    def same(a, b):
+        if isinstance(a, (tuple, list)):
+            return len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
+        if isinstance(a, np.ndarray):
+            return np.array_equal(a, b)
+        return a == b
+
+    s0, f0, c0, n0 = run(False)
+    s1, f1, c1, n1 = run(True)
+    assert n0[20] == 0 and n1[20] > 50, (n0[20], n1[20])     # the twin never speculated; the pipelined run did, scan after scan
+    assert c0 == c1
+    assert len(s0) == len(s1)
+    def worst(a, b):
+        if isinstance(a, (tuple, list)):
+            return max([worst(x, y) for x, y in zip(a, b)] + [0.0])
+        if isinstance(a, np.ndarray):
+            return float(np.max(np.abs(np.asarray(a, float) - np.asarray(b, float)))) if a.shape == b.shape and a.size else 0.0
+        return abs(float(a) - float(b)) if isinstance(a, (int, float)) and isinstance(b, (int, float)) else 0.0
+    for k, (a, b) in enumerate(zip(s0, s1)):
+        assert same(a, b), (k, a[0], worst(a[1:], b[1:]))
+    assert np.array_equal(f0.mu, f1.mu) and np.array_equal(f0.sigma, f1.sigma) and f0.time == f1.time
