@@ -696,8 +696,9 @@ __device__ static inline v4d block_mma2(const v4d &At, const v4d &B, v4d acc)
 // Blocked Gauss-Jordan inverse of the (16 nbr) x (16 nbr) matrix whose block column w this wave holds in S[] (C layout),
 // in place; the scheme is described above k_solve.  EVERY wave of the workgroup must call it (one s_barrier per block
 // step); waves with w >= nbr only keep the barrier count.  Returns true when a pivot block was not positive definite.
-template <int NBR, class Idle>
-__device__ static inline bool gj_invert_blocks(v4d (&S)[NBR], int nbr, int w, int g, int c, double (*s_col)[NBR + 1][REKF_PATCH], double *lp, Idle &&idle)
+struct NoMark { __device__ void operator()() const {} };
+template <int NBR, class Idle, class Mark = NoMark>
+__device__ static inline bool gj_invert_blocks(v4d (&S)[NBR], int nbr, int w, int g, int c, double (*s_col)[NBR + 1][REKF_PATCH], double *lp, Idle &&idle, Mark &&mark = Mark())
 {
     // idle(slot): the waves 4.. (no block column; they only keep the barrier count) are called back before the first barrier (slot 0) and
     // behind each one (slot K + 1) with work of the caller that must not sit on the pivot chain
@@ -716,7 +717,9 @@ __device__ static inline bool gj_invert_blocks(v4d (&S)[NBR], int nbr, int w, in
     for (int K = 0; K < NBR; ++K) {
         if (K >= nbr) break;
         double (*col)[REKF_PATCH] = s_col[K & 1];
+        mark();                                       // (debug builds: wave 0 reaches the barrier ...)
         lds_barrier();                                // column K and D^-1 of step K are published
+        mark();                                       // (... and leaves it)
         if (w >= nbr) { if (w >= 4) idle(K + 1); continue; }      // a wave without a block column only keeps the barrier count
         if (w == K) {
             // S(i,K) <- -S(i,K) D^-1 ; S(K,K) = D^-1 is already in place
@@ -2012,7 +2015,11 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, int h0, int h1,
         const bool bad = gj_invert_blocks<NBR>(S, nbr, w, g, c, s_col, s_leaf[w & 3], [&](int slot) __attribute__((always_inline)) {
             if (slot == 0) own_correct();             // (every element of s_pw has one owner; the barrier behind slot 0 orders it in front of own_w)
             else if (slot == 1) own_w();
-        });
+        }
+#ifdef REKF_DEBUG_GJ
+        , [&]() __attribute__((always_inline)) { MMARK(); }
+#endif
+        );
         MMARK();                                    // 5: inverted
         if (w < nbr) {
             if (bad && lane == 0 && first) atomicOr(&ctl->err, REKF_FLAG_SINGULAR);
