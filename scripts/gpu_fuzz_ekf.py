@@ -119,6 +119,10 @@ for seed in range(first, first + n_seeds):
             worst = max(worst, float(np.abs(g.mu() - o.mu()).max()))
     cov = 0.0
     if not overflow and not assoc_bad:
+        code = g.sync_code()                                                  # (the last burst of a steady tail ends without a check of its own)
+        if code == -4 or o.mu().shape[0] != g.mu().shape[0]: overflow = True
+        elif code != 0: assoc_bad += 1
+    if not overflow and not assoc_bad:
         st = g.GetState()
         _, Po = o.state()
         cov = float(np.abs(st.sigma - Po).max())
