@@ -784,9 +784,12 @@ static int process_scan(rekf_t *h, double t, const float *xy, int K, const doubl
     // ONE LAUNCH PER SCAN (struct rekf): the held-back downdate runs beside this scan's k_mid, from the stored P into the other buffer, and
     // the mid role corrects what it gathers -- for a filter that cannot grow, with n known, whole scans on this side
     const bool fast = h->dd_pending && h->scan_launch && h->full && h->n_exact && !h->dd_aug && !blocks && !staged && K <= 32;
-    // else the previous scan's downdate and this scan's front end go out as ONE launch (k_dd_front) when the caller has not read the pose
-    // since; after a read-back (the scan is host-predicted) it goes out first
-    const bool with_dd = h->dd_pending && (fast || !h->mir_valid);
+    // else the previous scan's downdate and this scan's front end go out as ONE launch (k_dd_front) -- also behind a read-back (the scan is
+    // host-predicted: its front end is a match only, which hides under the downdate), unless the handle is exclusive: there the front end
+    // runs inside k_mid's own grid and the downdate goes out first.  (Until round 5 every read-back sent the downdate out alone and
+    // the front end as a launch of its own behind it: 8 us per update of a caller that reads the pose after every scan of a growing filter.)
+    const bool with_dd = h->dd_pending && (fast || !h->mir_valid || !(in_grid_ok(h) && h->front_in_mid)) &&
+                         h->inject_failure != 2;          // (rekf_debug_inject_failure(2): the downdate goes out alone, and that launch "fails")
     if (!with_dd) {
         if (h->inject_failure == 2) { h->inject_failure = 0; h->hip_error = "injected failure (held-back downdate)"; return REKF_ERR_HIP; }
         int rcf = flush_dd(h);

@@ -52,7 +52,7 @@ def test_a_failing_scan_leaves_the_handle_as_it_found_it(oracle_lib, readback):
         stage = {5: 1, 9: 2, 14: 3, 40: 2, 41: 1, 57: 3, 58: 2}.get(scans, 0)
         if stage:
             if stage == 2:
-                g.pose()                                 # (a call that sends the held-back downdate out WITH its front end never gets to stage 2)
+                g.pose()                                 # (rounds 3-4: only behind a read-back did the held-back downdate go out alone; now the injection itself sees to it)
             g.inject_failure(stage)
             with pytest.raises(RekfError) as err:
                 g.handle_observation(t, ob)
@@ -76,21 +76,26 @@ def test_a_failing_scan_leaves_the_handle_as_it_found_it(oracle_lib, readback):
     assert g.sync_code() == 0
 
 
-def test_inject_stage_2_is_armed_until_a_call_reaches_it(oracle_lib):
-    """A call that sends the held-back downdate out together with its own front end (k_dd_front) never reaches stage 2; the
-    injection then stays armed for the first call that does -- here the scan behind a pose read-back."""
+def test_inject_stage_2_sends_the_held_back_downdate_out_alone_and_fails_it(oracle_lib):
+    """Since round 5 the held-back downdate of a default handle always travels with the next scan's launch (k_dd_front, or the scan's
+    one launch) -- also behind a pose read-back.  rekf_debug_inject_failure(2) therefore makes the next scan send it out ALONE, as an
+    exclusive handle does behind a read-back, and fails that launch before anything of the handle has moved: the call returns
+    REKF_ERR_HIP, the same scan handed over again is applied once."""
     cfg, sess = _session(L=30, obs=8, seed=4402)
     lin, ang, ob2 = cfg.sigma_v ** 2, cfg.sigma_w ** 2, cfg.sigma_obs ** 2
     g = make_gpu(cfg.odom_model, sess.init_time, sess.init_pose, lin, ang, ob2, cfg.n_landmarks)
+    o = make_oracle(cfg.odom_model, sess.init_time, sess.init_pose, lin, ang, ob2)
     scans = [(sess.ev_time[e], sess.obs_of(e)) for e in range(sess.n_events) if sess.ev_type[e] != synth.EV_ODOM][1:8]
-    g.handle_observation(*scans[0])
-    g.inject_failure(2)
-    g.handle_observation(*scans[1])                      # pipelined: goes out as k_dd_front, stage 2 not reached
-    g.pose()                                             # read-back: the held-back downdate goes out on its own
-    with pytest.raises(RekfError):
-        g.handle_observation(*scans[2])                  # nothing held back, mirror valid -> flush path -> injected
-    g.handle_observation(*scans[2])
-    assert g.sync_code() == 0 and np.isfinite(g.mu()).all()
+    for k, sc in enumerate(scans):
+        if k in (1, 4):
+            if k == 4: g.pose()                          # (... and behind a read-back)
+            g.inject_failure(2)
+            with pytest.raises(RekfError) as err:
+                g.handle_observation(*sc)
+            assert err.value.code == -2
+        g.handle_observation(*sc)
+        o.handle_observation(*sc)
+    assert g.sync_code() == 0 and g.n == o.n and np.abs(g.mu() - o.mu()).max() < TIGHT
 
 
 def test_default_wrapper_capacity_grows_like_the_reference(oracle_lib):
