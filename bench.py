@@ -598,7 +598,7 @@ def not_full_leg(args, base, cfg, sess, device, out_value=None):
     elapsed, used = timed_region(ekf, scans, 100, steps, None, lambda: None)
     res = {"value": steps / elapsed, "unit": "updates/s", "us_per_update": 1e6 * elapsed / steps, "steps": steps,
            "max_landmarks": 2 * cfg.n_landmarks, "n": ekf.n,
-           "note": "capacity 2 L: k_dd_front (the previous scan's downdate + this scan's front end) -> k_augment (the previous scan's; early-out) -> k_mid per update; k_mid publishes pose and the post-augment n"}
+           "note": "capacity 2 L: k_dd_front (the previous scan's downdate, whose last workgroup to finish appends that scan's new reflectors, + this scan's front end) -> k_mid per update; k_mid publishes pose and the post-augment n"}
     # ... and as the reference's node drives it: the pose read back after every scan (the host then knows n exactly and predicts itself)
     t0 = time.perf_counter()
     for t, ob in scans[used:used + steps]:

@@ -86,6 +86,7 @@ struct RekfCtl {
     // next k_mid's workgroup 0 does the appending first thing; the other workgroups wait for aug_done only when there IS something
     struct AugRec { int n_before, n2; float obs[2 * REKF_MAX_OBS_DEV]; } augrec[2];
     unsigned aug_done;                // scan id of the last k_mid whose workgroup 0 has appended its predecessor's new reflectors
+    int aug_arrive;                   // k_dd_front, RekfDev::aug_tail: downdate workgroups of the launch that are through (the last one appends; back to 0 by it)
     unsigned rec_seq;                 // scan id of the last scan whose match record (rec) the front role INSIDE k_mid's grid has completed
     // WRITE-AHEAD CORRECTION (round 5): at the end of a scan's k_mid the workgroups that own rows of the scan's sub-block R write the scan's
     // rank-m correction of P(R, R) -- sum_k HPt(lo, k) Kn(hi, k), the downdate's own arithmetic -- to RekfDev::cp (by scan parity).  The
@@ -184,6 +185,8 @@ struct RekfDev {
     int dd_sub;         // k_downdate2: class B holds the tiles with I >= J + dd_sub (2: a class-A workgroup also takes the tile below its
                         // diagonal tile; 1: it does not; 0: the host does not know n exactly -- the kernel derives the schedule itself)
     int dd_grid;        // k_dd_front: workgroups [0, dd_grid) are the downdate, the rest the next scan's front end (0: k_downdate2, the whole grid)
+    int aug_tail;       // k_dd_front: this view's scan may have met new reflectors (RekfCtl::augrec[aug_tail - 1]): the LAST downdate workgroup to
+                        // finish appends their covariance rows -- k_augment without a launch of its own; 0: no
     int pred_ix;        // the RekfCtl::pred index of the scan this view belongs to (scan id mod 4)
     int post_slot;      // k_downdate2 / k_mid: the RekfCtl::post_C9 slot of the scan this view belongs to (k_mid writes it, the scan's downdate stores it)
     int pred_slot;      // k_downdate2: >= 0: the scan's pending Predict (RekfCtl::pred[pred_slot]) is applied to the tiles of column 0 as they are

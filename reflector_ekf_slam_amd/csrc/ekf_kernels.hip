@@ -289,8 +289,8 @@ __device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs
     const double *__restrict__ P = d.P;
     const double *mu = d.mu;
     const size_t ld = (size_t)d.ld;
-    int n = (d.n_known >= 0) ? d.n_known : ctl->n + (A.aug_pending ? 2 * ctl->n_new : 0);
-    if (d.n_known < 0 && A.front_in_mid && A.aug_in_mid) {
+    int n = (d.n_known >= 0) ? d.n_known : ctl->n + (A.aug_pending == 1 ? 2 * ctl->n_new : 0);
+    if (d.n_known < 0 && ((A.front_in_mid && A.aug_in_mid) || A.aug_pending == 2)) {
         // inside k_mid's grid beside the mid role whose workgroup 0 is appending the previous scan's reflectors (and moving ctl->n) right
         // now: the dimension comes from that scan's augmentation record, as the mid role takes it
         const RekfCtl::AugRec *ar = &ctl->augrec[(A.pred_slot ^ 1) & 1];
@@ -2755,6 +2755,33 @@ __global__ __launch_bounds__(256) void k_dd_front(RekfDev d, RekfDev dn, RekfFro
     }
     extern __shared__ __attribute__((aligned(16))) double dd_smem_k[];
     dd_body<KC, false>(d, dd_smem_k, (int)blockIdx.x, d.dd_grid, nullptr, blockIdx.x == 0);
+    if (d.aug_tail) {
+        // The scan this downdate belongs to may have met new reflectors (a filter below its capacity): their covariance rows (cc:311-364) are
+        // functions of the DOWNDATED pose columns, i.e. of what this launch's workgroups are writing.  No launch of its own (k_augment:
+        // a kernel boundary and an early-out per scan) and no waiting workgroup: when there IS something to append -- every workgroup
+        // reads the same n2 -- each one releases its tiles and counts, and the one that counts last appends.
+        RekfCtl *ctl = d.ctl;
+        const RekfCtl::AugRec *ar = &ctl->augrec[(d.aug_tail - 1) & 1];
+        const int n2 = ar->n2;
+        if (n2 > 0) {
+            __shared__ int s_last_dd;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                s_last_dd = __hip_atomic_fetch_add(&ctl->aug_arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == d.dd_grid - 1;
+            }
+            __syncthreads();
+            if (s_last_dd) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                const int nb = ar->n_before;
+                double *scr = dd_smem_k;                 // (the downdate's panels are dead)
+                augment_rows(d, nb, n2, A.obs_cov, (double (*)[6])scr, scr + 6 * REKF_MAX_OBS_DEV, scr + 6 * REKF_MAX_OBS_DEV + 9, 256,
+                             [&](int k, float &rx, float &ry) { rx = ar->obs[2 * k]; ry = ar->obs[2 * k + 1]; });
+                if (threadIdx.x == 0) { ctl->n = nb + 2 * n2; ctl->aug_arrive = 0; }      // cc:360-363
+            }
+        }
+    }
 }
 
 // ----------------------------------------------------------------------------

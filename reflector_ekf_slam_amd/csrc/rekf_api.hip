@@ -91,6 +91,7 @@ struct rekf {
     bool aug_in_mid = true;         // REKF_AUG_IN_MID=0 in the environment turns that off (A/B measurements)
     bool front_in_mid = true;       // a scan's front end runs inside k_mid's grid (REKF_FRONT_IN_MID=0: as k_front_mb, a launch of its own)
     bool compact_in_mid = true;     // RekfFrontArgs::compact_in_mid (REKF_COMPACT_IN_MID=0: the front end counts, its last workgroup compacts)
+    bool aug_in_tail = true;        // RekfDev::aug_tail (REKF_AUG_IN_TAIL=0: k_augment as a launch of its own behind k_dd_front)
     // ONE LAUNCH PER SCAN (round 5; REKF_SCAN_LAUNCH=0 turns it off): the held-back downdate is not applied in front of the next scan's
     // k_mid but BESIDE it -- as a role of the same launch, from the stored P into the other P buffer -- while the mid role corrects what
     // it gathers by the pending panels (k_mid): the rank-m downdate is off the update's critical path.  For a filter that cannot grow
@@ -540,6 +541,7 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
     { const char *e = std::getenv("REKF_AUG_IN_MID"); h->aug_in_mid = !(e && e[0] == '0'); }
     { const char *e = std::getenv("REKF_FRONT_IN_MID"); h->front_in_mid = !(e && e[0] == '0'); }
     { const char *e = std::getenv("REKF_COMPACT_IN_MID"); h->compact_in_mid = !(e && e[0] == '0'); }
+    { const char *e = std::getenv("REKF_AUG_IN_TAIL"); h->aug_in_tail = !(e && e[0] == '0'); }
     { const char *e = std::getenv("REKF_SCAN_LAUNCH"); h->scan_launch = !(e && e[0] == '0'); }
     { const char *e = std::getenv("REKF_EXCLUSIVE"); h->exclusive = e && e[0] == '1'; }
     { const char *e = std::getenv("REKF_SPEC"); h->spec_enable = !(e && e[0] == '0'); }
@@ -861,13 +863,17 @@ static int process_scan(rekf_t *h, double t, const float *xy, int K, const doubl
         else { ProfScope ps(h, REKF_K_FRONT); rekf_launch_front_mb(h->dev, a, h->n_ub, h->stream); }
     } else if (with_dd) {
         h->dd_pending = false;
-        a.aug_pending = h->dd_aug ? 1 : 0;
-        h->dd_dev.P_out = h->dd_dev.P;                // (in place)
-        { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_dd_front(h->dd_dev, h->dd_n_ub, h->dev, a, h->stream); }
-        // the previous scan's augmentation: inside this scan's k_mid (its workgroup 0 appends the rows first thing -- no launch of its
-        // own between the two scans; whole scans on both sides), else as k_augment right behind the downdate
+        // the previous scan's augmentation: inside this scan's k_mid on an exclusive handle (its workgroup 0 appends the rows first thing;
+        // whole scans on both sides); else by the LAST downdate workgroup of this launch to finish (RekfDev::aug_tail: the previous scan
+        // was a whole scan, its record is in RekfCtl::augrec); else as k_augment right behind the downdate
         const bool inline_aug = alone && h->dd_aug && h->aug_in_mid && h->dd_aug_inline_ok && !blocks;
-        if (h->dd_aug && !inline_aug) { ProfScope ps(h, REKF_K_AUGMENT); rekf_launch_augment(h->dd_dev, h->dd_aug_args, h->stream); }
+        const bool tail_aug = h->dd_aug && !inline_aug && h->dd_aug_inline_ok && h->aug_in_tail;
+        a.aug_pending = h->dd_aug ? (tail_aug ? 2 : 1) : 0;
+        h->dd_dev.P_out = h->dd_dev.P;                // (in place)
+        h->dd_dev.aug_tail = tail_aug ? 1 + ((pred_slot ^ 1) & 1) : 0;
+        { ProfScope ps(h, REKF_K_DOWNDATE); rekf_launch_dd_front(h->dd_dev, h->dd_n_ub, h->dev, a, h->stream); }
+        h->dd_dev.aug_tail = 0;
+        if (h->dd_aug && !inline_aug && !tail_aug) { ProfScope ps(h, REKF_K_AUGMENT); rekf_launch_augment(h->dd_dev, h->dd_aug_args, h->stream); }
         h->dd_aug = false;
         a.aug_pending = 0;
         a.aug_in_mid = inline_aug ? 1 : 0;

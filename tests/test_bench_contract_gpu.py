@@ -77,7 +77,7 @@ def test_driver_command_steps20_warmup5_has_every_object():
     nf = d["not_full"]
     assert "error" not in nf, nf
     assert nf["max_landmarks"] == 2048 and nf["n"] == 2051 and nf["value"] > 5000 and nf["with_pose_readback"]["value"] > 3000
-    assert nf["kernel_us"]["augment"] is not None      # no launch of this library contains a waiting workgroup by default: k_augment is a launch of its own again
+    assert nf["kernel_us"]["augment"] is None          # k_augment has no launch of its own: the last downdate workgroup of k_dd_front to finish appends (no waiting workgroup either)
     assert nf["exclusive_handle"]["value"] > 5000
     assert d["multi_session"]["sessions_bit_identical"] is True
     det = d["detectors"]
