@@ -729,7 +729,7 @@ def cpu_baseline(args, cfg, sess, st, device):
     from reflector_ekf_slam_amd import ReflectorEKFSLAM, synth
     from reflector_ekf_slam_amd import session as S
     ns, nl = max(args.cpu_structured_steps, 1), max(args.cpu_literal_steps, 0)
-    all_scans = synth.steady_state_scans(sess, ns + nl + min(ns, 40), seed_offset=2000)
+    all_scans = synth.steady_state_scans(sess, ns + nl + 5 * max(min(ns, 40) // 5, 4), seed_offset=2000)
     shift = st.time - sess.ev_time[-1]            # these scans start right after the snapshot's time
     all_scans = [(t + shift, ob) for t, ob in all_scans]
     o = OracleEKF(cfg.odom_model, sess.init_time, sess.init_pose, cfg.sigma_v ** 2, cfg.sigma_w ** 2,
@@ -744,13 +744,22 @@ def cpu_baseline(args, cfg, sess, st, device):
     t_struct = (time.perf_counter() - t0) / ns
     # ... and the same algorithm on ALL host cores ("--mode structured --threads <all cores>"): the column-parallel loops of
     # the structured update (P H^T gather, H P gather, P -= K (H P)) under OpenMP; bit-identical to the 1-thread run by construction
+    # (a fork-join per column loop over 256 threads costs more than the loop: the thread counts in between are timed too, the best one named)
     ncores = os.cpu_count() or 1
-    o.set_threads(ncores)
     n_all = min(ns, 40)
-    t0 = time.perf_counter()
-    for t, ob in all_scans[ns:ns + n_all]:
-        o.handle_observation(t, ob)
-    t_all = (time.perf_counter() - t0) / max(n_all, 1)
+    sweep, k0, per = {}, ns, max(n_all // 5, 4)
+    for T in sorted({ncores, min(ncores, 64), min(ncores, 32), min(ncores, 16), min(ncores, 8)}, reverse=True):
+        o.set_threads(T)
+        chunk = all_scans[k0:k0 + per]
+        if not chunk: break
+        k0 += len(chunk)
+        t0 = time.perf_counter()
+        for t, ob in chunk:
+            o.handle_observation(t, ob)
+        sweep[T] = len(chunk) / (time.perf_counter() - t0)
+    t_all = 1.0 / sweep[ncores]
+    best_T = max(sweep, key=sweep.get)
+    n_all = k0 - ns
     o.set_threads(1)
     g2 = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks, device=device, auto_grow=False)
     g2.set_state(st.time, st.mu, st.sigma, vt)
@@ -766,7 +775,9 @@ def cpu_baseline(args, cfg, sess, st, device):
     res = {"value": None, "unit": "updates/s", "cores": 1, "kind": "port",
            "structured_value": 1.0 / t_struct, "structured_sample": f"{ns} updates, O(n^2 m) algorithm, 1 thread",
            "structured_all_cores_value": 1.0 / t_all, "structured_all_cores": ncores,
-           "structured_all_cores_sample": f"{n_all} further updates, the same O(n^2 m) algorithm with its column loops on {ncores} OpenMP threads",
+           "structured_all_cores_sample": f"{per} further updates per thread count, the same O(n^2 m) algorithm with its column loops on {ncores} OpenMP threads",
+           "structured_best_value": sweep[best_T], "structured_best_threads": best_T,
+           "structured_thread_sweep": {str(T): round(v, 2) for T, v in sorted(sweep.items())},
            "host_cores": os.cpu_count()}
     lit_scans = all_scans[ns + n_all:ns + n_all + nl]             # the scans that follow, times still increasing
     if len(lit_scans) == 0:
