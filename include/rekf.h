@@ -34,8 +34,8 @@
  *    rekf_handle_odometry, rekf_sync, rekf_predict_state*, rekf_reserve, rekf_device_layout, ...) sends whatever is held first: no
  *    caller can observe a state without it, and a caller that reads the pose after every scan (the reference's node) is never held.
  *    An error of a held scan is reported by the call that sends it.  Callers that read device memory through their own HIP calls must
- *    call rekf_device_layout or rekf_sync each time.  REKF_LAZY_DD=0 / REKF_SPEC=0 / REKF_SCAN_LAUNCH=0 in the environment turn the
- *    pieces off (A/B measurements; same results).
+ *    call rekf_device_layout or rekf_sync each time.  REKF_LAZY_DD=0 / REKF_SPEC=0 / REKF_SCAN_LAUNCH=0 / REKF_COMPACT_IN_MID=0 /
+ *    REKF_AUG_IN_TAIL=0 in the environment turn the pieces off (A/B measurements; same results).
  *  - the covariance lives in HBM for the life of the handle, column-major like
  *    Eigen::MatrixXd (ekf_slam_interface.h:47) with a fixed leading dimension, as its LOWER TRIANGLE (element (i, j) is
  *    valid iff i >= j; nothing reads the memory above the diagonal); the getters mirror it into the caller's n x n buffer.
