@@ -34,8 +34,8 @@ Extra objects on that line (rank 0, N = 1 unless noted):
                  committed rocprofv3 PMC summary and labelled with its source file.
   not_full       the same steady state on a filter created with max_landmarks = 2 L (the
                  state a deployed node is in: capacity is a cap, not the map size):
-                 k_augment is launched for every scan, n is not known to the host while
-                 it runs ahead of the device.
+                 every scan may append reflectors (the last downdate workgroup of k_dd_front
+                 sees to it), n is not known to the host while it runs ahead of the device.
   latency_us     median / p99 of one update: hipEvent pair around each whole chain
                  (device) and host wall time of HandleObservationMessage + GetPose.
   with_5_predicts_per_scan   the same scans with five HandleOdometryMessage
@@ -585,8 +585,8 @@ def detectors_leg(args, device):
 
 def not_full_leg(args, base, cfg, sess, device, out_value=None):
     """The same steady state on a filter whose capacity is a CAP (max_landmarks = 2 L), not the map size: what a deployed
-    node runs all session long (src/ros_node.cc:440 constructs once, landmarks keep arriving).  k_augment is launched
-    behind every chain (and publishes the pose), and while the host runs ahead of the device it does not know n."""
+    node runs all session long (src/ros_node.cc:440 constructs once, landmarks keep arriving).  Every scan may append reflectors
+    (cc:311-364: the last downdate workgroup of k_dd_front to finish does it), and while the host runs ahead of the device it does not know n."""
     from reflector_ekf_slam_amd import session as S
     from reflector_ekf_slam_amd import synth
     ekf = gpu_filter_factory(cfg, sess, device, capacity=2 * cfg.n_landmarks)
