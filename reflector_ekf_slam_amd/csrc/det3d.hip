@@ -95,7 +95,8 @@ struct Det3dBufs {
     float *p1;        // 3 x cap, SoA: x | y | z  after the intensity filter, arrival order ("node" numbering)
     float *s1;        // the same points in Morton order
     int *perm;        // sorted position -> node (= arrival index among the survivors: the reference's point index)
-    float *box;       // 8 floats per BOX_PTS sorted points: min x, y, z, max x, y, z
+    float *box;       // 8 floats per BOX_PTS sorted points: min x, y, z, max x, y, z -- of all survivors of the gate (k3_boxes)
+    float *box2;      // the same without SOR's outliers (k3_cc_min writes, k3_cc_link and k3_clusters read)
     int *hist;        // GRID_CELLS cell counts (zero between calls)
     int *cursor;      // GRID_CELLS scatter cursors
     float *dist;      // per node: SOR mean neighbour distance
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(1024) void k3_filter_write(Det3dBufs B, int N, doub
 // bounding boxes of BOX_PTS consecutive sorted points: lane = point (x, y, z in registers), 32-lane halves reduce by
 // shuffles.  NaN coordinates (the outliers k3_cc_min masks: x) are ignored by fminf / fmaxf; a tile without any number gets an
 // empty box (+inf, -inf).
-__device__ static inline void tile_boxes(const Det3dBufs &B, int s, int M, float x, float y, float z)
+__device__ static inline void tile_boxes(float *box, int s, int M, float x, float y, float z)
 {
     const float qn = __int_as_float(0x7fc00000);
     const bool ok = s < M && x == x;                                              // x carries the mask
@@ -291,7 +292,7 @@ __device__ static inline void tile_boxes(const Det3dBufs &B, int s, int M, float
         lo.x = (m[0] == m[0]) ? m[0] : INFINITY; lo.y = (m[1] == m[1]) ? m[1] : INFINITY; lo.z = (m[2] == m[2]) ? m[2] : INFINITY;
         lo.w = (m[3] == m[3]) ? m[3] : -INFINITY; hi.x = (m[4] == m[4]) ? m[4] : -INFINITY; hi.y = (m[5] == m[5]) ? m[5] : -INFINITY;
         hi.z = hi.w = 0.f;
-        *(float4 *)(B.box + 8 * (s >> 5)) = lo; *(float4 *)(B.box + 8 * (s >> 5) + 4) = hi;
+        *(float4 *)(box + 8 * (s >> 5)) = lo; *(float4 *)(box + 8 * (s >> 5) + 4) = hi;
     }
 }
 
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(256) void k3_boxes(Det3dBufs B, int N)
     const int ss = s < N ? s : 0;
     const float x = B.s1[ss], y = B.s1[B.cap + ss], z = B.s1[2 * B.cap + ss];    // (beside M, not behind it; past M: masked)
     if ((int)blockIdx.x * 256 >= M) return;
-    tile_boxes(B, s, M, x, y, z);
+    tile_boxes(B.box, s, M, x, y, z);
 }
 
 // ---- the three neighbour sweeps: ONE WAVE PER QUERY, lane = candidate ----------------------------------------
@@ -393,22 +394,22 @@ constexpr int KNN_FEW = 6;          // a step with at most this many admissible 
 // query's first loads -- M, the query, its aligned 64 neighbours, these boxes -- are issued together and waited for once (each used to
 // wait for the one before: four round trips to a memory that is a microsecond away right after a kernel boundary).
 struct BoxPre { float4 lo0, hi0, lo1, hi1; };
-__device__ static inline void box_prefetch(const Det3dBufs &B, int lane, int ntiles_ub, BoxPre &P)
+__device__ static inline void box_prefetch(const float *box, int lane, int ntiles_ub, BoxPre &P)
 {
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     P.lo0 = P.hi0 = P.lo1 = P.hi1 = z;
-    if (lane < ntiles_ub) { P.lo0 = *(const float4 *)(B.box + 8 * lane); P.hi0 = *(const float4 *)(B.box + 8 * lane + 4); }
-    if (lane + 64 < ntiles_ub) { P.lo1 = *(const float4 *)(B.box + 8 * (lane + 64)); P.hi1 = *(const float4 *)(B.box + 8 * (lane + 64) + 4); }
+    if (lane < ntiles_ub) { P.lo0 = *(const float4 *)(box + 8 * lane); P.hi0 = *(const float4 *)(box + 8 * lane + 4); }
+    if (lane + 64 < ntiles_ub) { P.lo1 = *(const float4 *)(box + 8 * (lane + 64)); P.hi1 = *(const float4 *)(box + 8 * (lane + 64) + 4); }
 }
 // squared distance from the query to the box of tile r0 + lane (inf past the last tile)
-__device__ static inline float round_box_d2(const Det3dBufs &B, const BoxPre &P, int r0, int lane, int ntiles, float qx, float qy, float qz)
+__device__ static inline float round_box_d2(const float *box, const BoxPre &P, int r0, int lane, int ntiles, float qx, float qy, float qz)
 {
     const int t = r0 + lane;
     if (t >= ntiles) return INFINITY;
     float4 lo, hi;
     if (r0 == 0) { lo = P.lo0; hi = P.hi0; }
     else if (r0 == 64) { lo = P.lo1; hi = P.hi1; }
-    else { lo = *(const float4 *)(B.box + 8 * t); hi = *(const float4 *)(B.box + 8 * t + 4); }
+    else { lo = *(const float4 *)(box + 8 * t); hi = *(const float4 *)(box + 8 * t + 4); }
     return box_d2(qx, qy, qz, lo.x, lo.y, lo.z, lo.w, hi.x, hi.y);
 }
 
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(64 * QW) void k3_knn(Det3dBufs B, int N, int ntiles
         const float ax = X[ja], ay = Y[ja], az = Z[ja];          // (past M: padding, masked)
         const int node = B.perm[q];
         BoxPre P;
-        box_prefetch(B, lane, ntiles_ub, P);
+        box_prefetch(B.box, lane, ntiles_ub, P);
         if (q >= M) break;
         const int ntiles = (M + BOX_PTS - 1) / BOX_PTS;
         float S;
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(64 * QW) void k3_knn(Det3dBufs B, int N, int ntiles
         float bound = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S), KNN - 1));
         for (int r0 = 0; r0 < ntiles; r0 += 64) {
             const int t = r0 + lane;
-            const float db = ((t >> 1) == (a0 >> 6)) ? INFINITY : round_box_d2(B, P, r0, lane, ntiles, qx, qy, qz) * BOX_MARGIN;
+            const float db = ((t >> 1) == (a0 >> 6)) ? INFINITY : round_box_d2(B.box, P, r0, lane, ntiles, qx, qy, qz) * BOX_MARGIN;
             unsigned long long todo = __ballot(db < bound);
             while (todo) {
                 float cx[KNN_AHEAD], cy[KNN_AHEAD], cz[KNN_AHEAD];
@@ -562,7 +563,7 @@ __global__ __launch_bounds__(64 * QW) void k3_cc_min(Det3dBufs B, int N, int nti
     float tx = 0.f, ty = 0.f, tz = 0.f, td = 0.f;
     if (boxer) { tx = X[q + lane]; ty = Y[q + lane]; tz = Z[q + lane]; td = DS[q + lane]; }
     BoxPre P;
-    box_prefetch(B, lane, ntiles_ub, P);
+    box_prefetch(B.box, lane, ntiles_ub, P);
     if ((int)blockIdx.x * QW >= M) return;                                        // (the whole workgroup: no query)
     // ---- SOR part 2 (:43-47 setStddevMulThresh): mean and (n-1)-variance of the M distances in FP64.  EVERY workgroup takes them for
     // itself (M floats out of L2: cheaper than a launch in between, and than any hand-over inside one): 1024 chunk sums in node
@@ -600,15 +601,14 @@ __global__ __launch_bounds__(64 * QW) void k3_cc_min(Det3dBufs B, int N, int nti
             own = B.perm[q];
             bx = (q & 63) == 0;
             if (bx) { tx = X[q + lane]; ty = Y[q + lane]; tz = Z[q + lane]; td = DS[q + lane]; }
-            box_prefetch(B, lane, ntiles_ub, P);
+            box_prefetch(B.box, lane, ntiles_ub, P);
         }
         if (q >= M) break;
         // The boxes so far are those of ALL survivors of the gate; SOR's outliers -- a quarter of them, the sparse fringes -- blow them
-        // up (twenty tiles within 0.2 m of a query instead of two).  The wave that starts a pair of tiles rewrites their boxes without
-        // the outliers, IN PLACE, while other waves read them: a reader sees the old box, the new one or any mix of their
-        // components, and each of those contains every inlier of the tile -- all a sweep asks of a box (outliers are nobody's
-        // neighbours).  k3_cc_link, a launch later, sees the tight ones throughout.  (Round 4: a kernel of its own.)
-        if (bx) tile_boxes(B, q + lane, M, ((double)td > thr) ? __int_as_float(0x7fc00000) : tx, ty, tz);
+        // up (twenty tiles within 0.2 m of a query instead of two).  The wave that starts a pair of tiles leaves their boxes without
+        // the outliers in a second array: this kernel's sweeps run on the loose ones, k3_cc_link, a launch later, on the tight ones.
+        // (Round 4: a kernel of its own.)
+        if (bx) tile_boxes(B.box2, q + lane, M, ((double)td > thr) ? __int_as_float(0x7fc00000) : tx, ty, tz);
         if ((double)qd > thr) {                                  // :47 -- an outlier: out of the graph
             if (lane == 0) B.label[own] = -1;
             continue;
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(64 * QW) void k3_cc_min(Det3dBufs B, int N, int nti
         const int ntiles = (M + BOX_PTS - 1) / BOX_PTS;
         int mi = own;
         for (int r0 = 0; r0 < ntiles; r0 += 64) {
-            unsigned long long todo = __ballot(round_box_d2(B, P, r0, lane, ntiles, qx, qy, qz) * BOX_MARGIN < TOL2);
+            unsigned long long todo = __ballot(round_box_d2(B.box, P, r0, lane, ntiles, qx, qy, qz) * BOX_MARGIN < TOL2);
             while (todo) {
                 float cx[CC_AHEAD], cy[CC_AHEAD], cz[CC_AHEAD], cd[CC_AHEAD];
                 int pj[CC_AHEAD];
@@ -652,7 +652,7 @@ __global__ __launch_bounds__(64 * QW) void k3_cc_link(Det3dBufs B, int N, int nt
         const float qx = X[q], qy = Y[q], qz = Z[q];
         const int own = B.perm[q];
         BoxPre P;
-        box_prefetch(B, lane, ntiles_ub, P);
+        box_prefetch(B.box2, lane, ntiles_ub, P);
         if (q >= M) break;
 #ifdef RDET_DEBUG_MARKS
         const bool dbg = q == (int)blockIdx.x * QW;
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(64 * QW) void k3_cc_link(Det3dBufs B, int N, int nt
 #endif
         const int ntiles = (M + BOX_PTS - 1) / BOX_PTS;
         for (int r0 = 0; r0 < ntiles; r0 += 64) {
-            const float db = round_box_d2(B, P, r0, lane, ntiles, qx, qy, qz) * BOX_MARGIN;
+            const float db = round_box_d2(B.box2, P, r0, lane, ntiles, qx, qy, qz) * BOX_MARGIN;
             unsigned long long todo = __ballot(db < TOL2 && BOX_PTS * (r0 + lane) < q);   // (a tile behind the query holds no earlier point)
 #ifdef RDET_DEBUG_MARKS
             if (dbg && r0 == 0) { D3_MARK(2); if (threadIdx.x == 0 && blockIdx.x < 2048) d3_marks[blockIdx.x][6] = __popcll(todo); }
@@ -852,13 +852,13 @@ __global__ __launch_bounds__(256) void k3_clusters(Det3dBufs B, int max_centers,
         B.ctl->K = n; B.ctl->err = err;
         d3_host_store16(&B.hout->head, (unsigned)n, (unsigned)err, (unsigned)B.ctl->M, (unsigned)B.seq);   // the centres follow, each with its own tag
     }
-    // the next cloud's grid: the box of this cloud's survivors (= of the tiles' boxes), a little wider, at least 1/8 m per cell -- by the LAST
+    // the next cloud's grid: the box of this cloud's inliers (= of the tiles' tight boxes), a little wider, at least 1/8 m per cell -- by the LAST
     // workgroup, the one least likely to have a component to sum (round 4: the first one, which has the largest)
     if (blockIdx.x == gridDim.x - 1 && wave == 3) {
         const int ntiles = (B.ctl->M + BOX_PTS - 1) / BOX_PTS;
         float x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY;
         for (int t = lane; t < ntiles; t += 64) {
-            const float4 lo = *(const float4 *)(B.box + 8 * t), hi = *(const float4 *)(B.box + 8 * t + 4);
+            const float4 lo = *(const float4 *)(B.box2 + 8 * t), hi = *(const float4 *)(B.box2 + 8 * t + 4);
             x0 = fminf(x0, lo.x); y0 = fminf(y0, lo.y); x1 = fmaxf(x1, lo.w); y1 = fmaxf(y1, hi.x);
         }
         for (int off = 32; off > 0; off >>= 1) {
@@ -945,7 +945,7 @@ struct rdet3d {
     double s2b[3];
     int max_points, device;
     hipStream_t stream;
-    float *d_xyzi, *d_p1, *d_s1, *d_dist, *d_dist_s, *d_box;
+    float *d_xyzi, *d_p1, *d_s1, *d_dist, *d_dist_s, *d_box, *d_box2;
     int *d_label, *d_cnt, *d_first, *d_last, *d_roots, *d_perm, *d_hist, *d_cursor;
     Det3dCtl *d_ctl;
     Det3dHostOut *h_out, *dv_out;      // pinned + mapped: polled result slots (host / device view)
@@ -994,6 +994,7 @@ int rdet3d_create(const rdet3d_options *opt, const double s2b[3], int max_points
         DET3_TRY(h, hipMalloc(&h->d_s1, 12 * np + 4096)); DET3_TRY(h, hipMemset(h->d_s1, 0, 12 * np + 4096));
         DET3_TRY(h, hipMalloc(&h->d_perm, 4 * np + 4096)); DET3_TRY(h, hipMemset(h->d_perm, 0, 4 * np + 4096));
         DET3_TRY(h, hipMalloc(&h->d_box, 32 * (np / BOX_PTS + 2)));
+        DET3_TRY(h, hipMalloc(&h->d_box2, 32 * (np / BOX_PTS + 2)));
         DET3_TRY(h, hipMalloc(&h->d_hist, 4 * GRID_CELLS)); DET3_TRY(h, hipMemset(h->d_hist, 0, 4 * GRID_CELLS));
         DET3_TRY(h, hipMalloc(&h->d_cursor, 4 * GRID_CELLS));
         DET3_TRY(h, hipMalloc(&h->d_dist, 4 * np + 4096)); DET3_TRY(h, hipMemset(h->d_dist, 0, 4 * np + 4096));
@@ -1026,7 +1027,7 @@ void rdet3d_destroy(rdet3d_t *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *ptrs[] = {h->d_xyzi, h->d_p1, h->d_s1, h->d_dist, h->d_dist_s, h->d_box, h->d_label, h->d_cnt, h->d_first, h->d_last, h->d_roots, h->d_perm, h->d_hist, h->d_cursor, h->d_ctl};
+    void *ptrs[] = {h->d_xyzi, h->d_p1, h->d_s1, h->d_dist, h->d_dist_s, h->d_box, h->d_box2, h->d_label, h->d_cnt, h->d_first, h->d_last, h->d_roots, h->d_perm, h->d_hist, h->d_cursor, h->d_ctl};
     for (void *p : ptrs) (void)hipFree(p);
     if (h->h_out) (void)hipHostFree(h->h_out);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -1068,7 +1069,7 @@ int rdet3d_handle_cloud(rdet3d_t *h, double stamp, const float *xyzi, int N, flo
     dbg_t[1] = dbg_us();
 #endif
     Det3dBufs B;
-    B.xyzi = h->d_xyzi; B.p1 = h->d_p1; B.s1 = h->d_s1; B.dist_s = h->d_dist_s; B.perm = h->d_perm; B.box = h->d_box; B.hist = h->d_hist; B.cursor = h->d_cursor;
+    B.xyzi = h->d_xyzi; B.p1 = h->d_p1; B.s1 = h->d_s1; B.dist_s = h->d_dist_s; B.perm = h->d_perm; B.box = h->d_box; B.box2 = h->d_box2; B.hist = h->d_hist; B.cursor = h->d_cursor;
     B.dist = h->d_dist; B.label = h->d_label; B.cnt = h->d_cnt; B.first = h->d_first; B.last = h->d_last; B.roots = h->d_roots;
     B.ctl = h->d_ctl; B.cap = h->max_points;
     B.hout = h->dv_out; B.seq = ++h->seq;
