@@ -86,6 +86,15 @@ void rdet3d_destroy(rdet3d_t *h);
 int rdet3d_handle_cloud(rdet3d_t *h, double stamp, const float *xyzi, int N,
                         float *centers_xy, int max_centers, int *K, double *obs_time);
 
+/* The same in two halves, for a caller that wants the next cloud's copy and launches to run while the device is still on this one
+ * (a node whose callback hands clouds over back to back; the reference's own callback, point_cloud_reflector_detect.cc:9-106, is the
+ * synchronous call above).  rdet3d_submit: the cloud into device memory and the kernels enqueued, no waiting.  rdet3d_collect: the
+ * centres of the OLDEST cloud submitted and not yet collected (blocks until they are there).  At most two clouds may be submitted and
+ * not collected (a third submit returns RDET_ERR_INVALID, as does a collect with nothing submitted, or rdet3d_handle_cloud in
+ * between); results are those of rdet3d_handle_cloud called in the same order. */
+int rdet3d_submit(rdet3d_t *h, double stamp, const float *xyzi, int N, int max_centers);
+int rdet3d_collect(rdet3d_t *h, float *centers_xy, int max_centers, int *K, double *obs_time);
+
 const char *rdet_strerror(int code);
 int rdet_abi_version(void);
 

@@ -945,13 +945,25 @@ struct rdet3d {
     double s2b[3];
     int max_points, device;
     hipStream_t stream;
-    float *d_xyzi, *d_p1, *d_s1, *d_dist, *d_dist_s, *d_box, *d_box2;
+    float *d_p1, *d_s1, *d_dist, *d_dist_s, *d_box, *d_box2;
     int *d_label, *d_cnt, *d_first, *d_last, *d_roots, *d_perm, *d_hist, *d_cursor;
     Det3dCtl *d_ctl;
-    Det3dHostOut *h_out, *dv_out;      // pinned + mapped: polled result slots (host / device view)
+    // TWO clouds may be on their way (rdet3d_submit / rdet3d_collect): what the host writes while the device still works on the cloud
+    // before -- the cloud itself -- and what the device writes while the host may still read the cloud before's -- the result slots --
+    // exist twice; everything in between is produced and consumed inside one cloud's chain of kernels, and the chains follow each other
+    // on the handle's stream
+    struct Slot {
+        float *d_xyzi;                 // the cloud on the device
+        bool xyzi_in_vram;             // ... in fine-grained device memory the host writes through the PCIe BAR (else: pinned staging + copy)
+        float *h_stage;
+        Det3dHostOut *h_out, *dv_out;  // pinned + mapped: polled result slots (host / device view)
+        bool busy;                     // submitted, not collected
+        int seq, max_centers;
+        double stamp;
+    } slot[2];
+    int n_out;                         // clouds submitted and not collected (0 .. 2); the older one is slot[(next + 2 - n_out) & 1]
+    int next;                          // the slot the next submit takes
     bool in_flight;                    // a call returned before its kernels had published everything
-    bool xyzi_in_vram;                 // d_xyzi is fine-grained device memory the host writes through the PCIe BAR (else: pinned staging + copy)
-    float *h_stage;
     int seq;
     int m_hint;                        // the previous cloud's survivors of the gate (k3_knn: m_hint)
     std::string hip_error;
@@ -982,12 +994,14 @@ int rdet3d_create(const rdet3d_options *opt, const double s2b[3], int max_points
     int rc = [&]() -> int {
         DET3_TRY(h, hipSetDevice(device));
         DET3_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-        h->d_xyzi = (float *)host_visible::alloc(16 * np);
-        if (h->d_xyzi) h->xyzi_in_vram = true;
-        else {
-            h->xyzi_in_vram = false;
-            DET3_TRY(h, hipMalloc(&h->d_xyzi, 16 * np));
-            DET3_TRY(h, hipHostMalloc(&h->h_stage, 16 * np));
+        for (auto &sl : h->slot) {
+            sl.d_xyzi = (float *)host_visible::alloc(16 * np);
+            if (sl.d_xyzi) sl.xyzi_in_vram = true;
+            else {
+                sl.xyzi_in_vram = false;
+                DET3_TRY(h, hipMalloc(&sl.d_xyzi, 16 * np));
+                DET3_TRY(h, hipHostMalloc(&sl.h_stage, 16 * np));
+            }
         }
         // + 1024 floats: the sweeps ask for the aligned 64 points around a query before they know M (up to 63 past the end)
         DET3_TRY(h, hipMalloc(&h->d_p1, 12 * np + 4096)); DET3_TRY(h, hipMemset(h->d_p1, 0, 12 * np + 4096));
@@ -1011,10 +1025,12 @@ int rdet3d_create(const rdet3d_options *opt, const double s2b[3], int max_points
             c0.gx0 = c0.gy0 = -32.f; c0.ginv = (float)GRID_G / 64.f;
             DET3_TRY(h, hipMemcpy(h->d_ctl, &c0, sizeof(c0), hipMemcpyHostToDevice));
         }
-        DET3_TRY(h, hipHostMalloc(&h->h_out, sizeof(Det3dHostOut), hipHostMallocMapped | hipHostMallocCoherent));
-        std::memset(h->h_out, 0, sizeof(Det3dHostOut));
-        void *dv = nullptr;
-        DET3_TRY(h, hipHostGetDevicePointer(&dv, h->h_out, 0)); h->dv_out = (Det3dHostOut *)dv;
+        for (auto &sl : h->slot) {
+            DET3_TRY(h, hipHostMalloc(&sl.h_out, sizeof(Det3dHostOut), hipHostMallocMapped | hipHostMallocCoherent));
+            std::memset(sl.h_out, 0, sizeof(Det3dHostOut));
+            void *dv = nullptr;
+            DET3_TRY(h, hipHostGetDevicePointer(&dv, sl.h_out, 0)); sl.dv_out = (Det3dHostOut *)dv;
+        }
         return RDET_OK;
     }();
     if (rc != RDET_OK) { std::fprintf(stderr, "rdet3d_create: %s\n", h->hip_error.c_str()); rdet3d_destroy(h); return rc; }
@@ -1027,79 +1043,101 @@ void rdet3d_destroy(rdet3d_t *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *ptrs[] = {h->d_xyzi, h->d_p1, h->d_s1, h->d_dist, h->d_dist_s, h->d_box, h->d_box2, h->d_label, h->d_cnt, h->d_first, h->d_last, h->d_roots, h->d_perm, h->d_hist, h->d_cursor, h->d_ctl};
+    for (auto &sl : h->slot) {
+        if (sl.d_xyzi) (void)hipFree(sl.d_xyzi);
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
+        if (sl.h_stage) (void)hipHostFree(sl.h_stage);
+    }
+    void *ptrs[] = {h->d_p1, h->d_s1, h->d_dist, h->d_dist_s, h->d_box, h->d_box2, h->d_label, h->d_cnt, h->d_first, h->d_last, h->d_roots, h->d_perm, h->d_hist, h->d_cursor, h->d_ctl};
     for (void *p : ptrs) (void)hipFree(p);
-    if (h->h_out) (void)hipHostFree(h->h_out);
-    if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
-int rdet3d_handle_cloud(rdet3d_t *h, double stamp, const float *xyzi, int N, float *centers_xy, int max_centers,
-                        int *K, double *obs_time)
+// The two halves of HandlePointCloud.  rdet3d_submit: the cloud into the device's memory and the nine launches, no waiting; rdet3d_collect:
+// the OLDEST submitted cloud's centres, polled from its result slots.  Up to two clouds may be submitted and not collected: the host copies
+// and enqueues cloud k + 1 while the device is still on cloud k, whose chain of kernels precedes it on the handle's stream.
+int rdet3d_submit(rdet3d_t *h, double stamp, const float *xyzi, int N, int max_centers)
 {
-    if (!h || !K || N < 0 || (N > 0 && !xyzi) || max_centers < 0 || (max_centers > 0 && !centers_xy))
-        return RDET_ERR_INVALID;
-    *K = 0;
-    if (obs_time) *obs_time = stamp;                                  // :16
-    if (N == 0) return RDET_OK;
+    if (!h || N < 0 || (N > 0 && !xyzi) || max_centers < 0) return RDET_ERR_INVALID;
     if (N > h->max_points) return RDET_ERR_CAPACITY;
+    if (h->n_out >= 2) return RDET_ERR_INVALID;                        // (collect first: two clouds are on their way)
+    rdet3d::Slot &sl = h->slot[h->next];
+    sl.stamp = stamp; sl.max_centers = max_centers; sl.seq = 0;       // (seq 0: an empty cloud, nothing to wait for)
+    if (N > 0) {
 #ifdef RDET_DEBUG_MARKS
-    const auto dbg_t0 = std::chrono::steady_clock::now();
-    auto dbg_us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t0).count(); };
-    double dbg_t[6] = {0, 0, 0, 0, 0, 0};
+        const auto dbg_t0 = std::chrono::steady_clock::now();
+        auto dbg_us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t0).count(); };
+        double dbg_t[3] = {0, 0, 0};
 #endif
-    DET3_TRY(h, hipSetDevice(h->device));
-    // The previous call returned on its last result slot.  Every slot is written by the LAST kernel of the chain, which
-    // starts when all others have ended, so by then nothing reads the cloud buffer any more and the host may overwrite it;
-    // the kernels enqueued below are ordered behind whatever is left of that kernel by the stream.  (hipStreamSynchronize on
-    // an idle stream costs 15 us.)  Only a call that gave up waiting leaves kernels in flight.
-    if (h->in_flight) { DET3_TRY(h, hipStreamSynchronize(h->stream)); h->in_flight = false; }
+        DET3_TRY(h, hipSetDevice(h->device));
+        // Every result slot of a cloud is written by the LAST kernel of its chain, which starts when all others have ended: a cloud that has
+        // been collected reads its input no more, and this slot's previous cloud has been collected (n_out < 2).  Only a call that gave up
+        // waiting leaves kernels in flight.  (hipStreamSynchronize on an idle stream costs 15 us.)
+        if (h->in_flight) { DET3_TRY(h, hipStreamSynchronize(h->stream)); h->in_flight = false; }
 #ifdef RDET_DEBUG_MARKS
-    dbg_t[0] = dbg_us();
+        dbg_t[0] = dbg_us();
 #endif
-    if (h->xyzi_in_vram) {                                             // the cloud goes straight into device memory: posted writes, no copy engine
-        std::memcpy(h->d_xyzi, xyzi, sizeof(float) * 4 * (size_t)N);
-        __atomic_thread_fence(__ATOMIC_SEQ_CST);
-    } else {
-        std::memcpy(h->h_stage, xyzi, sizeof(float) * 4 * (size_t)N);
-        DET3_TRY(h, hipMemcpyAsync(h->d_xyzi, h->h_stage, sizeof(float) * 4 * (size_t)N, hipMemcpyHostToDevice, h->stream));
+        if (sl.xyzi_in_vram) {                                         // the cloud goes straight into device memory: posted writes, no copy engine
+            std::memcpy(sl.d_xyzi, xyzi, sizeof(float) * 4 * (size_t)N);
+            __atomic_thread_fence(__ATOMIC_SEQ_CST);
+        } else {
+            std::memcpy(sl.h_stage, xyzi, sizeof(float) * 4 * (size_t)N);
+            DET3_TRY(h, hipMemcpyAsync(sl.d_xyzi, sl.h_stage, sizeof(float) * 4 * (size_t)N, hipMemcpyHostToDevice, h->stream));
+        }
+#ifdef RDET_DEBUG_MARKS
+        dbg_t[1] = dbg_us();
+#endif
+        Det3dBufs B;
+        B.xyzi = sl.d_xyzi; B.p1 = h->d_p1; B.s1 = h->d_s1; B.dist_s = h->d_dist_s; B.perm = h->d_perm; B.box = h->d_box; B.box2 = h->d_box2; B.hist = h->d_hist; B.cursor = h->d_cursor;
+        B.dist = h->d_dist; B.label = h->d_label; B.cnt = h->d_cnt; B.first = h->d_first; B.last = h->d_last; B.roots = h->d_roots;
+        B.ctl = h->d_ctl; B.cap = h->max_points;
+        B.hout = sl.dv_out; B.seq = sl.seq = ++h->seq;
+        const int ftiles = (N + 1023) / 1024, b256 = (N + 255) / 256, ntiles_ub = (N + BOX_PTS - 1) / BOX_PTS;
+        hipLaunchKernelGGL(k3_filter_count, dim3(ftiles), dim3(1024), 0, h->stream, B, N, h->opt.intensity_min);
+        hipLaunchKernelGGL(k3_filter_write, dim3(ftiles + GRID_CELLS / 1024), dim3(1024), 0, h->stream, B, N, h->opt.intensity_min, ftiles);
+        hipLaunchKernelGGL(k3_scatter, dim3(ftiles), dim3(1024), 0, h->stream, B, N);
+        hipLaunchKernelGGL(k3_boxes, dim3(b256), dim3(256), 0, h->stream, B, N);
+        const int qblocks = (N + QW - 1) / QW < Q_GRID ? (N + QW - 1) / QW : Q_GRID;   // a wave per query, dealt round-robin: M <= N stays on the device
+        hipLaunchKernelGGL(k3_knn, dim3(qblocks), dim3(64 * QW), 0, h->stream, B, N, ntiles_ub, h->m_hint);
+        hipLaunchKernelGGL(k3_cc_min, dim3(qblocks), dim3(64 * QW), 0, h->stream, B, N, ntiles_ub, h->m_hint);
+        hipLaunchKernelGGL(k3_cc_link, dim3(qblocks), dim3(64 * QW), 0, h->stream, B, N, ntiles_ub, h->m_hint);
+        const float sa = (float)h->s2b[2];
+        hipLaunchKernelGGL(k3_finish_a, dim3(b256), dim3(256), 0, h->stream, B, N);
+        hipLaunchKernelGGL(k3_clusters, dim3(RDET_MAX_CENTERS / 4), dim3(256), 0, h->stream, B, max_centers < RDET_MAX_CENTERS ? max_centers : RDET_MAX_CENTERS,
+                           (float)h->s2b[0], (float)h->s2b[1], cosf(sa), sinf(sa));
+        DET3_TRY(h, hipGetLastError());
+#ifdef RDET_DEBUG_MARKS
+        dbg_t[2] = dbg_us();
+        if (getenv("RDET3_HOST_MARKS")) std::fprintf(stderr, "rdet3d host us: synced %.1f cloud written %.1f launched %.1f\n", dbg_t[0], dbg_t[1], dbg_t[2]);
+#endif
     }
-#ifdef RDET_DEBUG_MARKS
-    dbg_t[1] = dbg_us();
-#endif
-    Det3dBufs B;
-    B.xyzi = h->d_xyzi; B.p1 = h->d_p1; B.s1 = h->d_s1; B.dist_s = h->d_dist_s; B.perm = h->d_perm; B.box = h->d_box; B.box2 = h->d_box2; B.hist = h->d_hist; B.cursor = h->d_cursor;
-    B.dist = h->d_dist; B.label = h->d_label; B.cnt = h->d_cnt; B.first = h->d_first; B.last = h->d_last; B.roots = h->d_roots;
-    B.ctl = h->d_ctl; B.cap = h->max_points;
-    B.hout = h->dv_out; B.seq = ++h->seq;
-    h->in_flight = true;
-    const int ftiles = (N + 1023) / 1024, b256 = (N + 255) / 256, ntiles_ub = (N + BOX_PTS - 1) / BOX_PTS;
-    hipLaunchKernelGGL(k3_filter_count, dim3(ftiles), dim3(1024), 0, h->stream, B, N, h->opt.intensity_min);
-    hipLaunchKernelGGL(k3_filter_write, dim3(ftiles + GRID_CELLS / 1024), dim3(1024), 0, h->stream, B, N, h->opt.intensity_min, ftiles);
-    hipLaunchKernelGGL(k3_scatter, dim3(ftiles), dim3(1024), 0, h->stream, B, N);
-    hipLaunchKernelGGL(k3_boxes, dim3(b256), dim3(256), 0, h->stream, B, N);
-    const int qblocks = (N + QW - 1) / QW < Q_GRID ? (N + QW - 1) / QW : Q_GRID;   // a wave per query, dealt round-robin: M <= N stays on the device
-    hipLaunchKernelGGL(k3_knn, dim3(qblocks), dim3(64 * QW), 0, h->stream, B, N, ntiles_ub, h->m_hint);
-    hipLaunchKernelGGL(k3_cc_min, dim3(qblocks), dim3(64 * QW), 0, h->stream, B, N, ntiles_ub, h->m_hint);
-    hipLaunchKernelGGL(k3_cc_link, dim3(qblocks), dim3(64 * QW), 0, h->stream, B, N, ntiles_ub, h->m_hint);
-    const float sa = (float)h->s2b[2];
-    hipLaunchKernelGGL(k3_finish_a, dim3(b256), dim3(256), 0, h->stream, B, N);
-    hipLaunchKernelGGL(k3_clusters, dim3(RDET_MAX_CENTERS / 4), dim3(256), 0, h->stream, B, max_centers < RDET_MAX_CENTERS ? max_centers : RDET_MAX_CENTERS,
-                       (float)h->s2b[0], (float)h->s2b[1], cosf(sa), sinf(sa));
-    DET3_TRY(h, hipGetLastError());
-#ifdef RDET_DEBUG_MARKS
-    dbg_t[2] = dbg_us();
-#endif
+    sl.busy = true;
+    h->next ^= 1;
+    ++h->n_out;
+    return RDET_OK;
+}
+
+int rdet3d_collect(rdet3d_t *h, float *centers_xy, int max_centers, int *K, double *obs_time)
+{
+    if (!h || !K || max_centers < 0 || (max_centers > 0 && !centers_xy)) return RDET_ERR_INVALID;
+    *K = 0;
+    if (h->n_out == 0) return RDET_ERR_INVALID;                        // nothing was submitted
+    rdet3d::Slot &sl = h->slot[(h->next + 2 - h->n_out) & 1];          // the older of the clouds on their way
+    --h->n_out;
+    sl.busy = false;
+    if (obs_time) *obs_time = sl.stamp;                               // :16
+    if (sl.seq == 0) return RDET_OK;                                  // an empty cloud
+    if (max_centers < sl.max_centers && max_centers < RDET_MAX_CENTERS) return RDET_ERR_BUFFER;   // (room for what the submit promised)
     // poll the head, then each centre's own tag (k3_clusters)
     auto wait_tag = [&](const int *tag) -> int {
         const auto t0 = std::chrono::steady_clock::now();
         unsigned spins = 0;
-        while (__atomic_load_n(tag, __ATOMIC_ACQUIRE) != B.seq) {
+        while (__atomic_load_n(tag, __ATOMIC_ACQUIRE) != sl.seq) {
             if ((++spins & 0xfffffu) == 0) {
                 if (hipStreamQuery(h->stream) != hipErrorNotReady) {
                     DET3_TRY(h, hipStreamSynchronize(h->stream));
-                    if (__atomic_load_n(tag, __ATOMIC_ACQUIRE) == B.seq) break;
+                    if (__atomic_load_n(tag, __ATOMIC_ACQUIRE) == sl.seq) break;
                     h->hip_error = "the 3D detector's kernels finished without publishing their result";
                     return RDET_ERR_HIP;
                 }
@@ -1108,26 +1146,30 @@ int rdet3d_handle_cloud(rdet3d_t *h, double stamp, const float *xyzi, int N, flo
         }
         return RDET_OK;
     };
-    int rc = wait_tag(&h->h_out->head.seq);
-    if (rc != RDET_OK) return rc;
-#ifdef RDET_DEBUG_MARKS
-    dbg_t[3] = dbg_us();
-#endif
-    const Det3dHead head = h->h_out->head;
+    int rc = wait_tag(&sl.h_out->head.seq);
+    if (rc != RDET_OK) { h->in_flight = true; return rc; }
+    const Det3dHead head = sl.h_out->head;
     h->m_hint = head.M;
-    if (head.err) { h->in_flight = true; return head.err; }          // (whatever is left of the chain: synchronised by the next call)
+    if (head.err) { h->in_flight = true; return head.err; }          // (whatever is left of the chain: synchronised by the next submit)
     *K = head.K;
     for (int c = 0; c < head.K; ++c) {
-        rc = wait_tag(&h->h_out->centers[c].seq);
-        if (rc != RDET_OK) return rc;
-        centers_xy[2 * c] = h->h_out->centers[c].x; centers_xy[2 * c + 1] = h->h_out->centers[c].y;
+        rc = wait_tag(&sl.h_out->centers[c].seq);
+        if (rc != RDET_OK) { h->in_flight = true; return rc; }
+        centers_xy[2 * c] = sl.h_out->centers[c].x; centers_xy[2 * c + 1] = sl.h_out->centers[c].y;
     }
-    h->in_flight = false;
-#ifdef RDET_DEBUG_MARKS
-    dbg_t[4] = dbg_us();
-    if (getenv("RDET3_HOST_MARKS")) std::fprintf(stderr, "rdet3d host us: synced %.1f cloud written %.1f launched %.1f head %.1f centres %.1f\n", dbg_t[0], dbg_t[1], dbg_t[2], dbg_t[3], dbg_t[4]);
-#endif
     return RDET_OK;
+}
+
+int rdet3d_handle_cloud(rdet3d_t *h, double stamp, const float *xyzi, int N, float *centers_xy, int max_centers,
+                        int *K, double *obs_time)
+{
+    if (!h || !K || N < 0 || (N > 0 && !xyzi) || max_centers < 0 || (max_centers > 0 && !centers_xy))
+        return RDET_ERR_INVALID;
+    *K = 0;
+    if (h->n_out != 0) return RDET_ERR_INVALID;                        // (clouds submitted and not collected: collect them first)
+    int rc = rdet3d_submit(h, stamp, xyzi, N, max_centers);
+    if (rc != RDET_OK) { if (obs_time) *obs_time = stamp; return rc; }
+    return rdet3d_collect(h, centers_xy, max_centers, K, obs_time);
 }
 
 #ifdef RDET_DEBUG_MARKS

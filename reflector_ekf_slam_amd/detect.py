@@ -59,6 +59,8 @@ def _rdet():
         L.rdet3d_destroy.argtypes = [vp]
         L.rdet3d_destroy.restype = None
         L.rdet3d_handle_cloud.argtypes = [vp, C.c_double, vp, C.c_int, vp, C.c_int, vp, vp]
+        L.rdet3d_submit.argtypes = [vp, C.c_double, vp, C.c_int, C.c_int]
+        L.rdet3d_collect.argtypes = [vp, vp, C.c_int, vp, vp]
     _lib_rdet = L
     return L
 
@@ -233,4 +235,22 @@ class PointCloudReflectorDetect:
         rc = self._L.rdet3d_handle_cloud(self._h, float(stamp), pts.ctypes.data, pts.size >> 2, out[3], MAX_CENTERS, out[4], out[5])
         if rc != 0:
             raise RdetError(rc, "HandlePointCloud")
+        return Observation(float(out[2][0]), out[0][: int(out[1][0])].copy())
+
+    def SubmitPointCloud(self, stamp: float, xyzi) -> None:
+        """First half of HandlePointCloud (rdet3d_submit): the cloud goes to the device and its kernels are enqueued; returns at once.
+        At most two clouds may be submitted and not collected."""
+        pts = _as_f32(xyzi)
+        if pts.size & 3:
+            raise ValueError("points are (x, y, z, intensity) quadruples")
+        rc = self._L.rdet3d_submit(self._h, float(stamp), pts.ctypes.data, pts.size >> 2, MAX_CENTERS)
+        if rc != 0:
+            raise RdetError(rc, "SubmitPointCloud")
+
+    def CollectObservation(self) -> Observation:
+        """Second half (rdet3d_collect): the Observation of the oldest cloud submitted and not yet collected."""
+        out = _result_slots(self)
+        rc = self._L.rdet3d_collect(self._h, out[3], MAX_CENTERS, out[4], out[5])
+        if rc != 0:
+            raise RdetError(rc, "CollectObservation")
         return Observation(float(out[2][0]), out[0][: int(out[1][0])].copy())

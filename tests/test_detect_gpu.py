@@ -317,6 +317,44 @@ def test_detect3d_world_clouds_match(oracle_lib):
         assert obs.cloud_.shape[0] >= 40
 
 
+def test_detect3d_two_clouds_on_their_way_give_the_synchronous_calls_results(oracle_lib):
+    """rdet3d_submit / rdet3d_collect: cloud k + 1 is copied and enqueued while the device is still on cloud k (two input buffers, two sets
+    of result slots, one chain of kernels behind the other on the handle's stream).  Ten different clouds -- an empty one among them --
+    through the two halves, always two on their way, give bit for bit what HandlePointCloud gives for the same sequence on a twin
+    (the sorting grid each cloud inherits from its predecessor included); the misuse cases return errors and leave the pipeline intact."""
+    from reflector_ekf_slam_amd import synth
+    from reflector_ekf_slam_amd.detect import PointCloudOptions, PointCloudReflectorDetect, RdetError
+    rng = np.random.Generator(np.random.PCG64(11))
+    lms = synth.make_world(synth.C4, rng)
+    clouds = []
+    for k in range(10):
+        pose = (float(rng.uniform(5, 60)), float(rng.uniform(5, 60)), float(rng.uniform(-3, 3)))
+        clouds.append(synth.make_point_cloud(lms, pose, rng, rings=int(rng.choice([8, 16])), n_az=int(rng.choice([900, 1800]))))
+    clouds[4] = np.zeros((0, 4), np.float32)
+    a = PointCloudReflectorDetect(PointCloudOptions(), max_points=65536)
+    b = PointCloudReflectorDetect(PointCloudOptions(), max_points=65536)
+    ref = [a.HandlePointCloud(1.0 + k, c) for k, c in enumerate(clouds)]
+    with pytest.raises(RdetError):
+        b.CollectObservation()                               # nothing submitted
+    got = []
+    b.SubmitPointCloud(1.0, clouds[0])
+    for k in range(1, len(clouds)):
+        b.SubmitPointCloud(1.0 + k, clouds[k])               # two on their way
+        if k == 3:
+            with pytest.raises(RdetError):
+                b.SubmitPointCloud(99.0, clouds[0])          # a third one: refused, nothing changes
+            with pytest.raises(RdetError):
+                b.HandlePointCloud(99.0, clouds[0])          # ... and so is the synchronous call in between
+        got.append(b.CollectObservation())
+    got.append(b.CollectObservation())
+    assert len(got) == len(ref)
+    for k, (x, y) in enumerate(zip(got, ref)):
+        assert x.time_ == y.time_ and x.cloud_.shape == y.cloud_.shape and np.array_equal(x.cloud_, y.cloud_), k
+    assert sum(r.cloud_.shape[0] for r in ref) > 100
+    assert np.array_equal(b.HandlePointCloud(50.0, clouds[1]).cloud_, a.HandlePointCloud(50.0, clouds[1]).cloud_)   # (the pipeline is empty again)
+    a.close(); b.close()
+
+
 def test_c4_short_cloud_to_filter_omni(oracle_lib):
     """BASELINE.json configs[3] (shortened): synthetic 3D clouds -> 3D detector -> EKF with the OMNI
     odometry model, HIP path vs oracle path, lock-step."""
