@@ -132,9 +132,14 @@ def respawn_under_torchrun(args):
 # the part every rank runs (also driven by tests/test_host_cpu.py with a CPU stub filter over gloo)
 # ---------------------------------------------------------------------------------------------------
 def gpu_filter_factory(cfg, sess, device, capacity=None):
+    """The filter every leg runs on.  Default: the wrapper's OWN defaults -- ReflectorEKFSLAM(options): auto_grow on, initial capacity 1024
+    reflectors, doubling on demand like the reference's ever-growing state (cc:311-364) -- which is what the headline is measured on since
+    round 6.  `capacity` = a FIXED capacity (auto_grow off): the `not_full` leg (2 L) and the `fixed_capacity` leg (L: round 5's headline form)."""
     from reflector_ekf_slam_amd import ReflectorEKFSLAM
     from reflector_ekf_slam_amd import session as S
-    return ReflectorEKFSLAM(S.options_for(sess), max_landmarks=capacity or cfg.n_landmarks, device=device, auto_grow=False)
+    if capacity is None:
+        return ReflectorEKFSLAM(S.options_for(sess), device=device)
+    return ReflectorEKFSLAM(S.options_for(sess), max_landmarks=capacity, device=device, auto_grow=False)
 
 
 def build_session(cfg_name, rank, world):
@@ -242,7 +247,9 @@ def run_rank(args, dist_mod, rank, local_rank, world, make_filter=gpu_filter_fac
         "config": {"workload": f"{base.name}: synthetic 2D session, L={L} landmarks (n={n}), "
                                f"{m // 2} matched observations/scan (m={m}), "
                                f"{'diff-drive' if cfg.odom_model == synth.DIFF else 'omni'} odometry, "
-                               "steady-state HandleObservationMessage",
+                               "steady-state HandleObservationMessage; filter built with the wrapper's defaults "
+                               "(ReflectorEKFSLAM(options): auto_grow, initial capacity 1024)",
+                   "max_landmarks": int(getattr(ekf, "max_landmarks", 0) or 0),
                    "sessions": world, "parallelism": "replicas: one independent session per GPU",
                    "map_build_s": round(map_build_s, 3)},
         "dist_backend": (dist_mod.get_backend() if dist_mod is not None else None),
@@ -493,6 +500,10 @@ def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world, cha
             out["not_full"] = not_full_leg(args, base, cfg, sess, device, out_value=None)
         except Exception as e:                 # a secondary figure must never take the headline down
             out["not_full"] = {"error": repr(e)}
+        try:
+            out["fixed_capacity"] = fixed_capacity_leg(args, cfg, sess, device)
+        except Exception as e:
+            out["fixed_capacity"] = {"error": repr(e)}
     if world == 1 and args.secondary:
         sec = {}
         for name in [s for s in args.secondary.split(",") if s and s != args.config]:
@@ -624,6 +635,23 @@ def not_full_leg(args, base, cfg, sess, device, out_value=None):
     return res
 
 
+def fixed_capacity_leg(args, cfg, sess, device):
+    """Rounds 1-5 measured the headline on a filter created with max_landmarks = L, auto_grow off (n == n_max: the state cannot grow, the
+    host knows n without asking).  Kept as a leg of its own so that the rounds stay comparable; `value` is the wrapper-default filter."""
+    from reflector_ekf_slam_amd import session as S
+    from reflector_ekf_slam_amd import synth
+    ekf = gpu_filter_factory(cfg, sess, device, capacity=cfg.n_landmarks)
+    S.replay(sess, ekf)
+    ekf.sync()
+    steps = max(args.steps, 500)
+    scans = synth.steady_state_scans(sess, 100 + steps, seed_offset=3100)
+    elapsed, _ = timed_region(ekf, scans, 100, steps, None, lambda: None)
+    res = {"value": steps / elapsed, "unit": "updates/s", "us_per_update": 1e6 * elapsed / steps, "steps": steps,
+           "max_landmarks": cfg.n_landmarks, "auto_grow": False, "note": "round 5's headline configuration (n == n_max)"}
+    ekf.close()
+    return res
+
+
 def secondary_config(args, name, device):
     """Rate + per-kernel times at another BASELINE.json config (C2: N=128/16 obs, launch-latency-bound;
     C4: N=512, omni odometry, and the 3D detector -> filter pipeline).  Single session, this GPU."""
@@ -718,7 +746,7 @@ def multi_session(args, cfg, sess, device):
     scans = synth.steady_state_scans(sess, 100 + steps)
     handles = []
     for _ in range(ns):
-        g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks, device=device, auto_grow=False)
+        g = ReflectorEKFSLAM(S.options_for(sess), device=device)          # (the wrapper's defaults, like the headline)
         S.replay(sess, g)
         g.sync()
         handles.append(g)
@@ -784,7 +812,7 @@ def cpu_baseline(args, cfg, sess, st, device):
     best_T = max(sweep, key=sweep.get)
     n_all = k0 - ns
     o.set_threads(1)
-    g2 = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks, device=device, auto_grow=False)
+    g2 = ReflectorEKFSLAM(S.options_for(sess), device=device)
     g2.set_state(st.time, st.mu, st.sigma, vt)
     err2 = []
     for (t, ob), po in zip(all_scans[:ns], poses):

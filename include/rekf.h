@@ -25,7 +25,7 @@
  *    back yet, the first odometry message behind it waits for that pose to be published (never, in the reference's
  *    call pattern: its node reads the pose after every scan, src/ros_node.cc:514-515).  rekf_get_pose and
  *    rekf_predict_state between scans are answered from the mirror without touching the device.
- *  - PENDING WORK (rounds 3-5).  Of the work a scan enqueues, the covariance downdate (reflector_ekf_slam.cc:308) and the landmark
+ *  - PENDING WORK (rounds 3-6).  Of the work a scan enqueues, the covariance downdate (reflector_ekf_slam.cc:308) and the landmark
  *    augmentation (:311-364) are held back and go out with the NEXT call: with the next scan they run beside that scan's update (the
  *    stored covariance is kept one scan behind the filter; the update corrects what it reads of it -- same bits).  A caller that hands
  *    scan after scan over WITHOUT reading anything back in between also has its NEWEST SCAN held on the host until the next call:
@@ -33,9 +33,16 @@
  *    the next scan's update: identical association lists by construction).  Every entry point that reads the state (the getters,
  *    rekf_handle_odometry, rekf_sync, rekf_predict_state*, rekf_reserve, rekf_device_layout, ...) sends whatever is held first: no
  *    caller can observe a state without it, and a caller that reads the pose after every scan (the reference's node) is never held.
- *    An error of a held scan is reported by the call that sends it.  Callers that read device memory through their own HIP calls must
- *    call rekf_device_layout or rekf_sync each time.  REKF_LAZY_DD=0 / REKF_SPEC=0 / REKF_SCAN_LAUNCH=0 / REKF_COMPACT_IN_MID=0 /
- *    REKF_AUG_IN_TAIL=0 in the environment turn the pieces off (A/B measurements; same results).
+ *    ERRORS of a held scan (ABI 7): the call that sends it reports them, and that call's OWN scan (if it brought one) has then not been
+ *    touched -- repeat the call.  If the failure came before anything of the handle had moved (every HIP call that can fail comes first)
+ *    the held scan is still held and the repeated call sends both, each exactly once; after a refused kernel launch the held scan counts
+ *    as applied, like any scan whose call fails there (the handle resynchronises with the device).
+ *    A filter that can still GROW (n < 3 + 2 max_landmarks) waits, at the start of each scan's call, until the PREVIOUS scan's launch
+ *    has published the n that scan leaves (a few microseconds into that launch: its match is final long before its update is) -- the
+ *    host of a growing filter runs at most one launch ahead of the device, and in exchange knows n exactly when it plans a launch.
+ *    Callers that read device memory through their own HIP calls must call rekf_device_layout or rekf_sync each time.
+ *    REKF_SPEC=0 / REKF_SCAN_LAUNCH=0 in the environment (read at rekf_create) switch the speculation / the one-launch form off: the
+ *    twins the bit-identity tests compare against (same results); REKF_EXCLUSIVE=1 = rekf_set_exclusive.
  *  - the covariance lives in HBM for the life of the handle, column-major like
  *    Eigen::MatrixXd (ekf_slam_interface.h:47) with a fixed leading dimension, as its LOWER TRIANGLE (element (i, j) is
  *    valid iff i >= j; nothing reads the memory above the diagonal); the getters mirror it into the caller's n x n buffer.
@@ -47,12 +54,13 @@
 extern "C" {
 #endif
 
-#define REKF_ABI_VERSION 6
+#define REKF_ABI_VERSION 7
 
 /* Most observations one scan may carry (K).  The reference has no limit (reflector_ekf_slam.cc:397 loops over
  * obs.cloud_.size()); this one is a buffer size, equal to what the detectors of rdet.h can emit (RDET_MAX_CENTERS).
- * Up to 64 observations (128 innovation rows) update jointly in one pass; wider scans are matched once and updated
- * in exact block steps of 32 matched pairs (same posterior: see k_mid in csrc/ekf_kernels.hip). */
+ * Up to 32 observations (64 innovation rows: a 64 x 64 innovation covariance is what one pass of k_mid inverts) update jointly in
+ * one pass; wider scans are matched once and updated in exact block steps of 32 matched pairs (same posterior: see k_mid in
+ * csrc/ekf_kernels.hip).  Scans of up to 64 observations travel by value in the launch packet, wider ones through a staging buffer. */
 #define REKF_MAX_OBS 256
 
 enum {

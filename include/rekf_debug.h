@@ -42,9 +42,13 @@ int rekf_profile_samples(rekf_t *h, float *out_us, long cap, long *count);
  * (snapshot / restore it with rekf_get_state / rekf_set_state).  `ablate` must be 0 (reserved). */
 int rekf_debug_time_kernel(rekf_t *h, int kernel, int reps, int ablate, double *avg_us);
 
-/* Debug builds (-DREKF_DEBUG_TIMING) let kernels drop cycle counters here; zeros otherwise -- except out32[24] of a release build:
- * the number of downdate workgroups that ran as roles INSIDE k_mid's grid so far (the opt-in one-launch form for small states,
- * REKF_ONE_LAUNCH=1 in the environment when the handle is created; rekf_api.hip, struct rekf). */
+/* Debug builds (-DREKF_DEBUG_TIMING) let kernels drop cycle counters here.  In a release build: out32[20] / [21] = scans whose
+ * SPECULATIVE match record k_mid proved / of those, scans with observations it had to re-match; [22] / [23] = scans that met a pending
+ * downdate / of those, scans that computed its correction themselves (no write-ahead panel); [24] = work items the in-launch downdate
+ * roles of the last two launches asked for (> 0: the one-launch form ran); [26] / [27] = device time stamps (100 MHz) of the downdate
+ * role's first start / last end in the last launch.  The environment knobs of the library (read at rekf_create; twins for the
+ * bit-identity tests and A/B measurements, same results): REKF_SPEC=0 (no speculative match), REKF_SCAN_LAUNCH=0 (two-launch chain),
+ * REKF_EXCLUSIVE=1 (= rekf_set_exclusive). */
 int rekf_debug_counters(rekf_t *h, long long out32[32]);
 
 /* Fault injection (tests): the NEXT rekf_handle_observation fails with REKF_ERR_HIP at `stage` as if a HIP call had:

@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 MAX_OBS = 256
-REKF_ABI_VERSION = 6          # must equal REKF_ABI_VERSION of include/rekf.h and rekf_abi_version() of the built library
+REKF_ABI_VERSION = 7          # must equal REKF_ABI_VERSION of include/rekf.h and rekf_abi_version() of the built library
 
 
 class RekfOptions(C.Structure):

@@ -1124,11 +1124,13 @@ int rdet3d_collect(rdet3d_t *h, float *centers_xy, int max_centers, int *K, doub
     *K = 0;
     if (h->n_out == 0) return RDET_ERR_INVALID;                        // nothing was submitted
     rdet3d::Slot &sl = h->slot[(h->next + 2 - h->n_out) & 1];          // the older of the clouds on their way
+    // (room for what the submit promised -- checked BEFORE the slot is given up: the caller can come again with a larger buffer, the cloud's
+    // result is not lost, and nobody writes the slot's input buffer under a chain that has not been waited for)
+    if (sl.seq != 0 && max_centers < sl.max_centers && max_centers < RDET_MAX_CENTERS) return RDET_ERR_BUFFER;
     --h->n_out;
     sl.busy = false;
     if (obs_time) *obs_time = sl.stamp;                               // :16
     if (sl.seq == 0) return RDET_OK;                                  // an empty cloud
-    if (max_centers < sl.max_centers && max_centers < RDET_MAX_CENTERS) return RDET_ERR_BUFFER;   // (room for what the submit promised)
     // poll the head, then each centre's own tag (k3_clusters)
     auto wait_tag = [&](const int *tag) -> int {
         const auto t0 = std::chrono::steady_clock::now();

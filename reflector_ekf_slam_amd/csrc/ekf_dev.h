@@ -192,6 +192,10 @@ struct RekfDev {
     int pred_slot;      // k_downdate2: >= 0: the scan's pending Predict (RekfCtl::pred[pred_slot]) is applied to the tiles of column 0 as they are
                         // read (and so committed by this launch); -1: nothing pending (later block steps of a wide scan, timing hook)
     int kc_ub;          // host bound of m_pad for the current scan, rounded up to 16 (0: unknown); columns [m, kc_ub) of HPt / Kn are zero
+    int aug_write;      // k_mid: leave the scan's augmentation record (RekfCtl::augrec) whatever the kernel's MODE (a growing filter in the one-launch form)
+    RekfHostSlot *early;  // k_mid (whole scans on a filter that can still grow): workgroup 0 publishes the n the state has behind this scan -- n + 2 (new
+    int early_seq;        // reflectors) -- under this tag AS SOON AS the scan's match record is final (rekf_api.hip, struct rekf: EARLY n)
+    int pad_;
 };
 
 // ----------------------------------------------------------------------------
@@ -302,6 +306,7 @@ void rekf_launch_compact_wide(const RekfDev &d, const RekfFrontArgs &a, hipStrea
 void rekf_launch_mid(const RekfDev &d, RekfFrontArgs &a, int n_ub, int m_ub, bool mode_grow, hipStream_t s);   // mode_grow: the filter can still grow, or the previous scan's augmentation rides in this launch
 void rekf_launch_downdate(const RekfDev &d, int n_ub, hipStream_t s);
 void rekf_launch_dd_front(const RekfDev &d, int n_ub, const RekfDev &dn, const RekfFrontArgs &an, hipStream_t s);
+bool rekf_scan_launch_fits(int n_ub, int K_front);   // the one-launch form leaves the downdate role enough CUs (and its header fields hold the grid)
 int rekf_launch_scan(const RekfDev &dd, const RekfDev &d, RekfFrontArgs &a, int n_ub, int m_ub, int front_wgs, const RekfFrontArgs *an, hipStream_t s);   // ONE launch per scan: [front end |] mid role (corrects what it gathers by dd's pending panels) | dd's downdate from dd.P into dd.P_out
 void rekf_launch_augment(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);
 void rekf_launch_ellipses(const RekfDev &d, double *out5, int cap, hipStream_t s);

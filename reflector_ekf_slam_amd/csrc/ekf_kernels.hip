@@ -35,6 +35,7 @@
 //   * P exactly symmetric (above); consecutive predicts applied to P's landmark rows as their exact composite.
 #include "ekf_dev.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <type_traits>
@@ -217,7 +218,7 @@ __device__ static inline int distinct_ranks(int key, int rk, int M, int lane, in
     nu = M - __popcll(D);
     return rk - __popcll(D & ((2ull << (rk & 63)) - 1ull));       // repeats at sorted positions <= rk
 }
-__device__ static inline void compact_record(RekfCtl::Rec *rec, RekfCtl *ctl, int kind, int oidx, int lane, int K, int n, int n_max, int has_gps)
+__device__ static inline void compact_record(RekfCtl::Rec *rec, RekfCtl *ctl, int kind, int oidx, int lane, int K, int n, int n_max, int has_gps, bool raise_flag = true)
 {
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const unsigned long long ms = __ballot(kind == 1);
@@ -227,7 +228,9 @@ __device__ static inline void compact_record(RekfCtl::Rec *rec, RekfCtl *ctl, in
     int N2 = __popcll(mn);
     const int room = (n_max - n) / 2;
     if (N2 > room) {                                               // capacity guard (ours)
-        if (lane == 0) atomicOr(&ctl->err, REKF_FLAG_CAPACITY);
+        // (raise_flag = false: the SPECULATIVE front end -- its record is not the scan's until k_mid has proved it, and an observation it
+        // calls new may match after all: k_mid raises the flag once the record stands)
+        if (lane == 0 && raise_flag) atomicOr(&ctl->err, REKF_FLAG_CAPACITY);
         N2 = room;
     }
     int rk = 0;
@@ -525,7 +528,7 @@ __device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs
         const int *kp = SPEC ? &sp->kind[lane & 31] : &ctl->obs_kind[lane], *ip = SPEC ? &sp->idx[lane & 31] : &ctl->obs_idx[lane];
         const int kind = (lane < K) ? __hip_atomic_load(kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
         const int oidx = (lane < K) ? __hip_atomic_load(ip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
-        compact_record(&ctl->rec[A.pred_slot & 1], ctl, kind, oidx, lane, K, n, d.n_max, A.has_gps);
+        compact_record(&ctl->rec[A.pred_slot & 1], ctl, kind, oidx, lane, K, n, d.n_max, A.has_gps, !SPEC);
     }
 #ifdef REKF_DEBUG_FRONT
     if (recf) {
@@ -1327,6 +1330,11 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, int h0, int h1,
         unsigned long long bad = __ballot(!okv);
         if (!rec_ok) bad = (A.K >= 64) ? ~0ull : ((1ull << A.K) - 1ull);
         if (first && tid == 0) { ctl->dbg[20] += 1; if (bad) ctl->dbg[21] += 1; }      // (speculative scans / those with observations re-matched)
+        if (!bad && first && tid < 64) {
+            // the record stands as the front role left it -- without the capacity flag (compact_record, raise_flag): raised here, by the scan itself
+            const int n_kind2 = __popcll(__ballot(lane < A.K && sp_kind == 2));
+            if (lane == 0 && n_kind2 > (d.n_max - n) / 2) atomicOr(&ctl->err, REKF_FLAG_CAPACITY);
+        }
         if (bad) {
             // (rare) the exact match of the observations that did not pass, one at a time by the whole workgroup; then the record again
             if (tid < 32) { s_fk[tid] = sp_kind; s_fi[tid] = sp_idx; }
@@ -1366,13 +1374,15 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, int h0, int h1,
             ctl->K = s_cnt[7]; ctl->n_state = NS; ctl->n_map = Mm; ctl->n_new = N2r;
             ctl->m = m; ctl->m_pad = m_pad;
         }
+        // EARLY n (rekf_api.hip, struct rekf): the n this scan leaves, for the host that plans the next scan's launch -- now, not at the kernel's end
+        if (d.early && tid == 130) host_slot_store(d.early, (double)(n + 2 * N2r), d.early_seq, 0);
         if (DDROLE && A.cp_write) {                     // which landmarks this scan's write-ahead correction covers (phase G)
             const int nu0 = (NS > 0) ? s_rec.nu : 0;
             if (tid >= 256 && tid < 256 + 32) ctl->cp_uid[d.post_slot & 1][tid - 256] = (tid - 256 < nu0) ? s_uid[tid - 256] : -1;
             if (tid == 288) { ctl->cp_nu[d.post_slot & 1] = nu0; ctl->cp_scan[d.post_slot & 1] = A.scan_id; }
         }
         // ... and what this scan's augmentation needs, should it be deferred into the next scan's k_mid (RekfCtl::augrec)
-        if (AUGW && A.K <= REKF_MAX_OBS_DEV) {
+        if ((AUGW || d.aug_write) && A.K <= REKF_MAX_OBS_DEV) {
             RekfCtl::AugRec *aw = &ctl->augrec[A.pred_slot & 1];
             if (tid >= 192 && tid < 192 + N2r) {
                 const int lid = s_newid[tid - 192];
@@ -1398,6 +1408,38 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, int h0, int h1,
             d.mu_out[n + 2 * tid + 1] = (double)gy;
         }
     };
+    // The NEXT scan's Predict, when that scan is in the speculation pipeline (its launch packet An came with this launch): Predict's scalar
+    // part (cc:154-206) is evaluated HERE, by workgroup 0 at its tail -- the front end's own source (front_role, device-predicted path) on
+    // the pose this scan commits (s_np) and the pose block it leaves (s_cpred[2..10]) -- while the other workgroups write their share of
+    // the write-ahead correction: the next k_mid starts with one load of it.  Called on EVERY path that ends a scan, the one without a
+    // matched observation included (round-5 advice: that path returned in front of it, and the next scan read a Predict two scans old).
+    auto next_scan_predict = [&]() __attribute__((always_inline)) {
+        if constexpr (DDROLE && !FRONT) {
+            if (A.spec_front > 0) {
+                const int ns = (A.pred_slot ^ 1) & 1;
+                if (tid == 0) {
+#pragma clang fp contract(off)
+                    const double th = s_np[2] + An.vt[2] * An.dt;
+                    double sn, cs;
+                    sincos(th, &sn, &cs);
+                    ctl->pose_next[ns][3] = cs; ctl->pose_next[ns][4] = sn;
+                    ctl->pose_next[ns][2] = atan2(sn, cs);                     // the wrapped heading (cc:181 / :205)
+                }
+                if (tid == 64) {
+#pragma clang fp contract(off)
+                    Motion mo;
+                    double C9[9];
+                    for (int q = 0; q < 9; ++q) C9[q] = s_cpred[2 + q];
+                    motion_terms(An, s_np[2], mo);
+                    ctl->pose_next[ns][0] = s_np[0] + mo.d[0]; ctl->pose_next[ns][1] = s_np[1] + mo.d[1];
+                    corner_predict(C9, 3, mo);
+                    RekfCtl::Pred *pr = &ctl->pred[(A.pred_ix + 1) & 3];
+                    pr->ab[0] = mo.a; pr->ab[1] = mo.b;
+                    for (int q = 0; q < 9; ++q) pr->C9[q] = C9[q];
+                }
+            }
+        }
+    };
     double *const post_out = ctl->post_C9[d.post_slot & 1];
     // The mean is double-buffered: other workgroups read landmark means from d.mu (phase B) while this one is already
     // done, so the updated rows go to d.mu_out and the host swaps the two pointers behind this launch.
@@ -1417,9 +1459,11 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, int h0, int h1,
                 const int pi = tid % 3, pj = tid / 3, hi = pi > pj ? pi : pj, lo = pi > pj ? pj : pi;
                 const double v9 = do_pred ? s_pred[2 + hi + 3 * lo] : (corr ? ctl->post_C9[A.corr_post & 1][hi + 3 * lo] : rekf_plower(P, (int)ld, hi, lo));
                 post_out[tid] = v9;
+                s_cpred[2 + tid] = v9;          // (for the next scan's Predict below; the pending scan's block, if it was there, is dead)
                 if (d.pub) host_slot_store(d.pub + 3 + tid, v9, d.pub_seq, 0);
             }
-            append_new_means();                 // (a barrier inside: s_np is complete behind it)
+            append_new_means();                 // (a barrier inside: s_np and the pose block are complete behind it)
+            next_scan_predict();
             if (d.pub) {                        // (the early publisher, see the end of the kernel)
                 if (tid < 3) host_slot_store(d.pub + tid, s_np[tid], d.pub_seq, 0);
                 if (tid == 3) host_slot_store(d.pub + 12, (double)(n + 2 * s_cnt[5]), d.pub_seq,
@@ -2120,35 +2164,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, int h0, int h1,
             if (d.pub) host_slot_store(d.pub + 3 + e, v9, d.pub_seq, 0);
         }
         append_new_means();                     // (a barrier inside: s_np is complete behind it)
-        if constexpr (DDROLE && !FRONT) {
-            if (A.spec_front > 0) {
-                // the NEXT scan is in the speculation pipeline (its launch packet An came with this launch): its Predict (cc:154-206) is
-                // evaluated here -- the front end's own source (front_role, device-predicted path) on the pose just committed and the
-                // pose block just evaluated -- while the other workgroups write their share of the write-ahead correction: the next
-                // k_mid starts with one load of it
-                const int ns = (A.pred_slot ^ 1) & 1;
-                if (tid == 0) {
-#pragma clang fp contract(off)
-                    const double th = s_np[2] + An.vt[2] * An.dt;
-                    double sn, cs;
-                    sincos(th, &sn, &cs);
-                    ctl->pose_next[ns][3] = cs; ctl->pose_next[ns][4] = sn;
-                    ctl->pose_next[ns][2] = atan2(sn, cs);                     // the wrapped heading (cc:181 / :205)
-                }
-                if (tid == 64) {
-#pragma clang fp contract(off)
-                    Motion mo;
-                    double C9[9];
-                    for (int q = 0; q < 9; ++q) C9[q] = s_cpred[2 + q];
-                    motion_terms(An, s_np[2], mo);
-                    ctl->pose_next[ns][0] = s_np[0] + mo.d[0]; ctl->pose_next[ns][1] = s_np[1] + mo.d[1];
-                    corner_predict(C9, 3, mo);
-                    RekfCtl::Pred *pr = &ctl->pred[(A.pred_ix + 1) & 3];
-                    pr->ab[0] = mo.a; pr->ab[1] = mo.b;
-                    for (int q = 0; q < 9; ++q) pr->C9[q] = C9[q];
-                }
-            }
-        }
+        next_scan_predict();
         // The EARLY publisher (d.pub set on this launch: the caller has been reading the pose back after its scans, rekf_api.hip): pose,
         // block, n and flags go to the host from here, a kernel before the downdate -- at the price of 0.8 us at the end of this kernel
         // (it ends when the PCIe writes are through).  Otherwise the downdate's first workgroup publishes, at its start.
@@ -2899,6 +2915,10 @@ template <int NBR, int MODE> static void launch_mid_as(int grid, int with_dd, hi
         }
     }
     // (the fields the kernel's first instructions need, as leading scalars: k_mid)
+    if (a.dd_first > 0xfff || a.n_mid > 0xfff || a.spec_front > 0xff || a.dd_in_mid > 0xfff || a.front_in_mid > 0xff) {
+        std::fprintf(stderr, "rekf: k_mid launch header overflow (n_mid %d, dd_first %d, dd_in_mid %d): launch dropped\n", a.n_mid, a.dd_first, a.dd_in_mid);
+        return;
+    }
     const int h0 = (a.pred_slot & 1) | ((a.pred_ix & 3) << 1) | ((a.corr ? 1 : 0) << 3) | ((a.corr_post & 1) << 4) | ((a.corr_pred_ix & 3) << 5) |
                    ((a.spec ? 1 : 0) << 7) | ((a.corr && a.corr_pred >= 0 ? 1 : 0) << 8) | ((a.dd_par & 1) << 9);
     const int h4 = (a.dd_first & 0xfff) | ((a.n_mid & 0xfff) << 12) | ((a.spec_front & 0xff) << 24);
@@ -2925,14 +2945,25 @@ void rekf_launch_mid(const RekfDev &d, RekfFrontArgs &a, int n_ub, int m_ub, boo
 // ONE launch per scan (round 5): [the scan's front end, front_wgs workgroups (0: it ran before this launch) | its mid role, which takes the
 // pending downdate dd as a correction of what it gathers | dd itself, from dd.P into dd.P_out, on the CUs the others leave free, tiles from
 // RekfCtl::dd_queue].  The caller has set a.corr / corr_pred / corr_post / dd_par.  Returns the launch's grid.
+// The one-launch form needs CUs for three roles at once (one workgroup per CU: the arena).  With fewer than REKF_SCAN_MIN_DD_WGS left for the
+// downdate role -- n beyond ~3000 on 256 CUs -- the whole O(n^2 m) downdate would crawl on a handful of workgroups: the host then keeps the
+// two-launch chain (k_dd_front with every CU, then k_mid).  Also guards the 12-bit fields of k_mid's launch header (launch_mid_as).
+#define REKF_SCAN_MIN_DD_WGS 48
+static int device_cu_count()
+{
+    std::lock_guard<std::mutex> guard(g_dd_cache.mu);
+    int dev = 0;
+    return g_dd_cache.n_cu_of[dd_cache_slot(dev)];
+}
+bool rekf_scan_launch_fits(int n_ub, int K_front)
+{
+    const int n_mid = (n_ub + MID_ROWS - 1) / MID_ROWS;
+    const int dd_first = (n_mid + (K_front > 0 ? K_front : 0) + 7) & ~7;
+    return dd_first + REKF_SCAN_MIN_DD_WGS <= device_cu_count() && dd_first < 0x1000;
+}
 int rekf_launch_scan(const RekfDev &dd, const RekfDev &d, RekfFrontArgs &a, int n_ub, int m_ub, int front_wgs, const RekfFrontArgs *an, hipStream_t s)
 {
-    int n_cu;
-    {
-        std::lock_guard<std::mutex> guard(g_dd_cache.mu);
-        int dev = 0;
-        n_cu = g_dd_cache.n_cu_of[dd_cache_slot(dev)];
-    }
+    const int n_cu = device_cu_count();
     a.n_mid = (n_ub + MID_ROWS - 1) / MID_ROWS;
     a.front_in_mid = front_wgs;
     a.spec_front = (an && front_wgs == 0) ? an->K : 0;    // the NEXT scan's speculative front end: workgroups behind the mid role's
@@ -2940,7 +2971,7 @@ int rekf_launch_scan(const RekfDev &dd, const RekfDev &d, RekfFrontArgs &a, int 
     const int n_dd = (dd.n_known >= 0) ? dd.n_known : dd.n_max;
     const int T = (n_dd + DT - 1) / DT, nB = (T - 1) * (T - 2) / 2, items = T + (nB + 2) / 3;
     int wgs = n_cu - a.dd_first;                          // one workgroup per CU (the arena), everybody resident from the start
-    if (wgs < 8) wgs = 8;
+    if (wgs < 8) wgs = 8;                                 // (never on the host's path: rekf_scan_launch_fits)
     if (wgs > items) wgs = items;
     a.dd_in_mid = wgs;
     const int grid = a.dd_first + wgs;

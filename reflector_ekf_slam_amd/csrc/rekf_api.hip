@@ -88,10 +88,6 @@ struct rekf {
     bool dd_aug = false;            // the scan's k_augment is held back with it (the state can still grow): it runs right behind the downdate
     RekfFrontArgs dd_aug_args;      // ... with the scan's launch packet (the new reflectors' observations)
     bool dd_aug_inline_ok = false;  // ... and it may run inside the next scan's k_mid instead of a launch of its own (RekfCtl::augrec: whole scans only)
-    bool aug_in_mid = true;         // REKF_AUG_IN_MID=0 in the environment turns that off (A/B measurements)
-    bool front_in_mid = true;       // a scan's front end runs inside k_mid's grid (REKF_FRONT_IN_MID=0: as k_front_mb, a launch of its own)
-    bool compact_in_mid = true;     // RekfFrontArgs::compact_in_mid (REKF_COMPACT_IN_MID=0: the front end counts, its last workgroup compacts)
-    bool aug_in_tail = true;        // RekfDev::aug_tail (REKF_AUG_IN_TAIL=0: k_augment as a launch of its own behind k_dd_front)
     // ONE LAUNCH PER SCAN (round 5; REKF_SCAN_LAUNCH=0 turns it off): the held-back downdate is not applied in front of the next scan's
     // k_mid but BESIDE it -- as a role of the same launch, from the stored P into the other P buffer -- while the mid role corrects what
     // it gathers by the pending panels (k_mid): the rank-m downdate is off the update's critical path.  For a filter that cannot grow
@@ -103,7 +99,6 @@ struct rekf {
     // only live handle.  Off: the front end is a launch of its own (k_front_mb / k_dd_front), the augmentation k_augment.
     bool exclusive = false;
     bool live_counted = false;      // this handle is in g_live_handles
-    bool lazy_dd = true;            // REKF_LAZY_DD=0 in the environment turns it off (A/B measurements)
     // SPECULATIVE MATCH (round 5; REKF_SPEC=0 turns it off).  What a scan's update waits for -- Predict's pose and ReflectorMatch against the
     // mean the PREVIOUS update left -- cannot start before that update has ended; run one scan EARLY it can: scan t + 1's front end as a
     // role of scan t's launch, against the mean that launch starts from, with the margins that let scan t + 1's k_mid prove (or repair)
@@ -111,7 +106,6 @@ struct rekf {
     // scan (no read-back in between) has its newest scan HELD on the host until the next call brings the one after it; every other
     // call (getters, odometry, sync) sends the held scan first.  Same results, bit for bit, as the exact front end.
     bool spec_enable = true;
-    bool cp_enable = true;          // REKF_CP_WRITE=0: no write-ahead correction panels (A/B measurements)
     bool held = false;              // a scan waits on the host: ...
     double held_t = 0;
     int held_K = 0;
@@ -119,6 +113,16 @@ struct rekf {
     double held_gps3[3] = {0, 0, 0};
     float held_xy[2 * 32];
     bool spec_ready = false;        // the last launch ran the speculative front end of scan spec_scan
+    bool scan_committed = false;    // process_scan: the host's bookkeeping has moved (an error before that leaves the handle as it was: the scan can be handed over again)
+    // EARLY n (round 6): on a filter that can still grow the host does not know, when it enqueues scan t + 1, whether scan t appended reflectors --
+    // and everything that makes an update ONE launch (n in the launch packet, the downdate as a role beside the mid role) needs to know.
+    // k_mid's workgroup 0 therefore publishes the n the state will have behind the scan as soon as the scan's match record is final
+    // (a few microseconds into the launch: host slot 13), and the NEXT scan's call waits for that slot before it plans its launch: the
+    // host of a growing filter runs at most one launch ahead of the device (the device is never idle for it: the launch it waits for has
+    // only just started).  A filter that cannot grow (n == n_max) publishes nothing and waits for nothing.
+    bool early_valid = false;       // the last scan's k_mid publishes its n under tag early_seq ...
+    int early_seq = 0;
+    int early_n_before = -1;        // ... and this was the (exact) n it started from (-1: not known): equal = the scan appended nothing
     unsigned spec_scan = 0;
     // WHO PUBLISHES pose, pose block, n and flags of a scan.  A caller that reads the pose back after its scans (the reference's node,
     // src/ros_node.cc:514-515) gets them from k_mid's workgroup 0 -- a kernel earlier: GetPose does not wait for the downdate -- which
@@ -323,6 +327,23 @@ void peek_n(rekf_t *h)
     const long nb = (long)v + slack;
     if (nb < h->n_ub || slack == 0) h->n_ub = (int)(nb < h->dev.n_max ? nb : h->dev.n_max);
     if (slack == 0) { h->n_exact = true; h->full = h->n_ub >= h->dev.n_max; }
+}
+
+// EARLY n (struct rekf): the n the last scan leaves, from its k_mid's workgroup 0 (host slot 13) -- waits for that launch to have got
+// as far as its match record (a few microseconds in).  Tells, too, whether that scan appended reflectors: if it did not, nothing of it is
+// pending but its downdate (no k_augment, no rows to append), and the next scan may take it along as a role of its own launch.
+int learn_early_n(rekf_t *h)
+{
+    if (!h->early_valid) return REKF_OK;
+    const int rc = wait_slots(h, 13, 1, h->early_seq);
+    h->early_valid = false;                            // (whatever happened: a launch that never published must not fail every later call)
+    if (rc != REKF_OK) return rc;
+    int n = (int)h->host_slots[13].v;
+    if (n > h->dev.n_max) n = h->dev.n_max;
+    h->n_ub = n; h->n_det = n; h->n_exact = true;
+    h->full = n >= h->dev.n_max;
+    if (h->early_n_before >= 0 && n == h->early_n_before) h->dd_aug = false;     // (the held-back k_augment would find nothing to do)
+    return REKF_OK;
 }
 
 // the held-back downdate (struct rekf: LAZY DOWNDATE) goes out on its own
@@ -537,15 +558,9 @@ int rekf_create(const rekf_options *opt, int max_landmarks, int device, rekf_t *
     h->vt[0] = h->vt[1] = h->vt[2] = 0.0;             // cc:6
     h->n_ub = 3;
     h->full = false;
-    { const char *e = std::getenv("REKF_LAZY_DD"); h->lazy_dd = !(e && e[0] == '0'); }
-    { const char *e = std::getenv("REKF_AUG_IN_MID"); h->aug_in_mid = !(e && e[0] == '0'); }
-    { const char *e = std::getenv("REKF_FRONT_IN_MID"); h->front_in_mid = !(e && e[0] == '0'); }
-    { const char *e = std::getenv("REKF_COMPACT_IN_MID"); h->compact_in_mid = !(e && e[0] == '0'); }
-    { const char *e = std::getenv("REKF_AUG_IN_TAIL"); h->aug_in_tail = !(e && e[0] == '0'); }
     { const char *e = std::getenv("REKF_SCAN_LAUNCH"); h->scan_launch = !(e && e[0] == '0'); }
     { const char *e = std::getenv("REKF_EXCLUSIVE"); h->exclusive = e && e[0] == '1'; }
     { const char *e = std::getenv("REKF_SPEC"); h->spec_enable = !(e && e[0] == '0'); }
-    { const char *e = std::getenv("REKF_CP_WRITE"); h->cp_enable = !(e && e[0] == '0'); }
     h->prof_on = false;
     h->prof_mask = -1;
     h->prof_used = 0;
@@ -719,23 +734,32 @@ static int flush_held(rekf_t *h)
 {
     if (!h->held) return REKF_OK;
     h->held = false;
-    return process_scan(h, h->held_t, h->held_xy, h->held_K, h->held_gps ? h->held_gps3 : nullptr, nullptr);
+    const int rc = process_scan(h, h->held_t, h->held_xy, h->held_K, h->held_gps ? h->held_gps3 : nullptr, nullptr);
+    if (rc != REKF_OK && !h->scan_committed) h->held = true;       // nothing has moved: the scan is still held, the caller's next call sends it again
+    return rc;
 }
 
 int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const double *gps_pose3)
 {
     if (!h || K < 0 || (K > 0 && !xy)) return REKF_ERR_INVALID;
     if (K > REKF_MAX_OBS) return REKF_ERR_TOO_MANY_OBS;
-    // a scan that can take part in the speculation pipeline: a whole scan on a filter that cannot grow, no pre-loaded map (its branch of the
-    // match has no margin proof), handed over without a pose read-back since the last scan
-    const bool holdable = h->spec_enable && h->scan_launch && h->lazy_dd && h->full && K >= 1 && K <= 32 && h->dev.M_map == 0 &&
+    // a scan that can take part in the speculation pipeline: a whole scan (a filter that can still grow included: struct rekf, EARLY n), no
+    // pre-loaded map (its branch of the match has no margin proof), handed over without a pose read-back since the last scan
+    const bool holdable = h->spec_enable && h->scan_launch && K >= 1 && K <= 32 && h->dev.M_map == 0 &&
                           !h->mir_valid && !h->prof_on;
     if (h->held) {
         if (!holdable) { FLUSH_HELD(h); return process_scan(h, t, xy, K, gps_pose3, nullptr); }
         const NextScan nx = {t, xy, K, gps_pose3 != nullptr};
         h->held = false;
         const int rc = process_scan(h, h->held_t, h->held_xy, h->held_K, h->held_gps ? h->held_gps3 : nullptr, &nx);
-        if (rc != REKF_OK) { (void)process_scan(h, t, xy, K, gps_pose3, nullptr); return rc; }      // (the held scan's error is reported; this one still goes out)
+        if (rc != REKF_OK) {
+            // The held scan failed; THIS call's scan has not been touched, and the error is this call's: hand it over again.  An error in
+            // front of the host's bookkeeping (everything that can fail comes first, process_scan) leaves the held scan held -- the retry
+            // sends both, nothing is applied twice, nothing is lost; behind it (a refused launch) the held scan counts as applied, like
+            // any scan whose call fails there
+            if (!h->scan_committed) h->held = true;
+            return rc;
+        }
     } else if (!holdable || !h->dd_pending) return process_scan(h, t, xy, K, gps_pose3, nullptr);
     h->held = true; h->held_t = t; h->held_K = K; h->held_gps = gps_pose3 != nullptr;
     if (gps_pose3) { h->held_gps3[0] = gps_pose3[0]; h->held_gps3[1] = gps_pose3[1]; h->held_gps3[2] = gps_pose3[2]; }
@@ -747,7 +771,9 @@ static int process_scan(rekf_t *h, double t, const float *xy, int K, const doubl
 {
     const bool staged = K > REKF_MAX_OBS_DEV;                       // too many observations for the launch packet
     const bool blocks = 2 * K + (gps_pose3 ? 3 : 0) > 64;           // more innovation rows than one pass of k_mid takes
+    h->scan_committed = false;
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->early_valid) { int rce = learn_early_n(h); if (rce != REKF_OK) return rce; }      // (a growing filter: struct rekf, EARLY n)
     peek_n(h);                                        // whatever the device has published meanwhile tightens the bound on n, for free
     if (K == 0) {                                     // cc:235-236: Predict only -- on the mirror, like an odometry message
         int rc = refresh_mirror(h);
@@ -784,13 +810,15 @@ static int process_scan(rekf_t *h, double t, const float *xy, int K, const doubl
         h->obs_staging_busy = true;
     }
     // ONE LAUNCH PER SCAN (struct rekf): the held-back downdate runs beside this scan's k_mid, from the stored P into the other buffer, and
-    // the mid role corrects what it gathers -- for a filter that cannot grow, with n known, whole scans on this side
-    const bool fast = h->dd_pending && h->scan_launch && h->full && h->n_exact && !h->dd_aug && !blocks && !staged && K <= 32;
+    // the mid role corrects what it gathers -- with n known exactly and no landmark augmentation pending on the stored P (a filter that
+    // cannot grow, or one whose last scan is known to have appended nothing: struct rekf, EARLY n), whole scans on this side
+    const bool fast = h->dd_pending && h->scan_launch && h->n_exact && !h->dd_aug && !blocks && !staged && K <= 32 &&
+                      rekf_scan_launch_fits(h->n_ub, next ? next->K : K);
     // else the previous scan's downdate and this scan's front end go out as ONE launch (k_dd_front) -- also behind a read-back (the scan is
     // host-predicted: its front end is a match only, which hides under the downdate), unless the handle is exclusive: there the front end
     // runs inside k_mid's own grid and the downdate goes out first.  (Until round 5 every read-back sent the downdate out alone and
     // the front end as a launch of its own behind it: 8 us per update of a caller that reads the pose after every scan of a growing filter.)
-    const bool with_dd = h->dd_pending && (fast || !h->mir_valid || !(in_grid_ok(h) && h->front_in_mid)) &&
+    const bool with_dd = h->dd_pending && (fast || !h->mir_valid || !in_grid_ok(h)) &&
                          h->inject_failure != 2;          // (rekf_debug_inject_failure(2): the downdate goes out alone, and that launch "fails")
     if (!with_dd) {
         if (h->inject_failure == 2) { h->inject_failure = 0; h->hip_error = "injected failure (held-back downdate)"; return REKF_ERR_HIP; }
@@ -798,6 +826,8 @@ static int process_scan(rekf_t *h, double t, const float *xy, int K, const doubl
         if (rcf != REKF_OK) return rcf;
     }
     // ---- from here on: host bookkeeping and launches only
+    h->scan_committed = true;
+    h->early_valid = false;                           // (set again below by a whole scan on a growing filter)
     const bool alone = in_grid_ok(h);                 // (in-launch hand-overs only on an exclusive, lone handle: struct rekf, EXCLUSIVE)
     h->last_scan_empty = false;
     RekfFrontArgs a;
@@ -833,17 +863,17 @@ static int process_scan(rekf_t *h, double t, const float *xy, int K, const doubl
     h->spec_ready = false;
     // a whole scan whose front end is a launch in front of k_mid leaves its raw results; k_mid compacts for itself (RekfFrontArgs::compact_in_mid).
     // (Decided further down -- where the front end goes -- but the count it would have added to belongs here.)
-    const bool front_in_grid = !use_spec && alone && h->front_in_mid &&
+    const bool front_in_grid = !use_spec && alone &&
                                ((fast && !next) || (!fast && !with_dd && a.host_pred && !blocks && !staged && K <= 32));   // (as decided below)
     // (not when the front end rides inside k_dd_front: there the previous scan's downdate sets the launch's length, the election is hidden,
     // and k_mid would pay 0.9 us for the compaction)
-    const bool cim = h->compact_in_mid && !use_spec && !blocks && !staged && K <= 32 && !front_in_grid && (fast || !with_dd);
+    const bool cim = !use_spec && !blocks && !staged && K <= 32 && !front_in_grid && (fast || !with_dd);
     a.compact_in_mid = cim ? 1 : 0;
     if (!use_spec && !cim) h->front_total += (unsigned)K;    // (the front end counts the observations it matches; the speculative one has counted these)
     a.front_target = h->front_total;
     a.spec = use_spec ? 1 : 0;
     a.compact_in_front = blocks ? 0 : 1;
-    a.cp_write = (blocks || !h->cp_enable) ? 0 : 1;   // (whole scans leave their write-ahead correction: k_mid phase G)
+    a.cp_write = blocks ? 0 : 1;   // (whole scans leave their write-ahead correction: k_mid phase G)
     h->dev.pred_slot = -1;
     h->dev.post_slot = pred_slot;                     // (RekfCtl::post_C9: k_mid writes the scan's slot, the scan's downdate stores it)
     h->dev.P_out = h->dev.P;
@@ -859,15 +889,15 @@ static int process_scan(rekf_t *h, double t, const float *xy, int K, const doubl
         // the pending downdate stays pending until the k_mid launch below takes it along; the mid role sees it as a correction
         a.corr = 1; a.corr_pred = h->dd_dev.pred_slot; a.corr_post = h->dd_dev.post_slot; a.corr_pred_ix = h->dd_dev.pred_ix; a.corr_scan = h->dd_scan;
         if (use_spec) { /* nothing: the record is there */ }
-        else if (alone && h->front_in_mid && !next) front_wgs = K;
+        else if (alone && !next) front_wgs = K;
         else { ProfScope ps(h, REKF_K_FRONT); rekf_launch_front_mb(h->dev, a, h->n_ub, h->stream); }
     } else if (with_dd) {
         h->dd_pending = false;
         // the previous scan's augmentation: inside this scan's k_mid on an exclusive handle (its workgroup 0 appends the rows first thing;
         // whole scans on both sides); else by the LAST downdate workgroup of this launch to finish (RekfDev::aug_tail: the previous scan
         // was a whole scan, its record is in RekfCtl::augrec); else as k_augment right behind the downdate
-        const bool inline_aug = alone && h->dd_aug && h->aug_in_mid && h->dd_aug_inline_ok && !blocks;
-        const bool tail_aug = h->dd_aug && !inline_aug && h->dd_aug_inline_ok && h->aug_in_tail;
+        const bool inline_aug = alone && h->dd_aug && h->dd_aug_inline_ok && !blocks;
+        const bool tail_aug = h->dd_aug && !inline_aug && h->dd_aug_inline_ok;
         a.aug_pending = h->dd_aug ? (tail_aug ? 2 : 1) : 0;
         h->dd_dev.P_out = h->dd_dev.P;                // (in place)
         h->dd_dev.aug_tail = tail_aug ? 1 + ((pred_slot ^ 1) & 1) : 0;
@@ -877,7 +907,7 @@ static int process_scan(rekf_t *h, double t, const float *xy, int K, const doubl
         h->dd_aug = false;
         a.aug_pending = 0;
         a.aug_in_mid = inline_aug ? 1 : 0;
-    } else if (alone && h->front_in_mid && a.host_pred && !blocks && !staged && K <= 32) {
+    } else if (alone && a.host_pred && !blocks && !staged && K <= 32) {
         // behind a pose read-back the front end is a match only (pose, cos / sin, pose block go by value): it runs as the first
         // workgroups of k_mid's own grid, one observation each, and hands the record over inside the launch
         a.front_in_mid = K;
@@ -891,7 +921,7 @@ static int process_scan(rekf_t *h, double t, const float *xy, int K, const doubl
     h->dev.mu_lin = h->dev.mu;
     // lazy downdate (struct rekf): the scan's last downdate -- and its k_augment -- go out with the next call.  (Not for a staged scan:
     // its k_augment reads the observations from a device buffer the next staged scan overwrites.)
-    const bool hold_back = h->lazy_dd && !staged;
+    const bool hold_back = !staged;
     hipError_t enq_err = hipSuccess;
     const bool early_pub = h->pose_read_since_scan;   // (struct rekf: WHO PUBLISHES)
     h->pose_read_since_scan = false;
@@ -935,6 +965,12 @@ static int process_scan(rekf_t *h, double t, const float *xy, int K, const doubl
         {
             RekfDev dm = h->dev;
             if (early_pub) { dm.pub = h->host_slots_dev; dm.pub_seq = pub_seq; }
+            if (aug) {
+                // a filter that can still grow: workgroup 0 publishes the n this scan leaves as soon as its match record is final, for the
+                // next scan's call (struct rekf, EARLY n), and leaves the scan's augmentation record whatever form the launch has
+                dm.early = h->host_slots_dev + 13; dm.early_seq = ++h->early_seq; dm.aug_write = 1;
+                h->early_valid = true; h->early_n_before = h->n_exact ? n_ub : -1;
+            }
             ProfScope ps(h, REKF_K_MID);
             if (fast) {
                 // [front end |] mid role | the held-back downdate, from the stored P into the other buffer -- which then IS the stored P
@@ -995,7 +1031,7 @@ static int process_scan(rekf_t *h, double t, const float *xy, int K, const doubl
             h->n_ub = h->ctl_staging->n; h->n_det = h->n_ub; h->n_exact = true; h->full = h->n_ub >= h->dev.n_max;
         }
         (void)hipGetLastError();
-        h->pub_valid = false; h->mir_valid = false;
+        h->pub_valid = false; h->mir_valid = false; h->early_valid = false;
         return REKF_ERR_HIP;
     }
     return REKF_OK;
@@ -1097,6 +1133,8 @@ int rekf_set_state(rekf_t *h, double t, int n, const double *mu, const double *s
 {
     if (!h || !mu || !sigma || n < 3 || n > h->dev.n_max || ((n - 3) & 1)) return REKF_ERR_INVALID;
     if (h->held) (void)flush_held(h);
+    h->held = false;                                              // (a held scan that could not be sent belonged to the state being replaced)
+    h->early_valid = false;
     h->spec_ready = false;
     h->pub_valid = false;
     for (auto &r : h->pub_ring) r = {0, 0};                       // an n published before this call says nothing about the new state

@@ -29,7 +29,7 @@ def _pair(cfg, sess, cap=None):
 def test_extension_is_loaded_and_there_is_no_fallback():
     from reflector_ekf_slam_amd import _lib
     assert os.path.exists(_lib.lib_path("librekf.so"))
-    assert _lib.rekf().rekf_abi_version() == _lib.REKF_ABI_VERSION == 6
+    assert _lib.rekf().rekf_abi_version() == _lib.REKF_ABI_VERSION == 7
 
 
 @pytest.mark.parametrize("case", ["diff_L24_obs8", "omni_L30_obs10", "map_L24_obs8", "gps_L20_obs6", "diff_L128_obs16"])

@@ -364,25 +364,21 @@ def test_localisation_against_a_preloaded_map_only(oracle_lib):
 
 # ---------------------------------------------------------------------------------------------- lazy downdate (k_dd_front)
 @pytest.mark.parametrize("L,obs,capf", [(96, 12, 1), (130, 20, 1), (96, 12, 2)], ids=["n195_strips", "n263_generic", "n195_below_capacity"])
-def test_lazy_downdate_gives_the_eager_chains_bits(oracle_lib, monkeypatch, L, obs, capf):
-    """Scans enqueued back to back on a filter at capacity run as k_dd_front (the previous scan's downdate + this scan's front end
-    in one launch) + k_mid; with REKF_LAZY_DD=0 the same calls run as k_front_mb + k_mid + k_downdate2.  Both are the same
-    arithmetic in the same order: the states must agree BIT FOR BIT, and with the oracle to the usual bounds -- with odometry
-    (which reads the pose: the held-back downdate goes out alone), empty scans and a pose observation in the mix."""
+def test_lazy_downdate_with_odometry_empty_scans_and_pose_observations(oracle_lib, L, obs, capf):
+    """Scans enqueued back to back have their downdate (and augmentation) held back and sent with the next call -- as a role of the next
+    scan's launch, as k_dd_front, or alone in front of whoever reads the state.  With odometry (which reads the pose mirror), empty scans
+    and a pose observation in the mix, at capacity and below it: associations and state agree with the oracle to the usual bounds.
+    (Until round 5 this test also ran an eager twin, REKF_LAZY_DD=0; that switch is gone -- the eager chain survives only for scans too
+    wide for the launch packet, which test_wide_scans_more_than_64_observations covers -- and the one-launch / two-launch / unpipelined twins
+    of rounds 4-6 compare the surviving forms bit for bit.)"""
     from reflector_ekf_slam_amd import session as S
     cfg = synth.SessionConfig("lazy", L, obs, synth.DIFF, seed=77 + L, speed=1.0, row_spacing=5.0)
     sess = synth.make_session(cfg)
     lin, ang, oc = cfg.sigma_v ** 2, cfg.sigma_w ** 2, cfg.sigma_obs ** 2
-
-    def run(lazy):
-        monkeypatch.setenv("REKF_LAZY_DD", "1" if lazy else "0")
-        g = make_gpu(cfg.odom_model, sess.init_time, sess.init_pose, lin, ang, oc, capf * cfg.n_landmarks)
-        S.replay(sess, g)                                                 # (capf = 2: the map build itself runs with k_augment held back)
-        assert g.GetState().mu.shape[0] == 3 + 2 * L                      # capf = 1: at capacity, nothing can be appended any more
-        return g
-
-    ga, gb = run(True), run(False)
+    ga = make_gpu(cfg.odom_model, sess.init_time, sess.init_pose, lin, ang, oc, capf * cfg.n_landmarks)
+    S.replay(sess, ga)                                                    # (capf = 2: the map build itself runs with k_augment held back)
     st = ga.GetState()
+    assert st.mu.shape[0] == 3 + 2 * L                                    # capf = 1: at capacity, nothing can be appended any more
     o = make_oracle(cfg.odom_model, sess.init_time, sess.init_pose, lin, ang, oc)
     vt = sess.odom[np.nonzero(sess.ev_type == synth.EV_ODOM)[0][-1]]
     o.set_state(st.time, st.mu, st.sigma, vt)
@@ -390,21 +386,20 @@ def test_lazy_downdate_gives_the_eager_chains_bits(oracle_lib, monkeypatch, L, o
     for k, (t, ob) in enumerate(scans):
         gps = None
         if k % 17 == 5:
-            for f in (ga, gb, o):
+            for f in (ga, o):
                 f.handle_odometry(t - 0.01, 0.05, 0.0, 0.01)              # reads the pose mirror: flushes the held-back downdate
         if k % 13 == 7:
             ob = ob[:0]                                                   # an empty scan (Predict only, on the host)
         if k % 11 == 3:
             gps = tuple(o.mu()[:3] + np.array([0.01, -0.01, 0.002]))
-        for f in (ga, gb, o):
+        for f in (ga, o):
             f.handle_observation(t, ob, gps) if gps is not None else f.handle_observation(t, ob)
         if k % 20 == 19:
-            assert _same_match(ga, o) and _same_match(gb, o), f"scan {k}"
-    sa, sb = ga.GetState(), gb.GetState()
+            assert _same_match(ga, o), f"scan {k}"
+    sa = ga.GetState()
     mo, Po = o.state()
-    assert np.array_equal(sa.mu, sb.mu) and np.array_equal(sa.sigma, sb.sigma)
     assert np.abs(sa.mu - mo).max() < TIGHT and np.abs(sa.sigma - Po).max() < 1e-11
-    assert ga.sync_code() == 0 and gb.sync_code() == 0
+    assert ga.sync_code() == 0
 
 
 @pytest.mark.parametrize("seed", range(6))

@@ -105,6 +105,8 @@ def test_the_deployed_default_at_full_size_in_both_call_patterns(oracle_lib):
         if k % 50 == 49:
             assert _same_match(g, o), f"association differs at update {k} (pipelined)"
             assert np.abs(g.mu() - o.mu()).max() < TIGHT
+    cnt = _counters(g)
+    assert cnt[20] > 250 and cnt[24] > 0, (cnt[20], cnt[24])               # (round 6) the default filter really ran the speculative one-launch form
     st2 = g.GetState()
     mo, Po = o.state()
     assert st2.mu.shape == mo.shape and np.abs(st2.mu - mo).max() < TIGHT and np.abs(st2.sigma - Po).max() < 1e-11
