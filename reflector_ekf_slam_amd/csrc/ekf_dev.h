@@ -76,7 +76,7 @@ struct RekfCtl {
     // reflector and to the runner-up; scan t + 1's k_mid accepts the record when every decision is PROVABLY the one the exact match would
     // take -- |d1 - gate| and d2 - d1 against a bound of how far the update moved the pose and the reflectors -- and re-matches the
     // observations that do not pass
-    struct Spec { int kind[32], idx[32]; double d1[32], d2[32]; double pose[3]; int n; unsigned scan; } spec[2];
+    struct Spec { int kind[32], idx[32]; double d1[32], d2[32]; double dm1[32]; double pose[3]; int n; unsigned scan; } spec[2];     // (dm1: with a pre-loaded map, the distance to the nearest MAP point of an observation that did not match the map)
     unsigned long long dmmax[4];      // bits of max |mu_new - mu_old| over the landmark rows of a scan's update (by scan id mod 4: a launch writes its own, reads the previous scan's, zeroes the next one's)
     unsigned front_count;             // observations matched so far, over the life of the handle (never reset)
     // ---- a scan's landmark augmentation deferred into the NEXT scan's k_mid (round 4): while the state can grow, every scan used to
@@ -196,6 +196,9 @@ struct RekfDev {
     RekfHostSlot *early;  // k_mid (whole scans on a filter that can still grow): workgroup 0 publishes the n the state has behind this scan -- n + 2 (new
     int early_seq;        // reflectors) -- under this tag AS SOON AS the scan's match record is final (rekf_api.hip, struct rekf: EARLY n)
     int pad_;
+    double map_lip;       // pre-loaded map: sqrt of the largest eigenvalue over its covariances -- sqrt(e^T S e) moves by at most map_lip |de| when the
+                          // observation's global point moves by de (the speculative match's margin proof, k_mid); < 0: some covariance is not
+                          // symmetric positive semi-definite, no bound (scans are then not speculated for)
 };
 
 // ----------------------------------------------------------------------------

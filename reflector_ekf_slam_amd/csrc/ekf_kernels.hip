@@ -264,6 +264,68 @@ __device__ static inline void compact_record(RekfCtl::Rec *rec, RekfCtl *ctl, in
         rec->nu = nu;
     }
 }
+// ReflectorMatch's MAP branch (cc:401-425) for one observation, by ONE wave: sqrt(e^T S e) against every pre-loaded point (S the stored
+// covariance, not its inverse: quirk Q3), first minimum in index order, a match below 0.05.  The literal form: per-lane first minimum,
+// then the wave-wide one (a NaN distance -- e^T S e < 0 for an indefinite S -- is treated as the reference's sort treats it here: never
+// smaller than anything, but a lane's first candidate stands until a smaller one comes).
+__device__ static inline void map_match_wave(const RekfDev &d, int mlane, float gx, float gy, int &kind, int &best_j)
+{
+#pragma clang fp contract(off)
+    const int M_ = d.M_map;
+    double best = 0; int bj = -1;
+    for (int j = mlane; j < M_; j += 64) {
+        const double *S = d.map_cov + 4 * (size_t)j;
+        const float ex = d.map_xy[2 * j] - gx;
+        const float ey = d.map_xy[2 * j + 1] - gy;
+        const double dx = (double)ex, dy = (double)ey;
+        const double t0 = dx * S[0] + dy * S[2];
+        const double t1 = dx * S[1] + dy * S[3];
+        const double dist = sqrt(t0 * dx + t1 * dy);
+        if (bj < 0 || dist < best) { best = dist; bj = j; }
+    }
+    wave_argmin(best, bj);
+    if (bj >= 0 && best < 0.05) { kind = 0; best_j = bj; }
+}
+__device__ static inline double readlane63_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+// ... and for the SPECULATIVE front end: the same decision (map_lip >= 0: every S is symmetric positive semi-definite, no NaN can arise
+// but from round-off -- which makes the observation unprovable: dm1 = NaN), with what the margin proof needs: the distance to the nearest
+// map point (d1) and to the runner-up (d2)
+__device__ static inline void map_match_wave_spec(const RekfDev &d, int mlane, float gx, float gy, int &kind, int &best_j, double &d1, double &d2)
+{
+#pragma clang fp contract(off)
+    const int M_ = d.M_map;
+    double b1 = 1e300, b2 = 1e300; int bj = -1; bool nan = false;
+    for (int j = mlane; j < M_; j += 64) {
+        const double *S = d.map_cov + 4 * (size_t)j;
+        const float ex = d.map_xy[2 * j] - gx;
+        const float ey = d.map_xy[2 * j + 1] - gy;
+        const double dx = (double)ex, dy = (double)ey;
+        const double t0 = dx * S[0] + dy * S[2];
+        const double t1 = dx * S[1] + dy * S[3];
+        const double dist = sqrt(t0 * dx + t1 * dy);
+        nan = nan || !(dist == dist);
+        b2 = vmin_f64(b2, vmax_f64(dist, b1));
+        bj = (dist < b1) ? j : bj;
+        b1 = vmin_f64(b1, dist);
+    }
+    double g1 = b1, g2 = b2; int gj = bj;
+    argmin2_dpp_step<0x111, 0xf>(g1, gj, g2);
+    argmin2_dpp_step<0x112, 0xf>(g1, gj, g2);
+    argmin2_dpp_step<0x114, 0xf>(g1, gj, g2);
+    argmin2_dpp_step<0x118, 0xf>(g1, gj, g2);
+    argmin2_dpp_step<0x142, 0xa>(g1, gj, g2);
+    argmin2_dpp_step<0x143, 0xc>(g1, gj, g2);
+    g1 = readlane63_f64(g1); g2 = readlane63_f64(g2); gj = __builtin_amdgcn_readlane(gj, 63);
+    d1 = g1; d2 = g2;
+    if (__ballot(nan) != 0ull) { d1 = __longlong_as_double(0x7ff8000000000000ll); d2 = d1; return; }     // unprovable: k_mid re-matches it
+    if (gj >= 0 && g1 < 0.05) { kind = 0; best_j = gj; }
+}
+
 // The front end as a ROLE of a workgroup of NT threads (a multiple of 256): k_front_mb below is nothing else; the fused kernel
 // k_dd_front runs it in the workgroups behind its downdate workgroups.  corner_in_ctl: the pose block to predict from is
 // RekfCtl::post_C9 (what k_mid evaluated for the previous scan) -- in k_dd_front the previous scan's downdate, which stores that block
@@ -428,21 +490,10 @@ __device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs
         if (mwave < 4) obs_to_global(pose[0], pose[1], pose[3], pose[4], obx, oby, gx, gy);
         int kind = 2, best_j = -1;
         FMARK();                                      // m0: observation in the global frame
+        double dm1v = 1e300, dm2v = 1e300;                           // SPEC: distance to the nearest map point / the runner-up
         if (mwave == 0 && M_ > 0) {                                // cc:401-425
-#pragma clang fp contract(off)
-            double best = 0; int bj = -1;
-            for (int j = mlane; j < M_; j += 64) {
-                const double *S = d.map_cov + 4 * (size_t)j;
-                const float ex = d.map_xy[2 * j] - gx;
-                const float ey = d.map_xy[2 * j + 1] - gy;
-                const double dx = (double)ex, dy = (double)ey;
-                const double t0 = dx * S[0] + dy * S[2];
-                const double t1 = dx * S[1] + dy * S[3];
-                const double dist = sqrt(t0 * dx + t1 * dy);
-                if (bj < 0 || dist < best) { best = dist; bj = j; }
-            }
-            wave_argmin(best, bj);
-            if (bj >= 0 && best < 0.05) { kind = 0; best_j = bj; }
+            if constexpr (SPEC) map_match_wave_spec(d, mlane, gx, gy, kind, best_j, dm1v, dm2v);
+            else map_match_wave(d, mlane, gx, gy, kind, best_j);
         }
         if (mwave < 4 && L > 0) {                                  // cc:426-451, this wave's quarter of the landmarks
 #pragma clang fp contract(off)
@@ -504,7 +555,9 @@ __device__ __forceinline__ void front_role(const RekfDev &d, const RekfFrontArgs
                 if (SPEC) {
                     __hip_atomic_store(&sp->kind[i & 31], kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&sp->idx[i & 31], best_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    store_wt(&sp->d1[i & 31], d1v); store_wt(&sp->d2[i & 31], d2v);
+                    // (a map match: its own distances; else the state branch's, and the nearest map point's for the "no map match" half of the proof)
+                    store_wt(&sp->d1[i & 31], kind == 0 ? dm1v : d1v); store_wt(&sp->d2[i & 31], kind == 0 ? dm2v : d2v);
+                    store_wt(&sp->dm1[i & 31], dm1v);
                 } else {
                     __hip_atomic_store(&ctl->obs_kind[i], kind, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&ctl->obs_idx[i], best_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -895,11 +948,13 @@ __device__ static inline void augment_rows(const RekfDev &d, int n, int N2, doub
 // ReflectorMatch's state branch (cc:426-451) for ONE observation, by a whole workgroup of >= 256 threads (waves 0..3 sweep the landmarks,
 // every thread must call; two workgroup barriers): the exact re-match of an observation whose speculative result k_mid could not prove
 // (RekfCtl::spec).  Same arithmetic as front_role's sweep -- smallest and second smallest squared distance, the literal scan on a tie.
-__device__ static inline void rematch_obs(const double *mu, int L, float gx, float gy, int &kind, int &best_j)
+__device__ static inline void rematch_obs(const RekfDev &d, const double *mu, int L, float gx, float gy, int &kind, int &best_j)
 {
     __shared__ double s_rp[4][2];
     __shared__ int s_rj[4], s_rk[2];
     const int tid = threadIdx.x, mwave = tid >> 6, mlane = tid & 63;
+    int kind_m = 2, idx_m = -1;                          // the map branch comes first (cc:401-425): wave 0, before it finishes the state branch
+    if (mwave == 0 && d.M_map > 0) map_match_wave(d, mlane, gx, gy, kind_m, idx_m);
     if (mwave < 4) {
 #pragma clang fp contract(off)
         double b1 = 1e300, b2 = 1e300; int bj = -1;
@@ -925,8 +980,8 @@ __device__ static inline void rematch_obs(const double *mu, int L, float gx, flo
     __syncthreads();
     if (mwave == 0) {
 #pragma clang fp contract(off)
-        int kd = 2, bjj = -1;
-        if (L > 0) {
+        int kd = kind_m, bjj = idx_m;
+        if (kind_m == 2 && L > 0) {
             double g1 = s_rp[0][0], g2 = s_rp[0][1]; int gj = s_rj[0];
 #pragma unroll
             for (int w = 1; w < 4; ++w) argmin2_combine(g1, gj, g2, s_rp[w][0], s_rj[w], s_rp[w][1]);
@@ -1225,13 +1280,14 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, int h0, int h1,
     const bool first = bx == 0;
     // a speculative scan: its per-observation results with their margins (lane = observation)
     int sp_kind = -1, sp_idx = -1;
-    double sp_d1 = 0.0, sp_d2 = 0.0, sp_rng = 0.0, sp_pose0 = 0.0, sp_pose1 = 0.0, sp_pose2 = 0.0, sp_dmm = 0.0;
+    double sp_d1 = 0.0, sp_d2 = 0.0, sp_dm1 = 1e300, sp_rng = 0.0, sp_pose0 = 0.0, sp_pose1 = 0.0, sp_pose2 = 0.0, sp_dmm = 0.0;
     bool sp_rec_ok = false;
     if (spec) {
         // (everything the proof needs goes in flight now: behind the barrier only arithmetic is left)
         const RekfCtl::Spec *sq = &ctl->spec[hd_pred_slot];
         if (lane < hd_K) {
             sp_kind = sq->kind[lane & 31]; sp_idx = sq->idx[lane & 31]; sp_d1 = sq->d1[lane & 31]; sp_d2 = sq->d2[lane & 31];
+            if (d.M_map > 0) sp_dm1 = sq->dm1[lane & 31];
             const double px = (double)rekf_obs(A, 2 * lane), py = (double)rekf_obs(A, 2 * lane + 1);
             sp_rng = sqrt(px * px + py * py);
         }
@@ -1318,12 +1374,18 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, int h0, int h1,
             const double dmm = sp_dmm;
             if (lane < A.K) {
                 const double rng = sp_rng;
-                const double delta = sqrt(dxp * dxp + dyp * dyp) + rng * fabs(dth) + 1.5 * dmm
-                                   + 3e-7 * (fabs(pose[0]) + fabs(pose[1]) + rng + 1.0);
-                if (sp_kind == 1) okv = (sp_d1 + delta < 0.6) && (sp_d2 - sp_d1 > 2.0 * delta);
-                else if (sp_kind == 2) okv = sp_d1 - delta > 0.6;
+                // dg: how far the observation's global point can have moved (pose shift + the float32 roundings of the two evaluations);
+                // the state branch adds the reflectors' own shift; the map branch (fixed points) scales dg by the map's Lipschitz bound
+                const double dg = sqrt(dxp * dxp + dyp * dyp) + rng * fabs(dth) + 3e-7 * (fabs(pose[0]) + fabs(pose[1]) + rng + 1.0);
+                const double delta = dg + 1.5 * dmm;
+                const double dmap = d.map_lip * dg + 1e-12;
+                // with a pre-loaded map an observation reaches the state branch only if NO map point is inside 0.05 (cc:401-425 come first)
+                const bool map_free = d.M_map == 0 || (d.map_lip >= 0.0 && sp_dm1 - dmap > 0.05);
+                if (sp_kind == 1) okv = map_free && (sp_d1 + delta < 0.6) && (sp_d2 - sp_d1 > 2.0 * delta);
+                else if (sp_kind == 2) okv = map_free && (sp_d1 - delta > 0.6);
+                else if (sp_kind == 0) okv = d.map_lip >= 0.0 && (sp_d1 + dmap < 0.05) && (sp_d2 - sp_d1 > 2.0 * dmap);
                 else okv = false;
-                if (!(delta == delta)) okv = false;
+                if (!(delta == delta) || !(dmap == dmap)) okv = false;
             }
         }
         const bool rec_ok = sp_rec_ok && d.n_known == n;
@@ -1343,7 +1405,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, int h0, int h1,
                     float gx, gy;
                     obs_to_global(pose[0], pose[1], pose[3], pose[4], rekf_obs(A, 2 * i), rekf_obs(A, 2 * i + 1), gx, gy);
                     int kd, bj;
-                    rematch_obs(d.mu, (n - 3) / 2, gx, gy, kd, bj);
+                    rematch_obs(d, d.mu, (n - 3) / 2, gx, gy, kd, bj);
                     if (tid == 0) { s_fk[i] = kd; s_fi[i] = bj; }
                 }
             }

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -697,8 +698,24 @@ int rekf_set_map(rekf_t *h, const float *xy, const double *cov, int M)
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     (void)hipFree(h->dev.map_xy); (void)hipFree(h->dev.map_cov);
-    h->dev.map_xy = nullptr; h->dev.map_cov = nullptr; h->dev.M_map = 0;
+    h->dev.map_xy = nullptr; h->dev.map_cov = nullptr; h->dev.M_map = 0; h->dev.map_lip = 0.0;
     if (M == 0) return REKF_OK;
+    // the map branch of the match measures sqrt(e^T S e) with S the stored 2 x 2 COVARIANCE (cc:411, quirk Q3).  For symmetric positive
+    // semi-definite S that is a seminorm: it moves by at most sqrt(lambda_max) |de| when the observation moves by de -- the bound the
+    // speculative match's margin proof needs (k_mid).  Any other S: no bound, scans are not speculated for (map_lip < 0)
+    double lip2 = 0.0;
+    bool psd = true;
+    for (int j = 0; j < M; ++j) {
+        const double a = cov[4 * j], b = cov[4 * j + 1], c = cov[4 * j + 2], d = cov[4 * j + 3];
+        const double tol = 1e-12 * (std::fabs(a) + std::fabs(d) + 1e-300);
+        if (!(std::fabs(b - c) <= tol)) { psd = false; break; }
+        const double tr = a + d, det = a * d - b * c;
+        const double disc = std::sqrt(std::fmax(0.25 * tr * tr - det, 0.0));
+        const double lmax = 0.5 * tr + disc, lmin = 0.5 * tr - disc;
+        if (!(lmin >= -tol) || !(lmax == lmax)) { psd = false; break; }
+        if (lmax > lip2) lip2 = lmax;
+    }
+    h->dev.map_lip = psd ? std::sqrt(lip2) : -1.0;
     HIP_TRY(h, hipMalloc(&h->dev.map_xy, sizeof(float) * 2 * (size_t)M));
     HIP_TRY(h, hipMalloc(&h->dev.map_cov, sizeof(double) * 4 * (size_t)M));
     HIP_TRY(h, hipMemcpy(h->dev.map_xy, xy, sizeof(float) * 2 * (size_t)M, hipMemcpyHostToDevice));
@@ -743,9 +760,10 @@ int rekf_handle_observation(rekf_t *h, double t, const float *xy, int K, const d
 {
     if (!h || K < 0 || (K > 0 && !xy)) return REKF_ERR_INVALID;
     if (K > REKF_MAX_OBS) return REKF_ERR_TOO_MANY_OBS;
-    // a scan that can take part in the speculation pipeline: a whole scan (a filter that can still grow included: struct rekf, EARLY n), no
-    // pre-loaded map (its branch of the match has no margin proof), handed over without a pose read-back since the last scan
-    const bool holdable = h->spec_enable && h->scan_launch && K >= 1 && K <= 32 && h->dev.M_map == 0 &&
+    // a scan that can take part in the speculation pipeline: a whole scan (a filter that can still grow included: struct rekf, EARLY n; a
+    // pre-loaded map whose covariances give its branch of the match a margin proof included: RekfDev::map_lip), handed over without a
+    // pose read-back since the last scan
+    const bool holdable = h->spec_enable && h->scan_launch && K >= 1 && K <= 32 && (h->dev.M_map == 0 || h->dev.map_lip >= 0.0) &&
                           !h->mir_valid && !h->prof_on;
     if (h->held) {
         if (!holdable) { FLUSH_HELD(h); return process_scan(h, t, xy, K, gps_pose3, nullptr); }

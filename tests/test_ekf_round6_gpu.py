@@ -209,3 +209,60 @@ def test_a_held_scan_whose_launch_fails_stays_held(oracle_lib):
     mo, Po = o.state()
     assert np.abs(st.mu - mo).max() < TIGHT and np.abs(st.sigma - Po).max() < 1e-11
     assert g.sync_code() == 0
+
+
+def test_map_localisation_at_512_reflectors_through_the_speculative_path(oracle_lib):
+    """BASELINE configs[3]'s world (512 reflectors, omni odometry) as the reference's DEPLOYMENT runs it: 400 reflectors come from a
+    pre-loaded map (cc:401-425: matched first, by sqrt(e^T S e) < 0.05 against the stored covariances, some of them anisotropic), the
+    rest enter the state.  The moving session in the node's call pattern, then 300 scans handed over back to back: since round 6 the
+    map branch has a margin proof of its own (RekfDev::map_lip), so these run the speculative one-launch form -- every third one with an
+    observation pushed onto the map gate (0.5 m at S = 0.01 I) or the state gate (0.6 m), where the proof must fail and the exact
+    re-match decide.  Associations identical to the oracle's, |mu - oracle| < 1e-9."""
+    from reflector_ekf_slam_amd import ReflectorEKFSLAM
+    from reflector_ekf_slam_amd import session as S
+    from tests.helpers import drive_pair
+    cfg = synth.C4
+    sess = synth.make_session(cfg, max_scans=260)
+    rng = np.random.default_rng(6500)
+    ids = np.sort(rng.choice(cfg.n_landmarks, size=400, replace=False))
+    mxy = (sess.landmarks[ids] + rng.normal(0, 0.01, size=(ids.size, 2))).astype(np.float32)
+    mcov = np.tile(np.array([0.01, 0.0, 0.0, 0.01]), (ids.size, 1))
+    mcov[::7] = np.array([0.012, 0.003, 0.003, 0.008])                  # symmetric positive definite, anisotropic
+    g = ReflectorEKFSLAM(S.options_for(sess))                           # the wrapper's defaults
+    o = make_oracle(cfg.odom_model, sess.init_time, sess.init_pose, cfg.sigma_v ** 2, cfg.sigma_w ** 2, cfg.sigma_obs ** 2)
+    g.set_map(mxy, mcov); o.set_map(mxy, mcov)
+    seen = [0, 0]
+
+    def chk(e, k):
+        if k % 25 == 0:
+            assert _same_match(g, o), f"association differs at scan {k}"
+            m = norm_match(g.last_match())
+            seen[0] += m[1].shape[0]; seen[1] += m[0].shape[0]
+            assert np.abs(g.mu() - o.mu()).max() < TIGHT
+
+    drive_pair(sess, g, o, chk)
+    assert seen[0] > 50 and seen[1] > 10 and g.n == o.n                  # map matches and state matches both occur
+    t_park = float(sess.ev_time[-1]) + 0.01                              # (the truncated session ends in motion: park, the scans below are taken standing still)
+    g.handle_odometry(t_park, 0.0, 0.0, 0.0); o.handle_odometry(t_park, 0.0, 0.0, 0.0)
+    c0 = _counters(g)[20]
+    scans = synth.steady_state_scans(sess, 300)
+    for k, (t, ob) in enumerate(scans):
+        ob = np.array(ob, np.float32, copy=True)
+        if k % 3 == 1:
+            j = int(rng.integers(0, ob.shape[0]))
+            phi = rng.uniform(0, 2 * np.pi)
+            r = (0.5 if k % 2 else 0.6) + rng.choice([-4e-3, -1.5e-3, -3e-4, 3e-4, 1.5e-3, 4e-3])
+            ob[j] += np.float32(r) * np.array([np.cos(phi), np.sin(phi)], np.float32)
+        g.handle_observation(t, ob)
+        o.handle_observation(t, ob)
+        if k % 29 == 28:
+            assert _same_match(g, o), f"association differs at steady scan {k}"
+            assert np.abs(g.mu() - o.mu()).max() < TIGHT
+    cnt = _counters(g)
+    # speculative records proved / with re-matched observations (a third of the gate cases land outside 0.6 m: a new reflector, and the
+    # scan behind it takes the two-launch chain; every check above drains the pipeline)
+    assert cnt[20] - c0 > 150 and cnt[21] > 10, (c0, cnt[20], cnt[21])
+    st = g.GetState()
+    mo, Po = o.state()
+    assert st.mu.shape == mo.shape and np.abs(st.mu - mo).max() < TIGHT and np.abs(st.sigma - Po).max() < 1e-11
+    assert g.sync_code() == 0 and g.flags() == 0
