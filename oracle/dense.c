@@ -103,6 +103,13 @@ static void od_gemm_acc_1(int M, int N, int K, double alpha,
     }
 }
 
+/* the single-thread kernel on a caller-chosen sub-block (the persistent-team structured update of ekf_oracle.c deals row blocks
+ * and 16-column blocks to its threads itself); column blocks must start on multiples of four of the full matrix */
+void od_gemm_acc_block(int M, int N, int K, double alpha, const double *A, int lda, const double *B, int ldb, double *C, int ldc)
+{
+    od_gemm_acc_1(M, N, K, alpha, A, lda, B, ldb, C, ldc);
+}
+
 /* C(MxN) = A(MxK) * B(KxN) */
 void od_gemm(int M, int N, int K, const double *A, int lda,
              const double *B, int ldb, double *C, int ldc)

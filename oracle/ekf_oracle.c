@@ -39,6 +39,10 @@ void od_gemm(int M, int N, int K, const double *A, int lda, const double *B,
 void od_transpose(int M, int N, const double *A, int lda, double *B, int ldb);
 int od_lu_inverse(int m, double *A, int lda);
 int od_get_threads(void);
+void od_gemm_acc_block(int M, int N, int K, double alpha, const double *A, int lda, const double *B, int ldb, double *C, int ldc);
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 enum { OEKF_DIFF = 0, OEKF_OMNI = 1 };
 
@@ -244,6 +248,7 @@ static __attribute__((noinline)) void obs_to_global(const double *mu, float px, 
     *gx = x; *gy = y;
 }
 
+static void reflector_match_team(oekf_t *e, const float *obs, int K, int T);
 static void reflector_match(oekf_t *e, const float *obs, int K)
 {
     ensure_match_cap(e, K);
@@ -252,6 +257,7 @@ static void reflector_match(oekf_t *e, const float *obs, int K)
         for (int i = 0; i < K; ++i) e->new_ids[e->n_new++] = i;
         return;
     }
+    if (!e->literal && od_get_threads() > 1 && K > 1) { reflector_match_team(e, obs, K, od_get_threads()); return; }
     const int M = (e->n - 3) / 2;                                    /* :395 */
     const int M_ = e->M_map;                                         /* :396 */
     for (int i = 0; i < K; ++i) {
@@ -301,6 +307,139 @@ static void reflector_match(oekf_t *e, const float *obs, int K)
     }
 }
 
+/* The same decisions (cc:397-453), one observation per loop iteration with the iterations dealt to an OpenMP team (the structured
+ * all-core baseline): every observation's result depends only on the state, so the per-observation loop bodies are the
+ * ones above, verbatim; the three lists are filled in observation order behind the loop. */
+static void reflector_match_team(oekf_t *e, const float *obs, int K, int T)
+{
+    const int M = (e->n - 3) / 2, M_ = e->M_map;
+    int *kind = (int *)malloc(sizeof(int) * 2 * (size_t)K), *idx = kind + K;
+#pragma omp parallel for schedule(static) num_threads(T)
+    for (int i = 0; i < K; ++i) {
+        float gx, gy;
+        obs_to_global(e->mu, obs[2 * i], obs[2 * i + 1], &gx, &gy);  /* :399 */
+        kind[i] = 2; idx[i] = -1;
+        if (M_ > 0) {                                                /* :401-425 */
+            double best = 0; int bj = -1;
+            for (int j = 0; j < M_; ++j) {
+                const double *S = e->map_cov + 4 * (size_t)j;
+                const float ex = e->map_xy[2 * j] - gx;
+                const float ey = e->map_xy[2 * j + 1] - gy;
+                const double dx = (double)ex, dy = (double)ey;
+                const double t0 = dx * S[0] + dy * S[2];
+                const double t1 = dx * S[1] + dy * S[3];
+                const double dist = sqrt(t0 * dx + t1 * dy);
+                if (bj < 0 || dist < best) { best = dist; bj = j; }
+            }
+            if (best < 0.05) { kind[i] = 0; idx[i] = bj; continue; } /* :420 */
+        }
+        if (M > 0) {                                                 /* :426-451 */
+            double best = 0; int bj = -1;
+            for (int j = 0; j < M; ++j) {
+                const float lx = (float)e->mu[3 + 2 * j];
+                const float ly = (float)e->mu[3 + 2 * j + 1];
+                const float ex = gx - lx;
+                const float ey = gy - ly;
+                const double dx = (double)ex, dy = (double)ey;
+                const double dist = sqrt(dx * dx + dy * dy);
+                if (bj < 0 || dist < best) { best = dist; bj = j; }
+            }
+            if (best < 0.6) { kind[i] = 1; idx[i] = bj; }            /* :446 */
+        }
+    }
+    for (int i = 0; i < K; ++i) {
+        if (kind[i] == 0) { e->map_pairs[2 * e->n_map] = i; e->map_pairs[2 * e->n_map + 1] = idx[i]; e->n_map++; }
+        else if (kind[i] == 1) { e->state_pairs[2 * e->n_state] = i; e->state_pairs[2 * e->n_state + 1] = idx[i]; e->n_state++; }
+        else e->new_ids[e->n_new++] = i;                             /* :452 */
+    }
+    free(kind);
+}
+
+/* The structured update (cc:246-309 with the sparsity of H exploited: O(n^2 m)) by ONE persistent OpenMP team per update -- the fair
+ * algorithmic CPU baseline SURVEY.md 8(d) asks for.  Thread t OWNS a fixed, contiguous range of P's columns (chunks of 16, the dense
+ * kernel's unit) and the same range of rows of the n x m panels: its share of P stays in its own cache from update to update, every
+ * phase is a loop over owned rows or columns, and the phases meet at four barriers instead of a fork-join per loop.  Every element sees
+ * exactly the operations, in the order, of the single-thread structured path below (same source expressions in this file, the same dense
+ * kernel on column / row sub-blocks): bit-identical results at any thread count (tests/test_oracle_cpu.py).
+ * hc / hv / hn: the <= 5 structural non-zeros of each H row; returns 0, or -3 when S is singular. */
+static int update_structured_team(oekf_t *e, int m, const int *hc, const double *hv, const int *hn, const double *Qd, const double *dz, int T)
+{
+    const int N = e->n;
+    double *PHt = (double *)malloc(sizeof(double) * (size_t)N * m);
+    double *Kt = (double *)malloc(sizeof(double) * (size_t)N * m);
+    double *HP = (double *)malloc(sizeof(double) * (size_t)m * N);
+    double *S = (double *)malloc(sizeof(double) * (size_t)m * m);
+    int bad = 0;
+    const int chunks = (N + 15) / 16;
+#pragma omp parallel num_threads(T)
+    {
+#ifdef _OPENMP
+        const int t = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+        const int t = 0, nt = 1;
+#endif
+        const int per = (chunks + nt - 1) / nt;
+        int o0 = 16 * per * t, o1 = 16 * per * (t + 1);                /* owned rows of the panels = owned columns of P */
+        if (o0 > N) o0 = N;
+        if (o1 > N) o1 = N;
+        /* (P H^T)(r, j) = sum over the <= 5 non-zeros of H row j, owned rows */
+        for (int j = 0; j < m; ++j) {
+            double *w = PHt + (size_t)j * N;
+            for (int r = o0; r < o1; ++r) w[r] = 0.0;
+            for (int q = 0; q < hn[j]; ++q) {
+                const double h = hv[5 * j + q];
+                const double *pc = e->P + (size_t)hc[5 * j + q] * N;
+                for (int r = o0; r < o1; ++r) w[r] += pc[r] * h;
+            }
+        }
+        /* (H P)(i, c) from the rows of P, owned columns (read before anybody writes P: the barrier below) */
+        for (int cidx = o0; cidx < o1; ++cidx) {
+            const double *pc = e->P + (size_t)cidx * N;
+            for (int i = 0; i < m; ++i) {
+                double acc = 0;
+                for (int q = 0; q < hn[i]; ++q)
+                    acc += hv[5 * i + q] * pc[hc[5 * i + q]];
+                HP[i + (size_t)cidx * m] = acc;
+            }
+        }
+#pragma omp barrier
+#pragma omp single
+        {
+            for (int j = 0; j < m; ++j)
+                for (int i = 0; i < m; ++i) {
+                    double acc = 0;
+                    for (int q = 0; q < hn[i]; ++q)
+                        acc += hv[5 * i + q] * PHt[hc[5 * i + q] + (size_t)j * N];
+                    S[i + (size_t)j * m] = acc;
+                }
+            for (int r = 0; r < m; ++r) S[r + (size_t)r * m] += Qd[r];
+            if (od_lu_inverse(m, S, m) != 0) bad = 1;
+        }                                                              /* (implicit barrier) */
+        if (!bad && o1 > o0) {
+            /* K_t rows: the dense kernel on this thread's row block (od_gemm = zero + accumulate) */
+            for (int j = 0; j < m; ++j)
+                memset(Kt + o0 + (size_t)j * N, 0, sizeof(double) * (size_t)(o1 - o0));
+            od_gemm_acc_block(o1 - o0, m, m, 1.0, PHt + o0, N, S, m, Kt + o0, N);
+            for (int r = o0; r < o1; ++r) {                            /* :306 */
+                double acc = 0;
+                for (int j = 0; j < m; ++j) acc += Kt[r + (size_t)j * N] * dz[j];
+                e->mu[r] += acc;
+            }
+        }
+#pragma omp barrier
+        if (!bad) {
+            /* P -= K (H P), owned columns, 16 at a time (the dense kernel's column grouping is part of the arithmetic) */
+            for (int j0 = o0; j0 < o1; j0 += 16) {
+                const int nj = (o1 - j0 < 16) ? (o1 - j0) : 16;
+                od_gemm_acc_block(N, nj, m, -1.0, Kt, N, HP + (size_t)j0 * m, m, e->P + (size_t)j0 * N, N);
+            }
+        }
+    }
+    if (!bad) e->mu[2] = atan2(sin(e->mu[2]), cos(e->mu[2]));          /* :307 */
+    free(PHt); free(Kt); free(HP); free(S);
+    return bad ? -3 : 0;
+}
+
 /* quaternion (w,0,0,z) -> angle-axis z component: transform.h:46-70 as used at
  * reflector_ekf_slam_gps.cc:320-322. */
 static double yaw_innovation(double delta_theta)
@@ -328,7 +467,10 @@ int oekf_handle_observation(oekf_t *e, double t, const float *obs, int K,
     const int N = e->n;
     if (MM > 0) {                                                    /* :246 */
         const int m = 2 * MM + (gps_pose3 ? 3 : 0);
-        double *H = (double *)calloc((size_t)m * N, sizeof(double));  /* m x N col-major */
+        /* the dense H (m x N col-major) only where the dense products need it: the structured mode works from its <= 5 non-zeros per row */
+        double *H = (double *)calloc(e->literal ? (size_t)m * N : (size_t)m * 5, sizeof(double));
+        const int ldh = m;
+#define HSET(r, col, slot, v) do { if (e->literal) H[(r) + (size_t)(col) * ldh] = (v); else H[(r) + (size_t)(slot) * ldh] = (v); } while (0)
         double *z = (double *)calloc((size_t)m, sizeof(double));
         double *zh = (double *)calloc((size_t)m, sizeof(double));
         double *Qd = (double *)calloc((size_t)m, sizeof(double));     /* diagonal of Q */
@@ -351,18 +493,18 @@ int oekf_handle_observation(oekf_t *e, double t, const float *obs, int K,
             zh[2 * i] = dx * c + dy * s;                              /* :269 */
             zh[2 * i + 1] = -dx * s + dy * c;                         /* :270 */
             /* A_i (:272-273) */
-            H[(2 * i) + (size_t)0 * m] = -c;
-            H[(2 * i) + (size_t)1 * m] = -s;
-            H[(2 * i) + (size_t)2 * m] = -dx * s + dy * c;
-            H[(2 * i + 1) + (size_t)0 * m] = s;
-            H[(2 * i + 1) + (size_t)1 * m] = -c;
-            H[(2 * i + 1) + (size_t)2 * m] = -dx * c - dy * s;
+            HSET(2 * i, 0, 0, -c);
+            HSET(2 * i, 1, 1, -s);
+            HSET(2 * i, 2, 2, -dx * s + dy * c);
+            HSET(2 * i + 1, 0, 0, s);
+            HSET(2 * i + 1, 1, 1, -c);
+            HSET(2 * i + 1, 2, 2, -dx * c - dy * s);
             if (is_state) {                                           /* B (:255,:275); map rows have none (:300) */
                 const int col = 3 + 2 * global_id;
-                H[(2 * i) + (size_t)col * m] = c;
-                H[(2 * i) + (size_t)(col + 1) * m] = s;
-                H[(2 * i + 1) + (size_t)col * m] = -s;
-                H[(2 * i + 1) + (size_t)(col + 1) * m] = c;
+                HSET(2 * i, col, 3, c);
+                HSET(2 * i, col + 1, 4, s);
+                HSET(2 * i + 1, col, 3, -s);
+                HSET(2 * i + 1, col + 1, 4, c);
             }
             Qd[2 * i] = e->obs_cov; Qd[2 * i + 1] = e->obs_cov;       /* :276 / :302 */
         }
@@ -370,7 +512,7 @@ int oekf_handle_observation(oekf_t *e, double t, const float *obs, int K,
         for (int r = 0; r < 2 * MM; ++r) dz[r] = z[r] - zh[r];
         if (gps_pose3) {                                              /* gps.cc:305-332 */
             const int r0 = 2 * MM;
-            for (int k = 0; k < 3; ++k) H[(r0 + k) + (size_t)k * m] = 1.0;
+            for (int k = 0; k < 3; ++k) HSET(r0 + k, k, k, 1.0);
             dz[r0] = gps_pose3[0] - e->mu[0];
             dz[r0 + 1] = gps_pose3[1] - e->mu[1];
             dz[r0 + 2] = yaw_innovation(gps_pose3[2] - e->mu[2]);
@@ -384,15 +526,23 @@ int oekf_handle_observation(oekf_t *e, double t, const float *obs, int K,
             for (int q = 0; q < 5; ++q)
                 if (cand[q] >= 0) {
                     hc[5 * r + hn[r]] = cand[q];
-                    hv[5 * r + hn[r]] = H[r + (size_t)cand[q] * m];
+                    hv[5 * r + hn[r]] = e->literal ? H[r + (size_t)cand[q] * m] : H[r + (size_t)q * ldh];
                     hn[r]++;
                 }
+        }
+#undef HSET
+        if (!e->literal && od_get_threads() > 1) {                   /* the all-core baseline: one persistent team per update */
+            const int rct = update_structured_team(e, m, hc, hv, hn, Qd, dz, od_get_threads());
+            free(H); free(z); free(zh); free(Qd); free(dz);
+            free(hc); free(hv); free(hn);
+            if (rct != 0) return rct;
+            goto update_done;
         }
         double *Ht = (double *)malloc(sizeof(double) * (size_t)N * m); /* N x m */
         double *PHt = (double *)malloc(sizeof(double) * (size_t)N * m);
         double *S = (double *)malloc(sizeof(double) * (size_t)m * m);
         double *Kt = (double *)malloc(sizeof(double) * (size_t)N * m);
-        od_transpose(m, N, H, m, Ht, N);
+        if (e->literal) od_transpose(m, N, H, m, Ht, N);
         const int passes = e->literal ? 2 : 1; /* lazy 'auto K_t' evaluated at :306 and :308 */
         for (int pass = 0; pass < passes; ++pass) {
             if (e->literal) {
@@ -400,7 +550,6 @@ int oekf_handle_observation(oekf_t *e, double t, const float *obs, int K,
                 od_gemm(m, m, N, H, m, PHt, N, S, m);                 /* H * (sigma H^T) */
             } else {
                 /* column gather: (P H^T)(r, j) = sum over the <=5 nonzeros of H row j */
-#pragma omp parallel for schedule(static) num_threads(od_get_threads()) if (od_get_threads() > 1)
                 for (int j = 0; j < m; ++j) {
                     double *w = PHt + (size_t)j * N;
                     memset(w, 0, sizeof(double) * (size_t)N);
@@ -445,7 +594,6 @@ int oekf_handle_observation(oekf_t *e, double t, const float *obs, int K,
         } else {
             /* HP from rows of P, then P -= K * HP */
             double *HP = (double *)malloc(sizeof(double) * (size_t)m * N);
-#pragma omp parallel for schedule(static) num_threads(od_get_threads()) if (od_get_threads() > 1)
             for (int cidx = 0; cidx < N; ++cidx) {
                 const double *pc = e->P + (size_t)cidx * N;
                 for (int i = 0; i < m; ++i) {
@@ -462,6 +610,7 @@ int oekf_handle_observation(oekf_t *e, double t, const float *obs, int K,
         free(hc); free(hv); free(hn);
         free(Ht); free(PHt); free(S); free(Kt);
     }
+update_done:;
 
     const int N2 = e->n_new;                                          /* :311 */
     if (N2 > 0) {
