@@ -19,23 +19,17 @@ all-gather of a 64-byte result record per rank (reflector_ekf_slam_amd/dist.py).
 Rank 0 prints ONE JSON line.
 
 Extra objects on that line (rank 0, N = 1 unless noted):
-  roofline       the P -= K (H P) kernel (k_downdate2; inside the chain it goes out with the
-                 NEXT scan as k_dd_front, the same body plus that scan's front end in 32
-                 further workgroups).  `frac` / `achieved` / `mfma.frac` are the IN-CHAIN figures: the
-                 kernel's average time inside the update chain, measured in this run as the hipEvent
-                 bracket around each launch minus the empty bracket (behind k_mid, its panels fresh);
-                 `frac_back_to_back` is the same kernel re-launched back to back between one event pair
-                 (L2-warm panels: a state the filter is never in -- round 3 quoted that one as `frac`).  P is stored as its LOWER TRIANGLE, so ("scale both FLOP and BYTES by the
-                 executed tile fraction") `achieved` / `frac` count the bytes that algorithm
-                 must move -- the triangle read and written, the two panels -- and
-                 `mfma.frac` the MFMA FLOP actually executed; the full-square SURVEY figure
-                 (16 n^2 + 8 n (3+m)) is kept as `frac_fullsquare`, the PMC-measured bytes as
-                 `frac_moved`.  `traffic` is NOT measured in this run: it is read from the
-                 committed rocprofv3 PMC summary and labelled with its source file.
-  not_full       the same steady state on a filter created with max_landmarks = 2 L (the
-                 state a deployed node is in: capacity is a cap, not the map size):
-                 every scan may append reflectors (the last downdate workgroup of k_dd_front
-                 sees to it), n is not known to the host while it runs ahead of the device.
+  roofline       the update's ONE launch, k_mid<4, 0>: the scan's mid role (a latency chain), the previous scan's downdate P -= K (H P) as a
+                 role beside it (the HBM / MFMA work) and the next scan's speculative front end.  `frac` / `achieved` / `mfma.frac` are over
+                 the launch's average duration measured in this run (the update period of an un-instrumented window); P is stored as its LOWER
+                 TRIANGLE, so ("scale both FLOP and BYTES by the executed tile fraction") they count the bytes that algorithm
+                 must move -- the triangle read and written, the two panels -- and the MFMA FLOP actually executed; the full-square SURVEY
+                 figure (16 n^2 + 8 n (3+m)) is kept as `frac_fullsquare`, the PMC-measured bytes as `frac_moved`.  `bound` says what
+                 really binds the launch (the latency chain); `traffic` and `mfma.counter_busy_cycles` are NOT measured in this run: they are
+                 read from the committed rocprofv3 PMC summaries (profiles/MANIFEST.json names the commit and the sources they describe).
+  not_full       the same steady state on a filter created with a FIXED capacity of 2 L (auto_grow off): like the headline's wrapper-default
+                 filter it can still grow, so the host learns each scan's n from that scan's k_mid (rekf.h, PENDING WORK) and runs the same
+                 one-launch form.  `fixed_capacity` = max_landmarks = L, auto_grow off: the configuration rounds 1-5 measured the headline on.
   latency_us     median / p99 of one update: hipEvent pair around each whole chain
                  (device) and host wall time of HandleObservationMessage + GetPose.
   with_5_predicts_per_scan   the same scans with five HandleOdometryMessage
@@ -424,7 +418,6 @@ def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world, cha
             dd_role_us = (cnt[27] - cnt[26]) * 0.01
     except Exception:
         pass
-    dd_us = ekf.time_kernel("downdate", reps=max(args.steps, 200))
 
     bytes_full = 16.0 * n * n + 8.0 * n * (3 + m)         # SURVEY.md 8(d) BYTES_alg(n, m): every element of P read and written once
     # what the EXECUTED algorithm must move (SURVEY 8(d) for a lower-triangular builder): P is STORED as its lower triangle
@@ -434,7 +427,7 @@ def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world, cha
     tiles_exec = T * (T + 1) // 2
     flop_exec = tiles_exec * 2.0 * 64 * 64 * 64            # MFMA FLOP the downdate role issues (16x16x4 tiles, KC = 64)
     flop_k7 = 2.0 * n * n * m                              # the reference's full-square count
-    t_frac = chain_us if chain_us else dd_us
+    t_frac = chain_us
     achieved = bytes_exec / (t_frac * 1e-6) / 1e9
     rocprof_us, traffic, traffic_src, rocprof_src = None, None, None, None
     try:
@@ -462,38 +455,38 @@ def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world, cha
         "kernel": "k_mid<4, 0>: ONE launch per update -- the scan's mid role (gather, 64 x 64 inverse, gain: the latency chain that sets the "
                   "launch's length), the PREVIOUS scan's downdate P -= K (H P) as a role on the CUs beside it (FP64 MFMA 16x16x4 tiles of the "
                   "stored lower triangle, panels by LDS DMA, one P buffer read, the other written) and the NEXT scan's speculative front end",
-        "bound": "hbm",
+        "bound": "latency (the mid role's dependent chain: match record -> sub-block gather -> S -> 64 x 64 inverse -> gain; the HBM work -- the "
+                 "downdate role -- hides under it)",
+        "bound_hbm_or_mfma": "hbm",
         "bytes_note": "achieved / frac = bytes the executed lower-triangle algorithm must move per launch: 2 * 8 n(n+1)/2 (triangle read and written) "
                       "+ 8 n (3+m) panels, over the launch's average duration measured in this run (avg_launch_us: the update period of an "
-                      "un-instrumented window, one launch per update -- an upper bound of the kernel time).  The launch is NOT HBM-bound by "
-                      "design: the downdate has left the update's critical path and fills the CUs the latency chain leaves free; "
+                      "un-instrumented window, one launch per update -- an upper bound of the kernel time).  The launch is NOT HBM-bound: the "
+                      "downdate has left the update's critical path and fills the CUs the latency chain leaves free, so frac (of the 8 TB/s HBM peak) "
+                      "and mfma.frac (of the FP64 MFMA peak) say how far BOTH rooflines are from binding; north_star's '>= 30 % MFMA utilisation on the "
+                      "covariance GEMM' is NOT met in this launch (see mfma.frac / mfma.frac_by_counter).  "
                       "frac_downdate_role = the same bytes over the role's own span inside the launch (device time stamps); "
-                      "frac_back_to_back = over the stand-alone kernel k_downdate2<64> (same body, all CUs) re-launched back to back; "
                       "frac_fullsquare = SURVEY 8(d)'s 16 n^2 + 8 n (3+m) over avg_launch_us; frac_moved = HBM bytes by PMC counters (committed summary)",
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "frac_fullsquare": bytes_full / (t_frac * 1e-6) / 1e9 / HBM_PEAK_GBS,
         "frac_moved": (moved / HBM_PEAK_GBS) if moved else None,
         "downdate_role_us": dd_role_us,
         "frac_downdate_role": (bytes_exec / (dd_role_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if dd_role_us else None,
-        "frac_back_to_back": bytes_exec / (dd_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
         "frac_inchain_rocprof": (bytes_exec / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if rocprof_us else None,
         "traffic": traffic, "traffic_source": traffic_src,
         "bytes_per_launch": bytes_exec, "bytes_per_launch_fullsquare": bytes_full,
         "avg_launch_us": t_frac,
-        "avg_launch_us_method": ("measured in this run: the update period of an un-instrumented 500-update window on the handle's stream, ONE launch "
-                                 "(k_mid<4, 0>) per update, back to back -- launch + launch boundary, an upper bound of the kernel's duration"
-                                 if chain_us else "measured in this run: k_downdate2<64> back to back between one hipEvent pair"),
-        "avg_launch_us_back_to_back": dd_us,
+        "avg_launch_us_method": "measured in this run: the update period of an un-instrumented 500-update window on the handle's stream, ONE launch "
+                                "(k_mid<4, 0>) per update, back to back -- launch + launch boundary, an upper bound of the kernel's duration",
         "rocprof_avg_launch_us": rocprof_us, "rocprof_source": rocprof_src,
         "mfma": {"achieved_tflops": flop_exec / (t_frac * 1e-6) / 1e12, "peak_tflops": FP64_MFMA_PEAK_TF,
                  "frac": flop_exec / (t_frac * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF,
                  "frac_downdate_role": (flop_exec / (dd_role_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF) if dd_role_us else None,
                  "frac_fullsquare_flop": flop_k7 / (t_frac * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF,
-                 "frac_back_to_back": flop_exec / (dd_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TF,
                  "counter_busy_cycles": mfma_busy, "counter_source": mfma_src,
                  "frac_by_counter": (mfma_busy / (1024.0 * t_frac * 1e-6 * 2.4e9)) if mfma_busy else None,
                  "note": f"frac = the downdate role's EXECUTED MFMA FLOP ({tiles_exec} lower-triangle tiles x 2*64*64*64) over avg_launch_us (the mid "
                          "role's MFMAs -- correction, inverse, gain -- are not counted); frac_downdate_role over the role's own span; "
+                         "north_star's 30 % target is not met in the shipped launch (the downdate is sized to hide under the latency chain, not to saturate the MFMA pipes); "
                          "frac_fullsquare_flop = the reference's 2 n^2 m over avg_launch_us; frac_by_counter = SQ_VALU_MFMA_BUSY_CYCLES of the whole launch (both roles; "
                          "committed counter pass) over 1024 SIMDs x avg_launch_us at 2.4 GHz"}}
     out["kernel_us"] = kernel_us

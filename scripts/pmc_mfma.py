@@ -10,3 +10,14 @@ for k, c, v in rows:
 for (k, c), vs in sorted(by.items()):
     vs = vs[-last:]
     print(json.dumps({"kernel": k, "counter": c, "dispatches": len(vs), "median": statistics.median(vs), "mean": sum(vs) / len(vs)}))
+
+if "--json" in sys.argv:
+    path = sys.argv[sys.argv.index("--json") + 1]
+    commit = sys.argv[sys.argv.index("--commit") + 1] if "--commit" in sys.argv else None
+    tag = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else "x"
+    vs = by.get(("void k_mid<4, 0>", "SQ_VALU_MFMA_BUSY_CYCLES"), [])[-last:]
+    if vs:
+        json.dump({"kernel": "void k_mid<4, 0>", "sq_valu_mfma_busy_cycles_median": statistics.median(vs), "simds": 1024, "clock_ghz": 2.4,
+                   "_commit": commit,
+                   "note": f"rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES over bench.py --timed-only, last {last} dispatches (profiles/{tag}_pmc_mfma.txt); "
+                           "utilisation = busy / (simds x launch cycles)"}, open(path, "w"), indent=1)

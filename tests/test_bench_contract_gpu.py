@@ -32,19 +32,19 @@ def _check_contract(d, steps, warmup):
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "avg_launch_us_method"):
         assert k in r
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.05 < r["frac"] < 1.0
+    # (round 6: the launch is bound by the mid role's latency chain and says so; of the two rooflines the HBM one is the nearer)
+    assert r["bound"].startswith("latency") and r["bound_hbm_or_mfma"] == "hbm" and "NOT met" in r["bytes_note"] and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.05 < r["frac"] < 1.0
     assert r["traffic"] is None or "NOT measured in this run" in r["traffic_source"]
     # honest accounting: frac counts what the lower-triangle algorithm must move; the full-square figure rides along
     assert r["frac_fullsquare"] > 1.5 * r["frac"] and r["bytes_per_launch"] < 0.55 * r["bytes_per_launch_fullsquare"]   # triangle read + written
     # `frac` is measured in this run over the ONE launch an update is (its period in an un-instrumented window); the downdate role's own span
     # inside that launch (device time stamps) and the stand-alone kernel back to back ride along
     assert "ONE launch" in r["avg_launch_us_method"] and "500-update window" in r["avg_launch_us_method"] and r["avg_launch_us"] > 1.0
-    assert 0.05 < r["frac_back_to_back"] < 1.0 and r["frac"] <= r["frac_back_to_back"] * 1.25
+    assert "frac_back_to_back" not in r and "frac_back_to_back" not in r["mfma"]      # (the stand-alone, Infinity-Cache-resident re-launch figure is gone from the line)
     assert abs(r["frac"] - r["bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9 / r["peak"]) < 1e-9
     assert r["downdate_role_us"] is not None and 2.0 < r["downdate_role_us"] < r["avg_launch_us"] * 1.2
     assert r["frac"] <= r["frac_downdate_role"] * 1.2 < 1.2
     assert r["frac_moved"] is None or 0.05 < r["frac_moved"] < 1.0
-    assert r["mfma"]["frac"] <= r["mfma"]["frac_back_to_back"] * 1.25
     # every rank's record carries its parity figure (here: the one rank), taken after the timed region
     pe = d["ranks"]["max_abs_err_vs_oracle"]
     assert len(pe) == 1 and pe[0] is not None and pe[0] < 1e-9, pe
@@ -73,6 +73,8 @@ def test_driver_command_steps20_warmup5_has_every_object():
     ex = lat["exclusive_handle"]
     assert 5.0 < ex["host_sync_median"] < 5000.0 and 5.0 < ex["host_sync_idle_device_median"] < 5000.0
     assert c["structured_all_cores"] >= 1 and c["structured_all_cores_value"] > 1.0
+    assert "fixed_capacity" in d and "error" not in d["fixed_capacity"] and d["fixed_capacity"]["value"] > 5000
+    assert d["config"]["max_landmarks"] >= 1024 and nf["value"] > 0.8 * d["fixed_capacity"]["value"]     # (a growing filter takes the one-launch form, too)
     assert 0.05 < d["kernel_us"]["odometry_message_plus_get_pose_host_us"] < 50.0     # no launch: host pose mirror
     nf = d["not_full"]
     assert "error" not in nf, nf

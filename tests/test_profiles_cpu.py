@@ -1,6 +1,7 @@
-"""The committed profile summaries bench.py reads (profiles/kernel_avg_us.json, pmc_downdate.json, pmc_mfma.json) must describe the
-tree that is built: every kernel they name is a symbol of librekf.so, and the commit they were measured on is an ancestor of HEAD with at
-most a few later commits touching csrc/ (round 4's summaries named kernels the shipped library no longer had)."""
+"""The committed profile summaries the bench line and the docs cite must describe the tree that is built.  profiles/MANIFEST.json lists,
+per summary, the commit it was measured on and the SOURCES whose kernels it describes; a summary is stale -- and this suite red -- as
+soon as ANY later commit touched one of those sources (round 5's guard tolerated 12 later csrc commits and did not look at the detector
+summaries at all).  Every kernel the EKF summaries name must also be a symbol of the built librekf.so."""
 import json
 import os
 import re
@@ -9,20 +10,35 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-MAX_LATER_CSRC_COMMITS = 12
+MANIFEST = os.path.join(ROOT, "profiles", "MANIFEST.json")
 
 
-def _symbols():
-    out = subprocess.run(["nm", "-D", "-C", os.path.join(ROOT, "reflector_ekf_slam_amd", "librekf.so")], capture_output=True, text=True, check=True).stdout
-    return out
+def _symbols(lib):
+    return subprocess.run(["nm", "-D", "-C", os.path.join(ROOT, "reflector_ekf_slam_amd", lib)], capture_output=True, text=True, check=True).stdout
 
 
 def _norm(name):
     return re.sub(r"\s+", "", name.replace("void ", ""))
 
 
+def test_manifest_covers_what_the_bench_line_reads():
+    man = json.load(open(MANIFEST))["summaries"]
+    for f in ("kernel_avg_us.json", "pmc_downdate.json", "pmc_mfma.json"):
+        assert f in man, f"{f} is read by bench.py but profiles/MANIFEST.json does not list it"
+    assert any("det3d.hip" in " ".join(e["sources"]) for e in man.values()), "no detector summary in the manifest"
+    for f, e in man.items():
+        assert os.path.exists(os.path.join(ROOT, "profiles", f)), f"{f} is in the manifest but not in profiles/"
+        assert e.get("commit") and e.get("sources"), f
+        for src in e["sources"]:
+            assert os.path.exists(os.path.join(ROOT, src)), (f, src)
+        j = os.path.join(ROOT, "profiles", f)
+        if f.endswith(".json"):
+            c = json.load(open(j)).get("_commit")
+            assert c is None or c == e["commit"], f"{f} says it was measured on {c}, the manifest on {e['commit']}"
+
+
 def test_every_profiled_kernel_is_in_the_built_library():
-    syms = re.sub(r"\s+", "", _symbols())
+    syms = re.sub(r"\s+", "", _symbols("librekf.so"))
     avg = json.load(open(os.path.join(ROOT, "profiles", "kernel_avg_us.json")))
     ours = [k for k in avg if not k.startswith("_") and not k.startswith("__amd")]
     assert any("k_mid<4,0>" in _norm(k) for k in ours)
@@ -33,12 +49,17 @@ def test_every_profiled_kernel_is_in_the_built_library():
         assert _norm(j["kernel"].split("(")[0]) in syms, (f, j["kernel"])
 
 
-def test_the_profiles_were_taken_close_to_head():
+def test_no_summary_is_older_than_the_sources_it_describes():
     if not os.path.isdir(os.path.join(ROOT, ".git")):
         pytest.skip("no git history here (a GPU box snapshot)")
-    for f in ("kernel_avg_us.json", "pmc_downdate.json", "pmc_mfma.json"):
-        c = json.load(open(os.path.join(ROOT, "profiles", f))).get("_commit")
-        assert c, f"{f} does not say which commit it was measured on"
+    man = json.load(open(MANIFEST))["summaries"]
+    stale = []
+    for f, e in man.items():
+        c = e["commit"]
         assert subprocess.run(["git", "merge-base", "--is-ancestor", c, "HEAD"], cwd=ROOT).returncode == 0, (f, c)
-        later = subprocess.run(["git", "rev-list", "--count", f"{c}..HEAD", "--", "reflector_ekf_slam_amd/csrc"], cwd=ROOT, capture_output=True, text=True, check=True).stdout
-        assert int(later) <= MAX_LATER_CSRC_COMMITS, f"{f} is {later.strip()} csrc commits behind HEAD: re-run scripts/gpu_profile_round.sh"
+        later = subprocess.run(["git", "rev-list", f"{c}..HEAD", "--", *e["sources"]], cwd=ROOT, capture_output=True, text=True, check=True).stdout.split()
+        # (the working tree counts, too: an uncommitted edit of a described source makes the summary stale)
+        dirty = subprocess.run(["git", "status", "--porcelain", "--", *e["sources"]], cwd=ROOT, capture_output=True, text=True, check=True).stdout.strip()
+        if later or dirty:
+            stale.append((f, c, later[:3], dirty[:80]))
+    assert not stale, f"stale profile summaries (re-run scripts/gpu_profile_round.sh and scripts/profiles_commit.py): {stale}"
