@@ -57,6 +57,14 @@ int rekf_debug_counters(rekf_t *h, long long out32[32]);
  * applied at all (hand it over again), after stage 3 it was. */
 int rekf_debug_inject_failure(rekf_t *h, int stage);
 
+/* The match grid (csrc/ekf_dev.h, RekfCtl::grid_state: k_mid matches a host-predicted scan itself from the few landmarks in the 3 x 3 grid
+ * cells around each observation).  on = 0: off (the scan's front end is a launch of its own again: the twin the parity tests compare with);
+ * drift_limit > 0: replaces the 0.3 m bound on how far a landmark may stand from its binning position (tiny values force rebuilds and the
+ * full-sweep fall-back); mask >= 0 (2^k - 1): a table of mask + 1 buckets (overflow: the library stops using the grid by itself).
+ * rekf_debug_counters: out32[18] = scans k_mid matched itself, out32[19] = of those, by the full sweep (grid invalid at that moment),
+ * out32[17] = k_grid_build launches so far, out32[16] = the grid is still in use (1) or was given up / switched off (0). */
+int rekf_debug_set_grid(rekf_t *h, int on, double drift_limit, int mask);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,5 +83,7 @@ def rekf():
     L.rekf_debug_time_kernel.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
     if hasattr(L, "rekf_debug_inject_failure"):           # (absent from older builds that scripts/gpu_ab.py compares against)
         L.rekf_debug_inject_failure.argtypes = [vp, C.c_int]
+    if hasattr(L, "rekf_debug_set_grid"):
+        L.rekf_debug_set_grid.argtypes = [vp, C.c_int, C.c_double, C.c_int]
     _rekf = L
     return L

@@ -97,8 +97,19 @@ struct RekfCtl {
     unsigned cp_scan[2];              // ... and the scan (RekfFrontArgs::scan_id) that wrote it
     unsigned dd_queue[2];             // the downdate role INSIDE k_mid's grid takes its tiles from a queue: next work item, by launch parity (the
                                       // mid role's workgroup 0 zeroes the other parity's counter for the next launch)
+    // MATCH GRID (round 6): a hash grid over the landmarks' float32 means -- 1 m cells, buckets of {count, 7 x (landmark id, its CURRENT float32
+    // mean)}, RekfDev::grid_bucket (layout: rekf_grid_* below); RekfDev::grid_p0 = where each landmark stood when it was binned, and its entry.
+    // The entries' means are kept current by whoever updates the mean (k_mid phase F, double-buffered by RekfDev::grid_par like the mean itself).  ReflectorMatch's state branch accepts a landmark only inside 0.6 m
+    // (cc:446), and such a landmark -- as long as it has drifted less than REKF_GRID_DRIFT from its binning position -- sits in one of the
+    // 3 x 3 cells around the observation's global point: k_mid can match a host-predicted scan ITSELF, exactly, from ~10 candidates per
+    // observation instead of all L (no front-end launch).  grid_state: 1 = built and every landmark within the drift bound; 0 = not
+    // (k_mid then matches by the full sweep, slowly, and the host rebuilds: k_grid_build).
+    int grid_state;
+    int grid_overflow;            // a bucket ran over: the table is too small for this world (the host stops using the grid)
     long long dbg[32];            // scratch for in-kernel timing experiments (REKF_DEBUG_TIMING builds)
 };
+#define REKF_GRID_SLOTS 7
+#define REKF_GRID_DRIFT 0.3f
 
 // By-value kernel argument of the front kernel: one scan's worth of host input.
 struct RekfFrontArgs {
@@ -149,6 +160,7 @@ struct RekfFrontArgs {
     unsigned scan_id;         // running number of the scan (RekfCtl::aug_done)
     int apply_pred;           // k_mid: apply the pending Predict to the gathered P (whole scan or FIRST block step of a wide scan)
     int host_pred;
+    int grid_match;           // k_mid (a host-predicted whole scan): no front end has run -- every workgroup matches the scan itself through the match grid (RekfCtl::grid_state)
     double pre_pose[5];       // x, y, theta (wrapped, cc:181/:205), cos(theta), sin(theta) of the WRAPPED heading as the reference takes them (cc:252-253)
     double pre_ab[2];
     double pre_C9[9];         // column-major 3 x 3
@@ -196,6 +208,13 @@ struct RekfDev {
     RekfHostSlot *early;  // k_mid (whole scans on a filter that can still grow): workgroup 0 publishes the n the state has behind this scan -- n + 2 (new
     int early_seq;        // reflectors) -- under this tag AS SOON AS the scan's match record is final (rekf_api.hip, struct rekf: EARLY n)
     int pad_;
+    int *grid_bucket;     // the match grid (RekfCtl::grid_state), one allocation: cnt[GH] | id[7 GH] | xy[2 parities][7 GH][2] (GH = grid_mask + 1), or null
+    float *grid_p0;       // ... and per landmark: its binning position p0[Lcap][2] | its entry slot[Lcap] (bucket * 7 + slot, -1: none); Lcap = (n_max - 3) / 2 + 8
+    RekfHostSlot *grid_note;  // where a kernel that invalidates the grid tells the host (tag = the scan's id, v = 1 drift / 2 overflow)
+    int grid_mask;
+    float grid_drift;     // how far a landmark may stand from its binning position before the grid is invalid (REKF_GRID_DRIFT; tests lower it)
+    int grid_par;         // which half of xy holds the means a launch STARTS from (it writes the updated ones into the other half; the host flips it with mu / mu_out)
+    int pad3_;
     double map_lip;       // pre-loaded map: sqrt of the largest eigenvalue over its covariances -- sqrt(e^T S e) moves by at most map_lip |de| when the
                           // observation's global point moves by de (the speculative match's margin proof, k_mid); < 0: some covariance is not
                           // symmetric positive semi-definite, no bound (scans are then not speculated for)
@@ -302,6 +321,18 @@ __host__ __device__ static inline double rekf_plower(const double *P, int ld, in
     return (i >= j) ? P[(size_t)i + (size_t)j * (size_t)ld] : P[(size_t)j + (size_t)i * (size_t)ld];
 }
 
+// bucket of the 1 m cell (cx, cy) of the match grid
+__host__ __device__ static inline int rekf_grid_hash(int cx, int cy, int mask)
+{
+    return (int)(((unsigned)cx * 73856093u) ^ ((unsigned)cy * 19349663u)) & mask;
+}
+
+__host__ __device__ static inline int *rekf_grid_cnt(const RekfDev &d) { return d.grid_bucket; }
+__host__ __device__ static inline int *rekf_grid_id(const RekfDev &d) { return d.grid_bucket + (d.grid_mask + 1); }
+__host__ __device__ static inline float *rekf_grid_xy(const RekfDev &d, int par) { return (float *)(d.grid_bucket + 8 * (size_t)(d.grid_mask + 1)) + (size_t)(par & 1) * 14 * (size_t)(d.grid_mask + 1); }
+__host__ __device__ static inline int *rekf_grid_slot(const RekfDev &d) { return (int *)(d.grid_p0 + 2 * (size_t)((d.n_max - 3) / 2 + 8)); }
+#define REKF_GRID_INTS_PER_BUCKET 36          // 1 + 7 + 2 * 14
+
 // launch wrappers (ekf_kernels.hip)
 void rekf_launch_apply_predict(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);
 void rekf_launch_front_mb(const RekfDev &d, const RekfFrontArgs &a, int n_ub, hipStream_t s);
@@ -313,5 +344,6 @@ bool rekf_scan_launch_fits(int n_ub, int K_front);   // the one-launch form leav
 int rekf_launch_scan(const RekfDev &dd, const RekfDev &d, RekfFrontArgs &a, int n_ub, int m_ub, int front_wgs, const RekfFrontArgs *an, hipStream_t s);   // ONE launch per scan: [front end |] mid role (corrects what it gathers by dd's pending panels) | dd's downdate from dd.P into dd.P_out
 void rekf_launch_augment(const RekfDev &d, const RekfFrontArgs &a, hipStream_t s);
 void rekf_launch_ellipses(const RekfDev &d, double *out5, int cap, hipStream_t s);
+void rekf_launch_grid_build(const RekfDev &d, int n, int note_tag, hipStream_t s);
 void rekf_launch_publish_pose(const RekfDev &d, RekfHostSlot *hout, int seq, hipStream_t s);
 void rekf_launch_predict_rows(const RekfDev &d, const RekfFrontArgs &a, double *out, hipStream_t s);

@@ -143,6 +143,49 @@ __device__ static inline void store_wt2(double *p, rekf_v2d v)
 {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
+// ----------------------------------------------------------------------------
+// MATCH GRID (ekf_dev.h, RekfCtl::grid_state): binning of one landmark, the rebuild kernel.
+// ----------------------------------------------------------------------------
+__device__ static inline void grid_insert(const RekfDev &d, RekfCtl *ctl, int j, float fx, float fy)
+{
+    const int h = rekf_grid_hash((int)floorf(fx), (int)floorf(fy), d.grid_mask);
+    const int slot = atomicAdd(&rekf_grid_cnt(d)[h], 1);
+    int e = -1;
+    if (slot < REKF_GRID_SLOTS) {
+        e = REKF_GRID_SLOTS * h + slot;
+        rekf_grid_id(d)[e] = j;
+        float *x0 = rekf_grid_xy(d, 0), *x1 = rekf_grid_xy(d, 1);         // (both halves: whichever the next launch starts from)
+        x0[2 * e] = fx; x0[2 * e + 1] = fy; x1[2 * e] = fx; x1[2 * e + 1] = fy;
+    } else {
+        __hip_atomic_store(&ctl->grid_overflow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ctl->grid_state, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    rekf_grid_slot(d)[j] = e;
+    d.grid_p0[2 * j] = fx; d.grid_p0[2 * j + 1] = fy;
+}
+// One workgroup: empty the table, bin every landmark of the current mean where it stands now.  The host launches it (in stream order, in
+// front of the scan that wants the grid) after rekf_create / rekf_set_state / rekf_reserve and when a kernel has reported drift.
+__global__ __launch_bounds__(1024) void k_grid_build(RekfDev d, int n, int note_tag)
+{
+    RekfCtl *ctl = d.ctl;
+    const int tid = threadIdx.x;
+    const int nb = d.grid_mask + 1;
+    if (tid == 0) { ctl->grid_overflow = 0; ctl->grid_state = 1; }
+    for (int e = tid; e < nb; e += 1024) rekf_grid_cnt(d)[e] = 0;
+    __threadfence_block();
+    __syncthreads();
+    const int L = (n - 3) / 2;
+    for (int j = tid; j < L; j += 1024) grid_insert(d, ctl, j, (float)d.mu[3 + 2 * j], (float)d.mu[4 + 2 * j]);
+    __threadfence_block();
+    __syncthreads();
+    // (a table too small for this world: tell the host, which stops asking for the grid)
+    if (tid == 0 && d.grid_note && __hip_atomic_load(&ctl->grid_overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) host_slot_store(d.grid_note, 2.0, note_tag, 0);
+}
+void rekf_launch_grid_build(const RekfDev &d, int n, int note_tag, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(1024), 0, s, d, n, note_tag);
+}
+
 __global__ __launch_bounds__(1024) void k_apply_predict(RekfDev d, RekfFrontArgs A)
 {
 #pragma clang fp contract(off)
@@ -1068,7 +1111,8 @@ constexpr int REKF_DD_LDS_BYTES = 4 * 64 * 64 * (int)sizeof(double);      // the
 // MODE picks what else the launch hosts (separate instantiations: the steady state of a full filter, MODE 0, carries none of it):
 //   0  nothing;  1  a filter that can still grow: workgroup 0 leaves the scan's augmentation record (RekfCtl::augrec) and, with
 //   A.aug_in_mid, first appends the PREVIOUS scan's new reflectors;  2  the scan's front end runs as the first A.front_in_mid
-//   workgroups of this grid; also leaves the augmentation record.
+//   workgroups of this grid; also leaves the augmentation record;  3  like 0, and every workgroup may match the scan itself through the
+//   match grid (A.grid_match; MODE 1 can, too).
 // ONE LAUNCH PER SCAN (round 5, MODE 0 and 2): with A.dd_in_mid the workgroups from A.dd_first on are the PREVIOUS scan's downdate
 // (dd_body<64> on four of their eight waves, tiles from a queue, from dp.P into dp.P_out); the mid role reads dp.P = d.P and takes
 // the pending correction from dp's panels (A.corr); nobody waits for anybody inside the launch except the mid role for an in-grid
@@ -1097,7 +1141,9 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, int h0, int h1,
     const RekfDev &dp = *(const RekfDev *)(kargs + KOFF + sizeof(RekfDev) + sizeof(RekfFrontArgs));
     const RekfFrontArgs &An = *(const RekfFrontArgs *)(kargs + KOFF + 2 * sizeof(RekfDev) + sizeof(RekfFrontArgs));
     (void)d_arg; (void)A_arg; (void)dp_arg; (void)An_arg;
-    constexpr bool FRONT = (MODE & 2) != 0, AUGR = (MODE & 1) != 0, AUGW = MODE >= 1, DDROLE = MODE != 1;
+    // (MODE 3 = MODE 0 + the in-kernel grid match: an instantiation of its own, so that the steady-state kernel of the speculation pipeline
+    // -- which never matches anything itself -- keeps its register budget)
+    constexpr bool FRONT = MODE == 2, AUGR = MODE == 1, AUGW = MODE == 1 || MODE == 2, DDROLE = MODE != 1, GM = MODE == 1 || MODE == 3;
     // ctl_first = d.ctl, as a leading pointer argument of its own: built with -mllvm -amdgpu-kernarg-preload-count the wave starts with it
     // in SGPRs, and the kernel's first loads (the match results) do not wait for the kernel-argument fetch
     using LT = MidLds<NBR>;
@@ -1210,14 +1256,125 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, int h0, int h1,
     // scalar one, so the control block costs one memory round trip, not two
     constexpr int NREC = (int)(sizeof(RekfCtl::Rec) / sizeof(int));
     static_assert(NREC <= 512, "one load per thread");
-    const bool cim = !FRONT && A.compact_in_mid != 0 && A.pair0 < 0;            // the front end's raw results instead (RekfFrontArgs::compact_in_mid)
-    const int rec_raw = (!FRONT && !cim && tid < NREC) ? ((const int *)&ctl->rec[hd_pred_slot])[tid] : 0;
-    const int cim_kind = (cim && tid < A.K && tid < 32) ? ctl->obs_kind[tid] : -1, cim_idx = (cim && tid < A.K && tid < 32) ? ctl->obs_idx[tid] : -1;
-    // ... and the pending scan's WRITE-AHEAD CORRECTION (RekfCtl::cp_*, RekfDev::cp; phase G below): which landmarks it covers
+    // MATCH GRID (RekfCtl::grid_state): no front end has run for this (host-predicted, whole) scan -- every workgroup matches it itself,
+    // exactly: an observation can only match a landmark inside 0.6 m (cc:446), and every such landmark is in one of the 3 x 3 grid cells
+    // around the observation's global point; the literal distances (cc:431-437) of those few candidates, first minimum in index order.
+    // Wave w takes the observations w, w + 8, ...: all their bucket loads, then all their mean loads in flight together.
+    const bool gm = GM && A.grid_match != 0 && A.pair0 < 0;
+    // (what the phases behind the match need of the control block goes in flight FIRST: these loads then fly under the grid match instead of
+    // costing a round trip of their own behind its barrier)
     int cp_uid_l = -1, cp_nu_l = -1;
     unsigned cp_scan_l = 0u;
     if (DDROLE && hd_corr && lane < 32) cp_uid_l = ctl->cp_uid[hd_corr_post][lane];
     if (DDROLE && hd_corr) { cp_nu_l = ctl->cp_nu[hd_corr_post]; cp_scan_l = ctl->cp_scan[hd_corr_post]; }
+    double cpred_early = 0.0;                        // (s_cpred's source: the pending scan's (a, b) and its pose block after the update)
+    if (DDROLE && hd_corr != 0 && tid >= 128 && tid < 128 + 11) {
+        const int e = tid - 128;
+        cpred_early = (e < 2) ? (hd_cpred != 0 ? ctl->pred[hd_corr_pred_ix].ab[e] : 0.0) : ctl->post_C9[hd_corr_post][e - 2];
+    }
+    if (GM && gm) {
+#pragma clang fp contract(off)
+#ifdef REKF_DEBUG_GRID
+        MMARK();                                    // (g0: the grid match begins)
+#endif
+        const int nG = d.n_known, LG = (nG - 3) / 2;
+        const double *muG = d.mu;
+        const int grid_state_now = ctl->grid_state;                       // (in flight beside the bucket loads: looked at behind them)
+        {
+            constexpr int GQ = 4;                                         // K <= 32 observations over 8 waves
+            // lane = (cell of the 3 x 3, slot of its bucket): count, landmark id and the landmark's current float32 mean (cc:431) in ONE
+            // round trip -- all of this wave's observations' loads in flight together
+            const int *gcnt = rekf_grid_cnt(d), *gid = rekf_grid_id(d);
+            const float *gxy = rekf_grid_xy(d, d.grid_par);
+            int cnt[GQ], cand[GQ];
+            float ggx[GQ], ggy[GQ], flx[GQ], fly[GQ];
+            const int nbk = lane / REKF_GRID_SLOTS, sl = lane - REKF_GRID_SLOTS * nbk;
+            const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // (uniform on purpose: the observations then come by SCALAR loads out of the launch packet)
+#pragma unroll
+            for (int q = 0; q < GQ; ++q) {
+                const int i = wave_u + 8 * q;
+                cnt[q] = 0; cand[q] = -1; ggx[q] = 0.f; ggy[q] = 0.f; flx[q] = 0.f; fly[q] = 0.f;
+                if (i < A.K) {
+                    float gx0, gy0;
+                    // (a grid-matched scan travels in the launch packet: A.obs directly -- one scalar round trip, not obs_ext's and then the data's)
+                    obs_to_global(A.pre_pose[0], A.pre_pose[1], A.pre_pose[3], A.pre_pose[4], A.obs[2 * i], A.obs[2 * i + 1], gx0, gy0);
+                    ggx[q] = gx0; ggy[q] = gy0;
+                    if (lane < 9 * REKF_GRID_SLOTS) {
+                        const int cx = (int)floorf(gx0) + (nbk % 3) - 1, cy = (int)floorf(gy0) + (nbk / 3) - 1;
+                        const int hb = rekf_grid_hash(cx, cy, d.grid_mask), e = REKF_GRID_SLOTS * hb + sl;
+                        cnt[q] = gcnt[hb]; cand[q] = gid[e];
+                        const float2 xy = *(const float2 *)(gxy + 2 * (size_t)e);
+                        flx[q] = xy.x; fly[q] = xy.y;
+                    }
+                }
+            }
+#ifdef REKF_DEBUG_GRID
+            MMARK();                                // (g1: bucket loads issued)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            MMARK();                                // (g2: ... arrived)
+#endif
+#pragma unroll
+            for (int q = 0; q < GQ; ++q) {
+                const int i = wave_u + 8 * q;
+                if (i < A.K) {                                             // (wave-uniform)
+                    int kdm = 2, ixm = -1;
+                    if (d.M_map > 0) map_match_wave(d, lane, ggx[q], ggy[q], kdm, ixm);               // cc:401-425 come first
+                    const bool live = lane < 9 * REKF_GRID_SLOTS && sl < cnt[q] && cand[q] >= 0 && cand[q] < LG;
+                    const float ex = ggx[q] - flx[q], ey = ggy[q] - fly[q];                           // cc:433
+                    const double dx = (double)ex, dy = (double)ey;
+                    const double d2 = dx * dx + dy * dy;
+                    // cc:437-446 compare sqrt(d2) with 0.6 and take the first minimum in index order.  sqrt is monotone: away from the gate
+                    // d2 < 0.36 decides the same, and ONE candidate inside needs no distance at all -- the usual case (a ballot, no
+                    // reduction, no sqrt).  Only a candidate within rounding of the gate, or several inside, take the literal path.
+                    const bool near_gate = live && fabs(d2 - 0.36) < 1e-12;
+                    unsigned long long inside = __ballot(live && d2 < 0.36);
+                    int best_j2 = -1;
+                    if (__ballot(near_gate) != 0ull || __popcll(inside) > 1) {
+                        const double dist = live ? sqrt(d2) : 1e300;                                  // cc:437, literally
+                        inside = __ballot(live && dist < 0.6);
+                        double best = 1e300;
+                        while (inside) {
+                            const int l = __builtin_ctzll(inside);
+                            inside &= inside - 1ull;
+                            const long long db = __double_as_longlong(dist);
+                            const double dl = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(db >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)db, l));
+                            const int jl = __builtin_amdgcn_readlane(cand[q], l);
+                            if (best_j2 < 0 || dl < best || (dl == best && jl < best_j2)) { best = dl; best_j2 = jl; }
+                        }
+                    } else if (inside) best_j2 = __builtin_amdgcn_readlane(cand[q], __builtin_ctzll(inside));
+                    int kd = kdm, ix = ixm;
+                    if (kd == 2 && best_j2 >= 0) { kd = 1; ix = best_j2; }                            // cc:446
+                    if (lane == 0) { s_fk[i] = kd; s_fi[i] = ix; }
+                }
+            }
+        }
+#ifdef REKF_DEBUG_GRID
+        MMARK();                                    // (g3: this wave's observations matched)
+#endif
+        const bool grid_live = grid_state_now != 0;
+        if (bx == 0 && tid == 0) {                     // (grid-matched scans / of those, by the full sweep: fire-and-forget counters)
+            atomicAdd((unsigned long long *)&ctl->dbg[18], 1ull);
+            if (!grid_live) atomicAdd((unsigned long long *)&ctl->dbg[19], 1ull);
+        }
+        if (!grid_live) {
+            // the grid is not usable (a landmark has drifted too far from where it was binned, or a bucket ran over: the host rebuilds it or
+            // gives it up): the exact match by the full sweep, one observation at a time by the whole workgroup -- slow, rare, the same result
+            __syncthreads();
+            for (int i = 0; i < A.K && i < 32; ++i) {
+                float gx, gy;
+                obs_to_global(A.pre_pose[0], A.pre_pose[1], A.pre_pose[3], A.pre_pose[4], rekf_obs(A, 2 * i), rekf_obs(A, 2 * i + 1), gx, gy);
+                int kd, bj;
+                rematch_obs(d, muG, LG, gx, gy, kd, bj);
+                if (tid == 0) { s_fk[i] = kd; s_fi[i] = bj; }
+            }
+        }
+        __syncthreads();
+    }
+    const bool cim = gm || (!FRONT && A.compact_in_mid != 0 && A.pair0 < 0);      // the front end's raw results instead (RekfFrontArgs::compact_in_mid)
+    const int rec_raw = (!FRONT && !cim && tid < NREC) ? ((const int *)&ctl->rec[hd_pred_slot])[tid] : 0;
+    const int cim_kind = (cim && tid < A.K && tid < 32) ? (gm ? s_fk[tid] : ctl->obs_kind[tid]) : -1,
+              cim_idx = (cim && tid < A.K && tid < 32) ? (gm ? s_fi[tid] : ctl->obs_idx[tid]) : -1;
+    // ... and the pending scan's WRITE-AHEAD CORRECTION (RekfCtl::cp_*, RekfDev::cp; phase G below): which landmarks it covers
 #ifdef REKF_DEBUG_MID_FIRST
     MMARK();                                        // (x0: first loads issued)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1276,7 +1433,17 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, int h0, int h1,
     const double *pp_src = spec ? ctl->pose_next[hd_pred_slot] : ctl->pose_pred;
     const double pose[5] = {hp ? A.pre_pose[0] : ctl_f64(&pp_src[0]), hp ? A.pre_pose[1] : ctl_f64(&pp_src[1]), hp ? A.pre_pose[2] : ctl_f64(&pp_src[2]),
                             hp ? A.pre_pose[3] : ctl_f64(&pp_src[3]), hp ? A.pre_pose[4] : ctl_f64(&pp_src[4])};
-    const bool pending = (FRONT || spec) ? true : ctl->pose_pending != 0;      // (the in-grid front role sets it beside us: a host-predicted scan always has one)
+    const bool pending = (FRONT || spec || gm) ? true : ctl->pose_pending != 0;      // (the in-grid front role sets it beside us: a host-predicted scan always has one)
+    // (a grid-matched scan had no front end to leave its Predict in the control block: the scan's downdate and the next scan's correction
+    // read it there -- workgroup 0 writes what the launch packet carries)
+    if (gm && bx == 0 && tid >= 192 && tid < 192 + 11) {
+        const int e = tid - 192;
+        ((double *)&ctl->pred[A.pred_ix & 3])[e] = (e < 2) ? A.pre_ab[e] : A.pre_C9[e - 2];
+    }
+    // (the match grid's share of this workgroup's rows: where each landmark was binned, and its entry -- whose mean phase F keeps current)
+    const bool grid_row = d.grid_bucket && tid < MID_ROWS && bx * MID_ROWS + tid >= 3 && bx * MID_ROWS + tid < d.n_max;
+    const float grid_p0_own = grid_row ? d.grid_p0[bx * MID_ROWS + tid - 3] : 0.f;
+    const int grid_slot_own = grid_row ? rekf_grid_slot(d)[(bx * MID_ROWS + tid - 3) >> 1] : -1;
     const bool first = bx == 0;
     // a speculative scan: its per-observation results with their margins (lane = observation)
     int sp_kind = -1, sp_idx = -1;
@@ -1302,14 +1469,11 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, int h0, int h1,
     if (do_pred && tid >= 64 && tid < 64 + 11) {                          // ab[0], ab[1], C9[0..8]
         // (with the front role in this grid the control block's copy is being written beside us: a host-predicted scan carries the values)
         const int e = tid - 64;
-        s_pred[e] = (FRONT && hp) ? (e < 2 ? A.pre_ab[e] : A.pre_C9[e - 2]) : ctl_f64(&((const double *)&ctl->pred[hd_pred_ix])[e]);
+        s_pred[e] = ((FRONT || gm) && hp) ? (e < 2 ? A.pre_ab[e] : A.pre_C9[e - 2]) : ctl_f64(&((const double *)&ctl->pred[hd_pred_ix])[e]);
     }
     // ... and what is PENDING on the stored P (A.corr): the previous scan's (a, b) and its pose block after the update
     const bool corr = DDROLE && hd_corr != 0, cpred = corr && hd_cpred != 0;     // (MODE 1, the two-launch chain of a filter that can still grow: never)
-    if (corr && tid >= 128 && tid < 128 + 11) {
-        const int e = tid - 128;
-        s_cpred[e] = (e < 2) ? (cpred ? ctl->pred[hd_corr_pred_ix].ab[e] : 0.0) : ctl->post_C9[hd_corr_post][e - 2];
-    }
+    if (corr && tid >= 128 && tid < 128 + 11) s_cpred[tid - 128] = cpred_early;
 
     // ---- A: the scan's matched pairs.  Whole scan (pair0 < 0): the record the front end left.  Block step of a wide scan (pair0 >= 0): the
     // pairs [pair0, pair0 + stride) of the record k_compact_wide wrote, state pairs first, then map pairs, compacted here.
@@ -1468,6 +1632,12 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, int h0, int h1,
             obs_to_global(x, y, cs, sn, rekf_obs(A, 2 * local_id), rekf_obs(A, 2 * local_id + 1), gx, gy);
             d.mu_out[n + 2 * tid] = (double)gx;                         // cc:341-342
             d.mu_out[n + 2 * tid + 1] = (double)gy;
+            // ... and the match grid takes them in where they stand (RekfCtl::grid_state; nobody reads the grid in this launch any more:
+            // every workgroup matched at its start)
+            if (d.grid_bucket && ctl->grid_state) {
+                grid_insert(d, ctl, (n - 3) / 2 + tid, gx, gy);
+                if (ctl->grid_overflow && d.grid_note) host_slot_store(d.grid_note, 2.0, (int)A.scan_id, 0);
+            }
         }
     };
     // The NEXT scan's Predict, when that scan is in the speculation pipeline (its launch packet An came with this launch): Predict's scalar
@@ -1511,6 +1681,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, int h0, int h1,
             const double pp = (i == 0) ? pose[0] : ((i == 1) ? pose[1] : pose[2]);      // no dynamic indexing of pose[]
             const double vv = (pending && i < 3) ? pp : d.mu[i];
             d.mu_out[i] = vv;
+            if (i >= 3 && grid_slot_own >= 0) rekf_grid_xy(d, d.grid_par ^ 1)[2 * grid_slot_own + ((i - 3) & 1)] = (float)vv;
             if (first && i < 3) s_np[i] = vv;
         }
         if (pending && first && tid == 0) ctl->pose_pending = 0;
@@ -2201,6 +2372,11 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, int h0, int h1,
             if (i == 2) v = atan2(sin(v), cos(v));                               // cc:307
             d.mu_out[i] = v;
             if (i >= 3) adm = fabs(dm);
+            if (i >= 3 && grid_slot_own >= 0) rekf_grid_xy(d, d.grid_par ^ 1)[2 * grid_slot_own + ((i - 3) & 1)] = (float)v;     // (the entry's mean, for the NEXT launch: cc:431's float32)
+            // the match grid stays exact only while every landmark is within REKF_GRID_DRIFT of where it was binned
+            if (i >= 3 && d.grid_bucket && fabsf((float)v - grid_p0_own) > d.grid_drift) {
+                if (ctl->grid_state) { ctl->grid_state = 0; if (d.grid_note) host_slot_store(d.grid_note, 1.0, (int)A.scan_id, 0); }
+            }
             if (i == 0) ctl->pose_pending = 0;
             if (first && i < 3) s_np[i] = v;
         }
@@ -2970,7 +3146,7 @@ template <int NBR, int MODE> static void launch_mid_as(int grid, int with_dd, hi
         std::lock_guard<std::mutex> guard(g_dd_cache.mu);
         int dev = 0;
         const int slot = dd_cache_slot(dev);
-        const unsigned bit = 1u << (3 * (NBR / 2 - 1) + MODE);
+        const unsigned bit = 1u << (4 * (NBR / 2 - 1) + MODE);
         if (!(g_dd_cache.attr_mid[slot] & bit) || dev != slot) {
             (void)hipFuncSetAttribute((const void *)k_mid<NBR, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
             g_dd_cache.attr_mid[slot] |= bit;
@@ -2993,14 +3169,16 @@ void rekf_launch_mid(const RekfDev &d, RekfFrontArgs &a, int n_ub, int m_ub, boo
     a.n_mid = (n_ub + MID_ROWS - 1) / MID_ROWS;
     a.dd_in_mid = 0; a.dd_first = 0; a.spec_front = 0;
     const int grid = a.n_mid + (a.front_in_mid > 0 ? a.front_in_mid : 0);
-    const int mode = (a.front_in_mid > 0) ? 2 : (mode_grow ? 1 : 0);
+    const int mode = (a.front_in_mid > 0) ? 2 : (mode_grow ? 1 : (a.grid_match ? 3 : 0));
     if (m_ub <= 32) {
         if (mode == 0) launch_mid_as<2, 0>(grid, 0, s, d, a, d, a);          // (the last argument: the downdate role's view, one launch per scan only)
         else if (mode == 1) launch_mid_as<2, 1>(grid, 0, s, d, a, d, a);
+        else if (mode == 3) launch_mid_as<2, 3>(grid, 0, s, d, a, d, a);
         else launch_mid_as<2, 2>(grid, 0, s, d, a, d, a);
     } else {
         if (mode == 0) launch_mid_as<4, 0>(grid, 0, s, d, a, d, a);
         else if (mode == 1) launch_mid_as<4, 1>(grid, 0, s, d, a, d, a);
+        else if (mode == 3) launch_mid_as<4, 3>(grid, 0, s, d, a, d, a);
         else launch_mid_as<4, 2>(grid, 0, s, d, a, d, a);
     }
 }
@@ -3037,11 +3215,15 @@ int rekf_launch_scan(const RekfDev &dd, const RekfDev &d, RekfFrontArgs &a, int 
     if (wgs > items) wgs = items;
     a.dd_in_mid = wgs;
     const int grid = a.dd_first + wgs;
-    const int mode = front_wgs > 0 ? 2 : 0;
+    const int mode = front_wgs > 0 ? 2 : (a.grid_match ? 3 : 0);
     if (m_ub <= 32) {
-        if (mode == 0) launch_mid_as<2, 0>(grid, 1, s, d, a, dd, an ? *an : a); else launch_mid_as<2, 2>(grid, 1, s, d, a, dd, a);
+        if (mode == 0) launch_mid_as<2, 0>(grid, 1, s, d, a, dd, an ? *an : a);
+        else if (mode == 3) launch_mid_as<2, 3>(grid, 1, s, d, a, dd, an ? *an : a);
+        else launch_mid_as<2, 2>(grid, 1, s, d, a, dd, a);
     } else {
-        if (mode == 0) launch_mid_as<4, 0>(grid, 1, s, d, a, dd, an ? *an : a); else launch_mid_as<4, 2>(grid, 1, s, d, a, dd, a);
+        if (mode == 0) launch_mid_as<4, 0>(grid, 1, s, d, a, dd, an ? *an : a);
+        else if (mode == 3) launch_mid_as<4, 3>(grid, 1, s, d, a, dd, an ? *an : a);
+        else launch_mid_as<4, 2>(grid, 1, s, d, a, dd, a);
     }
     return grid;
 }

@@ -121,6 +121,20 @@ struct rekf {
     // (a few microseconds into the launch: host slot 13), and the NEXT scan's call waits for that slot before it plans its launch: the
     // host of a growing filter runs at most one launch ahead of the device (the device is never idle for it: the launch it waits for has
     // only just started).  A filter that cannot grow (n == n_max) publishes nothing and waits for nothing.
+    // MATCH GRID (round 6; ekf_dev.h RekfCtl::grid_state): a hash grid over the landmark means lets k_mid match a HOST-PREDICTED scan itself
+    // (the reference node's pattern: the pose read back after every scan, odometry in between) -- no front-end launch, no kernel boundary on
+    // the scan-to-pose path.  Built lazily (k_grid_build, in stream order in front of the first scan that wants it), kept by the kernels
+    // (new reflectors are binned where they appear; a landmark that drifts too far from its binning position invalidates the grid and
+    // says so through host slot 14: the scans in between match by the full sweep, the host rebuilds).
+    bool grid_on = true;            // rekf_debug_set_grid(h, 0) turns it off (the twin of the parity tests: k_front_mb as a launch of its own)
+    bool grid_dev_valid = false;    // the device grid is built and the kernels are maintaining it (h->dev.grid_* set)
+    int grid_note_seen = 0;         // tag of the last invalidation note taken from host slot 14
+    int grid_builds = 0;
+    int *grid_bucket = nullptr;
+    float *grid_p0 = nullptr;
+    int grid_mask = 0;
+    float grid_drift = REKF_GRID_DRIFT;
+    int grid_mask_override = -1;    // rekf_debug_set_grid: a smaller table (tests: bucket overflow)
     bool early_valid = false;       // the last scan's k_mid publishes its n under tag early_seq ...
     int early_seq = 0;
     int early_n_before = -1;        // ... and this was the (exact) n it started from (-1: not known): equal = the scan appended nothing
@@ -347,6 +361,30 @@ int learn_early_n(rekf_t *h)
     return REKF_OK;
 }
 
+// MATCH GRID (struct rekf): an invalidation note from the device (host slot 14: a landmark drifted out of its bin -- rebuild; a bucket ran
+// over -- this world does not fit the table, stop using the grid), and the lazy build in front of a scan that wants the grid.
+void grid_take_note(rekf_t *h)
+{
+    if (!h->grid_dev_valid) return;
+    const RekfHostSlot *s = &h->host_slots[14];
+    const int tag = __atomic_load_n(&s->seq, __ATOMIC_ACQUIRE);
+    if (tag == h->grid_note_seen) return;
+    h->grid_note_seen = tag;
+    if (*(volatile const double *)&s->v >= 2.0) h->grid_on = false;
+    h->grid_dev_valid = false;
+    h->dev.grid_bucket = nullptr; h->dev.grid_p0 = nullptr; h->dev.grid_note = nullptr;
+}
+void grid_ensure(rekf_t *h)          // (call with n exact: h->n_ub landmarks' means are in h->dev.mu)
+{
+    if (h->grid_dev_valid) return;
+    h->dev.grid_bucket = h->grid_bucket; h->dev.grid_p0 = h->grid_p0;
+    h->dev.grid_mask = (h->grid_mask_override >= 0 && h->grid_mask_override < h->grid_mask) ? h->grid_mask_override : h->grid_mask;
+    h->dev.grid_drift = h->grid_drift;
+    h->dev.grid_note = h->host_slots_dev + 14;
+    rekf_launch_grid_build(h->dev, h->n_ub, -(++h->grid_builds), h->stream);      // (note tags of a build are negative: never a scan id)
+    h->grid_dev_valid = true;
+}
+
 // the held-back downdate (struct rekf: LAZY DOWNDATE) goes out on its own
 int flush_dd(rekf_t *h)
 {
@@ -463,12 +501,15 @@ void mirror_lower(double *sg, int n)
 struct DevBuffers {            // everything whose size depends on max_landmarks (rekf_create, rekf_reserve)
     double *mu = nullptr, *mu_out = nullptr, *P = nullptr, *P2 = nullptr, *HPt = nullptr, *Kn = nullptr, *dev_pred = nullptr, *dev_mu_lin = nullptr,
            *dev_ell = nullptr;
+    int *grid_bucket = nullptr;
+    float *grid_p0 = nullptr;
+    int grid_mask = 0;
     int ld = 0, n_max = 0;
 };
 void free_buffers(DevBuffers &b)
 {
     (void)hipFree(b.mu); (void)hipFree(b.mu_out); (void)hipFree(b.P); (void)hipFree(b.P2); (void)hipFree(b.HPt); (void)hipFree(b.Kn);
-    (void)hipFree(b.dev_pred); (void)hipFree(b.dev_mu_lin); (void)hipFree(b.dev_ell);
+    (void)hipFree(b.dev_pred); (void)hipFree(b.dev_mu_lin); (void)hipFree(b.dev_ell); (void)hipFree(b.grid_bucket); (void)hipFree(b.grid_p0);
     b = DevBuffers();
 }
 int alloc_buffers(rekf_t *h, int max_landmarks, DevBuffers &b)
@@ -486,6 +527,15 @@ int alloc_buffers(rekf_t *h, int max_landmarks, DevBuffers &b)
     HIP_TRY(h, hipMalloc(&b.dev_pred, sizeof(double) * (4 * (size_t)ld + 16)));
     HIP_TRY(h, hipMalloc(&b.dev_mu_lin, sizeof(double) * ld));
     HIP_TRY(h, hipMalloc(&b.dev_ell, sizeof(double) * 5 * (size_t)(max_landmarks > 0 ? max_landmarks : 1)));
+    {   // the match grid: at least four buckets per reflector of the capacity (a power of two), 8 ints each
+        int gh = 1024;
+        while (gh < 4 * max_landmarks) gh *= 2;
+        b.grid_mask = gh - 1;
+        HIP_TRY(h, hipMalloc(&b.grid_bucket, sizeof(int) * REKF_GRID_INTS_PER_BUCKET * (size_t)gh));
+        HIP_TRY(h, hipMemsetAsync(b.grid_bucket, 0, sizeof(int) * REKF_GRID_INTS_PER_BUCKET * (size_t)gh, h->stream));
+        HIP_TRY(h, hipMalloc(&b.grid_p0, sizeof(float) * 3 * (size_t)(max_landmarks + 8)));         // (p0[Lcap][2] | slot[Lcap])
+        HIP_TRY(h, hipMemsetAsync(b.grid_p0, 0xff, sizeof(float) * 3 * (size_t)(max_landmarks + 8), h->stream));     // (slot = -1: no entry)
+    }
     HIP_TRY(h, hipMemsetAsync(b.mu, 0, sizeof(double) * ld, h->stream));
     HIP_TRY(h, hipMemsetAsync(b.mu_out, 0, sizeof(double) * ld, h->stream));
     HIP_TRY(h, hipMemsetAsync(b.P, 0, sizeof(double) * (size_t)ld * ld, h->stream));              // cc:10-11
@@ -503,6 +553,9 @@ void adopt_buffers(rekf_t *h, const DevBuffers &b, int max_landmarks)
     h->dev.ld = b.ld; h->dev.n_max = b.n_max;
     h->dev.mu_lin = nullptr;
     h->max_landmarks = max_landmarks;
+    h->grid_bucket = b.grid_bucket; h->grid_p0 = b.grid_p0; h->grid_mask = b.grid_mask;
+    h->grid_dev_valid = false;                        // (new buffers: built again in front of the first scan that wants it)
+    h->dev.grid_bucket = nullptr; h->dev.grid_p0 = nullptr; h->dev.grid_mask = 0; h->dev.grid_note = nullptr;
 }
 // the other set of panels for the next k_mid (call once the scan's downdate has taken its copy of the device view)
 void flip_panels(rekf_t *h)
@@ -516,6 +569,7 @@ DevBuffers current_buffers(const rekf_t *h)
     DevBuffers b;
     b.mu = h->dev.mu; b.mu_out = h->dev.mu_out; b.P = h->dev.P; b.P2 = h->P_alt; b.HPt = h->panel_base[0]; b.Kn = h->panel_base[1];
     b.dev_pred = h->dev_pred; b.dev_mu_lin = h->dev_mu_lin; b.dev_ell = h->dev_ell; b.ld = h->dev.ld; b.n_max = h->dev.n_max;
+    b.grid_bucket = h->grid_bucket; b.grid_p0 = h->grid_p0; b.grid_mask = h->grid_mask;
     return b;
 }
 
@@ -793,6 +847,7 @@ static int process_scan(rekf_t *h, double t, const float *xy, int K, const doubl
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->early_valid) { int rce = learn_early_n(h); if (rce != REKF_OK) return rce; }      // (a growing filter: struct rekf, EARLY n)
     peek_n(h);                                        // whatever the device has published meanwhile tightens the bound on n, for free
+    grid_take_note(h);
     if (K == 0) {                                     // cc:235-236: Predict only -- on the mirror, like an odometry message
         int rc = refresh_mirror(h);
         if (rc != REKF_OK) return rc;
@@ -887,6 +942,8 @@ static int process_scan(rekf_t *h, double t, const float *xy, int K, const doubl
     // and k_mid would pay 0.9 us for the compaction)
     const bool cim = !use_spec && !blocks && !staged && K <= 32 && !front_in_grid && (fast || !with_dd);
     a.compact_in_mid = cim ? 1 : 0;
+    // a host-predicted whole scan whose front end would be a launch of its own: k_mid matches it itself through the match grid
+    const bool use_grid = h->grid_on && cim && a.host_pred && h->n_exact && h->grid_bucket != nullptr;
     if (!use_spec && !cim) h->front_total += (unsigned)K;    // (the front end counts the observations it matches; the speculative one has counted these)
     a.front_target = h->front_total;
     a.spec = use_spec ? 1 : 0;
@@ -908,6 +965,7 @@ static int process_scan(rekf_t *h, double t, const float *xy, int K, const doubl
         a.corr = 1; a.corr_pred = h->dd_dev.pred_slot; a.corr_post = h->dd_dev.post_slot; a.corr_pred_ix = h->dd_dev.pred_ix; a.corr_scan = h->dd_scan;
         if (use_spec) { /* nothing: the record is there */ }
         else if (alone && !next) front_wgs = K;
+        else if (use_grid) { grid_ensure(h); a.grid_match = 1; }      // (k_mid matches the scan itself: struct rekf, MATCH GRID)
         else { ProfScope ps(h, REKF_K_FRONT); rekf_launch_front_mb(h->dev, a, h->n_ub, h->stream); }
     } else if (with_dd) {
         h->dd_pending = false;
@@ -929,6 +987,8 @@ static int process_scan(rekf_t *h, double t, const float *xy, int K, const doubl
         // behind a pose read-back the front end is a match only (pose, cos / sin, pose block go by value): it runs as the first
         // workgroups of k_mid's own grid, one observation each, and hands the record over inside the launch
         a.front_in_mid = K;
+    } else if (use_grid) {
+        grid_ensure(h); a.grid_match = 1;             // (k_mid matches the scan itself: struct rekf, MATCH GRID)
     } else {
         ProfScope ps(h, REKF_K_FRONT);
         rekf_launch_front_mb(h->dev, a, h->n_ub, h->stream);
@@ -972,7 +1032,7 @@ static int process_scan(rekf_t *h, double t, const float *xy, int K, const doubl
                 ProfScope ps(h, REKF_K_MID);
                 rekf_launch_mid(dm, a, n_ub, 64, aug, h->stream);
             }
-            std::swap(h->dev.mu, h->dev.mu_out);
+            std::swap(h->dev.mu, h->dev.mu_out); h->dev.grid_par ^= 1;
             downdate(p0 == 0, p0 + stride >= K);      // the last step commits the final pose
         }
         a.pair0 = -1;
@@ -1015,7 +1075,7 @@ static int process_scan(rekf_t *h, double t, const float *xy, int K, const doubl
                 h->dev.P_out = h->dev.P;
             } else rekf_launch_mid(dm, a, n_ub, m_ub, aug || a.aug_in_mid != 0, h->stream);
         }
-        std::swap(h->dev.mu, h->dev.mu_out);
+        std::swap(h->dev.mu, h->dev.mu_out); h->dev.grid_par ^= 1;
         downdate(true, true);
     }
     h->last_m_ub = m_ub;
@@ -1153,6 +1213,7 @@ int rekf_set_state(rekf_t *h, double t, int n, const double *mu, const double *s
     if (h->held) (void)flush_held(h);
     h->held = false;                                              // (a held scan that could not be sent belonged to the state being replaced)
     h->early_valid = false;
+    h->grid_dev_valid = false; h->dev.grid_bucket = nullptr; h->dev.grid_p0 = nullptr; h->dev.grid_note = nullptr;
     h->spec_ready = false;
     h->pub_valid = false;
     for (auto &r : h->pub_ring) r = {0, 0};                       // an n published before this call says nothing about the new state
@@ -1378,7 +1439,24 @@ int rekf_debug_counters(rekf_t *h, long long out8[32])
     for (int i = 0; i < 32; ++i) out8[i] = h->ctl_staging->dbg[i];
 #ifndef REKF_DEBUG_TIMING
     out8[24] = (long long)h->ctl_staging->dd_queue[0] + (long long)h->ctl_staging->dd_queue[1];    // work items the in-launch downdate roles of the last two launches asked for
+    out8[17] = h->grid_builds;                         // k_grid_build launches so far (host count)
+    out8[16] = h->grid_on ? 1 : 0;
 #endif
+    return REKF_OK;
+}
+
+/* MATCH GRID test hook: on = 0 switches the grid match off (the scan's front end is a launch again: the twin of the parity tests);
+ * drift_limit > 0 replaces the drift bound (metres; tiny values make every update invalidate the grid: rebuilds and sweep fall-backs);
+ * mask >= 0 shrinks the hash table to mask + 1 buckets (mask = 2^k - 1; overflow: the library must stop using the grid by itself). */
+int rekf_debug_set_grid(rekf_t *h, int on, double drift_limit, int mask)
+{
+    if (!h || (mask >= 0 && (mask & (mask + 1)) != 0)) return REKF_ERR_INVALID;
+    FLUSH_HELD(h);
+    h->grid_on = on != 0;
+    h->grid_drift = drift_limit > 0.0 ? (float)drift_limit : REKF_GRID_DRIFT;
+    h->grid_mask_override = mask;
+    h->grid_dev_valid = false;
+    h->dev.grid_bucket = nullptr; h->dev.grid_p0 = nullptr; h->dev.grid_note = nullptr;
     return REKF_OK;
 }
 

@@ -390,6 +390,10 @@ class ReflectorEKFSLAM:
         """Test hook (include/rekf_debug.h): the next HandleObservationMessage fails at `stage` as if a HIP call had."""
         self._chk(self._L.rekf_debug_inject_failure(self._h, int(stage)), "rekf_debug_inject_failure")
 
+    def debug_set_grid(self, on: bool = True, drift_limit: float = 0.0, mask: int = -1):
+        """Test hook (include/rekf_debug.h): the match grid off / with another drift bound / with a smaller hash table."""
+        self._chk(self._L.rekf_debug_set_grid(self._h, 1 if on else 0, float(drift_limit), int(mask)), "rekf_debug_set_grid")
+
     def time_kernel(self, name: str, reps: int = 200, ablate: int = 0) -> float:
         """Average device time (us) of `reps` back-to-back launches of one kernel of the chain between ONE
         pair of hipEvents on the handle's stream (rekf_debug_time_kernel).  Leaves the state meaningless."""

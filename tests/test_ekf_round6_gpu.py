@@ -266,3 +266,104 @@ def test_map_localisation_at_512_reflectors_through_the_speculative_path(oracle_
     mo, Po = o.state()
     assert st.mu.shape == mo.shape and np.abs(st.mu - mo).max() < TIGHT and np.abs(st.sigma - Po).max() < 1e-11
     assert g.sync_code() == 0 and g.flags() == 0
+
+
+def _readback_session(g, scans, extra_from=None, extra=None, odometry=True):
+    """The reference node's call pattern (src/ros_node.cc:514-515, 627-660): odometry messages between the scans, the pose read back after
+    every scan.  Returns every pose read and the association lists of every 9th scan."""
+    out = []
+    t_prev = g.GetLatestTime()
+    for k, (t, ob) in enumerate(scans):
+        ob = np.array(ob, np.float32, copy=True)
+        if extra_from is not None and k >= extra_from:
+            ob = np.concatenate([ob, extra])
+        if odometry and k % 2 == 0:
+            g.handle_odometry(0.5 * (t_prev + t), 0.03, 0.0, 0.004 * ((k % 5) - 2))
+        g.handle_observation(t, ob)
+        out.append(g.pose())
+        if k % 9 == 8:
+            out.append(norm_match(g.last_match()))
+        t_prev = t
+    return out
+
+
+def _same(a, b):
+    if isinstance(a, (tuple, list)):
+        return len(a) == len(b) and all(_same(x, y) for x, y in zip(a, b))
+    if isinstance(a, np.ndarray):
+        return np.array_equal(a, b)
+    return a == b
+
+
+@pytest.mark.parametrize("growing", [False, True], ids=["full_filter", "growing_filter"])
+def test_grid_match_gives_the_front_kernels_bits_in_the_nodes_call_pattern(oracle_lib, growing):
+    """A host-predicted scan (the pose was read back, odometry came in between: the reference node's pattern) needs no front-end launch any
+    more: every k_mid workgroup matches it itself from the landmarks in the 3 x 3 match-grid cells around each observation -- exactly the
+    reference's first minimum over ALL landmarks, because only a landmark inside 0.6 m can match and those are all in the cells.  Twin:
+    the same calls with the grid off (k_front_mb sweeps all L).  Gate cases (observations pushed to 0.6 m +- millimetres), a new
+    reflector appearing in the middle (binned where it appears) and, on the growing filter, the oracle's state at the end."""
+    from reflector_ekf_slam_amd import ReflectorEKFSLAM
+    from reflector_ekf_slam_amd import session as S
+    cfg = synth.SessionConfig("r6_grid", 150, 22, synth.DIFF, seed=6600, speed=1.4, row_spacing=6.0)
+    sess = synth.make_session(cfg)
+    rng = np.random.default_rng(66)
+    scans = []
+    for k, (t, ob) in enumerate(synth.steady_state_scans(sess, 150)):
+        ob = np.array(ob, np.float32, copy=True)
+        if k % 4 == 1:
+            j = int(rng.integers(0, ob.shape[0]))
+            phi = rng.uniform(0, 2 * np.pi)
+            r = 0.6 + rng.choice([-3e-3, -1e-3, -2e-4, 2e-4, 1e-3, 3e-3])
+            ob[j] += np.float32(r) * np.array([np.cos(phi), np.sin(phi)], np.float32)
+        scans.append((t, ob))
+    extra = _free_points(sess, 1)
+
+    def run(grid):
+        g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=(4 if growing else 1) * cfg.n_landmarks, auto_grow=False)
+        g.debug_set_grid(grid)
+        S.replay(sess, g)
+        seen = _readback_session(g, scans, extra_from=60 if growing else None, extra=extra)
+        cnt = _counters(g)
+        code = g.sync_code()
+        st = g.GetState()
+        return g, st, seen, cnt, code
+
+    g0, s0, seen0, c0, code0 = run(False)
+    g1, s1, seen1, c1, code1 = run(True)
+    assert c0[18] == 0 and c1[18] > 100 and c1[19] == 0, (c0[18], c1[18], c1[19])      # k_mid matched the scans itself, never by the sweep
+    assert code0 == code1 and _same(seen0, seen1)
+    assert np.array_equal(s0.mu, s1.mu) and np.array_equal(s0.sigma, s1.sigma)
+    g0.close(); g1.close()
+
+
+def test_grid_invalidation_rebuild_and_overflow_fall_back_to_the_same_bits(oracle_lib):
+    """The grid is exact only while every landmark stands within the drift bound of where it was binned; a kernel that sees one outside
+    marks the grid invalid and tells the host, the scans in between match by the full sweep inside k_mid, the host rebuilds.  With the
+    bound lowered to 20 micrometres (rekf_debug_set_grid) that happens every few scans: same bits as the twin without a grid.  And a hash
+    table of 8 buckets overflows at once: the library must stop using the grid by itself -- same bits again."""
+    from reflector_ekf_slam_amd import ReflectorEKFSLAM
+    from reflector_ekf_slam_amd import session as S
+    cfg = synth.SessionConfig("r6_grid2", 90, 16, synth.OMNI, seed=6700, speed=1.3, row_spacing=6.0)
+    sess = synth.make_session(cfg)
+    scans = synth.steady_state_scans(sess, 90)
+
+    def run(on, drift, mask):
+        g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks, auto_grow=False)
+        g.debug_set_grid(on, drift, mask)
+        S.replay(sess, g)
+        seen = _readback_session(g, scans)
+        cnt = _counters(g)
+        assert g.sync_code() == 0
+        st = g.GetState()
+        g.close()
+        return st, seen, cnt
+
+    ref, seen_ref, c_ref = run(False, 0.0, -1)
+    dr, seen_dr, c_dr = run(True, 2e-5, -1)
+    ov, seen_ov, c_ov = run(True, 0.0, 7)
+    assert c_ref[18] == 0 and c_ref[17] == 0
+    assert c_dr[18] > 60 and c_dr[17] > 20 and c_dr[16] == 1, (c_dr[18], c_dr[17])     # grid-matched scans; rebuilt again and again (every drift note); still in use
+    assert c_ov[16] == 0 and c_ov[17] >= 1, (c_ov[16], c_ov[17], c_ov[18])              # the overflowing table was built once or twice and given up
+    for st, seen in ((dr, seen_dr), (ov, seen_ov)):
+        assert _same(seen_ref, seen)
+        assert np.array_equal(ref.mu, st.mu) and np.array_equal(ref.sigma, st.sigma)
