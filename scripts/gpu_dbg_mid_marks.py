@@ -15,14 +15,14 @@ g = ReflectorEKFSLAM(S.options_for(sess), max_landmarks=cfg.n_landmarks, auto_gr
 S.replay(sess, g); g.sync()
 L = _lib.rekf(); L.rekf_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
 scans = synth.steady_state_scans(sess, 40)
-for k, (t, ob) in enumerate(scans[:6]):
+for k, (t, ob) in enumerate(scans[:12]):
     g.handle_observation(t, ob)
-    if k >= 3:
+    if k >= 8:
         out = (C.c_longlong * 32)(); L.rekf_debug_counters(g._h, out)
         o = list(out)
         ghz = o[6] / max(o[5], 1) * 0.1
         print("kernel %.2f us @ %.2f GHz marks(us):" % (o[5] * 0.01, ghz), [round(x / ghz / 1e3, 2) for x in o[8:8 + o[7]]])
-        if o[26]:                                     # the one-launch form: wall clock (100 MHz) of the roles, relative to the downdate role's entry
-            t0 = o[26]
-            print("   one launch: downdate role wg 0: body done %.2f, counted %.2f | front role wg 0: entry %.2f, exit %.2f | mid wg 1: entry %.2f, exit %.2f us"
-                  % tuple((o[k] - t0) * 0.01 for k in (27, 28, 29, 30, 4, 31)))
+        # wall clock (100 MHz) of the LAST launch's roles, relative to mid workgroup 1's entry (dbg[4])
+        e1 = o[4]
+        print("   rel. to mid wg 1's entry: wg 1 exit %.2f | wg 0 exit %.2f | last mid wg: entry %.2f | last exit of any mid wg %.2f | downdate role: first start %.2f, last end %.2f us"
+              % tuple((o[k] - e1) * 0.01 for k in (31, 29, 25, 30, 26, 27)))
