@@ -3,6 +3,9 @@ call and after the closing sync, median over repetitions.  GPU box: python scrip
 import json, sys, time
 sys.path.insert(0, ".")
 import numpy as np
+from reflector_ekf_slam_amd import _lib
+if len(sys.argv) > 2:                               # another build of librekf.so (A/B of experimental builds)
+    _lib.lib_path = lambda name, _p=sys.argv[2]: _p if name == "librekf.so" else __import__("os").path.join(_lib._HERE, name)
 from reflector_ekf_slam_amd import synth, session as S, ReflectorEKFSLAM
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 cfg = synth.C3
