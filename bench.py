@@ -95,6 +95,9 @@ def parse_args(argv=None):
     ap.add_argument("--rank-parity-steps", type=int, default=20,
                     help="updates every rank replays against the CPU oracle AFTER the timed region (its parity figure in `ranks`; 0: skip)")
     ap.add_argument("--detector-reps", type=int, default=200, help="calls per detector in the `detectors` leg (0: skip)")
+    ap.add_argument("--fixed-capacity", action="store_true",
+                    help="build the headline filter with max_landmarks = L, auto_grow off (rounds 1-5's configuration) instead of the wrapper's "
+                         "defaults: for A/B and counter passes; the line's config says so")
     ap.add_argument("--timed-only", action="store_true",
                     help="map build, warm-up and the timed steps only (no instrumented legs): what scripts/gpu_profile_round.sh "
                          "runs under rocprofv3, so that the LAST dispatches of every kernel are the timed region's")
@@ -201,7 +204,7 @@ def run_rank(args, dist_mod, rank, local_rank, world, make_filter=gpu_filter_fac
     base, cfg, sess = build_session(args.config, rank, world)
     L = cfg.n_landmarks
     n_expect = 3 + 2 * L
-    ekf = make_filter(cfg, sess, local_rank)
+    ekf = make_filter(cfg, sess, local_rank, cfg.n_landmarks) if getattr(args, "fixed_capacity", False) else make_filter(cfg, sess, local_rank)
 
     # ---- untimed: build the map (augment path) ---------------------------------
     t0 = time.time()
@@ -245,8 +248,9 @@ def run_rank(args, dist_mod, rank, local_rank, world, make_filter=gpu_filter_fac
         "config": {"workload": f"{base.name}: synthetic 2D session, L={L} landmarks (n={n}), "
                                f"{m // 2} matched observations/scan (m={m}), "
                                f"{'diff-drive' if cfg.odom_model == synth.DIFF else 'omni'} odometry, "
-                               "steady-state HandleObservationMessage; filter built with the wrapper's defaults "
-                               "(ReflectorEKFSLAM(options): auto_grow, initial capacity 1024)",
+                               "steady-state HandleObservationMessage; filter built with " +
+                               ("max_landmarks = L, auto_grow off (--fixed-capacity)" if getattr(args, "fixed_capacity", False) else
+                                "the wrapper's defaults (ReflectorEKFSLAM(options): auto_grow, initial capacity 1024)"),
                    "max_landmarks": int(getattr(ekf, "max_landmarks", 0) or 0),
                    "sessions": world, "parallelism": "replicas: one independent session per GPU",
                    "map_build_s": round(map_build_s, 3)},
