@@ -26,10 +26,11 @@ o = make_oracle(model, sess.init_time, sess.init_pose, lin, ang, obs)
 use_map, use_gps = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
 assert not use_map
 burst_left, scans, first_scan, worst, reported = 0, 0, True, 0.0, False
+log = []                                            # the session as fed: (kind, t, payload) -- for off-line witnesses (scripts/ld_witness.py)
 for e in range(sess.n_events):
     t = float(sess.ev_time[e])
     if sess.ev_type[e] == synth.EV_ODOM:
-        g.handle_odometry(t, *sess.odom[e]); o.handle_odometry(t, *sess.odom[e]); continue
+        g.handle_odometry(t, *sess.odom[e]); o.handle_odometry(t, *sess.odom[e]); log.append((0, t, np.asarray(sess.odom[e], np.float64))); continue
     if first_scan: first_scan = False; continue
     ob = sess.obs_of(e)
     r = rng.random()
@@ -38,6 +39,7 @@ for e in range(sess.n_events):
     if rng.random() < 0.03: t -= 0.05
     gps = (sess.true_pose[e] + rng.normal(0, [0.03, 0.03, 0.01])) if (use_gps and rng.random() < 0.5) else None
     g.handle_observation(t, ob, gps); o.handle_observation(t, ob, gps); scans += 1
+    log.append((1, t, np.asarray(ob, np.float32).reshape(-1, 2).copy()))
     if not every:
         if burst_left > 0: burst_left -= 1; continue
         burst_left = int(rng.integers(1, 12))
@@ -52,4 +54,12 @@ for e in range(sess.n_events):
         print(json.dumps({"first_bad_scan": scans, "n": int(mg.shape[0]), "cap": g.max_landmarks, "err": err, "row": j, "K_this": int(ob.shape[0]),
                           "match": [x.tolist() for x in norm_match(g.last_match())], "dP_max": float(dP.max()), "dP_at": [int(jj[0]), int(jj[1])]}))
     worst = max(worst, err)
+if os.environ.get("FUZZ_DUMP"):
+    st = g.GetState(); mo, Po = o.state()
+    np.savez_compressed(os.environ["FUZZ_DUMP"], kind=np.array([k for k, _, _ in log]), t=np.array([t for _, t, _ in log]),
+                        odom=np.array([p if k == 0 else np.zeros(3) for k, _, p in log]),
+                        obs_off=np.cumsum([0] + [(p.shape[0] if k == 1 else 0) for k, _, p in log]),
+                        obs=np.concatenate([p for k, _, p in log if k == 1] + [np.zeros((0, 2), np.float32)]),
+                        gpu_mu=st.mu, gpu_P=st.sigma, oracle_mu=mo, oracle_P=Po, init_pose=np.asarray(sess.init_pose), init_time=sess.init_time,
+                        lin=lin, ang=ang, obsv=obs, model=model)
 print(json.dumps({"seed": seed, "scans": scans, "worst": worst, "n_final": int(g.mu().shape[0]), "env": {k: v for k, v in os.environ.items() if k.startswith(("REKF_", "FUZZ_"))}}))
