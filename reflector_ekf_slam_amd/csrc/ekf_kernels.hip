@@ -1183,7 +1183,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, int h0, int h1,
 #endif
     // ---- roles of the grid: [front end: A.front_in_mid workgroups][mid: A.n_mid][(idle up to A.dd_first)][downdate: the rest]
     if constexpr (DDROLE) {
-        if (__builtin_expect(hd_dd_in_mid && (int)blockIdx.x >= hd_dd_first, 0)) {
+        if (hd_dd_in_mid && (int)blockIdx.x >= hd_dd_first) {
             // the previous scan's downdate: waves 0..3 (the body is cut for 256 threads; a barrier counts the waves that have not ended)
             if (threadIdx.x < 256) {
                 // (two device time stamps, 100 MHz, for the bench's roofline: when the role's first workgroup starts, when its last one ends)
@@ -1196,7 +1196,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, int h0, int h1,
         }
     }
     const int bxf = (int)blockIdx.x;
-    if (FRONT && __builtin_expect(bxf < hd_front_in_mid, 0)) {
+    if (FRONT && bxf < hd_front_in_mid) {
         // A scan's front end as the FIRST workgroups of this grid instead of a launch of its own (7.5 us + a kernel boundary in front
         // of k_mid, on the path every read-back caller waits for); the mid workgroups wait for its count below.  One-way: the front
         // role waits for nobody, its workgroups are dispatched first and the grid's first 256 workgroups are resident together.
@@ -1212,7 +1212,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, int h0, int h1,
     }
     const int bx = bxf - (FRONT ? hd_front_in_mid : 0);          // this workgroup's number among the mid workgroups
     if constexpr (DDROLE && !FRONT) {
-        if (__builtin_expect(hd_spec_front > 0 && bx >= hd_n_mid && bx < hd_n_mid + hd_spec_front, 0)) {
+        if (hd_spec_front > 0 && bx >= hd_n_mid && bx < hd_n_mid + hd_spec_front) {
             // the NEXT scan's front end, speculatively (RekfCtl::spec): against the mean this launch's mid role starts from; nobody in
             // this launch waits for it.  Then it helps the downdate role.
             front_role<512, true>(d, An, bx - A.n_mid, A.spec_front, false);
@@ -1223,7 +1223,7 @@ __global__ __launch_bounds__(512) void k_mid(RekfCtl *ctl_first, int h0, int h1,
             return;
         }
     }
-    if (__builtin_expect(bx >= hd_n_mid, 0)) return;
+    if (bx >= hd_n_mid) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool steam = wave < 4;                  // S team; the other is the "own" team
     const int tt = tid & 255;                     // thread index within the team
