@@ -50,6 +50,8 @@ def test_every_profiled_kernel_is_in_the_built_library():
 
 
 def test_no_summary_is_older_than_the_sources_it_describes():
+    """Stale = a described source DIFFERS from what the summary was measured on: the blob of every source at the manifest's commit against
+    the file in the working tree (content, not history: a change that was committed and reverted leaves the measured code in place)."""
     if not os.path.isdir(os.path.join(ROOT, ".git")):
         pytest.skip("no git history here (a GPU box snapshot)")
     man = json.load(open(MANIFEST))["summaries"]
@@ -57,9 +59,9 @@ def test_no_summary_is_older_than_the_sources_it_describes():
     for f, e in man.items():
         c = e["commit"]
         assert subprocess.run(["git", "merge-base", "--is-ancestor", c, "HEAD"], cwd=ROOT).returncode == 0, (f, c)
-        later = subprocess.run(["git", "rev-list", f"{c}..HEAD", "--", *e["sources"]], cwd=ROOT, capture_output=True, text=True, check=True).stdout.split()
-        # (the working tree counts, too: an uncommitted edit of a described source makes the summary stale)
-        dirty = subprocess.run(["git", "status", "--porcelain", "--", *e["sources"]], cwd=ROOT, capture_output=True, text=True, check=True).stdout.strip()
-        if later or dirty:
-            stale.append((f, c, later[:3], dirty[:80]))
+        for src in e["sources"]:
+            then = subprocess.run(["git", "rev-parse", f"{c}:{src}"], cwd=ROOT, capture_output=True, text=True, check=True).stdout.strip()
+            now = subprocess.run(["git", "hash-object", src], cwd=ROOT, capture_output=True, text=True, check=True).stdout.strip()
+            if then != now:
+                stale.append((f, c, src))
     assert not stale, f"stale profile summaries (re-run scripts/gpu_profile_round.sh and scripts/profiles_commit.py): {stale}"
