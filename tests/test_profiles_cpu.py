@@ -1,6 +1,6 @@
 """The committed profile summaries the bench line and the docs cite must describe the tree that is built.  profiles/MANIFEST.json lists,
 per summary, the commit it was measured on and the SOURCES whose kernels it describes; a summary is stale -- and this suite red -- as
-soon as ANY later commit touched one of those sources (round 5's guard tolerated 12 later csrc commits and did not look at the detector
+soon as one of those sources DIFFERS (by content) from what it was at that commit (round 5's guard tolerated 12 later csrc commits and did not look at the detector
 summaries at all).  Every kernel the EKF summaries name must also be a symbol of the built librekf.so."""
 import json
 import os
