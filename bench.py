@@ -394,14 +394,29 @@ def instrumented_legs(args, base, cfg, sess, ekf, rest, n, m, device, world, cha
     pos += args.instr_steps
     # (the chain's us per update from a window of its own, 500 updates: the driver's 20-step timed region carries its pipeline fill and
     # its closing synchronisations 25 times harder, which is not kernel time)
+    def pipeline_counters():
+        import ctypes as _Cc
+        c = (_Cc.c_longlong * 32)()
+        return [int(x) for x in c] if ekf._L.rekf_debug_counters(ekf._h, c) == 0 else None
     if len(rest) - pos >= 500:
         ekf.sync()
+        c0 = pipeline_counters()
         t0c = time.perf_counter()
         for t, ob in rest[pos:pos + 500]:
             ekf.handle_observation(t, ob)
         ekf.sync()
         chain_us = 1e6 * (time.perf_counter() - t0c) / 500
+        c1 = pipeline_counters()
         pos += 500
+        if c0 and c1:
+            dlt = [b - a for a, b in zip(c0, c1)]
+            out["pipeline"] = {"window_updates": 500,
+                               "speculative_records_proved": dlt[20], "of_those_with_rematched_observations": dlt[21],
+                               "scans_beside_a_pending_downdate": dlt[22], "of_those_computing_its_correction_themselves": dlt[23],
+                               "grid_matched_scans": dlt[18], "of_those_by_the_full_sweep": dlt[19], "grid_builds_so_far": c1[17],
+                               "note": "rekf_debug_counters over the un-instrumented 500-update window the roofline's avg_launch_us comes from: how often "
+                                       "the speculative match record stood as proved, how often the write-ahead panel served (the rest computed the pending "
+                                       "scan's correction themselves: +6 us on that scan)"}
     # ---- the roofline kernel.  Since round 5 a steady-state update is ONE launch, k_mid<4, 0>: the scan's mid role (gather + 64 x 64
     # inverse + gain: a latency chain), the PREVIOUS scan's rank-m downdate P -= K (H P) as a role beside it (the HBM work: the stored lower
     # triangle read from one P buffer and written to the other, tiles from a queue) and the NEXT scan's speculative front end.  Its average

@@ -50,6 +50,10 @@ def _check_contract(d, steps, warmup):
     assert len(pe) == 1 and pe[0] is not None and pe[0] < 1e-9, pe
     assert r["mfma"]["frac"] < r["mfma"]["frac_fullsquare_flop"] and 0.02 < r["mfma"]["frac"] < 1.0
     assert d["value"] > 5000                                                   # the north-star bar is 10 k; 20-step runs are noisy
+    # (round 6) how the pipeline fared in the window the roofline's duration comes from: the wrapper-default filter speculated nearly every scan
+    pl = d["pipeline"]
+    assert pl["window_updates"] == 500 and pl["speculative_records_proved"] > 450 and pl["scans_beside_a_pending_downdate"] > 450
+    assert 0 <= pl["of_those_computing_its_correction_themselves"] <= pl["scans_beside_a_pending_downdate"]
 
 
 def test_driver_command_steps20_warmup5_has_every_object():
