@@ -73,7 +73,11 @@ struct Det3dCtl {
     // the grid the NEXT cloud is sorted on = the bounding box of this cloud's inliers (clouds of one sensor look alike;
     // only the sweeps' pruning, never a result, depends on it): k3_finish
     float gx0, gy0, ginv;
+    // the short front end (k3f_sort) found more survivors than it holds: every later kernel of this chain sees M = 0, the last one reports
+    // D3_RETRY and the host sends the cloud through the long chain (m_true: the count, for the next cloud's choice)
+    int retry, m_true;
 };
+constexpr int D3_RETRY = 1 << 20;   // (never leaves this file)
 
 // what the kernels hand back, in pinned host memory: every slot is ONE 16-byte system-scope store that carries the call's
 // number, polled by the host (no D2H copy, no wait for the completion signal; same scheme as det2d.hip)
@@ -107,16 +111,21 @@ struct Det3dBufs {
     int *roots;       // all roots, in no particular order
     Det3dCtl *ctl;
     int cap;
+    int cap1;         // p1's plane stride in the short front end: cap rounded up to whole 1024-point tiles
     Det3dHostOut *hout;   // pinned host memory (device view)
     int seq;              // this call's number
 };
 
 #ifdef RDET_DEBUG_MARKS
 // in-kernel timelines (k3_clusters, k3_cc_link): wall_clock64() (100 MHz) per workgroup and phase; scripts/gpu_dbg_det3d.py
-__device__ unsigned long long d3_marks[2048][8];
+// (one table per kernel: 0 k3_clusters, 1 k3_cc_link, 2 k3_knn, 3 k3_cc_min)
+__device__ unsigned long long d3_marks_all[4][2048][8];
+#define d3_marks d3_marks_all[D3_KERNEL]
 #define D3_MARK(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) d3_marks[blockIdx.x][i] = wall_clock64(); } while (0)
+#define D3_NOTE(i, v) do { if (threadIdx.x == 0 && blockIdx.x < 2048) d3_marks[blockIdx.x][i] = (unsigned long long)(v); } while (0)
 #else
 #define D3_MARK(i) do { } while (0)
+#define D3_NOTE(i, v) do { } while (0)
 #endif
 
 __device__ static float d2f(float ax, float ay, float az, float bx, float by, float bz)
@@ -167,6 +176,20 @@ __device__ static inline float lane_xor(float f, int lane)
     else if (J == 16) { const auto p = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false); r = (int)((lane & 16) ? p[0] : p[1]); }
     else { const auto p = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false); r = (int)((lane & 32) ? p[0] : p[1]); }
     return __int_as_float(r);
+}
+// the sum of one double per lane, in every lane: a butterfly (partners 1, 2, 4, ... 32 apart add up -- the same pairs in either order, so all
+// lanes end with the same bits)
+template <int J>
+__device__ static inline double lane_xor_f64(double v, int lane)
+{
+    const float lo = lane_xor<J>(__int_as_float(__double2loint(v)), lane), hi = lane_xor<J>(__int_as_float(__double2hiint(v)), lane);
+    return __hiloint2double(__float_as_int(hi), __float_as_int(lo));
+}
+__device__ static inline double wave_sum_f64(double v, int lane)
+{
+    v += lane_xor_f64<1>(v, lane); v += lane_xor_f64<2>(v, lane); v += lane_xor_f64<4>(v, lane);
+    v += lane_xor_f64<8>(v, lane); v += lane_xor_f64<16>(v, lane); v += lane_xor_f64<32>(v, lane);
+    return v;
 }
 // lanes of a wave that hold the same cell code (< 0: none): the lowest such lane, how many there are, and this lane's rank
 // among them -- so that ONE lane per (wave, cell) talks to memory, and all of a wave's leaders do so in one instruction
@@ -267,7 +290,7 @@ __global__ __launch_bounds__(1024) void k3_filter_write(Det3dBufs B, int N, doub
     const bool keep = i < N && (double)cur.w > intensity_min;
     const int pos = tile_compact_pos(keep, wsum, &base);
     if (keep) { B.p1[pos] = cur.x; B.p1[B.cap + pos] = cur.y; B.p1[2 * B.cap + pos] = cur.z; }
-    if ((int)blockIdx.x == ftiles - 1 && tid == 0) { B.ctl->M = base; B.ctl->M2 = 0; B.ctl->K = 0; B.ctl->err = 0; B.ctl->nroots = 0; }   // base now includes this tile
+    if ((int)blockIdx.x == ftiles - 1 && tid == 0) { B.ctl->M = base; B.ctl->M2 = 0; B.ctl->K = 0; B.ctl->err = 0; B.ctl->nroots = 0; B.ctl->retry = 0; B.ctl->m_true = base; }   // base now includes this tile
 }
 
 // bounding boxes of BOX_PTS consecutive sorted points: lane = point (x, y, z in registers), 32-lane halves reduce by
@@ -332,6 +355,130 @@ __global__ __launch_bounds__(256) void k3_boxes(Det3dBufs B, int N)
     tile_boxes(B.box, s, M, x, y, z);
 }
 
+// ---- the short front end (round 6): gate + sort + boxes in TWO launches for clouds whose survivors fit one workgroup's LDS ------------
+// The four launches above are a chain of all-to-all hand-overs of almost no data (3 k survivors = 40 KB): 20 us.  Here every 1024-point
+// tile compacts its own survivors in place (k3f_gate: no count to wait for, no histogram), and ONE workgroup does the rest in LDS
+// (k3f_sort): the tiles' prefix, the survivors in registers (eight per thread, asked for together), the cell histogram by LDS atomics
+// whose return value is the rank inside the cell, the scan of the 16 k cells, the sorted copy (over the histogram's storage), boxes, and
+// coalesced stores.  Node numbers are the same as the long chain's (tile prefix + place in the tile = arrival index among the survivors),
+// the order inside a cell is as arbitrary as there: nothing of the result can tell the two front ends apart.
+constexpr int MFAST = 8192, MFAST_PT = MFAST / 1024;
+__global__ __launch_bounds__(1024) void k3f_gate(Det3dBufs B, int N, double intensity_min)
+{
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x * 1024 + tid;
+    const float4 cur = (i < N) ? ((const float4 *)B.xyzi)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool keep = i < N && (double)cur.w > intensity_min;      // :33
+    const unsigned long long bal = __ballot(keep);
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const int c = wsum[w]; if (w < wave) off += c; tot += c; }
+    if (keep) {
+        const int pos = blockIdx.x * 1024 + off + __popcll(bal & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+        B.p1[pos] = cur.x; B.p1[B.cap1 + pos] = cur.y; B.p1[2 * B.cap1 + pos] = cur.z;
+    }
+    if (tid == 0) B.cnt[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(1024) void k3f_sort(Det3dBufs B, int N, int ftiles)
+{
+    __shared__ int s_pre[1024 + 1];
+    __shared__ int s_w[16];
+    __shared__ __attribute__((aligned(16))) int s_mem[4 * MFAST];                  // the cell histogram (16 k ints), then the sorted copy: x | y | z | node
+    static_assert(GRID_CELLS <= 4 * MFAST && GRID_CELLS == 16 * 1024, "k3f_sort's LDS plan");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = (tid < ftiles) ? B.cnt[tid] : 0;
+    const float gx0 = B.ctl->gx0, gy0 = B.ctl->gy0, ginv = B.ctl->ginv;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s_mem[tid + 1024 * k] = 0;
+    // exclusive scan of the tiles' counts
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int wbase = 0, M = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const int v = s_w[w]; if (w < wave) wbase += v; M += v; }
+    s_pre[tid] = wbase + incl - c;
+    if (tid == 0) s_pre[1024] = M;
+    __syncthreads();
+    if (M > MFAST) {                                                              // (uniform) not for this front end
+        if (tid == 0) { B.ctl->M = 0; B.ctl->M2 = 0; B.ctl->K = 0; B.ctl->err = 0; B.ctl->nroots = 0; B.ctl->retry = 1; B.ctl->m_true = M; }
+        return;
+    }
+    // the survivors, MFAST_PT per thread: node g sits in tile t = the last one whose prefix is <= g, at place g - prefix
+    float x[MFAST_PT], y[MFAST_PT], z[MFAST_PT];
+    int code[MFAST_PT], rank[MFAST_PT];
+    int steps = 0;
+    while ((1 << steps) < ftiles) ++steps;
+#pragma unroll
+    for (int r = 0; r < MFAST_PT; ++r) {
+        const int g = tid + 1024 * r;
+        int t = 0;
+        for (int b = steps - 1; b >= 0; --b) { const int u = t | (1 << b); if (u < ftiles && s_pre[u] <= g) t = u; }
+        const int idx = (g < M) ? t * 1024 + (g - s_pre[t]) : 0;
+        x[r] = B.p1[idx]; y[r] = B.p1[B.cap1 + idx]; z[r] = B.p1[2 * B.cap1 + idx];
+    }
+#pragma unroll
+    for (int r = 0; r < MFAST_PT; ++r) {
+        const int g = tid + 1024 * r;
+        code[r] = cell_code(x[r], y[r], gx0, gy0, ginv);
+        rank[r] = (g < M) ? atomicAdd(&s_mem[code[r]], 1) : 0;
+    }
+    __syncthreads();
+    // exclusive scan of the 16 k cells: sixteen consecutive cells per thread
+    {
+        int4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = *(const int4 *)&s_mem[16 * tid + 4 * k];
+        int run = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int a = v[k].x, b = v[k].y, cc = v[k].z, d = v[k].w;
+            v[k].x = run; v[k].y = run + a; v[k].z = run + a + b; v[k].w = run + a + b + cc;
+            run += a + b + cc + d;
+        }
+        int inc2 = run;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc2, off, 64); if (lane >= off) inc2 += t; }
+        if (lane == 63) s_w[wave] = inc2;                                         // (two barriers since anybody read the tiles' sums)
+        __syncthreads();
+        int base = inc2 - run;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) if (w < wave) base += s_w[w];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k].x += base; v[k].y += base; v[k].z += base; v[k].w += base; *(int4 *)&s_mem[16 * tid + 4 * k] = v[k]; }
+    }
+    __syncthreads();
+    int pos[MFAST_PT];
+#pragma unroll
+    for (int r = 0; r < MFAST_PT; ++r) pos[r] = s_mem[code[r]] + rank[r];
+    __syncthreads();
+    float *sx = reinterpret_cast<float *>(s_mem), *sy = sx + MFAST, *sz = sx + 2 * MFAST;
+    int *sp = s_mem + 3 * MFAST;
+#pragma unroll
+    for (int r = 0; r < MFAST_PT; ++r) {
+        const int g = tid + 1024 * r;
+        if (g < M) { sx[pos[r]] = x[r]; sy[pos[r]] = y[r]; sz[pos[r]] = z[r]; sp[pos[r]] = g; }
+    }
+    __syncthreads();
+    for (int s0 = 0; s0 < M; s0 += 1024) {
+        const int sidx = s0 + tid;
+        const bool v = sidx < M;
+        const float px = v ? sx[sidx] : 0.f, py = v ? sy[sidx] : 0.f, pz = v ? sz[sidx] : 0.f;
+        if (v) {
+            B.s1[sidx] = px; B.s1[B.cap + sidx] = py; B.s1[2 * B.cap + sidx] = pz;
+            B.perm[sidx] = sp[sidx];
+            B.cnt[sidx] = 0; B.first[sidx] = 0x7fffffff; B.last[sidx] = 0;       // (what k3_finish_a expects; the tiles' counts have been read)
+        }
+        tile_boxes(B.box, sidx, M, px, py, pz);
+    }
+    if (tid == 0) { B.ctl->M = M; B.ctl->M2 = 0; B.ctl->K = 0; B.ctl->err = 0; B.ctl->nroots = 0; B.ctl->retry = 0; B.ctl->m_true = M; }
+}
+
 // ---- the three neighbour sweeps: ONE WAVE PER QUERY, lane = candidate ----------------------------------------
 // (Round 4.  Earlier forms, all exact, all parity-green: lane = query with the candidates through the scalar cache and a
 // sorted list per lane -- 142 us all-pairs, 104 us with the boxes below; the same with LDS-staged tiles, per-lane tile
@@ -386,8 +533,15 @@ __device__ static inline int nearest_of(unsigned long long set, float v, int lan
 }
 constexpr int QW = 4;               // queries (waves) per workgroup
 constexpr int Q_GRID = 2048;        // workgroups: the queries are dealt round-robin
-constexpr int KNN_AHEAD = 4;        // steps (pairs of tiles) whose loads are issued together
-constexpr int CC_AHEAD = 4;         // the same in the radius-graph sweeps
+#ifndef D3_KNN_AHEAD
+#define D3_KNN_AHEAD 4
+#endif
+#ifndef D3_CCMIN_AHEAD
+#define D3_CCMIN_AHEAD 4
+#endif
+constexpr int KNN_AHEAD = D3_KNN_AHEAD;     // steps (pairs of tiles) whose loads are issued together
+constexpr int CC_AHEAD = 4;                 // the same in k3_cc_link's sweep
+constexpr int CCMIN_AHEAD = D3_CCMIN_AHEAD; // ... and in k3_cc_min's
 constexpr int KNN_FEW = 6;          // a step with at most this many admissible candidates inserts them one by one
 
 // What a sweep can ask for before it knows anything but its query's number: the boxes of the first 128 tiles (two per lane).  All of a
@@ -421,8 +575,10 @@ __device__ static inline float round_box_d2(const float *box, const BoxPre &P, i
 // m_hint: the previous cloud's M (clouds of one sensor look alike).  A wave whose query number is below it asks for everything at once;
 // one above it (most of the grid: the grid is sized for N, the gate leaves an eighth) first waits for M -- 5000 idle waves asking for
 // eleven loads each cost the working ones 6 us.  A wrong hint costs time, never a result.
+#define D3_KERNEL 2
 __global__ __launch_bounds__(64 * QW) void k3_knn(Det3dBufs B, int N, int ntiles_ub, int m_hint)
 {
+    D3_MARK(0);
     const int lane = threadIdx.x & 63;
     const int M = B.ctl->M;                                                       // (the first load out: waited for behind the query's own)
     const float *__restrict__ X = B.s1, *__restrict__ Y = B.s1 + B.cap, *__restrict__ Z = B.s1 + 2 * B.cap;
@@ -436,6 +592,9 @@ __global__ __launch_bounds__(64 * QW) void k3_knn(Det3dBufs B, int N, int ntiles
         BoxPre P;
         box_prefetch(B.box, lane, ntiles_ub, P);
         if (q >= M) break;
+        D3_MARK(1);
+        int dbg_steps = 0, dbg_merges = 0;
+        (void)dbg_steps; (void)dbg_merges;
         const int ntiles = (M + BOX_PTS - 1) / BOX_PTS;
         float S;
         {
@@ -443,6 +602,7 @@ __global__ __launch_bounds__(64 * QW) void k3_knn(Det3dBufs B, int N, int ntiles
             S = wave_sort64<false>((ja < M && d2 == d2) ? d2 : INFINITY, lane);
         }
         float bound = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S), KNN - 1));
+        D3_MARK(2);
         for (int r0 = 0; r0 < ntiles; r0 += 64) {
             const int t = r0 + lane;
             const float db = ((t >> 1) == (a0 >> 6)) ? INFINITY : round_box_d2(B.box, P, r0, lane, ntiles, qx, qy, qz) * BOX_MARGIN;
@@ -465,6 +625,7 @@ __global__ __launch_bounds__(64 * QW) void k3_knn(Det3dBufs B, int N, int ntiles
 #pragma unroll
                 for (int u = 0; u < KNN_AHEAD; ++u) {
                     if (u >= nstep) break;
+                    ++dbg_steps;
                     const float d2 = d2f(qx, qy, qz, cx[u], cy[u], cz[u]);
                     const float d = (ok[u] && d2 == d2) ? d2 : INFINITY;
                     unsigned long long adm = __ballot(d < bound);
@@ -481,6 +642,7 @@ __global__ __launch_bounds__(64 * QW) void k3_knn(Det3dBufs B, int N, int ntiles
                             bound = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S), KNN - 1));
                         }
                     } else {
+                        ++dbg_merges;
                         S = wave_merge64(S, wave_sort64<true>(d, lane), lane);
                         bound = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S), KNN - 1));
                     }
@@ -488,6 +650,8 @@ __global__ __launch_bounds__(64 * QW) void k3_knn(Det3dBufs B, int N, int ntiles
                 todo &= __ballot(db < bound);
             }
         }
+        D3_MARK(3);
+        D3_NOTE(6, dbg_steps); D3_NOTE(7, dbg_merges);
         const float sq = sqrtf(S);
         double dist_sum = 0;
 #pragma unroll
@@ -496,8 +660,10 @@ __global__ __launch_bounds__(64 * QW) void k3_knn(Det3dBufs B, int N, int ntiles
             const float md = (M >= KNN) ? (float)(dist_sum / MEAN_K) : 0.f;      // fewer than MeanK+1 points: the search "failed"
             B.dist[node] = md; B.dist_s[q] = md;                    // (by node: the statistics' order; by sorted position: the sweeps')
         }
+        D3_MARK(4);
     }
 }
+#undef D3_KERNEL
 
 // ---- connected components of the radius graph: lock-free union-find ------------------------------
 // parent = B.label.  Only roots are ever hooked (CAS root -> a SMALLER root), so the final root of a
@@ -546,13 +712,15 @@ __device__ static int uf_union(int *parent, int a, int b)
 //               union), and only adjacent pairs whose tops differ go into the union code -- once per DISTINCT top of a query's
 //               neighbours, by one lane (round 4: every lane for itself, dozens of compare-and-swaps on the same root).
 // Both as one wave per query over the tiles whose box lies within 0.2 m of it, like k3_knn.
+#define D3_KERNEL 3
 __global__ __launch_bounds__(64 * QW) void k3_cc_min(Det3dBufs B, int N, int ntiles_ub, int m_hint)
 {
-    __shared__ double red[2][1024];
+    __shared__ double red[2][QW];
+    D3_MARK(0);
     const int M = B.ctl->M;
     const int tid = threadIdx.x, lane = tid & 63;
     const float *__restrict__ X = B.s1, *__restrict__ Y = B.s1 + B.cap, *__restrict__ Z = B.s1 + 2 * B.cap, *__restrict__ DS = B.dist_s;
-    // the first query's loads go out before the statistics (which wait for M, then for M distances)
+    // the first query's loads go out before the statistics
     int q = __builtin_amdgcn_readfirstlane(blockIdx.x * QW + (threadIdx.x >> 6));
     if ((int)blockIdx.x * QW >= m_hint && (int)blockIdx.x * QW >= M) return;      // (the whole workgroup: no query; k3_knn on m_hint)
     const int q0 = q < N ? q : 0;
@@ -564,35 +732,55 @@ __global__ __launch_bounds__(64 * QW) void k3_cc_min(Det3dBufs B, int N, int nti
     if (boxer) { tx = X[q + lane]; ty = Y[q + lane]; tz = Z[q + lane]; td = DS[q + lane]; }
     BoxPre P;
     box_prefetch(B.box, lane, ntiles_ub, P);
+    // ... and so do the first 16 * 64 * QW of the M distances the statistics are taken over (sixteen per thread, by node; the arrays end 1024
+    // floats behind B.cap): with everything else a workgroup asks for before it knows M.  (Round 5 waited for M, then for one distance after
+    // the other: 5 us of this kernel's 12.)
+    constexpr int SPT = 16, SPW = SPT * 64 * QW;                                  // distances per thread and round / per workgroup and round
+    float4 e[SPT / 4];
+    {
+        const bool can = SPT * tid + SPT - 1 < B.cap + 1024;
+#pragma unroll
+        for (int k = 0; k < SPT / 4; ++k) e[k] = can ? ((const float4 *)B.dist)[(SPT / 4) * tid + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if ((int)blockIdx.x * QW >= M) return;                                        // (the whole workgroup: no query)
+    D3_MARK(1);
     // ---- SOR part 2 (:43-47 setStddevMulThresh): mean and (n-1)-variance of the M distances in FP64.  EVERY workgroup takes them for
-    // itself (M floats out of L2: cheaper than a launch in between, and than any hand-over inside one): 1024 chunk sums in node
-    // order, then the pairwise tree -- the operations, in the order, of the serial loop's partial sums, so the threshold's bits do not
-    // depend on the grid.  Which points are outliers is never stored: the sweeps compare dist_s with the threshold as they go.
+    // itself (M floats out of L2: cheaper than a launch in between, and than any hand-over inside one), in an order that depends on M alone:
+    // thread t adds up the distances of the nodes [16 (t + 256 r), + 16), r = 0, 1, ..., one after the other; the threads' sums meet in a
+    // butterfly over the lanes and the four waves' in turn -- the threshold's bits do not depend on the grid or on which workgroup asks.
+    // Which points are outliers is never stored: the sweeps compare dist_s with the threshold as they go.
     double thr;
     {
-        const int CH = (M + 1023) / 1024;
-        for (int c = tid; c < 1024; c += 64 * QW) {
-            const int b0 = c * CH, b1 = min(M, b0 + CH);
-            double sum = 0, sq = 0;
-            for (int i = b0; i < b1; ++i) { const double v = B.dist[i]; sum += v; sq += v * v; }   // chunked like the serial loop's partial sums
-            red[0][c] = sum; red[1][c] = sq;
-        }
-        __syncthreads();
-        for (int off = 512; off >= 64; off >>= 1) {
-            for (int i = tid; i < off; i += 64 * QW) { red[0][i] += red[0][i + off]; red[1][i] += red[1][i + off]; }
-            __syncthreads();
-        }
-        // (the last six levels: entries 0 .. 63, one per lane, every wave for itself -- the same additions of the same pairs, by shuffles)
-        double r0 = red[0][lane], r1 = red[1][lane];
+        double sum = 0, sq = 0;
+        for (int base = SPT * tid; base < M; base += SPW) {
+            if (base != SPT * tid) {
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { r0 += __shfl_down(r0, off, 64); r1 += __shfl_down(r1, off, 64); }
-        r0 = __shfl(r0, 0, 64); r1 = __shfl(r1, 0, 64);
+                for (int k = 0; k < SPT / 4; ++k) e[k] = ((const float4 *)B.dist)[base / 4 + k];
+            }
+#pragma unroll
+            for (int k = 0; k < SPT / 4; ++k) {
+                const float v4[4] = {e[k].x, e[k].y, e[k].z, e[k].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double v = (base + 4 * k + j < M) ? (double)v4[j] : 0.0;
+                    sum += v; sq += v * v;
+                }
+            }
+        }
+        sum = wave_sum_f64(sum, lane); sq = wave_sum_f64(sq, lane);
+        if (lane == 0) { red[0][tid >> 6] = sum; red[1][tid >> 6] = sq; }
+        __syncthreads();
+        double r0 = red[0][0], r1 = red[1][0];
+#pragma unroll
+        for (int w = 1; w < QW; ++w) { r0 += red[0][w]; r1 += red[1][w]; }
         const double valid = (M >= MEAN_K + 1) ? (double)M : 0.0;
         const double mean = r0 / valid;
         const double variance = (r1 - r0 * r0 / valid) / (valid - 1);
         thr = mean + STD_MUL * sqrt(variance);                                   // (every thread: the same bits; NaN keeps everything)
     }
+    D3_MARK(2);
+    int dbg_tiles = 0;
+    (void)dbg_tiles;
     for (bool first = true; q < N; q += gridDim.x * QW, first = false) {
         bool bx = boxer;
         if (!first) {
@@ -617,12 +805,13 @@ __global__ __launch_bounds__(64 * QW) void k3_cc_min(Det3dBufs B, int N, int nti
         int mi = own;
         for (int r0 = 0; r0 < ntiles; r0 += 64) {
             unsigned long long todo = __ballot(round_box_d2(B.box, P, r0, lane, ntiles, qx, qy, qz) * BOX_MARGIN < TOL2);
+            dbg_tiles += __popcll(todo);
             while (todo) {
-                float cx[CC_AHEAD], cy[CC_AHEAD], cz[CC_AHEAD], cd[CC_AHEAD];
-                int pj[CC_AHEAD];
-                bool ok[CC_AHEAD];
+                float cx[CCMIN_AHEAD], cy[CCMIN_AHEAD], cz[CCMIN_AHEAD], cd[CCMIN_AHEAD];
+                int pj[CCMIN_AHEAD];
+                bool ok[CCMIN_AHEAD];
 #pragma unroll
-                for (int u = 0; u < CC_AHEAD; ++u) {                        // four steps' loads in flight
+                for (int u = 0; u < CCMIN_AHEAD; ++u) {                        // four steps' loads in flight
                     int ta = -1, tb = -1;
                     if (todo) { ta = __ffsll((long long)todo) - 1; todo &= todo - 1; }
                     if (todo) { tb = __ffsll((long long)todo) - 1; todo &= todo - 1; }
@@ -633,14 +822,17 @@ __global__ __launch_bounds__(64 * QW) void k3_cc_min(Det3dBufs B, int N, int nti
                     cx[u] = X[jj]; cy[u] = Y[jj]; cz[u] = Z[jj]; cd[u] = DS[jj]; pj[u] = B.perm[jj];   // (the id with the coordinates, not behind the test)
                 }
 #pragma unroll
-                for (int u = 0; u < CC_AHEAD; ++u)
+                for (int u = 0; u < CCMIN_AHEAD; ++u)
                     if (ok[u] && !((double)cd[u] > thr) && d2f(qx, qy, qz, cx[u], cy[u], cz[u]) < TOL2) mi = min(mi, pj[u]);
             }
         }
         for (int off = 32; off > 0; off >>= 1) mi = min(mi, __shfl_xor(mi, off, 64));
         if (lane == 0) B.label[own] = mi;
+        if (first) { D3_MARK(3); D3_NOTE(6, dbg_tiles); }
     }
 }
+#undef D3_KERNEL
+#define D3_KERNEL 1
 __global__ __launch_bounds__(64 * QW) void k3_cc_link(Det3dBufs B, int N, int ntiles_ub, int m_hint)
 {
     const int M = B.ctl->M;
@@ -657,6 +849,8 @@ __global__ __launch_bounds__(64 * QW) void k3_cc_link(Det3dBufs B, int N, int nt
 #ifdef RDET_DEBUG_MARKS
         const bool dbg = q == (int)blockIdx.x * QW;
         if (dbg) D3_MARK(0);
+        unsigned long long dbg_tl = 0, dbg_tc = 0, dbg_tu = 0, dbg_t = 0;
+        int dbg_batches = 0, dbg_hops = 0, dbg_rounds = 0, dbg_tiles = 0;
 #endif
         int rs = uf_ld(&parent[own]);           // top of the query's chain as it stands
         if (rs < 0) continue;                                    // removed by SOR (k3_cc_min)
@@ -670,9 +864,13 @@ __global__ __launch_bounds__(64 * QW) void k3_cc_link(Det3dBufs B, int N, int nt
             const float db = round_box_d2(B.box2, P, r0, lane, ntiles, qx, qy, qz) * BOX_MARGIN;
             unsigned long long todo = __ballot(db < TOL2 && BOX_PTS * (r0 + lane) < q);   // (a tile behind the query holds no earlier point)
 #ifdef RDET_DEBUG_MARKS
-            if (dbg && r0 == 0) { D3_MARK(2); if (threadIdx.x == 0 && blockIdx.x < 2048) d3_marks[blockIdx.x][6] = __popcll(todo); }
+            if (dbg && r0 == 0) D3_MARK(2);
+            dbg_tiles += __popcll(todo);
 #endif
             while (todo) {
+#ifdef RDET_DEBUG_MARKS
+                ++dbg_batches; dbg_t = wall_clock64();
+#endif
                 float cx[CC_AHEAD], cy[CC_AHEAD], cz[CC_AHEAD];
                 int top[CC_AHEAD];
                 bool ok[CC_AHEAD];
@@ -694,8 +892,7 @@ __global__ __launch_bounds__(64 * QW) void k3_cc_link(Det3dBufs B, int N, int nt
                 for (int u = 0; u < CC_AHEAD; ++u)
                     if (!(ok[u] && top[u] >= 0 && d2f(qx, qy, qz, cx[u], cy[u], cz[u]) < TOL2)) top[u] = rs;
 #ifdef RDET_DEBUG_MARKS
-                int dbg_hops = 0, dbg_rounds = 0;
-                if (dbg) D3_MARK(4);
+                { const unsigned long long t = wall_clock64(); dbg_tl += t - dbg_t; dbg_t = t; }
 #endif
                 bool moving = true;
                 while (__ballot(moving)) {
@@ -710,7 +907,7 @@ __global__ __launch_bounds__(64 * QW) void k3_cc_link(Det3dBufs B, int N, int nt
                     for (int u = 0; u < CC_AHEAD; ++u) { moving |= p[u] != top[u]; top[u] = p[u]; }
                 }
 #ifdef RDET_DEBUG_MARKS
-                if (dbg) D3_MARK(5);
+                { const unsigned long long t = wall_clock64(); dbg_tc += t - dbg_t; dbg_t = t; }
 #endif
                 // one union per DISTINCT top that is not the query's: the k-th distinct one is lane k's, all of them at once (64 per round)
                 while (true) {
@@ -730,21 +927,30 @@ __global__ __launch_bounds__(64 * QW) void k3_cc_link(Det3dBufs B, int N, int nt
                     if (nd == 0) break;
 #ifdef RDET_DEBUG_MARKS
                     ++dbg_rounds;
-                    if (dbg && threadIdx.x == 0 && blockIdx.x < 2048) d3_marks[blockIdx.x][7] = (unsigned long long)(dbg_hops * 10000 + dbg_rounds * 100 + nd);
 #endif
                     int a = ri;
                     if (mine >= 0) a = uf_union(parent, ri, mine);
                     for (int off = 32; off > 0; off >>= 1) a = min(a, __shfl_xor(a, off, 64));
                     ri = a;                                                 // (the smallest root any lane has seen: a hint, like rs)
                 }
+#ifdef RDET_DEBUG_MARKS
+                { const unsigned long long t = wall_clock64(); dbg_tu += t - dbg_t; dbg_t = t; }
+#endif
             }
         }
 #ifdef RDET_DEBUG_MARKS
-        if (dbg) D3_MARK(3);
+        if (dbg) {
+            D3_MARK(3);
+            D3_NOTE(4, dbg_tl); D3_NOTE(5, dbg_tc);
+            D3_NOTE(6, ((unsigned long long)dbg_tiles << 32) | (unsigned)(dbg_batches * 10000 + dbg_hops * 100 + dbg_rounds));
+            D3_NOTE(7, dbg_tu);
+        }
 #endif
     }
 }
 
+#undef D3_KERNEL
+#define D3_KERNEL 0
 // ---- sizes, gate, order, centroids ------------------------------------------------------------------
 // k3_finish_a (thread = sorted position, over the CUs): final roots, component sizes, the stretch of the sorted copy
 // each component lives in, and the list of roots.  One atomic group per (wave, component) instead of one per point:
@@ -833,6 +1039,7 @@ __global__ __launch_bounds__(256) void k3_clusters(Det3dBufs B, int max_centers,
     int n = min(s_n, RDET_MAX_CENTERS);
     int err = s_err;
     if (n > max_centers) { err = RDET_ERR_BUFFER; n = 0; }
+    if (B.ctl->retry) { err = D3_RETRY; n = 0; }
     // rank = the number of keys below one's own ((MAX_SZ - size, root): size descending, root ascending); four threads per entry, two
     // keys per LDS read (round 4: one thread per entry, size and root apart: 3 us for 76 entries)
     for (int e0 = 0; e0 < n; e0 += 64) {
@@ -850,7 +1057,7 @@ __global__ __launch_bounds__(256) void k3_clusters(Det3dBufs B, int max_centers,
     __syncthreads();
     if (blockIdx.x == 0 && tid == 0) {
         B.ctl->K = n; B.ctl->err = err;
-        d3_host_store16(&B.hout->head, (unsigned)n, (unsigned)err, (unsigned)B.ctl->M, (unsigned)B.seq);   // the centres follow, each with its own tag
+        d3_host_store16(&B.hout->head, (unsigned)n, (unsigned)err, (unsigned)B.ctl->m_true, (unsigned)B.seq);   // the centres follow, each with its own tag
     }
     // the next cloud's grid: the box of this cloud's inliers (= of the tiles' tight boxes), a little wider, at least 1/8 m per cell -- by the LAST
     // workgroup, the one least likely to have a component to sum (round 4: the first one, which has the largest)
@@ -937,6 +1144,7 @@ __global__ __launch_bounds__(256) void k3_clusters(Det3dBufs B, int max_centers,
     }
     D3_MARK(4);
 }
+#undef D3_KERNEL
 
 }  // namespace
 
@@ -958,14 +1166,18 @@ struct rdet3d {
         float *h_stage;
         Det3dHostOut *h_out, *dv_out;  // pinned + mapped: polled result slots (host / device view)
         bool busy;                     // submitted, not collected
+        bool fast;                     // its chain starts with the short front end
         int seq, max_centers;
+        int N;                         // points of the submitted cloud (a chain that has to be launched again: D3_RETRY)
         double stamp;
     } slot[2];
     int n_out;                         // clouds submitted and not collected (0 .. 2); the older one is slot[(next + 2 - n_out) & 1]
     int next;                          // the slot the next submit takes
     bool in_flight;                    // a call returned before its kernels had published everything
     int seq;
-    int m_hint;                        // the previous cloud's survivors of the gate (k3_knn: m_hint)
+    int m_hint;                        // the previous cloud's survivors of the gate (k3_knn: m_hint; which front end the next cloud gets)
+    int path_mode;                     // 0: by m_hint; 1: always the long chain; 2: always try the short front end (rdet3d_debug_set_path)
+    unsigned long long n_short, n_retry;   // clouds sent through the short front end / of those, sent again through the long one
     std::string hip_error;
 };
 
@@ -977,6 +1189,40 @@ struct rdet3d {
             return RDET_ERR_HIP;                                                    \
         }                                                                           \
     } while (0)
+
+// one cloud's chain of kernels onto the handle's stream (the cloud is in sl.d_xyzi): the short front end when the previous cloud's survivors
+// would have fitted it, else the long one
+static int d3_launch(rdet3d_t *h, rdet3d::Slot &sl)
+{
+    const int N = sl.N, max_centers = sl.max_centers;
+    Det3dBufs B;
+    B.xyzi = sl.d_xyzi; B.p1 = h->d_p1; B.s1 = h->d_s1; B.dist_s = h->d_dist_s; B.perm = h->d_perm; B.box = h->d_box; B.box2 = h->d_box2; B.hist = h->d_hist; B.cursor = h->d_cursor;
+    B.dist = h->d_dist; B.label = h->d_label; B.cnt = h->d_cnt; B.first = h->d_first; B.last = h->d_last; B.roots = h->d_roots;
+    B.ctl = h->d_ctl; B.cap = h->max_points; B.cap1 = (h->max_points + 1023) & ~1023;
+    B.hout = sl.dv_out; B.seq = sl.seq = ++h->seq;
+    const int ftiles = (N + 1023) / 1024, b256 = (N + 255) / 256, ntiles_ub = (N + BOX_PTS - 1) / BOX_PTS;
+    sl.fast = ftiles <= 1024 && (h->path_mode == 2 || (h->path_mode == 0 && h->m_hint <= MFAST - MFAST / 8));
+    if (sl.fast) {
+        ++h->n_short;
+        hipLaunchKernelGGL(k3f_gate, dim3(ftiles), dim3(1024), 0, h->stream, B, N, h->opt.intensity_min);
+        hipLaunchKernelGGL(k3f_sort, dim3(1), dim3(1024), 0, h->stream, B, N, ftiles);
+    } else {
+        hipLaunchKernelGGL(k3_filter_count, dim3(ftiles), dim3(1024), 0, h->stream, B, N, h->opt.intensity_min);
+        hipLaunchKernelGGL(k3_filter_write, dim3(ftiles + GRID_CELLS / 1024), dim3(1024), 0, h->stream, B, N, h->opt.intensity_min, ftiles);
+        hipLaunchKernelGGL(k3_scatter, dim3(ftiles), dim3(1024), 0, h->stream, B, N);
+        hipLaunchKernelGGL(k3_boxes, dim3(b256), dim3(256), 0, h->stream, B, N);
+    }
+    const int qblocks = (N + QW - 1) / QW < Q_GRID ? (N + QW - 1) / QW : Q_GRID;   // a wave per query, dealt round-robin: M <= N stays on the device
+    hipLaunchKernelGGL(k3_knn, dim3(qblocks), dim3(64 * QW), 0, h->stream, B, N, ntiles_ub, h->m_hint);
+    hipLaunchKernelGGL(k3_cc_min, dim3(qblocks), dim3(64 * QW), 0, h->stream, B, N, ntiles_ub, h->m_hint);
+    hipLaunchKernelGGL(k3_cc_link, dim3(qblocks), dim3(64 * QW), 0, h->stream, B, N, ntiles_ub, h->m_hint);
+    const float sa = (float)h->s2b[2];
+    hipLaunchKernelGGL(k3_finish_a, dim3(b256), dim3(256), 0, h->stream, B, N);
+    hipLaunchKernelGGL(k3_clusters, dim3(RDET_MAX_CENTERS / 4), dim3(256), 0, h->stream, B, max_centers < RDET_MAX_CENTERS ? max_centers : RDET_MAX_CENTERS,
+                       (float)h->s2b[0], (float)h->s2b[1], cosf(sa), sinf(sa));
+    DET3_TRY(h, hipGetLastError());
+    return RDET_OK;
+}
 
 extern "C" {
 
@@ -1004,7 +1250,7 @@ int rdet3d_create(const rdet3d_options *opt, const double s2b[3], int max_points
             }
         }
         // + 1024 floats: the sweeps ask for the aligned 64 points around a query before they know M (up to 63 past the end)
-        DET3_TRY(h, hipMalloc(&h->d_p1, 12 * np + 4096)); DET3_TRY(h, hipMemset(h->d_p1, 0, 12 * np + 4096));
+        DET3_TRY(h, hipMalloc(&h->d_p1, 12 * (np + 1024) + 4096)); DET3_TRY(h, hipMemset(h->d_p1, 0, 12 * (np + 1024) + 4096));   // (+ 1024: k3f_gate's whole tiles)
         DET3_TRY(h, hipMalloc(&h->d_s1, 12 * np + 4096)); DET3_TRY(h, hipMemset(h->d_s1, 0, 12 * np + 4096));
         DET3_TRY(h, hipMalloc(&h->d_perm, 4 * np + 4096)); DET3_TRY(h, hipMemset(h->d_perm, 0, 4 * np + 4096));
         DET3_TRY(h, hipMalloc(&h->d_box, 32 * (np / BOX_PTS + 2)));
@@ -1088,25 +1334,8 @@ int rdet3d_submit(rdet3d_t *h, double stamp, const float *xyzi, int N, int max_c
 #ifdef RDET_DEBUG_MARKS
         dbg_t[1] = dbg_us();
 #endif
-        Det3dBufs B;
-        B.xyzi = sl.d_xyzi; B.p1 = h->d_p1; B.s1 = h->d_s1; B.dist_s = h->d_dist_s; B.perm = h->d_perm; B.box = h->d_box; B.box2 = h->d_box2; B.hist = h->d_hist; B.cursor = h->d_cursor;
-        B.dist = h->d_dist; B.label = h->d_label; B.cnt = h->d_cnt; B.first = h->d_first; B.last = h->d_last; B.roots = h->d_roots;
-        B.ctl = h->d_ctl; B.cap = h->max_points;
-        B.hout = sl.dv_out; B.seq = sl.seq = ++h->seq;
-        const int ftiles = (N + 1023) / 1024, b256 = (N + 255) / 256, ntiles_ub = (N + BOX_PTS - 1) / BOX_PTS;
-        hipLaunchKernelGGL(k3_filter_count, dim3(ftiles), dim3(1024), 0, h->stream, B, N, h->opt.intensity_min);
-        hipLaunchKernelGGL(k3_filter_write, dim3(ftiles + GRID_CELLS / 1024), dim3(1024), 0, h->stream, B, N, h->opt.intensity_min, ftiles);
-        hipLaunchKernelGGL(k3_scatter, dim3(ftiles), dim3(1024), 0, h->stream, B, N);
-        hipLaunchKernelGGL(k3_boxes, dim3(b256), dim3(256), 0, h->stream, B, N);
-        const int qblocks = (N + QW - 1) / QW < Q_GRID ? (N + QW - 1) / QW : Q_GRID;   // a wave per query, dealt round-robin: M <= N stays on the device
-        hipLaunchKernelGGL(k3_knn, dim3(qblocks), dim3(64 * QW), 0, h->stream, B, N, ntiles_ub, h->m_hint);
-        hipLaunchKernelGGL(k3_cc_min, dim3(qblocks), dim3(64 * QW), 0, h->stream, B, N, ntiles_ub, h->m_hint);
-        hipLaunchKernelGGL(k3_cc_link, dim3(qblocks), dim3(64 * QW), 0, h->stream, B, N, ntiles_ub, h->m_hint);
-        const float sa = (float)h->s2b[2];
-        hipLaunchKernelGGL(k3_finish_a, dim3(b256), dim3(256), 0, h->stream, B, N);
-        hipLaunchKernelGGL(k3_clusters, dim3(RDET_MAX_CENTERS / 4), dim3(256), 0, h->stream, B, max_centers < RDET_MAX_CENTERS ? max_centers : RDET_MAX_CENTERS,
-                           (float)h->s2b[0], (float)h->s2b[1], cosf(sa), sinf(sa));
-        DET3_TRY(h, hipGetLastError());
+        sl.N = N;
+        { const int rc = d3_launch(h, sl); if (rc != RDET_OK) return rc; }
 #ifdef RDET_DEBUG_MARKS
         dbg_t[2] = dbg_us();
         if (getenv("RDET3_HOST_MARKS")) std::fprintf(stderr, "rdet3d host us: synced %.1f cloud written %.1f launched %.1f\n", dbg_t[0], dbg_t[1], dbg_t[2]);
@@ -1150,7 +1379,18 @@ int rdet3d_collect(rdet3d_t *h, float *centers_xy, int max_centers, int *K, doub
     };
     int rc = wait_tag(&sl.h_out->head.seq);
     if (rc != RDET_OK) { h->in_flight = true; return rc; }
-    const Det3dHead head = sl.h_out->head;
+    Det3dHead head = sl.h_out->head;
+    if (head.err == D3_RETRY) {                                       // more survivors than the short front end holds: the long chain, now
+        h->m_hint = head.M;
+        ++h->n_retry;
+        const int keep = h->path_mode;
+        h->path_mode = 1;
+        rc = d3_launch(h, sl);
+        h->path_mode = keep;
+        if (rc == RDET_OK) rc = wait_tag(&sl.h_out->head.seq);
+        if (rc != RDET_OK) { h->in_flight = true; return rc; }
+        head = sl.h_out->head;
+    }
     h->m_hint = head.M;
     if (head.err) { h->in_flight = true; return head.err; }          // (whatever is left of the chain: synchronised by the next submit)
     *K = head.K;
@@ -1174,11 +1414,27 @@ int rdet3d_handle_cloud(rdet3d_t *h, double stamp, const float *xyzi, int N, flo
     return rdet3d_collect(h, centers_xy, max_centers, K, obs_time);
 }
 
+// test hooks (include/rdet.h does not declare them): which front end the next clouds get (0: by the previous cloud's count, 1: the long chain,
+// 2: the short one whatever the count), and how often each was taken
+int rdet3d_debug_set_path(rdet3d_t *h, int mode)
+{
+    if (!h || mode < 0 || mode > 2) return RDET_ERR_INVALID;
+    h->path_mode = mode;
+    return RDET_OK;
+}
+int rdet3d_debug_path_counts(rdet3d_t *h, unsigned long long *n_short, unsigned long long *n_retry)
+{
+    if (!h) return RDET_ERR_INVALID;
+    if (n_short) *n_short = h->n_short;
+    if (n_retry) *n_retry = h->n_retry;
+    return RDET_OK;
+}
+
 #ifdef RDET_DEBUG_MARKS
-int rdet3d_debug_marks(rdet3d_t *h, unsigned long long *out)   // 2048 x 8
+int rdet3d_debug_marks(rdet3d_t *h, unsigned long long *out)   // 4 x 2048 x 8
 {
     DET3_TRY(h, hipStreamSynchronize(h->stream));
-    DET3_TRY(h, hipMemcpyFromSymbol(out, HIP_SYMBOL(d3_marks), sizeof(unsigned long long) * 2048 * 8));
+    DET3_TRY(h, hipMemcpyFromSymbol(out, HIP_SYMBOL(d3_marks_all), sizeof(unsigned long long) * 4 * 2048 * 8));
     return RDET_OK;
 }
 #endif

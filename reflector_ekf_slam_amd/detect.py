@@ -61,6 +61,8 @@ def _rdet():
         L.rdet3d_handle_cloud.argtypes = [vp, C.c_double, vp, C.c_int, vp, C.c_int, vp, vp]
         L.rdet3d_submit.argtypes = [vp, C.c_double, vp, C.c_int, C.c_int]
         L.rdet3d_collect.argtypes = [vp, vp, C.c_int, vp, vp]
+        L.rdet3d_debug_set_path.argtypes = [vp, C.c_int]
+        L.rdet3d_debug_path_counts.argtypes = [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     _lib_rdet = L
     return L
 
@@ -236,6 +238,20 @@ class PointCloudReflectorDetect:
         if rc != 0:
             raise RdetError(rc, "HandlePointCloud")
         return Observation(float(out[2][0]), out[0][: int(out[1][0])].copy())
+
+    def debug_set_path(self, mode: int) -> None:
+        """Test hook: which front end the next clouds get -- 0 by the previous cloud's survivor count (default), 1 the long chain (four
+        launches: count, write, scatter, boxes), 2 the short one (two launches; a cloud with more survivors than it holds is sent again
+        through the long chain by the collecting call)."""
+        rc = self._L.rdet3d_debug_set_path(self._h, int(mode))
+        if rc != 0:
+            raise RdetError(rc, "debug_set_path")
+
+    def debug_path_counts(self):
+        """(clouds sent through the short front end, of those: sent again through the long chain)"""
+        a, b = C.c_ulonglong(0), C.c_ulonglong(0)
+        self._L.rdet3d_debug_path_counts(self._h, C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
 
     def SubmitPointCloud(self, stamp: float, xyzi) -> None:
         """First half of HandlePointCloud (rdet3d_submit): the cloud goes to the device and its kernels are enqueued; returns at once.

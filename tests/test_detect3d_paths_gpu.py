@@ -1,0 +1,127 @@
+"""The 3D detector's two front ends (round 6).  A cloud whose survivors of the intensity gate fit one workgroup's LDS goes through the
+short one (k3f_gate + k3f_sort: two launches), anything else through the long one (count, write, scatter, boxes: four); a cloud that
+turns out too big for the short one is sent again through the long one by the collecting call.  Nothing of the result may depend on
+which was taken: every cloud below goes through both (forced through the test hook) and must give the oracle's centres bit for bit.
+Reference: src/reflector_detect/point_cloud/point_cloud_reflector_detect.cc:9-106."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _blob(center, n, spread, rng, intensity=200.0):
+    p = rng.normal(0, spread, size=(n, 3)) + np.asarray(center)
+    return np.concatenate([p, np.full((n, 1), intensity)], -1)
+
+
+def _scene(rng, n_clusters, dim=2000, per=(8, 60), spread=0.03, extent=10.0, outliers=30):
+    parts = [_blob((0, 0, 0), dim, extent / 2, rng, intensity=20.0)]
+    for _ in range(n_clusters):
+        parts.append(_blob(rng.uniform(-extent, extent, 3) * np.array([1, 1, 0.05]), int(rng.integers(*per)), spread, rng))
+    if outliers:
+        o = rng.uniform(-extent, extent, (outliers, 3)) * np.array([1, 1, 0.05])
+        parts.append(np.concatenate([o, np.full((outliers, 1), 230.0)], -1))
+    c = np.concatenate(parts).astype(np.float32)
+    return c[rng.permutation(c.shape[0])]
+
+
+def _clouds():
+    from reflector_ekf_slam_amd import synth
+    rng = np.random.default_rng(21)
+    out = {}
+    out["empty"] = np.zeros((0, 4), np.float32)
+    out["nothing_bright"] = _blob((0, 0, 0), 700, 5.0, rng, intensity=20.0).astype(np.float32)
+    out["one_bright_point"] = np.concatenate([_blob((0, 0, 0), 100, 5.0, rng, intensity=20.0), [[1.0, 2.0, 0.1, 250.0]]]).astype(np.float32)
+    out["below_meank"] = np.concatenate([_blob((0, 0, 0), 500, 5.0, rng, 20.0), _blob((2, 1, 0.3), 25, 0.03, rng)]).astype(np.float32)
+    out["thirty_clusters"] = _scene(rng, 30)
+    out["ragged_1025"] = _scene(rng, 12)[:1025]
+    out["ragged_1023"] = _scene(rng, 12)[:1023]
+    out["many_tiles_few_bright"] = np.concatenate([_blob((0, 0, 0), 40000, 6.0, rng, 20.0), _blob((3, 3, 0.2), 40, 0.03, rng),
+                                                   _blob((-4, 2, 0.4), 33, 0.03, rng)]).astype(np.float32)
+    g = np.random.Generator(np.random.PCG64(3))
+    lms = synth.make_world(synth.C4, g)
+    out["world_16_rings"] = synth.make_point_cloud(lms, (34.4, 34.0, 1.15), g)
+    out["world_32_rings"] = synth.make_point_cloud(lms, (30.0, 36.0, -0.7), g, rings=32, n_az=1800)
+    c = _scene(rng, 20)
+    c[100:110, :3] = np.nan
+    c[200:240, :3] = c[200, :3]
+    out["non_finite_and_coincident"] = c
+    # 8192 survivors exactly: the short front end's last size; 8193: one too many
+    big = _scene(rng, 160, dim=3000, per=(40, 70), outliers=200)
+    bright = np.flatnonzero(big[:, 3] > 100.0)
+    assert bright.size > 8200
+    keep = np.ones(big.shape[0], bool)
+    keep[bright[8192:]] = False
+    out["exactly_8192_survivors"] = big[keep]
+    keep[bright[8192]] = True
+    out["8193_survivors"] = big[keep]
+    out["12k_survivors"] = _scene(rng, 240, dim=5000, per=(40, 70), outliers=300)
+    return out
+
+
+def test_both_front_ends_give_the_oracles_centres(oracle_lib):
+    from oracle.binding import oracle_detect3d
+    from reflector_ekf_slam_amd.detect import PointCloudOptions, PointCloudReflectorDetect
+    clouds = _clouds()
+    want = {k: oracle_detect3d(c) for k, c in clouds.items()}
+    assert want["exactly_8192_survivors"][1] == 8192 and want["8193_survivors"][1] == 8193 and want["12k_survivors"][1] > 10000
+    for mode in (1, 2):
+        g = PointCloudReflectorDetect(PointCloudOptions(), max_points=65536)
+        g.debug_set_path(mode)
+        retried = 0
+        for name, c in clouds.items():
+            obs = g.HandlePointCloud(2.5, c)
+            oc, m1, _ = want[name]
+            assert obs.cloud_.shape == oc.shape and np.array_equal(obs.cloud_, oc), (mode, name, obs.cloud_.shape, oc.shape)
+            n_short, n_retry = g.debug_path_counts()
+            if mode == 2 and c.shape[0]:
+                assert (n_retry > retried) == (m1 > 8192), (name, m1, n_retry)       # sent again iff it did not fit
+            retried = n_retry
+        n_short, n_retry = g.debug_path_counts()
+        assert (n_short == 0 and n_retry == 0) if mode == 1 else (n_short == len(clouds) - 1 and n_retry == 2)
+        g.close()
+    assert want["thirty_clusters"][0].shape[0] >= 20 and want["12k_survivors"][0].shape[0] >= 100
+
+
+def test_the_front_end_follows_the_previous_clouds_count(oracle_lib):
+    """Default mode: the first cloud takes the short front end; a cloud after a big one takes the long one; one too big for the short one is
+    sent again (once), and small clouds return to the short one.  Same centres throughout."""
+    from oracle.binding import oracle_detect3d
+    from reflector_ekf_slam_amd.detect import PointCloudOptions, PointCloudReflectorDetect
+    cl = _clouds()
+    seq = ["thirty_clusters", "world_16_rings", "12k_survivors", "12k_survivors", "thirty_clusters", "world_32_rings", "8193_survivors", "empty",
+           "exactly_8192_survivors", "thirty_clusters"]
+    #        short             short             short+again      long             long               short             short+again       -
+    #        long (hint 8193)          long (hint 8192 > 7168)
+    expect = [(1, 0), (2, 0), (3, 1), (3, 1), (3, 1), (4, 1), (5, 2), (5, 2), (5, 2), (5, 2)]
+    g = PointCloudReflectorDetect(PointCloudOptions(), max_points=65536)
+    for name, e in zip(seq, expect):
+        obs = g.HandlePointCloud(1.0, cl[name])
+        oc, _, _ = oracle_detect3d(cl[name])
+        assert np.array_equal(obs.cloud_, oc), name
+        assert g.debug_path_counts() == e, (name, g.debug_path_counts(), e)
+    g.close()
+
+
+def test_two_clouds_on_their_way_through_either_front_end(oracle_lib):
+    """rdet3d_submit / rdet3d_collect with the short front end forced: a cloud that has to be sent again is re-launched by ITS collect, behind
+    the chain of the cloud submitted after it; results are those of the synchronous calls."""
+    from oracle.binding import oracle_detect3d
+    from reflector_ekf_slam_amd.detect import PointCloudOptions, PointCloudReflectorDetect
+    cl = _clouds()
+    names = ["thirty_clusters", "12k_survivors", "world_16_rings", "8193_survivors", "empty", "12k_survivors", "below_meank", "world_32_rings"]
+    g = PointCloudReflectorDetect(PointCloudOptions(), max_points=65536)
+    g.debug_set_path(2)
+    got = []
+    g.SubmitPointCloud(0.0, cl[names[0]])
+    for k in range(1, len(names)):
+        g.SubmitPointCloud(float(k), cl[names[k]])
+        got.append(g.CollectObservation())
+    got.append(g.CollectObservation())
+    for k, (name, obs) in enumerate(zip(names, got)):
+        oc, _, _ = oracle_detect3d(cl[name])
+        assert obs.time_ == float(k) and np.array_equal(obs.cloud_, oc), name
+    assert g.debug_path_counts() == (7, 3)
+    g.close()
