@@ -76,6 +76,7 @@ struct Det3dCtl {
     // the short front end (k3f_sort) found more survivors than it holds: every later kernel of this chain sees M = 0, the last one reports
     // D3_RETRY and the host sends the cloud through the long chain (m_true: the count, for the next cloud's choice)
     int retry, m_true;
+    int arrived;                    // k3f_front: tile workgroups that have written their survivors (back to 0 when the launch ends)
 };
 constexpr int D3_RETRY = 1 << 20;   // (never leaves this file)
 
@@ -118,8 +119,8 @@ struct Det3dBufs {
 
 #ifdef RDET_DEBUG_MARKS
 // in-kernel timelines (k3_clusters, k3_cc_link): wall_clock64() (100 MHz) per workgroup and phase; scripts/gpu_dbg_det3d.py
-// (one table per kernel: 0 k3_clusters, 1 k3_cc_link, 2 k3_knn, 3 k3_cc_min)
-__device__ unsigned long long d3_marks_all[4][2048][8];
+// (one table per kernel: 0 k3_clusters, 1 k3_cc_link, 2 k3_knn, 3 k3_cc_min, 4 k3f_sort)
+__device__ unsigned long long d3_marks_all[5][2048][8];
 #define d3_marks d3_marks_all[D3_KERNEL]
 #define D3_MARK(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) d3_marks[blockIdx.x][i] = wall_clock64(); } while (0)
 #define D3_NOTE(i, v) do { if (threadIdx.x == 0 && blockIdx.x < 2048) d3_marks[blockIdx.x][i] = (unsigned long long)(v); } while (0)
@@ -150,10 +151,13 @@ __device__ static inline float box_d2(float px, float py, float pz, float x0, fl
 
 // Morton code of the grid cell of (x, y); non-finite and out-of-grid coordinates are clamped to the border cells (the
 // clamp is monotone, which is all the sort has to be: locality is a matter of speed, never of the result)
+// (G: the grid's side; ginv is always GRID_G cells per extent, a coarser grid scales it)
+template <int G = GRID_G>
 __device__ static inline int cell_code(float x, float y, float gx0, float gy0, float ginv)
 {
-    const float fx = fminf(fmaxf((x - gx0) * ginv, 0.f), (float)(GRID_G - 1));
-    const float fy = fminf(fmaxf((y - gy0) * ginv, 0.f), (float)(GRID_G - 1));
+    const float gs = ginv * ((float)G / (float)GRID_G);
+    const float fx = fminf(fmaxf((x - gx0) * gs, 0.f), (float)(G - 1));
+    const float fy = fminf(fmaxf((y - gy0) * gs, 0.f), (float)(G - 1));
     unsigned cx = (unsigned)(int)fx, cy = (unsigned)(int)fy;
     cx = (cx | (cx << 4)) & 0x0f0fu; cx = (cx | (cx << 2)) & 0x3333u; cx = (cx | (cx << 1)) & 0x5555u;
     cy = (cy | (cy << 4)) & 0x0f0fu; cy = (cy | (cy << 2)) & 0x3333u; cy = (cy | (cy << 1)) & 0x5555u;
@@ -189,6 +193,17 @@ __device__ static inline double wave_sum_f64(double v, int lane)
 {
     v += lane_xor_f64<1>(v, lane); v += lane_xor_f64<2>(v, lane); v += lane_xor_f64<4>(v, lane);
     v += lane_xor_f64<8>(v, lane); v += lane_xor_f64<16>(v, lane); v += lane_xor_f64<32>(v, lane);
+    return v;
+}
+// inclusive scan of one int per lane (row shifts, then the row broadcasts of gfx9)
+__device__ static inline int wave_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);              // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);              // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);              // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);              // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);              // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);              // row_bcast:31 into rows 2 and 3
     return v;
 }
 // lanes of a wave that hold the same cell code (< 0: none): the lowest such lane, how many there are, and this lane's rank
@@ -363,6 +378,7 @@ __global__ __launch_bounds__(256) void k3_boxes(Det3dBufs B, int N)
 // coalesced stores.  Node numbers are the same as the long chain's (tile prefix + place in the tile = arrival index among the survivors),
 // the order inside a cell is as arbitrary as there: nothing of the result can tell the two front ends apart.
 constexpr int MFAST = 8192, MFAST_PT = MFAST / 1024;
+constexpr int FGRID_G = 64, FGRID_CELLS = FGRID_G * FGRID_G;     // k3f_sort's grid: at most two points per cell on average, a quarter of the cells to clear and scan
 __global__ __launch_bounds__(1024) void k3f_gate(Det3dBufs B, int N, double intensity_min)
 {
     __shared__ int wsum[16];
@@ -382,17 +398,23 @@ __global__ __launch_bounds__(1024) void k3f_gate(Det3dBufs B, int N, double inte
     }
     if (tid == 0) B.cnt[blockIdx.x] = tot;
 }
-__global__ __launch_bounds__(1024) void k3f_sort(Det3dBufs B, int N, int ftiles)
+#define D3_KERNEL 4
+// what another workgroup of the SAME launch has written (k3f_front): past this XCD's L2
+template <bool DEV, typename T>
+__device__ static inline T f_ld(const T *p) { return DEV ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p; }
+template <bool DEV>
+__device__ static inline void f_sort_body(const Det3dBufs &B, int N, int ftiles)
 {
     __shared__ int s_pre[1024 + 1];
     __shared__ int s_w[16];
-    __shared__ __attribute__((aligned(16))) int s_mem[4 * MFAST];                  // the cell histogram (16 k ints), then the sorted copy: x | y | z | node
-    static_assert(GRID_CELLS <= 4 * MFAST && GRID_CELLS == 16 * 1024, "k3f_sort's LDS plan");
+    __shared__ __attribute__((aligned(16))) int s_mem[4 * MFAST];                  // the cell histogram (4 k ints), then the sorted copy: x | y | z | node
+    static_assert(FGRID_CELLS <= 4 * MFAST && FGRID_CELLS == 4 * 1024, "k3f_sort's LDS plan");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = (tid < ftiles) ? B.cnt[tid] : 0;
+    D3_MARK(0);
+    const int c = (tid < ftiles) ? f_ld<DEV>(&B.cnt[tid]) : 0;
     const float gx0 = B.ctl->gx0, gy0 = B.ctl->gy0, ginv = B.ctl->ginv;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) s_mem[tid + 1024 * k] = 0;
+    for (int k = 0; k < FGRID_CELLS / 1024; ++k) s_mem[tid + 1024 * k] = 0;
     // exclusive scan of the tiles' counts
     int incl = c;
 #pragma unroll
@@ -409,53 +431,64 @@ __global__ __launch_bounds__(1024) void k3f_sort(Det3dBufs B, int N, int ftiles)
         if (tid == 0) { B.ctl->M = 0; B.ctl->M2 = 0; B.ctl->K = 0; B.ctl->err = 0; B.ctl->nroots = 0; B.ctl->retry = 1; B.ctl->m_true = M; }
         return;
     }
+    D3_MARK(1);
     // the survivors, MFAST_PT per thread: node g sits in tile t = the last one whose prefix is <= g, at place g - prefix
     float x[MFAST_PT], y[MFAST_PT], z[MFAST_PT];
     int code[MFAST_PT], rank[MFAST_PT];
-    int steps = 0;
-    while ((1 << steps) < ftiles) ++steps;
+    {
+        int steps = 0;
+        while ((1 << steps) < ftiles) ++steps;
+        int t[MFAST_PT];
 #pragma unroll
-    for (int r = 0; r < MFAST_PT; ++r) {
-        const int g = tid + 1024 * r;
-        int t = 0;
-        for (int b = steps - 1; b >= 0; --b) { const int u = t | (1 << b); if (u < ftiles && s_pre[u] <= g) t = u; }
-        const int idx = (g < M) ? t * 1024 + (g - s_pre[t]) : 0;
-        x[r] = B.p1[idx]; y[r] = B.p1[B.cap1 + idx]; z[r] = B.p1[2 * B.cap1 + idx];
+        for (int r = 0; r < MFAST_PT; ++r) t[r] = 0;
+        for (int b = steps - 1; b >= 0; --b) {                                    // (all of a thread's searches side by side: one LDS round trip per bit)
+#pragma unroll
+            for (int r = 0; r < MFAST_PT; ++r) { const int u = t[r] | (1 << b); if (u < ftiles && s_pre[u] <= tid + 1024 * r) t[r] = u; }
+        }
+#pragma unroll
+        for (int r = 0; r < MFAST_PT; ++r) {
+            const int g = tid + 1024 * r;
+            x[r] = y[r] = z[r] = 0.f;
+            if (g < M) {                                                          // (a load nobody needs still costs its cycles of the CU's one memory pipeline)
+                const int idx = t[r] * 1024 + (g - s_pre[t[r]]);
+                x[r] = f_ld<DEV>(&B.p1[idx]); y[r] = f_ld<DEV>(&B.p1[B.cap1 + idx]); z[r] = f_ld<DEV>(&B.p1[2 * B.cap1 + idx]);
+            }
+        }
     }
 #pragma unroll
     for (int r = 0; r < MFAST_PT; ++r) {
         const int g = tid + 1024 * r;
-        code[r] = cell_code(x[r], y[r], gx0, gy0, ginv);
+        code[r] = cell_code<FGRID_G>(x[r], y[r], gx0, gy0, ginv);
+        if (r == 0) D3_MARK(2);
         rank[r] = (g < M) ? atomicAdd(&s_mem[code[r]], 1) : 0;
     }
     __syncthreads();
-    // exclusive scan of the 16 k cells: sixteen consecutive cells per thread
+    D3_MARK(3);
+    // exclusive scan of the 4 k cells: wave w takes the cells [256 w, + 256) in four rounds of 64 consecutive ones (conflict-free
+    // LDS accesses, the scan over the lanes on DPP); the chunks' bases stay apart (s_w) and are added when a cell is looked up.  (Sixteen
+    // consecutive cells per THREAD, the first version, was a 16-way bank conflict on every access: 4 us.)
     {
-        int4 v[4];
+        int carry = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = *(const int4 *)&s_mem[16 * tid + 4 * k];
-        int run = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int a = v[k].x, b = v[k].y, cc = v[k].z, d = v[k].w;
-            v[k].x = run; v[k].y = run + a; v[k].z = run + a + b; v[k].w = run + a + b + cc;
-            run += a + b + cc + d;
+        for (int k = 0; k < FGRID_CELLS / 1024; ++k) {
+            const int a = (FGRID_CELLS / 16) * wave + 64 * k + lane;
+            const int v = s_mem[a];
+            const int inc = wave_incl_scan(v);
+            s_mem[a] = carry + inc - v;
+            carry += __builtin_amdgcn_readlane(inc, 63);
         }
-        int inc2 = run;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc2, off, 64); if (lane >= off) inc2 += t; }
-        if (lane == 63) s_w[wave] = inc2;                                         // (two barriers since anybody read the tiles' sums)
-        __syncthreads();
-        int base = inc2 - run;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) if (w < wave) base += s_w[w];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { v[k].x += base; v[k].y += base; v[k].z += base; v[k].w += base; *(int4 *)&s_mem[16 * tid + 4 * k] = v[k]; }
+        if (lane == 0) s_w[wave] = carry;                                         // (two barriers since anybody read the tiles' sums)
     }
     __syncthreads();
+    int cbase = 0;                                                                // lane w: the cells in front of chunk w
+    {
+        const int v = (lane < 16) ? s_w[lane] : 0;
+        cbase = wave_incl_scan(v) - v;
+    }
+    D3_MARK(4);
     int pos[MFAST_PT];
 #pragma unroll
-    for (int r = 0; r < MFAST_PT; ++r) pos[r] = s_mem[code[r]] + rank[r];
+    for (int r = 0; r < MFAST_PT; ++r) pos[r] = s_mem[code[r]] + __shfl(cbase, code[r] / (FGRID_CELLS / 16), 64) + rank[r];
     __syncthreads();
     float *sx = reinterpret_cast<float *>(s_mem), *sy = sx + MFAST, *sz = sx + 2 * MFAST;
     int *sp = s_mem + 3 * MFAST;
@@ -465,6 +498,7 @@ __global__ __launch_bounds__(1024) void k3f_sort(Det3dBufs B, int N, int ftiles)
         if (g < M) { sx[pos[r]] = x[r]; sy[pos[r]] = y[r]; sz[pos[r]] = z[r]; sp[pos[r]] = g; }
     }
     __syncthreads();
+    D3_MARK(5);
     for (int s0 = 0; s0 < M; s0 += 1024) {
         const int sidx = s0 + tid;
         const bool v = sidx < M;
@@ -477,7 +511,46 @@ __global__ __launch_bounds__(1024) void k3f_sort(Det3dBufs B, int N, int ftiles)
         tile_boxes(B.box, sidx, M, px, py, pz);
     }
     if (tid == 0) { B.ctl->M = M; B.ctl->M2 = 0; B.ctl->K = 0; B.ctl->err = 0; B.ctl->nroots = 0; B.ctl->retry = 0; B.ctl->m_true = M; }
+    D3_MARK(6);
 }
+__global__ __launch_bounds__(1024) void k3f_sort(Det3dBufs B, int N, int ftiles) { f_sort_body<false>(B, N, ftiles); }
+// ... and both in ONE launch: the tile workgroup that counts itself in last goes on as the sorting workgroup.  No workgroup waits for
+// another: a tile's survivors and count are written through to memory (device-scope stores), waited for, and only then does the tile's
+// first thread bump the arrival counter; whoever sees ftiles - 1 there knows everything has landed and reads it past its own L2
+// (device-scope loads).  One kernel boundary and one kernel's start-up less than k3f_gate + k3f_sort.
+__global__ __launch_bounds__(1024) void k3f_front(Det3dBufs B, int N, double intensity_min, int ftiles)
+{
+    __shared__ int wsum[16];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x * 1024 + tid;
+    const float4 cur = (i < N) ? ((const float4 *)B.xyzi)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool keep = i < N && (double)cur.w > intensity_min;      // :33
+    const unsigned long long bal = __ballot(keep);
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const int c = wsum[w]; if (w < wave) off += c; tot += c; }
+    if (keep) {
+        const int pos = blockIdx.x * 1024 + off + __popcll(bal & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+        __hip_atomic_store(&B.p1[pos], cur.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&B.p1[B.cap1 + pos], cur.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&B.p1[2 * B.cap1 + pos], cur.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) __hip_atomic_store(&B.cnt[blockIdx.x], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // every wave: its stores have been acknowledged
+    __syncthreads();
+    if (tid == 0) {
+        const int before = __hip_atomic_fetch_add(&B.ctl->arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = before == ftiles - 1;
+        if (s_last) __hip_atomic_store(&B.ctl->arrived, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (for the next cloud)
+    }
+    __syncthreads();
+    if (!s_last) return;
+    f_sort_body<true>(B, N, ftiles);
+}
+#undef D3_KERNEL
 
 // ---- the three neighbour sweeps: ONE WAVE PER QUERY, lane = candidate ----------------------------------------
 // (Round 4.  Earlier forms, all exact, all parity-green: lane = query with the candidates through the scalar cache and a
@@ -1204,8 +1277,12 @@ static int d3_launch(rdet3d_t *h, rdet3d::Slot &sl)
     sl.fast = ftiles <= 1024 && (h->path_mode == 2 || (h->path_mode == 0 && h->m_hint <= MFAST - MFAST / 8));
     if (sl.fast) {
         ++h->n_short;
+#ifdef D3_TWO_LAUNCH_FRONT
         hipLaunchKernelGGL(k3f_gate, dim3(ftiles), dim3(1024), 0, h->stream, B, N, h->opt.intensity_min);
         hipLaunchKernelGGL(k3f_sort, dim3(1), dim3(1024), 0, h->stream, B, N, ftiles);
+#else
+        hipLaunchKernelGGL(k3f_front, dim3(ftiles), dim3(1024), 0, h->stream, B, N, h->opt.intensity_min, ftiles);
+#endif
     } else {
         hipLaunchKernelGGL(k3_filter_count, dim3(ftiles), dim3(1024), 0, h->stream, B, N, h->opt.intensity_min);
         hipLaunchKernelGGL(k3_filter_write, dim3(ftiles + GRID_CELLS / 1024), dim3(1024), 0, h->stream, B, N, h->opt.intensity_min, ftiles);
@@ -1431,10 +1508,10 @@ int rdet3d_debug_path_counts(rdet3d_t *h, unsigned long long *n_short, unsigned 
 }
 
 #ifdef RDET_DEBUG_MARKS
-int rdet3d_debug_marks(rdet3d_t *h, unsigned long long *out)   // 4 x 2048 x 8
+int rdet3d_debug_marks(rdet3d_t *h, unsigned long long *out)   // 5 x 2048 x 8
 {
     DET3_TRY(h, hipStreamSynchronize(h->stream));
-    DET3_TRY(h, hipMemcpyFromSymbol(out, HIP_SYMBOL(d3_marks_all), sizeof(unsigned long long) * 4 * 2048 * 8));
+    DET3_TRY(h, hipMemcpyFromSymbol(out, HIP_SYMBOL(d3_marks_all), sizeof(unsigned long long) * 5 * 2048 * 8));
     return RDET_OK;
 }
 #endif
