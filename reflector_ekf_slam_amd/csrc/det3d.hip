@@ -119,8 +119,8 @@ struct Det3dBufs {
 
 #ifdef RDET_DEBUG_MARKS
 // in-kernel timelines (k3_clusters, k3_cc_link): wall_clock64() (100 MHz) per workgroup and phase; scripts/gpu_dbg_det3d.py
-// (one table per kernel: 0 k3_clusters, 1 k3_cc_link, 2 k3_knn, 3 k3_cc_min, 4 k3f_sort)
-__device__ unsigned long long d3_marks_all[5][2048][8];
+// (one table per kernel: 0 k3_clusters, 1 k3_cc_link, 2 k3_knn, 3 k3_cc_min, 4 k3f_sort, 5 k3f_clusters)
+__device__ unsigned long long d3_marks_all[6][2048][8];
 #define d3_marks d3_marks_all[D3_KERNEL]
 #define D3_MARK(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) d3_marks[blockIdx.x][i] = wall_clock64(); } while (0)
 #define D3_NOTE(i, v) do { if (threadIdx.x == 0 && blockIdx.x < 2048) d3_marks[blockIdx.x][i] = (unsigned long long)(v); } while (0)
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void k3_boxes(Det3dBufs B, int N)
 // whose return value is the rank inside the cell, the scan of the 16 k cells, the sorted copy (over the histogram's storage), boxes, and
 // coalesced stores.  Node numbers are the same as the long chain's (tile prefix + place in the tile = arrival index among the survivors),
 // the order inside a cell is as arbitrary as there: nothing of the result can tell the two front ends apart.
-constexpr int MFAST = 8192, MFAST_PT = MFAST / 1024;
+constexpr int MFAST = 5120, MFAST_PT = MFAST / 1024;   // (at 6.5 k survivors one workgroup's sort and the LDS forest are no faster than the long chain; at 3.3 k they save 7 us)
 constexpr int FGRID_G = 64, FGRID_CELLS = FGRID_G * FGRID_G;     // k3f_sort's grid: at most two points per cell on average, a quarter of the cells to clear and scan
 __global__ __launch_bounds__(1024) void k3f_gate(Det3dBufs B, int N, double intensity_min)
 {
@@ -443,7 +443,11 @@ __device__ static inline void f_sort_body(const Det3dBufs &B, int N, int ftiles)
         for (int r = 0; r < MFAST_PT; ++r) t[r] = 0;
         for (int b = steps - 1; b >= 0; --b) {                                    // (all of a thread's searches side by side: one LDS round trip per bit)
 #pragma unroll
-            for (int r = 0; r < MFAST_PT; ++r) { const int u = t[r] | (1 << b); if (u < ftiles && s_pre[u] <= tid + 1024 * r) t[r] = u; }
+            for (int r = 0; r < MFAST_PT; ++r) {
+                if (1024 * r >= M) break;                                         // (whole rounds nobody has an item in: skipped by every wave)
+                const int u = t[r] | (1 << b);
+                if (u < ftiles && s_pre[u] <= tid + 1024 * r) t[r] = u;
+            }
         }
 #pragma unroll
         for (int r = 0; r < MFAST_PT; ++r) {
@@ -458,9 +462,12 @@ __device__ static inline void f_sort_body(const Det3dBufs &B, int N, int ftiles)
 #pragma unroll
     for (int r = 0; r < MFAST_PT; ++r) {
         const int g = tid + 1024 * r;
-        code[r] = cell_code<FGRID_G>(x[r], y[r], gx0, gy0, ginv);
+        code[r] = rank[r] = 0;
+        if (g < M) {
+            code[r] = cell_code<FGRID_G>(x[r], y[r], gx0, gy0, ginv);
+            rank[r] = atomicAdd(&s_mem[code[r]], 1);
+        }
         if (r == 0) D3_MARK(2);
-        rank[r] = (g < M) ? atomicAdd(&s_mem[code[r]], 1) : 0;
     }
     __syncthreads();
     D3_MARK(3);
@@ -488,7 +495,10 @@ __device__ static inline void f_sort_body(const Det3dBufs &B, int N, int ftiles)
     D3_MARK(4);
     int pos[MFAST_PT];
 #pragma unroll
-    for (int r = 0; r < MFAST_PT; ++r) pos[r] = s_mem[code[r]] + __shfl(cbase, code[r] / (FGRID_CELLS / 16), 64) + rank[r];
+    for (int r = 0; r < MFAST_PT; ++r) {
+        pos[r] = 0;
+        if (1024 * r < M) pos[r] = s_mem[code[r]] + __shfl(cbase, code[r] / (FGRID_CELLS / 16), 64) + rank[r];
+    }
     __syncthreads();
     float *sx = reinterpret_cast<float *>(s_mem), *sy = sx + MFAST, *sz = sx + 2 * MFAST;
     int *sp = s_mem + 3 * MFAST;
@@ -506,7 +516,6 @@ __device__ static inline void f_sort_body(const Det3dBufs &B, int N, int ftiles)
         if (v) {
             B.s1[sidx] = px; B.s1[B.cap + sidx] = py; B.s1[2 * B.cap + sidx] = pz;
             B.perm[sidx] = sp[sidx];
-            B.cnt[sidx] = 0; B.first[sidx] = 0x7fffffff; B.last[sidx] = 0;       // (what k3_finish_a expects; the tiles' counts have been read)
         }
         tile_boxes(B.box, sidx, M, px, py, pz);
     }
@@ -607,7 +616,7 @@ __device__ static inline int nearest_of(unsigned long long set, float v, int lan
 constexpr int QW = 4;               // queries (waves) per workgroup
 constexpr int Q_GRID = 2048;        // workgroups: the queries are dealt round-robin
 #ifndef D3_KNN_AHEAD
-#define D3_KNN_AHEAD 4
+#define D3_KNN_AHEAD 3
 #endif
 #ifndef D3_CCMIN_AHEAD
 #define D3_CCMIN_AHEAD 4
@@ -1219,6 +1228,169 @@ __global__ __launch_bounds__(256) void k3_clusters(Det3dBufs B, int max_centers,
 }
 #undef D3_KERNEL
 
+// ---- the short back end (round 6): k3_finish_a + k3_clusters in ONE launch for clouds of at most MFAST survivors ---------------------
+// Every workgroup takes the whole forest into LDS for itself -- parents by node (one trip to memory), then roots by chasing in LDS (a hop is
+// an LDS access, not a trip to L2), sizes by run-length counting (consecutive nodes mostly share their component), the members' (x, y) by
+// node -- gates and ranks the components like k3_clusters, and each of its four waves sums one component: its members are the nodes whose
+// root it is, found IN NODE ORDER = arrival order by a sweep over the LDS table, so the float32 sums of compute3DCentroid (:94) need no
+// re-ordering (k3_clusters gathers from the sorted copy and sorts by node id: O(size^2)).  No sizes, extents or root lists in memory.
+#define D3_KERNEL 5
+constexpr int FC_T = 1024, FC_W = FC_T / 64;                                      // threads / waves = components per workgroup
+__global__ __launch_bounds__(FC_T) void k3f_clusters(Det3dBufs B, int max_centers, float sx, float sy, float cs, float sn)
+{
+#pragma clang fp contract(off)
+    __shared__ int par[MFAST];                                                    // by node: parent, then root (-1: SOR's outliers)
+    __shared__ int csz[MFAST];                                                    // by root: component size
+    __shared__ float nx[MFAST], ny[MFAST];                                        // by node
+    __shared__ __attribute__((aligned(16))) unsigned long long s_key[RDET_MAX_CENTERS];
+    __shared__ int s_root[RDET_MAX_CENTERS], s_size[RDET_MAX_CENTERS], s_byrank[RDET_MAX_CENTERS];
+    __shared__ int s_n, s_err;
+    __shared__ __attribute__((aligned(16))) float m_x[FC_W][MAX_SZ], m_y[FC_W][MAX_SZ];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    D3_MARK(0);
+    const int M = B.ctl->M;
+    if (tid == 0) { s_n = 0; s_err = 0; }
+    if (tid < RDET_MAX_CENTERS) s_key[tid] = ~0ull;                                                           // (no real key is above it)
+    // one trip: parents by node; coordinates and node numbers by sorted position (eight of each per thread in flight)
+    for (int b0 = 0; b0 < M; b0 += FC_T * 8) {
+        int lb[8], pn[8];
+        float px[8], py[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = b0 + tid + FC_T * k;
+            const bool v = i < M;
+            lb[k] = v ? B.label[i] : -1;
+            pn[k] = v ? B.perm[i] : 0; px[k] = v ? B.s1[i] : 0.f; py[k] = v ? B.s1[B.cap + i] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = b0 + tid + FC_T * k;
+            if (i < M) { par[i] = lb[k]; csz[i] = 0; nx[pn[k]] = px[k]; ny[pn[k]] = py[k]; }
+        }
+    }
+    __syncthreads();
+    D3_MARK(1);
+    // roots + sizes: a thread takes four consecutive nodes (started at an offset that keeps the lanes off each other's banks), chases them
+    // side by side, and adds a run of equal roots to that root's size with one atomic.  (Sixteen nodes per thread, the first version,
+    // left three quarters of the workgroup idle at M = 3 k and took 6 us: a wave's chase is a chain of LDS round trips.)
+    for (int blk = tid; 4 * blk < M; blk += FC_T) {
+        int r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int n = 4 * blk + ((j + (blk >> 4)) & 3); r[j] = (n < M) ? par[n] : -1; }
+        bool moving = true;
+        while (moving) {
+            moving = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const int p = (r[j] >= 0) ? par[r[j]] : -1; moving |= p != r[j]; r[j] = p; }
+        }
+        int run_root = -1, run = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = 4 * blk + ((j + (blk >> 4)) & 3);
+            if (n < M && r[j] >= 0) par[n] = r[j];                               // (a root is an ancestor: whoever still chases through n stays right)
+            if (r[j] != run_root) { if (run_root >= 0) atomicAdd(&csz[run_root], run); run_root = r[j]; run = 0; }
+            ++run;
+        }
+        if (run_root >= 0) atomicAdd(&csz[run_root], run);
+    }
+    __syncthreads();
+    D3_MARK(2);
+    for (int n = tid; n < M; n += FC_T) {
+        const int c = (par[n] == n) ? csz[n] : 0;
+        if (c >= MIN_SZ && c <= MAX_SZ) {                                         // :70-71
+            const int pos = atomicAdd(&s_n, 1);
+            if (pos < RDET_MAX_CENTERS) {
+                s_root[pos] = n; s_size[pos] = c;
+                s_key[pos] = ((unsigned long long)(unsigned)(MAX_SZ - c) << 32) | (unsigned)n;
+            } else s_err = RDET_ERR_CAPACITY;
+        }
+    }
+    __syncthreads();
+    D3_MARK(3);
+    int n = min(s_n, RDET_MAX_CENTERS);
+    int err = s_err;
+    if (n > max_centers) { err = RDET_ERR_BUFFER; n = 0; }
+    if (B.ctl->retry) { err = D3_RETRY; n = 0; }
+    // rank = the number of keys below one's own ((MAX_SZ - size, root): size descending, root ascending); four threads per entry
+    for (int e0 = 0; e0 < n; e0 += FC_T / 4) {
+        const int e = e0 + (tid >> 2), sub = tid & 3;
+        if (e >= RDET_MAX_CENTERS) break;
+        const unsigned long long me = s_key[e];
+        int rank = 0;
+#pragma unroll 4
+        for (int k = 2 * sub; k < n; k += 8) {
+            const ulonglong2 kk = *(const ulonglong2 *)&s_key[k];
+            rank += (kk.x < me) + (kk.y < me);
+        }
+        rank += __shfl_xor(rank, 1, 64); rank += __shfl_xor(rank, 2, 64);
+        if (sub == 0 && e < n) s_byrank[rank] = e;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && tid == 0) {
+        B.ctl->K = n; B.ctl->err = err;
+        d3_host_store16(&B.hout->head, (unsigned)n, (unsigned)err, (unsigned)B.ctl->m_true, (unsigned)B.seq);   // the centres follow, each with its own tag
+    }
+    // the next cloud's grid: as k3_clusters
+    D3_MARK(4);
+    if (blockIdx.x == gridDim.x - 1 && wave == FC_W - 1) {
+        const int ntiles = (M + BOX_PTS - 1) / BOX_PTS;
+        float x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY;
+        for (int t = lane; t < ntiles; t += 64) {
+            const float4 lo = *(const float4 *)(B.box2 + 8 * t), hi = *(const float4 *)(B.box2 + 8 * t + 4);
+            x0 = fminf(x0, lo.x); y0 = fminf(y0, lo.y); x1 = fmaxf(x1, lo.w); y1 = fmaxf(y1, hi.x);
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            x0 = fminf(x0, __shfl_xor(x0, off, 64)); y0 = fminf(y0, __shfl_xor(y0, off, 64));
+            x1 = fmaxf(x1, __shfl_xor(x1, off, 64)); y1 = fmaxf(y1, __shfl_xor(y1, off, 64));
+        }
+        if (lane == 0 && x0 <= x1 && y0 <= y1 && fabsf(x0) < 1e30f && fabsf(x1) < 1e30f && fabsf(y0) < 1e30f && fabsf(y1) < 1e30f) {
+            const float ext = fmaxf(fmaxf(x1 - x0, y1 - y0) * 1.05f, 0.125f * GRID_G);
+            B.ctl->gx0 = 0.5f * (x0 + x1) - 0.5f * ext; B.ctl->gy0 = 0.5f * (y0 + y1) - 0.5f * ext; B.ctl->ginv = (float)GRID_G / ext;
+        }
+    }
+    const int rank = blockIdx.x * FC_W + wave;
+    if (rank >= n) return;
+    const int e = s_byrank[rank], root = s_root[e], size = s_size[e];
+    // the members in node order: the nodes whose root this is (none is below the root: a component's label is its smallest node)
+    int have = 0;
+    for (int n0 = root & ~63; n0 < M && have < size; n0 += 512) {                 // (eight table reads in flight; a block without a member costs a compare)
+        int pr[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int nn = n0 + 64 * u + lane; pr[u] = (nn < M) ? par[nn] : -1; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int nn = n0 + 64 * u + lane;
+            const bool mem = pr[u] == root;
+            const unsigned long long mask = __ballot(mem);
+            if (mask == 0ull) continue;                                           // (reading every block's coordinates up front, predicated, was slower: 2.8 -> 4.3 us for 112 members)
+            if (mem) {
+                const int k = have + __popcll(mask & ((1ull << lane) - 1));
+                m_x[wave][k] = nx[nn]; m_y[wave][k] = ny[nn];
+            }
+            have += __popcll(mask);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    D3_MARK(5);
+    float cx = 0.f, cy = 0.f;
+    int q = 0;
+#pragma unroll 4
+    for (; q + 4 <= size; q += 4) {
+        const float4 vx = *(const float4 *)&m_x[wave][q], vy = *(const float4 *)&m_y[wave][q];
+        cx += vx.x; cx += vx.y; cx += vx.z; cx += vx.w;
+        cy += vy.x; cy += vy.y; cy += vy.z; cy += vy.w;
+    }
+    for (; q < size; ++q) { cx += m_x[wave][q]; cy += m_y[wave][q]; }
+    if (lane == 0) {
+        const float sz = (float)size;
+        cx /= sz; cy /= sz;
+        const float ox = (cs * cx + (-sn) * cy) + sx, oy = (sn * cx + cs * cy) + sy;   // :96 Project2D(s2b).cast<float>() * p
+        d3_host_store16(&B.hout->centers[rank], __float_as_uint(ox), __float_as_uint(oy), (unsigned)B.seq, 0u);
+    }
+    D3_MARK(6);
+}
+#undef D3_KERNEL
+
 }  // namespace
 
 struct rdet3d {
@@ -1274,7 +1446,7 @@ static int d3_launch(rdet3d_t *h, rdet3d::Slot &sl)
     B.ctl = h->d_ctl; B.cap = h->max_points; B.cap1 = (h->max_points + 1023) & ~1023;
     B.hout = sl.dv_out; B.seq = sl.seq = ++h->seq;
     const int ftiles = (N + 1023) / 1024, b256 = (N + 255) / 256, ntiles_ub = (N + BOX_PTS - 1) / BOX_PTS;
-    sl.fast = ftiles <= 1024 && (h->path_mode == 2 || (h->path_mode == 0 && h->m_hint <= MFAST - MFAST / 8));
+    sl.fast = ftiles <= 1024 && (h->path_mode == 2 || (h->path_mode == 0 && h->m_hint <= MFAST - MFAST / 10));
     if (sl.fast) {
         ++h->n_short;
 #ifdef D3_TWO_LAUNCH_FRONT
@@ -1294,9 +1466,14 @@ static int d3_launch(rdet3d_t *h, rdet3d::Slot &sl)
     hipLaunchKernelGGL(k3_cc_min, dim3(qblocks), dim3(64 * QW), 0, h->stream, B, N, ntiles_ub, h->m_hint);
     hipLaunchKernelGGL(k3_cc_link, dim3(qblocks), dim3(64 * QW), 0, h->stream, B, N, ntiles_ub, h->m_hint);
     const float sa = (float)h->s2b[2];
-    hipLaunchKernelGGL(k3_finish_a, dim3(b256), dim3(256), 0, h->stream, B, N);
-    hipLaunchKernelGGL(k3_clusters, dim3(RDET_MAX_CENTERS / 4), dim3(256), 0, h->stream, B, max_centers < RDET_MAX_CENTERS ? max_centers : RDET_MAX_CENTERS,
-                       (float)h->s2b[0], (float)h->s2b[1], cosf(sa), sinf(sa));
+    if (sl.fast) {                                                     // (M <= MFAST, or M = 0 and D3_RETRY)
+        hipLaunchKernelGGL(k3f_clusters, dim3(RDET_MAX_CENTERS / FC_W), dim3(FC_T), 0, h->stream, B, max_centers < RDET_MAX_CENTERS ? max_centers : RDET_MAX_CENTERS,
+                           (float)h->s2b[0], (float)h->s2b[1], cosf(sa), sinf(sa));
+    } else {
+        hipLaunchKernelGGL(k3_finish_a, dim3(b256), dim3(256), 0, h->stream, B, N);
+        hipLaunchKernelGGL(k3_clusters, dim3(RDET_MAX_CENTERS / 4), dim3(256), 0, h->stream, B, max_centers < RDET_MAX_CENTERS ? max_centers : RDET_MAX_CENTERS,
+                           (float)h->s2b[0], (float)h->s2b[1], cosf(sa), sinf(sa));
+    }
     DET3_TRY(h, hipGetLastError());
     return RDET_OK;
 }
@@ -1508,10 +1685,10 @@ int rdet3d_debug_path_counts(rdet3d_t *h, unsigned long long *n_short, unsigned 
 }
 
 #ifdef RDET_DEBUG_MARKS
-int rdet3d_debug_marks(rdet3d_t *h, unsigned long long *out)   // 5 x 2048 x 8
+int rdet3d_debug_marks(rdet3d_t *h, unsigned long long *out)   // 6 x 2048 x 8
 {
     DET3_TRY(h, hipStreamSynchronize(h->stream));
-    DET3_TRY(h, hipMemcpyFromSymbol(out, HIP_SYMBOL(d3_marks_all), sizeof(unsigned long long) * 5 * 2048 * 8));
+    DET3_TRY(h, hipMemcpyFromSymbol(out, HIP_SYMBOL(d3_marks_all), sizeof(unsigned long long) * 6 * 2048 * 8));
     return RDET_OK;
 }
 #endif

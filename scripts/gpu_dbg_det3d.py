@@ -17,13 +17,18 @@ cloud = synth.make_point_cloud(lms, pose, rng, rings=rings, n_az=1800)
 g = PointCloudReflectorDetect(PointCloudOptions(), max_points=65536)
 for _ in range(8):
     g.HandlePointCloud(1.0, cloud)
-m_all = np.zeros((5, 2048, 8), np.uint64)
+m_all = np.zeros((6, 2048, 8), np.uint64)
 g._L.rdet3d_debug_marks.argtypes = [C.c_void_p, C.c_void_p]
 g._L.rdet3d_debug_marks(g._h, m_all.ctypes.data)
 m_all = m_all.astype(np.int64)
 r = m_all[4][int(np.argmax(m_all[4][:, 0]))]            # (k3f_front: the tile workgroup that arrived last)
 print("k3f_sort (one workgroup): prefix %.2f  survivors in registers %.2f  histogram %.2f  scan %.2f  sorted in LDS %.2f  out + boxes %.2f  = %.2f us" % (
     (r[1] - r[0]) / 100, (r[2] - r[1]) / 100, (r[3] - r[2]) / 100, (r[4] - r[3]) / 100, (r[5] - r[4]) / 100, (r[6] - r[5]) / 100, (r[6] - r[0]) / 100))
+for b in range(0, 8):
+    r = m_all[5][b]
+    if r[6] > r[0] > 0:
+        print("k3f_clusters wg %d (wave 0): tables in LDS %.2f  roots + sizes %.2f  gate %.2f  rank %.2f  (grid) members %.2f  sum + publish %.2f  = %.2f us" % (
+            b, (r[1] - r[0]) / 100, (r[2] - r[1]) / 100, (r[3] - r[2]) / 100, (r[4] - r[3]) / 100, (r[5] - r[4]) / 100, (r[6] - r[5]) / 100, (r[6] - r[0]) / 100))
 m = m_all[0][:64]
 t0 = m[:, 0].min()
 print("k3_clusters")

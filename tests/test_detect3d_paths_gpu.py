@@ -9,6 +9,8 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+MFAST = 5120            # det3d.hip: what the short front end and the LDS back end hold
+HINT_MAX = MFAST - MFAST // 10
 
 
 def _blob(center, n, spread, rng, intensity=200.0):
@@ -48,15 +50,16 @@ def _clouds():
     c[100:110, :3] = np.nan
     c[200:240, :3] = c[200, :3]
     out["non_finite_and_coincident"] = c
-    # 8192 survivors exactly: the short front end's last size; 8193: one too many
-    big = _scene(rng, 160, dim=3000, per=(40, 70), outliers=200)
-    bright = np.flatnonzero(big[:, 3] > 100.0)
-    assert bright.size > 8200
+    # MFAST survivors exactly: the short front end's last size; one more: one too many
+    big = _scene(rng, 104, dim=3000, per=(40, 70), outliers=200)
+    bright = np.flatnonzero(big[:, 3] > 170.0)
+    assert bright.size > MFAST + 100
     keep = np.ones(big.shape[0], bool)
-    keep[bright[8192:]] = False
-    out["exactly_8192_survivors"] = big[keep]
-    keep[bright[8192]] = True
-    out["8193_survivors"] = big[keep]
+    keep[bright[MFAST:]] = False
+    out["exactly_mfast_survivors"] = big[keep]
+    keep[bright[MFAST]] = True
+    out["mfast_plus_1_survivors"] = big[keep]
+    out["4700_survivors"] = _scene(rng, 82, dim=3000, per=(50, 60), outliers=200)
     out["12k_survivors"] = _scene(rng, 240, dim=5000, per=(40, 70), outliers=300)
     return out
 
@@ -66,7 +69,8 @@ def test_both_front_ends_give_the_oracles_centres(oracle_lib):
     from reflector_ekf_slam_amd.detect import PointCloudOptions, PointCloudReflectorDetect
     clouds = _clouds()
     want = {k: oracle_detect3d(c) for k, c in clouds.items()}
-    assert want["exactly_8192_survivors"][1] == 8192 and want["8193_survivors"][1] == 8193 and want["12k_survivors"][1] > 10000
+    assert want["exactly_mfast_survivors"][1] == MFAST and want["mfast_plus_1_survivors"][1] == MFAST + 1 and want["12k_survivors"][1] > 10000
+    assert HINT_MAX < want["4700_survivors"][1] < MFAST and want["world_32_rings"][1] > MFAST
     for mode in (1, 2):
         g = PointCloudReflectorDetect(PointCloudOptions(), max_points=65536)
         g.debug_set_path(mode)
@@ -77,10 +81,10 @@ def test_both_front_ends_give_the_oracles_centres(oracle_lib):
             assert obs.cloud_.shape == oc.shape and np.array_equal(obs.cloud_, oc), (mode, name, obs.cloud_.shape, oc.shape)
             n_short, n_retry = g.debug_path_counts()
             if mode == 2 and c.shape[0]:
-                assert (n_retry > retried) == (m1 > 8192), (name, m1, n_retry)       # sent again iff it did not fit
+                assert (n_retry > retried) == (m1 > MFAST), (name, m1, n_retry)       # sent again iff it did not fit
             retried = n_retry
         n_short, n_retry = g.debug_path_counts()
-        assert (n_short == 0 and n_retry == 0) if mode == 1 else (n_short == len(clouds) - 1 and n_retry == 2)
+        assert (n_short == 0 and n_retry == 0) if mode == 1 else (n_short == len(clouds) - 1 and n_retry == 3)   # (32 rings, MFAST + 1, 12 k)
         g.close()
     assert want["thirty_clusters"][0].shape[0] >= 20 and want["12k_survivors"][0].shape[0] >= 100
 
@@ -91,11 +95,11 @@ def test_the_front_end_follows_the_previous_clouds_count(oracle_lib):
     from oracle.binding import oracle_detect3d
     from reflector_ekf_slam_amd.detect import PointCloudOptions, PointCloudReflectorDetect
     cl = _clouds()
-    seq = ["thirty_clusters", "world_16_rings", "12k_survivors", "12k_survivors", "thirty_clusters", "world_32_rings", "8193_survivors", "empty",
-           "exactly_8192_survivors", "thirty_clusters"]
-    #        short             short             short+again      long             long               short             short+again       -
-    #        long (hint 8193)          long (hint 8192 > 7168)
-    expect = [(1, 0), (2, 0), (3, 1), (3, 1), (3, 1), (4, 1), (5, 2), (5, 2), (5, 2), (5, 2)]
+    seq = ["thirty_clusters", "world_16_rings", "12k_survivors", "12k_survivors", "thirty_clusters", "4700_survivors", "thirty_clusters",
+           "mfast_plus_1_survivors", "empty", "exactly_mfast_survivors", "thirty_clusters", "thirty_clusters"]
+    # short, short, short + again (hint 3.7 k), long (hint 13 k), long (hint 13 k), short (hint 1 k), long (hint 4.7 k > HINT_MAX), short + again (hint
+    # 1 k), nothing, long (hint MFAST + 1), long (hint MFAST), short (hint 1 k)
+    expect = [(1, 0), (2, 0), (3, 1), (3, 1), (3, 1), (4, 1), (4, 1), (5, 2), (5, 2), (5, 2), (5, 2), (6, 2)]
     g = PointCloudReflectorDetect(PointCloudOptions(), max_points=65536)
     for name, e in zip(seq, expect):
         obs = g.HandlePointCloud(1.0, cl[name])
@@ -111,7 +115,7 @@ def test_two_clouds_on_their_way_through_either_front_end(oracle_lib):
     from oracle.binding import oracle_detect3d
     from reflector_ekf_slam_amd.detect import PointCloudOptions, PointCloudReflectorDetect
     cl = _clouds()
-    names = ["thirty_clusters", "12k_survivors", "world_16_rings", "8193_survivors", "empty", "12k_survivors", "below_meank", "world_32_rings"]
+    names = ["thirty_clusters", "12k_survivors", "world_16_rings", "mfast_plus_1_survivors", "empty", "12k_survivors", "below_meank", "world_32_rings"]
     g = PointCloudReflectorDetect(PointCloudOptions(), max_points=65536)
     g.debug_set_path(2)
     got = []
@@ -123,5 +127,5 @@ def test_two_clouds_on_their_way_through_either_front_end(oracle_lib):
     for k, (name, obs) in enumerate(zip(names, got)):
         oc, _, _ = oracle_detect3d(cl[name])
         assert obs.time_ == float(k) and np.array_equal(obs.cloud_, oc), name
-    assert g.debug_path_counts() == (7, 3)
+    assert g.debug_path_counts() == (7, 4)                                       # (12 k twice, MFAST + 1, 32 rings)
     g.close()
