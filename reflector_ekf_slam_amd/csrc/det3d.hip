@@ -22,13 +22,20 @@
 //   k3_clusters   size gate [4,160], order (size desc, first index asc), float32 centroids in index order (one wave
 //                 per component, spread over the CUs), Rigid2f to base_link             (:70-71, :77-97)
 //
-// NINE launches per cloud, each a short chain of dependent trips to memory.  Round 5 tried FIVE -- gate + sort + boxes as one launch
-// whose scatter workgroups wait for its tile workgroups, k-NN with the statistics by its last workgroup, finish + clusters likewise
+// Two chains (round 6).  A cloud whose survivors of the gate number at most MFAST = 5120 (judged by the previous cloud's count) takes FIVE
+// launches: k3f_front (gate + sort + boxes: every tile compacts its survivors in place, and the tile workgroup that arrives last -- no
+// workgroup ever waits for another -- sorts them in LDS), k3_knn, k3_cc_min, k3_cc_link, k3f_clusters (final roots, sizes, gate, order and
+// centroids from an LDS copy of the forest).  Anything bigger takes the NINE launches listed above; a cloud that turns out too big for the
+// short front end is sent again through the long chain by the collecting call (D3_RETRY).  Nothing of the result depends on the chain
+// (tests/test_detect3d_paths_gpu.py forces every cloud through both).
+// Every launch is a short chain of dependent trips to memory.  Round 5 tried FIVE launches another way -- gate + sort + boxes as one launch
+// whose scatter workgroups WAIT for its tile workgroups, k-NN with the statistics by its last workgroup, finish + clusters likewise
 // -- bit-identical, and SLOWER (120 us against 88): every edge of this chain is all-to-all, and a hand-over inside a launch that
 // crosses the XCDs' L2s (device-scope stores, a counter, a poll, device-scope loads; or release / acquire fences, which the L2
-// serialises at 13 ns a wave) costs 3 - 5 us where a kernel boundary costs 1.5 - 2 (profiles/r05_chain_experiments.txt, item 12).
-// What did pay is inside the kernels: first loads asked for together instead of one behind the other, the union-find's reads through
-// the caches, one union per distinct neighbour tree, the statistics inside k3_cc_min.
+// serialises at 13 ns a wave) costs 3 - 5 us where a kernel boundary costs 1.5 - 2 (profiles/r05_chain_experiments.txt, item 12).  What
+// pays is a hand-over nobody waits at, to ONE workgroup (a few dozen arrivals: 1 us), for work that fits one CU's LDS
+// (profiles/r06_experiments.txt, items 14 - 17); and what is inside the kernels: first loads asked for together instead of one behind the
+// other, the union-find's reads through the caches, one union per distinct neighbour tree, the statistics inside k3_cc_min.
 // No kd-tree: after the intensity gate a cloud holds 10^2..10^4 points; a counting sort into Morton order and a box per
 // 32 points prune as well as a tree would at this size and stay coalesced, data-parallel and free of pointer chasing.
 // Nothing waits on the host between stages: the point count M stays on the device and every grid is sized for the
@@ -370,15 +377,17 @@ __global__ __launch_bounds__(256) void k3_boxes(Det3dBufs B, int N)
     tile_boxes(B.box, s, M, x, y, z);
 }
 
-// ---- the short front end (round 6): gate + sort + boxes in TWO launches for clouds whose survivors fit one workgroup's LDS ------------
+// ---- the short front end (round 6): gate + sort + boxes in ONE launch (k3f_front; or two: k3f_gate + k3f_sort, -DD3_TWO_LAUNCH_FRONT) for clouds
+// whose survivors fit one workgroup's LDS ------------
 // The four launches above are a chain of all-to-all hand-overs of almost no data (3 k survivors = 40 KB): 20 us.  Here every 1024-point
 // tile compacts its own survivors in place (k3f_gate: no count to wait for, no histogram), and ONE workgroup does the rest in LDS
-// (k3f_sort): the tiles' prefix, the survivors in registers (eight per thread, asked for together), the cell histogram by LDS atomics
-// whose return value is the rank inside the cell, the scan of the 16 k cells, the sorted copy (over the histogram's storage), boxes, and
-// coalesced stores.  Node numbers are the same as the long chain's (tile prefix + place in the tile = arrival index among the survivors),
+// (f_sort_body): the tiles' prefix, the survivors in registers (up to five per thread, asked for together), the histogram of a 64 x 64
+// grid's cells by LDS atomics whose return value is the rank inside the cell, the scan of the cells, the sorted copy (over the histogram's
+// storage), boxes, and coalesced stores.  Node numbers are the same as the long chain's (tile prefix + place in the tile = arrival index among the survivors),
 // the order inside a cell is as arbitrary as there: nothing of the result can tell the two front ends apart.
 constexpr int MFAST = 5120, MFAST_PT = MFAST / 1024;   // (at 6.5 k survivors one workgroup's sort and the LDS forest are no faster than the long chain; at 3.3 k they save 7 us)
 constexpr int FGRID_G = 64, FGRID_CELLS = FGRID_G * FGRID_G;     // k3f_sort's grid: at most two points per cell on average, a quarter of the cells to clear and scan
+#ifdef D3_TWO_LAUNCH_FRONT
 __global__ __launch_bounds__(1024) void k3f_gate(Det3dBufs B, int N, double intensity_min)
 {
     __shared__ int wsum[16];
@@ -398,6 +407,7 @@ __global__ __launch_bounds__(1024) void k3f_gate(Det3dBufs B, int N, double inte
     }
     if (tid == 0) B.cnt[blockIdx.x] = tot;
 }
+#endif
 #define D3_KERNEL 4
 // what another workgroup of the SAME launch has written (k3f_front): past this XCD's L2
 template <bool DEV, typename T>
@@ -522,7 +532,9 @@ __device__ static inline void f_sort_body(const Det3dBufs &B, int N, int ftiles)
     if (tid == 0) { B.ctl->M = M; B.ctl->M2 = 0; B.ctl->K = 0; B.ctl->err = 0; B.ctl->nroots = 0; B.ctl->retry = 0; B.ctl->m_true = M; }
     D3_MARK(6);
 }
+#ifdef D3_TWO_LAUNCH_FRONT
 __global__ __launch_bounds__(1024) void k3f_sort(Det3dBufs B, int N, int ftiles) { f_sort_body<false>(B, N, ftiles); }
+#endif
 // ... and both in ONE launch: the tile workgroup that counts itself in last goes on as the sorting workgroup.  No workgroup waits for
 // another: a tile's survivors and count are written through to memory (device-scope stores), waited for, and only then does the tile's
 // first thread bump the arrival counter; whoever sees ftiles - 1 there knows everything has landed and reads it past its own L2

@@ -61,12 +61,15 @@ for seed in range(n2d):
         fails.append({"kind": "2d", "seed": seed, "beams": nb, "gpu": list(obs.cloud_.shape), "oracle": list(c.shape)})
 
 g3 = PointCloudReflectorDetect(PointCloudOptions(), max_points=65536, sensor_to_base_link=(0.2, -0.1, 0.3))
+g3l = PointCloudReflectorDetect(PointCloudOptions(), max_points=65536, sensor_to_base_link=(0.2, -0.1, 0.3))
+g3l.debug_set_path(1)                                   # the long chain whatever the size (g3: the short one up to 5120 survivors, by the previous cloud's count)
+exact3 = 0
 for seed in range(n3d):
     rng = np.random.default_rng(7000 + seed)
     parts = []
     ndim = int(rng.integers(0, 4000))
     parts.append(np.concatenate([rng.normal(0, 6.0, (ndim, 3)), rng.uniform(0, 90, (ndim, 1))], -1))          # dim background
-    for _ in range(int(rng.integers(0, 40))):
+    for _ in range(int(rng.integers(0, 40)) if seed % 9 != 8 else int(rng.integers(60, 160))):      # (every ninth cloud: 4 - 12 k bright points)
         centre = rng.uniform(-15, 15, 3) * [1, 1, 0.05]
         n = int(rng.choice([2, 3, 4, 5, 30, 31, 32, 60, 159, 160, 161, 200]))
         spread = float(rng.choice([0.01, 0.03, 0.06, 0.12]))
@@ -77,10 +80,12 @@ for seed in range(n3d):
     cloud = np.concatenate(parts).astype(np.float32)
     cloud = cloud[rng.permutation(cloud.shape[0])]
     obs = g3.HandlePointCloud(1.0 + seed, cloud)
+    obl = g3l.HandlePointCloud(1.0 + seed, cloud)
     c, m1, m2 = oracle_detect3d(cloud, sensor_to_base_link=(0.2, -0.1, 0.3))
-    ok = obs.cloud_.shape == c.shape
+    ok = obs.cloud_.shape == c.shape and obl.cloud_.shape == c.shape
     if ok and c.size:
-        d = float(np.abs(obs.cloud_ - c).max()); worst3 = max(worst3, d); ok = d < TOL
+        d = max(float(np.abs(obs.cloud_ - c).max()), float(np.abs(obl.cloud_ - c).max())); worst3 = max(worst3, d); ok = d < TOL
+    exact3 += bool(ok and np.array_equal(obs.cloud_, c) and np.array_equal(obl.cloud_, c))
     refl3 += c.shape[0]
     if not ok:
         fails.append({"kind": "3d", "seed": seed, "points": int(cloud.shape[0]), "gpu": list(obs.cloud_.shape), "oracle": list(c.shape)})
@@ -88,4 +93,5 @@ for f in fails:
     print(json.dumps(f))
 print(json.dumps({"summary": True, "scans_2d": n2d, "clouds_3d": n3d, "failed": len(fails), "reflectors_2d": refl2, "clusters_3d": refl3,
                   "worst_centre_diff_2d_m": worst2, "worst_return_diff_2d_m": worst_ret2, "scans_2d_bit_identical": exact2,
-                  "scans_2d_with_far_odometry": int(far2), "worst_centre_diff_3d_m": worst3}))
+                  "scans_2d_with_far_odometry": int(far2), "worst_centre_diff_3d_m": worst3,
+                  "clouds_3d_bit_identical_both_chains": exact3, "clouds_3d_short_front_end_and_sent_again": list(g3.debug_path_counts())}))
