@@ -591,7 +591,9 @@ def detectors_leg(args, device):
     b3 = 16 * int(cloud.shape[0])
     out["cloud_3d"] = {"points": int(cloud.shape[0]), "reflectors": int(obs3.cloud_.shape[0]), "call_us": q(t3), "input_bytes": b3,
                        "gb_per_s": b3 / (np.median(t3) * 1e-6) / 1e9,
-                       "kernels": "k3_filter_count/write, k3_scatter, k3_boxes, k3_knn, k3_cc_min (+ SOR statistics), k3_cc_link, k3_finish_a, k3_clusters (nine launches per cloud)"}
+                       "kernels": "k3f_front (gate + sort + boxes), k3_knn, k3_cc_min (+ SOR statistics), k3_cc_link, k3f_clusters: five launches per cloud of at "
+                                  "most 5120 survivors of the gate; k3_filter_count/write, k3_scatter, k3_boxes, ..., k3_finish_a, k3_clusters (nine) beyond",
+                       "clouds_through_short_chain_and_sent_again": list(g3.debug_path_counts())}
     g3.close()
     if not args.no_cpu_baseline:               # the CPU-baseline leg: the oracle (the checker) timed on the same inputs, and compared
         from oracle.binding import OracleDetect2D, oracle_detect3d
