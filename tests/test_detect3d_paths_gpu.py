@@ -129,3 +129,30 @@ def test_two_clouds_on_their_way_through_either_front_end(oracle_lib):
         assert obs.time_ == float(k) and np.array_equal(obs.cloud_, oc), name
     assert g.debug_path_counts() == (7, 4)                                       # (12 k twice, MFAST + 1, 32 rings)
     g.close()
+
+
+def test_a_million_points_1024_tiles_and_beyond(oracle_lib):
+    """The short front end counts its tile workgroups in: 1024 of them (N = 2^20, the most it takes) is its largest launch -- four rounds of
+    workgroups over the CUs, the last arrival among 1024 sorts; one point more makes 1025 tiles and sends the cloud through the long chain
+    whatever its survivor count.  A handful of bright points either way."""
+    from oracle.binding import oracle_detect3d
+    from reflector_ekf_slam_amd.detect import PointCloudOptions, PointCloudReflectorDetect
+    rng = np.random.default_rng(77)
+    n = 1 << 20
+    dim = np.concatenate([rng.normal(0, 8.0, (n + 1, 3)), rng.uniform(0, 90, (n + 1, 1))], -1).astype(np.float32)
+    posts = [(3.0, 2.0, 0.4, 40), (-6.0, 1.5, 0.2, 33), (8.0, -7.0, 0.6, 25), (0.5, 9.0, 0.3, 60)]
+    where = rng.choice(n, sum(p[3] for p in posts), replace=False)               # (bright points anywhere in the arrival order: first and last tiles included)
+    where[0], where[1] = 0, n - 1
+    k = 0
+    for (x, y, z, c) in posts:
+        dim[where[k:k + c], :3] = rng.normal(0, 0.03, (c, 3)) + np.array([x, y, z])
+        dim[where[k:k + c], 3] = 200.0
+        k += c
+    g = PointCloudReflectorDetect(PointCloudOptions(), max_points=(1 << 20) + 8)
+    for cloud, short in ((dim[:n], 1), (dim, 1), (dim[:n], 2)):
+        obs = g.HandlePointCloud(1.0, cloud)
+        oc, m1, _ = oracle_detect3d(cloud)
+        assert m1 >= 150 and oc.shape[0] >= 3
+        assert obs.cloud_.shape == oc.shape and np.array_equal(obs.cloud_, oc), cloud.shape
+        assert g.debug_path_counts() == (short, 0), (cloud.shape, g.debug_path_counts())
+    g.close()
