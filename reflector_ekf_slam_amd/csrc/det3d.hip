@@ -180,8 +180,8 @@ __device__ static inline float lane_xor(float f, int lane)
 {
     const int v = __float_as_int(f);
     int r;
-    if (J == 1) r = d3_dpp<0xB1, 0xf>(v, v);
-    else if (J == 2) r = d3_dpp<0x4E, 0xf>(v, v);
+    if (J == 1) r = __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);             // (every lane has a source: nothing of the old value to keep)
+    else if (J == 2) r = __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);
     else if (J == 4) r = d3_dpp<0x114, 0xA>(d3_dpp<0x104, 0x5>(v, v), v);
     else if (J == 8) r = d3_dpp<0x118, 0xC>(d3_dpp<0x108, 0x3>(v, v), v);
     else if (J == 16) { const auto p = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false); r = (int)((lane & 16) ? p[0] : p[1]); }
@@ -315,24 +315,39 @@ __global__ __launch_bounds__(1024) void k3_filter_write(Det3dBufs B, int N, doub
     if ((int)blockIdx.x == ftiles - 1 && tid == 0) { B.ctl->M = base; B.ctl->M2 = 0; B.ctl->K = 0; B.ctl->err = 0; B.ctl->nroots = 0; B.ctl->retry = 0; B.ctl->m_true = base; }   // base now includes this tile
 }
 
+// Reductions over the lanes with the partner taken straight through DPP: ONE instruction a level (row shifts 1, 2, 4, 8, then the row
+// broadcasts 15 and 31), written out because the compiler turns the builtins into copy + wait + v_mov_b32_dpp + operation, and fminf / fmaxf
+// into that plus a canonicalising v_max.  A lane whose source lies outside its row (or whose row is masked) keeps its value; the result is
+// lane 63's (all lanes), lane 31's (the lower half), lane 15's of every row (that row).
+#define D3_DPP_LEVEL(OP, V, CTRL) asm volatile("s_nop 1\n\t" OP " %0, %0, %0 " CTRL : "+v"(V))
+#define D3_DPP_REDUCE32(OP, V)                                                                                     \
+    D3_DPP_LEVEL(OP, V, "row_shr:1 row_mask:0xf bank_mask:0xf"); D3_DPP_LEVEL(OP, V, "row_shr:2 row_mask:0xf bank_mask:0xf"); \
+    D3_DPP_LEVEL(OP, V, "row_shr:4 row_mask:0xf bank_mask:0xf"); D3_DPP_LEVEL(OP, V, "row_shr:8 row_mask:0xf bank_mask:0xf"); \
+    D3_DPP_LEVEL(OP, V, "row_bcast:15 row_mask:0xa bank_mask:0xf")
+// the smallest of one non-negative int per lane (as unsigned: also of non-negative floats' bit patterns), in every lane
+__device__ static inline int wave_min_u32(int m)
+{
+    D3_DPP_REDUCE32("v_min_u32_dpp", m);
+    D3_DPP_LEVEL("v_min_u32_dpp", m, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+    asm volatile("s_nop 1" ::: "memory");
+    return __builtin_amdgcn_readlane(m, 63);
+}
+
 // bounding boxes of BOX_PTS consecutive sorted points: lane = point (x, y, z in registers), 32-lane halves reduce by
-// shuffles.  NaN coordinates (the outliers k3_cc_min masks: x) are ignored by fminf / fmaxf; a tile without any number gets an
+// shuffles.  NaN coordinates (the outliers k3_cc_min masks: x) are skipped (v_min_f32 / v_max_f32 return the other operand); a tile without any number gets an
 // empty box (+inf, -inf).
 __device__ static inline void tile_boxes(float *box, int s, int M, float x, float y, float z)
 {
     const float qn = __int_as_float(0x7fc00000);
     const bool ok = s < M && x == x;                                              // x carries the mask
-    float m[6] = {ok ? x : qn, ok ? y : qn, ok ? z : qn, ok ? x : qn, ok ? y : qn, ok ? z : qn};
-    const int lane = threadIdx.x & 63;
+    // (v_min_f32 / v_max_f32 skip a QUIET NaN; a signalling one -- whatever bits the driver sent -- would come back as the result: every NaN is
+    // replaced by the quiet one first)
+    const float cx = ok ? x : qn, cy = (ok && y == y) ? y : qn, cz = (ok && z == z) ? z : qn;
+    float m[6] = {cx, cy, cz, cx, cy, cz};
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        m[k] = fminf(m[k], lane_xor<16>(m[k], lane)); m[3 + k] = fmaxf(m[3 + k], lane_xor<16>(m[3 + k], lane));
-        m[k] = fminf(m[k], lane_xor<8>(m[k], lane)); m[3 + k] = fmaxf(m[3 + k], lane_xor<8>(m[3 + k], lane));
-        m[k] = fminf(m[k], lane_xor<4>(m[k], lane)); m[3 + k] = fmaxf(m[3 + k], lane_xor<4>(m[3 + k], lane));
-        m[k] = fminf(m[k], lane_xor<2>(m[k], lane)); m[3 + k] = fmaxf(m[3 + k], lane_xor<2>(m[3 + k], lane));
-        m[k] = fminf(m[k], lane_xor<1>(m[k], lane)); m[3 + k] = fmaxf(m[3 + k], lane_xor<1>(m[3 + k], lane));
-    }
-    if ((threadIdx.x & 31) == 0 && (s & ~31) < M) {
+    for (int k = 0; k < 3; ++k) { D3_DPP_REDUCE32("v_min_f32_dpp", m[k]); D3_DPP_REDUCE32("v_max_f32_dpp", m[3 + k]); }
+    asm volatile("s_nop 1" ::: "memory");
+    if ((threadIdx.x & 31) == 31 && (s & ~31) < M) {                              // (the half's last lane holds its minimum / maximum)
         float4 lo, hi;
         lo.x = (m[0] == m[0]) ? m[0] : INFINITY; lo.y = (m[1] == m[1]) ? m[1] : INFINITY; lo.z = (m[2] == m[2]) ? m[2] : INFINITY;
         lo.w = (m[3] == m[3]) ? m[3] : -INFINITY; hi.x = (m[4] == m[4]) ? m[4] : -INFINITY; hi.y = (m[5] == m[5]) ? m[5] : -INFINITY;
@@ -619,11 +634,10 @@ __device__ static inline float wave_merge64(float S, float D, int lane)
 // other tiles are never opened)
 __device__ static inline int nearest_of(unsigned long long set, float v, int lane)
 {
+    // (v >= 0 or +inf: the bit patterns order like the values)
     const bool in = (set >> lane) & 1ull;
-    float m = in ? v : INFINITY;
-    m = fminf(m, lane_xor<1>(m, lane)); m = fminf(m, lane_xor<2>(m, lane)); m = fminf(m, lane_xor<4>(m, lane));
-    m = fminf(m, lane_xor<8>(m, lane)); m = fminf(m, lane_xor<16>(m, lane)); m = fminf(m, lane_xor<32>(m, lane));
-    return __ffsll((long long)__ballot(in && v == m)) - 1;
+    const int mn = wave_min_u32(in ? __float_as_int(v) : 0x7f800000);
+    return __ffsll((long long)__ballot(in && __float_as_int(v) == mn)) - 1;
 }
 constexpr int QW = 4;               // queries (waves) per workgroup
 constexpr int Q_GRID = 2048;        // workgroups: the queries are dealt round-robin
@@ -636,7 +650,10 @@ constexpr int Q_GRID = 2048;        // workgroups: the queries are dealt round-r
 constexpr int KNN_AHEAD = D3_KNN_AHEAD;     // steps (pairs of tiles) whose loads are issued together
 constexpr int CC_AHEAD = 4;                 // the same in k3_cc_link's sweep
 constexpr int CCMIN_AHEAD = D3_CCMIN_AHEAD; // ... and in k3_cc_min's
-constexpr int KNN_FEW = 6;          // a step with at most this many admissible candidates inserts them one by one
+#ifndef D3_KNN_FEW
+#define D3_KNN_FEW 6
+#endif
+constexpr int KNN_FEW = D3_KNN_FEW;      // a step with at most this many admissible candidates inserts them one by one
 
 // What a sweep can ask for before it knows anything but its query's number: the boxes of the first 128 tiles (two per lane).  All of a
 // query's first loads -- M, the query, its aligned 64 neighbours, these boxes -- are issued together and waited for once (each used to
@@ -920,7 +937,7 @@ __global__ __launch_bounds__(64 * QW) void k3_cc_min(Det3dBufs B, int N, int nti
                     if (ok[u] && !((double)cd[u] > thr) && d2f(qx, qy, qz, cx[u], cy[u], cz[u]) < TOL2) mi = min(mi, pj[u]);
             }
         }
-        for (int off = 32; off > 0; off >>= 1) mi = min(mi, __shfl_xor(mi, off, 64));
+        mi = wave_min_u32(mi);                                   // (node numbers: >= 0)
         if (lane == 0) B.label[own] = mi;
         if (first) { D3_MARK(3); D3_NOTE(6, dbg_tiles); }
     }
