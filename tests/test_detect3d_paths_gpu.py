@@ -156,3 +156,38 @@ def test_a_million_points_1024_tiles_and_beyond(oracle_lib):
         assert obs.cloud_.shape == oc.shape and np.array_equal(obs.cloud_, oc), cloud.shape
         assert g.debug_path_counts() == (short, 0), (cloud.shape, g.debug_path_counts())
     g.close()
+
+
+def test_error_tails_of_both_chains(oracle_lib):
+    """What the last kernel of either chain reports instead of centres: more accepted clusters than the caller's buffer holds
+    (RDET_ERR_BUFFER) or than a cloud may yield at all (RDET_MAX_CENTERS = 256: RDET_ERR_CAPACITY) -- straight through the C ABI, on both
+    chains; the handle goes on working afterwards (the call that gave up waiting leaves kernels in flight: the next submit synchronises)."""
+    import ctypes as C
+    from oracle.binding import oracle_detect3d
+    from reflector_ekf_slam_amd.detect import PointCloudOptions, PointCloudReflectorDetect, MAX_CENTERS
+    rng = np.random.default_rng(31)
+    thirty = _scene(rng, 30)
+    # 320 small clusters on a lattice (0.6 m apart: none touches another), 8 points each: more than 256 survive SOR and the size gate
+    parts = [_blob((0, 0, 0), 1500, 5.0, rng, intensity=20.0)]
+    for i in range(320):
+        parts.append(_blob((0.6 * (i % 20) - 6.0, 0.6 * (i // 20) - 4.5, 0.3), 8, 0.01, rng))
+    lattice = np.concatenate(parts).astype(np.float32)
+    assert oracle_detect3d(thirty)[0].shape[0] > 20
+    with pytest.raises(ValueError):                                         # (the oracle's own capacity: the same 256)
+        oracle_detect3d(lattice)
+    for mode in (1, 2):
+        g = PointCloudReflectorDetect(PointCloudOptions(), max_points=65536)
+        g.debug_set_path(mode)
+        out = np.zeros((MAX_CENTERS, 2), np.float32)
+        K, t = C.c_int(-1), C.c_double(0)
+
+        def call(cloud, max_centers):
+            return g._L.rdet3d_handle_cloud(g._h, 1.0, cloud.ctypes.data, cloud.shape[0], out.ctypes.data, max_centers, C.byref(K), C.byref(t))
+
+        assert call(thirty, 3) == -5 and K.value == 0                       # RDET_ERR_BUFFER
+        obs = g.HandlePointCloud(2.0, thirty)
+        assert np.array_equal(obs.cloud_, oracle_detect3d(thirty)[0])
+        assert call(lattice, MAX_CENTERS) == -4 and K.value == 0            # RDET_ERR_CAPACITY
+        obs = g.HandlePointCloud(3.0, thirty)
+        assert np.array_equal(obs.cloud_, oracle_detect3d(thirty)[0])
+        g.close()
