@@ -1426,15 +1426,17 @@ struct rdet3d {
     rdet3d_options opt;
     double s2b[3];
     int max_points, device;
-    hipStream_t stream;
-    float *d_p1, *d_s1, *d_dist, *d_dist_s, *d_box, *d_box2;
-    int *d_label, *d_cnt, *d_first, *d_last, *d_roots, *d_perm, *d_hist, *d_cursor;
-    Det3dCtl *d_ctl;
-    // TWO clouds may be on their way (rdet3d_submit / rdet3d_collect): what the host writes while the device still works on the cloud
-    // before -- the cloud itself -- and what the device writes while the host may still read the cloud before's -- the result slots --
-    // exist twice; everything in between is produced and consumed inside one cloud's chain of kernels, and the chains follow each other
-    // on the handle's stream
+    // TWO clouds may be on their way (rdet3d_submit / rdet3d_collect), and their chains of kernels run SIDE BY SIDE: a slot is a complete
+    // detector -- input buffer, every intermediate array, control block, result slots and a stream of its own (round 5 shared everything
+    // between the input and the results, so cloud k + 1's chain queued behind cloud k's; most of these kernels are a few dozen workgroups
+    // of latency chain and leave the chip nearly empty).  The slots alternate; a slot's next cloud follows its previous one on its stream,
+    // and inherits its sorting grid.
     struct Slot {
+        hipStream_t stream;
+        float *d_p1, *d_s1, *d_dist, *d_dist_s, *d_box, *d_box2;
+        int *d_label, *d_cnt, *d_first, *d_last, *d_roots, *d_perm, *d_hist, *d_cursor;
+        Det3dCtl *d_ctl;
+        bool in_flight;                // a call returned before this slot's kernels had published everything
         float *d_xyzi;                 // the cloud on the device
         bool xyzi_in_vram;             // ... in fine-grained device memory the host writes through the PCIe BAR (else: pinned staging + copy)
         float *h_stage;
@@ -1447,7 +1449,6 @@ struct rdet3d {
     } slot[2];
     int n_out;                         // clouds submitted and not collected (0 .. 2); the older one is slot[(next + 2 - n_out) & 1]
     int next;                          // the slot the next submit takes
-    bool in_flight;                    // a call returned before its kernels had published everything
     int seq;
     int m_hint;                        // the previous cloud's survivors of the gate (k3_knn: m_hint; which front end the next cloud gets)
     int path_mode;                     // 0: by m_hint; 1: always the long chain; 2: always try the short front end (rdet3d_debug_set_path)
@@ -1470,37 +1471,37 @@ static int d3_launch(rdet3d_t *h, rdet3d::Slot &sl)
 {
     const int N = sl.N, max_centers = sl.max_centers;
     Det3dBufs B;
-    B.xyzi = sl.d_xyzi; B.p1 = h->d_p1; B.s1 = h->d_s1; B.dist_s = h->d_dist_s; B.perm = h->d_perm; B.box = h->d_box; B.box2 = h->d_box2; B.hist = h->d_hist; B.cursor = h->d_cursor;
-    B.dist = h->d_dist; B.label = h->d_label; B.cnt = h->d_cnt; B.first = h->d_first; B.last = h->d_last; B.roots = h->d_roots;
-    B.ctl = h->d_ctl; B.cap = h->max_points; B.cap1 = (h->max_points + 1023) & ~1023;
+    B.xyzi = sl.d_xyzi; B.p1 = sl.d_p1; B.s1 = sl.d_s1; B.dist_s = sl.d_dist_s; B.perm = sl.d_perm; B.box = sl.d_box; B.box2 = sl.d_box2; B.hist = sl.d_hist; B.cursor = sl.d_cursor;
+    B.dist = sl.d_dist; B.label = sl.d_label; B.cnt = sl.d_cnt; B.first = sl.d_first; B.last = sl.d_last; B.roots = sl.d_roots;
+    B.ctl = sl.d_ctl; B.cap = h->max_points; B.cap1 = (h->max_points + 1023) & ~1023;
     B.hout = sl.dv_out; B.seq = sl.seq = ++h->seq;
     const int ftiles = (N + 1023) / 1024, b256 = (N + 255) / 256, ntiles_ub = (N + BOX_PTS - 1) / BOX_PTS;
     sl.fast = ftiles <= 1024 && (h->path_mode == 2 || (h->path_mode == 0 && h->m_hint <= MFAST - MFAST / 10));
     if (sl.fast) {
         ++h->n_short;
 #ifdef D3_TWO_LAUNCH_FRONT
-        hipLaunchKernelGGL(k3f_gate, dim3(ftiles), dim3(1024), 0, h->stream, B, N, h->opt.intensity_min);
-        hipLaunchKernelGGL(k3f_sort, dim3(1), dim3(1024), 0, h->stream, B, N, ftiles);
+        hipLaunchKernelGGL(k3f_gate, dim3(ftiles), dim3(1024), 0, sl.stream, B, N, h->opt.intensity_min);
+        hipLaunchKernelGGL(k3f_sort, dim3(1), dim3(1024), 0, sl.stream, B, N, ftiles);
 #else
-        hipLaunchKernelGGL(k3f_front, dim3(ftiles), dim3(1024), 0, h->stream, B, N, h->opt.intensity_min, ftiles);
+        hipLaunchKernelGGL(k3f_front, dim3(ftiles), dim3(1024), 0, sl.stream, B, N, h->opt.intensity_min, ftiles);
 #endif
     } else {
-        hipLaunchKernelGGL(k3_filter_count, dim3(ftiles), dim3(1024), 0, h->stream, B, N, h->opt.intensity_min);
-        hipLaunchKernelGGL(k3_filter_write, dim3(ftiles + GRID_CELLS / 1024), dim3(1024), 0, h->stream, B, N, h->opt.intensity_min, ftiles);
-        hipLaunchKernelGGL(k3_scatter, dim3(ftiles), dim3(1024), 0, h->stream, B, N);
-        hipLaunchKernelGGL(k3_boxes, dim3(b256), dim3(256), 0, h->stream, B, N);
+        hipLaunchKernelGGL(k3_filter_count, dim3(ftiles), dim3(1024), 0, sl.stream, B, N, h->opt.intensity_min);
+        hipLaunchKernelGGL(k3_filter_write, dim3(ftiles + GRID_CELLS / 1024), dim3(1024), 0, sl.stream, B, N, h->opt.intensity_min, ftiles);
+        hipLaunchKernelGGL(k3_scatter, dim3(ftiles), dim3(1024), 0, sl.stream, B, N);
+        hipLaunchKernelGGL(k3_boxes, dim3(b256), dim3(256), 0, sl.stream, B, N);
     }
     const int qblocks = (N + QW - 1) / QW < Q_GRID ? (N + QW - 1) / QW : Q_GRID;   // a wave per query, dealt round-robin: M <= N stays on the device
-    hipLaunchKernelGGL(k3_knn, dim3(qblocks), dim3(64 * QW), 0, h->stream, B, N, ntiles_ub, h->m_hint);
-    hipLaunchKernelGGL(k3_cc_min, dim3(qblocks), dim3(64 * QW), 0, h->stream, B, N, ntiles_ub, h->m_hint);
-    hipLaunchKernelGGL(k3_cc_link, dim3(qblocks), dim3(64 * QW), 0, h->stream, B, N, ntiles_ub, h->m_hint);
+    hipLaunchKernelGGL(k3_knn, dim3(qblocks), dim3(64 * QW), 0, sl.stream, B, N, ntiles_ub, h->m_hint);
+    hipLaunchKernelGGL(k3_cc_min, dim3(qblocks), dim3(64 * QW), 0, sl.stream, B, N, ntiles_ub, h->m_hint);
+    hipLaunchKernelGGL(k3_cc_link, dim3(qblocks), dim3(64 * QW), 0, sl.stream, B, N, ntiles_ub, h->m_hint);
     const float sa = (float)h->s2b[2];
     if (sl.fast) {                                                     // (M <= MFAST, or M = 0 and D3_RETRY)
-        hipLaunchKernelGGL(k3f_clusters, dim3(RDET_MAX_CENTERS / FC_W), dim3(FC_T), 0, h->stream, B, max_centers < RDET_MAX_CENTERS ? max_centers : RDET_MAX_CENTERS,
+        hipLaunchKernelGGL(k3f_clusters, dim3(RDET_MAX_CENTERS / FC_W), dim3(FC_T), 0, sl.stream, B, max_centers < RDET_MAX_CENTERS ? max_centers : RDET_MAX_CENTERS,
                            (float)h->s2b[0], (float)h->s2b[1], cosf(sa), sinf(sa));
     } else {
-        hipLaunchKernelGGL(k3_finish_a, dim3(b256), dim3(256), 0, h->stream, B, N);
-        hipLaunchKernelGGL(k3_clusters, dim3(RDET_MAX_CENTERS / 4), dim3(256), 0, h->stream, B, max_centers < RDET_MAX_CENTERS ? max_centers : RDET_MAX_CENTERS,
+        hipLaunchKernelGGL(k3_finish_a, dim3(b256), dim3(256), 0, sl.stream, B, N);
+        hipLaunchKernelGGL(k3_clusters, dim3(RDET_MAX_CENTERS / 4), dim3(256), 0, sl.stream, B, max_centers < RDET_MAX_CENTERS ? max_centers : RDET_MAX_CENTERS,
                            (float)h->s2b[0], (float)h->s2b[1], cosf(sa), sinf(sa));
     }
     DET3_TRY(h, hipGetLastError());
@@ -1522,8 +1523,8 @@ int rdet3d_create(const rdet3d_options *opt, const double s2b[3], int max_points
     const size_t np = (size_t)max_points;
     int rc = [&]() -> int {
         DET3_TRY(h, hipSetDevice(device));
-        DET3_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         for (auto &sl : h->slot) {
+            DET3_TRY(h, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
             sl.d_xyzi = (float *)host_visible::alloc(16 * np);
             if (sl.d_xyzi) sl.xyzi_in_vram = true;
             else {
@@ -1531,28 +1532,28 @@ int rdet3d_create(const rdet3d_options *opt, const double s2b[3], int max_points
                 DET3_TRY(h, hipMalloc(&sl.d_xyzi, 16 * np));
                 DET3_TRY(h, hipHostMalloc(&sl.h_stage, 16 * np));
             }
-        }
-        // + 1024 floats: the sweeps ask for the aligned 64 points around a query before they know M (up to 63 past the end)
-        DET3_TRY(h, hipMalloc(&h->d_p1, 12 * (np + 1024) + 4096)); DET3_TRY(h, hipMemset(h->d_p1, 0, 12 * (np + 1024) + 4096));   // (+ 1024: k3f_gate's whole tiles)
-        DET3_TRY(h, hipMalloc(&h->d_s1, 12 * np + 4096)); DET3_TRY(h, hipMemset(h->d_s1, 0, 12 * np + 4096));
-        DET3_TRY(h, hipMalloc(&h->d_perm, 4 * np + 4096)); DET3_TRY(h, hipMemset(h->d_perm, 0, 4 * np + 4096));
-        DET3_TRY(h, hipMalloc(&h->d_box, 32 * (np / BOX_PTS + 2)));
-        DET3_TRY(h, hipMalloc(&h->d_box2, 32 * (np / BOX_PTS + 2)));
-        DET3_TRY(h, hipMalloc(&h->d_hist, 4 * GRID_CELLS)); DET3_TRY(h, hipMemset(h->d_hist, 0, 4 * GRID_CELLS));
-        DET3_TRY(h, hipMalloc(&h->d_cursor, 4 * GRID_CELLS));
-        DET3_TRY(h, hipMalloc(&h->d_dist, 4 * np + 4096)); DET3_TRY(h, hipMemset(h->d_dist, 0, 4 * np + 4096));
-        DET3_TRY(h, hipMalloc(&h->d_dist_s, 4 * np + 4096)); DET3_TRY(h, hipMemset(h->d_dist_s, 0, 4 * np + 4096));
-        DET3_TRY(h, hipMalloc(&h->d_label, 4 * np));
-        DET3_TRY(h, hipMalloc(&h->d_cnt, 4 * np));
-        DET3_TRY(h, hipMalloc(&h->d_last, 4 * np));
-        DET3_TRY(h, hipMalloc(&h->d_first, 4 * np));
-        DET3_TRY(h, hipMalloc(&h->d_roots, 4 * np));
-        DET3_TRY(h, hipMalloc(&h->d_ctl, sizeof(Det3dCtl)));
-        {   // the first cloud is sorted on a 64 m x 64 m grid around the sensor; every later one on its predecessor's box
-            Det3dCtl c0;
-            std::memset(&c0, 0, sizeof(c0));
-            c0.gx0 = c0.gy0 = -32.f; c0.ginv = (float)GRID_G / 64.f;
-            DET3_TRY(h, hipMemcpy(h->d_ctl, &c0, sizeof(c0), hipMemcpyHostToDevice));
+            // + 1024 floats: the sweeps ask for the aligned 64 points around a query before they know M (up to 63 past the end)
+            DET3_TRY(h, hipMalloc(&sl.d_p1, 12 * (np + 1024) + 4096)); DET3_TRY(h, hipMemset(sl.d_p1, 0, 12 * (np + 1024) + 4096));   // (+ 1024: k3f_front's whole tiles)
+            DET3_TRY(h, hipMalloc(&sl.d_s1, 12 * np + 4096)); DET3_TRY(h, hipMemset(sl.d_s1, 0, 12 * np + 4096));
+            DET3_TRY(h, hipMalloc(&sl.d_perm, 4 * np + 4096)); DET3_TRY(h, hipMemset(sl.d_perm, 0, 4 * np + 4096));
+            DET3_TRY(h, hipMalloc(&sl.d_box, 32 * (np / BOX_PTS + 2)));
+            DET3_TRY(h, hipMalloc(&sl.d_box2, 32 * (np / BOX_PTS + 2)));
+            DET3_TRY(h, hipMalloc(&sl.d_hist, 4 * GRID_CELLS)); DET3_TRY(h, hipMemset(sl.d_hist, 0, 4 * GRID_CELLS));
+            DET3_TRY(h, hipMalloc(&sl.d_cursor, 4 * GRID_CELLS));
+            DET3_TRY(h, hipMalloc(&sl.d_dist, 4 * np + 4096)); DET3_TRY(h, hipMemset(sl.d_dist, 0, 4 * np + 4096));
+            DET3_TRY(h, hipMalloc(&sl.d_dist_s, 4 * np + 4096)); DET3_TRY(h, hipMemset(sl.d_dist_s, 0, 4 * np + 4096));
+            DET3_TRY(h, hipMalloc(&sl.d_label, 4 * np));
+            DET3_TRY(h, hipMalloc(&sl.d_cnt, 4 * np));
+            DET3_TRY(h, hipMalloc(&sl.d_last, 4 * np));
+            DET3_TRY(h, hipMalloc(&sl.d_first, 4 * np));
+            DET3_TRY(h, hipMalloc(&sl.d_roots, 4 * np));
+            DET3_TRY(h, hipMalloc(&sl.d_ctl, sizeof(Det3dCtl)));
+            {   // a slot's first cloud is sorted on a 64 m x 64 m grid around the sensor; every later one on its predecessor's box
+                Det3dCtl c0;
+                std::memset(&c0, 0, sizeof(c0));
+                c0.gx0 = c0.gy0 = -32.f; c0.ginv = (float)GRID_G / 64.f;
+                DET3_TRY(h, hipMemcpy(sl.d_ctl, &c0, sizeof(c0), hipMemcpyHostToDevice));
+            }
         }
         for (auto &sl : h->slot) {
             DET3_TRY(h, hipHostMalloc(&sl.h_out, sizeof(Det3dHostOut), hipHostMallocMapped | hipHostMallocCoherent));
@@ -1571,21 +1572,21 @@ void rdet3d_destroy(rdet3d_t *h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto &sl : h->slot) {
+        if (sl.stream) (void)hipStreamSynchronize(sl.stream);
         if (sl.d_xyzi) (void)hipFree(sl.d_xyzi);
         if (sl.h_out) (void)hipHostFree(sl.h_out);
         if (sl.h_stage) (void)hipHostFree(sl.h_stage);
+        void *ptrs[] = {sl.d_p1, sl.d_s1, sl.d_dist, sl.d_dist_s, sl.d_box, sl.d_box2, sl.d_label, sl.d_cnt, sl.d_first, sl.d_last, sl.d_roots, sl.d_perm, sl.d_hist, sl.d_cursor, sl.d_ctl};
+        for (void *p : ptrs) (void)hipFree(p);
+        if (sl.stream) (void)hipStreamDestroy(sl.stream);
     }
-    void *ptrs[] = {h->d_p1, h->d_s1, h->d_dist, h->d_dist_s, h->d_box, h->d_box2, h->d_label, h->d_cnt, h->d_first, h->d_last, h->d_roots, h->d_perm, h->d_hist, h->d_cursor, h->d_ctl};
-    for (void *p : ptrs) (void)hipFree(p);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
-// The two halves of HandlePointCloud.  rdet3d_submit: the cloud into the device's memory and the nine launches, no waiting; rdet3d_collect:
+// The two halves of HandlePointCloud.  rdet3d_submit: the cloud into the device's memory and its chain of launches, no waiting; rdet3d_collect:
 // the OLDEST submitted cloud's centres, polled from its result slots.  Up to two clouds may be submitted and not collected: the host copies
-// and enqueues cloud k + 1 while the device is still on cloud k, whose chain of kernels precedes it on the handle's stream.
+// and enqueues cloud k + 1 while the device is still on cloud k -- on the other slot's stream and arrays, so the two chains share the chip.
 int rdet3d_submit(rdet3d_t *h, double stamp, const float *xyzi, int N, int max_centers)
 {
     if (!h || N < 0 || (N > 0 && !xyzi) || max_centers < 0) return RDET_ERR_INVALID;
@@ -1603,7 +1604,7 @@ int rdet3d_submit(rdet3d_t *h, double stamp, const float *xyzi, int N, int max_c
         // Every result slot of a cloud is written by the LAST kernel of its chain, which starts when all others have ended: a cloud that has
         // been collected reads its input no more, and this slot's previous cloud has been collected (n_out < 2).  Only a call that gave up
         // waiting leaves kernels in flight.  (hipStreamSynchronize on an idle stream costs 15 us.)
-        if (h->in_flight) { DET3_TRY(h, hipStreamSynchronize(h->stream)); h->in_flight = false; }
+        if (sl.in_flight) { DET3_TRY(h, hipStreamSynchronize(sl.stream)); sl.in_flight = false; }
 #ifdef RDET_DEBUG_MARKS
         dbg_t[0] = dbg_us();
 #endif
@@ -1612,7 +1613,7 @@ int rdet3d_submit(rdet3d_t *h, double stamp, const float *xyzi, int N, int max_c
             __atomic_thread_fence(__ATOMIC_SEQ_CST);
         } else {
             std::memcpy(sl.h_stage, xyzi, sizeof(float) * 4 * (size_t)N);
-            DET3_TRY(h, hipMemcpyAsync(sl.d_xyzi, sl.h_stage, sizeof(float) * 4 * (size_t)N, hipMemcpyHostToDevice, h->stream));
+            DET3_TRY(h, hipMemcpyAsync(sl.d_xyzi, sl.h_stage, sizeof(float) * 4 * (size_t)N, hipMemcpyHostToDevice, sl.stream));
         }
 #ifdef RDET_DEBUG_MARKS
         dbg_t[1] = dbg_us();
@@ -1649,8 +1650,8 @@ int rdet3d_collect(rdet3d_t *h, float *centers_xy, int max_centers, int *K, doub
         unsigned spins = 0;
         while (__atomic_load_n(tag, __ATOMIC_ACQUIRE) != sl.seq) {
             if ((++spins & 0xfffffu) == 0) {
-                if (hipStreamQuery(h->stream) != hipErrorNotReady) {
-                    DET3_TRY(h, hipStreamSynchronize(h->stream));
+                if (hipStreamQuery(sl.stream) != hipErrorNotReady) {
+                    DET3_TRY(h, hipStreamSynchronize(sl.stream));
                     if (__atomic_load_n(tag, __ATOMIC_ACQUIRE) == sl.seq) break;
                     h->hip_error = "the 3D detector's kernels finished without publishing their result";
                     return RDET_ERR_HIP;
@@ -1661,7 +1662,7 @@ int rdet3d_collect(rdet3d_t *h, float *centers_xy, int max_centers, int *K, doub
         return RDET_OK;
     };
     int rc = wait_tag(&sl.h_out->head.seq);
-    if (rc != RDET_OK) { h->in_flight = true; return rc; }
+    if (rc != RDET_OK) { sl.in_flight = true; return rc; }
     Det3dHead head = sl.h_out->head;
     if (head.err == D3_RETRY) {                                       // more survivors than the short front end holds: the long chain, now
         h->m_hint = head.M;
@@ -1671,15 +1672,15 @@ int rdet3d_collect(rdet3d_t *h, float *centers_xy, int max_centers, int *K, doub
         rc = d3_launch(h, sl);
         h->path_mode = keep;
         if (rc == RDET_OK) rc = wait_tag(&sl.h_out->head.seq);
-        if (rc != RDET_OK) { h->in_flight = true; return rc; }
+        if (rc != RDET_OK) { sl.in_flight = true; return rc; }
         head = sl.h_out->head;
     }
     h->m_hint = head.M;
-    if (head.err) { h->in_flight = true; return head.err; }          // (whatever is left of the chain: synchronised by the next submit)
+    if (head.err) { sl.in_flight = true; return head.err; }          // (whatever is left of the chain: synchronised by the next submit)
     *K = head.K;
     for (int c = 0; c < head.K; ++c) {
         rc = wait_tag(&sl.h_out->centers[c].seq);
-        if (rc != RDET_OK) { h->in_flight = true; return rc; }
+        if (rc != RDET_OK) { sl.in_flight = true; return rc; }
         centers_xy[2 * c] = sl.h_out->centers[c].x; centers_xy[2 * c + 1] = sl.h_out->centers[c].y;
     }
     return RDET_OK;
@@ -1716,7 +1717,7 @@ int rdet3d_debug_path_counts(rdet3d_t *h, unsigned long long *n_short, unsigned 
 #ifdef RDET_DEBUG_MARKS
 int rdet3d_debug_marks(rdet3d_t *h, unsigned long long *out)   // 6 x 2048 x 8
 {
-    DET3_TRY(h, hipStreamSynchronize(h->stream));
+    for (auto &sl : h->slot) DET3_TRY(h, hipStreamSynchronize(sl.stream));
     DET3_TRY(h, hipMemcpyFromSymbol(out, HIP_SYMBOL(d3_marks_all), sizeof(unsigned long long) * 6 * 2048 * 8));
     return RDET_OK;
 }

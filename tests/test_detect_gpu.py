@@ -319,7 +319,7 @@ def test_detect3d_world_clouds_match(oracle_lib):
 
 def test_detect3d_two_clouds_on_their_way_give_the_synchronous_calls_results(oracle_lib):
     """rdet3d_submit / rdet3d_collect: cloud k + 1 is copied and enqueued while the device is still on cloud k (two input buffers, two sets
-    of result slots, one chain of kernels behind the other on the handle's stream).  Ten different clouds -- an empty one among them --
+    of result slots, of every array in between and two streams: the two chains share the chip).  Ten different clouds -- an empty one among them --
     through the two halves, always two on their way, give bit for bit what HandlePointCloud gives for the same sequence on a twin
     (the sorting grid each cloud inherits from its predecessor included); the misuse cases return errors and leave the pipeline intact."""
     from reflector_ekf_slam_amd import synth
